@@ -1,0 +1,245 @@
+"""ctypes binding of libasciichat_hip.so (C-ABI: include/asciichat_hip.h, include/asciichat_render.h)."""
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libasciichat_hip.so")
+
+MODE_MONO, MODE_TRUE_FG, MODE_256_FG, MODE_16_FG, MODE_TRUE_BG = 0, 1, 2, 3, 4
+MODE_HB_TRUE, MODE_HB_256, MODE_HB_16, MODE_HB_MONO = 5, 6, 7, 8
+MODE_NAMES = ["mono", "true_fg", "256_fg", "16_fg", "true_bg", "hb_true", "hb_256", "hb_16", "hb_mono"]
+LEN_OVERFLOW, LEN_BADDESC = 0xFFFFFFFF, 0xFFFFFFFE
+ERR_NO_DEVICE = 200
+
+
+class CompSrc(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("src_w", C.c_int32), ("src_h", C.c_int32), ("src_stride", C.c_int32),
+                ("_pad0", C.c_int32), ("tile_w", C.c_int32), ("tile_h", C.c_int32), ("org_x", C.c_int32),
+                ("org_y", C.c_int32), ("x_ratio", C.c_uint32), ("y_ratio", C.c_uint32)]
+
+
+class Composite(C.Structure):
+    _fields_ = [("canvas_w", C.c_int32), ("canvas_h", C.c_int32), ("cols", C.c_int32), ("rows", C.c_int32),
+                ("cell_w", C.c_int32), ("cell_h", C.c_int32), ("n_src", C.c_int32), ("_pad", C.c_int32),
+                ("s", CompSrc * 9)]
+
+
+class Frame(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("comp", C.c_void_p), ("src_w", C.c_int32), ("src_h", C.c_int32),
+                ("out_w", C.c_int32), ("out_h", C.c_int32), ("pad_left", C.c_int32), ("pad_top", C.c_int32),
+                ("x_ratio", C.c_uint32), ("y_ratio", C.c_uint32), ("src_stride", C.c_int32), ("_pad0", C.c_int32)]
+
+
+class Image(C.Structure):  # image_t
+    _fields_ = [("w", C.c_int), ("h", C.c_int), ("pixels", C.c_void_p), ("alloc_method", C.c_uint8)]
+
+
+class TermCaps(C.Structure):  # terminal_capabilities_t
+    _fields_ = [("color_level", C.c_int), ("capabilities", C.c_uint32), ("color_count", C.c_uint32),
+                ("utf8_support", C.c_bool), ("detection_reliable", C.c_bool), ("render_mode", C.c_int),
+                ("term_type", C.c_char * 64), ("colorterm", C.c_char * 64), ("wants_background", C.c_bool),
+                ("palette_type", C.c_int), ("palette_custom", C.c_char * 64), ("desired_fps", C.c_uint8),
+                ("color_filter", C.c_int), ("wants_padding", C.c_bool), ("pad_height", C.c_size_t)]
+
+
+class FrameSource(C.Structure):  # ascii_frame_source_t
+    _fields_ = [("frame_data", C.c_char_p), ("frame_size", C.c_size_t)]
+
+
+def build(force=False):
+    """Compile the library in-tree (hipcc --offload-arch=gfx950 via ascii-chat_amd/Makefile)."""
+    if force:
+        subprocess.check_call(["make", "-C", HERE, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", HERE], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load libasciichat_hip.so (never a substitute: raises if it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc, gfx950) first")
+    L = C.CDLL(LIB_PATH)
+    vp, ci, ss, sz = C.c_void_p, C.c_int, C.c_ssize_t, C.c_size_t
+    L.asciichat_hip_device_count.restype = ci
+    L.asciichat_hip_last_error.restype = C.c_char_p
+    L.asciichat_hip_plan_create.restype = ci
+    L.asciichat_hip_plan_create.argtypes = [C.POINTER(vp), ci, C.c_char_p, C.POINTER(Frame), ci]
+    L.asciichat_hip_plan_update.restype = ci
+    L.asciichat_hip_plan_update.argtypes = [vp, C.POINTER(Frame), vp]
+    L.asciichat_hip_plan_out_stride.restype = sz
+    L.asciichat_hip_plan_out_stride.argtypes = [vp]
+    L.asciichat_hip_plan_set_variant.restype = ci
+    L.asciichat_hip_plan_set_variant.argtypes = [vp, ci]
+    L.asciichat_hip_plan_get_variant.restype = ci
+    L.asciichat_hip_plan_get_variant.argtypes = [vp]
+    L.asciichat_hip_plan_render.restype = ci
+    L.asciichat_hip_plan_render.argtypes = [vp, vp, sz, vp, vp]
+    L.asciichat_hip_plan_render_range.restype = ci
+    L.asciichat_hip_plan_render_range.argtypes = [vp, ci, ci, vp, sz, vp, vp]
+    L.asciichat_hip_plan_destroy.restype = None
+    L.asciichat_hip_plan_destroy.argtypes = [vp]
+    L.asciichat_hip_resize.restype = ci
+    L.asciichat_hip_resize.argtypes = [vp, ci, ci, vp, ci, ci, vp]
+    L.asciichat_hip_composite.restype = ci
+    L.asciichat_hip_composite.argtypes = [C.POINTER(Composite), vp, vp]
+    L.asciichat_hip_composite_upload.restype = ci
+    L.asciichat_hip_composite_upload.argtypes = [C.POINTER(Composite), C.POINTER(vp)]
+    L.asciichat_hip_free.restype = None
+    L.asciichat_hip_free.argtypes = [vp]
+    # achip_host.h
+    L.aspect_ratio.restype = None
+    L.aspect_ratio.argtypes = [ss, ss, ss, ss, C.c_bool, C.POINTER(ss), C.POINTER(ss)]
+    L.achip_mode_from_caps.restype = ci
+    L.achip_mode_from_caps.argtypes = [ci, ci]
+    L.achip_frame_setup.restype = ci
+    L.achip_frame_setup.argtypes = [C.POINTER(Frame), vp, ci, ci, ss, ss, ci, C.c_bool, C.c_bool, C.c_bool]
+    L.achip_frame_identity.restype = ci
+    L.achip_frame_identity.argtypes = [C.POINTER(Frame), vp, ci, ci]
+    L.achip_out_bound.restype = sz
+    L.achip_out_bound.argtypes = [ci, C.POINTER(Frame)]
+    L.achip_grid_layout.restype = None
+    L.achip_grid_layout.argtypes = [C.POINTER(ci), C.POINTER(ci), ci, ci, ci, C.POINTER(ci), C.POINTER(ci)]
+    L.achip_composite_setup.restype = None
+    L.achip_composite_setup.argtypes = [C.POINTER(Composite), C.POINTER(vp), C.POINTER(ci), C.POINTER(ci), ci, ci, ci]
+    # drop-in layer (asciichat_render.h)
+    L.ascii_convert.restype = vp
+    L.ascii_convert.argtypes = [C.POINTER(Image), ss, ss, C.c_bool, C.c_bool, C.c_bool, C.c_char_p, C.c_char_p]
+    L.ascii_convert_with_capabilities.restype = vp
+    L.ascii_convert_with_capabilities.argtypes = [C.POINTER(Image), ss, ss, C.POINTER(TermCaps), C.c_bool, C.c_bool,
+                                                  C.c_char_p]
+    L.image_print_with_capabilities.restype = vp
+    L.image_print_with_capabilities.argtypes = [C.POINTER(Image), C.POINTER(TermCaps), C.c_char_p]
+    for name in ("image_print", "image_print_color", "image_print_256color", "image_print_16color",
+                 "image_print_color_background"):
+        f = getattr(L, name)
+        f.restype = vp
+        f.argtypes = [C.POINTER(Image), C.c_char_p]
+    L.image_print_color_simd.restype = vp
+    L.image_print_color_simd.argtypes = [C.POINTER(Image), C.c_bool, C.c_bool, C.c_char_p]
+    L.rgb_to_truecolor_halfblocks_scalar.restype = vp
+    L.rgb_to_truecolor_halfblocks_scalar.argtypes = [vp, ci, ci, ci]
+    for name in ("rgb_to_256color_halfblocks_scalar", "rgb_to_16color_halfblocks_scalar", "rgb_to_halfblocks_scalar"):
+        f = getattr(L, name)
+        f.restype = vp
+        f.argtypes = [vp, ci, ci, ci, C.c_char_p]
+    L.ascii_pad_frame_width.restype = vp
+    L.ascii_pad_frame_width.argtypes = [C.c_char_p, sz]
+    L.ascii_pad_frame_height.restype = vp
+    L.ascii_pad_frame_height.argtypes = [C.c_char_p, sz]
+    L.ascii_create_grid.restype = vp
+    L.ascii_create_grid.argtypes = [C.POINTER(FrameSource), ci, ci, ci, C.POINTER(sz)]
+    L.asciichat_hip_set_option_render_mode.restype = None
+    L.asciichat_hip_set_option_render_mode.argtypes = [ci]
+    L.image_new.restype = C.POINTER(Image)
+    L.image_new.argtypes = [sz, sz]
+    L.image_new_from_pool.restype = C.POINTER(Image)
+    L.image_new_from_pool.argtypes = [sz, sz]
+    L.image_new_copy.restype = C.POINTER(Image)
+    L.image_new_copy.argtypes = [C.POINTER(Image)]
+    for name in ("image_destroy", "image_destroy_to_pool", "image_clear"):
+        f = getattr(L, name)
+        f.restype = None
+        f.argtypes = [C.POINTER(Image)]
+    L.image_resize.restype = None
+    L.image_resize.argtypes = [C.POINTER(Image), C.POINTER(Image)]
+    L.rgb_to_256color.restype = C.c_uint8
+    L.rgb_to_256color.argtypes = [C.c_uint8] * 3
+    L.rgb_to_16color.restype = C.c_uint8
+    L.rgb_to_16color.argtypes = [C.c_uint8] * 3
+    L.rep_is_profitable.restype = C.c_bool
+    L.rep_is_profitable.argtypes = [C.c_uint32]
+    for name in ("append_truecolor_fg", "append_truecolor_bg"):
+        f = getattr(L, name)
+        f.restype = vp
+        f.argtypes = [vp, C.c_uint8, C.c_uint8, C.c_uint8]
+    L.buffer_pool_alloc.restype = vp
+    L.buffer_pool_alloc.argtypes = [vp, sz]
+    L.buffer_pool_free.restype = None
+    L.buffer_pool_free.argtypes = [vp, vp, sz]
+    L.buffer_pool_is_pinned.restype = C.c_bool
+    L.buffer_pool_is_pinned.argtypes = [vp]
+    L.buffer_pool_pinned_blocks.restype = sz
+    L.buffer_pool_pinned_blocks.argtypes = [vp]
+    L.buffer_pool_get_global.restype = vp
+    L.buffer_pool_get_stats.restype = None
+    L.buffer_pool_get_stats.argtypes = [vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]
+    L.buffer_pool_cleanup_global.restype = None
+    L.free = C.CDLL(None).free
+    L.free.argtypes = [vp]
+    _lib = L
+    return L
+
+
+def last_error():
+    return lib().asciichat_hip_last_error().decode("utf-8", "replace")
+
+
+def take_string(ptr):
+    """Copy a malloc'd NUL-terminated result to bytes and free() it (None for NULL)."""
+    if not ptr:
+        return None
+    out = C.string_at(ptr)
+    lib().free(ptr)
+    return out
+
+
+def frame_setup(src_ptr, src_w, src_h, width, height, render_mode, wants_padding=False, use_aspect=False,
+                stretch=False):
+    f = Frame()
+    rc = lib().achip_frame_setup(C.byref(f), src_ptr, src_w, src_h, width, height, render_mode, wants_padding,
+                                 use_aspect, stretch)
+    return f if rc == 0 else None
+
+
+class Plan:
+    """Batch plan: N device-resident frames -> output slab (asciichat_hip_plan_*)."""
+
+    def __init__(self, mode, palette, frames):
+        self.n = len(frames)
+        self._arr = (Frame * self.n)(*frames)
+        self._h = C.c_void_p()
+        p = palette.encode("utf-8") if isinstance(palette, str) else palette
+        rc = lib().asciichat_hip_plan_create(C.byref(self._h), mode, p, self._arr, self.n)
+        if rc != 0:
+            raise RuntimeError(f"asciichat_hip_plan_create failed ({rc}): {last_error()}")
+        self.stride = int(lib().asciichat_hip_plan_out_stride(self._h))
+
+    @property
+    def variant(self):
+        return lib().asciichat_hip_plan_get_variant(self._h)
+
+    def set_variant(self, v):
+        rc = lib().asciichat_hip_plan_set_variant(self._h, v)
+        if rc != 0:
+            raise RuntimeError(f"set_variant({v}) failed: {last_error()}")
+
+    def update(self, frames, stream=0):
+        self._arr = (Frame * self.n)(*frames)
+        rc = lib().asciichat_hip_plan_update(self._h, self._arr, stream)
+        if rc != 0:
+            raise RuntimeError(f"plan_update failed: {last_error()}")
+        self.stride = int(lib().asciichat_hip_plan_out_stride(self._h))
+
+    def render(self, out_ptr, out_stride, len_ptr, stream=0, first=0, count=None):
+        count = self.n - first if count is None else count
+        rc = lib().asciichat_hip_plan_render_range(self._h, first, count, out_ptr, out_stride, len_ptr, stream)
+        if rc != 0:
+            raise RuntimeError(f"plan_render failed ({rc}): {last_error()}")
+
+    def close(self):
+        if self._h:
+            lib().asciichat_hip_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

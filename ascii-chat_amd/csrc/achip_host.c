@@ -1,0 +1,301 @@
+/* achip_host.c -- see achip_host.h.  Plain C11, no GPU calls. */
+#include "achip_host.h"
+
+#include <string.h>
+
+/* ROUND(), include/ascii-chat/util/math.h:53; result floored at MIN_DIMENSION (aspect_ratio.c:18-36) */
+static ssize_t round_dim(float v) {
+  int r = (int)(0.5f + v);
+  return r > 0 ? r : 1;
+}
+
+void aspect_ratio(const ssize_t img_w, const ssize_t img_h, const ssize_t width, const ssize_t height,
+                  const bool stretch, ssize_t *out_width, ssize_t *out_height) {
+  if (!out_width || !out_height)
+    return;
+  if (img_w <= 0 || img_h <= 0) {
+    *out_width = 1;
+    *out_height = 1;
+    return;
+  }
+  if (stretch) {
+    *out_width = width;
+    *out_height = height;
+    return;
+  }
+  /* terminal cells are twice as tall as wide (CHAR_ASPECT 2.0f); float on purpose: parity with the reference */
+  const float cell = 2.0f;
+  ssize_t w_fit = round_dim((float)height * (float)img_w / (float)img_h * cell);
+  ssize_t h_fit = round_dim(((float)width / cell) * (float)img_h / (float)img_w);
+  if (w_fit <= width) {
+    *out_width = w_fit;
+    *out_height = height;
+  } else {
+    *out_width = width;
+    *out_height = h_fit;
+  }
+  if (*out_width <= 0)
+    *out_width = 1;
+  if (*out_height <= 0)
+    *out_height = 1;
+}
+
+static int utf8_seq_len(unsigned char c) {
+  if ((c & 0xE0) == 0xC0)
+    return 2;
+  if ((c & 0xF0) == 0xE0)
+    return 3;
+  if ((c & 0xF8) == 0xF0)
+    return 4;
+  return 1;
+}
+
+int achip_lut_build(const char *palette_chars, achip_lut_t *lut) {
+  if (!palette_chars || !lut || palette_chars[0] == '\0')
+    return -1;
+  memset(lut, 0, sizeof(*lut));
+  uint32_t packed[256];
+  int count = 0;
+  size_t len = strlen(palette_chars), pos = 0;
+  while (pos < len && count < 255) {
+    int n = utf8_seq_len((unsigned char)palette_chars[pos]);
+    uint32_t g = 0;
+    for (int k = 0; k < n && pos + (size_t)k < len; k++)
+      g |= (uint32_t)(unsigned char)palette_chars[pos + (size_t)k] << (8 * k);
+    packed[count++] = g;
+    pos += (size_t)n;
+  }
+  for (int i = 0; i < 256; i++) {
+    int ci = count > 1 ? (i * (count - 1) + 127) / 255 : 0;
+    if (ci >= count)
+      ci = count - 1;
+    lut->glyph[i] = packed[ci];
+  }
+  for (int i = 0; i < 64; i++) {
+    int ci = count > 1 ? (i * (count - 1) + 31) / 63 : 0;
+    if (ci >= count)
+      ci = count - 1;
+    lut->ramp[i] = (uint8_t)ci;
+    lut->glyph64[i] = packed[ci];
+  }
+  return 0;
+}
+
+int achip_mode_from_caps(int color_level, int render_mode) {
+  if (render_mode == 2) { /* RENDER_MODE_HALF_BLOCK */
+    switch (color_level) {
+    case 3:
+      return ACHIP_MODE_HB_TRUE;
+    case 2:
+      return ACHIP_MODE_HB_256;
+    case 1:
+      return ACHIP_MODE_HB_16;
+    default:
+      return ACHIP_MODE_HB_MONO;
+    }
+  }
+  switch (color_level) {
+  case 3:
+    return render_mode == 1 ? -1 : ACHIP_MODE_TRUE_FG; /* BACKGROUND -> dithered 16-colour (sgr.c:429) */
+  case 2:
+    return ACHIP_MODE_256_FG;
+  case 1:
+    return ACHIP_MODE_16_FG;
+  default:
+    return ACHIP_MODE_MONO;
+  }
+}
+
+uint32_t achip_nn_ratio(int src, int dst) { return (uint32_t)((((uint64_t)src << 16) / (uint64_t)dst) + 1u); }
+
+int achip_frame_identity(achip_frame_t *f, const uint8_t *src_dev, int w, int h) {
+  if (!f || w <= 0 || h <= 0)
+    return -1;
+  memset(f, 0, sizeof(*f));
+  f->src = src_dev;
+  f->src_w = w;
+  f->src_h = h;
+  f->out_w = w;
+  f->out_h = h;
+  f->x_ratio = achip_nn_ratio(w, w);
+  f->y_ratio = achip_nn_ratio(h, h);
+  return 0;
+}
+
+int achip_frame_setup(achip_frame_t *f, const uint8_t *src_dev, int src_w, int src_h, ssize_t width, ssize_t height,
+                      int render_mode, bool wants_padding, bool use_aspect, bool stretch) {
+  if (!f)
+    return -1;
+  if (src_w <= 0 || src_w > 10000 || src_h <= 0 || src_h > 10000) /* ascii.c:204 */
+    return -1;
+  ssize_t rw = width, rh = height;
+  if (use_aspect)
+    aspect_ratio(src_w, src_h, rw, rh, stretch, &rw, &rh);
+  const ssize_t text_w = rw, text_h = rh;
+  if (render_mode == 2)
+    rh *= 2; /* ascii.c:230-232 */
+  ssize_t pad_w = 0, pad_h = 0;
+  if (use_aspect && wants_padding) { /* ascii.c:238-244 */
+    pad_w = width > text_w ? (width - text_w) / 2 : 0;
+    pad_h = height > text_h ? (height - text_h) / 2 : 0;
+  }
+  /* image_new() of the resized image: image_validate_dimensions, lib/util/image.c:100-113 */
+  if (rw <= 0 || rh <= 0 || rw > 3840 || rh > 2160)
+    return -1;
+  memset(f, 0, sizeof(*f));
+  f->src = src_dev;
+  f->src_w = src_w;
+  f->src_h = src_h;
+  f->out_w = (int32_t)rw;
+  f->out_h = (int32_t)rh;
+  f->pad_left = (int32_t)pad_w;
+  f->pad_top = (int32_t)pad_h;
+  f->x_ratio = achip_nn_ratio(src_w, (int)rw);
+  f->y_ratio = achip_nn_ratio(src_h, (int)rh);
+  return 0;
+}
+
+size_t achip_out_bound(int mode, const achip_frame_t *f) {
+  const bool hb = mode >= ACHIP_MODE_HB_TRUE && mode <= ACHIP_MODE_HB_MONO;
+  const size_t rows = hb ? ((size_t)f->out_h + 1) / 2 : (size_t)f->out_h;
+  size_t cell; /* worst-case bytes a single cell can own (a REP head replaces >= 5 suppressed cells) */
+  switch (mode) {
+  case ACHIP_MODE_MONO:
+    cell = 4;
+    break;
+  case ACHIP_MODE_TRUE_FG:
+    cell = 19 + 4;
+    break;
+  case ACHIP_MODE_256_FG:
+    cell = 11 + 4;
+    break;
+  case ACHIP_MODE_16_FG:
+    cell = 5 + 4;
+    break;
+  case ACHIP_MODE_TRUE_BG:
+    cell = 19 + 19 + 4;
+    break;
+  case ACHIP_MODE_HB_TRUE:
+    cell = 19 + 19 + 3;
+    break;
+  case ACHIP_MODE_HB_256:
+    cell = 11 + 11 + 3;
+    break;
+  case ACHIP_MODE_HB_16:
+    cell = 5 + 6 + 3;
+    break;
+  default:
+    cell = 3;
+    break;
+  }
+  /* per row: padding + cells + one REP tail (ESC [ dddd b) + reset + newline; per frame: pad_top + final reset */
+  const size_t row = (size_t)f->pad_left + (size_t)f->out_w * cell + 7 + 4 + 4 + 1;
+  return (size_t)f->pad_top + rows * row + 8;
+}
+
+void achip_grid_layout(const int *src_w, const int *src_h, int n, int term_w, int term_h, int *cols, int *rows) {
+  if (n <= 0) {
+    *cols = 0;
+    *rows = 0;
+    return;
+  }
+  if (n == 1) {
+    *cols = 1;
+    *rows = 1;
+    return;
+  }
+  const float cell_ratio = 2.0f;
+  float mean_aspect = 0.0f;
+  int counted = 0;
+  for (int i = 0; i < n; i++) {
+    if (src_w[i] > 0 && src_h[i] > 0) {
+      mean_aspect += (float)src_w[i] / (float)src_h[i];
+      counted++;
+    }
+  }
+  if (counted > 0)
+    mean_aspect /= counted;
+  else
+    mean_aspect = 1.6f;
+  int pick_c = 1, pick_r = n;
+  float pick_u = 0.0f;
+  for (int c = 1; c <= n; c++) {
+    const int r = (n + c - 1) / c;
+    if (c * r - n > c)
+      continue;
+    const int cw = term_w / c, ch = term_h / r;
+    if (cw < 20 || ch < 10)
+      continue;
+    float used = 0.0f;
+    for (int i = 0; i < n; i++) {
+      const float cell_visual = (float)cw / ((float)ch * cell_ratio);
+      int fw, fh;
+      if (mean_aspect > cell_visual) {
+        fw = cw;
+        fh = (int)((cw / mean_aspect) / cell_ratio);
+      } else {
+        fh = ch;
+        fw = (int)(ch * cell_ratio * mean_aspect);
+      }
+      if (fw > cw)
+        fw = cw;
+      if (fh > ch)
+        fh = ch;
+      used += fw * fh;
+    }
+    const float u = used / (float)(cw * ch * n);
+    if (u > pick_u) {
+      pick_u = u;
+      pick_c = c;
+      pick_r = r;
+    }
+  }
+  *cols = pick_c;
+  *rows = pick_r;
+}
+
+void achip_composite_setup(achip_composite_t *comp, const uint8_t *const *src_dev, const int *src_w, const int *src_h,
+                           int n, int term_w, int term_h) {
+  memset(comp, 0, sizeof(*comp));
+  int cols, rows;
+  achip_grid_layout(src_w, src_h, n, term_w, term_h, &cols, &rows);
+  comp->canvas_w = term_w;
+  comp->canvas_h = term_h * 2;
+  comp->cols = cols;
+  comp->rows = rows;
+  if (cols <= 0 || rows <= 0)
+    return;
+  comp->cell_w = comp->canvas_w / cols;
+  comp->cell_h = comp->canvas_h / rows;
+  int placed = 0;
+  for (int i = 0; i < n && placed < 9; i++) {
+    if (!src_dev[i])
+      continue;
+    achip_comp_src_t *s = &comp->s[placed];
+    const int row = placed / cols, col = placed % cols;
+    placed++;
+    const float sa = (float)src_w[i] / (float)src_h[i];
+    const float ca = (float)comp->cell_w / (float)comp->cell_h;
+    int tw, th;
+    if (sa > ca) {
+      tw = comp->cell_w;
+      th = (int)((comp->cell_w / sa) + 0.5f);
+    } else {
+      th = comp->cell_h;
+      tw = (int)((comp->cell_h * sa) + 0.5f);
+    }
+    if (tw <= 0 || th <= 0)
+      continue; /* leaves s->src NULL: an empty cell */
+    s->src = src_dev[i];
+    s->src_w = src_w[i];
+    s->src_h = src_h[i];
+    s->src_stride = 3 * src_w[i];
+    s->tile_w = tw;
+    s->tile_h = th;
+    s->org_x = col * comp->cell_w + (comp->cell_w - tw) / 2;
+    s->org_y = row * comp->cell_h + (comp->cell_h - th) / 2;
+    s->x_ratio = achip_nn_ratio(src_w[i], tw);
+    s->y_ratio = achip_nn_ratio(src_h[i], th);
+  }
+  comp->n_src = placed;
+}

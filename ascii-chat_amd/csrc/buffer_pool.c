@@ -1,0 +1,387 @@
+/*
+ * buffer_pool.c -- buffer_pool_* of the reference (lib/buffer_pool.c:122-277, include/ascii-chat/buffer_pool.h)
+ * re-designed for a GPU renderer:
+ *
+ *  - small objects (64 B .. 4 MiB) keep the reference's scheme: one header+payload malloc block, recycled
+ *    through a free list, freed for real by buffer_pool_shrink() after shrink_delay_ns of idleness;
+ *  - objects above 4 MiB -- every 1080p (6.2 MB) / 4K (24.9 MB) frame, which the reference hands to the
+ *    malloc fallback -- come from a new PINNED size class: hipHostMalloc(mapped) blocks kept in
+ *    per-size free lists, so the GPU gathers its ~2 K samples per frame straight out of the producer's
+ *    buffer over PCIe and nothing is staged or copied;
+ *  - the header-magic contract is kept: buffer_pool_free(NULL, p, size) works on any block from here.
+ *
+ * Host-side memory management only; no pixel arithmetic happens in this file.
+ */
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "asciichat_render.h"
+#include "internal.h"
+
+#define MAGIC_POOLED 0xBF00B001u   /* MAGIC_BUFFER_POOL_VALID,    include/ascii-chat/util/magic.h:23 */
+#define MAGIC_FALLBACK 0xBF00FA11u /* MAGIC_BUFFER_POOL_FALLBACK, magic.h:26 */
+#define MAGIC_PINNED 0xBF00D1A1u   /* new: pinned + device-mapped frame block */
+
+typedef struct pool_node {
+  uint32_t magic;
+  uint32_t _pad;
+  size_t size; /* payload capacity */
+  struct pool_node *next;
+  uint64_t returned_at_ns;
+  struct buffer_pool *pool;
+  void *device_alias; /* pinned blocks: device address of the payload */
+  uint64_t _reserved;
+} pool_node_t; /* 64 bytes: payloads stay 64-byte aligned */
+
+struct buffer_pool {
+  pthread_mutex_t mu;
+  pool_node_t *free_small;
+  pool_node_t *free_pinned;
+  size_t max_bytes;
+  uint64_t shrink_delay_ns;
+  size_t current_bytes, used_bytes, peak_bytes;
+  size_t pinned_bytes, pinned_live;
+  uint64_t hits, allocs, returns, shrink_freed, fallbacks;
+};
+
+static buffer_pool_t *g_pool;
+static pthread_mutex_t g_pool_mu = PTHREAD_MUTEX_INITIALIZER;
+
+/* registry of live pinned blocks so that any interior pointer can be resolved to its device alias */
+#define PIN_REG_MAX 1024
+static struct {
+  const uint8_t *lo, *hi;
+  const uint8_t *dev;
+} g_pins[PIN_REG_MAX];
+static int g_pin_count;
+static pthread_mutex_t g_pin_mu = PTHREAD_MUTEX_INITIALIZER;
+
+static uint64_t now_ns(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
+}
+
+static void *payload_of(pool_node_t *n) { return (uint8_t *)n + sizeof(pool_node_t); }
+static pool_node_t *node_of(const void *p) { return (pool_node_t *)((uint8_t *)p - sizeof(pool_node_t)); }
+
+static void pin_register(pool_node_t *n) {
+  pthread_mutex_lock(&g_pin_mu);
+  if (g_pin_count < PIN_REG_MAX) {
+    g_pins[g_pin_count].lo = (const uint8_t *)payload_of(n);
+    g_pins[g_pin_count].hi = g_pins[g_pin_count].lo + n->size;
+    g_pins[g_pin_count].dev = (const uint8_t *)n->device_alias;
+    g_pin_count++;
+  }
+  pthread_mutex_unlock(&g_pin_mu);
+}
+
+static void pin_unregister(pool_node_t *n) {
+  pthread_mutex_lock(&g_pin_mu);
+  for (int i = 0; i < g_pin_count; i++) {
+    if (g_pins[i].lo == (const uint8_t *)payload_of(n)) {
+      g_pins[i] = g_pins[--g_pin_count];
+      break;
+    }
+  }
+  pthread_mutex_unlock(&g_pin_mu);
+}
+
+const void *achip_pool_device_ptr(const void *host_ptr) {
+  const uint8_t *p = (const uint8_t *)host_ptr;
+  const void *out = NULL;
+  pthread_mutex_lock(&g_pin_mu);
+  for (int i = 0; i < g_pin_count; i++) {
+    if (p >= g_pins[i].lo && p < g_pins[i].hi) {
+      out = g_pins[i].dev + (p - g_pins[i].lo);
+      break;
+    }
+  }
+  pthread_mutex_unlock(&g_pin_mu);
+  return out;
+}
+
+bool buffer_pool_is_pinned(const void *data) { return achip_pool_device_ptr(data) != NULL; }
+
+buffer_pool_t *buffer_pool_create(size_t max_bytes, uint64_t shrink_delay_ns) {
+  buffer_pool_t *p = (buffer_pool_t *)calloc(1, sizeof(*p));
+  if (!p)
+    return NULL;
+  pthread_mutex_init(&p->mu, NULL);
+  p->max_bytes = max_bytes ? max_bytes : BUFFER_POOL_MAX_BYTES;
+  p->shrink_delay_ns = shrink_delay_ns ? shrink_delay_ns : BUFFER_POOL_SHRINK_DELAY_NS;
+  return p;
+}
+
+static void release_node(pool_node_t *n) {
+  if (n->magic == MAGIC_PINNED) {
+    pin_unregister(n);
+    n->magic = 0;
+    (void)hipHostFree(n);
+  } else {
+    n->magic = 0;
+    free(n);
+  }
+}
+
+void buffer_pool_destroy(buffer_pool_t *pool) {
+  if (!pool)
+    return;
+  for (pool_node_t *n = pool->free_small; n;) {
+    pool_node_t *nx = n->next;
+    release_node(n);
+    n = nx;
+  }
+  for (pool_node_t *n = pool->free_pinned; n;) {
+    pool_node_t *nx = n->next;
+    release_node(n);
+    n = nx;
+  }
+  pthread_mutex_destroy(&pool->mu);
+  free(pool);
+}
+
+static pool_node_t *fallback_node(buffer_pool_t *pool, size_t size) {
+  pool_node_t *n = (pool_node_t *)malloc(sizeof(pool_node_t) + size);
+  if (!n)
+    return NULL;
+  memset(n, 0, sizeof(*n));
+  n->magic = MAGIC_FALLBACK;
+  n->size = size;
+  n->pool = pool;
+  return n;
+}
+
+static void *alloc_pinned(buffer_pool_t *pool, size_t size) {
+  /* best fit among idle pinned blocks (frames come in very few distinct sizes) */
+  pthread_mutex_lock(&pool->mu);
+  pool_node_t **best = NULL;
+  for (pool_node_t **pp = &pool->free_pinned; *pp; pp = &(*pp)->next)
+    if ((*pp)->size >= size && (!best || (*pp)->size < (*best)->size))
+      best = pp;
+  if (best && (*best)->size <= size + size / 4) {
+    pool_node_t *n = *best;
+    *best = n->next;
+    n->next = NULL;
+    pool->used_bytes += n->size;
+    pool->pinned_live++;
+    pool->hits++;
+    pthread_mutex_unlock(&pool->mu);
+    return payload_of(n);
+  }
+  const int room = pool->pinned_bytes + size + sizeof(pool_node_t) <= BUFFER_POOL_PINNED_MAX_BYTES;
+  pthread_mutex_unlock(&pool->mu);
+
+  pool_node_t *n = NULL;
+  if (room) {
+    void *raw = NULL;
+    if (hipHostMalloc(&raw, sizeof(pool_node_t) + size, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess) {
+      n = (pool_node_t *)raw;
+      memset(n, 0, sizeof(*n));
+      void *dev = NULL;
+      if (hipHostGetDevicePointer(&dev, payload_of(n), 0) != hipSuccess)
+        dev = payload_of(n); /* unified addressing: same value */
+      n->magic = MAGIC_PINNED;
+      n->size = size;
+      n->pool = pool;
+      n->device_alias = dev;
+      pin_register(n);
+    } else {
+      (void)hipGetLastError(); /* no device / out of pinned memory: plain host block, as the reference does */
+    }
+  }
+  pthread_mutex_lock(&pool->mu);
+  if (n) {
+    pool->pinned_bytes += sizeof(pool_node_t) + size;
+    pool->used_bytes += size;
+    pool->pinned_live++;
+    pool->allocs++;
+  } else {
+    pool->fallbacks++;
+  }
+  pthread_mutex_unlock(&pool->mu);
+  if (!n) {
+    n = fallback_node(pool, size);
+    if (!n)
+      return NULL;
+  }
+  return payload_of(n);
+}
+
+void *buffer_pool_alloc(buffer_pool_t *pool, size_t size) {
+  if (!pool)
+    pool = buffer_pool_get_global();
+  if (!pool || size < BUFFER_POOL_MIN_SIZE) {
+    pool_node_t *n = fallback_node(pool, size);
+    return n ? payload_of(n) : NULL;
+  }
+  if (size > BUFFER_POOL_MAX_SINGLE_SIZE)
+    return alloc_pinned(pool, size);
+
+  pthread_mutex_lock(&pool->mu);
+  pool_node_t *n = pool->free_small;
+  if (n && n->size >= size) { /* LIFO head only, like the reference's lock-free pop */
+    pool->free_small = n->next;
+    n->next = NULL;
+    pool->used_bytes += n->size;
+    pool->hits++;
+    if (pool->used_bytes > pool->peak_bytes)
+      pool->peak_bytes = pool->used_bytes;
+    pthread_mutex_unlock(&pool->mu);
+    return payload_of(n);
+  }
+  const size_t total = sizeof(pool_node_t) + size;
+  const int room = pool->current_bytes + total <= pool->max_bytes;
+  if (room)
+    pool->current_bytes += total;
+  pthread_mutex_unlock(&pool->mu);
+
+  if (room) {
+    void *raw = NULL;
+    if (posix_memalign(&raw, 64, total) == 0) {
+      n = (pool_node_t *)raw;
+      memset(n, 0, sizeof(*n));
+      n->magic = MAGIC_POOLED;
+      n->size = size;
+      n->pool = pool;
+      pthread_mutex_lock(&pool->mu);
+      pool->used_bytes += size;
+      pool->allocs++;
+      if (pool->used_bytes > pool->peak_bytes)
+        pool->peak_bytes = pool->used_bytes;
+      pthread_mutex_unlock(&pool->mu);
+      return payload_of(n);
+    }
+    pthread_mutex_lock(&pool->mu);
+    pool->current_bytes -= total;
+    pthread_mutex_unlock(&pool->mu);
+  }
+  pthread_mutex_lock(&pool->mu);
+  pool->fallbacks++;
+  pthread_mutex_unlock(&pool->mu);
+  n = fallback_node(pool, size);
+  return n ? payload_of(n) : NULL;
+}
+
+void buffer_pool_free(buffer_pool_t *pool, const void *data, size_t size) {
+  (void)size;
+  if (!data)
+    return;
+  pool_node_t *n = node_of(data);
+  if (n->magic == MAGIC_FALLBACK) {
+    n->magic = 0;
+    free(n);
+    return;
+  }
+  if (n->magic != MAGIC_POOLED && n->magic != MAGIC_PINNED) {
+    free((void *)data); /* unknown allocation: the reference frees the payload pointer itself */
+    return;
+  }
+  if (!pool)
+    pool = n->pool;
+  if (!pool)
+    return;
+  int do_shrink = 0;
+  pthread_mutex_lock(&pool->mu);
+  pool->used_bytes -= n->size;
+  pool->returns++;
+  n->returned_at_ns = now_ns();
+  if (n->magic == MAGIC_PINNED) {
+    n->next = pool->free_pinned;
+    pool->free_pinned = n;
+    pool->pinned_live--;
+  } else {
+    n->next = pool->free_small;
+    pool->free_small = n;
+  }
+  do_shrink = pool->returns % 100 == 0;
+  pthread_mutex_unlock(&pool->mu);
+  if (do_shrink)
+    buffer_pool_shrink(pool);
+}
+
+void buffer_pool_shrink(buffer_pool_t *pool) {
+  if (!pool || pool->shrink_delay_ns == 0)
+    return;
+  const uint64_t now = now_ns();
+  const uint64_t cutoff = now > pool->shrink_delay_ns ? now - pool->shrink_delay_ns : 0;
+  pool_node_t *doomed = NULL;
+  pthread_mutex_lock(&pool->mu);
+  pool_node_t **lists[2] = {&pool->free_small, &pool->free_pinned};
+  for (int k = 0; k < 2; k++) {
+    for (pool_node_t **pp = lists[k]; *pp;) {
+      pool_node_t *n = *pp;
+      if (n->returned_at_ns < cutoff) {
+        *pp = n->next;
+        if (n->magic == MAGIC_PINNED)
+          pool->pinned_bytes -= sizeof(pool_node_t) + n->size;
+        else
+          pool->current_bytes -= sizeof(pool_node_t) + n->size;
+        pool->shrink_freed++;
+        n->next = doomed;
+        doomed = n;
+      } else {
+        pp = &n->next;
+      }
+    }
+  }
+  pthread_mutex_unlock(&pool->mu);
+  while (doomed) {
+    pool_node_t *nx = doomed->next;
+    release_node(doomed);
+    doomed = nx;
+  }
+}
+
+void buffer_pool_get_stats(buffer_pool_t *pool, size_t *current_bytes, size_t *used_bytes, size_t *free_bytes) {
+  size_t cur = 0, used = 0;
+  if (pool) {
+    pthread_mutex_lock(&pool->mu);
+    cur = pool->current_bytes + pool->pinned_bytes;
+    used = pool->used_bytes;
+    pthread_mutex_unlock(&pool->mu);
+  }
+  if (current_bytes)
+    *current_bytes = cur;
+  if (used_bytes)
+    *used_bytes = used;
+  if (free_bytes)
+    *free_bytes = cur > used ? cur - used : 0;
+}
+
+size_t buffer_pool_pinned_blocks(buffer_pool_t *pool) {
+  if (!pool)
+    pool = buffer_pool_get_global();
+  if (!pool)
+    return 0;
+  pthread_mutex_lock(&pool->mu);
+  size_t n = pool->pinned_live;
+  pthread_mutex_unlock(&pool->mu);
+  return n;
+}
+
+void buffer_pool_init_global(void) {
+  pthread_mutex_lock(&g_pool_mu);
+  if (!g_pool)
+    g_pool = buffer_pool_create(0, 0);
+  pthread_mutex_unlock(&g_pool_mu);
+}
+
+void buffer_pool_cleanup_global(void) {
+  pthread_mutex_lock(&g_pool_mu);
+  buffer_pool_t *p = g_pool;
+  g_pool = NULL;
+  pthread_mutex_unlock(&g_pool_mu);
+  buffer_pool_destroy(p);
+}
+
+buffer_pool_t *buffer_pool_get_global(void) {
+  if (!g_pool)
+    buffer_pool_init_global();
+  return g_pool;
+}

@@ -1,0 +1,497 @@
+/*
+ * dropin.c -- the reference's render entry points (asciichat_render.h) on top of the GPU path.
+ *
+ * Every call is a 1-frame batch: the calling thread owns a HIP stream and one pinned, device-mapped
+ * block holding [frame descriptor | length | output slab].  The kernel reads the descriptor and writes
+ * length + bytes straight into that block, so a call is: (stage source if it is not pool-pinned) ->
+ * one kernel launch -> one stream sync -> malloc+memcpy of the result string the caller will free().
+ *
+ * Host logic here is only what the reference does outside its pixel loops: argument checks with the
+ * same NULL conditions, aspect fit, padding sizes, mode dispatch.
+ */
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+
+#include <limits.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "achip_host.h"
+#include "asciichat_hip.h"
+#include "asciichat_render.h"
+#include "hip_launch.h"
+#include "internal.h"
+
+/* ------------------------------------------------------------------------------------------- */
+/* per-thread GPU context                                                                        */
+/* ------------------------------------------------------------------------------------------- */
+#define PIN_DESC_OFF 0
+#define PIN_LEN_OFF 64
+#define PIN_OUT_OFF 128
+
+typedef struct {
+  hipStream_t stream;
+  uint8_t *pin;      /* host address of the pinned block */
+  uint8_t *pin_dev;  /* its device alias                 */
+  size_t pin_cap;
+  uint8_t *stage;    /* device staging for sources that are not device-visible */
+  size_t stage_cap;
+  uint8_t *scratch;  /* device scratch for image_resize() destinations */
+  size_t scratch_cap;
+} tls_ctx_t;
+
+static pthread_key_t g_tls_key;
+static pthread_once_t g_tls_once = PTHREAD_ONCE_INIT;
+
+static void tls_destroy(void *p) {
+  tls_ctx_t *c = (tls_ctx_t *)p;
+  if (!c)
+    return;
+  if (c->stream)
+    (void)hipStreamDestroy(c->stream);
+  if (c->pin)
+    (void)hipHostFree(c->pin);
+  if (c->stage)
+    (void)hipFree(c->stage);
+  if (c->scratch)
+    (void)hipFree(c->scratch);
+  free(c);
+}
+static void tls_make_key(void) { pthread_key_create(&g_tls_key, tls_destroy); }
+
+static tls_ctx_t *tls_get(void) {
+  pthread_once(&g_tls_once, tls_make_key);
+  tls_ctx_t *c = (tls_ctx_t *)pthread_getspecific(g_tls_key);
+  if (c)
+    return c;
+  if (achip_require_device())
+    return NULL;
+  c = (tls_ctx_t *)calloc(1, sizeof(*c));
+  if (!c)
+    return NULL;
+  if (achip_hip_check((int)hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate")) {
+    free(c);
+    return NULL;
+  }
+  pthread_setspecific(g_tls_key, c);
+  return c;
+}
+
+static int ensure_pin(tls_ctx_t *c, size_t need) {
+  if (c->pin_cap >= need)
+    return 0;
+  if (c->pin)
+    (void)hipHostFree(c->pin);
+  c->pin = NULL;
+  c->pin_cap = 0;
+  size_t cap = need + need / 2;
+  void *host = NULL, *dev = NULL;
+  if (achip_hip_check((int)hipHostMalloc(&host, cap, hipHostMallocMapped), "hipHostMalloc(output)"))
+    return -1;
+  if (hipHostGetDevicePointer(&dev, host, 0) != hipSuccess)
+    dev = host;
+  c->pin = (uint8_t *)host;
+  c->pin_dev = (uint8_t *)dev;
+  c->pin_cap = cap;
+  return 0;
+}
+
+static int ensure_dev(uint8_t **buf, size_t *cap, size_t need) {
+  if (*cap >= need)
+    return 0;
+  if (*buf)
+    (void)hipFree(*buf);
+  *buf = NULL;
+  *cap = 0;
+  if (achip_hip_check((int)hipMalloc((void **)buf, need + need / 4), "hipMalloc(staging)"))
+    return -1;
+  *cap = need + need / 4;
+  return 0;
+}
+
+/* device-visible address of `bytes` bytes of host pixels: pool-pinned frames are read in place,
+ * anything else is copied to the thread's staging buffer first */
+static const uint8_t *resolve_source(tls_ctx_t *c, const void *host_px, size_t bytes) {
+  const void *alias = achip_pool_device_ptr(host_px);
+  if (alias)
+    return (const uint8_t *)alias;
+  if (ensure_dev(&c->stage, &c->stage_cap, bytes))
+    return NULL;
+  if (achip_hip_check((int)hipMemcpyAsync(c->stage, host_px, bytes, hipMemcpyHostToDevice, c->stream),
+                      "hipMemcpyAsync(source frame)"))
+    return NULL;
+  return c->stage;
+}
+
+static int variant_for(int wp) {
+  for (int v = 2; v >= 0; v--)
+    if (wp <= achip_variant_cap(v))
+      return v;
+  return -1;
+}
+
+/* render one frame described by `f` (f->src = HOST pixels, `src_bytes` long) and return the malloc'd string */
+static char *render_one(int mode, const char *palette, achip_frame_t *f, size_t src_bytes) {
+  tls_ctx_t *c = tls_get();
+  if (!c)
+    return NULL;
+  const achip_lut_t *lut = NULL;
+  if (achip_lut_get(palette, &lut))
+    return NULL;
+  const int variant = variant_for(f->pad_left + f->out_w);
+  if (variant < 0) {
+    achip_fail(ASCIICHAT_HIP_ERR_NOT_SUPPORTED, "row of %d cells exceeds the kernel chunk", f->pad_left + f->out_w);
+    return NULL;
+  }
+  const uint8_t *src_dev = resolve_source(c, f->src, src_bytes);
+  if (!src_dev)
+    return NULL;
+  size_t stride = (achip_out_bound(mode, f) + 1 + 15) & ~(size_t)15;
+  if (stride > 0xFFFFFFF0u) {
+    achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame too large");
+    return NULL;
+  }
+  if (ensure_pin(c, PIN_OUT_OFF + stride))
+    return NULL;
+  achip_frame_t *desc = (achip_frame_t *)(c->pin + PIN_DESC_OFF);
+  *desc = *f;
+  desc->src = src_dev;
+  volatile uint32_t *len_host = (volatile uint32_t *)(c->pin + PIN_LEN_OFF);
+  *len_host = ACHIP_LEN_BADDESC;
+  if (achip_hip_check(achip_launch_render(mode, variant, (const achip_frame_t *)(c->pin_dev + PIN_DESC_OFF), 1, lut,
+                                          c->pin_dev + PIN_OUT_OFF, (uint64_t)stride,
+                                          (uint32_t *)(c->pin_dev + PIN_LEN_OFF), c->stream),
+                      "render kernel launch"))
+    return NULL;
+  if (achip_hip_check((int)hipStreamSynchronize(c->stream), "hipStreamSynchronize"))
+    return NULL;
+  const uint32_t len = *len_host;
+  if (len >= 0xFFFFFFF0u) {
+    achip_fail(ASCIICHAT_HIP_ERR_BUFFER, "render kernel reported %s",
+               len == ACHIP_LEN_OVERFLOW ? "output overflow" : "a bad descriptor");
+    return NULL;
+  }
+  char *out = (char *)malloc((size_t)len + 1);
+  if (!out) {
+    achip_fail(ASCIICHAT_HIP_ERR_MEMORY, "out of memory");
+    return NULL;
+  }
+  memcpy(out, c->pin + PIN_OUT_OFF, len);
+  out[len] = '\0';
+  return out;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* images (lib/video/rgba/image.c:38-253)                                                        */
+/* ------------------------------------------------------------------------------------------- */
+static bool dims_valid(size_t w, size_t h) { return w && h && w <= IMAGE_MAX_WIDTH && h <= IMAGE_MAX_HEIGHT; }
+
+image_t *image_new(size_t width, size_t height) {
+  if (!dims_valid(width, height)) {
+    achip_fail(ERROR_INVALID_PARAM, "image dimensions invalid or too large: %zu x %zu", width, height);
+    return NULL;
+  }
+  image_t *im = (image_t *)malloc(sizeof(*im));
+  void *px = NULL;
+  if (!im || posix_memalign(&px, 64, width * height * sizeof(rgb_pixel_t)) != 0) {
+    free(im);
+    achip_fail(ERROR_MEMORY, "image_new: out of memory");
+    return NULL;
+  }
+  im->w = (int)width;
+  im->h = (int)height;
+  im->pixels = (rgb_pixel_t *)px;
+  im->alloc_method = IMAGE_ALLOC_SIMD;
+  return im;
+}
+
+static size_t pooled_size(const image_t *im) {
+  return sizeof(image_t) + (size_t)im->w * (size_t)im->h * sizeof(rgb_pixel_t);
+}
+
+void image_destroy(image_t *p) {
+  if (!p)
+    return;
+  if (p->alloc_method == IMAGE_ALLOC_POOL) {
+    if (p->w <= 0 || p->h <= 0)
+      return;
+    buffer_pool_free(NULL, p, pooled_size(p));
+    return;
+  }
+  free(p->pixels);
+  free(p);
+}
+
+image_t *image_new_from_pool(size_t width, size_t height) {
+  if (!dims_valid(width, height)) {
+    achip_fail(ERROR_INVALID_PARAM, "image_new_from_pool: invalid dimensions %zux%zu", width, height);
+    return NULL;
+  }
+  const size_t total = sizeof(image_t) + width * height * sizeof(rgb_pixel_t);
+  image_t *im = (image_t *)buffer_pool_alloc(NULL, total);
+  if (!im) {
+    achip_fail(ERROR_MEMORY, "image_new_from_pool: allocation of %zu bytes failed", total);
+    return NULL;
+  }
+  im->w = (int)width;
+  im->h = (int)height;
+  im->pixels = (rgb_pixel_t *)((uint8_t *)im + sizeof(image_t));
+  im->alloc_method = IMAGE_ALLOC_POOL;
+  return im;
+}
+
+void image_destroy_to_pool(image_t *image) {
+  if (!image || image->w <= 0 || image->h <= 0)
+    return;
+  buffer_pool_free(NULL, image, pooled_size(image));
+}
+
+void image_clear(image_t *p) {
+  if (!p || !p->pixels || p->w <= 0 || p->h <= 0)
+    return;
+  memset(p->pixels, 0, (size_t)p->w * (size_t)p->h * sizeof(rgb_pixel_t));
+}
+
+image_t *image_new_copy(const image_t *source) {
+  if (!source)
+    return NULL;
+  image_t *copy = image_new((size_t)source->w, (size_t)source->h);
+  if (copy && source->pixels)
+    memcpy(copy->pixels, source->pixels, (size_t)source->w * (size_t)source->h * sizeof(rgb_pixel_t));
+  return copy;
+}
+
+void image_resize_interpolation(const image_t *source, image_t *dest) {
+  if (!source || !dest || !source->pixels || !dest->pixels || source->w <= 0 || source->h <= 0 || dest->w <= 0 ||
+      dest->h <= 0) {
+    achip_fail(ERROR_INVALID_PARAM, "invalid parameters to image_resize_interpolation");
+    return;
+  }
+  tls_ctx_t *c = tls_get();
+  if (!c)
+    return;
+  const size_t src_bytes = (size_t)source->w * (size_t)source->h * 3u;
+  const size_t dst_bytes = (size_t)dest->w * (size_t)dest->h * 3u;
+  const uint8_t *src_dev = resolve_source(c, source->pixels, src_bytes);
+  if (!src_dev)
+    return;
+  uint8_t *dst_alias = (uint8_t *)achip_pool_device_ptr(dest->pixels);
+  uint8_t *dst_dev = dst_alias;
+  if (!dst_dev) {
+    if (ensure_dev(&c->scratch, &c->scratch_cap, dst_bytes))
+      return;
+    dst_dev = c->scratch;
+  }
+  if (achip_hip_check(achip_launch_resize(src_dev, source->w, source->h, dst_dev, dest->w, dest->h, c->stream),
+                      "resize launch"))
+    return;
+  if (!dst_alias &&
+      achip_hip_check((int)hipMemcpyAsync(dest->pixels, dst_dev, dst_bytes, hipMemcpyDeviceToHost, c->stream),
+                      "hipMemcpyAsync(resized image)"))
+    return;
+  (void)achip_hip_check((int)hipStreamSynchronize(c->stream), "hipStreamSynchronize");
+}
+
+void image_resize(const image_t *s, image_t *d) {
+  if (!s || !d) {
+    achip_fail(ERROR_INVALID_PARAM, "image_resize: s or d is NULL");
+    return;
+  }
+  image_resize_interpolation(s, d);
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* renderers on an already-sized image (scalar/foreground.h, background.h, halfblock.h)          */
+/* ------------------------------------------------------------------------------------------- */
+static char *print_identity(int mode, const uint8_t *rgb, int w, int h, int stride_bytes, const char *palette) {
+  achip_frame_t f;
+  if (achip_frame_identity(&f, rgb, w, h) != 0) {
+    achip_fail(ERROR_INVALID_PARAM, "invalid dimensions h=%d, w=%d", h, w);
+    return NULL;
+  }
+  f.src_stride = stride_bytes > 0 ? stride_bytes : w * 3;
+  return render_one(mode, palette, &f, (size_t)f.src_stride * (size_t)(h - 1) + (size_t)w * 3u);
+}
+
+static char *print_image(int mode, const image_t *p, const char *palette) {
+  if (!p || !palette || !p->pixels) {
+    achip_fail(ERROR_INVALID_PARAM, "image, pixels or palette is NULL");
+    return NULL;
+  }
+  if (palette[0] == '\0') { /* get_utf8_palette_cache() rejects an empty palette (common.c:274-276) */
+    achip_fail(ERROR_INVALID_STATE, "empty palette");
+    return NULL;
+  }
+  return print_identity(mode, (const uint8_t *)p->pixels, p->w, p->h, 0, palette);
+}
+
+char *image_print(const image_t *p, const char *palette) { return print_image(ACHIP_MODE_MONO, p, palette); }
+char *image_print_color(const image_t *p, const char *palette) { return print_image(ACHIP_MODE_TRUE_FG, p, palette); }
+char *image_print_256color(const image_t *image, const char *palette) {
+  return print_image(ACHIP_MODE_256_FG, image, palette);
+}
+char *image_print_16color(const image_t *image, const char *palette) {
+  return print_image(ACHIP_MODE_16_FG, image, palette);
+}
+char *image_print_color_background(const image_t *p, const char *palette) {
+  return print_image(ACHIP_MODE_TRUE_BG, p, palette);
+}
+
+/* sgr.c:413-436: despite its name this falls through to the scalar renderers */
+char *image_print_color_simd(image_t *image, bool use_background_mode, bool use_256color, const char *ascii_chars) {
+  if (!image || !ascii_chars) {
+    achip_fail(ERROR_INVALID_PARAM, "image_print_color_simd: image or ascii_chars is NULL");
+    return NULL;
+  }
+  if (use_background_mode) {
+    /* image_print_16color_dithered_with_background: Floyd-Steinberg error diffusion, a serial
+     * dependency chain -- SURVEY.md 8(f).4 ranks it after the parallel modes; not on the GPU yet */
+    achip_fail(ERROR_NOT_SUPPORTED, "dithered 16-colour background mode is not implemented on the GPU path");
+    return NULL;
+  }
+  return use_256color ? image_print_256color(image, ascii_chars) : image_print_color(image, ascii_chars);
+}
+
+static char *halfblock_entry(int mode, const uint8_t *rgb, int width, int height, int stride_bytes) {
+  if (width <= 0 || height <= 0) { /* halfblock.c:50-51 */
+    char *e = (char *)malloc(1);
+    if (e)
+      e[0] = '\0';
+    return e;
+  }
+  if (!rgb)
+    return NULL;
+  return print_identity(mode, rgb, width, height, stride_bytes, PALETTE_CHARS_STANDARD /* unused by these modes */);
+}
+
+char *rgb_to_truecolor_halfblocks_scalar(const uint8_t *rgb, int width, int height, int stride_bytes) {
+  return halfblock_entry(ACHIP_MODE_HB_TRUE, rgb, width, height, stride_bytes);
+}
+char *rgb_to_256color_halfblocks_scalar(const uint8_t *rgb, int width, int height, int stride_bytes,
+                                        const char *palette) {
+  (void)palette;
+  return halfblock_entry(ACHIP_MODE_HB_256, rgb, width, height, stride_bytes);
+}
+char *rgb_to_16color_halfblocks_scalar(const uint8_t *rgb, int width, int height, int stride_bytes,
+                                       const char *palette) {
+  (void)palette;
+  return halfblock_entry(ACHIP_MODE_HB_16, rgb, width, height, stride_bytes);
+}
+char *rgb_to_halfblocks_scalar(const uint8_t *rgb, int width, int height, int stride_bytes, const char *palette) {
+  (void)palette;
+  return halfblock_entry(ACHIP_MODE_HB_MONO, rgb, width, height, stride_bytes);
+}
+
+/* ascii.c:955-1002 */
+char *image_print_with_capabilities(const image_t *image, const terminal_capabilities_t *caps, const char *palette) {
+  if (!image || !caps || !palette)
+    return NULL;
+  if (caps->render_mode == RENDER_MODE_HALF_BLOCK) {
+    const uint8_t *rgb = (const uint8_t *)image->pixels;
+    switch (caps->color_level) {
+    case TERM_COLOR_TRUECOLOR:
+      return rgb_to_truecolor_halfblocks_scalar(rgb, image->w, image->h, 0);
+    case TERM_COLOR_256:
+      return rgb_to_256color_halfblocks_scalar(rgb, image->w, image->h, 0, palette);
+    case TERM_COLOR_16:
+      return rgb_to_16color_halfblocks_scalar(rgb, image->w, image->h, 0, palette);
+    default:
+      return rgb_to_halfblocks_scalar(rgb, image->w, image->h, 0, palette);
+    }
+  }
+  switch (caps->color_level) {
+  case TERM_COLOR_TRUECOLOR:
+    return image_print_color_simd((image_t *)image, caps->render_mode == RENDER_MODE_BACKGROUND, false, palette);
+  case TERM_COLOR_256:
+    return image_print_256color(image, palette);
+  case TERM_COLOR_16:
+    return image_print_16color(image, palette);
+  default:
+    return image_print(image, palette);
+  }
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* ascii_convert / ascii_convert_with_capabilities (ascii.c:72-387): resize + render + pad fused  */
+/* ------------------------------------------------------------------------------------------- */
+static render_mode_t g_option_render_mode = RENDER_MODE_FOREGROUND;
+void asciichat_hip_set_option_render_mode(render_mode_t mode) { g_option_render_mode = mode; }
+
+char *ascii_convert_with_capabilities(image_t *original, const ssize_t width, const ssize_t height,
+                                      const terminal_capabilities_t *caps, const bool use_aspect_ratio,
+                                      const bool stretch, const char *palette_chars) {
+  if (!original || !caps) {
+    achip_fail(ERROR_INVALID_PARAM, "invalid parameters for ascii_convert_with_capabilities");
+    return NULL;
+  }
+  if (original->w <= 0 || original->w > 10000 || original->h <= 0 || original->h > 10000 || !original->pixels) {
+    achip_fail(ERROR_INVALID_PARAM, "invalid original image");
+    return NULL;
+  }
+  if (!palette_chars || palette_chars[0] == '\0') { /* image_print_with_capabilities / palette cache reject these */
+    achip_fail(ERROR_INVALID_PARAM, "NULL or empty palette");
+    return NULL;
+  }
+  const int mode = achip_mode_from_caps((int)caps->color_level, (int)caps->render_mode);
+  if (mode < 0) {
+    achip_fail(ERROR_NOT_SUPPORTED, "dithered 16-colour background mode is not implemented on the GPU path");
+    return NULL;
+  }
+  achip_frame_t f;
+  if (achip_frame_setup(&f, (const uint8_t *)original->pixels, original->w, original->h, width, height,
+                        (int)caps->render_mode, caps->wants_padding, use_aspect_ratio, stretch) != 0) {
+    achip_fail(ERROR_INVALID_PARAM, "invalid dimensions for resize: width=%zd, height=%zd", width, height);
+    return NULL;
+  }
+  return render_one(mode, palette_chars, &f, (size_t)original->w * (size_t)original->h * 3u);
+}
+
+char *ascii_convert(image_t *original, const ssize_t width, const ssize_t height, const bool color,
+                    const bool _aspect_ratio, const bool stretch, const char *palette_chars,
+                    const char luminance_palette[256]) {
+  if (!original || !palette_chars || !luminance_palette || !original->pixels) {
+    achip_fail(ERROR_INVALID_PARAM, "ascii_convert: invalid parameters");
+    return NULL;
+  }
+  if (palette_chars[0] == '\0' || luminance_palette[0] == '\0') {
+    achip_fail(ERROR_INVALID_PARAM, "ascii_convert: empty palette strings");
+    return NULL;
+  }
+  if (original->w <= 0 || original->h <= 0)
+    return NULL;
+  int mode = ACHIP_MODE_MONO;
+  if (color) { /* ascii.c:136-161: mode comes from the global render_mode option */
+    if (g_option_render_mode == RENDER_MODE_HALF_BLOCK) {
+      mode = ACHIP_MODE_HB_TRUE;
+    } else if (g_option_render_mode == RENDER_MODE_BACKGROUND) {
+      achip_fail(ERROR_NOT_SUPPORTED, "dithered 16-colour background mode is not implemented on the GPU path");
+      return NULL;
+    } else {
+      mode = ACHIP_MODE_TRUE_FG;
+    }
+  }
+  /* same sizing as above except: padding whenever aspect correction is on, and the half-block renderer
+   * receives the resized image without height doubling (ascii.c:97-131) */
+  ssize_t rw = width, rh = height;
+  if (_aspect_ratio)
+    aspect_ratio(original->w, original->h, rw, rh, stretch, &rw, &rh);
+  if (rw <= 0 || rh <= 0 || rw > IMAGE_MAX_WIDTH || rh > IMAGE_MAX_HEIGHT) {
+    achip_fail(ERROR_INVALID_PARAM, "invalid dimensions for resize: width=%zd, height=%zd", rw, rh);
+    return NULL;
+  }
+  achip_frame_t f;
+  memset(&f, 0, sizeof(f));
+  f.src = (const uint8_t *)original->pixels;
+  f.src_w = original->w;
+  f.src_h = original->h;
+  f.out_w = (int32_t)rw;
+  f.out_h = (int32_t)rh;
+  if (_aspect_ratio) {
+    f.pad_left = (int32_t)(width > rw ? (width - rw) / 2 : 0);
+    f.pad_top = (int32_t)(height > rh ? (height - rh) / 2 : 0);
+  }
+  f.x_ratio = achip_nn_ratio(original->w, (int)rw);
+  f.y_ratio = achip_nn_ratio(original->h, (int)rh);
+  return render_one(mode, palette_chars, &f, (size_t)original->w * (size_t)original->h * 3u);
+}

@@ -1,0 +1,27 @@
+/* hip_launch.h -- C interface between the host shim (C) and the hipcc-compiled kernels. */
+#ifndef ACHIP_HIP_LAUNCH_H
+#define ACHIP_HIP_LAUNCH_H
+
+#include <stdint.h>
+
+#include "achip_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* all return a hipError_t as int (0 = hipSuccess); `stream` is a hipStream_t */
+int achip_launch_render(int mode, int variant, const achip_frame_t *frames_dev, int n_frames,
+                        const achip_lut_t *lut_dev, uint8_t *out, uint64_t out_stride, uint32_t *out_len,
+                        void *stream);
+int achip_launch_resize(const uint8_t *src, int sw, int sh, uint8_t *dst, int dw, int dh, void *stream);
+int achip_launch_composite(const achip_composite_t *comp_dev, int canvas_w, int canvas_h, uint8_t *dst, void *stream);
+
+int achip_variant_block(int variant); /* threads per workgroup, -1 for an unknown id */
+int achip_variant_cap(int variant);   /* cells per chunk                               */
+int achip_variant_lds_bytes(int mode, int variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

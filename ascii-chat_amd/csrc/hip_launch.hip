@@ -1,0 +1,145 @@
+/*
+ * hip_launch.hip -- instantiates the gfx950 kernels and exposes plain-C launchers.
+ * Built only with hipcc --offload-arch=gfx950; there is no host/CPU variant of these entry points.
+ */
+#include "hip_launch.h"
+
+#include <hip/hip_runtime.h>
+
+#include "render_kernels.hpp"
+#include "render_variants.h"
+
+namespace {
+
+template <int MODE, int BLOCK, int CAP, int RING>
+hipError_t launch_one(const achip_frame_t *frames, int n, const achip_lut_t *lut, uint8_t *out, uint64_t stride,
+                      uint32_t *len, hipStream_t stream) {
+  using L = achip::Lds<MODE, BLOCK, CAP, RING>;
+  auto kern = achip::render_frames_kernel<MODE, BLOCK, CAP, RING>;
+  static bool attr_set = false; /* one flag per instantiation; benign race (idempotent call) */
+  if (!attr_set) {
+    if (L::bytes > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, L::bytes);
+      if (e != hipSuccess)
+        return e;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(BLOCK), (size_t)L::bytes, stream, frames, lut, out, stride, len, n);
+  return hipGetLastError();
+}
+
+template <int BLOCK, int CAP, int RING>
+hipError_t launch_mode(int mode, const achip_frame_t *frames, int n, const achip_lut_t *lut, uint8_t *out,
+                       uint64_t stride, uint32_t *len, hipStream_t stream) {
+  switch (mode) {
+#define M(m)                                                                                                           \
+  case m:                                                                                                              \
+    return launch_one<m, BLOCK, CAP, RING>(frames, n, lut, out, stride, len, stream);
+    M(ACHIP_MODE_MONO)
+    M(ACHIP_MODE_TRUE_FG)
+    M(ACHIP_MODE_256_FG)
+    M(ACHIP_MODE_16_FG)
+    M(ACHIP_MODE_TRUE_BG)
+    M(ACHIP_MODE_HB_TRUE)
+    M(ACHIP_MODE_HB_256)
+    M(ACHIP_MODE_HB_16)
+    M(ACHIP_MODE_HB_MONO)
+#undef M
+  }
+  return hipErrorInvalidValue;
+}
+
+template <int BLOCK, int CAP, int RING> int lds_for_mode(int mode) {
+  switch (mode) {
+#define M(m)                                                                                                           \
+  case m:                                                                                                              \
+    return achip::Lds<m, BLOCK, CAP, RING>::bytes;
+    M(ACHIP_MODE_MONO)
+    M(ACHIP_MODE_TRUE_FG)
+    M(ACHIP_MODE_256_FG)
+    M(ACHIP_MODE_16_FG)
+    M(ACHIP_MODE_TRUE_BG)
+    M(ACHIP_MODE_HB_TRUE)
+    M(ACHIP_MODE_HB_256)
+    M(ACHIP_MODE_HB_16)
+    M(ACHIP_MODE_HB_MONO)
+#undef M
+  }
+  return -1;
+}
+
+} // namespace
+
+extern "C" int achip_launch_render(int mode, int variant, const achip_frame_t *frames_dev, int n_frames,
+                                   const achip_lut_t *lut_dev, uint8_t *out, uint64_t out_stride, uint32_t *out_len,
+                                   void *stream) {
+  if (n_frames <= 0)
+    return (int)hipSuccess;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (variant) {
+#define X(id, B, C, R)                                                                                                 \
+  case id:                                                                                                             \
+    return (int)launch_mode<B, C, R>(mode, frames_dev, n_frames, lut_dev, out, out_stride, out_len, s);
+    ACHIP_VARIANTS(X)
+#undef X
+  }
+  return (int)hipErrorInvalidValue;
+}
+
+extern "C" int achip_variant_block(int variant) {
+  switch (variant) {
+#define X(id, B, C, R)                                                                                                 \
+  case id:                                                                                                             \
+    return B;
+    ACHIP_VARIANTS(X)
+#undef X
+  }
+  return -1;
+}
+
+extern "C" int achip_variant_cap(int variant) {
+  switch (variant) {
+#define X(id, B, C, R)                                                                                                 \
+  case id:                                                                                                             \
+    return C;
+    ACHIP_VARIANTS(X)
+#undef X
+  }
+  return -1;
+}
+
+extern "C" int achip_variant_lds_bytes(int mode, int variant) {
+  switch (variant) {
+#define X(id, B, C, R)                                                                                                 \
+  case id:                                                                                                             \
+    return lds_for_mode<B, C, R>(mode);
+    ACHIP_VARIANTS(X)
+#undef X
+  }
+  return -1;
+}
+
+extern "C" int achip_launch_resize(const uint8_t *src, int sw, int sh, uint8_t *dst, int dw, int dh, void *stream) {
+  const uint32_t xr = (uint32_t)((((uint64_t)sw << 16) / (uint64_t)dw) + 1u);
+  const uint32_t yr = (uint32_t)((((uint64_t)sh << 16) / (uint64_t)dh) + 1u);
+  const uint64_t total = (uint64_t)dw * (uint64_t)dh;
+  unsigned blocks = (unsigned)((total + 255) / 256);
+  if (blocks > 2048u)
+    blocks = 2048u;
+  hipLaunchKernelGGL(achip::resize_nn_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), src, sw, sh,
+                     3 * sw, dst, dw, dh, xr, yr);
+  return (int)hipGetLastError();
+}
+
+extern "C" int achip_launch_composite(const achip_composite_t *comp_dev, int canvas_w, int canvas_h, uint8_t *dst,
+                                      void *stream) {
+  const uint64_t total = (uint64_t)canvas_w * (uint64_t)canvas_h;
+  unsigned blocks = (unsigned)((total + 255) / 256);
+  if (blocks > 2048u)
+    blocks = 2048u;
+  hipLaunchKernelGGL(achip::composite_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), comp_dev,
+                     dst);
+  return (int)hipGetLastError();
+}

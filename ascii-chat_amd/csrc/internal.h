@@ -1,0 +1,29 @@
+/* internal.h -- declarations shared by the host C sources of libasciichat_hip.so (not installed). */
+#ifndef ACHIP_INTERNAL_H
+#define ACHIP_INTERNAL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "achip_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* records a thread-local message, returns `code` */
+int achip_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+/* 0 when a HIP device exists, else ASCIICHAT_HIP_ERR_NO_DEVICE (and a message on stderr) */
+int achip_require_device(void);
+/* maps a hipError_t to 0 / ASCIICHAT_HIP_ERR_NO_DEVICE with a message */
+int achip_hip_check(int hip_error, const char *what);
+/* device glyph tables for a palette string, cached per device */
+int achip_lut_get(const char *palette, const achip_lut_t **out_dev);
+
+/* buffer_pool.c: device alias of a pointer inside a pinned pool block, or NULL */
+const void *achip_pool_device_ptr(const void *host_ptr);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

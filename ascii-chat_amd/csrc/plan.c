@@ -1,0 +1,321 @@
+/*
+ * plan.c -- the batch layer of the C-ABI (asciichat_hip.h): plan objects, glyph-table cache, device
+ * helpers.  Host code is plain C calling the HIP runtime C API; the kernels live in hip_launch.hip.
+ */
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+
+#include <pthread.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "achip_host.h"
+#include "asciichat_hip.h"
+#include "hip_launch.h"
+#include "internal.h"
+#include "render_variants.h"
+
+/* ------------------------------------------------------------------------------------------- */
+/* thread-local error text (stands for the reference's SET_ERRNO context, asciichat_errno.h:311)  */
+/* ------------------------------------------------------------------------------------------- */
+static _Thread_local char tl_err[256];
+
+int achip_fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(tl_err, sizeof(tl_err), fmt, ap);
+  va_end(ap);
+  if (code == ASCIICHAT_HIP_ERR_NO_DEVICE || getenv("ASCIICHAT_HIP_VERBOSE"))
+    fprintf(stderr, "asciichat_hip: %s\n", tl_err);
+  return code;
+}
+
+const char *asciichat_hip_last_error(void) { return tl_err; }
+
+int asciichat_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+int achip_require_device(void) {
+  static int cached = -1; /* benign race: idempotent */
+  if (cached < 0)
+    cached = asciichat_hip_device_count();
+  if (cached <= 0)
+    return achip_fail(ASCIICHAT_HIP_ERR_NO_DEVICE,
+                      "no HIP device visible: this library has no CPU fallback (built for gfx950)");
+  return 0;
+}
+
+int achip_hip_check(int e, const char *what) {
+  if (e == (int)hipSuccess)
+    return 0;
+  return achip_fail(ASCIICHAT_HIP_ERR_NO_DEVICE, "%s failed: %s", what, hipGetErrorString((hipError_t)e));
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* glyph-table cache: palette string -> device achip_lut_t (per device)                           */
+/* the counterpart of get_utf8_palette_cache (common.c:270-377): built once per palette, shared    */
+/* ------------------------------------------------------------------------------------------- */
+#define LUT_CACHE_MAX 64
+typedef struct {
+  char *palette;
+  int device;
+  achip_lut_t *dev;
+} lut_entry_t;
+static lut_entry_t g_luts[LUT_CACHE_MAX];
+static int g_lut_count;
+static pthread_mutex_t g_lut_mu = PTHREAD_MUTEX_INITIALIZER;
+
+int achip_lut_get(const char *palette, const achip_lut_t **out_dev) {
+  if (!palette || !palette[0])
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "empty palette");
+  int device = 0;
+  if (achip_hip_check((int)hipGetDevice(&device), "hipGetDevice"))
+    return ASCIICHAT_HIP_ERR_NO_DEVICE;
+  pthread_mutex_lock(&g_lut_mu);
+  for (int i = 0; i < g_lut_count; i++) {
+    if (g_luts[i].device == device && strcmp(g_luts[i].palette, palette) == 0) {
+      *out_dev = g_luts[i].dev;
+      pthread_mutex_unlock(&g_lut_mu);
+      return 0;
+    }
+  }
+  achip_lut_t host;
+  if (achip_lut_build(palette, &host) != 0) {
+    pthread_mutex_unlock(&g_lut_mu);
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "bad palette");
+  }
+  achip_lut_t *dev = NULL;
+  int rc = achip_hip_check((int)hipMalloc((void **)&dev, sizeof(host)), "hipMalloc(lut)");
+  if (!rc)
+    rc = achip_hip_check((int)hipMemcpy(dev, &host, sizeof(host), hipMemcpyHostToDevice), "hipMemcpy(lut)");
+  if (rc) {
+    pthread_mutex_unlock(&g_lut_mu);
+    return rc;
+  }
+  if (g_lut_count == LUT_CACHE_MAX) { /* evict the oldest entry; plans hold their own reference count of 0: */
+    /* entries are tiny (1.3 KB) and never freed while a plan may still use them -> just stop caching */
+    *out_dev = dev;
+    pthread_mutex_unlock(&g_lut_mu);
+    return 0;
+  }
+  g_luts[g_lut_count].palette = strdup(palette);
+  g_luts[g_lut_count].device = device;
+  g_luts[g_lut_count].dev = dev;
+  g_lut_count++;
+  *out_dev = dev;
+  pthread_mutex_unlock(&g_lut_mu);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* plans                                                                                         */
+/* ------------------------------------------------------------------------------------------- */
+struct asciichat_hip_plan {
+  int mode;
+  int n;
+  int variant;      /* resolved geometry */
+  int variant_user; /* -1 = automatic */
+  int max_wp;
+  size_t stride;
+  achip_frame_t *frames_dev;
+  achip_frame_t *frames_pinned; /* staging for async updates */
+  const achip_lut_t *lut_dev;
+};
+
+static int pick_variant(int max_wp) {
+  const char *env = getenv("ASCIICHAT_HIP_VARIANT");
+  if (env && env[0]) {
+    int v = atoi(env);
+    if (achip_variant_cap(v) >= max_wp)
+      return v;
+  }
+  /* smallest production geometry whose chunk holds the widest padded row (variant 3 is test-only) */
+  if (max_wp <= achip_variant_cap(2))
+    return 2;
+  if (max_wp <= achip_variant_cap(1))
+    return 1;
+  if (max_wp <= achip_variant_cap(0))
+    return 0;
+  return -1;
+}
+
+static int plan_measure(asciichat_hip_plan_t *p, const achip_frame_t *frames) {
+  size_t stride = 0;
+  int max_wp = 0;
+  for (int i = 0; i < p->n; i++) {
+    const achip_frame_t *f = &frames[i];
+    if (f->out_w <= 0 || f->out_h <= 0 || f->src_w <= 0 || f->src_h <= 0 || f->pad_left < 0 || f->pad_top < 0 ||
+        (!f->src && !f->comp))
+      return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame %d: bad descriptor", i);
+    size_t b = achip_out_bound(p->mode, f) + 1;
+    if (b > stride)
+      stride = b;
+    if (f->pad_left + f->out_w > max_wp)
+      max_wp = f->pad_left + f->out_w;
+  }
+  stride = (stride + 15) & ~(size_t)15;
+  if (stride > 0xFFFFFFF0u)
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame output bound exceeds 4 GiB");
+  p->stride = stride;
+  p->max_wp = max_wp;
+  int v = p->variant_user >= 0 ? p->variant_user : pick_variant(max_wp);
+  if (v < 0 || achip_variant_cap(v) < max_wp)
+    return achip_fail(ASCIICHAT_HIP_ERR_NOT_SUPPORTED, "padded row of %d cells exceeds the kernel chunk (max %d)",
+                      max_wp, achip_variant_cap(0));
+  p->variant = v;
+  return 0;
+}
+
+int asciichat_hip_plan_create(asciichat_hip_plan_t **plan, int mode, const char *palette_chars,
+                              const achip_frame_t *frames, int n_frames) {
+  if (!plan || !frames || n_frames <= 0 || mode < 0 || mode >= ACHIP_MODE_COUNT)
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "plan_create: bad arguments");
+  *plan = NULL;
+  int rc = achip_require_device();
+  if (rc)
+    return rc;
+  asciichat_hip_plan_t *p = (asciichat_hip_plan_t *)calloc(1, sizeof(*p));
+  if (!p)
+    return achip_fail(ASCIICHAT_HIP_ERR_MEMORY, "out of memory");
+  p->mode = mode;
+  p->n = n_frames;
+  p->variant_user = -1;
+  rc = plan_measure(p, frames);
+  if (!rc)
+    rc = achip_lut_get(palette_chars, &p->lut_dev);
+  const size_t bytes = (size_t)n_frames * sizeof(achip_frame_t);
+  if (!rc)
+    rc = achip_hip_check((int)hipMalloc((void **)&p->frames_dev, bytes), "hipMalloc(frames)");
+  if (!rc)
+    rc = achip_hip_check((int)hipHostMalloc((void **)&p->frames_pinned, bytes, hipHostMallocDefault),
+                         "hipHostMalloc(frames)");
+  if (!rc) {
+    memcpy(p->frames_pinned, frames, bytes);
+    rc = achip_hip_check((int)hipMemcpy(p->frames_dev, p->frames_pinned, bytes, hipMemcpyHostToDevice),
+                         "hipMemcpy(frames)");
+  }
+  if (rc) {
+    asciichat_hip_plan_destroy(p);
+    return rc;
+  }
+  *plan = p;
+  return 0;
+}
+
+int asciichat_hip_plan_update(asciichat_hip_plan_t *p, const achip_frame_t *frames, void *stream) {
+  if (!p || !frames)
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "plan_update: bad arguments");
+  int rc = plan_measure(p, frames);
+  if (rc)
+    return rc;
+  const size_t bytes = (size_t)p->n * sizeof(achip_frame_t);
+  /* the pinned staging copy may still be in flight from the previous update on this stream */
+  rc = achip_hip_check((int)hipStreamSynchronize((hipStream_t)stream), "hipStreamSynchronize");
+  if (rc)
+    return rc;
+  memcpy(p->frames_pinned, frames, bytes);
+  return achip_hip_check(
+      (int)hipMemcpyAsync(p->frames_dev, p->frames_pinned, bytes, hipMemcpyHostToDevice, (hipStream_t)stream),
+      "hipMemcpyAsync(frames)");
+}
+
+size_t asciichat_hip_plan_out_stride(const asciichat_hip_plan_t *p) { return p ? p->stride : 0; }
+
+int asciichat_hip_plan_set_variant(asciichat_hip_plan_t *p, int variant) {
+  if (!p)
+    return ASCIICHAT_HIP_ERR_INVALID_PARAM;
+  if (variant >= 0 && achip_variant_cap(variant) < p->max_wp)
+    return achip_fail(ASCIICHAT_HIP_ERR_NOT_SUPPORTED, "variant %d cannot hold a %d-cell row", variant, p->max_wp);
+  p->variant_user = variant;
+  p->variant = variant >= 0 ? variant : pick_variant(p->max_wp);
+  return 0;
+}
+
+int asciichat_hip_plan_get_variant(const asciichat_hip_plan_t *p) { return p ? p->variant : -1; }
+
+int asciichat_hip_plan_render_range(asciichat_hip_plan_t *p, int first, int count, uint8_t *out_dev, size_t out_stride,
+                                    uint32_t *out_len_dev, void *stream) {
+  if (!p || !out_dev || !out_len_dev || first < 0 || count < 0 || first + count > p->n)
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "plan_render: bad arguments");
+  if (((uintptr_t)out_dev & 15u) || (out_stride & 15u) || out_stride < p->stride)
+    return achip_fail(ASCIICHAT_HIP_ERR_BUFFER, "output slab must be 16-byte aligned with stride >= %zu (multiple of 16)",
+                      p->stride);
+  if (count == 0)
+    return 0;
+  return achip_hip_check(achip_launch_render(p->mode, p->variant, p->frames_dev + first, count, p->lut_dev, out_dev,
+                                             (uint64_t)out_stride, out_len_dev, stream),
+                         "render kernel launch");
+}
+
+int asciichat_hip_plan_render(asciichat_hip_plan_t *p, uint8_t *out_dev, size_t out_stride, uint32_t *out_len_dev,
+                              void *stream) {
+  return asciichat_hip_plan_render_range(p, 0, p ? p->n : 0, out_dev, out_stride, out_len_dev, stream);
+}
+
+void asciichat_hip_plan_destroy(asciichat_hip_plan_t *p) {
+  if (!p)
+    return;
+  if (p->frames_dev)
+    (void)hipFree(p->frames_dev);
+  if (p->frames_pinned)
+    (void)hipHostFree(p->frames_pinned);
+  free(p);
+}
+
+/* ------------------------------------------------------------------------------------------- */
+int asciichat_hip_resize(const uint8_t *src_dev, int src_w, int src_h, uint8_t *dst_dev, int dst_w, int dst_h,
+                         void *stream) {
+  if (!src_dev || !dst_dev || src_w <= 0 || src_h <= 0 || dst_w <= 0 || dst_h <= 0)
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "resize: bad arguments");
+  int rc = achip_require_device();
+  if (rc)
+    return rc;
+  return achip_hip_check(achip_launch_resize(src_dev, src_w, src_h, dst_dev, dst_w, dst_h, stream), "resize launch");
+}
+
+int asciichat_hip_composite_upload(const achip_composite_t *comp_host, achip_composite_t **comp_dev) {
+  if (!comp_host || !comp_dev)
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "composite_upload: bad arguments");
+  int rc = achip_require_device();
+  if (rc)
+    return rc;
+  achip_composite_t *d = NULL;
+  rc = achip_hip_check((int)hipMalloc((void **)&d, sizeof(*d)), "hipMalloc(composite)");
+  if (!rc)
+    rc = achip_hip_check((int)hipMemcpy(d, comp_host, sizeof(*d), hipMemcpyHostToDevice), "hipMemcpy(composite)");
+  if (rc) {
+    if (d)
+      (void)hipFree(d);
+    return rc;
+  }
+  *comp_dev = d;
+  return 0;
+}
+
+void asciichat_hip_free(void *dev_ptr) {
+  if (dev_ptr)
+    (void)hipFree(dev_ptr);
+}
+
+int asciichat_hip_composite(const achip_composite_t *comp_host, uint8_t *dst_dev, void *stream) {
+  if (!comp_host || !dst_dev)
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "composite: bad arguments");
+  achip_composite_t *d = NULL;
+  int rc = asciichat_hip_composite_upload(comp_host, &d);
+  if (rc)
+    return rc;
+  rc = achip_hip_check(achip_launch_composite(d, comp_host->canvas_w, comp_host->canvas_h, dst_dev, stream),
+                       "composite launch");
+  if (!rc)
+    rc = achip_hip_check((int)hipStreamSynchronize((hipStream_t)stream), "hipStreamSynchronize");
+  (void)hipFree(d);
+  return rc;
+}

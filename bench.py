@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s of the MI355X render path on BASELINE.json's metric.
+
+A "step" is one pass of the hot path (one asciichat_hip_plan_render launch) over one batch of
+device-resident synthetic frames.  Default workload = the configuration the metric is quoted on:
+batch=256 x 1080p -> 80x24 truecolor foreground (BASELINE.json `metric`; `configs[1]` is the same
+shape in ANSI-256, reported under "other_workloads").  One process per GPU; frames are independent,
+so N>1 shards the batch across ranks with no data-path collective (weak scaling: 256 frames/rank).
+
+Prints ONE JSON line on rank 0 (see the task contract): value = whole-job frames/s with inputs already
+resident in HBM; roofline = algorithmic bytes / kernel time vs the 8 TB/s HBM peak; cpu_baseline = the
+CPU oracle (a port of the reference's scalar path) timed on this host on a bounded sample.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+PALETTE_STANDARD = "   ...',;:clodxkO0KXNWM"  # PALETTE_CHARS_STANDARD (palette.h:161)
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+WORKLOADS = {
+    # name: (src_w, src_h, W, H, color_level, render_mode, mode_name)
+    "1080p_80x24_truecolor": (1920, 1080, 80, 24, 3, 0),
+    "1080p_80x24_ansi256": (1920, 1080, 80, 24, 2, 0),
+    "4k_200x60_truecolor": (3840, 2160, 200, 60, 3, 0),
+    "4k_400x120_halfblock": (3840, 2160, 400, 120, 3, 2),
+    "640x480_80x24_mono": (640, 480, 80, 24, 0, 0),
+}
+
+
+def make_frames(torch, batch, w, h, seed):
+    """Device-resident synthetic S-noise-like frames: uniform random RGB24 (every cell changes colour,
+    no runs -- the worst case for output size, as in BASELINE.md's 'noise' rows)."""
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    return torch.randint(0, 256, (batch, h, w, 3), dtype=torch.uint8, device="cuda", generator=g)
+
+
+def build_plan(pkg, frames_t, W, H, cl, rm):
+    b, h, w, _ = frames_t.shape
+    mode = pkg.lib().achip_mode_from_caps(cl, rm)
+    descs = []
+    base = frames_t.data_ptr()
+    for i in range(b):
+        f = pkg.frame_setup(base + i * h * w * 3, w, h, W, H, rm, False, False, False)
+        descs.append(f)
+    return pkg.Plan(mode, PALETTE_STANDARD, descs), mode
+
+
+def time_steps(torch, plan, out, ln, steps, warmup, dist=None):
+    stream = torch.cuda.current_stream().cuda_stream
+    for _ in range(warmup):
+        plan.render(out.data_ptr(), plan.stride, ln.data_ptr(), stream)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        plan.render(out.data_ptr(), plan.stride, ln.data_ptr(), stream)
+    e1.record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    gpu_ms = e0.elapsed_time(e1)
+    return wall, gpu_ms
+
+
+def kernel_time_events(torch, plan, out, ln, reps):
+    """Per-launch duration: HIP events recorded on the launch stream around EACH launch (idle stream
+    in between), averaged -- this is the number rocprofv3's kernel trace should agree with."""
+    stream = torch.cuda.current_stream().cuda_stream
+    tot = 0.0
+    for _ in range(reps):
+        a = torch.cuda.Event(enable_timing=True)
+        b = torch.cuda.Event(enable_timing=True)
+        a.record()
+        plan.render(out.data_ptr(), plan.stride, ln.data_ptr(), stream)
+        b.record()
+        b.synchronize()
+        tot += a.elapsed_time(b)
+    return tot / reps
+
+
+def run_workload(torch, pkg, name, batch, steps, warmup, dist=None, seed=1234, variant=-1):
+    sw, sh, W, H, cl, rm = WORKLOADS[name]
+    frames_t = make_frames(torch, batch, sw, sh, seed)
+    plan, mode = build_plan(pkg, frames_t, W, H, cl, rm)
+    if variant >= 0:
+        plan.set_variant(variant)
+    out = torch.empty(batch * plan.stride, dtype=torch.uint8, device="cuda")
+    ln = torch.zeros(batch, dtype=torch.int32, device="cuda")
+    wall, gpu_ms = time_steps(torch, plan, out, ln, steps, warmup, dist)
+    lens = ln.cpu().numpy().astype("uint32")
+    assert (lens < 0xFFFFFFF0).all(), "kernel reported overflow/bad descriptor"
+    rows = 2 * H if rm == 2 else H
+    alg_bytes = int(lens.sum()) + batch * 3 * W * rows  # sampled RGB consumed + exact output bytes
+    per_launch_ms = kernel_time_events(torch, plan, out, ln, 20)
+    res = dict(name=name, mode=pkg.MODE_NAMES[mode], batch=batch, wall_s=wall, gpu_ms=gpu_ms, steps=steps,
+               out_bytes_per_frame=float(lens.mean()), alg_bytes_per_launch=alg_bytes,
+               kernel_ms_event_pair=per_launch_ms, kernel_ms_back_to_back=gpu_ms / steps, variant=plan.variant,
+               frames=frames_t, plan=plan, out=out, ln=ln, lens=lens)
+    return res
+
+
+def cpu_baseline(name, budget_s=12.0):
+    """Times the CPU oracle (port of the reference's scalar path) on this host: 1 thread and all cores,
+    on a bounded sample of the same workload (same frame shape, S-noise input, same caps)."""
+    import numpy as np
+
+    import orc
+
+    sw, sh, W, H, cl, rm = WORKLOADS[name]
+    rng = np.random.default_rng(7)
+    img = rng.integers(0, 256, (sh, sw, 3), dtype=np.uint8)
+    L = orc.lib()
+    pal = orc.PALETTE_STANDARD.encode()
+    nb = C.c_uint64()
+    # calibrate
+    t = L.orc_bench_convert(img.ctypes.data, sw, sh, W, H, cl, rm, pal, 20, 1, C.byref(nb))
+    per = max(t / 20, 1e-7)
+    it1 = max(50, int(budget_s * 0.4 / per))
+    t1 = L.orc_bench_convert(img.ctypes.data, sw, sh, W, H, cl, rm, pal, it1, 1, C.byref(nb))
+    cores = os.cpu_count() or 1
+    th = min(cores, 256)
+    itn = max(20, int(budget_s * 0.6 / per))
+    tn = L.orc_bench_convert(img.ctypes.data, sw, sh, W, H, cl, rm, pal, itn, th, C.byref(nb))
+    return {
+        "value": it1 / t1, "unit": "frames/s", "cores": 1, "kind": "port",
+        "sample": f"{it1} x ({sw}x{sh}->{W}x{H}, color_level={cl}, render_mode={rm}, uniform-noise frame) on 1 thread; "
+                  f"{itn} per thread on {th} threads",
+        "all_cores": {"value": itn * th / tn, "cores": th},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--workload", default="1080p_80x24_truecolor", choices=sorted(WORKLOADS))
+    ap.add_argument("--others", default="1080p_80x24_ansi256,4k_200x60_truecolor,4k_400x120_halfblock",
+                    help="comma list of extra workloads reported under other_workloads (N=1 only); '' = none")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--variant", type=int, default=-1)
+    args = ap.parse_args()
+
+    import torch
+
+    from __graft_entry__ import load_package
+
+    pkg = load_package()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available() or pkg.lib().asciichat_hip_device_count() <= 0:
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (this path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as d
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        d.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist = d
+
+    res = run_workload(torch, pkg, args.workload, args.batch, args.steps, args.warmup, dist, seed=1234 + rank,
+                       variant=args.variant)
+    wall = res["wall_s"]
+    if dist is not None:
+        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    total_frames = args.batch * args.steps * world
+    value = total_frames / wall
+
+    kernel_ms = res["kernel_ms_event_pair"]
+    achieved = res["alg_bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9
+    line = {
+        "metric": "frames/sec, 1080p->80x24 truecolor (batch of independent client frames)",
+        "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8", "data": "synthetic (uniform-random RGB24 frames generated on device, resident in HBM)",
+        "config": {"workload": args.workload, "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+                   "src": f"{WORKLOADS[args.workload][0]}x{WORKLOADS[args.workload][1]}",
+                   "grid": f"{WORKLOADS[args.workload][2]}x{WORKLOADS[args.workload][3]}", "mode": res["mode"],
+                   "parallelism": f"frames sharded over {world} rank(s), no data-path collective",
+                   "kernel_variant": res["variant"]},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "alg_bytes_per_launch": res["alg_bytes_per_launch"], "kernel_ms": kernel_ms,
+                     "kernel_ms_back_to_back": res["kernel_ms_back_to_back"],
+                     "out_bytes_per_frame": res["out_bytes_per_frame"]},
+    }
+    if rank == 0 and world == 1:
+        if not args.no_cpu:
+            line["cpu_baseline"] = cpu_baseline(args.workload)
+        others = {}
+        for name in [s for s in args.others.split(",") if s]:
+            if name == args.workload:
+                continue
+            del res
+            torch.cuda.empty_cache()
+            b = args.batch
+            res = run_workload(torch, pkg, name, b, max(10, args.steps // 10), 3, None)
+            k = res["kernel_ms_event_pair"]
+            a = res["alg_bytes_per_launch"] / (k * 1e-3) / 1e9
+            others[name] = {"frames_per_s": b * res["steps"] / res["wall_s"], "kernel_ms": k,
+                            "out_bytes_per_frame": res["out_bytes_per_frame"], "roofline_GBps": a,
+                            "roofline_frac": a / HBM_PEAK_GBS, "kernel_variant": res["variant"]}
+        line["other_workloads"] = others
+    if rank == 0:
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,57 @@
+/*
+ * achip_host.h -- host-side (plain C, no GPU) planning logic of the render path: what the reference
+ * does around its hot loops before/after pixels are touched -- aspect fit, padding sizes, sampling
+ * ratios, glyph tables, mode dispatch, output bounds.  Shared by the C-ABI shim and the tests.
+ */
+#ifndef ACHIP_HOST_H
+#define ACHIP_HOST_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <sys/types.h>
+
+#include "achip_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* aspect_ratio(), lib/util/aspect_ratio.c:69-91 -- exported with the reference's own name & signature */
+void aspect_ratio(const ssize_t img_w, const ssize_t img_h, const ssize_t width, const ssize_t height,
+                  const bool stretch, ssize_t *out_width, ssize_t *out_height);
+
+/* build_utf8_luminance_cache + build_utf8_ramp64_cache (common.c:380-490) into the device layout.
+ * Returns 0, or -1 for a NULL/empty palette. */
+int achip_lut_build(const char *palette_chars, achip_lut_t *lut);
+
+/* image_print_with_capabilities dispatch (ascii.c:955-1002 + sgr.c:413-436, x86 SIMD_SUPPORT build).
+ * Returns the ACHIP_MODE_*, or -1 for TRUECOLOR+BACKGROUND (Floyd-Steinberg, serial: not on the GPU yet). */
+int achip_mode_from_caps(int color_level, int render_mode);
+
+/* Fill one frame descriptor the way ascii_convert_with_capabilities (ascii.c:194-387) sizes things:
+ * aspect fit BEFORE half-block doubling, padding only when use_aspect && wants_padding.
+ * Returns 0 on success, -1 where the reference returns NULL (bad dims, resized image > 3840x2160). */
+int achip_frame_setup(achip_frame_t *f, const uint8_t *src_dev, int src_w, int src_h, ssize_t width, ssize_t height,
+                      int render_mode, bool wants_padding, bool use_aspect, bool stretch);
+
+/* Descriptor for rendering an image as-is (image_print_* / rgb_to_*_halfblocks_scalar on an already sized image). */
+int achip_frame_identity(achip_frame_t *f, const uint8_t *src_dev, int w, int h);
+
+/* 16.16 nearest-neighbour ratio, image.c:293-294 */
+uint32_t achip_nn_ratio(int src, int dst);
+
+/* Upper bound (bytes, excluding the NUL) of one rendered frame; multiple of 16 when rounded by the caller. */
+size_t achip_out_bound(int mode, const achip_frame_t *f);
+
+/* calculate_optimal_grid_layout (src/server/stream.c:523-651) */
+void achip_grid_layout(const int *src_w, const int *src_h, int n, int term_w, int term_h, int *cols, int *rows);
+
+/* create_multi_source_composite geometry (stream.c:664-779): fills comp for n (<= 9 used) sources. */
+void achip_composite_setup(achip_composite_t *comp, const uint8_t *const *src_dev, const int *src_w, const int *src_h,
+                           int n, int term_w, int term_h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

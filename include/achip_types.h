@@ -1,0 +1,76 @@
+/*
+ * achip_types.h -- plain-C descriptor structs shared by the host shim (C), the HIP kernels and the
+ * tests.  "achip" = asciichat-hip.  Everything here is POD and lives in HBM (or pinned host memory)
+ * exactly as laid out below.
+ */
+#ifndef ACHIP_TYPES_H
+#define ACHIP_TYPES_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Render modes: one per reference renderer on the path (SURVEY.md section 8a rows PM..HM). */
+enum {
+  ACHIP_MODE_MONO = 0,    /* image_print                         foreground.c:27-138   */
+  ACHIP_MODE_TRUE_FG = 1, /* image_print_color (+ansi_rle_*)     foreground.c:195-308  */
+  ACHIP_MODE_256_FG = 2,  /* image_print_256color                foreground.c:433-509  */
+  ACHIP_MODE_16_FG = 3,   /* image_print_16color                 foreground.c:535-624  */
+  ACHIP_MODE_TRUE_BG = 4, /* image_print_color_background        background.c:17-84    */
+  ACHIP_MODE_HB_TRUE = 5, /* rgb_to_truecolor_halfblocks_scalar  halfblock.c:48-165    */
+  ACHIP_MODE_HB_256 = 6,  /* rgb_to_256color_halfblocks_scalar   halfblock.c:416-524   */
+  ACHIP_MODE_HB_16 = 7,   /* rgb_to_16color_halfblocks_scalar    halfblock.c:297-405   */
+  ACHIP_MODE_HB_MONO = 8, /* rgb_to_halfblocks_scalar            halfblock.c:184-286   */
+  ACHIP_MODE_COUNT = 9
+};
+
+/* One source of a pixel-space grid composite (create_multi_source_composite, src/server/stream.c:664-779). */
+typedef struct {
+  const uint8_t *src; /* RGB24, tightly packed; NULL = empty cell */
+  int32_t src_w, src_h;
+  int32_t src_stride;           /* bytes per source row (>= 3*src_w)          */
+  int32_t _pad0;
+  int32_t tile_w, tile_h;       /* contain-fitted size inside the cell        */
+  int32_t org_x, org_y;         /* canvas position of tile pixel (0,0)        */
+  uint32_t x_ratio, y_ratio;    /* 16.16 nearest-neighbour ratios src -> tile */
+} achip_comp_src_t;
+
+typedef struct {
+  int32_t canvas_w, canvas_h; /* W x 2H pixels */
+  int32_t cols, rows;
+  int32_t cell_w, cell_h;
+  int32_t n_src; /* <= 9 */
+  int32_t _pad;
+  achip_comp_src_t s[9];
+} achip_composite_t;
+
+/* One frame of a batch.  Sampling is the reference's nearest-neighbour rule (image.c:293-325):
+ * sx = min((x * x_ratio) >> 16, src_w - 1). */
+typedef struct {
+  const uint8_t *src;            /* RGB24 source frame (device-visible); ignored when comp != NULL */
+  const achip_composite_t *comp; /* optional: sample a virtual composite canvas instead of src     */
+  int32_t src_w, src_h;          /* source (or canvas) size in pixels                              */
+  int32_t out_w, out_h;          /* sampled size: text columns x pixel rows (2 per text row in half-block) */
+  int32_t pad_left, pad_top;     /* ascii_pad_frame_width / _height folded into the emission       */
+  uint32_t x_ratio, y_ratio;     /* ((src << 16) / out) + 1                                         */
+  int32_t src_stride;            /* bytes per source row; 0 = tightly packed (3*src_w)              */
+  int32_t _pad0;
+} achip_frame_t;
+
+/* Glyph tables of one palette (utf8_palette_cache_t restated, common.c:380-490).  A glyph is its
+ * UTF-8 bytes packed little-endian in a u32; its length follows from the lead byte. */
+typedef struct {
+  uint32_t glyph[256];  /* cache[Y]                 */
+  uint32_t glyph64[64]; /* cache64[i]               */
+  uint8_t ramp[64];     /* char_index_ramp[0..63]   */
+} achip_lut_t;
+
+#define ACHIP_LEN_OVERFLOW 0xFFFFFFFFu /* out_len[] value when a frame did not fit its slab slot */
+#define ACHIP_LEN_BADDESC 0xFFFFFFFEu  /* out_len[] value for an unsupported descriptor          */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

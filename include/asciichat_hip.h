@@ -1,0 +1,103 @@
+/*
+ * asciichat_hip.h -- C-ABI of libasciichat_hip.so, the MI355X-native image->ASCII render path.
+ *
+ * Two layers are exported by the same shared object:
+ *
+ *  (1) the DROP-IN layer, declared in asciichat_render.h: the reference's own libasciichat render
+ *      entry points (ascii_convert, ascii_convert_with_capabilities, image_print_*, rgb_to_*_halfblocks_*,
+ *      ascii_create_grid, image_*, buffer_pool_*) with identical C signatures, ownership and NULL/error
+ *      behaviour.  Each call runs a 1-frame batch on the GPU.
+ *
+ *  (2) the BATCH layer below (additive, not in the reference): a plan object renders N independent
+ *      frames per launch from device-resident RGB24 into an HBM slab.  This is what a server with many
+ *      clients binds instead of calling ascii_convert_with_capabilities once per client per tick
+ *      (reference call site: src/server/stream.c:841, one call per client render thread).
+ *
+ * Plain C, plain pointers and sizes; `stream` arguments are hipStream_t passed as void* (NULL = the
+ * null stream).  All functions return an asciichat_error_t-compatible int: 0 = ASCIICHAT_OK
+ * (include/ascii-chat/common/error_codes.h:51-109 in the reference).
+ *
+ * The library has no CPU fallback: without a visible gfx950 device every compute entry point fails
+ * with ASCIICHAT_HIP_ERR_NO_DEVICE and prints the reason to stderr.
+ */
+#ifndef ASCIICHAT_HIP_H
+#define ASCIICHAT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "achip_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* error codes shared with the drop-in layer (values = the reference's asciichat_error_t) */
+enum {
+  ASCIICHAT_HIP_OK = 0,
+  ASCIICHAT_HIP_ERR_MEMORY = 3,         /* ERROR_MEMORY        */
+  ASCIICHAT_HIP_ERR_NOT_SUPPORTED = 30, /* ERROR_NOT_SUPPORTED */
+  ASCIICHAT_HIP_ERR_BUFFER = 81,        /* ERROR_BUFFER        */
+  ASCIICHAT_HIP_ERR_INVALID_STATE = 85, /* ERROR_INVALID_STATE */
+  ASCIICHAT_HIP_ERR_INVALID_PARAM = 86, /* ERROR_INVALID_PARAM */
+  ASCIICHAT_HIP_ERR_NO_DEVICE = 200,    /* no HIP device / HIP runtime failure (new) */
+};
+
+typedef struct asciichat_hip_plan asciichat_hip_plan_t;
+
+/* Number of visible HIP devices (0 when there is none); never fails. */
+int asciichat_hip_device_count(void);
+
+/* Last error message of the calling thread ("" when none). */
+const char *asciichat_hip_last_error(void);
+
+/*
+ * Create a plan for `n_frames` frames rendered in `mode` (ACHIP_MODE_*, achip_types.h) with the glyph
+ * palette `palette_chars` (UTF-8; what the reference passes as palette_chars / client_palette_chars).
+ * `frames` is a HOST array; the src/comp pointers inside must be device-visible.  Use
+ * achip_frame_setup()/achip_frame_identity() (achip_host.h, also exported) to fill descriptors exactly
+ * as ascii_convert_with_capabilities sizes them.
+ */
+int asciichat_hip_plan_create(asciichat_hip_plan_t **plan, int mode, const char *palette_chars,
+                              const achip_frame_t *frames, int n_frames);
+
+/* Replace the frame descriptors (e.g. new source pointers for the next tick); same n_frames. */
+int asciichat_hip_plan_update(asciichat_hip_plan_t *plan, const achip_frame_t *frames, void *stream);
+
+/* Bytes each frame needs in the output slab (worst case incl. NUL, multiple of 16). */
+size_t asciichat_hip_plan_out_stride(const asciichat_hip_plan_t *plan);
+
+/* Kernel geometry: -1 = automatic (by widest padded row), else a variant id from render_variants.h. */
+int asciichat_hip_plan_set_variant(asciichat_hip_plan_t *plan, int variant);
+int asciichat_hip_plan_get_variant(const asciichat_hip_plan_t *plan);
+
+/*
+ * Render all frames: frame i's bytes go to out_dev + i*out_stride (16-byte aligned base, stride a
+ * multiple of 16, >= plan_out_stride), its length to out_len_dev[i] (ACHIP_LEN_OVERFLOW /
+ * ACHIP_LEN_BADDESC on error).  Asynchronous on `stream`; inputs must already be resident.
+ */
+int asciichat_hip_plan_render(asciichat_hip_plan_t *plan, uint8_t *out_dev, size_t out_stride, uint32_t *out_len_dev,
+                              void *stream);
+
+/* Render only frames [first, first+count) of the plan (multi-GPU sharding of one logical batch). */
+int asciichat_hip_plan_render_range(asciichat_hip_plan_t *plan, int first, int count, uint8_t *out_dev,
+                                    size_t out_stride, uint32_t *out_len_dev, void *stream);
+
+void asciichat_hip_plan_destroy(asciichat_hip_plan_t *plan);
+
+/* image_resize on device memory: nearest-neighbour, lib/video/rgba/image.c:267-328 */
+int asciichat_hip_resize(const uint8_t *src_dev, int src_w, int src_h, uint8_t *dst_dev, int dst_w, int dst_h,
+                         void *stream);
+
+/* Materialise the W x 2H pixel-space grid composite (src/server/stream.c:664-779) on device.
+ * comp_host is filled by achip_composite_setup(); dst_dev holds canvas_w*canvas_h*3 bytes. */
+int asciichat_hip_composite(const achip_composite_t *comp_host, uint8_t *dst_dev, void *stream);
+
+/* Upload a composite descriptor for use as achip_frame_t.comp; free with asciichat_hip_free. */
+int asciichat_hip_composite_upload(const achip_composite_t *comp_host, achip_composite_t **comp_dev);
+void asciichat_hip_free(void *dev_ptr);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,89 @@
+"""Builds and drives the CPU fiber emulation of the HIP kernels (tests/hipemu). TESTS ONLY."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from achip_ctypes import Composite, Frame, Lut, bind_host
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "ascii-chat_amd", "csrc")
+INC = os.path.join(ROOT, "include")
+EMU_DIR = os.path.join(ROOT, "tests", "hipemu")
+EMU_SO = os.path.join(EMU_DIR, "_build", "libachip_emu.so")
+
+_lib = None
+
+
+def build():
+    srcs = [os.path.join(EMU_DIR, "emu_driver.cpp"), os.path.join(EMU_DIR, "hip_emu.h"),
+            os.path.join(CSRC, "render_kernels.hpp"), os.path.join(CSRC, "render_variants.h"),
+            os.path.join(INC, "achip_types.h"), os.path.join(CSRC, "achip_host.c"), os.path.join(INC, "achip_host.h")]
+    if os.path.exists(EMU_SO) and all(os.path.getmtime(s) <= os.path.getmtime(EMU_SO) for s in srcs):
+        return EMU_SO
+    os.makedirs(os.path.dirname(EMU_SO), exist_ok=True)
+    obj = os.path.join(os.path.dirname(EMU_SO), "achip_host.o")
+    subprocess.check_call(["gcc", "-std=gnu11", "-O2", "-fPIC", "-I" + INC, "-c", os.path.join(CSRC, "achip_host.c"), "-o", obj])
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-shared", "-fPIC", "-I" + CSRC, "-I" + INC, "-I" + EMU_DIR,
+                           os.path.join(EMU_DIR, "emu_driver.cpp"), obj, "-o", EMU_SO])
+    return EMU_SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = bind_host(C.CDLL(build()))
+        _lib.emu_render_batch.restype = C.c_int
+        _lib.emu_render_batch.argtypes = [C.c_int, C.c_int, C.POINTER(Frame), C.c_int, C.POINTER(Lut), C.c_void_p,
+                                          C.c_uint64, C.c_void_p]
+        _lib.emu_resize_nn.restype = None
+        _lib.emu_resize_nn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_uint32,
+                                       C.c_uint32]
+        _lib.emu_composite.restype = None
+        _lib.emu_composite.argtypes = [C.POINTER(Composite), C.c_void_p]
+    return _lib
+
+
+def make_lut(palette):
+    lut = Lut()
+    p = palette.encode("utf-8") if isinstance(palette, str) else palette
+    assert lib().achip_lut_build(p, C.byref(lut)) == 0
+    return lut
+
+
+def render_frames(mode, frames, palette, variant=0, stride=None):
+    """frames: ctypes array/list of Frame (src pointers = host numpy memory). Returns list of bytes / int codes."""
+    L = lib()
+    n = len(frames)
+    arr = (Frame * n)(*frames)
+    lut = make_lut(palette)
+    if stride is None:
+        stride = max(int(L.achip_out_bound(mode, C.byref(arr[i]))) for i in range(n))
+        stride = (stride + 1 + 15) // 16 * 16
+    out = np.full(n * stride + 64, 0xEE, dtype=np.uint8)
+    # 16-byte align the slab like hipMalloc would
+    base = (out.ctypes.data + 15) // 16 * 16
+    ln = np.zeros(n, dtype=np.uint32)
+    rc = L.emu_render_batch(mode, variant, arr, n, C.byref(lut), base, stride, ln.ctypes.data)
+    assert rc == 0
+    res = []
+    for i in range(n):
+        if ln[i] >= 0xFFFFFFF0:
+            res.append(int(ln[i]))
+        else:
+            res.append(C.string_at(base + i * stride, int(ln[i])))
+    return res
+
+
+def frame_for_convert(img, width, height, render_mode, wants_padding=False, use_aspect=False, stretch=False):
+    f = Frame()
+    rc = lib().achip_frame_setup(C.byref(f), img.ctypes.data, img.shape[1], img.shape[0], width, height, render_mode,
+                                 wants_padding, use_aspect, stretch)
+    return f if rc == 0 else None
+
+
+def frame_identity(img):
+    f = Frame()
+    assert lib().achip_frame_identity(C.byref(f), img.ctypes.data, img.shape[1], img.shape[0]) == 0
+    return f

@@ -1,0 +1,59 @@
+/*
+ * emu_driver.cpp -- runs the product kernels (render_kernels.hpp, unmodified) under the CPU fiber
+ * emulator.  TESTS ONLY; built by tests/emu.py with g++ -DACHIP_HIPEMU.
+ */
+#define ACHIP_HIPEMU 1
+#include "render_kernels.hpp"
+#include "render_variants.h"
+
+template <int MODE, int BLOCK, int CAP, int RING>
+static void run(const achip_frame_t *frames, int n, const achip_lut_t *lut, uint8_t *out, uint64_t stride,
+                uint32_t *len) {
+  using L = achip::Lds<MODE, BLOCK, CAP, RING>;
+  hipemu::launch(dim3((unsigned)n), dim3(BLOCK), (size_t)L::bytes, [&] {
+    achip::render_frames_kernel<MODE, BLOCK, CAP, RING>(frames, lut, out, stride, len, n);
+  });
+}
+
+template <int BLOCK, int CAP, int RING>
+static int by_mode(int mode, const achip_frame_t *frames, int n, const achip_lut_t *lut, uint8_t *out, uint64_t stride,
+                   uint32_t *len) {
+  switch (mode) {
+#define M(m)                                                                                                           \
+  case m:                                                                                                              \
+    run<m, BLOCK, CAP, RING>(frames, n, lut, out, stride, len);                                                        \
+    return 0;
+    M(ACHIP_MODE_MONO)
+    M(ACHIP_MODE_TRUE_FG)
+    M(ACHIP_MODE_256_FG)
+    M(ACHIP_MODE_16_FG)
+    M(ACHIP_MODE_TRUE_BG)
+    M(ACHIP_MODE_HB_TRUE)
+    M(ACHIP_MODE_HB_256)
+    M(ACHIP_MODE_HB_16)
+    M(ACHIP_MODE_HB_MONO)
+#undef M
+  }
+  return -1;
+}
+
+extern "C" int emu_render_batch(int mode, int variant, const achip_frame_t *frames, int n, const achip_lut_t *lut,
+                                uint8_t *out, uint64_t stride, uint32_t *len) {
+  switch (variant) {
+#define X(id, B, C, R)                                                                                                 \
+  case id:                                                                                                             \
+    return by_mode<B, C, R>(mode, frames, n, lut, out, stride, len);
+    ACHIP_VARIANTS(X)
+#undef X
+  }
+  return -1;
+}
+
+extern "C" void emu_resize_nn(const uint8_t *src, int sw, int sh, uint8_t *dst, int dw, int dh, uint32_t xr,
+                              uint32_t yr) {
+  hipemu::launch(dim3(3), dim3(256), 0, [&] { achip::resize_nn_kernel(src, sw, sh, 3 * sw, dst, dw, dh, xr, yr); });
+}
+
+extern "C" void emu_composite(const achip_composite_t *comp, uint8_t *dst) {
+  hipemu::launch(dim3(2), dim3(256), 0, [&] { achip::composite_kernel(comp, dst); });
+}

@@ -1,0 +1,195 @@
+"""-m gpu: the reference's own entry points (asciichat_render.h) exported by libasciichat_hip.so."""
+import ctypes as C
+import os
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import orc  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def api():
+    import torch  # noqa: F401  (loads the HIP runtime first)
+
+    from __graft_entry__ import load_package
+
+    pkg = load_package()
+    assert pkg.lib().asciichat_hip_device_count() > 0
+    return pkg
+
+
+def as_image(pkg, arr):
+    arr = np.ascontiguousarray(arr, dtype=np.uint8)
+    im = pkg.Image(arr.shape[1], arr.shape[0], arr.ctypes.data, 0)
+    im._keep = arr
+    return im
+
+
+def caps(pkg, color_level, render_mode, wants_padding=False):
+    c = pkg.TermCaps()
+    c.color_level = color_level
+    c.render_mode = render_mode
+    c.wants_padding = wants_padding
+    c.utf8_support = True
+    return c
+
+
+TORTURE = orc.frame_torture()
+PAL = orc.PALETTE_STANDARD.encode()
+
+
+def test_ascii_convert_with_capabilities_matrix(api):
+    L = api.lib()
+    im = as_image(api, TORTURE)
+    for cl in (0, 1, 2, 3):
+        for rm in (0, 2):
+            for (aspect, pad) in ((False, False), (True, True), (True, False)):
+                c = caps(api, cl, rm, pad)
+                got = api.take_string(L.ascii_convert_with_capabilities(C.byref(im), 97, 31, C.byref(c), aspect, False, PAL))
+                exp = orc.convert_with_caps(TORTURE, 97, 31, cl, rm, pad, aspect, False)
+                assert got == exp, (cl, rm, aspect, pad)
+
+
+def test_config1_ascii_convert_mono_640x480(api):
+    """BASELINE configs[0]: single 640x480 frame -> 80x24 monochrome via ascii_convert (host.c:696 call shape)."""
+    L = api.lib()
+    g = orc.frame_anchor_gradient()
+    im = as_image(api, g)
+    lum = C.create_string_buffer(b"x" * 255, 256)
+    got = api.take_string(L.ascii_convert(C.byref(im), 80, 24, False, False, False, PAL, lum))
+    assert len(got) == 1635 and orc.fnv1a32(got) == 0xCEFD0A18  # SURVEY 8(c) anchor of the reference's output
+    for color, mode_opt in ((True, 0), (True, 2), (False, 0)):
+        L.asciichat_hip_set_option_render_mode(mode_opt)
+        for aspect in (False, True):
+            got = api.take_string(L.ascii_convert(C.byref(im), 80, 24, color, aspect, False, PAL, lum))
+            assert got == orc.convert(g, 80, 24, color, aspect, False, orc.PALETTE_STANDARD, mode_opt), (color, mode_opt, aspect)
+    L.asciichat_hip_set_option_render_mode(0)
+
+
+def test_null_and_error_conditions(api):
+    L = api.lib()
+    im = as_image(api, TORTURE)
+    c = caps(api, 3, 0)
+    lum = C.create_string_buffer(b"x" * 255, 256)
+    # ascii.c:75-84, 198-212; tests/unit/video/ascii_test.c:118-156, 741-765
+    assert not L.ascii_convert(None, 80, 24, False, False, False, PAL, lum)
+    assert not L.ascii_convert(C.byref(im), 80, 24, False, False, False, None, lum)
+    assert not L.ascii_convert(C.byref(im), 80, 24, False, False, False, b"", lum)
+    assert not L.ascii_convert(C.byref(im), 0, 24, False, False, False, PAL, lum)
+    assert not L.ascii_convert_with_capabilities(None, 80, 24, C.byref(c), False, False, PAL)
+    assert not L.ascii_convert_with_capabilities(C.byref(im), 80, 24, None, False, False, PAL)
+    assert not L.ascii_convert_with_capabilities(C.byref(im), 0, 0, C.byref(c), False, False, PAL)
+    assert not L.ascii_convert_with_capabilities(C.byref(im), 5000, 24, C.byref(c), False, False, PAL)  # > 3840 wide
+    bad = api.Image(0, 10, im.pixels, 0)
+    assert not L.ascii_convert_with_capabilities(C.byref(bad), 80, 24, C.byref(c), False, False, PAL)
+    assert not L.image_print(None, PAL)
+    assert not L.image_print_with_capabilities(C.byref(im), None, PAL)
+    # TRUECOLOR + BACKGROUND dispatches to the Floyd-Steinberg renderer: explicit "not supported", never a wrong answer
+    cb = caps(api, 3, 1)
+    assert not L.ascii_convert_with_capabilities(C.byref(im), 80, 24, C.byref(cb), False, False, PAL)
+    assert b"not implemented" in L.asciichat_hip_last_error()
+    # halfblock.c:50-51: non-positive dims -> empty string, not NULL
+    assert api.take_string(L.rgb_to_truecolor_halfblocks_scalar(im.pixels, 0, 5, 0)) == b""
+
+
+def test_image_print_family_and_halfblocks(api):
+    L = api.lib()
+    small = orc.resize_nn(TORTURE, 61, 23)  # odd height: last half-block row duplicates the top row
+    im = as_image(api, small)
+    for fn, (cl, rm) in (("image_print", (0, 0)), ("image_print_color", (3, 0)), ("image_print_256color", (2, 0)),
+                         ("image_print_16color", (1, 0))):
+        got = api.take_string(getattr(L, fn)(C.byref(im), PAL))
+        assert got == orc.print_with_caps(small, cl, rm), fn
+    assert api.take_string(L.image_print_color_background(C.byref(im), PAL)) == orc.print_truecolor_bg(small)
+    for cl in (0, 1, 2, 3):
+        c = caps(api, cl, 2)
+        got = api.take_string(L.image_print_with_capabilities(C.byref(im), C.byref(c), PAL))
+        assert got == orc.print_with_caps(small, cl, 2), cl
+    # explicit row stride: render the left 40 columns of the 61-wide image
+    got = api.take_string(L.rgb_to_truecolor_halfblocks_scalar(im.pixels, 40, 23, 61 * 3))
+    assert got == orc.print_with_caps(np.ascontiguousarray(small[:, :40]), 3, 2)
+
+
+def test_pool_images_are_read_in_place(api):
+    """image_new_from_pool() frames (> 4 MiB) come from the pinned, device-mapped class: zero-copy source."""
+    L = api.lib()
+    img = orc.frame_hash_noise(1920, 1080, 5)
+    p = L.image_new_from_pool(1920, 1080)
+    assert p and p.contents.alloc_method == 1
+    assert L.buffer_pool_is_pinned(p.contents.pixels)
+    assert L.buffer_pool_pinned_blocks(None) >= 1
+    C.memmove(p.contents.pixels, img.ctypes.data, img.nbytes)
+    for cl, rm in ((3, 0), (2, 0), (3, 2)):
+        c = caps(api, cl, rm, True)
+        got = api.take_string(L.ascii_convert_with_capabilities(p, 80, 24, C.byref(c), True, False, PAL))
+        assert got == orc.convert_with_caps(img, 80, 24, cl, rm, True, True, False)
+    # image_resize: pool -> pool and pool -> malloc'd image
+    d1 = L.image_new_from_pool(1600, 1000)  # > 4 MiB -> pinned destination
+    d2 = L.image_new(53, 30)
+    L.image_resize(p, d1)
+    L.image_resize(p, d2)
+    a1 = np.frombuffer(C.string_at(d1.contents.pixels, 1600 * 1000 * 3), np.uint8).reshape(1000, 1600, 3)
+    a2 = np.frombuffer(C.string_at(d2.contents.pixels, 53 * 30 * 3), np.uint8).reshape(30, 53, 3)
+    assert np.array_equal(a1, orc.resize_nn(img, 1600, 1000))
+    assert np.array_equal(a2, orc.resize_nn(img, 53, 30))
+    L.image_destroy_to_pool(d1)
+    L.image_destroy(d2)
+    L.image_destroy(p)  # pool-allocated images may also be released through image_destroy (image.c:86-125)
+    # the block is recycled, not freed
+    q = L.image_new_from_pool(1920, 1080)
+    assert L.buffer_pool_is_pinned(q.contents.pixels)
+    L.image_destroy_to_pool(q)
+    small = L.buffer_pool_alloc(None, 1000)
+    assert small and not L.buffer_pool_is_pinned(small)
+    L.buffer_pool_free(None, small, 1000)
+
+
+def test_concurrent_render_threads(api):
+    """One render thread per client (src/server/render.c:1233): the drop-in layer is re-entrant."""
+    L = api.lib()
+    imgs = [orc.frame_hash_noise(640, 360, 100 + i) for i in range(6)]
+    exp = [orc.convert_with_caps(im, 80, 24, 3, 0) for im in imgs]
+    errors = []
+
+    def worker(k):
+        im = as_image(api, imgs[k])
+        c = caps(api, 3, 0)
+        for _ in range(20):
+            got = api.take_string(L.ascii_convert_with_capabilities(C.byref(im), 80, 24, C.byref(c), False, False, PAL))
+            if got != exp[k]:
+                errors.append(k)
+                return
+
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(6)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors
+
+
+def test_grid_and_padding_host_utilities(api):
+    L = api.lib()
+    img = orc.frame_anchor_gradient()
+    frames = [orc.convert(img, 39 + i, 15, False, False, False) for i in range(9)]
+    for n, (w, h) in ((9, (160, 48)), (4, (160, 48)), (2, (80, 24)), (3, (120, 40)), (5, (200, 60)), (1, (80, 24)),
+                      (2, (60, 40)), (9, (80, 24))):
+        arr = (api.FrameSource * n)()
+        for i in range(n):
+            arr[i].frame_data = frames[i]
+            arr[i].frame_size = len(frames[i])
+        sz = C.c_size_t()
+        p = L.ascii_create_grid(arr, n, w, h, C.byref(sz))
+        got = C.string_at(p, sz.value)
+        L.free(p)
+        assert got == orc.create_grid(frames[:n], w, h), (n, w, h)
+    assert api.take_string(L.ascii_pad_frame_width(b"ab\ncd", 3)) == b"   ab\n   cd"
+    assert api.take_string(L.ascii_pad_frame_height(b"ab\ncd", 2)) == b"\n\nab\ncd"
+    assert L.rgb_to_16color(255, 0, 0) == 9 and L.rgb_to_256color(10, 10, 10) == 232
+    assert L.rep_is_profitable(6) and not L.rep_is_profitable(5)

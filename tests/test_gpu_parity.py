@@ -1,0 +1,259 @@
+"""-m gpu: the HIP path, called through the C-ABI of libasciichat_hip.so, must be byte-identical to the
+oracle (integer pipeline: the bar is bit-exact).  Small cases are compared in full; BASELINE.json's
+full-size batches are compared on a sample of frames plus size-independent properties."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import orc  # noqa: E402
+from achip_ctypes import ALL_MODES, MODE_CAPS, MODE_NAMES, MODE_TRUE_BG  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+
+    from __graft_entry__ import load_package
+
+    pkg = load_package()
+    assert torch.cuda.is_available(), "these tests need a GPU"
+    assert pkg.lib().asciichat_hip_device_count() > 0, "libasciichat_hip.so sees no HIP device"
+    torch.cuda.set_device(0)
+    return pkg, torch
+
+
+def oracle_convert(img, mode, W, H, palette, wants_padding=False, use_aspect=False):
+    if mode == MODE_TRUE_BG:
+        return orc.print_truecolor_bg(orc.resize_nn(img, W, H), palette)
+    cl, rm = MODE_CAPS[mode]
+    return orc.convert_with_caps(img, W, H, cl, rm, wants_padding, use_aspect, False, palette)
+
+
+def render_batch(gpu, mode, imgs, W, H, palette=orc.PALETTE_STANDARD, wants_padding=False, use_aspect=False,
+                 variant=-1, dims=None):
+    """imgs: list of HxWx3 uint8 numpy arrays -> list of bytes via the batch C-ABI."""
+    pkg, torch = gpu
+    rm = MODE_CAPS.get(mode, (3, 0))[1]
+    dev = [torch.from_numpy(np.ascontiguousarray(i)).cuda() for i in imgs]
+    frames = []
+    for k, (i, d) in enumerate(zip(imgs, dev)):
+        w, h = (W, H) if dims is None else dims[k]
+        f = pkg.frame_setup(d.data_ptr(), i.shape[1], i.shape[0], w, h, rm, wants_padding, use_aspect, False)
+        assert f is not None
+        frames.append(f)
+    plan = pkg.Plan(mode, palette, frames)
+    if variant >= 0:
+        plan.set_variant(variant)
+    out = torch.full((len(imgs) * plan.stride,), 0xEE, dtype=torch.uint8, device="cuda")
+    ln = torch.zeros(len(imgs), dtype=torch.int32, device="cuda")
+    plan.render(out.data_ptr(), plan.stride, ln.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    host = out.cpu().numpy()
+    lens = ln.cpu().numpy().astype(np.uint32)
+    res = []
+    for k in range(len(imgs)):
+        assert lens[k] < 0xFFFFFFF0, f"frame {k}: kernel error code {lens[k]:#x}"
+        res.append(host[k * plan.stride:k * plan.stride + int(lens[k])].tobytes())
+        assert host[k * plan.stride + int(lens[k])] == 0  # NUL after the frame
+    plan.close()
+    return res
+
+
+TORTURE = orc.frame_torture()
+
+
+@pytest.mark.parametrize("mode", ALL_MODES, ids=MODE_NAMES)
+def test_torture_all_modes_all_variants(gpu, mode):
+    for variant in (2, 1, 0, 3):
+        for (W, H) in [(80, 24), (97, 31), (200, 60)]:
+            if variant == 3 and W > 200:
+                continue
+            got = render_batch(gpu, mode, [TORTURE], W, H, variant=variant)[0]
+            assert got == oracle_convert(TORTURE, mode, W, H, orc.PALETTE_STANDARD), (MODE_NAMES[mode], variant, W, H)
+
+
+@pytest.mark.parametrize("mode", [m for m in ALL_MODES if m != MODE_TRUE_BG],
+                         ids=[MODE_NAMES[m] for m in ALL_MODES if m != MODE_TRUE_BG])
+def test_aspect_and_padding(gpu, mode):
+    for (W, H) in [(80, 24), (97, 31), (60, 40), (300, 20)]:
+        got = render_batch(gpu, mode, [TORTURE], W, H, wants_padding=True, use_aspect=True)[0]
+        assert got == oracle_convert(TORTURE, mode, W, H, orc.PALETTE_STANDARD, True, True), (MODE_NAMES[mode], W, H)
+
+
+@pytest.mark.parametrize("palette", [orc.PALETTE_BLOCKS, orc.PALETTE_COOL, orc.PALETTE_DIGITAL, orc.PALETTE_MINIMAL,
+                                     "ab", "x", "é漢😀 ."], ids=["blocks", "cool", "digital", "minimal", "ab", "x", "mixed"])
+def test_palettes(gpu, palette):
+    for mode in (0, 1, 2, 3, 4):
+        got = render_batch(gpu, mode, [TORTURE], 61, 17, palette)[0]
+        assert got == oracle_convert(TORTURE, mode, 61, 17, palette), MODE_NAMES[mode]
+
+
+def test_survey_anchor_through_gpu(gpu):
+    """The SURVEY 8(c) reference-output anchors, reproduced by the GPU path itself."""
+    g = orc.frame_anchor_gradient()
+    for mode, (length, fnv) in {2: (22255, 0xBE60A438), 1: (35852, 0x885DA51D), 5: (73802, 0x362719AD)}.items():
+        got = render_batch(gpu, mode, [g], 80, 24)[0]
+        assert len(got) == length and orc.fnv1a32(got) == fnv
+    got = render_batch(gpu, 0, [g], 80, 24, wants_padding=True, use_aspect=True)[0]
+    assert len(got) == 1721 and orc.fnv1a32(got) == 0x7D62F78F
+
+
+def test_synthetic_inputs_mixed_batch(gpu):
+    """S-noise / S-smooth / S-bars / S-gray in one ragged batch: different source sizes per frame."""
+    imgs = [orc.frame_noise(320, 240, 12345), orc.frame_smooth(640, 480), orc.frame_bars(480, 270, 4),
+            orc.frame_gray(200, 100), orc.frame_bars(333, 77, 1), np.zeros((50, 70, 3), np.uint8),
+            np.full((9, 9, 3), 255, np.uint8), orc.frame_noise(17, 5, 99)]
+    for mode in ALL_MODES:
+        got = render_batch(gpu, mode, imgs, 80, 24)
+        for k, im in enumerate(imgs):
+            assert got[k] == oracle_convert(im, mode, 80, 24, orc.PALETTE_STANDARD), (MODE_NAMES[mode], k)
+
+
+def test_ragged_output_sizes_and_edges(gpu):
+    """Per-frame output dims differ inside one batch; 1x1 outputs; a row as wide as the largest chunk."""
+    img = orc.frame_hash_noise(97, 41, 3)
+    dims = [(1, 1), (2, 1), (1, 2), (80, 24), (3, 50), (500, 3), (1024, 2), (2048, 2), (3840, 2)]
+    for mode in (0, 1, 5, 6, 8):
+        got = render_batch(gpu, mode, [img] * len(dims), 0, 0, dims=dims)
+        for k, (w, h) in enumerate(dims):
+            exp = oracle_convert(img, mode, w, h, orc.PALETTE_STANDARD)
+            if exp is None:  # resized image would exceed 3840x2160: the reference returns NULL
+                continue
+            assert got[k] == exp, (MODE_NAMES[mode], w, h)
+
+
+def test_overflow_and_bad_descriptor_are_reported(gpu):
+    pkg, torch = gpu
+    img = torch.from_numpy(orc.frame_noise(64, 64, 5)).cuda()
+    f = pkg.frame_setup(img.data_ptr(), 64, 64, 40, 12, 0)
+    plan = pkg.Plan(1, orc.PALETTE_STANDARD, [f])
+    out = torch.zeros(plan.stride, dtype=torch.uint8, device="cuda")
+    ln = torch.zeros(1, dtype=torch.int32, device="cuda")
+    with pytest.raises(RuntimeError):  # stride below the plan's bound is refused on the host
+        plan.render(out.data_ptr(), 64, ln.data_ptr())
+    with pytest.raises(RuntimeError):  # unaligned slab
+        plan.render(out.data_ptr() + 4, plan.stride, ln.data_ptr())
+    plan.close()
+    bad = pkg.Frame()
+    with pytest.raises(RuntimeError):
+        pkg.Plan(1, orc.PALETTE_STANDARD, [bad])
+    with pytest.raises(RuntimeError):
+        pkg.Plan(1, "", [f])
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE.json full-size configurations
+# ------------------------------------------------------------------------------------------------
+FULL = [
+    ("K2 1080p->80x24 ANSI-256 b256", 1920, 1080, 80, 24, 2, 256, 6),
+    ("K2' 1080p->80x24 truecolor b256", 1920, 1080, 80, 24, 1, 256, 6),
+    ("K3 4K->200x60 truecolor b256", 3840, 2160, 200, 60, 1, 256, 4),
+    ("K5 4K->400x120 half-block truecolor b64", 3840, 2160, 400, 120, 5, 64, 3),
+]
+
+
+@pytest.mark.parametrize("name,sw,sh,W,H,mode,batch,nsample", FULL, ids=[f[0].split()[0] for f in FULL])
+def test_full_size_batches(gpu, name, sw, sh, W, H, mode, batch, nsample):
+    pkg, torch = gpu
+    g = torch.Generator(device="cuda")
+    g.manual_seed(42)
+    frames_t = torch.randint(0, 256, (batch, sh, sw, 3), dtype=torch.uint8, device="cuda", generator=g)
+    # make some frames run-heavy / transparent-heavy instead of pure noise
+    frames_t[1] = torch.from_numpy(orc.frame_bars(sw, sh, 6)).cuda()
+    frames_t[2] = torch.from_numpy(orc.frame_smooth(sw, sh)).cuda()
+    frames_t[3] = 0
+    frames_t[4] = frames_t[0]  # duplicate input -> identical output (determinism / no cross-frame leakage)
+    rm = MODE_CAPS[mode][1]
+    descs = [pkg.frame_setup(frames_t.data_ptr() + i * sh * sw * 3, sw, sh, W, H, rm) for i in range(batch)]
+    plan = pkg.Plan(mode, orc.PALETTE_STANDARD, descs)
+    out = torch.zeros(batch * plan.stride, dtype=torch.uint8, device="cuda")
+    ln = torch.zeros(batch, dtype=torch.int32, device="cuda")
+    plan.render(out.data_ptr(), plan.stride, ln.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    lens = ln.cpu().numpy().astype(np.uint32)
+    assert (lens < 0xFFFFFFF0).all()
+    rows = H
+    check = sorted(set([0, 1, 2, 3, 4, batch - 1] + list(range(5, 5 + nsample))))
+    outs = {}
+    for k in check:
+        got = out[k * plan.stride:k * plan.stride + int(lens[k])].cpu().numpy().tobytes()
+        outs[k] = got
+        img = frames_t[k].cpu().numpy()
+        assert got == oracle_convert(img, mode, W, H, orc.PALETTE_STANDARD), (name, k)
+    assert outs[0] == outs[4]
+    # size-independent properties on EVERY frame of the batch
+    host = out.cpu().numpy().reshape(batch, plan.stride)
+    for k in range(batch):
+        fr = host[k, :int(lens[k])]
+        assert int((fr == 10).sum()) == rows - 1, (name, k)          # one newline between text rows, none after
+        assert fr[-4:].tobytes() == b"\033[0m", (name, k)              # colour modes end in a reset
+        assert host[k, int(lens[k])] == 0
+    # re-render is idempotent
+    out2 = torch.zeros_like(out)
+    plan.render(out2.data_ptr(), plan.stride, ln.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)
+    plan.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# pixel-space composite (K4) and stand-alone resize
+# ------------------------------------------------------------------------------------------------
+def _composite(pkg, torch, imgs, tw, th):
+    dev = [torch.from_numpy(np.ascontiguousarray(i)).cuda() for i in imgs]
+    n = len(imgs)
+    ptrs = (C.c_void_p * n)(*[d.data_ptr() for d in dev])
+    ws = (C.c_int * n)(*[i.shape[1] for i in imgs])
+    hs = (C.c_int * n)(*[i.shape[0] for i in imgs])
+    comp = pkg.Composite()
+    pkg.lib().achip_composite_setup(C.byref(comp), ptrs, ws, hs, n, tw, th)
+    return comp, dev
+
+
+def test_grid9_composite_fused_and_materialised(gpu):
+    pkg, torch = gpu
+    imgs = [orc.frame_hash_noise(1920, 1080, 10 + i) if i % 2 else orc.frame_bars(1920, 1080, i) for i in range(9)]
+    comp, keep = _composite(pkg, torch, imgs, 160, 48)
+    assert (comp.cols, comp.rows, comp.cell_w, comp.cell_h) == (3, 3, 53, 32)
+    ref_canvas = orc.composite(imgs, 160, 48)
+    # materialised canvas
+    dst = torch.zeros(96 * 160 * 3, dtype=torch.uint8, device="cuda")
+    assert pkg.lib().asciichat_hip_composite(C.byref(comp), dst.data_ptr(), None) == 0
+    assert np.array_equal(dst.cpu().numpy().reshape(96, 160, 3), ref_canvas)
+    # fused: render straight from the nine sources, canvas never built (convert_composite_to_ascii, stream.c:790-854)
+    comp_dev = C.c_void_p()
+    assert pkg.lib().asciichat_hip_composite_upload(C.byref(comp), C.byref(comp_dev)) == 0
+    for mode in (1, 5, 2, 0):
+        cl, rm = MODE_CAPS[mode]
+        h = 96 if rm == 2 else 48  # stream.c:831
+        f = pkg.frame_setup(None, 160, 96, 160, h, rm, True, True, False)
+        f.comp = comp_dev.value
+        plan = pkg.Plan(mode, orc.PALETTE_STANDARD, [f])
+        out = torch.zeros(plan.stride, dtype=torch.uint8, device="cuda")
+        ln = torch.zeros(1, dtype=torch.int32, device="cuda")
+        plan.render(out.data_ptr(), plan.stride, ln.data_ptr())
+        torch.cuda.synchronize()
+        got = out[:int(ln[0].item())].cpu().numpy().tobytes()
+        exp = orc.convert_with_caps(ref_canvas, 160, h, cl, rm, True, True, False)
+        assert got == exp, MODE_NAMES[mode]
+        plan.close()
+    pkg.lib().asciichat_hip_free(comp_dev)
+
+
+def test_resize_kernel(gpu):
+    pkg, torch = gpu
+    img = orc.frame_hash_noise(1920, 1080, 77)
+    src = torch.from_numpy(img).cuda()
+    for (dw, dh) in [(80, 24), (53, 30), (1, 1), (1920, 1080), (2500, 1400), (3, 2000)]:
+        dst = torch.zeros(dh * dw * 3, dtype=torch.uint8, device="cuda")
+        assert pkg.lib().asciichat_hip_resize(src.data_ptr(), 1920, 1080, dst.data_ptr(), dw, dh, None) == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(dst.cpu().numpy().reshape(dh, dw, 3), orc.resize_nn(img, dw, dh)), (dw, dh)

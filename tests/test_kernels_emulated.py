@@ -1,0 +1,64 @@
+"""Runs the unmodified HIP kernel source under the CPU fiber emulator and checks it byte-for-byte
+against the oracle.  (The -m gpu tests repeat these cases on the real MI355X through the C-ABI.)"""
+import numpy as np
+import pytest
+
+import emu
+import orc
+from achip_ctypes import (ALL_MODES, MODE_16_FG, MODE_256_FG, MODE_CAPS, MODE_HB_TRUE, MODE_MONO, MODE_NAMES,
+                          MODE_TRUE_BG, MODE_TRUE_FG)
+
+
+def oracle_convert(img, mode, W, H, palette, wants_padding=False, use_aspect=False):
+    if mode == MODE_TRUE_BG:
+        assert not use_aspect
+        rows = H
+        rs = orc.resize_nn(img, W, rows)
+        return orc.print_truecolor_bg(rs, palette)
+    cl, rm = MODE_CAPS[mode]
+    return orc.convert_with_caps(img, W, H, cl, rm, wants_padding, use_aspect, False, palette)
+
+
+def emu_convert(img, mode, W, H, palette, variant, wants_padding=False, use_aspect=False):
+    rm = MODE_CAPS.get(mode, (3, 0))[1]
+    f = emu.frame_for_convert(img, W, H, rm, wants_padding, use_aspect)
+    return emu.render_frames(mode, [f], palette, variant)[0]
+
+
+TORTURE = orc.frame_torture()
+
+
+@pytest.mark.parametrize("mode", ALL_MODES, ids=MODE_NAMES)
+@pytest.mark.parametrize("variant", [3, 2])
+def test_torture_all_modes(mode, variant):
+    # Appendix-B torture image: transparent runs, REP runs, gradient, noise
+    for (W, H) in [(80, 24), (97, 31)]:
+        exp = oracle_convert(TORTURE, mode, W, H, orc.PALETTE_STANDARD)
+        got = emu_convert(TORTURE, mode, W, H, orc.PALETTE_STANDARD, variant)
+        assert got == exp, (MODE_NAMES[mode], W, H)
+
+
+@pytest.mark.parametrize("mode", [MODE_MONO, MODE_TRUE_FG, MODE_HB_TRUE], ids=["mono", "true_fg", "hb_true"])
+def test_aspect_and_padding(mode):
+    for (W, H) in [(80, 24), (97, 31), (60, 40)]:
+        exp = oracle_convert(TORTURE, mode, W, H, orc.PALETTE_STANDARD, True, True)
+        got = emu_convert(TORTURE, mode, W, H, orc.PALETTE_STANDARD, 3, True, True)
+        assert got == exp, (MODE_NAMES[mode], W, H)
+
+
+@pytest.mark.parametrize("palette", [orc.PALETTE_BLOCKS, orc.PALETTE_COOL, orc.PALETTE_DIGITAL, orc.PALETTE_MINIMAL,
+                                     "ab", "x", "é漢😀 ."], ids=["blocks", "cool", "digital", "minimal", "ab", "x", "mixed"])
+@pytest.mark.parametrize("mode", [MODE_MONO, MODE_TRUE_FG, MODE_256_FG, MODE_16_FG, MODE_TRUE_BG],
+                         ids=["mono", "true_fg", "256_fg", "16_fg", "true_bg"])
+def test_palettes(palette, mode):
+    exp = oracle_convert(TORTURE, mode, 61, 17, palette)
+    got = emu_convert(TORTURE, mode, 61, 17, palette, 3)
+    assert got == exp
+
+
+def test_wide_variant_big_frame():
+    img = orc.frame_hash_noise(320, 200, 7)
+    for mode in (MODE_TRUE_FG, MODE_HB_TRUE, MODE_MONO):
+        exp = oracle_convert(img, mode, 200, 60, orc.PALETTE_STANDARD)
+        got = emu_convert(img, mode, 200, 60, orc.PALETTE_STANDARD, 0)
+        assert got == exp, MODE_NAMES[mode]
