@@ -9,3 +9,4 @@ The directory name contains a hyphen, so import it with the helper in __graft_en
     from __graft_entry__ import load_package; achip = load_package()
 """
 from .binding import *  # noqa: F401,F403
+from . import distributed  # noqa: F401

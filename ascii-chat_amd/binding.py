@@ -63,6 +63,12 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    try:
+        # torch bundles its own libamdhip64.so (soname libamdhip64.so.7): load it FIRST so that our library's
+        # DT_NEEDED libamdhip64.so.7 binds to the same runtime instead of a second copy from /opt/rocm
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc, gfx950) first")
     L = C.CDLL(LIB_PATH)
@@ -83,6 +89,8 @@ def lib():
     L.asciichat_hip_plan_render.argtypes = [vp, vp, sz, vp, vp]
     L.asciichat_hip_plan_render_range.restype = ci
     L.asciichat_hip_plan_render_range.argtypes = [vp, ci, ci, vp, sz, vp, vp]
+    L.asciichat_hip_plan_render_profiled.restype = ci
+    L.asciichat_hip_plan_render_profiled.argtypes = [vp, vp, sz, vp, vp, vp]
     L.asciichat_hip_plan_destroy.restype = None
     L.asciichat_hip_plan_destroy.argtypes = [vp]
     L.asciichat_hip_resize.restype = ci
@@ -232,6 +240,11 @@ class Plan:
         rc = lib().asciichat_hip_plan_render_range(self._h, first, count, out_ptr, out_stride, len_ptr, stream)
         if rc != 0:
             raise RuntimeError(f"plan_render failed ({rc}): {last_error()}")
+
+    def render_profiled(self, out_ptr, out_stride, len_ptr, prof_ptr, stream=0):
+        rc = lib().asciichat_hip_plan_render_profiled(self._h, out_ptr, out_stride, len_ptr, prof_ptr, stream)
+        if rc != 0:
+            raise RuntimeError(f"plan_render_profiled failed ({rc}): {last_error()}")
 
     def close(self):
         if self._h:

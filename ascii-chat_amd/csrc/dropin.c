@@ -161,7 +161,7 @@ static char *render_one(int mode, const char *palette, achip_frame_t *f, size_t 
   *len_host = ACHIP_LEN_BADDESC;
   if (achip_hip_check(achip_launch_render(mode, variant, (const achip_frame_t *)(c->pin_dev + PIN_DESC_OFF), 1, lut,
                                           c->pin_dev + PIN_OUT_OFF, (uint64_t)stride,
-                                          (uint32_t *)(c->pin_dev + PIN_LEN_OFF), c->stream),
+                                          (uint32_t *)(c->pin_dev + PIN_LEN_OFF), NULL, c->stream),
                       "render kernel launch"))
     return NULL;
   if (achip_hip_check((int)hipStreamSynchronize(c->stream), "hipStreamSynchronize"))

@@ -13,7 +13,7 @@ extern "C" {
 /* all return a hipError_t as int (0 = hipSuccess); `stream` is a hipStream_t */
 int achip_launch_render(int mode, int variant, const achip_frame_t *frames_dev, int n_frames,
                         const achip_lut_t *lut_dev, uint8_t *out, uint64_t out_stride, uint32_t *out_len,
-                        void *stream);
+                        unsigned long long *phase_cycles /* NULL, or 8 u64 per frame (diagnostics) */, void *stream);
 int achip_launch_resize(const uint8_t *src, int sw, int sh, uint8_t *dst, int dw, int dh, void *stream);
 int achip_launch_composite(const achip_composite_t *comp_dev, int canvas_w, int canvas_h, uint8_t *dst, void *stream);
 

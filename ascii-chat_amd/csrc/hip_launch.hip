@@ -13,7 +13,7 @@ namespace {
 
 template <int MODE, int BLOCK, int CAP, int RING>
 hipError_t launch_one(const achip_frame_t *frames, int n, const achip_lut_t *lut, uint8_t *out, uint64_t stride,
-                      uint32_t *len, hipStream_t stream) {
+                      uint32_t *len, unsigned long long *prof, hipStream_t stream) {
   using L = achip::Lds<MODE, BLOCK, CAP, RING>;
   auto kern = achip::render_frames_kernel<MODE, BLOCK, CAP, RING>;
   static bool attr_set = false; /* one flag per instantiation; benign race (idempotent call) */
@@ -26,17 +26,17 @@ hipError_t launch_one(const achip_frame_t *frames, int n, const achip_lut_t *lut
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(BLOCK), (size_t)L::bytes, stream, frames, lut, out, stride, len, n);
+  hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(BLOCK), (size_t)L::bytes, stream, frames, lut, out, stride, len, n, prof);
   return hipGetLastError();
 }
 
 template <int BLOCK, int CAP, int RING>
 hipError_t launch_mode(int mode, const achip_frame_t *frames, int n, const achip_lut_t *lut, uint8_t *out,
-                       uint64_t stride, uint32_t *len, hipStream_t stream) {
+                       uint64_t stride, uint32_t *len, unsigned long long *prof, hipStream_t stream) {
   switch (mode) {
 #define M(m)                                                                                                           \
   case m:                                                                                                              \
-    return launch_one<m, BLOCK, CAP, RING>(frames, n, lut, out, stride, len, stream);
+    return launch_one<m, BLOCK, CAP, RING>(frames, n, lut, out, stride, len, prof, stream);
     M(ACHIP_MODE_MONO)
     M(ACHIP_MODE_TRUE_FG)
     M(ACHIP_MODE_256_FG)
@@ -74,14 +74,14 @@ template <int BLOCK, int CAP, int RING> int lds_for_mode(int mode) {
 
 extern "C" int achip_launch_render(int mode, int variant, const achip_frame_t *frames_dev, int n_frames,
                                    const achip_lut_t *lut_dev, uint8_t *out, uint64_t out_stride, uint32_t *out_len,
-                                   void *stream) {
+                                   unsigned long long *prof, void *stream) {
   if (n_frames <= 0)
     return (int)hipSuccess;
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (variant) {
 #define X(id, B, C, R)                                                                                                 \
   case id:                                                                                                             \
-    return (int)launch_mode<B, C, R>(mode, frames_dev, n_frames, lut_dev, out, out_stride, out_len, s);
+    return (int)launch_mode<B, C, R>(mode, frames_dev, n_frames, lut_dev, out, out_stride, out_len, prof, s);
     ACHIP_VARIANTS(X)
 #undef X
   }

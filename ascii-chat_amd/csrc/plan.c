@@ -241,8 +241,8 @@ int asciichat_hip_plan_set_variant(asciichat_hip_plan_t *p, int variant) {
 
 int asciichat_hip_plan_get_variant(const asciichat_hip_plan_t *p) { return p ? p->variant : -1; }
 
-int asciichat_hip_plan_render_range(asciichat_hip_plan_t *p, int first, int count, uint8_t *out_dev, size_t out_stride,
-                                    uint32_t *out_len_dev, void *stream) {
+static int render_range(asciichat_hip_plan_t *p, int first, int count, uint8_t *out_dev, size_t out_stride,
+                        uint32_t *out_len_dev, unsigned long long *phase_cycles_dev, void *stream) {
   if (!p || !out_dev || !out_len_dev || first < 0 || count < 0 || first + count > p->n)
     return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "plan_render: bad arguments");
   if (((uintptr_t)out_dev & 15u) || (out_stride & 15u) || out_stride < p->stride)
@@ -251,8 +251,18 @@ int asciichat_hip_plan_render_range(asciichat_hip_plan_t *p, int first, int coun
   if (count == 0)
     return 0;
   return achip_hip_check(achip_launch_render(p->mode, p->variant, p->frames_dev + first, count, p->lut_dev, out_dev,
-                                             (uint64_t)out_stride, out_len_dev, stream),
+                                             (uint64_t)out_stride, out_len_dev, phase_cycles_dev, stream),
                          "render kernel launch");
+}
+
+int asciichat_hip_plan_render_range(asciichat_hip_plan_t *p, int first, int count, uint8_t *out_dev, size_t out_stride,
+                                    uint32_t *out_len_dev, void *stream) {
+  return render_range(p, first, count, out_dev, out_stride, out_len_dev, NULL, stream);
+}
+
+int asciichat_hip_plan_render_profiled(asciichat_hip_plan_t *p, uint8_t *out_dev, size_t out_stride,
+                                       uint32_t *out_len_dev, unsigned long long *phase_cycles_dev, void *stream) {
+  return render_range(p, 0, p ? p->n : 0, out_dev, out_stride, out_len_dev, phase_cycles_dev, stream);
 }
 
 int asciichat_hip_plan_render(asciichat_hip_plan_t *p, uint8_t *out_dev, size_t out_stride, uint32_t *out_len_dev,

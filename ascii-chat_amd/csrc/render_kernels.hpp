@@ -493,10 +493,27 @@ __device__ inline void drain_ring(unsigned char *ring, uint8_t *__restrict__ out
     *reinterpret_cast<uint4 *>(out + o) = *reinterpret_cast<const uint4 *>(ring + (o & (RING - 1u)));
 }
 
+/* optional per-phase cycle accounting (diagnostics: prof == NULL in production launches).
+ * prof[frame*8 + k]: 0 setup+pad_top, 1 gather, 2 heads, 3 lengths, 4 scan, 5 emit+drain, 6 total */
+#ifdef ACHIP_HIPEMU
+__device__ inline unsigned long long cycle_now() { return 0ull; }
+#else
+__device__ inline unsigned long long cycle_now() { return (unsigned long long)clock64(); }
+#endif
+#define ACHIP_STAMP(slot)                                                                                              \
+  do {                                                                                                                 \
+    if (prof) {                                                                                                        \
+      const unsigned long long t_now = cycle_now();                                                                    \
+      t_acc[slot] += t_now - t_prev;                                                                                   \
+      t_prev = t_now;                                                                                                  \
+    }                                                                                                                  \
+  } while (0)
+
 template <int MODE, int BLOCK, int CAP, int RING>
 __global__ void __launch_bounds__(BLOCK)
     render_frames_kernel(const achip_frame_t *__restrict__ frames, const achip_lut_t *__restrict__ lut,
-                         uint8_t *__restrict__ out, uint64_t out_stride, uint32_t *__restrict__ out_len, int n_frames) {
+                         uint8_t *__restrict__ out, uint64_t out_stride, uint32_t *__restrict__ out_len, int n_frames,
+                         unsigned long long *__restrict__ prof) {
   using L = Lds<MODE, BLOCK, CAP, RING>;
   constexpr bool HB = mode_is_halfblock(MODE);
   constexpr int NW = BLOCK / 64;
@@ -547,6 +564,10 @@ __global__ void __launch_bounds__(BLOCK)
   const int rows_per_chunk = max(1, CAP / wp);
   const uint32_t cap_bytes = out_stride > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)out_stride;
 
+  unsigned long long t_acc[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long t_prev = prof ? cycle_now() : 0ull;
+  const unsigned long long t_start = t_prev;
+
   uint32_t base = 0;    /* stream bytes produced before the current chunk */
   uint32_t flushed = 0; /* stream bytes already in HBM (multiple of 16)   */
   bool overflow = false;
@@ -570,6 +591,7 @@ __global__ void __launch_bounds__(BLOCK)
     }
   }
   __syncthreads();
+  ACHIP_STAMP(0);
 
   for (int r0 = 0; r0 < rows; r0 += rows_per_chunk) {
     const int r1 = min(rows, r0 + rows_per_chunk);
@@ -605,6 +627,7 @@ __global__ void __launch_bounds__(BLOCK)
         pixB[i] = pb;
     }
     __syncthreads();
+    ACHIP_STAMP(1);
 
     /* ---- B: run heads / ASCII-glyph mask (one 64-cell word per wave step) -------------- */
     if (mode_has_runs(MODE) || MODE == ACHIP_MODE_TRUE_FG) {
@@ -632,6 +655,7 @@ __global__ void __launch_bounds__(BLOCK)
       __syncthreads();
     }
 
+    ACHIP_STAMP(2);
     Chunk c;
     c.pixT = pixT;
     c.pixB = pixB;
@@ -660,6 +684,7 @@ __global__ void __launch_bounds__(BLOCK)
       off[i] = len;
     }
     __syncthreads();
+    ACHIP_STAMP(3);
 
     /* ---- D: exclusive scan of off[0..CAP) -------------------------------------------------- */
     uint32_t total;
@@ -701,6 +726,7 @@ __global__ void __launch_bounds__(BLOCK)
       __syncthreads();
     }
 
+    ACHIP_STAMP(4);
     if ((uint64_t)base + total > cap_bytes)
       overflow = true;
 
@@ -741,6 +767,13 @@ __global__ void __launch_bounds__(BLOCK)
     }
     base = chunk_end;
     __syncthreads(); /* pixT/off/masks are rewritten by the next chunk */
+    ACHIP_STAMP(5);
+  }
+  if (prof && tid == 0) {
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+      prof[(size_t)fidx * 8u + (size_t)k] = t_acc[k];
+    prof[(size_t)fidx * 8u + 6u] = cycle_now() - t_start;
   }
 
   if (tid == 0) {

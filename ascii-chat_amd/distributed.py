@@ -1,0 +1,97 @@
+"""Multi-GPU plumbing for the render path: one process per GPU, torch.distributed (backend "nccl" = RCCL
+over xGMI on the GPU box, "gloo" in the CPU tests).
+
+Frames are independent units: a logical batch is cut into contiguous per-rank blocks and
+each rank renders only its block -- no halo, no reduction, glyph tables replicated (1.3 KB).  The only
+collectives on the data path are all-gathers, used where a consumer needs data produced on other ranks:
+
+  * ShardedBatch.all_gather(): fixed-stride output slab + uint32 lengths of every rank's block;
+  * gather_grid_tiles(): the <= 9 resized source tiles of a pixel-space grid composite
+    (create_multi_source_composite, src/server/stream.c:664-779) so that every rank can render the
+    composite for the target clients it owns (BASELINE config 4).
+
+Messages are KB..MB, i.e. latency-bound on xGMI: one collective per batch, never per frame.
+Compute is injected through a small backend object so that the same code runs the real library on the
+GPU box and the kernel emulator in the CPU tests.
+"""
+import ctypes as C
+
+
+def shard_bounds(n_items, world, rank):
+    """Contiguous block partition: (items per rank, first, count) for `rank`."""
+    per = (n_items + world - 1) // world
+    first = min(n_items, rank * per)
+    return per, first, max(0, min(per, n_items - first))
+
+
+class ShardedBatch:
+    """A logical batch of n_frames rendered by `world` ranks into one fixed-stride slab layout."""
+
+    def __init__(self, torch, n_frames, stride, world, rank, device):
+        self.torch = torch
+        self.n, self.stride, self.world, self.rank = n_frames, stride, world, rank
+        self.per, self.first, self.count = shard_bounds(n_frames, world, rank)
+        # room for world*per frames so that every rank contributes an equal-sized block to the all-gather
+        self.slab = torch.zeros(world * self.per * stride, dtype=torch.uint8, device=device)
+        self.lens = torch.zeros(world * self.per, dtype=torch.int32, device=device)
+
+    def local_views(self):
+        a, b = self.rank * self.per, (self.rank + 1) * self.per
+        return self.slab[a * self.stride:b * self.stride], self.lens[a:b]
+
+    def render_local(self, render_range):
+        """render_range(first, count, out_ptr, len_ptr): renders this rank's block in place."""
+        slab, lens = self.local_views()
+        if self.count:
+            render_range(self.first, self.count, slab.data_ptr(), lens.data_ptr())
+
+    def all_gather(self, dist, group=None):
+        """Every rank ends up with all ranks' frames (one all-gather for bytes, one for lengths)."""
+        if self.world == 1:
+            return
+        slab, lens = self.local_views()
+        dist.all_gather_into_tensor(self.slab, slab.clone(), group=group)
+        dist.all_gather_into_tensor(self.lens, lens.clone(), group=group)
+
+    def frame_bytes(self, i):
+        """Host copy of logical frame i (after all_gather, or local frames before)."""
+        n = int(self.lens[i].item()) & 0xFFFFFFFF
+        return bytes(self.slab[i * self.stride:i * self.stride + n].cpu().numpy())
+
+
+def gather_grid_tiles(torch, dist, backend, comp, local_sources, world, rank, device):
+    """Resize this rank's sources into their composite tiles, all-gather the tiles, and return
+    (tiles tensor, per-slot byte stride, composite descriptor rewired to read the gathered tiles).
+
+    comp            achip_composite_t filled by achip_composite_setup() with the geometry of ALL sources
+                    (every rank knows every source's dimensions; pointers may be dummies)
+    local_sources   {slot index: uint8 tensor HxWx3 on `device`} for the slots this rank owns; slots are
+                    dealt in contiguous blocks: rank r owns [r*per, (r+1)*per)
+    """
+    n = comp.n_src
+    per, first, count = shard_bounds(n, world, rank)
+    tile_stride = 16
+    for k in range(n):
+        tile_stride = max(tile_stride, (comp.s[k].tile_w * comp.s[k].tile_h * 3 + 15) // 16 * 16)
+    tiles = torch.zeros(world * per * tile_stride, dtype=torch.uint8, device=device)
+    for k in range(first, first + count):
+        s = comp.s[k]
+        if not s.src:
+            continue
+        src = local_sources[k]
+        backend.resize(src.data_ptr(), s.src_w, s.src_h, tiles.data_ptr() + k * tile_stride, s.tile_w, s.tile_h)
+    backend.sync()
+    if world > 1:
+        mine = tiles[rank * per * tile_stride:(rank + 1) * per * tile_stride].clone()
+        dist.all_gather_into_tensor(tiles, mine)
+    # the composite now samples the already-resized tiles: identity ratio, tile-sized "sources"
+    out = type(comp)()
+    C.memmove(C.byref(out), C.byref(comp), C.sizeof(comp))
+    for k in range(n):
+        s = out.s[k]
+        if not s.src:
+            continue
+        s.src = tiles.data_ptr() + k * tile_stride
+        s.src_w, s.src_h, s.src_stride = s.tile_w, s.tile_h, 3 * s.tile_w
+        s.x_ratio = s.y_ratio = 65537  # ((n << 16) / n) + 1
+    return tiles, tile_stride, out

@@ -10,6 +10,6 @@ echo "== pytest -m gpu"; timeout 1500 python -m pytest tests -m gpu -q --timeout
 echo "== smoke"; timeout 300 python __graft_entry__.py smoke 2>&1 | tail -5 | tee $OUT/smoke.log
 echo "== bench"; timeout 900 python bench.py --steps 200 --warmup 20 2>&1 | tail -3 | tee $OUT/bench.log
 echo "== rocprof"
-cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 20 --no-cpu --others '' > $GRAFT_REPO_ROOT/$OUT/rocprof_run.log 2>&1
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 20 --no-cpu --others '' > $GRAFT_REPO_ROOT/$OUT/rocprof_run.log 2>&1
 cd $GRAFT_REPO_ROOT
 find $OUT/prof -name "*stats*" | head; for f in $(find $OUT/prof -name "*kernel_stats.csv"); do head -12 $f; done

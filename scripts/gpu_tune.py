@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""GPU tuning aid: per-workload, per-geometry kernel time and per-phase cycle breakdown.
+Usage (on the GPU box): python scripts/gpu_tune.py [--batch 256] [--workloads a,b] > gpurun_out/tune.txt"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--workloads", default="1080p_80x24_truecolor,1080p_80x24_ansi256,4k_200x60_truecolor,4k_400x120_halfblock")
+    ap.add_argument("--variants", default="0,1,2")
+    ap.add_argument("--reps", type=int, default=50)
+    args = ap.parse_args()
+    import torch
+
+    from __graft_entry__ import load_package
+
+    pkg = load_package()
+    torch.cuda.set_device(0)
+    names = ["setup", "gather", "heads", "lengths", "scan", "emit", "total"]
+    for wl in args.workloads.split(","):
+        sw, sh, W, H, cl, rm = bench.WORKLOADS[wl]
+        frames_t = bench.make_frames(torch, args.batch, sw, sh, 1234)
+        plan, mode = bench.build_plan(pkg, frames_t, W, H, cl, rm)
+        out = torch.empty(args.batch * plan.stride, dtype=torch.uint8, device="cuda")
+        ln = torch.zeros(args.batch, dtype=torch.int32, device="cuda")
+        prof = torch.zeros(args.batch * 8, dtype=torch.int64, device="cuda")
+        for v in [int(x) for x in args.variants.split(",")]:
+            try:
+                plan.set_variant(v)
+            except RuntimeError as e:
+                print(f"{wl} variant {v}: skipped ({e})")
+                continue
+            for _ in range(5):
+                plan.render(out.data_ptr(), plan.stride, ln.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            ms = bench.kernel_time_events(torch, plan, out, ln, args.reps)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.reps):
+                plan.render(out.data_ptr(), plan.stride, ln.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            e1.record()
+            torch.cuda.synchronize()
+            b2b = e0.elapsed_time(e1) / args.reps
+            plan.render_profiled(out.data_ptr(), plan.stride, ln.data_ptr(), prof.data_ptr(),
+                                 torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            p = prof.cpu().numpy().reshape(args.batch, 8).astype("float64")
+            mean = p.mean(axis=0)
+            mx = p.max(axis=0)
+            lens = ln.cpu().numpy().astype("uint32")
+            rows = 2 * H if rm == 2 else H
+            alg = int(lens.sum()) + args.batch * 3 * W * rows
+            print(f"{wl:26s} v{v} kernel {ms*1e3:8.1f} us (b2b {b2b*1e3:8.1f} us) alg {alg/1e6:8.2f} MB -> "
+                  f"{alg/(ms*1e-3)/1e9:7.1f} GB/s  | cycles/frame mean: " +
+                  " ".join(f"{n}={int(m)}" for n, m in zip(names, mean[:7])) + f" | max total={int(mx[6])}")
+        plan.close()
+        del frames_t, out
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()

@@ -5,7 +5,7 @@ import subprocess
 
 import numpy as np
 
-from achip_ctypes import Composite, Frame, Lut, bind_host
+from achip_ctypes import Composite, Frame, Lut, bind_host  # noqa: F401
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "ascii-chat_amd", "csrc")

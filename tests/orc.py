@@ -233,7 +233,7 @@ def frame_noise(w, h, seed=12345):
 def frame_hash_noise(w, h, seed=1):
     """Fast counter-hash noise for large frames (not one of the survey's inputs; used where xorshift's
     sequential generator would dominate test time). Also implemented on device in bench.py."""
-    i = np.arange(w * h, dtype=np.uint64) + np.uint64(seed) * np.uint64(0x9E3779B97F4A7C15)
+    i = np.arange(w * h, dtype=np.uint64) + np.uint64((seed * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)
     i ^= i >> np.uint64(33)
     i *= np.uint64(0xFF51AFD7ED558CCD)
     i ^= i >> np.uint64(33)
