@@ -30,10 +30,14 @@
 
 #ifdef ACHIP_HIPEMU
 #include "hip_emu.h"
-#define ACHIP_DYN_SMEM(name) unsigned char *name = hipemu::g_smem.data()
+#define ACHIP_SMEM (hipemu::g_smem.data())
 #else
 #include <hip/hip_runtime.h>
-#define ACHIP_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+/* The one dynamic-LDS block of the frame kernel.  Every LDS access below is derived from this symbol
+ * (never from a pointer stored in a struct), so the compiler keeps the accesses in the LDS address
+ * space: ds_read/ds_write instead of flat_load/flat_store. */
+extern __shared__ __attribute__((aligned(16))) unsigned char achip_smem[];
+#define ACHIP_SMEM achip_smem
 #endif
 
 #include <stdint.h>
@@ -41,6 +45,46 @@
 #include "achip_types.h"
 
 namespace achip {
+
+/* pointers read out of descriptors are generic; tell the compiler they are global memory so that it
+ * emits global_load (vmcnt only) rather than flat_load (vmcnt + lgkmcnt, shared with the LDS queue) */
+#ifdef ACHIP_HIPEMU
+#define ACHIP_GLOBAL
+#else
+#define ACHIP_GLOBAL __attribute__((address_space(1)))
+#endif
+struct __attribute__((packed)) unaligned_u32 {
+  uint32_t v;
+};
+
+template <class T> __device__ inline T *lds_ptr(int byte_off) { return reinterpret_cast<T *>(ACHIP_SMEM + byte_off); }
+
+/* one LDS byte store at (LDS byte address `addr`) + OFF; HI selects bits 23..16 of `v` instead of 7..0.
+ * Written as asm so that neighbouring byte stores are never fused into a misaligned wide store. */
+template <int OFF, bool HI> __device__ inline void lds_store_byte(uint32_t addr, uint32_t v) {
+#ifdef ACHIP_HIPEMU
+  ACHIP_SMEM[addr + OFF] = (unsigned char)(HI ? v >> 16 : v);
+#else
+  if (HI)
+    asm volatile("ds_write_b8_d16_hi %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+  else
+    asm volatile("ds_write_b8 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+#endif
+}
+/* LDS byte address of ACHIP_SMEM[0] (0 for a kernel without static LDS, but do not assume) */
+__device__ inline uint32_t lds_base_addr() {
+#ifdef ACHIP_HIPEMU
+  return 0u;
+#else
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(achip_smem);
+#endif
+}
+/* all DS operations issued by inline asm must have landed before other waves read the ring */
+__device__ inline void lds_store_fence() {
+#ifndef ACHIP_HIPEMU
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+}
 
 /* ------------------------------------------------------------------------------------------- */
 /* wave64 primitives                                                                             */
@@ -131,103 +175,122 @@ __device__ inline bool rep_profitable(uint32_t run) {
 }
 
 /* ------------------------------------------------------------------------------------------- */
-/* byte sinks: one token body serves both the length pass and the emit pass                      */
+/* token sinks.  A token is a short sequence of FIELDS of <= 4 bytes (packed little-endian in a   */
+/* u32).  One token body drives three sinks: CountSink (length pass), FastSink (token lies wholly  */
+/* inside the ring window: plain LDS byte stores, constant-length fields fold to immediate-offset  */
+/* stores) and ClipSink (token straddles a window edge or the ring's wrap point: per-byte checks). */
+/* Measured on gfx950 (scripts/ubench/lds_unaligned.hip): a ds_write_b8 costs ~1.5 cycles per      */
+/* wave-instruction per CU, a MISALIGNED ds_write_b32 ~16 -- so bytes are stored one by one        */
+/* through a volatile pointer, which also stops the compiler from fusing them into wide stores.    */
 /* ------------------------------------------------------------------------------------------- */
-struct CountSink {
+/* dec[v], v in 0..255: ASCII digits of v without leading zeros, first digit in the low byte, digit
+ * count in bits 31..24 (the reference's dec3 table, lib/video/ascii/common.c:546-570) */
+__device__ inline uint32_t dec_entry(uint32_t v) {
+  const uint32_t d2 = (v * 41u) >> 12, r = v - 100u * d2, d1 = (r * 205u) >> 11, d0 = r - 10u * d1;
+  if (d2)
+    return (0x30u + d2) | ((0x30u + d1) << 8) | ((0x30u + d0) << 16) | (3u << 24);
+  if (d1)
+    return (0x30u + d1) | ((0x30u + d0) << 8) | (2u << 24);
+  return (0x30u + d0) | (1u << 24);
+}
+
+template <class L> struct CountSink {
   uint32_t n;
-  __device__ inline void put(uint32_t) { n++; }
-  __device__ inline void skip(uint32_t k) { n += k; }
+  template <int K> __device__ inline void c(uint32_t) { n += (uint32_t)K; }
+  __device__ inline void v4(uint32_t, uint32_t k) { n += k; }
+  __device__ inline void num(uint32_t value, uint32_t) { n += (lds_ptr<const uint32_t>(L::o_dec)[value] >> 24) + 1u; }
 };
 
-template <uint32_t RING> struct RingSink {
-  unsigned char *ring;
+template <class L> struct FastSink {
+  uint32_t a; /* LDS byte address of the next byte; the token neither wraps nor leaves the window */
+  template <int K> __device__ inline void c(uint32_t v) {
+    const uint32_t w = v >> 8;
+    lds_store_byte<0, false>(a, v);
+    if (K > 1) lds_store_byte<1, false>(a, w);
+    if (K > 2) lds_store_byte<2, true>(a, v);
+    if (K > 3) lds_store_byte<3, true>(a, w);
+    a += K;
+  }
+  __device__ inline void v4(uint32_t v, uint32_t k) { /* k in 1..4 */
+    const uint32_t w = v >> 8;
+    lds_store_byte<0, false>(a, v);
+    if (k > 1u) lds_store_byte<1, false>(a, w);
+    if (k > 2u) lds_store_byte<2, true>(a, v);
+    if (k > 3u) lds_store_byte<3, true>(a, w);
+    a += k;
+  }
+  __device__ inline void num(uint32_t value, uint32_t term) { /* 1-3 digits + terminator */
+    const uint32_t e = lds_ptr<const uint32_t>(L::o_dec)[value], d = e >> 24;
+    const uint32_t v = (e & 0x00FFFFFFu) | (term << (8u * d)), w = v >> 8;
+    lds_store_byte<0, false>(a, v);
+    lds_store_byte<1, false>(a, w);
+    if (d > 1u) lds_store_byte<2, true>(a, v);
+    if (d > 2u) lds_store_byte<3, true>(a, w);
+    a += d + 1u;
+  }
+};
+
+template <class L, uint32_t RING> struct ClipSink {
   uint32_t pos;    /* absolute stream offset of the next byte */
   uint32_t lo, hi; /* window of the stream currently backed by the ring */
   __device__ inline void put(uint32_t b) {
     if (pos >= lo && pos < hi)
-      ring[pos & (RING - 1u)] = (unsigned char)b;
+      lds_ptr<unsigned char>(L::o_ring)[pos & (RING - 1u)] = (unsigned char)b;
     pos++;
+  }
+  template <int K> __device__ inline void c(uint32_t v) {
+#pragma unroll
+    for (int k = 0; k < K; k++)
+      put((v >> (8 * k)) & 0xFFu);
+  }
+  __device__ inline void v4(uint32_t v, uint32_t k) {
+    for (uint32_t j = 0; j < k; j++)
+      put((v >> (8u * j)) & 0xFFu);
+  }
+  __device__ inline void num(uint32_t value, uint32_t term) {
+    const uint32_t e = lds_ptr<const uint32_t>(L::o_dec)[value], d = e >> 24;
+    v4((e & 0x00FFFFFFu) | (term << (8u * d)), d + 1u);
   }
 };
 
-template <class S> __device__ inline void put_dec(S &s, uint32_t v) { /* decimal, no leading zeros */
-  if (v >= 1000u) {                                                  /* REP counts up to 3839     */
-    s.put('0' + v / 1000u);
-    v %= 1000u;
-    s.put('0' + v / 100u);
-    v %= 100u;
-    s.put('0' + v / 10u);
-    s.put('0' + v % 10u);
-    return;
-  }
-  if (v >= 100u) {
-    s.put('0' + v / 100u);
-    v %= 100u;
-    s.put('0' + v / 10u);
-    s.put('0' + v % 10u);
-  } else if (v >= 10u) {
-    s.put('0' + v / 10u);
-    s.put('0' + v % 10u);
-  } else {
-    s.put('0' + v);
-  }
-}
-
 /* ESC[38;2;R;G;Bm / ESC[48;2;R;G;Bm  (append_truecolor_fg/bg ansi.c:143-193; emit_set_fg/bg output_buffer.c:186-214) */
 template <class S> __device__ inline void put_sgr_true(S &s, bool bg, uint32_t p) {
-  s.put(0x1B);
-  s.put('[');
-  s.put(bg ? '4' : '3');
-  s.put('8');
-  s.put(';');
-  s.put('2');
-  s.put(';');
-  put_dec(s, px_r(p));
-  s.put(';');
-  put_dec(s, px_g(p));
-  s.put(';');
-  put_dec(s, px_b(p));
-  s.put('m');
+  s.template c<4>(bg ? 0x38345B1Bu : 0x38335B1Bu); /* ESC [ 3|4 8 */
+  s.template c<3>(0x003B323Bu);                    /* ; 2 ;       */
+  s.num(px_r(p), ';');
+  s.num(px_g(p), ';');
+  s.num(px_b(p), 'm');
 }
 /* ESC[38;5;Nm / ESC[48;5;Nm  (ansi.c:326-357) */
 template <class S> __device__ inline void put_sgr_256(S &s, bool bg, uint32_t idx) {
-  s.put(0x1B);
-  s.put('[');
-  s.put(bg ? '4' : '3');
-  s.put('8');
-  s.put(';');
-  s.put('5');
-  s.put(';');
-  put_dec(s, idx);
-  s.put('m');
+  s.template c<4>(bg ? 0x38345B1Bu : 0x38335B1Bu);
+  s.template c<3>(0x003B353Bu); /* ; 5 ; */
+  s.num(idx, 'm');
 }
 /* fg 30-37/90-97, bg 40-47/100-107  (ansi.c:384-435) */
 template <class S> __device__ inline void put_sgr_16(S &s, bool bg, uint32_t idx) {
   const uint32_t code = bg ? (idx < 8u ? 40u + idx : 92u + idx) : (idx < 8u ? 30u + idx : 82u + idx);
-  s.put(0x1B);
-  s.put('[');
-  put_dec(s, code);
-  s.put('m');
+  s.template c<2>(0x5B1Bu);
+  s.num(code, 'm');
 }
-template <class S> __device__ inline void put_reset(S &s) { /* ESC[0m */
-  s.put(0x1B);
-  s.put('[');
-  s.put('0');
-  s.put('m');
+template <class S> __device__ inline void put_reset(S &s) { s.template c<4>(0x6D305B1Bu); } /* ESC[0m */
+/* emit_rep: ESC[<extra>b, extra <= 4095 (a run never exceeds one chunk row) */
+template <class S> __device__ inline void put_rep(S &s, uint32_t extra) {
+  s.template c<2>(0x5B1Bu);
+  if (extra < 256u) {
+    s.num(extra, 'b');
+  } else {
+    const uint32_t d3 = extra / 1000u, r3 = extra - d3 * 1000u, d2 = r3 / 100u, r2 = r3 - d2 * 100u, d1 = r2 / 10u,
+                   d0 = r2 - d1 * 10u;
+    if (d3) {
+      s.template c<4>((0x30u + d3) | ((0x30u + d2) << 8) | ((0x30u + d1) << 16) | ((0x30u + d0) << 24));
+      s.template c<1>('b');
+    } else {
+      s.template c<4>((0x30u + d2) | ((0x30u + d1) << 8) | ((0x30u + d0) << 16) | ((uint32_t)'b' << 24));
+    }
+  }
 }
-template <class S> __device__ inline void put_rep(S &s, uint32_t extra) { /* emit_rep: ESC[<extra>b */
-  s.put(0x1B);
-  s.put('[');
-  put_dec(s, extra);
-  s.put('b');
-}
-template <class S> __device__ inline void put_glyph(S &s, uint32_t g) {
-  const uint32_t n = glyph_len(g);
-  s.put(g & 0xFFu);
-  if (n > 1u) s.put((g >> 8) & 0xFFu);
-  if (n > 2u) s.put((g >> 16) & 0xFFu);
-  if (n > 3u) s.put(g >> 24);
-}
+template <class S> __device__ inline void put_glyph(S &s, uint32_t g) { s.v4(g, glyph_len(g)); }
 
 /* ------------------------------------------------------------------------------------------- */
 /* bit scans over the ballot masks (64 cells per word)                                           */
@@ -280,7 +343,8 @@ template <int MODE, int BLOCK, int CAP, int RING> struct Lds {
   static constexpr int o_glyph = o_amask + MASKW * 8;
   static constexpr int o_glyph64 = o_glyph + 256 * 4;
   static constexpr int o_ramp = o_glyph64 + 64 * 4;
-  static constexpr int o_wsum = o_ramp + 64;
+  static constexpr int o_dec = o_ramp + 64;
+  static constexpr int o_wsum = o_dec + 256 * 4;
   static constexpr int bytes = o_wsum + (BLOCK / 64) * 4 + 16;
 };
 
@@ -288,20 +352,26 @@ template <int MODE, int BLOCK, int CAP, int RING> struct Lds {
 /* sampling (R1) and the fused pixel-space composite (C2)                                        */
 /* ------------------------------------------------------------------------------------------- */
 __device__ inline uint32_t load_rgb(const uint8_t *__restrict__ src, int32_t stride_bytes, uint32_t x, uint32_t y) {
-  const uint8_t *p = src + (size_t)y * (size_t)stride_bytes + (size_t)x * 3u;
-  return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+  const size_t a = (size_t)y * (size_t)stride_bytes + (size_t)x * 3u;
+  const ACHIP_GLOBAL uint8_t *p = (const ACHIP_GLOBAL uint8_t *)src + a;
+  if (a == 0) /* first pixel of the buffer: nothing in front of it to borrow a byte from */
+    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+  /* one (unaligned) dword covering the byte before the pixel and the pixel: never reads past the
+   * last pixel of the buffer, and costs one VMEM instruction instead of three */
+  return ((const ACHIP_GLOBAL unaligned_u32 *)(p - 1))->v >> 8;
 }
 
 /* pixel (X,Y) of the virtual W x 2H composite canvas (stream.c:664-779): the tile of the cell that
  * contains it, nearest-neighbour resized on the fly; black outside every tile. */
-__device__ inline uint32_t sample_composite(const achip_composite_t *__restrict__ c, uint32_t X, uint32_t Y) {
+__device__ inline uint32_t sample_composite(const achip_composite_t *__restrict__ cgen, uint32_t X, uint32_t Y) {
+  const ACHIP_GLOBAL achip_composite_t *c = (const ACHIP_GLOBAL achip_composite_t *)cgen;
   const int col = (int)X / c->cell_w, row = (int)Y / c->cell_h;
   if (col >= c->cols || row >= c->rows)
     return 0u;
   const int idx = row * c->cols + col;
   if (idx >= c->n_src)
     return 0u;
-  const achip_comp_src_t *s = &c->s[idx];
+  const ACHIP_GLOBAL achip_comp_src_t *s = &c->s[idx];
   if (!s->src)
     return 0u;
   const int lx = (int)X - s->org_x, ly = (int)Y - s->org_y;
@@ -327,13 +397,6 @@ __device__ inline uint32_t sample_frame(const achip_frame_t &f, uint32_t x, uint
 /* per-chunk view handed to the token bodies                                                     */
 /* ------------------------------------------------------------------------------------------- */
 struct Chunk {
-  const uint32_t *pixT;
-  const uint32_t *pixB;
-  const uint64_t *hmask;
-  const uint64_t *amask;
-  const uint32_t *glyph;
-  const uint32_t *glyph64;
-  const uint8_t *ramp;
   int n;           /* cells in this chunk (pad pseudo-cells included) */
   int wp;          /* cells per text row = pad_left + out_w           */
   int pad_left;
@@ -344,23 +407,31 @@ struct Chunk {
 };
 
 /* The token owned by cell i (text row r, column xp inside the padded row). */
-template <int MODE, class S> __device__ inline void emit_token(S &s, const Chunk &c, int i, int r, int xp) {
+template <int MODE, class L, class S> __device__ inline void emit_token(S &s, const Chunk &c, int i, int r, int xp) {
+  const uint32_t *pixT = lds_ptr<const uint32_t>(L::o_pixT);
+  const uint32_t *pixB = lds_ptr<const uint32_t>(L::o_pixB);
+  const uint64_t *hmask = lds_ptr<const uint64_t>(L::o_hmask);
+  const uint64_t *amask = lds_ptr<const uint64_t>(L::o_amask);
+  const uint32_t *glyph = lds_ptr<const uint32_t>(L::o_glyph);
+  const uint32_t *glyph64 = lds_ptr<const uint32_t>(L::o_glyph64);
+  const uint8_t *ramp = lds_ptr<const uint8_t>(L::o_ramp);
+  (void)pixB; (void)hmask; (void)amask; (void)glyph; (void)glyph64; (void)ramp;
   if (xp < c.pad_left) { /* ascii_pad_frame_width: pad_left spaces in front of every row */
-    s.put(' ');
+    s.template c<1>(' ');
     return;
   }
-  const uint32_t pt = c.pixT[i];
+  const uint32_t pt = pixT[i];
 
   if (MODE == ACHIP_MODE_TRUE_FG) {
     /* image_print_color + ansi_rle_add_pixel (foreground.c:268-303, ansi.c:261-300): ASCII glyph ->
      * SGR only when the colour differs from the previous ASCII-glyph pixel (state survives row ends);
      * any other glyph -> SGR always, state untouched. */
-    const uint32_t g = c.glyph[luma601(pt)];
+    const uint32_t g = glyph[luma601(pt)];
     bool sgr = true;
     if ((g & 0xFFu) < 128u) {
-      const int j = prev_set(c.amask, i);
+      const int j = prev_set(amask, i);
       if (j >= 0)
-        sgr = px_rgb(c.pixT[j]) != px_rgb(pt);
+        sgr = px_rgb(pixT[j]) != px_rgb(pt);
       else if (c.carry_have)
         sgr = c.carry_rgb != px_rgb(pt);
     }
@@ -369,26 +440,26 @@ template <int MODE, class S> __device__ inline void emit_token(S &s, const Chunk
     put_glyph(s, g);
   } else if (MODE == ACHIP_MODE_256_FG) { /* foreground.c:475-500 */
     put_sgr_256(s, false, quant256(pt));
-    put_glyph(s, c.glyph[luma601(pt)]);
+    put_glyph(s, glyph[luma601(pt)]);
   } else if (MODE == ACHIP_MODE_16_FG) { /* foreground.c:584-612: glyph = cache[ramp[Y>>2]] (sic) */
     put_sgr_16(s, false, quant16(pt));
-    put_glyph(s, c.glyph[c.ramp[luma601(pt) >> 2]]);
+    put_glyph(s, glyph[ramp[luma601(pt) >> 2]]);
   } else if (MODE == ACHIP_MODE_TRUE_BG) { /* background.c:49-68 */
     const uint32_t Y = luma601(pt);
     put_sgr_true(s, true, pt);
     put_sgr_true(s, false, Y < 128u ? 0x00FFFFFFu : 0u);
-    put_glyph(s, c.glyph[Y]);
+    put_glyph(s, glyph[Y]);
   } else {
     /* run-structured modes: head h, end e, run = e - h */
-    const bool is_head = (c.hmask[i >> 6] >> (i & 63)) & 1ull;
-    const int h = is_head ? i : prev_set(c.hmask, i);
-    const int e = next_set(c.hmask, i);
+    const bool is_head = (hmask[i >> 6] >> (i & 63)) & 1ull;
+    const int h = is_head ? i : prev_set(hmask, i);
+    const int e = next_set(hmask, i);
     const uint32_t run = (uint32_t)(e - h);
     const bool rep = rep_profitable(run);
 
     if (MODE == ACHIP_MODE_MONO) {
       /* image_print (foreground.c:86-127): key = ramp[Y>>2], glyph = cache64[key] (double mapping) */
-      const uint32_t g = c.glyph64[px_key(pt)];
+      const uint32_t g = glyph64[px_key(pt)];
       if (is_head) {
         put_glyph(s, g);
         if (rep)
@@ -398,16 +469,14 @@ template <int MODE, class S> __device__ inline void emit_token(S &s, const Chunk
       }
     } else if (MODE == ACHIP_MODE_HB_MONO) {
       /* rgb_to_halfblocks_scalar (halfblock.c:203-275): 76/150/29 luminance, no rounding term */
-      const uint32_t pb = c.pixB[i];
+      const uint32_t pb = pixB[i];
       const uint32_t lt = (76u * px_r(pt) + 150u * px_g(pt) + 29u * px_b(pt)) >> 8;
       const uint32_t lb = (76u * px_r(pb) + 150u * px_g(pb) + 29u * px_b(pb)) >> 8;
       if (lt < 16u && lb < 16u) {
-        s.put(' ');
+        s.template c<1>(' ');
       } else if (is_head || !rep) {
-        const uint32_t sh = lt >> 6; /* U+2591 U+2592 U+2593 U+2588 */
-        s.put(0xE2);
-        s.put(0x96);
-        s.put(sh == 3u ? 0x88u : 0x91u + sh);
+        const uint32_t sh = lt >> 6; /* U+2591 U+2592 U+2593 U+2588 = E2 96 91|92|93|88 */
+        s.template c<3>(0x0096E2u | ((sh == 3u ? 0x88u : 0x91u + sh) << 16));
         if (is_head && rep)
           put_rep(s, run - 1u);
       }
@@ -415,20 +484,20 @@ template <int MODE, class S> __device__ inline void emit_token(S &s, const Chunk
       /* HT / H256 / H16 (halfblock.c:48-165, 297-524): transparency is decided by the run HEAD's raw
        * rgb; fg/bg SGRs only when they differ from the state left by the previous run in this row
        * (unset at row start and after a transparent run). */
-      const uint32_t hT = c.pixT[h], hB = c.pixB[h];
+      const uint32_t hT = pixT[h], hB = pixB[h];
       const bool transparent = (px_rgb(hT) | px_rgb(hB)) == 0u;
       bool state_set = false;
       uint32_t pT = 0, pB = 0;
       if (is_head && xp > c.pad_left) { /* not the first pixel cell of its row */
-        const int p = prev_set(c.hmask, h);
-        pT = c.pixT[p];
-        pB = c.pixB[p];
+        const int p = prev_set(hmask, h);
+        pT = pixT[p];
+        pB = pixB[p];
         state_set = (px_rgb(pT) | px_rgb(pB)) != 0u;
       }
       if (transparent) {
         if (is_head && state_set)
           put_reset(s);
-        s.put(' ');
+        s.template c<1>(' ');
       } else {
         if (is_head) {
           if (MODE == ACHIP_MODE_HB_TRUE) {
@@ -448,11 +517,8 @@ template <int MODE, class S> __device__ inline void emit_token(S &s, const Chunk
               put_sgr_16(s, true, px_key(hB));
           }
         }
-        if (is_head || !rep) { /* U+2580 upper half block */
-          s.put(0xE2);
-          s.put(0x96);
-          s.put(0x80);
-        }
+        if (is_head || !rep) /* U+2580 upper half block = E2 96 80 */
+          s.template c<3>(0x8096E2u);
         if (is_head && rep)
           put_rep(s, run - 1u);
       }
@@ -464,7 +530,7 @@ template <int MODE, class S> __device__ inline void emit_token(S &s, const Chunk
     if (mode_row_reset(MODE))
       put_reset(s);
     if (r < c.rows - 1)
-      s.put('\n');
+      s.template c<1>('\n');
     else if (MODE == ACHIP_MODE_TRUE_FG)
       put_reset(s); /* ansi_rle_finish: the single trailing ESC[0m */
   }
@@ -494,7 +560,7 @@ __device__ inline void drain_ring(unsigned char *ring, uint8_t *__restrict__ out
 }
 
 /* optional per-phase cycle accounting (diagnostics: prof == NULL in production launches).
- * prof[frame*8 + k]: 0 setup+pad_top, 1 gather, 2 heads, 3 lengths, 4 scan, 5 emit+drain, 6 total */
+ * prof[frame*8 + k]: 0 setup+pad_top, 1 gather, 2 heads, 3 lengths, 4 scan, 5 emit tokens, 6 drain, 7 total */
 #ifdef ACHIP_HIPEMU
 __device__ inline unsigned long long cycle_now() { return 0ull; }
 #else
@@ -520,7 +586,7 @@ __global__ void __launch_bounds__(BLOCK)
   constexpr int SEG = CAP / BLOCK;
   static_assert(CAP % BLOCK == 0 && (RING & (RING - 1)) == 0 && RING % 16 == 0, "geometry");
 
-  ACHIP_DYN_SMEM(smem);
+  unsigned char *smem = ACHIP_SMEM;
   unsigned char *ring = smem + L::o_ring;
   uint32_t *pixT = reinterpret_cast<uint32_t *>(smem + L::o_pixT);
   uint32_t *pixB = reinterpret_cast<uint32_t *>(smem + L::o_pixB);
@@ -530,6 +596,7 @@ __global__ void __launch_bounds__(BLOCK)
   uint32_t *glyph = reinterpret_cast<uint32_t *>(smem + L::o_glyph);
   uint32_t *glyph64 = reinterpret_cast<uint32_t *>(smem + L::o_glyph64);
   uint8_t *ramp = smem + L::o_ramp;
+  uint32_t *dec = reinterpret_cast<uint32_t *>(smem + L::o_dec);
   uint32_t *wsum = reinterpret_cast<uint32_t *>(smem + L::o_wsum);
 
   const int tid = (int)threadIdx.x;
@@ -551,9 +618,11 @@ __global__ void __launch_bounds__(BLOCK)
     return;
   }
 
-  /* glyph tables -> LDS */
-  for (int k = tid; k < 256; k += BLOCK)
+  /* glyph tables -> LDS; decimal table generated in place */
+  for (int k = tid; k < 256; k += BLOCK) {
     glyph[k] = lut->glyph[k];
+    dec[k] = dec_entry((uint32_t)k);
+  }
   for (int k = tid; k < 64; k += BLOCK) {
     glyph64[k] = lut->glyph64[k];
     ramp[k] = lut->ramp[k];
@@ -563,8 +632,9 @@ __global__ void __launch_bounds__(BLOCK)
   const uint32_t wp_magic = wp > 1 ? (uint32_t)(0x100000000ull / (uint32_t)wp) + 1u : 0u;
   const int rows_per_chunk = max(1, CAP / wp);
   const uint32_t cap_bytes = out_stride > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)out_stride;
+  const uint32_t ring_addr = lds_base_addr() + (uint32_t)L::o_ring;
 
-  unsigned long long t_acc[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long t_acc[7] = {0, 0, 0, 0, 0, 0, 0};
   unsigned long long t_prev = prof ? cycle_now() : 0ull;
   const unsigned long long t_start = t_prev;
 
@@ -597,34 +667,55 @@ __global__ void __launch_bounds__(BLOCK)
     const int r1 = min(rows, r0 + rows_per_chunk);
     const int n = (r1 - r0) * wp;
 
-    /* ---- A: gather ------------------------------------------------------------------ */
-    for (int i = tid; i < n; i += BLOCK) {
-      const int rr = row_of(i, wp_magic);
-      const int xp = i - rr * wp;
-      uint32_t pt = 0, pb = 0;
-      if (xp >= f.pad_left) {
-        const uint32_t x = (uint32_t)(xp - f.pad_left);
-        const uint32_t r = (uint32_t)(r0 + rr);
-        if (HB) {
-          const uint32_t yt = 2u * r, yb = 2u * r + 1u;
-          pt = sample_frame(f, x, yt);
-          pb = yb < (uint32_t)f.out_h ? sample_frame(f, x, yb) : pt; /* odd height: bottom = top (halfblock.c:81-88) */
-          if (MODE == ACHIP_MODE_HB_256) {
-            pt |= quant256(pt) << 24;
-            pb |= quant256(pb) << 24;
-          } else if (MODE == ACHIP_MODE_HB_16) {
-            pt |= quant16(pt) << 24;
-            pb |= quant16(pb) << 24;
+    /* ---- A: gather: all of a thread's samples are requested before any is consumed, so a thread
+     * keeps up to 2*SEG sparse 64-byte-sector fetches in flight ---------------------------------- */
+    {
+      uint32_t gt[SEG], gb[SEG];
+#pragma unroll
+      for (int k = 0; k < SEG; k++) {
+        const int i = tid + k * BLOCK;
+        gt[k] = 0;
+        gb[k] = 0;
+        if (i < n) {
+          const int rr = row_of(i, wp_magic);
+          const int xp = i - rr * wp;
+          if (xp >= f.pad_left) {
+            const uint32_t x = (uint32_t)(xp - f.pad_left);
+            const uint32_t r = (uint32_t)(r0 + rr);
+            if (HB) {
+              const uint32_t yt = 2u * r, yb = 2u * r + 1u;
+              gt[k] = sample_frame(f, x, yt);
+              /* odd height: the last text row's bottom half repeats the top (halfblock.c:81-88) */
+              gb[k] = yb < (uint32_t)f.out_h ? sample_frame(f, x, yb) : 0xFFFFFFFFu;
+            } else {
+              gt[k] = sample_frame(f, x, r);
+            }
           }
-        } else {
-          pt = sample_frame(f, x, r);
-          if (MODE == ACHIP_MODE_MONO)
-            pt |= (uint32_t)ramp[luma601(pt) >> 2] << 24;
         }
       }
-      pixT[i] = pt;
-      if (HB)
-        pixB[i] = pb;
+#pragma unroll
+      for (int k = 0; k < SEG; k++) {
+        const int i = tid + k * BLOCK;
+        if (i < n) {
+          uint32_t pt = gt[k], pb = gb[k] == 0xFFFFFFFFu ? gt[k] : gb[k];
+          const int rr = row_of(i, wp_magic);
+          const bool is_pixel = (i - rr * wp) >= f.pad_left;
+          if (is_pixel) {
+            if (MODE == ACHIP_MODE_HB_256) {
+              pt |= quant256(pt) << 24;
+              pb |= quant256(pb) << 24;
+            } else if (MODE == ACHIP_MODE_HB_16) {
+              pt |= quant16(pt) << 24;
+              pb |= quant16(pb) << 24;
+            } else if (MODE == ACHIP_MODE_MONO) {
+              pt |= (uint32_t)ramp[luma601(pt) >> 2] << 24;
+            }
+          }
+          pixT[i] = pt;
+          if (HB)
+            pixB[i] = pb;
+        }
+      }
     }
     __syncthreads();
     ACHIP_STAMP(1);
@@ -657,13 +748,6 @@ __global__ void __launch_bounds__(BLOCK)
 
     ACHIP_STAMP(2);
     Chunk c;
-    c.pixT = pixT;
-    c.pixB = pixB;
-    c.hmask = hmask;
-    c.amask = amask;
-    c.glyph = glyph;
-    c.glyph64 = glyph64;
-    c.ramp = ramp;
     c.n = n;
     c.wp = wp;
     c.pad_left = f.pad_left;
@@ -677,8 +761,8 @@ __global__ void __launch_bounds__(BLOCK)
       uint32_t len = 0;
       if (i < n) {
         const int rr = row_of(i, wp_magic);
-        CountSink cs{0};
-        emit_token<MODE>(cs, c, i, r0 + rr, i - rr * wp);
+        CountSink<L> cs{0u};
+        emit_token<MODE, L>(cs, c, i, r0 + rr, i - rr * wp);
         len = cs.n;
       }
       off[i] = len;
@@ -740,11 +824,19 @@ __global__ void __launch_bounds__(BLOCK)
         const uint32_t b = base + off[i + 1];
         if (b > a && a < hi && b > lo) {
           const int rr = row_of(i, wp_magic);
-          RingSink<RING> rs{ring, a, lo, hi};
-          emit_token<MODE>(rs, c, i, r0 + rr, i - rr * wp);
+          const uint32_t ra = a & (RING - 1u);
+          if (a >= lo && b <= hi && ra + (b - a) <= (uint32_t)RING) {
+            FastSink<L> fs{ring_addr + ra};
+            emit_token<MODE, L>(fs, c, i, r0 + rr, i - rr * wp);
+          } else {
+            ClipSink<L, RING> cs{a, lo, hi};
+            emit_token<MODE, L>(cs, c, i, r0 + rr, i - rr * wp);
+          }
         }
       }
+      lds_store_fence();
       __syncthreads();
+      ACHIP_STAMP(5);
       const uint32_t avail = min(chunk_end, hi);
       drain_ring<MODE, BLOCK, CAP, RING>(ring, dst, flushed, avail);
       if (last_chunk && avail == chunk_end) { /* frame tail: < 16 bytes, byte stores */
@@ -752,6 +844,7 @@ __global__ void __launch_bounds__(BLOCK)
           dst[o] = ring[o & (RING - 1u)];
       }
       __syncthreads();
+      ACHIP_STAMP(6);
       flushed = avail & ~15u;
       if (chunk_end <= hi)
         break;
@@ -767,13 +860,13 @@ __global__ void __launch_bounds__(BLOCK)
     }
     base = chunk_end;
     __syncthreads(); /* pixT/off/masks are rewritten by the next chunk */
-    ACHIP_STAMP(5);
+    ACHIP_STAMP(6);
   }
   if (prof && tid == 0) {
 #pragma unroll
-    for (int k = 0; k < 6; k++)
+    for (int k = 0; k < 7; k++)
       prof[(size_t)fidx * 8u + (size_t)k] = t_acc[k];
-    prof[(size_t)fidx * 8u + 6u] = cycle_now() - t_start;
+    prof[(size_t)fidx * 8u + 7u] = cycle_now() - t_start;
   }
 
   if (tid == 0) {

@@ -84,7 +84,7 @@ int asciichat_hip_plan_render_range(asciichat_hip_plan_t *plan, int first, int c
                                     size_t out_stride, uint32_t *out_len_dev, void *stream);
 
 /* Diagnostics: as plan_render, and additionally fills phase_cycles_dev[frame*8 + k] with shader-clock cycles
- * spent per kernel phase (0 setup, 1 gather, 2 heads, 3 lengths, 4 scan, 5 emit+drain, 6 total). */
+ * spent per kernel phase (0 setup, 1 gather, 2 heads, 3 lengths, 4 scan, 5 emit tokens, 6 drain to HBM, 7 total). */
 int asciichat_hip_plan_render_profiled(asciichat_hip_plan_t *plan, uint8_t *out_dev, size_t out_stride,
                                        uint32_t *out_len_dev, unsigned long long *phase_cycles_dev, void *stream);
 

@@ -23,7 +23,7 @@ def main():
 
     pkg = load_package()
     torch.cuda.set_device(0)
-    names = ["setup", "gather", "heads", "lengths", "scan", "emit", "total"]
+    names = ["setup", "gather", "heads", "lengths", "scan", "emit", "drain", "total"]
     for wl in args.workloads.split(","):
         sw, sh, W, H, cl, rm = bench.WORKLOADS[wl]
         frames_t = bench.make_frames(torch, args.batch, sw, sh, 1234)
@@ -59,7 +59,7 @@ def main():
             alg = int(lens.sum()) + args.batch * 3 * W * rows
             print(f"{wl:26s} v{v} kernel {ms*1e3:8.1f} us (b2b {b2b*1e3:8.1f} us) alg {alg/1e6:8.2f} MB -> "
                   f"{alg/(ms*1e-3)/1e9:7.1f} GB/s  | cycles/frame mean: " +
-                  " ".join(f"{n}={int(m)}" for n, m in zip(names, mean[:7])) + f" | max total={int(mx[6])}")
+                  " ".join(f"{n}={int(m)}" for n, m in zip(names, mean[:8])) + f" | max total={int(mx[7])}")
         plan.close()
         del frames_t, out
         torch.cuda.empty_cache()
