@@ -4,7 +4,7 @@ import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libasciichat_hip.so")
+LIB_PATH = os.environ.get("ASCIICHAT_HIP_LIB") or os.path.join(HERE, "libasciichat_hip.so")
 
 MODE_MONO, MODE_TRUE_FG, MODE_256_FG, MODE_16_FG, MODE_TRUE_BG = 0, 1, 2, 3, 4
 MODE_HB_TRUE, MODE_HB_256, MODE_HB_16, MODE_HB_MONO = 5, 6, 7, 8

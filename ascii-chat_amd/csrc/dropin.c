@@ -124,11 +124,10 @@ static const uint8_t *resolve_source(tls_ctx_t *c, const void *host_px, size_t b
   return c->stage;
 }
 
-static int variant_for(int wp) {
-  for (int v = 2; v >= 0; v--)
-    if (wp <= achip_variant_cap(v))
-      return v;
-  return -1;
+static int variant_for(int wp) { /* same policy as plan.c:pick_variant */
+  if (wp <= achip_variant_cap(4))
+    return 4;
+  return wp <= achip_variant_cap(0) ? 0 : -1;
 }
 
 /* render one frame described by `f` (f->src = HOST pixels, `src_bytes` long) and return the malloc'd string */
@@ -159,7 +158,7 @@ static char *render_one(int mode, const char *palette, achip_frame_t *f, size_t 
   desc->src = src_dev;
   volatile uint32_t *len_host = (volatile uint32_t *)(c->pin + PIN_LEN_OFF);
   *len_host = ACHIP_LEN_BADDESC;
-  if (achip_hip_check(achip_launch_render(mode, variant, (const achip_frame_t *)(c->pin_dev + PIN_DESC_OFF), 1, lut,
+  if (achip_hip_check(achip_launch_render(mode, variant, 0, (const achip_frame_t *)(c->pin_dev + PIN_DESC_OFF), 1, lut,
                                           c->pin_dev + PIN_OUT_OFF, (uint64_t)stride,
                                           (uint32_t *)(c->pin_dev + PIN_LEN_OFF), NULL, c->stream),
                       "render kernel launch"))

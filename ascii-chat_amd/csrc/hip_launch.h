@@ -11,7 +11,8 @@ extern "C" {
 #endif
 
 /* all return a hipError_t as int (0 = hipSuccess); `stream` is a hipStream_t */
-int achip_launch_render(int mode, int variant, const achip_frame_t *frames_dev, int n_frames,
+/* has_composite: some frame of the batch samples a virtual composite (achip_frame_t.comp != NULL) */
+int achip_launch_render(int mode, int variant, int has_composite, const achip_frame_t *frames_dev, int n_frames,
                         const achip_lut_t *lut_dev, uint8_t *out, uint64_t out_stride, uint32_t *out_len,
                         unsigned long long *phase_cycles /* NULL, or 8 u64 per frame (diagnostics) */, void *stream);
 int achip_launch_resize(const uint8_t *src, int sw, int sh, uint8_t *dst, int dw, int dh, void *stream);

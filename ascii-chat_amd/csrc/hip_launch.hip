@@ -11,11 +11,11 @@
 
 namespace {
 
-template <int MODE, int BLOCK, int CAP, int RING>
+template <int MODE, int BLOCK, int CAP, int RING, bool COMP>
 hipError_t launch_one(const achip_frame_t *frames, int n, const achip_lut_t *lut, uint8_t *out, uint64_t stride,
                       uint32_t *len, unsigned long long *prof, hipStream_t stream) {
   using L = achip::Lds<MODE, BLOCK, CAP, RING>;
-  auto kern = achip::render_frames_kernel<MODE, BLOCK, CAP, RING>;
+  auto kern = achip::render_frames_kernel<MODE, BLOCK, CAP, RING, COMP>;
   static bool attr_set = false; /* one flag per instantiation; benign race (idempotent call) */
   if (!attr_set) {
     if (L::bytes > 48 * 1024) {
@@ -31,12 +31,13 @@ hipError_t launch_one(const achip_frame_t *frames, int n, const achip_lut_t *lut
 }
 
 template <int BLOCK, int CAP, int RING>
-hipError_t launch_mode(int mode, const achip_frame_t *frames, int n, const achip_lut_t *lut, uint8_t *out,
+hipError_t launch_mode(int mode, bool comp, const achip_frame_t *frames, int n, const achip_lut_t *lut, uint8_t *out,
                        uint64_t stride, uint32_t *len, unsigned long long *prof, hipStream_t stream) {
   switch (mode) {
 #define M(m)                                                                                                           \
   case m:                                                                                                              \
-    return launch_one<m, BLOCK, CAP, RING>(frames, n, lut, out, stride, len, prof, stream);
+    return comp ? launch_one<m, BLOCK, CAP, RING, true>(frames, n, lut, out, stride, len, prof, stream)                \
+                : launch_one<m, BLOCK, CAP, RING, false>(frames, n, lut, out, stride, len, prof, stream);
     M(ACHIP_MODE_MONO)
     M(ACHIP_MODE_TRUE_FG)
     M(ACHIP_MODE_256_FG)
@@ -72,7 +73,7 @@ template <int BLOCK, int CAP, int RING> int lds_for_mode(int mode) {
 
 } // namespace
 
-extern "C" int achip_launch_render(int mode, int variant, const achip_frame_t *frames_dev, int n_frames,
+extern "C" int achip_launch_render(int mode, int variant, int has_composite, const achip_frame_t *frames_dev, int n_frames,
                                    const achip_lut_t *lut_dev, uint8_t *out, uint64_t out_stride, uint32_t *out_len,
                                    unsigned long long *prof, void *stream) {
   if (n_frames <= 0)
@@ -81,7 +82,7 @@ extern "C" int achip_launch_render(int mode, int variant, const achip_frame_t *f
   switch (variant) {
 #define X(id, B, C, R)                                                                                                 \
   case id:                                                                                                             \
-    return (int)launch_mode<B, C, R>(mode, frames_dev, n_frames, lut_dev, out, out_stride, out_len, prof, s);
+    return (int)launch_mode<B, C, R>(mode, has_composite != 0, frames_dev, n_frames, lut_dev, out, out_stride, out_len, prof, s);
     ACHIP_VARIANTS(X)
 #undef X
   }

@@ -124,6 +124,7 @@ struct asciichat_hip_plan {
   int variant;      /* resolved geometry */
   int variant_user; /* -1 = automatic */
   int max_wp;
+  int has_comp; /* some frame samples a virtual composite */
   size_t stride;
   achip_frame_t *frames_dev;
   achip_frame_t *frames_pinned; /* staging for async updates */
@@ -137,11 +138,11 @@ static int pick_variant(int max_wp) {
     if (achip_variant_cap(v) >= max_wp)
       return v;
   }
-  /* smallest production geometry whose chunk holds the widest padded row (variant 3 is test-only) */
-  if (max_wp <= achip_variant_cap(2))
-    return 2;
-  if (max_wp <= achip_variant_cap(1))
-    return 1;
+  /* measured on MI355X (gpurun_out/r1g, r1i): the 1024-thread / 2-cells-per-thread geometry wins on every
+   * BASELINE workload (no register spills, 4 waves per SIMD); the 4096-cell geometry only serves rows wider
+   * than 2048 cells.  Variants 1-3 remain selectable for experiments and tests. */
+  if (max_wp <= achip_variant_cap(4))
+    return 4;
   if (max_wp <= achip_variant_cap(0))
     return 0;
   return -1;
@@ -150,8 +151,11 @@ static int pick_variant(int max_wp) {
 static int plan_measure(asciichat_hip_plan_t *p, const achip_frame_t *frames) {
   size_t stride = 0;
   int max_wp = 0;
+  p->has_comp = 0;
   for (int i = 0; i < p->n; i++) {
     const achip_frame_t *f = &frames[i];
+    if (f->comp)
+      p->has_comp = 1;
     if (f->out_w <= 0 || f->out_h <= 0 || f->src_w <= 0 || f->src_h <= 0 || f->pad_left < 0 || f->pad_top < 0 ||
         (!f->src && !f->comp))
       return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame %d: bad descriptor", i);
@@ -250,7 +254,7 @@ static int render_range(asciichat_hip_plan_t *p, int first, int count, uint8_t *
                       p->stride);
   if (count == 0)
     return 0;
-  return achip_hip_check(achip_launch_render(p->mode, p->variant, p->frames_dev + first, count, p->lut_dev, out_dev,
+  return achip_hip_check(achip_launch_render(p->mode, p->variant, p->has_comp, p->frames_dev + first, count, p->lut_dev, out_dev,
                                              (uint64_t)out_stride, out_len_dev, phase_cycles_dev, stream),
                          "render kernel launch");
 }

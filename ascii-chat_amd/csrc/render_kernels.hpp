@@ -62,6 +62,10 @@ template <class T> __device__ inline T *lds_ptr(int byte_off) { return reinterpr
 /* one LDS byte store at (LDS byte address `addr`) + OFF; HI selects bits 23..16 of `v` instead of 7..0.
  * Written as asm so that neighbouring byte stores are never fused into a misaligned wide store. */
 template <int OFF, bool HI> __device__ inline void lds_store_byte(uint32_t addr, uint32_t v) {
+#if defined(ACHIP_ABLATE) && ACHIP_ABLATE == 1
+  asm volatile("" ::"v"(addr), "v"(v)); /* diagnostics: keep the operands alive, issue no store */
+  return;
+#endif
 #ifdef ACHIP_HIPEMU
   ACHIP_SMEM[addr + OFF] = (unsigned char)(HI ? v >> 16 : v);
 #else
@@ -175,16 +179,54 @@ __device__ inline bool rep_profitable(uint32_t run) {
 }
 
 /* ------------------------------------------------------------------------------------------- */
-/* token sinks.  A token is a short sequence of FIELDS of <= 4 bytes (packed little-endian in a   */
-/* u32).  One token body drives three sinks: CountSink (length pass), FastSink (token lies wholly  */
-/* inside the ring window: plain LDS byte stores, constant-length fields fold to immediate-offset  */
-/* stores) and ClipSink (token straddles a window edge or the ring's wrap point: per-byte checks). */
-/* Measured on gfx950 (scripts/ubench/lds_unaligned.hip): a ds_write_b8 costs ~1.5 cycles per      */
-/* wave-instruction per CU, a MISALIGNED ds_write_b32 ~16 -- so bytes are stored one by one        */
-/* through a volatile pointer, which also stops the compiler from fusing them into wide stores.    */
+/* wave64 inclusive scan without LDS: DPP row shifts + row broadcasts (the ds_bpermute that        */
+/* __shfl_up compiles to costs an LDS round trip per step)                                        */
 /* ------------------------------------------------------------------------------------------- */
-/* dec[v], v in 0..255: ASCII digits of v without leading zeros, first digit in the low byte, digit
- * count in bits 31..24 (the reference's dec3 table, lib/video/ascii/common.c:546-570) */
+#ifdef ACHIP_HIPEMU
+__device__ inline uint32_t wave_inclusive_scan(uint32_t v) {
+  const int l = hipemu::lane();
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t t = hipemu::shfl_from(v, l - d);
+    if (l >= d)
+      v += t;
+  }
+  return v;
+}
+__device__ inline uint32_t wave_read_lane(uint32_t v, int lane) { return hipemu::shfl_from(v, lane); }
+__device__ inline int wave_uniform(int v) { return v; }
+#else
+template <int CTRL, int ROW_MASK> __device__ inline uint32_t dpp_add(uint32_t v) {
+  /* lanes whose DPP source is invalid (or whose row is masked off) add 0 */
+  return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ inline uint32_t wave_inclusive_scan(uint32_t v) {
+  v = dpp_add<0x111, 0xF>(v); /* row_shr:1  */
+  v = dpp_add<0x112, 0xF>(v); /* row_shr:2  */
+  v = dpp_add<0x114, 0xF>(v); /* row_shr:4  */
+  v = dpp_add<0x118, 0xF>(v); /* row_shr:8  : every 16-lane row now holds its own inclusive scan */
+  v = dpp_add<0x142, 0xA>(v); /* row_bcast:15 into rows 1 and 3 */
+  v = dpp_add<0x143, 0xC>(v); /* row_bcast:31 into rows 2 and 3 */
+  return v;
+}
+__device__ inline uint32_t wave_read_lane(uint32_t v, int lane) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
+}
+__device__ inline int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+#endif
+
+/* ------------------------------------------------------------------------------------------- */
+/* token sinks.  A token is a short sequence of FIELDS of <= 4 bytes (packed little-endian in a   */
+/* u32).  One field walk drives two sinks: CountSink (length) and FastSink (plain LDS byte stores,  */
+/* constant-length fields fold to immediate-offset stores).  The few tokens that straddle a window */
+/* edge or the ring's wrap point are first written linearly into a 64-byte LDS slot by the same    */
+/* FastSink code and then copied byte-wise with the window test (see phase E).                     */
+/* Measured on gfx950 (scripts/ubench/lds_unaligned.hip): a ds_write_b8 costs ~1.5 cycles per      */
+/* wave-instruction per CU, a MISALIGNED ds_write_b32 ~16 -- so bytes are stored one by one, in    */
+/* asm, which also stops the compiler from fusing them into misaligned wide stores.                */
+/* ------------------------------------------------------------------------------------------- */
+/* ASCII digits of v (0..255) without leading zeros, first digit in the low byte, digit count in bits
+ * 31..24 -- the content of the reference's dec3 table (lib/video/ascii/common.c:546-570), computed in
+ * ~10 VALU ops instead of being looked up: no LDS dependency in the store pass, no registers held */
 __device__ inline uint32_t dec_entry(uint32_t v) {
   const uint32_t d2 = (v * 41u) >> 12, r = v - 100u * d2, d1 = (r * 205u) >> 11, d0 = r - 10u * d1;
   if (d2)
@@ -194,15 +236,31 @@ __device__ inline uint32_t dec_entry(uint32_t v) {
   return (0x30u + d0) | (1u << 24);
 }
 
-template <class L> struct CountSink {
+/* Decimal fields ("<1-3 digits><terminator>") are the variable-length part of every SGR.  The store
+ * sink takes the digits from a 256-entry LDS table (entry = digits, first in the low byte, zero padded;
+ * bits 31..24 = 8 * digit count, i.e. the shift that places the terminator) and always stores at least
+ * the bytes that are certain to be overwritten later BY THE SAME LANE: DS operations of one wave execute
+ * in order, so a 4-byte store whose tail is garbage is harmless as long as the following fields of the
+ * same token cover that tail.  ROOM = number of bytes guaranteed to follow the field inside its token;
+ * only tails that could reach past the token are predicated, and then by redirecting the store to a
+ * dummy LDS byte (one v_cndmask) instead of branching on the exec mask. */
+__device__ inline uint32_t dec_table_entry(uint32_t v) {
+  const uint32_t e = dec_entry(v);
+  return (e & 0x00FFFFFFu) | ((e >> 24) << 27);
+}
+
+struct CountSink {
   uint32_t n;
+  __device__ inline uint32_t lookup(uint32_t v) const { return 1u + (v >= 10u) + (v >= 100u); } /* digit count */
   template <int K> __device__ inline void c(uint32_t) { n += (uint32_t)K; }
   __device__ inline void v4(uint32_t, uint32_t k) { n += k; }
-  __device__ inline void num(uint32_t value, uint32_t) { n += (lds_ptr<const uint32_t>(L::o_dec)[value] >> 24) + 1u; }
+  template <int ROOM> __device__ inline void num(uint32_t digits, uint32_t) { n += digits + 1u; }
 };
 
-template <class L> struct FastSink {
-  uint32_t a; /* LDS byte address of the next byte; the token neither wraps nor leaves the window */
+template <int DEC_OFF, int DUMMY_OFF> struct FastSink {
+  uint32_t a;     /* LDS byte address of the next byte; the token neither wraps nor leaves the window */
+  uint32_t dummy; /* LDS byte address that swallows predicated-off stores */
+  __device__ inline uint32_t lookup(uint32_t v) const { return lds_ptr<const uint32_t>(DEC_OFF)[v]; }
   template <int K> __device__ inline void c(uint32_t v) {
     const uint32_t w = v >> 8;
     lds_store_byte<0, false>(a, v);
@@ -211,89 +269,33 @@ template <class L> struct FastSink {
     if (K > 3) lds_store_byte<3, true>(a, w);
     a += K;
   }
-  __device__ inline void v4(uint32_t v, uint32_t k) { /* k in 1..4 */
+  __device__ inline void v4(uint32_t v, uint32_t k) { /* k in 1..4, nothing guaranteed to follow */
     const uint32_t w = v >> 8;
     lds_store_byte<0, false>(a, v);
-    if (k > 1u) lds_store_byte<1, false>(a, w);
-    if (k > 2u) lds_store_byte<2, true>(a, v);
-    if (k > 3u) lds_store_byte<3, true>(a, w);
+    lds_store_byte<0, false>(k > 1u ? a + 1u : dummy, w);
+    lds_store_byte<0, true>(k > 2u ? a + 2u : dummy, v);
+    lds_store_byte<0, true>(k > 3u ? a + 3u : dummy, w);
     a += k;
   }
-  __device__ inline void num(uint32_t value, uint32_t term) { /* 1-3 digits + terminator */
-    const uint32_t e = lds_ptr<const uint32_t>(L::o_dec)[value], d = e >> 24;
-    const uint32_t v = (e & 0x00FFFFFFu) | (term << (8u * d)), w = v >> 8;
+  template <int ROOM> __device__ inline void num(uint32_t entry, uint32_t term) { /* 1-3 digits + terminator */
+    const uint32_t sh = entry >> 24; /* 8 * digits */
+    const uint32_t v = (entry & 0x00FFFFFFu) | (term << sh), w = v >> 8;
     lds_store_byte<0, false>(a, v);
     lds_store_byte<1, false>(a, w);
-    if (d > 1u) lds_store_byte<2, true>(a, v);
-    if (d > 2u) lds_store_byte<3, true>(a, w);
-    a += d + 1u;
+    if (ROOM >= 1)
+      lds_store_byte<2, true>(a, v);
+    else
+      lds_store_byte<0, true>(sh >= 16u ? a + 2u : dummy, v);
+    if (ROOM >= 2)
+      lds_store_byte<3, true>(a, w);
+    else
+      lds_store_byte<0, true>(sh >= (ROOM == 1 ? 16u : 24u) ? a + 3u : dummy, w);
+    a += (sh >> 3) + 1u;
   }
 };
-
-template <class L, uint32_t RING> struct ClipSink {
-  uint32_t pos;    /* absolute stream offset of the next byte */
-  uint32_t lo, hi; /* window of the stream currently backed by the ring */
-  __device__ inline void put(uint32_t b) {
-    if (pos >= lo && pos < hi)
-      lds_ptr<unsigned char>(L::o_ring)[pos & (RING - 1u)] = (unsigned char)b;
-    pos++;
-  }
-  template <int K> __device__ inline void c(uint32_t v) {
-#pragma unroll
-    for (int k = 0; k < K; k++)
-      put((v >> (8 * k)) & 0xFFu);
-  }
-  __device__ inline void v4(uint32_t v, uint32_t k) {
-    for (uint32_t j = 0; j < k; j++)
-      put((v >> (8u * j)) & 0xFFu);
-  }
-  __device__ inline void num(uint32_t value, uint32_t term) {
-    const uint32_t e = lds_ptr<const uint32_t>(L::o_dec)[value], d = e >> 24;
-    v4((e & 0x00FFFFFFu) | (term << (8u * d)), d + 1u);
-  }
-};
-
-/* ESC[38;2;R;G;Bm / ESC[48;2;R;G;Bm  (append_truecolor_fg/bg ansi.c:143-193; emit_set_fg/bg output_buffer.c:186-214) */
-template <class S> __device__ inline void put_sgr_true(S &s, bool bg, uint32_t p) {
-  s.template c<4>(bg ? 0x38345B1Bu : 0x38335B1Bu); /* ESC [ 3|4 8 */
-  s.template c<3>(0x003B323Bu);                    /* ; 2 ;       */
-  s.num(px_r(p), ';');
-  s.num(px_g(p), ';');
-  s.num(px_b(p), 'm');
-}
-/* ESC[38;5;Nm / ESC[48;5;Nm  (ansi.c:326-357) */
-template <class S> __device__ inline void put_sgr_256(S &s, bool bg, uint32_t idx) {
-  s.template c<4>(bg ? 0x38345B1Bu : 0x38335B1Bu);
-  s.template c<3>(0x003B353Bu); /* ; 5 ; */
-  s.num(idx, 'm');
-}
-/* fg 30-37/90-97, bg 40-47/100-107  (ansi.c:384-435) */
-template <class S> __device__ inline void put_sgr_16(S &s, bool bg, uint32_t idx) {
-  const uint32_t code = bg ? (idx < 8u ? 40u + idx : 92u + idx) : (idx < 8u ? 30u + idx : 82u + idx);
-  s.template c<2>(0x5B1Bu);
-  s.num(code, 'm');
-}
-template <class S> __device__ inline void put_reset(S &s) { s.template c<4>(0x6D305B1Bu); } /* ESC[0m */
-/* emit_rep: ESC[<extra>b, extra <= 4095 (a run never exceeds one chunk row) */
-template <class S> __device__ inline void put_rep(S &s, uint32_t extra) {
-  s.template c<2>(0x5B1Bu);
-  if (extra < 256u) {
-    s.num(extra, 'b');
-  } else {
-    const uint32_t d3 = extra / 1000u, r3 = extra - d3 * 1000u, d2 = r3 / 100u, r2 = r3 - d2 * 100u, d1 = r2 / 10u,
-                   d0 = r2 - d1 * 10u;
-    if (d3) {
-      s.template c<4>((0x30u + d3) | ((0x30u + d2) << 8) | ((0x30u + d1) << 16) | ((0x30u + d0) << 24));
-      s.template c<1>('b');
-    } else {
-      s.template c<4>((0x30u + d2) | ((0x30u + d1) << 8) | ((0x30u + d0) << 16) | ((uint32_t)'b' << 24));
-    }
-  }
-}
-template <class S> __device__ inline void put_glyph(S &s, uint32_t g) { s.v4(g, glyph_len(g)); }
 
 /* ------------------------------------------------------------------------------------------- */
-/* bit scans over the ballot masks (64 cells per word)                                           */
+/* bit scans over the head / ASCII masks (64 cells per word)                                     */
 /* ------------------------------------------------------------------------------------------- */
 /* largest set bit index < i, or -1 */
 __device__ inline int prev_set(const uint64_t *m, int i) {
@@ -334,25 +336,32 @@ __host__ __device__ constexpr bool mode_row_reset(int m) {
 
 template <int MODE, int BLOCK, int CAP, int RING> struct Lds {
   static constexpr int MASKW = CAP / 64 + 1;
+  static constexpr int SEG = CAP / BLOCK; /* cells per thread per chunk */
+  static constexpr int NW = BLOCK / 64;
   static constexpr int o_ring = 0;
   static constexpr int o_pixT = o_ring + RING;
   static constexpr int o_pixB = o_pixT + CAP * 4;
-  static constexpr int o_off = o_pixB + (mode_is_halfblock(MODE) ? CAP * 4 : 0);
-  static constexpr int o_hmask = o_off + (CAP + 4) * 4;
+  static constexpr int o_hmask = o_pixB + (mode_is_halfblock(MODE) ? CAP * 4 : 0);
   static constexpr int o_amask = o_hmask + MASKW * 8;
   static constexpr int o_glyph = o_amask + MASKW * 8;
   static constexpr int o_glyph64 = o_glyph + 256 * 4;
   static constexpr int o_ramp = o_glyph64 + 64 * 4;
-  static constexpr int o_dec = o_ramp + 64;
-  static constexpr int o_wsum = o_dec + 256 * 4;
-  static constexpr int bytes = o_wsum + (BLOCK / 64) * 4 + 16;
+  static constexpr int o_dec = o_ramp + 64;     /* 256 decimal-field entries */
+  static constexpr int o_wsum = o_dec + 256 * 4; /* SEG*NW wave totals (<= 64) */
+  static constexpr int o_flags = o_wsum + 64 * 4; /* [0] palette-not-all-ASCII, [1] straddler slot counter, [2] dummy store target */
+  static constexpr int o_strad = o_flags + 16;    /* STRAD_SLOTS x 64-byte linear token slots              */
+  static constexpr int STRAD_SLOTS = 8;           /* <= 3 tokens can straddle per window (lo, hi, wrap)    */
+  static constexpr int o_prof = o_strad + STRAD_SLOTS * 64; /* 8 x u64 diagnostics accumulators */
+  static constexpr int bytes = o_prof + 8 * 8;
+  static_assert(SEG * NW <= 64, "wave-total table must fit one wave");
 };
 
 /* ------------------------------------------------------------------------------------------- */
 /* sampling (R1) and the fused pixel-space composite (C2)                                        */
 /* ------------------------------------------------------------------------------------------- */
 __device__ inline uint32_t load_rgb(const uint8_t *__restrict__ src, int32_t stride_bytes, uint32_t x, uint32_t y) {
-  const size_t a = (size_t)y * (size_t)stride_bytes + (size_t)x * 3u;
+  /* a frame is at most 3840x2160x3 = 24.9 MB: 32-bit offsets keep the address in (SGPR base + VGPR offset) form */
+  const uint32_t a = y * (uint32_t)stride_bytes + x * 3u;
   const ACHIP_GLOBAL uint8_t *p = (const ACHIP_GLOBAL uint8_t *)src + a;
   if (a == 0) /* first pixel of the buffer: nothing in front of it to borrow a byte from */
     return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
@@ -383,31 +392,65 @@ __device__ inline uint32_t sample_composite(const achip_composite_t *__restrict_
   return load_rgb(s->src, s->src_stride, sx, sy);
 }
 
-/* sample (x, y) of the out_w x out_h resized image that the reference would have built */
-__device__ inline uint32_t sample_frame(const achip_frame_t &f, uint32_t x, uint32_t y) {
+/* sample (x, y) of the out_w x out_h resized image that the reference would have built.
+ * COMP selects the virtual-composite sampler at compile time (its own kernel instantiation), so the
+ * common single-source kernels carry none of its address arithmetic. */
+template <bool COMP> __device__ inline uint32_t sample_frame(const achip_frame_t &f, uint32_t x, uint32_t y) {
   uint32_t sx = (x * f.x_ratio) >> 16, sy = (y * f.y_ratio) >> 16;
   sx = min(sx, (uint32_t)f.src_w - 1u);
   sy = min(sy, (uint32_t)f.src_h - 1u);
-  if (f.comp)
-    return sample_composite(f.comp, sx, sy);
+#if defined(ACHIP_ABLATE) && ACHIP_ABLATE == 3
+  return (sx * 2654435761u + sy * 40503u) & 0x00FFFFFFu; /* diagnostics: no memory access */
+#endif
+  if (COMP)
+    return f.comp ? sample_composite(f.comp, sx, sy) : load_rgb(f.src, f.src_stride, sx, sy);
   return load_rgb(f.src, f.src_stride, sx, sy);
 }
 
 /* ------------------------------------------------------------------------------------------- */
-/* per-chunk view handed to the token bodies                                                     */
+/* tokens.  build_token() takes every decision the reference's sequential emitters take for one   */
+/* cell (all LDS look-ups happen here) and leaves a register-resident descriptor; token_fields()   */
+/* walks the descriptor into a sink.  The descriptor is built once per cell and used for the       */
+/* length pass and for the store pass(es).                                                         */
 /* ------------------------------------------------------------------------------------------- */
+enum : uint32_t {
+  TF_PAD = 1u << 0,         /* padding pseudo-cell: one space                          */
+  TF_RESET_PRE = 1u << 1,   /* ESC[0m before a transparent run (half-block)            */
+  TF_SGR_FG = 1u << 2,      /* foreground SGR                                          */
+  TF_SGR_BG = 1u << 3,      /* background SGR                                          */
+  TF_SPACE = 1u << 4,       /* a space instead of a glyph (transparent half-block)     */
+  TF_GLYPH = 1u << 5,       /* the glyph                                               */
+  TF_REP = 1u << 6,         /* ESC[<rep>b after the glyph                              */
+  TF_ROW_RESET = 1u << 7,   /* ESC[0m at the end of the text row                       */
+  TF_NL = 1u << 8,          /* newline after the row                                   */
+  TF_FINAL_RESET = 1u << 9, /* the single trailing ESC[0m of image_print_color         */
+  TF_FG_WHITE = 1u << 10,   /* PB: contrasting foreground is white (else black)        */
+};
+
+struct Tok {
+  uint32_t flags;
+  uint32_t fg; /* 0x00BBGGRR (truecolor) or palette index / SGR code (256/16-colour) */
+  uint32_t bg;
+  uint32_t glyph;
+  uint32_t rep;
+};
+
 struct Chunk {
   int n;           /* cells in this chunk (pad pseudo-cells included) */
   int wp;          /* cells per text row = pad_left + out_w           */
   int pad_left;
-  int r0;          /* first text row of the chunk                     */
   int rows;        /* text rows in the frame                          */
-  bool carry_have; /* PT: an ASCII-glyph pixel exists before this chunk */
+  bool all_ascii;  /* PT: every glyph of the palette is a single ASCII byte */
+  bool carry_have; /* PT: an ASCII-glyph pixel exists before this chunk     */
   uint32_t carry_rgb;
 };
 
-/* The token owned by cell i (text row r, column xp inside the padded row). */
-template <int MODE, class L, class S> __device__ inline void emit_token(S &s, const Chunk &c, int i, int r, int xp) {
+__device__ inline uint32_t sgr16_code(bool bg, uint32_t idx) { /* fg 30-37/90-97, bg 40-47/100-107 (ansi.c:384-435) */
+  return bg ? (idx < 8u ? 40u + idx : 92u + idx) : (idx < 8u ? 30u + idx : 82u + idx);
+}
+
+/* the token owned by cell i of the chunk (text row r of the frame, rr within the chunk, column xp of the padded row) */
+template <int MODE, class L> __device__ inline Tok build_token(const Chunk &c, int i, int r, int rr, int xp) {
   const uint32_t *pixT = lds_ptr<const uint32_t>(L::o_pixT);
   const uint32_t *pixB = lds_ptr<const uint32_t>(L::o_pixB);
   const uint64_t *hmask = lds_ptr<const uint64_t>(L::o_hmask);
@@ -415,10 +458,14 @@ template <int MODE, class L, class S> __device__ inline void emit_token(S &s, co
   const uint32_t *glyph = lds_ptr<const uint32_t>(L::o_glyph);
   const uint32_t *glyph64 = lds_ptr<const uint32_t>(L::o_glyph64);
   const uint8_t *ramp = lds_ptr<const uint8_t>(L::o_ramp);
-  (void)pixB; (void)hmask; (void)amask; (void)glyph; (void)glyph64; (void)ramp;
+  (void)pixB; (void)hmask; (void)amask; (void)glyph; (void)glyph64; (void)ramp; (void)rr;
+
+  Tok t;
+  t.flags = 0;
+  t.fg = t.bg = t.glyph = t.rep = 0;
   if (xp < c.pad_left) { /* ascii_pad_frame_width: pad_left spaces in front of every row */
-    s.template c<1>(' ');
-    return;
+    t.flags = TF_PAD;
+    return t;
   }
   const uint32_t pt = pixT[i];
 
@@ -428,27 +475,39 @@ template <int MODE, class L, class S> __device__ inline void emit_token(S &s, co
      * any other glyph -> SGR always, state untouched. */
     const uint32_t g = glyph[luma601(pt)];
     bool sgr = true;
-    if ((g & 0xFFu) < 128u) {
+    if (c.all_ascii) {
+      /* previous pixel in raster order: left neighbour, or the last pixel of the previous row */
+      int j = xp > c.pad_left ? i - 1 : (rr > 0 ? i - 1 - c.pad_left : -1);
+      if (j >= 0)
+        sgr = px_rgb(pixT[j]) != px_rgb(pt);
+      else if (c.carry_have)
+        sgr = c.carry_rgb != px_rgb(pt);
+    } else if ((g & 0xFFu) < 128u) {
       const int j = prev_set(amask, i);
       if (j >= 0)
         sgr = px_rgb(pixT[j]) != px_rgb(pt);
       else if (c.carry_have)
         sgr = c.carry_rgb != px_rgb(pt);
     }
-    if (sgr)
-      put_sgr_true(s, false, pt);
-    put_glyph(s, g);
+    if (sgr) {
+      t.flags |= TF_SGR_FG;
+      t.fg = px_rgb(pt);
+    }
+    t.flags |= TF_GLYPH;
+    t.glyph = g;
   } else if (MODE == ACHIP_MODE_256_FG) { /* foreground.c:475-500 */
-    put_sgr_256(s, false, quant256(pt));
-    put_glyph(s, glyph[luma601(pt)]);
+    t.flags |= TF_SGR_FG | TF_GLYPH;
+    t.fg = quant256(pt);
+    t.glyph = glyph[luma601(pt)];
   } else if (MODE == ACHIP_MODE_16_FG) { /* foreground.c:584-612: glyph = cache[ramp[Y>>2]] (sic) */
-    put_sgr_16(s, false, quant16(pt));
-    put_glyph(s, glyph[ramp[luma601(pt) >> 2]]);
+    t.flags |= TF_SGR_FG | TF_GLYPH;
+    t.fg = sgr16_code(false, quant16(pt));
+    t.glyph = glyph[ramp[luma601(pt) >> 2]];
   } else if (MODE == ACHIP_MODE_TRUE_BG) { /* background.c:49-68 */
     const uint32_t Y = luma601(pt);
-    put_sgr_true(s, true, pt);
-    put_sgr_true(s, false, Y < 128u ? 0x00FFFFFFu : 0u);
-    put_glyph(s, glyph[Y]);
+    t.flags |= TF_SGR_BG | TF_SGR_FG | TF_GLYPH | (Y < 128u ? TF_FG_WHITE : 0u);
+    t.bg = px_rgb(pt);
+    t.glyph = glyph[Y];
   } else {
     /* run-structured modes: head h, end e, run = e - h */
     const bool is_head = (hmask[i >> 6] >> (i & 63)) & 1ull;
@@ -456,29 +515,28 @@ template <int MODE, class L, class S> __device__ inline void emit_token(S &s, co
     const int e = next_set(hmask, i);
     const uint32_t run = (uint32_t)(e - h);
     const bool rep = rep_profitable(run);
+    if (is_head && rep) {
+      t.flags |= TF_REP;
+      t.rep = run - 1u;
+    }
 
     if (MODE == ACHIP_MODE_MONO) {
       /* image_print (foreground.c:86-127): key = ramp[Y>>2], glyph = cache64[key] (double mapping) */
-      const uint32_t g = glyph64[px_key(pt)];
-      if (is_head) {
-        put_glyph(s, g);
-        if (rep)
-          put_rep(s, run - 1u);
-      } else if (!rep) {
-        put_glyph(s, g);
-      }
+      t.glyph = glyph64[px_key(pt)];
+      if (is_head || !rep)
+        t.flags |= TF_GLYPH;
     } else if (MODE == ACHIP_MODE_HB_MONO) {
       /* rgb_to_halfblocks_scalar (halfblock.c:203-275): 76/150/29 luminance, no rounding term */
       const uint32_t pb = pixB[i];
       const uint32_t lt = (76u * px_r(pt) + 150u * px_g(pt) + 29u * px_b(pt)) >> 8;
       const uint32_t lb = (76u * px_r(pb) + 150u * px_g(pb) + 29u * px_b(pb)) >> 8;
       if (lt < 16u && lb < 16u) {
-        s.template c<1>(' ');
-      } else if (is_head || !rep) {
+        t.flags = TF_SPACE; /* no REP for padding */
+      } else {
         const uint32_t sh = lt >> 6; /* U+2591 U+2592 U+2593 U+2588 = E2 96 91|92|93|88 */
-        s.template c<3>(0x0096E2u | ((sh == 3u ? 0x88u : 0x91u + sh) << 16));
-        if (is_head && rep)
-          put_rep(s, run - 1u);
+        t.glyph = 0x0096E2u | ((sh == 3u ? 0x88u : 0x91u + sh) << 16);
+        if (is_head || !rep)
+          t.flags |= TF_GLYPH;
       }
     } else {
       /* HT / H256 / H16 (halfblock.c:48-165, 297-524): transparency is decided by the run HEAD's raw
@@ -495,32 +553,33 @@ template <int MODE, class L, class S> __device__ inline void emit_token(S &s, co
         state_set = (px_rgb(pT) | px_rgb(pB)) != 0u;
       }
       if (transparent) {
-        if (is_head && state_set)
-          put_reset(s);
-        s.template c<1>(' ');
+        t.flags = TF_SPACE | ((is_head && state_set) ? TF_RESET_PRE : 0u);
       } else {
+        t.glyph = 0x8096E2u; /* U+2580 upper half block = E2 96 80 */
+        if (is_head || !rep)
+          t.flags |= TF_GLYPH;
         if (is_head) {
           if (MODE == ACHIP_MODE_HB_TRUE) {
-            if (!state_set || px_rgb(pT) != px_rgb(hT))
-              put_sgr_true(s, false, hT);
-            if (!state_set || px_rgb(pB) != px_rgb(hB))
-              put_sgr_true(s, true, hB);
-          } else if (MODE == ACHIP_MODE_HB_256) {
-            if (!state_set || px_key(pT) != px_key(hT))
-              put_sgr_256(s, false, px_key(hT));
-            if (!state_set || px_key(pB) != px_key(hB))
-              put_sgr_256(s, true, px_key(hB));
+            if (!state_set || px_rgb(pT) != px_rgb(hT)) {
+              t.flags |= TF_SGR_FG;
+              t.fg = px_rgb(hT);
+            }
+            if (!state_set || px_rgb(pB) != px_rgb(hB)) {
+              t.flags |= TF_SGR_BG;
+              t.bg = px_rgb(hB);
+            }
           } else {
-            if (!state_set || px_key(pT) != px_key(hT))
-              put_sgr_16(s, false, px_key(hT));
-            if (!state_set || px_key(pB) != px_key(hB))
-              put_sgr_16(s, true, px_key(hB));
+            const bool is256 = MODE == ACHIP_MODE_HB_256;
+            if (!state_set || px_key(pT) != px_key(hT)) {
+              t.flags |= TF_SGR_FG;
+              t.fg = is256 ? px_key(hT) : sgr16_code(false, px_key(hT));
+            }
+            if (!state_set || px_key(pB) != px_key(hB)) {
+              t.flags |= TF_SGR_BG;
+              t.bg = is256 ? px_key(hB) : sgr16_code(true, px_key(hB));
+            }
           }
         }
-        if (is_head || !rep) /* U+2580 upper half block = E2 96 80 */
-          s.template c<3>(0x8096E2u);
-        if (is_head && rep)
-          put_rep(s, run - 1u);
       }
     }
   }
@@ -528,12 +587,118 @@ template <int MODE, class L, class S> __device__ inline void emit_token(S &s, co
   /* end of a text row */
   if (xp == c.wp - 1) {
     if (mode_row_reset(MODE))
-      put_reset(s);
+      t.flags |= TF_ROW_RESET;
     if (r < c.rows - 1)
-      s.template c<1>('\n');
+      t.flags |= TF_NL;
     else if (MODE == ACHIP_MODE_TRUE_FG)
-      put_reset(s); /* ansi_rle_finish: the single trailing ESC[0m */
+      t.flags |= TF_FINAL_RESET; /* ansi_rle_finish: the single trailing ESC[0m */
   }
+  return t;
+}
+
+/* ESC[38;2;R;G;Bm / ESC[48;2;R;G;Bm  (append_truecolor_fg/bg ansi.c:143-193; emit_set_fg/bg output_buffer.c:186-214).
+ * ROOM = bytes of the same token guaranteed to follow the SGR. */
+template <int ROOM, class S> __device__ inline void put_sgr_true(S &s, bool bg, uint32_t rgb) {
+  const uint32_t e0 = s.lookup(px_r(rgb)), e1 = s.lookup(px_g(rgb)), e2 = s.lookup(px_b(rgb));
+  s.template c<4>(bg ? 0x38345B1Bu : 0x38335B1Bu); /* ESC [ 3|4 8 */
+  s.template c<3>(0x003B323Bu);                    /* ; 2 ;       */
+  s.template num<2>(e0, ';');
+  s.template num<2>(e1, ';');
+  s.template num<ROOM>(e2, 'm');
+}
+/* ESC[38;5;Nm / ESC[48;5;Nm  (ansi.c:326-357) */
+template <int ROOM, class S> __device__ inline void put_sgr_256(S &s, bool bg, uint32_t idx) {
+  const uint32_t e = s.lookup(idx);
+  s.template c<4>(bg ? 0x38345B1Bu : 0x38335B1Bu);
+  s.template c<3>(0x003B353Bu); /* ; 5 ; */
+  s.template num<ROOM>(e, 'm');
+}
+/* ESC[<code>m */
+template <int ROOM, class S> __device__ inline void put_sgr_16(S &s, uint32_t code) {
+  const uint32_t e = s.lookup(code);
+  s.template c<2>(0x5B1Bu);
+  s.template num<ROOM>(e, 'm');
+}
+template <class S> __device__ inline void put_reset(S &s) { s.template c<4>(0x6D305B1Bu); } /* ESC[0m */
+/* emit_rep (output_buffer.c:157-164): ESC[<extra>b, extra <= 4095 (a run never exceeds one chunk row) */
+template <class S> __device__ inline void put_rep(S &s, uint32_t extra) {
+  s.template c<2>(0x5B1Bu);
+  if (extra < 256u) {
+    const uint32_t e = s.lookup(extra);
+    s.template num<0>(e, 'b');
+  } else {
+    const uint32_t d3 = extra / 1000u, r3 = extra - d3 * 1000u, d2 = r3 / 100u, r2 = r3 - d2 * 100u, d1 = r2 / 10u,
+                   d0 = r2 - d1 * 10u;
+    if (d3) {
+      s.template c<4>((0x30u + d3) | ((0x30u + d2) << 8) | ((0x30u + d1) << 16) | ((0x30u + d0) << 24));
+      s.template c<1>('b');
+    } else {
+      s.template c<4>((0x30u + d2) | ((0x30u + d1) << 8) | ((0x30u + d0) << 16) | ((uint32_t)'b' << 24));
+    }
+  }
+}
+
+/* ascii_only: every glyph of the palette is one byte (uniform per frame) */
+template <int MODE, class S> __device__ inline void token_fields(S &s, const Tok &t, bool ascii_only) {
+  const uint32_t f = t.flags;
+  if (f & TF_PAD) {
+    s.template c<1>(' ');
+    return;
+  }
+  if (mode_is_halfblock(MODE) && (f & TF_RESET_PRE))
+    put_reset(s);
+  if (MODE == ACHIP_MODE_TRUE_BG) { /* background SGR first, then the contrasting foreground (background.c:53-62) */
+    put_sgr_true<3>(s, true, t.bg); /* the fixed foreground SGR follows */
+    if (f & TF_FG_WHITE) {
+      s.template c<4>(0x38335B1Bu); /* ESC[38;2;255;255;255m */
+      s.template c<4>(0x323B323Bu);
+      s.template c<4>(0x323B3535u);
+      s.template c<4>(0x323B3535u);
+      s.template c<3>(0x006D3535u);
+    } else {
+      s.template c<4>(0x38335B1Bu); /* ESC[38;2;0;0;0m */
+      s.template c<4>(0x303B323Bu);
+      s.template c<4>(0x303B303Bu);
+      s.template c<1>('m');
+    }
+  } else {
+    if (f & TF_SGR_FG) {
+      /* what is certain to follow a foreground SGR: the glyph -- 3 bytes in half-block modes, >= 1 otherwise */
+      constexpr int ROOM = mode_is_halfblock(MODE) ? 3 : 1;
+      if (MODE == ACHIP_MODE_TRUE_FG || MODE == ACHIP_MODE_HB_TRUE)
+        put_sgr_true<ROOM>(s, false, t.fg);
+      else if (MODE == ACHIP_MODE_256_FG || MODE == ACHIP_MODE_HB_256)
+        put_sgr_256<ROOM>(s, false, t.fg);
+      else if (MODE == ACHIP_MODE_16_FG || MODE == ACHIP_MODE_HB_16)
+        put_sgr_16<ROOM>(s, t.fg);
+    }
+    if (mode_is_halfblock(MODE) && (f & TF_SGR_BG)) {
+      if (MODE == ACHIP_MODE_HB_TRUE) /* a background SGR is always followed by the 3-byte half block */
+        put_sgr_true<3>(s, true, t.bg);
+      else if (MODE == ACHIP_MODE_HB_256)
+        put_sgr_256<3>(s, true, t.bg);
+      else if (MODE == ACHIP_MODE_HB_16)
+        put_sgr_16<3>(s, t.bg);
+    }
+  }
+  if (mode_is_halfblock(MODE) && (f & TF_SPACE))
+    s.template c<1>(' ');
+  if (f & TF_GLYPH) {
+    if (mode_is_halfblock(MODE))
+      s.template c<3>(t.glyph);
+    else if (ascii_only)
+      s.template c<1>(t.glyph);
+    else
+      s.v4(t.glyph, glyph_len(t.glyph));
+  }
+  if (mode_has_runs(MODE) && (f & TF_REP))
+    put_rep(s, t.rep);
+  if (f & TF_ROW_RESET)
+    put_reset(s);
+  if (f & TF_NL)
+    s.template c<1>('\n');
+  if (f & TF_FINAL_RESET)
+    put_reset(s);
 }
 
 /* i / wp via the per-frame magic multiplier (magic == 0 encodes wp == 1) */
@@ -551,16 +716,17 @@ template <int MODE> __device__ inline bool same_run(const uint32_t *pixT, const 
 /* ------------------------------------------------------------------------------------------- */
 /* the frame kernel                                                                              */
 /* ------------------------------------------------------------------------------------------- */
-template <int MODE, int BLOCK, int CAP, int RING>
-__device__ inline void drain_ring(unsigned char *ring, uint8_t *__restrict__ out, uint32_t from, uint32_t to) {
+template <int BLOCK, int RING>
+__device__ inline void drain_ring(int ring_off, uint8_t *__restrict__ out, uint32_t from, uint32_t to) {
   /* [from, to) are stream offsets, from is 16-byte aligned; full 16-byte groups go out as uint4 */
+  const unsigned char *ring = lds_ptr<const unsigned char>(ring_off);
   const uint32_t vec_end = to & ~15u;
   for (uint32_t o = from + 16u * threadIdx.x; o < vec_end; o += 16u * BLOCK)
     *reinterpret_cast<uint4 *>(out + o) = *reinterpret_cast<const uint4 *>(ring + (o & (RING - 1u)));
 }
 
 /* optional per-phase cycle accounting (diagnostics: prof == NULL in production launches).
- * prof[frame*8 + k]: 0 setup+pad_top, 1 gather, 2 heads, 3 lengths, 4 scan, 5 emit tokens, 6 drain, 7 total */
+ * prof[frame*8 + k]: 0 setup+pad_top, 1 gather, 2 heads, 3 tokens+lengths, 4 scan, 5 token stores, 6 drain, 7 total */
 #ifdef ACHIP_HIPEMU
 __device__ inline unsigned long long cycle_now() { return 0ull; }
 #else
@@ -568,39 +734,38 @@ __device__ inline unsigned long long cycle_now() { return (unsigned long long)cl
 #endif
 #define ACHIP_STAMP(slot)                                                                                              \
   do {                                                                                                                 \
-    if (prof) {                                                                                                        \
+    if (prof && tid == 0) { /* accumulators live in LDS: no registers are held for diagnostics */                     \
+      unsigned long long *pa = lds_ptr<unsigned long long>(L::o_prof);                                                 \
       const unsigned long long t_now = cycle_now();                                                                    \
-      t_acc[slot] += t_now - t_prev;                                                                                   \
-      t_prev = t_now;                                                                                                  \
+      pa[slot] += t_now - pa[7];                                                                                       \
+      pa[7] = t_now;                                                                                                   \
     }                                                                                                                  \
   } while (0)
 
-template <int MODE, int BLOCK, int CAP, int RING>
+template <int MODE, int BLOCK, int CAP, int RING, bool COMP>
 __global__ void __launch_bounds__(BLOCK)
     render_frames_kernel(const achip_frame_t *__restrict__ frames, const achip_lut_t *__restrict__ lut,
                          uint8_t *__restrict__ out, uint64_t out_stride, uint32_t *__restrict__ out_len, int n_frames,
                          unsigned long long *__restrict__ prof) {
   using L = Lds<MODE, BLOCK, CAP, RING>;
   constexpr bool HB = mode_is_halfblock(MODE);
-  constexpr int NW = BLOCK / 64;
-  constexpr int SEG = CAP / BLOCK;
+  constexpr int NW = L::NW;
+  constexpr int SEG = L::SEG;
   static_assert(CAP % BLOCK == 0 && (RING & (RING - 1)) == 0 && RING % 16 == 0, "geometry");
 
-  unsigned char *smem = ACHIP_SMEM;
-  unsigned char *ring = smem + L::o_ring;
-  uint32_t *pixT = reinterpret_cast<uint32_t *>(smem + L::o_pixT);
-  uint32_t *pixB = reinterpret_cast<uint32_t *>(smem + L::o_pixB);
-  uint32_t *off = reinterpret_cast<uint32_t *>(smem + L::o_off);
-  uint64_t *hmask = reinterpret_cast<uint64_t *>(smem + L::o_hmask);
-  uint64_t *amask = reinterpret_cast<uint64_t *>(smem + L::o_amask);
-  uint32_t *glyph = reinterpret_cast<uint32_t *>(smem + L::o_glyph);
-  uint32_t *glyph64 = reinterpret_cast<uint32_t *>(smem + L::o_glyph64);
-  uint8_t *ramp = smem + L::o_ramp;
-  uint32_t *dec = reinterpret_cast<uint32_t *>(smem + L::o_dec);
-  uint32_t *wsum = reinterpret_cast<uint32_t *>(smem + L::o_wsum);
+  unsigned char *ring = lds_ptr<unsigned char>(L::o_ring);
+  uint32_t *pixT = lds_ptr<uint32_t>(L::o_pixT);
+  uint32_t *pixB = lds_ptr<uint32_t>(L::o_pixB);
+  uint64_t *hmask = lds_ptr<uint64_t>(L::o_hmask);
+  uint64_t *amask = lds_ptr<uint64_t>(L::o_amask);
+  uint32_t *glyph = lds_ptr<uint32_t>(L::o_glyph);
+  uint32_t *glyph64 = lds_ptr<uint32_t>(L::o_glyph64);
+  uint8_t *ramp = lds_ptr<uint8_t>(L::o_ramp);
+  uint32_t *wsum = lds_ptr<uint32_t>(L::o_wsum);
+  uint32_t *flags = lds_ptr<uint32_t>(L::o_flags);
 
   const int tid = (int)threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = wave_uniform(tid >> 6);
   const int fidx = (int)blockIdx.x;
   if (fidx >= n_frames)
     return;
@@ -612,20 +777,40 @@ __global__ void __launch_bounds__(BLOCK)
   const int wp = f.pad_left + f.out_w;
   const int rows = HB ? (f.out_h + 1) / 2 : f.out_h;
   if (f.out_w <= 0 || f.out_h <= 0 || f.src_w <= 0 || f.src_h <= 0 || f.pad_left < 0 || f.pad_top < 0 || wp > CAP ||
-      (!f.src && !f.comp)) {
+      (!f.src && !f.comp) || (!COMP && f.comp)) {
     if (tid == 0)
       out_len[fidx] = ACHIP_LEN_BADDESC;
     return;
   }
 
-  /* glyph tables -> LDS; decimal table generated in place */
-  for (int k = tid; k < 256; k += BLOCK) {
-    glyph[k] = lut->glyph[k];
-    dec[k] = dec_entry((uint32_t)k);
+  unsigned long long t_start = 0ull;
+  if (prof && tid == 0) {
+    unsigned long long *pa = lds_ptr<unsigned long long>(L::o_prof);
+    for (int k = 0; k < 7; k++)
+      pa[k] = 0ull;
+    pa[7] = t_start = cycle_now();
   }
-  for (int k = tid; k < 64; k += BLOCK) {
-    glyph64[k] = lut->glyph64[k];
-    ramp[k] = lut->ramp[k];
+
+  /* glyph tables -> LDS; is every glyph a single ASCII byte? */
+  if (tid == 0) {
+    flags[0] = 0u;
+    flags[1] = 0u;
+  }
+  __syncthreads();
+  {
+    bool non_ascii = false;
+    for (int k = tid; k < 256; k += BLOCK) {
+      const uint32_t g = lut->glyph[k];
+      glyph[k] = g;
+      lds_ptr<uint32_t>(L::o_dec)[k] = dec_table_entry((uint32_t)k);
+      non_ascii |= (g & 0xFFu) >= 128u;
+    }
+    for (int k = tid; k < 64; k += BLOCK) {
+      glyph64[k] = lut->glyph64[k];
+      ramp[k] = lut->ramp[k];
+    }
+    if (non_ascii)
+      flags[0] = 1u; /* benign race: every writer stores the same value */
   }
 
   /* i / wp == umulhi(i, magic) for i, wp <= CAP (i * wp < 2^32); wp == 1 would need magic 2^32 */
@@ -633,16 +818,12 @@ __global__ void __launch_bounds__(BLOCK)
   const int rows_per_chunk = max(1, CAP / wp);
   const uint32_t cap_bytes = out_stride > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)out_stride;
   const uint32_t ring_addr = lds_base_addr() + (uint32_t)L::o_ring;
-
-  unsigned long long t_acc[7] = {0, 0, 0, 0, 0, 0, 0};
-  unsigned long long t_prev = prof ? cycle_now() : 0ull;
-  const unsigned long long t_start = t_prev;
+  const uint32_t strad_addr = lds_base_addr() + (uint32_t)L::o_strad;
+  const uint32_t dummy_addr = lds_base_addr() + (uint32_t)L::o_flags + 8u;
 
   uint32_t base = 0;    /* stream bytes produced before the current chunk */
   uint32_t flushed = 0; /* stream bytes already in HBM (multiple of 16)   */
   bool overflow = false;
-  bool carry_have = false;
-  uint32_t carry_rgb = 0;
 
   /* ascii_pad_frame_height: pad_top bare newlines */
   if (f.pad_top > 0) {
@@ -654,74 +835,93 @@ __global__ void __launch_bounds__(BLOCK)
       for (uint32_t o = base + (uint32_t)tid; o < hi; o += BLOCK)
         ring[o & (RING - 1u)] = '\n';
       __syncthreads();
-      drain_ring<MODE, BLOCK, CAP, RING>(ring, dst, flushed, hi);
+      drain_ring<BLOCK, RING>(L::o_ring, dst, flushed, hi);
       __syncthreads();
       flushed = hi & ~15u;
       base = hi;
     }
   }
   __syncthreads();
+
+  Chunk c;
+  c.wp = wp;
+  c.pad_left = f.pad_left;
+  c.rows = rows;
+  const bool ascii_only = flags[0] == 0u;
+  c.all_ascii = MODE == ACHIP_MODE_TRUE_FG && ascii_only;
+  c.carry_have = false;
+  c.carry_rgb = 0;
+  /* gather: all of a thread's samples of a chunk are requested before any is consumed, so a thread keeps
+   * up to 2*SEG sparse fetches in flight; cell i_k = tid + k*BLOCK (lane <-> consecutive cells) */
+  uint32_t gt[SEG], gb[SEG];
+  auto gather_issue = [&](int row0, int cells) {
+#pragma unroll
+    for (int k = 0; k < SEG; k++) {
+      const int i = tid + k * BLOCK;
+      const int rr = row_of(i, wp_magic);
+      const int xp = i - rr * wp;
+      gt[k] = 0;
+      gb[k] = 0;
+      if (i < cells && xp >= f.pad_left) {
+        const uint32_t x = (uint32_t)(xp - f.pad_left);
+        const uint32_t r = (uint32_t)(row0 + rr);
+        if (HB) {
+          const uint32_t yt = 2u * r, yb = 2u * r + 1u;
+          gt[k] = sample_frame<COMP>(f, x, yt);
+          /* odd height: the last text row's bottom half repeats the top (halfblock.c:81-88) */
+          gb[k] = yb < (uint32_t)f.out_h ? sample_frame<COMP>(f, x, yb) : 0xFFFFFFFFu;
+        } else {
+          gt[k] = sample_frame<COMP>(f, x, r);
+        }
+      }
+    }
+  };
+  gather_issue(0, min(rows, rows_per_chunk) * wp);
   ACHIP_STAMP(0);
 
   for (int r0 = 0; r0 < rows; r0 += rows_per_chunk) {
     const int r1 = min(rows, r0 + rows_per_chunk);
     const int n = (r1 - r0) * wp;
+    c.n = n;
 
-    /* ---- A: gather: all of a thread's samples are requested before any is consumed, so a thread
-     * keeps up to 2*SEG sparse 64-byte-sector fetches in flight ---------------------------------- */
-    {
-      uint32_t gt[SEG], gb[SEG];
+    /* per-thread cell coordinates: cell i_k = tid + k*BLOCK (lane <-> consecutive cells keeps the LDS
+     * byte stores of a wave spread over the banks) */
+#define ACHIP_CELL_RR(k) row_of(tid + (k)*BLOCK, wp_magic)
+#define ACHIP_CELL_XP(k) (tid + (k)*BLOCK - ACHIP_CELL_RR(k) * wp)
+
+    /* ---- A: commit the samples requested one chunk ago (see the prefetch below) to LDS, with the
+     * mode's run key in bits 31..24 ------------------------------------------------------------- */
 #pragma unroll
-      for (int k = 0; k < SEG; k++) {
-        const int i = tid + k * BLOCK;
-        gt[k] = 0;
-        gb[k] = 0;
-        if (i < n) {
-          const int rr = row_of(i, wp_magic);
-          const int xp = i - rr * wp;
-          if (xp >= f.pad_left) {
-            const uint32_t x = (uint32_t)(xp - f.pad_left);
-            const uint32_t r = (uint32_t)(r0 + rr);
-            if (HB) {
-              const uint32_t yt = 2u * r, yb = 2u * r + 1u;
-              gt[k] = sample_frame(f, x, yt);
-              /* odd height: the last text row's bottom half repeats the top (halfblock.c:81-88) */
-              gb[k] = yb < (uint32_t)f.out_h ? sample_frame(f, x, yb) : 0xFFFFFFFFu;
-            } else {
-              gt[k] = sample_frame(f, x, r);
-            }
+    for (int k = 0; k < SEG; k++) {
+      const int i = tid + k * BLOCK;
+      if (i < n) {
+        uint32_t pt = gt[k], pb = gb[k] == 0xFFFFFFFFu ? gt[k] : gb[k];
+        if (ACHIP_CELL_XP(k) >= f.pad_left) {
+          if (MODE == ACHIP_MODE_HB_256) {
+            pt |= quant256(pt) << 24;
+            pb |= quant256(pb) << 24;
+          } else if (MODE == ACHIP_MODE_HB_16) {
+            pt |= quant16(pt) << 24;
+            pb |= quant16(pb) << 24;
+          } else if (MODE == ACHIP_MODE_MONO) {
+            pt |= (uint32_t)ramp[luma601(pt) >> 2] << 24;
           }
         }
-      }
-#pragma unroll
-      for (int k = 0; k < SEG; k++) {
-        const int i = tid + k * BLOCK;
-        if (i < n) {
-          uint32_t pt = gt[k], pb = gb[k] == 0xFFFFFFFFu ? gt[k] : gb[k];
-          const int rr = row_of(i, wp_magic);
-          const bool is_pixel = (i - rr * wp) >= f.pad_left;
-          if (is_pixel) {
-            if (MODE == ACHIP_MODE_HB_256) {
-              pt |= quant256(pt) << 24;
-              pb |= quant256(pb) << 24;
-            } else if (MODE == ACHIP_MODE_HB_16) {
-              pt |= quant16(pt) << 24;
-              pb |= quant16(pb) << 24;
-            } else if (MODE == ACHIP_MODE_MONO) {
-              pt |= (uint32_t)ramp[luma601(pt) >> 2] << 24;
-            }
-          }
-          pixT[i] = pt;
-          if (HB)
-            pixB[i] = pb;
-        }
+        pixT[i] = pt;
+        if (HB)
+          pixB[i] = pb;
       }
     }
     __syncthreads();
+    /* software pipeline: request the NEXT chunk's samples now; the sparse 64-byte-sector fetches (the
+     * memory-bound part of the frame) stay in flight while this chunk is tokenised, scanned and stored */
+    if (r1 < rows)
+      gather_issue(r1, (min(rows, r1 + rows_per_chunk) - r1) * wp);
     ACHIP_STAMP(1);
 
-    /* ---- B: run heads / ASCII-glyph mask (one 64-cell word per wave step) -------------- */
-    if (mode_has_runs(MODE) || MODE == ACHIP_MODE_TRUE_FG) {
+    /* ---- B: run heads / ASCII-glyph mask (one 64-cell word per wave step); skipped entirely for the
+     * per-cell modes and for truecolor-fg with an all-ASCII palette ------------------------------- */
+    if (mode_has_runs(MODE) || (MODE == ACHIP_MODE_TRUE_FG && !c.all_ascii)) {
       for (int w0 = wave; w0 <= (n >> 6); w0 += NW) {
         const int i = (w0 << 6) + lane;
         bool bit = false;
@@ -745,130 +945,131 @@ __global__ void __launch_bounds__(BLOCK)
       }
       __syncthreads();
     }
-
     ACHIP_STAMP(2);
-    Chunk c;
-    c.n = n;
-    c.wp = wp;
-    c.pad_left = f.pad_left;
-    c.r0 = r0;
-    c.rows = rows;
-    c.carry_have = carry_have;
-    c.carry_rgb = carry_rgb;
 
-    /* ---- C: token lengths ------------------------------------------------------------- */
-    for (int i = tid; i < CAP; i += BLOCK) {
-      uint32_t len = 0;
+    /* ---- C: build the tokens (registers) and their lengths ------------------------------------ */
+    Tok tok[SEG];
+    uint32_t len[SEG];
+#pragma unroll
+    for (int k = 0; k < SEG; k++) {
+      const int i = tid + k * BLOCK;
+      len[k] = 0;
+      tok[k].flags = 0;
       if (i < n) {
-        const int rr = row_of(i, wp_magic);
-        CountSink<L> cs{0u};
-        emit_token<MODE, L>(cs, c, i, r0 + rr, i - rr * wp);
-        len = cs.n;
+        tok[k] = build_token<MODE, L>(c, i, r0 + ACHIP_CELL_RR(k), ACHIP_CELL_RR(k), ACHIP_CELL_XP(k));
+        CountSink cs{0u};
+        token_fields<MODE>(cs, tok[k], ascii_only);
+        len[k] = cs.n;
       }
-      off[i] = len;
     }
-    __syncthreads();
+    /* PT: colour of the last ASCII-glyph pixel seen so far (the RLE state crosses rows and chunks);
+     * read before the barrier below, after which pixT may be overwritten by the next chunk's gather */
+    if (MODE == ACHIP_MODE_TRUE_FG) {
+      const int j = c.all_ascii ? n - 1 : prev_set(amask, n);
+      if (j >= 0) {
+        c.carry_have = true;
+        c.carry_rgb = px_rgb(pixT[j]);
+      }
+    }
     ACHIP_STAMP(3);
 
-    /* ---- D: exclusive scan of off[0..CAP) -------------------------------------------------- */
+    /* ---- D: exclusive scan over the chunk's cells in cell order.  Round k covers the contiguous cells
+     * [k*BLOCK, (k+1)*BLOCK): a DPP wave scan per round, one LDS exchange of the SEG*NW wave totals,
+     * then every wave scans that 64-entry table itself ------------------------------------------- */
+    uint32_t off[SEG];
     uint32_t total;
     {
-      uint32_t v[SEG];
-      uint32_t sum = 0;
+      uint32_t incl[SEG];
 #pragma unroll
       for (int k = 0; k < SEG; k++) {
-        v[k] = off[tid * SEG + k];
-        sum += v[k];
+        incl[k] = wave_inclusive_scan(len[k]);
+        if (lane == 63)
+          wsum[k * NW + wave] = incl[k];
       }
-      uint32_t inc = sum;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = wave_shfl_up(inc, d);
-        if (lane >= d)
-          inc += t;
-      }
-      if (lane == 63)
-        wsum[wave] = inc;
       __syncthreads();
-      uint32_t wbase = 0;
-      total = 0;
-#pragma unroll
-      for (int k = 0; k < NW; k++) {
-        const uint32_t t = wsum[k];
-        if (k < wave)
-          wbase += t;
-        total += t;
-      }
-      uint32_t run = wbase + inc - sum;
+      const uint32_t t = lane < SEG * NW ? wsum[lane] : 0u;
+      const uint32_t ts = wave_inclusive_scan(t);
+      total = wave_read_lane(ts, SEG * NW - 1);
 #pragma unroll
       for (int k = 0; k < SEG; k++) {
-        off[tid * SEG + k] = run;
-        run += v[k];
+        const int slot = k * NW + wave;
+        const uint32_t before = wave_read_lane(ts, slot) - wave_read_lane(t, slot);
+        off[k] = before + incl[k] - len[k];
       }
-      if (tid == 0)
-        off[CAP] = total;
-      __syncthreads();
     }
-
     ACHIP_STAMP(4);
     if ((uint64_t)base + total > cap_bytes)
       overflow = true;
 
-    /* ---- E: emit through the ring, one window at a time ---------------------------------- */
+    /* ---- E: store the tokens through the ring, one window of the stream at a time ------------------ */
     const uint32_t chunk_end = base + total;
     const bool last_chunk = r1 >= rows;
     while (!overflow) {
       const uint32_t lo = flushed, hi = flushed + (uint32_t)RING;
-      for (int i = tid; i < n; i += BLOCK) {
-        const uint32_t a = base + off[i];
-        const uint32_t b = base + off[i + 1];
+      uint32_t strad = 0; /* bit k: cell k was written to a straddler slot; bits 8+4k..: its slot */
+#pragma unroll
+      for (int k = 0; k < SEG; k++) {
+        const uint32_t a = base + off[k];
+        const uint32_t b = a + len[k];
         if (b > a && a < hi && b > lo) {
-          const int rr = row_of(i, wp_magic);
           const uint32_t ra = a & (RING - 1u);
-          if (a >= lo && b <= hi && ra + (b - a) <= (uint32_t)RING) {
-            FastSink<L> fs{ring_addr + ra};
-            emit_token<MODE, L>(fs, c, i, r0 + rr, i - rr * wp);
-          } else {
-            ClipSink<L, RING> cs{a, lo, hi};
-            emit_token<MODE, L>(cs, c, i, r0 + rr, i - rr * wp);
+          uint32_t target = ring_addr + ra;
+          if (!(a >= lo && b <= hi && ra + len[k] <= (uint32_t)RING)) {
+            const uint32_t slot = atomicAdd(&flags[1], 1u) & (uint32_t)(L::STRAD_SLOTS - 1);
+            strad |= (1u << k) | (slot << (8 + 4 * k));
+            target = strad_addr + slot * 64u;
+          }
+#if !defined(ACHIP_ABLATE) || ACHIP_ABLATE != 2
+          FastSink<L::o_dec, L::o_flags + 8> fs{target, dummy_addr};
+          token_fields<MODE>(fs, tok[k], ascii_only);
+#else
+          asm volatile("" ::"v"(target), "v"(tok[k].flags), "v"(tok[k].fg), "v"(tok[k].glyph));
+#endif
+        }
+      }
+      if (strad) { /* rare: copy the linear slot into the ring, byte by byte, inside the window only */
+        lds_store_fence();
+#pragma unroll
+        for (int k = 0; k < SEG; k++) {
+          if (strad & (1u << k)) {
+            const unsigned char *slot = lds_ptr<const unsigned char>(L::o_strad) + ((strad >> (8 + 4 * k)) & 15u) * 64u;
+            const uint32_t a = base + off[k];
+            for (uint32_t j = 0; j < len[k]; j++) {
+              const uint32_t o = a + j;
+              if (o >= lo && o < hi)
+                ring[o & (RING - 1u)] = slot[j];
+            }
           }
         }
       }
       lds_store_fence();
       __syncthreads();
       ACHIP_STAMP(5);
+      if (tid == 0)
+        flags[1] = 0u; /* next use is at least one barrier away */
       const uint32_t avail = min(chunk_end, hi);
-      drain_ring<MODE, BLOCK, CAP, RING>(ring, dst, flushed, avail);
+      drain_ring<BLOCK, RING>(L::o_ring, dst, flushed, avail);
       if (last_chunk && avail == chunk_end) { /* frame tail: < 16 bytes, byte stores */
         for (uint32_t o = (avail & ~15u) + (uint32_t)tid; o < avail; o += BLOCK)
           dst[o] = ring[o & (RING - 1u)];
       }
-      __syncthreads();
-      ACHIP_STAMP(6);
       flushed = avail & ~15u;
-      if (chunk_end <= hi)
-        break;
-    }
-
-    /* PT: colour of the last ASCII-glyph pixel seen so far (RLE state crosses rows and chunks) */
-    if (MODE == ACHIP_MODE_TRUE_FG) {
-      const int j = prev_set(amask, n);
-      if (j >= 0) {
-        carry_have = true;
-        carry_rgb = px_rgb(pixT[j]);
+      if (chunk_end <= hi) {
+        ACHIP_STAMP(6);
+        break; /* the next ring writes are several barriers away (next chunk's A/B/D) */
       }
+      __syncthreads(); /* the next window overwrites ring bytes that are being drained */
+      ACHIP_STAMP(6);
     }
     base = chunk_end;
-    __syncthreads(); /* pixT/off/masks are rewritten by the next chunk */
-    ACHIP_STAMP(6);
-  }
-  if (prof && tid == 0) {
-#pragma unroll
-    for (int k = 0; k < 7; k++)
-      prof[(size_t)fidx * 8u + (size_t)k] = t_acc[k];
-    prof[(size_t)fidx * 8u + 7u] = cycle_now() - t_start;
   }
 
+  if (prof && tid == 0) {
+    const unsigned long long *pa = lds_ptr<const unsigned long long>(L::o_prof);
+    for (int k = 0; k < 7; k++)
+      prof[(size_t)fidx * 8u + (size_t)k] = pa[k];
+    prof[(size_t)fidx * 8u + 7u] = cycle_now() - t_start;
+  }
   if (tid == 0) {
     out_len[fidx] = overflow ? ACHIP_LEN_OVERFLOW : base;
     if (!overflow && (uint64_t)base < out_stride)

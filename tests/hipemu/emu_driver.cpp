@@ -11,7 +11,7 @@ static void run(const achip_frame_t *frames, int n, const achip_lut_t *lut, uint
                 uint32_t *len) {
   using L = achip::Lds<MODE, BLOCK, CAP, RING>;
   hipemu::launch(dim3((unsigned)n), dim3(BLOCK), (size_t)L::bytes, [&] {
-    achip::render_frames_kernel<MODE, BLOCK, CAP, RING>(frames, lut, out, stride, len, n, nullptr);
+    achip::render_frames_kernel<MODE, BLOCK, CAP, RING, true>(frames, lut, out, stride, len, n, nullptr);
   });
 }
 

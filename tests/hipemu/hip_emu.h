@@ -186,3 +186,8 @@ static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long l
 static inline int __clzll(long long v) { return v ? __builtin_clzll(v) : 64; }
 using std::max;
 using std::min;
+static inline uint32_t atomicAdd(uint32_t *p, uint32_t v) { /* fibers run one at a time */
+  const uint32_t old = *p;
+  *p = old + v;
+  return old;
+}
