@@ -8,7 +8,8 @@ LIB_PATH = os.environ.get("ASCIICHAT_HIP_LIB") or os.path.join(HERE, "libasciich
 
 MODE_MONO, MODE_TRUE_FG, MODE_256_FG, MODE_16_FG, MODE_TRUE_BG = 0, 1, 2, 3, 4
 MODE_HB_TRUE, MODE_HB_256, MODE_HB_16, MODE_HB_MONO = 5, 6, 7, 8
-MODE_NAMES = ["mono", "true_fg", "256_fg", "16_fg", "true_bg", "hb_true", "hb_256", "hb_16", "hb_mono"]
+MODE_16_DITHER_BG = 9
+MODE_NAMES = ["mono", "true_fg", "256_fg", "16_fg", "true_bg", "hb_true", "hb_256", "hb_16", "hb_mono", "16_dither_bg"]
 LEN_OVERFLOW, LEN_BADDESC = 0xFFFFFFFF, 0xFFFFFFFE
 ERR_NO_DEVICE = 200
 

@@ -96,7 +96,7 @@ int achip_mode_from_caps(int color_level, int render_mode) {
   }
   switch (color_level) {
   case 3:
-    return render_mode == 1 ? -1 : ACHIP_MODE_TRUE_FG; /* BACKGROUND -> dithered 16-colour (sgr.c:429) */
+    return render_mode == 1 ? ACHIP_MODE_16_DITHER_BG : ACHIP_MODE_TRUE_FG; /* BACKGROUND -> dithered (sgr.c:429) */
   case 2:
     return ACHIP_MODE_256_FG;
   case 1:
@@ -183,6 +183,9 @@ size_t achip_out_bound(int mode, const achip_frame_t *f) {
     break;
   case ACHIP_MODE_HB_16:
     cell = 5 + 6 + 3;
+    break;
+  case ACHIP_MODE_16_DITHER_BG:
+    cell = 6 + 5 + 4;
     break;
   default:
     cell = 3;

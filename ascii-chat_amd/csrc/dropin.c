@@ -343,12 +343,8 @@ char *image_print_color_simd(image_t *image, bool use_background_mode, bool use_
     achip_fail(ERROR_INVALID_PARAM, "image_print_color_simd: image or ascii_chars is NULL");
     return NULL;
   }
-  if (use_background_mode) {
-    /* image_print_16color_dithered_with_background: Floyd-Steinberg error diffusion, a serial
-     * dependency chain -- SURVEY.md 8(f).4 ranks it after the parallel modes; not on the GPU yet */
-    achip_fail(ERROR_NOT_SUPPORTED, "dithered 16-colour background mode is not implemented on the GPU path");
-    return NULL;
-  }
+  if (use_background_mode) /* image_print_16color_dithered_with_background(image, true, ..) */
+    return print_image(ACHIP_MODE_16_DITHER_BG, image, ascii_chars);
   return use_256color ? image_print_256color(image, ascii_chars) : image_print_color(image, ascii_chars);
 }
 
@@ -433,10 +429,6 @@ char *ascii_convert_with_capabilities(image_t *original, const ssize_t width, co
     return NULL;
   }
   const int mode = achip_mode_from_caps((int)caps->color_level, (int)caps->render_mode);
-  if (mode < 0) {
-    achip_fail(ERROR_NOT_SUPPORTED, "dithered 16-colour background mode is not implemented on the GPU path");
-    return NULL;
-  }
   achip_frame_t f;
   if (achip_frame_setup(&f, (const uint8_t *)original->pixels, original->w, original->h, width, height,
                         (int)caps->render_mode, caps->wants_padding, use_aspect_ratio, stretch) != 0) {
@@ -464,8 +456,7 @@ char *ascii_convert(image_t *original, const ssize_t width, const ssize_t height
     if (g_option_render_mode == RENDER_MODE_HALF_BLOCK) {
       mode = ACHIP_MODE_HB_TRUE;
     } else if (g_option_render_mode == RENDER_MODE_BACKGROUND) {
-      achip_fail(ERROR_NOT_SUPPORTED, "dithered 16-colour background mode is not implemented on the GPU path");
-      return NULL;
+      mode = ACHIP_MODE_16_DITHER_BG;
     } else {
       mode = ACHIP_MODE_TRUE_FG;
     }

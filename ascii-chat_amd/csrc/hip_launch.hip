@@ -47,6 +47,7 @@ hipError_t launch_mode(int mode, bool comp, const achip_frame_t *frames, int n, 
     M(ACHIP_MODE_HB_256)
     M(ACHIP_MODE_HB_16)
     M(ACHIP_MODE_HB_MONO)
+    M(ACHIP_MODE_16_DITHER_BG)
 #undef M
   }
   return hipErrorInvalidValue;
@@ -66,6 +67,7 @@ template <int BLOCK, int CAP, int RING> int lds_for_mode(int mode) {
     M(ACHIP_MODE_HB_256)
     M(ACHIP_MODE_HB_16)
     M(ACHIP_MODE_HB_MONO)
+    M(ACHIP_MODE_16_DITHER_BG)
 #undef M
   }
   return -1;

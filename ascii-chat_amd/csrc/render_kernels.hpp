@@ -150,6 +150,17 @@ __device__ inline uint32_t quant16(uint32_t p) {
   return best;
 }
 
+/* packed 0xBBGGRR of ANSI colour idx (get_16color_rgb, ansi.c:480-509) */
+__device__ inline uint32_t ansi16_rgb(uint32_t idx) {
+  const uint32_t tbl[16] = {0x000000u, 0x000080u, 0x008000u, 0x008080u, 0x800000u, 0x800080u, 0x808000u, 0xC0C0C0u,
+                            0x808080u, 0x0000FFu, 0x00FF00u, 0x00FFFFu, 0xFF0000u, 0xFF00FFu, 0xFFFF00u, 0xFFFFFFu};
+  uint32_t v = 0;
+#pragma unroll
+  for (int i = 0; i < 16; i++)
+    v = idx == (uint32_t)i ? tbl[i] : v;
+  return v;
+}
+
 /* UTF-8 sequence length from the lead byte -- the palette parser's rule (common.c:397-410) */
 __device__ inline uint32_t glyph_len(uint32_t g) {
   const uint32_t c = g & 0xFFu;
@@ -331,7 +342,7 @@ __host__ __device__ constexpr bool mode_has_runs(int m) { return m == ACHIP_MODE
 /* modes that end every text row with ESC[0m (P256/P16/PB/HT/H256/H16) */
 __host__ __device__ constexpr bool mode_row_reset(int m) {
   return m == ACHIP_MODE_256_FG || m == ACHIP_MODE_16_FG || m == ACHIP_MODE_TRUE_BG || m == ACHIP_MODE_HB_TRUE ||
-         m == ACHIP_MODE_HB_256 || m == ACHIP_MODE_HB_16;
+         m == ACHIP_MODE_HB_256 || m == ACHIP_MODE_HB_16 || m == ACHIP_MODE_16_DITHER_BG;
 }
 
 template <int MODE, int BLOCK, int CAP, int RING> struct Lds {
@@ -352,7 +363,8 @@ template <int MODE, int BLOCK, int CAP, int RING> struct Lds {
   static constexpr int o_strad = o_flags + 16;    /* STRAD_SLOTS x 64-byte linear token slots              */
   static constexpr int STRAD_SLOTS = 8;           /* <= 3 tokens can straddle per window (lo, hi, wrap)    */
   static constexpr int o_prof = o_strad + STRAD_SLOTS * 64; /* 8 x u64 diagnostics accumulators */
-  static constexpr int bytes = o_prof + 8 * 8;
+  static constexpr int o_carry = o_prof + 8 * 8;             /* dither: error sums entering the next row, 3 x int per column */
+  static constexpr int bytes = o_carry + (MODE == ACHIP_MODE_16_DITHER_BG ? CAP * 12 : 0);
   static_assert(SEG * NW <= 64, "wave-total table must fit one wave");
 };
 
@@ -508,6 +520,15 @@ template <int MODE, class L> __device__ inline Tok build_token(const Chunk &c, i
     t.flags |= TF_SGR_BG | TF_SGR_FG | TF_GLYPH | (Y < 128u ? TF_FG_WHITE : 0u);
     t.bg = px_rgb(pt);
     t.glyph = glyph[Y];
+  } else if (MODE == ACHIP_MODE_16_DITHER_BG) {
+    /* foreground.c:787-827: background = dithered colour (index left in bits 31..24 by the dither pass),
+     * foreground = white on dark / black on bright, glyph = cache[Y] of the ORIGINAL pixel */
+    const uint32_t idx = px_key(pt), pal = ansi16_rgb(idx);
+    const uint32_t bl = (77u * px_r(pal) + 150u * px_g(pal) + 29u * px_b(pal)) / 256u;
+    t.flags |= TF_SGR_BG | TF_SGR_FG | TF_GLYPH;
+    t.bg = sgr16_code(true, idx);
+    t.fg = bl < 127u ? 97u : 30u; /* append_16color_fg(15) / append_16color_fg(0) */
+    t.glyph = glyph[luma601(pt)];
   } else {
     /* run-structured modes: head h, end e, run = e - h */
     const bool is_head = (hmask[i >> 6] >> (i & 63)) & 1ull;
@@ -661,6 +682,9 @@ template <int MODE, class S> __device__ inline void token_fields(S &s, const Tok
       s.template c<4>(0x303B303Bu);
       s.template c<1>('m');
     }
+  } else if (MODE == ACHIP_MODE_16_DITHER_BG) {
+    put_sgr_16<3>(s, t.bg); /* the 5-byte foreground SGR follows */
+    put_sgr_16<1>(s, t.fg);
   } else {
     if (f & TF_SGR_FG) {
       /* what is certain to follow a foreground SGR: the glyph -- 3 bytes in half-block modes, >= 1 otherwise */
@@ -723,6 +747,82 @@ __device__ inline void drain_ring(int ring_off, uint8_t *__restrict__ out, uint3
   const uint32_t vec_end = to & ~15u;
   for (uint32_t o = from + 16u * threadIdx.x; o < vec_end; o += 16u * BLOCK)
     *reinterpret_cast<uint4 *>(out + o) = *reinterpret_cast<const uint4 *>(ring + (o & (RING - 1u)));
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* Floyd-Steinberg 16-colour dithering (rgb_to_16color_dithered, lib/video/terminal/ansi.c:511-583)  */
+/* as a register-resident wavefront.  Error diffusion is serial along a row and from row to row, but  */
+/* pixel (x, y) only needs (x-1, y) and (x+1, y-1): lane y of ONE wave walks row y two columns behind */
+/* lane y-1.  The error a row sends to the row below never touches memory: after pixel x the lane     */
+/* knows the complete sum entering (x-1, y+1) -- (e(x-2)*1)/16 + (e(x-1)*5)/16 + (e(x)*3)/16, each    */
+/* term truncated like the reference's integer divisions -- and hands it to lane y+1 with one shuffle */
+/* per channel, exactly when that lane starts (x-1, y+1).  Sweeps of 64 rows are chained through a    */
+/* 3 x int per column LDS buffer, which also carries the state from chunk to chunk.                   */
+/* ------------------------------------------------------------------------------------------- */
+__device__ inline int fs_term(int e, int w) { return (e * w) / 16; } /* C division: truncates toward zero */
+
+template <class L>
+__device__ inline void dither16_rows(int lane, int chunk_rows, int wp, int pad_left, int out_w, int first_row,
+                                     int frame_rows) {
+  uint32_t *pixT = lds_ptr<uint32_t>(L::o_pixT);
+  int *carry = lds_ptr<int>(L::o_carry);
+  for (int rb = 0; rb < chunk_rows; rb += 64) {
+    const int nrows = min(64, chunk_rows - rb);
+    const bool row_ok = lane < nrows;
+    const int row_base = (rb + lane) * wp + pad_left;
+    int right[3] = {0, 0, 0};              /* (e(x-1)*7)/16 entering the next pixel of this row            */
+    int pa[3] = {0, 0, 0}, pb[3] = {0, 0, 0}; /* partial sums entering columns x-1 and x of the row below  */
+    int in[3] = {0, 0, 0};                 /* complete sum entering the pixel this lane processes next      */
+    const int steps = out_w + 1 + 2 * (nrows - 1);
+    for (int t = 0; t < steps; t++) {
+      const int x = t - 2 * lane;
+      const bool active = row_ok && x >= 0 && x <= out_w;
+      int out[3] = {0, 0, 0};
+      if (active) {
+        int e[3] = {0, 0, 0};
+        if (x < out_w) {
+          if (lane == 0) { /* first row of the sweep: what the previous sweep / chunk left for this column */
+            in[0] = carry[3 * x + 0];
+            in[1] = carry[3 * x + 1];
+            in[2] = carry[3 * x + 2];
+          }
+          const uint32_t p = pixT[row_base + x];
+          const int v0 = (int)px_r(p) + in[0] + right[0];
+          const int v1 = (int)px_g(p) + in[1] + right[1];
+          const int v2 = (int)px_b(p) + in[2] + right[2];
+          const uint32_t c0 = (uint32_t)min(255, max(0, v0)), c1 = (uint32_t)min(255, max(0, v1)),
+                         c2 = (uint32_t)min(255, max(0, v2));
+          const uint32_t idx = quant16(c0 | (c1 << 8) | (c2 << 16));
+          const uint32_t pal = ansi16_rgb(idx);
+          e[0] = v0 - (int)px_r(pal); /* the error uses the UNclamped value (ansi.c:541-543) */
+          e[1] = v1 - (int)px_g(pal);
+          e[2] = v2 - (int)px_b(pal);
+          pixT[row_base + x] = px_rgb(p) | (idx << 24);
+        }
+        const bool has_right = x + 1 < out_w; /* the reference drops contributions that leave the image */
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          out[k] = pa[k] + fs_term(e[k], 3);                    /* completes column x-1 of the row below */
+          pa[k] = pb[k] + fs_term(e[k], 5);                     /* column x   */
+          pb[k] = has_right ? fs_term(e[k], 1) : 0;             /* column x+1 */
+          right[k] = has_right ? fs_term(e[k], 7) : 0;
+        }
+        /* last row of the sweep: park the completed sums for the next sweep / chunk */
+        if (lane == nrows - 1 && x >= 1 && first_row + rb + lane + 1 < frame_rows) {
+          carry[3 * (x - 1) + 0] = out[0];
+          carry[3 * (x - 1) + 1] = out[1];
+          carry[3 * (x - 1) + 2] = out[2];
+        }
+      }
+      /* hand the completed sums to the lane below: it starts column x-1 in the next step */
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const int got = (int)wave_shfl_up((uint32_t)out[k], 1);
+        if (lane > 0)
+          in[k] = got;
+      }
+    }
+  }
 }
 
 /* optional per-phase cycle accounting (diagnostics: prof == NULL in production launches).
@@ -811,6 +911,12 @@ __global__ void __launch_bounds__(BLOCK)
     }
     if (non_ascii)
       flags[0] = 1u; /* benign race: every writer stores the same value */
+  }
+
+  if (MODE == ACHIP_MODE_16_DITHER_BG) { /* no error enters the first row */
+    int *carry = lds_ptr<int>(L::o_carry);
+    for (int k = tid; k < 3 * CAP; k += BLOCK)
+      carry[k] = 0;
   }
 
   /* i / wp == umulhi(i, magic) for i, wp <= CAP (i * wp < 2^32); wp == 1 would need magic 2^32 */
@@ -918,6 +1024,11 @@ __global__ void __launch_bounds__(BLOCK)
     if (r1 < rows)
       gather_issue(r1, (min(rows, r1 + rows_per_chunk) - r1) * wp);
     ACHIP_STAMP(1);
+    if (MODE == ACHIP_MODE_16_DITHER_BG) { /* one wave diffuses the errors and leaves the colour index in the key byte */
+      if (wave == 0)
+        dither16_rows<L>(lane, r1 - r0, wp, f.pad_left, f.out_w, r0, rows);
+      __syncthreads();
+    }
 
     /* ---- B: run heads / ASCII-glyph mask (one 64-cell word per wave step); skipped entirely for the
      * per-cell modes and for truecolor-fg with an all-ASCII palette ------------------------------- */

@@ -95,3 +95,54 @@ def gather_grid_tiles(torch, dist, backend, comp, local_sources, world, rank, de
         s.src_w, s.src_h, s.src_stride = s.tile_w, s.tile_h, 3 * s.tile_w
         s.x_ratio = s.y_ratio = 65537  # ((n << 16) / n) + 1
     return tiles, tile_stride, out
+
+
+class GpuBackend:
+    """Compute backend for gather_grid_tiles() on the GPU box: the library's resize kernel on torch's stream."""
+
+    def __init__(self, torch, lib):
+        self.torch, self.lib = torch, lib
+
+    def resize(self, src_ptr, sw, sh, dst_ptr, dw, dh):
+        rc = self.lib.asciichat_hip_resize(src_ptr, sw, sh, dst_ptr, dw, dh,
+                                           self.torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            raise RuntimeError("asciichat_hip_resize failed: %d" % rc)
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+
+def render_grid_for_targets(torch, dist, pkg, sources, src_dims, term_w, term_h, targets, palette, world, rank,
+                            device="cuda"):
+    """BASELINE config 4 end to end: `sources` = {slot: uint8 HxWx3 device tensor} owned by this rank (contiguous
+    blocks of slots per rank), `src_dims` = [(w, h)] of ALL sources, `targets` = [(color_level, render_mode,
+    wants_padding)] of the target clients this rank renders.  Returns a list of bytes, one frame per target."""
+    n = len(src_dims)
+    ptrs = (C.c_void_p * n)(*[1] * n)
+    ws = (C.c_int * n)(*[d[0] for d in src_dims])
+    hs = (C.c_int * n)(*[d[1] for d in src_dims])
+    comp = pkg.Composite()
+    pkg.lib().achip_composite_setup(C.byref(comp), ptrs, ws, hs, n, term_w, term_h)
+    tiles, _, comp2 = gather_grid_tiles(torch, dist, GpuBackend(torch, pkg.lib()), comp, sources, world, rank, device)
+    comp_dev = C.c_void_p()
+    if pkg.lib().asciichat_hip_composite_upload(C.byref(comp2), C.byref(comp_dev)) != 0:
+        raise RuntimeError("composite upload failed")
+    out = []
+    try:
+        for (cl, rm, pad) in targets:
+            mode = pkg.lib().achip_mode_from_caps(cl, rm)
+            h = term_h * 2 if rm == 2 else term_h  # convert_composite_to_ascii, src/server/stream.c:831
+            f = pkg.frame_setup(None, comp.canvas_w, comp.canvas_h, term_w, h, rm, pad, True, False)
+            f.comp = comp_dev.value
+            plan = pkg.Plan(mode, palette, [f])
+            slab = torch.zeros(plan.stride, dtype=torch.uint8, device=device)
+            ln = torch.zeros(1, dtype=torch.int32, device=device)
+            plan.render(slab.data_ptr(), plan.stride, ln.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            out.append(bytes(slab[:int(ln[0].item()) & 0xFFFFFFFF].cpu().numpy()))
+            plan.close()
+    finally:
+        pkg.lib().asciichat_hip_free(comp_dev)
+    del tiles
+    return out

@@ -26,7 +26,7 @@ void aspect_ratio(const ssize_t img_w, const ssize_t img_h, const ssize_t width,
 int achip_lut_build(const char *palette_chars, achip_lut_t *lut);
 
 /* image_print_with_capabilities dispatch (ascii.c:955-1002 + sgr.c:413-436, x86 SIMD_SUPPORT build).
- * Returns the ACHIP_MODE_*, or -1 for TRUECOLOR+BACKGROUND (Floyd-Steinberg, serial: not on the GPU yet). */
+ * TRUECOLOR+BACKGROUND maps to the Floyd-Steinberg 16-colour renderer, as in the reference. */
 int achip_mode_from_caps(int color_level, int render_mode);
 
 /* Fill one frame descriptor the way ascii_convert_with_capabilities (ascii.c:194-387) sizes things:

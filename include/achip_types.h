@@ -23,7 +23,9 @@ enum {
   ACHIP_MODE_HB_256 = 6,  /* rgb_to_256color_halfblocks_scalar   halfblock.c:416-524   */
   ACHIP_MODE_HB_16 = 7,   /* rgb_to_16color_halfblocks_scalar    halfblock.c:297-405   */
   ACHIP_MODE_HB_MONO = 8, /* rgb_to_halfblocks_scalar            halfblock.c:184-286   */
-  ACHIP_MODE_COUNT = 9
+  ACHIP_MODE_16_DITHER_BG = 9, /* image_print_16color_dithered_with_background(.., true, ..)  foreground.c:752-846
+                                  (what TRUECOLOR + RENDER_MODE_BACKGROUND dispatches to, sgr.c:429-430) */
+  ACHIP_MODE_COUNT = 10
 };
 
 /* One source of a pixel-space grid composite (create_multi_source_composite, src/server/stream.c:664-779). */

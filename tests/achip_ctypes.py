@@ -3,13 +3,15 @@ import ctypes as C
 
 MODE_MONO, MODE_TRUE_FG, MODE_256_FG, MODE_16_FG, MODE_TRUE_BG = 0, 1, 2, 3, 4
 MODE_HB_TRUE, MODE_HB_256, MODE_HB_16, MODE_HB_MONO = 5, 6, 7, 8
-ALL_MODES = list(range(9))
-MODE_NAMES = ["mono", "true_fg", "256_fg", "16_fg", "true_bg", "hb_true", "hb_256", "hb_16", "hb_mono"]
+MODE_16_DITHER_BG = 9
+ALL_MODES = list(range(10))
+MODE_NAMES = ["mono", "true_fg", "256_fg", "16_fg", "true_bg", "hb_true", "hb_256", "hb_16", "hb_mono", "16_dither_bg"]
 
 # (color_level, render_mode) that image_print_with_capabilities maps to each mode; TRUE_BG is only
 # reachable through image_print_color_background() itself
 MODE_CAPS = {MODE_MONO: (0, 0), MODE_TRUE_FG: (3, 0), MODE_256_FG: (2, 0), MODE_16_FG: (1, 0),
-             MODE_HB_TRUE: (3, 2), MODE_HB_256: (2, 2), MODE_HB_16: (1, 2), MODE_HB_MONO: (0, 2)}
+             MODE_HB_TRUE: (3, 2), MODE_HB_256: (2, 2), MODE_HB_16: (1, 2), MODE_HB_MONO: (0, 2),
+             MODE_16_DITHER_BG: (3, 1)}
 
 LEN_OVERFLOW = 0xFFFFFFFF
 LEN_BADDESC = 0xFFFFFFFE

@@ -32,6 +32,7 @@ static int by_mode(int mode, const achip_frame_t *frames, int n, const achip_lut
     M(ACHIP_MODE_HB_256)
     M(ACHIP_MODE_HB_16)
     M(ACHIP_MODE_HB_MONO)
+    M(ACHIP_MODE_16_DITHER_BG)
 #undef M
   }
   return -1;

@@ -119,7 +119,7 @@ def test_frame_setup_matches_reference_null_conditions(pkg):
     assert (f.out_w, f.out_h, f.pad_left, f.pad_top) == (64, 24, 8, 0)
     f = pkg.frame_setup(1, 640, 480, 80, 24, 0, False, True, False)  # wants_padding off -> no padding
     assert (f.pad_left, f.pad_top) == (0, 0)
-    assert pkg.lib().achip_mode_from_caps(3, 1) == -1  # TRUECOLOR+BACKGROUND = dithered path, not on GPU
+    assert pkg.lib().achip_mode_from_caps(3, 1) == 9  # TRUECOLOR+BACKGROUND = Floyd-Steinberg 16-colour (sgr.c:429)
     assert [pkg.lib().achip_mode_from_caps(c, 0) for c in (-1, 0, 1, 2, 3)] == [0, 0, 3, 2, 1]
     assert [pkg.lib().achip_mode_from_caps(c, 2) for c in (-1, 0, 1, 2, 3)] == [8, 8, 7, 6, 5]
 

@@ -66,7 +66,7 @@ def test_config1_ascii_convert_mono_640x480(api):
     lum = C.create_string_buffer(b"x" * 255, 256)
     got = api.take_string(L.ascii_convert(C.byref(im), 80, 24, False, False, False, PAL, lum))
     assert len(got) == 1635 and orc.fnv1a32(got) == 0xCEFD0A18  # SURVEY 8(c) anchor of the reference's output
-    for color, mode_opt in ((True, 0), (True, 2), (False, 0)):
+    for color, mode_opt in ((True, 0), (True, 2), (True, 1), (False, 0)):
         L.asciichat_hip_set_option_render_mode(mode_opt)
         for aspect in (False, True):
             got = api.take_string(L.ascii_convert(C.byref(im), 80, 24, color, aspect, False, PAL, lum))
@@ -92,10 +92,12 @@ def test_null_and_error_conditions(api):
     assert not L.ascii_convert_with_capabilities(C.byref(bad), 80, 24, C.byref(c), False, False, PAL)
     assert not L.image_print(None, PAL)
     assert not L.image_print_with_capabilities(C.byref(im), None, PAL)
-    # TRUECOLOR + BACKGROUND dispatches to the Floyd-Steinberg renderer: explicit "not supported", never a wrong answer
+    # TRUECOLOR + BACKGROUND dispatches to the Floyd-Steinberg 16-colour renderer (sgr.c:429-430)
     cb = caps(api, 3, 1)
-    assert not L.ascii_convert_with_capabilities(C.byref(im), 80, 24, C.byref(cb), False, False, PAL)
-    assert b"not implemented" in L.asciichat_hip_last_error()
+    got = api.take_string(L.ascii_convert_with_capabilities(C.byref(im), 97, 31, C.byref(cb), False, False, PAL))
+    assert got == orc.convert_with_caps(TORTURE, 97, 31, 3, 1) and len(got) == 34602  # SURVEY App. B anchor
+    got = api.take_string(L.image_print_color_simd(C.byref(im), True, False, PAL))
+    assert got == orc.print_with_caps(TORTURE, 3, 1)
     # halfblock.c:50-51: non-positive dims -> empty string, not NULL
     assert api.take_string(L.rgb_to_truecolor_halfblocks_scalar(im.pixels, 0, 5, 0)) == b""
 

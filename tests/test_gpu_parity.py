@@ -120,8 +120,8 @@ def test_synthetic_inputs_mixed_batch(gpu):
 def test_ragged_output_sizes_and_edges(gpu):
     """Per-frame output dims differ inside one batch; 1x1 outputs; a row as wide as the largest chunk."""
     img = orc.frame_hash_noise(97, 41, 3)
-    dims = [(1, 1), (2, 1), (1, 2), (80, 24), (3, 50), (500, 3), (1024, 2), (2048, 2), (3840, 2)]
-    for mode in (0, 1, 5, 6, 8):
+    dims = [(1, 1), (2, 1), (1, 2), (80, 24), (3, 50), (7, 200), (500, 3), (1024, 2), (2048, 2), (3840, 2)]
+    for mode in (0, 1, 5, 6, 8, 9):
         got = render_batch(gpu, mode, [img] * len(dims), 0, 0, dims=dims)
         for k, (w, h) in enumerate(dims):
             exp = oracle_convert(img, mode, w, h, orc.PALETTE_STANDARD)
@@ -257,3 +257,18 @@ def test_resize_kernel(gpu):
         assert pkg.lib().asciichat_hip_resize(src.data_ptr(), 1920, 1080, dst.data_ptr(), dw, dh, None) == 0
         torch.cuda.synchronize()
         assert np.array_equal(dst.cpu().numpy().reshape(dh, dw, 3), orc.resize_nn(img, dw, dh)), (dw, dh)
+
+
+def test_grid9_tile_exchange_path_single_rank(gpu):
+    """The multi-GPU grid path (tiles resized by their owners, gathered, composite rendered from the tiles) with
+    world=1: same code the ranks run over RCCL, minus the collective."""
+    pkg, torch = gpu
+    imgs = [orc.frame_hash_noise(1920, 1080, 30 + i) if i % 3 else orc.frame_bars(1920, 1080, i) for i in range(9)]
+    local = {k: torch.from_numpy(imgs[k]).cuda() for k in range(9)}
+    targets = [(3, 0, True), (3, 2, True), (2, 0, False), (0, 0, True)]
+    got = pkg.distributed.render_grid_for_targets(torch, None, pkg, local, [(1920, 1080)] * 9, 160, 48, targets,
+                                                  orc.PALETTE_STANDARD, 1, 0)
+    canvas = orc.composite(imgs, 160, 48)
+    for (cl, rm, pad), g in zip(targets, got):
+        h = 96 if rm == 2 else 48
+        assert g == orc.convert_with_caps(canvas, 160, h, cl, rm, pad, True, False), (cl, rm, pad)

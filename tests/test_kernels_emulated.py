@@ -62,3 +62,18 @@ def test_wide_variant_big_frame():
         exp = oracle_convert(img, mode, 200, 60, orc.PALETTE_STANDARD)
         got = emu_convert(img, mode, 200, 60, orc.PALETTE_STANDARD, 0)
         assert got == exp, MODE_NAMES[mode]
+
+
+def test_dither_multi_sweep_and_carry():
+    """Floyd-Steinberg mode: > 64 rows per chunk (several 64-row sweeps chained through the LDS carry),
+    chunk-to-chunk carry, 1-pixel-wide and 1-row images, padding."""
+    from achip_ctypes import MODE_16_DITHER_BG
+    img = orc.frame_hash_noise(97, 211, 21)
+    img[50:120, 20:60] = 37  # flat area: error accumulates without clamping
+    for (W, H, variant) in [(10, 150, 4), (7, 200, 0), (1, 130, 4), (130, 1, 2), (64, 65, 4), (300, 20, 2), (80, 24, 1)]:
+        exp = oracle_convert(img, MODE_16_DITHER_BG, W, H, orc.PALETTE_STANDARD)
+        got = emu_convert(img, MODE_16_DITHER_BG, W, H, orc.PALETTE_STANDARD, variant)
+        assert got == exp, (W, H, variant)
+    exp = oracle_convert(img, MODE_16_DITHER_BG, 60, 40, orc.PALETTE_COOL, True, True)
+    got = emu_convert(img, MODE_16_DITHER_BG, 60, 40, orc.PALETTE_COOL, 4, True, True)
+    assert got == exp
