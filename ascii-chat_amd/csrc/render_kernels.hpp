@@ -228,9 +228,8 @@ __device__ inline int wave_uniform(int v) { return __builtin_amdgcn_readfirstlan
 /* ------------------------------------------------------------------------------------------- */
 /* token sinks.  A token is a short sequence of FIELDS of <= 4 bytes (packed little-endian in a   */
 /* u32).  One field walk drives two sinks: CountSink (length) and FastSink (plain LDS byte stores,  */
-/* constant-length fields fold to immediate-offset stores).  The few tokens that straddle a window */
-/* edge or the ring's wrap point are first written linearly into a 64-byte LDS slot by the same    */
-/* FastSink code and then copied byte-wise with the window test (see phase E).                     */
+/* constant-length fields fold to immediate-offset stores).  Windows of the output stream are cut   */
+/* at token boundaries (phase E), so a token never straddles anything and no store is checked.       */
 /* Measured on gfx950 (scripts/ubench/lds_unaligned.hip): a ds_write_b8 costs ~1.5 cycles per      */
 /* wave-instruction per CU, a MISALIGNED ds_write_b32 ~16 -- so bytes are stored one by one, in    */
 /* asm, which also stops the compiler from fusing them into misaligned wide stores.                */
@@ -359,10 +358,8 @@ template <int MODE, int BLOCK, int CAP, int RING> struct Lds {
   static constexpr int o_ramp = o_glyph64 + 64 * 4;
   static constexpr int o_dec = o_ramp + 64;     /* 256 decimal-field entries */
   static constexpr int o_wsum = o_dec + 256 * 4; /* SEG*NW wave totals (<= 64) */
-  static constexpr int o_flags = o_wsum + 64 * 4; /* [0] palette-not-all-ASCII, [1] straddler slot counter, [2] dummy store target */
-  static constexpr int o_strad = o_flags + 16;    /* STRAD_SLOTS x 64-byte linear token slots              */
-  static constexpr int STRAD_SLOTS = 8;           /* <= 3 tokens can straddle per window (lo, hi, wrap)    */
-  static constexpr int o_prof = o_strad + STRAD_SLOTS * 64; /* 8 x u64 diagnostics accumulators */
+  static constexpr int o_flags = o_wsum + 64 * 4; /* [0] palette-not-all-ASCII, [1],[2] window cut (ping-pong), [3] dummy store target */
+  static constexpr int o_prof = o_flags + 16;     /* 8 x u64 diagnostics accumulators */
   static constexpr int o_carry = o_prof + 8 * 8;             /* dither: error sums entering the next row, 3 x int per column */
   static constexpr int bytes = o_carry + (MODE == ACHIP_MODE_16_DITHER_BG ? CAP * 12 : 0);
   static_assert(SEG * NW <= 64, "wave-total table must fit one wave");
@@ -740,13 +737,21 @@ template <int MODE> __device__ inline bool same_run(const uint32_t *pixT, const 
 /* ------------------------------------------------------------------------------------------- */
 /* the frame kernel                                                                              */
 /* ------------------------------------------------------------------------------------------- */
-template <int BLOCK, int RING>
+template <int BLOCK>
 __device__ inline void drain_ring(int ring_off, uint8_t *__restrict__ out, uint32_t from, uint32_t to) {
-  /* [from, to) are stream offsets, from is 16-byte aligned; full 16-byte groups go out as uint4 */
+  /* [from, to) are stream offsets, `from` is 16-byte aligned and sits at byte 0 of the staging buffer;
+   * full 16-byte groups go out as uint4, group g by thread g mod BLOCK */
   const unsigned char *ring = lds_ptr<const unsigned char>(ring_off);
   const uint32_t vec_end = to & ~15u;
-  for (uint32_t o = from + 16u * threadIdx.x; o < vec_end; o += 16u * BLOCK)
-    *reinterpret_cast<uint4 *>(out + o) = *reinterpret_cast<const uint4 *>(ring + (o & (RING - 1u)));
+  uint32_t o = from + 16u * threadIdx.x;
+  for (; o + 16u * BLOCK < vec_end; o += 32u * BLOCK) { /* two groups per trip: both LDS reads in flight */
+    const uint4 v0 = *reinterpret_cast<const uint4 *>(ring + (o - from));
+    const uint4 v1 = *reinterpret_cast<const uint4 *>(ring + (o - from) + 16u * BLOCK);
+    *reinterpret_cast<uint4 *>(out + o) = v0;
+    *reinterpret_cast<uint4 *>(out + o + 16u * BLOCK) = v1;
+  }
+  if (o < vec_end)
+    *reinterpret_cast<uint4 *>(out + o) = *reinterpret_cast<const uint4 *>(ring + (o - from));
 }
 
 /* ------------------------------------------------------------------------------------------- */
@@ -851,7 +856,7 @@ __global__ void __launch_bounds__(BLOCK)
   constexpr bool HB = mode_is_halfblock(MODE);
   constexpr int NW = L::NW;
   constexpr int SEG = L::SEG;
-  static_assert(CAP % BLOCK == 0 && (RING & (RING - 1)) == 0 && RING % 16 == 0, "geometry");
+  static_assert(CAP % BLOCK == 0 && RING % 16 == 0 && RING >= 256, "geometry");
 
   unsigned char *ring = lds_ptr<unsigned char>(L::o_ring);
   uint32_t *pixT = lds_ptr<uint32_t>(L::o_pixT);
@@ -894,7 +899,8 @@ __global__ void __launch_bounds__(BLOCK)
   /* glyph tables -> LDS; is every glyph a single ASCII byte? */
   if (tid == 0) {
     flags[0] = 0u;
-    flags[1] = 0u;
+    flags[1] = 0xFFFFFFFFu;
+    flags[2] = 0xFFFFFFFFu;
   }
   __syncthreads();
   {
@@ -924,27 +930,32 @@ __global__ void __launch_bounds__(BLOCK)
   const int rows_per_chunk = max(1, CAP / wp);
   const uint32_t cap_bytes = out_stride > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)out_stride;
   const uint32_t ring_addr = lds_base_addr() + (uint32_t)L::o_ring;
-  const uint32_t strad_addr = lds_base_addr() + (uint32_t)L::o_strad;
-  const uint32_t dummy_addr = lds_base_addr() + (uint32_t)L::o_flags + 8u;
+  const uint32_t dummy_addr = lds_base_addr() + (uint32_t)L::o_flags + 12u;
 
+  uint32_t window_no = 0; /* parity selects the LDS slot that carries the window cut */
   uint32_t base = 0;    /* stream bytes produced before the current chunk */
   uint32_t flushed = 0; /* stream bytes already in HBM (multiple of 16)   */
   bool overflow = false;
 
-  /* ascii_pad_frame_height: pad_top bare newlines */
+  /* ascii_pad_frame_height: pad_top bare newlines, through the same staging buffer */
   if (f.pad_top > 0) {
     const uint32_t total = (uint32_t)f.pad_top;
     if (total > cap_bytes)
       overflow = true;
     while (!overflow && base < total) {
-      const uint32_t hi = min(total, flushed + (uint32_t)RING);
+      const uint32_t lo = flushed;
+      const uint32_t hi = min(total, lo + (uint32_t)RING);
       for (uint32_t o = base + (uint32_t)tid; o < hi; o += BLOCK)
-        ring[o & (RING - 1u)] = '\n';
+        ring[o - lo] = '\n';
       __syncthreads();
-      drain_ring<BLOCK, RING>(L::o_ring, dst, flushed, hi);
-      __syncthreads();
+      drain_ring<BLOCK>(L::o_ring, dst, lo, hi);
       flushed = hi & ~15u;
+      if (tid == 0 && flushed > lo) {
+        for (uint32_t j = 0; j < hi - flushed; j++)
+          ring[j] = ring[flushed - lo + j];
+      }
       base = hi;
+      __syncthreads();
     }
   }
   __syncthreads();
@@ -982,7 +993,6 @@ __global__ void __launch_bounds__(BLOCK)
       }
     }
   };
-  gather_issue(0, min(rows, rows_per_chunk) * wp);
   ACHIP_STAMP(0);
 
   for (int r0 = 0; r0 < rows; r0 += rows_per_chunk) {
@@ -995,8 +1005,10 @@ __global__ void __launch_bounds__(BLOCK)
 #define ACHIP_CELL_RR(k) row_of(tid + (k)*BLOCK, wp_magic)
 #define ACHIP_CELL_XP(k) (tid + (k)*BLOCK - ACHIP_CELL_RR(k) * wp)
 
-    /* ---- A: commit the samples requested one chunk ago (see the prefetch below) to LDS, with the
-     * mode's run key in bits 31..24 ------------------------------------------------------------- */
+    /* ---- A: gather the chunk's samples and commit them to LDS with the mode's run key in bits 31..24.
+     * (Requesting chunk c+1 before tokenising chunk c was measured and does not pay: the sparse loads
+     * stall at ISSUE -- 64 distinct lines per wave instruction -- so there is nothing left to hide.) --- */
+    gather_issue(r0, n);
 #pragma unroll
     for (int k = 0; k < SEG; k++) {
       const int i = tid + k * BLOCK;
@@ -1019,10 +1031,6 @@ __global__ void __launch_bounds__(BLOCK)
       }
     }
     __syncthreads();
-    /* software pipeline: request the NEXT chunk's samples now; the sparse 64-byte-sector fetches (the
-     * memory-bound part of the frame) stay in flight while this chunk is tokenised, scanned and stored */
-    if (r1 < rows)
-      gather_issue(r1, (min(rows, r1 + rows_per_chunk) - r1) * wp);
     ACHIP_STAMP(1);
     if (MODE == ACHIP_MODE_16_DITHER_BG) { /* one wave diffuses the errors and leaves the colour index in the key byte */
       if (wave == 0)
@@ -1112,64 +1120,57 @@ __global__ void __launch_bounds__(BLOCK)
     if ((uint64_t)base + total > cap_bytes)
       overflow = true;
 
-    /* ---- E: store the tokens through the ring, one window of the stream at a time ------------------ */
+    /* ---- E: store the tokens into the LDS staging buffer and drain it to HBM, one window of the stream
+     * at a time.  The buffer is linear: its byte 0 is stream offset `flushed` (16-byte aligned).  A window is
+     * cut at a TOKEN boundary -- the first token that does not fit entirely waits for the next window -- so a
+     * token never straddles anything and every store is a plain, unchecked LDS byte store.  After a drain the
+     * < 16 not-yet-flushable tail bytes are moved to the front by the one thread that owns 16-byte group 0. */
     const uint32_t chunk_end = base + total;
     const bool last_chunk = r1 >= rows;
+    uint32_t done = base; /* tokens starting below `done` are already in the buffer or in HBM */
     while (!overflow) {
       const uint32_t lo = flushed, hi = flushed + (uint32_t)RING;
-      uint32_t strad = 0; /* bit k: cell k was written to a straddler slot; bits 8+4k..: its slot */
+      uint32_t *cut_slot = &flags[1 + (window_no & 1)];
 #pragma unroll
       for (int k = 0; k < SEG; k++) {
         const uint32_t a = base + off[k];
         const uint32_t b = a + len[k];
-        if (b > a && a < hi && b > lo) {
-          const uint32_t ra = a & (RING - 1u);
-          uint32_t target = ring_addr + ra;
-          if (!(a >= lo && b <= hi && ra + len[k] <= (uint32_t)RING)) {
-            const uint32_t slot = atomicAdd(&flags[1], 1u) & (uint32_t)(L::STRAD_SLOTS - 1);
-            strad |= (1u << k) | (slot << (8 + 4 * k));
-            target = strad_addr + slot * 64u;
-          }
+        if (len[k] != 0u && a >= done) {
+          if (b <= hi) {
 #if !defined(ACHIP_ABLATE) || ACHIP_ABLATE != 2
-          FastSink<L::o_dec, L::o_flags + 8> fs{target, dummy_addr};
-          token_fields<MODE>(fs, tok[k], ascii_only);
+            FastSink<L::o_dec, L::o_flags + 12> fs{ring_addr + (a - lo), dummy_addr};
+            token_fields<MODE>(fs, tok[k], ascii_only);
 #else
-          asm volatile("" ::"v"(target), "v"(tok[k].flags), "v"(tok[k].fg), "v"(tok[k].glyph));
+            asm volatile("" ::"v"(a), "v"(tok[k].flags), "v"(tok[k].fg), "v"(tok[k].glyph));
 #endif
-        }
-      }
-      if (strad) { /* rare: copy the linear slot into the ring, byte by byte, inside the window only */
-        lds_store_fence();
-#pragma unroll
-        for (int k = 0; k < SEG; k++) {
-          if (strad & (1u << k)) {
-            const unsigned char *slot = lds_ptr<const unsigned char>(L::o_strad) + ((strad >> (8 + 4 * k)) & 15u) * 64u;
-            const uint32_t a = base + off[k];
-            for (uint32_t j = 0; j < len[k]; j++) {
-              const uint32_t o = a + j;
-              if (o >= lo && o < hi)
-                ring[o & (RING - 1u)] = slot[j];
-            }
+          } else if (a <= hi) {
+            *cut_slot = a; /* the unique token that starts inside the window but does not fit: the cut */
           }
         }
       }
       lds_store_fence();
       __syncthreads();
       ACHIP_STAMP(5);
+      const uint32_t cut = min(*cut_slot, chunk_end);
       if (tid == 0)
-        flags[1] = 0u; /* next use is at least one barrier away */
-      const uint32_t avail = min(chunk_end, hi);
-      drain_ring<BLOCK, RING>(L::o_ring, dst, flushed, avail);
-      if (last_chunk && avail == chunk_end) { /* frame tail: < 16 bytes, byte stores */
-        for (uint32_t o = (avail & ~15u) + (uint32_t)tid; o < avail; o += BLOCK)
-          dst[o] = ring[o & (RING - 1u)];
+        flags[1 + ((window_no + 1) & 1)] = 0xFFFFFFFFu; /* next window's slot; its last readers are a barrier behind */
+      window_no++;
+      drain_ring<BLOCK>(L::o_ring, dst, lo, cut);
+      if (last_chunk && cut == chunk_end) { /* frame tail: < 16 bytes, byte stores */
+        for (uint32_t o = (cut & ~15u) + (uint32_t)tid; o < cut; o += BLOCK)
+          dst[o] = ring[o - lo];
       }
-      flushed = avail & ~15u;
-      if (chunk_end <= hi) {
+      flushed = cut & ~15u;
+      if (tid == 0 && flushed > lo) { /* tid 0 drained group 0 itself (program order): safe to overwrite it */
+        for (uint32_t j = 0; j < cut - flushed; j++)
+          ring[j] = ring[flushed - lo + j];
+      }
+      done = cut;
+      if (cut >= chunk_end) {
         ACHIP_STAMP(6);
-        break; /* the next ring writes are several barriers away (next chunk's A/B/D) */
+        break; /* the next buffer writes are several barriers away (next chunk's A/B/D) */
       }
-      __syncthreads(); /* the next window overwrites ring bytes that are being drained */
+      __syncthreads(); /* the next window overwrites bytes that are being drained */
       ACHIP_STAMP(6);
     }
     base = chunk_end;

@@ -2,7 +2,7 @@
  * render_variants.h -- the (BLOCK, CAP, RING) geometries the frame kernel is instantiated for.
  *   BLOCK  threads per workgroup (one workgroup renders one frame)
  *   CAP    cells per chunk; a padded text row (pad_left + out_w) must fit in one chunk
- *   RING   bytes of the LDS output ring
+ *   RING   bytes of the LDS output staging buffer (multiple of 16)
  * X(id, BLOCK, CAP, RING)
  */
 #ifndef ACHIP_RENDER_VARIANTS_H
@@ -13,7 +13,8 @@
   X(1, 512, 2048, 32768)  /* narrow: rows up to 2048 cells, 2-3 workgroups per CU                               */ \
   X(2, 256, 1024, 16384)  /* small grids (<= 1024-cell rows): 4+ workgroups per CU                              */ \
   X(3, 64, 256, 256)      /* test geometry: forces multi-chunk frames and ring wrap-around on tiny inputs      */ \
-  X(4, 1024, 2048, 65536) /* rows up to 2048 cells, 2 cells per thread: lowest register pressure                */
+  X(4, 1024, 2048, 114688) /* rows up to 2048 cells, 2 cells per thread (no spills); 112 KB staging: one window per
+                              chunk even for 41-byte half-block tokens; with the other tables ~132-156 KB of the 160 KB LDS */
 
 #define ACHIP_VARIANT_COUNT 5
 
