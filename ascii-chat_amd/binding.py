@@ -29,7 +29,7 @@ class Composite(C.Structure):
 class Frame(C.Structure):
     _fields_ = [("src", C.c_void_p), ("comp", C.c_void_p), ("src_w", C.c_int32), ("src_h", C.c_int32),
                 ("out_w", C.c_int32), ("out_h", C.c_int32), ("pad_left", C.c_int32), ("pad_top", C.c_int32),
-                ("x_ratio", C.c_uint32), ("y_ratio", C.c_uint32), ("src_stride", C.c_int32), ("_pad0", C.c_int32)]
+                ("x_ratio", C.c_uint32), ("y_ratio", C.c_uint32), ("src_stride", C.c_int32), ("ops", C.c_uint32)]
 
 
 class Image(C.Structure):  # image_t
@@ -100,6 +100,10 @@ def lib():
     L.asciichat_hip_composite.argtypes = [C.POINTER(Composite), vp, vp]
     L.asciichat_hip_composite_upload.restype = ci
     L.asciichat_hip_composite_upload.argtypes = [C.POINTER(Composite), C.POINTER(vp)]
+    L.asciichat_hip_apply_color_filter.restype = ci
+    L.asciichat_hip_apply_color_filter.argtypes = [vp, ci, ci, ci, ci, vp]
+    L.asciichat_hip_image_flip.restype = ci
+    L.asciichat_hip_image_flip.argtypes = [vp, vp, ci, ci, ci, ci, vp]
     L.asciichat_hip_free.restype = None
     L.asciichat_hip_free.argtypes = [vp]
     # achip_host.h
@@ -109,6 +113,8 @@ def lib():
     L.achip_mode_from_caps.argtypes = [ci, ci]
     L.achip_frame_setup.restype = ci
     L.achip_frame_setup.argtypes = [C.POINTER(Frame), vp, ci, ci, ss, ss, ci, C.c_bool, C.c_bool, C.c_bool]
+    L.achip_frame_set_display_ops.restype = ci
+    L.achip_frame_set_display_ops.argtypes = [C.POINTER(Frame), C.c_bool, C.c_bool, ci]
     L.achip_frame_identity.restype = ci
     L.achip_frame_identity.argtypes = [C.POINTER(Frame), vp, ci, ci]
     L.achip_out_bound.restype = sz

@@ -106,6 +106,32 @@ int achip_mode_from_caps(int color_level, int render_mode) {
   }
 }
 
+/* tint colours and modes of lib/video/rgba/color_filter.c:24-150 (index = color_filter_t) */
+static const struct {
+  uint8_t r, g, b, on_white;
+} k_filters[12] = {{0, 0, 0, 0},     {0, 0, 0, 1},     {255, 255, 255, 0}, {0, 255, 65, 0},  {255, 0, 255, 0}, {255, 0, 170, 0},
+                   {255, 136, 0, 0}, {0, 221, 221, 0}, {0, 255, 255, 0},   {255, 182, 193, 0}, {255, 51, 51, 0}, {255, 235, 153, 0}};
+
+int achip_frame_set_display_ops(achip_frame_t *f, bool flip_x, bool flip_y, int color_filter) {
+  if (!f || color_filter < 0 || color_filter >= 12)
+    return -1;
+  uint32_t ops = 0;
+  if (f->src_w > 1 && f->src_h > 1) { /* display.c:549 */
+    if (flip_x)
+      ops |= ACHIP_OP_FLIP_X;
+    if (flip_y)
+      ops |= ACHIP_OP_FLIP_Y;
+  }
+  if (color_filter != 0) {
+    ops |= ACHIP_OP_TINT | (k_filters[color_filter].on_white ? ACHIP_OP_TINT_ON_WHITE : 0u);
+    ops |= ((uint32_t)k_filters[color_filter].r | ((uint32_t)k_filters[color_filter].g << 8) |
+            ((uint32_t)k_filters[color_filter].b << 16))
+           << ACHIP_OP_TINT_SHIFT;
+  }
+  f->ops = ops;
+  return 0;
+}
+
 uint32_t achip_nn_ratio(int src, int dst) { return (uint32_t)((((uint64_t)src << 16) / (uint64_t)dst) + 1u); }
 
 int achip_frame_identity(achip_frame_t *f, const uint8_t *src_dev, int w, int h) {

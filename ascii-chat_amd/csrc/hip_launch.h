@@ -18,6 +18,11 @@ int achip_launch_render(int mode, int variant, int has_composite, const achip_fr
 int achip_launch_resize(const uint8_t *src, int sw, int sh, uint8_t *dst, int dw, int dh, void *stream);
 int achip_launch_composite(const achip_composite_t *comp_dev, int canvas_w, int canvas_h, uint8_t *dst, void *stream);
 
+/* display-path streaming passes (stream_kernels.hpp); ops as in achip_frame_t.ops */
+int achip_launch_tint(uint8_t *px, int w, int h, int stride, uint32_t ops, void *stream);
+int achip_launch_flip(const uint8_t *src, uint8_t *dst, int w, int h, int src_stride, int dst_stride, uint32_t ops,
+                      void *stream);
+
 int achip_variant_block(int variant); /* threads per workgroup, -1 for an unknown id */
 int achip_variant_cap(int variant);   /* cells per chunk                               */
 int achip_variant_lds_bytes(int mode, int variant);

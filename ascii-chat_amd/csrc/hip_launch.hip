@@ -146,3 +146,38 @@ extern "C" int achip_launch_composite(const achip_composite_t *comp_dev, int can
                      dst);
   return (int)hipGetLastError();
 }
+
+/* ---- display-path streaming passes (stream_kernels.hpp) -------------------------------------------- */
+#include "stream_kernels.hpp"
+
+static unsigned stream_blocks(uint64_t items) {
+  uint64_t b = (items + 255) / 256;
+  return (unsigned)(b < 1 ? 1 : (b > 256u * 16u ? 256u * 16u : b)); /* <= 16 workgroups per CU, grid-stride beyond */
+}
+
+extern "C" int achip_launch_tint(uint8_t *px, int w, int h, int stride, uint32_t ops, void *stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (stride == 3 * w && (reinterpret_cast<uintptr_t>(px) & 15u) == 0) {
+    const uint64_t nbytes = (uint64_t)w * (uint64_t)h * 3u;
+    hipLaunchKernelGGL(achip::tint_stream_kernel, dim3(stream_blocks(nbytes / 48u + 1)), dim3(256), 0, s, px, nbytes,
+                       ops);
+  } else {
+    hipLaunchKernelGGL(achip::tint_pixels_kernel, dim3(stream_blocks((uint64_t)w * (uint64_t)h)), dim3(256), 0, s, px,
+                       w, h, stride, ops);
+  }
+  return (int)hipGetLastError();
+}
+
+extern "C" int achip_launch_flip(const uint8_t *src, uint8_t *dst, int w, int h, int src_stride, int dst_stride,
+                                 uint32_t ops, void *stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool vec = w % 16 == 0 && src_stride == 3 * w && dst_stride == 3 * w &&
+                   ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0;
+  if (vec)
+    hipLaunchKernelGGL(achip::flip_stream_kernel, dim3(stream_blocks((uint64_t)(w / 16) * (uint64_t)h)), dim3(256), 0,
+                       s, src, dst, w, h, ops);
+  else
+    hipLaunchKernelGGL(achip::flip_pixels_kernel, dim3(stream_blocks((uint64_t)w * (uint64_t)h)), dim3(256), 0, s, src,
+                       dst, w, h, src_stride, dst_stride, ops);
+  return (int)hipGetLastError();
+}

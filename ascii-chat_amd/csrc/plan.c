@@ -314,6 +314,37 @@ int asciichat_hip_composite_upload(const achip_composite_t *comp_host, achip_com
   return 0;
 }
 
+int asciichat_hip_apply_color_filter(uint8_t *pixels_dev, int width, int height, int stride, int color_filter,
+                                     void *stream) {
+  if (!pixels_dev || width <= 0 || height <= 0 || stride < 3 * width)
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "apply_color_filter: bad arguments");
+  achip_frame_t probe;
+  memset(&probe, 0, sizeof(probe));
+  if (achip_frame_set_display_ops(&probe, false, false, color_filter) != 0)
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "apply_color_filter: unknown or unsupported filter %d",
+                      color_filter);
+  if (!(probe.ops & ACHIP_OP_TINT))
+    return 0; /* COLOR_FILTER_NONE */
+  int rc = achip_require_device();
+  if (rc)
+    return rc;
+  return achip_hip_check(achip_launch_tint(pixels_dev, width, height, stride, probe.ops, stream), "tint launch");
+}
+
+int asciichat_hip_image_flip(const uint8_t *src_dev, uint8_t *dst_dev, int width, int height, int flip_x, int flip_y,
+                             void *stream) {
+  if (!src_dev || !dst_dev || src_dev == dst_dev || width <= 0 || height <= 0)
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "image_flip: bad arguments");
+  int rc = achip_require_device();
+  if (rc)
+    return rc;
+  uint32_t ops = 0;
+  if (width > 1 && height > 1) /* display.c:549 */
+    ops = (flip_x ? ACHIP_OP_FLIP_X : 0u) | (flip_y ? ACHIP_OP_FLIP_Y : 0u);
+  return achip_hip_check(achip_launch_flip(src_dev, dst_dev, width, height, 3 * width, 3 * width, ops, stream),
+                         "flip launch");
+}
+
 void asciichat_hip_free(void *dev_ptr) {
   if (dev_ptr)
     (void)hipFree(dev_ptr);

@@ -379,6 +379,24 @@ __device__ inline uint32_t load_rgb(const uint8_t *__restrict__ src, int32_t str
   return ((const ACHIP_GLOBAL unaligned_u32 *)(p - 1))->v >> 8;
 }
 
+/* apply_color_filter for one pixel (lib/video/rgba/color_filter.c:246-345; rgb_to_grayscale color_filter.h:172:
+ * (77R + 150G + 29B) >> 8, no rounding term) */
+__device__ inline uint32_t tint_pixel(uint32_t p, uint32_t ops) {
+  const uint32_t gray = (77u * px_r(p) + 150u * px_g(p) + 29u * px_b(p)) >> 8;
+  const uint32_t t = ops >> ACHIP_OP_TINT_SHIFT;
+  uint32_t r, g, b;
+  if (ops & ACHIP_OP_TINT_ON_WHITE) {
+    r = (px_r(t) * (255u - gray) + 255u * gray) / 255u;
+    g = (px_g(t) * (255u - gray) + 255u * gray) / 255u;
+    b = (px_b(t) * (255u - gray) + 255u * gray) / 255u;
+  } else {
+    r = (px_r(t) * gray) / 255u;
+    g = (px_g(t) * gray) / 255u;
+    b = (px_b(t) * gray) / 255u;
+  }
+  return r | (g << 8) | (b << 16);
+}
+
 /* pixel (X,Y) of the virtual W x 2H composite canvas (stream.c:664-779): the tile of the cell that
  * contains it, nearest-neighbour resized on the fly; black outside every tile. */
 __device__ inline uint32_t sample_composite(const achip_composite_t *__restrict__ cgen, uint32_t X, uint32_t Y) {
@@ -411,9 +429,17 @@ template <bool COMP> __device__ inline uint32_t sample_frame(const achip_frame_t
 #if defined(ACHIP_ABLATE) && ACHIP_ABLATE == 3
   return (sx * 2654435761u + sy * 40503u) & 0x00FFFFFFu; /* diagnostics: no memory access */
 #endif
-  if (COMP)
-    return f.comp ? sample_composite(f.comp, sx, sy) : load_rgb(f.src, f.src_stride, sx, sy);
-  return load_rgb(f.src, f.src_stride, sx, sy);
+  if (COMP && f.comp)
+    return sample_composite(f.comp, sx, sy);
+  /* display-path pre-passes folded in (uniform per frame): flip = index map, tint = per-sample map */
+  if (f.ops & ACHIP_OP_FLIP_X)
+    sx = (uint32_t)f.src_w - 1u - sx;
+  if (f.ops & ACHIP_OP_FLIP_Y)
+    sy = (uint32_t)f.src_h - 1u - sy;
+  uint32_t p = load_rgb(f.src, f.src_stride, sx, sy);
+  if (f.ops & ACHIP_OP_TINT)
+    p = tint_pixel(p, f.ops);
+  return p;
 }
 
 /* ------------------------------------------------------------------------------------------- */

@@ -1,0 +1,134 @@
+/*
+ * stream_kernels.hpp -- the two full-frame passes of the client display path as stand-alone HBM-streaming
+ * kernels: apply_color_filter (lib/video/rgba/color_filter.c:274-345) and the
+ * x/y flips of session_display_convert_to_ascii (src/common/session/display.c:546-600).
+ *
+ * The render kernel does not need them -- achip_frame_t.ops folds both into its sampler, touching ~2 K
+ * pixels instead of 2 M -- but callers that want the transformed IMAGE get it at memory speed: every byte
+ * is read once and written once with 16-byte accesses (16 RGB24 pixels = 48 bytes = three uint4 per
+ * thread); these are the genuinely bandwidth-bound neighbours of the path.
+ */
+#pragma once
+
+#include "render_kernels.hpp"
+
+namespace achip {
+
+/* one RGB24 pixel through the filter; `ops` as in achip_frame_t.ops */
+__device__ inline uint32_t tint_rgb(uint32_t r, uint32_t g, uint32_t b, uint32_t ops) {
+  return tint_pixel(r | (g << 8) | (b << 16), ops);
+}
+
+/* 48 bytes = 16 pixels held in 12 dwords: apply `fn` to every pixel in place */
+template <class F> __device__ inline void map_16_pixels(uint32_t (&w)[12], F fn) {
+#pragma unroll
+  for (int q = 0; q < 4; q++) { /* 4 pixels = 3 dwords: R0G0B0R1 G1B1R2G2 B2R3G3B3 */
+    uint32_t &a = w[3 * q], &b = w[3 * q + 1], &c = w[3 * q + 2];
+    const uint32_t p0 = fn(a & 0x00FFFFFFu);
+    const uint32_t p1 = fn((a >> 24) | ((b & 0xFFFFu) << 8));
+    const uint32_t p2 = fn((b >> 16) | ((c & 0xFFu) << 16));
+    const uint32_t p3 = fn(c >> 8);
+    a = p0 | (p1 << 24);
+    b = (p1 >> 8) | (p2 << 16);
+    c = (p2 >> 16) | (p3 << 8);
+  }
+}
+
+/* in-place tint of a tightly packed RGB24 buffer of `nbytes` (multiple of 3), base 16-byte aligned */
+__global__ void __launch_bounds__(256) tint_stream_kernel(uint8_t *__restrict__ px, uint64_t nbytes, uint32_t ops) {
+  const uint64_t groups = nbytes / 48u;
+  for (uint64_t gidx = (uint64_t)blockIdx.x * 256u + threadIdx.x; gidx < groups; gidx += (uint64_t)gridDim.x * 256u) {
+    uint4 *p = reinterpret_cast<uint4 *>(px + gidx * 48u);
+    uint4 v0 = p[0], v1 = p[1], v2 = p[2];
+    uint32_t w[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
+    map_16_pixels(w, [ops](uint32_t rgb) { return tint_pixel(rgb, ops); });
+    p[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    p[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    p[2] = make_uint4(w[8], w[9], w[10], w[11]);
+  }
+  /* tail (< 16 pixels) */
+  const uint64_t tail0 = groups * 48u;
+  for (uint64_t o = tail0 + 3u * ((uint64_t)blockIdx.x * 256u + threadIdx.x); o + 2u < nbytes;
+       o += 3u * (uint64_t)gridDim.x * 256u) {
+    const uint32_t r = tint_rgb(px[o], px[o + 1], px[o + 2], ops);
+    px[o] = (uint8_t)r;
+    px[o + 1] = (uint8_t)(r >> 8);
+    px[o + 2] = (uint8_t)(r >> 16);
+  }
+}
+
+/* generic (strided / unaligned) variant: one pixel per thread */
+__global__ void __launch_bounds__(256)
+    tint_pixels_kernel(uint8_t *__restrict__ px, int w, int h, int stride, uint32_t ops) {
+  const uint64_t total = (uint64_t)w * (uint64_t)h;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < total; i += (uint64_t)gridDim.x * 256u) {
+    const uint32_t y = (uint32_t)(i / (uint32_t)w), x = (uint32_t)(i - (uint64_t)y * (uint32_t)w);
+    uint8_t *p = px + (size_t)y * (size_t)stride + (size_t)x * 3u;
+    const uint32_t r = tint_rgb(p[0], p[1], p[2], ops);
+    p[0] = (uint8_t)r;
+    p[1] = (uint8_t)(r >> 8);
+    p[2] = (uint8_t)(r >> 16);
+  }
+}
+
+/* out-of-place flip of a tightly packed image whose rows are a multiple of 48 bytes (w % 16 == 0):
+ * group g of source row y goes, pixel-reversed when flip_x, to the mirrored group of the target row */
+__global__ void __launch_bounds__(256)
+    flip_stream_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int w, int h, uint32_t ops) {
+  const uint32_t gpr = (uint32_t)w / 16u; /* groups per row */
+  const uint64_t groups = (uint64_t)gpr * (uint64_t)h;
+  for (uint64_t gidx = (uint64_t)blockIdx.x * 256u + threadIdx.x; gidx < groups; gidx += (uint64_t)gridDim.x * 256u) {
+    const uint32_t y = (uint32_t)(gidx / gpr), g = (uint32_t)(gidx - (uint64_t)y * gpr);
+    const uint4 *p = reinterpret_cast<const uint4 *>(src + ((size_t)y * gpr + g) * 48u);
+    const uint4 v0 = p[0], v1 = p[1], v2 = p[2];
+    uint32_t a[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
+    uint32_t o[12];
+    if (ops & ACHIP_OP_FLIP_X) {
+      /* pixel k of the output group = pixel 15-k of the input group */
+      uint32_t px[16];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        px[4 * q + 0] = a[3 * q] & 0x00FFFFFFu;
+        px[4 * q + 1] = (a[3 * q] >> 24) | ((a[3 * q + 1] & 0xFFFFu) << 8);
+        px[4 * q + 2] = (a[3 * q + 1] >> 16) | ((a[3 * q + 2] & 0xFFu) << 16);
+        px[4 * q + 3] = a[3 * q + 2] >> 8;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const uint32_t p0 = px[15 - 4 * q], p1 = px[14 - 4 * q], p2 = px[13 - 4 * q], p3 = px[12 - 4 * q];
+        o[3 * q] = p0 | (p1 << 24);
+        o[3 * q + 1] = (p1 >> 8) | (p2 << 16);
+        o[3 * q + 2] = (p2 >> 16) | (p3 << 8);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 12; k++)
+        o[k] = a[k];
+    }
+    const uint32_t ty = (ops & ACHIP_OP_FLIP_Y) ? (uint32_t)h - 1u - y : y;
+    const uint32_t tg = (ops & ACHIP_OP_FLIP_X) ? gpr - 1u - g : g;
+    uint4 *q = reinterpret_cast<uint4 *>(dst + ((size_t)ty * gpr + tg) * 48u);
+    q[0] = make_uint4(o[0], o[1], o[2], o[3]);
+    q[1] = make_uint4(o[4], o[5], o[6], o[7]);
+    q[2] = make_uint4(o[8], o[9], o[10], o[11]);
+  }
+}
+
+/* generic flip: one pixel per thread, any width / stride */
+__global__ void __launch_bounds__(256)
+    flip_pixels_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, int w, int h, int src_stride,
+                       int dst_stride, uint32_t ops) {
+  const uint64_t total = (uint64_t)w * (uint64_t)h;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < total; i += (uint64_t)gridDim.x * 256u) {
+    const uint32_t y = (uint32_t)(i / (uint32_t)w), x = (uint32_t)(i - (uint64_t)y * (uint32_t)w);
+    const uint32_t sx = (ops & ACHIP_OP_FLIP_X) ? (uint32_t)w - 1u - x : x;
+    const uint32_t sy = (ops & ACHIP_OP_FLIP_Y) ? (uint32_t)h - 1u - y : y;
+    const uint8_t *s = src + (size_t)sy * (size_t)src_stride + (size_t)sx * 3u;
+    uint8_t *d = dst + (size_t)y * (size_t)dst_stride + (size_t)x * 3u;
+    d[0] = s[0];
+    d[1] = s[1];
+    d[2] = s[2];
+  }
+}
+
+} // namespace achip

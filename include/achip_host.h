@@ -38,6 +38,12 @@ int achip_frame_setup(achip_frame_t *f, const uint8_t *src_dev, int src_w, int s
 /* Descriptor for rendering an image as-is (image_print_* / rgb_to_*_halfblocks_scalar on an already sized image). */
 int achip_frame_identity(achip_frame_t *f, const uint8_t *src_dev, int w, int h);
 
+/* Fold the display path's pre-passes into a frame descriptor (session_display_convert_to_ascii,
+ * src/common/session/display.c:546-623): flips apply only to images larger than 1x1 (display.c:549);
+ * color_filter is the reference's color_filter_t (0 none, 1 black .. 11 yellow; 12 = rainbow is a
+ * post-pass on the ANSI string there and is rejected here).  Returns 0, or -1 for an unknown filter. */
+int achip_frame_set_display_ops(achip_frame_t *f, bool flip_x, bool flip_y, int color_filter);
+
 /* 16.16 nearest-neighbour ratio, image.c:293-294 */
 uint32_t achip_nn_ratio(int src, int dst);
 

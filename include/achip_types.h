@@ -58,8 +58,17 @@ typedef struct {
   int32_t pad_left, pad_top;     /* ascii_pad_frame_width / _height folded into the emission       */
   uint32_t x_ratio, y_ratio;     /* ((src << 16) / out) + 1                                         */
   int32_t src_stride;            /* bytes per source row; 0 = tightly packed (3*src_w)              */
-  int32_t _pad0;
+  uint32_t ops;                  /* display-path pre-passes folded into the sampler: ACHIP_OP_* | tint << 8 */
 } achip_frame_t;
+
+/* achip_frame_t.ops: the client display path flips the frame and applies a monochrome tint on full-frame
+ * copies before rendering (src/common/session/display.c:546-623, lib/video/rgba/color_filter.c:246-345).
+ * Both commute with nearest-neighbour sampling, so here they are an index map and a per-sample map. */
+#define ACHIP_OP_FLIP_X 1u      /* sample column src_w-1-x                                   */
+#define ACHIP_OP_FLIP_Y 2u      /* sample row    src_h-1-y                                   */
+#define ACHIP_OP_TINT 4u        /* grey = (77R+150G+29B)>>8, channel = tint*grey/255          */
+#define ACHIP_OP_TINT_ON_WHITE 8u /* foreground_on_bg filters: (tint*(255-grey) + 255*grey)/255 */
+#define ACHIP_OP_TINT_SHIFT 8   /* bits 31..8: tint colour 0xBBGGRR                           */
 
 /* Glyph tables of one palette (utf8_palette_cache_t restated, common.c:380-490).  A glyph is its
  * UTF-8 bytes packed little-endian in a u32; its length follows from the lead byte. */

@@ -98,6 +98,15 @@ int asciichat_hip_resize(const uint8_t *src_dev, int src_w, int src_h, uint8_t *
  * comp_host is filled by achip_composite_setup(); dst_dev holds canvas_w*canvas_h*3 bytes. */
 int asciichat_hip_composite(const achip_composite_t *comp_host, uint8_t *dst_dev, void *stream);
 
+/* The client display path's full-frame passes on DEVICE images (RGB24): apply_color_filter
+ * (lib/video/rgba/color_filter.c:274-345; color_filter = the reference's color_filter_t 0..11, in place) and the
+ * x/y flips of src/common/session/display.c:546-600 (out of place).  The render path does not need them --
+ * achip_frame_set_display_ops() folds both into its sampler -- they exist for callers that want the image. */
+int asciichat_hip_apply_color_filter(uint8_t *pixels_dev, int width, int height, int stride, int color_filter,
+                                     void *stream);
+int asciichat_hip_image_flip(const uint8_t *src_dev, uint8_t *dst_dev, int width, int height, int flip_x, int flip_y,
+                             void *stream);
+
 /* Upload a composite descriptor for use as achip_frame_t.comp; free with asciichat_hip_free. */
 int asciichat_hip_composite_upload(const achip_composite_t *comp_host, achip_composite_t **comp_dev);
 void asciichat_hip_free(void *dev_ptr);

@@ -782,6 +782,77 @@ char *orc_convert(const uint8_t *rgb, int src_w, int src_h, long width, long hei
 }
 
 /* ------------------------------------------------------------------------- */
+/* display-path pre-passes                                                     */
+/* ------------------------------------------------------------------------- */
+void orc_flip(uint8_t *rgb, int w, int h, bool flip_x, bool flip_y) {
+  if (!rgb || !(flip_x || flip_y) || w <= 1 || h <= 1) /* display.c:549 */
+    return;
+  if (flip_x) {
+    for (int y = 0; y < h; y++) {
+      uint8_t *row = rgb + (size_t)y * w * 3;
+      for (int x = 0; x < w / 2; x++) {
+        uint8_t t[3];
+        memcpy(t, row + 3 * x, 3);
+        memcpy(row + 3 * x, row + 3 * (w - 1 - x), 3);
+        memcpy(row + 3 * (w - 1 - x), t, 3);
+      }
+    }
+  }
+  if (flip_y) {
+    uint8_t *tmp = (uint8_t *)malloc((size_t)w * 3);
+    for (int y = 0; y < h / 2; y++) {
+      uint8_t *a = rgb + (size_t)y * w * 3, *b = rgb + (size_t)(h - 1 - y) * w * 3;
+      memcpy(tmp, a, (size_t)w * 3);
+      memcpy(a, b, (size_t)w * 3);
+      memcpy(b, tmp, (size_t)w * 3);
+    }
+    free(tmp);
+  }
+}
+
+/* the registry of color_filter.c:24-150: {r, g, b, foreground_on_bg}, index = color_filter_t */
+static const uint8_t k_filter_tint[12][4] = {{0, 0, 0, 0},     {0, 0, 0, 1},     {255, 255, 255, 0}, {0, 255, 65, 0},
+                                             {255, 0, 255, 0}, {255, 0, 170, 0}, {255, 136, 0, 0},   {0, 221, 221, 0},
+                                             {0, 255, 255, 0}, {255, 182, 193, 0}, {255, 51, 51, 0}, {255, 235, 153, 0}};
+
+int orc_color_filter(uint8_t *rgb, int w, int h, int stride, int color_filter) {
+  if (!rgb || w <= 0 || h <= 0 || stride <= 0)
+    return -1;
+  if (color_filter == 0)
+    return 0;
+  if (color_filter < 0 || color_filter >= 12)
+    return -1; /* 12 = rainbow: time-dependent float path + ANSI post-pass, not restated */
+  const uint8_t *t = k_filter_tint[color_filter];
+  for (int y = 0; y < h; y++) {
+    uint8_t *row = rgb + (size_t)y * (size_t)stride;
+    for (int x = 0; x < w; x++) {
+      uint8_t *px = row + 3 * x;
+      const unsigned gray = (77u * px[0] + 150u * px[1] + 29u * px[2]) >> 8; /* rgb_to_grayscale, color_filter.h:172 */
+      for (int k = 0; k < 3; k++)
+        px[k] = (uint8_t)(t[3] ? (t[k] * (255u - gray) + 255u * gray) / 255u : (t[k] * gray) / 255u);
+    }
+  }
+  return 0;
+}
+
+char *orc_display_convert(const uint8_t *rgb, int src_w, int src_h, long width, long height, int color_level,
+                          int render_mode, bool wants_padding, bool use_aspect, bool stretch, const char *palette,
+                          bool flip_x, bool flip_y, int color_filter, size_t *len) {
+  if (!rgb || src_w <= 0 || src_h <= 0)
+    return NULL;
+  const size_t bytes = (size_t)src_w * (size_t)src_h * 3;
+  uint8_t *copy = (uint8_t *)malloc(bytes);
+  memcpy(copy, rgb, bytes);
+  orc_flip(copy, src_w, src_h, flip_x, flip_y);
+  if (color_filter != 0 && color_filter != 12)
+    orc_color_filter(copy, src_w, src_h, src_w * 3, color_filter);
+  char *out = orc_convert_with_caps(copy, src_w, src_h, width, height, color_level, render_mode, wants_padding,
+                                    use_aspect, stretch, palette, len);
+  free(copy);
+  return out;
+}
+
+/* ------------------------------------------------------------------------- */
 /* G1: text-space grid (ascii.c:527-885)                                       */
 /* ------------------------------------------------------------------------- */
 static int csi_skip(const char *d, int n, int i) { /* i points at ESC '[' ; returns index after the final byte */

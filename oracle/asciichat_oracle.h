@@ -96,6 +96,14 @@ char *orc_convert_with_caps(const uint8_t *rgb, int src_w, int src_h, long width
 char *orc_convert(const uint8_t *rgb, int src_w, int src_h, long width, long height, bool color, bool use_aspect,
                   bool stretch, const char *palette, int option_render_mode, size_t *len);
 
+/* client display path pre-passes (src/common/session/display.c:546-623):
+ * flips on a full copy, then apply_color_filter (lib/video/rgba/color_filter.c:246-345) on another copy */
+void orc_flip(uint8_t *rgb, int w, int h, bool flip_x, bool flip_y);                 /* display.c:563-590 */
+int orc_color_filter(uint8_t *rgb, int w, int h, int stride, int color_filter);      /* color_filter.c:274-345 */
+char *orc_display_convert(const uint8_t *rgb, int src_w, int src_h, long width, long height, int color_level,
+                          int render_mode, bool wants_padding, bool use_aspect, bool stretch, const char *palette,
+                          bool flip_x, bool flip_y, int color_filter, size_t *len);
+
 /* ascii_create_grid, ascii.c:602-885 */
 typedef struct {
   const char *frame_data;

@@ -65,5 +65,46 @@ def main():
         torch.cuda.empty_cache()
 
 
+def stream_passes():
+    """HBM-streaming neighbours: colour filter (in place) and flips (out of place) on a batch of 1080p frames."""
+    import torch
+
+    from __graft_entry__ import load_package
+
+    pkg = load_package()
+    L = pkg.lib()
+    b, h, w = 64, 1080, 1920
+    src = torch.randint(0, 256, (b, h, w, 3), dtype=torch.uint8, device="cuda")
+    dst = torch.empty_like(src)
+    nbytes = b * h * w * 3
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def timeit(fn, reps=20):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    # the whole batch is one tightly packed buffer of b*h rows
+    ms = timeit(lambda: L.asciichat_hip_apply_color_filter(src.data_ptr(), w, b * h, 3 * w, 3, stream))
+    print(f"color_filter  {b}x1080p in place : {ms*1e3:8.1f} us  {2*nbytes/(ms*1e-3)/1e9:7.1f} GB/s (read+write) "
+          f"= {2*nbytes/(ms*1e-3)/8e12*100:4.1f} % of 8 TB/s")
+    for fx, fy in ((1, 0), (0, 1), (1, 1)):
+        ms = timeit(lambda: L.asciichat_hip_image_flip(src.data_ptr(), dst.data_ptr(), w, b * h, fx, fy, stream))
+        print(f"flip x={fx} y={fy} {b}x1080p          : {ms*1e3:8.1f} us  {2*nbytes/(ms*1e-3)/1e9:7.1f} GB/s (read+write) "
+              f"= {2*nbytes/(ms*1e-3)/8e12*100:4.1f} % of 8 TB/s")
+    ms = timeit(lambda: dst.copy_(src))
+    print(f"torch copy_ (reference point)      : {ms*1e3:8.1f} us  {2*nbytes/(ms*1e-3)/1e9:7.1f} GB/s")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "--stream-passes":
+        stream_passes()
+    else:
+        main()

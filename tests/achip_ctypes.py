@@ -32,7 +32,7 @@ class Composite(C.Structure):
 class Frame(C.Structure):
     _fields_ = [("src", C.c_void_p), ("comp", C.c_void_p), ("src_w", C.c_int32), ("src_h", C.c_int32),
                 ("out_w", C.c_int32), ("out_h", C.c_int32), ("pad_left", C.c_int32), ("pad_top", C.c_int32),
-                ("x_ratio", C.c_uint32), ("y_ratio", C.c_uint32), ("src_stride", C.c_int32), ("_pad0", C.c_int32)]
+                ("x_ratio", C.c_uint32), ("y_ratio", C.c_uint32), ("src_stride", C.c_int32), ("ops", C.c_uint32)]
 
 
 class Lut(C.Structure):
@@ -53,6 +53,8 @@ def bind_host(L):
                                     C.c_bool, C.c_bool]
     L.achip_frame_identity.restype = C.c_int
     L.achip_frame_identity.argtypes = [C.POINTER(Frame), C.c_void_p, C.c_int, C.c_int]
+    L.achip_frame_set_display_ops.restype = C.c_int
+    L.achip_frame_set_display_ops.argtypes = [C.POINTER(Frame), C.c_bool, C.c_bool, C.c_int]
     L.achip_nn_ratio.restype = C.c_uint32
     L.achip_nn_ratio.argtypes = [C.c_int, C.c_int]
     L.achip_out_bound.restype = C.c_size_t

@@ -18,7 +18,7 @@ _lib = None
 
 def build():
     srcs = [os.path.join(EMU_DIR, "emu_driver.cpp"), os.path.join(EMU_DIR, "hip_emu.h"),
-            os.path.join(CSRC, "render_kernels.hpp"), os.path.join(CSRC, "render_variants.h"),
+            os.path.join(CSRC, "render_kernels.hpp"), os.path.join(CSRC, "stream_kernels.hpp"), os.path.join(CSRC, "render_variants.h"),
             os.path.join(INC, "achip_types.h"), os.path.join(CSRC, "achip_host.c"), os.path.join(INC, "achip_host.h")]
     if os.path.exists(EMU_SO) and all(os.path.getmtime(s) <= os.path.getmtime(EMU_SO) for s in srcs):
         return EMU_SO
@@ -40,6 +40,10 @@ def lib():
         _lib.emu_resize_nn.restype = None
         _lib.emu_resize_nn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_uint32,
                                        C.c_uint32]
+        _lib.emu_tint.restype = None
+        _lib.emu_tint.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int]
+        _lib.emu_flip.restype = None
+        _lib.emu_flip.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_int]
         _lib.emu_composite.restype = None
         _lib.emu_composite.argtypes = [C.POINTER(Composite), C.c_void_p]
     return _lib

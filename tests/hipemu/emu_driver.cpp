@@ -58,3 +58,19 @@ extern "C" void emu_resize_nn(const uint8_t *src, int sw, int sh, uint8_t *dst, 
 extern "C" void emu_composite(const achip_composite_t *comp, uint8_t *dst) {
   hipemu::launch(dim3(2), dim3(256), 0, [&] { achip::composite_kernel(comp, dst); });
 }
+
+#include "stream_kernels.hpp"
+
+extern "C" void emu_tint(uint8_t *px, int w, int h, int stride, uint32_t ops, int vector_path) {
+  if (vector_path)
+    hipemu::launch(dim3(3), dim3(256), 0, [&] { achip::tint_stream_kernel(px, (uint64_t)w * h * 3u, ops); });
+  else
+    hipemu::launch(dim3(3), dim3(256), 0, [&] { achip::tint_pixels_kernel(px, w, h, stride, ops); });
+}
+
+extern "C" void emu_flip(const uint8_t *src, uint8_t *dst, int w, int h, uint32_t ops, int vector_path) {
+  if (vector_path)
+    hipemu::launch(dim3(3), dim3(256), 0, [&] { achip::flip_stream_kernel(src, dst, w, h, ops); });
+  else
+    hipemu::launch(dim3(3), dim3(256), 0, [&] { achip::flip_pixels_kernel(src, dst, w, h, 3 * w, 3 * w, ops); });
+}

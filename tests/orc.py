@@ -92,6 +92,13 @@ def lib():
         L.orc_grid_layout.argtypes = [vp, vp, ci, ci, ci, C.POINTER(ci), C.POINTER(ci)]
         L.orc_composite.restype = vp
         L.orc_composite.argtypes = [vp, vp, vp, ci, ci, ci, C.POINTER(ci), C.POINTER(ci)]
+        L.orc_flip.restype = None
+        L.orc_flip.argtypes = [vp, ci, ci, C.c_bool, C.c_bool]
+        L.orc_color_filter.restype = ci
+        L.orc_color_filter.argtypes = [vp, ci, ci, ci, ci]
+        L.orc_display_convert.restype = vp
+        L.orc_display_convert.argtypes = [vp, ci, ci, cl, cl, ci, ci, C.c_bool, C.c_bool, C.c_bool, C.c_char_p,
+                                          C.c_bool, C.c_bool, ci, C.POINTER(sz)]
         L.orc_bench_convert.restype = C.c_double
         L.orc_bench_convert.argtypes = [vp, ci, ci, ci, ci, ci, ci, C.c_char_p, ci, ci, C.POINTER(C.c_uint64)]
         L.free.argtypes = [vp]
@@ -151,6 +158,28 @@ def convert(img, width, height, color, use_aspect, stretch, palette=PALETTE_STAN
     p = lib().orc_convert(img.ctypes.data, img.shape[1], img.shape[0], width, height, color, use_aspect, stretch,
                           _pal(palette), option_render_mode, C.byref(n))
     return _take(p, n.value)
+
+
+def display_convert(img, width, height, color_level, render_mode, wants_padding=False, use_aspect=False,
+                    flip_x=False, flip_y=False, color_filter=0, palette=PALETTE_STANDARD):
+    img = _img(img)
+    n = C.c_size_t()
+    p = lib().orc_display_convert(img.ctypes.data, img.shape[1], img.shape[0], width, height, color_level, render_mode,
+                                  wants_padding, use_aspect, False, _pal(palette), flip_x, flip_y, color_filter,
+                                  C.byref(n))
+    return _take(p, n.value)
+
+
+def color_filter(img, flt):
+    out = _img(img).copy()
+    assert lib().orc_color_filter(out.ctypes.data, out.shape[1], out.shape[0], out.shape[1] * 3, flt) == 0
+    return out
+
+
+def flip(img, flip_x, flip_y):
+    out = _img(img).copy()
+    lib().orc_flip(out.ctypes.data, out.shape[1], out.shape[0], flip_x, flip_y)
+    return out
 
 
 def aspect_ratio(img_w, img_h, width, height, stretch=False):

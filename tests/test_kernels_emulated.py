@@ -77,3 +77,29 @@ def test_dither_multi_sweep_and_carry():
     exp = oracle_convert(img, MODE_16_DITHER_BG, 60, 40, orc.PALETTE_COOL, True, True)
     got = emu_convert(img, MODE_16_DITHER_BG, 60, 40, orc.PALETTE_COOL, 4, True, True)
     assert got == exp
+
+
+def test_display_prepasses_folded_into_sampler():
+    """flip_x / flip_y / colour filters of the client display path (display.c:546-623) as sampler maps."""
+    import ctypes as C
+
+    import numpy as np
+    img = orc.frame_torture()
+    # the oracle's flips agree with plain array reversal; odd sizes keep the middle column/row
+    assert np.array_equal(orc.flip(img, True, False), img[:, ::-1])
+    assert np.array_equal(orc.flip(img, False, True), img[::-1])
+    assert np.array_equal(orc.flip(img[:1], True, True), img[:1])  # h == 1: flips are skipped (display.c:549)
+    # reference filter semantics on known points: grey = (77R+150G+29B)>>8, channel = tint*grey/255
+    px = np.array([[[255, 255, 255], [0, 0, 0], [10, 200, 30]]], dtype=np.uint8)
+    assert orc.color_filter(px, 3).tolist() == [[[0, 255, 65], [0, 0, 0], [0, 123, 31]]]      # green (0,255,65)
+    assert orc.color_filter(px, 1).tolist() == [[[255, 255, 255], [0, 0, 0], [123, 123, 123]]]  # black-on-white
+    for mode, (cl, rm) in ((1, (3, 0)), (5, (3, 2)), (0, (0, 0)), (2, (2, 0))):
+        for fx, fy, flt in ((True, False, 0), (False, True, 0), (True, True, 3), (False, False, 1), (True, False, 9),
+                            (False, True, 11)):
+            f = emu.frame_for_convert(img, 97, 31, rm, True, True)
+            assert emu.lib().achip_frame_set_display_ops(C.byref(f), fx, fy, flt) == 0
+            got = emu.render_frames(mode, [f], orc.PALETTE_STANDARD, 2)[0]
+            exp = orc.display_convert(img, 97, 31, cl, rm, True, True, fx, fy, flt)
+            assert got == exp, (mode, fx, fy, flt)
+    f = emu.frame_for_convert(img, 97, 31, 0)
+    assert emu.lib().achip_frame_set_display_ops(C.byref(f), False, False, 12) == -1  # rainbow: not a pixel pre-pass

@@ -1,0 +1,110 @@
+"""Randomised differential tests: random frame sizes, grid sizes, paddings, modes, palettes and pixel
+statistics, HIP kernel source (under the CPU fiber emulator; on the GPU in the -m gpu variant) vs the oracle."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import emu  # noqa: E402
+import orc  # noqa: E402
+from achip_ctypes import ALL_MODES, MODE_CAPS, MODE_NAMES, MODE_TRUE_BG  # noqa: E402
+
+PALETTES = [orc.PALETTE_STANDARD, orc.PALETTE_BLOCKS, orc.PALETTE_MINIMAL, orc.PALETTE_COOL, "@", " .:-=+*#%@", "a█b"]
+
+
+def random_image(rng, w, h):
+    kind = rng.integers(0, 6)
+    if kind == 0:
+        return rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    if kind == 1:  # few colours, long runs
+        pal = rng.integers(0, 256, (4, 3), dtype=np.uint8)
+        pal[0] = 0
+        idx = np.repeat(rng.integers(0, 4, (h, (w + 6) // 7)), 7, axis=1)[:, :w]
+        return pal[idx]
+    if kind == 2:  # dark noise around the transparency / grey thresholds
+        return rng.integers(0, 3, (h, w, 3), dtype=np.uint8)
+    if kind == 3:
+        return orc.frame_smooth(w, h)
+    if kind == 4:
+        return orc.frame_bars(w, h, int(rng.integers(0, 9)))
+    g = rng.integers(0, 256, (h, w, 1), dtype=np.uint8)
+    return np.repeat(g, 3, axis=2) ^ rng.integers(0, 2, (h, w, 3), dtype=np.uint8)  # near-grey
+
+
+def random_case(rng):
+    sw, sh = int(rng.integers(1, 200)), int(rng.integers(1, 120))
+    W, H = int(rng.integers(1, 140)), int(rng.integers(1, 50))
+    mode = int(rng.choice(ALL_MODES))
+    aspect = bool(rng.integers(0, 2)) and mode != MODE_TRUE_BG
+    pad = bool(rng.integers(0, 2))
+    return sw, sh, W, H, mode, aspect, pad, PALETTES[int(rng.integers(0, len(PALETTES)))]
+
+
+def oracle_case(img, W, H, mode, aspect, pad, palette):
+    if mode == MODE_TRUE_BG:
+        return orc.print_truecolor_bg(orc.resize_nn(img, W, H), palette)
+    cl, rm = MODE_CAPS[mode]
+    return orc.convert_with_caps(img, W, H, cl, rm, pad, aspect, False, palette)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_cases_emulated(seed):
+    rng = np.random.default_rng(1000 + seed)
+    for _ in range(25):
+        sw, sh, W, H, mode, aspect, pad, palette = random_case(rng)
+        img = random_image(rng, sw, sh)
+        rm = MODE_CAPS.get(mode, (3, 0))[1]
+        f = emu.frame_for_convert(img, W, H, rm, pad, aspect)
+        exp = oracle_case(img, W, H, mode, aspect, pad, palette)
+        if f is None:
+            assert exp is None
+            continue
+        variant = int(rng.choice([3, 3, 2, 4]))
+        got = emu.render_frames(mode, [f], palette, variant)[0]
+        assert got == exp, (seed, sw, sh, W, H, MODE_NAMES[mode], aspect, pad, palette, variant)
+
+
+@pytest.mark.gpu
+def test_random_cases_gpu():
+    import torch
+
+    from __graft_entry__ import load_package
+
+    pkg = load_package()
+    torch.cuda.set_device(0)
+    rng = np.random.default_rng(4242)
+    for _round in range(12):
+        mode = int(rng.choice(ALL_MODES))
+        palette = PALETTES[int(rng.integers(0, len(PALETTES)))]
+        aspect = bool(rng.integers(0, 2)) and mode != MODE_TRUE_BG
+        pad = bool(rng.integers(0, 2))
+        rm = MODE_CAPS.get(mode, (3, 0))[1]
+        cases, frames, keep = [], [], []
+        for _ in range(40):
+            sw, sh = int(rng.integers(1, 700)), int(rng.integers(1, 400))
+            W, H = int(rng.integers(1, 500)), int(rng.integers(1, 130))
+            img = random_image(rng, sw, sh)
+            dev = torch.from_numpy(np.ascontiguousarray(img)).cuda()
+            f = pkg.frame_setup(dev.data_ptr(), sw, sh, W, H, rm, pad, aspect, False)
+            if f is None:
+                continue
+            keep.append(dev)
+            frames.append(f)
+            cases.append((img, W, H))
+        plan = pkg.Plan(mode, palette, frames)
+        out = torch.zeros(len(frames) * plan.stride, dtype=torch.uint8, device="cuda")
+        ln = torch.zeros(len(frames), dtype=torch.int32, device="cuda")
+        plan.render(out.data_ptr(), plan.stride, ln.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        host = out.cpu().numpy()
+        lens = ln.cpu().numpy().astype(np.uint32)
+        for k, (img, W, H) in enumerate(cases):
+            assert lens[k] < 0xFFFFFFF0
+            got = host[k * plan.stride:k * plan.stride + int(lens[k])].tobytes()
+            assert got == oracle_case(img, W, H, mode, aspect, pad, palette), (MODE_NAMES[mode], k, img.shape, W, H)
+        plan.close()
