@@ -86,6 +86,10 @@ def lib():
     L.asciichat_hip_plan_set_variant.argtypes = [vp, ci]
     L.asciichat_hip_plan_get_variant.restype = ci
     L.asciichat_hip_plan_get_variant.argtypes = [vp]
+    L.asciichat_hip_plan_set_split.restype = ci
+    L.asciichat_hip_plan_set_split.argtypes = [vp, ci]
+    L.asciichat_hip_plan_get_parts.restype = ci
+    L.asciichat_hip_plan_get_parts.argtypes = [vp]
     L.asciichat_hip_plan_render.restype = ci
     L.asciichat_hip_plan_render.argtypes = [vp, vp, sz, vp, vp]
     L.asciichat_hip_plan_render_range.restype = ci
@@ -234,6 +238,15 @@ class Plan:
         rc = lib().asciichat_hip_plan_set_variant(self._h, v)
         if rc != 0:
             raise RuntimeError(f"set_variant({v}) failed: {last_error()}")
+
+    @property
+    def parts(self):
+        return lib().asciichat_hip_plan_get_parts(self._h)
+
+    def set_split(self, rows_per_part):
+        rc = lib().asciichat_hip_plan_set_split(self._h, rows_per_part)
+        if rc != 0:
+            raise RuntimeError(f"set_split({rows_per_part}) failed: {last_error()}")
 
     def update(self, frames, stream=0):
         self._arr = (Frame * self.n)(*frames)

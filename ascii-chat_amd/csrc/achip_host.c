@@ -78,6 +78,9 @@ int achip_lut_build(const char *palette_chars, achip_lut_t *lut) {
     lut->ramp[i] = (uint8_t)ci;
     lut->glyph64[i] = packed[ci];
   }
+  for (int i = 0; i < 256; i++) /* the kernels take a one-byte-per-glyph fast path when nothing is multi-byte */
+    if ((lut->glyph[i] & 0xFFu) >= 128u || (lut->glyph64[i & 63] & 0xFFu) >= 128u)
+      lut->flags |= ACHIP_LUT_MULTIBYTE;
   return 0;
 }
 
@@ -220,6 +223,95 @@ size_t achip_out_bound(int mode, const achip_frame_t *f) {
   /* per row: padding + cells + one REP tail (ESC [ dddd b) + reset + newline; per frame: pad_top + final reset */
   const size_t row = (size_t)f->pad_left + (size_t)f->out_w * cell + 7 + 4 + 4 + 1;
   return (size_t)f->pad_top + rows * row + 8;
+}
+
+bool achip_palette_ascii_only(const char *palette_chars) {
+  if (!palette_chars)
+    return false;
+  for (const unsigned char *p = (const unsigned char *)palette_chars; *p; p++)
+    if (*p >= 0x80)
+      return false;
+  return true;
+}
+
+int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, bool palette_ascii_only,
+                          const int *variant_caps, int n_cus, int split_request, int forced_variant, int *variant,
+                          int *parts, int *rows_per_part) {
+  const bool hb = mode >= ACHIP_MODE_HB_TRUE && mode <= ACHIP_MODE_HB_MONO;
+  int max_wp = 0, max_rows = 0;
+  for (int i = 0; i < n_frames; i++) {
+    const int wp = frames[i].pad_left + frames[i].out_w;
+    const int rows = hb ? (frames[i].out_h + 1) / 2 : frames[i].out_h;
+    if (wp > max_wp)
+      max_wp = wp;
+    if (rows > max_rows)
+      max_rows = rows;
+  }
+  *parts = 1;
+  *rows_per_part = max_rows > 0 ? max_rows : 1;
+  if (n_cus < 1)
+    n_cus = 256;
+  /* Whole-frame geometries (measured on MI355X, profiles/r01_split_sweep.txt): up to ~1.5 workgroups per CU
+   * the 1024-thread x 2-cell geometry (4) has the shortest per-frame latency chain; with more frames than
+   * that, several small workgroups per CU overlap each other's gather / token / drain phases instead. */
+  const int small = max_wp <= variant_caps[2] ? 2 : (max_wp <= variant_caps[1] ? 1 : -1);
+  if (forced_variant >= 0) {
+    if (max_wp > variant_caps[forced_variant])
+      return -1;
+    *variant = forced_variant;
+  } else if (n_frames > (3 * n_cus) / 2 && small >= 0) {
+    *variant = small;
+  } else if (max_wp <= variant_caps[4]) {
+    *variant = 4;
+  } else if (max_wp <= variant_caps[0]) {
+    *variant = 0;
+  } else {
+    return -1;
+  }
+  /* Row bands.  Never for the serial dither, nor for truecolor-fg with multi-byte glyphs (its RLE state would
+   * have to be searched backwards across bands).  Automatic splitting only when whole frames would leave CUs
+   * idle (fewer than 3/4 frame per CU): at one frame per CU and above it costs more than it gains. */
+  const bool splittable = mode != ACHIP_MODE_16_DITHER_BG && !(mode == ACHIP_MODE_TRUE_FG && !palette_ascii_only) &&
+                          split_request >= 0 && max_rows > 1;
+  if (!splittable || (split_request == 0 && 4 * n_frames >= 3 * n_cus))
+    return 0;
+  /* a band is exactly one chunk: at most cap / wp rows for every frame of the batch */
+  const int band_cap = forced_variant >= 0 ? variant_caps[forced_variant] : variant_caps[4];
+  if (max_wp > band_cap)
+    return 0;
+  int rpp_max = band_cap / max_wp;
+  if (rpp_max > max_rows)
+    rpp_max = max_rows;
+  int rpp;
+  if (split_request > 0) {
+    rpp = split_request;
+  } else { /* about one band per CU; more bands than that only when the chunk size forces it */
+    const int want = (n_cus + n_frames - 1) / n_frames;
+    rpp = (max_rows + want - 1) / want;
+  }
+  if (rpp > rpp_max)
+    rpp = rpp_max;
+  if (rpp < 1)
+    rpp = 1;
+  const int np = (max_rows + rpp - 1) / rpp;
+  if (np <= 1)
+    return 0;
+  if (forced_variant < 0) {
+    /* geometry of a band: the half-block kernels need > 128 VGPRs in the small geometries (half the waves per
+     * CU), so they always take the 1024-thread one; the others take it while all bands fit the GPU at once and
+     * otherwise the geometry whose chunk matches the band, several of which share a CU */
+    const long blocks = (long)n_frames * np;
+    const int cells = rpp * max_wp;
+    if (hb || blocks <= n_cus)
+      *variant = 4;
+    else if (cells > variant_caps[2])
+      *variant = 1;
+    else
+      *variant = 2;
+  }
+  *parts = np;
+  *rows_per_part = rpp;
+  return 0;
 }
 
 void achip_grid_layout(const int *src_w, const int *src_h, int n, int term_w, int term_h, int *cols, int *rows) {

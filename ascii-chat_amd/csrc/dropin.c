@@ -22,6 +22,7 @@
 #include "asciichat_render.h"
 #include "hip_launch.h"
 #include "internal.h"
+#include "render_variants.h"
 
 /* ------------------------------------------------------------------------------------------- */
 /* per-thread GPU context                                                                        */
@@ -39,6 +40,8 @@ typedef struct {
   size_t stage_cap;
   uint8_t *scratch;  /* device scratch for image_resize() destinations */
   size_t scratch_cap;
+  unsigned long long *part_sync; /* hand-off words of multi-workgroup frames (<= 2160 parts), zeroed once */
+  uint32_t epoch;
 } tls_ctx_t;
 
 static pthread_key_t g_tls_key;
@@ -56,6 +59,8 @@ static void tls_destroy(void *p) {
     (void)hipFree(c->stage);
   if (c->scratch)
     (void)hipFree(c->scratch);
+  if (c->part_sync)
+    (void)hipFree(c->part_sync);
   free(c);
 }
 static void tls_make_key(void) { pthread_key_create(&g_tls_key, tls_destroy); }
@@ -124,10 +129,18 @@ static const uint8_t *resolve_source(tls_ctx_t *c, const void *host_px, size_t b
   return c->stage;
 }
 
-static int variant_for(int wp) { /* same policy as plan.c:pick_variant */
-  if (wp <= achip_variant_cap(4))
-    return 4;
-  return wp <= achip_variant_cap(0) ? 0 : -1;
+#define DROPIN_MAX_PARTS 2160 /* IMAGE_MAX_HEIGHT text rows at one row per part */
+
+static int device_cu_count(void) {
+  static int cached = 0; /* benign race */
+  if (!cached) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    cached = n;
+  }
+  return cached;
 }
 
 /* render one frame described by `f` (f->src = HOST pixels, `src_bytes` long) and return the malloc'd string */
@@ -138,11 +151,23 @@ static char *render_one(int mode, const char *palette, achip_frame_t *f, size_t 
   const achip_lut_t *lut = NULL;
   if (achip_lut_get(palette, &lut))
     return NULL;
-  const int variant = variant_for(f->pad_left + f->out_w);
-  if (variant < 0) {
+  /* a single frame on a 256-CU device: cut it into row bands so that many workgroups share it */
+  int caps[ACHIP_VARIANT_COUNT], variant = -1, parts = 1, rows_per_part = 1;
+  for (int v = 0; v < ACHIP_VARIANT_COUNT; v++)
+    caps[v] = achip_variant_cap(v);
+  if (achip_choose_geometry(mode, f, 1, achip_palette_ascii_only(palette), caps, device_cu_count(), 0, -1, &variant, &parts,
+                            &rows_per_part) != 0 ||
+      variant < 0 || parts > DROPIN_MAX_PARTS) {
     achip_fail(ASCIICHAT_HIP_ERR_NOT_SUPPORTED, "row of %d cells exceeds the kernel chunk", f->pad_left + f->out_w);
     return NULL;
   }
+  if (parts > 1 && !c->part_sync) {
+    const size_t bytes = (size_t)DROPIN_MAX_PARTS * sizeof(unsigned long long);
+    if (achip_hip_check((int)hipMalloc((void **)&c->part_sync, bytes), "hipMalloc(part_sync)") ||
+        achip_hip_check((int)hipMemset(c->part_sync, 0, bytes), "hipMemset(part_sync)"))
+      return NULL;
+  }
+  c->epoch = c->epoch + 1u ? c->epoch + 1u : 1u;
   const uint8_t *src_dev = resolve_source(c, f->src, src_bytes);
   if (!src_dev)
     return NULL;
@@ -160,7 +185,8 @@ static char *render_one(int mode, const char *palette, achip_frame_t *f, size_t 
   *len_host = ACHIP_LEN_BADDESC;
   if (achip_hip_check(achip_launch_render(mode, variant, 0, (const achip_frame_t *)(c->pin_dev + PIN_DESC_OFF), 1, lut,
                                           c->pin_dev + PIN_OUT_OFF, (uint64_t)stride,
-                                          (uint32_t *)(c->pin_dev + PIN_LEN_OFF), NULL, c->stream),
+                                          (uint32_t *)(c->pin_dev + PIN_LEN_OFF), NULL, parts, rows_per_part,
+                                          parts > 1 ? c->part_sync : NULL, c->epoch, c->stream),
                       "render kernel launch"))
     return NULL;
   if (achip_hip_check((int)hipStreamSynchronize(c->stream), "hipStreamSynchronize"))

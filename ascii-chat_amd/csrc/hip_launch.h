@@ -14,7 +14,10 @@ extern "C" {
 /* has_composite: some frame of the batch samples a virtual composite (achip_frame_t.comp != NULL) */
 int achip_launch_render(int mode, int variant, int has_composite, const achip_frame_t *frames_dev, int n_frames,
                         const achip_lut_t *lut_dev, uint8_t *out, uint64_t out_stride, uint32_t *out_len,
-                        unsigned long long *phase_cycles /* NULL, or 8 u64 per frame (diagnostics) */, void *stream);
+                        unsigned long long *phase_cycles /* NULL, or 8 u64 per frame (diagnostics) */,
+                        int parts /* workgroups per frame (1 = whole frame per workgroup) */, int rows_per_part,
+                        unsigned long long *part_sync /* n_frames*parts u64, zeroed once; NULL when parts == 1 */,
+                        uint32_t epoch /* differs from launch to launch on the same part_sync */, void *stream);
 int achip_launch_resize(const uint8_t *src, int sw, int sh, uint8_t *dst, int dw, int dh, void *stream);
 int achip_launch_composite(const achip_composite_t *comp_dev, int canvas_w, int canvas_h, uint8_t *dst, void *stream);
 

@@ -13,7 +13,8 @@ namespace {
 
 template <int MODE, int BLOCK, int CAP, int RING, bool COMP>
 hipError_t launch_one(const achip_frame_t *frames, int n, const achip_lut_t *lut, uint8_t *out, uint64_t stride,
-                      uint32_t *len, unsigned long long *prof, hipStream_t stream) {
+                      uint32_t *len, unsigned long long *prof, int parts, int rows_per_part, unsigned long long *part_sync,
+                      uint32_t epoch, hipStream_t stream) {
   using L = achip::Lds<MODE, BLOCK, CAP, RING>;
   auto kern = achip::render_frames_kernel<MODE, BLOCK, CAP, RING, COMP>;
   static bool attr_set = false; /* one flag per instantiation; benign race (idempotent call) */
@@ -26,18 +27,22 @@ hipError_t launch_one(const achip_frame_t *frames, int n, const achip_lut_t *lut
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(BLOCK), (size_t)L::bytes, stream, frames, lut, out, stride, len, n, prof);
+  hipLaunchKernelGGL(kern, dim3((unsigned)n * (unsigned)parts), dim3(BLOCK), (size_t)L::bytes, stream, frames, lut, out,
+                     stride, len, n, prof, parts, rows_per_part, part_sync, epoch);
   return hipGetLastError();
 }
 
 template <int BLOCK, int CAP, int RING>
 hipError_t launch_mode(int mode, bool comp, const achip_frame_t *frames, int n, const achip_lut_t *lut, uint8_t *out,
-                       uint64_t stride, uint32_t *len, unsigned long long *prof, hipStream_t stream) {
+                       uint64_t stride, uint32_t *len, unsigned long long *prof, int parts, int rows_per_part,
+                       unsigned long long *part_sync, uint32_t epoch, hipStream_t stream) {
   switch (mode) {
 #define M(m)                                                                                                           \
   case m:                                                                                                              \
-    return comp ? launch_one<m, BLOCK, CAP, RING, true>(frames, n, lut, out, stride, len, prof, stream)                \
-                : launch_one<m, BLOCK, CAP, RING, false>(frames, n, lut, out, stride, len, prof, stream);
+    return comp ? launch_one<m, BLOCK, CAP, RING, true>(frames, n, lut, out, stride, len, prof, parts, rows_per_part,  \
+                                                        part_sync, epoch, stream)                                      \
+                : launch_one<m, BLOCK, CAP, RING, false>(frames, n, lut, out, stride, len, prof, parts, rows_per_part, \
+                                                         part_sync, epoch, stream);
     M(ACHIP_MODE_MONO)
     M(ACHIP_MODE_TRUE_FG)
     M(ACHIP_MODE_256_FG)
@@ -77,14 +82,18 @@ template <int BLOCK, int CAP, int RING> int lds_for_mode(int mode) {
 
 extern "C" int achip_launch_render(int mode, int variant, int has_composite, const achip_frame_t *frames_dev, int n_frames,
                                    const achip_lut_t *lut_dev, uint8_t *out, uint64_t out_stride, uint32_t *out_len,
-                                   unsigned long long *prof, void *stream) {
+                                   unsigned long long *prof, int parts, int rows_per_part,
+                                   unsigned long long *part_sync, uint32_t epoch, void *stream) {
   if (n_frames <= 0)
     return (int)hipSuccess;
+  if (parts < 1 || (parts > 1 && (!part_sync || rows_per_part < 1)))
+    return (int)hipErrorInvalidValue;
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (variant) {
 #define X(id, B, C, R)                                                                                                 \
   case id:                                                                                                             \
-    return (int)launch_mode<B, C, R>(mode, has_composite != 0, frames_dev, n_frames, lut_dev, out, out_stride, out_len, prof, s);
+    return (int)launch_mode<B, C, R>(mode, has_composite != 0, frames_dev, n_frames, lut_dev, out, out_stride, out_len, prof,    \
+                                     parts, rows_per_part, part_sync, epoch, s);
     ACHIP_VARIANTS(X)
 #undef X
   }

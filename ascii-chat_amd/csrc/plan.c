@@ -125,27 +125,43 @@ struct asciichat_hip_plan {
   int variant_user; /* -1 = automatic */
   int max_wp;
   int has_comp; /* some frame samples a virtual composite */
+  int parts, rows_per_part, split_request; /* multi-workgroup frames (achip_choose_geometry) */
+  int palette_ascii;
+  unsigned long long *part_sync; /* n * parts_cap u64 hand-off words, zeroed once */
+  int parts_cap;
+  uint32_t epoch;
   size_t stride;
   achip_frame_t *frames_dev;
   achip_frame_t *frames_pinned; /* staging for async updates */
   const achip_lut_t *lut_dev;
 };
 
-static int pick_variant(int max_wp) {
-  const char *env = getenv("ASCIICHAT_HIP_VARIANT");
-  if (env && env[0]) {
-    int v = atoi(env);
-    if (achip_variant_cap(v) >= max_wp)
-      return v;
+static int device_cus(void) {
+  static int cached = 0; /* benign race */
+  if (!cached) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    cached = n;
   }
-  /* measured on MI355X (gpurun_out/r1g, r1i): the 1024-thread / 2-cells-per-thread geometry wins on every
-   * BASELINE workload (no register spills, 4 waves per SIMD); the 4096-cell geometry only serves rows wider
-   * than 2048 cells.  Variants 1-3 remain selectable for experiments and tests. */
-  if (max_wp <= achip_variant_cap(4))
-    return 4;
-  if (max_wp <= achip_variant_cap(0))
-    return 0;
-  return -1;
+  return cached;
+}
+
+static int choose_geometry(asciichat_hip_plan_t *p, const achip_frame_t *frames) {
+  int caps[ACHIP_VARIANT_COUNT];
+  for (int v = 0; v < ACHIP_VARIANT_COUNT; v++)
+    caps[v] = achip_variant_cap(v);
+  int variant = -1, parts = 1, rpp = 1;
+  const char *env = getenv("ASCIICHAT_HIP_VARIANT");
+  const int forced = p->variant_user >= 0 ? p->variant_user : (env && env[0] ? atoi(env) : -1);
+  if (achip_choose_geometry(p->mode, frames, p->n, p->palette_ascii != 0, caps, device_cus(),
+                            forced >= 0 && p->split_request == 0 ? -1 : p->split_request, /* explicit geometry alone: whole frames */
+                            forced < ACHIP_VARIANT_COUNT ? forced : -1, &variant, &parts, &rpp) != 0)
+    return -1;
+  p->variant = variant;
+  p->parts = parts;
+  p->rows_per_part = rpp;
+  return 0;
 }
 
 static int plan_measure(asciichat_hip_plan_t *p, const achip_frame_t *frames) {
@@ -170,11 +186,21 @@ static int plan_measure(asciichat_hip_plan_t *p, const achip_frame_t *frames) {
     return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame output bound exceeds 4 GiB");
   p->stride = stride;
   p->max_wp = max_wp;
-  int v = p->variant_user >= 0 ? p->variant_user : pick_variant(max_wp);
-  if (v < 0 || achip_variant_cap(v) < max_wp)
+  if (choose_geometry(p, frames) != 0 || p->variant < 0 || achip_variant_cap(p->variant) < max_wp)
     return achip_fail(ASCIICHAT_HIP_ERR_NOT_SUPPORTED, "padded row of %d cells exceeds the kernel chunk (max %d)",
                       max_wp, achip_variant_cap(0));
-  p->variant = v;
+  if (p->parts > 1 && p->parts > p->parts_cap) { /* hand-off words for the multi-workgroup frames */
+    if (p->part_sync)
+      (void)hipFree(p->part_sync);
+    p->part_sync = NULL;
+    const size_t bytes = (size_t)p->n * (size_t)p->parts * sizeof(unsigned long long);
+    int rc = achip_hip_check((int)hipMalloc((void **)&p->part_sync, bytes), "hipMalloc(part_sync)");
+    if (!rc)
+      rc = achip_hip_check((int)hipMemset(p->part_sync, 0, bytes), "hipMemset(part_sync)");
+    if (rc)
+      return rc;
+    p->parts_cap = p->parts;
+  }
   return 0;
 }
 
@@ -192,6 +218,7 @@ int asciichat_hip_plan_create(asciichat_hip_plan_t **plan, int mode, const char 
   p->mode = mode;
   p->n = n_frames;
   p->variant_user = -1;
+  p->palette_ascii = achip_palette_ascii_only(palette_chars) ? 1 : 0;
   rc = plan_measure(p, frames);
   if (!rc)
     rc = achip_lut_get(palette_chars, &p->lut_dev);
@@ -239,9 +266,17 @@ int asciichat_hip_plan_set_variant(asciichat_hip_plan_t *p, int variant) {
   if (variant >= 0 && achip_variant_cap(variant) < p->max_wp)
     return achip_fail(ASCIICHAT_HIP_ERR_NOT_SUPPORTED, "variant %d cannot hold a %d-cell row", variant, p->max_wp);
   p->variant_user = variant;
-  p->variant = variant >= 0 ? variant : pick_variant(p->max_wp);
-  return 0;
+  return plan_measure(p, p->frames_pinned);
 }
+
+int asciichat_hip_plan_set_split(asciichat_hip_plan_t *p, int rows_per_part) {
+  if (!p)
+    return ASCIICHAT_HIP_ERR_INVALID_PARAM;
+  p->split_request = rows_per_part;
+  return plan_measure(p, p->frames_pinned);
+}
+
+int asciichat_hip_plan_get_parts(const asciichat_hip_plan_t *p) { return p ? p->parts : 0; }
 
 int asciichat_hip_plan_get_variant(const asciichat_hip_plan_t *p) { return p ? p->variant : -1; }
 
@@ -254,8 +289,14 @@ static int render_range(asciichat_hip_plan_t *p, int first, int count, uint8_t *
                       p->stride);
   if (count == 0)
     return 0;
-  return achip_hip_check(achip_launch_render(p->mode, p->variant, p->has_comp, p->frames_dev + first, count, p->lut_dev, out_dev,
-                                             (uint64_t)out_stride, out_len_dev, phase_cycles_dev, stream),
+  /* a different epoch per launch makes last launch's hand-off words stale without clearing them; launches of
+   * one plan must therefore be ordered (one stream), which updating its descriptors requires anyway */
+  p->epoch = p->epoch + 1u ? p->epoch + 1u : 1u;
+  return achip_hip_check(achip_launch_render(p->mode, p->variant, p->has_comp, p->frames_dev + first, count, p->lut_dev,
+                                             out_dev, (uint64_t)out_stride, out_len_dev, phase_cycles_dev, p->parts,
+                                             p->rows_per_part,
+                                             p->part_sync ? p->part_sync + (size_t)first * (size_t)p->parts : NULL,
+                                             p->epoch, stream),
                          "render kernel launch");
 }
 
@@ -281,6 +322,8 @@ void asciichat_hip_plan_destroy(asciichat_hip_plan_t *p) {
     (void)hipFree(p->frames_dev);
   if (p->frames_pinned)
     (void)hipHostFree(p->frames_pinned);
+  if (p->part_sync)
+    (void)hipFree(p->part_sync);
   free(p);
 }
 

@@ -91,6 +91,38 @@ __device__ inline void lds_store_fence() {
 }
 
 /* ------------------------------------------------------------------------------------------- */
+/* inter-workgroup hand-off for frames rendered by several workgroups ("parts").  One naturally    */
+/* aligned 8-byte word per part carries {launch epoch : 32, byte length of the part : 32}; it is     */
+/* written by ONE agent-scope atomic store and polled with relaxed agent-scope loads (which bypass    */
+/* the reader's L1), so the word is its own payload and needs no fence (MI355X guide, G16 form R2).  */
+/* ------------------------------------------------------------------------------------------- */
+__device__ inline void part_publish(unsigned long long *slot, uint32_t epoch, uint32_t value) {
+  const unsigned long long w = ((unsigned long long)epoch << 32) | (unsigned long long)value;
+#ifdef ACHIP_HIPEMU
+  *slot = w;
+#else
+  __hip_atomic_store(slot, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+/* value published for this launch, or 0xFFFFFFFF after ~0.2 s of polling (never spins unbounded) */
+__device__ inline uint32_t part_wait(const unsigned long long *slot, uint32_t epoch) {
+  for (int spin = 0; spin < (1 << 21); spin++) {
+#ifdef ACHIP_HIPEMU
+    const unsigned long long w = *slot;
+#else
+    const unsigned long long w = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+    if ((uint32_t)(w >> 32) == epoch)
+      return (uint32_t)w;
+#ifndef ACHIP_HIPEMU
+    __builtin_amdgcn_s_sleep(2);
+#endif
+  }
+  return 0xFFFFFFFFu;
+}
+#define ACHIP_PART_POISON 0xFFFFFFF1u /* a predecessor failed / timed out: propagate, do not emit */
+
+/* ------------------------------------------------------------------------------------------- */
 /* wave64 primitives                                                                             */
 /* ------------------------------------------------------------------------------------------- */
 #ifdef ACHIP_HIPEMU
@@ -358,8 +390,9 @@ template <int MODE, int BLOCK, int CAP, int RING> struct Lds {
   static constexpr int o_ramp = o_glyph64 + 64 * 4;
   static constexpr int o_dec = o_ramp + 64;     /* 256 decimal-field entries */
   static constexpr int o_wsum = o_dec + 256 * 4; /* SEG*NW wave totals (<= 64) */
-  static constexpr int o_flags = o_wsum + 64 * 4; /* [0] palette-not-all-ASCII, [1],[2] window cut (ping-pong), [3] dummy store target */
-  static constexpr int o_prof = o_flags + 16;     /* 8 x u64 diagnostics accumulators */
+  static constexpr int o_flags = o_wsum + 64 * 4; /* [0] palette-not-all-ASCII, [1],[2] window cut (ping-pong), [3] predecessors' byte
+                                                     count (multi-part frames), [4] dummy store target */
+  static constexpr int o_prof = o_flags + 32;     /* 8 x u64 diagnostics accumulators */
   static constexpr int o_carry = o_prof + 8 * 8;             /* dither: error sums entering the next row, 3 x int per column */
   static constexpr int bytes = o_carry + (MODE == ACHIP_MODE_16_DITHER_BG ? CAP * 12 : 0);
   static_assert(SEG * NW <= 64, "wave-total table must fit one wave");
@@ -764,20 +797,36 @@ template <int MODE> __device__ inline bool same_run(const uint32_t *pixT, const 
 /* the frame kernel                                                                              */
 /* ------------------------------------------------------------------------------------------- */
 template <int BLOCK>
-__device__ inline void drain_ring(int ring_off, uint8_t *__restrict__ out, uint32_t from, uint32_t to) {
-  /* [from, to) are stream offsets, `from` is 16-byte aligned and sits at byte 0 of the staging buffer;
-   * full 16-byte groups go out as uint4, group g by thread g mod BLOCK */
+__device__ inline void drain_ring(int ring_off, uint8_t *__restrict__ out, uint32_t from, uint32_t to, uint32_t own_from,
+                                  bool flush_tail) {
+  /* [from, to) are stream offsets, `from` is 16-byte aligned and sits at byte 0 of the staging buffer.  This
+   * workgroup owns the bytes >= own_from (own_from > from only for the first window of a frame part whose
+   * predecessor ended mid-group).  Whole 16-byte groups go out as uint4 (group g by thread g mod BLOCK); the
+   * partial head group and, when flush_tail, the partial tail group go out as bytes. */
   const unsigned char *ring = lds_ptr<const unsigned char>(ring_off);
+  const uint32_t vec_begin = (own_from + 15u) & ~15u;
   const uint32_t vec_end = to & ~15u;
-  uint32_t o = from + 16u * threadIdx.x;
+  uint32_t o = vec_begin + 16u * threadIdx.x;
   for (; o + 16u * BLOCK < vec_end; o += 32u * BLOCK) { /* two groups per trip: both LDS reads in flight */
     const uint4 v0 = *reinterpret_cast<const uint4 *>(ring + (o - from));
     const uint4 v1 = *reinterpret_cast<const uint4 *>(ring + (o - from) + 16u * BLOCK);
+#if defined(ACHIP_ABLATE) && ACHIP_ABLATE == 4
+    asm volatile("" ::"v"(v0.x), "v"(v0.y), "v"(v1.z), "v"(v1.w)); /* diagnostics: no HBM writes */
+#else
     *reinterpret_cast<uint4 *>(out + o) = v0;
     *reinterpret_cast<uint4 *>(out + o + 16u * BLOCK) = v1;
+#endif
   }
   if (o < vec_end)
     *reinterpret_cast<uint4 *>(out + o) = *reinterpret_cast<const uint4 *>(ring + (o - from));
+  /* head: [own_from, min(vec_begin, to)), < 16 bytes of the buffer's group 0.  Thread 0 alone touches group 0
+   * (it moves the carry there right after this call), so it copies the head itself. */
+  if (threadIdx.x == 0)
+    for (uint32_t h = own_from; h < min(vec_begin, to); h++)
+      out[h] = ring[h - from];
+  if (flush_tail) /* tail: what lies beyond the last whole group (and beyond the head) */
+    for (uint32_t t = max(vec_end, vec_begin) + threadIdx.x; t < to; t += BLOCK)
+      out[t] = ring[t - from];
 }
 
 /* ------------------------------------------------------------------------------------------- */
@@ -877,7 +926,11 @@ template <int MODE, int BLOCK, int CAP, int RING, bool COMP>
 __global__ void __launch_bounds__(BLOCK)
     render_frames_kernel(const achip_frame_t *__restrict__ frames, const achip_lut_t *__restrict__ lut,
                          uint8_t *__restrict__ out, uint64_t out_stride, uint32_t *__restrict__ out_len, int n_frames,
-                         unsigned long long *__restrict__ prof) {
+                         unsigned long long *__restrict__ prof, int parts, int rows_per_part,
+                         unsigned long long *__restrict__ part_sync, uint32_t epoch) {
+  /* parts == 1: one workgroup renders the whole frame.  parts > 1: workgroup (frame, part) renders text rows
+   * [part*rows_per_part, ...) -- exactly one chunk -- and learns where its bytes start from the lengths its
+   * predecessors publish in part_sync[frame*parts + q] (see part_publish / part_wait). */
   using L = Lds<MODE, BLOCK, CAP, RING>;
   constexpr bool HB = mode_is_halfblock(MODE);
   constexpr int NW = L::NW;
@@ -897,9 +950,21 @@ __global__ void __launch_bounds__(BLOCK)
 
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63, wave = wave_uniform(tid >> 6);
-  const int fidx = (int)blockIdx.x;
+  const int fidx = parts > 1 ? (int)blockIdx.x / parts : (int)blockIdx.x;
+  const int part = parts > 1 ? (int)blockIdx.x - fidx * parts : 0;
   if (fidx >= n_frames)
     return;
+  /* the glyph tables are requested before the descriptor is: the two fetches are one overlapped latency.
+   * (Requesting the first chunk's pixels here as well was measured: no gain, and the extra live registers push
+   * the small geometries over 128 VGPRs, i.e. to half the waves per CU.) */
+  constexpr int LUTN = (256 + BLOCK - 1) / BLOCK;
+  uint32_t lut_g[LUTN];
+#pragma unroll
+  for (int k = 0; k < LUTN; k++)
+    lut_g[k] = tid + k * BLOCK < 256 ? lut->glyph[tid + k * BLOCK] : 0u;
+  const uint32_t lut_g64 = tid < 64 ? lut->glyph64[tid] : 0u;
+  const uint32_t lut_ramp = tid < 64 ? lut->ramp[tid] : 0u;
+  const bool ascii_only = (lut->flags & ACHIP_LUT_MULTIBYTE) == 0u;
   achip_frame_t f = frames[fidx];
   if (f.src_stride == 0)
     f.src_stride = 3 * f.src_w;
@@ -908,11 +973,18 @@ __global__ void __launch_bounds__(BLOCK)
   const int wp = f.pad_left + f.out_w;
   const int rows = HB ? (f.out_h + 1) / 2 : f.out_h;
   if (f.out_w <= 0 || f.out_h <= 0 || f.src_w <= 0 || f.src_h <= 0 || f.pad_left < 0 || f.pad_top < 0 || wp > CAP ||
-      (!f.src && !f.comp) || (!COMP && f.comp)) {
-    if (tid == 0)
+      (!f.src && !f.comp) || (!COMP && f.comp) || (parts > 1 && rows_per_part * wp > CAP)) {
+    if (tid == 0 && part == 0)
       out_len[fidx] = ACHIP_LEN_BADDESC;
+    if (tid == 0 && parts > 1)
+      part_publish(&part_sync[(size_t)fidx * parts + part], epoch, ACHIP_PART_POISON);
     return;
   }
+  const int row_begin = parts > 1 ? part * rows_per_part : 0;
+  const int row_end = parts > 1 ? min(rows, row_begin + rows_per_part) : rows;
+  if (row_begin >= rows)
+    return; /* this frame has fewer parts than the launch provides: nobody waits for them */
+  const bool last_part = row_end >= rows;
 
   unsigned long long t_start = 0ull;
   if (prof && tid == 0) {
@@ -922,78 +994,31 @@ __global__ void __launch_bounds__(BLOCK)
     pa[7] = t_start = cycle_now();
   }
 
-  /* glyph tables -> LDS; is every glyph a single ASCII byte? */
-  if (tid == 0) {
-    flags[0] = 0u;
-    flags[1] = 0xFFFFFFFFu;
-    flags[2] = 0xFFFFFFFFu;
-  }
-  __syncthreads();
-  {
-    bool non_ascii = false;
-    for (int k = tid; k < 256; k += BLOCK) {
-      const uint32_t g = lut->glyph[k];
-      glyph[k] = g;
-      lds_ptr<uint32_t>(L::o_dec)[k] = dec_table_entry((uint32_t)k);
-      non_ascii |= (g & 0xFFu) >= 128u;
-    }
-    for (int k = tid; k < 64; k += BLOCK) {
-      glyph64[k] = lut->glyph64[k];
-      ramp[k] = lut->ramp[k];
-    }
-    if (non_ascii)
-      flags[0] = 1u; /* benign race: every writer stores the same value */
-  }
-
-  if (MODE == ACHIP_MODE_16_DITHER_BG) { /* no error enters the first row */
-    int *carry = lds_ptr<int>(L::o_carry);
-    for (int k = tid; k < 3 * CAP; k += BLOCK)
-      carry[k] = 0;
-  }
-
   /* i / wp == umulhi(i, magic) for i, wp <= CAP (i * wp < 2^32); wp == 1 would need magic 2^32 */
   const uint32_t wp_magic = wp > 1 ? (uint32_t)(0x100000000ull / (uint32_t)wp) + 1u : 0u;
   const int rows_per_chunk = max(1, CAP / wp);
   const uint32_t cap_bytes = out_stride > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)out_stride;
   const uint32_t ring_addr = lds_base_addr() + (uint32_t)L::o_ring;
-  const uint32_t dummy_addr = lds_base_addr() + (uint32_t)L::o_flags + 12u;
+  const uint32_t dummy_addr = lds_base_addr() + (uint32_t)L::o_flags + 16u;
 
   uint32_t window_no = 0; /* parity selects the LDS slot that carries the window cut */
   uint32_t base = 0;    /* stream bytes produced before the current chunk */
   uint32_t flushed = 0; /* stream bytes already in HBM (multiple of 16)   */
   bool overflow = false;
 
-  /* ascii_pad_frame_height: pad_top bare newlines, through the same staging buffer */
-  if (f.pad_top > 0) {
-    const uint32_t total = (uint32_t)f.pad_top;
-    if (total > cap_bytes)
-      overflow = true;
-    while (!overflow && base < total) {
-      const uint32_t lo = flushed;
-      const uint32_t hi = min(total, lo + (uint32_t)RING);
-      for (uint32_t o = base + (uint32_t)tid; o < hi; o += BLOCK)
-        ring[o - lo] = '\n';
-      __syncthreads();
-      drain_ring<BLOCK>(L::o_ring, dst, lo, hi);
-      flushed = hi & ~15u;
-      if (tid == 0 && flushed > lo) {
-        for (uint32_t j = 0; j < hi - flushed; j++)
-          ring[j] = ring[flushed - lo + j];
-      }
-      base = hi;
-      __syncthreads();
-    }
-  }
-  __syncthreads();
-
   Chunk c;
   c.wp = wp;
   c.pad_left = f.pad_left;
   c.rows = rows;
-  const bool ascii_only = flags[0] == 0u;
   c.all_ascii = MODE == ACHIP_MODE_TRUE_FG && ascii_only;
   c.carry_have = false;
   c.carry_rgb = 0;
+  if (MODE == ACHIP_MODE_TRUE_FG && row_begin > 0) {
+    /* the RLE state entering this part is the colour of the last pixel of the previous text row
+     * (all-ASCII palettes only: the host does not split frames otherwise) */
+    c.carry_have = true;
+    c.carry_rgb = px_rgb(sample_frame<COMP>(f, (uint32_t)f.out_w - 1u, (uint32_t)row_begin - 1u));
+  }
   /* gather: all of a thread's samples of a chunk are requested before any is consumed, so a thread keeps
    * up to 2*SEG sparse fetches in flight; cell i_k = tid + k*BLOCK (lane <-> consecutive cells) */
   uint32_t gt[SEG], gb[SEG];
@@ -1019,10 +1044,55 @@ __global__ void __launch_bounds__(BLOCK)
       }
     }
   };
+  /* glyph tables -> LDS */
+#pragma unroll
+  for (int k = 0; k < LUTN; k++)
+    if (tid + k * BLOCK < 256) {
+      glyph[tid + k * BLOCK] = lut_g[k];
+      lds_ptr<uint32_t>(L::o_dec)[tid + k * BLOCK] = dec_table_entry((uint32_t)(tid + k * BLOCK));
+    }
+  if (tid < 64) {
+    glyph64[tid] = lut_g64;
+    ramp[tid] = (uint8_t)lut_ramp;
+  }
+  if (tid == 0) {
+    flags[1] = 0xFFFFFFFFu;
+    flags[2] = 0xFFFFFFFFu;
+  }
+  if (MODE == ACHIP_MODE_16_DITHER_BG) { /* no error enters the first row */
+    int *carry = lds_ptr<int>(L::o_carry);
+    for (int k = tid; k < 3 * CAP; k += BLOCK)
+      carry[k] = 0;
+  }
+
+  /* ascii_pad_frame_height: pad_top bare newlines, through the same staging buffer */
+  if (f.pad_top > 0 && part == 0) {
+    const uint32_t total = (uint32_t)f.pad_top;
+    if (total > cap_bytes)
+      overflow = true;
+    while (!overflow && base < total) {
+      const uint32_t lo = flushed;
+      const uint32_t hi = min(total, lo + (uint32_t)RING);
+      for (uint32_t o = base + (uint32_t)tid; o < hi; o += BLOCK)
+        ring[o - lo] = '\n';
+      __syncthreads();
+      drain_ring<BLOCK>(L::o_ring, dst, lo, hi, lo, false);
+      flushed = hi & ~15u;
+      if (tid == 0 && flushed > lo) {
+        for (uint32_t j = 0; j < hi - flushed; j++)
+          ring[j] = ring[flushed - lo + j];
+      }
+      base = hi;
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+
   ACHIP_STAMP(0);
 
-  for (int r0 = 0; r0 < rows; r0 += rows_per_chunk) {
-    const int r1 = min(rows, r0 + rows_per_chunk);
+  uint32_t own_from = 0; /* first stream byte this workgroup owns (parts > 1: set once its predecessors are known) */
+  for (int r0 = row_begin; r0 < row_end; r0 += rows_per_chunk) {
+    const int r1 = min(row_end, r0 + rows_per_chunk);
     const int n = (r1 - r0) * wp;
     c.n = n;
 
@@ -1143,6 +1213,37 @@ __global__ void __launch_bounds__(BLOCK)
       }
     }
     ACHIP_STAMP(4);
+    if (parts > 1) {
+      /* publish this part's byte count, then add up the predecessors' (one lane per predecessor) */
+      unsigned long long *sync = part_sync + (size_t)fidx * parts;
+      if (tid == 0)
+        part_publish(&sync[part], epoch, base + total); /* part 0: base = pad_top, else 0 so far */
+      if (part > 0) {
+        if (wave == 0) {
+          uint32_t acc = 0;
+          bool bad = false;
+          for (int q0 = 0; q0 < part; q0 += 64) {
+            const int q = q0 + lane;
+            uint32_t v = 0;
+            if (q < part) {
+              v = part_wait(&sync[q], epoch);
+              bad |= v >= 0xFFFFFFF0u;
+            }
+            acc += wave_read_lane(wave_inclusive_scan(v), 63);
+          }
+          const uint64_t any_bad = wave_ballot(bad);
+          if (lane == 0)
+            flags[3] = any_bad != 0ull ? 0xFFFFFFFFu : acc;
+        }
+        __syncthreads();
+        const uint32_t before = flags[3];
+        if (before == 0xFFFFFFFFu)
+          overflow = true; /* a predecessor failed or never published: emit nothing, report below */
+        base = before;
+        own_from = base; /* the bytes below belong to the predecessor, even inside our first 16-byte group */
+        flushed = base & ~15u;
+      }
+    }
     if ((uint64_t)base + total > cap_bytes)
       overflow = true;
 
@@ -1152,7 +1253,7 @@ __global__ void __launch_bounds__(BLOCK)
      * token never straddles anything and every store is a plain, unchecked LDS byte store.  After a drain the
      * < 16 not-yet-flushable tail bytes are moved to the front by the one thread that owns 16-byte group 0. */
     const uint32_t chunk_end = base + total;
-    const bool last_chunk = r1 >= rows;
+    const bool last_chunk = r1 >= row_end;
     uint32_t done = base; /* tokens starting below `done` are already in the buffer or in HBM */
     while (!overflow) {
       const uint32_t lo = flushed, hi = flushed + (uint32_t)RING;
@@ -1164,7 +1265,7 @@ __global__ void __launch_bounds__(BLOCK)
         if (len[k] != 0u && a >= done) {
           if (b <= hi) {
 #if !defined(ACHIP_ABLATE) || ACHIP_ABLATE != 2
-            FastSink<L::o_dec, L::o_flags + 12> fs{ring_addr + (a - lo), dummy_addr};
+            FastSink<L::o_dec, L::o_flags + 16> fs{ring_addr + (a - lo), dummy_addr};
             token_fields<MODE>(fs, tok[k], ascii_only);
 #else
             asm volatile("" ::"v"(a), "v"(tok[k].flags), "v"(tok[k].fg), "v"(tok[k].glyph));
@@ -1181,11 +1282,8 @@ __global__ void __launch_bounds__(BLOCK)
       if (tid == 0)
         flags[1 + ((window_no + 1) & 1)] = 0xFFFFFFFFu; /* next window's slot; its last readers are a barrier behind */
       window_no++;
-      drain_ring<BLOCK>(L::o_ring, dst, lo, cut);
-      if (last_chunk && cut == chunk_end) { /* frame tail: < 16 bytes, byte stores */
-        for (uint32_t o = (cut & ~15u) + (uint32_t)tid; o < cut; o += BLOCK)
-          dst[o] = ring[o - lo];
-      }
+      /* the bytes of a part's last window are flushed completely (its successor owns the rest of the group) */
+      drain_ring<BLOCK>(L::o_ring, dst, lo, cut, max(own_from, lo), last_chunk && cut == chunk_end);
       flushed = cut & ~15u;
       if (tid == 0 && flushed > lo) { /* tid 0 drained group 0 itself (program order): safe to overwrite it */
         for (uint32_t j = 0; j < cut - flushed; j++)
@@ -1208,7 +1306,7 @@ __global__ void __launch_bounds__(BLOCK)
       prof[(size_t)fidx * 8u + (size_t)k] = pa[k];
     prof[(size_t)fidx * 8u + 7u] = cycle_now() - t_start;
   }
-  if (tid == 0) {
+  if (tid == 0 && last_part) {
     out_len[fidx] = overflow ? ACHIP_LEN_OVERFLOW : base;
     if (!overflow && (uint64_t)base < out_stride)
       dst[base] = 0; /* NUL after the frame when the slot has room, as the reference's strings carry */

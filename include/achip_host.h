@@ -50,6 +50,22 @@ uint32_t achip_nn_ratio(int src, int dst);
 /* Upper bound (bytes, excluding the NUL) of one rendered frame; multiple of 16 when rounded by the caller. */
 size_t achip_out_bound(int mode, const achip_frame_t *f);
 
+/* Launch geometry for a batch.  A batch with fewer frames than the GPU has CUs leaves most of it idle when one
+ * workgroup renders a whole frame, so such frames are cut into `parts` bands of text rows rendered by separate
+ * workgroups (each band exactly one chunk of its geometry; the bands learn their output offset from each other
+ * on the device).
+ *   variant_caps[v]  cells per chunk of kernel geometry v (render_variants.h)
+ *   n_cus            compute units of the device
+ *   split_request    0 = automatic, < 0 = never split, > 0 = this many text rows per band
+ *   forced_variant   >= 0: use this geometry (tuning), -1: choose
+ * Outputs the geometry id, bands per frame (1 = no split) and text rows per band.  Returns 0, or -1 when a
+ * padded row does not fit the geometry. */
+int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, bool palette_ascii_only,
+                          const int *variant_caps, int n_cus, int split_request, int forced_variant, int *variant,
+                          int *parts, int *rows_per_part);
+/* true when every glyph of the palette is a single byte < 0x80 */
+bool achip_palette_ascii_only(const char *palette_chars);
+
 /* calculate_optimal_grid_layout (src/server/stream.c:523-651) */
 void achip_grid_layout(const int *src_w, const int *src_h, int n, int term_w, int term_h, int *cols, int *rows);
 

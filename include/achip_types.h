@@ -76,7 +76,9 @@ typedef struct {
   uint32_t glyph[256];  /* cache[Y]                 */
   uint32_t glyph64[64]; /* cache64[i]               */
   uint8_t ramp[64];     /* char_index_ramp[0..63]   */
+  uint32_t flags;       /* ACHIP_LUT_*              */
 } achip_lut_t;
+#define ACHIP_LUT_MULTIBYTE 1u /* some glyph is a multi-byte UTF-8 sequence */
 
 #define ACHIP_LEN_OVERFLOW 0xFFFFFFFFu /* out_len[] value when a frame did not fit its slab slot */
 #define ACHIP_LEN_BADDESC 0xFFFFFFFEu  /* out_len[] value for an unsupported descriptor          */

@@ -71,6 +71,11 @@ size_t asciichat_hip_plan_out_stride(const asciichat_hip_plan_t *plan);
 int asciichat_hip_plan_set_variant(asciichat_hip_plan_t *plan, int variant);
 int asciichat_hip_plan_get_variant(const asciichat_hip_plan_t *plan);
 
+/* Multi-workgroup frames: 0 = automatic (small batches are cut into row bands so that the whole GPU works on
+ * them), < 0 = never, > 0 = this many text rows per workgroup.  get_parts() reports workgroups per frame. */
+int asciichat_hip_plan_set_split(asciichat_hip_plan_t *plan, int rows_per_part);
+int asciichat_hip_plan_get_parts(const asciichat_hip_plan_t *plan);
+
 /*
  * Render all frames: frame i's bytes go to out_dev + i*out_stride (16-byte aligned base, stride a
  * multiple of 16, >= plan_out_stride), its length to out_len_dev[i] (ACHIP_LEN_OVERFLOW /

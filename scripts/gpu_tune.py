@@ -15,6 +15,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--workloads", default="1080p_80x24_truecolor,1080p_80x24_ansi256,4k_200x60_truecolor,4k_400x120_halfblock")
     ap.add_argument("--variants", default="0,1,2")
+    ap.add_argument("--splits", default="-1", help="rows per workgroup: -1 whole frames, 0 automatic, n = n text rows")
     ap.add_argument("--reps", type=int, default=50)
     args = ap.parse_args()
     import torch
@@ -32,10 +33,12 @@ def main():
         ln = torch.zeros(args.batch, dtype=torch.int32, device="cuda")
         prof = torch.zeros(args.batch * 8, dtype=torch.int64, device="cuda")
         for v in [int(x) for x in args.variants.split(",")]:
+          for sp in [int(x) for x in args.splits.split(",")]:
             try:
                 plan.set_variant(v)
+                plan.set_split(sp)
             except RuntimeError as e:
-                print(f"{wl} variant {v}: skipped ({e})")
+                print(f"{wl} variant {v} split {sp}: skipped ({e})")
                 continue
             for _ in range(5):
                 plan.render(out.data_ptr(), plan.stride, ln.data_ptr(), torch.cuda.current_stream().cuda_stream)
@@ -48,17 +51,22 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             b2b = e0.elapsed_time(e1) / args.reps
+            lens = ln.cpu().numpy().astype("uint32")
+            assert (lens < 0xFFFFFFF0).all(), "kernel reported an error code"
+            rows = 2 * H if rm == 2 else H
+            alg = int(lens.sum()) + args.batch * 3 * W * rows
+            head = (f"{wl:26s} v{plan.variant} parts {plan.parts:3d} (req v{v} split {sp:2d}) kernel {ms*1e3:8.1f} us "
+                    f"(b2b {b2b*1e3:8.1f} us) alg {alg/1e6:8.2f} MB -> {alg/(ms*1e-3)/1e9:7.1f} GB/s")
+            if plan.parts > 1:
+                print(head)
+                continue
             plan.render_profiled(out.data_ptr(), plan.stride, ln.data_ptr(), prof.data_ptr(),
                                  torch.cuda.current_stream().cuda_stream)
             torch.cuda.synchronize()
             p = prof.cpu().numpy().reshape(args.batch, 8).astype("float64")
             mean = p.mean(axis=0)
             mx = p.max(axis=0)
-            lens = ln.cpu().numpy().astype("uint32")
-            rows = 2 * H if rm == 2 else H
-            alg = int(lens.sum()) + args.batch * 3 * W * rows
-            print(f"{wl:26s} v{v} kernel {ms*1e3:8.1f} us (b2b {b2b*1e3:8.1f} us) alg {alg/1e6:8.2f} MB -> "
-                  f"{alg/(ms*1e-3)/1e9:7.1f} GB/s  | cycles/frame mean: " +
+            print(head + "  | cycles/frame mean: " +
                   " ".join(f"{n}={int(m)}" for n, m in zip(names, mean[:8])) + f" | max total={int(mx[7])}")
         plan.close()
         del frames_t, out

@@ -36,7 +36,7 @@ class Frame(C.Structure):
 
 
 class Lut(C.Structure):
-    _fields_ = [("glyph", C.c_uint32 * 256), ("glyph64", C.c_uint32 * 64), ("ramp", C.c_uint8 * 64)]
+    _fields_ = [("glyph", C.c_uint32 * 256), ("glyph64", C.c_uint32 * 64), ("ramp", C.c_uint8 * 64), ("flags", C.c_uint32)]
 
 
 def bind_host(L):
@@ -59,6 +59,11 @@ def bind_host(L):
     L.achip_nn_ratio.argtypes = [C.c_int, C.c_int]
     L.achip_out_bound.restype = C.c_size_t
     L.achip_out_bound.argtypes = [C.c_int, C.POINTER(Frame)]
+    L.achip_choose_geometry.restype = C.c_int
+    L.achip_choose_geometry.argtypes = [C.c_int, C.POINTER(Frame), C.c_int, C.c_bool, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int,
+                                        C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.achip_palette_ascii_only.restype = C.c_bool
+    L.achip_palette_ascii_only.argtypes = [C.c_char_p]
     L.achip_grid_layout.restype = None
     L.achip_grid_layout.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int,
                                     C.POINTER(C.c_int), C.POINTER(C.c_int)]

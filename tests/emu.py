@@ -37,6 +37,8 @@ def lib():
         _lib.emu_render_batch.restype = C.c_int
         _lib.emu_render_batch.argtypes = [C.c_int, C.c_int, C.POINTER(Frame), C.c_int, C.POINTER(Lut), C.c_void_p,
                                           C.c_uint64, C.c_void_p]
+        _lib.emu_set_parts.restype = None
+        _lib.emu_set_parts.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_uint32]
         _lib.emu_resize_nn.restype = None
         _lib.emu_resize_nn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_uint32,
                                        C.c_uint32]
@@ -56,7 +58,11 @@ def make_lut(palette):
     return lut
 
 
-def render_frames(mode, frames, palette, variant=0, stride=None):
+_EPOCH = [0]
+
+
+def render_frames(mode, frames, palette, variant=0, stride=None, rows_per_part=0):
+    """rows_per_part > 0 renders every frame with ceil(rows / rows_per_part) workgroups (multi-part frames)."""
     """frames: ctypes array/list of Frame (src pointers = host numpy memory). Returns list of bytes / int codes."""
     L = lib()
     n = len(frames)
@@ -69,7 +75,17 @@ def render_frames(mode, frames, palette, variant=0, stride=None):
     # 16-byte align the slab like hipMalloc would
     base = (out.ctypes.data + 15) // 16 * 16
     ln = np.zeros(n, dtype=np.uint32)
-    rc = L.emu_render_batch(mode, variant, arr, n, C.byref(lut), base, stride, ln.ctypes.data)
+    if rows_per_part > 0:
+        hb = mode in (5, 6, 7, 8)
+        max_rows = max(((f.out_h + 1) // 2 if hb else f.out_h) for f in frames)
+        parts = (max_rows + rows_per_part - 1) // rows_per_part
+        sync = np.zeros(n * parts, dtype=np.uint64)
+        _EPOCH[0] += 1
+        L.emu_set_parts(parts, rows_per_part, sync.ctypes.data, _EPOCH[0])
+    try:
+        rc = L.emu_render_batch(mode, variant, arr, n, C.byref(lut), base, stride, ln.ctypes.data)
+    finally:
+        L.emu_set_parts(1, 0, None, 1)
     assert rc == 0
     res = []
     for i in range(n):

@@ -6,13 +6,26 @@
 #include "render_kernels.hpp"
 #include "render_variants.h"
 
+static int g_parts = 1, g_rows_per_part = 0;
+static unsigned long long *g_part_sync = nullptr;
+static uint32_t g_epoch = 1;
+
 template <int MODE, int BLOCK, int CAP, int RING>
 static void run(const achip_frame_t *frames, int n, const achip_lut_t *lut, uint8_t *out, uint64_t stride,
                 uint32_t *len) {
   using L = achip::Lds<MODE, BLOCK, CAP, RING>;
-  hipemu::launch(dim3((unsigned)n), dim3(BLOCK), (size_t)L::bytes, [&] {
-    achip::render_frames_kernel<MODE, BLOCK, CAP, RING, true>(frames, lut, out, stride, len, n, nullptr);
+  hipemu::launch(dim3((unsigned)(n * g_parts)), dim3(BLOCK), (size_t)L::bytes, [&] {
+    achip::render_frames_kernel<MODE, BLOCK, CAP, RING, true>(frames, lut, out, stride, len, n, nullptr, g_parts,
+                                                              g_rows_per_part, g_part_sync, g_epoch);
   });
+}
+
+/* multi-workgroup frames: set before emu_render_batch (parts == 1 restores the default) */
+extern "C" void emu_set_parts(int parts, int rows_per_part, unsigned long long *part_sync, uint32_t epoch) {
+  g_parts = parts;
+  g_rows_per_part = rows_per_part;
+  g_part_sync = part_sync;
+  g_epoch = epoch;
 }
 
 template <int BLOCK, int CAP, int RING>

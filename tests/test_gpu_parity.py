@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 import orc  # noqa: E402
-from achip_ctypes import ALL_MODES, MODE_CAPS, MODE_NAMES, MODE_TRUE_BG  # noqa: E402
+from achip_ctypes import ALL_MODES, MODE_CAPS, MODE_NAMES, MODE_16_DITHER_BG, MODE_TRUE_BG  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -38,7 +38,7 @@ def oracle_convert(img, mode, W, H, palette, wants_padding=False, use_aspect=Fal
 
 
 def render_batch(gpu, mode, imgs, W, H, palette=orc.PALETTE_STANDARD, wants_padding=False, use_aspect=False,
-                 variant=-1, dims=None):
+                 variant=-1, dims=None, split=None, repeat=1, want_parts=None):
     """imgs: list of HxWx3 uint8 numpy arrays -> list of bytes via the batch C-ABI."""
     pkg, torch = gpu
     rm = MODE_CAPS.get(mode, (3, 0))[1]
@@ -52,9 +52,14 @@ def render_batch(gpu, mode, imgs, W, H, palette=orc.PALETTE_STANDARD, wants_padd
     plan = pkg.Plan(mode, palette, frames)
     if variant >= 0:
         plan.set_variant(variant)
+    if split is not None:
+        plan.set_split(split)
+    if want_parts is not None:
+        assert plan.parts == want_parts, (plan.parts, want_parts)
     out = torch.full((len(imgs) * plan.stride,), 0xEE, dtype=torch.uint8, device="cuda")
     ln = torch.zeros(len(imgs), dtype=torch.int32, device="cuda")
-    plan.render(out.data_ptr(), plan.stride, ln.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    for _ in range(repeat):  # multi-workgroup frames: every launch is a new epoch of the hand-off words
+        plan.render(out.data_ptr(), plan.stride, ln.data_ptr(), torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     host = out.cpu().numpy()
     lens = ln.cpu().numpy().astype(np.uint32)
@@ -86,6 +91,41 @@ def test_aspect_and_padding(gpu, mode):
     for (W, H) in [(80, 24), (97, 31), (60, 40), (300, 20)]:
         got = render_batch(gpu, mode, [TORTURE], W, H, wants_padding=True, use_aspect=True)[0]
         assert got == oracle_convert(TORTURE, mode, W, H, orc.PALETTE_STANDARD, True, True), (MODE_NAMES[mode], W, H)
+
+
+SPLITTABLE = [m for m in ALL_MODES if m != MODE_16_DITHER_BG]
+
+
+@pytest.mark.parametrize("mode", SPLITTABLE, ids=[MODE_NAMES[m] for m in SPLITTABLE])
+def test_multi_workgroup_frames(gpu, mode):
+    """A frame cut into row bands rendered by several workgroups (device-side length hand-off): same bytes."""
+    for (W, H, split, pad, n) in [(80, 24, 0, False, 1), (80, 24, 1, True, 3), (97, 31, 4, True, 2), (200, 60, 3, False, 5),
+                                  (400, 120, 0, False, 2), (80, 24, 0, False, 40)]:
+        aspect = pad and mode != MODE_TRUE_BG
+        imgs = [TORTURE] + [orc.frame_hash_noise(160, 120, 7 + k) for k in range(n - 1)]
+        got = render_batch(gpu, mode, imgs, W, H, wants_padding=pad, use_aspect=aspect, split=split, repeat=3)
+        for k, img in enumerate(imgs):
+            assert got[k] == oracle_convert(img, mode, W, H, orc.PALETTE_STANDARD, pad, aspect), (MODE_NAMES[mode], W, H, k)
+    # policy: one 80x24 frame -> 24 single-row workgroups; never when asked not to
+    render_batch(gpu, mode, [TORTURE], 80, 24, split=0, want_parts=24)
+    render_batch(gpu, mode, [TORTURE], 80, 24, split=-1, want_parts=1)
+
+
+def test_split_exclusions_and_ragged_parts(gpu):
+    # multi-byte glyphs in truecolor-fg and the serial dither stay whole-frame
+    render_batch(gpu, 1, [TORTURE], 80, 24, palette=orc.PALETTE_BLOCKS, split=0, want_parts=1)
+    render_batch(gpu, MODE_16_DITHER_BG, [TORTURE], 80, 24, split=0, want_parts=1)
+    # but a multi-byte palette splits fine in the other modes
+    for mode in (0, 2, 3):
+        got = render_batch(gpu, mode, [TORTURE], 80, 24, palette=orc.PALETTE_BLOCKS, split=5)
+        assert got[0] == oracle_convert(TORTURE, mode, 80, 24, orc.PALETTE_BLOCKS)
+    # ragged batch: frames with fewer rows than the tallest leave their later workgroups idle
+    imgs = [orc.frame_hash_noise(120, 90, i) for i in range(4)]
+    dims = [(80, 24), (60, 7), (33, 40), (80, 1)]
+    for mode in (1, 2, 5):
+        got = render_batch(gpu, mode, imgs, 0, 0, dims=dims, split=4, repeat=2)
+        for k, (im, (w, h)) in enumerate(zip(imgs, dims)):
+            assert got[k] == oracle_convert(im, mode, w, h, orc.PALETTE_STANDARD), (mode, k)
 
 
 @pytest.mark.parametrize("palette", [orc.PALETTE_BLOCKS, orc.PALETTE_COOL, orc.PALETTE_DIGITAL, orc.PALETTE_MINIMAL,

@@ -1,0 +1,79 @@
+"""Multi-workgroup frames: a frame cut into row bands rendered by separate workgroups that learn their output
+offset from each other (part_publish / part_wait).  Emulated here; the -m gpu tests run it on the MI355X."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import emu  # noqa: E402
+import orc  # noqa: E402
+from achip_ctypes import ALL_MODES, MODE_16_DITHER_BG, MODE_CAPS, MODE_NAMES, MODE_TRUE_BG, Frame  # noqa: E402
+
+SPLITTABLE = [m for m in ALL_MODES if m != MODE_16_DITHER_BG]
+
+
+def oracle(img, mode, W, H, pad, aspect, palette=orc.PALETTE_STANDARD):
+    if mode == MODE_TRUE_BG:
+        return orc.print_truecolor_bg(orc.resize_nn(img, W, H), palette)
+    cl, rm = MODE_CAPS[mode]
+    return orc.convert_with_caps(img, W, H, cl, rm, pad, aspect, False, palette)
+
+
+@pytest.mark.parametrize("mode", SPLITTABLE, ids=[MODE_NAMES[m] for m in SPLITTABLE])
+def test_split_frames_emulated(mode):
+    img = orc.frame_torture()
+    rm = MODE_CAPS.get(mode, (3, 0))[1]
+    for (W, H, rpp, variant, pad) in [(80, 24, 6, 2, False), (80, 24, 1, 2, True), (97, 31, 4, 2, True), (40, 50, 3, 3, False),
+                                      (200, 60, 5, 2, False)]:
+        aspect = pad and mode != MODE_TRUE_BG
+        f = emu.frame_for_convert(img, W, H, rm, pad, aspect)
+        got = emu.render_frames(mode, [f], orc.PALETTE_STANDARD, variant, rows_per_part=rpp)[0]
+        assert got == oracle(img, mode, W, H, pad, aspect), (MODE_NAMES[mode], W, H, rpp)
+
+
+def test_split_ragged_batch_and_policy():
+    # frames with different row counts in one launch: later parts of short frames simply do not exist
+    imgs = [orc.frame_hash_noise(120, 90, i) for i in range(4)]
+    dims = [(80, 24), (60, 7), (33, 40), (80, 1)]
+    frames = [emu.frame_for_convert(im, w, h, 0) for im, (w, h) in zip(imgs, dims)]
+    for mode in (1, 2, 0):
+        got = emu.render_frames(mode, frames, orc.PALETTE_STANDARD, 2, rows_per_part=5)
+        for k, (im, (w, h)) in enumerate(zip(imgs, dims)):
+            assert got[k] == oracle(im, mode, w, h, False, False), (mode, k)
+    # host policy (achip_choose_geometry)
+    L = emu.lib()
+    caps = (C.c_int * 5)(4096, 2048, 1024, 256, 2048)
+    v, p, r = C.c_int(), C.c_int(), C.c_int()
+
+    def choose(mode, fr, ascii_only=True, req=0, cus=256, forced=-1):
+        arr = (Frame * len(fr))(*fr)
+        assert L.achip_choose_geometry(mode, arr, len(fr), ascii_only, caps, cus, req, forced, C.byref(v), C.byref(p),
+                                       C.byref(r)) == 0
+        return v.value, p.value, r.value
+
+    one = [emu.frame_for_convert(imgs[0], 80, 24, 0)]
+    assert choose(1, one) == (4, 24, 1)                       # a single frame: one text row per workgroup
+    assert choose(1, one * 64) == (4, 4, 6)                   # 64 frames on 256 CUs: 4 bands each
+    assert choose(1, one * 128) == (4, 2, 12)
+    assert choose(1, one * 150) == (2, 2, 12)                 # more bands than CUs: the geometry that fits a band
+    assert choose(1, one * 256) == (4, 1, 24)                 # BASELINE batch = one frame per CU: whole frames
+    assert choose(1, one * 600) == (2, 1, 24)                 # many frames: whole frames, small workgroups
+    assert choose(9, one) == (4, 1, 24)                       # serial dither: never split
+    assert choose(1, one, ascii_only=False) == (4, 1, 24)     # truecolor-fg with multi-byte glyphs: never split
+    assert choose(2, one, ascii_only=False) == (4, 24, 1)
+    assert choose(1, one, req=-1) == (4, 1, 24)
+    assert choose(1, one, req=12) == (4, 2, 12)
+    assert choose(1, one, req=3, forced=2) == (2, 8, 3)
+    assert choose(1, one, forced=1, req=-1) == (1, 1, 24)
+    k3 = [emu.frame_for_convert(imgs[0], 200, 60, 0)]
+    assert choose(1, k3 * 64) == (1, 6, 10)                   # bands limited by the 2048-cell chunk
+    k5 = [emu.frame_for_convert(imgs[0], 400, 120, 2)]        # half-block: 120 text rows of 400 cells
+    assert choose(5, k5 * 32) == (4, 24, 5)
+    wide = [emu.frame_for_convert(imgs[0], 3000, 4, 0)]
+    assert choose(0, wide) == (0, 1, 4)                       # rows wider than the band geometries: no split
+    assert L.achip_palette_ascii_only(orc.PALETTE_STANDARD.encode()) and not L.achip_palette_ascii_only(orc.PALETTE_COOL.encode())
