@@ -90,6 +90,10 @@ def lib():
     L.asciichat_hip_plan_set_split.argtypes = [vp, ci]
     L.asciichat_hip_plan_get_parts.restype = ci
     L.asciichat_hip_plan_get_parts.argtypes = [vp]
+    L.asciichat_hip_crc32c.restype = ci
+    L.asciichat_hip_crc32c.argtypes = [vp, C.c_size_t, vp, C.c_uint32, C.c_uint32, ci, vp, vp]
+    L.asciichat_hip_frame_packets.restype = ci
+    L.asciichat_hip_frame_packets.argtypes = [vp, C.c_size_t, vp, C.c_uint32, ci, vp, vp, vp, vp, vp]
     L.asciichat_hip_plan_render.restype = ci
     L.asciichat_hip_plan_render.argtypes = [vp, vp, sz, vp, vp]
     L.asciichat_hip_plan_render_range.restype = ci

@@ -275,6 +275,8 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
                           split_request >= 0 && max_rows > 1;
   if (!splittable || (split_request == 0 && 4 * n_frames >= 3 * n_cus))
     return 0;
+  if (forced_variant >= 0 && forced_variant != 1 && forced_variant != 2 && forced_variant != 4)
+    return 0; /* row-band kernels exist for the geometries this policy picks (render_inst.hip: HAS_SPLIT) */
   /* a band is exactly one chunk: at most cap / wp rows for every frame of the batch */
   const int band_cap = forced_variant >= 0 ? variant_caps[forced_variant] : variant_caps[4];
   if (max_wp > band_cap)

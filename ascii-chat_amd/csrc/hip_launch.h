@@ -26,6 +26,15 @@ int achip_launch_tint(uint8_t *px, int w, int h, int stride, uint32_t ops, void 
 int achip_launch_flip(const uint8_t *src, uint8_t *dst, int w, int h, int src_stride, int dst_stride, uint32_t ops,
                       void *stream);
 
+/* wire stage (crc_kernels.hpp): CRC-32C of n buffers at base + i*stride (len_dev[i] bytes, or fixed_len when
+ * len_dev == NULL; every length <= max_len) and, when hdr_out != NULL, the 24-byte ascii_frame_packet_t headers
+ * (dims_dev = n x {width, height}) and the CRC of header || frame.  partial: n * achip_crc_parts(max_len) u32 of
+ * device scratch, unused (may be NULL) when achip_crc_parts(max_len) == 1. */
+int achip_crc_parts(uint32_t max_len);
+int achip_launch_crc32c(const uint8_t *base, uint64_t stride, const uint32_t *len_dev, uint32_t fixed_len,
+                        uint32_t max_len, int n, uint32_t *partial, const uint32_t *dims_dev, uint32_t *crc_out,
+                        uint8_t *hdr_out, uint32_t *pkt_crc_out, void *stream);
+
 int achip_variant_block(int variant); /* threads per workgroup, -1 for an unknown id */
 int achip_variant_cap(int variant);   /* cells per chunk                               */
 int achip_variant_lds_bytes(int mode, int variant);

@@ -1,84 +1,16 @@
 /*
- * hip_launch.hip -- instantiates the gfx950 kernels and exposes plain-C launchers.
+ * hip_launch.hip -- plain-C launchers of the gfx950 kernels (the frame kernel itself is instantiated per
+ * geometry in render_inst.hip).
  * Built only with hipcc --offload-arch=gfx950; there is no host/CPU variant of these entry points.
  */
 #include "hip_launch.h"
 
 #include <hip/hip_runtime.h>
 
+#include "render_inst.h"
 #include "render_kernels.hpp"
+#include "crc_kernels.hpp"
 #include "render_variants.h"
-
-namespace {
-
-template <int MODE, int BLOCK, int CAP, int RING, bool COMP>
-hipError_t launch_one(const achip_frame_t *frames, int n, const achip_lut_t *lut, uint8_t *out, uint64_t stride,
-                      uint32_t *len, unsigned long long *prof, int parts, int rows_per_part, unsigned long long *part_sync,
-                      uint32_t epoch, hipStream_t stream) {
-  using L = achip::Lds<MODE, BLOCK, CAP, RING>;
-  auto kern = achip::render_frames_kernel<MODE, BLOCK, CAP, RING, COMP>;
-  static bool attr_set = false; /* one flag per instantiation; benign race (idempotent call) */
-  if (!attr_set) {
-    if (L::bytes > 48 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, L::bytes);
-      if (e != hipSuccess)
-        return e;
-    }
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(kern, dim3((unsigned)n * (unsigned)parts), dim3(BLOCK), (size_t)L::bytes, stream, frames, lut, out,
-                     stride, len, n, prof, parts, rows_per_part, part_sync, epoch);
-  return hipGetLastError();
-}
-
-template <int BLOCK, int CAP, int RING>
-hipError_t launch_mode(int mode, bool comp, const achip_frame_t *frames, int n, const achip_lut_t *lut, uint8_t *out,
-                       uint64_t stride, uint32_t *len, unsigned long long *prof, int parts, int rows_per_part,
-                       unsigned long long *part_sync, uint32_t epoch, hipStream_t stream) {
-  switch (mode) {
-#define M(m)                                                                                                           \
-  case m:                                                                                                              \
-    return comp ? launch_one<m, BLOCK, CAP, RING, true>(frames, n, lut, out, stride, len, prof, parts, rows_per_part,  \
-                                                        part_sync, epoch, stream)                                      \
-                : launch_one<m, BLOCK, CAP, RING, false>(frames, n, lut, out, stride, len, prof, parts, rows_per_part, \
-                                                         part_sync, epoch, stream);
-    M(ACHIP_MODE_MONO)
-    M(ACHIP_MODE_TRUE_FG)
-    M(ACHIP_MODE_256_FG)
-    M(ACHIP_MODE_16_FG)
-    M(ACHIP_MODE_TRUE_BG)
-    M(ACHIP_MODE_HB_TRUE)
-    M(ACHIP_MODE_HB_256)
-    M(ACHIP_MODE_HB_16)
-    M(ACHIP_MODE_HB_MONO)
-    M(ACHIP_MODE_16_DITHER_BG)
-#undef M
-  }
-  return hipErrorInvalidValue;
-}
-
-template <int BLOCK, int CAP, int RING> int lds_for_mode(int mode) {
-  switch (mode) {
-#define M(m)                                                                                                           \
-  case m:                                                                                                              \
-    return achip::Lds<m, BLOCK, CAP, RING>::bytes;
-    M(ACHIP_MODE_MONO)
-    M(ACHIP_MODE_TRUE_FG)
-    M(ACHIP_MODE_256_FG)
-    M(ACHIP_MODE_16_FG)
-    M(ACHIP_MODE_TRUE_BG)
-    M(ACHIP_MODE_HB_TRUE)
-    M(ACHIP_MODE_HB_256)
-    M(ACHIP_MODE_HB_16)
-    M(ACHIP_MODE_HB_MONO)
-    M(ACHIP_MODE_16_DITHER_BG)
-#undef M
-  }
-  return -1;
-}
-
-} // namespace
 
 extern "C" int achip_launch_render(int mode, int variant, int has_composite, const achip_frame_t *frames_dev, int n_frames,
                                    const achip_lut_t *lut_dev, uint8_t *out, uint64_t out_stride, uint32_t *out_len,
@@ -88,12 +20,11 @@ extern "C" int achip_launch_render(int mode, int variant, int has_composite, con
     return (int)hipSuccess;
   if (parts < 1 || (parts > 1 && (!part_sync || rows_per_part < 1)))
     return (int)hipErrorInvalidValue;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  switch (variant) {
+  switch (variant) { /* one translation unit per geometry: render_inst.hip */
 #define X(id, B, C, R)                                                                                                 \
   case id:                                                                                                             \
-    return (int)launch_mode<B, C, R>(mode, has_composite != 0, frames_dev, n_frames, lut_dev, out, out_stride, out_len, prof,    \
-                                     parts, rows_per_part, part_sync, epoch, s);
+    return achip_render_inst_launch_##id(mode, has_composite, frames_dev, n_frames, lut_dev, out, out_stride, out_len, \
+                                         prof, parts, rows_per_part, part_sync, epoch, stream);
     ACHIP_VARIANTS(X)
 #undef X
   }
@@ -126,7 +57,7 @@ extern "C" int achip_variant_lds_bytes(int mode, int variant) {
   switch (variant) {
 #define X(id, B, C, R)                                                                                                 \
   case id:                                                                                                             \
-    return lds_for_mode<B, C, R>(mode);
+    return achip_render_inst_lds_##id(mode);
     ACHIP_VARIANTS(X)
 #undef X
   }
@@ -188,5 +119,31 @@ extern "C" int achip_launch_flip(const uint8_t *src, uint8_t *dst, int w, int h,
   else
     hipLaunchKernelGGL(achip::flip_pixels_kernel, dim3(stream_blocks((uint64_t)w * (uint64_t)h)), dim3(256), 0, s, src,
                        dst, w, h, src_stride, dst_stride, ops);
+  return (int)hipGetLastError();
+}
+
+/* CRC-32C of n buffers + optional wire headers (crc_kernels.hpp).  Buffers up to 128 KB are checksummed by one
+ * workgroup each, which also finishes them; larger ones are cut into 64 KB spans and finished by a second
+ * kernel, which needs `partial` = n * achip_crc_parts(max_len) u32 of device scratch. */
+extern "C" int achip_crc_parts(uint32_t max_len) {
+  return max_len <= 32u * 4096u ? 1 : (int)(((uint64_t)max_len + 65535u) / 65536u);
+}
+
+extern "C" int achip_launch_crc32c(const uint8_t *base, uint64_t stride, const uint32_t *len_dev, uint32_t fixed_len,
+                                   uint32_t max_len, int n, uint32_t *partial, const uint32_t *dims_dev,
+                                   uint32_t *crc_out, uint8_t *hdr_out, uint32_t *pkt_crc_out, void *stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int parts = achip_crc_parts(max_len);
+  const int rounds = parts == 1 ? (int)((max_len + 4095u) / 4096u > 0 ? (max_len + 4095u) / 4096u : 1u) : 16;
+  const uint64_t v_bytes = (uint64_t)parts * (uint64_t)rounds * 4096u;
+  const uint32_t xinv_v = achip::crc_pow(achip::CRC_XINV8, v_bytes);
+  hipLaunchKernelGGL(achip::crc32c_frames_kernel, dim3((unsigned)n * (unsigned)parts), dim3(achip::CRC_BLOCK),
+                     (size_t)achip::CrcLds::bytes, s, base, stride, len_dev, fixed_len, n, parts, rounds, xinv_v,
+                     parts == 1 ? crc_out : partial, dims_dev, crc_out, hdr_out, pkt_crc_out);
+  if (parts > 1) {
+    const uint32_t cspan = achip::crc_pow(achip::CRC_X8, (uint64_t)rounds * 4096u);
+    hipLaunchKernelGGL(achip::crc32c_finish_kernel, dim3((unsigned)n), dim3(64), 256, s, partial, parts, cspan, xinv_v,
+                       len_dev, fixed_len, n, dims_dev, crc_out, hdr_out, pkt_crc_out);
+  }
   return (int)hipGetLastError();
 }

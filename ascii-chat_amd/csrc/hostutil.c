@@ -7,6 +7,7 @@
 #include <limits.h>
 #include <math.h>
 #include <stdlib.h>
+#include <pthread.h>
 #include <string.h>
 
 #include "asciichat_render.h"
@@ -289,6 +290,63 @@ void build_utf8_ramp64_cache(const char *ascii_chars, utf8_char_t cache64[64], u
     char_index_ramp[i] = (uint8_t)ci;
     fill_glyph(&cache64[i], start[ci], blen[ci], limit);
   }
+}
+
+/* get_utf8_palette_cache (common.c:270-377): palette string -> tables, built once, shared by all threads.
+ * The reference evicts by a recency/frequency score once 2048 palettes are cached; entries here are 5 KB and
+ * are kept for the life of the process up to the same 2048, after which the table stops growing (a palette
+ * beyond that is rebuilt into a per-thread slot on every call). */
+#define PALCACHE_BUCKETS 256
+#define PALCACHE_MAX 2048
+typedef struct palcache_node {
+  utf8_palette_cache_t tables; /* first: the pointer handed out is the node */
+  struct palcache_node *next;
+  uint32_t key;
+  char palette[256];
+} palcache_node_t;
+static palcache_node_t *g_palcache[PALCACHE_BUCKETS];
+static int g_palcache_count;
+static pthread_rwlock_t g_palcache_lock = PTHREAD_RWLOCK_INITIALIZER;
+
+static palcache_node_t *palcache_find(uint32_t key, const char *chars) {
+  for (palcache_node_t *n = g_palcache[key % PALCACHE_BUCKETS]; n; n = n->next)
+    if (n->key == key && strcmp(n->palette, chars) == 0)
+      return n;
+  return NULL;
+}
+
+utf8_palette_cache_t *get_utf8_palette_cache(const char *ascii_chars) {
+  if (!ascii_chars || ascii_chars[0] == '\0' || strlen(ascii_chars) >= sizeof(((palcache_node_t *)0)->palette))
+    return NULL;
+  uint32_t key = 2166136261u; /* FNV-1a, as the reference keys its table (common.c:275) */
+  for (const unsigned char *p = (const unsigned char *)ascii_chars; *p; p++)
+    key = (key ^ *p) * 16777619u;
+  pthread_rwlock_rdlock(&g_palcache_lock);
+  palcache_node_t *n = palcache_find(key, ascii_chars);
+  pthread_rwlock_unlock(&g_palcache_lock);
+  if (n)
+    return &n->tables;
+  pthread_rwlock_wrlock(&g_palcache_lock);
+  n = palcache_find(key, ascii_chars); /* someone may have built it while the lock was dropped */
+  if (!n) {
+    static __thread palcache_node_t overflow_slot;
+    const bool full = g_palcache_count >= PALCACHE_MAX;
+    n = full ? &overflow_slot : (palcache_node_t *)calloc(1, sizeof(*n));
+    if (n) {
+      memset(n, 0, sizeof(*n));
+      build_utf8_luminance_cache(ascii_chars, n->tables.cache);
+      build_utf8_ramp64_cache(ascii_chars, n->tables.cache64, n->tables.char_index_ramp);
+      n->key = key;
+      memcpy(n->palette, ascii_chars, strlen(ascii_chars) + 1);
+      if (!full) {
+        n->next = g_palcache[key % PALCACHE_BUCKETS];
+        g_palcache[key % PALCACHE_BUCKETS] = n;
+        g_palcache_count++;
+      }
+    }
+  }
+  pthread_rwlock_unlock(&g_palcache_lock);
+  return n ? &n->tables : NULL;
 }
 
 void ascii_simd_init(void) { /* common.c:576-604: default luminance palette over PALETTE_CHARS_STANDARD */

@@ -388,6 +388,54 @@ int asciichat_hip_image_flip(const uint8_t *src_dev, uint8_t *dst_dev, int width
                          "flip launch");
 }
 
+/* ---- wire stage -------------------------------------------------------------------------------- */
+static __thread uint32_t *t_crc_scratch; /* span registers of large buffers; grown on demand, one per thread */
+static __thread size_t t_crc_scratch_n;
+
+static int crc_common(const uint8_t *base_dev, size_t stride, const uint32_t *len_dev, uint32_t fixed_len,
+                      uint32_t max_len, int n, const uint32_t *dims_dev, uint32_t *crc_out_dev, uint8_t *hdr_out_dev,
+                      uint32_t *packet_crc_out_dev, void *stream) {
+  if (!base_dev || !crc_out_dev || n <= 0 || ((uintptr_t)base_dev & 15u) || (stride & 15u) ||
+      (len_dev ? max_len == 0 : fixed_len > max_len) || max_len >= 0xFFFFFFF0u || (n > 1 && stride < max_len))
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "crc32c: bad arguments");
+  int rc = achip_require_device();
+  if (rc)
+    return rc;
+  const int parts = achip_crc_parts(max_len);
+  uint32_t *scratch = NULL;
+  if (parts > 1) {
+    const size_t need = (size_t)n * (size_t)parts;
+    if (need > t_crc_scratch_n) {
+      if (t_crc_scratch)
+        (void)hipFree(t_crc_scratch); /* synchronises with work that may still read the old block */
+      t_crc_scratch = NULL;
+      t_crc_scratch_n = 0;
+      rc = achip_hip_check((int)hipMalloc((void **)&t_crc_scratch, need * sizeof(uint32_t)), "hipMalloc(crc scratch)");
+      if (rc)
+        return rc;
+      t_crc_scratch_n = need;
+    }
+    scratch = t_crc_scratch;
+  }
+  return achip_hip_check(achip_launch_crc32c(base_dev, stride, len_dev, fixed_len, max_len, n, scratch, dims_dev,
+                                             crc_out_dev, hdr_out_dev, packet_crc_out_dev, stream),
+                         "crc32c launch");
+}
+
+int asciichat_hip_crc32c(const uint8_t *base_dev, size_t stride, const uint32_t *len_dev, uint32_t fixed_len,
+                         uint32_t max_len, int n, uint32_t *crc_out_dev, void *stream) {
+  return crc_common(base_dev, stride, len_dev, fixed_len, max_len, n, NULL, crc_out_dev, NULL, NULL, stream);
+}
+
+int asciichat_hip_frame_packets(const uint8_t *base_dev, size_t stride, const uint32_t *len_dev, uint32_t max_len, int n,
+                                const uint32_t *dims_dev, uint32_t *crc_out_dev, uint8_t *hdr_out_dev,
+                                uint32_t *packet_crc_out_dev, void *stream) {
+  if (!len_dev || !hdr_out_dev)
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame_packets: lengths and a header buffer are required");
+  return crc_common(base_dev, stride, len_dev, 0, max_len, n, dims_dev, crc_out_dev, hdr_out_dev, packet_crc_out_dev,
+                    stream);
+}
+
 void asciichat_hip_free(void *dev_ptr) {
   if (dev_ptr)
     (void)hipFree(dev_ptr);

@@ -1,0 +1,25 @@
+/* render_inst.h -- entry points of the per-geometry translation units (render_inst.hip, -DACHIP_INST=id). */
+#ifndef ACHIP_RENDER_INST_H
+#define ACHIP_RENDER_INST_H
+
+#include <stdint.h>
+
+#include "achip_types.h"
+#include "render_variants.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define X(id, B, C, R)                                                                                                 \
+  int achip_render_inst_launch_##id(int mode, int comp, const achip_frame_t *frames, int n, const achip_lut_t *lut,    \
+                                    uint8_t *out, uint64_t stride, uint32_t *len, unsigned long long *prof, int parts, \
+                                    int rows_per_part, unsigned long long *part_sync, uint32_t epoch, void *stream);   \
+  int achip_render_inst_lds_##id(int mode);
+ACHIP_VARIANTS(X)
+#undef X
+
+#ifdef __cplusplus
+}
+#endif
+#endif

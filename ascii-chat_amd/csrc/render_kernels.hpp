@@ -922,7 +922,7 @@ __device__ inline unsigned long long cycle_now() { return (unsigned long long)cl
     }                                                                                                                  \
   } while (0)
 
-template <int MODE, int BLOCK, int CAP, int RING, bool COMP>
+template <int MODE, int BLOCK, int CAP, int RING, bool COMP, bool SPLIT = true>
 __global__ void __launch_bounds__(BLOCK)
     render_frames_kernel(const achip_frame_t *__restrict__ frames, const achip_lut_t *__restrict__ lut,
                          uint8_t *__restrict__ out, uint64_t out_stride, uint32_t *__restrict__ out_len, int n_frames,
@@ -931,6 +931,10 @@ __global__ void __launch_bounds__(BLOCK)
   /* parts == 1: one workgroup renders the whole frame.  parts > 1: workgroup (frame, part) renders text rows
    * [part*rows_per_part, ...) -- exactly one chunk -- and learns where its bytes start from the lengths its
    * predecessors publish in part_sync[frame*parts + q] (see part_publish / part_wait). */
+  /* SPLIT = false instantiations serve whole-frame launches: the band plumbing folds away (measured: 3 % of
+   * the 1080p -> 80x24 kernel, profiles/r01_ablation.txt) */
+  if (!SPLIT)
+    parts = 1;
   using L = Lds<MODE, BLOCK, CAP, RING>;
   constexpr bool HB = mode_is_halfblock(MODE);
   constexpr int NW = L::NW;
@@ -966,6 +970,9 @@ __global__ void __launch_bounds__(BLOCK)
   const uint32_t lut_ramp = tid < 64 ? lut->ramp[tid] : 0u;
   const bool ascii_only = (lut->flags & ACHIP_LUT_MULTIBYTE) == 0u;
   achip_frame_t f = frames[fidx];
+#if defined(ACHIP_ABLATE_NOOPS) /* diagnostics: cost of the folded display ops */
+  f.ops = 0;
+#endif
   if (f.src_stride == 0)
     f.src_stride = 3 * f.src_w;
   uint8_t *dst = out + (size_t)fidx * out_stride;
@@ -1313,6 +1320,7 @@ __global__ void __launch_bounds__(BLOCK)
   }
 }
 
+#ifndef ACHIP_FRAME_KERNEL_ONLY /* render_inst.hip: the non-template kernels below live in hip_launch.hip only */
 /* ------------------------------------------------------------------------------------------- */
 /* stand-alone image_resize (lib/video/rgba/image.c:256-328): writes the resized RGB24 image       */
 /* ------------------------------------------------------------------------------------------- */
@@ -1346,5 +1354,7 @@ __global__ void __launch_bounds__(256)
     d[2] = (uint8_t)(p >> 16);
   }
 }
+
+#endif /* ACHIP_FRAME_KERNEL_ONLY */
 
 } // namespace achip

@@ -112,6 +112,26 @@ int asciichat_hip_apply_color_filter(uint8_t *pixels_dev, int width, int height,
 int asciichat_hip_image_flip(const uint8_t *src_dev, uint8_t *dst_dev, int width, int height, int flip_x, int flip_y,
                              void *stream);
 
+/*
+ * Wire stage after render, on DEVICE buffers, for the frames of a slab (frame i at
+ * base_dev + i*stride, len_dev[i] bytes; or fixed_len bytes each when len_dev == NULL; max_len bounds every
+ * length -- pass the slab stride for a plan's output):
+ *   crc_out_dev[i]   asciichat_crc32(frame i) -- CRC-32C, lib/network/crc32.c:95-190
+ *   hdr_out_dev      n x 24 bytes: the ascii_frame_packet_t that acip_send_ascii_frame builds
+ *                    (lib/network/acip/server.c:186-214; include/ascii-chat/network/packet/packet.h:847-862):
+ *                    {width, height, original_size = len, compressed_size = 0, checksum, flags = 0}, network
+ *                    byte order; dims_dev = n x {width, height} (uint32, host byte order)
+ *   packet_crc_out_dev[i]  CRC-32C of header || frame, the packet_header_t.crc32 that
+ *                    packet_send_via_transport computes over the payload (lib/network/acip/send.c:59-69)
+ * hdr_out_dev / dims_dev / packet_crc_out_dev may be NULL.  A frame whose length is a render error code
+ * (>= 0xFFFFFFF0) gets CRC 0.  base_dev and stride must be 16-byte aligned.
+ */
+int asciichat_hip_crc32c(const uint8_t *base_dev, size_t stride, const uint32_t *len_dev, uint32_t fixed_len,
+                         uint32_t max_len, int n, uint32_t *crc_out_dev, void *stream);
+int asciichat_hip_frame_packets(const uint8_t *base_dev, size_t stride, const uint32_t *len_dev, uint32_t max_len, int n,
+                                const uint32_t *dims_dev, uint32_t *crc_out_dev, uint8_t *hdr_out_dev,
+                                uint32_t *packet_crc_out_dev, void *stream);
+
 /* Upload a composite descriptor for use as achip_frame_t.comp; free with asciichat_hip_free. */
 int asciichat_hip_composite_upload(const achip_composite_t *comp_host, achip_composite_t **comp_dev);
 void asciichat_hip_free(void *dev_ptr);

@@ -103,6 +103,18 @@ typedef struct {
   uint8_t _pad;
 } utf8_char_t;
 
+/* utf8_palette_cache_t (common.h:474-490): callers read the three leading tables; the reference's bookkeeping
+ * tail (access counters, eviction heap index, third-party hash handle) is private there and opaque here. */
+typedef struct utf8_palette_cache {
+  utf8_char_t cache[256];
+  utf8_char_t cache64[64];
+  uint8_t char_index_ramp[256];
+  uint64_t _private[40];
+} utf8_palette_cache_t;
+
+/* get_utf8_palette_cache (common.c:270-377): borrowed, thread-safe, built once per palette string. */
+utf8_palette_cache_t *get_utf8_palette_cache(const char *ascii_chars);
+
 void build_utf8_luminance_cache(const char *ascii_chars, utf8_char_t cache[256]);
 void build_utf8_ramp64_cache(const char *ascii_chars, utf8_char_t cache64[64], uint8_t char_index_ramp[256]);
 void ascii_simd_init(void);

@@ -1134,3 +1134,35 @@ uint8_t *orc_composite(const uint8_t *const *src, const int *src_w, const int *s
   }
   return canvas;
 }
+
+/* ------------------------------------------------------------------------------------------- */
+/* wire stage: CRC-32C and the ASCII frame packet header                                         */
+/* ------------------------------------------------------------------------------------------- */
+static uint32_t crc32c_update(uint32_t crc, const uint8_t *p, size_t n) {
+  for (size_t i = 0; i < n; i++) { /* lib/network/crc32.c:177-186 */
+    crc ^= p[i];
+    for (int j = 0; j < 8; j++)
+      crc = (crc & 1u) ? (crc >> 1) ^ 0x82F63B78u : crc >> 1;
+  }
+  return crc;
+}
+
+uint32_t orc_crc32c(const void *data, size_t n) { return ~crc32c_update(0xFFFFFFFFu, (const uint8_t *)data, n); }
+
+static void be32(uint8_t *p, uint32_t v) {
+  p[0] = (uint8_t)(v >> 24);
+  p[1] = (uint8_t)(v >> 16);
+  p[2] = (uint8_t)(v >> 8);
+  p[3] = (uint8_t)v;
+}
+
+uint32_t orc_ascii_frame_packet(const void *frame, size_t n, uint32_t width, uint32_t height, uint8_t hdr[24]) {
+  be32(hdr + 0, width); /* server.c:208-214 */
+  be32(hdr + 4, height);
+  be32(hdr + 8, (uint32_t)n);
+  be32(hdr + 12, 0);
+  be32(hdr + 16, orc_crc32c(frame, n));
+  be32(hdr + 20, 0);
+  uint32_t c = crc32c_update(0xFFFFFFFFu, hdr, 24); /* the payload send.c checksums is header followed by frame */
+  return ~crc32c_update(c, (const uint8_t *)frame, n);
+}

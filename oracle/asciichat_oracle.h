@@ -104,6 +104,13 @@ char *orc_display_convert(const uint8_t *rgb, int src_w, int src_h, long width, 
                           int render_mode, bool wants_padding, bool use_aspect, bool stretch, const char *palette,
                           bool flip_x, bool flip_y, int color_filter, size_t *len);
 
+/* ---- wire stage after render ------------------------------------------------ */
+/* asciichat_crc32_sw, lib/network/crc32.c:171-189: CRC-32C (Castagnoli), bit by bit */
+uint32_t orc_crc32c(const void *data, size_t n);
+/* acip_send_ascii_frame's header, lib/network/acip/server.c:186-214: 24 bytes in network byte order;
+ * returns the CRC that packet_send_via_transport (lib/network/acip/send.c:59-69) computes over header+frame */
+uint32_t orc_ascii_frame_packet(const void *frame, size_t n, uint32_t width, uint32_t height, uint8_t hdr[24]);
+
 /* ascii_create_grid, ascii.c:602-885 */
 typedef struct {
   const char *frame_data;

@@ -111,8 +111,62 @@ def stream_passes():
     print(f"torch copy_ (reference point)      : {ms*1e3:8.1f} us  {2*nbytes/(ms*1e-3)/1e9:7.1f} GB/s")
 
 
+def wire_stage():
+    """CRC-32C + packet headers: on a rendered K2 slab, and on 1080p payloads (HBM-bound)."""
+    import torch
+
+    from __graft_entry__ import load_package
+
+    pkg = load_package()
+    L = pkg.lib()
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def timeit(fn, reps=50):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    for wl in ("1080p_80x24_truecolor", "4k_200x60_truecolor"):
+        sw, sh, W, H, cl, rm = bench.WORKLOADS[wl]
+        b = 256
+        frames_t = bench.make_frames(torch, b, sw, sh, 1234)
+        plan, mode = bench.build_plan(pkg, frames_t, W, H, cl, rm)
+        out = torch.empty(b * plan.stride, dtype=torch.uint8, device="cuda")
+        ln = torch.zeros(b, dtype=torch.int32, device="cuda")
+        plan.render(out.data_ptr(), plan.stride, ln.data_ptr(), stream)
+        torch.cuda.synchronize()
+        total = int(ln.cpu().numpy().astype("uint32").sum())
+        dims = torch.tensor([[W, H]] * b, dtype=torch.int32, device="cuda")
+        crc = torch.zeros(b, dtype=torch.int32, device="cuda")
+        hdr = torch.zeros(b * 24, dtype=torch.uint8, device="cuda")
+        pkt = torch.zeros(b, dtype=torch.int32, device="cuda")
+        ms = timeit(lambda: L.asciichat_hip_frame_packets(out.data_ptr(), plan.stride, ln.data_ptr(), plan.stride, b,
+                                                          dims.data_ptr(), crc.data_ptr(), hdr.data_ptr(), pkt.data_ptr(), stream))
+        ms_r = timeit(lambda: plan.render(out.data_ptr(), plan.stride, ln.data_ptr(), stream))
+        print(f"frame_packets {wl} b{b}: {ms*1e3:8.1f} us for {total/1e6:.2f} MB of frames -> {total/(ms*1e-3)/1e9:7.1f} GB/s "
+              f"(render alone {ms_r*1e3:.1f} us)")
+        plan.close()
+        del frames_t, out
+    for nb in (8, 64):
+        nbytes = 1920 * 1080 * 3
+        buf = torch.randint(0, 256, (nb * nbytes,), dtype=torch.uint8, device="cuda")
+        crc = torch.zeros(nb, dtype=torch.int32, device="cuda")
+        ms = timeit(lambda: L.asciichat_hip_crc32c(buf.data_ptr(), nbytes, None, nbytes, nbytes, nb, crc.data_ptr(), stream), 20)
+        print(f"crc32c {nb} x 1080p payload: {ms*1e3:8.1f} us -> {nb*nbytes/(ms*1e-3)/1e9:7.1f} GB/s = "
+              f"{nb*nbytes/(ms*1e-3)/8e12*100:4.1f} % of 8 TB/s")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--stream-passes":
         stream_passes()
+    elif len(sys.argv) > 1 and sys.argv[1] == "--wire-stage":
+        wire_stage()
     else:
         main()

@@ -18,7 +18,8 @@ _lib = None
 
 def build():
     srcs = [os.path.join(EMU_DIR, "emu_driver.cpp"), os.path.join(EMU_DIR, "hip_emu.h"),
-            os.path.join(CSRC, "render_kernels.hpp"), os.path.join(CSRC, "stream_kernels.hpp"), os.path.join(CSRC, "render_variants.h"),
+            os.path.join(CSRC, "render_kernels.hpp"), os.path.join(CSRC, "stream_kernels.hpp"), os.path.join(CSRC, "crc_kernels.hpp"),
+            os.path.join(CSRC, "render_variants.h"),
             os.path.join(INC, "achip_types.h"), os.path.join(CSRC, "achip_host.c"), os.path.join(INC, "achip_host.h")]
     if os.path.exists(EMU_SO) and all(os.path.getmtime(s) <= os.path.getmtime(EMU_SO) for s in srcs):
         return EMU_SO
@@ -46,6 +47,15 @@ def lib():
         _lib.emu_tint.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int]
         _lib.emu_flip.restype = None
         _lib.emu_flip.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_int]
+        _lib.emu_crc32c.restype = None
+        _lib.emu_crc32c.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.emu_crc_mulmod.restype = C.c_uint32
+        _lib.emu_crc_mulmod.argtypes = [C.c_uint32, C.c_uint32]
+        _lib.emu_crc_pow.restype = C.c_uint32
+        _lib.emu_crc_pow.argtypes = [C.c_uint32, C.c_uint64]
+        _lib.emu_crc_x8_pow2.restype = C.c_uint32
+        _lib.emu_crc_x8_pow2.argtypes = [C.c_int]
         _lib.emu_composite.restype = None
         _lib.emu_composite.argtypes = [C.POINTER(Composite), C.c_void_p]
     return _lib
@@ -107,3 +117,28 @@ def frame_identity(img):
     f = Frame()
     assert lib().achip_frame_identity(C.byref(f), img.ctypes.data, img.shape[1], img.shape[0]) == 0
     return f
+
+
+def crc32c_frames(frames, dims=None, stride=None, force=None, want_headers=True):
+    """frames: list of bytes.  Returns (crc[n], headers[n] (24 B each) or None, packet_crc[n] or None) from the
+    emulated wire-stage kernels.  force = (parts, rounds) overrides the launcher's span geometry."""
+    n = len(frames)
+    mx = max([len(f) for f in frames] + [1])
+    if stride is None:
+        stride = (mx + 15) & ~15
+    slab = np.full(n * stride + 16, 0xEE, dtype=np.uint8)  # garbage behind every frame must not matter
+    base = slab.ctypes.data + (-slab.ctypes.data % 16)
+    view = np.ctypeslib.as_array((C.c_uint8 * (n * stride)).from_address(base))
+    for i, f in enumerate(frames):
+        view[i * stride:i * stride + len(f)] = np.frombuffer(f, dtype=np.uint8)
+    ln = np.array([len(f) for f in frames], dtype=np.uint32)
+    crc = np.zeros(n, dtype=np.uint32)
+    hdr = np.zeros(n * 24, dtype=np.uint8)
+    pkt = np.zeros(n, dtype=np.uint32)
+    d = np.array(dims if dims is not None else [(0, 0)] * n, dtype=np.uint32).reshape(n, 2)
+    fp, fr = force if force else (0, 0)
+    lib().emu_crc32c(base, stride, ln.ctypes.data, 0, mx, n, fp, fr, d.ctypes.data if dims is not None else None,
+                     crc.ctypes.data, hdr.ctypes.data if want_headers else None, pkt.ctypes.data if want_headers else None)
+    if not want_headers:
+        return crc, None, None
+    return crc, [hdr[24 * i:24 * i + 24].tobytes() for i in range(n)], pkt

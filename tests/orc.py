@@ -44,6 +44,10 @@ def lib():
         vp, ci, cl, sz = C.c_void_p, C.c_int, C.c_long, C.c_size_t
         L.orc_fnv1a32.restype = C.c_uint32
         L.orc_fnv1a32.argtypes = [vp, sz]
+        L.orc_crc32c.restype = C.c_uint32
+        L.orc_crc32c.argtypes = [C.c_char_p, sz]
+        L.orc_ascii_frame_packet.restype = C.c_uint32
+        L.orc_ascii_frame_packet.argtypes = [C.c_char_p, sz, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint8 * 24)]
         for name in ("orc_print_mono", "orc_print_truecolor_fg", "orc_print_256_fg", "orc_print_16_fg",
                      "orc_print_truecolor_bg"):
             f = getattr(L, name)
@@ -122,6 +126,17 @@ def _img(a):
 
 def _pal(p):
     return p.encode("utf-8") if isinstance(p, str) else p
+
+
+def crc32c(b):
+    return lib().orc_crc32c(bytes(b), len(b))
+
+
+def ascii_frame_packet(frame, width, height):
+    """-> (24-byte header, CRC of header+frame) as acip_send_ascii_frame / packet_send_via_transport produce them."""
+    hdr = (C.c_uint8 * 24)()
+    crc = lib().orc_ascii_frame_packet(bytes(frame), len(frame), width, height, hdr)
+    return bytes(hdr), crc
 
 
 def fnv1a32(b):

@@ -174,6 +174,45 @@ def test_host_utilities_match_oracle(pkg):
     assert not L.ascii_create_grid(None, 1, 80, 24, C.byref(sz))
 
 
+def test_palette_cache_matches_oracle_and_is_shared(pkg):
+    """get_utf8_palette_cache (common.c:270-377): borrowed pointer, same tables as the oracle's L2/L3 restatement."""
+    L = C.CDLL(pkg.LIB_PATH)
+    OL = orc.lib()
+
+    class U8Char(C.Structure):
+        _fields_ = [("width", C.c_uint8), ("bytes", C.c_uint8 * 4), ("len", C.c_uint8), ("pad", C.c_uint8)]
+
+    class Cache(C.Structure):
+        _fields_ = [("cache", U8Char * 256), ("cache64", U8Char * 64), ("ramp", C.c_uint8 * 256)]
+
+    class OGlyph(C.Structure):
+        _fields_ = [("bytes", C.c_uint8 * 4), ("len", C.c_uint8)]
+
+    class OPal(C.Structure):
+        _fields_ = [("cache", OGlyph * 256), ("cache64", OGlyph * 64), ("ramp", C.c_uint8 * 64), ("count", C.c_int)]
+
+    L.get_utf8_palette_cache.restype = C.POINTER(Cache)
+    L.get_utf8_palette_cache.argtypes = [C.c_char_p]
+    OL.orc_palette_build.argtypes = [C.c_char_p, C.POINTER(OPal)]
+    seen = {}
+    for pal in (orc.PALETTE_STANDARD, orc.PALETTE_BLOCKS, orc.PALETTE_COOL, orc.PALETTE_DIGITAL, orc.PALETTE_MINIMAL, "ab"):
+        c = L.get_utf8_palette_cache(pal.encode())
+        assert c, pal
+        o = OPal()
+        OL.orc_palette_build(pal.encode(), C.byref(o))
+        for i in range(256):
+            g, e = c.contents.cache[i], o.cache[i]
+            assert g.len == e.len and bytes(g.bytes)[:g.len] == bytes(e.bytes)[:e.len], (pal, i)
+        for i in range(64):
+            g, e = c.contents.cache64[i], o.cache64[i]
+            assert g.len == e.len and bytes(g.bytes)[:g.len] == bytes(e.bytes)[:e.len], (pal, i)
+            assert c.contents.ramp[i] == o.ramp[i]
+        seen[pal] = C.addressof(c.contents)
+        assert C.addressof(L.get_utf8_palette_cache(pal.encode()).contents) == seen[pal]  # cached, not rebuilt
+    assert len(set(seen.values())) == len(seen)
+    assert not L.get_utf8_palette_cache(None) and not L.get_utf8_palette_cache(b"")
+
+
 def test_composite_geometry_and_kernel_emulated(pkg):
     """achip_composite_setup + the composite/fused sampler (run under the emulator) vs the oracle's C1+C2."""
     EL = emu.lib()

@@ -312,3 +312,56 @@ def test_grid9_tile_exchange_path_single_rank(gpu):
     for (cl, rm, pad), g in zip(targets, got):
         h = 96 if rm == 2 else 48
         assert g == orc.convert_with_caps(canvas, 160, h, cl, rm, pad, True, False), (cl, rm, pad)
+
+
+# ------------------------------------------------------------------------------------------------
+# wire stage: CRC-32C + ascii_frame_packet_t headers of a rendered slab
+# ------------------------------------------------------------------------------------------------
+def test_wire_stage_crc_and_headers(gpu):
+    pkg, torch = gpu
+    L = pkg.lib()
+    stream = torch.cuda.current_stream().cuda_stream
+    imgs = [TORTURE] + [orc.frame_hash_noise(320, 240, 3 + k) for k in range(6)]
+    dims = [(80, 24), (60, 7), (33, 40), (80, 1), (200, 60), (97, 31), (1, 1)]
+    for mode in (1, 2, 0, 5):
+        rm = MODE_CAPS[mode][1]
+        dev = [torch.from_numpy(np.ascontiguousarray(i)).cuda() for i in imgs]
+        frames = [pkg.frame_setup(d.data_ptr(), i.shape[1], i.shape[0], w, h, rm) for i, d, (w, h) in zip(imgs, dev, dims)]
+        plan = pkg.Plan(mode, orc.PALETTE_STANDARD, frames)
+        n = len(imgs)
+        out = torch.full((n * plan.stride,), 0xEE, dtype=torch.uint8, device="cuda")
+        ln = torch.zeros(n, dtype=torch.int32, device="cuda")
+        plan.render(out.data_ptr(), plan.stride, ln.data_ptr(), stream)
+        d32 = torch.tensor(dims, dtype=torch.int32, device="cuda")
+        crc = torch.zeros(n, dtype=torch.int32, device="cuda")
+        hdr = torch.zeros(n * 24, dtype=torch.uint8, device="cuda")
+        pkt = torch.zeros(n, dtype=torch.int32, device="cuda")
+        rc = L.asciichat_hip_frame_packets(out.data_ptr(), plan.stride, ln.data_ptr(), plan.stride, n, d32.data_ptr(),
+                                           crc.data_ptr(), hdr.data_ptr(), pkt.data_ptr(), stream)
+        assert rc == 0, pkg.last_error()
+        torch.cuda.synchronize()
+        host, lens = out.cpu().numpy(), ln.cpu().numpy().astype(np.uint32)
+        crc_h, pkt_h, hdr_h = crc.cpu().numpy().astype(np.uint32), pkt.cpu().numpy().astype(np.uint32), hdr.cpu().numpy()
+        for k in range(n):
+            fr = host[k * plan.stride:k * plan.stride + int(lens[k])].tobytes()
+            assert fr == oracle_convert(imgs[k], mode, dims[k][0], dims[k][1], orc.PALETTE_STANDARD), (mode, k)
+            eh, ep = orc.ascii_frame_packet(fr, *dims[k])
+            assert int(crc_h[k]) == orc.crc32c(fr), (mode, k)
+            assert hdr_h[24 * k:24 * k + 24].tobytes() == eh and int(pkt_h[k]) == ep, (mode, k)
+        plan.close()
+    # large fixed-length buffers (ingest payloads): multi-span path, incl. a length that is not a multiple of 16
+    g = torch.Generator(device="cuda")
+    g.manual_seed(7)
+    for nbytes, nb in ((1920 * 1080 * 3, 3), (131073, 2), (640 * 480 * 3 + 5, 2)):
+        stride = (nbytes + 15) & ~15
+        buf = torch.randint(0, 256, (nb * stride,), dtype=torch.uint8, device="cuda", generator=g)
+        crc = torch.zeros(nb, dtype=torch.int32, device="cuda")
+        rc = L.asciichat_hip_crc32c(buf.data_ptr(), stride, None, nbytes, nbytes, nb, crc.data_ptr(), stream)
+        assert rc == 0, pkg.last_error()
+        torch.cuda.synchronize()
+        hb = buf.cpu().numpy()
+        for k in range(nb):
+            assert int(crc.cpu().numpy().astype(np.uint32)[k]) == orc.crc32c(hb[k * stride:k * stride + nbytes].tobytes())
+    # bad arguments are refused on the host
+    assert L.asciichat_hip_crc32c(buf.data_ptr() + 4, stride, None, 16, 16, 1, crc.data_ptr(), stream) != 0
+    assert L.asciichat_hip_crc32c(None, stride, None, 16, 16, 1, crc.data_ptr(), stream) != 0
