@@ -134,16 +134,17 @@ extern "C" int achip_launch_crc32c(const uint8_t *base, uint64_t stride, const u
                                    uint32_t *crc_out, uint8_t *hdr_out, uint32_t *pkt_crc_out, void *stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int parts = achip_crc_parts(max_len);
-  const int rounds = parts == 1 ? (int)((max_len + 4095u) / 4096u > 0 ? (max_len + 4095u) / 4096u : 1u) : 16;
-  const uint64_t v_bytes = (uint64_t)parts * (uint64_t)rounds * 4096u;
-  const uint32_t xinv_v = achip::crc_pow(achip::CRC_XINV8, v_bytes);
-  hipLaunchKernelGGL(achip::crc32c_frames_kernel, dim3((unsigned)n * (unsigned)parts), dim3(achip::CRC_BLOCK),
-                     (size_t)achip::CrcLds::bytes, s, base, stride, len_dev, fixed_len, n, parts, rounds, xinv_v,
-                     parts == 1 ? crc_out : partial, dims_dev, crc_out, hdr_out, pkt_crc_out);
-  if (parts > 1) {
-    const uint32_t cspan = achip::crc_pow(achip::CRC_X8, (uint64_t)rounds * 4096u);
-    hipLaunchKernelGGL(achip::crc32c_finish_kernel, dim3((unsigned)n), dim3(64), 256, s, partial, parts, cspan, xinv_v,
-                       len_dev, fixed_len, n, dims_dev, crc_out, hdr_out, pkt_crc_out);
+  if (parts == 1) { /* 1024 threads per frame; every workgroup runs only the rounds its own frame needs */
+    hipLaunchKernelGGL(achip::crc32c_frame_kernel<1024>, dim3((unsigned)n), dim3(1024), (size_t)achip::CrcLds::bytes, s,
+                       base, stride, len_dev, fixed_len, n, dims_dev, crc_out, hdr_out, pkt_crc_out);
+    return (int)hipGetLastError();
   }
+  const int rounds = 16; /* 64 KB spans of 256-thread workgroups */
+  const uint64_t v_bytes = (uint64_t)parts * (uint64_t)rounds * 4096u;
+  hipLaunchKernelGGL(achip::crc32c_span_kernel, dim3((unsigned)n * (unsigned)parts), dim3(256),
+                     (size_t)achip::CrcLds::bytes, s, base, stride, len_dev, fixed_len, n, parts, rounds, partial);
+  hipLaunchKernelGGL(achip::crc32c_finish_kernel, dim3((unsigned)n), dim3(64), 256, s, partial, parts,
+                     achip::crc_pow(achip::CRC_X8, (uint64_t)rounds * 4096u), achip::crc_pow(achip::CRC_XINV8, v_bytes),
+                     len_dev, fixed_len, n, dims_dev, crc_out, hdr_out, pkt_crc_out);
   return (int)hipGetLastError();
 }

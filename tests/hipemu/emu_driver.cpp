@@ -90,30 +90,32 @@ extern "C" void emu_flip(const uint8_t *src, uint8_t *dst, int w, int h, uint32_
 
 #include "crc_kernels.hpp"
 
-/* the launcher's geometry (hip_launch.hip: achip_launch_crc32c) restated for the emulator; force_parts > 0
- * overrides it so that small buffers exercise the multi-span path */
+/* the launcher's geometry (hip_launch.hip: achip_launch_crc32c) restated for the emulator; force_parts > 1
+ * sends small buffers through the multi-span path with spans of force_rounds * 4 KB */
 extern "C" void emu_crc32c(const uint8_t *base, uint64_t stride, const uint32_t *len, uint32_t fixed_len, uint32_t max_len,
                            int n, int force_parts, int force_rounds, const uint32_t *dims, uint32_t *crc_out,
                            uint8_t *hdr_out, uint32_t *pkt_out) {
   int parts = max_len <= 32u * 4096u ? 1 : (int)(((uint64_t)max_len + 65535u) / 65536u);
-  int rounds = parts == 1 ? (int)std::max<uint32_t>(1u, (max_len + 4095u) / 4096u) : 16;
+  int rounds = 16;
   if (force_parts > 0) {
     parts = force_parts;
     rounds = force_rounds;
   }
-  const uint64_t v_bytes = (uint64_t)parts * rounds * 4096u;
-  const uint32_t xinv_v = achip::crc_pow(achip::CRC_XINV8, v_bytes);
-  std::vector<uint32_t> partial((size_t)n * parts);
-  hipemu::launch(dim3((unsigned)(n * parts)), dim3(achip::CRC_BLOCK), achip::CrcLds::bytes, [&] {
-    achip::crc32c_frames_kernel(base, stride, len, fixed_len, n, parts, rounds, xinv_v,
-                                parts == 1 ? crc_out : partial.data(), dims, crc_out, hdr_out, pkt_out);
-  });
-  if (parts > 1) {
-    const uint32_t cspan = achip::crc_pow(achip::CRC_X8, (uint64_t)rounds * 4096u);
-    hipemu::launch(dim3((unsigned)n), dim3(64), 256, [&] {
-      achip::crc32c_finish_kernel(partial.data(), parts, cspan, xinv_v, len, fixed_len, n, dims, crc_out, hdr_out, pkt_out);
+  if (parts == 1) {
+    hipemu::launch(dim3((unsigned)n), dim3(1024), achip::CrcLds::bytes, [&] {
+      achip::crc32c_frame_kernel<1024>(base, stride, len, fixed_len, n, dims, crc_out, hdr_out, pkt_out);
     });
+    return;
   }
+  const uint64_t v_bytes = (uint64_t)parts * rounds * 4096u;
+  std::vector<uint32_t> partial((size_t)n * parts);
+  hipemu::launch(dim3((unsigned)(n * parts)), dim3(256), achip::CrcLds::bytes, [&] {
+    achip::crc32c_span_kernel(base, stride, len, fixed_len, n, parts, rounds, partial.data());
+  });
+  hipemu::launch(dim3((unsigned)n), dim3(64), 256, [&] {
+    achip::crc32c_finish_kernel(partial.data(), parts, achip::crc_pow(achip::CRC_X8, (uint64_t)rounds * 4096u),
+                                achip::crc_pow(achip::CRC_XINV8, v_bytes), len, fixed_len, n, dims, crc_out, hdr_out, pkt_out);
+  });
 }
 
 extern "C" uint32_t emu_crc_mulmod(uint32_t a, uint32_t b) { return achip::crc_mulmod(a, b); }
