@@ -90,6 +90,15 @@ def lib():
     L.asciichat_hip_plan_set_split.argtypes = [vp, ci]
     L.asciichat_hip_plan_get_parts.restype = ci
     L.asciichat_hip_plan_get_parts.argtypes = [vp]
+    L.asciichat_hip_frame_table_create.restype = ci
+    L.asciichat_hip_frame_table_create.argtypes = [C.POINTER(vp), ci]
+    L.asciichat_hip_frame_table_destroy.restype = None
+    L.asciichat_hip_frame_table_destroy.argtypes = [vp]
+    L.asciichat_hip_frame_table_publish.restype = ci
+    L.asciichat_hip_frame_table_publish.argtypes = [vp, ci, C.c_char_p, C.c_size_t, vp]
+    L.asciichat_hip_frame_table_latest.restype = ci
+    L.asciichat_hip_frame_table_latest.argtypes = [vp, ci, vp, C.POINTER(vp), C.POINTER(ci), C.POINTER(ci),
+                                                   C.POINTER(C.c_uint64)]
     L.asciichat_hip_crc32c.restype = ci
     L.asciichat_hip_crc32c.argtypes = [vp, C.c_size_t, vp, C.c_uint32, C.c_uint32, ci, vp, vp]
     L.asciichat_hip_frame_packets.restype = ci
@@ -273,6 +282,39 @@ class Plan:
     def close(self):
         if self._h:
             lib().asciichat_hip_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class FrameTable:
+    """Device-resident latest-frame table (asciichat_hip_frame_table_*)."""
+
+    def __init__(self, n_slots):
+        self._h = C.c_void_p()
+        if lib().asciichat_hip_frame_table_create(C.byref(self._h), n_slots) != 0:
+            raise RuntimeError(f"frame_table_create failed: {last_error()}")
+
+    def publish(self, slot, blob, stream=0):
+        rc = lib().asciichat_hip_frame_table_publish(self._h, slot, bytes(blob), len(blob), stream)
+        if rc != 0:
+            raise RuntimeError(f"frame_table_publish failed: {last_error()}")
+
+    def latest(self, slot, stream=0):
+        """-> (device pointer or None, width, height, generation)"""
+        p, w, h, g = C.c_void_p(), C.c_int(), C.c_int(), C.c_uint64()
+        rc = lib().asciichat_hip_frame_table_latest(self._h, slot, stream, C.byref(p), C.byref(w), C.byref(h), C.byref(g))
+        if rc != 0:
+            raise RuntimeError(f"frame_table_latest failed: {last_error()}")
+        return p.value, w.value, h.value, g.value
+
+    def close(self):
+        if self._h:
+            lib().asciichat_hip_frame_table_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

@@ -316,6 +316,29 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
   return 0;
 }
 
+int achip_frame_blob_parse(const void *blob, size_t size, bool exact, uint32_t *width, uint32_t *height,
+                           const uint8_t **pixels) {
+  const uint8_t *b = (const uint8_t *)blob;
+  if (!b || size < 8u + 3u) /* stream.c:330: a header and at least one pixel */
+    return ACHIP_BLOB_SHORT;
+  const uint32_t w = ((uint32_t)b[0] << 24) | ((uint32_t)b[1] << 16) | ((uint32_t)b[2] << 8) | b[3]; /* NET_TO_HOST_U32 */
+  const uint32_t h = ((uint32_t)b[4] << 24) | ((uint32_t)b[5] << 16) | ((uint32_t)b[6] << 8) | b[7];
+  /* stream.c:334 (0 < w <= 4096, 0 < h <= 2160) and image_validate_dimensions (lib/util/image.c:100-113:
+   * <= IMAGE_MAX_WIDTH x IMAGE_MAX_HEIGHT = 3840 x 2160), which is the tighter of the two */
+  if (w == 0u || h == 0u || w > 4096u || h > 2160u || w > 3840u)
+    return ACHIP_BLOB_DIMS;
+  const size_t expect = 8u + (size_t)w * (size_t)h * 3u; /* image_calc_rgb_size cannot overflow at these sizes */
+  if (exact ? size != expect : size < expect) /* protocol.c:812 receive check / stream.c:363 collect check */
+    return ACHIP_BLOB_SIZE;
+  if (width)
+    *width = w;
+  if (height)
+    *height = h;
+  if (pixels)
+    *pixels = b + 8;
+  return 0;
+}
+
 void achip_grid_layout(const int *src_w, const int *src_h, int n, int term_w, int term_h, int *cols, int *rows) {
   if (n <= 0) {
     *cols = 0;

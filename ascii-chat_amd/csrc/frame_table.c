@@ -1,0 +1,170 @@
+/*
+ * frame_table.c -- ingest side of the path: a device-resident table of every client's
+ * latest camera frame.
+ *
+ * The reference keeps the latest frame of a client as a host blob [u32 BE width][u32 BE height][RGB24]
+ * (video_frame_get_latest), and EVERY render thread copies EVERY client's blob twice per tick
+ * (collect_video_sources, src/server/stream.c:221-463: SAFE_MALLOC + memcpy, then image_new_from_pool +
+ * memcpy) -- 2*N^2 full-frame host copies per tick for N clients.  Here the receive path publishes a blob
+ * once: it is validated exactly as collect_video_sources validates it, sent to HBM with one DMA, and every
+ * render descriptor of the tick points at the same device frame.  Slots are double-buffered: a publish never
+ * writes the frame that the renders already queued may still be reading.
+ */
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "achip_host.h"
+#include "asciichat_hip.h"
+#include "internal.h"
+
+typedef struct {
+  uint8_t *dev[2];      /* frame buffers in HBM                                       */
+  size_t cap[2];        /* bytes allocated                                            */
+  hipEvent_t ready[2];  /* recorded after the upload of buffer k                      */
+  uint8_t *stage[2];    /* pinned staging for blobs that are not in the pinned pool   */
+  size_t stage_cap[2];
+  int cur;              /* buffer holding the latest complete frame, -1 = none yet    */
+  int w, h;
+  uint64_t generation;
+} ft_slot_t;
+
+struct asciichat_hip_frame_table {
+  int n;
+  pthread_mutex_t mu;
+  ft_slot_t *slot;
+};
+
+int asciichat_hip_frame_table_create(asciichat_hip_frame_table_t **table, int n_slots) {
+  if (!table || n_slots <= 0)
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame_table_create: bad arguments");
+  *table = NULL;
+  int rc = achip_require_device();
+  if (rc)
+    return rc;
+  asciichat_hip_frame_table_t *t = (asciichat_hip_frame_table_t *)calloc(1, sizeof(*t));
+  if (t)
+    t->slot = (ft_slot_t *)calloc((size_t)n_slots, sizeof(ft_slot_t));
+  if (!t || !t->slot) {
+    free(t);
+    return achip_fail(ASCIICHAT_HIP_ERR_MEMORY, "out of memory");
+  }
+  t->n = n_slots;
+  pthread_mutex_init(&t->mu, NULL);
+  for (int i = 0; i < n_slots; i++)
+    t->slot[i].cur = -1;
+  *table = t;
+  return 0;
+}
+
+void asciichat_hip_frame_table_destroy(asciichat_hip_frame_table_t *t) {
+  if (!t)
+    return;
+  for (int i = 0; i < t->n; i++)
+    for (int k = 0; k < 2; k++) {
+      ft_slot_t *s = &t->slot[i];
+      if (s->ready[k]) {
+        (void)hipEventSynchronize(s->ready[k]);
+        (void)hipEventDestroy(s->ready[k]);
+      }
+      if (s->dev[k])
+        (void)hipFree(s->dev[k]);
+      if (s->stage[k])
+        (void)hipHostFree(s->stage[k]);
+    }
+  pthread_mutex_destroy(&t->mu);
+  free(t->slot);
+  free(t);
+}
+
+int asciichat_hip_frame_table_publish(asciichat_hip_frame_table_t *t, int slot, const void *blob, size_t blob_size,
+                                      void *stream) {
+  if (!t || slot < 0 || slot >= t->n || !blob)
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame_table_publish: bad arguments");
+  uint32_t w = 0, h = 0;
+  const uint8_t *pixels = NULL;
+  const int pr = achip_frame_blob_parse(blob, blob_size, false, &w, &h, &pixels);
+  if (pr != 0) /* the conditions under which collect_video_sources skips the client's frame */
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame blob rejected (%s)",
+                      pr == ACHIP_BLOB_SHORT ? "shorter than a header and one pixel"
+                                             : (pr == ACHIP_BLOB_DIMS ? "dimensions out of range" : "size below 8 + 3*w*h"));
+  const size_t bytes = (size_t)w * (size_t)h * 3u;
+  pthread_mutex_lock(&t->mu);
+  ft_slot_t *s = &t->slot[slot];
+  const int k = s->cur == 0 ? 1 : 0; /* the buffer no reader of the current generation uses */
+  int rc = 0;
+  if (s->ready[k]) /* renders queued two publishes ago may still read this buffer: order behind them */
+    rc = achip_hip_check((int)hipEventSynchronize(s->ready[k]), "hipEventSynchronize(frame buffer)");
+  if (!rc && s->cap[k] < bytes) {
+    if (s->dev[k])
+      (void)hipFree(s->dev[k]);
+    s->dev[k] = NULL;
+    s->cap[k] = 0;
+    rc = achip_hip_check((int)hipMalloc((void **)&s->dev[k], bytes), "hipMalloc(frame)");
+    if (!rc)
+      s->cap[k] = bytes;
+  }
+  if (!rc && !s->ready[k])
+    rc = achip_hip_check((int)hipEventCreateWithFlags(&s->ready[k], hipEventDisableTiming), "hipEventCreate");
+  const void *src = pixels;
+  if (!rc && !achip_pool_device_ptr(pixels)) { /* pageable blob: one copy into pinned staging, then DMA */
+    if (s->stage_cap[k] < bytes) {
+      if (s->stage[k])
+        (void)hipHostFree(s->stage[k]);
+      s->stage[k] = NULL;
+      s->stage_cap[k] = 0;
+      rc = achip_hip_check((int)hipHostMalloc((void **)&s->stage[k], bytes, hipHostMallocDefault), "hipHostMalloc(stage)");
+      if (!rc)
+        s->stage_cap[k] = bytes;
+    }
+    if (!rc) {
+      memcpy(s->stage[k], pixels, bytes);
+      src = s->stage[k];
+    }
+  }
+  if (!rc)
+    rc = achip_hip_check((int)hipMemcpyAsync(s->dev[k], src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream),
+                         "hipMemcpyAsync(frame)");
+  if (!rc)
+    rc = achip_hip_check((int)hipEventRecord(s->ready[k], (hipStream_t)stream), "hipEventRecord");
+  if (!rc) {
+    s->cur = k;
+    s->w = (int)w;
+    s->h = (int)h;
+    s->generation++;
+  }
+  pthread_mutex_unlock(&t->mu);
+  return rc;
+}
+
+int asciichat_hip_frame_table_latest(asciichat_hip_frame_table_t *t, int slot, void *consumer_stream,
+                                     const uint8_t **pixels_dev, int *width, int *height, uint64_t *generation) {
+  if (!t || slot < 0 || slot >= t->n || !pixels_dev)
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame_table_latest: bad arguments");
+  pthread_mutex_lock(&t->mu);
+  ft_slot_t *s = &t->slot[slot];
+  int rc = 0;
+  if (s->cur < 0) {
+    *pixels_dev = NULL; /* has_video = false (stream.c:272-274) */
+    if (width)
+      *width = 0;
+    if (height)
+      *height = 0;
+    if (generation)
+      *generation = 0;
+  } else {
+    /* work queued on consumer_stream after this call sees the complete upload */
+    rc = achip_hip_check((int)hipStreamWaitEvent((hipStream_t)consumer_stream, s->ready[s->cur], 0), "hipStreamWaitEvent");
+    *pixels_dev = s->dev[s->cur];
+    if (width)
+      *width = s->w;
+    if (height)
+      *height = s->h;
+    if (generation)
+      *generation = s->generation;
+  }
+  pthread_mutex_unlock(&t->mu);
+  return rc;
+}

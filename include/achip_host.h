@@ -50,6 +50,17 @@ uint32_t achip_nn_ratio(int src, int dst);
 /* Upper bound (bytes, excluding the NUL) of one rendered frame; multiple of 16 when rounded by the caller. */
 size_t achip_out_bound(int mode, const achip_frame_t *f);
 
+/* The in-memory camera frame blob [u32 BE width][u32 BE height][RGB24 pixels] that the server keeps per client
+ * (video_frame_get_latest).  Validates it as the reference does -- exact = false: collect_video_sources
+ * (src/server/stream.c:330-372: size >= 8 + 3wh, extra bytes ignored); exact = true: the IMAGE_FRAME receive
+ * handler (src/server/protocol.c:784-815: size == 8 + 3wh) -- with dimensions in 1..3840 x 1..2160
+ * (image_validate_dimensions, lib/util/image.c:100-113).  Returns 0 and the parsed fields, or ACHIP_BLOB_*. */
+#define ACHIP_BLOB_SHORT (-1) /* shorter than a header and one pixel        */
+#define ACHIP_BLOB_DIMS (-2)  /* zero or oversized dimensions               */
+#define ACHIP_BLOB_SIZE (-3)  /* byte count does not match the dimensions   */
+int achip_frame_blob_parse(const void *blob, size_t size, bool exact, uint32_t *width, uint32_t *height,
+                           const uint8_t **pixels);
+
 /* Launch geometry for a batch.  A batch with fewer frames than the GPU has CUs leaves most of it idle when one
  * workgroup renders a whole frame, so such frames are cut into `parts` bands of text rows rendered by separate
  * workgroups (each band exactly one chunk of its geometry; the bands learn their output offset from each other

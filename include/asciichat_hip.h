@@ -113,6 +113,26 @@ int asciichat_hip_image_flip(const uint8_t *src_dev, uint8_t *dst_dev, int width
                              void *stream);
 
 /*
+ * Ingest: a device-resident table of every client's latest camera frame, replacing the two
+ * full-frame host copies that each render thread makes of each client's frame per tick
+ * (collect_video_sources, src/server/stream.c:221-463).
+ *   publish   validates the blob [u32 BE width][u32 BE height][RGB24] like collect_video_sources does
+ *             (achip_frame_blob_parse, exact = false) and uploads it on `stream`.  A blob inside the pinned
+ *             buffer pool is DMA'd in place and must stay valid until `stream` has passed the copy; any other
+ *             blob is copied to pinned staging first and may be released when publish returns.
+ *   latest    device pointer + size of the newest published frame of a slot (NULL / 0 while the client has
+ *             sent none: has_video = false) and makes consumer_stream wait for its upload.  The frame stays
+ *             intact until the publish after next on that slot.
+ */
+typedef struct asciichat_hip_frame_table asciichat_hip_frame_table_t;
+int asciichat_hip_frame_table_create(asciichat_hip_frame_table_t **table, int n_slots);
+void asciichat_hip_frame_table_destroy(asciichat_hip_frame_table_t *table);
+int asciichat_hip_frame_table_publish(asciichat_hip_frame_table_t *table, int slot, const void *blob, size_t blob_size,
+                                      void *stream);
+int asciichat_hip_frame_table_latest(asciichat_hip_frame_table_t *table, int slot, void *consumer_stream,
+                                     const uint8_t **pixels_dev, int *width, int *height, uint64_t *generation);
+
+/*
  * Wire stage after render, on DEVICE buffers, for the frames of a slab (frame i at
  * base_dev + i*stride, len_dev[i] bytes; or fixed_len bytes each when len_dev == NULL; max_len bounds every
  * length -- pass the slab stride for a plan's output):

@@ -1166,3 +1166,29 @@ uint32_t orc_ascii_frame_packet(const void *frame, size_t n, uint32_t width, uin
   uint32_t c = crc32c_update(0xFFFFFFFFu, hdr, 24); /* the payload send.c checksums is header followed by frame */
   return ~crc32c_update(c, (const uint8_t *)frame, n);
 }
+
+/* ------------------------------------------------------------------------------------------- */
+/* ingest: the camera frame blob                                                                 */
+/* ------------------------------------------------------------------------------------------- */
+int orc_frame_blob_accept(const void *blob, size_t size, int exact, uint32_t *w, uint32_t *h) {
+  const uint8_t *p = (const uint8_t *)blob;
+  if (!exact && !(size > 0 && size >= 4 * 2 + 3)) /* stream.c:330 */
+    return 0;
+  if (exact && size < 8) /* protocol.c reads the two header words first */
+    return 0;
+  const uint32_t pw = ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3];
+  const uint32_t ph = ((uint32_t)p[4] << 24) | ((uint32_t)p[5] << 16) | ((uint32_t)p[6] << 8) | p[7];
+  if (!exact && (pw == 0 || ph == 0 || pw > 4096 || ph > 2160)) /* stream.c:334 */
+    return 0;
+  if (pw == 0 || ph == 0 || pw > 3840 || ph > 2160) /* image_validate_dimensions, lib/util/image.c:100-113 */
+    return 0;
+  const size_t rgb = (size_t)pw * (size_t)ph * 3; /* image_calc_rgb_size */
+  if (exact && rgb > (size_t)3840 * 2160 * 3)     /* image_validate_buffer_size, protocol.c:804 */
+    return 0;
+  const size_t expect = 8 + rgb;
+  if (exact ? size != expect : size < expect) /* protocol.c:812 / stream.c:363 */
+    return 0;
+  *w = pw;
+  *h = ph;
+  return 1;
+}

@@ -104,6 +104,12 @@ char *orc_display_convert(const uint8_t *rgb, int src_w, int src_h, long width, 
                           int render_mode, bool wants_padding, bool use_aspect, bool stretch, const char *palette,
                           bool flip_x, bool flip_y, int color_filter, size_t *len);
 
+/* ---- ingest ---------------------------------------------------------------- */
+/* the frame-blob checks of collect_video_sources (src/server/stream.c:330-372; exact = 0) and of the IMAGE_FRAME
+ * receive handler (src/server/protocol.c:784-815; exact = 1).  Returns 1 when the reference accepts the blob
+ * (and its dimensions), 0 when it skips / rejects it. */
+int orc_frame_blob_accept(const void *blob, size_t size, int exact, uint32_t *w, uint32_t *h);
+
 /* ---- wire stage after render ------------------------------------------------ */
 /* asciichat_crc32_sw, lib/network/crc32.c:171-189: CRC-32C (Castagnoli), bit by bit */
 uint32_t orc_crc32c(const void *data, size_t n);

@@ -64,6 +64,9 @@ def bind_host(L):
                                         C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.achip_palette_ascii_only.restype = C.c_bool
     L.achip_palette_ascii_only.argtypes = [C.c_char_p]
+    L.achip_frame_blob_parse.restype = C.c_int
+    L.achip_frame_blob_parse.argtypes = [C.c_char_p, C.c_size_t, C.c_bool, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                         C.POINTER(C.c_void_p)]
     L.achip_grid_layout.restype = None
     L.achip_grid_layout.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int,
                                     C.POINTER(C.c_int), C.POINTER(C.c_int)]

@@ -44,6 +44,8 @@ def lib():
         vp, ci, cl, sz = C.c_void_p, C.c_int, C.c_long, C.c_size_t
         L.orc_fnv1a32.restype = C.c_uint32
         L.orc_fnv1a32.argtypes = [vp, sz]
+        L.orc_frame_blob_accept.restype = C.c_int
+        L.orc_frame_blob_accept.argtypes = [C.c_char_p, sz, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.orc_crc32c.restype = C.c_uint32
         L.orc_crc32c.argtypes = [C.c_char_p, sz]
         L.orc_ascii_frame_packet.restype = C.c_uint32
@@ -126,6 +128,13 @@ def _img(a):
 
 def _pal(p):
     return p.encode("utf-8") if isinstance(p, str) else p
+
+
+def frame_blob_accept(blob, exact=False):
+    """-> (w, h) when the reference accepts the camera frame blob, else None."""
+    w, h = C.c_uint32(), C.c_uint32()
+    ok = lib().orc_frame_blob_accept(bytes(blob), len(blob), int(exact), C.byref(w), C.byref(h))
+    return (w.value, h.value) if ok else None
 
 
 def crc32c(b):

@@ -213,6 +213,33 @@ def test_palette_cache_matches_oracle_and_is_shared(pkg):
     assert not L.get_utf8_palette_cache(None) and not L.get_utf8_palette_cache(b"")
 
 
+def test_frame_blob_validation_matches_reference_rules(pkg):
+    """achip_frame_blob_parse vs the oracle's restatement of stream.c:330-372 / protocol.c:784-815."""
+    import struct
+    L = emu.lib()
+
+    def parse(blob, exact):
+        w, h, px = C.c_uint32(), C.c_uint32(), C.c_void_p()
+        rc = L.achip_frame_blob_parse(blob, len(blob), exact, C.byref(w), C.byref(h), C.byref(px))
+        return (rc, (w.value, h.value) if rc == 0 else None)
+
+    def blob(w, h, extra=0):
+        n = max(0, w * h * 3 + extra) if 0 < w <= 4096 and 0 < h <= 4096 else max(0, 3 + extra)
+        return struct.pack(">II", w & 0xFFFFFFFF, h & 0xFFFFFFFF) + bytes(n)
+
+    cases = [blob(4, 3), blob(4, 3, 5), blob(4, 3, -1), blob(1, 1), blob(1, 1, -1), blob(0, 5), blob(5, 0), blob(3840, 1),
+             blob(3841, 1), blob(4096, 1), blob(4097, 1), blob(1, 2160), blob(1, 2161), blob(640, 480), blob(640, 480, 1),
+             b"", b"\0" * 7, b"\0" * 10, struct.pack(">II", 0xBEBEBEBE, 0xBEBEBEBE) + bytes(16),
+             struct.pack(">II", 0xFFFFFFFF, 0xFFFFFFFF) + bytes(16)]
+    for b in cases:
+        for exact in (False, True):
+            rc, dims = parse(b, exact)
+            want = orc.frame_blob_accept(b, exact) if len(b) >= 8 else None
+            assert dims == want, (len(b), b[:8], exact, rc)
+            assert (rc == 0) == (want is not None)
+    assert parse(b"\0" * 10, False)[0] == -1 and parse(blob(0, 5), False)[0] == -2 and parse(blob(4, 3, -1), False)[0] == -3
+
+
 def test_composite_geometry_and_kernel_emulated(pkg):
     """achip_composite_setup + the composite/fused sampler (run under the emulator) vs the oracle's C1+C2."""
     EL = emu.lib()

@@ -72,6 +72,20 @@ def render_batch(gpu, mode, imgs, W, H, palette=orc.PALETTE_STANDARD, wants_padd
     return res
 
 
+def render_descs(gpu, mode, frames, palette=orc.PALETTE_STANDARD):
+    """Render ready-made descriptors (device sources) through a plan -> list of bytes."""
+    pkg, torch = gpu
+    plan = pkg.Plan(mode, palette, frames)
+    n = len(frames)
+    out = torch.zeros(n * plan.stride, dtype=torch.uint8, device="cuda")
+    ln = torch.zeros(n, dtype=torch.int32, device="cuda")
+    plan.render(out.data_ptr(), plan.stride, ln.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    host, lens = out.cpu().numpy(), ln.cpu().numpy().astype(np.uint32)
+    plan.close()
+    return [host[k * plan.stride:k * plan.stride + int(lens[k])].tobytes() for k in range(n)]
+
+
 TORTURE = orc.frame_torture()
 
 
@@ -365,3 +379,58 @@ def test_wire_stage_crc_and_headers(gpu):
     # bad arguments are refused on the host
     assert L.asciichat_hip_crc32c(buf.data_ptr() + 4, stride, None, 16, 16, 1, crc.data_ptr(), stream) != 0
     assert L.asciichat_hip_crc32c(None, stride, None, 16, 16, 1, crc.data_ptr(), stream) != 0
+
+
+# ------------------------------------------------------------------------------------------------
+# ingest: device-resident latest-frame table
+# ------------------------------------------------------------------------------------------------
+def test_frame_table_ingest(gpu):
+    import struct
+    pkg, torch = gpu
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def blob_of(img, extra=b""):
+        return struct.pack(">II", img.shape[1], img.shape[0]) + np.ascontiguousarray(img).tobytes() + extra
+
+    table = pkg.FrameTable(3)
+    assert table.latest(0, stream)[0] is None  # no frame yet: has_video = false
+    imgs = [TORTURE, orc.frame_hash_noise(640, 480, 5), orc.frame_bars(320, 200, 2)]
+    for s_, im in enumerate(imgs):
+        table.publish(s_, blob_of(im, b"trailing bytes are ignored" if s_ == 1 else b""), stream)
+    # every "render thread" describes the same device frames -- no per-thread copies
+    for mode in (1, 2, 5):
+        rm = MODE_CAPS[mode][1]
+        frames = []
+        for s_, im in enumerate(imgs):
+            ptr, w, h, gen = table.latest(s_, stream)
+            assert (w, h, gen) == (im.shape[1], im.shape[0], 1) and ptr
+            frames.append(pkg.frame_setup(ptr, w, h, 80, 24, rm))
+        plan = pkg.Plan(mode, orc.PALETTE_STANDARD, frames * 4)  # 4 target clients looking at the same 3 sources
+        n = len(frames) * 4
+        out = torch.zeros(n * plan.stride, dtype=torch.uint8, device="cuda")
+        ln = torch.zeros(n, dtype=torch.int32, device="cuda")
+        plan.render(out.data_ptr(), plan.stride, ln.data_ptr(), stream)
+        torch.cuda.synchronize()
+        host, lens = out.cpu().numpy(), ln.cpu().numpy().astype(np.uint32)
+        for k in range(n):
+            got = host[k * plan.stride:k * plan.stride + int(lens[k])].tobytes()
+            assert got == oracle_convert(imgs[k % 3], mode, 80, 24, orc.PALETTE_STANDARD), (mode, k)
+        plan.close()
+    # a new frame of another size replaces slot 0; the previous device frame stays intact for work in flight
+    old_ptr = table.latest(0, stream)[0]
+    newer = orc.frame_smooth(200, 100)
+    table.publish(0, blob_of(newer), stream)
+    ptr, w, h, gen = table.latest(0, stream)
+    assert (w, h, gen) == (200, 100, 2) and ptr != old_ptr
+    stale = pkg.frame_setup(old_ptr, TORTURE.shape[1], TORTURE.shape[0], 80, 24, 0)  # a render queued before the publish
+    assert render_descs(gpu, 1, [stale])[0] == oracle_convert(TORTURE, 1, 80, 24, orc.PALETTE_STANDARD)
+    f = pkg.frame_setup(ptr, w, h, 60, 20, 0)
+    got = render_descs(gpu, 1, [f])[0]
+    assert got == oracle_convert(newer, 1, 60, 20, orc.PALETTE_STANDARD)
+    # rejected blobs leave the slot untouched (the reference skips such a frame)
+    for bad in (b"", struct.pack(">II", 0, 4) + bytes(12), struct.pack(">II", 4000, 4) + bytes(4000 * 4 * 3),
+                struct.pack(">II", 8, 8) + bytes(8 * 8 * 3 - 1)):
+        with pytest.raises(RuntimeError):
+            table.publish(0, bad, stream)
+    assert table.latest(0, stream)[3] == 2
+    table.close()
