@@ -935,6 +935,7 @@ __global__ void __launch_bounds__(BLOCK)
    * the 1080p -> 80x24 kernel, profiles/r01_ablation.txt) */
   if (!SPLIT)
     parts = 1;
+
   using L = Lds<MODE, BLOCK, CAP, RING>;
   constexpr bool HB = mode_is_halfblock(MODE);
   constexpr int NW = L::NW;
