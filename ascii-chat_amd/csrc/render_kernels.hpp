@@ -401,15 +401,35 @@ template <int MODE, int BLOCK, int CAP, int RING> struct Lds {
 /* ------------------------------------------------------------------------------------------- */
 /* sampling (R1) and the fused pixel-space composite (C2)                                        */
 /* ------------------------------------------------------------------------------------------- */
-__device__ inline uint32_t load_rgb(const uint8_t *__restrict__ src, int32_t stride_bytes, uint32_t x, uint32_t y) {
+/* A sample is requested as ONE unaligned dword and finished later (finish_rgb), so that nothing between the
+ * requests of a thread consumes loaded data and all of them are in flight together (a use right behind the load
+ * makes the compiler wait for every sample in turn).  kind says how the dword maps to the pixel. */
+enum : uint32_t {
+  RAW_FINAL = 0u, /* v is the pixel already (0x00BBGGRR)                                  */
+  RAW_BACK = 1u,  /* v = byte before the pixel + the pixel: never past the last pixel      */
+  RAW_FIRST = 2u, /* v = the buffer's first pixel + the byte behind it (buffer >= 2 pixels) */
+  RAW_TOP = 3u    /* half-block bottom sample of an odd last row: repeats the top sample    */
+};
+__device__ inline uint32_t load_rgb_raw(const uint8_t *__restrict__ src, int32_t stride_bytes, uint32_t x, uint32_t y,
+                                        bool single_pixel, uint32_t &kind) {
   /* a frame is at most 3840x2160x3 = 24.9 MB: 32-bit offsets keep the address in (SGPR base + VGPR offset) form */
   const uint32_t a = y * (uint32_t)stride_bytes + x * 3u;
   const ACHIP_GLOBAL uint8_t *p = (const ACHIP_GLOBAL uint8_t *)src + a;
-  if (a == 0) /* first pixel of the buffer: nothing in front of it to borrow a byte from */
+  if (single_pixel) { /* a 1x1 source is 3 bytes: no dword to read (uniform per frame) */
+    kind = RAW_FINAL;
     return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
-  /* one (unaligned) dword covering the byte before the pixel and the pixel: never reads past the
-   * last pixel of the buffer, and costs one VMEM instruction instead of three */
-  return ((const ACHIP_GLOBAL unaligned_u32 *)(p - 1))->v >> 8;
+  }
+  kind = a != 0u ? RAW_BACK : RAW_FIRST;
+  return ((const ACHIP_GLOBAL unaligned_u32 *)(p - (a != 0u ? 1u : 0u)))->v;
+}
+__device__ inline uint32_t finish_rgb(uint32_t v, uint32_t kind) {
+  return kind == RAW_BACK ? v >> 8 : (kind == RAW_FIRST ? v & 0x00FFFFFFu : v);
+}
+__device__ inline uint32_t load_rgb(const uint8_t *__restrict__ src, int32_t stride_bytes, uint32_t x, uint32_t y,
+                                    bool single_pixel = false) {
+  uint32_t kind;
+  const uint32_t v = load_rgb_raw(src, stride_bytes, x, y, single_pixel, kind);
+  return finish_rgb(v, kind);
 }
 
 /* apply_color_filter for one pixel (lib/video/rgba/color_filter.c:246-345; rgb_to_grayscale color_filter.h:172:
@@ -449,30 +469,42 @@ __device__ inline uint32_t sample_composite(const achip_composite_t *__restrict_
   uint32_t sx = ((uint32_t)lx * s->x_ratio) >> 16, sy = ((uint32_t)ly * s->y_ratio) >> 16;
   sx = min(sx, (uint32_t)s->src_w - 1u);
   sy = min(sy, (uint32_t)s->src_h - 1u);
-  return load_rgb(s->src, s->src_stride, sx, sy);
+  return load_rgb(s->src, s->src_stride, sx, sy, s->src_w * s->src_h == 1);
 }
 
 /* sample (x, y) of the out_w x out_h resized image that the reference would have built.
  * COMP selects the virtual-composite sampler at compile time (its own kernel instantiation), so the
  * common single-source kernels carry none of its address arithmetic. */
-template <bool COMP> __device__ inline uint32_t sample_frame(const achip_frame_t &f, uint32_t x, uint32_t y) {
+template <bool COMP>
+__device__ inline uint32_t sample_frame_raw(const achip_frame_t &f, uint32_t x, uint32_t y, uint32_t &kind) {
   uint32_t sx = (x * f.x_ratio) >> 16, sy = (y * f.y_ratio) >> 16;
   sx = min(sx, (uint32_t)f.src_w - 1u);
   sy = min(sy, (uint32_t)f.src_h - 1u);
+  kind = RAW_FINAL;
 #if defined(ACHIP_ABLATE) && ACHIP_ABLATE == 3
   return (sx * 2654435761u + sy * 40503u) & 0x00FFFFFFu; /* diagnostics: no memory access */
 #endif
   if (COMP && f.comp)
     return sample_composite(f.comp, sx, sy);
-  /* display-path pre-passes folded in (uniform per frame): flip = index map, tint = per-sample map */
+  /* display-path flips folded in (uniform per frame): an index map */
   if (f.ops & ACHIP_OP_FLIP_X)
     sx = (uint32_t)f.src_w - 1u - sx;
   if (f.ops & ACHIP_OP_FLIP_Y)
     sy = (uint32_t)f.src_h - 1u - sy;
-  uint32_t p = load_rgb(f.src, f.src_stride, sx, sy);
-  if (f.ops & ACHIP_OP_TINT)
+  return load_rgb_raw(f.src, f.src_stride, sx, sy, f.src_w * f.src_h == 1, kind);
+}
+/* raw dword -> pixel, then the display path's colour filter (a per-sample map); composite samples come back
+ * final and are not filtered, like the reference's server path */
+template <bool COMP> __device__ inline uint32_t sample_finish(const achip_frame_t &f, uint32_t v, uint32_t kind) {
+  uint32_t p = finish_rgb(v, kind);
+  if ((f.ops & ACHIP_OP_TINT) && !(COMP && f.comp))
     p = tint_pixel(p, f.ops);
   return p;
+}
+template <bool COMP> __device__ inline uint32_t sample_frame(const achip_frame_t &f, uint32_t x, uint32_t y) {
+  uint32_t kind;
+  const uint32_t v = sample_frame_raw<COMP>(f, x, y, kind);
+  return sample_finish<COMP>(f, v, kind);
 }
 
 /* ------------------------------------------------------------------------------------------- */
@@ -938,6 +970,15 @@ __global__ void __launch_bounds__(BLOCK)
 
   using L = Lds<MODE, BLOCK, CAP, RING>;
   constexpr bool HB = mode_is_halfblock(MODE);
+  /* Samples of chunk c+1 are requested while chunk c is tokenised -- in the 1024 x 2 geometry only: its 2(+2)
+   * samples per thread fit the 128-VGPR budget (4K -> 200x60: 58 -> 47 us, 4K -> 400x120 half-block: 314 -> 287 us,
+   * profiles/r01_prefetch.txt); the smaller geometries would drop to half the waves per CU, and a row band is a
+   * single chunk anyway. */
+#ifdef ACHIP_HIPEMU /* tests: the request-ahead order in every geometry, so that tiny inputs exercise it */
+  constexpr bool PREFETCH = !SPLIT;
+#else
+  constexpr bool PREFETCH = BLOCK == 1024 && CAP == 2048 && !SPLIT;
+#endif
   constexpr int NW = L::NW;
   constexpr int SEG = L::SEG;
   static_assert(CAP % BLOCK == 0 && RING % 16 == 0 && RING >= 256, "geometry");
@@ -1030,7 +1071,9 @@ __global__ void __launch_bounds__(BLOCK)
   /* gather: all of a thread's samples of a chunk are requested before any is consumed, so a thread keeps
    * up to 2*SEG sparse fetches in flight; cell i_k = tid + k*BLOCK (lane <-> consecutive cells) */
   uint32_t gt[SEG], gb[SEG];
+  uint32_t gkind = 0; /* 2 bits per sample: top of cell k at bit 2k, bottom at bit 2(SEG+k) */
   auto gather_issue = [&](int row0, int cells) {
+    gkind = 0;
 #pragma unroll
     for (int k = 0; k < SEG; k++) {
       const int i = tid + k * BLOCK;
@@ -1041,14 +1084,19 @@ __global__ void __launch_bounds__(BLOCK)
       if (i < cells && xp >= f.pad_left) {
         const uint32_t x = (uint32_t)(xp - f.pad_left);
         const uint32_t r = (uint32_t)(row0 + rr);
+        uint32_t kt = RAW_FINAL, kb = RAW_FINAL;
         if (HB) {
           const uint32_t yt = 2u * r, yb = 2u * r + 1u;
-          gt[k] = sample_frame<COMP>(f, x, yt);
+          gt[k] = sample_frame_raw<COMP>(f, x, yt, kt);
           /* odd height: the last text row's bottom half repeats the top (halfblock.c:81-88) */
-          gb[k] = yb < (uint32_t)f.out_h ? sample_frame<COMP>(f, x, yb) : 0xFFFFFFFFu;
+          if (yb < (uint32_t)f.out_h)
+            gb[k] = sample_frame_raw<COMP>(f, x, yb, kb);
+          else
+            kb = RAW_TOP;
         } else {
-          gt[k] = sample_frame<COMP>(f, x, r);
+          gt[k] = sample_frame_raw<COMP>(f, x, r, kt);
         }
+        gkind |= (kt << (2 * k)) | (kb << (2 * (SEG + k)));
       }
     }
   };
@@ -1109,16 +1157,19 @@ __global__ void __launch_bounds__(BLOCK)
 #define ACHIP_CELL_RR(k) row_of(tid + (k)*BLOCK, wp_magic)
 #define ACHIP_CELL_XP(k) (tid + (k)*BLOCK - ACHIP_CELL_RR(k) * wp)
 
-    /* ---- A: gather the chunk's samples and commit them to LDS with the mode's run key in bits 31..24.
-     * (Requesting chunk c+1 before tokenising chunk c was measured and does not pay: the sparse loads
-     * stall at ISSUE -- 64 distinct lines per wave instruction -- so there is nothing left to hide.) --- */
-    gather_issue(r0, n);
+    /* ---- A: commit the chunk's samples (requested one chunk ahead) to LDS with the mode's run key in
+     * bits 31..24 ------------------------------------------------------------------------------- */
+    if (!PREFETCH || r0 == row_begin)
+      gather_issue(r0, n);
 #pragma unroll
     for (int k = 0; k < SEG; k++) {
       const int i = tid + k * BLOCK;
       if (i < n) {
-        uint32_t pt = gt[k], pb = gb[k] == 0xFFFFFFFFu ? gt[k] : gb[k];
+        const uint32_t kt = (gkind >> (2 * k)) & 3u, kb = (gkind >> (2 * (SEG + k))) & 3u;
+        uint32_t pt = gt[k], pb = gb[k];
         if (ACHIP_CELL_XP(k) >= f.pad_left) {
+          pt = sample_finish<COMP>(f, pt, kt);
+          pb = kb == RAW_TOP ? pt : sample_finish<COMP>(f, pb, kb);
           if (MODE == ACHIP_MODE_HB_256) {
             pt |= quant256(pt) << 24;
             pb |= quant256(pb) << 24;
@@ -1135,6 +1186,9 @@ __global__ void __launch_bounds__(BLOCK)
       }
     }
     __syncthreads();
+    /* request the next chunk's samples now: the sparse fetches stay in flight during B-E of this chunk */
+    if (PREFETCH && r1 < row_end)
+      gather_issue(r1, (min(row_end, r1 + rows_per_chunk) - r1) * wp);
     ACHIP_STAMP(1);
     if (MODE == ACHIP_MODE_16_DITHER_BG) { /* one wave diffuses the errors and leaves the colour index in the key byte */
       if (wave == 0)
@@ -1334,7 +1388,7 @@ __global__ void __launch_bounds__(256)
     uint32_t sx = (x * x_ratio) >> 16, sy = (y * y_ratio) >> 16;
     sx = min(sx, (uint32_t)sw - 1u);
     sy = min(sy, (uint32_t)sh - 1u);
-    const uint32_t p = load_rgb(src, src_stride, sx, sy);
+    const uint32_t p = load_rgb(src, src_stride, sx, sy, sw * sh == 1);
     uint8_t *d = dst + (size_t)i * 3u;
     d[0] = (uint8_t)p;
     d[1] = (uint8_t)(p >> 8);

@@ -14,10 +14,16 @@ template <int MODE, int BLOCK, int CAP, int RING>
 static void run(const achip_frame_t *frames, int n, const achip_lut_t *lut, uint8_t *out, uint64_t stride,
                 uint32_t *len) {
   using L = achip::Lds<MODE, BLOCK, CAP, RING>;
-  hipemu::launch(dim3((unsigned)(n * g_parts)), dim3(BLOCK), (size_t)L::bytes, [&] {
-    achip::render_frames_kernel<MODE, BLOCK, CAP, RING, true>(frames, lut, out, stride, len, n, nullptr, g_parts,
-                                                              g_rows_per_part, g_part_sync, g_epoch);
-  });
+  if (g_parts > 1) /* the two instantiations the product launches: row bands / whole frames (render_inst.hip) */
+    hipemu::launch(dim3((unsigned)(n * g_parts)), dim3(BLOCK), (size_t)L::bytes, [&] {
+      achip::render_frames_kernel<MODE, BLOCK, CAP, RING, true, true>(frames, lut, out, stride, len, n, nullptr, g_parts,
+                                                                      g_rows_per_part, g_part_sync, g_epoch);
+    });
+  else
+    hipemu::launch(dim3((unsigned)n), dim3(BLOCK), (size_t)L::bytes, [&] {
+      achip::render_frames_kernel<MODE, BLOCK, CAP, RING, true, false>(frames, lut, out, stride, len, n, nullptr, 1, 0,
+                                                                       nullptr, g_epoch);
+    });
 }
 
 /* multi-workgroup frames: set before emu_render_batch (parts == 1 restores the default) */
