@@ -979,6 +979,10 @@ __global__ void __launch_bounds__(BLOCK)
 #else
   constexpr bool PREFETCH = BLOCK == 1024 && CAP == 2048 && !SPLIT;
 #endif
+  /* the four requests per thread of a half-block chunk are issued at four points of B/C instead of at once: the
+   * memory pipeline accepts a limited number of lines, and a wave waits at the request until its lines fit
+   * (4K -> 400x120: 281 -> 266 us; for the two requests of the other modes one burst is better) */
+  constexpr bool SPREAD = PREFETCH && HB;
   constexpr int NW = L::NW;
   constexpr int SEG = L::SEG;
   static_assert(CAP % BLOCK == 0 && RING % 16 == 0 && RING >= 256, "geometry");
@@ -1072,32 +1076,37 @@ __global__ void __launch_bounds__(BLOCK)
    * up to 2*SEG sparse fetches in flight; cell i_k = tid + k*BLOCK (lane <-> consecutive cells) */
   uint32_t gt[SEG], gb[SEG];
   uint32_t gkind = 0; /* 2 bits per sample: top of cell k at bit 2k, bottom at bit 2(SEG+k) */
+  /* request ONE sample of cell k (top, or the half-block bottom row) of the chunk starting at text row row0 */
+  auto gather_one = [&](int k, bool bottom, int row0, int cells) {
+    const int i = tid + k * BLOCK;
+    const int rr = row_of(i, wp_magic);
+    const int xp = i - rr * wp;
+    const int sh = 2 * (bottom ? SEG + k : k);
+    gkind &= ~(3u << sh);
+    if (bottom)
+      gb[k] = 0;
+    else
+      gt[k] = 0;
+    if (i < cells && xp >= f.pad_left) {
+      const uint32_t x = (uint32_t)(xp - f.pad_left);
+      const uint32_t r = (uint32_t)(row0 + rr);
+      uint32_t kind = RAW_FINAL;
+      if (!bottom) {
+        gt[k] = sample_frame_raw<COMP>(f, x, HB ? 2u * r : r, kind);
+      } else if (2u * r + 1u < (uint32_t)f.out_h) {
+        gb[k] = sample_frame_raw<COMP>(f, x, 2u * r + 1u, kind);
+      } else {
+        kind = RAW_TOP; /* odd height: the last text row's bottom half repeats the top (halfblock.c:81-88) */
+      }
+      gkind |= kind << sh;
+    }
+  };
   auto gather_issue = [&](int row0, int cells) {
-    gkind = 0;
 #pragma unroll
     for (int k = 0; k < SEG; k++) {
-      const int i = tid + k * BLOCK;
-      const int rr = row_of(i, wp_magic);
-      const int xp = i - rr * wp;
-      gt[k] = 0;
-      gb[k] = 0;
-      if (i < cells && xp >= f.pad_left) {
-        const uint32_t x = (uint32_t)(xp - f.pad_left);
-        const uint32_t r = (uint32_t)(row0 + rr);
-        uint32_t kt = RAW_FINAL, kb = RAW_FINAL;
-        if (HB) {
-          const uint32_t yt = 2u * r, yb = 2u * r + 1u;
-          gt[k] = sample_frame_raw<COMP>(f, x, yt, kt);
-          /* odd height: the last text row's bottom half repeats the top (halfblock.c:81-88) */
-          if (yb < (uint32_t)f.out_h)
-            gb[k] = sample_frame_raw<COMP>(f, x, yb, kb);
-          else
-            kb = RAW_TOP;
-        } else {
-          gt[k] = sample_frame_raw<COMP>(f, x, r, kt);
-        }
-        gkind |= (kt << (2 * k)) | (kb << (2 * (SEG + k)));
-      }
+      gather_one(k, false, row0, cells);
+      if (HB)
+        gather_one(k, true, row0, cells);
     }
   };
   /* glyph tables -> LDS */
@@ -1186,9 +1195,13 @@ __global__ void __launch_bounds__(BLOCK)
       }
     }
     __syncthreads();
-    /* request the next chunk's samples now: the sparse fetches stay in flight during B-E of this chunk */
-    if (PREFETCH && r1 < row_end)
-      gather_issue(r1, (min(row_end, r1 + rows_per_chunk) - r1) * wp);
+    /* request the next chunk's samples: the sparse fetches stay in flight during B-E of this chunk */
+    const bool pf = PREFETCH && r1 < row_end;
+    const int pf_cells = (min(row_end, r1 + rows_per_chunk) - r1) * wp;
+    if (pf && SPREAD)
+      gather_one(0, false, r1, pf_cells);
+    else if (pf)
+      gather_issue(r1, pf_cells);
     ACHIP_STAMP(1);
     if (MODE == ACHIP_MODE_16_DITHER_BG) { /* one wave diffuses the errors and leaves the colour index in the key byte */
       if (wave == 0)
@@ -1223,6 +1236,8 @@ __global__ void __launch_bounds__(BLOCK)
       __syncthreads();
     }
     ACHIP_STAMP(2);
+    if (pf && SPREAD)
+      gather_one(0, true, r1, pf_cells);
 
     /* ---- C: build the tokens (registers) and their lengths ------------------------------------ */
     Tok tok[SEG];
@@ -1237,6 +1252,13 @@ __global__ void __launch_bounds__(BLOCK)
         CountSink cs{0u};
         token_fields<MODE>(cs, tok[k], ascii_only);
         len[k] = cs.n;
+      }
+      if (pf && SPREAD && k + 1 < SEG)
+        gather_one(k + 1, false, r1, pf_cells);
+      if (pf && SPREAD && k + 1 == SEG) {
+#pragma unroll
+        for (int q = 1; q < SEG; q++)
+          gather_one(q, true, r1, pf_cells);
       }
     }
     /* PT: colour of the last ASCII-glyph pixel seen so far (the RLE state crosses rows and chunks);
