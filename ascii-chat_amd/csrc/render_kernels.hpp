@@ -44,6 +44,11 @@ extern __shared__ __attribute__((aligned(16))) unsigned char achip_smem[];
 
 #include "achip_types.h"
 
+#ifndef ACHIP_EMIT_OR_MODES
+#define ACHIP_EMIT_OR_MODES (1 << 5) /* bit m set: mode m emits through PackSink; measured to pay for the 41-byte
+                                         half-block truecolor tokens only (profiles/r01_emit_or.txt) */
+#endif
+
 namespace achip {
 
 /* pointers read out of descriptors are generic; tell the compiler they are global memory so that it
@@ -73,6 +78,19 @@ template <int OFF, bool HI> __device__ inline void lds_store_byte(uint32_t addr,
     asm volatile("ds_write_b8_d16_hi %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
   else
     asm volatile("ds_write_b8 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+#endif
+}
+/* LDS atomic OR of an aligned dword (no return value): tokens built in registers are OR-ed into a pre-zeroed
+ * staging buffer, so that neighbouring tokens can share a dword without byte stores */
+__device__ inline void lds_or_u32(uint32_t addr, uint32_t v) {
+#if defined(ACHIP_ABLATE) && ACHIP_ABLATE == 1
+  asm volatile("" ::"v"(addr), "v"(v));
+  return;
+#endif
+#ifdef ACHIP_HIPEMU
+  *reinterpret_cast<uint32_t *>(ACHIP_SMEM + addr) |= v;
+#else
+  asm volatile("ds_or_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
 #endif
 }
 /* LDS byte address of ACHIP_SMEM[0] (0 for a kernel without static LDS, but do not assume) */
@@ -333,6 +351,39 @@ template <int DEC_OFF, int DUMMY_OFF> struct FastSink {
     else
       lds_store_byte<0, true>(sh >= (ROOM == 1 ? 16u : 24u) ? a + 3u : dummy, w);
     a += (sh >> 3) + 1u;
+  }
+};
+
+/* PackSink: the token is assembled in a 64-bit register window and leaves it one ALIGNED dword at a time as
+ * an LDS atomic OR into the pre-zeroed staging buffer (the drain re-zeroes what it flushes).  Compared with
+ * FastSink a 41-byte half-block token costs 12 LDS instructions instead of 41 -- token stores are bound by LDS
+ * bank conflicts (64 lanes land 19-41 bytes apart), so fewer instructions win even though each field costs a
+ * few more VALU operations.  Every field is at most 4 bytes, so at most one dword completes per field. */
+template <int DEC_OFF> struct PackSink {
+  uint32_t a;   /* LDS byte address (4-byte aligned) of the window's first byte */
+  uint32_t nb;  /* bytes pending in the window, 0..3 between fields                */
+  uint64_t acc; /* pending bytes, first in the low byte                            */
+  __device__ inline explicit PackSink(uint32_t addr) : a(addr & ~3u), nb(addr & 3u), acc(0ull) {}
+  __device__ inline uint32_t lookup(uint32_t v) const { return lds_ptr<const uint32_t>(DEC_OFF)[v]; }
+  __device__ inline void put(uint32_t v, uint32_t k) { /* v holds exactly k <= 4 bytes (zero above) */
+    acc |= (uint64_t)v << (8u * nb);
+    nb += k;
+    /* OR-ing the window's low dword is idempotent, so it goes out after every field whether complete or not
+     * (no select); the window only advances when the dword is complete (nb >= 4, and nb < 8 always) */
+    lds_or_u32(a, (uint32_t)acc);
+    const uint32_t step = nb & 4u;
+    acc >>= 8u * step;
+    a += step;
+    nb &= 3u;
+  }
+  template <int K> __device__ inline void c(uint32_t v) { put(K >= 4 ? v : v & ((1u << (8 * (K & 3))) - 1u), (uint32_t)K); }
+  __device__ inline void v4(uint32_t v, uint32_t k) { put(k >= 4u ? v : v & ((1u << (8u * k)) - 1u), k); }
+  template <int ROOM> __device__ inline void num(uint32_t entry, uint32_t term) { /* 1-3 digits + terminator */
+    const uint32_t sh = entry >> 24; /* 8 * digits */
+    put((entry & 0x00FFFFFFu) | (term << sh), (sh >> 3) + 1u);
+  }
+  __device__ inline void finish() { /* the last 0..3 bytes; the zeros above them leave the next token's bytes alone */
+    lds_or_u32(a, (uint32_t)acc);
   }
 };
 
@@ -828,20 +879,27 @@ template <int MODE> __device__ inline bool same_run(const uint32_t *pixT, const 
 /* ------------------------------------------------------------------------------------------- */
 /* the frame kernel                                                                              */
 /* ------------------------------------------------------------------------------------------- */
-template <int BLOCK>
+template <int BLOCK, bool REZERO = false>
 __device__ inline void drain_ring(int ring_off, uint8_t *__restrict__ out, uint32_t from, uint32_t to, uint32_t own_from,
                                   bool flush_tail) {
   /* [from, to) are stream offsets, `from` is 16-byte aligned and sits at byte 0 of the staging buffer.  This
    * workgroup owns the bytes >= own_from (own_from > from only for the first window of a frame part whose
    * predecessor ended mid-group).  Whole 16-byte groups go out as uint4 (group g by thread g mod BLOCK); the
    * partial head group and, when flush_tail, the partial tail group go out as bytes. */
-  const unsigned char *ring = lds_ptr<const unsigned char>(ring_off);
+  /* REZERO: the staging buffer is filled by atomic ORs (PackSink) and must read as zero wherever the next
+   * window's tokens land: every flushed byte is cleared behind the read */
+  unsigned char *ring = lds_ptr<unsigned char>(ring_off);
+  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
   const uint32_t vec_begin = (own_from + 15u) & ~15u;
   const uint32_t vec_end = to & ~15u;
   uint32_t o = vec_begin + 16u * threadIdx.x;
   for (; o + 16u * BLOCK < vec_end; o += 32u * BLOCK) { /* two groups per trip: both LDS reads in flight */
     const uint4 v0 = *reinterpret_cast<const uint4 *>(ring + (o - from));
     const uint4 v1 = *reinterpret_cast<const uint4 *>(ring + (o - from) + 16u * BLOCK);
+    if (REZERO) {
+      *reinterpret_cast<uint4 *>(ring + (o - from)) = zero4;
+      *reinterpret_cast<uint4 *>(ring + (o - from) + 16u * BLOCK) = zero4;
+    }
 #if defined(ACHIP_ABLATE) && ACHIP_ABLATE == 4
     asm volatile("" ::"v"(v0.x), "v"(v0.y), "v"(v1.z), "v"(v1.w)); /* diagnostics: no HBM writes */
 #else
@@ -849,16 +907,25 @@ __device__ inline void drain_ring(int ring_off, uint8_t *__restrict__ out, uint3
     *reinterpret_cast<uint4 *>(out + o + 16u * BLOCK) = v1;
 #endif
   }
-  if (o < vec_end)
+  if (o < vec_end) {
     *reinterpret_cast<uint4 *>(out + o) = *reinterpret_cast<const uint4 *>(ring + (o - from));
+    if (REZERO)
+      *reinterpret_cast<uint4 *>(ring + (o - from)) = zero4;
+  }
   /* head: [own_from, min(vec_begin, to)), < 16 bytes of the buffer's group 0.  Thread 0 alone touches group 0
    * (it moves the carry there right after this call), so it copies the head itself. */
   if (threadIdx.x == 0)
-    for (uint32_t h = own_from; h < min(vec_begin, to); h++)
+    for (uint32_t h = own_from; h < min(vec_begin, to); h++) {
       out[h] = ring[h - from];
+      if (REZERO)
+        ring[h - from] = 0;
+    }
   if (flush_tail) /* tail: what lies beyond the last whole group (and beyond the head) */
-    for (uint32_t t = max(vec_end, vec_begin) + threadIdx.x; t < to; t += BLOCK)
+    for (uint32_t t = max(vec_end, vec_begin) + threadIdx.x; t < to; t += BLOCK) {
       out[t] = ring[t - from];
+      if (REZERO)
+        ring[t - from] = 0;
+    }
 }
 
 /* ------------------------------------------------------------------------------------------- */
@@ -983,6 +1050,8 @@ __global__ void __launch_bounds__(BLOCK)
    * memory pipeline accepts a limited number of lines, and a wave waits at the request until its lines fit
    * (4K -> 400x120: 281 -> 266 us; for the two requests of the other modes one burst is better) */
   constexpr bool SPREAD = PREFETCH && HB;
+  /* token stores as aligned atomic ORs of register-built dwords (PackSink) instead of byte stores (FastSink) */
+  constexpr bool EMIT_OR = ((ACHIP_EMIT_OR_MODES) >> MODE) & 1;
   constexpr int NW = L::NW;
   constexpr int SEG = L::SEG;
   static_assert(CAP % BLOCK == 0 && RING % 16 == 0 && RING >= 256, "geometry");
@@ -1130,6 +1199,11 @@ __global__ void __launch_bounds__(BLOCK)
       carry[k] = 0;
   }
 
+  if (EMIT_OR) { /* the OR-filled staging buffer starts out zero (as far as this frame can reach); the drain keeps it so */
+    const int groups = (int)(min((uint64_t)RING, out_stride + 32u) / 16u);
+    for (int k = tid; k < groups; k += BLOCK)
+      reinterpret_cast<uint4 *>(ring)[k] = make_uint4(0u, 0u, 0u, 0u);
+  }
   /* ascii_pad_frame_height: pad_top bare newlines, through the same staging buffer */
   if (f.pad_top > 0 && part == 0) {
     const uint32_t total = (uint32_t)f.pad_top;
@@ -1141,11 +1215,14 @@ __global__ void __launch_bounds__(BLOCK)
       for (uint32_t o = base + (uint32_t)tid; o < hi; o += BLOCK)
         ring[o - lo] = '\n';
       __syncthreads();
-      drain_ring<BLOCK>(L::o_ring, dst, lo, hi, lo, false);
+      drain_ring<BLOCK, EMIT_OR>(L::o_ring, dst, lo, hi, lo, false);
       flushed = hi & ~15u;
       if (tid == 0 && flushed > lo) {
-        for (uint32_t j = 0; j < hi - flushed; j++)
+        for (uint32_t j = 0; j < hi - flushed; j++) {
           ring[j] = ring[flushed - lo + j];
+          if (EMIT_OR)
+            ring[flushed - lo + j] = 0;
+        }
       }
       base = hi;
       __syncthreads();
@@ -1349,8 +1426,14 @@ __global__ void __launch_bounds__(BLOCK)
         if (len[k] != 0u && a >= done) {
           if (b <= hi) {
 #if !defined(ACHIP_ABLATE) || ACHIP_ABLATE != 2
-            FastSink<L::o_dec, L::o_flags + 16> fs{ring_addr + (a - lo), dummy_addr};
-            token_fields<MODE>(fs, tok[k], ascii_only);
+            if (EMIT_OR) {
+              PackSink<L::o_dec> ps(ring_addr + (a - lo));
+              token_fields<MODE>(ps, tok[k], ascii_only);
+              ps.finish();
+            } else {
+              FastSink<L::o_dec, L::o_flags + 16> fs{ring_addr + (a - lo), dummy_addr};
+              token_fields<MODE>(fs, tok[k], ascii_only);
+            }
 #else
             asm volatile("" ::"v"(a), "v"(tok[k].flags), "v"(tok[k].fg), "v"(tok[k].glyph));
 #endif
@@ -1367,11 +1450,15 @@ __global__ void __launch_bounds__(BLOCK)
         flags[1 + ((window_no + 1) & 1)] = 0xFFFFFFFFu; /* next window's slot; its last readers are a barrier behind */
       window_no++;
       /* the bytes of a part's last window are flushed completely (its successor owns the rest of the group) */
-      drain_ring<BLOCK>(L::o_ring, dst, lo, cut, max(own_from, lo), last_chunk && cut == chunk_end);
+      const bool final_flush = last_chunk && cut == chunk_end; /* the tail bytes go out too: nothing to carry */
+      drain_ring<BLOCK, EMIT_OR>(L::o_ring, dst, lo, cut, max(own_from, lo), final_flush);
       flushed = cut & ~15u;
-      if (tid == 0 && flushed > lo) { /* tid 0 drained group 0 itself (program order): safe to overwrite it */
-        for (uint32_t j = 0; j < cut - flushed; j++)
+      if (tid == 0 && flushed > lo && !final_flush) { /* tid 0 drained group 0 itself (program order): safe to overwrite it */
+        for (uint32_t j = 0; j < cut - flushed; j++) {
           ring[j] = ring[flushed - lo + j];
+          if (EMIT_OR)
+            ring[flushed - lo + j] = 0;
+        }
       }
       done = cut;
       if (cut >= chunk_end) {

@@ -26,7 +26,8 @@ def build():
     os.makedirs(os.path.dirname(EMU_SO), exist_ok=True)
     obj = os.path.join(os.path.dirname(EMU_SO), "achip_host.o")
     subprocess.check_call(["gcc", "-std=gnu11", "-O2", "-fPIC", "-I" + INC, "-c", os.path.join(CSRC, "achip_host.c"), "-o", obj])
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-shared", "-fPIC", "-I" + CSRC, "-I" + INC, "-I" + EMU_DIR,
+    extra = os.environ.get("ACHIP_EMU_DEFS", "").split()  # e.g. -DACHIP_EMIT_OR_MODES=0x3FF to test an experiment
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-shared", "-fPIC", *extra, "-I" + CSRC, "-I" + INC, "-I" + EMU_DIR,
                            os.path.join(EMU_DIR, "emu_driver.cpp"), obj, "-o", EMU_SO])
     return EMU_SO
 
