@@ -462,7 +462,7 @@ enum : uint32_t {
   RAW_TOP = 3u    /* half-block bottom sample of an odd last row: repeats the top sample    */
 };
 __device__ inline uint32_t load_rgb_raw(const uint8_t *__restrict__ src, int32_t stride_bytes, uint32_t x, uint32_t y,
-                                        bool single_pixel, uint32_t &kind) {
+                                        bool single_pixel, uint32_t &kind, bool stream = false) {
   /* a frame is at most 3840x2160x3 = 24.9 MB: 32-bit offsets keep the address in (SGPR base + VGPR offset) form */
   const uint32_t a = y * (uint32_t)stride_bytes + x * 3u;
   const ACHIP_GLOBAL uint8_t *p = (const ACHIP_GLOBAL uint8_t *)src + a;
@@ -471,6 +471,17 @@ __device__ inline uint32_t load_rgb_raw(const uint8_t *__restrict__ src, int32_t
     return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
   }
   kind = a != 0u ? RAW_BACK : RAW_FIRST;
+#ifndef ACHIP_HIPEMU
+  /* samples a cache line apart or more share no line with their neighbours: a non-temporal load keeps them out of
+   * the L2 (1080p -> 80 columns, 72-byte stride: 13.1 -> 12.0 us per 256 frames); closer samples do share lines
+   * and want the cache (4K -> 200 / 400 columns get 3-5 % slower without it) -- profiles/r01_nontemporal.txt */
+  if (stream) {
+    typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+    uint32_t back = a != 0u ? 1u : 0u;
+    asm volatile("" : "+v"(back)); /* keeps this load distinct: merged with the cached one it would lose its hint */
+    return __builtin_nontemporal_load((const ACHIP_GLOBAL u32_unaligned *)(p - back));
+  }
+#endif
   return ((const ACHIP_GLOBAL unaligned_u32 *)(p - (a != 0u ? 1u : 0u)))->v;
 }
 __device__ inline uint32_t finish_rgb(uint32_t v, uint32_t kind) {
@@ -542,7 +553,8 @@ __device__ inline uint32_t sample_frame_raw(const achip_frame_t &f, uint32_t x, 
     sx = (uint32_t)f.src_w - 1u - sx;
   if (f.ops & ACHIP_OP_FLIP_Y)
     sy = (uint32_t)f.src_h - 1u - sy;
-  return load_rgb_raw(f.src, f.src_stride, sx, sy, f.src_w * f.src_h == 1, kind);
+  return load_rgb_raw(f.src, f.src_stride, sx, sy, f.src_w * f.src_h == 1, kind,
+                      f.x_ratio >= ((64u << 16) + 2u) / 3u /* horizontal sample stride >= 64 bytes */);
 }
 /* raw dword -> pixel, then the display path's colour filter (a per-sample map); composite samples come back
  * final and are not filtered, like the reference's server path */
@@ -879,6 +891,18 @@ template <int MODE> __device__ inline bool same_run(const uint32_t *pixT, const 
 /* ------------------------------------------------------------------------------------------- */
 /* the frame kernel                                                                              */
 /* ------------------------------------------------------------------------------------------- */
+/* 16 output bytes to HBM.  The stream is written once and never read back by the kernel: a non-temporal
+ * store lets the lines leave the L2 during the kernel instead of in the write-back at its end. */
+__device__ inline void store_out16(uint8_t *__restrict__ p, uint4 v) {
+#if defined(ACHIP_HIPEMU) || defined(ACHIP_NO_NT_STORE)
+  *reinterpret_cast<uint4 *>(p) = v;
+#else
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 w = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(w, reinterpret_cast<u32x4 *>(p));
+#endif
+}
+
 template <int BLOCK, bool REZERO = false>
 __device__ inline void drain_ring(int ring_off, uint8_t *__restrict__ out, uint32_t from, uint32_t to, uint32_t own_from,
                                   bool flush_tail) {
@@ -903,12 +927,12 @@ __device__ inline void drain_ring(int ring_off, uint8_t *__restrict__ out, uint3
 #if defined(ACHIP_ABLATE) && ACHIP_ABLATE == 4
     asm volatile("" ::"v"(v0.x), "v"(v0.y), "v"(v1.z), "v"(v1.w)); /* diagnostics: no HBM writes */
 #else
-    *reinterpret_cast<uint4 *>(out + o) = v0;
-    *reinterpret_cast<uint4 *>(out + o + 16u * BLOCK) = v1;
+    store_out16(out + o, v0);
+    store_out16(out + o + 16u * BLOCK, v1);
 #endif
   }
   if (o < vec_end) {
-    *reinterpret_cast<uint4 *>(out + o) = *reinterpret_cast<const uint4 *>(ring + (o - from));
+    store_out16(out + o, *reinterpret_cast<const uint4 *>(ring + (o - from)));
     if (REZERO)
       *reinterpret_cast<uint4 *>(ring + (o - from)) = zero4;
   }
