@@ -115,6 +115,40 @@ def run_workload(torch, pkg, name, batch, steps, warmup, dist=None, seed=1234, v
     return res
 
 
+def run_grid9(torch, pkg, steps, warmup):
+    """BASELINE configs[3]: nine 1080p sources -> the 3x3 grid at 160x48 for each of the nine clients.  One launch
+    renders the nine client frames straight from the sources (the W x 2H canvas of create_multi_source_composite
+    is virtual); with 9 frames the launch is cut into row bands automatically."""
+    import ctypes as C
+    n, sw, sh, tw, th = 9, 1920, 1080, 160, 48
+    src = make_frames(torch, n, sw, sh, 4321)
+    ptrs = (C.c_void_p * n)(*[src.data_ptr() + i * sh * sw * 3 for i in range(n)])
+    ws, hs = (C.c_int * n)(*([sw] * n)), (C.c_int * n)(*([sh] * n))
+    comp = pkg.Composite()
+    pkg.lib().achip_composite_setup(C.byref(comp), ptrs, ws, hs, n, tw, th)
+    comp_dev = C.c_void_p()
+    assert pkg.lib().asciichat_hip_composite_upload(C.byref(comp), C.byref(comp_dev)) == 0
+    descs = []
+    for _ in range(n):  # every client looks at the same grid (stream.c:790-854: aspect + padding on)
+        f = pkg.frame_setup(None, tw, 2 * th, tw, th, 0, True, True, False)
+        f.comp = comp_dev.value
+        descs.append(f)
+    plan = pkg.Plan(pkg.lib().achip_mode_from_caps(3, 0), PALETTE_STANDARD, descs)
+    out = torch.empty(n * plan.stride, dtype=torch.uint8, device="cuda")
+    ln = torch.zeros(n, dtype=torch.int32, device="cuda")
+    wall, gpu_ms = time_steps(torch, plan, out, ln, steps, warmup, None)
+    lens = ln.cpu().numpy().astype("uint32")
+    assert (lens < 0xFFFFFFF0).all()
+    cells = int(sum(d.out_w * d.out_h for d in descs))
+    res = {"frames_per_s": n * steps / wall, "kernel_ms": gpu_ms / steps, "out_bytes_per_frame": float(lens.mean()),
+           "alg_bytes_per_launch": int(lens.sum()) + 3 * cells, "kernel_variant": plan.variant, "bands_per_frame": plan.parts}
+    res["roofline_GBps"] = res["alg_bytes_per_launch"] / (res["kernel_ms"] * 1e-3) / 1e9
+    res["roofline_frac"] = res["roofline_GBps"] / HBM_PEAK_GBS
+    plan.close()
+    pkg.lib().asciichat_hip_free(comp_dev)
+    return res
+
+
 def cpu_baseline(name, budget_s=12.0):
     """Times the CPU oracle (port of the reference's scalar path) on this host: 1 thread and all cores,
     on a bounded sample of the same workload (same frame shape, S-noise input, same caps)."""
@@ -250,6 +284,9 @@ def main():
             others[name] = {"frames_per_s": b * res["steps"] / res["wall_s"], "kernel_ms": k,
                             "out_bytes_per_frame": res["out_bytes_per_frame"], "roofline_GBps": a,
                             "roofline_frac": a / HBM_PEAK_GBS, "kernel_variant": res["variant"]}
+        del res
+        torch.cuda.empty_cache()
+        others["grid9_1080p_160x48_truecolor"] = run_grid9(torch, pkg, max(10, args.steps // 10), 3)
         line["other_workloads"] = others
     if rank == 0:
         print(json.dumps(line))
