@@ -144,13 +144,8 @@ static int device_cu_count(void) {
 }
 
 /* render one frame described by `f` (f->src = HOST pixels, `src_bytes` long) and return the malloc'd string */
-static char *render_one(int mode, const char *palette, achip_frame_t *f, size_t src_bytes) {
-  tls_ctx_t *c = tls_get();
-  if (!c)
-    return NULL;
-  const achip_lut_t *lut = NULL;
-  if (achip_lut_get(palette, &lut))
-    return NULL;
+static char *render_with_lut(tls_ctx_t *c, const achip_lut_t *lut, int mode, const char *palette, achip_frame_t *f,
+                             size_t src_bytes) {
   /* a single frame on a 256-CU device: cut it into row bands so that many workgroups share it */
   int caps[ACHIP_VARIANT_COUNT], variant = -1, parts = 1, rows_per_part = 1;
   for (int v = 0; v < ACHIP_VARIANT_COUNT; v++)
@@ -204,6 +199,18 @@ static char *render_one(int mode, const char *palette, achip_frame_t *f, size_t 
   }
   memcpy(out, c->pin + PIN_OUT_OFF, len);
   out[len] = '\0';
+  return out;
+}
+
+static char *render_one(int mode, const char *palette, achip_frame_t *f, size_t src_bytes) {
+  tls_ctx_t *c = tls_get();
+  if (!c)
+    return NULL;
+  const achip_lut_t *lut = NULL;
+  if (achip_lut_get(palette, &lut))
+    return NULL;
+  char *out = render_with_lut(c, lut, mode, palette, f, src_bytes); /* synchronous: the tables are free again */
+  achip_lut_put(lut);
   return out;
 }
 

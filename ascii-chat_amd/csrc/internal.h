@@ -17,8 +17,9 @@ int achip_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 
 int achip_require_device(void);
 /* maps a hipError_t to 0 / ASCIICHAT_HIP_ERR_NO_DEVICE with a message */
 int achip_hip_check(int hip_error, const char *what);
-/* device glyph tables for a palette string, cached per device */
+/* device glyph tables for a palette string, cached per device; get pins the entry, put releases it */
 int achip_lut_get(const char *palette, const achip_lut_t **out_dev);
+void achip_lut_put(const achip_lut_t *dev);
 
 /* buffer_pool.c: device alias of a pointer inside a pinned pool block, or NULL */
 const void *achip_pool_device_ptr(const void *host_ptr);

@@ -63,16 +63,21 @@ int achip_hip_check(int e, const char *what) {
 /* glyph-table cache: palette string -> device achip_lut_t (per device)                           */
 /* the counterpart of get_utf8_palette_cache (common.c:270-377): built once per palette, shared    */
 /* ------------------------------------------------------------------------------------------- */
-#define LUT_CACHE_MAX 64
+#define LUT_CACHE_MAX 2048 /* the reference's own cap (common.c: heap eviction at 2048 palettes) */
 typedef struct {
   char *palette;
   int device;
+  int pins;          /* users between achip_lut_get and achip_lut_put; only unpinned entries are evicted */
+  unsigned long age; /* g_lut_clock at the last get */
   achip_lut_t *dev;
 } lut_entry_t;
 static lut_entry_t g_luts[LUT_CACHE_MAX];
 static int g_lut_count;
+static unsigned long g_lut_clock;
 static pthread_mutex_t g_lut_mu = PTHREAD_MUTEX_INITIALIZER;
 
+/* Pins the device tables of `palette` (building and uploading them on first use); release with achip_lut_put
+ * once no queued work reads them any more. */
 int achip_lut_get(const char *palette, const achip_lut_t **out_dev) {
   if (!palette || !palette[0])
     return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "empty palette");
@@ -80,8 +85,11 @@ int achip_lut_get(const char *palette, const achip_lut_t **out_dev) {
   if (achip_hip_check((int)hipGetDevice(&device), "hipGetDevice"))
     return ASCIICHAT_HIP_ERR_NO_DEVICE;
   pthread_mutex_lock(&g_lut_mu);
+  g_lut_clock++;
   for (int i = 0; i < g_lut_count; i++) {
     if (g_luts[i].device == device && strcmp(g_luts[i].palette, palette) == 0) {
+      g_luts[i].pins++;
+      g_luts[i].age = g_lut_clock;
       *out_dev = g_luts[i].dev;
       pthread_mutex_unlock(&g_lut_mu);
       return 0;
@@ -92,27 +100,62 @@ int achip_lut_get(const char *palette, const achip_lut_t **out_dev) {
     pthread_mutex_unlock(&g_lut_mu);
     return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "bad palette");
   }
+  int slot = g_lut_count;
+  if (slot == LUT_CACHE_MAX) { /* full: recycle the least recently used entry nobody holds */
+    slot = -1;
+    for (int i = 0; i < g_lut_count; i++)
+      if (g_luts[i].pins == 0 && (slot < 0 || g_luts[i].age < g_luts[slot].age))
+        slot = i;
+    if (slot < 0) {
+      pthread_mutex_unlock(&g_lut_mu);
+      return achip_fail(ASCIICHAT_HIP_ERR_MEMORY, "%d palettes are in use at once", LUT_CACHE_MAX);
+    }
+    (void)hipFree(g_luts[slot].dev); /* unpinned: no queued work reads it */
+    free(g_luts[slot].palette);
+    g_luts[slot].dev = NULL;
+    g_luts[slot].palette = NULL;
+  }
   achip_lut_t *dev = NULL;
-  int rc = achip_hip_check((int)hipMalloc((void **)&dev, sizeof(host)), "hipMalloc(lut)");
+  char *copy = strdup(palette);
+  int rc = copy ? 0 : achip_fail(ASCIICHAT_HIP_ERR_MEMORY, "out of memory");
+  if (!rc)
+    rc = achip_hip_check((int)hipMalloc((void **)&dev, sizeof(host)), "hipMalloc(lut)");
   if (!rc)
     rc = achip_hip_check((int)hipMemcpy(dev, &host, sizeof(host), hipMemcpyHostToDevice), "hipMemcpy(lut)");
   if (rc) {
+    if (dev)
+      (void)hipFree(dev);
+    free(copy);
+    if (slot < g_lut_count) { /* the recycled slot stays empty: close the gap */
+      g_luts[slot] = g_luts[g_lut_count - 1];
+      g_lut_count--;
+    }
     pthread_mutex_unlock(&g_lut_mu);
     return rc;
   }
-  if (g_lut_count == LUT_CACHE_MAX) { /* evict the oldest entry; plans hold their own reference count of 0: */
-    /* entries are tiny (1.3 KB) and never freed while a plan may still use them -> just stop caching */
-    *out_dev = dev;
-    pthread_mutex_unlock(&g_lut_mu);
-    return 0;
-  }
-  g_luts[g_lut_count].palette = strdup(palette);
-  g_luts[g_lut_count].device = device;
-  g_luts[g_lut_count].dev = dev;
-  g_lut_count++;
+  g_luts[slot].palette = copy;
+  g_luts[slot].device = device;
+  g_luts[slot].pins = 1;
+  g_luts[slot].age = g_lut_clock;
+  g_luts[slot].dev = dev;
+  if (slot == g_lut_count)
+    g_lut_count++;
   *out_dev = dev;
   pthread_mutex_unlock(&g_lut_mu);
   return 0;
+}
+
+void achip_lut_put(const achip_lut_t *dev) {
+  if (!dev)
+    return;
+  pthread_mutex_lock(&g_lut_mu);
+  for (int i = 0; i < g_lut_count; i++)
+    if (g_luts[i].dev == dev) {
+      if (g_luts[i].pins > 0)
+        g_luts[i].pins--;
+      break;
+    }
+  pthread_mutex_unlock(&g_lut_mu);
 }
 
 /* ------------------------------------------------------------------------------------------- */
@@ -324,6 +367,7 @@ void asciichat_hip_plan_destroy(asciichat_hip_plan_t *p) {
     (void)hipHostFree(p->frames_pinned);
   if (p->part_sync)
     (void)hipFree(p->part_sync);
+  achip_lut_put(p->lut_dev);
   free(p);
 }
 

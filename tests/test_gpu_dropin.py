@@ -195,3 +195,29 @@ def test_grid_and_padding_host_utilities(api):
     assert api.take_string(L.ascii_pad_frame_height(b"ab\ncd", 2)) == b"\n\nab\ncd"
     assert L.rgb_to_16color(255, 0, 0) == 9 and L.rgb_to_256color(10, 10, 10) == 232
     assert L.rep_is_profitable(6) and not L.rep_is_profitable(5)
+
+
+def test_palette_cache_churn(api):
+    """More distinct palettes than the device glyph-table cache holds (2048, the reference's own cap): unpinned
+    entries are recycled, a table a plan holds is never evicted, and every render stays byte-exact."""
+    import torch
+
+    L = api.lib()
+    img = orc.frame_hash_noise(64, 48, 9)
+    im = as_image(api, img)
+    c = caps(api, 2, 0)
+    dev = torch.from_numpy(np.ascontiguousarray(TORTURE)).cuda()
+    held_pal = "  .oO@"
+    plan = api.Plan(1, held_pal, [api.frame_setup(dev.data_ptr(), TORTURE.shape[1], TORTURE.shape[0], 40, 12, 0)])
+    alphabet = "abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789"
+    for k in range(2100):
+        pal = "  " + alphabet[k % 62] + alphabet[(k // 62) % 62] + alphabet[(k * 7) % 62] + "#"
+        got = api.take_string(L.ascii_convert_with_capabilities(C.byref(im), 16, 6, C.byref(c), False, False, pal.encode()))
+        if k % 150 == 0 or k > 2090:
+            assert got == orc.convert_with_caps(img, 16, 6, 2, 0, False, False, False, pal), pal
+    out = torch.zeros(plan.stride, dtype=torch.uint8, device="cuda")
+    ln = torch.zeros(1, dtype=torch.int32, device="cuda")
+    plan.render(out.data_ptr(), plan.stride, ln.data_ptr())
+    torch.cuda.synchronize()
+    assert out[:int(ln[0].item())].cpu().numpy().tobytes() == orc.convert_with_caps(TORTURE, 40, 12, 3, 0, False, False, False, held_pal)
+    plan.close()
