@@ -38,6 +38,8 @@ typedef struct {
   size_t pin_cap;
   uint8_t *stage;    /* device staging for sources that are not device-visible */
   size_t stage_cap;
+  uint8_t *hstage;   /* pinned host staging: the sampled rows of such a source, gathered for one DMA */
+  size_t hstage_cap;
   uint8_t *scratch;  /* device scratch for image_resize() destinations */
   size_t scratch_cap;
   unsigned long long *part_sync; /* hand-off words of multi-workgroup frames (<= 2160 parts), zeroed once */
@@ -57,6 +59,8 @@ static void tls_destroy(void *p) {
     (void)hipHostFree(c->pin);
   if (c->stage)
     (void)hipFree(c->stage);
+  if (c->hstage)
+    (void)hipHostFree(c->hstage);
   if (c->scratch)
     (void)hipFree(c->scratch);
   if (c->part_sync)
@@ -129,6 +133,50 @@ static const uint8_t *resolve_source(tls_ctx_t *c, const void *host_px, size_t b
   return c->stage;
 }
 
+/* A pageable source is not uploaded whole: the renderer point-samples out_h of its src_h rows, so only those
+ * rows are gathered into pinned staging (plain row memcpys) and sent with one DMA -- 138 KB instead of 6.2 MB
+ * for 1080p -> 80x24.  The descriptor copy `d` is rewritten to address the compacted image (row y of it IS sampled
+ * row y; a vertical flip is folded into the gather).  Pool-pinned sources are read in place as before. */
+static const uint8_t *stage_source(tls_ctx_t *c, achip_frame_t *d, size_t src_bytes) {
+  const uint8_t *host_px = d->src;
+  const void *alias = achip_pool_device_ptr(host_px);
+  if (alias)
+    return (const uint8_t *)alias;
+  const size_t stride = d->src_stride ? (size_t)d->src_stride : (size_t)d->src_w * 3u;
+  const size_t row_bytes = (size_t)d->src_w * 3u;
+  if (d->comp || d->out_h >= d->src_h) /* every row is needed (or repeated): upload the image as it is */
+    return resolve_source(c, host_px, src_bytes);
+  const size_t need = (size_t)d->out_h * row_bytes;
+  if (c->hstage_cap < need) {
+    if (c->hstage)
+      (void)hipHostFree(c->hstage);
+    c->hstage = NULL;
+    c->hstage_cap = 0;
+    if (achip_hip_check((int)hipHostMalloc((void **)&c->hstage, need + need / 4, hipHostMallocDefault),
+                        "hipHostMalloc(row staging)"))
+      return NULL;
+    c->hstage_cap = need + need / 4;
+  }
+  if (ensure_dev(&c->stage, &c->stage_cap, need))
+    return NULL;
+  for (int y = 0; y < d->out_h; y++) { /* the rows the sampler will ask for (image.c:293-312), top to bottom */
+    uint32_t sy = (uint32_t)(((uint64_t)(uint32_t)y * d->y_ratio) >> 16);
+    if (sy > (uint32_t)d->src_h - 1u)
+      sy = (uint32_t)d->src_h - 1u;
+    if (d->ops & ACHIP_OP_FLIP_Y)
+      sy = (uint32_t)d->src_h - 1u - sy;
+    memcpy(c->hstage + (size_t)y * row_bytes, host_px + (size_t)sy * stride, row_bytes);
+  }
+  if (achip_hip_check((int)hipMemcpyAsync(c->stage, c->hstage, need, hipMemcpyHostToDevice, c->stream),
+                      "hipMemcpyAsync(sampled rows)"))
+    return NULL;
+  d->src_h = d->out_h;
+  d->y_ratio = 1u << 16; /* sampled row y = row y of the compacted image */
+  d->src_stride = (int32_t)row_bytes;
+  d->ops &= ~ACHIP_OP_FLIP_Y;
+  return c->stage;
+}
+
 #define DROPIN_MAX_PARTS 2160 /* IMAGE_MAX_HEIGHT text rows at one row per part */
 
 static int device_cu_count(void) {
@@ -163,7 +211,8 @@ static char *render_with_lut(tls_ctx_t *c, const achip_lut_t *lut, int mode, con
       return NULL;
   }
   c->epoch = c->epoch + 1u ? c->epoch + 1u : 1u;
-  const uint8_t *src_dev = resolve_source(c, f->src, src_bytes);
+  achip_frame_t staged = *f;
+  const uint8_t *src_dev = stage_source(c, &staged, src_bytes);
   if (!src_dev)
     return NULL;
   size_t stride = (achip_out_bound(mode, f) + 1 + 15) & ~(size_t)15;
@@ -174,7 +223,7 @@ static char *render_with_lut(tls_ctx_t *c, const achip_lut_t *lut, int mode, con
   if (ensure_pin(c, PIN_OUT_OFF + stride))
     return NULL;
   achip_frame_t *desc = (achip_frame_t *)(c->pin + PIN_DESC_OFF);
-  *desc = *f;
+  *desc = staged;
   desc->src = src_dev;
   volatile uint32_t *len_host = (volatile uint32_t *)(c->pin + PIN_LEN_OFF);
   *len_host = ACHIP_LEN_BADDESC;

@@ -163,10 +163,64 @@ def wire_stage():
               f"{nb*nbytes/(ms*1e-3)/8e12*100:4.1f} % of 8 TB/s")
 
 
+def dropin_latency():
+    """End-to-end latency of the reference's own call (ascii_convert_with_capabilities, host image in, malloc'd
+    string out) through libasciichat_hip.so, next to the CPU oracle on the same host."""
+    import ctypes as C
+    import time
+
+    import numpy as np
+    import torch  # noqa: F401
+
+    from __graft_entry__ import load_package
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+
+    pkg = load_package()
+    L = pkg.lib()
+    pal = orc.PALETTE_STANDARD.encode()
+    for (sw, sh, W, H, cl, rm, name) in ((1920, 1080, 80, 24, 3, 0, "1080p->80x24 truecolor"), (3840, 2160, 200, 60, 3, 0, "4K->200x60 truecolor"),
+                                       (3840, 2160, 400, 120, 3, 2, "4K->400x120 half-block"), (640, 480, 80, 24, 0, 0, "640x480->80x24 mono")):
+        img = orc.frame_hash_noise(sw, sh, 5)
+        caps = pkg.TermCaps()
+        caps.color_level, caps.render_mode, caps.utf8_support = cl, rm, True
+        arr = np.ascontiguousarray(img)
+        pageable = pkg.Image(sw, sh, arr.ctypes.data, 0)
+        L.image_new_from_pool.restype = C.POINTER(pkg.Image)
+        pooled = L.image_new_from_pool(sw, sh)
+        C.memmove(pooled.contents.pixels, arr.ctypes.data, arr.size)
+
+        def call(im):
+            p = L.ascii_convert_with_capabilities(im, W, H, C.byref(caps), False, False, pal)
+            s = pkg.take_string(p)
+            return s
+
+        exp = orc.convert_with_caps(img, W, H, cl, rm)
+        res = {}
+        for label, im in (("pageable image", C.byref(pageable)), ("pool (pinned) image", pooled)):
+            assert call(im) == exp
+            for _ in range(20):
+                call(im)
+            t0 = time.perf_counter()
+            reps = 200
+            for _ in range(reps):
+                call(im)
+            res[label] = (time.perf_counter() - t0) / reps * 1e6
+        t0 = time.perf_counter()
+        reps = 50
+        for _ in range(reps):
+            orc.convert_with_caps(img, W, H, cl, rm)
+        cpu = (time.perf_counter() - t0) / reps * 1e6
+        print(f"drop-in {name:26s}: " + "  ".join(f"{k} {v:7.1f} us" for k, v in res.items()) + f"   CPU oracle (1 thread) {cpu:8.1f} us")
+        L.image_destroy_to_pool(pooled)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--stream-passes":
         stream_passes()
     elif len(sys.argv) > 1 and sys.argv[1] == "--wire-stage":
         wire_stage()
+    elif len(sys.argv) > 1 and sys.argv[1] == "--dropin":
+        dropin_latency()
     else:
         main()
