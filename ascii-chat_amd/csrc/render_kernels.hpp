@@ -1070,9 +1070,11 @@ __global__ void __launch_bounds__(BLOCK)
 #else
   constexpr bool PREFETCH = BLOCK == 1024 && CAP == 2048 && !SPLIT;
 #endif
-  /* the four requests per thread of a half-block chunk are issued at four points of B/C instead of at once: the
-   * memory pipeline accepts a limited number of lines, and a wave waits at the request until its lines fit
-   * (4K -> 400x120: 281 -> 266 us; for the two requests of the other modes one burst is better) */
+  /* A wave waits AT the request until the memory pipeline has room for its lines, so the requests of a chunk are
+   * not issued in one burst behind phase A's barrier but at four points of B/C: in the half-block modes every
+   * thread issues one of its four requests per point (4K -> 400x120: 281 -> 266 us); in the other modes a
+   * quarter of the waves (wave & 3) issues both of its requests per point while the rest tokenises
+   * (4K -> 200x60: 46.9 -> 45.1 us; profiles/r01_prefetch.txt) */
   constexpr bool SPREAD = PREFETCH && HB;
   /* token stores as aligned atomic ORs of register-built dwords (PackSink) instead of byte stores (FastSink) */
   constexpr bool EMIT_OR = ((ACHIP_EMIT_OR_MODES) >> MODE) & 1;
@@ -1301,7 +1303,7 @@ __global__ void __launch_bounds__(BLOCK)
     const int pf_cells = (min(row_end, r1 + rows_per_chunk) - r1) * wp;
     if (pf && SPREAD)
       gather_one(0, false, r1, pf_cells);
-    else if (pf)
+    else if (pf && (wave & 3) == 0)
       gather_issue(r1, pf_cells);
     ACHIP_STAMP(1);
     if (MODE == ACHIP_MODE_16_DITHER_BG) { /* one wave diffuses the errors and leaves the colour index in the key byte */
@@ -1339,6 +1341,8 @@ __global__ void __launch_bounds__(BLOCK)
     ACHIP_STAMP(2);
     if (pf && SPREAD)
       gather_one(0, true, r1, pf_cells);
+    else if (pf && (wave & 3) == 1)
+      gather_issue(r1, pf_cells);
 
     /* ---- C: build the tokens (registers) and their lengths ------------------------------------ */
     Tok tok[SEG];
@@ -1361,6 +1365,10 @@ __global__ void __launch_bounds__(BLOCK)
         for (int q = 1; q < SEG; q++)
           gather_one(q, true, r1, pf_cells);
       }
+      if (pf && !SPREAD && k == 0 && (wave & 3) == 2)
+        gather_issue(r1, pf_cells);
+      if (pf && !SPREAD && k + 1 == SEG && (wave & 3) == 3)
+        gather_issue(r1, pf_cells);
     }
     /* PT: colour of the last ASCII-glyph pixel seen so far (the RLE state crosses rows and chunks);
      * read before the barrier below, after which pixT may be overwritten by the next chunk's gather */
