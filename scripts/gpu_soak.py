@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Randomised soak on the GPU (not part of the pytest suites): many random batches -- sizes, modes, palettes, paddings,
+display ops, batch sizes, band splits, kernel geometries -- every frame compared byte-for-byte with the oracle.
+Usage (GPU box): python scripts/gpu_soak.py [--rounds 150] [--seed 1]"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import orc  # noqa: E402
+from achip_ctypes import ALL_MODES, MODE_CAPS, MODE_NAMES, MODE_TRUE_BG  # noqa: E402
+from test_random_differential import PALETTES, oracle_case, random_image  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rounds", type=int, default=150)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    import torch
+
+    from __graft_entry__ import load_package
+
+    pkg = load_package()
+    torch.cuda.set_device(0)
+    rng = np.random.default_rng(args.seed)
+    checked = 0
+    for rnd in range(args.rounds):
+        mode = int(rng.choice(ALL_MODES))
+        palette = PALETTES[int(rng.integers(0, len(PALETTES)))]
+        aspect = bool(rng.integers(0, 2)) and mode != MODE_TRUE_BG
+        pad = bool(rng.integers(0, 2))
+        rm = MODE_CAPS.get(mode, (3, 0))[1]
+        nframes = int(rng.choice([1, 2, 3, 7, 16, 40, 100, 200, 300, 420]))
+        big = rng.integers(0, 4) == 0
+        flt = int(rng.choice([0, 0, 0, 3, 7, 11]))
+        fx, fy = bool(rng.integers(0, 4) == 0), bool(rng.integers(0, 4) == 0)
+        pool = []
+        for _ in range(min(nframes, 12)):  # a few distinct sources, reused round-robin
+            sw, sh = (int(rng.integers(200, 2000)), int(rng.integers(100, 1100))) if big else (int(rng.integers(1, 300)), int(rng.integers(1, 200)))
+            img = random_image(rng, sw, sh)
+            pool.append((img, torch.from_numpy(np.ascontiguousarray(img)).cuda()))
+        frames, cases = [], []
+        for k in range(nframes):
+            img, dev = pool[k % len(pool)]
+            W, H = (int(rng.integers(1, 520)), int(rng.integers(1, 140))) if big else (int(rng.integers(1, 200)), int(rng.integers(1, 70)))
+            f = pkg.frame_setup(dev.data_ptr(), img.shape[1], img.shape[0], W, H, rm, pad, aspect, False)
+            if f is None:
+                continue
+            if (flt or fx or fy) and mode != MODE_TRUE_BG:
+                import ctypes as C
+                assert pkg.lib().achip_frame_set_display_ops(C.byref(f), fx, fy, flt) == 0
+            frames.append(f)
+            cases.append((img, W, H))
+        if not frames:
+            continue
+        plan = pkg.Plan(mode, palette, frames)
+        choice = int(rng.integers(0, 5))
+        try:
+            if choice == 1:
+                plan.set_split(-1)
+            elif choice == 2:
+                plan.set_split(int(rng.integers(1, 9)))
+            elif choice == 3:
+                plan.set_variant(int(rng.choice([0, 1, 2, 3, 4])))
+            elif choice == 4:
+                plan.set_variant(int(rng.choice([1, 2, 4])))
+                plan.set_split(int(rng.integers(1, 6)))
+        except RuntimeError:
+            pass  # geometry cannot hold this batch's rows: keep the automatic one
+        out = torch.full((len(frames) * plan.stride,), 0xAB, dtype=torch.uint8, device="cuda")
+        ln = torch.zeros(len(frames), dtype=torch.int32, device="cuda")
+        for _ in range(2):
+            plan.render(out.data_ptr(), plan.stride, ln.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        host, lens = out.cpu().numpy(), ln.cpu().numpy().astype(np.uint32)
+        memo = {}
+        for k, (img, W, H) in enumerate(cases):
+            assert lens[k] < 0xFFFFFFF0, (rnd, k, hex(int(lens[k])))
+            got = host[k * plan.stride:k * plan.stride + int(lens[k])].tobytes()
+            key = (id(img), W, H)
+            if key not in memo:
+                if (flt or fx or fy) and mode != MODE_TRUE_BG:
+                    cl, rmm = MODE_CAPS[mode]
+                    memo[key] = orc.display_convert(img, W, H, cl, rmm, pad, aspect, fx, fy, flt, palette)
+                else:
+                    memo[key] = oracle_case(img, W, H, mode, aspect, pad, palette)
+            assert got == memo[key], (rnd, MODE_NAMES[mode], k, img.shape, W, H, pad, aspect, palette, plan.variant, plan.parts, flt, fx, fy)
+            checked += 1
+        print(f"round {rnd:3d}: {MODE_NAMES[mode]:10s} frames {len(frames):3d} geometry v{plan.variant} bands {plan.parts:3d} ok", flush=True)
+        plan.close()
+    print(f"soak OK: {checked} frames byte-identical to the oracle")
+
+
+if __name__ == "__main__":
+    main()
