@@ -434,3 +434,53 @@ def test_frame_table_ingest(gpu):
             table.publish(0, bad, stream)
     assert table.latest(0, stream)[3] == 2
     table.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# one server tick end to end: ingest -> render -> wire stage (SURVEY 8f.2 + hot path + 8f.3)
+# ------------------------------------------------------------------------------------------------
+def test_server_tick_end_to_end(gpu):
+    """What a server tick does with this library: every client's camera blob is published once, all client
+    frames are rendered in one launch from the shared device frames, and the ASCII frame packets (header +
+    frame + CRCs) come back ready for the socket.  Each packet is then checked the way the reference CLIENT
+    checks it (src/client/protocol.c:380-408: header fields in network order, CRC-32C of the frame)."""
+    import struct
+    pkg, torch = gpu
+    L = pkg.lib()
+    stream = torch.cuda.current_stream().cuda_stream
+    n = 9
+    cams = [orc.frame_hash_noise(640, 480, 30 + i) if i % 3 else orc.frame_bars(640, 480, i) for i in range(n)]
+    table = pkg.FrameTable(n)
+    for i, cam in enumerate(cams):
+        table.publish(i, struct.pack(">II", 640, 480) + cam.tobytes(), stream)
+    terms = [(80, 24), (120, 40), (200, 60), (33, 7), (80, 24), (97, 31), (160, 48), (20, 10), (80, 25)]
+    for mode in (1, 2, 5):  # every client watches client (i+1) % n, in its own terminal size
+        cl, rm = MODE_CAPS[mode]
+        frames = []
+        for i in range(n):
+            ptr, w, h, _gen = table.latest((i + 1) % n, stream)
+            frames.append(pkg.frame_setup(ptr, w, h, terms[i][0], terms[i][1], rm, True, True, False))
+        plan = pkg.Plan(mode, orc.PALETTE_STANDARD, frames)
+        out = torch.zeros(n * plan.stride, dtype=torch.uint8, device="cuda")
+        ln = torch.zeros(n, dtype=torch.int32, device="cuda")
+        dims = torch.tensor(terms, dtype=torch.int32, device="cuda")
+        crc = torch.zeros(n, dtype=torch.int32, device="cuda")
+        hdr = torch.zeros(n * 24, dtype=torch.uint8, device="cuda")
+        pkt = torch.zeros(n, dtype=torch.int32, device="cuda")
+        plan.render(out.data_ptr(), plan.stride, ln.data_ptr(), stream)
+        assert L.asciichat_hip_frame_packets(out.data_ptr(), plan.stride, ln.data_ptr(), plan.stride, n, dims.data_ptr(),
+                                             crc.data_ptr(), hdr.data_ptr(), pkt.data_ptr(), stream) == 0
+        torch.cuda.synchronize()
+        host, lens, hdrs = out.cpu().numpy(), ln.cpu().numpy().astype(np.uint32), hdr.cpu().numpy()
+        pkts = pkt.cpu().numpy().astype(np.uint32)
+        for i in range(n):
+            payload = hdrs[24 * i:24 * i + 24].tobytes() + host[i * plan.stride:i * plan.stride + int(lens[i])].tobytes()
+            # --- the receiving client's checks ---
+            width, height, original_size, compressed_size, checksum, flags = struct.unpack(">6I", payload[:24])
+            frame = payload[24:]
+            assert (width, height, compressed_size, flags) == (terms[i][0], terms[i][1], 0, 0)
+            assert original_size == len(frame) and orc.crc32c(frame) == checksum
+            assert orc.crc32c(payload) == int(pkts[i])  # packet_header_t.crc32 over the whole payload
+            assert frame == orc.convert_with_caps(cams[(i + 1) % n], terms[i][0], terms[i][1], cl, rm, True, True, False)
+        plan.close()
+    table.close()
