@@ -571,3 +571,119 @@ char *ascii_create_grid(ascii_frame_source_t *sources, int source_count, int wid
   *out_size = strlen(canvas);
   return canvas;
 }
+
+/* ------------------------------------------------------------------------------------------- */
+/* lib/video/ascii/rle.c:13-162 and lib/video/ascii/frame_validator.c:13-80                       */
+/* ------------------------------------------------------------------------------------------- */
+static size_t csi_params_end(const char *in, size_t n, size_t i, uint32_t *last_param) {
+  uint32_t param = 0; /* rle.c:33-40: digits accumulate, ';' restarts the parameter */
+  while (i < n && ((in[i] >= '0' && in[i] <= '9') || in[i] == ';')) {
+    param = in[i] == ';' ? 0u : param * 10u + (uint32_t)(in[i] - '0');
+    i++;
+  }
+  if (last_param)
+    *last_param = param;
+  return i;
+}
+
+char *ansi_expand_rle(const char *input, size_t input_len) {
+  if (!input || input_len == 0)
+    return NULL;
+  outbuf_t ob = {0};
+  ob_reserve(&ob, input_len * 2);
+  char last_char[5] = " ";
+  size_t last_len = 1;
+  size_t i = 0;
+  while (i < input_len) {
+    if (input[i] == '\033' && i + 1 < input_len && input[i + 1] == '[') {
+      const size_t start = i;
+      uint32_t param = 0;
+      i = csi_params_end(input, input_len, i + 2, &param);
+      if (i < input_len) { /* a sequence cut off by the end of the input is dropped (rle.c:43) */
+        const char final_byte = input[i++];
+        if (final_byte == 'b' && param > 0) {
+          for (uint32_t r = 0; r < param; r++)
+            ob_write(&ob, last_char, last_len);
+        } else {
+          ob_write(&ob, input + start, i - start);
+        }
+      }
+    } else {
+      const unsigned char c = (unsigned char)input[i];
+      size_t len = (c & 0xE0) == 0xC0 ? 2 : ((c & 0xF0) == 0xE0 ? 3 : ((c & 0xF8) == 0xF0 ? 4 : 1));
+      if (i + len > input_len)
+        len = input_len - i;
+      ob_write(&ob, input + i, len);
+      if (c >= 0x20 && c != 0x7F) {
+        memcpy(last_char, input + i, len);
+        last_char[len] = '\0';
+        last_len = len;
+      }
+      i += len;
+    }
+  }
+  ob_term(&ob);
+  return ob.buf;
+}
+
+char *ansi_compress_rle(const char *input, size_t input_len) {
+  if (!input || input_len == 0)
+    return NULL;
+  outbuf_t ob = {0};
+  ob_reserve(&ob, input_len);
+  size_t i = 0;
+  while (i < input_len) {
+    if (input[i] == '\033' && i + 1 < input_len && input[i + 1] == '[') {
+      const size_t start = i;
+      i = csi_params_end(input, input_len, i + 2, NULL);
+      if (i < input_len)
+        i++;
+      ob_write(&ob, input + start, i - start);
+    } else {
+      const signed char c = (signed char)input[i]; /* the reference compares a plain (signed) char: bytes >= 0x80 never run */
+      if (c >= 0x20 && c != 0x7F) {
+        size_t run = 1;
+        i++;
+        while (i < input_len && input[i] == (char)c) {
+          run++;
+          i++;
+        }
+        ob_putc(&ob, (char)c);
+        if (run > 1 && rep_is_profitable((uint32_t)run)) {
+          emit_rep(&ob, (uint32_t)(run - 1));
+        } else {
+          for (size_t k = 1; k < run; k++)
+            ob_putc(&ob, (char)c);
+        }
+      } else {
+        ob_putc(&ob, (char)c);
+        i++;
+      }
+    }
+  }
+  ob_term(&ob);
+  return ob.buf;
+}
+
+static size_t final_reset_pos(const char *d, size_t n) { /* frame_validator.c:13-30: the LAST ESC[0m */
+  if (!d || n < 4)
+    return SIZE_MAX;
+  for (size_t i = n - 4 + 1; i-- > 0;)
+    if (memcmp(d + i, "\033[0m", 4) == 0)
+      return i;
+  return SIZE_MAX;
+}
+
+bool frame_validate_integrity(const char *frame_data, size_t frame_size) {
+  if (!frame_data || frame_size == 0)
+    return false;
+  const size_t pos = final_reset_pos(frame_data, frame_size);
+  return pos != SIZE_MAX && pos + 4 == frame_size; /* no reset at all, or bytes behind the last one: invalid */
+}
+
+size_t frame_get_valid_end(const char *frame_data, size_t frame_size) {
+  if (!frame_data || frame_size < 4)
+    return frame_size;
+  const size_t pos = final_reset_pos(frame_data, frame_size);
+  return pos == SIZE_MAX ? frame_size : pos + 4;
+}

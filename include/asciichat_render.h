@@ -211,6 +211,13 @@ void emit_reset(outbuf_t *ob);
 bool rep_is_profitable(uint32_t runlen);
 void emit_rep(outbuf_t *ob, uint32_t extra);
 
+/* ---- video/ascii/rle.h:61,87 and video/ascii/frame_validator.h:20,32 (exported by the reference,
+ * called from nowhere in its tree; host string utilities on finished frames) ------------------------------------ */
+char *ansi_expand_rle(const char *input, size_t input_len);   /* ESC[Nb -> N copies of the last printable character */
+char *ansi_compress_rle(const char *input, size_t input_len); /* runs of one byte >= 6 long -> byte ESC[<n-1>b          */
+bool frame_validate_integrity(const char *frame_data, size_t frame_size); /* ends right after its last ESC[0m ?       */
+size_t frame_get_valid_end(const char *frame_data, size_t frame_size);
+
 /* ---- util/aspect_ratio.h ---------------------------------------------------------------------------- */
 void aspect_ratio(const ssize_t img_w, const ssize_t img_h, const ssize_t width, const ssize_t height,
                   const bool stretch, ssize_t *out_width, ssize_t *out_height);

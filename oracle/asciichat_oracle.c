@@ -6,6 +6,7 @@
 
 #include <limits.h>
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -1191,4 +1192,129 @@ int orc_frame_blob_accept(const void *blob, size_t size, int exact, uint32_t *w,
   *w = pw;
   *h = ph;
   return 1;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* uncalled leftovers: REP expansion / compression of a finished frame, frame integrity check    */
+/* (written independently of the product's hostutil.c: byte-at-a-time state machines)            */
+/* ------------------------------------------------------------------------------------------- */
+typedef struct {
+  char *p;
+  size_t n, cap;
+} obuf_t;
+static void obuf_put(obuf_t *o, const char *s, size_t k) {
+  if (o->n + k + 1 > o->cap) {
+    o->cap = (o->n + k + 1) * 2 + 64;
+    o->p = (char *)realloc(o->p, o->cap);
+  }
+  memcpy(o->p + o->n, s, k);
+  o->n += k;
+  o->p[o->n] = 0;
+}
+
+char *orc_expand_rle(const char *in, size_t n, size_t *out_len) {
+  if (!in || !n)
+    return NULL;
+  obuf_t o = {0};
+  char last[4] = {' ', 0, 0, 0};
+  size_t last_n = 1, i = 0;
+  while (i < n) {
+    if (in[i] == 27 && i + 1 < n && in[i + 1] == '[') { /* rle.c:25-52 */
+      size_t j = i + 2;
+      unsigned long param = 0;
+      for (; j < n && ((in[j] >= '0' && in[j] <= '9') || in[j] == ';'); j++)
+        param = in[j] == ';' ? 0 : (unsigned long)(uint32_t)(param * 10 + (unsigned long)(in[j] - '0'));
+      if (j >= n)
+        break; /* truncated sequence: nothing more is written */
+      if (in[j] == 'b' && (uint32_t)param > 0) {
+        for (uint32_t r = 0; r < (uint32_t)param; r++)
+          obuf_put(&o, last, last_n);
+      } else {
+        obuf_put(&o, in + i, j + 1 - i);
+      }
+      i = j + 1;
+      continue;
+    }
+    unsigned char c = (unsigned char)in[i]; /* rle.c:53-80 */
+    size_t k = 1;
+    if (c >= 0xC0 && c < 0xE0)
+      k = 2;
+    else if (c >= 0xE0 && c < 0xF0)
+      k = 3;
+    else if (c >= 0xF0 && c < 0xF8)
+      k = 4;
+    if (k > n - i)
+      k = n - i;
+    obuf_put(&o, in + i, k);
+    if (c >= 0x20 && c != 0x7F) {
+      memcpy(last, in + i, k);
+      last_n = k;
+    }
+    i += k;
+  }
+  if (!o.p)
+    obuf_put(&o, "", 0);
+  *out_len = o.n;
+  return o.p;
+}
+
+char *orc_compress_rle(const char *in, size_t n, size_t *out_len) {
+  if (!in || !n)
+    return NULL;
+  obuf_t o = {0};
+  size_t i = 0;
+  while (i < n) {
+    if (in[i] == 27 && i + 1 < n && in[i + 1] == '[') { /* rle.c:103-117: sequences pass through */
+      size_t j = i + 2;
+      while (j < n && ((in[j] >= '0' && in[j] <= '9') || in[j] == ';'))
+        j++;
+      if (j < n)
+        j++;
+      obuf_put(&o, in + i, j - i);
+      i = j;
+      continue;
+    }
+    const int c = (signed char)in[i]; /* rle.c:119-121 compares a plain char, signed on x86-64 */
+    if (c < 0x20 || c == 0x7F) {
+      obuf_put(&o, in + i, 1);
+      i++;
+      continue;
+    }
+    size_t run = 0;
+    while (i + run < n && in[i + run] == in[i])
+      run++;
+    obuf_put(&o, in + i, 1);
+    if (run > 1 && orc_rep_is_profitable((uint32_t)run)) {
+      char t[16];
+      int k = snprintf(t, sizeof t, "\033[%ub", (unsigned)(run - 1));
+      obuf_put(&o, t, (size_t)k);
+    } else {
+      for (size_t q = 1; q < run; q++)
+        obuf_put(&o, in + i, 1);
+    }
+    i += run;
+  }
+  if (!o.p)
+    obuf_put(&o, "", 0);
+  *out_len = o.n;
+  return o.p;
+}
+
+static long last_reset(const char *d, size_t n) {
+  for (long i = (long)n - 4; i >= 0; i--)
+    if (d[i] == 27 && d[i + 1] == '[' && d[i + 2] == '0' && d[i + 3] == 'm')
+      return i;
+  return -1;
+}
+int orc_frame_validate_integrity(const char *d, size_t n) {
+  if (!d || n == 0)
+    return 0;
+  const long p = n >= 4 ? last_reset(d, n) : -1;
+  return p >= 0 && (size_t)p + 4 == n;
+}
+size_t orc_frame_get_valid_end(const char *d, size_t n) {
+  if (!d || n < 4)
+    return n;
+  const long p = last_reset(d, n);
+  return p < 0 ? n : (size_t)p + 4;
 }

@@ -104,6 +104,12 @@ char *orc_display_convert(const uint8_t *rgb, int src_w, int src_h, long width, 
                           int render_mode, bool wants_padding, bool use_aspect, bool stretch, const char *palette,
                           bool flip_x, bool flip_y, int color_filter, size_t *len);
 
+/* ---- uncalled leftovers: lib/video/ascii/rle.c:13-162, frame_validator.c:13-80 ---- */
+char *orc_expand_rle(const char *in, size_t n, size_t *out_len);
+char *orc_compress_rle(const char *in, size_t n, size_t *out_len);
+int orc_frame_validate_integrity(const char *d, size_t n);
+size_t orc_frame_get_valid_end(const char *d, size_t n);
+
 /* ---- ingest ---------------------------------------------------------------- */
 /* the frame-blob checks of collect_video_sources (src/server/stream.c:330-372; exact = 0) and of the IMAGE_FRAME
  * receive handler (src/server/protocol.c:784-815; exact = 1).  Returns 1 when the reference accepts the blob

@@ -15,7 +15,8 @@ run fetch FETCH_SIZE
 run write WRITE_SIZE
 cd $GRAFT_REPO_ROOT
 python - <<PY
-import csv, glob, collections
+import csv, glob, collections, json
+traffic = {}
 for name in ("sq1","sq2","fetch","write"):
     for f in glob.glob("$OUT/%s/**/*counter_collection.csv" % name, recursive=True):
         acc = collections.defaultdict(lambda: [0.0,0])
@@ -24,4 +25,12 @@ for name in ("sq1","sq2","fetch","write"):
                 k = row["Counter_Name"]; acc[k][0] += float(row["Counter_Value"]); acc[k][1] += 1
         for k,(v,n) in sorted(acc.items()):
             print(f"{name:6s} {k:28s} per-dispatch mean {v/n:16.1f}  (n={n})")
+            if k in ("FETCH_SIZE", "WRITE_SIZE"):
+                traffic[k] = (v / n, n)
+if len(traffic) == 2:  # what bench.py reads as profiles/pmc_traffic.json (copy it there together with the summary)
+    json.dump({"$WL": {"variant": 4, "batch": 256, "fetch_size_kb": round(traffic["FETCH_SIZE"][0], 1),
+                       "write_size_kb": round(traffic["WRITE_SIZE"][0], 1),
+                       "source": "profiles/r01_pmc_summary_$WL.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, "
+                                 "per-dispatch mean over %d dispatches)" % traffic["FETCH_SIZE"][1]}},
+              open("$OUT/pmc_traffic.json", "w"), indent=1)
 PY

@@ -44,6 +44,13 @@ def lib():
         vp, ci, cl, sz = C.c_void_p, C.c_int, C.c_long, C.c_size_t
         L.orc_fnv1a32.restype = C.c_uint32
         L.orc_fnv1a32.argtypes = [vp, sz]
+        for f in (L.orc_expand_rle, L.orc_compress_rle):
+            f.restype = vp
+            f.argtypes = [C.c_char_p, sz, C.POINTER(sz)]
+        L.orc_frame_validate_integrity.restype = C.c_int
+        L.orc_frame_validate_integrity.argtypes = [C.c_char_p, sz]
+        L.orc_frame_get_valid_end.restype = sz
+        L.orc_frame_get_valid_end.argtypes = [C.c_char_p, sz]
         L.orc_frame_blob_accept.restype = C.c_int
         L.orc_frame_blob_accept.argtypes = [C.c_char_p, sz, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.orc_crc32c.restype = C.c_uint32
@@ -128,6 +135,18 @@ def _img(a):
 
 def _pal(p):
     return p.encode("utf-8") if isinstance(p, str) else p
+
+
+def expand_rle(b):
+    n = C.c_size_t()
+    p = lib().orc_expand_rle(bytes(b), len(b), C.byref(n))
+    return _take(p, n.value) if p else None
+
+
+def compress_rle(b):
+    n = C.c_size_t()
+    p = lib().orc_compress_rle(bytes(b), len(b), C.byref(n))
+    return _take(p, n.value) if p else None
 
 
 def frame_blob_accept(blob, exact=False):

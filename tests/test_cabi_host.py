@@ -213,6 +213,53 @@ def test_palette_cache_matches_oracle_and_is_shared(pkg):
     assert not L.get_utf8_palette_cache(None) and not L.get_utf8_palette_cache(b"")
 
 
+def test_rle_and_frame_validator_utilities(pkg):
+    """SURVEY 8f.4 leftovers (rle.c, frame_validator.c): product vs the oracle's independent restatement, plus the
+    properties that make them useful as checkers: expanding a REP-compressed mono frame gives W characters per
+    line, and compressing that expansion again never grows it."""
+    L = C.CDLL(pkg.LIB_PATH)
+    OL = orc.lib()
+    for f in (L.ansi_expand_rle, L.ansi_compress_rle):
+        f.restype = C.c_void_p
+        f.argtypes = [C.c_char_p, C.c_size_t]
+    L.frame_validate_integrity.restype = C.c_bool
+    L.frame_validate_integrity.argtypes = [C.c_char_p, C.c_size_t]
+    L.frame_get_valid_end.restype = C.c_size_t
+    L.frame_get_valid_end.argtypes = [C.c_char_p, C.c_size_t]
+    L.free.argtypes = [C.c_void_p]
+
+    def prod(fn, b):
+        p = fn(b, len(b))
+        if not p:
+            return None
+        out = C.string_at(p)
+        L.free(p)
+        return out
+
+    img = orc.frame_bars(400, 300, 2)
+    mono = orc.convert(img, 120, 30, False, False, False)
+    tc = orc.convert_with_caps(orc.frame_torture(), 80, 24, 3, 0)
+    hb = orc.convert_with_caps(orc.frame_torture(), 80, 24, 3, 2)
+    rng = np.random.default_rng(3)
+    junk = [bytes(rng.integers(0, 256, 300, dtype=np.uint8)).replace(b"\0", b"\x01") for _ in range(4)]
+    cases = [mono, tc, hb, b"a\033[5b", b"\033[3bX", b"ab\033[0b", b"x\033[2;3bz", b"\033[", b"ab\033[12", b"aaaaaaaaaa", b"aaaaa",
+             "▀▀▀▀▀▀▀▀".encode(), b"\t\t\t\t\t\t\t", b"~\x7f\x7f\x7f\x7f\x7f\x7f\x7f", b"z" * 5000] + junk
+    for b in cases:
+        assert prod(L.ansi_expand_rle, b) == orc.expand_rle(b), b[:40]
+        assert prod(L.ansi_compress_rle, b) == orc.compress_rle(b), b[:40]
+        assert L.frame_validate_integrity(b, len(b)) == bool(OL.orc_frame_validate_integrity(b, len(b)))
+        assert L.frame_get_valid_end(b, len(b)) == OL.orc_frame_get_valid_end(b, len(b))
+    assert prod(L.ansi_expand_rle, b"") is None and prod(L.ansi_compress_rle, b"") is None
+    # properties on real frames
+    lines = orc.expand_rle(mono).split(b"\n")
+    assert len(lines) == 30 and all(len(l) == 120 for l in lines)
+    again = orc.compress_rle(orc.expand_rle(mono))
+    assert orc.expand_rle(again) == orc.expand_rle(mono) and len(again) <= len(orc.expand_rle(mono))
+    assert L.frame_validate_integrity(tc, len(tc)) and L.frame_validate_integrity(hb, len(hb))
+    assert not L.frame_validate_integrity(mono, len(mono))              # mono frames carry no reset at all
+    assert not L.frame_validate_integrity(tc + b"xx", len(tc) + 2) and L.frame_get_valid_end(tc + b"xx", len(tc) + 2) == len(tc)
+
+
 def test_frame_blob_validation_matches_reference_rules(pkg):
     """achip_frame_blob_parse vs the oracle's restatement of stream.c:330-372 / protocol.c:784-815."""
     import struct
