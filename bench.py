@@ -286,7 +286,8 @@ def main():
                             "roofline_frac": a / HBM_PEAK_GBS, "kernel_variant": res["variant"]}
         del res
         torch.cuda.empty_cache()
-        others["grid9_1080p_160x48_truecolor"] = run_grid9(torch, pkg, max(10, args.steps // 10), 3)
+        if args.others:
+            others["grid9_1080p_160x48_truecolor"] = run_grid9(torch, pkg, max(10, args.steps // 10), 3)
         line["other_workloads"] = others
     if rank == 0:
         print(json.dumps(line))
