@@ -1,16 +1,21 @@
 /*
  * render_kernels.hpp -- MI355X (gfx950) kernels of the image -> ASCII/ANSI render path.
  *
- * One workgroup renders one frame end to end, fused:
+ * One workgroup renders one frame -- or one band of text rows of it (small batches) -- end to end, fused:
  *
  *   A  gather    nearest-neighbour point samples straight from the source frame in HBM
  *                (reference: image_resize_interpolation, lib/video/rgba/image.c:267-328) -- the
- *                resized image is never materialised; samples + run keys are parked in LDS
+ *                resized image is never materialised; samples are requested as raw dwords (all of a
+ *                thread's requests in flight together, the next chunk's during this chunk's B-E) and
+ *                parked in LDS with their run keys
  *   B  heads     run-head / ASCII-glyph bitmasks via wave64 ballots
- *   C  lengths   every cell computes the exact byte length of the token it owns
- *   D  scan      exclusive scan of token lengths (per-thread segment + wave64 shuffle scan + LDS carry)
- *   E  emit      every cell writes its token into an LDS ring; the ring is drained to HBM with
- *                16-byte coalesced stores
+ *   C  tokens    every cell builds the register-resident descriptor of the token it owns and its
+ *                exact byte length
+ *   D  scan      exclusive scan of token lengths (DPP wave scans + one LDS exchange of wave totals);
+ *                bands publish / look back their byte counts here
+ *   E  emit      every cell writes its token into a linear LDS staging buffer (byte stores, or aligned
+ *                atomic ORs of register-built dwords for 41-byte half-block tokens); windows cut at
+ *                token boundaries are drained to HBM with 16-byte non-temporal stores
  *
  * The reference emits bytes with a sequential state machine (colour-change-only SGR, REP run-length
  * sequences, per-row resets, transparent half-block runs).  Here every piece of that state is
@@ -441,7 +446,7 @@ template <int MODE, int BLOCK, int CAP, int RING> struct Lds {
   static constexpr int o_ramp = o_glyph64 + 64 * 4;
   static constexpr int o_dec = o_ramp + 64;     /* 256 decimal-field entries */
   static constexpr int o_wsum = o_dec + 256 * 4; /* SEG*NW wave totals (<= 64) */
-  static constexpr int o_flags = o_wsum + 64 * 4; /* [0] palette-not-all-ASCII, [1],[2] window cut (ping-pong), [3] predecessors' byte
+  static constexpr int o_flags = o_wsum + 64 * 4; /* [0] unused, [1],[2] window cut (ping-pong), [3] predecessors' byte
                                                      count (multi-part frames), [4] dummy store target */
   static constexpr int o_prof = o_flags + 32;     /* 8 x u64 diagnostics accumulators */
   static constexpr int o_carry = o_prof + 8 * 8;             /* dither: error sums entering the next row, 3 x int per column */
