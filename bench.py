@@ -115,6 +115,30 @@ def run_workload(torch, pkg, name, batch, steps, warmup, dist=None, seed=1234, v
     return res
 
 
+def time_with_d2h(torch, plan, n, steps):
+    """the same steps with the output copied to pinned host memory after every launch -- slab and
+    lengths share one allocation so that they cross PCIe in ONE transfer (a second, tiny copy behind the big one
+    costs more than the big one).  The PCIe-inclusive rate, never `value`."""
+    stream = torch.cuda.current_stream().cuda_stream
+    slab = n * plan.stride
+    buf = torch.empty(slab + 4 * n, dtype=torch.uint8, device="cuda")
+    host = torch.empty(buf.shape, dtype=buf.dtype, pin_memory=True)
+    out_ptr, len_ptr = buf.data_ptr(), buf.data_ptr() + slab
+
+    def step():
+        plan.render(out_ptr, plan.stride, len_ptr, stream)
+        host.copy_(buf, non_blocking=True)
+
+    for _ in range(30):  # the first transfers into a fresh pinned block are slow
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps, int(buf.numel())
+
+
 def run_grid9(torch, pkg, steps, warmup):
     """BASELINE configs[3]: nine 1080p sources -> the 3x3 grid at 160x48 for each of the nine clients.  One launch
     renders the nine client frames straight from the sources (the W x 2H canvas of create_multi_source_composite
@@ -269,6 +293,10 @@ def main():
         line["roofline"]["traffic"] = traffic["hbm_bytes"]
         line["roofline"]["traffic_detail"] = traffic
     if rank == 0 and world == 1:
+        d2h_s, d2h_bytes = time_with_d2h(torch, res["plan"], args.batch, max(50, args.steps // 4))
+        line["with_d2h"] = {"ms_per_step": d2h_s * 1e3, "frames_per_s": args.batch / d2h_s, "copied_bytes_per_step": d2h_bytes,
+                            "GBps": d2h_bytes / d2h_s / 1e9,
+                            "note": "whole fixed-stride slab + lengths to pinned host memory after every launch; PCIe-bound"}
         if not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(args.workload)
         others = {}
