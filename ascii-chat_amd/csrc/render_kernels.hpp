@@ -1148,8 +1148,12 @@ __global__ void __launch_bounds__(BLOCK)
   }
 
   /* i / wp == umulhi(i, magic) for i, wp <= CAP (i * wp < 2^32); wp == 1 would need magic 2^32 */
-  const uint32_t wp_magic = wp > 1 ? (uint32_t)(0x100000000ull / (uint32_t)wp) + 1u : 0u;
-  const int rows_per_chunk = max(1, CAP / wp);
+  /* One float division instead of a 64-bit integer one (a ~150-instruction dependent chain in front of the
+   * first gather): any m with 2^32/wp < m < 2^32/wp + 256 divides exactly for i * wp <= 2^24; the float quotient
+   * is within 64 of the true one, so +65 lands inside (checked exhaustively for wp <= 4096, i <= 4096 in
+   * tests/test_cabi_host.py). */
+  const uint32_t wp_magic = wp > 1 ? (uint32_t)(4294967296.0f / (float)wp) + 65u : 0u;
+  const int rows_per_chunk = max(1, row_of(CAP, wp_magic));
   const uint32_t cap_bytes = out_stride > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)out_stride;
   const uint32_t ring_addr = lds_base_addr() + (uint32_t)L::o_ring;
   const uint32_t dummy_addr = lds_base_addr() + (uint32_t)L::o_flags + 16u;

@@ -213,6 +213,15 @@ def test_palette_cache_matches_oracle_and_is_shared(pkg):
     assert not L.get_utf8_palette_cache(None) and not L.get_utf8_palette_cache(b"")
 
 
+def test_row_divisor_magic_is_exact():
+    """The frame kernel divides cell indices by the padded row width with umulhi(i, m), m = uint32(2^32 / wp in
+    float32) + 65 (render_kernels.hpp): exact for every row width and cell index a chunk can hold."""
+    for wp in range(2, 4097):
+        m = int(np.uint32(np.float32(4294967296.0) / np.float32(wp))) + 65
+        i = np.arange(0, 4097, dtype=np.uint64)
+        assert (((i * np.uint64(m)) >> np.uint64(32)) == i // np.uint64(wp)).all(), wp
+
+
 def test_rle_and_frame_validator_utilities(pkg):
     """SURVEY 8f.4 leftovers (rle.c, frame_validator.c): product vs the oracle's independent restatement, plus the
     properties that make them useful as checkers: expanding a REP-compressed mono frame gives W characters per
