@@ -1494,12 +1494,15 @@ __global__ void __launch_bounds__(BLOCK)
       const bool final_flush = last_chunk && cut == chunk_end; /* the tail bytes go out too: nothing to carry */
       drain_ring<BLOCK, EMIT_OR>(L::o_ring, dst, lo, cut, max(own_from, lo), final_flush);
       flushed = cut & ~15u;
-      if (tid == 0 && flushed > lo && !final_flush) { /* tid 0 drained group 0 itself (program order): safe to overwrite it */
-        for (uint32_t j = 0; j < cut - flushed; j++) {
-          ring[j] = ring[flushed - lo + j];
-          if (EMIT_OR)
-            ring[flushed - lo + j] = 0;
-        }
+      if (tid == 0 && flushed > lo && cut > flushed && !final_flush) {
+        /* the < 16 bytes behind the last flushed group move to the front as ONE 16-byte group (a byte loop here
+         * is a chain of dependent LDS round trips between every two chunks).  tid 0 drained group 0 itself
+         * (program order), so it may overwrite it; the bytes behind `cut` in the group are stale (FastSink: the
+         * next window overwrites them) or zero (PackSink: they must stay zero, and the source group is cleared) */
+        uint4 *src = reinterpret_cast<uint4 *>(ring + (flushed - lo));
+        *reinterpret_cast<uint4 *>(ring) = *src;
+        if (EMIT_OR)
+          *src = make_uint4(0u, 0u, 0u, 0u);
       }
       done = cut;
       if (cut >= chunk_end) {
