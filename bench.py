@@ -232,6 +232,7 @@ def main():
     ap.add_argument("--others", default="1080p_80x24_ansi256,4k_200x60_truecolor,4k_400x120_halfblock",
                     help="comma list of extra workloads reported under other_workloads (N=1 only); '' = none")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-d2h", action="store_true", help="skip the PCIe-inclusive with_d2h leg (profiling runs)")
     ap.add_argument("--variant", type=int, default=-1)
     args = ap.parse_args()
 
@@ -293,10 +294,11 @@ def main():
         line["roofline"]["traffic"] = traffic["hbm_bytes"]
         line["roofline"]["traffic_detail"] = traffic
     if rank == 0 and world == 1:
-        d2h_s, d2h_bytes = time_with_d2h(torch, res["plan"], args.batch, max(50, args.steps // 4))
-        line["with_d2h"] = {"ms_per_step": d2h_s * 1e3, "frames_per_s": args.batch / d2h_s, "copied_bytes_per_step": d2h_bytes,
-                            "GBps": d2h_bytes / d2h_s / 1e9,
-                            "note": "whole fixed-stride slab + lengths to pinned host memory after every launch; PCIe-bound"}
+        if not args.no_d2h:
+            d2h_s, d2h_bytes = time_with_d2h(torch, res["plan"], args.batch, max(50, args.steps // 4))
+            line["with_d2h"] = {"ms_per_step": d2h_s * 1e3, "frames_per_s": args.batch / d2h_s,
+                                "copied_bytes_per_step": d2h_bytes, "GBps": d2h_bytes / d2h_s / 1e9,
+                                "note": "whole fixed-stride slab + lengths to pinned host memory after every launch; PCIe-bound"}
         if not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(args.workload)
         others = {}
