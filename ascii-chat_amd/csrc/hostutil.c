@@ -542,9 +542,11 @@ char *ascii_create_grid(ascii_frame_source_t *sources, int source_count, int wid
       while (pos < n && src[pos] != '\n')
         pos++;
       const int take = bytes_for_columns(src + line, pos - line, cell_w);
-      /* raw bytes are pasted: escape-laden lines may overrun the cell in byte space, exactly as upstream */
-      if (take > 0 && col0 + columns_of(src + line, take) <= width)
-        memcpy(canvas + (size_t)(row0 + line_no) * (size_t)(width + 1) + (size_t)col0, src + line, (size_t)take);
+      /* raw bytes are pasted: escape-laden lines may overrun the cell in byte space, exactly as upstream -- but never
+       * the canvas: upstream's SAFE_MEMCPY(dest, mixed_size - mixed_pos, ...) refuses such a copy as a whole */
+      const size_t at = (size_t)(row0 + line_no) * (size_t)(width + 1) + (size_t)col0;
+      if (take > 0 && col0 + columns_of(src + line, take) <= width && (size_t)take <= total - at)
+        memcpy(canvas + at, src + line, (size_t)take);
       if (pos < n && src[pos] == '\n')
         pos++;
     }
@@ -568,6 +570,8 @@ char *ascii_create_grid(ascii_frame_source_t *sources, int source_count, int wid
       }
     }
   }
+  canvas[total - 1] = '\0'; /* a paste that ends exactly at the end of the canvas takes the terminator with it; upstream
+                               then runs strlen() off the block (ascii.c:883) -- the only place where we differ */
   *out_size = strlen(canvas);
   return canvas;
 }

@@ -1002,7 +1002,9 @@ char *orc_create_grid(const orc_frame_source_t *sources, int n, int width, int h
       if (copy > 0 && c0 + vw <= width) {
         /* raw bytes are copied, so escape-laden lines may overrun the cell in byte space (reference behaviour) */
         size_t at = (size_t)(r0 + srow) * (size_t)(width + 1) + (size_t)c0;
-        memcpy(mix + at, sd + ls, (size_t)copy);
+        if ((size_t)copy <= total - at) /* SAFE_MEMCPY(dest, mixed_size - mixed_pos, ..): a copy that would leave the
+                                           canvas is refused as a whole (lib/platform/posix/system.c:653-666) */
+          memcpy(mix + at, sd + ls, (size_t)copy);
       }
       if (pos < ss && sd[pos] == '\n')
         pos++;
@@ -1028,6 +1030,8 @@ char *orc_create_grid(const orc_frame_source_t *sources, int n, int width, int h
       }
     }
   }
+  mix[total - 1] = '\0'; /* the reference's strlen (ascii.c:883) is undefined when a paste took the terminator with it;
+                            outside that case this line changes nothing */
   *out_size = strlen(mix);
   return mix;
 }

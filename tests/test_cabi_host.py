@@ -171,6 +171,19 @@ def test_host_utilities_match_oracle(pkg):
         got = C.string_at(p, sz.value)
         L.free(p)
         assert got == orc.create_grid(frames[:n], w, h), (n, w, h)
+    # escape-laden lines in the last grid cell: pasting them raw would run past the canvas; the reference's
+    # SAFE_MEMCPY refuses such a copy as a whole (lib/platform/posix/system.c:653-666) and so do product and oracle
+    heavy = [orc.convert_with_caps(img, 40, 12, 3, 0) for _ in range(4)]
+    for (w, h) in ((41, 13), (60, 9), (25, 7), (100, 30)):
+        arr = (pkg.FrameSource * 4)()
+        for i in range(4):
+            arr[i].frame_data = heavy[i]
+            arr[i].frame_size = len(heavy[i])
+        p = L.ascii_create_grid(arr, 4, w, h, C.byref(sz))
+        got = C.string_at(p, sz.value)
+        L.free(p)
+        assert got == orc.create_grid(heavy, w, h), (w, h)
+        assert len(got) <= w * h + h
     assert not L.ascii_create_grid(None, 1, 80, 24, C.byref(sz))
 
 
