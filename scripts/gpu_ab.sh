@@ -5,6 +5,6 @@ mkdir -p $OUT; : > $OUT/ab.txt
 cd $GRAFT_REPO_ROOT
 for rep in 1 2; do
 for lib in ascii-chat_amd/libasciichat_hip.so $(ls gpurun_tmp/*.so); do
-  ASCIICHAT_HIP_LIB=$GRAFT_REPO_ROOT/$lib timeout 300 python scripts/gpu_tune.py --batch 256 --variants=-1 --splits=-1 --reps 100 --workloads 4k_400x120_halfblock,640x480_80x24_mono 2>&1 | grep -v amdgpu.ids | sed "s|^|$(basename $lib) |" | cut -c1-330 | tee -a $OUT/ab.txt
+  ASCIICHAT_HIP_LIB=$GRAFT_REPO_ROOT/$lib timeout 300 python scripts/gpu_tune.py --batch 256 --variants=-1 --splits=-1 --reps 100 2>&1 | grep -v amdgpu.ids | sed "s|^|$(basename $lib) |" | cut -c1-330 | tee -a $OUT/ab.txt
 done
 done

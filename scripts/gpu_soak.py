@@ -93,7 +93,51 @@ def main():
             checked += 1
         print(f"round {rnd:3d}: {MODE_NAMES[mode]:10s} frames {len(frames):3d} geometry v{plan.variant} bands {plan.parts:3d} ok", flush=True)
         plan.close()
-    print(f"soak OK: {checked} frames byte-identical to the oracle")
+    # pixel-space composites (the server's multi-source grid): random source counts / sizes / terminal sizes,
+    # rendered fused (canvas never built) for several client modes at once
+    import ctypes as C
+    comp_checked = 0
+    for rnd in range(max(1, args.rounds // 4)):
+        n_src = int(rng.integers(1, 10))
+        tw, th = int(rng.integers(20, 260)), int(rng.integers(8, 90))
+        imgs = [random_image(rng, int(rng.integers(16, 900)), int(rng.integers(16, 500))) for _ in range(n_src)]
+        dev = [torch.from_numpy(np.ascontiguousarray(i)).cuda() for i in imgs]
+        ptrs = (C.c_void_p * n_src)(*[d.data_ptr() for d in dev])
+        ws = (C.c_int * n_src)(*[i.shape[1] for i in imgs])
+        hs = (C.c_int * n_src)(*[i.shape[0] for i in imgs])
+        comp = pkg.Composite()
+        pkg.lib().achip_composite_setup(C.byref(comp), ptrs, ws, hs, n_src, tw, th)
+        comp_dev = C.c_void_p()
+        assert pkg.lib().asciichat_hip_composite_upload(C.byref(comp), C.byref(comp_dev)) == 0
+        canvas = orc.composite(imgs, tw, th)
+        mode = int(rng.choice([0, 1, 2, 3, 5, 6, 8]))
+        cl, rm = MODE_CAPS[mode]
+        pad = bool(rng.integers(0, 2))
+        h = 2 * th if rm == 2 else th
+        nclients = int(rng.choice([1, 3, 9, 40]))
+        frames = []
+        for _ in range(nclients):
+            f = pkg.frame_setup(None, tw, 2 * th, tw, h, rm, pad, True, False)
+            assert f is not None
+            f.comp = comp_dev.value
+            frames.append(f)
+        plan = pkg.Plan(mode, orc.PALETTE_STANDARD, frames)
+        if rng.integers(0, 3) == 0:
+            plan.set_split(-1)
+        out = torch.zeros(nclients * plan.stride, dtype=torch.uint8, device="cuda")
+        ln = torch.zeros(nclients, dtype=torch.int32, device="cuda")
+        plan.render(out.data_ptr(), plan.stride, ln.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        exp = orc.convert_with_caps(canvas, tw, h, cl, rm, pad, True, False)
+        host, lens = out.cpu().numpy(), ln.cpu().numpy().astype(np.uint32)
+        for k in range(nclients):
+            got = host[k * plan.stride:k * plan.stride + int(lens[k])].tobytes()
+            assert got == exp, ("composite", rnd, MODE_NAMES[mode], n_src, tw, th, pad, k, plan.variant, plan.parts)
+            comp_checked += 1
+        print(f"composite {rnd:3d}: {MODE_NAMES[mode]:10s} sources {n_src} term {tw}x{th} clients {nclients:2d} v{plan.variant} bands {plan.parts:3d} ok", flush=True)
+        plan.close()
+        pkg.lib().asciichat_hip_free(comp_dev)
+    print(f"soak OK: {checked} frames + {comp_checked} composite frames byte-identical to the oracle")
 
 
 if __name__ == "__main__":
