@@ -251,7 +251,30 @@ static char *render_with_lut(tls_ctx_t *c, const achip_lut_t *lut, int mode, con
   return out;
 }
 
+static char *render_unpadded_one(int mode, const char *palette, achip_frame_t *f, size_t src_bytes);
+
+/* The kernel models padding as pseudo-cells of the text row, and a row holds at most 4096 cells.  A terminal so
+ * wide that padding alone exceeds that (> 4096 columns) is served the way the reference does it: render the
+ * unpadded frame, then ascii_pad_frame_width / ascii_pad_frame_height on the finished string (ascii.c:358-385). */
 static char *render_one(int mode, const char *palette, achip_frame_t *f, size_t src_bytes) {
+  if (f->pad_left + f->out_w <= achip_variant_cap(0))
+    return render_unpadded_one(mode, palette, f, src_bytes);
+  const size_t pad_left = (size_t)f->pad_left, pad_top = (size_t)f->pad_top;
+  f->pad_left = 0;
+  f->pad_top = 0;
+  char *plain = render_unpadded_one(mode, palette, f, src_bytes);
+  if (!plain)
+    return NULL;
+  char *wide = ascii_pad_frame_width(plain, pad_left);
+  free(plain);
+  if (!wide)
+    return NULL;
+  char *tall = ascii_pad_frame_height(wide, pad_top);
+  free(wide);
+  return tall;
+}
+
+static char *render_unpadded_one(int mode, const char *palette, achip_frame_t *f, size_t src_bytes) {
   tls_ctx_t *c = tls_get();
   if (!c)
     return NULL;

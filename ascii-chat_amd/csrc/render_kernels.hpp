@@ -699,7 +699,8 @@ template <int MODE, class L> __device__ inline Tok build_token(const Chunk &c, i
 
     if (MODE == ACHIP_MODE_MONO) {
       /* image_print (foreground.c:86-127): key = ramp[Y>>2], glyph = cache64[key] (double mapping) */
-      t.glyph = glyph64[px_key(pt)];
+      /* palettes of more than 64 characters: the reference reads past cache64[64] here (undefined); clamped */
+      t.glyph = glyph64[min(px_key(pt), 63u)];
       if (is_head || !rep)
         t.flags |= TF_GLYPH;
     } else if (MODE == ACHIP_MODE_HB_MONO) {
@@ -1238,6 +1239,8 @@ __global__ void __launch_bounds__(BLOCK)
     const int groups = (int)(min((uint64_t)RING, out_stride + 32u) / 16u);
     for (int k = tid; k < groups; k += BLOCK)
       reinterpret_cast<uint4 *>(ring)[k] = make_uint4(0u, 0u, 0u, 0u);
+    if (f.pad_top > 0 && part == 0)
+      __syncthreads(); /* the newline fill below writes other threads' groups */
   }
   /* ascii_pad_frame_height: pad_top bare newlines, through the same staging buffer */
   if (f.pad_top > 0 && part == 0) {

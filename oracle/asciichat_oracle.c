@@ -292,7 +292,9 @@ char *orc_print_mono(const uint8_t *rgb, int w, int h, const char *palette, size
       while (j < w && pal.ramp[orc_luma(row[3 * j], row[3 * j + 1], row[3 * j + 2]) >> 2] == key)
         j++;
       uint32_t run = (uint32_t)(j - x);
-      const orc_glyph_t *g = &pal.cache64[key];
+      /* a palette of more than 64 characters makes the reference index cache64[] past its 64 entries (undefined
+       * behaviour there: foreground.c:93-102 reads whatever follows the table); product and oracle clamp instead */
+      const orc_glyph_t *g = &pal.cache64[key < 64 ? key : 63];
       sk_mem(&s, g->bytes, g->len);
       if (orc_rep_is_profitable(run)) {
         sk_rep(&s, run - 1);

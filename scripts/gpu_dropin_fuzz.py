@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Randomised calls of the drop-in entry points on the GPU box: odd sizes, zero / negative / huge terminal sizes,
+malformed palettes, every capability combination.  Valid calls must equal the oracle byte for byte, invalid ones
+must return NULL exactly where the oracle (= the reference's argument checks) does; nothing may crash."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import orc  # noqa: E402
+from test_random_differential import random_image  # noqa: E402
+
+
+def main():
+    import torch  # noqa: F401
+
+    from __graft_entry__ import load_package
+
+    pkg = load_package()
+    L = pkg.lib()
+    rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+    pals = [orc.PALETTE_STANDARD.encode(), orc.PALETTE_BLOCKS.encode(), orc.PALETTE_COOL.encode(), b"@", b" .:-=+*#%@",
+            "a█b".encode(), b"\xff\xfe", b"\xe2\x96", b"x" * 200]
+    n_ok = n_null = 0
+    for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 3000):
+        sw, sh = int(rng.choice([1, 2, 3, 7, 64, 333, 640, 1920])), int(rng.choice([1, 2, 5, 48, 201, 480, 1080]))
+        img = random_image(rng, sw, sh)
+        arr = np.ascontiguousarray(img)
+        im = pkg.Image(sw, sh, arr.ctypes.data, 0)
+        W = int(rng.choice([-5, 0, 1, 2, 17, 80, 97, 200, 511, 3000, 10001]))
+        H = int(rng.choice([-1, 0, 1, 3, 24, 31, 60, 140, 2000, 10001]))
+        cl, rm = int(rng.choice([-1, 0, 1, 2, 3])), int(rng.choice([0, 1, 2]))
+        pad, aspect, stretch = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        pal = pals[int(rng.integers(0, len(pals)))]
+        caps = pkg.TermCaps()
+        caps.color_level, caps.render_mode, caps.wants_padding, caps.utf8_support = cl, rm, pad, True
+        palb = pal
+        p = L.ascii_convert_with_capabilities(C.byref(im), W, H, C.byref(caps), aspect, stretch, palb)
+        got = pkg.take_string(p)
+        exp = orc.convert_with_caps(img, W, H, cl, rm, pad, aspect, stretch, palb)
+        assert got == exp, (it, sw, sh, W, H, cl, rm, pad, aspect, stretch, palb[:12], None if got is None else len(got), None if exp is None else len(exp))
+        if got is None:
+            n_null += 1
+        else:
+            n_ok += 1
+    print(f"drop-in fuzz OK: {n_ok} renders byte-identical, {n_null} NULL returns matching the oracle")
+
+
+if __name__ == "__main__":
+    main()

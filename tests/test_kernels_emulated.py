@@ -103,3 +103,15 @@ def test_display_prepasses_folded_into_sampler():
             assert got == exp, (mode, fx, fy, flt)
     f = emu.frame_for_convert(img, 97, 31, 0)
     assert emu.lib().achip_frame_set_display_ops(C.byref(f), False, False, 12) == -1  # rainbow: not a pixel pre-pass
+
+
+def test_tall_padding_crosses_threads_groups():
+    """pad_top in the thousands (a terminal far taller than the fitted frame): the newline fill of one thread lands in
+    staging groups that other threads zero for the OR-filled half-block buffer -- ordered by a barrier."""
+    img = orc.frame_hash_noise(7, 2, 3)
+    for (W, H, mode) in ((1, 10001, 5), (80, 4000, 1), (3, 9000, 0), (40, 2500, 6)):
+        cl, rm = MODE_CAPS[mode]
+        exp = orc.convert_with_caps(img, W, H, cl, rm, True, True, False, "@")
+        f = emu.frame_for_convert(img, W, H, rm, True, True)
+        for variant in (4, 3):
+            assert emu.render_frames(mode, [f], "@", variant)[0] == exp, (W, H, mode, variant)
