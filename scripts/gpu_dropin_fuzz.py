@@ -48,6 +48,50 @@ def main():
         else:
             n_ok += 1
     print(f"drop-in fuzz OK: {n_ok} renders byte-identical, {n_null} NULL returns matching the oracle")
+    # the other entry points: ascii_convert (mode from the global option), image_print_* on images as they are,
+    # half-block functions with explicit strides
+    lum = C.create_string_buffer(b"x" * 255, 256)
+    n2 = 0
+    for it in range((int(sys.argv[2]) if len(sys.argv) > 2 else 3000) // 2):
+        sw, sh = int(rng.choice([1, 2, 3, 7, 61, 200, 333, 640])), int(rng.choice([1, 2, 5, 23, 48, 201, 480]))
+        img = random_image(rng, sw, sh)
+        arr = np.ascontiguousarray(img)
+        im = pkg.Image(sw, sh, arr.ctypes.data, 0)
+        pal = pals[int(rng.integers(0, 6))]
+        which = int(rng.integers(0, 4))
+        if which == 0:
+            W, H = int(rng.choice([0, 1, 17, 80, 200, 4000])), int(rng.choice([0, 1, 24, 60, 3000]))
+            color, opt = bool(rng.integers(0, 2)), int(rng.integers(0, 3))
+            aspect, stretch = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+            L.asciichat_hip_set_option_render_mode(opt)
+            got = pkg.take_string(L.ascii_convert(C.byref(im), W, H, color, aspect, stretch, pal, lum))
+            exp = orc.convert(img, W, H, color, aspect, stretch, pal, opt)
+            L.asciichat_hip_set_option_render_mode(0)
+            ctx = ("ascii_convert", sw, sh, W, H, color, opt, aspect, stretch)
+        elif which == 1:
+            cl, rm = int(rng.choice([-1, 0, 1, 2, 3])), int(rng.choice([0, 1, 2]))
+            caps = pkg.TermCaps()
+            caps.color_level, caps.render_mode, caps.utf8_support = cl, rm, True
+            got = pkg.take_string(L.image_print_with_capabilities(C.byref(im), C.byref(caps), pal))
+            exp = orc.print_with_caps(img, cl, rm, pal)
+            ctx = ("image_print_with_capabilities", sw, sh, cl, rm)
+        elif which == 2:
+            fn, (cl, rm) = [("image_print", (0, 0)), ("image_print_color", (3, 0)), ("image_print_256color", (2, 0)),
+                            ("image_print_16color", (1, 0))][int(rng.integers(0, 4))]
+            got = pkg.take_string(getattr(L, fn)(C.byref(im), pal))
+            exp = orc.print_with_caps(img, cl, rm, pal)
+            ctx = (fn, sw, sh)
+        else:
+            fn, cl = [("rgb_to_truecolor_halfblocks_scalar", 3), ("rgb_to_256color_halfblocks_scalar", 2),
+                      ("rgb_to_16color_halfblocks_scalar", 1), ("rgb_to_halfblocks_scalar", 0)][int(rng.integers(0, 4))]
+            sub = int(rng.integers(1, sw + 1))  # the left `sub` columns through an explicit stride
+            args = (im.pixels, sub, sh, sw * 3) if cl == 3 else (im.pixels, sub, sh, sw * 3, pal)  # palette unused by them
+            got = pkg.take_string(getattr(L, fn)(*args))
+            exp = orc.print_with_caps(np.ascontiguousarray(img[:, :sub]), cl, 2)
+            ctx = (fn, sw, sh, sub)
+        assert got == exp, (it, ctx, pal[:8], None if got is None else len(got), None if exp is None else len(exp))
+        n2 += 1
+    print(f"drop-in fuzz OK: {n2} calls of the other entry points match the oracle")
 
 
 if __name__ == "__main__":
