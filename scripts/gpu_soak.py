@@ -76,8 +76,18 @@ def main():
         ln = torch.zeros(len(frames), dtype=torch.int32, device="cuda")
         for _ in range(2):
             plan.render(out.data_ptr(), plan.stride, ln.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        # wire stage over the same slab: CRC-32C, packet headers, packet CRCs
+        nfr = len(frames)
+        dims_t = torch.tensor([[c[1], c[2]] for c in cases], dtype=torch.int32, device="cuda")
+        crc_t = torch.zeros(nfr, dtype=torch.int32, device="cuda")
+        hdr_t = torch.zeros(nfr * 24, dtype=torch.uint8, device="cuda")
+        pkt_t = torch.zeros(nfr, dtype=torch.int32, device="cuda")
+        assert pkg.lib().asciichat_hip_frame_packets(out.data_ptr(), plan.stride, ln.data_ptr(), plan.stride, nfr, dims_t.data_ptr(),
+                                                     crc_t.data_ptr(), hdr_t.data_ptr(), pkt_t.data_ptr(),
+                                                     torch.cuda.current_stream().cuda_stream) == 0, pkg.last_error()
         torch.cuda.synchronize()
         host, lens = out.cpu().numpy(), ln.cpu().numpy().astype(np.uint32)
+        crc_h, pkt_h, hdr_h = crc_t.cpu().numpy().astype(np.uint32), pkt_t.cpu().numpy().astype(np.uint32), hdr_t.cpu().numpy()
         memo = {}
         for k, (img, W, H) in enumerate(cases):
             assert lens[k] < 0xFFFFFFF0, (rnd, k, hex(int(lens[k])))
@@ -90,6 +100,9 @@ def main():
                 else:
                     memo[key] = oracle_case(img, W, H, mode, aspect, pad, palette)
             assert got == memo[key], (rnd, MODE_NAMES[mode], k, img.shape, W, H, pad, aspect, palette, plan.variant, plan.parts, flt, fx, fy)
+            if k < 24:  # the bit-serial oracle CRC is slow: a sample per batch
+                eh, ep = orc.ascii_frame_packet(got, W, H)
+                assert int(crc_h[k]) == orc.crc32c(got) and hdr_h[24 * k:24 * k + 24].tobytes() == eh and int(pkt_h[k]) == ep, ("crc", rnd, k, len(got))
             checked += 1
         print(f"round {rnd:3d}: {MODE_NAMES[mode]:10s} frames {len(frames):3d} geometry v{plan.variant} bands {plan.parts:3d} ok", flush=True)
         plan.close()
