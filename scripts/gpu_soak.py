@@ -104,6 +104,36 @@ def main():
                 eh, ep = orc.ascii_frame_packet(got, W, H)
                 assert int(crc_h[k]) == orc.crc32c(got) and hdr_h[24 * k:24 * k + 24].tobytes() == eh and int(pkt_h[k]) == ep, ("crc", rnd, k, len(got))
             checked += 1
+        # the same plan after an update to new terminal sizes (the tick when clients resize), rendered as two
+        # sub-ranges into the slab (what the ranks of a sharded batch do)
+        if rnd % 3 == 0 and (flt or fx or fy) == 0:
+            frames2, cases2 = [], []
+            for (img, _, _), f_old in zip(cases, frames):
+                W2, H2 = (int(rng.integers(1, 200)), int(rng.integers(1, 70)))
+                f2 = pkg.frame_setup(f_old.src, img.shape[1], img.shape[0], W2, H2, rm, pad, aspect, False)
+                if f2 is None:
+                    f2, W2, H2 = f_old, None, None
+                frames2.append(f2)
+                cases2.append((img, W2, H2))
+            try:
+                plan.update(frames2, torch.cuda.current_stream().cuda_stream)
+            except RuntimeError:
+                frames2 = None  # the forced geometry cannot hold the new rows: a caller would rebuild the plan
+            if frames2 is not None:
+                out2 = torch.full((len(frames2) * plan.stride,), 0xCD, dtype=torch.uint8, device="cuda")
+                half = len(frames2) // 2
+                st2 = torch.cuda.current_stream().cuda_stream
+                plan.render(out2.data_ptr(), plan.stride, ln.data_ptr(), st2, 0, half)
+                plan.render(out2.data_ptr() + half * plan.stride, plan.stride, ln.data_ptr() + 4 * half, st2, half, len(frames2) - half)
+                torch.cuda.synchronize()
+                host2, lens2 = out2.cpu().numpy(), ln.cpu().numpy().astype(np.uint32)
+                for k, (img, W2, H2) in enumerate(cases2):
+                    if W2 is None:
+                        continue
+                    assert lens2[k] < 0xFFFFFFF0
+                    got2 = host2[k * plan.stride:k * plan.stride + int(lens2[k])].tobytes()
+                    assert got2 == oracle_case(img, W2, H2, mode, aspect, pad, palette), ("update", rnd, k, W2, H2, plan.variant, plan.parts)
+                    checked += 1
         print(f"round {rnd:3d}: {MODE_NAMES[mode]:10s} frames {len(frames):3d} geometry v{plan.variant} bands {plan.parts:3d} ok", flush=True)
         plan.close()
     # pixel-space composites (the server's multi-source grid): random source counts / sizes / terminal sizes,
