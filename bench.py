@@ -246,20 +246,27 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available() or pkg.lib().asciichat_hip_device_count() <= 0:
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (this path has no CPU fallback)")
+    # one process per GPU; ASCIICHAT_BENCH_BACKEND=gloo lets several ranks share a GPU for testing the N > 1 control flow
+    backend = os.environ.get("ASCIICHAT_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as d
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        d.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            d.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            d.init_process_group(backend)
         dist = d
 
     res = run_workload(torch, pkg, args.workload, args.batch, args.steps, args.warmup, dist, seed=1234 + rank,
                        variant=args.variant)
     wall = res["wall_s"]
     if dist is not None:
-        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        t = torch.tensor([wall], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
     total_frames = args.batch * args.steps * world
