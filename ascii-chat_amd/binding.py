@@ -132,6 +132,8 @@ def lib():
     L.achip_frame_setup.argtypes = [C.POINTER(Frame), vp, ci, ci, ss, ss, ci, C.c_bool, C.c_bool, C.c_bool]
     L.achip_frame_set_display_ops.restype = ci
     L.achip_frame_set_display_ops.argtypes = [C.POINTER(Frame), C.c_bool, C.c_bool, ci]
+    L.achip_frame_set_dither_style.restype = ci
+    L.achip_frame_set_dither_style.argtypes = [C.POINTER(Frame), C.c_bool, C.c_bool]
     L.achip_frame_identity.restype = ci
     L.achip_frame_identity.argtypes = [C.POINTER(Frame), vp, ci, ci]
     L.achip_out_bound.restype = sz
@@ -155,6 +157,10 @@ def lib():
         f.argtypes = [C.POINTER(Image), C.c_char_p]
     L.image_print_color_simd.restype = vp
     L.image_print_color_simd.argtypes = [C.POINTER(Image), C.c_bool, C.c_bool, C.c_char_p]
+    L.image_print_16color_dithered.restype = vp
+    L.image_print_16color_dithered.argtypes = [C.POINTER(Image), C.c_char_p]
+    L.image_print_16color_dithered_with_background.restype = vp
+    L.image_print_16color_dithered_with_background.argtypes = [C.POINTER(Image), C.c_bool, C.c_char_p]
     L.rgb_to_truecolor_halfblocks_scalar.restype = vp
     L.rgb_to_truecolor_halfblocks_scalar.argtypes = [vp, ci, ci, ci]
     for name in ("rgb_to_256color_halfblocks_scalar", "rgb_to_16color_halfblocks_scalar", "rgb_to_halfblocks_scalar"):

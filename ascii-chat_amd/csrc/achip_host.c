@@ -131,7 +131,16 @@ int achip_frame_set_display_ops(achip_frame_t *f, bool flip_x, bool flip_y, int 
             ((uint32_t)k_filters[color_filter].b << 16))
            << ACHIP_OP_TINT_SHIFT;
   }
-  f->ops = ops;
+  f->ops = (f->ops & ACHIP_OP_DITHER_MASK) | ops;
+  return 0;
+}
+
+int achip_frame_set_dither_style(achip_frame_t *f, bool use_background, bool ramp_glyph) {
+  if (!f || (use_background && ramp_glyph)) /* the ramp glyph only exists in the foreground-only function */
+    return -1;
+  f->ops &= ~ACHIP_OP_DITHER_MASK;
+  if (!use_background)
+    f->ops |= ACHIP_OP_DITHER_FG | (ramp_glyph ? ACHIP_OP_DITHER_RAMP : 0u);
   return 0;
 }
 

@@ -408,14 +408,19 @@ void image_resize(const image_t *s, image_t *d) {
 /* ------------------------------------------------------------------------------------------- */
 /* renderers on an already-sized image (scalar/foreground.h, background.h, halfblock.h)          */
 /* ------------------------------------------------------------------------------------------- */
-static char *print_identity(int mode, const uint8_t *rgb, int w, int h, int stride_bytes, const char *palette) {
+static char *print_identity_ops(int mode, uint32_t ops, const uint8_t *rgb, int w, int h, int stride_bytes,
+                                const char *palette) {
   achip_frame_t f;
   if (achip_frame_identity(&f, rgb, w, h) != 0) {
     achip_fail(ERROR_INVALID_PARAM, "invalid dimensions h=%d, w=%d", h, w);
     return NULL;
   }
+  f.ops |= ops;
   f.src_stride = stride_bytes > 0 ? stride_bytes : w * 3;
   return render_one(mode, palette, &f, (size_t)f.src_stride * (size_t)(h - 1) + (size_t)w * 3u);
+}
+static char *print_identity(int mode, const uint8_t *rgb, int w, int h, int stride_bytes, const char *palette) {
+  return print_identity_ops(mode, 0u, rgb, w, h, stride_bytes, palette);
 }
 
 static char *print_image(int mode, const image_t *p, const char *palette) {
@@ -451,6 +456,41 @@ char *image_print_color_simd(image_t *image, bool use_background_mode, bool use_
   if (use_background_mode) /* image_print_16color_dithered_with_background(image, true, ..) */
     return print_image(ACHIP_MODE_16_DITHER_BG, image, ascii_chars);
   return use_256color ? image_print_256color(image, ascii_chars) : image_print_color(image, ascii_chars);
+}
+
+/* foreground.c:752-846; with use_background this is what image_print_color_simd dispatches to */
+char *image_print_16color_dithered_with_background(const image_t *image, bool use_background, const char *palette) {
+  if (!image || !image->pixels || !palette) {
+    achip_fail(ERROR_INVALID_PARAM, "image, pixels or palette is NULL");
+    return NULL;
+  }
+  if (image->h <= 0 || image->w <= 0) {
+    achip_fail(ERROR_INVALID_STATE, "invalid dimensions h=%d, w=%d", image->h, image->w);
+    return NULL;
+  }
+  if (palette[0] == '\0') {
+    achip_fail(ERROR_INVALID_STATE, "empty palette");
+    return NULL;
+  }
+  return print_identity_ops(ACHIP_MODE_16_DITHER_BG, use_background ? 0u : ACHIP_OP_DITHER_FG,
+                            (const uint8_t *)image->pixels, image->w, image->h, 0, palette);
+}
+/* foreground.c:650-750: foreground colour only, glyph through the 64-entry ramp */
+char *image_print_16color_dithered(const image_t *image, const char *palette) {
+  if (!image || !image->pixels || !palette) {
+    achip_fail(ERROR_INVALID_PARAM, "image, pixels or palette is NULL");
+    return NULL;
+  }
+  if (image->h <= 0 || image->w <= 0) {
+    achip_fail(ERROR_INVALID_STATE, "invalid dimensions h=%d, w=%d", image->h, image->w);
+    return NULL;
+  }
+  if (palette[0] == '\0') {
+    achip_fail(ERROR_INVALID_STATE, "empty palette");
+    return NULL;
+  }
+  return print_identity_ops(ACHIP_MODE_16_DITHER_BG, ACHIP_OP_DITHER_FG | ACHIP_OP_DITHER_RAMP,
+                            (const uint8_t *)image->pixels, image->w, image->h, 0, palette);
 }
 
 static char *halfblock_entry(int mode, const uint8_t *rgb, int width, int height, int stride_bytes) {

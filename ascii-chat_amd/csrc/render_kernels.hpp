@@ -610,6 +610,7 @@ struct Chunk {
   int rows;        /* text rows in the frame                          */
   bool all_ascii;  /* PT: every glyph of the palette is a single ASCII byte */
   bool carry_have; /* PT: an ASCII-glyph pixel exists before this chunk     */
+  uint32_t ops;    /* achip_frame_t.ops (the dithered renderer's style bits)  */
   uint32_t carry_rgb;
 };
 
@@ -681,10 +682,16 @@ template <int MODE, class L> __device__ inline Tok build_token(const Chunk &c, i
      * foreground = white on dark / black on bright, glyph = cache[Y] of the ORIGINAL pixel */
     const uint32_t idx = px_key(pt), pal = ansi16_rgb(idx);
     const uint32_t bl = (77u * px_r(pal) + 150u * px_g(pal) + 29u * px_b(pal)) / 256u;
-    t.flags |= TF_SGR_BG | TF_SGR_FG | TF_GLYPH;
-    t.bg = sgr16_code(true, idx);
-    t.fg = bl < 127u ? 97u : 30u; /* append_16color_fg(15) / append_16color_fg(0) */
-    t.glyph = glyph[luma601(pt)];
+    if (c.ops & ACHIP_OP_DITHER_FG) { /* the exported foreground-only forms (foreground.c:712-723, 809-819) */
+      t.flags |= TF_SGR_FG | TF_GLYPH;
+      t.fg = sgr16_code(false, idx);
+      t.glyph = (c.ops & ACHIP_OP_DITHER_RAMP) ? glyph[ramp[luma601(pt) >> 2]] : glyph[luma601(pt)];
+    } else {
+      t.flags |= TF_SGR_BG | TF_SGR_FG | TF_GLYPH;
+      t.bg = sgr16_code(true, idx);
+      t.fg = bl < 127u ? 97u : 30u; /* append_16color_fg(15) / append_16color_fg(0) */
+      t.glyph = glyph[luma601(pt)];
+    }
   } else {
     /* run-structured modes: head h, end e, run = e - h */
     const bool is_head = (hmask[i >> 6] >> (i & 63)) & 1ull;
@@ -840,7 +847,8 @@ template <int MODE, class S> __device__ inline void token_fields(S &s, const Tok
       s.template c<1>('m');
     }
   } else if (MODE == ACHIP_MODE_16_DITHER_BG) {
-    put_sgr_16<3>(s, t.bg); /* the 5-byte foreground SGR follows */
+    if (f & TF_SGR_BG)
+      put_sgr_16<3>(s, t.bg); /* the 5-byte foreground SGR follows */
     put_sgr_16<1>(s, t.fg);
   } else {
     if (f & TF_SGR_FG) {
@@ -1169,6 +1177,7 @@ __global__ void __launch_bounds__(BLOCK)
   c.pad_left = f.pad_left;
   c.rows = rows;
   c.all_ascii = MODE == ACHIP_MODE_TRUE_FG && ascii_only;
+  c.ops = f.ops;
   c.carry_have = false;
   c.carry_rgb = 0;
   if (MODE == ACHIP_MODE_TRUE_FG && row_begin > 0) {

@@ -43,6 +43,11 @@ int achip_frame_identity(achip_frame_t *f, const uint8_t *src_dev, int w, int h)
  * color_filter is the reference's color_filter_t (0 none, 1 black .. 11 yellow; 12 = rainbow is a
  * post-pass on the ANSI string there and is rejected here).  Returns 0, or -1 for an unknown filter. */
 int achip_frame_set_display_ops(achip_frame_t *f, bool flip_x, bool flip_y, int color_filter);
+/* ACHIP_MODE_16_DITHER_BG frames: pick which exported form of the dithered renderer the frame follows --
+ * image_print_16color_dithered_with_background(img, use_background, pal) (foreground.c:752-846), or with
+ * ramp_glyph (and !use_background) image_print_16color_dithered(img, pal) (foreground.c:650-750).
+ * Default (never called) = use_background, what image_print_color_simd dispatches to (sgr.c:429-430). */
+int achip_frame_set_dither_style(achip_frame_t *f, bool use_background, bool ramp_glyph);
 
 /* 16.16 nearest-neighbour ratio, image.c:293-294 */
 uint32_t achip_nn_ratio(int src, int dst);

@@ -69,6 +69,12 @@ typedef struct {
 #define ACHIP_OP_TINT 4u        /* grey = (77R+150G+29B)>>8, channel = tint*grey/255          */
 #define ACHIP_OP_TINT_ON_WHITE 8u /* foreground_on_bg filters: (tint*(255-grey) + 255*grey)/255 */
 #define ACHIP_OP_TINT_SHIFT 8   /* bits 31..8: tint colour 0xBBGGRR                           */
+/* ACHIP_MODE_16_DITHER_BG only: the two exported foreground-only forms of the dithered renderer */
+#define ACHIP_OP_DITHER_FG 16u   /* image_print_16color_dithered_with_background(.., false, ..): one fg SGR per
+                                    cell, glyph cache[Y]  (foreground.c:809-819)                */
+#define ACHIP_OP_DITHER_RAMP 32u /* image_print_16color_dithered: as above with the glyph taken through the
+                                    64-entry ramp, cache[ramp[Y>>2]]  (foreground.c:712-723)    */
+#define ACHIP_OP_DITHER_MASK 48u
 
 /* Glyph tables of one palette (utf8_palette_cache_t restated, common.c:380-490).  A glyph is its
  * UTF-8 bytes packed little-endian in a u32; its length follows from the lead byte. */

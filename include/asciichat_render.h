@@ -158,6 +158,10 @@ char *image_print_256color(const image_t *image, const char *palette);
 char *image_print_16color(const image_t *image, const char *palette);
 char *image_print_color_background(const image_t *p, const char *palette);
 char *image_print_color_simd(image_t *image, bool use_background_mode, bool use_256color, const char *ascii_chars);
+/* include/ascii-chat/video/rgba/image.h:462,488 (lib/video/ascii/scalar/foreground.c:650-750, 752-846):
+ * Floyd-Steinberg 16-colour renderers; (.., true, ..) is what image_print_color_simd dispatches to */
+char *image_print_16color_dithered(const image_t *image, const char *palette);
+char *image_print_16color_dithered_with_background(const image_t *image, bool use_background, const char *palette);
 
 /* ---- video/ascii/scalar/halfblock.h ------------------------------------------------------------- */
 char *rgb_to_truecolor_halfblocks_scalar(const uint8_t *rgb, int width, int height, int stride_bytes);

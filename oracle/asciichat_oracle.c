@@ -418,8 +418,8 @@ char *orc_print_truecolor_bg(const uint8_t *rgb, int w, int h, const char *palet
 
 /* PD (foreground.c:752-846 + rgb_to_16color_dithered, ansi.c:511-583): Floyd-Steinberg, int errors,
  * C truncating division; error uses the UNclamped accumulated value. */
-char *orc_print_16_dithered(const uint8_t *rgb, int w, int h, bool use_background, const char *palette,
-                            size_t *len) {
+static char *dithered16(const uint8_t *rgb, int w, int h, bool use_background, bool ramp_glyph, const char *palette,
+                        size_t *len) {
   orc_palette_t pal;
   if (!rgb || w <= 0 || h <= 0 || orc_palette_build(palette, &pal) != 0)
     return NULL;
@@ -455,9 +455,10 @@ char *orc_print_16_dithered(const uint8_t *rgb, int w, int h, bool use_backgroun
       } else {
         sk_mem(&s, t, (size_t)orc_sgr_16(t, 0, idx));
       }
-      /* glyph: with_background variant uses cache[Y] (foreground.c:819); the fg-only function at
-       * foreground.c:650-750 uses cache[ramp[Y>>2]] -- not reachable from any dispatcher. */
-      const orc_glyph_t *gl = &pal.cache[orc_luma(px[0], px[1], px[2])];
+      /* glyph: the with_background function uses cache[Y] (foreground.c:819); the fg-only function at
+       * foreground.c:650-750 uses cache[ramp[Y>>2]] (:719-723) -- not reachable from any dispatcher. */
+      const int Y = orc_luma(px[0], px[1], px[2]);
+      const orc_glyph_t *gl = &pal.cache[ramp_glyph ? pal.ramp[Y >> 2] : Y];
       sk_mem(&s, gl->bytes, gl->len);
     }
     sk_reset(&s);
@@ -466,6 +467,14 @@ char *orc_print_16_dithered(const uint8_t *rgb, int w, int h, bool use_backgroun
   }
   free(err);
   return sk_finish(&s, len);
+}
+/* image_print_16color_dithered_with_background, foreground.c:752-846 */
+char *orc_print_16_dithered(const uint8_t *rgb, int w, int h, bool use_background, const char *palette, size_t *len) {
+  return dithered16(rgb, w, h, use_background, false, palette, len);
+}
+/* image_print_16color_dithered, foreground.c:650-750 */
+char *orc_print_16_dithered_fg(const uint8_t *rgb, int w, int h, const char *palette, size_t *len) {
+  return dithered16(rgb, w, h, false, true, palette, len);
 }
 
 /* ------------------------------------------------------------------------- */

@@ -76,6 +76,7 @@ char *orc_print_16_fg(const uint8_t *rgb, int w, int h, const char *palette, siz
 char *orc_print_truecolor_bg(const uint8_t *rgb, int w, int h, const char *palette, size_t *len);  /* background.c:17-84   */
 char *orc_print_16_dithered(const uint8_t *rgb, int w, int h, bool use_background, const char *palette,
                             size_t *len);                                                          /* foreground.c:752-846 */
+char *orc_print_16_dithered_fg(const uint8_t *rgb, int w, int h, const char *palette, size_t *len); /* foreground.c:650-750 */
 char *orc_halfblock_truecolor(const uint8_t *rgb, int w, int h, size_t *len);                      /* halfblock.c:48-165   */
 char *orc_halfblock_256(const uint8_t *rgb, int w, int h, size_t *len);                            /* halfblock.c:416-524  */
 char *orc_halfblock_16(const uint8_t *rgb, int w, int h, size_t *len);                             /* halfblock.c:297-405  */

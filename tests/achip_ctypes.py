@@ -55,6 +55,8 @@ def bind_host(L):
     L.achip_frame_identity.argtypes = [C.POINTER(Frame), C.c_void_p, C.c_int, C.c_int]
     L.achip_frame_set_display_ops.restype = C.c_int
     L.achip_frame_set_display_ops.argtypes = [C.POINTER(Frame), C.c_bool, C.c_bool, C.c_int]
+    L.achip_frame_set_dither_style.restype = C.c_int
+    L.achip_frame_set_dither_style.argtypes = [C.POINTER(Frame), C.c_bool, C.c_bool]
     L.achip_nn_ratio.restype = C.c_uint32
     L.achip_nn_ratio.argtypes = [C.c_int, C.c_int]
     L.achip_out_bound.restype = C.c_size_t

@@ -64,6 +64,8 @@ def lib():
             f.argtypes = [vp, ci, ci, C.c_char_p, C.POINTER(sz)]
         L.orc_print_16_dithered.restype = vp
         L.orc_print_16_dithered.argtypes = [vp, ci, ci, C.c_bool, C.c_char_p, C.POINTER(sz)]
+        L.orc_print_16_dithered_fg.restype = vp
+        L.orc_print_16_dithered_fg.argtypes = [vp, ci, ci, C.c_char_p, C.POINTER(sz)]
         for name in ("orc_halfblock_truecolor", "orc_halfblock_256", "orc_halfblock_16", "orc_halfblock_mono"):
             f = getattr(L, name)
             f.restype = vp
@@ -176,6 +178,20 @@ def print_with_caps(img, color_level, render_mode, palette=PALETTE_STANDARD):
     n = C.c_size_t()
     p = lib().orc_print_with_caps(img.ctypes.data, img.shape[1], img.shape[0], color_level, render_mode,
                                   _pal(palette), C.byref(n))
+    return _take(p, n.value)
+
+
+def print_16_dithered(img, use_background, palette=PALETTE_STANDARD, ramp_glyph=False):
+    """image_print_16color_dithered_with_background(img, use_background, pal), or with ramp_glyph the
+    foreground-only image_print_16color_dithered(img, pal)"""
+    img = _img(img)
+    n = C.c_size_t()
+    if ramp_glyph:
+        assert not use_background
+        p = lib().orc_print_16_dithered_fg(img.ctypes.data, img.shape[1], img.shape[0], _pal(palette), C.byref(n))
+    else:
+        p = lib().orc_print_16_dithered(img.ctypes.data, img.shape[1], img.shape[0], use_background, _pal(palette),
+                                        C.byref(n))
     return _take(p, n.value)
 
 

@@ -111,6 +111,15 @@ def test_image_print_family_and_halfblocks(api):
         got = api.take_string(getattr(L, fn)(C.byref(im), PAL))
         assert got == orc.print_with_caps(small, cl, rm), fn
     assert api.take_string(L.image_print_color_background(C.byref(im), PAL)) == orc.print_truecolor_bg(small)
+    # the three exported forms of the Floyd-Steinberg renderer (image.h:462,488)
+    for pal in (PAL, orc.PALETTE_BLOCKS.encode()):
+        for bgm in (True, False):
+            got = api.take_string(L.image_print_16color_dithered_with_background(C.byref(im), bgm, pal))
+            assert got == orc.print_16_dithered(small, bgm, pal), bgm
+        got = api.take_string(L.image_print_16color_dithered(C.byref(im), pal))
+        assert got == orc.print_16_dithered(small, False, pal, ramp_glyph=True)
+    assert not L.image_print_16color_dithered(None, PAL)
+    assert not L.image_print_16color_dithered_with_background(C.byref(im), False, None)
     for cl in (0, 1, 2, 3):
         c = caps(api, cl, 2)
         got = api.take_string(L.image_print_with_capabilities(C.byref(im), C.byref(c), PAL))

@@ -79,6 +79,25 @@ def test_dither_multi_sweep_and_carry():
     assert got == exp
 
 
+def test_dither_foreground_only_forms():
+    """image_print_16color_dithered_with_background(.., false, ..) and image_print_16color_dithered (exported,
+    image.h:462,488; no dispatcher reaches them): one fg SGR per cell, glyph cache[Y] / cache[ramp[Y>>2]]."""
+    import ctypes as C
+
+    from achip_ctypes import MODE_16_DITHER_BG
+    for (W, H, variant, pal) in [(61, 23, 4, orc.PALETTE_STANDARD), (10, 150, 0, orc.PALETTE_BLOCKS),
+                                 (130, 3, 2, "é漢😀 .")]:
+        img = orc.resize_nn(orc.frame_hash_noise(97, 211, 5), W, H)
+        for bgm, ramp in ((True, False), (False, False), (False, True)):
+            f = emu.frame_for_convert(img, W, H, 0)
+            assert emu.lib().achip_frame_set_dither_style(C.byref(f), bgm, ramp) == 0
+            assert emu.lib().achip_frame_set_display_ops(C.byref(f), False, False, 0) == 0  # keeps the style bits
+            got = emu.render_frames(MODE_16_DITHER_BG, [f], pal, variant)[0]
+            assert got == orc.print_16_dithered(img, bgm, pal, ramp_glyph=ramp), (W, H, bgm, ramp)
+    f = emu.frame_for_convert(img, W, H, 0)
+    assert emu.lib().achip_frame_set_dither_style(C.byref(f), True, True) == -1
+
+
 def test_display_prepasses_folded_into_sampler():
     """flip_x / flip_y / colour filters of the client display path (display.c:546-623) as sampler maps."""
     import ctypes as C
