@@ -132,6 +132,14 @@ def lib():
     L.achip_frame_setup.argtypes = [C.POINTER(Frame), vp, ci, ci, ss, ss, ci, C.c_bool, C.c_bool, C.c_bool]
     L.achip_frame_set_display_ops.restype = ci
     L.achip_frame_set_display_ops.argtypes = [C.POINTER(Frame), C.c_bool, C.c_bool, ci]
+    L.achip_rainbow_color.restype = None
+    L.achip_rainbow_color.argtypes = [C.c_float, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.POINTER(C.c_uint8)]
+    L.achip_frame_set_rainbow.restype = ci
+    L.achip_frame_set_rainbow.argtypes = [C.POINTER(Frame), C.c_float]
+    L.color_filter_calculate_rainbow.restype = None
+    L.color_filter_calculate_rainbow.argtypes = [C.c_float, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.POINTER(C.c_uint8)]
+    L.rainbow_replace_ansi_colors.restype = vp
+    L.rainbow_replace_ansi_colors.argtypes = [C.c_char_p, C.c_float]
     L.achip_frame_set_dither_style.restype = ci
     L.achip_frame_set_dither_style.argtypes = [C.POINTER(Frame), C.c_bool, C.c_bool]
     L.achip_frame_identity.restype = ci

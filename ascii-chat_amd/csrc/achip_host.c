@@ -1,6 +1,7 @@
 /* achip_host.c -- see achip_host.h.  Plain C11, no GPU calls. */
 #include "achip_host.h"
 
+#include <math.h>
 #include <string.h>
 
 /* ROUND(), include/ascii-chat/util/math.h:53; result floored at MIN_DIMENSION (aspect_ratio.c:18-36) */
@@ -132,6 +133,47 @@ int achip_frame_set_display_ops(achip_frame_t *f, bool flip_x, bool flip_y, int 
            << ACHIP_OP_TINT_SHIFT;
   }
   f->ops = (f->ops & ACHIP_OP_DITHER_MASK) | ops;
+  return 0;
+}
+
+/* color_filter.c:169-243: hue = 360 * (t mod 3.5 s) / 3.5 s walked through the six HSV sextants at S = V = 1, then
+ * white is added until the BT.709 luminance reaches 120.  float throughout, like the reference. */
+void achip_rainbow_color(float time_seconds, uint8_t *r, uint8_t *g, uint8_t *b) {
+  const float period = 3.5f;
+  const float phase = fmodf(time_seconds, period) / period;
+  const float hue = phase * 360.0f;
+  const float h = hue / 60.0f;
+  const int sextant = (int)floorf(h);
+  const float rise = h - (float)sextant, fall = 1.0f - rise;
+  const uint8_t up = (uint8_t)(rise * 255.0f + 0.5f), down = (uint8_t)(fall * 255.0f + 0.5f);
+  /* per sextant: which channel is full, which one moves (up or down), which one is zero */
+  static const uint8_t k_full[6] = {0, 1, 1, 2, 2, 0}, k_move[6] = {1, 0, 2, 1, 0, 2}, k_rising[6] = {1, 0, 1, 0, 1, 0};
+  uint8_t c[3] = {255, 0, 0}; /* negative times leave the switch through its default: red */
+  const int s = sextant % 6;
+  if (s >= 0) {
+    c[0] = c[1] = c[2] = 0;
+    c[k_full[s]] = 255;
+    c[k_move[s]] = k_rising[s] ? up : down;
+  }
+  const float floor_lum = 120.0f;
+  const float lum = 0.2126f * c[0] + 0.7152f * c[1] + 0.0722f * c[2];
+  if (lum < floor_lum) {
+    const float boost = (floor_lum - lum) / 3.0f;
+    for (int k = 0; k < 3; k++)
+      c[k] = (uint8_t)fminf(255.0f, c[k] + boost);
+  }
+  *r = c[0];
+  *g = c[1];
+  *b = c[2];
+}
+
+int achip_frame_set_rainbow(achip_frame_t *f, float time_seconds) {
+  if (!f)
+    return -1;
+  uint8_t r, g, b;
+  achip_rainbow_color(time_seconds, &r, &g, &b);
+  f->ops &= ACHIP_OP_FLIP_X | ACHIP_OP_FLIP_Y | ACHIP_OP_DITHER_MASK;
+  f->ops |= ACHIP_OP_FG_OVERRIDE | (((uint32_t)r | ((uint32_t)g << 8) | ((uint32_t)b << 16)) << ACHIP_OP_TINT_SHIFT);
   return 0;
 }
 

@@ -6,10 +6,12 @@
  */
 #include <limits.h>
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <pthread.h>
 #include <string.h>
 
+#include "achip_host.h"
 #include "asciichat_render.h"
 
 char g_default_luminance_palette[256];
@@ -690,4 +692,52 @@ size_t frame_get_valid_end(const char *frame_data, size_t frame_size) {
     return frame_size;
   const size_t pos = final_reset_pos(frame_data, frame_size);
   return pos == SIZE_MAX ? frame_size : pos + 4;
+}
+
+/* ---- COLOR_FILTER_RAINBOW on a finished frame (lib/video/rgba/color_filter.c:169-243, 348-408) ---------------- */
+void color_filter_calculate_rainbow(float time, uint8_t *r, uint8_t *g, uint8_t *b) {
+  if (r && g && b)
+    achip_rainbow_color(time, r, g, b);
+}
+
+char *rainbow_replace_ansi_colors(const char *ansi_string, float time_seconds) {
+  static const char lead[] = "\033[38;2;";
+  if (!ansi_string)
+    return NULL;
+  const char *hit = strstr(ansi_string, lead);
+  if (!hit)
+    return NULL; /* nothing to recolour: the caller keeps its string (color_filter.c:363-365) */
+  uint8_t r, g, b;
+  achip_rainbow_color(time_seconds, &r, &g, &b);
+  char code[24];
+  const size_t code_len = (size_t)snprintf(code, sizeof code, "\033[38;2;%u;%u;%um", r, g, b);
+  /* first pass: size.  Every SGR shrinks or grows by (code_len - its own length). */
+  const size_t n = strlen(ansi_string);
+  size_t out_n = n, count = 0;
+  for (const char *p = hit; p;) {
+    const char *end = strchr(p + 7, 'm');
+    if (!end)
+      break; /* a lead-in with no terminator behind it: the tail stays as it is */
+    out_n = out_n - (size_t)(end + 1 - p) + code_len;
+    count++;
+    p = strstr(end + 1, lead);
+  }
+  char *out = (char *)malloc(out_n + 1);
+  if (!out)
+    return NULL;
+  char *d = out;
+  const char *src = ansi_string;
+  for (const char *p = hit; p && count; count--) {
+    const char *end = strchr(p + 7, 'm');
+    memcpy(d, src, (size_t)(p - src));
+    d += p - src;
+    memcpy(d, code, code_len);
+    d += code_len;
+    src = end + 1;
+    p = strstr(src, lead);
+  }
+  const size_t rest = n - (size_t)(src - ansi_string);
+  memcpy(d, src, rest);
+  d[rest] = '\0';
+  return out;
 }

@@ -593,6 +593,7 @@ enum : uint32_t {
   TF_NL = 1u << 8,          /* newline after the row                                   */
   TF_FINAL_RESET = 1u << 9, /* the single trailing ESC[0m of image_print_color         */
   TF_FG_WHITE = 1u << 10,   /* PB: contrasting foreground is white (else black)        */
+  TF_FG_GIVEN = 1u << 11,   /* PB: foreground colour in Tok::fg (rainbow override)     */
 };
 
 struct Tok {
@@ -769,6 +770,14 @@ template <int MODE, class L> __device__ inline Tok build_token(const Chunk &c, i
     }
   }
 
+  /* rainbow_replace_ansi_colors (color_filter.c:348-408) rewrites every ESC[38;2;..m of the finished frame */
+  if ((MODE == ACHIP_MODE_TRUE_FG || MODE == ACHIP_MODE_HB_TRUE || MODE == ACHIP_MODE_TRUE_BG) &&
+      (c.ops & ACHIP_OP_FG_OVERRIDE) && (t.flags & TF_SGR_FG)) {
+    t.fg = c.ops >> ACHIP_OP_TINT_SHIFT;
+    if (MODE == ACHIP_MODE_TRUE_BG)
+      t.flags |= TF_FG_GIVEN;
+  }
+
   /* end of a text row */
   if (xp == c.wp - 1) {
     if (mode_row_reset(MODE))
@@ -834,7 +843,9 @@ template <int MODE, class S> __device__ inline void token_fields(S &s, const Tok
     put_reset(s);
   if (MODE == ACHIP_MODE_TRUE_BG) { /* background SGR first, then the contrasting foreground (background.c:53-62) */
     put_sgr_true<3>(s, true, t.bg); /* the fixed foreground SGR follows */
-    if (f & TF_FG_WHITE) {
+    if (f & TF_FG_GIVEN) {
+      put_sgr_true<1>(s, false, t.fg);
+    } else if (f & TF_FG_WHITE) {
       s.template c<4>(0x38335B1Bu); /* ESC[38;2;255;255;255m */
       s.template c<4>(0x323B323Bu);
       s.template c<4>(0x323B3535u);

@@ -48,6 +48,13 @@ int achip_frame_set_display_ops(achip_frame_t *f, bool flip_x, bool flip_y, int 
  * ramp_glyph (and !use_background) image_print_16color_dithered(img, pal) (foreground.c:650-750).
  * Default (never called) = use_background, what image_print_color_simd dispatches to (sgr.c:429-430). */
 int achip_frame_set_dither_style(achip_frame_t *f, bool use_background, bool ramp_glyph);
+/* COLOR_FILTER_RAINBOW of the display path: the colour of color_filter_calculate_rainbow(time_seconds)
+ * (lib/video/rgba/color_filter.c:169-243, float HSV walk with a luminance floor) ... */
+void achip_rainbow_color(float time_seconds, uint8_t *r, uint8_t *g, uint8_t *b);
+/* ... and the frame rendered as if rainbow_replace_ansi_colors(result, time_seconds) had been run over its output
+ * (color_filter.c:348-408).  Replaces any tint set by achip_frame_set_display_ops (the reference applies one or the
+ * other, display.c:611,639); flips are kept. */
+int achip_frame_set_rainbow(achip_frame_t *f, float time_seconds);
 
 /* 16.16 nearest-neighbour ratio, image.c:293-294 */
 uint32_t achip_nn_ratio(int src, int dst);

@@ -75,6 +75,10 @@ typedef struct {
 #define ACHIP_OP_DITHER_RAMP 32u /* image_print_16color_dithered: as above with the glyph taken through the
                                     64-entry ramp, cache[ramp[Y>>2]]  (foreground.c:712-723)    */
 #define ACHIP_OP_DITHER_MASK 48u
+/* rainbow_replace_ansi_colors (lib/video/rgba/color_filter.c:348-408; display.c:639-650, web/mirror.c:223) folded
+ * into the emission: every `ESC[38;2;..m` the frame would carry is written with the colour in bits 31..8 instead
+ * (the decision WHETHER to emit one still follows the pixels).  Exclusive with ACHIP_OP_TINT. */
+#define ACHIP_OP_FG_OVERRIDE 64u
 
 /* Glyph tables of one palette (utf8_palette_cache_t restated, common.c:380-490).  A glyph is its
  * UTF-8 bytes packed little-endian in a u32; its length follows from the lead byte. */

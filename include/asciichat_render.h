@@ -222,6 +222,12 @@ char *ansi_compress_rle(const char *input, size_t input_len); /* runs of one byt
 bool frame_validate_integrity(const char *frame_data, size_t frame_size); /* ends right after its last ESC[0m ?       */
 size_t frame_get_valid_end(const char *frame_data, size_t frame_size);
 
+/* ---- video/rgba/color_filter.h:129,155 (COLOR_FILTER_RAINBOW of the display path, src/common/session/display.c:639-650,
+ * src/web/mirror.c:223).  The batch path folds this into the emission (achip_frame_set_rainbow); these are the
+ * reference's host-string forms.  rainbow_replace_ansi_colors returns NULL when the frame holds no ESC[38;2;..m. */
+void color_filter_calculate_rainbow(float time, uint8_t *r, uint8_t *g, uint8_t *b);
+char *rainbow_replace_ansi_colors(const char *ansi_string, float time_seconds);
+
 /* ---- util/aspect_ratio.h ---------------------------------------------------------------------------- */
 void aspect_ratio(const ssize_t img_w, const ssize_t img_h, const ssize_t width, const ssize_t height,
                   const bool stretch, ssize_t *out_width, ssize_t *out_height);

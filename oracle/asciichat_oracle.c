@@ -1333,3 +1333,65 @@ size_t orc_frame_get_valid_end(const char *d, size_t n) {
   const long p = last_reset(d, n);
   return p < 0 ? n : (size_t)p + 4;
 }
+
+/* ------------------------------------------------------------------------- */
+/* rainbow filter (color_filter.c:169-243, 348-408)                            */
+/* ------------------------------------------------------------------------- */
+void orc_rainbow_color(float time_seconds, uint8_t rgb[3]) {
+  float phase = fmodf(time_seconds, 3.5f) / 3.5f;
+  float hue = phase * 360.0f;
+  float h = hue / 60.0f;
+  int i = (int)floorf(h);
+  float f = h - (float)i;
+  float q = 1.0f - f;
+  uint8_t r = 255, g = 0, b = 0;
+  switch (i % 6) {
+  case 0: r = 255; g = (uint8_t)(f * 255.0f + 0.5f); b = 0; break;
+  case 1: r = (uint8_t)(q * 255.0f + 0.5f); g = 255; b = 0; break;
+  case 2: r = 0; g = 255; b = (uint8_t)(f * 255.0f + 0.5f); break;
+  case 3: r = 0; g = (uint8_t)(q * 255.0f + 0.5f); b = 255; break;
+  case 4: r = (uint8_t)(f * 255.0f + 0.5f); g = 0; b = 255; break;
+  case 5: r = 255; g = 0; b = (uint8_t)(q * 255.0f + 0.5f); break;
+  default: break;
+  }
+  float lum = 0.2126f * r + 0.7152f * g + 0.0722f * b;
+  if (lum < 120.0f) {
+    float boost = (120.0f - lum) / 3.0f;
+    r = (uint8_t)fminf(255.0f, r + boost);
+    g = (uint8_t)fminf(255.0f, g + boost);
+    b = (uint8_t)fminf(255.0f, b + boost);
+  }
+  rgb[0] = r;
+  rgb[1] = g;
+  rgb[2] = b;
+}
+
+char *orc_rainbow_replace(const char *frame, float time_seconds, size_t *out_len) {
+  static const char k_lead[] = "\033[38;2;";
+  if (!frame || !strstr(frame, k_lead))
+    return NULL;
+  uint8_t c[3];
+  orc_rainbow_color(time_seconds, c);
+  char code[32];
+  int code_len = snprintf(code, sizeof code, "\033[38;2;%d;%d;%dm", c[0], c[1], c[2]);
+  sink_t s = {0};
+  const char *p = frame;
+  while (*p) {
+    const char *hit = strstr(p, k_lead);
+    if (!hit) {
+      sk_mem(&s, p, strlen(p));
+      break;
+    }
+    sk_mem(&s, p, (size_t)(hit - p));
+    const char *end = strchr(hit + 7, 'm');
+    if (end) {
+      sk_mem(&s, code, (size_t)code_len);
+      p = end + 1;
+    } else { /* no 'm' anywhere behind the lead-in (never in a rendered frame): the reference re-copies bytes it has
+              * already copied and can run past its 2n buffer (color_filter.c:396-399); here the tail stays as it is */
+      sk_byte(&s, *hit);
+      p = hit + 1;
+    }
+  }
+  return sk_finish(&s, out_len);
+}

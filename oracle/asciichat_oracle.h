@@ -105,6 +105,11 @@ char *orc_display_convert(const uint8_t *rgb, int src_w, int src_h, long width, 
                           int render_mode, bool wants_padding, bool use_aspect, bool stretch, const char *palette,
                           bool flip_x, bool flip_y, int color_filter, size_t *len);
 
+/* COLOR_FILTER_RAINBOW: lib/video/rgba/color_filter.c:169-243 (colour of the moment, float) and :348-408 (every
+ * ESC[38;2;..m of a finished frame rewritten with it; NULL when the frame holds none, as the reference) */
+void orc_rainbow_color(float time_seconds, uint8_t rgb[3]);
+char *orc_rainbow_replace(const char *frame, float time_seconds, size_t *out_len);
+
 /* ---- uncalled leftovers: lib/video/ascii/rle.c:13-162, frame_validator.c:13-80 ---- */
 char *orc_expand_rle(const char *in, size_t n, size_t *out_len);
 char *orc_compress_rle(const char *in, size_t n, size_t *out_len);

@@ -58,7 +58,7 @@ def main():
         arr = np.ascontiguousarray(img)
         im = pkg.Image(sw, sh, arr.ctypes.data, 0)
         pal = pals[int(rng.integers(0, 6))]
-        which = int(rng.integers(0, 4))
+        which = int(rng.integers(0, 5))
         if which == 0:
             W, H = int(rng.choice([0, 1, 17, 80, 200, 4000])), int(rng.choice([0, 1, 24, 60, 3000]))
             color, opt = bool(rng.integers(0, 2)), int(rng.integers(0, 3))
@@ -81,6 +81,15 @@ def main():
             got = pkg.take_string(getattr(L, fn)(C.byref(im), pal))
             exp = orc.print_with_caps(img, cl, rm, pal)
             ctx = (fn, sw, sh)
+        elif which == 4:  # the three exported forms of the Floyd-Steinberg renderer
+            style = int(rng.integers(0, 3))
+            if style == 2:
+                got = pkg.take_string(L.image_print_16color_dithered(C.byref(im), pal))
+                exp = orc.print_16_dithered(img, False, pal, ramp_glyph=True)
+            else:
+                got = pkg.take_string(L.image_print_16color_dithered_with_background(C.byref(im), style == 0, pal))
+                exp = orc.print_16_dithered(img, style == 0, pal)
+            ctx = ("dithered", style, sw, sh)
         else:
             fn, cl = [("rgb_to_truecolor_halfblocks_scalar", 3), ("rgb_to_256color_halfblocks_scalar", 2),
                       ("rgb_to_16color_halfblocks_scalar", 1), ("rgb_to_halfblocks_scalar", 0)][int(rng.integers(0, 4))]

@@ -55,6 +55,10 @@ def bind_host(L):
     L.achip_frame_identity.argtypes = [C.POINTER(Frame), C.c_void_p, C.c_int, C.c_int]
     L.achip_frame_set_display_ops.restype = C.c_int
     L.achip_frame_set_display_ops.argtypes = [C.POINTER(Frame), C.c_bool, C.c_bool, C.c_int]
+    L.achip_rainbow_color.restype = None
+    L.achip_rainbow_color.argtypes = [C.c_float, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.POINTER(C.c_uint8)]
+    L.achip_frame_set_rainbow.restype = C.c_int
+    L.achip_frame_set_rainbow.argtypes = [C.POINTER(Frame), C.c_float]
     L.achip_frame_set_dither_style.restype = C.c_int
     L.achip_frame_set_dither_style.argtypes = [C.POINTER(Frame), C.c_bool, C.c_bool]
     L.achip_nn_ratio.restype = C.c_uint32

@@ -64,6 +64,10 @@ def lib():
             f.argtypes = [vp, ci, ci, C.c_char_p, C.POINTER(sz)]
         L.orc_print_16_dithered.restype = vp
         L.orc_print_16_dithered.argtypes = [vp, ci, ci, C.c_bool, C.c_char_p, C.POINTER(sz)]
+        L.orc_rainbow_color.restype = None
+        L.orc_rainbow_color.argtypes = [C.c_float, C.POINTER(C.c_uint8 * 3)]
+        L.orc_rainbow_replace.restype = vp
+        L.orc_rainbow_replace.argtypes = [C.c_char_p, C.c_float, C.POINTER(sz)]
         L.orc_print_16_dithered_fg.restype = vp
         L.orc_print_16_dithered_fg.argtypes = [vp, ci, ci, C.c_char_p, C.POINTER(sz)]
         for name in ("orc_halfblock_truecolor", "orc_halfblock_256", "orc_halfblock_16", "orc_halfblock_mono"):
@@ -193,6 +197,20 @@ def print_16_dithered(img, use_background, palette=PALETTE_STANDARD, ramp_glyph=
         p = lib().orc_print_16_dithered(img.ctypes.data, img.shape[1], img.shape[0], use_background, _pal(palette),
                                         C.byref(n))
     return _take(p, n.value)
+
+
+def rainbow_color(t):
+    c = (C.c_uint8 * 3)()
+    lib().orc_rainbow_color(t, C.byref(c))
+    return tuple(c)
+
+
+def rainbow_replace(frame, t):
+    """rainbow_replace_ansi_colors as its callers use it: the frame itself when there is nothing to recolour"""
+    assert b"\0" not in frame
+    n = C.c_size_t()
+    p = lib().orc_rainbow_replace(bytes(frame), t, C.byref(n))
+    return _take(p, n.value) if p else bytes(frame)
 
 
 def print_truecolor_bg(img, palette=PALETTE_STANDARD):

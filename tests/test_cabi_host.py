@@ -282,6 +282,44 @@ def test_rle_and_frame_validator_utilities(pkg):
     assert not L.frame_validate_integrity(tc + b"xx", len(tc) + 2) and L.frame_get_valid_end(tc + b"xx", len(tc) + 2) == len(tc)
 
 
+def test_rainbow_colour_and_host_string_pass(pkg):
+    """COLOR_FILTER_RAINBOW (color_filter.c:169-243, 348-408): the colour of the moment (float HSV walk + luminance floor)
+    and the host-string replacement, product vs oracle, plus known points of the colour wheel."""
+    L = pkg.lib()
+    r, g, b = C.c_uint8(), C.c_uint8(), C.c_uint8()
+
+    def colour(t, fn=L.achip_rainbow_color):
+        fn(t, C.byref(r), C.byref(g), C.byref(b))
+        return (r.value, g.value, b.value)
+
+    assert colour(0.0)[0] == 255 and colour(0.0)[1] == colour(0.0)[2]  # t = 0: red, lifted towards white by the floor
+    assert colour(3.5 / 3)[1] == 255                                   # a third of the period: green
+    lum = lambda c: 0.2126 * c[0] + 0.7152 * c[1] + 0.0722 * c[2]
+    ts = [k * 0.0137 for k in range(600)] + [-1.0, -0.2, 1e6, 123456.78, 3.5, 7.0, 3.4999]
+    for t in ts:
+        c = colour(t)
+        assert c == orc.rainbow_color(t), t
+        assert c == colour(t, L.color_filter_calculate_rainbow)
+        # the boost truncates each channel, so the floor is approached from below by at most one step per channel
+        assert lum(c) >= 119.0 or 255 in c, (t, c)
+    tc = orc.convert_with_caps(orc.frame_torture(), 80, 24, 3, 0)
+    hb = orc.convert_with_caps(orc.frame_torture(), 80, 24, 3, 2)
+    mono = orc.convert(orc.frame_torture(), 80, 24, False, False, False)
+    for frame in (tc, hb, b"\033[38;2;1;2;3mA", b"xy\033[38;2;1;2;3", b"A\033[38;2;9;9;9mB\033[38;2;7;7", b"\033[38;2;m"):
+        for t in (0.0, 0.9, 2.2):
+            p = L.rainbow_replace_ansi_colors(frame, t)
+            assert p
+            got = pkg.take_string(p)
+            assert got == orc.rainbow_replace(frame, t), (frame[:20], t)
+            code = b"\033[38;2;%d;%d;%dm" % colour(t)
+            if frame in (tc, hb):  # well-formed: every foreground SGR now carries the one colour, nothing else moved
+                assert got.count(code) == frame.count(b"\033[38;2;") == got.count(b"\033[38;2;")
+                assert got.count(b"\033[48;2;") == frame.count(b"\033[48;2;")
+    assert not L.rainbow_replace_ansi_colors(mono, 1.0)       # nothing to recolour: NULL, the caller keeps its string
+    assert not L.rainbow_replace_ansi_colors(None, 1.0)
+    assert orc.rainbow_replace(mono, 1.0) == mono
+
+
 def test_frame_blob_validation_matches_reference_rules(pkg):
     """achip_frame_blob_parse vs the oracle's restatement of stream.c:330-372 / protocol.c:784-815."""
     import struct

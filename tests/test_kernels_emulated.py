@@ -98,6 +98,33 @@ def test_dither_foreground_only_forms():
     assert emu.lib().achip_frame_set_dither_style(C.byref(f), True, True) == -1
 
 
+def test_rainbow_filter_folded_into_emission():
+    """COLOR_FILTER_RAINBOW (display.c:639-650): rainbow_replace_ansi_colors over the finished frame == the frame
+    rendered with every ESC[38;2;..m carrying the colour of the moment."""
+    import ctypes as C
+
+    from achip_ctypes import MODE_16_DITHER_BG, MODE_HB_256
+    img = orc.frame_torture()
+    for t in (0.0, 0.4, 1.3, 2.05, 3.49, 1234.567):
+        for mode, pal in ((MODE_TRUE_FG, orc.PALETTE_STANDARD), (MODE_TRUE_FG, "é漢😀 .m"), (MODE_HB_TRUE, orc.PALETTE_STANDARD),
+                          (MODE_TRUE_BG, orc.PALETTE_STANDARD), (MODE_256_FG, orc.PALETTE_STANDARD),
+                          (MODE_HB_256, orc.PALETTE_STANDARD), (MODE_MONO, orc.PALETTE_STANDARD)):
+            rm = MODE_CAPS.get(mode, (3, 0))[1]
+            pad = mode != MODE_TRUE_BG
+            f = emu.frame_for_convert(img, 97, 31, rm, pad, pad)
+            assert emu.lib().achip_frame_set_display_ops(C.byref(f), True, False, 3) == 0  # the tint is dropped, the flip kept
+            assert emu.lib().achip_frame_set_rainbow(C.byref(f), t) == 0
+            got = emu.render_frames(mode, [f], pal, 2)[0]
+            plain = oracle_convert(np.ascontiguousarray(img[:, ::-1]), mode, 97, 31, pal, pad, pad)
+            assert got == orc.rainbow_replace(plain, t), (t, MODE_NAMES[mode])
+    # an all-black half-block frame holds no foreground SGR: nothing to replace
+    black = np.zeros((40, 40, 3), np.uint8)
+    f = emu.frame_for_convert(black, 20, 10, 2)
+    emu.lib().achip_frame_set_rainbow(C.byref(f), 1.0)
+    assert emu.render_frames(MODE_HB_TRUE, [f], orc.PALETTE_STANDARD, 2)[0] == oracle_convert(black, MODE_HB_TRUE, 20, 10,
+                                                                                             orc.PALETTE_STANDARD)
+
+
 def test_display_prepasses_folded_into_sampler():
     """flip_x / flip_y / colour filters of the client display path (display.c:546-623) as sampler maps."""
     import ctypes as C

@@ -72,3 +72,19 @@ def test_tint_and_flip_kernels_gpu():
         got = out[:int(ln[0].item())].cpu().numpy().tobytes()
         assert got == orc.display_convert(img, 120, 40, cl, rm, True, True, True, True, 7)
         plan.close()
+    # COLOR_FILTER_RAINBOW folded into the emission (display.c:639-650): same bytes as rainbow_replace_ansi_colors over
+    # the finished frame; 256-colour frames hold nothing to recolour
+    for mode, (cl, rm) in ((1, (3, 0)), (5, (3, 2)), (2, (2, 0))):
+        for t in (0.25, 1.9, 3.3):
+            f = pkg.frame_setup(dev.data_ptr(), 1280, 720, 120, 40, rm, True, True, False)
+            assert L.achip_frame_set_display_ops(C.byref(f), False, True, 0) == 0
+            assert L.achip_frame_set_rainbow(C.byref(f), t) == 0
+            plan = pkg.Plan(mode, orc.PALETTE_STANDARD, [f])
+            out = torch.zeros(plan.stride, dtype=torch.uint8, device="cuda")
+            ln = torch.zeros(1, dtype=torch.int32, device="cuda")
+            plan.render(out.data_ptr(), plan.stride, ln.data_ptr())
+            torch.cuda.synchronize()
+            got = out[:int(ln[0].item())].cpu().numpy().tobytes()
+            exp = orc.rainbow_replace(orc.display_convert(img, 120, 40, cl, rm, True, True, False, True, 0), t)
+            assert got == exp, (mode, t)
+            plan.close()
