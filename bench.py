@@ -54,10 +54,12 @@ def build_plan(pkg, frames_t, W, H, cl, rm):
     return pkg.Plan(mode, PALETTE_STANDARD, descs), mode
 
 
-def time_steps(torch, plan, out, ln, steps, warmup, dist=None):
+def time_steps(torch, plans, out, ln, steps, warmup, dist=None):
+    """K back-to-back launches; launch k renders input set k % len(plans) (all sets share the output slab)."""
     stream = torch.cuda.current_stream().cuda_stream
-    for _ in range(warmup):
-        plan.render(out.data_ptr(), plan.stride, ln.data_ptr(), stream)
+    S = len(plans)
+    for k in range(warmup):
+        plans[k % S].render(out.data_ptr(), plans[0].stride, ln.data_ptr(), stream)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -66,8 +68,8 @@ def time_steps(torch, plan, out, ln, steps, warmup, dist=None):
     e1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()
-    for _ in range(steps):
-        plan.render(out.data_ptr(), plan.stride, ln.data_ptr(), stream)
+    for k in range(steps):
+        plans[k % S].render(out.data_ptr(), plans[0].stride, ln.data_ptr(), stream)
     e1.record()
     torch.cuda.synchronize()
     if dist is not None:
@@ -78,40 +80,55 @@ def time_steps(torch, plan, out, ln, steps, warmup, dist=None):
     return wall, gpu_ms
 
 
-def kernel_time_events(torch, plan, out, ln, reps):
+def kernel_time_events(torch, plans, out, ln, reps):
     """Per-launch duration: HIP events recorded on the launch stream around EACH launch (idle stream
-    in between), averaged -- this is the number rocprofv3's kernel trace should agree with."""
+    in between), averaged -- contains the launch latency the back-to-back figure hides."""
     stream = torch.cuda.current_stream().cuda_stream
     tot = 0.0
-    for _ in range(reps):
+    for k in range(reps):
         a = torch.cuda.Event(enable_timing=True)
         b = torch.cuda.Event(enable_timing=True)
         a.record()
-        plan.render(out.data_ptr(), plan.stride, ln.data_ptr(), stream)
+        plans[k % len(plans)].render(out.data_ptr(), plans[0].stride, ln.data_ptr(), stream)
         b.record()
         b.synchronize()
         tot += a.elapsed_time(b)
     return tot / reps
 
 
-def run_workload(torch, pkg, name, batch, steps, warmup, dist=None, seed=1234, variant=-1):
+def run_workload(torch, pkg, name, batch, steps, warmup, dist=None, seed=1234, variant=-1, input_sets=1,
+                 hot_leg=True):
+    """input_sets independent batches of source frames are rendered round-robin: a video tick never renders the frames
+    of the tick before, and the sampled sectors of ONE batch (~18-31 MB at 1080p->80x24) would otherwise be served by
+    the 256 MB Infinity Cache from the second step on (scripts/gpu_rotate.py: 11.8 us hot vs 14.0-14.3 us fresh)."""
     sw, sh, W, H, cl, rm = WORKLOADS[name]
-    frames_t = make_frames(torch, batch, sw, sh, seed)
-    plan, mode = build_plan(pkg, frames_t, W, H, cl, rm)
-    if variant >= 0:
-        plan.set_variant(variant)
-    out = torch.empty(batch * plan.stride, dtype=torch.uint8, device="cuda")
+    sets = [make_frames(torch, batch, sw, sh, seed + 7919 * s) for s in range(input_sets)]
+    plans = []
+    for t in sets:
+        plan, mode = build_plan(pkg, t, W, H, cl, rm)
+        if variant >= 0:
+            plan.set_variant(variant)
+        plans.append(plan)
+    out = torch.empty(batch * plans[0].stride, dtype=torch.uint8, device="cuda")
     ln = torch.zeros(batch, dtype=torch.int32, device="cuda")
-    wall, gpu_ms = time_steps(torch, plan, out, ln, steps, warmup, dist)
-    lens = ln.cpu().numpy().astype("uint32")
-    assert (lens < 0xFFFFFFF0).all(), "kernel reported overflow/bad descriptor"
     rows = 2 * H if rm == 2 else H
-    alg_bytes = int(lens.sum()) + batch * 3 * W * rows  # SURVEY 8(d): sampled RGB consumed + exact output bytes
-    per_launch_ms = kernel_time_events(torch, plan, out, ln, 20)
+    out_bytes = []
+    stream = torch.cuda.current_stream().cuda_stream
+    for plan in plans:  # exact output bytes of every set (SURVEY 8(d): sampled RGB consumed + exact output bytes)
+        plan.render(out.data_ptr(), plan.stride, ln.data_ptr(), stream)
+        lens = ln.cpu().numpy().astype("uint32")
+        assert (lens < 0xFFFFFFF0).all(), "kernel reported overflow/bad descriptor"
+        out_bytes.append(int(lens.sum()))
+    wall, gpu_ms = time_steps(torch, plans, out, ln, steps, warmup, dist)
+    alg_bytes = int(sum(out_bytes) / len(out_bytes)) + batch * 3 * W * rows
+    per_launch_ms = kernel_time_events(torch, plans, out, ln, 20)
+    hot_ms = None
+    if input_sets > 1 and hot_leg:  # the same figure when one batch is rendered over and over (its sectors stay in the Infinity Cache)
+        hot_ms = time_steps(torch, plans[:1], out, ln, max(20, steps // 4), 5, None)[1] / max(20, steps // 4)
     res = dict(name=name, mode=pkg.MODE_NAMES[mode], batch=batch, wall_s=wall, gpu_ms=gpu_ms, steps=steps,
-               out_bytes_per_frame=float(lens.mean()), alg_bytes_per_launch=alg_bytes,
-               kernel_ms_event_pair=per_launch_ms, kernel_ms_back_to_back=gpu_ms / steps, variant=plan.variant,
-               frames=frames_t, plan=plan, out=out, ln=ln, lens=lens)
+               out_bytes_per_frame=sum(out_bytes) / len(out_bytes) / batch, alg_bytes_per_launch=alg_bytes,
+               kernel_ms_event_pair=per_launch_ms, kernel_ms_back_to_back=gpu_ms / steps, kernel_ms_hot_input=hot_ms,
+               variant=plans[0].variant, input_sets=input_sets, frames=sets, plan=plans[0], plans=plans, out=out, ln=ln)
     return res
 
 
@@ -160,7 +177,7 @@ def run_grid9(torch, pkg, steps, warmup):
     plan = pkg.Plan(pkg.lib().achip_mode_from_caps(3, 0), PALETTE_STANDARD, descs)
     out = torch.empty(n * plan.stride, dtype=torch.uint8, device="cuda")
     ln = torch.zeros(n, dtype=torch.int32, device="cuda")
-    wall, gpu_ms = time_steps(torch, plan, out, ln, steps, warmup, None)
+    wall, gpu_ms = time_steps(torch, [plan], out, ln, steps, warmup, None)
     lens = ln.cpu().numpy().astype("uint32")
     assert (lens < 0xFFFFFFF0).all()
     cells = int(sum(d.out_w * d.out_h for d in descs))
@@ -234,6 +251,10 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-d2h", action="store_true", help="skip the PCIe-inclusive with_d2h leg (profiling runs)")
     ap.add_argument("--variant", type=int, default=-1)
+    ap.add_argument("--input-sets", type=int, default=4,
+                    help="independent batches of source frames rendered round-robin (1 = the same batch every step)")
+    ap.add_argument("--no-hot", action="store_true",
+                    help="skip the same-batch-every-step comparison leg (profiling runs: keeps the kernel trace to the timed launches)")
     args = ap.parse_args()
 
     import torch
@@ -263,7 +284,7 @@ def main():
         dist = d
 
     res = run_workload(torch, pkg, args.workload, args.batch, args.steps, args.warmup, dist, seed=1234 + rank,
-                       variant=args.variant)
+                       variant=args.variant, input_sets=args.input_sets, hot_leg=not args.no_hot)
     wall = res["wall_s"]
     if dist is not None:
         t = torch.tensor([wall], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
@@ -281,16 +302,18 @@ def main():
         "metric": "frames/sec, 1080p->80x24 truecolor (batch of independent client frames)",
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u8", "data": "synthetic (uniform-random RGB24 frames generated on device, resident in HBM)",
+        "dtype": "u8", "data": f"synthetic (uniform-random RGB24 frames generated on device, resident in HBM; {args.input_sets} independent "
+                "batches rendered round-robin so no step re-reads the frames of the step before)",
         "config": {"workload": args.workload, "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                    "src": f"{WORKLOADS[args.workload][0]}x{WORKLOADS[args.workload][1]}",
                    "grid": f"{WORKLOADS[args.workload][2]}x{WORKLOADS[args.workload][3]}", "mode": res["mode"],
                    "parallelism": f"frames sharded over {world} rank(s), no data-path collective",
-                   "kernel_variant": res["variant"]},
+                   "kernel_variant": res["variant"], "input_sets": args.input_sets},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "alg_bytes_per_launch": res["alg_bytes_per_launch"], "kernel_ms": kernel_ms,
                      "kernel_ms_event_pair": res["kernel_ms_event_pair"],
+                     "kernel_ms_same_batch_every_step": res["kernel_ms_hot_input"],
                      "out_bytes_per_frame": res["out_bytes_per_frame"]},
     }
     # HBM traffic per launch comes from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE cannot share a
@@ -315,12 +338,14 @@ def main():
             del res
             torch.cuda.empty_cache()
             b = args.batch
-            res = run_workload(torch, pkg, name, b, max(10, args.steps // 10), 3, None)
+            res = run_workload(torch, pkg, name, b, max(10, args.steps // 10), 3, None,
+                               input_sets=args.input_sets, hot_leg=False)
             k = res["kernel_ms_back_to_back"]
             a = res["alg_bytes_per_launch"] / (k * 1e-3) / 1e9
             others[name] = {"frames_per_s": b * res["steps"] / res["wall_s"], "kernel_ms": k,
                             "out_bytes_per_frame": res["out_bytes_per_frame"], "roofline_GBps": a,
-                            "roofline_frac": a / HBM_PEAK_GBS, "kernel_variant": res["variant"]}
+                            "roofline_frac": a / HBM_PEAK_GBS, "kernel_variant": res["variant"],
+                            "input_sets": res["input_sets"]}
         del res
         torch.cuda.empty_cache()
         if args.others:

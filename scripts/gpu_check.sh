@@ -13,7 +13,7 @@ echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 
 echo "== bench"; timeout 900 python bench.py 2>&1 | grep -v amdgpu.ids | tail -2 | tee $OUT/bench.json
 echo "== rocprof kernel trace"
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --no-cpu --no-d2h --others '' > $OUT/rocprof_run.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --no-cpu --no-d2h --no-hot --others '' > $OUT/rocprof_run.log 2>&1
 cd $GRAFT_REPO_ROOT
 for f in $(find $OUT/prof -name "*kernel_stats.csv"); do echo "-- $f"; head -6 $f | cut -c1-220; done
 echo "== PMC"

@@ -43,7 +43,7 @@ def main():
             for _ in range(5):
                 plan.render(out.data_ptr(), plan.stride, ln.data_ptr(), torch.cuda.current_stream().cuda_stream)
             torch.cuda.synchronize()
-            ms = bench.kernel_time_events(torch, plan, out, ln, args.reps)
+            ms = bench.kernel_time_events(torch, [plan], out, ln, args.reps)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(args.reps):
