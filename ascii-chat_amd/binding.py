@@ -88,6 +88,12 @@ def lib():
     L.asciichat_hip_plan_get_variant.argtypes = [vp]
     L.asciichat_hip_plan_set_split.restype = ci
     L.asciichat_hip_plan_set_split.argtypes = [vp, ci]
+    L.asciichat_hip_plan_set_uniform.restype = ci
+    L.asciichat_hip_plan_set_uniform.argtypes = [vp, ci]
+    L.asciichat_hip_plan_get_uniform.restype = ci
+    L.asciichat_hip_plan_get_uniform.argtypes = [vp]
+    L.achip_frames_uniform.restype = ci
+    L.achip_frames_uniform.argtypes = [C.POINTER(Frame), ci, C.c_void_p]
     L.asciichat_hip_plan_get_parts.restype = ci
     L.asciichat_hip_plan_get_parts.argtypes = [vp]
     L.asciichat_hip_frame_table_create.restype = ci
@@ -269,6 +275,14 @@ class Plan:
     @property
     def parts(self):
         return lib().asciichat_hip_plan_get_parts(self._h)
+
+    @property
+    def uniform(self):
+        """True when launches pass the batch's common descriptor in the kernel arguments"""
+        return bool(lib().asciichat_hip_plan_get_uniform(self._h))
+
+    def set_uniform(self, allow):
+        lib().asciichat_hip_plan_set_uniform(self._h, 1 if allow else 0)
 
     def set_split(self, rows_per_part):
         rc = lib().asciichat_hip_plan_set_split(self._h, rows_per_part)

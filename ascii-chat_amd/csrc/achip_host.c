@@ -177,6 +177,27 @@ int achip_frame_set_rainbow(achip_frame_t *f, float time_seconds) {
   return 0;
 }
 
+int achip_frames_uniform(const achip_frame_t *frames, int n, achip_uniform_t *u) {
+  if (!u)
+    return 0;
+  memset(u, 0, sizeof(*u));
+  if (!frames || n <= 0 || frames[0].comp || !frames[0].src)
+    return 0;
+  const int64_t pitch = n > 1 ? (int64_t)((intptr_t)frames[1].src - (intptr_t)frames[0].src) : 0;
+  for (int i = 1; i < n; i++) {
+    achip_frame_t a = frames[i];
+    if ((int64_t)((intptr_t)a.src - (intptr_t)frames[0].src) != pitch * i)
+      return 0;
+    a.src = frames[0].src;
+    if (memcmp(&a, &frames[0], sizeof(a)) != 0) /* descriptors are memset by achip_frame_setup: padding is zero */
+      return 0;
+  }
+  u->f = frames[0];
+  u->src_pitch = pitch;
+  u->enabled = 1;
+  return 1;
+}
+
 int achip_frame_set_dither_style(achip_frame_t *f, bool use_background, bool ramp_glyph) {
   if (!f || (use_background && ramp_glyph)) /* the ramp glyph only exists in the foreground-only function */
     return -1;

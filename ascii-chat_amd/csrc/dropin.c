@@ -227,10 +227,12 @@ static char *render_with_lut(tls_ctx_t *c, const achip_lut_t *lut, int mode, con
   desc->src = src_dev;
   volatile uint32_t *len_host = (volatile uint32_t *)(c->pin + PIN_LEN_OFF);
   *len_host = ACHIP_LEN_BADDESC;
+  achip_uniform_t uni; /* one frame: its descriptor rides in the kernel arguments (no PCIe read of the pinned copy) */
+  (void)achip_frames_uniform(desc, 1, &uni);
   if (achip_hip_check(achip_launch_render(mode, variant, 0, (const achip_frame_t *)(c->pin_dev + PIN_DESC_OFF), 1, lut,
                                           c->pin_dev + PIN_OUT_OFF, (uint64_t)stride,
                                           (uint32_t *)(c->pin_dev + PIN_LEN_OFF), NULL, parts, rows_per_part,
-                                          parts > 1 ? c->part_sync : NULL, c->epoch, c->stream),
+                                          parts > 1 ? c->part_sync : NULL, c->epoch, &uni, c->stream),
                       "render kernel launch"))
     return NULL;
   if (achip_hip_check((int)hipStreamSynchronize(c->stream), "hipStreamSynchronize"))

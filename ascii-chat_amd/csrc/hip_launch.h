@@ -17,7 +17,9 @@ int achip_launch_render(int mode, int variant, int has_composite, const achip_fr
                         unsigned long long *phase_cycles /* NULL, or 8 u64 per frame (diagnostics) */,
                         int parts /* workgroups per frame (1 = whole frame per workgroup) */, int rows_per_part,
                         unsigned long long *part_sync /* n_frames*parts u64, zeroed once; NULL when parts == 1 */,
-                        uint32_t epoch /* differs from launch to launch on the same part_sync */, void *stream);
+                        uint32_t epoch /* differs from launch to launch on the same part_sync */,
+                        const achip_uniform_t *uniform /* NULL, or the batch's common descriptor (achip_frames_uniform) */,
+                        void *stream);
 int achip_launch_resize(const uint8_t *src, int sw, int sh, uint8_t *dst, int dw, int dh, void *stream);
 int achip_launch_composite(const achip_composite_t *comp_dev, int canvas_w, int canvas_h, uint8_t *dst, void *stream);
 

@@ -15,7 +15,8 @@
 extern "C" int achip_launch_render(int mode, int variant, int has_composite, const achip_frame_t *frames_dev, int n_frames,
                                    const achip_lut_t *lut_dev, uint8_t *out, uint64_t out_stride, uint32_t *out_len,
                                    unsigned long long *prof, int parts, int rows_per_part,
-                                   unsigned long long *part_sync, uint32_t epoch, void *stream) {
+                                   unsigned long long *part_sync, uint32_t epoch, const achip_uniform_t *uniform,
+                                   void *stream) {
   if (n_frames <= 0)
     return (int)hipSuccess;
   if (parts < 1 || (parts > 1 && (!part_sync || rows_per_part < 1)))
@@ -24,7 +25,7 @@ extern "C" int achip_launch_render(int mode, int variant, int has_composite, con
 #define X(id, B, C, R)                                                                                                 \
   case id:                                                                                                             \
     return achip_render_inst_launch_##id(mode, has_composite, frames_dev, n_frames, lut_dev, out, out_stride, out_len, \
-                                         prof, parts, rows_per_part, part_sync, epoch, stream);
+                                         prof, parts, rows_per_part, part_sync, epoch, uniform, stream);
     ACHIP_VARIANTS(X)
 #undef X
   }

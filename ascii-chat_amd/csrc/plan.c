@@ -173,6 +173,8 @@ struct asciichat_hip_plan {
   unsigned long long *part_sync; /* n * parts_cap u64 hand-off words, zeroed once */
   int parts_cap;
   uint32_t epoch;
+  achip_uniform_t uniform; /* the batch's common descriptor, when it has one (achip_frames_uniform) */
+  int uniform_off;         /* asciichat_hip_plan_set_uniform(plan, 0): always read the device array */
   size_t stride;
   achip_frame_t *frames_dev;
   achip_frame_t *frames_pinned; /* staging for async updates */
@@ -229,6 +231,7 @@ static int plan_measure(asciichat_hip_plan_t *p, const achip_frame_t *frames) {
     return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame output bound exceeds 4 GiB");
   p->stride = stride;
   p->max_wp = max_wp;
+  (void)achip_frames_uniform(frames, p->n, &p->uniform);
   if (choose_geometry(p, frames) != 0 || p->variant < 0 || achip_variant_cap(p->variant) < max_wp)
     return achip_fail(ASCIICHAT_HIP_ERR_NOT_SUPPORTED, "padded row of %d cells exceeds the kernel chunk (max %d)",
                       max_wp, achip_variant_cap(0));
@@ -321,6 +324,17 @@ int asciichat_hip_plan_set_split(asciichat_hip_plan_t *p, int rows_per_part) {
 
 int asciichat_hip_plan_get_parts(const asciichat_hip_plan_t *p) { return p ? p->parts : 0; }
 
+int asciichat_hip_plan_set_uniform(asciichat_hip_plan_t *p, int allow) {
+  if (!p)
+    return ASCIICHAT_HIP_ERR_INVALID_PARAM;
+  p->uniform_off = !allow;
+  return 0;
+}
+
+int asciichat_hip_plan_get_uniform(const asciichat_hip_plan_t *p) {
+  return p && p->uniform.enabled && !p->uniform_off && !p->has_comp;
+}
+
 int asciichat_hip_plan_get_variant(const asciichat_hip_plan_t *p) { return p ? p->variant : -1; }
 
 static int render_range(asciichat_hip_plan_t *p, int first, int count, uint8_t *out_dev, size_t out_stride,
@@ -335,11 +349,15 @@ static int render_range(asciichat_hip_plan_t *p, int first, int count, uint8_t *
   /* a different epoch per launch makes last launch's hand-off words stale without clearing them; launches of
    * one plan must therefore be ordered (one stream), which updating its descriptors requires anyway */
   p->epoch = p->epoch + 1u ? p->epoch + 1u : 1u;
+  achip_uniform_t uni = p->uniform;
+  if (p->uniform_off)
+    uni.enabled = 0;
+  uni.f.src = uni.f.src ? uni.f.src + (int64_t)first * uni.src_pitch : NULL;
   return achip_hip_check(achip_launch_render(p->mode, p->variant, p->has_comp, p->frames_dev + first, count, p->lut_dev,
                                              out_dev, (uint64_t)out_stride, out_len_dev, phase_cycles_dev, p->parts,
                                              p->rows_per_part,
                                              p->part_sync ? p->part_sync + (size_t)first * (size_t)p->parts : NULL,
-                                             p->epoch, stream),
+                                             p->epoch, &uni, stream),
                          "render kernel launch");
 }
 

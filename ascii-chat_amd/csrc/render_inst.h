@@ -14,7 +14,8 @@ extern "C" {
 #define X(id, B, C, R)                                                                                                 \
   int achip_render_inst_launch_##id(int mode, int comp, const achip_frame_t *frames, int n, const achip_lut_t *lut,    \
                                     uint8_t *out, uint64_t stride, uint32_t *len, unsigned long long *prof, int parts, \
-                                    int rows_per_part, unsigned long long *part_sync, uint32_t epoch, void *stream);   \
+                                    int rows_per_part, unsigned long long *part_sync, uint32_t epoch,                  \
+                                    const achip_uniform_t *uniform, void *stream);                                     \
   int achip_render_inst_lds_##id(int mode);
 ACHIP_VARIANTS(X)
 #undef X

@@ -31,7 +31,7 @@ constexpr bool HAS_SPLIT = ACHIP_INST == 1 || ACHIP_INST == 2 || ACHIP_INST == 4
 template <int MODE, bool COMP, bool SPLIT>
 hipError_t launch_one(const achip_frame_t *frames, int n, const achip_lut_t *lut, uint8_t *out, uint64_t stride,
                       uint32_t *len, unsigned long long *prof, int parts, int rows_per_part, unsigned long long *part_sync,
-                      uint32_t epoch, hipStream_t stream) {
+                      uint32_t epoch, const achip_uniform_t &uni, hipStream_t stream) {
   using L = achip::Lds<MODE, G::BLOCK, G::CAP, G::RING>;
   auto kern = achip::render_frames_kernel<MODE, G::BLOCK, G::CAP, G::RING, COMP, SPLIT>;
   static bool attr_set = false; /* one flag per instantiation; benign race (idempotent call) */
@@ -45,28 +45,28 @@ hipError_t launch_one(const achip_frame_t *frames, int n, const achip_lut_t *lut
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)n * (unsigned)parts), dim3(G::BLOCK), (size_t)L::bytes, stream, frames, lut,
-                     out, stride, len, n, prof, parts, rows_per_part, part_sync, epoch);
+                     out, stride, len, n, prof, parts, rows_per_part, part_sync, epoch, uni);
   return hipGetLastError();
 }
 
 template <int MODE>
 hipError_t launch_mode(bool comp, const achip_frame_t *frames, int n, const achip_lut_t *lut, uint8_t *out,
                        uint64_t stride, uint32_t *len, unsigned long long *prof, int parts, int rows_per_part,
-                       unsigned long long *part_sync, uint32_t epoch, hipStream_t stream) {
+                       unsigned long long *part_sync, uint32_t epoch, const achip_uniform_t &uni, hipStream_t stream) {
   if (parts > 1) {
     if constexpr (HAS_SPLIT) {
       return comp ? launch_one<MODE, true, true>(frames, n, lut, out, stride, len, prof, parts, rows_per_part, part_sync,
-                                                 epoch, stream)
+                                                 epoch, uni, stream)
                   : launch_one<MODE, false, true>(frames, n, lut, out, stride, len, prof, parts, rows_per_part,
-                                                  part_sync, epoch, stream);
+                                                  part_sync, epoch, uni, stream);
     } else {
       return hipErrorInvalidValue;
     }
   }
   return comp ? launch_one<MODE, true, false>(frames, n, lut, out, stride, len, prof, 1, rows_per_part, nullptr, epoch,
-                                              stream)
+                                              uni, stream)
               : launch_one<MODE, false, false>(frames, n, lut, out, stride, len, prof, 1, rows_per_part, nullptr, epoch,
-                                               stream);
+                                               uni, stream);
 }
 
 } // namespace
@@ -78,12 +78,16 @@ extern "C" int ACHIP_CAT(achip_render_inst_launch_, ACHIP_INST)(int mode, int co
                                                                 const achip_lut_t *lut, uint8_t *out, uint64_t stride,
                                                                 uint32_t *len, unsigned long long *prof, int parts,
                                                                 int rows_per_part, unsigned long long *part_sync,
-                                                                uint32_t epoch, void *stream) {
+                                                                uint32_t epoch, const achip_uniform_t *uniform,
+                                                                void *stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
+  achip_uniform_t uni = {};
+  if (uniform && uniform->enabled && !comp)
+    uni = *uniform;
   switch (mode) {
 #define M(m)                                                                                                           \
   case m:                                                                                                              \
-    return (int)launch_mode<m>(comp != 0, frames, n, lut, out, stride, len, prof, parts, rows_per_part, part_sync, epoch, s);
+    return (int)launch_mode<m>(comp != 0, frames, n, lut, out, stride, len, prof, parts, rows_per_part, part_sync, epoch, uni, s);
     M(ACHIP_MODE_MONO)
     M(ACHIP_MODE_TRUE_FG)
     M(ACHIP_MODE_256_FG)

@@ -1075,7 +1075,7 @@ __global__ void __launch_bounds__(BLOCK)
     render_frames_kernel(const achip_frame_t *__restrict__ frames, const achip_lut_t *__restrict__ lut,
                          uint8_t *__restrict__ out, uint64_t out_stride, uint32_t *__restrict__ out_len, int n_frames,
                          unsigned long long *__restrict__ prof, int parts, int rows_per_part,
-                         unsigned long long *__restrict__ part_sync, uint32_t epoch) {
+                         unsigned long long *__restrict__ part_sync, uint32_t epoch, achip_uniform_t uni) {
   /* parts == 1: one workgroup renders the whole frame.  parts > 1: workgroup (frame, part) renders text rows
    * [part*rows_per_part, ...) -- exactly one chunk -- and learns where its bytes start from the lengths its
    * predecessors publish in part_sync[frame*parts + q] (see part_publish / part_wait). */
@@ -1101,6 +1101,7 @@ __global__ void __launch_bounds__(BLOCK)
    * quarter of the waves (wave & 3) issues both of its requests per point while the rest tokenises
    * (4K -> 200x60: 46.9 -> 45.1 us; profiles/r01_prefetch.txt) */
   constexpr bool SPREAD = PREFETCH && HB;
+  constexpr bool PRE_ISSUE = PREFETCH; /* same register budget argument */
   /* token stores as aligned atomic ORs of register-built dwords (PackSink) instead of byte stores (FastSink) */
   constexpr bool EMIT_OR = ((ACHIP_EMIT_OR_MODES) >> MODE) & 1;
   constexpr int NW = L::NW;
@@ -1124,9 +1125,9 @@ __global__ void __launch_bounds__(BLOCK)
   const int part = parts > 1 ? (int)blockIdx.x - fidx * parts : 0;
   if (fidx >= n_frames)
     return;
-  /* the glyph tables are requested before the descriptor is: the two fetches are one overlapped latency.
-   * (Requesting the first chunk's pixels here as well was measured: no gain, and the extra live registers push
-   * the small geometries over 128 VGPRs, i.e. to half the waves per CU.) */
+  /* the glyph tables are requested before the descriptor is: the two fetches are one overlapped latency.  In the
+   * 1024 x 2 geometry the first chunk's pixels are requested in the prologue as well (PRE_ISSUE below); the extra
+   * live registers would push the small geometries over 128 VGPRs, i.e. to half the waves per CU. */
   constexpr int LUTN = (256 + BLOCK - 1) / BLOCK;
   uint32_t lut_g[LUTN];
 #pragma unroll
@@ -1135,7 +1136,12 @@ __global__ void __launch_bounds__(BLOCK)
   const uint32_t lut_g64 = tid < 64 ? lut->glyph64[tid] : 0u;
   const uint32_t lut_ramp = tid < 64 ? lut->ramp[tid] : 0u;
   const bool ascii_only = (lut->flags & ACHIP_LUT_MULTIBYTE) == 0u;
-  achip_frame_t f = frames[fidx];
+  /* uniform batch: the descriptor came with the kernel arguments -- the first gather does not wait for a fetch */
+  achip_frame_t f = uni.f;
+  if (uni.enabled)
+    f.src = uni.f.src + (int64_t)fidx * uni.src_pitch;
+  else
+    f = frames[fidx];
 #if defined(ACHIP_ABLATE_NOOPS) /* diagnostics: cost of the folded display ops */
   f.ops = 0;
 #endif
@@ -1234,6 +1240,11 @@ __global__ void __launch_bounds__(BLOCK)
         gather_one(k, true, row0, cells);
     }
   };
+  /* the first chunk's samples are requested before the glyph tables are waited for: with the descriptor in the
+   * kernel arguments (uniform batches) nothing but address arithmetic stands between the launch and these requests,
+   * and the table fetch, the LDS set-up and the first barrier all run under their latency */
+  if (PRE_ISSUE)
+    gather_issue(row_begin, (min(row_end, row_begin + rows_per_chunk) - row_begin) * wp);
   /* glyph tables -> LDS */
 #pragma unroll
   for (int k = 0; k < LUTN; k++)
@@ -1303,7 +1314,7 @@ __global__ void __launch_bounds__(BLOCK)
 
     /* ---- A: commit the chunk's samples (requested one chunk ahead) to LDS with the mode's run key in
      * bits 31..24 ------------------------------------------------------------------------------- */
-    if (!PREFETCH || r0 == row_begin)
+    if (PRE_ISSUE ? false : (!PREFETCH || r0 == row_begin))
       gather_issue(r0, n);
 #pragma unroll
     for (int k = 0; k < SEG; k++) {

@@ -61,6 +61,17 @@ typedef struct {
   uint32_t ops;                  /* display-path pre-passes folded into the sampler: ACHIP_OP_* | tint << 8 */
 } achip_frame_t;
 
+/* A launch whose descriptors differ only in their source pointer, and there by a constant pitch (a batch of equally
+ * sized client frames in one slab, or a single frame): the common descriptor travels in the kernel arguments and
+ * workgroup i reads frame `f` with src = f.src + i * src_pitch -- no dependent descriptor fetch in front of the
+ * first gather.  enabled == 0: descriptors are read from the device array as usual. */
+typedef struct {
+  achip_frame_t f;
+  int64_t src_pitch;
+  uint32_t enabled;
+  uint32_t _pad;
+} achip_uniform_t;
+
 /* achip_frame_t.ops: the client display path flips the frame and applies a monochrome tint on full-frame
  * copies before rendering (src/common/session/display.c:546-623, lib/video/rgba/color_filter.c:246-345).
  * Both commute with nearest-neighbour sampling, so here they are an index map and a per-sample map. */

@@ -74,6 +74,12 @@ int asciichat_hip_plan_get_variant(const asciichat_hip_plan_t *plan);
 /* Multi-workgroup frames: 0 = automatic (small batches are cut into row bands so that the whole GPU works on
  * them), < 0 = never, > 0 = this many text rows per workgroup.  get_parts() reports workgroups per frame. */
 int asciichat_hip_plan_set_split(asciichat_hip_plan_t *plan, int rows_per_part);
+/* A plan whose descriptors differ only by a constant source pitch (equally sized client frames in one slab; or one
+ * frame) passes the common descriptor in the kernel arguments instead of having every workgroup fetch its own --
+ * one memory round trip less in front of the first gather.  Detected at create / update; on by default.
+ * set_uniform(plan, 0) forces the descriptor array (A/B measurements); get_uniform: 1 when the fast path is used. */
+int asciichat_hip_plan_set_uniform(asciichat_hip_plan_t *plan, int allow);
+int asciichat_hip_plan_get_uniform(const asciichat_hip_plan_t *plan);
 int asciichat_hip_plan_get_parts(const asciichat_hip_plan_t *plan);
 
 /*

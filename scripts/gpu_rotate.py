@@ -17,11 +17,13 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     for name in sys.argv[1:] or ["1080p_80x24_truecolor", "1080p_80x24_ansi256", "4k_200x60_truecolor"]:
         sw, sh, W, H, cl, rm = bench.WORKLOADS[name]
-        for S in (1, 2, 4, 8):
+        for S, uniform in ((1, True), (4, True), (4, False), (4, True), (4, False), (8, True)):
             if S * 256 * sw * sh * 3 > 60e9:
                 continue
             sets = [bench.make_frames(torch, 256, sw, sh, 100 + s) for s in range(S)]
             plans = [bench.build_plan(pkg, t, W, H, cl, rm)[0] for t in sets]
+            for p in plans:
+                p.set_uniform(uniform)
             out = torch.empty(256 * plans[0].stride, dtype=torch.uint8, device="cuda")
             ln = torch.zeros(256, dtype=torch.int32, device="cuda")
             for k in range(40):
@@ -35,7 +37,7 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1000 / steps
-            print(f"{name:24s} input sets {S}: {us:7.2f} us per 256-frame step  ({256 / us:6.2f} M frames/s)", flush=True)
+            print(f"{name:24s} input sets {S} descriptor {'by value' if plans[0].uniform else 'fetched '}: {us:7.2f} us per 256-frame step  ({256 / us:6.2f} M frames/s)", flush=True)
             for p in plans:
                 p.close()
             del sets, plans

@@ -35,6 +35,10 @@ class Frame(C.Structure):
                 ("x_ratio", C.c_uint32), ("y_ratio", C.c_uint32), ("src_stride", C.c_int32), ("ops", C.c_uint32)]
 
 
+class Uniform(C.Structure):
+    _fields_ = [("f", Frame), ("src_pitch", C.c_int64), ("enabled", C.c_uint32), ("_pad", C.c_uint32)]
+
+
 class Lut(C.Structure):
     _fields_ = [("glyph", C.c_uint32 * 256), ("glyph64", C.c_uint32 * 64), ("ramp", C.c_uint8 * 64), ("flags", C.c_uint32)]
 
@@ -59,6 +63,8 @@ def bind_host(L):
     L.achip_rainbow_color.argtypes = [C.c_float, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.POINTER(C.c_uint8)]
     L.achip_frame_set_rainbow.restype = C.c_int
     L.achip_frame_set_rainbow.argtypes = [C.POINTER(Frame), C.c_float]
+    L.achip_frames_uniform.restype = C.c_int
+    L.achip_frames_uniform.argtypes = [C.POINTER(Frame), C.c_int, C.POINTER(Uniform)]
     L.achip_frame_set_dither_style.restype = C.c_int
     L.achip_frame_set_dither_style.argtypes = [C.POINTER(Frame), C.c_bool, C.c_bool]
     L.achip_nn_ratio.restype = C.c_uint32

@@ -39,6 +39,8 @@ def lib():
         _lib.emu_render_batch.restype = C.c_int
         _lib.emu_render_batch.argtypes = [C.c_int, C.c_int, C.POINTER(Frame), C.c_int, C.POINTER(Lut), C.c_void_p,
                                           C.c_uint64, C.c_void_p]
+        _lib.emu_set_uniform.restype = C.c_int
+        _lib.emu_set_uniform.argtypes = [C.c_int]
         _lib.emu_set_parts.restype = None
         _lib.emu_set_parts.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_uint32]
         _lib.emu_resize_nn.restype = None
@@ -72,8 +74,9 @@ def make_lut(palette):
 _EPOCH = [0]
 
 
-def render_frames(mode, frames, palette, variant=0, stride=None, rows_per_part=0):
-    """rows_per_part > 0 renders every frame with ceil(rows / rows_per_part) workgroups (multi-part frames)."""
+def render_frames(mode, frames, palette, variant=0, stride=None, rows_per_part=0, uniform=False):
+    """uniform: pass the batch's common descriptor by value when it has one (what plans do by default).
+    rows_per_part > 0 renders every frame with ceil(rows / rows_per_part) workgroups (multi-part frames)."""
     """frames: ctypes array/list of Frame (src pointers = host numpy memory). Returns list of bytes / int codes."""
     L = lib()
     n = len(frames)
@@ -93,10 +96,12 @@ def render_frames(mode, frames, palette, variant=0, stride=None, rows_per_part=0
         sync = np.zeros(n * parts, dtype=np.uint64)
         _EPOCH[0] += 1
         L.emu_set_parts(parts, rows_per_part, sync.ctypes.data, _EPOCH[0])
+    L.emu_set_uniform(1 if uniform else 0)
     try:
         rc = L.emu_render_batch(mode, variant, arr, n, C.byref(lut), base, stride, ln.ctypes.data)
     finally:
         L.emu_set_parts(1, 0, None, 1)
+        L.emu_set_uniform(0)
     assert rc == 0
     res = []
     for i in range(n):

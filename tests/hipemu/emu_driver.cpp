@@ -5,25 +5,36 @@
 #define ACHIP_HIPEMU 1
 #include "render_kernels.hpp"
 #include "render_variants.h"
+#include "achip_host.h"
 
 static int g_parts = 1, g_rows_per_part = 0;
 static unsigned long long *g_part_sync = nullptr;
 static uint32_t g_epoch = 1;
+static int g_uniform = 0; /* 1: pass the batch's common descriptor by value when it has one (as plan.c does) */
 
 template <int MODE, int BLOCK, int CAP, int RING>
 static void run(const achip_frame_t *frames, int n, const achip_lut_t *lut, uint8_t *out, uint64_t stride,
                 uint32_t *len) {
   using L = achip::Lds<MODE, BLOCK, CAP, RING>;
+  achip_uniform_t uni = {};
+  if (g_uniform)
+    (void)achip_frames_uniform(frames, n, &uni);
   if (g_parts > 1) /* the two instantiations the product launches: row bands / whole frames (render_inst.hip) */
     hipemu::launch(dim3((unsigned)(n * g_parts)), dim3(BLOCK), (size_t)L::bytes, [&] {
       achip::render_frames_kernel<MODE, BLOCK, CAP, RING, true, true>(frames, lut, out, stride, len, n, nullptr, g_parts,
-                                                                      g_rows_per_part, g_part_sync, g_epoch);
+                                                                      g_rows_per_part, g_part_sync, g_epoch, uni);
     });
   else
     hipemu::launch(dim3((unsigned)n), dim3(BLOCK), (size_t)L::bytes, [&] {
       achip::render_frames_kernel<MODE, BLOCK, CAP, RING, true, false>(frames, lut, out, stride, len, n, nullptr, 1, 0,
-                                                                       nullptr, g_epoch);
+                                                                       nullptr, g_epoch, uni);
     });
+}
+
+extern "C" int emu_set_uniform(int on) {
+  const int was = g_uniform;
+  g_uniform = on;
+  return was;
 }
 
 /* multi-workgroup frames: set before emu_render_batch (parts == 1 restores the default) */

@@ -14,7 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 import orc  # noqa: E402
-from achip_ctypes import ALL_MODES, MODE_CAPS, MODE_NAMES, MODE_16_DITHER_BG, MODE_TRUE_BG  # noqa: E402
+from achip_ctypes import (ALL_MODES, MODE_CAPS, MODE_HB_TRUE, MODE_NAMES, MODE_16_DITHER_BG, MODE_TRUE_BG,  # noqa: E402
+                          MODE_TRUE_FG)
 
 
 @pytest.fixture(scope="module")
@@ -484,3 +485,51 @@ def test_server_tick_end_to_end(gpu):
             assert frame == orc.convert_with_caps(cams[(i + 1) % n], terms[i][0], terms[i][1], cl, rm, True, True, False)
         plan.close()
     table.close()
+
+
+def test_uniform_batches_pass_the_descriptor_by_value(gpu):
+    """Equally sized frames in one slab (and single frames): the plan hands the common descriptor to the kernel with
+    its arguments; bytes identical to the descriptor-array path, for whole batches, sub-ranges and row bands."""
+    pkg, torch = gpu
+    imgs = [orc.frame_hash_noise(320, 200, 50 + k) for k in range(6)]
+    slab = torch.from_numpy(np.ascontiguousarray(np.stack(imgs))).cuda()
+    for mode in (MODE_TRUE_FG, MODE_HB_TRUE, 2, 0, MODE_16_DITHER_BG):
+        rm = MODE_CAPS.get(mode, (3, 0))[1]
+        frames = [pkg.frame_setup(slab.data_ptr() + k * 320 * 200 * 3, 320, 200, 100, 30, rm, True, True, False)
+                  for k in range(6)]
+        exp = [oracle_convert(i, mode, 100, 30, orc.PALETTE_STANDARD, True, True) for i in imgs]
+        plan = pkg.Plan(mode, orc.PALETTE_STANDARD, frames)
+        assert plan.uniform
+        out = torch.zeros(6 * plan.stride, dtype=torch.uint8, device="cuda")
+        ln = torch.zeros(6, dtype=torch.int32, device="cuda")
+
+        def take(first=0, count=6):
+            torch.cuda.synchronize()
+            h, l = out.cpu().numpy(), ln.cpu().numpy()
+            return [h[k * plan.stride:k * plan.stride + int(l[k])].tobytes() for k in range(count)]
+
+        for allow in (True, False, True):
+            plan.set_uniform(allow)
+            assert plan.uniform == allow
+            out.zero_()
+            plan.render(out.data_ptr(), plan.stride, ln.data_ptr())
+            assert take() == exp, (mode, allow)
+        out.zero_()
+        plan.render(out.data_ptr(), plan.stride, ln.data_ptr(), 0, 2, 3)   # frames 2..4 into slots 0..2
+        assert take(count=3) == exp[2:5], mode
+        if mode != MODE_16_DITHER_BG:
+            plan.set_split(4)
+            assert plan.parts > 1 and plan.uniform
+            out.zero_()
+            plan.render(out.data_ptr(), plan.stride, ln.data_ptr())
+            assert take() == exp, (mode, "bands")
+        # an update that breaks the progression falls back to the array
+        frames[1], frames[4] = frames[4], frames[1]
+        plan.update(frames)
+        assert not plan.uniform
+        out.zero_()
+        plan.render(out.data_ptr(), plan.stride, ln.data_ptr())
+        e2 = list(exp)
+        e2[1], e2[4] = e2[4], e2[1]
+        assert take() == e2, (mode, "fallback")
+        plan.close()

@@ -125,6 +125,37 @@ def test_rainbow_filter_folded_into_emission():
                                                                                              orc.PALETTE_STANDARD)
 
 
+def test_uniform_batch_descriptor_by_value():
+    """Batches whose descriptors differ only by a constant source pitch (and single frames) get the common descriptor
+    with the kernel arguments (achip_frames_uniform): same bytes as through the descriptor array, in every mode,
+    whole-frame and row-band launches; anything else falls back to the array."""
+    import ctypes as C
+
+    from achip_ctypes import Uniform
+    L = emu.lib()
+    slab = np.ascontiguousarray(np.stack([orc.frame_hash_noise(96, 64, 30 + k) for k in range(3)]))
+    frames = [emu.frame_for_convert(slab[k], 40, 12, 0) for k in range(3)]
+    u = Uniform()
+    assert L.achip_frames_uniform((emu.Frame * 3)(*frames), 3, C.byref(u)) == 1 and u.src_pitch == 96 * 64 * 3
+    assert L.achip_frames_uniform((emu.Frame * 1)(frames[2]), 1, C.byref(u)) == 1 and u.src_pitch == 0
+    odd = [frames[0], frames[2], frames[1]]                       # not an arithmetic progression of sources
+    assert L.achip_frames_uniform((emu.Frame * 3)(*odd), 3, C.byref(u)) == 0 and u.enabled == 0
+    other = emu.frame_for_convert(slab[1], 41, 12, 0)             # a differing field
+    assert L.achip_frames_uniform((emu.Frame * 2)(frames[0], other), 2, C.byref(u)) == 0
+    back = [frames[2], frames[1], frames[0]]                      # negative pitch is a pitch too
+    assert L.achip_frames_uniform((emu.Frame * 3)(*back), 3, C.byref(u)) == 1 and u.src_pitch == -96 * 64 * 3
+    for mode in ALL_MODES:
+        rm = MODE_CAPS.get(mode, (3, 0))[1]
+        fs = [emu.frame_for_convert(slab[k], 40, 12, rm) for k in range(3)]
+        exp = [oracle_convert(slab[k], mode, 40, 12, orc.PALETTE_STANDARD) for k in range(3)]
+        assert emu.render_frames(mode, fs, orc.PALETTE_STANDARD, 2, uniform=True) == exp, MODE_NAMES[mode]
+        assert emu.render_frames(mode, fs[::-1], orc.PALETTE_STANDARD, 2, uniform=True) == exp[::-1]
+        assert emu.render_frames(mode, [fs[0], fs[2], fs[1]], orc.PALETTE_STANDARD, 2, uniform=True) == [exp[0], exp[2], exp[1]]
+    fs = [emu.frame_for_convert(slab[k], 40, 12, 2, True, True) for k in range(3)]
+    exp = [oracle_convert(slab[k], MODE_HB_TRUE, 40, 12, orc.PALETTE_STANDARD, True, True) for k in range(3)]
+    assert emu.render_frames(MODE_HB_TRUE, fs, orc.PALETTE_STANDARD, 2, rows_per_part=2, uniform=True) == exp
+
+
 def test_display_prepasses_folded_into_sampler():
     """flip_x / flip_y / colour filters of the client display path (display.c:546-623) as sampler maps."""
     import ctypes as C
