@@ -338,7 +338,7 @@ def main():
             del res
             torch.cuda.empty_cache()
             b = args.batch
-            res = run_workload(torch, pkg, name, b, max(10, args.steps // 10), 3, None,
+            res = run_workload(torch, pkg, name, b, max(40, args.steps // 4), 8, None,
                                input_sets=args.input_sets, hot_leg=False)
             k = res["kernel_ms_back_to_back"]
             a = res["alg_bytes_per_launch"] / (k * 1e-3) / 1e9
