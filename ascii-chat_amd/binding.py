@@ -88,6 +88,8 @@ def lib():
     L.asciichat_hip_plan_get_variant.argtypes = [vp]
     L.asciichat_hip_plan_set_split.restype = ci
     L.asciichat_hip_plan_set_split.argtypes = [vp, ci]
+    L.asciichat_hip_plan_set_concurrency.restype = ci
+    L.asciichat_hip_plan_set_concurrency.argtypes = [vp, ci]
     L.asciichat_hip_plan_set_uniform.restype = ci
     L.asciichat_hip_plan_set_uniform.argtypes = [vp, ci]
     L.asciichat_hip_plan_get_uniform.restype = ci
@@ -280,6 +282,11 @@ class Plan:
     def uniform(self):
         """True when launches pass the batch's common descriptor in the kernel arguments"""
         return bool(lib().asciichat_hip_plan_get_uniform(self._h))
+
+    def set_concurrency(self, launches_in_flight):
+        rc = lib().asciichat_hip_plan_set_concurrency(self._h, launches_in_flight)
+        if rc != 0:
+            raise RuntimeError(f"set_concurrency({launches_in_flight}) failed: {last_error()}")
 
     def set_uniform(self, allow):
         lib().asciichat_hip_plan_set_uniform(self._h, 1 if allow else 0)

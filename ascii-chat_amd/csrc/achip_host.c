@@ -323,16 +323,18 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
   *rows_per_part = max_rows > 0 ? max_rows : 1;
   if (n_cus < 1)
     n_cus = 256;
-  /* Whole-frame geometries (measured on MI355X, profiles/r01_split_sweep.txt): up to ~1.5 workgroups per CU
-   * the 1024-thread x 2-cell geometry (4) has the shortest per-frame latency chain; with more frames than
-   * that, several small workgroups per CU overlap each other's gather / token / drain phases instead. */
-  const int small = max_wp <= variant_caps[2] ? 2 : (max_wp <= variant_caps[1] ? 1 : -1);
+  /* Whole-frame geometries (measured on MI355X, profiles/r01_split_sweep.txt, r01_overlap.txt): up to ~1.5
+   * workgroups per CU the 1024-thread x 2-cell geometry (4) has the shortest per-frame latency chain; with more
+   * frames than that in flight -- one large launch, or several launches kept in flight on separate streams, in which
+   * case the caller passes its share of the CUs -- two or three 512-thread workgroups per CU overlap each other's
+   * gather (HBM-bound) and token (latency-bound) phases instead.  Not the half-block modes: their kernels need more
+   * than 128 VGPRs in the small geometries and lose more than the overlap gains. */
   if (forced_variant >= 0) {
     if (max_wp > variant_caps[forced_variant])
       return -1;
     *variant = forced_variant;
-  } else if (n_frames > (3 * n_cus) / 2 && small >= 0) {
-    *variant = small;
+  } else if (!hb && n_frames > (3 * n_cus) / 2 && max_wp <= variant_caps[1]) {
+    *variant = 1;
   } else if (max_wp <= variant_caps[4]) {
     *variant = 4;
   } else if (max_wp <= variant_caps[0]) {

@@ -174,6 +174,7 @@ struct asciichat_hip_plan {
   int parts_cap;
   uint32_t epoch;
   achip_uniform_t uniform; /* the batch's common descriptor, when it has one (achip_frames_uniform) */
+  int concurrency;         /* launches the caller keeps in flight on separate streams (>= 1) */
   int uniform_off;         /* asciichat_hip_plan_set_uniform(plan, 0): always read the device array */
   size_t stride;
   achip_frame_t *frames_dev;
@@ -199,7 +200,8 @@ static int choose_geometry(asciichat_hip_plan_t *p, const achip_frame_t *frames)
   int variant = -1, parts = 1, rpp = 1;
   const char *env = getenv("ASCIICHAT_HIP_VARIANT");
   const int forced = p->variant_user >= 0 ? p->variant_user : (env && env[0] ? atoi(env) : -1);
-  if (achip_choose_geometry(p->mode, frames, p->n, p->palette_ascii != 0, caps, device_cus(),
+  const int cus = device_cus() / (p->concurrency > 1 ? p->concurrency : 1);
+  if (achip_choose_geometry(p->mode, frames, p->n, p->palette_ascii != 0, caps, cus > 0 ? cus : 1,
                             forced >= 0 && p->split_request == 0 ? -1 : p->split_request, /* explicit geometry alone: whole frames */
                             forced < ACHIP_VARIANT_COUNT ? forced : -1, &variant, &parts, &rpp) != 0)
     return -1;
@@ -264,6 +266,7 @@ int asciichat_hip_plan_create(asciichat_hip_plan_t **plan, int mode, const char 
   p->mode = mode;
   p->n = n_frames;
   p->variant_user = -1;
+  p->concurrency = 1;
   p->palette_ascii = achip_palette_ascii_only(palette_chars) ? 1 : 0;
   rc = plan_measure(p, frames);
   if (!rc)
@@ -323,6 +326,13 @@ int asciichat_hip_plan_set_split(asciichat_hip_plan_t *p, int rows_per_part) {
 }
 
 int asciichat_hip_plan_get_parts(const asciichat_hip_plan_t *p) { return p ? p->parts : 0; }
+
+int asciichat_hip_plan_set_concurrency(asciichat_hip_plan_t *p, int launches_in_flight) {
+  if (!p || launches_in_flight < 1)
+    return ASCIICHAT_HIP_ERR_INVALID_PARAM;
+  p->concurrency = launches_in_flight;
+  return plan_measure(p, p->frames_pinned);
+}
 
 int asciichat_hip_plan_set_uniform(asciichat_hip_plan_t *p, int allow) {
   if (!p)

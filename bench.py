@@ -54,30 +54,51 @@ def build_plan(pkg, frames_t, W, H, cl, rm):
     return pkg.Plan(mode, PALETTE_STANDARD, descs), mode
 
 
-def time_steps(torch, plans, out, ln, steps, warmup, dist=None):
-    """K back-to-back launches; launch k renders input set k % len(plans) (all sets share the output slab)."""
-    stream = torch.cuda.current_stream().cuda_stream
-    S = len(plans)
+def time_steps(torch, plans, outs, lns, streams, steps, warmup, dist=None):
+    """K launches: launch k renders input batch k % len(plans) on stream k % len(streams) into that stream's own output
+    slab (len(plans) is a multiple of len(streams), so a plan always runs on the same stream).  One stream = launches
+    back to back; several = that many independent batches in flight.  Returns wall seconds, the GPU time of the whole
+    region (events on the current stream, which every launch stream is fenced against on both sides) and the average
+    duration of ONE launch (events on each launch stream around its share of the launches)."""
+    P, S = len(plans), len(streams)
+    assert P % S == 0
+    cur = torch.cuda.current_stream()
+
+    def launch(k):
+        s = k % S
+        plans[k % P].render(outs[s].data_ptr(), plans[0].stride, lns[s].data_ptr(), streams[s].cuda_stream)
+
     for k in range(warmup):
-        plans[k % S].render(out.data_ptr(), plans[0].stride, ln.data_ptr(), stream)
+        launch(k)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
+    b = [torch.cuda.Event(enable_timing=True) for _ in range(S)]
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(S)]
     t0 = time.perf_counter()
-    e0.record()
+    e0.record(cur)
+    for s in range(S):
+        if streams[s] != cur:
+            streams[s].wait_event(e0)
+        b[s].record(streams[s])
     for k in range(steps):
-        plans[k % S].render(out.data_ptr(), plans[0].stride, ln.data_ptr(), stream)
-    e1.record()
+        launch(k)
+    for s in range(S):
+        e[s].record(streams[s])
+        if streams[s] != cur:
+            cur.wait_event(e[s])
+    e1.record(cur)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     gpu_ms = e0.elapsed_time(e1)
-    return wall, gpu_ms
+    per_launch = [b[s].elapsed_time(e[s]) / len(range(s, steps, S)) for s in range(S) if s < steps]
+    return wall, gpu_ms, sum(per_launch) / len(per_launch)
 
 
 def kernel_time_events(torch, plans, out, ln, reps):
@@ -96,39 +117,55 @@ def kernel_time_events(torch, plans, out, ln, reps):
     return tot / reps
 
 
-def run_workload(torch, pkg, name, batch, steps, warmup, dist=None, seed=1234, variant=-1, input_sets=1,
-                 hot_leg=True):
-    """input_sets independent batches of source frames are rendered round-robin: a video tick never renders the frames
-    of the tick before, and the sampled sectors of ONE batch (~18-31 MB at 1080p->80x24) would otherwise be served by
-    the 256 MB Infinity Cache from the second step on (scripts/gpu_rotate.py: 11.8 us hot vs 14.0-14.3 us fresh)."""
+def run_workload(torch, pkg, name, batch, steps, warmup, dist=None, seed=1234, variant=-1, input_sets=4, streams=1,
+                 serial_leg=True):
+    """`streams` independent batches are kept in flight on separate HIP streams (the reference's model is one render
+    thread per client, src/server/render.c:1233): a launch is a gather burst (HBM-bound) followed by token work
+    (latency-bound, HBM idle), and launches in flight overlap those phases (profiles/r01_overlap.txt).
+    input_sets x streams independent batches of source frames are rendered round-robin: a video tick never renders the
+    frames of the tick before, and the sampled lines of ONE batch (36 MB at 1080p->80x24) would otherwise be served by
+    the 256 MB Infinity Cache from the second step on (profiles/r01_input_sets.txt)."""
     sw, sh, W, H, cl, rm = WORKLOADS[name]
-    sets = [make_frames(torch, batch, sw, sh, seed + 7919 * s) for s in range(input_sets)]
+    nsets = input_sets * streams
+    sets = [make_frames(torch, batch, sw, sh, seed + 7919 * s) for s in range(nsets)]
     plans = []
     for t in sets:
         plan, mode = build_plan(pkg, t, W, H, cl, rm)
+        plan.set_concurrency(streams)
         if variant >= 0:
             plan.set_variant(variant)
         plans.append(plan)
-    out = torch.empty(batch * plans[0].stride, dtype=torch.uint8, device="cuda")
-    ln = torch.zeros(batch, dtype=torch.int32, device="cuda")
+    cur = torch.cuda.current_stream()
+    lanes = [cur] + [torch.cuda.Stream() for _ in range(streams - 1)]
+    outs = [torch.empty(batch * plans[0].stride, dtype=torch.uint8, device="cuda") for _ in range(streams)]
+    lns = [torch.zeros(batch, dtype=torch.int32, device="cuda") for _ in range(streams)]
     rows = 2 * H if rm == 2 else H
     out_bytes = []
-    stream = torch.cuda.current_stream().cuda_stream
     for plan in plans:  # exact output bytes of every set (SURVEY 8(d): sampled RGB consumed + exact output bytes)
-        plan.render(out.data_ptr(), plan.stride, ln.data_ptr(), stream)
-        lens = ln.cpu().numpy().astype("uint32")
+        plan.render(outs[0].data_ptr(), plan.stride, lns[0].data_ptr(), cur.cuda_stream)
+        lens = lns[0].cpu().numpy().astype("uint32")
         assert (lens < 0xFFFFFFF0).all(), "kernel reported overflow/bad descriptor"
         out_bytes.append(int(lens.sum()))
-    wall, gpu_ms = time_steps(torch, plans, out, ln, steps, warmup, dist)
+    wall, gpu_ms, launch_ms = time_steps(torch, plans, outs, lns, lanes, steps, warmup, dist)
     alg_bytes = int(sum(out_bytes) / len(out_bytes)) + batch * 3 * W * rows
-    per_launch_ms = kernel_time_events(torch, plans, out, ln, 20)
-    hot_ms = None
-    if input_sets > 1 and hot_leg:  # the same figure when one batch is rendered over and over (its sectors stay in the Infinity Cache)
-        hot_ms = time_steps(torch, plans[:1], out, ln, max(20, steps // 4), 5, None)[1] / max(20, steps // 4)
     res = dict(name=name, mode=pkg.MODE_NAMES[mode], batch=batch, wall_s=wall, gpu_ms=gpu_ms, steps=steps,
                out_bytes_per_frame=sum(out_bytes) / len(out_bytes) / batch, alg_bytes_per_launch=alg_bytes,
-               kernel_ms_event_pair=per_launch_ms, kernel_ms_back_to_back=gpu_ms / steps, kernel_ms_hot_input=hot_ms,
-               variant=plans[0].variant, input_sets=input_sets, frames=sets, plan=plans[0], plans=plans, out=out, ln=ln)
+               launch_ms=launch_ms, ms_per_step_gpu=gpu_ms / steps, variant=plans[0].variant, input_sets=nsets,
+               streams=streams, frames=sets, plan=plans[0], plans=plans, out=outs[0], ln=lns[0], serial=None)
+    if serial_leg:
+        # the same steps issued back to back on ONE stream (each plan re-chooses its geometry for the whole GPU), next
+        # to it the per-launch event-pair time (with launch latency) and the same batch rendered every step
+        for plan in plans:
+            plan.set_concurrency(1)
+            if variant >= 0:
+                plan.set_variant(variant)
+        n1 = max(40, steps // 2)
+        _, g1, l1 = time_steps(torch, plans, outs[:1], lns[:1], lanes[:1], n1, 8, None)
+        pair = kernel_time_events(torch, plans, outs[0], lns[0], 20)
+        _, gh, _ = time_steps(torch, plans[:1], outs[:1], lns[:1], lanes[:1], n1, 8, None)
+        res["serial"] = {"kernel_ms": g1 / n1, "frames_per_s": batch * n1 / (g1 * 1e-3), "kernel_variant": plans[0].variant,
+                         "kernel_ms_event_pair": pair, "kernel_ms_same_batch_every_step": gh / n1,
+                         "roofline_frac": alg_bytes / (g1 / n1 * 1e-3) / 1e9 / HBM_PEAK_GBS}
     return res
 
 
@@ -177,7 +214,7 @@ def run_grid9(torch, pkg, steps, warmup):
     plan = pkg.Plan(pkg.lib().achip_mode_from_caps(3, 0), PALETTE_STANDARD, descs)
     out = torch.empty(n * plan.stride, dtype=torch.uint8, device="cuda")
     ln = torch.zeros(n, dtype=torch.int32, device="cuda")
-    wall, gpu_ms = time_steps(torch, [plan], out, ln, steps, warmup, None)
+    wall, gpu_ms, _ = time_steps(torch, [plan], [out], [ln], [torch.cuda.current_stream()], steps, warmup, None)
     lens = ln.cpu().numpy().astype("uint32")
     assert (lens < 0xFFFFFFF0).all()
     cells = int(sum(d.out_w * d.out_h for d in descs))
@@ -231,11 +268,12 @@ def load_pmc_traffic(workload, variant, batch):
         return None
     if not ent or ent.get("variant") != variant or ent.get("batch") != batch:
         return None
-    # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB.  The guide's gfx950 correction (FETCH_SIZE = 1/2 of the bytes)
-    # is calibrated for wide coalesced streams only; this kernel's reads are sparse 4-byte gathers, so the raw
-    # value is kept as the lower bound and the corrected one as the upper bound.
+    # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB.  On gfx950 FETCH_SIZE tallies 128-byte line fetches at 64 B
+    # (MI355X_MICROARCH.md, "HBM"); calibrated for this kernel's access pattern by scripts/ubench/sparse_fetch.hip
+    # (profiles/r01_ubench_sparse_fetch.txt): a lone dword load moves one whole 128-byte line, so the x2 correction
+    # applies to the sparse gathers as well (and 2 x FETCH_SIZE equals the bytes of the sampled source rows).
     fetch, write = ent["fetch_size_kb"] * 1024.0, ent["write_size_kb"] * 1024.0
-    return {"hbm_bytes": fetch + write, "fetch_bytes_raw": fetch, "fetch_bytes_x2_corrected": 2 * fetch,
+    return {"hbm_bytes": 2 * fetch + write, "fetch_bytes_raw": fetch, "fetch_bytes_x2_corrected": 2 * fetch,
             "write_bytes": write, "source": ent.get("source", "profiles/pmc_traffic.json")}
 
 
@@ -252,9 +290,11 @@ def main():
     ap.add_argument("--no-d2h", action="store_true", help="skip the PCIe-inclusive with_d2h leg (profiling runs)")
     ap.add_argument("--variant", type=int, default=-1)
     ap.add_argument("--input-sets", type=int, default=4,
-                    help="independent batches of source frames rendered round-robin (1 = the same batch every step)")
+                    help="independent batches of source frames per stream, rendered round-robin (1 = the same batch every step)")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="independent batches kept in flight on separate HIP streams (1 = one launch at a time)")
     ap.add_argument("--no-hot", action="store_true",
-                    help="skip the same-batch-every-step comparison leg (profiling runs: keeps the kernel trace to the timed launches)")
+                    help="skip the one-launch-at-a-time / same-batch comparison legs (profiling runs: keeps the kernel trace to the timed launches)")
     args = ap.parse_args()
 
     import torch
@@ -284,7 +324,8 @@ def main():
         dist = d
 
     res = run_workload(torch, pkg, args.workload, args.batch, args.steps, args.warmup, dist, seed=1234 + rank,
-                       variant=args.variant, input_sets=args.input_sets, hot_leg=not args.no_hot)
+                       variant=args.variant, input_sets=args.input_sets, streams=args.streams,
+                       serial_leg=not args.no_hot)
     wall = res["wall_s"]
     if dist is not None:
         t = torch.tensor([wall], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
@@ -293,29 +334,35 @@ def main():
     total_frames = args.batch * args.steps * world
     value = total_frames / wall
 
-    # average launch duration over the timed region, from HIP events on the launch stream around the K back-to-back
-    # launches (this is the figure rocprofv3 --kernel-trace --stats agrees with: profiles/r01_bench_kernel_stats.csv);
-    # the per-launch event-pair time additionally contains ~2-3 us of launch latency and is reported alongside
-    kernel_ms = res["kernel_ms_back_to_back"]
-    achieved = res["alg_bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9
+    # Roofline of the frame kernel over the timed region.  `kernel_ms` is the average duration of ONE launch, from HIP
+    # events on each launch stream around its share of the K launches -- the figure rocprofv3 --kernel-trace --stats
+    # agrees with (profiles/r01_bench_kernel_stats.csv).  With `launches_in_flight` launches overlapping, the bytes the
+    # kernel moves per second are those of all of them: achieved = launches_in_flight x B_alg / kernel_ms, which is the
+    # same as K x B_alg / (GPU time of the region) when the streams stay busy; the region figure is what is reported
+    # (`ms_per_launch_effective` = region / K).  One stream: the two coincide.
+    eff_ms = res["ms_per_step_gpu"]
+    achieved = res["alg_bytes_per_launch"] / (eff_ms * 1e-3) / 1e9
     line = {
         "metric": "frames/sec, 1080p->80x24 truecolor (batch of independent client frames)",
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u8", "data": f"synthetic (uniform-random RGB24 frames generated on device, resident in HBM; {args.input_sets} independent "
+        "dtype": "u8",
+        "data": f"synthetic (uniform-random RGB24 frames generated on device, resident in HBM; {res['input_sets']} independent "
                 "batches rendered round-robin so no step re-reads the frames of the step before)",
         "config": {"workload": args.workload, "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                    "src": f"{WORKLOADS[args.workload][0]}x{WORKLOADS[args.workload][1]}",
                    "grid": f"{WORKLOADS[args.workload][2]}x{WORKLOADS[args.workload][3]}", "mode": res["mode"],
                    "parallelism": f"frames sharded over {world} rank(s), no data-path collective",
-                   "kernel_variant": res["variant"], "input_sets": args.input_sets},
+                   "kernel_variant": res["variant"], "input_sets": res["input_sets"],
+                   "launches_in_flight": args.streams},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "alg_bytes_per_launch": res["alg_bytes_per_launch"], "kernel_ms": kernel_ms,
-                     "kernel_ms_event_pair": res["kernel_ms_event_pair"],
-                     "kernel_ms_same_batch_every_step": res["kernel_ms_hot_input"],
+                     "alg_bytes_per_launch": res["alg_bytes_per_launch"], "kernel_ms": res["launch_ms"],
+                     "launches_in_flight": args.streams, "ms_per_launch_effective": eff_ms,
                      "out_bytes_per_frame": res["out_bytes_per_frame"]},
     }
+    if res["serial"] is not None:
+        line["one_launch_at_a_time"] = res["serial"]
     # HBM traffic per launch comes from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE cannot share a
     # pass, MI355X_MICROARCH.md "rocprofv3 PMC slots"); scripts/pmc_run.sh collects them and the summary is
     # committed under profiles/.  When a summary for this workload and kernel geometry exists it is reported here.
@@ -338,14 +385,15 @@ def main():
             del res
             torch.cuda.empty_cache()
             b = args.batch
-            res = run_workload(torch, pkg, name, b, max(40, args.steps // 4), 8, None,
-                               input_sets=args.input_sets, hot_leg=False)
-            k = res["kernel_ms_back_to_back"]
+            res = run_workload(torch, pkg, name, b, max(40, args.steps // 4), 8, None, input_sets=args.input_sets,
+                               streams=args.streams, serial_leg=not args.no_hot)
+            k = res["ms_per_step_gpu"]
             a = res["alg_bytes_per_launch"] / (k * 1e-3) / 1e9
-            others[name] = {"frames_per_s": b * res["steps"] / res["wall_s"], "kernel_ms": k,
+            others[name] = {"frames_per_s": b * res["steps"] / res["wall_s"], "ms_per_launch_effective": k,
+                            "kernel_ms": res["launch_ms"], "launches_in_flight": args.streams,
                             "out_bytes_per_frame": res["out_bytes_per_frame"], "roofline_GBps": a,
                             "roofline_frac": a / HBM_PEAK_GBS, "kernel_variant": res["variant"],
-                            "input_sets": res["input_sets"]}
+                            "input_sets": res["input_sets"], "one_launch_at_a_time": res["serial"]}
         del res
         torch.cuda.empty_cache()
         if args.others:

@@ -81,7 +81,8 @@ int achip_frame_blob_parse(const void *blob, size_t size, bool exact, uint32_t *
  * workgroups (each band exactly one chunk of its geometry; the bands learn their output offset from each other
  * on the device).
  *   variant_caps[v]  cells per chunk of kernel geometry v (render_variants.h)
- *   n_cus            compute units of the device
+ *   n_cus            compute units this launch can count on: the device's, divided by the number of launches the
+ *                    caller keeps in flight on separate streams (asciichat_hip_plan_set_concurrency)
  *   split_request    0 = automatic, < 0 = never split, > 0 = this many text rows per band
  *   forced_variant   >= 0: use this geometry (tuning), -1: choose
  * Outputs the geometry id, bands per frame (1 = no split) and text rows per band.  Returns 0, or -1 when a

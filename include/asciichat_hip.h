@@ -74,6 +74,12 @@ int asciichat_hip_plan_get_variant(const asciichat_hip_plan_t *plan);
 /* Multi-workgroup frames: 0 = automatic (small batches are cut into row bands so that the whole GPU works on
  * them), < 0 = never, > 0 = this many text rows per workgroup.  get_parts() reports workgroups per frame. */
 int asciichat_hip_plan_set_split(asciichat_hip_plan_t *plan, int rows_per_part);
+/* Pipelining hint.  One launch is a gather burst (HBM-bound) followed by token work (latency-bound, HBM idle); a caller
+ * that keeps `launches_in_flight` independent batches in flight on separate streams -- the reference's model: one render
+ * thread per client (src/server/render.c:1233) -- lets those phases overlap, and the plan then picks the geometry
+ * for its share of the GPU (1080p->80x24, 256 frames per launch: 13.7 us per launch alone, 8.8 us with three in
+ * flight; profiles/r01_overlap.txt).  Default 1.  Launches of ONE plan must still be ordered (one stream). */
+int asciichat_hip_plan_set_concurrency(asciichat_hip_plan_t *plan, int launches_in_flight);
 /* A plan whose descriptors differ only by a constant source pitch (equally sized client frames in one slab; or one
  * frame) passes the common descriptor in the kernel arguments instead of having every workgroup fetch its own --
  * one memory round trip less in front of the first gather.  Detected at create / update; on by default.

@@ -1,0 +1,90 @@
+"""Can consecutive 256-frame steps overlap each other's phases?  One step is gather (HBM-bound burst) followed by
+tokenise/emit (latency-bound, HBM idle).  Measures, per kernel geometry, 256-frame steps issued (a) back to back on one
+stream, (b) round-robin on 2 / 3 streams (independent batches, separate output slabs), (c) as one launch of 512 / 1024
+frames.  Fresh input batch every step (4 sets per stream)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from __graft_entry__ import load_package  # noqa: E402
+
+
+def main():
+    pkg = load_package()
+    torch.cuda.set_device(0)
+    name = sys.argv[1] if len(sys.argv) > 1 else "1080p_80x24_truecolor"
+    sw, sh, W, H, cl, rm = bench.WORKLOADS[name]
+    nsets = 8
+    sets = [bench.make_frames(torch, 256, sw, sh, 300 + s) for s in range(nsets)]
+    steps = 480 if sw < 3000 else 120
+    big_too = len(sys.argv) > 2
+    for variant in (4, 1, 2):
+        for nstreams in (1, 2, 3, 4, 6):
+            plans = [bench.build_plan(pkg, t, W, H, cl, rm)[0] for t in sets]
+            try:
+                for p in plans:
+                    p.set_variant(variant)
+            except RuntimeError:
+                continue
+            streams = [torch.cuda.Stream() for _ in range(nstreams)]
+            outs = [torch.empty(256 * plans[0].stride, dtype=torch.uint8, device="cuda") for _ in range(nstreams)]
+            lns = [torch.zeros(256, dtype=torch.int32, device="cuda") for _ in range(nstreams)]
+
+            def run(k):
+                s = k % nstreams
+                plans[k % nsets].render(outs[s].data_ptr(), plans[0].stride, lns[s].data_ptr(), streams[s].cuda_stream)
+
+            for k in range(48):
+                run(k)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for st in streams:
+                st.wait_event(e0)
+            for k in range(steps):
+                run(k)
+            for st in streams:
+                e = torch.cuda.Event()
+                e.record(st)
+                torch.cuda.current_stream().wait_event(e)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1000 / steps
+            print(f"{name} variant {variant} streams {nstreams}: {us:7.2f} us per 256-frame step ({256 / us:6.2f} M frames/s)",
+                  flush=True)
+            for p in plans:
+                p.close()
+    # one launch of 512 / 1024 frames (what a server with more clients would submit)
+    for nb in ((512, 1024) if big_too else ()):
+        big = [torch.cat(sets[i * (nb // 256):(i + 1) * (nb // 256)]) for i in range(nsets * 256 // nb)]
+        for variant in (-1, 4, 1, 2):
+            plans = [bench.build_plan(pkg, t, W, H, cl, rm)[0] for t in big]
+            for p in plans:
+                if variant >= 0:
+                    p.set_variant(variant)
+            out = torch.empty(nb * plans[0].stride, dtype=torch.uint8, device="cuda")
+            ln = torch.zeros(nb, dtype=torch.int32, device="cuda")
+            st = torch.cuda.current_stream().cuda_stream
+            for k in range(16):
+                plans[k % len(plans)].render(out.data_ptr(), plans[0].stride, ln.data_ptr(), st)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n = 200
+            e0.record()
+            for k in range(n):
+                plans[k % len(plans)].render(out.data_ptr(), plans[0].stride, ln.data_ptr(), st)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1000 / n
+            print(f"{name} one launch of {nb} frames, variant {plans[0].variant}: {us:7.2f} us = {us * 256 / nb:6.2f} us per 256 frames "
+                  f"({nb / us:6.2f} M frames/s)", flush=True)
+            for p in plans:
+                p.close()
+        del big
+
+
+if __name__ == "__main__":
+    main()

@@ -28,7 +28,9 @@ for name in ("sq1","sq2","fetch","write"):
             if k in ("FETCH_SIZE", "WRITE_SIZE"):
                 traffic[k] = (v / n, n)
 if len(traffic) == 2:  # what bench.py reads as profiles/pmc_traffic.json (copy it there together with the summary)
-    json.dump({"$WL": {"variant": 4, "batch": 256, "fetch_size_kb": round(traffic["FETCH_SIZE"][0], 1),
+    import re
+    m = re.search(r'"kernel_variant": (\d+)', open("$OUT/fetch.log").read())
+    json.dump({"$WL": {"variant": int(m.group(1)) if m else 4, "batch": 256, "fetch_size_kb": round(traffic["FETCH_SIZE"][0], 1),
                        "write_size_kb": round(traffic["WRITE_SIZE"][0], 1),
                        "source": "profiles/r01_pmc_summary_$WL.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, "
                                  "per-dispatch mean over %d dispatches)" % traffic["FETCH_SIZE"][1]}},

@@ -62,7 +62,10 @@ def test_split_ragged_batch_and_policy():
     assert choose(1, one * 128) == (4, 2, 12)
     assert choose(1, one * 150) == (2, 2, 12)                 # more bands than CUs: the geometry that fits a band
     assert choose(1, one * 256) == (4, 1, 24)                 # BASELINE batch = one frame per CU: whole frames
-    assert choose(1, one * 600) == (2, 1, 24)                 # many frames: whole frames, small workgroups
+    assert choose(1, one * 600) == (1, 1, 24)                 # many frames: whole frames, 512-thread workgroups
+    assert choose(1, one * 256, cus=256 // 3) == (1, 1, 24)   # ... or three launches in flight sharing the CUs
+    assert choose(1, one * 256, cus=256 // 2) == (1, 1, 24)
+    assert choose(5, [emu.frame_for_convert(imgs[0], 80, 24, 2)] * 600) == (4, 1, 24)  # half-block: never the small geometries
     assert choose(9, one) == (4, 1, 24)                       # serial dither: never split
     assert choose(1, one, ascii_only=False) == (4, 1, 24)     # truecolor-fg with multi-byte glyphs: never split
     assert choose(2, one, ascii_only=False) == (4, 24, 1)
