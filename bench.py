@@ -101,6 +101,25 @@ def time_steps(torch, plans, outs, lns, streams, steps, warmup, dist=None):
     return wall, gpu_ms, sum(per_launch) / len(per_launch)
 
 
+def launch_durations(torch, plans, outs, lns, streams, n):
+    """Average duration of ONE launch while len(streams) launches are in flight: a HIP event pair around every launch,
+    on the stream it is launched on (the stream is busy, so the first event completes when the previous kernel of that
+    stream ends).  This is the per-kernel figure rocprofv3 --kernel-trace --stats reports."""
+    P, S = len(plans), len(streams)
+    pairs = []
+    for k in range(n + 2 * S):
+        s = k % S
+        a = torch.cuda.Event(enable_timing=True)
+        b = torch.cuda.Event(enable_timing=True)
+        a.record(streams[s])
+        plans[k % P].render(outs[s].data_ptr(), plans[0].stride, lns[s].data_ptr(), streams[s].cuda_stream)
+        b.record(streams[s])
+        pairs.append((a, b))
+    torch.cuda.synchronize()
+    d = [a.elapsed_time(b) for a, b in pairs[2 * S:]]  # the first launches start on idle streams
+    return sum(d) / len(d)
+
+
 def kernel_time_events(torch, plans, out, ln, reps):
     """Per-launch duration: HIP events recorded on the launch stream around EACH launch (idle stream
     in between), averaged -- contains the launch latency the back-to-back figure hides."""
@@ -141,16 +160,21 @@ def run_workload(torch, pkg, name, batch, steps, warmup, dist=None, seed=1234, v
     lns = [torch.zeros(batch, dtype=torch.int32, device="cuda") for _ in range(streams)]
     rows = 2 * H if rm == 2 else H
     out_bytes = []
-    for plan in plans:  # exact output bytes of every set (sampled RGB consumed + exact output bytes)
-        plan.render(outs[0].data_ptr(), plan.stride, lns[0].data_ptr(), cur.cuda_stream)
-        lens = lns[0].cpu().numpy().astype("uint32")
-        assert (lens < 0xFFFFFFF0).all(), "kernel reported overflow/bad descriptor"
-        out_bytes.append(int(lens.sum()))
-    wall, gpu_ms, launch_ms = time_steps(torch, plans, outs, lns, lanes, steps, warmup, dist)
+    for g in range(0, nsets, streams):  # exact output bytes of every set (sampled RGB consumed + exact output)
+        for s in range(streams):
+            plans[g + s].render(outs[s].data_ptr(), plans[0].stride, lns[s].data_ptr(), lanes[s].cuda_stream)
+        torch.cuda.synchronize()
+        for s in range(streams):
+            lens = lns[s].cpu().numpy().astype("uint32")
+            assert (lens < 0xFFFFFFF0).all(), "kernel reported overflow/bad descriptor"
+            out_bytes.append(int(lens.sum()))
+    wall, gpu_ms, stream_ms = time_steps(torch, plans, outs, lns, lanes, steps, warmup, dist)
+    launch_ms = launch_durations(torch, plans, outs, lns, lanes, max(60, steps // 2))
     alg_bytes = int(sum(out_bytes) / len(out_bytes)) + batch * 3 * W * rows
     res = dict(name=name, mode=pkg.MODE_NAMES[mode], batch=batch, wall_s=wall, gpu_ms=gpu_ms, steps=steps,
                out_bytes_per_frame=sum(out_bytes) / len(out_bytes) / batch, alg_bytes_per_launch=alg_bytes,
-               launch_ms=launch_ms, ms_per_step_gpu=gpu_ms / steps, variant=plans[0].variant, input_sets=nsets,
+               launch_ms=launch_ms, stream_ms_per_launch=stream_ms, ms_per_step_gpu=gpu_ms / steps,
+               variant=plans[0].variant, input_sets=nsets,
                streams=streams, frames=sets, plan=plans[0], plans=plans, out=outs[0], ln=lns[0], serial=None)
     if serial_leg:
         # the same steps issued back to back on ONE stream (each plan re-chooses its geometry for the whole GPU), next
@@ -334,12 +358,13 @@ def main():
     total_frames = args.batch * args.steps * world
     value = total_frames / wall
 
-    # Roofline of the frame kernel over the timed region.  `kernel_ms` is the average duration of ONE launch, from HIP
-    # events on each launch stream around its share of the K launches -- the figure rocprofv3 --kernel-trace --stats
-    # agrees with (profiles/r01_bench_kernel_stats.csv).  With `launches_in_flight` launches overlapping, the bytes the
-    # kernel moves per second are those of all of them: achieved = launches_in_flight x B_alg / kernel_ms, which is the
-    # same as K x B_alg / (GPU time of the region) when the streams stay busy; the region figure is what is reported
-    # (`ms_per_launch_effective` = region / K).  One stream: the two coincide.
+    # Roofline of the frame kernel.  `kernel_ms` is the average duration of ONE launch while `launches_in_flight` of them
+    # overlap: a HIP event pair around every launch, on its own stream, in a leg of >= 60 launches right after the timed
+    # region (event pairs inside the timed region would slow the host's launch rate) -- the figure rocprofv3
+    # --kernel-trace --stats agrees with (profiles/r01_bench_kernel_stats.csv).  The bytes the kernel moves per second
+    # are those of all launches in flight: achieved = K x B_alg / (GPU time of the timed region, HIP events fenced
+    # against every launch stream) = B_alg / ms_per_launch_effective, which is launches_in_flight x B_alg / kernel_ms
+    # while the streams stay busy.  One stream: kernel_ms and ms_per_launch_effective coincide.
     eff_ms = res["ms_per_step_gpu"]
     achieved = res["alg_bytes_per_launch"] / (eff_ms * 1e-3) / 1e9
     line = {
