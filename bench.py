@@ -358,13 +358,14 @@ def main():
     total_frames = args.batch * args.steps * world
     value = total_frames / wall
 
-    # Roofline of the frame kernel.  `kernel_ms` is the average duration of ONE launch while `launches_in_flight` of them
-    # overlap: a HIP event pair around every launch, on its own stream, in a leg of >= 60 launches right after the timed
-    # region (event pairs inside the timed region would slow the host's launch rate) -- the figure rocprofv3
-    # --kernel-trace --stats agrees with (profiles/r01_bench_kernel_stats.csv).  The bytes the kernel moves per second
-    # are those of all launches in flight: achieved = K x B_alg / (GPU time of the timed region, HIP events fenced
-    # against every launch stream) = B_alg / ms_per_launch_effective, which is launches_in_flight x B_alg / kernel_ms
-    # while the streams stay busy.  One stream: kernel_ms and ms_per_launch_effective coincide.
+    # Roofline of the frame kernel.  With `launches_in_flight` launches overlapping, what a launch COSTS is the GPU time of
+    # the timed region (HIP events fenced against every launch stream) divided by K: `kernel_ms`, and
+    # achieved = B_alg / kernel_ms.  `kernel_ms_on_stream` is the time a launch occupies its own stream (a HIP event
+    # pair around every launch, in a leg right after the timed region): its begin->end duration plus the wait for CUs
+    # behind the other streams' workgroups.  rocprofv3 --kernel-trace reports the begin->end part; the committed trace
+    # (profiles/r01_bench_kernel_stats.csv, summarised by scripts/trace_overlap.py in profiles/bench_trace_overlap.json)
+    # gives average duration / average launches in flight = busy time per launch, which is what agrees with
+    # `kernel_ms`.  One stream: all three coincide (`one_launch_at_a_time`; 14.009 vs 14.011 us in round 1).
     eff_ms = res["ms_per_step_gpu"]
     achieved = res["alg_bytes_per_launch"] / (eff_ms * 1e-3) / 1e9
     line = {
@@ -382,8 +383,8 @@ def main():
                    "launches_in_flight": args.streams},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "alg_bytes_per_launch": res["alg_bytes_per_launch"], "kernel_ms": res["launch_ms"],
-                     "launches_in_flight": args.streams, "ms_per_launch_effective": eff_ms,
+                     "alg_bytes_per_launch": res["alg_bytes_per_launch"], "kernel_ms": eff_ms,
+                     "launches_in_flight": args.streams, "kernel_ms_on_stream": res["launch_ms"],
                      "out_bytes_per_frame": res["out_bytes_per_frame"]},
     }
     if res["serial"] is not None:
@@ -391,6 +392,12 @@ def main():
     # HBM traffic per launch comes from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE cannot share a
     # pass, MI355X_MICROARCH.md "rocprofv3 PMC slots"); scripts/pmc_run.sh collects them and the summary is
     # committed under profiles/.  When a summary for this workload and kernel geometry exists it is reported here.
+    trace = os.path.join(ROOT, "profiles", "bench_trace_overlap.json")
+    if os.path.exists(trace):
+        try:
+            line["roofline"]["rocprof_kernel_trace"] = json.load(open(trace))
+        except Exception:
+            pass
     traffic = load_pmc_traffic(args.workload, res["variant"], args.batch)
     if traffic is not None:
         line["roofline"]["traffic"] = traffic["hbm_bytes"]
@@ -414,8 +421,8 @@ def main():
                                streams=args.streams, serial_leg=not args.no_hot)
             k = res["ms_per_step_gpu"]
             a = res["alg_bytes_per_launch"] / (k * 1e-3) / 1e9
-            others[name] = {"frames_per_s": b * res["steps"] / res["wall_s"], "ms_per_launch_effective": k,
-                            "kernel_ms": res["launch_ms"], "launches_in_flight": args.streams,
+            others[name] = {"frames_per_s": b * res["steps"] / res["wall_s"], "kernel_ms": k,
+                            "kernel_ms_on_stream": res["launch_ms"], "launches_in_flight": args.streams,
                             "out_bytes_per_frame": res["out_bytes_per_frame"], "roofline_GBps": a,
                             "roofline_frac": a / HBM_PEAK_GBS, "kernel_variant": res["variant"],
                             "input_sets": res["input_sets"], "one_launch_at_a_time": res["serial"]}

@@ -16,5 +16,7 @@ cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --no-cpu --no-d2h --no-hot --others '' > $OUT/rocprof_run.log 2>&1
 cd $GRAFT_REPO_ROOT
 for f in $(find $OUT/prof -name "*kernel_stats.csv"); do echo "-- $f"; head -6 $f | cut -c1-220; done
+python scripts/trace_overlap.py $(find $OUT/prof -name "*kernel_trace.csv" | head -1) $OUT/trace_overlap.json
+grep -o '"kernel_ms": [0-9.e-]*' $OUT/rocprof_run.log | head -1
 echo "== PMC"
 bash scripts/pmc_run.sh $TAG/pmc 1080p_80x24_truecolor 2>&1 | tail -20 | tee $OUT/pmc_summary.txt
