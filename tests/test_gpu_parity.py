@@ -533,3 +533,45 @@ def test_uniform_batches_pass_the_descriptor_by_value(gpu):
         e2[1], e2[4] = e2[4], e2[1]
         assert take() == e2, (mode, "fallback")
         plan.close()
+
+
+def test_launches_in_flight_on_three_streams(gpu):
+    """Three independent batches kept in flight on separate streams (what bench.py times): every plan takes the geometry
+    for its share of the GPU (asciichat_hip_plan_set_concurrency) and every frame of every launch stays byte-exact."""
+    pkg, torch = gpu
+    n = 200
+    rng = np.random.default_rng(77)
+    base = [orc.frame_hash_noise(160, 120, 500 + k) for k in range(8)] + [orc.frame_bars(160, 120, 3), TORTURE]
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    for mode in (MODE_TRUE_FG, 2, MODE_HB_TRUE):
+        rm = MODE_CAPS[mode][1]
+        exp_of = [oracle_convert(i, mode, 80, 24, orc.PALETTE_STANDARD) for i in base]
+        plans, outs, lns, picks, keep = [], [], [], [], []
+        for s in range(3):
+            pick = rng.integers(0, len(base), n)
+            dev = [torch.from_numpy(np.ascontiguousarray(base[i])).cuda() for i in range(len(base))]
+            frames = [pkg.frame_setup(dev[i].data_ptr(), base[i].shape[1], base[i].shape[0], 80, 24, rm, False, False, False)
+                      for i in pick]
+            plan = pkg.Plan(mode, orc.PALETTE_STANDARD, frames)
+            v0 = plan.variant
+            plan.set_concurrency(3)
+            if mode != MODE_HB_TRUE:
+                assert v0 == 4 and plan.variant == 1, (v0, plan.variant)   # 200 frames on a third of 256 CUs
+            else:
+                assert plan.variant == 4
+            plans.append(plan)
+            picks.append(pick)
+            keep.append(dev)
+            outs.append(torch.zeros(n * plan.stride, dtype=torch.uint8, device="cuda"))
+            lns.append(torch.zeros(n, dtype=torch.int32, device="cuda"))
+        torch.cuda.synchronize()
+        for rnd in range(20):
+            for s in range(3):
+                plans[s].render(outs[s].data_ptr(), plans[s].stride, lns[s].data_ptr(), streams[s].cuda_stream)
+        torch.cuda.synchronize()
+        for s in range(3):
+            h, l = outs[s].cpu().numpy(), lns[s].cpu().numpy()
+            st = plans[s].stride
+            for k in range(n):
+                assert h[k * st:k * st + int(l[k])].tobytes() == exp_of[picks[s][k]], (mode, s, k)
+            plans[s].close()
