@@ -83,6 +83,35 @@ def vector_matrix():
     return m
 
 
+def ops_matrix():
+    """Cases that go through achip_frame_t.ops: (input, width, height, kind, arg, palette) with kind =
+    'dither_bg' | 'dither_fg' | 'dither_fg_ramp' (the three exported forms of the Floyd-Steinberg renderer, on the
+    nearest-neighbour resize of the input) or 'rainbow_<color_level>_<render_mode>' (rainbow_replace_ansi_colors at
+    time `arg` over the plain frame)."""
+    m = []
+    for pal in ("STANDARD", "BLOCKS"):
+        for kind in ("dither_bg", "dither_fg", "dither_fg_ramp"):
+            m.append(("torture", 61, 23, kind, 0.0, pal))
+    m.append(("noise_320x240_s7", 10, 150, "dither_fg", 0.0, "STANDARD"))
+    for kind in ("rainbow_3_0", "rainbow_3_2", "rainbow_2_0"):
+        for t in (0.4, 2.05):
+            m.append(("anchor_gradient", 80, 24, kind, t, "STANDARD"))
+    m.append(("torture", 97, 31, "rainbow_3_0", 1234.5, "COOL"))
+    return m
+
+
+def render_ops(entry, cache={}):
+    inp, w, h, kind, arg, pal = entry
+    if inp not in cache:
+        cache[inp] = INPUTS[inp]()
+    img = cache[inp]
+    if kind.startswith("dither"):
+        small = orc.resize_nn(img, w, h)
+        return orc.print_16_dithered(small, kind == "dither_bg", PALETTES[pal], ramp_glyph=kind == "dither_fg_ramp")
+    _, cl, rm = kind.split("_")
+    return orc.rainbow_replace(orc.convert_with_caps(img, w, h, int(cl), int(rm), False, False, False, PALETTES[pal]), arg)
+
+
 def render(entry, cache={}):
     inp, w, h, cl, rm, pad, aspect, pal = entry
     if inp not in cache:
@@ -114,7 +143,13 @@ def main():
         f.write('{"_columns": ["input", "width", "height", "color_level", "render_mode", "wants_padding", "use_aspect", '
                 '"palette", "length", "fnv1a32", "crc32c"],\n')
         f.write(' "_generator": "tests/golden/make_golden.py (oracle/asciichat_oracle.c through tests/orc.py)",\n')
-        f.write(' "vectors": [\n' + ",\n".join("  " + json.dumps(v) for v in vecs) + "\n ]}\n")
+        f.write(' "vectors": [\n' + ",\n".join("  " + json.dumps(v) for v in vecs) + "\n ],\n")
+        ops = []
+        for e in ops_matrix():
+            out = render_ops(e)
+            ops.append(list(e) + [len(out), "%08x" % orc.fnv1a32(out)])
+        f.write(' "_ops_columns": ["input", "width", "height", "kind", "arg", "palette", "length", "fnv1a32"],\n')
+        f.write(' "ops_vectors": [\n' + ",\n".join("  " + json.dumps(v) for v in ops) + "\n ]}\n")
     print(f"wrote {len(vecs)} oracle vectors and {len(REFERENCE_ANCHORS['whole_frame']) + len(REFERENCE_ANCHORS['lengths'])} "
           "reference anchors")
 

@@ -22,6 +22,7 @@ import orc  # noqa: E402
 from achip_ctypes import MODE_TRUE_BG  # noqa: E402
 
 GOLD = json.load(open(os.path.join(HERE, "golden", "oracle_vectors.json")))["vectors"]
+GOLD_OPS = json.load(open(os.path.join(HERE, "golden", "oracle_vectors.json")))["ops_vectors"]
 REF = json.load(open(os.path.join(HERE, "golden", "reference_anchors.json")))
 _inputs = {}
 
@@ -35,6 +36,7 @@ def image(name):
 def test_fixture_files_match_the_generator_tables():
     assert REF["whole_frame"] == [list(x) for x in mg.REFERENCE_ANCHORS["whole_frame"]]
     assert [tuple(v[:8]) for v in GOLD] == [tuple(e) for e in mg.vector_matrix()]
+    assert [tuple(v[:6]) for v in GOLD_OPS] == [tuple(e) for e in mg.ops_matrix()]
 
 
 def test_oracle_reproduces_reference_anchors():
@@ -54,10 +56,27 @@ def test_oracle_reproduces_its_golden_vectors():
     for v in GOLD:
         out = mg.render(tuple(v[:8]))
         assert [len(out), "%08x" % orc.fnv1a32(out), "%08x" % orc.crc32c(out)] == v[8:], v[:8]
+    for v in GOLD_OPS:
+        out = mg.render_ops(tuple(v[:6]))
+        assert [len(out), "%08x" % orc.fnv1a32(out)] == v[6:], v[:6]
 
 
 def _mode(cl, rm):
     return emu.lib().achip_mode_from_caps(cl, rm)
+
+
+def _ops_frame(L, setup, src_ptr, img, v):
+    """Descriptor + mode of an ops vector: the dithered forms render the nearest-neighbour resize of the input in mode 9
+    with a style, the rainbow cases render the plain frame with the foreground override of the moment."""
+    inp, w, h, kind, arg, pal = v[:6]
+    if kind.startswith("dither"):
+        f = setup(src_ptr, img.shape[1], img.shape[0], w, h, 0, False, False, False)
+        assert L.achip_frame_set_dither_style(C.byref(f), kind == "dither_bg", kind == "dither_fg_ramp") == 0
+        return f, 9
+    _, cl, rm = kind.split("_")
+    f = setup(src_ptr, img.shape[1], img.shape[0], w, h, int(rm), False, False, False)
+    assert L.achip_frame_set_rainbow(C.byref(f), arg) == 0
+    return f, L.achip_mode_from_caps(int(cl), int(rm))
 
 
 def test_emulated_kernels_reproduce_golden_vectors():
@@ -69,6 +88,21 @@ def test_emulated_kernels_reproduce_golden_vectors():
         f = emu.frame_for_convert(image(inp), w, h, rm, pad, aspect)
         got = emu.render_frames(_mode(cl, rm), [f], mg.PALETTES[pal], 0 if w > 1000 else 2)[0]
         assert [len(got), "%08x" % orc.fnv1a32(got)] == [length, fnv], v[:8]
+
+
+def test_emulated_kernels_reproduce_ops_vectors():
+    L = emu.lib()
+
+    def setup(ptr, sw, sh, w, h, rm, pad, aspect, stretch):
+        f = emu.Frame()
+        assert L.achip_frame_setup(C.byref(f), ptr, sw, sh, w, h, rm, pad, aspect, stretch) == 0
+        return f
+
+    for v in GOLD_OPS:
+        img = image(v[0])
+        f, mode = _ops_frame(L, setup, img.ctypes.data, img, v)
+        got = emu.render_frames(mode, [f], mg.PALETTES[v[5]], 2, uniform=True)[0]
+        assert [len(got), "%08x" % orc.fnv1a32(got)] == v[6:], v[:6]
 
 
 @pytest.mark.gpu
@@ -108,4 +142,18 @@ def test_gpu_reproduces_golden_vectors_and_crcs():
         for k, v in enumerate(vs):
             got = host[k * plan.stride:k * plan.stride + int(lens[k])].tobytes()
             assert [len(got), "%08x" % orc.fnv1a32(got), "%08x" % int(crcs[k])] == v[8:], v[:8]
+        plan.close()
+    # the cases that go through achip_frame_t.ops (dithered styles, rainbow override), one plan each
+    for v in GOLD_OPS:
+        img = image(v[0])
+        if v[0] not in dev:
+            dev[v[0]] = torch.from_numpy(np.ascontiguousarray(img)).cuda()
+        f, mode = _ops_frame(L, pkg.frame_setup, dev[v[0]].data_ptr(), img, v)
+        plan = pkg.Plan(mode, mg.PALETTES[v[5]], [f])
+        out = torch.zeros(plan.stride, dtype=torch.uint8, device="cuda")
+        ln = torch.zeros(1, dtype=torch.int32, device="cuda")
+        plan.render(out.data_ptr(), plan.stride, ln.data_ptr(), stream)
+        torch.cuda.synchronize()
+        got = out[:int(ln[0].item())].cpu().numpy().tobytes()
+        assert [len(got), "%08x" % orc.fnv1a32(got)] == v[6:], v[:6]
         plan.close()
