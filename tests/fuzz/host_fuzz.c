@@ -66,9 +66,21 @@ static void fuzz_grid(int iters) {
     char *g = ascii_create_grid(nsrc ? src : NULL, nsrc, (int)(rnd() % 200), (int)(rnd() % 70), &out);
     free(g);
     if (nsrc) {
-      /* the pad helpers take NUL-terminated strings */
+      /* the pad helpers and the rainbow pass take NUL-terminated strings */
       size_t l = src[0].frame_size; char *z = malloc(l + 1); memcpy(z, bufs[0], l); z[l] = 0;
       for (size_t i = 0; i < l; i++) if (!z[i]) z[i] = 'x';
+      { /* every ESC[38;2;..m becomes the colour of the moment; truncated lead-ins at the end stay */
+        const float t = (float)(rnd() % 100000) / 997.0f - 3.0f;
+        char *rb = rainbow_replace_ansi_colors(z, t);
+        if (rb) {
+          uint8_t cr, cg, cb; char code[32];
+          color_filter_calculate_rainbow(t, &cr, &cg, &cb);
+          snprintf(code, sizeof code, "\033[38;2;%u;%u;%um", cr, cg, cb);
+          for (const char *q = rb; (q = strstr(q, "\033[38;2;")) != NULL; q += 7)
+            if (strchr(q + 7, 'm') && strncmp(q, code, strlen(code)) != 0) abort();
+          free(rb);
+        } else if (strstr(z, "\033[38;2;")) abort();
+      }
       char *p = ascii_pad_frame_width(z, rnd() % 9); free(p);
       p = ascii_pad_frame_height(z, rnd() % 5); free(p);
       free(z);
@@ -97,6 +109,17 @@ static void fuzz_geometry(int iters) {
       (void)achip_frame_setup(&fr[i], (const uint8_t *)0x1000, rnd() % 3900 + 1, rnd() % 2200 + 1, rnd() % 500 + 1, rnd() % 150 + 1, rnd() % 3, it & 1, it & 2, 0);
       if (fr[i].out_w <= 0) { fr[i].out_w = 1; fr[i].out_h = 1; }
     }
+    achip_uniform_t uni; /* descriptors from independent setups are uniform only when they really are */
+    if (achip_frames_uniform(fr, n, &uni)) {
+      for (int i = 0; i < n; i++) {
+        achip_frame_t a = uni.f; a.src = uni.f.src + (int64_t)i * uni.src_pitch;
+        if (memcmp(&a, &fr[i], sizeof a) != 0) abort();
+      }
+    }
+    (void)achip_frame_set_rainbow(&fr[0], (float)(rnd() % 9000) / 100.0f);
+    if (!(fr[0].ops & ACHIP_OP_FG_OVERRIDE) || (fr[0].ops & ACHIP_OP_TINT)) abort();
+    (void)achip_frame_set_display_ops(&fr[0], it & 1, it & 2, rnd() % 12);
+    (void)achip_frame_set_dither_style(&fr[0], it & 4, !(it & 4) && (it & 8));
     int v, p, r;
     (void)achip_choose_geometry(rnd() % 10, fr, n, it & 1, caps, rnd() % 300 + 1, (int)(rnd() % 12) - 2, (int)(rnd() % 7) - 2 > 4 ? 4 : (int)(rnd() % 6) - 1, &v, &p, &r);
     for (int m = 0; m < 10; m++) (void)achip_out_bound(m, &fr[0]);
