@@ -1070,8 +1070,21 @@ __device__ inline unsigned long long cycle_now() { return (unsigned long long)cl
     }                                                                                                                  \
   } while (0)
 
+/* The 512- and 256-thread geometries exist to put two (four) workgroups on a CU; that needs <= 128 VGPRs, and the
+ * non-half-block kernels sit right at that edge (125-130 depending on unrelated code motion: at 130 only ONE 512-thread
+ * workgroup fits and the step time doubles).  Pin it.  The half-block kernels need 160-185 there and are never
+ * launched in these geometries by the host policy. */
+#ifdef ACHIP_HIPEMU /* the CPU emulator (g++) has no such attribute */
+#define ACHIP_PIN_OCCUPANCY(M, B)
+#else
+#define ACHIP_PIN_OCCUPANCY(M, B) __attribute__((amdgpu_waves_per_eu(MinWaves<M, B>::value)))
+#endif
+template <int MODE, int BLOCK> struct MinWaves {
+  static constexpr int value = (BLOCK <= 512 && BLOCK >= 256 && !mode_is_halfblock(MODE)) ? 4 : 1;
+};
+
 template <int MODE, int BLOCK, int CAP, int RING, bool COMP, bool SPLIT = true>
-__global__ void __launch_bounds__(BLOCK)
+__global__ void __launch_bounds__(BLOCK) ACHIP_PIN_OCCUPANCY(MODE, BLOCK)
     render_frames_kernel(const achip_frame_t *__restrict__ frames, const achip_lut_t *__restrict__ lut,
                          uint8_t *__restrict__ out, uint64_t out_stride, uint32_t *__restrict__ out_len, int n_frames,
                          unsigned long long *__restrict__ prof, int parts, int rows_per_part,
@@ -1090,8 +1103,9 @@ __global__ void __launch_bounds__(BLOCK)
    * samples per thread fit the 128-VGPR budget (4K -> 200x60: 58 -> 47 us, 4K -> 400x120 half-block: 314 -> 287 us,
    * profiles/r01_prefetch.txt); the smaller geometries would drop to half the waves per CU, and a row band is a
    * single chunk anyway. */
-#ifdef ACHIP_HIPEMU /* tests: the request-ahead order in every geometry, so that tiny inputs exercise it */
-  constexpr bool PREFETCH = !SPLIT;
+#ifdef ACHIP_HIPEMU /* tests: the request-ahead order in every geometry, so that tiny inputs exercise it -- except in
+                       the 512 x 4 geometry, which keeps its product configuration (PRE_ISSUE without PREFETCH) */
+  constexpr bool PREFETCH = !SPLIT && !(BLOCK == 512 && CAP == 2048);
 #else
   constexpr bool PREFETCH = BLOCK == 1024 && CAP == 2048 && !SPLIT;
 #endif
@@ -1101,7 +1115,10 @@ __global__ void __launch_bounds__(BLOCK)
    * quarter of the waves (wave & 3) issues both of its requests per point while the rest tokenises
    * (4K -> 200x60: 46.9 -> 45.1 us; profiles/r01_prefetch.txt) */
   constexpr bool SPREAD = PREFETCH && HB;
-  constexpr bool PRE_ISSUE = PREFETCH; /* same register budget argument */
+  /* the first chunk's samples are requested in the prologue, ahead of the glyph-table wait: in the 1024 x 2 geometry
+   * (same register budget argument) and in the 512 x 4 one, where it is worth 4-6 % with three launches in flight
+   * (profiles/r01_overlap.txt) and costs no registers (125 instead of 128 VGPRs in truecolor-fg) */
+  constexpr bool PRE_ISSUE = PREFETCH || (BLOCK == 512 && CAP == 2048 && !SPLIT);
   /* token stores as aligned atomic ORs of register-built dwords (PackSink) instead of byte stores (FastSink) */
   constexpr bool EMIT_OR = ((ACHIP_EMIT_OR_MODES) >> MODE) & 1;
   constexpr int NW = L::NW;
@@ -1243,7 +1260,10 @@ __global__ void __launch_bounds__(BLOCK)
   /* the first chunk's samples are requested before the glyph tables are waited for: with the descriptor in the
    * kernel arguments (uniform batches) nothing but address arithmetic stands between the launch and these requests,
    * and the table fetch, the LDS set-up and the first barrier all run under their latency */
-  if (PRE_ISSUE)
+  /* without request-ahead (512 x 4 geometry) only single-chunk frames do this: with the prologue request in front of
+   * it the chunk loop of a multi-chunk frame runs 1.5x slower (4K -> 200x60, profiles/r01_overlap.txt) */
+  const bool pre_issued = PRE_ISSUE && (PREFETCH || row_end - row_begin <= rows_per_chunk);
+  if (pre_issued)
     gather_issue(row_begin, (min(row_end, row_begin + rows_per_chunk) - row_begin) * wp);
   /* glyph tables -> LDS */
 #pragma unroll
@@ -1314,7 +1334,8 @@ __global__ void __launch_bounds__(BLOCK)
 
     /* ---- A: commit the chunk's samples (requested one chunk ahead) to LDS with the mode's run key in
      * bits 31..24 ------------------------------------------------------------------------------- */
-    if (PRE_ISSUE ? false : (!PREFETCH || r0 == row_begin))
+    /* who requests this chunk's samples: the prologue (first chunk, PRE_ISSUE), the previous chunk (PREFETCH), or here */
+    if (r0 == row_begin ? !pre_issued : !PREFETCH)
       gather_issue(r0, n);
 #pragma unroll
     for (int k = 0; k < SEG; k++) {

@@ -64,6 +64,18 @@ def test_wide_variant_big_frame():
         assert got == exp, MODE_NAMES[mode]
 
 
+def test_512_thread_geometry_multi_chunk_frames():
+    """Geometry 1 (512 threads x 4 cells) is what plans pick with several launches in flight; it requests the first chunk's
+    samples in the prologue and every later chunk's at the top of the chunk loop (no request-ahead): frames of 1, 2 and
+    6 chunks, padded and not."""
+    img = orc.frame_hash_noise(320, 200, 17)
+    for mode in (MODE_TRUE_FG, MODE_256_FG, MODE_HB_TRUE, MODE_MONO):
+        for (W, H, pad) in ((80, 24, False), (97, 31, True), (200, 60, False)):
+            exp = oracle_convert(img, mode, W, H, orc.PALETTE_STANDARD, pad, pad)
+            got = emu_convert(img, mode, W, H, orc.PALETTE_STANDARD, 1, pad, pad)
+            assert got == exp, (MODE_NAMES[mode], W, H)
+
+
 def test_dither_multi_sweep_and_carry():
     """Floyd-Steinberg mode: > 64 rows per chunk (several 64-row sweeps chained through the LDS carry),
     chunk-to-chunk carry, 1-pixel-wide and 1-row images, padding."""
