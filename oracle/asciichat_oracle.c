@@ -833,7 +833,8 @@ int orc_color_filter(uint8_t *rgb, int w, int h, int stride, int color_filter) {
   if (color_filter == 0)
     return 0;
   if (color_filter < 0 || color_filter >= 12)
-    return -1; /* 12 = rainbow: time-dependent float path + ANSI post-pass, not restated */
+    return -1; /* 12 = rainbow: never reaches this function from the display path (display.c:611); its string pass is
+                * orc_rainbow_replace */
   const uint8_t *t = k_filter_tint[color_filter];
   for (int y = 0; y < h; y++) {
     uint8_t *row = rgb + (size_t)y * (size_t)stride;

@@ -191,3 +191,32 @@ def test_survey_server_grid_layout_3x3():
         assert (cell[0] == 0).all() and (cell[31] == 0).all()
         assert (cell[1:31] == 10 + 20 * i).all()
     assert (comp[:, 159] == 0).all()
+
+
+def test_reference_color_filter_known_answers():
+    """tests/unit/video/color_filter_test.c: grayscale of the primaries (:19-48), the tint of every filter (:197-218; a
+    white pixel takes exactly the filter's colour), white-on-colour CYAN and black-on-white BLACK on black / white /
+    grey pixels (:95-152), NONE leaves the pixels alone (:157-166), invalid parameters return -1 (:170-192)."""
+    px = lambda *rgb: np.array([[list(rgb)]], dtype=np.uint8)
+    # WHITE (255,255,255) in white-on-colour mode is the grayscale itself: channel = 255 * gray / 255
+    for rgb, lo, hi in (((255, 0, 0), 75, 79), ((0, 255, 0), 148, 152), ((0, 0, 255), 27, 31), ((255, 255, 255), 255, 255),
+                        ((0, 0, 0), 0, 0), ((128, 128, 128), 126, 130)):
+        g = orc.color_filter(px(*rgb), 2)[0, 0]
+        assert g[0] == g[1] == g[2] and lo <= g[0] <= hi, (rgb, g)
+    tints = {2: (255, 255, 255), 3: (0, 255, 65), 4: (255, 0, 255), 5: (255, 0, 170), 6: (255, 136, 0), 7: (0, 221, 221),
+             8: (0, 255, 255), 9: (255, 182, 193), 10: (255, 51, 51), 11: (255, 235, 153)}
+    for flt, rgb in tints.items():
+        assert tuple(orc.color_filter(px(255, 255, 255), flt)[0, 0]) == rgb, flt
+        assert tuple(orc.color_filter(px(0, 0, 0), flt)[0, 0]) == (0, 0, 0), flt
+    img = np.array([[[0, 0, 0], [255, 255, 255]], [[128, 128, 128], [64, 64, 64]]], dtype=np.uint8)
+    cy = orc.color_filter(img, 8)
+    assert cy[0, 0].tolist() == [0, 0, 0] and cy[0, 1].tolist() == [0, 255, 255]
+    assert cy[1, 0, 0] == 0 and cy[1, 1, 0] == 0 and cy[1, 0, 1] > cy[1, 1, 1] > 0        # grey levels scale the tint
+    bw = orc.color_filter(img[:1], 1)                                                     # BLACK: black on white
+    assert (bw[0, 0] < 50).all() and bw[0, 1].tolist() == [255, 255, 255]
+    assert np.array_equal(orc.color_filter(img, 0), img)
+    L = orc.lib()
+    buf = (C.c_uint8 * 3)(255, 255, 255)
+    assert L.orc_color_filter(None, 1, 1, 3, 3) == -1
+    assert L.orc_color_filter(buf, 0, 1, 3, 3) == -1 and L.orc_color_filter(buf, 1, 0, 3, 3) == -1
+    assert L.orc_color_filter(buf, 1, 1, 0, 3) == -1 and L.orc_color_filter(buf, 1, 1, 3, 999) == -1
