@@ -69,6 +69,55 @@ def test_random_cases_emulated(seed):
         assert got == exp, (seed, sw, sh, W, H, MODE_NAMES[mode], aspect, pad, palette, variant)
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_random_display_ops_emulated(seed):
+    """The descriptor's ops field under random combinations: flips, the eleven tints, the rainbow override, the three
+    dithered styles -- descriptor by value or from the array, whole frames or row bands, all geometries incl. the
+    512-thread one."""
+    from achip_ctypes import MODE_16_DITHER_BG, MODE_TRUE_FG
+    rng = np.random.default_rng(7000 + seed)
+    L = emu.lib()
+    for it in range(22):
+        sw, sh, W, H, mode, aspect, pad, palette = random_case(rng)
+        if mode == MODE_TRUE_BG:
+            continue
+        img = random_image(rng, sw, sh)
+        cl, rm = MODE_CAPS[mode]
+        fx, fy = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        kind = int(rng.integers(0, 3))  # 0: tint, 1: rainbow, 2: dithered style (mode 9 only) / plain flips
+        style = None
+        if mode == MODE_16_DITHER_BG:
+            aspect = pad = False
+            style = [(True, False), (False, False), (False, True)][int(rng.integers(0, 3))]
+            kind = 2
+        f = emu.frame_for_convert(img, W, H, rm, pad, aspect)
+        if f is None:
+            continue
+        flt = int(rng.integers(1, 12)) if kind == 0 else 0
+        assert L.achip_frame_set_display_ops(C.byref(f), fx, fy, flt) == 0
+        t = float(rng.integers(0, 4000)) / 100.0
+        if kind == 1:
+            assert L.achip_frame_set_rainbow(C.byref(f), t) == 0
+        if style is not None:
+            assert L.achip_frame_set_dither_style(C.byref(f), style[0], style[1]) == 0
+            exp = orc.print_16_dithered(orc.resize_nn(orc.flip(img, fx, fy), W, H), style[0], palette, ramp_glyph=style[1])
+        else:
+            exp = orc.display_convert(img, W, H, cl, rm, pad, aspect, fx, fy, flt, palette)
+            if kind == 1:
+                exp = orc.rainbow_replace(exp, t)
+        variant = int(rng.choice([3, 2, 4, 1]))
+        rows = (f.out_h + 1) // 2 if rm == 2 else f.out_h
+        wp = f.pad_left + f.out_w
+        cap = {1: 2048, 2: 1024, 3: 256, 4: 2048}[variant]
+        ascii_only = all(ord(c) < 128 for c in palette)
+        bands = 0
+        if (variant != 3 and mode != MODE_16_DITHER_BG and rows > 1 and wp <= cap and (mode != MODE_TRUE_FG or ascii_only)
+                and rng.integers(0, 2)):
+            bands = max(1, min(cap // wp, int(rng.integers(1, rows))))
+        got = emu.render_frames(mode, [f], palette, variant, rows_per_part=bands, uniform=bool(rng.integers(0, 2)))[0]
+        assert got == exp, (seed, it, sw, sh, W, H, MODE_NAMES[mode], aspect, pad, palette, variant, bands, fx, fy, flt, kind, style)
+
+
 @pytest.mark.gpu
 def test_random_cases_gpu():
     import torch
