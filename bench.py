@@ -385,6 +385,10 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "alg_bytes_per_launch": res["alg_bytes_per_launch"], "kernel_ms": eff_ms,
                      "launches_in_flight": args.streams, "kernel_ms_on_stream": res["launch_ms"],
+                     "kernel_ms_note": "kernel_ms = GPU time of the timed region / K while launches_in_flight launches "
+                                       "overlap (= what one launch costs); rocprofv3 reports each dispatch begin-to-end "
+                                       "(rocprof_kernel_trace.avg_duration_us), and that divided by the average number "
+                                       "in flight is the same busy time per launch (busy_us_per_launch)",
                      "out_bytes_per_frame": res["out_bytes_per_frame"]},
     }
     if res["serial"] is not None:
