@@ -119,6 +119,16 @@ def lib():
     L.asciichat_hip_plan_render_profiled.argtypes = [vp, vp, sz, vp, vp, vp]
     L.asciichat_hip_plan_destroy.restype = None
     L.asciichat_hip_plan_destroy.argtypes = [vp]
+    L.asciichat_hip_render_many.restype = ci
+    L.asciichat_hip_render_many.argtypes = [C.POINTER(vp), ci, C.POINTER(vp), C.POINTER(vp), sz, C.POINTER(vp), ci, ci, ci]
+    L.asciichat_hip_streams_wait.restype = ci
+    L.asciichat_hip_streams_wait.argtypes = [C.POINTER(vp), ci]
+    L.asciichat_hip_schedule_create.restype = ci
+    L.asciichat_hip_schedule_create.argtypes = [C.POINTER(vp), C.POINTER(vp), ci, C.POINTER(vp), C.POINTER(vp), sz, ci, ci, ci]
+    L.asciichat_hip_schedule_launch.restype = ci
+    L.asciichat_hip_schedule_launch.argtypes = [vp, vp]
+    L.asciichat_hip_schedule_destroy.restype = None
+    L.asciichat_hip_schedule_destroy.argtypes = [vp]
     L.asciichat_hip_resize.restype = ci
     L.asciichat_hip_resize.argtypes = [vp, ci, ci, vp, ci, ci, vp]
     L.asciichat_hip_composite.restype = ci
@@ -324,6 +334,53 @@ class Plan:
             self.close()
         except Exception:
             pass
+
+
+class Schedule:
+    """A round-robin tick loop issued from C (asciichat_hip_render_many): step k renders plans[k % P] on
+    streams[k % S] into outs[k % S].  One FFI call per K steps instead of one per launch."""
+
+    def __init__(self, plans, out_ptrs, len_ptrs, out_stride, stream_handles):
+        P, S = len(plans), len(stream_handles)
+        assert P % S == 0 and len(out_ptrs) == S and len(len_ptrs) == S
+        self._plans = (C.c_void_p * P)(*[p._h for p in plans])
+        self._outs = (C.c_void_p * S)(*out_ptrs)
+        self._lens = (C.c_void_p * S)(*len_ptrs)
+        self._streams = (C.c_void_p * S)(*stream_handles)
+        self.P, self.S, self.stride = P, S, out_stride
+
+    def issue(self, first_step, n_steps):
+        rc = lib().asciichat_hip_render_many(self._plans, self.P, self._outs, self._lens, self.stride, self._streams,
+                                             self.S, first_step, n_steps)
+        if rc != 0:
+            raise RuntimeError(f"render_many failed ({rc}): {last_error()}")
+
+    def wait(self):
+        rc = lib().asciichat_hip_streams_wait(self._streams, self.S)
+        if rc != 0:
+            raise RuntimeError(f"streams_wait failed ({rc}): {last_error()}")
+
+    def graph(self, first_step, n_steps):
+        """The same n_steps captured into a HIP graph (asciichat_hip_schedule_create); cached per (first % P, n)."""
+        key = (first_step % self.P, n_steps)
+        cache = self.__dict__.setdefault("_graphs", {})
+        if key not in cache:
+            h = C.c_void_p()
+            rc = lib().asciichat_hip_schedule_create(C.byref(h), self._plans, self.P, self._outs, self._lens, self.stride,
+                                                     self.S, key[0], n_steps)
+            if rc != 0:
+                raise RuntimeError(f"schedule_create failed ({rc}): {last_error()}")
+            cache[key] = h
+        return cache[key]
+
+    def replay(self, first_step, n_steps, stream):
+        rc = lib().asciichat_hip_schedule_launch(self.graph(first_step, n_steps), stream)
+        if rc != 0:
+            raise RuntimeError(f"schedule_launch failed ({rc}): {last_error()}")
+
+    def close(self):
+        for h in self.__dict__.pop("_graphs", {}).values():
+            lib().asciichat_hip_schedule_destroy(h)
 
 
 class FrameTable:

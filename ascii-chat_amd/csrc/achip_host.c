@@ -306,6 +306,10 @@ bool achip_palette_ascii_only(const char *palette_chars) {
   return true;
 }
 
+/* the stream-kernel family (render_variants.h: ACHIP_STREAM_VARIANTS; render_stream.hpp: ACHIP_STREAM_MAXBLK) */
+#define ACHIP_HOST_STREAM_FIRST 16
+#define ACHIP_HOST_STREAM_MAXBLK 2048
+
 int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, bool palette_ascii_only,
                           const int *variant_caps, int n_cus, int split_request, int forced_variant, int *variant,
                           int *parts, int *rows_per_part) {
@@ -329,6 +333,38 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
    * case the caller passes its share of the CUs -- two or three 512-thread workgroups per CU overlap each other's
    * gather (HBM-bound) and token (latency-bound) phases instead.  Not the half-block modes: their kernels need more
    * than 128 VGPRs in the small geometries and lose more than the overlap gains. */
+  /* The per-cell renderers (truecolor / 256 / 16 foreground, truecolor background; truecolor-fg with an all-ASCII
+   * palette) have no run structure: whole-frame launches of them take the wave-autonomous stream kernel
+   * (render_stream.hpp), whose waves gather, tokenise and drain independently -- no chunk, so no row-width limit,
+   * only a bound on the cells of a frame.  ACHIP_STREAM_* below restate render_variants.h / render_stream.hpp. */
+  long max_cells = 0;
+  for (int i = 0; i < n_frames; i++) {
+    const long c = (long)(frames[i].pad_left + frames[i].out_w) * (long)frames[i].out_h;
+    if (c > max_cells)
+      max_cells = c;
+  }
+  const bool cell_mode = mode == ACHIP_MODE_256_FG || mode == ACHIP_MODE_16_FG || mode == ACHIP_MODE_TRUE_BG ||
+                         (mode == ACHIP_MODE_TRUE_FG && palette_ascii_only);
+  const bool stream_forced = forced_variant >= ACHIP_HOST_STREAM_FIRST;
+  if (stream_forced) {
+    const int cpl = forced_variant == 19 || forced_variant == 20 ? 1 : 2;
+    if (!cell_mode || forced_variant > 20 || max_cells > (long)ACHIP_HOST_STREAM_MAXBLK * 64 * cpl)
+      return -1;
+    *variant = forced_variant;
+    return 0; /* whole frames only */
+  }
+  /* automatic: whenever whole frames are launched anyway (the split policy below decides that first) */
+  const bool may_split = mode != ACHIP_MODE_16_DITHER_BG && !(mode == ACHIP_MODE_TRUE_FG && !palette_ascii_only) &&
+                         split_request >= 0 && max_rows > 1 && !(split_request == 0 && 4 * n_frames >= 3 * n_cus);
+  if (forced_variant < 0 && cell_mode && (!may_split || max_wp > variant_caps[0]) &&
+      max_cells <= (long)ACHIP_HOST_STREAM_MAXBLK * 128) {
+    /* measured (profiles/r02_stream_sweep.txt): 1024 threads x 2 cells -- one block per wave for a 1080p -> 80x24
+     * frame -- is the shortest single launch while every frame has a CU to itself; with more frames than CUs in
+     * flight (a large batch, or several launches kept in flight: the caller passes its share of the CUs), or frames
+     * of several blocks per wave, 512-thread workgroups pack better (4K -> 200x60: 42.5 vs 48.2 us per step) */
+    *variant = (max_cells <= 2048 && n_frames <= n_cus) ? 16 : 17;
+    return 0;
+  }
   if (forced_variant >= 0) {
     if (max_wp > variant_caps[forced_variant])
       return -1;

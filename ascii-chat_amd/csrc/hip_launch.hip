@@ -8,7 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include "render_inst.h"
-#include "render_kernels.hpp"
+#include "render_stream.hpp"
 #include "crc_kernels.hpp"
 #include "render_variants.h"
 
@@ -21,6 +21,19 @@ extern "C" int achip_launch_render(int mode, int variant, int has_composite, con
     return (int)hipSuccess;
   if (parts < 1 || (parts > 1 && (!part_sync || rows_per_part < 1)))
     return (int)hipErrorInvalidValue;
+  if (ACHIP_IS_STREAM_VARIANT(variant)) { /* wave-autonomous kernel: per-cell modes, whole frames (render_stream.hpp) */
+    if (parts != 1)
+      return (int)hipErrorInvalidValue;
+    switch (variant) {
+#define X(id, W, C)                                                                                                    \
+  case id:                                                                                                             \
+    return achip_render_sinst_launch_##id(mode, has_composite, frames_dev, n_frames, lut_dev, out, out_stride, out_len, \
+                                          uniform, prof, stream);
+      ACHIP_STREAM_VARIANTS(X)
+#undef X
+    }
+    return (int)hipErrorInvalidValue;
+  }
   switch (variant) { /* one translation unit per geometry: render_inst.hip */
 #define X(id, B, C, R)                                                                                                 \
   case id:                                                                                                             \
@@ -34,6 +47,11 @@ extern "C" int achip_launch_render(int mode, int variant, int has_composite, con
 
 extern "C" int achip_variant_block(int variant) {
   switch (variant) {
+#define X(id, W, C)                                                                                                    \
+  case id:                                                                                                             \
+    return 64 * W;
+    ACHIP_STREAM_VARIANTS(X)
+#undef X
 #define X(id, B, C, R)                                                                                                 \
   case id:                                                                                                             \
     return B;
@@ -44,7 +62,12 @@ extern "C" int achip_variant_block(int variant) {
 }
 
 extern "C" int achip_variant_cap(int variant) {
-  switch (variant) {
+  switch (variant) { /* stream geometries: cells per FRAME (rows need not fit anything) */
+#define X(id, W, C)                                                                                                    \
+  case id:                                                                                                             \
+    return ACHIP_STREAM_MAXBLK * 64 * C;
+    ACHIP_STREAM_VARIANTS(X)
+#undef X
 #define X(id, B, C, R)                                                                                                 \
   case id:                                                                                                             \
     return C;
@@ -56,6 +79,11 @@ extern "C" int achip_variant_cap(int variant) {
 
 extern "C" int achip_variant_lds_bytes(int mode, int variant) {
   switch (variant) {
+#define X(id, W, C)                                                                                                    \
+  case id:                                                                                                             \
+    return achip_render_sinst_lds_##id(mode);
+    ACHIP_STREAM_VARIANTS(X)
+#undef X
 #define X(id, B, C, R)                                                                                                 \
   case id:                                                                                                             \
     return achip_render_inst_lds_##id(mode);

@@ -203,7 +203,7 @@ static int choose_geometry(asciichat_hip_plan_t *p, const achip_frame_t *frames)
   const int cus = device_cus() / (p->concurrency > 1 ? p->concurrency : 1);
   if (achip_choose_geometry(p->mode, frames, p->n, p->palette_ascii != 0, caps, cus > 0 ? cus : 1,
                             forced >= 0 && p->split_request == 0 ? -1 : p->split_request, /* explicit geometry alone: whole frames */
-                            forced < ACHIP_VARIANT_COUNT ? forced : -1, &variant, &parts, &rpp) != 0)
+                            forced < ACHIP_VARIANT_COUNT || (ACHIP_IS_STREAM_VARIANT(forced) && achip_variant_block(forced) > 0) ? forced : -1, &variant, &parts, &rpp) != 0)
     return -1;
   p->variant = variant;
   p->parts = parts;
@@ -217,7 +217,7 @@ static int plan_measure(asciichat_hip_plan_t *p, const achip_frame_t *frames) {
   p->has_comp = 0;
   for (int i = 0; i < p->n; i++) {
     const achip_frame_t *f = &frames[i];
-    if (f->comp)
+    if (f->comp || (long)f->src_w * (long)f->src_h == 1) /* the kernels' general sampler: composites, 1x1 sources */
       p->has_comp = 1;
     if (f->out_w <= 0 || f->out_h <= 0 || f->src_w <= 0 || f->src_h <= 0 || f->pad_left < 0 || f->pad_top < 0 ||
         (!f->src && !f->comp))
@@ -362,6 +362,7 @@ static int render_range(asciichat_hip_plan_t *p, int first, int count, uint8_t *
   achip_uniform_t uni = p->uniform;
   if (p->uniform_off)
     uni.enabled = 0;
+  uni.flags = p->palette_ascii ? ACHIP_UNIFORM_PALETTE_ASCII : 0u;
   uni.f.src = uni.f.src ? uni.f.src + (int64_t)first * uni.src_pitch : NULL;
   return achip_hip_check(achip_launch_render(p->mode, p->variant, p->has_comp, p->frames_dev + first, count, p->lut_dev,
                                              out_dev, (uint64_t)out_stride, out_len_dev, phase_cycles_dev, p->parts,
@@ -384,6 +385,140 @@ int asciichat_hip_plan_render_profiled(asciichat_hip_plan_t *p, uint8_t *out_dev
 int asciichat_hip_plan_render(asciichat_hip_plan_t *p, uint8_t *out_dev, size_t out_stride, uint32_t *out_len_dev,
                               void *stream) {
   return asciichat_hip_plan_render_range(p, 0, p ? p->n : 0, out_dev, out_stride, out_len_dev, stream);
+}
+
+/* K steps issued from C: step k renders plans[k % n_plans] on streams[k % n_streams] into that stream's slab.  A
+ * server tick loop (and bench.py) calls this instead of paying an FFI round trip per launch: at ~8 us per 256-frame
+ * step one interpreter thread cannot keep three streams fed. */
+int asciichat_hip_render_many(asciichat_hip_plan_t *const *plans, int n_plans, uint8_t *const *out_dev,
+                              uint32_t *const *out_len_dev, size_t out_stride, void *const *streams, int n_streams,
+                              int first_step, int n_steps) {
+  if (!plans || !out_dev || !out_len_dev || !streams || n_plans <= 0 || n_streams <= 0 || first_step < 0 || n_steps < 0 ||
+      n_plans % n_streams != 0)
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM,
+                      "render_many: bad arguments (n_plans must be a multiple of n_streams: a plan stays on one stream)");
+  for (int k = first_step; k < first_step + n_steps; k++) {
+    const int s = k % n_streams;
+    asciichat_hip_plan_t *p = plans[k % n_plans];
+    const int rc = render_range(p, 0, p ? p->n : 0, out_dev[s], out_stride, out_len_dev[s], NULL, streams[s]);
+    if (rc)
+      return rc;
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* A tick loop captured once and replayed: the n_steps launches of asciichat_hip_render_many as ONE hipGraph       */
+/* (n_lanes parallel branches, one per independent batch stream).  A replay costs one graph launch instead of      */
+/* n_steps kernel launches on n_lanes queues that each have to wake up after an idle period -- the fixed cost of a  */
+/* short burst of steps (profiles/r02_region_overhead.txt).                                                         */
+/* ------------------------------------------------------------------------------------------- */
+struct asciichat_hip_schedule {
+  hipGraph_t graph;
+  hipGraphExec_t exec;
+  int n_steps;
+};
+
+int asciichat_hip_schedule_create(asciichat_hip_schedule_t **sched, asciichat_hip_plan_t *const *plans, int n_plans,
+                                  uint8_t *const *out_dev, uint32_t *const *out_len_dev, size_t out_stride, int n_lanes,
+                                  int first_step, int n_steps) {
+  if (!sched || !plans || !out_dev || !out_len_dev || n_plans <= 0 || n_lanes <= 0 || n_lanes > 16 || first_step < 0 ||
+      n_steps <= 0 || n_plans % n_lanes != 0)
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM,
+                      "schedule_create: bad arguments (n_plans must be a multiple of n_lanes, n_lanes <= 16)");
+  *sched = NULL;
+  for (int i = 0; i < n_plans; i++)
+    if (!plans[i] || plans[i]->parts > 1) /* row-band launches carry a per-launch epoch: not replayable */
+      return achip_fail(ASCIICHAT_HIP_ERR_NOT_SUPPORTED, "schedule_create: plan %d renders row bands (small batch)", i);
+  int rc = achip_require_device();
+  if (rc)
+    return rc;
+  asciichat_hip_schedule_t *s = (asciichat_hip_schedule_t *)calloc(1, sizeof(*s));
+  if (!s)
+    return achip_fail(ASCIICHAT_HIP_ERR_MEMORY, "out of memory");
+  hipStream_t lane[16] = {0};
+  hipEvent_t fork = NULL, join[16] = {0};
+  int capturing = 0;
+  for (int l = 0; l < n_lanes && !rc; l++)
+    rc = achip_hip_check((int)hipStreamCreateWithFlags(&lane[l], hipStreamNonBlocking), "hipStreamCreate");
+  if (!rc)
+    rc = achip_hip_check((int)hipEventCreateWithFlags(&fork, hipEventDisableTiming), "hipEventCreate");
+  for (int l = 1; l < n_lanes && !rc; l++)
+    rc = achip_hip_check((int)hipEventCreateWithFlags(&join[l], hipEventDisableTiming), "hipEventCreate");
+  if (!rc) {
+    rc = achip_hip_check((int)hipStreamBeginCapture(lane[0], hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
+    capturing = !rc;
+  }
+  if (!rc && n_lanes > 1) { /* the other lanes join the capture behind a fork event */
+    rc = achip_hip_check((int)hipEventRecord(fork, lane[0]), "hipEventRecord");
+    for (int l = 1; l < n_lanes && !rc; l++)
+      rc = achip_hip_check((int)hipStreamWaitEvent(lane[l], fork, 0), "hipStreamWaitEvent");
+  }
+  for (int k = first_step; k < first_step + n_steps && !rc; k++) {
+    const int l = k % n_lanes;
+    asciichat_hip_plan_t *p = plans[k % n_plans];
+    rc = render_range(p, 0, p->n, out_dev[l], out_stride, out_len_dev[l], NULL, lane[l]);
+  }
+  for (int l = 1; l < n_lanes && !rc; l++) {
+    rc = achip_hip_check((int)hipEventRecord(join[l], lane[l]), "hipEventRecord");
+    if (!rc)
+      rc = achip_hip_check((int)hipStreamWaitEvent(lane[0], join[l], 0), "hipStreamWaitEvent");
+  }
+  if (capturing) {
+    hipGraph_t g = NULL;
+    const int e = (int)hipStreamEndCapture(lane[0], &g);
+    if (!rc)
+      rc = achip_hip_check(e, "hipStreamEndCapture");
+    s->graph = g;
+  }
+  if (!rc)
+    rc = achip_hip_check((int)hipGraphInstantiate(&s->exec, s->graph, NULL, NULL, 0), "hipGraphInstantiate");
+  for (int l = 0; l < n_lanes; l++) {
+    if (lane[l])
+      (void)hipStreamDestroy(lane[l]);
+    if (join[l])
+      (void)hipEventDestroy(join[l]);
+  }
+  if (fork)
+    (void)hipEventDestroy(fork);
+  if (rc) {
+    asciichat_hip_schedule_destroy(s);
+    return rc;
+  }
+  s->n_steps = n_steps;
+  *sched = s;
+  return 0;
+}
+
+int asciichat_hip_schedule_launch(asciichat_hip_schedule_t *s, void *stream) {
+  if (!s || !s->exec)
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "schedule_launch: bad arguments");
+  return achip_hip_check((int)hipGraphLaunch(s->exec, (hipStream_t)stream), "hipGraphLaunch");
+}
+
+void asciichat_hip_schedule_destroy(asciichat_hip_schedule_t *s) {
+  if (!s)
+    return;
+  if (s->exec)
+    (void)hipGraphExecDestroy(s->exec);
+  if (s->graph)
+    (void)hipGraphDestroy(s->graph);
+  free(s);
+}
+
+/* Spin until every stream has drained (hipStreamQuery polling: a blocking hipStreamSynchronize sleeps in the driver and
+ * wakes tens of microseconds late, which is most of a 20-step timed region). */
+int asciichat_hip_streams_wait(void *const *streams, int n_streams) {
+  if (!streams || n_streams <= 0)
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "streams_wait: bad arguments");
+  for (int s = 0; s < n_streams; s++) {
+    hipError_t e;
+    while ((e = hipStreamQuery((hipStream_t)streams[s])) == hipErrorNotReady)
+      ;
+    if (e != hipSuccess)
+      return achip_hip_check((int)e, "hipStreamQuery");
+  }
+  return 0;
 }
 
 void asciichat_hip_plan_destroy(asciichat_hip_plan_t *p) {

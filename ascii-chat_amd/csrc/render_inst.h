@@ -20,6 +20,15 @@ extern "C" {
 ACHIP_VARIANTS(X)
 #undef X
 
+/* the stream-kernel geometries (render_stream_inst.hip, -DACHIP_SINST=id) */
+#define X(id, W, C)                                                                                                    \
+  int achip_render_sinst_launch_##id(int mode, int comp, const achip_frame_t *frames, int n, const achip_lut_t *lut,   \
+                                     uint8_t *out, uint64_t stride, uint32_t *len, const achip_uniform_t *uniform,     \
+                                     unsigned long long *prof, void *stream);                                                                    \
+  int achip_render_sinst_lds_##id(int mode);
+ACHIP_STREAM_VARIANTS(X)
+#undef X
+
 #ifdef __cplusplus
 }
 #endif

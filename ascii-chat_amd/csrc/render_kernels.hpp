@@ -110,6 +110,8 @@ __device__ inline uint32_t lds_base_addr() {
 __device__ inline void lds_store_fence() {
 #ifndef ACHIP_HIPEMU
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+  hipemu::wave_barrier(); /* a wave's lanes run in lockstep on the GPU: every lane's stores precede the reads behind */
 #endif
 }
 

@@ -1,0 +1,533 @@
+/*
+ * render_stream.hpp -- the wave-autonomous ("stream") frame kernel for the per-cell renderers of the path:
+ *   image_print_color (truecolor foreground, all-ASCII palette)   lib/video/ascii/scalar/foreground.c:195-308
+ *   image_print_256color                                          foreground.c:433-509
+ *   image_print_16color                                           foreground.c:535-624
+ *   image_print_color_background                                  lib/video/ascii/scalar/background.c:17-84
+ * whose tokens depend on a cell and (truecolor-fg only) its raster predecessor -- no run structure.
+ *
+ * Why a second kernel.  render_frames_kernel (render_kernels.hpp) walks a frame in workgroup-wide phases fenced by
+ * barriers: every wave waits at the barrier behind the gather until the SLOWEST wave's samples have arrived, and the
+ * chip alternates between a fabric-bound burst (all CUs gathering) and latency-bound token work (memory idle).  Here a
+ * frame is cut into blocks of 64 x CPL consecutive cells and every WAVE takes a block through the whole path on its
+ * own -- gather -> tokens -> wave scan -> look-back -> token stores into a wave-private LDS staging area -> 16-byte
+ * stores to HBM -- with ONE workgroup barrier, in the prologue (glyph / decimal tables and the look-back words in
+ * LDS).  Waves whose samples have arrived tokenise and drain while the others' requests are still in flight; the next
+ * block's samples are requested before the current block is tokenised.  41-58 VGPRs: two 1024-thread (or four
+ * 512-thread) workgroups share a CU where the phase kernel needs 125.
+ *
+ * What the timeline of a launch showed (profiles/r02_stream_timeline.txt) and the code answers:
+ *   * the prologue was six DEPENDENT scalar-load round trips to the kernarg segment (the compiler loads an argument at
+ *     its first use, behind the branches above it): all arguments are now requested in one burst at the top;
+ *   * a wave alone in the tail of a launch runs at one instruction per ~5 cycles, so instruction COUNT is latency:
+ *     the sampler is branch-free (flips folded into the index, cached / non-temporal chosen once per frame) and the
+ *     per-cell decisions are selects, not exec-mask branches;
+ *   * requests are issued only as fast as lines return (the load instruction itself stalls once the CU's miss queue
+ *     is full): the gather is bound by the ~7 TB/s at which the fabric fills 128-byte lines, HBM or Infinity Cache
+ *     alike (profiles/r02_ubench_sparse_policy.txt: no load flavour or memory type fetches less than a whole line).
+ *
+ * The only cross-wave dependency is the byte offset of a block in the frame (variable-length output):
+ * a decoupled look-back over one LDS word per block -- {state:2, bytes:30}; state 1 = this block's own byte count
+ * (published right after its wave scan), 2 = inclusive prefix -- read 64 predecessors per poll, one lane each.
+ * All waves of a frame live in one workgroup, so the words are workgroup-scope LDS atomics; no global traffic.
+ *
+ * Everything byte-level (token grammar, sinks, sampler, quantisers) is shared with render_kernels.hpp.
+ */
+#pragma once
+
+#include "render_kernels.hpp"
+
+namespace achip {
+
+__host__ __device__ constexpr bool mode_is_cell(int m) {
+  return m == ACHIP_MODE_TRUE_FG || m == ACHIP_MODE_256_FG || m == ACHIP_MODE_16_FG || m == ACHIP_MODE_TRUE_BG;
+}
+/* longest token of a mode, bytes (SURVEY 8a "per-token byte lengths"): SGR(s) + glyph + row reset + newline */
+__host__ __device__ constexpr int stream_max_token(int m) {
+  return m == ACHIP_MODE_TRUE_FG ? 24    /* 19 + 1-byte glyph (all-ASCII palettes only) + max(NL, final reset 4) */
+         : m == ACHIP_MODE_256_FG ? 20   /* 11 + glyph <= 4 + reset 4 + NL                                      */
+         : m == ACHIP_MODE_16_FG ? 16    /* 5 + 4 + 4 + 1 (rounded up)                                           */
+                                 : 48;   /* background: 19 + 19 + 4 + 4 + 1 (rounded up)                         */
+}
+
+#define ACHIP_STREAM_MAXBLK 2048            /* blocks per frame the look-back table holds              */
+#define ACHIP_STREAM_MAX_STRIDE 0x3F000000u /* block prefixes are 30-bit: slab slots up to ~1 GB        */
+
+template <int MODE, int WAVES, int CPL> struct SLds {
+  static constexpr int BLK = 64 * CPL;
+  static constexpr int STAGE = BLK * stream_max_token(MODE) + 16; /* + the 16-byte group the block starts in */
+  static constexpr int o_stage = 0;
+  static constexpr int o_glyph = WAVES * STAGE;
+  static constexpr int o_ramp = o_glyph + 256 * 4;
+  static constexpr int o_dec = o_ramp + 64;
+  static constexpr int o_slots = o_dec + 256 * 4;
+  static constexpr int o_flags = o_slots + ACHIP_STREAM_MAXBLK * 4; /* [+16 ..] swallows predicated-off byte stores */
+  static constexpr int bytes = o_flags + 32 + 64 * 4;
+  static_assert(STAGE % 16 == 0, "staging areas stay 16-byte aligned");
+};
+
+/* ---- workgroup-scope LDS words of the look-back ------------------------------------------------- */
+__device__ inline void slot_store(uint32_t *p, uint32_t v) {
+#ifdef ACHIP_HIPEMU
+  *reinterpret_cast<volatile uint32_t *>(p) = v;
+#else
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+}
+__device__ inline uint32_t slot_load(const uint32_t *p) {
+#ifdef ACHIP_HIPEMU
+  return *reinterpret_cast<const volatile uint32_t *>(p);
+#else
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+}
+#define ACHIP_SLOT_AGG (1u << 30)
+#define ACHIP_SLOT_PREFIX (2u << 30)
+#define ACHIP_SLOT_VALUE 0x3FFFFFFFu
+
+/* lane l receives lane l-1's value; lane 0 receives `first` (one DPP move, no LDS round trip) */
+__device__ inline uint32_t wave_shift_up1(uint32_t v, uint32_t first) {
+#ifdef ACHIP_HIPEMU
+  const int l = hipemu::lane();
+  const uint32_t t = hipemu::shfl_from(v, l - 1);
+  return l == 0 ? first : t;
+#else
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)first, (int)v, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+#endif
+}
+
+/* bytes of the frame in front of block `blk` (blk >= 1): sums the predecessors' words, newest first, 64 per
+ * poll, until an inclusive prefix is met.  Returns 0xFFFFFFFF if a predecessor never publishes (bounded). */
+__device__ inline uint32_t stream_lookback(const uint32_t *slots, int blk, int lane) {
+  uint32_t acc = 0;
+  int hi = blk - 1;
+  for (int spin = 0; spin < (1 << 22);) {
+    const int j = hi - lane;
+    const uint32_t v = j >= 0 ? slot_load(&slots[j]) : 0u;
+    const uint32_t st = j >= 0 ? v >> 30 : 3u; /* lanes in front of block 0 neither block nor contribute */
+    const uint64_t pm = wave_ballot(st == 2u), am = wave_ballot(st != 0u);
+    if (pm != 0ull) {
+      const int P = __ffsll((unsigned long long)pm) - 1; /* nearest predecessor that knows its prefix */
+      const uint64_t need = P ? ((1ull << P) - 1ull) : 0ull;
+      if ((am & need) == need) {
+        const uint32_t c = lane <= P ? (v & ACHIP_SLOT_VALUE) : 0u;
+        return acc + wave_read_lane(wave_inclusive_scan(c), 63);
+      }
+    } else if (am == ~0ull) { /* 64 own counts and no prefix yet: take them and look further back */
+      acc += wave_read_lane(wave_inclusive_scan(v & ACHIP_SLOT_VALUE), 63);
+      hi -= 64;
+      continue;
+    }
+    spin++;
+#ifndef ACHIP_HIPEMU
+    __builtin_amdgcn_s_sleep(1);
+#endif
+  }
+  return 0xFFFFFFFFu;
+}
+
+struct CellPos {
+  uint32_t rr, xp; /* text row, column of the padded row */
+};
+
+__device__ inline uint32_t dec_digits(uint32_t v) { return 1u + (v >= 10u ? 1u : 0u) + (v >= 100u ? 1u : 0u); }
+
+/* The frame's source as the sampler needs it -- all wave-uniform (SGPRs) */
+struct StreamSrc {
+  const uint8_t *base;
+  uint32_t stride, xr, yr, w1, h1; /* w1 = src_w - 1 */
+  bool flip_x, flip_y, nt;
+};
+
+/* GENERIC = false: the fast sampler -- one unaligned dword per sample with the flips folded into the index, no
+ * branches (nothing between two requests waits for memory); requires a single source of >= 2 pixels.
+ * GENERIC = true: sample_frame_raw's full repertoire (virtual composite canvas, 1x1 sources). */
+template <bool GENERIC, bool NT>
+__device__ inline uint32_t stream_request(const achip_frame_t &f, const StreamSrc &s, uint32_t x, uint32_t y,
+                                          uint32_t &kind) {
+  if (GENERIC)
+    return sample_frame_raw<true>(f, x, y, kind);
+  uint32_t sx = min((x * s.xr) >> 16, s.w1), sy = min((y * s.yr) >> 16, s.h1);
+  sx = s.flip_x ? s.w1 - sx : sx;
+  sy = s.flip_y ? s.h1 - sy : sy;
+  const uint32_t a = sy * s.stride + sx * 3u;
+  const uint32_t back = a != 0u ? 1u : 0u; /* byte before the pixel + the pixel: never past the last pixel */
+  kind = back ? RAW_BACK : RAW_FIRST;
+  const ACHIP_GLOBAL uint8_t *p = (const ACHIP_GLOBAL uint8_t *)s.base + (a - back);
+#ifndef ACHIP_HIPEMU
+  if (NT) {
+    typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+    return __builtin_nontemporal_load((const ACHIP_GLOBAL u32_unaligned *)p);
+  }
+#endif
+  return ((const ACHIP_GLOBAL unaligned_u32 *)p)->v;
+}
+
+struct StreamTagNT {
+  static constexpr bool value = true;
+};
+struct StreamTagCached {
+  static constexpr bool value = false;
+};
+
+template <int MODE, int WAVES, int CPL, bool GENERIC>
+__global__ void __launch_bounds__(WAVES * 64)
+    render_stream_kernel(const achip_frame_t *__restrict__ frames, const achip_lut_t *__restrict__ lut,
+                         uint8_t *__restrict__ out, uint64_t out_stride, uint32_t *__restrict__ out_len, int n_frames,
+                         achip_uniform_t uni, unsigned long long *__restrict__ prof) {
+  /* prof (diagnostics, NULL in production launches): 8 timestamps of the 100 MHz wall clock per wave, for the wave's
+   * FIRST block -- prof[(frame*WAVES + wave)*8 + k]: 0 kernel entry, 1 prologue barrier passed, 2 samples requested,
+   * 3 samples arrived, 4 tokens + scan done, 5 look-back done, 6 token bytes in LDS, 7 stores issued */
+#ifdef ACHIP_HIPEMU
+#define ACHIP_SSTAMP(slot) do { } while (0)
+#else
+#define ACHIP_SSTAMP(slot)                                                                                             \
+  do {                                                                                                                 \
+    if (prof && lane == 0 && first_block)                                                                              \
+      prof[((size_t)fidx * WAVES + wave) * 8u + (slot)] = wall_clock64();                                              \
+  } while (0)
+#endif
+  static_assert(mode_is_cell(MODE), "run-structured modes use render_frames_kernel");
+  using L = SLds<MODE, WAVES, CPL>;
+  constexpr int BLOCK = WAVES * 64;
+  constexpr int BLK = L::BLK;
+
+  uint32_t *slots = lds_ptr<uint32_t>(L::o_slots);
+
+  const int tid = (int)threadIdx.x;
+  const int lane = tid & 63, wave = wave_uniform(tid >> 6);
+  const int fidx = (int)blockIdx.x;
+#ifndef ACHIP_HIPEMU
+  /* Every kernel argument the prologue needs is requested HERE, in one burst of scalar loads: left to itself the
+   * compiler loads each argument at its first use, behind the branches above it -- six dependent round trips to
+   * the kernarg segment in front of the first gather (profiles/r02_stream_timeline.txt). */
+  asm volatile("" ::"s"(n_frames), "s"(lut), "s"(out), "s"(out_stride), "s"(out_len), "s"(prof), "s"(frames),
+               "s"(uni.enabled), "s"(uni.flags), "s"(uni.src_pitch), "s"(uni.f.src), "s"(uni.f.comp));
+  asm volatile("" ::"s"(uni.f.src_w), "s"(uni.f.src_h), "s"(uni.f.out_w), "s"(uni.f.out_h), "s"(uni.f.pad_left),
+               "s"(uni.f.pad_top), "s"(uni.f.x_ratio), "s"(uni.f.y_ratio), "s"(uni.f.src_stride), "s"(uni.f.ops));
+#endif
+  if (fidx >= n_frames)
+    return;
+  bool first_block = true;
+  ACHIP_SSTAMP(0);
+
+  /* glyph tables are requested first, the first block's samples right behind (the descriptor came with the kernel
+   * arguments for uniform batches): one overlapped latency in front of the only barrier */
+  constexpr int LUTN = (256 + BLOCK - 1) / BLOCK;
+  uint32_t lut_g[LUTN];
+#pragma unroll
+  for (int k = 0; k < LUTN; k++)
+    lut_g[k] = tid + k * BLOCK < 256 ? lut->glyph[tid + k * BLOCK] : 0u;
+  const uint32_t lut_ramp = (MODE == ACHIP_MODE_16_FG && tid < 64) ? lut->ramp[tid] : 0u;
+  /* whether every glyph of the palette is one ASCII byte travels with the launch (the host knows the palette);
+   * reading achip_lut_t.flags here would be one more dependent round trip */
+  const bool ascii_only = (uni.flags & ACHIP_UNIFORM_PALETTE_ASCII) != 0u;
+  achip_frame_t f = uni.f;
+  if (uni.enabled)
+    f.src = uni.f.src + (int64_t)fidx * uni.src_pitch;
+  else
+    f = frames[fidx];
+  if (f.src_stride == 0)
+    f.src_stride = 3 * f.src_w;
+  uint8_t *dst = out + (size_t)fidx * out_stride;
+
+  const int wp = f.pad_left + f.out_w;
+  const int rows = f.out_h;
+  const long long cells_ll = (long long)rows * (long long)wp;
+  if (f.out_w <= 0 || f.out_h <= 0 || f.src_w <= 0 || f.src_h <= 0 || f.pad_left < 0 || f.pad_top < 0 ||
+      (!f.src && !f.comp) || (!GENERIC && (f.comp || f.src_w * f.src_h == 1)) ||
+      cells_ll > (long long)ACHIP_STREAM_MAXBLK * BLK || out_stride > (uint64_t)ACHIP_STREAM_MAX_STRIDE) {
+    if (tid == 0)
+      out_len[fidx] = ACHIP_LEN_BADDESC;
+    return;
+  }
+  const uint32_t ncells = (uint32_t)cells_ll;
+  const int nblk = (int)((ncells + BLK - 1) / BLK);
+  const uint32_t cap_bytes = (uint32_t)out_stride;
+  const uint32_t pad_left = (uint32_t)f.pad_left, uwp = (uint32_t)wp;
+  StreamSrc src;
+  src.base = f.src;
+  src.stride = (uint32_t)f.src_stride;
+  src.xr = f.x_ratio;
+  src.yr = f.y_ratio;
+  src.w1 = (uint32_t)f.src_w - 1u;
+  src.h1 = (uint32_t)f.src_h - 1u;
+  src.flip_x = (f.ops & ACHIP_OP_FLIP_X) != 0u;
+  src.flip_y = (f.ops & ACHIP_OP_FLIP_Y) != 0u;
+  /* samples a cache line apart or more share no line with their neighbours: non-temporal loads keep them out of the
+   * L2; closer samples do share lines and want the cache (profiles/r01_nontemporal.txt) */
+  src.nt = f.x_ratio >= ((64u << 16) + 2u) / 3u;
+
+  /* cell -> (row, column) without a division per cell: one division per lane here, then constant steps */
+  const uint32_t q64 = 64u / uwp, r64 = 64u - q64 * uwp;                                         /* k -> k+1 */
+  const uint32_t qit = (uint32_t)(WAVES * BLK) / uwp, rit = (uint32_t)(WAVES * BLK) - qit * uwp; /* block -> block + WAVES */
+  auto advance = [&](CellPos p, uint32_t q, uint32_t r) {
+    p.xp += r;
+    p.rr += q;
+    const bool wrap = p.xp >= uwp;
+    p.xp -= wrap ? uwp : 0u;
+    p.rr += wrap ? 1u : 0u;
+    return p;
+  };
+  /* truecolor-fg: which cells take their raster predecessor from an extra sample instead of the neighbouring lane --
+   * lane 0 of the block (its predecessor belongs to another wave) and, with left padding, the first pixel cell of
+   * every row (its predecessor is the last pixel of the row above, pad_left cells back) */
+  auto wants_ext = [&](CellPos p, int k) {
+    return p.xp == pad_left ? (p.rr > 0u && (pad_left > 0u || (k == 0 && lane == 0))) : (k == 0 && lane == 0);
+  };
+  /* request the samples of the block whose cell (k = 0, this lane) is cell0 at p0: nothing here consumes loaded data */
+  auto issue = [&](auto nt_tag, uint32_t cell0, CellPos p0, uint32_t (&raw)[CPL], uint32_t (&ext)[CPL], uint32_t &kinds) {
+    constexpr bool NT = decltype(nt_tag)::value;
+    kinds = 0;
+    CellPos p = p0;
+#pragma unroll
+    for (int k = 0; k < CPL; k++) {
+      raw[k] = 0;
+      ext[k] = 0;
+      if (cell0 + 64u * k < ncells && p.xp >= pad_left) {
+        uint32_t kind = RAW_FINAL;
+#if defined(ACHIP_STREAM_ABLATE) && ACHIP_STREAM_ABLATE == 2 /* diagnostics: no gather */
+        raw[k] = ((p.xp * 2654435761u) ^ (p.rr * 40503u) ^ (uint32_t)fidx) & 0x00FFFFFFu;
+#else
+        raw[k] = stream_request<GENERIC, NT>(f, src, p.xp - pad_left, p.rr, kind);
+#endif
+        kinds |= kind << (2 * k);
+      }
+      p = advance(p, q64, r64);
+    }
+    if (MODE == ACHIP_MODE_TRUE_FG) { /* the few extra samples behind the bulk, so that the bulk is one clause */
+      p = p0;
+#pragma unroll
+      for (int k = 0; k < CPL; k++) {
+        if (cell0 + 64u * k < ncells && p.xp >= pad_left && wants_ext(p, k)) {
+          const bool rowstart = p.xp == pad_left;
+          uint32_t kd = RAW_FINAL;
+          ext[k] = stream_request<GENERIC, NT>(f, src, rowstart ? (uint32_t)f.out_w - 1u : p.xp - pad_left - 1u,
+                                               rowstart ? p.rr - 1u : p.rr, kd);
+          kinds |= kd << (2 * (CPL + k));
+        }
+        p = advance(p, q64, r64);
+      }
+    }
+  };
+  auto issue_any = [&](uint32_t cell0, CellPos p0, uint32_t (&raw)[CPL], uint32_t (&ext)[CPL], uint32_t &kinds) {
+    if (!GENERIC && src.nt)
+      issue(StreamTagNT{}, cell0, p0, raw, ext, kinds);
+    else
+      issue(StreamTagCached{}, cell0, p0, raw, ext, kinds);
+  };
+
+  uint32_t cell0 = (uint32_t)(wave * BLK + lane);
+  CellPos pos;
+  pos.rr = cell0 / uwp;
+  pos.xp = cell0 - pos.rr * uwp;
+  uint32_t raw[CPL], ext[CPL], kinds = 0;
+  if (wave < nblk)
+    issue_any(cell0, pos, raw, ext, kinds);
+  ACHIP_SSTAMP(2);
+
+  if (MODE == ACHIP_MODE_TRUE_FG && !ascii_only) { /* the host sends such plans to render_frames_kernel */
+    if (tid == 0)
+      out_len[fidx] = ACHIP_LEN_BADDESC;
+    return;
+  }
+  /* tables -> LDS; look-back words of this frame cleared */
+  uint32_t *glyph = lds_ptr<uint32_t>(L::o_glyph);
+  uint8_t *ramp = lds_ptr<uint8_t>(L::o_ramp);
+#pragma unroll
+  for (int k = 0; k < LUTN; k++)
+    if (tid + k * BLOCK < 256) {
+      glyph[tid + k * BLOCK] = lut_g[k];
+      lds_ptr<uint32_t>(L::o_dec)[tid + k * BLOCK] = dec_table_entry((uint32_t)(tid + k * BLOCK));
+    }
+  if (MODE == ACHIP_MODE_16_FG && tid < 64)
+    ramp[tid] = (uint8_t)lut_ramp;
+  for (int k = tid; k < nblk; k += BLOCK)
+    slots[k] = 0u;
+  (void)ramp;
+  /* ascii_pad_frame_height (ascii.c:902-941): pad_top bare newlines in front of the frame */
+  const uint32_t first_base = (uint32_t)f.pad_top;
+  if (first_base > 0u && first_base <= cap_bytes)
+    for (uint32_t o = (uint32_t)tid; o < first_base; o += BLOCK)
+      dst[o] = '\n';
+  __syncthreads(); /* the only workgroup barrier */
+  ACHIP_SSTAMP(1);
+
+  const uint32_t stage_off = (uint32_t)(L::o_stage + wave * L::STAGE);
+  const uint32_t stage_addr = lds_base_addr() + stage_off;
+  /* predicated-off byte stores land in a per-lane dummy word (one address for all lanes would serialise them) */
+  const uint32_t dummy_addr = lds_base_addr() + (uint32_t)L::o_flags + 16u + 4u * (uint32_t)lane;
+
+  for (int blk = wave; blk < nblk; blk += WAVES) {
+    /* ---- request the next block's samples: they stay in flight while this block is tokenised and drained */
+    const uint32_t cell0_next = cell0 + (uint32_t)(WAVES * BLK);
+    const CellPos pos_next = advance(pos, qit, rit);
+    uint32_t raw_n[CPL], ext_n[CPL], kinds_n = 0;
+    if (blk + WAVES < nblk)
+      issue_any(cell0_next, pos_next, raw_n, ext_n, kinds_n);
+
+    if (prof) { /* diagnostics only: make "samples arrived" a point in time */
+#ifndef ACHIP_HIPEMU
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+      ACHIP_SSTAMP(3);
+    }
+    /* ---- tokens and lengths (registers).  Written select-style: per-lane conditions become v_cndmask, not
+     * exec-mask branches -- the tail of a launch is ONE wave's instruction stream, every branch is latency. */
+    Tok tok[CPL];
+    uint32_t len[CPL], px[CPL];
+    bool is_pix[CPL], is_valid[CPL];
+    {
+      CellPos p = pos;
+#pragma unroll
+      for (int k = 0; k < CPL; k++) {
+        is_valid[k] = cell0 + 64u * k < ncells;
+        is_pix[k] = is_valid[k] && p.xp >= pad_left;
+        const uint32_t v = sample_finish<GENERIC>(f, raw[k], (kinds >> (2 * k)) & 3u);
+        px[k] = is_pix[k] ? v : 0u;
+        p = advance(p, q64, r64);
+      }
+    }
+    {
+      CellPos p = pos;
+#pragma unroll
+      for (int k = 0; k < CPL; k++) {
+        const bool valid = is_valid[k], pix = is_pix[k];
+        const uint32_t pt = px[k];
+        const uint32_t Y = luma601(pt);
+        Tok t;
+        t.rep = 0;
+        t.bg = 0;
+        uint32_t flags, n;
+        const bool row_end = valid && p.xp == uwp - 1u; /* always a pixel cell: out_w >= 1 */
+        const bool nl = row_end && p.rr < (uint32_t)rows - 1u;
+        if (MODE == ACHIP_MODE_TRUE_FG) {
+          /* image_print_color + ansi_rle_add_pixel (foreground.c:268-303, ansi.c:261-300): the SGR only when the
+           * colour differs from the previous pixel in raster order (the state survives row ends) */
+          const uint32_t nbr = wave_shift_up1(pt, k > 0 ? wave_read_lane(px[k > 0 ? k - 1 : 0], 63) : 0u);
+          const uint32_t pe = sample_finish<GENERIC>(f, ext[k], (kinds >> (2 * (CPL + k))) & 3u);
+          const uint32_t prev = wants_ext(p, k) ? pe : nbr;
+          const bool have_prev = !(p.xp == pad_left && p.rr == 0u);
+          const bool sgr = !have_prev || px_rgb(prev) != px_rgb(pt);
+          t.glyph = glyph[Y];
+          t.fg = px_rgb(pt);
+          const bool fin = row_end && !nl; /* ansi_rle_finish: the single trailing ESC[0m */
+          flags = TF_GLYPH | (sgr ? TF_SGR_FG : 0u) | (nl ? TF_NL : 0u) | (fin ? TF_FINAL_RESET : 0u);
+          if (f.ops & ACHIP_OP_FG_OVERRIDE) /* rainbow_replace_ansi_colors (color_filter.c:348-408) folded in */
+            t.fg = f.ops >> ACHIP_OP_TINT_SHIFT;
+          n = (sgr ? 10u + dec_digits(px_r(t.fg)) + dec_digits(px_g(t.fg)) + dec_digits(px_b(t.fg)) : 0u) + 1u +
+              (nl ? 1u : 0u) + (fin ? 4u : 0u);
+        } else if (MODE == ACHIP_MODE_256_FG) { /* foreground.c:475-500 */
+          t.fg = quant256(pt);
+          t.glyph = glyph[Y];
+          flags = TF_SGR_FG | TF_GLYPH | (row_end ? TF_ROW_RESET : 0u) | (nl ? TF_NL : 0u);
+          n = 8u + dec_digits(t.fg) + (ascii_only ? 1u : glyph_len(t.glyph)) + (row_end ? 4u : 0u) + (nl ? 1u : 0u);
+        } else if (MODE == ACHIP_MODE_16_FG) { /* foreground.c:584-612: glyph = cache[ramp[Y>>2]] (sic) */
+          t.fg = sgr16_code(false, quant16(pt));
+          t.glyph = glyph[ramp[Y >> 2]];
+          flags = TF_SGR_FG | TF_GLYPH | (row_end ? TF_ROW_RESET : 0u) | (nl ? TF_NL : 0u);
+          n = 5u + (ascii_only ? 1u : glyph_len(t.glyph)) + (row_end ? 4u : 0u) + (nl ? 1u : 0u);
+        } else { /* background.c:49-68 */
+          t.bg = px_rgb(pt);
+          t.fg = 0;
+          t.glyph = glyph[Y];
+          flags = TF_SGR_BG | TF_SGR_FG | TF_GLYPH | (Y < 128u ? TF_FG_WHITE : 0u) | (row_end ? TF_ROW_RESET : 0u) |
+                  (nl ? TF_NL : 0u);
+          if (f.ops & ACHIP_OP_FG_OVERRIDE) {
+            t.fg = f.ops >> ACHIP_OP_TINT_SHIFT;
+            flags |= TF_FG_GIVEN;
+          }
+          t.flags = flags;
+          CountSink cs{0u};
+          token_fields<MODE>(cs, t, ascii_only);
+          n = cs.n;
+        }
+        /* ascii_pad_frame_width: a pad cell is one space; cells behind the frame own nothing */
+        t.flags = pix ? flags : (valid ? (uint32_t)TF_PAD : 0u);
+        len[k] = pix ? n : (valid ? 1u : 0u);
+        tok[k] = t;
+        p = advance(p, q64, r64);
+      }
+    }
+
+    /* ---- wave scan: cell order is k-major (cell = k*64 + lane) */
+    uint32_t off[CPL];
+    uint32_t total = 0;
+#pragma unroll
+    for (int k = 0; k < CPL; k++) {
+      const uint32_t incl = wave_inclusive_scan(len[k]);
+      off[k] = total + incl - len[k];
+      total += wave_read_lane(incl, 63);
+    }
+
+    ACHIP_SSTAMP(4);
+    /* ---- where the block starts in the frame.  Words hold absolute stream offsets (pad_top included). */
+    uint32_t base = first_base;
+    if (blk > 0) {
+      if (lane == 0)
+        slot_store(&slots[blk], ACHIP_SLOT_AGG | total);
+      base = stream_lookback(slots, blk, lane);
+    }
+    const bool ok = base != 0xFFFFFFFFu && (uint64_t)base + total <= cap_bytes;
+    /* a frame that overflows its slot (or whose look-back failed) publishes cap+1 from there on, so every later
+     * block fails the same test and prefixes stay below 2^30 (stride <= ACHIP_STREAM_MAX_STRIDE) */
+    if (lane == 0)
+      slot_store(&slots[blk], ACHIP_SLOT_PREFIX | (ok ? base + total : cap_bytes + 1u));
+
+    ACHIP_SSTAMP(5);
+    if (ok) {
+      /* ---- token bytes into this wave's staging area: stream offset g0 (16-byte aligned) sits at its byte 0 */
+      const uint32_t g0 = base & ~15u;
+#pragma unroll
+      for (int k = 0; k < CPL; k++)
+        if (len[k] != 0u) {
+#if defined(ACHIP_STREAM_ABLATE) && ACHIP_STREAM_ABLATE == 3 /* diagnostics: no token stores either */
+          asm volatile("" ::"v"(tok[k].flags), "v"(tok[k].fg), "v"(tok[k].glyph), "v"(off[k]));
+#else
+          FastSink<L::o_dec, L::o_flags + 16> fs{stage_addr + (base + off[k] - g0), dummy_addr};
+          token_fields<MODE>(fs, tok[k], ascii_only);
+#endif
+        }
+      lds_store_fence(); /* DS operations of one wave complete in order: the reads below see every lane's bytes */
+      ACHIP_SSTAMP(6);
+
+      /* ---- staging -> HBM: whole 16-byte groups as uint4, the shared first / last group as bytes */
+      const unsigned char *stage = lds_ptr<const unsigned char>((int)stage_off);
+      const uint32_t end = base + total;
+      const uint32_t vec_begin = (base + 15u) & ~15u, vec_end = end & ~15u;
+      for (uint32_t o = vec_begin + 16u * (uint32_t)lane; o < vec_end; o += 1024u) {
+#if defined(ACHIP_STREAM_ABLATE) && (ACHIP_STREAM_ABLATE == 1 || ACHIP_STREAM_ABLATE == 3) /* diagnostics: no HBM writes */
+        const uint4 v = *reinterpret_cast<const uint4 *>(stage + (o - g0));
+        asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+#else
+        store_out16(dst + o, *reinterpret_cast<const uint4 *>(stage + (o - g0)));
+#endif
+      }
+      const uint32_t head_end = min(vec_begin, end);
+      if (base + (uint32_t)lane < head_end)
+        dst[base + (uint32_t)lane] = stage[base + (uint32_t)lane - g0];
+      const uint32_t tail_begin = max(vec_end, head_end);
+      if (lane >= 32 && tail_begin + (uint32_t)(lane - 32) < end)
+        dst[tail_begin + (uint32_t)(lane - 32)] = stage[tail_begin + (uint32_t)(lane - 32) - g0];
+    }
+    ACHIP_SSTAMP(7);
+    first_block = false;
+    if (blk == nblk - 1 && lane == 0) {
+      out_len[fidx] = ok ? base + total : ACHIP_LEN_OVERFLOW;
+      if (ok && (uint64_t)base + total < out_stride)
+        dst[base + total] = 0; /* NUL behind the frame when the slot has room, as the reference's strings carry */
+    }
+
+    /* ---- next block */
+    cell0 = cell0_next;
+    pos = pos_next;
+    kinds = kinds_n;
+#pragma unroll
+    for (int k = 0; k < CPL; k++) {
+      raw[k] = raw_n[k];
+      ext[k] = ext_n[k];
+    }
+  }
+}
+
+} // namespace achip

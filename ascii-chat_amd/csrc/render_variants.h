@@ -18,4 +18,22 @@
 
 #define ACHIP_VARIANT_COUNT 5
 
+/* Geometries of the wave-autonomous stream kernel (render_stream.hpp; per-cell modes, whole-frame launches):
+ *   WAVES  waves per workgroup (one workgroup renders one frame)
+ *   CPL    cells per lane per block (a block = 64 * CPL consecutive cells, taken through the path by one wave)
+ * X(id, WAVES, CPL); ids continue behind a gap so that the two families cannot be confused. */
+#define ACHIP_STREAM_VARIANT_FIRST 16
+#ifdef ACHIP_TEST_GEOMETRY /* emulator builds only: many tiny blocks, look-back windows beyond 64 predecessors */
+#define ACHIP_STREAM_TEST_VARIANT(X) X(20, 2, 1)
+#else
+#define ACHIP_STREAM_TEST_VARIANT(X)
+#endif
+#define ACHIP_STREAM_VARIANTS(X)                                                                                  \
+  X(16, 16, 2) /* 1024 threads: a 1080p -> 80x24 frame is one block per wave                                   */ \
+  X(17, 8, 2)  /* 512 threads: two to four workgroups per CU                                                    */ \
+  X(18, 4, 2)  /* 256 threads                                                                                   */ \
+  X(19, 16, 1) /* 1024 threads, one cell per lane: fewest registers                                             */ \
+  ACHIP_STREAM_TEST_VARIANT(X)
+#define ACHIP_IS_STREAM_VARIANT(v) ((v) >= ACHIP_STREAM_VARIANT_FIRST)
+
 #endif

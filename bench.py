@@ -1,20 +1,35 @@
 #!/usr/bin/env python3
 """bench.py -- frames/s of the MI355X render path on BASELINE.json's metric.
 
-A "step" is one pass of the hot path (one asciichat_hip_plan_render launch) over one batch of
-device-resident synthetic frames.  Default workload = the configuration the metric is quoted on:
-batch=256 x 1080p -> 80x24 truecolor foreground (BASELINE.json `metric`; `configs[1]` is the same
-shape in ANSI-256, reported under "other_workloads").  One process per GPU; frames are independent,
-so N>1 shards the batch across ranks with no data-path collective (weak scaling: 256 frames/rank).
+A "step" is one pass of the hot path (one kernel launch through the C-ABI) over one batch of 256 device-resident
+synthetic frames.  Default workload = the configuration the metric is quoted on: 1080p -> 80x24 truecolor foreground
+(BASELINE.json `metric`; `configs[1]` is the same shape in ANSI-256 and is reported under "other_workloads" with the
+other configs).  One process per GPU; frames are independent, so N > 1 shards the batch across ranks with no
+data-path collective (weak scaling: 256 frames per rank and step).
 
-Prints ONE JSON line on rank 0 (see the task contract): value = whole-job frames/s with inputs already
-resident in HBM; roofline = algorithmic bytes / kernel time vs the 8 TB/s HBM peak; cpu_baseline = the
-CPU oracle (a port of the reference's scalar path) timed on this host on a bounded sample.
+Protocol (VERDICT r1 "next round" 1-2):
+  * the K steps of a timed region are issued from C (asciichat_hip_render_many) round-robin over `--streams`
+    independent batches on separate HIP streams -- the reference's model is one render thread per client
+    (src/server/render.c:1233) -- and drained with a spin wait; barrier + torch.cuda.synchronize() on both sides;
+  * the region is repeated (>= 5 times) and the MEDIAN region gives `value` / `ms_per_step`, so that a 20-step region
+    reports the same figure as a 200-step one;
+  * a fresh input batch every step (12 batches rotate: no step re-reads the previous step's frames out of the 256 MB
+    Infinity Cache);
+  * `roofline.kernel_ms` = GPU time per step from HIP events recorded on the launch streams around a long
+    back-to-back run of the same schedule; `roofline.achieved` = algorithmic bytes per launch / kernel_ms;
+  * after timing, 8 frames per workload are compared byte-for-byte with the CPU oracle on the very same input frames;
+  * everything in the line was measured by this run, except what sits under "committed_profile" (rocprofv3 summaries
+    from profiles/, labelled with their source).
+
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes as C
 import json
+import math
 import os
+import platform
+import statistics
 import sys
 import time
 
@@ -26,177 +41,222 @@ PALETTE_STANDARD = "   ...',;:clodxkO0KXNWM"  # PALETTE_CHARS_STANDARD (palette.
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 
 WORKLOADS = {
-    # name: (src_w, src_h, W, H, color_level, render_mode, mode_name)
-    "1080p_80x24_truecolor": (1920, 1080, 80, 24, 3, 0),
-    "1080p_80x24_ansi256": (1920, 1080, 80, 24, 2, 0),
-    "4k_200x60_truecolor": (3840, 2160, 200, 60, 3, 0),
-    "4k_400x120_halfblock": (3840, 2160, 400, 120, 3, 2),
-    "640x480_80x24_mono": (640, 480, 80, 24, 0, 0),
+    # name: (src_w, src_h, W, H, color_level, render_mode)
+    "1080p_80x24_truecolor": (1920, 1080, 80, 24, 3, 0),  # the metric's shape
+    "1080p_80x24_ansi256": (1920, 1080, 80, 24, 2, 0),    # configs[1] (K2)
+    "4k_200x60_truecolor": (3840, 2160, 200, 60, 3, 0),   # configs[2] (K3)
+    "4k_400x120_halfblock": (3840, 2160, 400, 120, 3, 2),  # configs[4] (K5)
+    "640x480_80x24_mono": (640, 480, 80, 24, 0, 0),       # configs[0] (K1)
 }
+INPUT_KINDS = ("noise", "smooth", "bars", "gray")
 
 
-def make_frames(torch, batch, w, h, seed):
-    """Device-resident synthetic S-noise-like frames: uniform random RGB24 (every cell changes colour,
-    no runs -- the worst case for output size, as in BASELINE.md's 'noise' rows)."""
-    g = torch.Generator(device="cuda")
-    g.manual_seed(seed)
-    return torch.randint(0, 256, (batch, h, w, 3), dtype=torch.uint8, device="cuda", generator=g)
+def make_frames(torch, batch, w, h, seed, kind="noise"):
+    """Device-resident synthetic inputs of SURVEY 8(d).  noise: uniform random RGB24 (every cell changes colour, no
+    runs -- the worst case for output size); smooth / bars / gray: the formulas of tests/orc.py frame_smooth /
+    frame_bars (phase = frame index / 2) / frame_gray, evaluated on the device."""
+    if kind == "noise":
+        g = torch.Generator(device="cuda")
+        g.manual_seed(seed)
+        return torch.randint(0, 256, (batch, h, w, 3), dtype=torch.uint8, device="cuda", generator=g)
+    x = torch.arange(w, device="cuda", dtype=torch.int64)[None, None, :]
+    y = torch.arange(h, device="cuda", dtype=torch.int64)[None, :, None]
+    out = torch.empty((batch, h, w, 3), dtype=torch.uint8, device="cuda")
+    if kind == "smooth":
+        out[..., 0] = (x * 255 // max(1, w - 1)).to(torch.uint8)
+        out[..., 1] = (y * 255 // max(1, h - 1)).to(torch.uint8)
+        out[..., 2] = ((((x // 64) + (y // 64)) * 32) & 0xFF).to(torch.uint8)
+    elif kind == "bars":
+        bar, rowgap = max(1, w // 8), max(1, h // 8)
+        phase = (torch.arange(batch, device="cuda", dtype=torch.int64) + seed % 1000)[:, None, None] // 2
+        ax = (x + phase) % w
+        sel = (ax // bar) % 3
+        grid = (ax % bar == 0) | (y % rowgap == 0)
+        for c in range(3):
+            out[..., c] = torch.where((sel == c) & ~grid, 255, 0).to(torch.uint8)
+    elif kind == "gray":
+        i = (y * w + x)
+        gch = (i * 255 // (w * h)).to(torch.uint8)
+        for c in range(3):
+            out[..., c] = gch
+    else:
+        raise ValueError(kind)
+    return out
 
 
-def build_plan(pkg, frames_t, W, H, cl, rm):
+def build_plan(pkg, frames_t, W, H, cl, rm, aspect=False):
+    """aspect=False: full W x H (SURVEY 8(d) first variant); aspect=True: use_aspect_ratio + wants_padding, the
+    server's call (stream.c:841)."""
     b, h, w, _ = frames_t.shape
     mode = pkg.lib().achip_mode_from_caps(cl, rm)
-    descs = []
     base = frames_t.data_ptr()
-    for i in range(b):
-        f = pkg.frame_setup(base + i * h * w * 3, w, h, W, H, rm, False, False, False)
-        descs.append(f)
+    descs = [pkg.frame_setup(base + i * h * w * 3, w, h, W, H, rm, aspect, aspect, False) for i in range(b)]
     return pkg.Plan(mode, PALETTE_STANDARD, descs), mode
 
 
-def time_steps(torch, plans, outs, lns, streams, steps, warmup, dist=None):
-    """K launches: launch k renders input batch k % len(plans) on stream k % len(streams) into that stream's own output
-    slab (len(plans) is a multiple of len(streams), so a plan always runs on the same stream).  One stream = launches
-    back to back; several = that many independent batches in flight.  Returns wall seconds, the GPU time of the whole
-    region (events on the current stream, which every launch stream is fenced against on both sides) and the average
-    duration of ONE launch (events on each launch stream around its share of the launches)."""
-    P, S = len(plans), len(streams)
-    assert P % S == 0
-    cur = torch.cuda.current_stream()
+class Runner:
+    """P plans (independent input batches) rendered round-robin on S streams through asciichat_hip_render_many."""
 
-    def launch(k):
-        s = k % S
-        plans[k % P].render(outs[s].data_ptr(), plans[0].stride, lns[s].data_ptr(), streams[s].cuda_stream)
+    def __init__(self, torch, pkg, plans, batch, streams):
+        self.torch, self.pkg, self.plans, self.batch = torch, pkg, plans, batch
+        self.S = streams
+        self.cur = torch.cuda.current_stream()
+        self.lanes = [self.cur] + [torch.cuda.Stream() for _ in range(streams - 1)]
+        self.stride = plans[0].stride
+        self.outs = [torch.empty(batch * self.stride, dtype=torch.uint8, device="cuda") for _ in range(streams)]
+        self.lns = [torch.zeros(batch, dtype=torch.int32, device="cuda") for _ in range(streams)]
+        self.sched = pkg.Schedule(plans, [o.data_ptr() for o in self.outs], [l.data_ptr() for l in self.lns],
+                                  self.stride, [s.cuda_stream for s in self.lanes])
+        self.step = 0
 
-    for k in range(warmup):
-        launch(k)
+    def issue(self, n):
+        self.sched.issue(self.step, n)
+        self.step += n
+
+    def region(self, K, dist=None):
+        """EXACTLY K steps, barrier + synchronize on both sides; returns wall seconds."""
+        torch = self.torch
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        self.issue(K)
+        self.sched.wait()  # spin on hipStreamQuery: no driver sleep in a ~170 us region
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    def gpu_ms_per_step(self, n):
+        """GPU time per step over n back-to-back steps: HIP events on every launch stream, first begin -> last end."""
+        torch = self.torch
+        torch.cuda.synchronize()
+        b = [torch.cuda.Event(enable_timing=True) for _ in range(self.S)]
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(self.S)]
+        self.issue(self.S)  # streams busy: the begin events complete when these kernels end, not at record time
+        for s in range(self.S):
+            b[s].record(self.lanes[s])
+        self.issue(n)
+        for s in range(self.S):
+            e[s].record(self.lanes[s])
+        torch.cuda.synchronize()
+        return max(b[s].elapsed_time(e[t]) for s in range(self.S) for t in range(self.S)) / n
+
+
+def verify_against_oracle(torch, pkg, plan, frames_t, W, H, cl, rm, aspect, n_check=8):
+    """Renders the batch once more (untimed) and compares n_check frames byte-for-byte with the CPU oracle run on the
+    very same input frames (downloaded from the device).  Raises on any difference."""
+    import numpy as np
+
+    import orc
+
+    b = frames_t.shape[0]
+    out = torch.zeros(b * plan.stride, dtype=torch.uint8, device="cuda")
+    ln = torch.zeros(b, dtype=torch.int32, device="cuda")
+    plan.render(out.data_ptr(), plan.stride, ln.data_ptr(), torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    e0 = torch.cuda.Event(enable_timing=True)
-    e1 = torch.cuda.Event(enable_timing=True)
-    b = [torch.cuda.Event(enable_timing=True) for _ in range(S)]
-    e = [torch.cuda.Event(enable_timing=True) for _ in range(S)]
-    t0 = time.perf_counter()
-    e0.record(cur)
-    for s in range(S):
-        if streams[s] != cur:
-            streams[s].wait_event(e0)
-        b[s].record(streams[s])
-    for k in range(steps):
-        launch(k)
-    for s in range(S):
-        e[s].record(streams[s])
-        if streams[s] != cur:
-            cur.wait_event(e[s])
-    e1.record(cur)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    gpu_ms = e0.elapsed_time(e1)
-    per_launch = [b[s].elapsed_time(e[s]) / len(range(s, steps, S)) for s in range(S) if s < steps]
-    return wall, gpu_ms, sum(per_launch) / len(per_launch)
+    lens = ln.cpu().numpy().astype("uint32")
+    assert (lens < 0xFFFFFFF0).all(), "kernel reported overflow / bad descriptor"
+    idx = sorted(set(int(round(i * (b - 1) / max(1, n_check - 1))) for i in range(min(n_check, b))))
+    for i in idx:
+        img = np.ascontiguousarray(frames_t[i].cpu().numpy())
+        exp = orc.convert_with_caps(img, W, H, cl, rm, aspect, aspect, False)
+        got = bytes(out[i * plan.stride:i * plan.stride + int(lens[i])].cpu().numpy())
+        if got != exp:
+            raise SystemExit(f"bench.py: output of frame {i} differs from the oracle ({len(got)} vs {len(exp)} bytes)")
+    return {"frames_checked": len(idx), "byte_identical_to_oracle": True}, lens
 
 
-def launch_durations(torch, plans, outs, lns, streams, n):
-    """Average duration of ONE launch while len(streams) launches are in flight: a HIP event pair around every launch,
-    on the stream it is launched on (the stream is busy, so the first event completes when the previous kernel of that
-    stream ends).  This is the per-kernel figure rocprofv3 --kernel-trace --stats reports."""
-    P, S = len(plans), len(streams)
-    pairs = []
-    for k in range(n + 2 * S):
-        s = k % S
-        a = torch.cuda.Event(enable_timing=True)
-        b = torch.cuda.Event(enable_timing=True)
-        a.record(streams[s])
-        plans[k % P].render(outs[s].data_ptr(), plans[0].stride, lns[s].data_ptr(), streams[s].cuda_stream)
-        b.record(streams[s])
-        pairs.append((a, b))
-    torch.cuda.synchronize()
-    d = [a.elapsed_time(b) for a, b in pairs[2 * S:]]  # the first launches start on idle streams
-    return sum(d) / len(d)
-
-
-def kernel_time_events(torch, plans, out, ln, reps):
-    """Per-launch duration: HIP events recorded on the launch stream around EACH launch (idle stream
-    in between), averaged -- contains the launch latency the back-to-back figure hides."""
-    stream = torch.cuda.current_stream().cuda_stream
-    tot = 0.0
-    for k in range(reps):
-        a = torch.cuda.Event(enable_timing=True)
-        b = torch.cuda.Event(enable_timing=True)
-        a.record()
-        plans[k % len(plans)].render(out.data_ptr(), plans[0].stride, ln.data_ptr(), stream)
-        b.record()
-        b.synchronize()
-        tot += a.elapsed_time(b)
-    return tot / reps
-
-
-def run_workload(torch, pkg, name, batch, steps, warmup, dist=None, seed=1234, variant=-1, input_sets=4, streams=1,
-                 serial_leg=True):
-    """`streams` independent batches are kept in flight on separate HIP streams (the reference's model is one render
-    thread per client, src/server/render.c:1233): a launch is a gather burst (HBM-bound) followed by token work
-    (latency-bound, HBM idle), and launches in flight overlap those phases (profiles/r01_overlap.txt).
-    input_sets x streams independent batches of source frames are rendered round-robin: a video tick never renders the
-    frames of the tick before, and the sampled lines of ONE batch (36 MB at 1080p->80x24) would otherwise be served by
-    the 256 MB Infinity Cache from the second step on (profiles/r01_input_sets.txt)."""
+def run_workload(torch, pkg, name, batch, steps, warmup, regions, dist=None, seed=1234, variant=-1, input_sets=3,
+                 streams=4, kind="noise", aspect=False, serial_leg=True, verify=True):
     sw, sh, W, H, cl, rm = WORKLOADS[name]
     nsets = input_sets * streams
-    sets = [make_frames(torch, batch, sw, sh, seed + 7919 * s) for s in range(nsets)]
+    sets = [make_frames(torch, batch, sw, sh, seed + 7919 * s, kind) for s in range(nsets)]
     plans = []
     for t in sets:
-        plan, mode = build_plan(pkg, t, W, H, cl, rm)
+        plan, mode = build_plan(pkg, t, W, H, cl, rm, aspect)
         plan.set_concurrency(streams)
         if variant >= 0:
             plan.set_variant(variant)
         plans.append(plan)
-    cur = torch.cuda.current_stream()
-    lanes = [cur] + [torch.cuda.Stream() for _ in range(streams - 1)]
-    outs = [torch.empty(batch * plans[0].stride, dtype=torch.uint8, device="cuda") for _ in range(streams)]
-    lns = [torch.zeros(batch, dtype=torch.int32, device="cuda") for _ in range(streams)]
-    rows = 2 * H if rm == 2 else H
+    run = Runner(torch, pkg, plans, batch, streams)
+    ver, lens = (verify_against_oracle(torch, pkg, plans[0], sets[0], W, H, cl, rm, aspect) if verify
+                 else (None, None))
+    # exact output bytes of every input set (SURVEY 8(d): B_alg = sampled RGB consumed + exact output length)
     out_bytes = []
-    for g in range(0, nsets, streams):  # exact output bytes of every set (SURVEY 8(d): sampled RGB consumed + exact output)
-        for s in range(streams):
-            plans[g + s].render(outs[s].data_ptr(), plans[0].stride, lns[s].data_ptr(), lanes[s].cuda_stream)
+    for g in range(0, nsets, streams):
+        run.step = g
+        run.issue(streams)
         torch.cuda.synchronize()
         for s in range(streams):
-            lens = lns[s].cpu().numpy().astype("uint32")
-            assert (lens < 0xFFFFFFF0).all(), "kernel reported overflow/bad descriptor"
-            out_bytes.append(int(lens.sum()))
-    wall, gpu_ms, stream_ms = time_steps(torch, plans, outs, lns, lanes, steps, warmup, dist)
-    launch_ms = launch_durations(torch, plans, outs, lns, lanes, max(60, steps // 2))
-    alg_bytes = int(sum(out_bytes) / len(out_bytes)) + batch * 3 * W * rows
-    res = dict(name=name, mode=pkg.MODE_NAMES[mode], batch=batch, wall_s=wall, gpu_ms=gpu_ms, steps=steps,
-               out_bytes_per_frame=sum(out_bytes) / len(out_bytes) / batch, alg_bytes_per_launch=alg_bytes,
-               launch_ms=launch_ms, stream_ms_per_launch=stream_ms, ms_per_step_gpu=gpu_ms / steps,
-               variant=plans[0].variant, input_sets=nsets,
-               streams=streams, frames=sets, plan=plans[0], plans=plans, out=outs[0], ln=lns[0], serial=None)
+            l = run.lns[s].cpu().numpy().astype("uint32")
+            assert (l < 0xFFFFFFF0).all(), "kernel reported overflow / bad descriptor"
+            out_bytes.append(int(l.sum()))
+    run.step = 0
+    run.issue(warmup)
+    torch.cuda.synchronize()
+    walls = [run.region(steps, dist) for _ in range(regions)]
+    gpu_ms = run.gpu_ms_per_step(max(200, steps))
+    f0 = pkg.frame_setup(sets[0].data_ptr(), sw, sh, W, H, rm, aspect, aspect, False)
+    cells_px = f0.out_w * f0.out_h  # sampled pixels per frame (2 rows per text row in half-block)
+    out_mean = sum(out_bytes) / len(out_bytes)
+    alg_bytes = int(out_mean) + batch * 3 * cells_px
+    res = dict(name=name, mode=pkg.MODE_NAMES[mode], batch=batch, walls=walls, steps=steps, gpu_ms=gpu_ms,
+               out_bytes_per_frame=out_mean / batch, alg_bytes_per_launch=alg_bytes, variant=plans[0].variant,
+               input_sets=nsets, streams=streams, kind=kind, aspect=aspect, verify=ver,
+               cells_per_frame=(f0.pad_left + f0.out_w) * ((f0.out_h + 1) // 2 if rm == 2 else f0.out_h),
+               serial=None, plans=plans, sets=sets)
     if serial_leg:
-        # the same steps issued back to back on ONE stream (each plan re-chooses its geometry for the whole GPU), next
-        # to it the per-launch event-pair time (with launch latency) and the same batch rendered every step
+        # the same steps one launch at a time (each plan re-chooses its geometry for the whole GPU), and the same
+        # batch rendered every step (its sampled lines then come out of the Infinity Cache)
         for plan in plans:
             plan.set_concurrency(1)
             if variant >= 0:
                 plan.set_variant(variant)
-        n1 = max(40, steps // 2)
-        _, g1, l1 = time_steps(torch, plans, outs[:1], lns[:1], lanes[:1], n1, 8, None)
-        pair = kernel_time_events(torch, plans, outs[0], lns[0], 20)
-        _, gh, _ = time_steps(torch, plans[:1], outs[:1], lns[:1], lanes[:1], n1, 8, None)
-        res["serial"] = {"kernel_ms": g1 / n1, "frames_per_s": batch * n1 / (g1 * 1e-3), "kernel_variant": plans[0].variant,
-                         "kernel_ms_event_pair": pair, "kernel_ms_same_batch_every_step": gh / n1,
-                         "roofline_frac": alg_bytes / (g1 / n1 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        one = Runner(torch, pkg, plans, batch, 1)
+        one.issue(8)
+        g1 = one.gpu_ms_per_step(max(100, steps))
+        w1 = statistics.median(one.region(steps, None) for _ in range(max(3, regions // 3)))
+        same = Runner(torch, pkg, plans[:1], batch, 1)
+        same.issue(8)
+        gs = same.gpu_ms_per_step(max(100, steps))
+        res["serial"] = {"kernel_ms": g1, "ms_per_step_wall": w1 / steps * 1e3, "frames_per_s": batch / (g1 * 1e-3),
+                         "kernel_variant": plans[0].variant, "kernel_ms_same_batch_every_step": gs,
+                         "roofline_frac": alg_bytes / (g1 * 1e-3) / 1e9 / HBM_PEAK_GBS}
     return res
+
+
+def summarize(res, world=1, wall=None):
+    """Per-workload entry of the JSON line (everything measured by this run)."""
+    wall = statistics.median(res["walls"]) if wall is None else wall
+    k = res["gpu_ms"]
+    a = res["alg_bytes_per_launch"] / (k * 1e-3) / 1e9
+    fps = res["batch"] * res["steps"] * world / wall
+    d = {"frames_per_s": fps, "ms_per_step": wall / res["steps"] * 1e3, "kernel_ms": k, "launches_in_flight": res["streams"],
+         "region_ms": {"min": min(res["walls"]) * 1e3, "median": statistics.median(res["walls"]) * 1e3,
+                       "max": max(res["walls"]) * 1e3, "regions": len(res["walls"]), "steps_per_region": res["steps"]},
+         "input": res["kind"], "aspect_and_padding": res["aspect"], "mode": res["mode"],
+         "out_bytes_per_frame": res["out_bytes_per_frame"], "alg_bytes_per_launch": res["alg_bytes_per_launch"],
+         "output_GBps": res["out_bytes_per_frame"] * fps / 1e9, "cells_per_s": res["cells_per_frame"] * fps,
+         "roofline_GBps": a, "roofline_frac": a / HBM_PEAK_GBS, "kernel_variant": res["variant"],
+         "input_sets": res["input_sets"], "verify": res["verify"]}
+    if res["serial"] is not None:
+        d["one_launch_at_a_time"] = res["serial"]
+    return d
+
+
+def free_workload(torch, res):
+    for p in res.pop("plans", []):
+        p.close()
+    res.pop("sets", None)
+    torch.cuda.empty_cache()
 
 
 def time_with_d2h(torch, plan, n, steps):
     """the same steps with the output copied to pinned host memory after every launch -- slab and
-    lengths share one allocation so that they cross PCIe in ONE transfer (a second, tiny copy behind the big one
-    costs more than the big one).  The PCIe-inclusive rate, never `value`."""
+    lengths share one allocation so that they cross PCIe in ONE transfer.  The PCIe-inclusive rate, never `value`."""
     stream = torch.cuda.current_stream().cuda_stream
     slab = n * plan.stride
     buf = torch.empty(slab + 4 * n, dtype=torch.uint8, device="cuda")
@@ -217,11 +277,10 @@ def time_with_d2h(torch, plan, n, steps):
     return (time.perf_counter() - t0) / steps, int(buf.numel())
 
 
-def run_grid9(torch, pkg, steps, warmup):
-    """BASELINE configs[3]: nine 1080p sources -> the 3x3 grid at 160x48 for each of the nine clients.  One launch
-    renders the nine client frames straight from the sources (the W x 2H canvas of create_multi_source_composite
-    is virtual); with 9 frames the launch is cut into row bands automatically."""
-    import ctypes as C
+def run_grid9(torch, pkg, steps, regions, targets=256):
+    """BASELINE configs[3]: nine 1080p sources -> the 3x3 grid at 160x48 (stream.c:523-854), rendered for `targets`
+    target clients per step (the server renders the mixed frame once per connected client, render.c:340-600).  One
+    launch renders all target frames straight from the nine sources: the W x 2H canvas is virtual."""
     n, sw, sh, tw, th = 9, 1920, 1080, 160, 48
     src = make_frames(torch, n, sw, sh, 4321)
     ptrs = (C.c_void_p * n)(*[src.data_ptr() + i * sh * sw * 3 for i in range(n)])
@@ -230,25 +289,40 @@ def run_grid9(torch, pkg, steps, warmup):
     pkg.lib().achip_composite_setup(C.byref(comp), ptrs, ws, hs, n, tw, th)
     comp_dev = C.c_void_p()
     assert pkg.lib().asciichat_hip_composite_upload(C.byref(comp), C.byref(comp_dev)) == 0
-    descs = []
-    for _ in range(n):  # every client looks at the same grid (stream.c:790-854: aspect + padding on)
-        f = pkg.frame_setup(None, tw, 2 * th, tw, th, 0, True, True, False)
-        f.comp = comp_dev.value
-        descs.append(f)
-    plan = pkg.Plan(pkg.lib().achip_mode_from_caps(3, 0), PALETTE_STANDARD, descs)
-    out = torch.empty(n * plan.stride, dtype=torch.uint8, device="cuda")
-    ln = torch.zeros(n, dtype=torch.int32, device="cuda")
-    wall, gpu_ms, _ = time_steps(torch, [plan], [out], [ln], [torch.cuda.current_stream()], steps, warmup, None)
-    lens = ln.cpu().numpy().astype("uint32")
-    assert (lens < 0xFFFFFFF0).all()
-    cells = int(sum(d.out_w * d.out_h for d in descs))
-    res = {"frames_per_s": n * steps / wall, "kernel_ms": gpu_ms / steps, "out_bytes_per_frame": float(lens.mean()),
-           "alg_bytes_per_launch": int(lens.sum()) + 3 * cells, "kernel_variant": plan.variant, "bands_per_frame": plan.parts}
-    res["roofline_GBps"] = res["alg_bytes_per_launch"] / (res["kernel_ms"] * 1e-3) / 1e9
-    res["roofline_frac"] = res["roofline_GBps"] / HBM_PEAK_GBS
-    plan.close()
+    out = {}
+    for label, nt in (("nine_targets", 9), (f"{targets}_targets", targets)):
+        descs = []
+        for _ in range(nt):  # every client looks at the same grid (stream.c:790-854: aspect + padding on)
+            f = pkg.frame_setup(None, tw, 2 * th, tw, th, 0, True, True, False)
+            f.comp = comp_dev.value
+            descs.append(f)
+        plan = pkg.Plan(pkg.lib().achip_mode_from_caps(3, 0), PALETTE_STANDARD, descs)
+        run = Runner(torch, pkg, [plan], nt, 1)
+        run.issue(5)
+        walls = [run.region(steps, None) for _ in range(regions)]
+        g = run.gpu_ms_per_step(max(100, steps))
+        lens = run.lns[0].cpu().numpy().astype("uint32")
+        assert (lens < 0xFFFFFFF0).all()
+        cells = int(sum(d.out_w * d.out_h for d in descs))
+        alg = int(lens.sum()) + 3 * cells
+        wall = statistics.median(walls)
+        out[label] = {"frames_per_s": nt * steps / wall, "ms_per_step": wall / steps * 1e3, "kernel_ms": g,
+                      "out_bytes_per_frame": float(lens.mean()), "alg_bytes_per_launch": alg,
+                      "roofline_GBps": alg / (g * 1e-3) / 1e9, "roofline_frac": alg / (g * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                      "kernel_variant": plan.variant, "bands_per_frame": plan.parts}
+        plan.close()
     pkg.lib().asciichat_hip_free(comp_dev)
-    return res
+    return out
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor() or "unknown"
 
 
 def cpu_baseline(name, budget_s=12.0):
@@ -264,7 +338,6 @@ def cpu_baseline(name, budget_s=12.0):
     L = orc.lib()
     pal = orc.PALETTE_STANDARD.encode()
     nb = C.c_uint64()
-    # calibrate
     t = L.orc_bench_convert(img.ctypes.data, sw, sh, W, H, cl, rm, pal, 20, 1, C.byref(nb))
     per = max(t / 20, 1e-7)
     it1 = max(50, int(budget_s * 0.4 / per))
@@ -274,52 +347,48 @@ def cpu_baseline(name, budget_s=12.0):
     itn = max(20, int(budget_s * 0.6 / per))
     tn = L.orc_bench_convert(img.ctypes.data, sw, sh, W, H, cl, rm, pal, itn, th, C.byref(nb))
     return {
-        "value": it1 / t1, "unit": "frames/s", "cores": 1, "kind": "port",
+        "value": it1 / t1, "unit": "frames/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
+        "host_threads": cores,
         "sample": f"{it1} x ({sw}x{sh}->{W}x{H}, color_level={cl}, render_mode={rm}, uniform-noise frame) on 1 thread; "
                   f"{itn} per thread on {th} threads",
         "all_cores": {"value": itn * th / tn, "cores": th},
     }
 
 
-def load_pmc_traffic(workload, variant, batch):
-    """profiles/pmc_traffic.json: {workload: {"variant": v, "batch": b, "fetch_size_kb": F, "write_size_kb": W, ...}}"""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if not os.path.exists(path):
-        return None
+def committed_profile(workload):
+    """rocprofv3 summaries committed under profiles/ (NOT measured by this run; labelled with their source)."""
+    path = os.path.join(ROOT, "profiles", "committed_profile.json")
     try:
         ent = json.load(open(path)).get(workload)
     except Exception:
         return None
-    if not ent or ent.get("variant") != variant or ent.get("batch") != batch:
-        return None
-    # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB.  On gfx950 FETCH_SIZE tallies 128-byte line fetches at 64 B
-    # (MI355X_MICROARCH.md, "HBM"); calibrated for this kernel's access pattern by scripts/ubench/sparse_fetch.hip
-    # (profiles/r01_ubench_sparse_fetch.txt): a lone dword load moves one whole 128-byte line, so the x2 correction
-    # applies to the sparse gathers as well (and 2 x FETCH_SIZE equals the bytes of the sampled source rows).
-    fetch, write = ent["fetch_size_kb"] * 1024.0, ent["write_size_kb"] * 1024.0
-    return {"hbm_bytes": 2 * fetch + write, "fetch_bytes_raw": fetch, "fetch_bytes_x2_corrected": 2 * fetch,
-            "write_bytes": write, "source": ent.get("source", "profiles/pmc_traffic.json")}
+    return ent
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--regions", type=int, default=0, help="timed regions of --steps steps each; 0 = max(5, 1200 / steps)")
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--workload", default="1080p_80x24_truecolor", choices=sorted(WORKLOADS))
-    ap.add_argument("--others", default="1080p_80x24_ansi256,4k_200x60_truecolor,4k_400x120_halfblock",
-                    help="comma list of extra workloads reported under other_workloads (N=1 only); '' = none")
+    ap.add_argument("--input", default="noise", choices=INPUT_KINDS)
+    ap.add_argument("--aspect", action="store_true", help="use_aspect_ratio + wants_padding for the main workload")
+    ap.add_argument("--others", default="default",
+                    help="'default' = every BASELINE config + the input / aspect variants of SURVEY 8(d) (N=1 only); '' = none; "
+                         "or a comma list of workload names")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-d2h", action="store_true", help="skip the PCIe-inclusive with_d2h leg (profiling runs)")
     ap.add_argument("--variant", type=int, default=-1)
-    ap.add_argument("--input-sets", type=int, default=4,
-                    help="independent batches of source frames per stream, rendered round-robin (1 = the same batch every step)")
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--input-sets", type=int, default=3,
+                    help="independent batches of source frames per stream, rendered round-robin")
+    ap.add_argument("--streams", type=int, default=4,
                     help="independent batches kept in flight on separate HIP streams (1 = one launch at a time)")
     ap.add_argument("--no-hot", action="store_true",
-                    help="skip the one-launch-at-a-time / same-batch comparison legs (profiling runs: keeps the kernel trace to the timed launches)")
+                    help="skip the one-launch-at-a-time / same-batch comparison legs (profiling runs)")
     args = ap.parse_args()
+    regions = args.regions if args.regions > 0 else max(5, min(60, 1200 // max(1, args.steps)))
 
     import torch
 
@@ -347,94 +416,82 @@ def main():
             d.init_process_group(backend)
         dist = d
 
-    res = run_workload(torch, pkg, args.workload, args.batch, args.steps, args.warmup, dist, seed=1234 + rank,
-                       variant=args.variant, input_sets=args.input_sets, streams=args.streams,
-                       serial_leg=not args.no_hot)
-    wall = res["wall_s"]
-    if dist is not None:
-        t = torch.tensor([wall], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+    res = run_workload(torch, pkg, args.workload, args.batch, args.steps, args.warmup, regions, dist, seed=1234 + rank,
+                       variant=args.variant, input_sets=args.input_sets, streams=args.streams, kind=args.input,
+                       aspect=args.aspect, serial_leg=not args.no_hot)
+    walls = res["walls"]
+    if dist is not None:  # MAX over ranks of every region's wall time
+        t = torch.tensor(walls, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
-    total_frames = args.batch * args.steps * world
-    value = total_frames / wall
-
-    # Roofline of the frame kernel.  With `launches_in_flight` launches overlapping, what a launch COSTS is the GPU time of
-    # the timed region (HIP events fenced against every launch stream) divided by K: `kernel_ms`, and
-    # achieved = B_alg / kernel_ms.  `kernel_ms_on_stream` is the time a launch occupies its own stream (a HIP event
-    # pair around every launch, in a leg right after the timed region): its begin->end duration plus the wait for CUs
-    # behind the other streams' workgroups.  rocprofv3 --kernel-trace reports the begin->end part; the committed trace
-    # (profiles/r01_bench_kernel_stats.csv, summarised by scripts/trace_overlap.py in profiles/bench_trace_overlap.json)
-    # gives average duration / average launches in flight = busy time per launch, which is what agrees with
-    # `kernel_ms`.  One stream: all three coincide (`one_launch_at_a_time`; 14.009 vs 14.011 us in round 1).
-    eff_ms = res["ms_per_step_gpu"]
-    achieved = res["alg_bytes_per_launch"] / (eff_ms * 1e-3) / 1e9
+        walls = [float(v) for v in t.tolist()]
+        res["walls"] = walls
+    wall = statistics.median(walls)
+    main_d = summarize(res, world, wall)
+    sw, sh, W, H, cl, rm = WORKLOADS[args.workload]
     line = {
         "metric": "frames/sec, 1080p->80x24 truecolor (batch of independent client frames)",
-        "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u8",
-        "data": f"synthetic (uniform-random RGB24 frames generated on device, resident in HBM; {res['input_sets']} independent "
-                "batches rendered round-robin so no step re-reads the frames of the step before)",
+        "value": main_d["frames_per_s"], "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": main_d["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8",
+        "data": f"synthetic ({args.input} RGB24 frames generated on device, resident in HBM; {res['input_sets']} "
+                "independent batches rendered round-robin so no step re-reads the frames of the step before)",
+        "timing": {"regions": len(walls), "steps_per_region": args.steps, "statistic": "median region",
+                   "region_ms": main_d["region_ms"],
+                   "issue": "asciichat_hip_render_many (C) + spin wait; barrier + synchronize on both sides of every region"},
         "config": {"workload": args.workload, "batch_per_gpu": args.batch, "global_batch": args.batch * world,
-                   "src": f"{WORKLOADS[args.workload][0]}x{WORKLOADS[args.workload][1]}",
-                   "grid": f"{WORKLOADS[args.workload][2]}x{WORKLOADS[args.workload][3]}", "mode": res["mode"],
+                   "src": f"{sw}x{sh}", "grid": f"{W}x{H}", "mode": res["mode"], "input": args.input,
+                   "aspect_and_padding": args.aspect,
                    "parallelism": f"frames sharded over {world} rank(s), no data-path collective",
                    "kernel_variant": res["variant"], "input_sets": res["input_sets"],
                    "launches_in_flight": args.streams},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "alg_bytes_per_launch": res["alg_bytes_per_launch"], "kernel_ms": eff_ms,
-                     "launches_in_flight": args.streams, "kernel_ms_on_stream": res["launch_ms"],
-                     "kernel_ms_note": "kernel_ms = GPU time of the timed region / K while launches_in_flight launches "
-                                       "overlap (= what one launch costs); rocprofv3 reports each dispatch begin-to-end "
-                                       "(rocprof_kernel_trace.avg_duration_us), and that divided by the average number "
-                                       "in flight is the same busy time per launch (busy_us_per_launch)",
-                     "out_bytes_per_frame": res["out_bytes_per_frame"]},
+        "roofline": {"bound": "hbm", "achieved": main_d["roofline_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": main_d["roofline_frac"], "traffic": None,
+                     "alg_bytes_per_launch": res["alg_bytes_per_launch"], "kernel_ms": res["gpu_ms"],
+                     "launches_in_flight": args.streams, "out_bytes_per_frame": res["out_bytes_per_frame"],
+                     "kernel_ms_note": "GPU time per step (HIP events on the launch streams, first begin -> last end of a "
+                                       "back-to-back run of the same schedule); with launches overlapping this is what "
+                                       "one launch costs, not one dispatch's begin-to-end duration",
+                     "traffic_note": "HBM bytes need rocprofv3 --pmc passes, which this run did not make: see "
+                                     "committed_profile (if present) for the committed figure and its source"},
+        "output_GBps": main_d["output_GBps"], "cells_per_s": main_d["cells_per_s"], "verify": res["verify"],
     }
     if res["serial"] is not None:
         line["one_launch_at_a_time"] = res["serial"]
-    # HBM traffic per launch comes from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE cannot share a
-    # pass, MI355X_MICROARCH.md "rocprofv3 PMC slots"); scripts/pmc_run.sh collects them and the summary is
-    # committed under profiles/.  When a summary for this workload and kernel geometry exists it is reported here.
-    trace = os.path.join(ROOT, "profiles", "bench_trace_overlap.json")
-    if os.path.exists(trace):
-        try:
-            line["roofline"]["rocprof_kernel_trace"] = json.load(open(trace))
-        except Exception:
-            pass
-    traffic = load_pmc_traffic(args.workload, res["variant"], args.batch)
-    if traffic is not None:
-        line["roofline"]["traffic"] = traffic["hbm_bytes"]
-        line["roofline"]["traffic_detail"] = traffic
+    cp = committed_profile(args.workload)
+    if cp is not None:
+        line["committed_profile"] = cp
     if rank == 0 and world == 1:
         if not args.no_d2h:
-            d2h_s, d2h_bytes = time_with_d2h(torch, res["plan"], args.batch, max(50, args.steps // 4))
+            d2h_s, d2h_bytes = time_with_d2h(torch, res["plans"][0], args.batch, 50)
             line["with_d2h"] = {"ms_per_step": d2h_s * 1e3, "frames_per_s": args.batch / d2h_s,
                                 "copied_bytes_per_step": d2h_bytes, "GBps": d2h_bytes / d2h_s / 1e9,
                                 "note": "whole fixed-stride slab + lengths to pinned host memory after every launch; PCIe-bound"}
+        free_workload(torch, res)
         if not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(args.workload)
         others = {}
-        for name in [s for s in args.others.split(",") if s]:
-            if name == args.workload:
-                continue
-            del res
-            torch.cuda.empty_cache()
-            b = args.batch
-            res = run_workload(torch, pkg, name, b, max(40, args.steps // 4), 8, None, input_sets=args.input_sets,
-                               streams=args.streams, serial_leg=not args.no_hot)
-            k = res["ms_per_step_gpu"]
-            a = res["alg_bytes_per_launch"] / (k * 1e-3) / 1e9
-            others[name] = {"frames_per_s": b * res["steps"] / res["wall_s"], "kernel_ms": k,
-                            "kernel_ms_on_stream": res["launch_ms"], "launches_in_flight": args.streams,
-                            "out_bytes_per_frame": res["out_bytes_per_frame"], "roofline_GBps": a,
-                            "roofline_frac": a / HBM_PEAK_GBS, "kernel_variant": res["variant"],
-                            "input_sets": res["input_sets"], "one_launch_at_a_time": res["serial"]}
-        del res
-        torch.cuda.empty_cache()
+        if args.others == "default":
+            # every BASELINE config at its own shape (noise, full W x H), then SURVEY 8(d)'s variants: the other three
+            # inputs on the metric's shape and aspect + padding on every workload
+            todo = [(n, "noise", False) for n in WORKLOADS if n != args.workload or args.input != "noise" or args.aspect]
+            todo += [(args.workload, k, False) for k in INPUT_KINDS if k != "noise"]
+            todo += [(n, "noise", True) for n in WORKLOADS]
+        else:
+            todo = [(n, "noise", False) for n in args.others.split(",") if n and n != args.workload]
+        for name, kind, aspect in todo:
+            big = WORKLOADS[name][0] > 3000
+            b = 1 if name == "640x480_80x24_mono" else args.batch  # K1 is a single frame (configs[0])
+            r = run_workload(torch, pkg, name, b, 40 if not big else 20, 8, 5, None,
+                             input_sets=2 if big else args.input_sets, streams=args.streams if b > 1 else 1, kind=kind,
+                             aspect=aspect, serial_leg=(not args.no_hot) and kind == "noise" and not aspect)
+            key = name + ("" if kind == "noise" else f"+{kind}") + ("+aspect_pad" if aspect else "")
+            others[key] = summarize(r)
+            free_workload(torch, r)
         if args.others:
-            others["grid9_1080p_160x48_truecolor"] = run_grid9(torch, pkg, max(10, args.steps // 10), 3)
+            others["grid9_1080p_160x48_truecolor"] = run_grid9(torch, pkg, 20, 5)
         line["other_workloads"] = others
+    else:
+        free_workload(torch, res)
     if rank == 0:
         print(json.dumps(line))
     if dist is not None:

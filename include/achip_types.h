@@ -69,8 +69,9 @@ typedef struct {
   achip_frame_t f;
   int64_t src_pitch;
   uint32_t enabled;
-  uint32_t _pad;
+  uint32_t flags; /* ACHIP_UNIFORM_*: launch-wide facts that travel with the kernel arguments even when enabled == 0 */
 } achip_uniform_t;
+#define ACHIP_UNIFORM_PALETTE_ASCII 1u /* every glyph of the launch's palette is a single byte < 0x80 */
 
 /* achip_frame_t.ops: the client display path flips the frame and applies a monochrome tint on full-frame
  * copies before rendering (src/common/session/display.c:546-623, lib/video/rgba/color_filter.c:246-345).

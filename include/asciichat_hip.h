@@ -105,6 +105,32 @@ int asciichat_hip_plan_render_range(asciichat_hip_plan_t *plan, int first, int c
 int asciichat_hip_plan_render_profiled(asciichat_hip_plan_t *plan, uint8_t *out_dev, size_t out_stride,
                                        uint32_t *out_len_dev, unsigned long long *phase_cycles_dev, void *stream);
 
+/*
+ * Issue n_steps launches from C: step k (k = first_step .. first_step + n_steps - 1) renders plans[k % n_plans] on
+ * streams[k % n_streams] into out_dev[k % n_streams] / out_len_dev[k % n_streams].  n_plans must be a multiple of
+ * n_streams so that a plan always runs on the same stream (launches of one plan must be ordered).  This is the
+ * tick loop of a server with several independent client batches -- one FFI call instead of one per launch.
+ * Asynchronous; asciichat_hip_streams_wait() spins (no driver sleep) until the given streams have drained.
+ */
+int asciichat_hip_render_many(asciichat_hip_plan_t *const *plans, int n_plans, uint8_t *const *out_dev,
+                              uint32_t *const *out_len_dev, size_t out_stride, void *const *streams, int n_streams,
+                              int first_step, int n_steps);
+int asciichat_hip_streams_wait(void *const *streams, int n_streams);
+
+/*
+ * The same tick loop captured ONCE into a HIP graph with n_lanes parallel branches (lane l renders into out_dev[l] /
+ * out_len_dev[l], step k runs on lane k % n_lanes) and replayed with one graph launch on `stream`.  For a server whose
+ * set of client batches is stable from tick to tick this removes the per-launch host cost and the wake-up of n_lanes
+ * idle queues that a short burst of launches pays.  Plans must render whole frames (batches of >= 3/4 frame per CU, or
+ * set_split(plan, -1)); they must not be updated or rendered elsewhere while a replay is in flight.
+ */
+typedef struct asciichat_hip_schedule asciichat_hip_schedule_t;
+int asciichat_hip_schedule_create(asciichat_hip_schedule_t **sched, asciichat_hip_plan_t *const *plans, int n_plans,
+                                  uint8_t *const *out_dev, uint32_t *const *out_len_dev, size_t out_stride, int n_lanes,
+                                  int first_step, int n_steps);
+int asciichat_hip_schedule_launch(asciichat_hip_schedule_t *sched, void *stream);
+void asciichat_hip_schedule_destroy(asciichat_hip_schedule_t *sched);
+
 void asciichat_hip_plan_destroy(asciichat_hip_plan_t *plan);
 
 /* image_resize on device memory: nearest-neighbour, lib/video/rgba/image.c:267-328 */

@@ -17,12 +17,14 @@ def main():
     torch.cuda.set_device(0)
     name = sys.argv[1] if len(sys.argv) > 1 else "1080p_80x24_truecolor"
     sw, sh, W, H, cl, rm = bench.WORKLOADS[name]
-    nsets = 8
+    nsets = int(os.environ.get("OVERLAP_NSETS", "12"))
     sets = [bench.make_frames(torch, 256, sw, sh, 300 + s) for s in range(nsets)]
     steps = 480 if sw < 3000 else 120
     big_too = len(sys.argv) > 2
-    for variant in (4, 1, 2):
-        for nstreams in (1, 2, 3, 4, 6):
+    variants = [int(v) for v in os.environ.get("OVERLAP_VARIANTS", "4,1,2").split(",")]
+    stream_counts = [int(v) for v in os.environ.get("OVERLAP_STREAMS", "1,2,3,4,6").split(",")]
+    for variant in variants:
+        for nstreams in stream_counts:
             plans = [bench.build_plan(pkg, t, W, H, cl, rm)[0] for t in sets]
             try:
                 for p in plans:
@@ -33,28 +35,28 @@ def main():
             outs = [torch.empty(256 * plans[0].stride, dtype=torch.uint8, device="cuda") for _ in range(nstreams)]
             lns = [torch.zeros(256, dtype=torch.int32, device="cuda") for _ in range(nstreams)]
 
-            def run(k):
-                s = k % nstreams
-                plans[k % nsets].render(outs[s].data_ptr(), plans[0].stride, lns[s].data_ptr(), streams[s].cuda_stream)
-
-            for k in range(48):
-                run(k)
+            sched = pkg.Schedule(plans, [o.data_ptr() for o in outs], [l.data_ptr() for l in lns], plans[0].stride,
+                                 [st.cuda_stream for st in streams])
+            sched.issue(0, 48)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for st in streams:
                 st.wait_event(e0)
-            for k in range(steps):
-                run(k)
+            import time
+            t0 = time.perf_counter()
+            sched.issue(0, steps)  # the K launches are issued from C (asciichat_hip_render_many)
+            t_issue = time.perf_counter() - t0
             for st in streams:
                 e = torch.cuda.Event()
                 e.record(st)
                 torch.cuda.current_stream().wait_event(e)
             e1.record()
             torch.cuda.synchronize()
+            t_wall = time.perf_counter() - t0
             us = e0.elapsed_time(e1) * 1000 / steps
-            print(f"{name} variant {variant} streams {nstreams}: {us:7.2f} us per 256-frame step ({256 / us:6.2f} M frames/s)",
-                  flush=True)
+            print(f"{name} variant {variant} streams {nstreams}: {us:7.2f} us per 256-frame step ({256 / us:6.2f} M frames/s)"
+                  f"  [host issue {t_issue * 1e6 / steps:5.2f} us/launch, wall {t_wall * 1e6 / steps:6.2f} us/step]", flush=True)
             for p in plans:
                 p.close()
     # one launch of 512 / 1024 frames (what a server with more clients would submit)

@@ -1,0 +1,55 @@
+"""Per-wave timeline of the stream kernel (render_stream.hpp, diagnostics stamps): one 256-frame launch at a time,
+fresh input batch per launch.  Prints, per stamp, the distribution over all waves of (stamp - earliest kernel entry)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from __graft_entry__ import load_package  # noqa: E402
+
+NAMES = ["entry", "barrier passed (after request)", "samples requested", "samples arrived", "tokens+scan", "look-back",
+         "token bytes in LDS", "stores issued"]
+
+
+def main():
+    pkg = load_package()
+    torch.cuda.set_device(0)
+    name = sys.argv[1] if len(sys.argv) > 1 else "1080p_80x24_truecolor"
+    variant = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+    sw, sh, W, H, cl, rm = bench.WORKLOADS[name]
+    sets = [bench.make_frames(torch, 256, sw, sh, 900 + s) for s in range(6)]
+    plans = [bench.build_plan(pkg, t, W, H, cl, rm)[0] for t in sets]
+    for p in plans:
+        p.set_variant(variant)
+    waves = pkg.lib().achip_variant_block(variant) // 64
+    out = torch.empty(256 * plans[0].stride, dtype=torch.uint8, device="cuda")
+    ln = torch.zeros(256, dtype=torch.int32, device="cuda")
+    prof = torch.zeros(256 * waves * 8, dtype=torch.int64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    acc = []
+    for k in range(12):
+        prof.zero_()
+        torch.cuda.synchronize()
+        plans[k % len(plans)].render_profiled(out.data_ptr(), plans[0].stride, ln.data_ptr(), prof.data_ptr(), st)
+        torch.cuda.synchronize()
+        if k >= 4:
+            acc.append(prof.cpu().numpy().reshape(256, waves, 8).astype(np.int64))
+    print(f"# {name} variant {variant}: {waves} waves per frame, 100 MHz wall clock -> us; per stamp over all active waves of 8 launches")
+    print(f"# {'stamp':28s} {'min':>7s} {'p10':>7s} {'median':>7s} {'p90':>7s} {'max':>7s}")
+    rows = [[] for _ in range(8)]
+    for a in acc:
+        active = a[:, :, 7] != 0
+        t0 = a[:, :, 0][a[:, :, 0] != 0].min()
+        for s in range(8):
+            v = a[:, :, s][active]
+            rows[s].append((v - t0) / 100.0)
+    for s in range(8):
+        v = np.concatenate(rows[s])
+        print(f"  {NAMES[s]:28s} {v.min():7.2f} {np.percentile(v, 10):7.2f} {np.median(v):7.2f} {np.percentile(v, 90):7.2f} {v.max():7.2f}")
+
+
+if __name__ == "__main__":
+    main()

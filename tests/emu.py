@@ -18,7 +18,7 @@ _lib = None
 
 def build():
     srcs = [os.path.join(EMU_DIR, "emu_driver.cpp"), os.path.join(EMU_DIR, "hip_emu.h"),
-            os.path.join(CSRC, "render_kernels.hpp"), os.path.join(CSRC, "stream_kernels.hpp"), os.path.join(CSRC, "crc_kernels.hpp"),
+            os.path.join(CSRC, "render_kernels.hpp"), os.path.join(CSRC, "render_stream.hpp"), os.path.join(CSRC, "stream_kernels.hpp"), os.path.join(CSRC, "crc_kernels.hpp"),
             os.path.join(CSRC, "render_variants.h"),
             os.path.join(INC, "achip_types.h"), os.path.join(CSRC, "achip_host.c"), os.path.join(INC, "achip_host.h")]
     if os.path.exists(EMU_SO) and all(os.path.getmtime(s) <= os.path.getmtime(EMU_SO) for s in srcs):

@@ -3,7 +3,10 @@
  * emulator.  TESTS ONLY; built by tests/emu.py with g++ -DACHIP_HIPEMU.
  */
 #define ACHIP_HIPEMU 1
-#include "render_kernels.hpp"
+#ifndef ACHIP_TEST_GEOMETRY
+#define ACHIP_TEST_GEOMETRY 1 /* the tiny stream geometry exists in emulator builds only */
+#endif
+#include "render_stream.hpp"
 #include "render_variants.h"
 #include "achip_host.h"
 
@@ -68,8 +71,46 @@ static int by_mode(int mode, const achip_frame_t *frames, int n, const achip_lut
   return -1;
 }
 
+/* the stream kernel (render_stream.hpp): per-cell modes, whole frames */
+template <int MODE, int WAVES, int CPL>
+static void run_stream(const achip_frame_t *frames, int n, const achip_lut_t *lut, uint8_t *out, uint64_t stride,
+                       uint32_t *len) {
+  using L = achip::SLds<MODE, WAVES, CPL>;
+  achip_uniform_t uni = {};
+  if (g_uniform)
+    (void)achip_frames_uniform(frames, n, &uni);
+  uni.flags = (lut->flags & ACHIP_LUT_MULTIBYTE) ? 0u : ACHIP_UNIFORM_PALETTE_ASCII; /* what plan.c / dropin.c pass */
+  hipemu::launch(dim3((unsigned)n), dim3(WAVES * 64), (size_t)L::bytes, [&] {
+    achip::render_stream_kernel<MODE, WAVES, CPL, true>(frames, lut, out, stride, len, n, uni, nullptr);
+  });
+}
+template <int WAVES, int CPL>
+static int stream_by_mode(int mode, const achip_frame_t *frames, int n, const achip_lut_t *lut, uint8_t *out,
+                          uint64_t stride, uint32_t *len) {
+  switch (mode) {
+#define M(m)                                                                                                           \
+  case m:                                                                                                              \
+    run_stream<m, WAVES, CPL>(frames, n, lut, out, stride, len);                                                       \
+    return 0;
+    M(ACHIP_MODE_TRUE_FG)
+    M(ACHIP_MODE_256_FG)
+    M(ACHIP_MODE_16_FG)
+    M(ACHIP_MODE_TRUE_BG)
+#undef M
+  }
+  return -1;
+}
+
 extern "C" int emu_render_batch(int mode, int variant, const achip_frame_t *frames, int n, const achip_lut_t *lut,
                                 uint8_t *out, uint64_t stride, uint32_t *len) {
+  if (g_parts == 1)
+    switch (variant) {
+#define X(id, W, C)                                                                                                    \
+  case id:                                                                                                             \
+    return stream_by_mode<W, C>(mode, frames, n, lut, out, stride, len);
+      ACHIP_STREAM_VARIANTS(X)
+#undef X
+    }
   switch (variant) {
 #define X(id, B, C, R)                                                                                                 \
   case id:                                                                                                             \

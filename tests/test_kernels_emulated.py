@@ -204,3 +204,72 @@ def test_tall_padding_crosses_threads_groups():
         f = emu.frame_for_convert(img, W, H, rm, True, True)
         for variant in (4, 3):
             assert emu.render_frames(mode, [f], "@", variant)[0] == exp, (W, H, mode, variant)
+
+
+# --------------------------------------------------------------------------------------------------------------- #
+# the wave-autonomous stream kernel (render_stream.hpp): per-cell modes, whole frames.  Geometry 20 (2 waves x 1    #
+# cell per lane, emulator builds only) cuts every frame into many 64-cell blocks, so look-back windows, the         #
+# request-ahead loop and blocks that straddle rows all run on small inputs; 16 / 17 / 19 are product geometries.    #
+# --------------------------------------------------------------------------------------------------------------- #
+STREAM_MODES = [MODE_TRUE_FG, MODE_256_FG, MODE_16_FG, MODE_TRUE_BG]
+
+
+@pytest.mark.parametrize("mode", STREAM_MODES, ids=["true_fg", "256_fg", "16_fg", "true_bg"])
+@pytest.mark.parametrize("variant", [20, 16, 17, 19])
+def test_stream_kernel_torture(mode, variant):
+    for (W, H) in [(80, 24), (97, 31), (3, 2), (1, 1), (64, 1), (65, 3)]:
+        exp = oracle_convert(TORTURE, mode, W, H, orc.PALETTE_STANDARD)
+        got = emu_convert(TORTURE, mode, W, H, orc.PALETTE_STANDARD, variant)
+        assert got == exp, (MODE_NAMES[mode], W, H, variant)
+
+
+@pytest.mark.parametrize("mode", [MODE_TRUE_FG, MODE_256_FG, MODE_16_FG], ids=["true_fg", "256_fg", "16_fg"])
+def test_stream_kernel_aspect_padding_and_many_blocks(mode):
+    # left / top padding (the raster predecessor of a row's first pixel sits pad_left cells back) and a frame of
+    # 200x60 = 188 blocks in geometry 20: look-back windows beyond 64 predecessors
+    for (W, H, variant) in [(80, 24, 20), (97, 31, 17), (60, 40, 20), (200, 60, 20), (200, 60, 16)]:
+        exp = oracle_convert(TORTURE, mode, W, H, orc.PALETTE_STANDARD, True, True)
+        got = emu_convert(TORTURE, mode, W, H, orc.PALETTE_STANDARD, variant, True, True)
+        assert got == exp, (MODE_NAMES[mode], W, H, variant)
+
+
+@pytest.mark.parametrize("palette", [orc.PALETTE_BLOCKS, orc.PALETTE_COOL, "ab", "x", "é漢😀 ."],
+                         ids=["blocks", "cool", "ab", "x", "mixed"])
+def test_stream_kernel_palettes(palette):
+    # multi-byte glyphs in the per-cell modes that allow them (truecolor-fg with such a palette stays on the phase
+    # kernel: the stream kernel must refuse it)
+    for mode in (MODE_256_FG, MODE_16_FG, MODE_TRUE_BG):
+        exp = oracle_convert(TORTURE, mode, 61, 17, palette)
+        assert emu_convert(TORTURE, mode, 61, 17, palette, 20) == exp, (MODE_NAMES[mode], palette)
+    ascii_only = all(ord(c) < 128 for c in palette)
+    got = emu_convert(TORTURE, MODE_TRUE_FG, 61, 17, palette, 20)
+    if ascii_only:
+        assert got == oracle_convert(TORTURE, MODE_TRUE_FG, 61, 17, palette)
+    else:
+        assert got == 0xFFFFFFFE  # ACHIP_LEN_BADDESC
+
+
+def test_stream_kernel_ragged_batch_flips_tint_and_overflow():
+    import ctypes as C
+    imgs = [orc.frame_hash_noise(120, 90, i) for i in range(5)] + [orc.frame_bars(64, 48, 3), orc.frame_smooth(33, 17)]
+    dims = [(80, 24), (60, 7), (33, 40), (80, 1), (1, 50), (17, 9), (128, 2)]
+    frames = [emu.frame_for_convert(im, w, h, 0) for im, (w, h) in zip(imgs, dims)]
+    for mode in (MODE_TRUE_FG, MODE_256_FG):
+        for variant in (20, 17):
+            got = emu.render_frames(mode, frames, orc.PALETTE_STANDARD, variant)
+            for k, (im, (w, h)) in enumerate(zip(imgs, dims)):
+                assert got[k] == oracle_convert(im, mode, w, h, orc.PALETTE_STANDARD), (mode, variant, k)
+            uni = emu.render_frames(mode, [frames[0]] * 3, orc.PALETTE_STANDARD, variant, uniform=True)
+            assert uni[0] == uni[1] == uni[2] == got[0]
+    # the display path's flips and colour filter folded into the sampler, checked against the oracle's
+    # full-frame passes
+    img = imgs[0]
+    for fx, fy, flt in [(True, False, 0), (False, True, 3), (True, True, 7)]:
+        f = emu.frame_for_convert(img, 80, 24, 0)
+        assert emu.lib().achip_frame_set_display_ops(C.byref(f), fx, fy, flt) == 0
+        exp = orc.display_convert(img, 80, 24, 3, 0, False, False, fx, fy, flt)
+        assert emu.render_frames(MODE_TRUE_FG, [f], orc.PALETTE_STANDARD, 20)[0] == exp, (fx, fy, flt)
+    # a slot that is too small reports ACHIP_LEN_OVERFLOW (and nothing is written past it)
+    f = emu.frame_for_convert(img, 80, 24, 0)
+    got = emu.render_frames(MODE_TRUE_FG, [f], orc.PALETTE_STANDARD, 20, stride=1024)
+    assert got[0] == 0xFFFFFFFF

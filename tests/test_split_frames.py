@@ -61,18 +61,27 @@ def test_split_ragged_batch_and_policy():
     assert choose(1, one * 64) == (4, 4, 6)                   # 64 frames on 256 CUs: 4 bands each
     assert choose(1, one * 128) == (4, 2, 12)
     assert choose(1, one * 150) == (2, 2, 12)                 # more bands than CUs: the geometry that fits a band
-    assert choose(1, one * 256) == (4, 1, 24)                 # BASELINE batch = one frame per CU: whole frames
-    assert choose(1, one * 600) == (1, 1, 24)                 # many frames: whole frames, 512-thread workgroups
-    assert choose(1, one * 256, cus=256 // 3) == (1, 1, 24)   # ... or three launches in flight sharing the CUs
-    assert choose(1, one * 256, cus=256 // 2) == (1, 1, 24)
+    # whole-frame launches of the per-cell modes take the stream kernel (render_stream.hpp): 1024 threads while every
+    # frame has a CU to itself, 512-thread workgroups beyond that
+    assert choose(1, one * 256) == (16, 1, 24)                # BASELINE batch = one frame per CU: whole frames
+    assert choose(1, one * 600) == (17, 1, 24)                # many frames: whole frames, 512-thread workgroups
+    assert choose(1, one * 256, cus=256 // 3) == (17, 1, 24)  # ... or several launches in flight sharing the CUs
+    assert choose(1, one * 256, cus=256 // 4) == (17, 1, 24)
+    assert choose(2, one * 256) == (16, 1, 24) and choose(3, one * 256) == (16, 1, 24) and choose(4, one * 300) == (17, 1, 24)
+    assert choose(0, one * 256) == (4, 1, 24)                 # run-structured modes stay on the phase kernel
+    assert choose(0, one * 600) == (1, 1, 24)
+    assert choose(1, one * 256, ascii_only=False) == (4, 1, 24)  # truecolor-fg with multi-byte glyphs too
+    assert choose(1, one * 256, forced=4) == (4, 1, 24) and choose(1, one * 256, forced=19) == (19, 1, 24)
     assert choose(5, [emu.frame_for_convert(imgs[0], 80, 24, 2)] * 600) == (4, 1, 24)  # half-block: never the small geometries
     assert choose(9, one) == (4, 1, 24)                       # serial dither: never split
     assert choose(1, one, ascii_only=False) == (4, 1, 24)     # truecolor-fg with multi-byte glyphs: never split
     assert choose(2, one, ascii_only=False) == (4, 24, 1)
-    assert choose(1, one, req=-1) == (4, 1, 24)
+    assert choose(1, one, req=-1) == (16, 1, 24)             # never split: one whole frame -> stream kernel
     assert choose(1, one, req=12) == (4, 2, 12)
     assert choose(1, one, req=3, forced=2) == (2, 8, 3)
     assert choose(1, one, forced=1, req=-1) == (1, 1, 24)
+    k3w = [emu.frame_for_convert(imgs[0], 200, 60, 0)]
+    assert choose(1, k3w * 256) == (17, 1, 60)                # several blocks per wave: 512-thread workgroups
     k3 = [emu.frame_for_convert(imgs[0], 200, 60, 0)]
     assert choose(1, k3 * 64) == (1, 6, 10)                   # bands limited by the 2048-cell chunk
     k5 = [emu.frame_for_convert(imgs[0], 400, 120, 2)]        # half-block: 120 text rows of 400 cells
