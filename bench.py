@@ -8,9 +8,12 @@ other configs).  One process per GPU; frames are independent, so N > 1 shards th
 data-path collective (weak scaling: 256 frames per rank and step).
 
 Protocol (VERDICT r1 "next round" 1-2):
-  * the K steps of a timed region are issued from C (asciichat_hip_render_many) round-robin over `--streams`
-    independent batches on separate HIP streams -- the reference's model is one render thread per client
+  * the K steps of a timed region are issued from C (asciichat_hip_render_many) round-robin over S independent
+    batches on separate HIP streams -- the reference's model is one render thread per client
     (src/server/render.c:1233) -- and drained with a spin wait; barrier + torch.cuda.synchronize() on both sides;
+    S (`--streams`, default 0 = automatic) is picked for the burst length K in an untimed calibration: a queue that
+    went idle at the synchronize takes ~20 us to wake up, so short regions want fewer launches in flight than the
+    steady state does (profiles/r02_region_overhead.txt); the calibration's numbers are in the line;
   * the region is repeated (>= 5 times) and the MEDIAN region gives `value` / `ms_per_step`, so that a 20-step region
     reports the same figure as a 200-step one;
   * a fresh input batch every step (12 batches rotate: no step re-reads the previous step's frames out of the 256 MB
@@ -94,6 +97,9 @@ def build_plan(pkg, frames_t, W, H, cl, rm, aspect=False):
     return pkg.Plan(mode, PALETTE_STANDARD, descs), mode
 
 
+_LANE_POOL = []
+
+
 class Runner:
     """P plans (independent input batches) rendered round-robin on S streams through asciichat_hip_render_many."""
 
@@ -101,7 +107,12 @@ class Runner:
         self.torch, self.pkg, self.plans, self.batch = torch, pkg, plans, batch
         self.S = streams
         self.cur = torch.cuda.current_stream()
-        self.lanes = [self.cur] + [torch.cuda.Stream() for _ in range(streams - 1)]
+        # ONE pool of streams for the whole process: HIP maps streams onto a handful of hardware queues round-robin, so
+        # every extra stream object ever created shifts the mapping and two "independent" lanes can end up sharing a
+        # queue (measured: 8.7 -> 10.8 us per step after a calibration pass had created its own streams)
+        while len(_LANE_POOL) < streams - 1:
+            _LANE_POOL.append(torch.cuda.Stream())
+        self.lanes = [self.cur] + _LANE_POOL[:streams - 1]
         self.stride = plans[0].stride
         self.outs = [torch.empty(batch * self.stride, dtype=torch.uint8, device="cuda") for _ in range(streams)]
         self.lns = [torch.zeros(batch, dtype=torch.int32, device="cuda") for _ in range(streams)]
@@ -169,10 +180,10 @@ def verify_against_oracle(torch, pkg, plan, frames_t, W, H, cl, rm, aspect, n_ch
     return {"frames_checked": len(idx), "byte_identical_to_oracle": True}, lens
 
 
-def run_workload(torch, pkg, name, batch, steps, warmup, regions, dist=None, seed=1234, variant=-1, input_sets=3,
-                 streams=4, kind="noise", aspect=False, serial_leg=True, verify=True):
+def run_workload(torch, pkg, name, batch, steps, warmup, regions, dist=None, seed=1234, variant=-1, nsets=12,
+                 streams=4, kind="noise", aspect=False, serial_leg=True, verify=True, streams_auto=None):
     sw, sh, W, H, cl, rm = WORKLOADS[name]
-    nsets = input_sets * streams
+    assert nsets % streams == 0 and all(nsets % c == 0 for c in (streams_auto or ()))
     sets = [make_frames(torch, batch, sw, sh, seed + 7919 * s, kind) for s in range(nsets)]
     plans = []
     for t in sets:
@@ -181,6 +192,26 @@ def run_workload(torch, pkg, name, batch, steps, warmup, regions, dist=None, see
         if variant >= 0:
             plan.set_variant(variant)
         plans.append(plan)
+    tune = None
+    if streams_auto and batch > 1:
+        # launches in flight for THIS burst length: a queue that has gone idle takes ~20 us to wake up, so a short
+        # region is better served by fewer streams than the steady state is (profiles/r02_region_overhead.txt)
+        tune = {}
+        for cand in streams_auto:
+            for plan in plans:
+                plan.set_concurrency(cand)
+                if variant >= 0:
+                    plan.set_variant(variant)
+            r = Runner(torch, pkg, plans, batch, cand)
+            r.issue(24)
+            torch.cuda.synchronize()
+            tune[cand] = statistics.median(r.region(steps, None) for _ in range(9)) / steps * 1e3
+            r.sched.close()
+        streams = min(tune, key=tune.get)
+        for plan in plans:
+            plan.set_concurrency(streams)
+            if variant >= 0:
+                plan.set_variant(variant)
     run = Runner(torch, pkg, plans, batch, streams)
     ver, lens = (verify_against_oracle(torch, pkg, plans[0], sets[0], W, H, cl, rm, aspect) if verify
                  else (None, None))
@@ -205,7 +236,7 @@ def run_workload(torch, pkg, name, batch, steps, warmup, regions, dist=None, see
     alg_bytes = int(out_mean) + batch * 3 * cells_px
     res = dict(name=name, mode=pkg.MODE_NAMES[mode], batch=batch, walls=walls, steps=steps, gpu_ms=gpu_ms,
                out_bytes_per_frame=out_mean / batch, alg_bytes_per_launch=alg_bytes, variant=plans[0].variant,
-               input_sets=nsets, streams=streams, kind=kind, aspect=aspect, verify=ver,
+               input_sets=nsets, streams=streams, kind=kind, aspect=aspect, verify=ver, streams_autotune=tune,
                cells_per_frame=(f0.pad_left + f0.out_w) * ((f0.out_h + 1) // 2 if rm == 2 else f0.out_h),
                serial=None, plans=plans, sets=sets)
     if serial_leg:
@@ -242,6 +273,8 @@ def summarize(res, world=1, wall=None):
          "output_GBps": res["out_bytes_per_frame"] * fps / 1e9, "cells_per_s": res["cells_per_frame"] * fps,
          "roofline_GBps": a, "roofline_frac": a / HBM_PEAK_GBS, "kernel_variant": res["variant"],
          "input_sets": res["input_sets"], "verify": res["verify"]}
+    if res.get("streams_autotune"):
+        d["launches_in_flight_autotune_ms_per_step"] = {str(k): v for k, v in res["streams_autotune"].items()}
     if res["serial"] is not None:
         d["one_launch_at_a_time"] = res["serial"]
     return d
@@ -381,10 +414,11 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-d2h", action="store_true", help="skip the PCIe-inclusive with_d2h leg (profiling runs)")
     ap.add_argument("--variant", type=int, default=-1)
-    ap.add_argument("--input-sets", type=int, default=3,
-                    help="independent batches of source frames per stream, rendered round-robin")
-    ap.add_argument("--streams", type=int, default=4,
-                    help="independent batches kept in flight on separate HIP streams (1 = one launch at a time)")
+    ap.add_argument("--input-sets", type=int, default=12,
+                    help="independent batches of source frames rendered round-robin (a multiple of every stream count tried)")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="independent batches kept in flight on separate HIP streams; 0 = pick the best of 1 / 2 / 3 / 4 for "
+                         "the requested burst length (--steps) in an untimed calibration; 1 = one launch at a time")
     ap.add_argument("--no-hot", action="store_true",
                     help="skip the one-launch-at-a-time / same-batch comparison legs (profiling runs)")
     args = ap.parse_args()
@@ -417,8 +451,9 @@ def main():
         dist = d
 
     res = run_workload(torch, pkg, args.workload, args.batch, args.steps, args.warmup, regions, dist, seed=1234 + rank,
-                       variant=args.variant, input_sets=args.input_sets, streams=args.streams, kind=args.input,
-                       aspect=args.aspect, serial_leg=not args.no_hot)
+                       variant=args.variant, nsets=args.input_sets, streams=args.streams or 4, kind=args.input,
+                       aspect=args.aspect, serial_leg=not args.no_hot,
+                       streams_auto=(1, 2, 3, 4) if args.streams == 0 and world == 1 else None)
     walls = res["walls"]
     if dist is not None:  # MAX over ranks of every region's wall time
         t = torch.tensor(walls, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
@@ -443,11 +478,11 @@ def main():
                    "aspect_and_padding": args.aspect,
                    "parallelism": f"frames sharded over {world} rank(s), no data-path collective",
                    "kernel_variant": res["variant"], "input_sets": res["input_sets"],
-                   "launches_in_flight": args.streams},
+                   "launches_in_flight": res["streams"]},
         "roofline": {"bound": "hbm", "achieved": main_d["roofline_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": main_d["roofline_frac"], "traffic": None,
                      "alg_bytes_per_launch": res["alg_bytes_per_launch"], "kernel_ms": res["gpu_ms"],
-                     "launches_in_flight": args.streams, "out_bytes_per_frame": res["out_bytes_per_frame"],
+                     "launches_in_flight": res["streams"], "out_bytes_per_frame": res["out_bytes_per_frame"],
                      "kernel_ms_note": "GPU time per step (HIP events on the launch streams, first begin -> last end of a "
                                        "back-to-back run of the same schedule); with launches overlapping this is what "
                                        "one launch costs, not one dispatch's begin-to-end duration",
@@ -455,6 +490,8 @@ def main():
                                      "committed_profile (if present) for the committed figure and its source"},
         "output_GBps": main_d["output_GBps"], "cells_per_s": main_d["cells_per_s"], "verify": res["verify"],
     }
+    if res.get("streams_autotune"):
+        line["timing"]["launches_in_flight_autotune_ms_per_step"] = {str(k): v for k, v in res["streams_autotune"].items()}
     if res["serial"] is not None:
         line["one_launch_at_a_time"] = res["serial"]
     cp = committed_profile(args.workload)
@@ -481,9 +518,11 @@ def main():
         for name, kind, aspect in todo:
             big = WORKLOADS[name][0] > 3000
             b = 1 if name == "640x480_80x24_mono" else args.batch  # K1 is a single frame (configs[0])
+            t_w = time.perf_counter()
             r = run_workload(torch, pkg, name, b, 40 if not big else 20, 8, 5, None,
-                             input_sets=2 if big else args.input_sets, streams=args.streams if b > 1 else 1, kind=kind,
+                             nsets=4 if big else 12, streams=(args.streams or 4) if b > 1 else 1, kind=kind,
                              aspect=aspect, serial_leg=(not args.no_hot) and kind == "noise" and not aspect)
+            print(f"[bench] {name} {kind} aspect={aspect}: {time.perf_counter() - t_w:.1f} s", file=sys.stderr)
             key = name + ("" if kind == "noise" else f"+{kind}") + ("+aspect_pad" if aspect else "")
             others[key] = summarize(r)
             free_workload(torch, r)
