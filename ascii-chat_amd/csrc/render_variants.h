@@ -8,15 +8,20 @@
 #ifndef ACHIP_RENDER_VARIANTS_H
 #define ACHIP_RENDER_VARIANTS_H
 
+#ifdef ACHIP_TEST_GEOMETRY /* emulator builds only (tests/hipemu): forces multi-chunk frames and window cuts on tiny inputs */
+#define ACHIP_TEST_VARIANT(X) X(3, 64, 256, 256)
+#else
+#define ACHIP_TEST_VARIANT(X)
+#endif
 #define ACHIP_VARIANTS(X)                                                                                         \
   X(0, 1024, 4096, 65536) /* wide: any row up to 4096 cells, 1 workgroup per CU                                */ \
   X(1, 512, 2048, 32768)  /* narrow: rows up to 2048 cells, 2-3 workgroups per CU                               */ \
   X(2, 256, 1024, 16384)  /* small grids (<= 1024-cell rows): 4+ workgroups per CU                              */ \
-  X(3, 64, 256, 256)      /* test geometry: forces multi-chunk frames and ring wrap-around on tiny inputs      */ \
+  ACHIP_TEST_VARIANT(X)   /* id 3 does not exist in the product library                                         */ \
   X(4, 1024, 2048, 114688) /* rows up to 2048 cells, 2 cells per thread (no spills); 112 KB staging: one window per
                               chunk even for 41-byte half-block tokens; with the other tables ~132-156 KB of the 160 KB LDS */
 
-#define ACHIP_VARIANT_COUNT 5
+#define ACHIP_VARIANT_COUNT 5 /* ids 0..4 (3 = the emulator's test geometry, absent from the product) */
 
 /* Geometries of the wave-autonomous stream kernel (render_stream.hpp; per-cell modes, whole-frame launches):
  *   WAVES  waves per workgroup (one workgroup renders one frame)

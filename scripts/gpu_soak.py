@@ -66,7 +66,7 @@ def main():
             elif choice == 2:
                 plan.set_split(int(rng.integers(1, 9)))
             elif choice == 3:
-                plan.set_variant(int(rng.choice([0, 1, 2, 3, 4])))
+                plan.set_variant(int(rng.choice([0, 1, 2, 4])))
             elif choice == 4:
                 plan.set_variant(int(rng.choice([1, 2, 4])))
                 plan.set_split(int(rng.integers(1, 6)))

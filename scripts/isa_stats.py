@@ -1,0 +1,126 @@
+#!/usr/bin/env python3
+"""Occupancy / spill guard for the gfx950 code objects of libasciichat_hip.so.
+
+Extracts the device code objects from the built library, reads every kernel's AMDGPU metadata note (.vgpr_count,
+.sgpr_count, spill counts, LDS) and fails when a kernel leaves the register budget its launch geometry depends on:
+
+  * render_frames_kernel, 512- and 256-thread geometries, non-half-block modes: <= 128 VGPRs (two / four workgroups
+    per CU; at 130 only one 512-thread workgroup fits and the step time doubles) -- they are pinned there with
+    amdgpu_waves_per_eu(4), which the compiler pays for with a handful of spilled VGPRs: at most 24, else the pin
+    has stopped being cheap;
+  * render_stream_kernel: <= 64 VGPRs (two 1024-thread or four 512-thread workgroups per CU; the truecolor-background
+    mode, whose 48-byte tokens fill the LDS first, <= 72) and no scratch memory (SGPRs parked in VGPR lanes are fine);
+  * every other kernel: no VGPR spills.
+
+Usage: isa_stats.py [path/to/libasciichat_hip.so] [--out profiles/isa_stats.txt]   (exit status 1 on a violation)
+"""
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LLVM = "/opt/rocm/lib/llvm/bin"
+HALFBLOCK = {5, 6, 7, 8}
+
+
+def kernels_of(lib):
+    tmp = tempfile.mkdtemp(prefix="isa_stats_")
+    try:
+        local = os.path.join(tmp, "lib.so")
+        shutil.copy(lib, local)
+        subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", local], check=True, stdout=subprocess.DEVNULL,
+                       stderr=subprocess.DEVNULL)
+        out = []
+        for f in sorted(os.listdir(tmp)):
+            if "gfx950" not in f:
+                continue
+            notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", os.path.join(tmp, f)], check=True,
+                                   capture_output=True, text=True).stdout
+            cur = {}
+            for line in notes.splitlines():
+                m = re.match(r"\s*-?\s*\.(\w+):\s*(.*)$", line)
+                if not m:
+                    continue
+                k, v = m.group(1), m.group(2).strip().strip("'")
+                if k == "agpr_count" and cur.get("name"):  # first key of a kernel's map in the note
+                    out.append(cur)
+                    cur = {}
+                cur[k] = v
+            if cur.get("name"):
+                out.append(cur)
+        return [k for k in out if "vgpr_count" in k and k.get("name")]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def demangle(name):
+    try:
+        return subprocess.run([os.path.join(LLVM, "llvm-cxxfilt"), name], capture_output=True, text=True).stdout.strip() or name
+    except OSError:
+        return name
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    lib = args[0] if args else os.path.join(ROOT, "ascii-chat_amd", "libasciichat_hip.so")
+    out_path = None
+    if "--out" in sys.argv:
+        out_path = sys.argv[sys.argv.index("--out") + 1]
+        if out_path in args:
+            args.remove(out_path)
+            lib = args[0] if args else os.path.join(ROOT, "ascii-chat_amd", "libasciichat_hip.so")
+    rows, bad = [], []
+    for k in kernels_of(lib):
+        name = k["name"]
+        vg, sg = int(k["vgpr_count"]), int(k["sgpr_count"])
+        vs, ss = int(k.get("vgpr_spill_count", 0)), int(k.get("sgpr_spill_count", 0))
+        lds = int(k.get("group_segment_fixed_size", 0))
+        scratch = int(k.get("private_segment_fixed_size", 0))
+        limit, why = None, ""
+        m = re.search(r"render_frames_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb([01])ELb([01])E", name)
+        ms = re.search(r"render_stream_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb([01])E", name)
+        if m:
+            mode, block = int(m.group(1)), int(m.group(2))
+            short = f"render_frames_kernel<mode {mode}, {block} thr, cap {m.group(3)}, comp {m.group(5)}, split {m.group(6)}>"
+            if block in (256, 512) and mode not in HALFBLOCK:
+                limit, why = 128, "two (four) workgroups per CU"
+        elif ms:
+            mode, waves, cpl = int(ms.group(1)), int(ms.group(2)), int(ms.group(3))
+            short = f"render_stream_kernel<mode {mode}, {waves} waves, {cpl} cells/lane, generic {ms.group(4)}>"
+            limit, why = (72, "7 waves per SIMD") if mode == 4 else (64, "8 waves per SIMD")
+        else:
+            short = demangle(name).split("(")[0][-70:]
+        problems = []
+        if limit is not None and vg > limit:
+            problems.append(f"{vg} VGPRs > {limit} ({why})")
+        if m and limit is not None and vs > 24:
+            problems.append(f"{vs} VGPRs spilled (> 24)")
+        if not m and vs > 0:
+            problems.append(f"{vs} VGPRs spilled")
+        if ms and scratch > 0:
+            problems.append(f"{scratch} B scratch")
+        rows.append((short, vg, sg, vs, ss, scratch, lds, "; ".join(problems)))
+        if problems:
+            bad.append((short, problems))
+    rows.sort()
+    lines = [f"# gfx950 kernel resources of {os.path.relpath(lib, ROOT)} (scripts/isa_stats.py; llvm-readelf --notes)",
+             f"# {'kernel':92s} {'VGPR':>5s} {'SGPR':>5s} {'vspill':>6s} {'sspill':>6s} {'scratch':>7s} {'LDS':>7s}"]
+    for r in rows:
+        lines.append(f"  {r[0]:92s} {r[1]:5d} {r[2]:5d} {r[3]:6d} {r[4]:6d} {r[5]:7d} {r[6]:7d}  {r[7]}")
+    lines.append(f"# {len(rows)} kernels, {len(bad)} violation(s)")
+    text = "\n".join(lines) + "\n"
+    if out_path:
+        with open(out_path, "w") as f:
+            f.write(text)
+    else:
+        sys.stdout.write(text)
+    for short, problems in bad:
+        print(f"isa_stats: {short}: {', '.join(problems)}", file=sys.stderr)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
