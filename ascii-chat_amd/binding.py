@@ -123,6 +123,38 @@ def lib():
     L.asciichat_hip_render_many.argtypes = [C.POINTER(vp), ci, C.POINTER(vp), C.POINTER(vp), sz, C.POINTER(vp), ci, ci, ci]
     L.asciichat_hip_streams_wait.restype = ci
     L.asciichat_hip_streams_wait.argtypes = [C.POINTER(vp), ci]
+    L.asciichat_hip_comm_unique_id.restype = ci
+    L.asciichat_hip_comm_unique_id.argtypes = [vp, sz]
+    L.asciichat_hip_comm_init.restype = ci
+    L.asciichat_hip_comm_init.argtypes = [C.POINTER(vp), ci, ci, vp, sz]
+    L.asciichat_hip_comm_world.restype = ci
+    L.asciichat_hip_comm_world.argtypes = [vp]
+    L.asciichat_hip_comm_rank.restype = ci
+    L.asciichat_hip_comm_rank.argtypes = [vp]
+    L.asciichat_hip_comm_destroy.restype = None
+    L.asciichat_hip_comm_destroy.argtypes = [vp]
+    L.asciichat_hip_comm_all_gather.restype = ci
+    L.asciichat_hip_comm_all_gather.argtypes = [vp, vp, vp, sz, vp]
+    L.asciichat_hip_comm_all_gather_slab.restype = ci
+    L.asciichat_hip_comm_all_gather_slab.argtypes = [vp, vp, sz, vp, ci, vp]
+    L.achip_shard_bounds.restype = None
+    L.achip_shard_bounds.argtypes = [ci, ci, ci, C.POINTER(ci), C.POINTER(ci)]
+    L.achip_shard_owner.restype = ci
+    L.achip_shard_owner.argtypes = [ci, ci, ci]
+    L.achip_shard_slots.restype = ci
+    L.achip_shard_slots.argtypes = [ci, ci]
+    L.asciichat_hip_grid_create.restype = ci
+    L.asciichat_hip_grid_create.argtypes = [C.POINTER(vp), vp, C.POINTER(ci), C.POINTER(ci), C.c_char_p, ci, ci, ci]
+    L.asciichat_hip_grid_owner.restype = ci
+    L.asciichat_hip_grid_owner.argtypes = [vp, ci]
+    L.asciichat_hip_grid_exchange.restype = ci
+    L.asciichat_hip_grid_exchange.argtypes = [vp, C.POINTER(vp), vp]
+    L.asciichat_hip_grid_composite_dev.restype = vp
+    L.asciichat_hip_grid_composite_dev.argtypes = [vp]
+    L.asciichat_hip_grid_geometry.restype = C.POINTER(Composite)
+    L.asciichat_hip_grid_geometry.argtypes = [vp]
+    L.asciichat_hip_grid_destroy.restype = None
+    L.asciichat_hip_grid_destroy.argtypes = [vp]
     L.asciichat_hip_schedule_create.restype = ci
     L.asciichat_hip_schedule_create.argtypes = [C.POINTER(vp), C.POINTER(vp), ci, C.POINTER(vp), C.POINTER(vp), sz, ci, ci, ci]
     L.asciichat_hip_schedule_launch.restype = ci
@@ -381,6 +413,77 @@ class Schedule:
     def close(self):
         for h in self.__dict__.pop("_graphs", {}).values():
             lib().asciichat_hip_schedule_destroy(h)
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """128-byte RCCL unique id (rank 0 creates it, every rank passes it to Comm)."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    rc = lib().asciichat_hip_comm_unique_id(buf, COMM_ID_BYTES)
+    if rc != 0:
+        raise RuntimeError(f"comm_unique_id failed ({rc}): {last_error()}")
+    return buf.raw
+
+
+class Comm:
+    """RCCL communicator of the C-ABI (asciichat_hip_comm_*): one process per GPU."""
+
+    def __init__(self, world, rank, unique_id):
+        self._h = C.c_void_p()
+        rc = lib().asciichat_hip_comm_init(C.byref(self._h), world, rank, unique_id, len(unique_id))
+        if rc != 0:
+            raise RuntimeError(f"comm_init failed ({rc}): {last_error()}")
+        self.world, self.rank = world, rank
+
+    def all_gather(self, send_ptr, recv_ptr, bytes_per_rank, stream=0):
+        rc = lib().asciichat_hip_comm_all_gather(self._h, send_ptr, recv_ptr, bytes_per_rank, stream)
+        if rc != 0:
+            raise RuntimeError(f"comm_all_gather failed ({rc}): {last_error()}")
+
+    def all_gather_slab(self, slab_ptr, stride, len_ptr, slots_per_rank, stream=0):
+        rc = lib().asciichat_hip_comm_all_gather_slab(self._h, slab_ptr, stride, len_ptr, slots_per_rank, stream)
+        if rc != 0:
+            raise RuntimeError(f"comm_all_gather_slab failed ({rc}): {last_error()}")
+
+    def close(self):
+        if self._h:
+            lib().asciichat_hip_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+
+class Grid:
+    """The pixel-space grid across GPUs (asciichat_hip_grid_*): exchange() resizes the sources this rank owns into
+    their tiles and all-gathers the tiles; frames whose .comp = composite_dev then render the grid."""
+
+    def __init__(self, comm, src_dims, term_w, term_h, has_video=None):
+        n = len(src_dims)
+        self._h = C.c_void_p()
+        ws = (C.c_int * n)(*[d[0] for d in src_dims])
+        hs = (C.c_int * n)(*[d[1] for d in src_dims])
+        hv = bytes(1 if v else 0 for v in has_video) if has_video is not None else None
+        rc = lib().asciichat_hip_grid_create(C.byref(self._h), comm._h if comm else None, ws, hs, hv, n, term_w, term_h)
+        if rc != 0:
+            raise RuntimeError(f"grid_create failed ({rc}): {last_error()}")
+        self.n = n
+        self.composite_dev = lib().asciichat_hip_grid_composite_dev(self._h)
+        self.geometry = lib().asciichat_hip_grid_geometry(self._h).contents
+
+    def owner(self, source):
+        return lib().asciichat_hip_grid_owner(self._h, source)
+
+    def exchange(self, local_ptrs, stream=0):
+        """local_ptrs: {source index: device pointer} for the sources this rank owns"""
+        arr = (C.c_void_p * self.n)(*[local_ptrs.get(k) for k in range(self.n)])
+        rc = lib().asciichat_hip_grid_exchange(self._h, arr, stream)
+        if rc != 0:
+            raise RuntimeError(f"grid_exchange failed ({rc}): {last_error()}")
+
+    def close(self):
+        if self._h:
+            lib().asciichat_hip_grid_destroy(self._h)
+            self._h = C.c_void_p()
 
 
 class FrameTable:

@@ -510,11 +510,22 @@ void achip_grid_layout(const int *src_w, const int *src_h, int n, int term_w, in
   *rows = pick_r;
 }
 
+#define ACHIP_GRID_MAX_SOURCES 64 /* the layout counts every client with video; only the first nine are placed */
+
 void achip_composite_setup(achip_composite_t *comp, const uint8_t *const *src_dev, const int *src_w, const int *src_h,
                            int n, int term_w, int term_h) {
   memset(comp, 0, sizeof(*comp));
   int cols, rows;
-  achip_grid_layout(src_w, src_h, n, term_w, term_h, &cols, &rows);
+  /* The layout is chosen for the sources that HAVE video -- the reference passes sources_with_video, and averages
+   * the aspect ratio over the sources with an image (stream.c:525-558, 671); a client without video gets no cell. */
+  int have_w[ACHIP_GRID_MAX_SOURCES], have_h[ACHIP_GRID_MAX_SOURCES], have = 0;
+  for (int i = 0; i < n && have < ACHIP_GRID_MAX_SOURCES; i++)
+    if (src_dev[i] && src_w[i] > 0 && src_h[i] > 0) {
+      have_w[have] = src_w[i];
+      have_h[have] = src_h[i];
+      have++;
+    }
+  achip_grid_layout(have_w, have_h, have, term_w, term_h, &cols, &rows);
   comp->canvas_w = term_w;
   comp->canvas_h = term_h * 2;
   comp->cols = cols;
@@ -525,7 +536,7 @@ void achip_composite_setup(achip_composite_t *comp, const uint8_t *const *src_de
   comp->cell_h = comp->canvas_h / rows;
   int placed = 0;
   for (int i = 0; i < n && placed < 9; i++) {
-    if (!src_dev[i])
+    if (!src_dev[i] || src_w[i] <= 0 || src_h[i] <= 0)
       continue;
     achip_comp_src_t *s = &comp->s[placed];
     const int row = placed / cols, col = placed % cols;

@@ -18,10 +18,21 @@ import ctypes as C
 
 
 def shard_bounds(n_items, world, rank):
-    """Contiguous block partition: (items per rank, first, count) for `rank`."""
-    per = (n_items + world - 1) // world
-    first = min(n_items, rank * per)
-    return per, first, max(0, min(per, n_items - first))
+    """Contiguous, balanced partition (achip_shard_bounds in comm.c): (slots every rank reserves, first, count) for
+    `rank` -- the first n % world ranks hold one item more, so nine sources over eight GPUs leave no rank idle."""
+    base, extra = divmod(max(0, n_items), max(1, world))
+    first = rank * base + min(rank, extra)
+    count = base + (1 if rank < extra else 0)
+    slots = (n_items + world - 1) // world if n_items > 0 else 0
+    return slots, first, count
+
+
+def shard_owner(n_items, world, item):
+    for r in range(world):
+        _, first, count = shard_bounds(n_items, world, r)
+        if first <= item < first + count:
+            return r
+    return -1
 
 
 class ShardedBatch:
@@ -53,10 +64,16 @@ class ShardedBatch:
         dist.all_gather_into_tensor(self.slab, slab.clone(), group=group)
         dist.all_gather_into_tensor(self.lens, lens.clone(), group=group)
 
+    def slot_of(self, i):
+        """Slab slot of logical frame i: its owner's block starts at owner * per."""
+        owner = shard_owner(self.n, self.world, i)
+        return owner * self.per + (i - shard_bounds(self.n, self.world, owner)[1])
+
     def frame_bytes(self, i):
         """Host copy of logical frame i (after all_gather, or local frames before)."""
-        n = int(self.lens[i].item()) & 0xFFFFFFFF
-        return bytes(self.slab[i * self.stride:i * self.stride + n].cpu().numpy())
+        k = self.slot_of(i)
+        n = int(self.lens[k].item()) & 0xFFFFFFFF
+        return bytes(self.slab[k * self.stride:k * self.stride + n].cpu().numpy())
 
 
 def gather_grid_tiles(torch, dist, backend, comp, local_sources, world, rank, device):
@@ -65,8 +82,7 @@ def gather_grid_tiles(torch, dist, backend, comp, local_sources, world, rank, de
 
     comp            achip_composite_t filled by achip_composite_setup() with the geometry of ALL sources
                     (every rank knows every source's dimensions; pointers may be dummies)
-    local_sources   {slot index: uint8 tensor HxWx3 on `device`} for the slots this rank owns; slots are
-                    dealt in contiguous blocks: rank r owns [r*per, (r+1)*per)
+    local_sources   {source index: uint8 tensor HxWx3 on `device`} for the sources this rank owns (shard_bounds)
     """
     n = comp.n_src
     per, first, count = shard_bounds(n, world, rank)
@@ -74,12 +90,16 @@ def gather_grid_tiles(torch, dist, backend, comp, local_sources, world, rank, de
     for k in range(n):
         tile_stride = max(tile_stride, (comp.s[k].tile_w * comp.s[k].tile_h * 3 + 15) // 16 * 16)
     tiles = torch.zeros(world * per * tile_stride, dtype=torch.uint8, device=device)
+    def slot_of(k):
+        owner = shard_owner(n, world, k)
+        return owner * per + (k - shard_bounds(n, world, owner)[1])
+
     for k in range(first, first + count):
         s = comp.s[k]
         if not s.src:
             continue
         src = local_sources[k]
-        backend.resize(src.data_ptr(), s.src_w, s.src_h, tiles.data_ptr() + k * tile_stride, s.tile_w, s.tile_h)
+        backend.resize(src.data_ptr(), s.src_w, s.src_h, tiles.data_ptr() + slot_of(k) * tile_stride, s.tile_w, s.tile_h)
     backend.sync()
     if world > 1:
         mine = tiles[rank * per * tile_stride:(rank + 1) * per * tile_stride].clone()
@@ -91,7 +111,7 @@ def gather_grid_tiles(torch, dist, backend, comp, local_sources, world, rank, de
         s = out.s[k]
         if not s.src:
             continue
-        s.src = tiles.data_ptr() + k * tile_stride
+        s.src = tiles.data_ptr() + slot_of(k) * tile_stride
         s.src_w, s.src_h, s.src_stride = s.tile_w, s.tile_h, 3 * s.tile_w
         s.x_ratio = s.y_ratio = 65537  # ((n << 16) / n) + 1
     return tiles, tile_stride, out

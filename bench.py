@@ -310,41 +310,101 @@ def time_with_d2h(torch, plan, n, steps):
     return (time.perf_counter() - t0) / steps, int(buf.numel())
 
 
-def run_grid9(torch, pkg, steps, regions, targets=256):
-    """BASELINE configs[3]: nine 1080p sources -> the 3x3 grid at 160x48 (stream.c:523-854), rendered for `targets`
-    target clients per step (the server renders the mixed frame once per connected client, render.c:340-600).  One
-    launch renders all target frames straight from the nine sources: the W x 2H canvas is virtual."""
+def run_grid9(torch, pkg, steps, regions, targets=256, dist=None, world=1, rank=0, backend="nccl"):
+    """BASELINE configs[3]: nine 1080p sources -> the 3x3 grid at 160x48 (stream.c:523-854), sharded over the ranks
+    with an RCCL all-gather for the composite -- through the C-ABI (asciichat_hip_comm_* / asciichat_hip_grid_*):
+    a step = every rank resizes the sources it owns into their tiles, ONE ncclAllGather moves the tiles to every rank,
+    and every rank renders the grid for its `targets` target clients (the server renders the mixed frame once per
+    connected client, render.c:340-600) straight from the gathered tiles -- the W x 2H canvas stays virtual.  The
+    exchange is inside the timed step.  World size 1 still runs the real ncclAllGather."""
+    import numpy as np
+
+    import orc
+
     n, sw, sh, tw, th = 9, 1920, 1080, 160, 48
-    src = make_frames(torch, n, sw, sh, 4321)
-    ptrs = (C.c_void_p * n)(*[src.data_ptr() + i * sh * sw * 3 for i in range(n)])
-    ws, hs = (C.c_int * n)(*([sw] * n)), (C.c_int * n)(*([sh] * n))
-    comp = pkg.Composite()
-    pkg.lib().achip_composite_setup(C.byref(comp), ptrs, ws, hs, n, tw, th)
-    comp_dev = C.c_void_p()
-    assert pkg.lib().asciichat_hip_composite_upload(C.byref(comp), C.byref(comp_dev)) == 0
+    comm = None
+    if backend == "nccl":
+        if world > 1:
+            uid = torch.zeros(pkg.COMM_ID_BYTES, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(pkg.comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(uid, 0)
+            comm = pkg.Comm(world, rank, bytes(uid.cpu().numpy()))
+        else:
+            comm = pkg.Comm(1, 0, pkg.comm_unique_id())
+    grid = pkg.Grid(comm, [(sw, sh)] * n, tw, th)
+    # every rank generates the sources it owns (same seeds on every rank: source k is the same frame everywhere)
+    own = [k for k in range(n) if grid.owner(k) == (rank if comm else 0)]
+    src = {k: make_frames(torch, 1, sw, sh, 4321 + k)[0] for k in own}
+    ptrs = {k: t.data_ptr() for k, t in src.items()}
     out = {}
+    cur = torch.cuda.current_stream()
     for label, nt in (("nine_targets", 9), (f"{targets}_targets", targets)):
         descs = []
         for _ in range(nt):  # every client looks at the same grid (stream.c:790-854: aspect + padding on)
             f = pkg.frame_setup(None, tw, 2 * th, tw, th, 0, True, True, False)
-            f.comp = comp_dev.value
+            f.comp = grid.composite_dev
             descs.append(f)
         plan = pkg.Plan(pkg.lib().achip_mode_from_caps(3, 0), PALETTE_STANDARD, descs)
-        run = Runner(torch, pkg, [plan], nt, 1)
-        run.issue(5)
-        walls = [run.region(steps, None) for _ in range(regions)]
-        g = run.gpu_ms_per_step(max(100, steps))
-        lens = run.lns[0].cpu().numpy().astype("uint32")
+        slab = torch.empty(nt * plan.stride, dtype=torch.uint8, device="cuda")
+        ln = torch.zeros(nt, dtype=torch.int32, device="cuda")
+
+        def step():
+            grid.exchange(ptrs, cur.cuda_stream)
+            plan.render(slab.data_ptr(), plan.stride, ln.data_ptr(), cur.cuda_stream)
+
+        def region(K):
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(K):
+                step()
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0
+
+        for _ in range(5):
+            step()
+        walls = [region(steps) for _ in range(regions)]
+        if dist is not None:
+            t = torch.tensor(walls, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            walls = [float(v) for v in t.tolist()]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        step()
+        e0.record(cur)
+        for _ in range(max(50, steps)):
+            step()
+        e1.record(cur)
+        torch.cuda.synchronize()
+        g = e0.elapsed_time(e1) / max(50, steps)
+        lens = ln.cpu().numpy().astype("uint32")
         assert (lens < 0xFFFFFFF0).all()
         cells = int(sum(d.out_w * d.out_h for d in descs))
         alg = int(lens.sum()) + 3 * cells
         wall = statistics.median(walls)
-        out[label] = {"frames_per_s": nt * steps / wall, "ms_per_step": wall / steps * 1e3, "kernel_ms": g,
-                      "out_bytes_per_frame": float(lens.mean()), "alg_bytes_per_launch": alg,
-                      "roofline_GBps": alg / (g * 1e-3) / 1e9, "roofline_frac": alg / (g * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                      "kernel_variant": plan.variant, "bands_per_frame": plan.parts}
+        entry = {"frames_per_s": nt * world * steps / wall, "ms_per_step": wall / steps * 1e3, "kernel_ms": g,
+                 "out_bytes_per_frame": float(lens.mean()), "alg_bytes_per_launch": alg,
+                 "roofline_GBps": alg / (g * 1e-3) / 1e9, "roofline_frac": alg / (g * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                 "kernel_variant": plan.variant, "bands_per_frame": plan.parts, "targets_per_rank": nt,
+                 "collective": "ncclAllGather of the composite tiles inside every step (C-ABI, comm.c)" if comm else "none (gloo run)",
+                 "sources_owned_by_rank0": len(own)}
+        if rank == 0 and world == 1:  # the composite every rank renders from is the oracle's, byte for byte
+            allsrc = [np.ascontiguousarray(make_frames(torch, 1, sw, sh, 4321 + k)[0].cpu().numpy()) for k in range(n)]
+            exp = orc.convert_with_caps(orc.composite(allsrc, tw, th), tw, th, 3, 0, True, True, False)
+            got = bytes(slab[:int(lens[0])].cpu().numpy())
+            if got != exp:
+                raise SystemExit("bench.py: grid frame differs from the oracle")
+            entry["verify"] = {"frames_checked": 1, "byte_identical_to_oracle": True}
+        out[label] = entry
         plan.close()
-    pkg.lib().asciichat_hip_free(comp_dev)
+    grid.close()
+    if comm:
+        comm.close()
     return out
 
 
@@ -405,7 +465,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--regions", type=int, default=0, help="timed regions of --steps steps each; 0 = max(5, 1200 / steps)")
     ap.add_argument("--batch", type=int, default=256)
-    ap.add_argument("--workload", default="1080p_80x24_truecolor", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="1080p_80x24_truecolor", choices=sorted(WORKLOADS) + ["grid9"],
+                    help="grid9 = BASELINE configs[3]: nine 1080p sources -> 3x3 grid at 160x48, sharded over the ranks "
+                         "with an RCCL all-gather of the composite tiles inside every step")
     ap.add_argument("--input", default="noise", choices=INPUT_KINDS)
     ap.add_argument("--aspect", action="store_true", help="use_aspect_ratio + wants_padding for the main workload")
     ap.add_argument("--others", default="default",
@@ -450,6 +512,25 @@ def main():
             d.init_process_group(backend)
         dist = d
 
+    if args.workload == "grid9":
+        g = run_grid9(torch, pkg, args.steps, regions, args.batch, dist, world, rank, backend)
+        e = g[f"{args.batch}_targets"]
+        if rank == 0:
+            print(json.dumps({
+                "metric": "frames/sec, nine 1080p sources -> 3x3 grid at 160x48 truecolor, one frame per target client",
+                "value": e["frames_per_s"], "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": 5,
+                "ms_per_step": e["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "u8", "data": "synthetic (nine uniform-random 1080p RGB24 sources, resident in HBM on their owner rank)",
+                "config": {"workload": "grid9", "targets_per_gpu": args.batch, "sources": 9, "grid": "160x48",
+                           "parallelism": f"sources and target clients sharded over {world} rank(s); one RCCL all-gather of "
+                                          "the composite tiles per step"},
+                "roofline": {"bound": "hbm", "achieved": e["roofline_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": e["roofline_frac"], "traffic": None, "kernel_ms": e["kernel_ms"],
+                             "alg_bytes_per_launch": e["alg_bytes_per_launch"]},
+                "grid9": g}))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     res = run_workload(torch, pkg, args.workload, args.batch, args.steps, args.warmup, regions, dist, seed=1234 + rank,
                        variant=args.variant, nsets=args.input_sets, streams=args.streams or 4, kind=args.input,
                        aspect=args.aspect, serial_leg=not args.no_hot,

@@ -190,6 +190,48 @@ int asciichat_hip_frame_packets(const uint8_t *base_dev, size_t stride, const ui
                                 const uint32_t *dims_dev, uint32_t *crc_out_dev, uint8_t *hdr_out_dev,
                                 uint32_t *packet_crc_out_dev, void *stream);
 
+/*
+ * Multi-GPU (comm.c): one process per GPU, RCCL over xGMI (librccl is dlopen'ed on first use).
+ * Frames are independent, so the render path needs no collective -- a batch is partitioned over the ranks
+ * (achip_shard_bounds, balanced and contiguous) and every rank renders its block.  Collectives exist where a consumer
+ * needs remote data:
+ *   comm_all_gather_slab   in-place all-gather of a sharded output slab + its lengths (one group per batch):
+ *                          rank r rendered its frames into slots [r*slots, (r+1)*slots), slots = achip_shard_slots();
+ *   grid_*                 BASELINE config 4, the server's pixel-space grid (create_multi_source_composite +
+ *                          convert_composite_to_ascii, src/server/stream.c:664-854): grid_exchange resizes the sources
+ *                          this rank owns into their composite tiles and all-gathers the tiles (one ncclAllGather of
+ *                          <= 2 x 4.8 KB per rank for nine 1080p sources at 160x48); every rank then renders the grid
+ *                          for its own target clients from plans whose frames point at grid_composite_dev().
+ * The 128-byte unique id goes from rank 0 to the others out of band (the server's control plane).  comm == NULL
+ * means a single GPU everywhere below.
+ */
+#define ASCIICHAT_HIP_COMM_ID_BYTES 128
+#define ASCIICHAT_HIP_GRID_MAX_SOURCES 64 /* clients the layout counts; the first nine with video are placed (stream.c:687) */
+typedef struct asciichat_hip_comm asciichat_hip_comm_t;
+typedef struct asciichat_hip_grid asciichat_hip_grid_t;
+int asciichat_hip_comm_unique_id(void *id_out, size_t id_bytes);
+int asciichat_hip_comm_init(asciichat_hip_comm_t **comm, int world, int rank, const void *id, size_t id_bytes);
+int asciichat_hip_comm_world(const asciichat_hip_comm_t *comm);
+int asciichat_hip_comm_rank(const asciichat_hip_comm_t *comm);
+void asciichat_hip_comm_destroy(asciichat_hip_comm_t *comm);
+int asciichat_hip_comm_all_gather(asciichat_hip_comm_t *comm, const void *send_dev, void *recv_dev, size_t bytes_per_rank,
+                                  void *stream);
+int asciichat_hip_comm_all_gather_slab(asciichat_hip_comm_t *comm, uint8_t *slab_dev, size_t stride, uint32_t *len_dev,
+                                       int slots_per_rank, void *stream);
+/* partition of n independent items: rank's [first, first+count); owner of an item; slots every rank reserves */
+void achip_shard_bounds(int n_items, int world, int rank, int *first, int *count);
+int achip_shard_owner(int n_items, int world, int item);
+int achip_shard_slots(int n_items, int world);
+/* has_video: NULL = every source has video, else n_src flags (a client without video takes no cell) */
+int asciichat_hip_grid_create(asciichat_hip_grid_t **grid, asciichat_hip_comm_t *comm, const int *src_w, const int *src_h,
+                              const unsigned char *has_video, int n_src, int term_w, int term_h);
+int asciichat_hip_grid_owner(const asciichat_hip_grid_t *grid, int source); /* rank that must pass this source's pixels */
+/* local_src_dev[k]: device pixels of source k (RGB24, tightly packed) for the sources this rank owns; others ignored */
+int asciichat_hip_grid_exchange(asciichat_hip_grid_t *grid, const uint8_t *const *local_src_dev, void *stream);
+const achip_composite_t *asciichat_hip_grid_composite_dev(const asciichat_hip_grid_t *grid); /* for achip_frame_t.comp */
+const achip_composite_t *asciichat_hip_grid_geometry(const asciichat_hip_grid_t *grid);      /* host copy: canvas size .. */
+void asciichat_hip_grid_destroy(asciichat_hip_grid_t *grid);
+
 /* Upload a composite descriptor for use as achip_frame_t.comp; free with asciichat_hip_free. */
 int asciichat_hip_composite_upload(const achip_composite_t *comp_host, achip_composite_t **comp_dev);
 void asciichat_hip_free(void *dev_ptr);

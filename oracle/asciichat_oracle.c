@@ -1108,7 +1108,16 @@ void orc_grid_layout(const int *src_w, const int *src_h, int n, int term_w, int 
 uint8_t *orc_composite(const uint8_t *const *src, const int *src_w, const int *src_h, int n, int term_w, int term_h,
                        int *out_w, int *out_h) {
   int cols, rows;
-  orc_grid_layout(src_w, src_h, n, term_w, term_h, &cols, &rows);
+  /* calculate_optimal_grid_layout (stream.c:523-651) sees sources_with_video cells and averages the aspect of the
+   * sources that have an image (:546-552): a client without video takes no cell and does not move the others'. */
+  int vw[64], vh[64], nv = 0;
+  for (int i = 0; i < n && nv < 64; i++)
+    if (src[i]) {
+      vw[nv] = src_w[i];
+      vh[nv] = src_h[i];
+      nv++;
+    }
+  orc_grid_layout(vw, vh, nv, term_w, term_h, &cols, &rows);
   int cw_px = term_w, ch_px = term_h * 2;
   uint8_t *canvas = (uint8_t *)calloc((size_t)cw_px * (size_t)ch_px, 3);
   *out_w = cw_px;

@@ -295,10 +295,11 @@ def grid_layout(dims, term_w, term_h):
 
 
 def composite(imgs, term_w, term_h):
-    imgs = [_img(i) for i in imgs]
-    ptrs = (C.c_void_p * len(imgs))(*[i.ctypes.data for i in imgs])
-    ws = (C.c_int * len(imgs))(*[i.shape[1] for i in imgs])
-    hs = (C.c_int * len(imgs))(*[i.shape[0] for i in imgs])
+    """imgs: list of HxWx3 arrays; None = a client without video (takes no cell, stream.c:690-692)"""
+    imgs = [None if i is None else _img(i) for i in imgs]
+    ptrs = (C.c_void_p * len(imgs))(*[None if i is None else i.ctypes.data for i in imgs])
+    ws = (C.c_int * len(imgs))(*[0 if i is None else i.shape[1] for i in imgs])
+    hs = (C.c_int * len(imgs))(*[0 if i is None else i.shape[0] for i in imgs])
     ow, oh = C.c_int(), C.c_int()
     p = lib().orc_composite(ptrs, ws, hs, len(imgs), term_w, term_h, C.byref(ow), C.byref(oh))
     out = np.frombuffer(C.string_at(p, ow.value * oh.value * 3), dtype=np.uint8).reshape(oh.value, ow.value, 3).copy()

@@ -374,6 +374,68 @@ def test_composite_geometry_and_kernel_emulated(pkg):
             assert got == orc.convert_with_caps(ref, tw, h, cl, rm, True, True, False), (n, mode)
 
 
+def test_composite_skips_clients_without_video(pkg):
+    """a client without video takes no grid cell and does not count in the layout
+    (calculate_optimal_grid_layout gets sources_with_video, src/server/stream.c:523-558, 671, 690-692).
+    Anchor derived by hand from those lines: five clients, the third without video, 16:9 sources at 160x48 -> four
+    cells: cols = rows = 2 (utilisation 22*80/(80*24) = 0.917 beats 3x2's 0.583), cell 80x48 px on the 160x96 canvas,
+    every tile 80 x (int)(80 / (16/9) + 0.5) = 80x45 centred with a 1-px top margin.  (Counting all five -- the bug --
+    gives 2 columns x 3 rows of 80x32 px cells.)"""
+    EL = emu.lib()
+    imgs = [orc.frame_hash_noise(192, 108, 70 + i) for i in range(5)]
+    imgs[2] = None
+    ptrs = (C.c_void_p * 5)(*[None if i is None else i.ctypes.data for i in imgs])
+    ws, hs = (C.c_int * 5)(*[192] * 5), (C.c_int * 5)(*[108] * 5)
+    comp = emu.Composite()
+    EL.achip_composite_setup(C.byref(comp), ptrs, ws, hs, 5, 160, 48)
+    assert (comp.cols, comp.rows, comp.cell_w, comp.cell_h, comp.n_src) == (2, 2, 80, 48, 4)
+    for k, src_i in enumerate((0, 1, 3, 4)):
+        s = comp.s[k]
+        assert (s.tile_w, s.tile_h, s.org_x, s.org_y) == (80, 45, (k % 2) * 80, (k // 2) * 48 + 1), k
+        assert s.src == imgs[src_i].ctypes.data
+    ref = orc.composite(imgs, 160, 48)
+    out = np.zeros((96, 160, 3), np.uint8)
+    EL.emu_composite(C.byref(comp), out.ctypes.data)
+    assert np.array_equal(out, ref)
+    assert np.array_equal(ref[1:46, 0:80], orc.resize_nn(imgs[0], 80, 45)) and not ref[0].any() and not ref[46:48, 0:80].any()
+    assert np.array_equal(ref[49:94, 80:160], orc.resize_nn(imgs[4], 80, 45))
+    # nobody has video: an empty (black) canvas; one client with video: one cell
+    none = (C.c_void_p * 2)(None, None)
+    EL.achip_composite_setup(C.byref(comp), none, ws, hs, 2, 160, 48)
+    assert (comp.cols, comp.rows, comp.n_src) == (0, 0, 0)
+    one = (C.c_void_p * 3)(None, imgs[1].ctypes.data, None)
+    EL.achip_composite_setup(C.byref(comp), one, ws, hs, 3, 160, 48)
+    assert (comp.cols, comp.rows, comp.n_src) == (1, 1, 1) and comp.s[0].src == imgs[1].ctypes.data
+    assert np.array_equal(orc.composite([None, imgs[1], None], 160, 48)[3:93, :], orc.resize_nn(imgs[1], 160, 90))
+
+
+def test_shard_partition_is_balanced(pkg):
+    """achip_shard_bounds / _owner / _slots (comm.c): contiguous and balanced -- nine sources over eight GPUs leave
+    no rank idle (the block partition left ranks 5-7 without work)."""
+    L = pkg.lib()
+    f, c = C.c_int(), C.c_int()
+
+    def bounds(n, w):
+        out = []
+        for r in range(w):
+            L.achip_shard_bounds(n, w, r, C.byref(f), C.byref(c))
+            out.append((f.value, c.value))
+        return out
+
+    assert bounds(9, 8) == [(0, 2), (2, 1), (3, 1), (4, 1), (5, 1), (6, 1), (7, 1), (8, 1)]
+    assert bounds(256, 8) == [(32 * r, 32) for r in range(8)]
+    assert bounds(5, 2) == [(0, 3), (3, 2)] and bounds(3, 4) == [(0, 1), (1, 1), (2, 1), (3, 0)] and bounds(0, 3) == [(0, 0)] * 3
+    for n in range(0, 40):
+        for w in range(1, 10):
+            b = bounds(n, w)
+            assert sum(c for _, c in b) == n and max(c for _, c in b) - min(c for _, c in b) <= 1
+            assert L.achip_shard_slots(n, w) == max(c for _, c in b)
+            for r, (first, count) in enumerate(b):
+                for i in range(first, first + count):
+                    assert L.achip_shard_owner(n, w, i) == r
+            assert L.achip_shard_owner(n, w, n) == -1 and L.achip_shard_owner(n, w, -1) == -1
+
+
 def test_resize_kernel_emulated():
     img = orc.frame_hash_noise(193, 109, 8)
     for (dw, dh) in ((80, 24), (1, 1), (193, 109), (400, 300)):

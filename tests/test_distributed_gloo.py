@@ -102,5 +102,7 @@ def test_shard_bounds():
 
     d = load_package().distributed
     assert [d.shard_bounds(256, 8, r)[1:] for r in range(8)] == [(32 * r, 32) for r in range(8)]
-    assert [d.shard_bounds(9, 8, r)[1:] for r in range(8)] == [(0, 2), (2, 2), (4, 2), (6, 2), (8, 1), (9, 0), (9, 0), (9, 0)]
-    assert d.shard_bounds(5, 2, 1) == (3, 3, 2)
+    # balanced: nine sources over eight GPUs leave no rank idle (the same rule as achip_shard_bounds in comm.c)
+    assert [d.shard_bounds(9, 8, r)[1:] for r in range(8)] == [(0, 2), (2, 1), (3, 1), (4, 1), (5, 1), (6, 1), (7, 1), (8, 1)]
+    assert d.shard_bounds(5, 2, 1) == (3, 3, 2) and d.shard_bounds(9, 8, 3)[0] == 2
+    assert [d.shard_owner(9, 8, k) for k in range(9)] == [0, 0, 1, 2, 3, 4, 5, 6, 7]

@@ -576,3 +576,60 @@ def test_launches_in_flight_on_three_streams(gpu):
             for k in range(n):
                 assert h[k * st:k * st + int(l[k])].tobytes() == exp_of[picks[s][k]], (mode, s, k)
             plans[s].close()
+
+
+def test_rccl_comm_and_grid_exchange_world1(gpu):
+    """The C-ABI's RCCL layer (comm.c) on one GPU: a world-size-1 communicator runs the real ncclAllGather calls of
+    the sharded-slab gather and of the grid's tile exchange; the grid rendered from the gathered tiles equals the
+    oracle's composite + convert (K4: nine 1080p sources, 3x3 at 160x48), with and without a client that has no video.
+    World size > 1 is the driver's to run (bench.py --workload grid9 --gpus N); the partition logic is CPU-tested."""
+    pkg, torch = gpu
+    comm = pkg.Comm(1, 0, pkg.comm_unique_id())
+    st = torch.cuda.current_stream().cuda_stream
+    # (1) in-place slab gather: a no-op permutation at world 1, but the calls, sizes and group must be accepted
+    imgs = [orc.frame_hash_noise(96, 54, 300 + i) for i in range(3)]
+    got0 = render_batch(gpu, MODE_TRUE_FG, imgs, 40, 12)
+    dev = [torch.from_numpy(i).cuda() for i in imgs]
+    frames = [pkg.frame_setup(d.data_ptr(), 96, 54, 40, 12, 0, False, False, False) for d in dev]
+    plan = pkg.Plan(MODE_TRUE_FG, orc.PALETTE_STANDARD, frames)
+    slab = torch.zeros(3 * plan.stride, dtype=torch.uint8, device="cuda")
+    ln = torch.zeros(3, dtype=torch.int32, device="cuda")
+    plan.render(slab.data_ptr(), plan.stride, ln.data_ptr(), st)
+    comm.all_gather_slab(slab.data_ptr(), plan.stride, ln.data_ptr(), 3, st)
+    torch.cuda.synchronize()
+    for i in range(3):
+        n = int(ln[i].item())
+        assert bytes(slab[i * plan.stride:i * plan.stride + n].cpu().numpy()) == got0[i]
+    plan.close()
+    # (2) K4 through asciichat_hip_grid_*: tiles resized by the owner, all-gathered, rendered by the fused sampler
+    srcs = [orc.frame_hash_noise(1920, 1080, 10 + i) if i % 2 else orc.frame_bars(1920, 1080, i) for i in range(9)]
+    dsrc = [torch.from_numpy(s).cuda() for s in srcs]
+    for has_video in (None, [True, True, False, True, True, True, False, True, True]):
+        grid = pkg.Grid(comm, [(1920, 1080)] * 9, 160, 48, has_video)
+        assert all(grid.owner(k) == 0 for k in range(9))
+        live = [s if (has_video is None or has_video[k]) else None for k, s in enumerate(srcs)]
+        if has_video is None:
+            assert (grid.geometry.cols, grid.geometry.rows, grid.geometry.n_src) == (3, 3, 9)
+        else:
+            assert grid.geometry.n_src == 7
+        grid.exchange({k: dsrc[k].data_ptr() for k in range(9)}, st)
+        ref = orc.composite(live, 160, 48)
+        for mode, (cl, rm) in ((MODE_TRUE_FG, (3, 0)), (MODE_HB_TRUE, (3, 2)), (2, (2, 0))):
+            h = 96 if rm == 2 else 48
+            fs = []
+            for _ in range(5):  # five target clients looking at the same grid
+                f = pkg.frame_setup(None, 160, 96, 160, h, rm, True, True, False)
+                f.comp = grid.composite_dev
+                fs.append(f)
+            plan = pkg.Plan(mode, orc.PALETTE_STANDARD, fs)
+            out = torch.zeros(5 * plan.stride, dtype=torch.uint8, device="cuda")
+            l5 = torch.zeros(5, dtype=torch.int32, device="cuda")
+            plan.render(out.data_ptr(), plan.stride, l5.data_ptr(), st)
+            torch.cuda.synchronize()
+            exp = orc.convert_with_caps(ref, 160, h, cl, rm, True, True, False)
+            for i in range(5):
+                n = int(l5[i].item())
+                assert bytes(out[i * plan.stride:i * plan.stride + n].cpu().numpy()) == exp, (mode, i, has_video is None)
+            plan.close()
+        grid.close()
+    comm.close()
