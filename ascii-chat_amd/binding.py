@@ -107,6 +107,8 @@ def lib():
     L.asciichat_hip_frame_table_latest.restype = ci
     L.asciichat_hip_frame_table_latest.argtypes = [vp, ci, vp, C.POINTER(vp), C.POINTER(ci), C.POINTER(ci),
                                                    C.POINTER(C.c_uint64)]
+    L.asciichat_hip_frame_table_forget_stream.restype = None
+    L.asciichat_hip_frame_table_forget_stream.argtypes = [vp, vp]
     L.asciichat_hip_crc32c.restype = ci
     L.asciichat_hip_crc32c.argtypes = [vp, C.c_size_t, vp, C.c_uint32, C.c_uint32, ci, vp, vp]
     L.asciichat_hip_frame_packets.restype = ci
@@ -506,6 +508,9 @@ class FrameTable:
         if rc != 0:
             raise RuntimeError(f"frame_table_latest failed: {last_error()}")
         return p.value, w.value, h.value, g.value
+
+    def forget_stream(self, stream):
+        lib().asciichat_hip_frame_table_forget_stream(self._h, stream)
 
     def close(self):
         if self._h:

@@ -30,6 +30,7 @@
 #define PIN_DESC_OFF 0
 #define PIN_LEN_OFF 64
 #define PIN_OUT_OFF 128
+#define PIN_KEEP_MAX ((size_t)32 << 20) /* pinned output blocks above 32 MiB are released after the call that needed them */
 
 typedef struct {
   hipStream_t stream;
@@ -94,7 +95,9 @@ static int ensure_pin(tls_ctx_t *c, size_t need) {
     (void)hipHostFree(c->pin);
   c->pin = NULL;
   c->pin_cap = 0;
-  size_t cap = need + need / 2;
+  /* head room only while the block is small: one image_print_color of a 3840x2160 image bounds its output at
+   * ~320 MB, and 1.5x of that pinned per calling thread is how a server runs out of pinnable memory */
+  size_t cap = need <= PIN_KEEP_MAX ? need + need / 2 : need;
   void *host = NULL, *dev = NULL;
   if (achip_hip_check((int)hipHostMalloc(&host, cap, hipHostMallocMapped), "hipHostMalloc(output)"))
     return -1;
@@ -104,6 +107,16 @@ static int ensure_pin(tls_ctx_t *c, size_t need) {
   c->pin_dev = (uint8_t *)dev;
   c->pin_cap = cap;
   return 0;
+}
+
+/* after a call: a block far above what a render thread's frames need does not stay pinned until thread exit */
+static void trim_pin(tls_ctx_t *c) {
+  if (c->pin_cap <= PIN_KEEP_MAX)
+    return;
+  (void)hipHostFree(c->pin);
+  c->pin = NULL;
+  c->pin_dev = NULL;
+  c->pin_cap = 0;
 }
 
 static int ensure_dev(uint8_t **buf, size_t *cap, size_t need) {
@@ -243,15 +256,18 @@ static char *render_with_lut(tls_ctx_t *c, const achip_lut_t *lut, int mode, con
   if (len >= 0xFFFFFFF0u) {
     achip_fail(ASCIICHAT_HIP_ERR_BUFFER, "render kernel reported %s",
                len == ACHIP_LEN_OVERFLOW ? "output overflow" : "a bad descriptor");
+    trim_pin(c);
     return NULL;
   }
   char *out = (char *)malloc((size_t)len + 1);
   if (!out) {
     achip_fail(ASCIICHAT_HIP_ERR_MEMORY, "out of memory");
+    trim_pin(c);
     return NULL;
   }
   memcpy(out, c->pin + PIN_OUT_OFF, len);
   out[len] = '\0';
+  trim_pin(c);
   return out;
 }
 

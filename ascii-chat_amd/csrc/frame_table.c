@@ -7,8 +7,14 @@
  * (collect_video_sources, src/server/stream.c:221-463: SAFE_MALLOC + memcpy, then image_new_from_pool +
  * memcpy) -- 2*N^2 full-frame host copies per tick for N clients.  Here the receive path publishes a blob
  * once: it is validated exactly as collect_video_sources validates it, sent to HBM with one DMA, and every
- * render descriptor of the tick points at the same device frame.  Slots are double-buffered: a publish never
- * writes the frame that the renders already queued may still be reading.
+ * render descriptor of the tick points at the same device frame.
+ *
+ * Slots are double-buffered and readers are tracked: latest() notes which stream was handed which buffer, and a
+ * publish that is about to overwrite a buffer first records an event on every stream that was handed it and makes the
+ * upload wait for those events -- the DMA is ordered behind every render ENQUEUED so far that may read the buffer
+ * (the previous version only ordered uploads behind uploads).  The contract that remains with the caller:
+ * a pointer from latest() is good for work enqueued before the publish after next on that slot.  Locks are per slot;
+ * nothing blocking happens under a table-wide lock.
  */
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
@@ -20,7 +26,14 @@
 #include "asciichat_hip.h"
 #include "internal.h"
 
+#define FT_MAX_READERS 32 /* consumer streams remembered per buffer; beyond that a publish synchronises the device */
+
 typedef struct {
+  pthread_mutex_t mu;   /* guards this slot only                                       */
+  hipStream_t reader[2][FT_MAX_READERS]; /* streams that were handed buffer k by latest() since its last upload */
+  int n_readers[2];
+  int readers_overflow[2];
+  hipEvent_t reader_done; /* scratch event: "everything enqueued on a reader stream so far" */
   uint8_t *dev[2];      /* frame buffers in HBM                                       */
   size_t cap[2];        /* bytes allocated                                            */
   hipEvent_t ready[2];  /* recorded after the upload of buffer k                      */
@@ -33,7 +46,6 @@ typedef struct {
 
 struct asciichat_hip_frame_table {
   int n;
-  pthread_mutex_t mu;
   ft_slot_t *slot;
 };
 
@@ -52,9 +64,10 @@ int asciichat_hip_frame_table_create(asciichat_hip_frame_table_t **table, int n_
     return achip_fail(ASCIICHAT_HIP_ERR_MEMORY, "out of memory");
   }
   t->n = n_slots;
-  pthread_mutex_init(&t->mu, NULL);
-  for (int i = 0; i < n_slots; i++)
+  for (int i = 0; i < n_slots; i++) {
     t->slot[i].cur = -1;
+    pthread_mutex_init(&t->slot[i].mu, NULL);
+  }
   *table = t;
   return 0;
 }
@@ -62,6 +75,11 @@ int asciichat_hip_frame_table_create(asciichat_hip_frame_table_t **table, int n_
 void asciichat_hip_frame_table_destroy(asciichat_hip_frame_table_t *t) {
   if (!t)
     return;
+  for (int i = 0; i < t->n; i++) {
+    pthread_mutex_destroy(&t->slot[i].mu);
+    if (t->slot[i].reader_done)
+      (void)hipEventDestroy(t->slot[i].reader_done);
+  }
   for (int i = 0; i < t->n; i++)
     for (int k = 0; k < 2; k++) {
       ft_slot_t *s = &t->slot[i];
@@ -74,7 +92,6 @@ void asciichat_hip_frame_table_destroy(asciichat_hip_frame_table_t *t) {
       if (s->stage[k])
         (void)hipHostFree(s->stage[k]);
     }
-  pthread_mutex_destroy(&t->mu);
   free(t->slot);
   free(t);
 }
@@ -91,12 +108,27 @@ int asciichat_hip_frame_table_publish(asciichat_hip_frame_table_t *t, int slot, 
                       pr == ACHIP_BLOB_SHORT ? "shorter than a header and one pixel"
                                              : (pr == ACHIP_BLOB_DIMS ? "dimensions out of range" : "size below 8 + 3*w*h"));
   const size_t bytes = (size_t)w * (size_t)h * 3u;
-  pthread_mutex_lock(&t->mu);
   ft_slot_t *s = &t->slot[slot];
-  const int k = s->cur == 0 ? 1 : 0; /* the buffer no reader of the current generation uses */
+  pthread_mutex_lock(&s->mu);
+  const int k = s->cur == 0 ? 1 : 0; /* the buffer that does not hold the latest frame */
   int rc = 0;
-  if (s->ready[k]) /* renders queued two publishes ago may still read this buffer: order behind them */
+  if (s->ready[k]) /* the previous upload into this buffer reads the same pinned staging block: let it finish */
     rc = achip_hip_check((int)hipEventSynchronize(s->ready[k]), "hipEventSynchronize(frame buffer)");
+  /* renders that were handed this buffer (one publish ago it was the latest frame) may still be queued or running:
+   * the upload goes behind everything enqueued so far on their streams */
+  if (!rc && s->n_readers[k] > 0 && !s->reader_done)
+    rc = achip_hip_check((int)hipEventCreateWithFlags(&s->reader_done, hipEventDisableTiming), "hipEventCreate");
+  for (int r = 0; r < s->n_readers[k] && !rc; r++) {
+    if (hipEventRecord(s->reader_done, s->reader[k][r]) != hipSuccess) {
+      (void)hipGetLastError(); /* the consumer destroyed its stream: nothing of it is left to wait for */
+      continue;
+    }
+    rc = achip_hip_check((int)hipStreamWaitEvent((hipStream_t)stream, s->reader_done, 0), "hipStreamWaitEvent(readers)");
+  }
+  if (!rc && s->readers_overflow[k])
+    rc = achip_hip_check((int)hipDeviceSynchronize(), "hipDeviceSynchronize(readers)");
+  s->n_readers[k] = 0;
+  s->readers_overflow[k] = 0;
   if (!rc && s->cap[k] < bytes) {
     if (s->dev[k])
       (void)hipFree(s->dev[k]);
@@ -135,7 +167,7 @@ int asciichat_hip_frame_table_publish(asciichat_hip_frame_table_t *t, int slot, 
     s->h = (int)h;
     s->generation++;
   }
-  pthread_mutex_unlock(&t->mu);
+  pthread_mutex_unlock(&s->mu);
   return rc;
 }
 
@@ -143,8 +175,8 @@ int asciichat_hip_frame_table_latest(asciichat_hip_frame_table_t *t, int slot, v
                                      const uint8_t **pixels_dev, int *width, int *height, uint64_t *generation) {
   if (!t || slot < 0 || slot >= t->n || !pixels_dev)
     return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame_table_latest: bad arguments");
-  pthread_mutex_lock(&t->mu);
   ft_slot_t *s = &t->slot[slot];
+  pthread_mutex_lock(&s->mu);
   int rc = 0;
   if (s->cur < 0) {
     *pixels_dev = NULL; /* has_video = false (stream.c:272-274) */
@@ -157,6 +189,17 @@ int asciichat_hip_frame_table_latest(asciichat_hip_frame_table_t *t, int slot, v
   } else {
     /* work queued on consumer_stream after this call sees the complete upload */
     rc = achip_hip_check((int)hipStreamWaitEvent((hipStream_t)consumer_stream, s->ready[s->cur], 0), "hipStreamWaitEvent");
+    /* remember the reader: the upload that will overwrite this buffer (the publish after next) waits for it */
+    const int k = s->cur;
+    int known = 0;
+    for (int r = 0; r < s->n_readers[k]; r++)
+      known |= s->reader[k][r] == (hipStream_t)consumer_stream;
+    if (!known) {
+      if (s->n_readers[k] < FT_MAX_READERS)
+        s->reader[k][s->n_readers[k]++] = (hipStream_t)consumer_stream;
+      else
+        s->readers_overflow[k] = 1;
+    }
     *pixels_dev = s->dev[s->cur];
     if (width)
       *width = s->w;
@@ -165,6 +208,23 @@ int asciichat_hip_frame_table_latest(asciichat_hip_frame_table_t *t, int slot, v
     if (generation)
       *generation = s->generation;
   }
-  pthread_mutex_unlock(&t->mu);
+  pthread_mutex_unlock(&s->mu);
   return rc;
+}
+
+/* A consumer that destroys a stream it passed to latest() calls this first (or simply stops: a dead stream is skipped). */
+void asciichat_hip_frame_table_forget_stream(asciichat_hip_frame_table_t *t, void *consumer_stream) {
+  if (!t)
+    return;
+  for (int i = 0; i < t->n; i++) {
+    ft_slot_t *s = &t->slot[i];
+    pthread_mutex_lock(&s->mu);
+    for (int k = 0; k < 2; k++)
+      for (int r = 0; r < s->n_readers[k];)
+        if (s->reader[k][r] == (hipStream_t)consumer_stream)
+          s->reader[k][r] = s->reader[k][--s->n_readers[k]];
+        else
+          r++;
+    pthread_mutex_unlock(&s->mu);
+  }
 }

@@ -22,6 +22,15 @@
 /* ------------------------------------------------------------------------------------------- */
 static _Thread_local char tl_err[256];
 
+/* The reference's own error channel: SET_ERRNO(code, fmt, ...) expands to asciichat_set_errno_with_message(...)
+ * (include/ascii-chat/asciichat_errno.h:311-319, lib/asciichat_errno.c:166-181), which fills the thread-local
+ * asciichat_errno / asciichat_errno_context that callers read through HAS_ERRNO / GET_ERRNO.  A WEAK reference: in a
+ * process that also carries libasciichat (the relinked server and client) the dynamic linker binds
+ * it to the real function and every failure below lands in the caller's errno context, exactly as the failures of
+ * the functions this library replaces did; in a process without it the reference is NULL and is skipped. */
+extern void asciichat_set_errno_with_message(int code, const char *file, int line, const char *function,
+                                             const char *format, ...) __attribute__((weak));
+
 int achip_fail(int code, const char *fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -29,6 +38,10 @@ int achip_fail(int code, const char *fmt, ...) {
   va_end(ap);
   if (code == ASCIICHAT_HIP_ERR_NO_DEVICE || getenv("ASCIICHAT_HIP_VERBOSE"))
     fprintf(stderr, "asciichat_hip: %s\n", tl_err);
+  if (asciichat_set_errno_with_message) /* codes are the reference's asciichat_error_t values; the one new code
+                                           (no HIP device) is reported as ERROR_INVALID_STATE there */
+    asciichat_set_errno_with_message(code == ASCIICHAT_HIP_ERR_NO_DEVICE ? ASCIICHAT_HIP_ERR_INVALID_STATE : code,
+                                     "libasciichat_hip", 0, "achip_fail", "%s", tl_err);
   return code;
 }
 
@@ -56,7 +69,15 @@ int achip_require_device(void) {
 int achip_hip_check(int e, const char *what) {
   if (e == (int)hipSuccess)
     return 0;
-  return achip_fail(ASCIICHAT_HIP_ERR_NO_DEVICE, "%s failed: %s", what, hipGetErrorString((hipError_t)e));
+  /* memory exhaustion, bad launches and a missing device are different failures */
+  int code = ASCIICHAT_HIP_ERR_NO_DEVICE;
+  if (e == (int)hipErrorOutOfMemory || e == (int)hipErrorMemoryAllocation)
+    code = ASCIICHAT_HIP_ERR_MEMORY;
+  else if (e == (int)hipErrorInvalidValue || e == (int)hipErrorInvalidConfiguration ||
+           e == (int)hipErrorInvalidDeviceFunction || e == (int)hipErrorLaunchFailure ||
+           e == (int)hipErrorLaunchOutOfResources || e == (int)hipErrorSharedObjectInitFailed)
+    code = ASCIICHAT_HIP_ERR_INVALID_STATE;
+  return achip_fail(code, "%s failed: %s", what, hipGetErrorString((hipError_t)e));
 }
 
 /* ------------------------------------------------------------------------------------------- */
@@ -211,18 +232,22 @@ static int choose_geometry(asciichat_hip_plan_t *p, const achip_frame_t *frames)
   return 0;
 }
 
+/* Measures `frames` under the plan's current settings.  Transactional: everything is computed in a copy
+ * and committed only when validation, geometry selection and the hand-off allocation have all succeeded -- after a
+ * failed update or set_* the plan renders exactly what it rendered before. */
 static int plan_measure(asciichat_hip_plan_t *p, const achip_frame_t *frames) {
+  asciichat_hip_plan_t q = *p;
   size_t stride = 0;
   int max_wp = 0;
-  p->has_comp = 0;
-  for (int i = 0; i < p->n; i++) {
+  q.has_comp = 0;
+  for (int i = 0; i < q.n; i++) {
     const achip_frame_t *f = &frames[i];
     if (f->comp || (long)f->src_w * (long)f->src_h == 1) /* the kernels' general sampler: composites, 1x1 sources */
-      p->has_comp = 1;
+      q.has_comp = 1;
     if (f->out_w <= 0 || f->out_h <= 0 || f->src_w <= 0 || f->src_h <= 0 || f->pad_left < 0 || f->pad_top < 0 ||
         (!f->src && !f->comp))
       return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame %d: bad descriptor", i);
-    size_t b = achip_out_bound(p->mode, f) + 1;
+    size_t b = achip_out_bound(q.mode, f) + 1;
     if (b > stride)
       stride = b;
     if (f->pad_left + f->out_w > max_wp)
@@ -231,24 +256,29 @@ static int plan_measure(asciichat_hip_plan_t *p, const achip_frame_t *frames) {
   stride = (stride + 15) & ~(size_t)15;
   if (stride > 0xFFFFFFF0u)
     return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame output bound exceeds 4 GiB");
-  p->stride = stride;
-  p->max_wp = max_wp;
-  (void)achip_frames_uniform(frames, p->n, &p->uniform);
-  if (choose_geometry(p, frames) != 0 || p->variant < 0 || achip_variant_cap(p->variant) < max_wp)
+  q.stride = stride;
+  q.max_wp = max_wp;
+  (void)achip_frames_uniform(frames, q.n, &q.uniform);
+  if (choose_geometry(&q, frames) != 0 || q.variant < 0 || achip_variant_cap(q.variant) < max_wp)
     return achip_fail(ASCIICHAT_HIP_ERR_NOT_SUPPORTED, "padded row of %d cells exceeds the kernel chunk (max %d)",
                       max_wp, achip_variant_cap(0));
-  if (p->parts > 1 && p->parts > p->parts_cap) { /* hand-off words for the multi-workgroup frames */
-    if (p->part_sync)
-      (void)hipFree(p->part_sync);
-    p->part_sync = NULL;
-    const size_t bytes = (size_t)p->n * (size_t)p->parts * sizeof(unsigned long long);
-    int rc = achip_hip_check((int)hipMalloc((void **)&p->part_sync, bytes), "hipMalloc(part_sync)");
+  unsigned long long *new_sync = NULL;
+  if (q.parts > 1 && q.parts > q.parts_cap) { /* hand-off words for the multi-workgroup frames */
+    const size_t bytes = (size_t)q.n * (size_t)q.parts * sizeof(unsigned long long);
+    int rc = achip_hip_check((int)hipMalloc((void **)&new_sync, bytes), "hipMalloc(part_sync)");
     if (!rc)
-      rc = achip_hip_check((int)hipMemset(p->part_sync, 0, bytes), "hipMemset(part_sync)");
-    if (rc)
+      rc = achip_hip_check((int)hipMemset(new_sync, 0, bytes), "hipMemset(part_sync)");
+    if (rc) {
+      if (new_sync)
+        (void)hipFree(new_sync);
       return rc;
-    p->parts_cap = p->parts;
+    }
+    q.part_sync = new_sync;
+    q.parts_cap = q.parts;
   }
+  if (new_sync && p->part_sync)
+    (void)hipFree(p->part_sync); /* synchronises with launches that still poll the old words */
+  *p = q;
   return 0;
 }
 
@@ -314,15 +344,23 @@ int asciichat_hip_plan_set_variant(asciichat_hip_plan_t *p, int variant) {
     return ASCIICHAT_HIP_ERR_INVALID_PARAM;
   if (variant >= 0 && achip_variant_cap(variant) < p->max_wp)
     return achip_fail(ASCIICHAT_HIP_ERR_NOT_SUPPORTED, "variant %d cannot hold a %d-cell row", variant, p->max_wp);
+  const int before = p->variant_user;
   p->variant_user = variant;
-  return plan_measure(p, p->frames_pinned);
+  const int rc = plan_measure(p, p->frames_pinned);
+  if (rc)
+    p->variant_user = before;
+  return rc;
 }
 
 int asciichat_hip_plan_set_split(asciichat_hip_plan_t *p, int rows_per_part) {
   if (!p)
     return ASCIICHAT_HIP_ERR_INVALID_PARAM;
+  const int before = p->split_request;
   p->split_request = rows_per_part;
-  return plan_measure(p, p->frames_pinned);
+  const int rc = plan_measure(p, p->frames_pinned);
+  if (rc)
+    p->split_request = before;
+  return rc;
 }
 
 int asciichat_hip_plan_get_parts(const asciichat_hip_plan_t *p) { return p ? p->parts : 0; }
@@ -330,8 +368,12 @@ int asciichat_hip_plan_get_parts(const asciichat_hip_plan_t *p) { return p ? p->
 int asciichat_hip_plan_set_concurrency(asciichat_hip_plan_t *p, int launches_in_flight) {
   if (!p || launches_in_flight < 1)
     return ASCIICHAT_HIP_ERR_INVALID_PARAM;
+  const int before = p->concurrency;
   p->concurrency = launches_in_flight;
-  return plan_measure(p, p->frames_pinned);
+  const int rc = plan_measure(p, p->frames_pinned);
+  if (rc)
+    p->concurrency = before;
+  return rc;
 }
 
 int asciichat_hip_plan_set_uniform(asciichat_hip_plan_t *p, int allow) {
@@ -596,9 +638,6 @@ int asciichat_hip_image_flip(const uint8_t *src_dev, uint8_t *dst_dev, int width
 }
 
 /* ---- wire stage -------------------------------------------------------------------------------- */
-static __thread uint32_t *t_crc_scratch; /* span registers of large buffers; grown on demand, one per thread */
-static __thread size_t t_crc_scratch_n;
-
 static int crc_common(const uint8_t *base_dev, size_t stride, const uint32_t *len_dev, uint32_t fixed_len,
                       uint32_t max_len, int n, const uint32_t *dims_dev, uint32_t *crc_out_dev, uint8_t *hdr_out_dev,
                       uint32_t *packet_crc_out_dev, void *stream) {
@@ -611,22 +650,23 @@ static int crc_common(const uint8_t *base_dev, size_t stride, const uint32_t *le
   const int parts = achip_crc_parts(max_len);
   uint32_t *scratch = NULL;
   if (parts > 1) {
-    const size_t need = (size_t)n * (size_t)parts;
-    if (need > t_crc_scratch_n) {
-      if (t_crc_scratch)
-        (void)hipFree(t_crc_scratch); /* synchronises with work that may still read the old block */
-      t_crc_scratch = NULL;
-      t_crc_scratch_n = 0;
-      rc = achip_hip_check((int)hipMalloc((void **)&t_crc_scratch, need * sizeof(uint32_t)), "hipMalloc(crc scratch)");
-      if (rc)
-        return rc;
-      t_crc_scratch_n = need;
-    }
-    scratch = t_crc_scratch;
+    /* span registers of large buffers: STREAM-ORDERED scratch, so that calls in flight on different streams (the
+     * plan API's normal use) never share a block (one thread-local block was shared by every stream) */
+    rc = achip_hip_check((int)hipMallocAsync((void **)&scratch, (size_t)n * (size_t)parts * sizeof(uint32_t),
+                                             (hipStream_t)stream),
+                         "hipMallocAsync(crc scratch)");
+    if (rc)
+      return rc;
   }
-  return achip_hip_check(achip_launch_crc32c(base_dev, stride, len_dev, fixed_len, max_len, n, scratch, dims_dev,
-                                             crc_out_dev, hdr_out_dev, packet_crc_out_dev, stream),
-                         "crc32c launch");
+  rc = achip_hip_check(achip_launch_crc32c(base_dev, stride, len_dev, fixed_len, max_len, n, scratch, dims_dev,
+                                           crc_out_dev, hdr_out_dev, packet_crc_out_dev, stream),
+                       "crc32c launch");
+  if (scratch) {
+    const int fr = achip_hip_check((int)hipFreeAsync(scratch, (hipStream_t)stream), "hipFreeAsync(crc scratch)");
+    if (!rc)
+      rc = fr;
+  }
+  return rc;
 }
 
 int asciichat_hip_crc32c(const uint8_t *base_dev, size_t stride, const uint32_t *len_dev, uint32_t fixed_len,

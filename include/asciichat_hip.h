@@ -159,8 +159,11 @@ int asciichat_hip_image_flip(const uint8_t *src_dev, uint8_t *dst_dev, int width
  *             buffer pool is DMA'd in place and must stay valid until `stream` has passed the copy; any other
  *             blob is copied to pinned staging first and may be released when publish returns.
  *   latest    device pointer + size of the newest published frame of a slot (NULL / 0 while the client has
- *             sent none: has_video = false) and makes consumer_stream wait for its upload.  The frame stays
- *             intact until the publish after next on that slot.
+ *             sent none: has_video = false) and makes consumer_stream wait for its upload.  The table remembers that
+ *             consumer_stream was handed this buffer: the upload that will overwrite it (the publish after next on
+ *             the slot) is ordered behind everything enqueued on consumer_stream up to that publish.  The pointer is
+ *             therefore good for work enqueued before the publish after next; call latest() again every tick.
+ *   forget_stream  before destroying a stream that was passed to latest()
  */
 typedef struct asciichat_hip_frame_table asciichat_hip_frame_table_t;
 int asciichat_hip_frame_table_create(asciichat_hip_frame_table_t **table, int n_slots);
@@ -169,6 +172,7 @@ int asciichat_hip_frame_table_publish(asciichat_hip_frame_table_t *table, int sl
                                       void *stream);
 int asciichat_hip_frame_table_latest(asciichat_hip_frame_table_t *table, int slot, void *consumer_stream,
                                      const uint8_t **pixels_dev, int *width, int *height, uint64_t *generation);
+void asciichat_hip_frame_table_forget_stream(asciichat_hip_frame_table_t *table, void *consumer_stream);
 
 /*
  * Wire stage after render, on DEVICE buffers, for the frames of a slab (frame i at

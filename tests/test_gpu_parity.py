@@ -633,3 +633,47 @@ def test_rccl_comm_and_grid_exchange_world1(gpu):
             plan.close()
         grid.close()
     comm.close()
+
+
+def test_frame_table_upload_waits_for_queued_readers(gpu):
+    """the publish after next on a slot overwrites the buffer that renders handed out by latest() may still
+    be reading.  A consumer stream is kept busy, a render of frame A is queued behind that work, then B and C are
+    published on another stream (C lands in A's buffer): the upload must go behind the queued render."""
+    import struct
+    pkg, torch = gpu
+    A, B, Cc = (orc.frame_hash_noise(1920, 1080, 900 + i) for i in range(3))
+
+    def blob_of(img):
+        return struct.pack(">II", img.shape[1], img.shape[0]) + np.ascontiguousarray(img).tobytes()
+
+    blobs = [blob_of(A), blob_of(B), blob_of(Cc)]
+    exp = oracle_convert(A, MODE_TRUE_FG, 80, 24, orc.PALETTE_STANDARD)
+    busy_src = torch.from_numpy(np.ascontiguousarray(orc.frame_hash_noise(3840, 2160, 5))).cuda()
+    pub, cons = torch.cuda.Stream(), torch.cuda.Stream()
+    for round_ in range(6):
+        table = pkg.FrameTable(1)
+        table.publish(0, blobs[0], pub.cuda_stream)
+        ptr, w, h, gen = table.latest(0, cons.cuda_stream)
+        # keep the consumer stream busy: 4K -> 400x120 half-block batches (~250 us each)
+        busy = pkg.Plan(MODE_HB_TRUE, orc.PALETTE_STANDARD,
+                        [pkg.frame_setup(busy_src.data_ptr(), 3840, 2160, 400, 120, 2, False, False, False)] * 256)
+        bout = torch.empty(256 * busy.stride, dtype=torch.uint8, device="cuda")
+        bln = torch.zeros(256, dtype=torch.int32, device="cuda")
+        for _ in range(8):
+            busy.render(bout.data_ptr(), busy.stride, bln.data_ptr(), cons.cuda_stream)
+        plan = pkg.Plan(MODE_TRUE_FG, orc.PALETTE_STANDARD, [pkg.frame_setup(ptr, w, h, 80, 24, 0, False, False, False)] * 64)
+        out = torch.zeros(64 * plan.stride, dtype=torch.uint8, device="cuda")
+        ln = torch.zeros(64, dtype=torch.int32, device="cuda")
+        plan.render(out.data_ptr(), plan.stride, ln.data_ptr(), cons.cuda_stream)   # queued, not yet running
+        table.publish(0, blobs[1], pub.cuda_stream)
+        table.publish(0, blobs[2], pub.cuda_stream)                               # overwrites A's buffer
+        torch.cuda.synchronize()
+        host, lens = out.cpu().numpy(), ln.cpu().numpy()
+        for k in range(64):
+            assert host[k * plan.stride:k * plan.stride + int(lens[k])].tobytes() == exp, (round_, k)
+        p2, w2, h2, g2 = table.latest(0, cons.cuda_stream)
+        assert g2 == 3 and p2 == ptr  # double buffering: C sits where A was
+        table.forget_stream(cons.cuda_stream)
+        plan.close()
+        busy.close()
+        table.close()
