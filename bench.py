@@ -484,6 +484,8 @@ def main():
     ap.add_argument("--no-hot", action="store_true",
                     help="skip the one-launch-at-a-time / same-batch comparison legs (profiling runs)")
     args = ap.parse_args()
+    if args.others in ("none", "''", '""'):
+        args.others = ""
     regions = args.regions if args.regions > 0 else max(5, min(60, 1200 // max(1, args.steps)))
 
     import torch
