@@ -157,6 +157,8 @@ def lib():
     L.asciichat_hip_grid_geometry.argtypes = [vp]
     L.asciichat_hip_grid_destroy.restype = None
     L.asciichat_hip_grid_destroy.argtypes = [vp]
+    L.asciichat_hip_set_coalesce_min_callers.restype = ci
+    L.asciichat_hip_set_coalesce_min_callers.argtypes = [ci]
     L.asciichat_hip_schedule_create.restype = ci
     L.asciichat_hip_schedule_create.argtypes = [C.POINTER(vp), C.POINTER(vp), ci, C.POINTER(vp), C.POINTER(vp), sz, ci, ci, ci]
     L.asciichat_hip_schedule_launch.restype = ci

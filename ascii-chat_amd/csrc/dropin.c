@@ -219,8 +219,9 @@ static char *render_with_lut(tls_ctx_t *c, const achip_lut_t *lut, int mode, con
   }
   if (parts > 1 && !c->part_sync) {
     const size_t bytes = (size_t)DROPIN_MAX_PARTS * sizeof(unsigned long long);
+    /* cleared on the thread's own (non-blocking) stream: a null-stream hipMemset is not ordered before its kernels */
     if (achip_hip_check((int)hipMalloc((void **)&c->part_sync, bytes), "hipMalloc(part_sync)") ||
-        achip_hip_check((int)hipMemset(c->part_sync, 0, bytes), "hipMemset(part_sync)"))
+        achip_hip_check((int)hipMemsetAsync(c->part_sync, 0, bytes, c->stream), "hipMemsetAsync(part_sync)"))
       return NULL;
   }
   c->epoch = c->epoch + 1u ? c->epoch + 1u : 1u;
@@ -295,14 +296,21 @@ static char *render_one(int mode, const char *palette, achip_frame_t *f, size_t 
 }
 
 static char *render_unpadded_one(int mode, const char *palette, achip_frame_t *f, size_t src_bytes) {
-  tls_ctx_t *c = tls_get();
-  if (!c)
+  if (achip_require_device())
     return NULL;
   const achip_lut_t *lut = NULL;
   if (achip_lut_get(palette, &lut))
     return NULL;
-  char *out = render_with_lut(c, lut, mode, palette, f, src_bytes); /* synchronous: the tables are free again */
-  achip_lut_put(lut);
+  /* many concurrent callers -- the reference's one render thread per client -- share launches (combine.c) */
+  achip_combine_enter();
+  int handled = 0;
+  char *out = achip_combine_render(mode, palette, lut, f, src_bytes, &handled);
+  if (!handled) { /* few callers in flight, or too large for a shared generation: this thread's own stream and staging */
+    tls_ctx_t *c = tls_get();
+    out = c ? render_with_lut(c, lut, mode, palette, f, src_bytes) : NULL;
+  }
+  achip_combine_leave();
+  achip_lut_put(lut); /* synchronous either way: the tables are free again */
   return out;
 }
 

@@ -21,6 +21,13 @@ int achip_hip_check(int hip_error, const char *what);
 int achip_lut_get(const char *palette, const achip_lut_t **out_dev);
 void achip_lut_put(const achip_lut_t *dev);
 
+/* combine.c: one frame through the flat-combining layer (f->src = host pixels).  *handled = 0: not combinable, take the
+ * direct path; else the malloc'd string or NULL (achip_fail has the reason). */
+void achip_combine_enter(void);
+void achip_combine_leave(void);
+char *achip_combine_render(int mode, const char *palette, const achip_lut_t *lut, const achip_frame_t *f, size_t src_bytes,
+                           int *handled);
+
 /* buffer_pool.c: device alias of a pointer inside a pinned pool block, or NULL */
 const void *achip_pool_device_ptr(const void *host_ptr);
 

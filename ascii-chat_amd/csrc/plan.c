@@ -268,6 +268,9 @@ static int plan_measure(asciichat_hip_plan_t *p, const achip_frame_t *frames) {
     int rc = achip_hip_check((int)hipMalloc((void **)&new_sync, bytes), "hipMalloc(part_sync)");
     if (!rc)
       rc = achip_hip_check((int)hipMemset(new_sync, 0, bytes), "hipMemset(part_sync)");
+    if (!rc) /* the launches that will poll these words run on the caller's streams, which do not wait for the null
+                stream: make the clear complete before anything can be launched (a rare path: plan creation / growth) */
+      rc = achip_hip_check((int)hipDeviceSynchronize(), "hipDeviceSynchronize(part_sync)");
     if (rc) {
       if (new_sync)
         (void)hipFree(new_sync);

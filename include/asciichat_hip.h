@@ -133,6 +133,16 @@ void asciichat_hip_schedule_destroy(asciichat_hip_schedule_t *sched);
 
 void asciichat_hip_plan_destroy(asciichat_hip_plan_t *plan);
 
+/*
+ * Drop-in layer: coalescing of concurrent calls (combine.c).  The reference's server calls
+ * ascii_convert_with_capabilities from one render thread per client; from `n` calls in flight on, those calls share
+ * launches (flat combining: one upload, one kernel per (mode, palette) group, one wait per generation of callers).
+ * n = 0 never, 1 always, default 24 -- below that every call launching on its own thread's stream is as fast or faster
+ * (profiles/r02_dropin_threads.txt).  Also settable with the environment variable ASCIICHAT_HIP_COALESCE.  Returns the
+ * previous setting.
+ */
+int asciichat_hip_set_coalesce_min_callers(int n);
+
 /* image_resize on device memory: nearest-neighbour, lib/video/rgba/image.c:267-328 */
 int asciichat_hip_resize(const uint8_t *src_dev, int src_w, int src_h, uint8_t *dst_dev, int dst_w, int dst_h,
                          void *stream);

@@ -29,7 +29,8 @@ static void *worker(void *arg) {
   for (int k = 0; k < j->calls; k++) {
     char *s = ascii_convert_with_capabilities(j->img, j->w, j->h, &j->caps, false, false, PALETTE_CHARS_STANDARD);
     if (!s) {
-      fprintf(stderr, "render failed\n");
+      extern const char *asciichat_hip_last_error(void);
+      fprintf(stderr, "render failed: %s\n", asciichat_hip_last_error());
       exit(1);
     }
     j->bytes += strlen(s);

@@ -185,6 +185,52 @@ def test_concurrent_render_threads(api):
     assert not errors
 
 
+def test_coalesced_calls_from_many_threads(api):
+    """combine.c: concurrent drop-in calls share launches.  32 threads with different images, sizes, colour levels, render
+    modes and palettes (so that one generation holds several (mode, palette) groups, whole-frame and row-band launches,
+    pool-pinned and pageable sources) with coalescing forced, then with the default threshold; every result compared
+    with the oracle."""
+    L = api.lib()
+    L.asciichat_hip_set_coalesce_min_callers.restype = C.c_int
+    L.asciichat_hip_set_coalesce_min_callers.argtypes = [C.c_int]
+    rng = np.random.default_rng(5)
+    jobs = []
+    for k in range(32):
+        w, h = [(640, 360), (320, 200), (1920, 1080), (97, 61)][k % 4]
+        im = orc.frame_hash_noise(w, h, 700 + k) if k % 3 else orc.frame_bars(w, h, k)
+        cl, rm = [(3, 0), (2, 0), (3, 2), (0, 0), (1, 0), (2, 2)][k % 6]
+        W, H = [(80, 24), (120, 40), (33, 17)][k % 3]
+        pal = [PAL, orc.PALETTE_BLOCKS.encode(), b"ab"][k % 3] if cl else PAL
+        asp = bool(k & 1)
+        jobs.append((im, cl, rm, W, H, pal, asp, orc.convert_with_caps(im, W, H, cl, rm, asp, asp, False, pal.decode())))
+    for setting in (1, 24):
+        before = L.asciichat_hip_set_coalesce_min_callers(setting)
+        errors = []
+
+        def worker(k):
+            im_np, cl, rm, W, H, pal, asp, exp = jobs[k]
+            pooled = None
+            if k % 4 == 2:  # the 1080p frames of every other such thread: pool-pinned, read in place
+                pooled = L.image_new_from_pool(im_np.shape[1], im_np.shape[0])
+                C.memmove(pooled.contents.pixels, np.ascontiguousarray(im_np).ctypes.data, im_np.size)
+            im = pooled.contents if pooled else as_image(api, im_np)
+            c = caps(api, cl, rm)
+            c.wants_padding = asp
+            for it in range(15):
+                got = api.take_string(L.ascii_convert_with_capabilities(C.byref(im), W, H, C.byref(c), asp, False, pal))
+                if got != exp:
+                    errors.append((k, it, None if got is None else len(got), len(exp)))
+                    break
+            if pooled:
+                L.image_destroy_to_pool(pooled)
+
+        ts = [threading.Thread(target=worker, args=(k,)) for k in range(32)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        L.asciichat_hip_set_coalesce_min_callers(before)
+        assert not errors, (setting, errors[:4])
+
+
 def test_grid_and_padding_host_utilities(api):
     L = api.lib()
     img = orc.frame_anchor_gradient()
