@@ -157,6 +157,14 @@ def lib():
     L.asciichat_hip_grid_geometry.argtypes = [vp]
     L.asciichat_hip_grid_destroy.restype = None
     L.asciichat_hip_grid_destroy.argtypes = [vp]
+    L.asciichat_hip_plan_render_crc.restype = ci
+    L.asciichat_hip_plan_render_crc.argtypes = [vp, vp, sz, vp, vp, vp]
+    L.asciichat_hip_plan_render_crc_profiled.restype = ci
+    L.asciichat_hip_plan_render_crc_profiled.argtypes = [vp, vp, sz, vp, vp, vp, vp]
+    L.asciichat_hip_plan_has_fused_crc.restype = ci
+    L.asciichat_hip_plan_has_fused_crc.argtypes = [vp]
+    L.asciichat_hip_packets_from_crc.restype = ci
+    L.asciichat_hip_packets_from_crc.argtypes = [vp, vp, ci, vp, vp, vp, vp]
     L.asciichat_hip_set_coalesce_min_callers.restype = ci
     L.asciichat_hip_set_coalesce_min_callers.argtypes = [ci]
     L.asciichat_hip_schedule_create.restype = ci
@@ -354,6 +362,15 @@ class Plan:
         rc = lib().asciichat_hip_plan_render_range(self._h, first, count, out_ptr, out_stride, len_ptr, stream)
         if rc != 0:
             raise RuntimeError(f"plan_render failed ({rc}): {last_error()}")
+
+    def render_crc(self, out_ptr, out_stride, len_ptr, crc_ptr, stream=0):
+        rc = lib().asciichat_hip_plan_render_crc(self._h, out_ptr, out_stride, len_ptr, crc_ptr, stream)
+        if rc != 0:
+            raise RuntimeError(f"plan_render_crc failed ({rc}): {last_error()}")
+
+    @property
+    def fused_crc(self):
+        return bool(lib().asciichat_hip_plan_has_fused_crc(self._h))
 
     def render_profiled(self, out_ptr, out_stride, len_ptr, prof_ptr, stream=0):
         rc = lib().asciichat_hip_plan_render_profiled(self._h, out_ptr, out_stride, len_ptr, prof_ptr, stream)

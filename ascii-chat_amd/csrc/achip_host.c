@@ -310,6 +310,17 @@ bool achip_palette_ascii_only(const char *palette_chars) {
 #define ACHIP_HOST_STREAM_FIRST 16
 #define ACHIP_HOST_STREAM_MAXBLK 2048
 
+/* cells ((pad_left + out_w) * out_h) of the largest frame: what ACHIP_UNIFORM_MAX_CELLS carries to the stream kernel */
+long achip_max_cells(const achip_frame_t *frames, int n_frames) {
+  long max_cells = 0;
+  for (int i = 0; i < n_frames; i++) {
+    const long c = (long)(frames[i].pad_left + frames[i].out_w) * (long)frames[i].out_h;
+    if (c > max_cells)
+      max_cells = c;
+  }
+  return max_cells;
+}
+
 int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, bool palette_ascii_only,
                           const int *variant_caps, int n_cus, int split_request, int forced_variant, int *variant,
                           int *parts, int *rows_per_part) {
@@ -337,12 +348,7 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
    * palette) have no run structure: whole-frame launches of them take the wave-autonomous stream kernel
    * (render_stream.hpp), whose waves gather, tokenise and drain independently -- no chunk, so no row-width limit,
    * only a bound on the cells of a frame.  ACHIP_STREAM_* below restate render_variants.h / render_stream.hpp. */
-  long max_cells = 0;
-  for (int i = 0; i < n_frames; i++) {
-    const long c = (long)(frames[i].pad_left + frames[i].out_w) * (long)frames[i].out_h;
-    if (c > max_cells)
-      max_cells = c;
-  }
+  const long max_cells = achip_max_cells(frames, n_frames);
   const bool cell_mode = mode == ACHIP_MODE_256_FG || mode == ACHIP_MODE_16_FG || mode == ACHIP_MODE_TRUE_BG ||
                          (mode == ACHIP_MODE_TRUE_FG && palette_ascii_only);
   const bool stream_forced = forced_variant >= ACHIP_HOST_STREAM_FIRST;

@@ -52,13 +52,19 @@ struct buffer_pool {
 static buffer_pool_t *g_pool;
 static pthread_mutex_t g_pool_mu = PTHREAD_MUTEX_INITIALIZER;
 
-/* registry of live pinned blocks so that any interior pointer can be resolved to its device alias */
+/* Registry of live pinned blocks, so that any interior pointer can be resolved to its device alias.  Every drop-in
+ * render call asks (is this image in the pinned pool?), from every render thread at once, while blocks come and go
+ * rarely: a SORTED array read under a sequence lock -- readers take no lock and write no shared word (a binary search
+ * between two reads of the sequence counter, retried if a writer was active), writers serialise on a mutex.
+ * (Round 1 took a global mutex and scanned up to 1024 entries linearly on every call.) */
 #define PIN_REG_MAX 1024
-static struct {
+typedef struct {
   const uint8_t *lo, *hi;
   const uint8_t *dev;
-} g_pins[PIN_REG_MAX];
+} pin_entry_t;
+static pin_entry_t g_pins[PIN_REG_MAX]; /* sorted by lo; blocks never overlap */
 static int g_pin_count;
+static unsigned g_pin_seq; /* odd while a writer is inside */
 static pthread_mutex_t g_pin_mu = PTHREAD_MUTEX_INITIALIZER;
 
 static uint64_t now_ns(void) {
@@ -70,40 +76,79 @@ static uint64_t now_ns(void) {
 static void *payload_of(pool_node_t *n) { return (uint8_t *)n + sizeof(pool_node_t); }
 static pool_node_t *node_of(const void *p) { return (pool_node_t *)((uint8_t *)p - sizeof(pool_node_t)); }
 
-static void pin_register(pool_node_t *n) {
+static void pin_write_begin(void) {
   pthread_mutex_lock(&g_pin_mu);
-  if (g_pin_count < PIN_REG_MAX) {
-    g_pins[g_pin_count].lo = (const uint8_t *)payload_of(n);
-    g_pins[g_pin_count].hi = g_pins[g_pin_count].lo + n->size;
-    g_pins[g_pin_count].dev = (const uint8_t *)n->device_alias;
-    g_pin_count++;
-  }
+  __atomic_store_n(&g_pin_seq, g_pin_seq + 1u, __ATOMIC_RELAXED);
+  __atomic_thread_fence(__ATOMIC_RELEASE); /* the odd counter is visible before any entry changes */
+}
+static void pin_write_end(void) {
+  __atomic_store_n(&g_pin_seq, g_pin_seq + 1u, __ATOMIC_RELEASE); /* entries are visible before the even counter */
   pthread_mutex_unlock(&g_pin_mu);
 }
 
+static void pin_register(pool_node_t *n) {
+  const uint8_t *lo = (const uint8_t *)payload_of(n);
+  pin_write_begin();
+  if (g_pin_count < PIN_REG_MAX) {
+    int at = g_pin_count;
+    while (at > 0 && g_pins[at - 1].lo > lo) { /* keep the array sorted: shift the tail up */
+      g_pins[at] = g_pins[at - 1];
+      at--;
+    }
+    g_pins[at].lo = lo;
+    g_pins[at].hi = lo + n->size;
+    g_pins[at].dev = (const uint8_t *)n->device_alias;
+    __atomic_store_n(&g_pin_count, g_pin_count + 1, __ATOMIC_RELAXED);
+  }
+  pin_write_end();
+}
+
 static void pin_unregister(pool_node_t *n) {
-  pthread_mutex_lock(&g_pin_mu);
+  const uint8_t *lo = (const uint8_t *)payload_of(n);
+  pin_write_begin();
   for (int i = 0; i < g_pin_count; i++) {
-    if (g_pins[i].lo == (const uint8_t *)payload_of(n)) {
-      g_pins[i] = g_pins[--g_pin_count];
+    if (g_pins[i].lo == lo) {
+      for (int k = i; k + 1 < g_pin_count; k++)
+        g_pins[k] = g_pins[k + 1];
+      __atomic_store_n(&g_pin_count, g_pin_count - 1, __ATOMIC_RELAXED);
       break;
     }
   }
-  pthread_mutex_unlock(&g_pin_mu);
+  pin_write_end();
 }
 
 const void *achip_pool_device_ptr(const void *host_ptr) {
   const uint8_t *p = (const uint8_t *)host_ptr;
-  const void *out = NULL;
-  pthread_mutex_lock(&g_pin_mu);
-  for (int i = 0; i < g_pin_count; i++) {
-    if (p >= g_pins[i].lo && p < g_pins[i].hi) {
-      out = g_pins[i].dev + (p - g_pins[i].lo);
-      break;
+  for (;;) {
+    const unsigned s0 = __atomic_load_n(&g_pin_seq, __ATOMIC_ACQUIRE);
+    if (s0 & 1u) { /* a writer is inside: it holds the mutex only for a few dozen stores */
+      __builtin_ia32_pause();
+      continue;
     }
+    /* the entry with the greatest lo <= p; indices stay inside the static array whatever a concurrent writer does,
+     * and a torn read is discarded by the sequence check below */
+    int lo_i = 0, hi_i = __atomic_load_n(&g_pin_count, __ATOMIC_RELAXED);
+    if (hi_i > PIN_REG_MAX)
+      hi_i = PIN_REG_MAX;
+    while (lo_i < hi_i) {
+      const int mid = (lo_i + hi_i) >> 1;
+      if (__atomic_load_n(&g_pins[mid].lo, __ATOMIC_RELAXED) <= p)
+        lo_i = mid + 1;
+      else
+        hi_i = mid;
+    }
+    const void *out = NULL;
+    if (lo_i > 0) {
+      const uint8_t *elo = __atomic_load_n(&g_pins[lo_i - 1].lo, __ATOMIC_RELAXED);
+      const uint8_t *ehi = __atomic_load_n(&g_pins[lo_i - 1].hi, __ATOMIC_RELAXED);
+      const uint8_t *edev = __atomic_load_n(&g_pins[lo_i - 1].dev, __ATOMIC_RELAXED);
+      if (p >= elo && p < ehi)
+        out = edev + (p - elo);
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    if (__atomic_load_n(&g_pin_seq, __ATOMIC_RELAXED) == s0)
+      return out;
   }
-  pthread_mutex_unlock(&g_pin_mu);
-  return out;
 }
 
 bool buffer_pool_is_pinned(const void *data) { return achip_pool_device_ptr(data) != NULL; }

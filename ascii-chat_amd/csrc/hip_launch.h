@@ -20,6 +20,15 @@ int achip_launch_render(int mode, int variant, int has_composite, const achip_fr
                         uint32_t epoch /* differs from launch to launch on the same part_sync */,
                         const achip_uniform_t *uniform /* NULL, or the batch's common descriptor (achip_frames_uniform) */,
                         void *stream);
+/* the same for a whole-frame launch of a per-cell mode in a stream geometry that carries the fused frame CRC
+ * (achip_variant_has_crc): crc_out[i] = asciichat_crc32(frame i), 0 for a frame that did not fit its slot */
+int achip_launch_render_crc(int mode, int variant, int has_composite, const achip_frame_t *frames_dev, int n_frames,
+                            const achip_lut_t *lut_dev, uint8_t *out, uint64_t out_stride, uint32_t *out_len,
+                            uint32_t *crc_out, const achip_uniform_t *uniform, unsigned long long *prof, void *stream);
+int achip_variant_has_crc(int variant);
+/* 24-byte ascii_frame_packet_t headers and header || frame CRCs from lengths + frame CRCs that are already known */
+int achip_launch_packets_from_crc(const uint32_t *len_dev, const uint32_t *crc_dev, const uint32_t *dims_dev, int n,
+                                  uint8_t *hdr_out, uint32_t *pkt_crc_out, void *stream);
 int achip_launch_resize(const uint8_t *src, int sw, int sh, uint8_t *dst, int dw, int dh, void *stream);
 int achip_launch_composite(const achip_composite_t *comp_dev, int canvas_w, int canvas_h, uint8_t *dst, void *stream);
 

@@ -28,7 +28,7 @@ extern "C" int achip_launch_render(int mode, int variant, int has_composite, con
 #define X(id, W, C)                                                                                                    \
   case id:                                                                                                             \
     return achip_render_sinst_launch_##id(mode, has_composite, frames_dev, n_frames, lut_dev, out, out_stride, out_len, \
-                                          uniform, prof, stream);
+                                          uniform, prof, nullptr, stream);
       ACHIP_STREAM_VARIANTS(X)
 #undef X
     }
@@ -43,6 +43,55 @@ extern "C" int achip_launch_render(int mode, int variant, int has_composite, con
 #undef X
   }
   return (int)hipErrorInvalidValue;
+}
+
+/* whole-frame launch of a per-cell mode with the frame CRC-32C riding the drain (stream geometries 16 / 17) */
+extern "C" int achip_launch_render_crc(int mode, int variant, int has_composite, const achip_frame_t *frames_dev,
+                                       int n_frames, const achip_lut_t *lut_dev, uint8_t *out, uint64_t out_stride,
+                                       uint32_t *out_len, uint32_t *crc_out, const achip_uniform_t *uniform,
+                                       unsigned long long *prof, void *stream) {
+  if (n_frames <= 0)
+    return (int)hipSuccess;
+  if (!crc_out)
+    return (int)hipErrorInvalidValue;
+  switch (variant) {
+#define X(id, W, C)                                                                                                    \
+  case id:                                                                                                             \
+    return achip_render_sinst_launch_##id(mode, has_composite, frames_dev, n_frames, lut_dev, out, out_stride, out_len, \
+                                          uniform, prof, crc_out, stream);
+    ACHIP_STREAM_VARIANTS(X)
+#undef X
+  }
+  return (int)hipErrorInvalidValue;
+}
+extern "C" int achip_variant_has_crc(int variant) { return variant == 16 || variant == 17; }
+
+/* headers + packet CRCs from frame CRCs that are already known (the fused render): one thread per frame */
+namespace achip {
+__global__ void __launch_bounds__(256)
+    crc_packets_kernel(const uint32_t *__restrict__ len, const uint32_t *__restrict__ crc_in, const uint32_t *__restrict__ dims,
+                       int n, uint8_t *__restrict__ hdr_out, uint32_t *__restrict__ pkt_crc_out) {
+  const int i = (int)(blockIdx.x * 256u + threadIdx.x);
+  if (i >= n)
+    return;
+  uint32_t L = len[i];
+  const bool bad = L >= 0xFFFFFFF0u;
+  if (bad)
+    L = 0;
+  const uint32_t w = dims && !bad ? dims[2 * i] : 0u, h = dims && !bad ? dims[2 * i + 1] : 0u;
+  const uint32_t crc = bad ? 0u : crc_in[i];
+  /* ~crc is the CRC register after the frame (from 0xFFFFFFFF): what crc32c_frame_kernel hands to crc_emit_packet */
+  crc_emit_packet(crc_header_state16(w, h, L), crc_x8_pow_len(L), ~crc, crc, w, h, L, bad, i, nullptr, hdr_out, pkt_crc_out);
+}
+} // namespace achip
+
+extern "C" int achip_launch_packets_from_crc(const uint32_t *len_dev, const uint32_t *crc_dev, const uint32_t *dims_dev,
+                                             int n, uint8_t *hdr_out, uint32_t *pkt_crc_out, void *stream) {
+  if (n <= 0)
+    return (int)hipSuccess;
+  hipLaunchKernelGGL(achip::crc_packets_kernel, dim3((unsigned)(n + 255) / 256u), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), len_dev, crc_dev, dims_dev, n, hdr_out, pkt_crc_out);
+  return (int)hipGetLastError();
 }
 
 extern "C" int achip_variant_block(int variant) {

@@ -190,6 +190,7 @@ struct asciichat_hip_plan {
   int max_wp;
   int has_comp; /* some frame samples a virtual composite */
   int parts, rows_per_part, split_request; /* multi-workgroup frames (achip_choose_geometry) */
+  long max_cells;                          /* cells of the largest frame (ACHIP_UNIFORM_MAX_CELLS)  */
   int palette_ascii;
   unsigned long long *part_sync; /* n * parts_cap u64 hand-off words, zeroed once */
   int parts_cap;
@@ -229,6 +230,7 @@ static int choose_geometry(asciichat_hip_plan_t *p, const achip_frame_t *frames)
   p->variant = variant;
   p->parts = parts;
   p->rows_per_part = rpp;
+  p->max_cells = achip_max_cells(frames, p->n);
   return 0;
 }
 
@@ -407,7 +409,7 @@ static int render_range(asciichat_hip_plan_t *p, int first, int count, uint8_t *
   achip_uniform_t uni = p->uniform;
   if (p->uniform_off)
     uni.enabled = 0;
-  uni.flags = p->palette_ascii ? ACHIP_UNIFORM_PALETTE_ASCII : 0u;
+  uni.flags = (p->palette_ascii ? ACHIP_UNIFORM_PALETTE_ASCII : 0u) | ACHIP_UNIFORM_MAX_CELLS(p->max_cells);
   uni.f.src = uni.f.src ? uni.f.src + (int64_t)first * uni.src_pitch : NULL;
   return achip_hip_check(achip_launch_render(p->mode, p->variant, p->has_comp, p->frames_dev + first, count, p->lut_dev,
                                              out_dev, (uint64_t)out_stride, out_len_dev, phase_cycles_dev, p->parts,
@@ -430,6 +432,58 @@ int asciichat_hip_plan_render_profiled(asciichat_hip_plan_t *p, uint8_t *out_dev
 int asciichat_hip_plan_render(asciichat_hip_plan_t *p, uint8_t *out_dev, size_t out_stride, uint32_t *out_len_dev,
                               void *stream) {
   return asciichat_hip_plan_render_range(p, 0, p ? p->n : 0, out_dev, out_stride, out_len_dev, stream);
+}
+
+/* Render + frame CRC-32C in one go ("a CRC over the output slab can ride the emit kernel").  Whole-frame
+ * launches of the per-cell modes carry the checksum inside the stream kernel's drain; every other plan renders and
+ * then runs the stand-alone CRC kernel on the slab -- same results either way. */
+static int plan_render_crc(asciichat_hip_plan_t *p, uint8_t *out_dev, size_t out_stride, uint32_t *out_len_dev,
+                           uint32_t *crc_out_dev, unsigned long long *prof, void *stream) {
+  if (!p || !out_dev || !out_len_dev || !crc_out_dev)
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "plan_render_crc: bad arguments");
+  if (((uintptr_t)out_dev & 15u) || (out_stride & 15u) || out_stride < p->stride)
+    return achip_fail(ASCIICHAT_HIP_ERR_BUFFER, "output slab must be 16-byte aligned with stride >= %zu (multiple of 16)",
+                      p->stride);
+  if (p->parts == 1 && achip_variant_has_crc(p->variant)) {
+    achip_uniform_t uni = p->uniform;
+    if (p->uniform_off)
+      uni.enabled = 0;
+    uni.flags = (p->palette_ascii ? ACHIP_UNIFORM_PALETTE_ASCII : 0u) | ACHIP_UNIFORM_MAX_CELLS(p->max_cells);
+    return achip_hip_check(achip_launch_render_crc(p->mode, p->variant, p->has_comp, p->frames_dev, p->n, p->lut_dev, out_dev,
+                                                   (uint64_t)out_stride, out_len_dev, crc_out_dev, &uni, prof, stream),
+                           "render + crc kernel launch");
+  }
+  int rc = render_range(p, 0, p->n, out_dev, out_stride, out_len_dev, prof, stream);
+  if (!rc)
+    rc = asciichat_hip_crc32c(out_dev, out_stride, out_len_dev, 0, (uint32_t)out_stride, p->n, crc_out_dev, stream);
+  return rc;
+}
+
+int asciichat_hip_plan_render_crc(asciichat_hip_plan_t *p, uint8_t *out_dev, size_t out_stride, uint32_t *out_len_dev,
+                                  uint32_t *crc_out_dev, void *stream) {
+  return plan_render_crc(p, out_dev, out_stride, out_len_dev, crc_out_dev, NULL, stream);
+}
+
+/* diagnostics: the same launch with the per-wave timestamps of plan_render_profiled */
+int asciichat_hip_plan_render_crc_profiled(asciichat_hip_plan_t *p, uint8_t *out_dev, size_t out_stride,
+                                           uint32_t *out_len_dev, uint32_t *crc_out_dev,
+                                           unsigned long long *phase_cycles_dev, void *stream) {
+  return plan_render_crc(p, out_dev, out_stride, out_len_dev, crc_out_dev, phase_cycles_dev, stream);
+}
+
+int asciichat_hip_plan_has_fused_crc(const asciichat_hip_plan_t *p) {
+  return p && p->parts == 1 && achip_variant_has_crc(p->variant);
+}
+
+int asciichat_hip_packets_from_crc(const uint32_t *len_dev, const uint32_t *crc_dev, int n, const uint32_t *dims_dev,
+                                   uint8_t *hdr_out_dev, uint32_t *packet_crc_out_dev, void *stream) {
+  if (!len_dev || !crc_dev || !hdr_out_dev || n <= 0)
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "packets_from_crc: bad arguments");
+  int rc = achip_require_device();
+  if (rc)
+    return rc;
+  return achip_hip_check(achip_launch_packets_from_crc(len_dev, crc_dev, dims_dev, n, hdr_out_dev, packet_crc_out_dev, stream),
+                         "packet header launch");
 }
 
 /* K steps issued from C: step k renders plans[k % n_plans] on streams[k % n_streams] into that stream's slab.  A

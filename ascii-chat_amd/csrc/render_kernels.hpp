@@ -262,6 +262,16 @@ __device__ inline uint32_t wave_inclusive_scan(uint32_t v) {
 }
 __device__ inline uint32_t wave_read_lane(uint32_t v, int lane) { return hipemu::shfl_from(v, lane); }
 __device__ inline int wave_uniform(int v) { return v; }
+/* xor over the wave; the result is valid in lane 63 */
+__device__ inline uint32_t wave_xor_to_last(uint32_t v) {
+  const int l = hipemu::lane();
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t t = hipemu::shfl_from(v, l - d);
+    if (l >= d)
+      v ^= t;
+  }
+  return v;
+}
 #else
 template <int CTRL, int ROW_MASK> __device__ inline uint32_t dpp_add(uint32_t v) {
   /* lanes whose DPP source is invalid (or whose row is masked off) add 0 */
@@ -274,6 +284,19 @@ __device__ inline uint32_t wave_inclusive_scan(uint32_t v) {
   v = dpp_add<0x118, 0xF>(v); /* row_shr:8  : every 16-lane row now holds its own inclusive scan */
   v = dpp_add<0x142, 0xA>(v); /* row_bcast:15 into rows 1 and 3 */
   v = dpp_add<0x143, 0xC>(v); /* row_bcast:31 into rows 2 and 3 */
+  return v;
+}
+template <int CTRL, int ROW_MASK> __device__ inline uint32_t dpp_xor(uint32_t v) {
+  return v ^ (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+/* xor over the wave; the result is valid in lane 63 */
+__device__ inline uint32_t wave_xor_to_last(uint32_t v) {
+  v = dpp_xor<0x111, 0xF>(v);
+  v = dpp_xor<0x112, 0xF>(v);
+  v = dpp_xor<0x114, 0xF>(v);
+  v = dpp_xor<0x118, 0xF>(v);
+  v = dpp_xor<0x142, 0xA>(v);
+  v = dpp_xor<0x143, 0xC>(v);
   return v;
 }
 __device__ inline uint32_t wave_read_lane(uint32_t v, int lane) {

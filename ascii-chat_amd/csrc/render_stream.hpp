@@ -36,6 +36,7 @@
 #pragma once
 
 #include "render_kernels.hpp"
+#include "crc_math.hpp" /* the GF(2) toolbox of the wire stage: the frame CRC can ride the drain */
 
 namespace achip {
 
@@ -53,18 +54,42 @@ __host__ __device__ constexpr int stream_max_token(int m) {
 #define ACHIP_STREAM_MAXBLK 2048            /* blocks per frame the look-back table holds              */
 #define ACHIP_STREAM_MAX_STRIDE 0x3F000000u /* block prefixes are 30-bit: slab slots up to ~1 GB        */
 
-template <int MODE, int WAVES, int CPL> struct SLds {
+template <int MODE, int WAVES, int CPL, bool CRC = false> struct SLds {
   static constexpr int BLK = 64 * CPL;
   static constexpr int STAGE = BLK * stream_max_token(MODE) + 16; /* + the 16-byte group the block starts in */
+  static constexpr int GPL = (STAGE / 16 + 63) / 64; /* 16-byte groups of a block per lane when it is checksummed */
   static constexpr int o_stage = 0;
   static constexpr int o_glyph = WAVES * STAGE;
   static constexpr int o_ramp = o_glyph + 256 * 4;
   static constexpr int o_dec = o_ramp + 64;
-  static constexpr int o_slots = o_dec + 256 * 4;
-  static constexpr int o_flags = o_slots + ACHIP_STREAM_MAXBLK * 4; /* [+16 ..] swallows predicated-off byte stores */
-  static constexpr int bytes = o_flags + 32 + 64 * 4;
-  static_assert(STAGE % 16 == 0, "staging areas stay 16-byte aligned");
+  static constexpr int o_flags = o_dec + 256 * 4; /* [+16 ..] swallows predicated-off byte stores */
+  /* CRC instantiations: constant tables, copied from global memory where crc_tables_init_kernel put them -- the 16
+   * slicing tables; window tables of the lanes' multipliers; x^(8v), x^(8*256v), x^(8*65536v); x^k (k = 0..62) -- then
+   * accumulator, deferred and finished counts */
+  static constexpr int o_tab = o_flags + 32 + 64 * 4;
+  static constexpr int o_slice = o_tab;
+  static constexpr int o_lanek = o_slice + (CRC ? 16 * 1024 : 0);
+  static constexpr int base_crc = o_lanek + (CRC ? 3 * 1024 + 256 + 16 + 2 * ACHIP_STREAM_MAXBLK * 4 : 0);
+  static constexpr int WIN = base_crc + 32 * 1024 <= 160 * 1024 ? 4 : 2; /* bits per window of the lane multiply */
+  static constexpr int NWIN = 32 / WIN;
+  static constexpr int o_pow = o_lanek + (CRC ? NWIN * (1 << WIN) * 64 * 4 : 0);
+  static constexpr int o_xk = o_pow + (CRC ? 3 * 1024 : 0);
+  static constexpr int TAB_BYTES = (CRC ? o_xk + 256 : o_tab) - o_tab; /* the image crc_tables_init_kernel writes */
+  static constexpr int o_crcacc = o_tab + TAB_BYTES; /* [0] acc [1] deferred [2] finished */
+  /* per-block words, as many as the launch's largest frame has blocks: look-back words {state:2, bytes:30}, and
+   * (CRC) behind them the raw CRC of a block that could not be placed yet */
+  static constexpr int o_slots = o_crcacc + (CRC ? 16 : 0);
+  static constexpr int bytes_for(int maxblk) { return o_slots + maxblk * 4 * (CRC ? 2 : 1); }
+  static constexpr int bytes = bytes_for(ACHIP_STREAM_MAXBLK);
+  static_assert(STAGE % 16 == 0 && o_tab % 16 == 0 && TAB_BYTES % 16 == 0, "16-byte aligned areas");
+  static_assert(bytes <= 160 * 1024, "one workgroup's LDS");
 };
+/* blocks the per-block LDS words of a launch hold: from the largest frame's cells when the host states them */
+__host__ __device__ constexpr int stream_maxblk(uint32_t uniform_flags, int blk_cells) {
+  const uint32_t cells = uniform_flags >> ACHIP_UNIFORM_MAX_CELLS_SHIFT;
+  const uint32_t nb = (cells + (uint32_t)blk_cells - 1u) / (uint32_t)blk_cells;
+  return cells == 0u || nb > (uint32_t)ACHIP_STREAM_MAXBLK ? ACHIP_STREAM_MAXBLK : (int)nb;
+}
 
 /* ---- workgroup-scope LDS words of the look-back ------------------------------------------------- */
 __device__ inline void slot_store(uint32_t *p, uint32_t v) {
@@ -79,6 +104,22 @@ __device__ inline uint32_t slot_load(const uint32_t *p) {
   return *reinterpret_cast<const volatile uint32_t *>(p);
 #else
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+}
+__device__ inline uint32_t slot_fetch_add(uint32_t *p, uint32_t v) {
+#ifdef ACHIP_HIPEMU
+  const uint32_t old = *reinterpret_cast<volatile uint32_t *>(p); /* fibers of one thread: no switch in between */
+  *reinterpret_cast<volatile uint32_t *>(p) = old + v;
+  return old;
+#else
+  return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+}
+__device__ inline void slot_xor(uint32_t *p, uint32_t v) {
+#ifdef ACHIP_HIPEMU
+  *reinterpret_cast<volatile uint32_t *>(p) = *reinterpret_cast<volatile uint32_t *>(p) ^ v;
+#else
+  (void)__hip_atomic_fetch_xor(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif
 }
 #define ACHIP_SLOT_AGG (1u << 30)
@@ -170,11 +211,108 @@ struct StreamTagCached {
   static constexpr bool value = false;
 };
 
-template <int MODE, int WAVES, int CPL, bool GENERIC>
+/* ---- GF(2) helpers of the fused frame CRC ----------------------------------------------------- */
+/* a * b mod P for WAVE-UNIFORM a, b, by the whole wave: lane k owns coefficient k of the 63-term carry-less product
+ * (parity of a's bits against b slid to position k) and contributes x^k mod P (xk, lane 63: 0); one xor reduction.
+ * ~14 instructions where the bit-serial crc_mulmod takes ~220.  Result uniform. */
+__device__ inline uint32_t wave_mulmod_uniform(uint32_t a, uint32_t b, int lane, uint32_t xk) {
+  /* reflected order: bit 31-i of a word is the coefficient of x^i.  Coefficient k of the product pairs bit p of a
+   * with bit 62-k-p of b: the parity of a & m_k, m_k = bitreverse(b) slid so that its bit 31 lands on bit 62-k */
+#ifdef ACHIP_HIPEMU /* g++ has no bit-reverse builtin */
+  uint32_t rb = 0;
+  for (int i = 0; i < 32; i++)
+    rb |= ((b >> i) & 1u) << (31 - i);
+#else
+  const uint32_t rb = __builtin_bitreverse32(b);
+#endif
+  const uint32_t m = (uint32_t)((((uint64_t)rb) << 31) >> lane);
+  const uint32_t c = (uint32_t)__builtin_popcount(a & m) & 1u;
+  return wave_read_lane(wave_xor_to_last((0u - c) & xk), 63);
+}
+/* x^(8n) for wave-uniform n from the LDS copies of CRC_POW_TAB's levels (n < 2^24; above: bit-serial fallback) */
+__device__ inline uint32_t wave_x8_pow_uniform(const uint32_t *pw, uint32_t n, int lane, uint32_t xk) {
+  if (n >> 24)
+    return crc_x8_pow_len(n);
+  uint32_t r = pw[n & 0xFFu];
+  if (n >> 8)
+    r = wave_mulmod_uniform(r, pw[256 + ((n >> 8) & 0xFFu)], lane, xk);
+  if (n >> 16)
+    r = wave_mulmod_uniform(r, pw[512 + (n >> 16)], lane, xk);
+  return r;
+}
+/* register s after m more zero bytes, 0 <= m <= 16: byte i of s is followed by m-1-i bytes (slicing rows) */
+__device__ inline uint32_t crc_advance16(const uint32_t *slice, uint32_t s, int m) {
+  uint32_t r = m < 4 ? (m ? s >> (8 * m) : s) : 0u;
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+    if (i < m)
+      r ^= slice[(m - 1 - i) * 256 + ((s >> (8 * i)) & 0xFFu)];
+  return r;
+}
+
+/* The constant tables of the CRC instantiation <MODE, WAVES, CPL>, written once per process into global memory (one
+ * workgroup of 256 threads; render_stream_inst.hip runs it before the first such launch); every launch copies the
+ * image into LDS.  Layout = SLds<.., true> from o_tab on. */
+template <int MODE, int WAVES, int CPL> __global__ void __launch_bounds__(256) crc_tables_init_kernel(uint32_t *tab) {
+  using L = SLds<MODE, WAVES, CPL, true>;
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint32_t *slice = tab + (L::o_slice - L::o_tab) / 4;
+  uint32_t *nib = tab + (L::o_lanek - L::o_tab) / 4;
+  uint32_t *pw = tab + (L::o_pow - L::o_tab) / 4;
+  uint32_t *xkt = tab + (L::o_xk - L::o_tab) / 4;
+  /* slice[k][b] = register after byte b followed by k zero bytes (as crc_build_tables) */
+  slice[tid] = crc_byte(0u, (uint32_t)tid);
+  for (int k = tid; k < 768; k += 256)
+    pw[k] = CRC_POW_TAB.t[k >> 8][k & 0xFF];
+  if (wave == 0) /* x^k mod P for the lane-parallel multiply; lane 63 takes no part */
+    xkt[lane] = lane == 63 ? 0u : (lane < 32 ? 0x80000000u >> lane : crc_mulmod(1u, 0x80000000u >> (lane - 31)));
+  if (wave == 1) {
+    /* lane l's GPL groups of a block are followed by 16*GPL*(63-l) bytes of the other lanes' groups: the lane's
+     * multiplier K_l = x^(8*16*GPL*(63-l)) as window tables, W[j][v][l] = (v placed at window j) * K_l, so that
+     * s * K_l is NWIN conflict-free lookups (the lane index is the bank).  Built bit by bit: K_l * x^i, i = 0..31. */
+    uint32_t kx = crc_x8_pow_len(16u * (uint32_t)L::GPL * (uint32_t)(63 - lane));
+    constexpr int WIN = L::WIN, NV = 1 << L::WIN;
+#pragma unroll
+    for (int j = 0; j < L::NWIN; j++) {
+      /* window j = bits [32-WIN*(j+1), 32-WIN*j) of the operand = coefficients x^(WIN*j) .. x^(WIN*j+WIN-1); bit t
+       * of the window value is the coefficient of x^(WIN*j + WIN-1-t) */
+      uint32_t basis[WIN];
+#pragma unroll
+      for (int t = WIN - 1; t >= 0; t--) {
+        basis[t] = kx;
+        kx = (kx & 1u) ? (kx >> 1) ^ CRC32C_POLY : kx >> 1; /* * x */
+      }
+      uint32_t w[NV];
+      w[0] = 0u;
+#pragma unroll
+      for (int v = 1; v < NV; v++) {
+        const int low = __builtin_ctz((unsigned)v);
+        w[v] = w[v & (v - 1)] ^ basis[low];
+      }
+#pragma unroll
+      for (int v = 0; v < NV; v++)
+        nib[(j * NV + v) * 64 + lane] = w[v];
+    }
+  }
+  __syncthreads();
+  uint32_t v = slice[tid];
+  for (int k = 1; k < 16; k++) {
+    v = (v >> 8) ^ slice[v & 0xFFu];
+    slice[k * 256 + tid] = v;
+  }
+}
+
+template <int MODE, int WAVES, int CPL, bool GENERIC, bool CRC = false>
 __global__ void __launch_bounds__(WAVES * 64)
     render_stream_kernel(const achip_frame_t *__restrict__ frames, const achip_lut_t *__restrict__ lut,
                          uint8_t *__restrict__ out, uint64_t out_stride, uint32_t *__restrict__ out_len, int n_frames,
-                         achip_uniform_t uni, unsigned long long *__restrict__ prof) {
+                         achip_uniform_t uni, unsigned long long *__restrict__ prof, uint32_t *__restrict__ crc_out,
+                         const uint4 *__restrict__ crc_tab) {
+  /* CRC = true: the frame's CRC-32C (asciichat_crc32, lib/network/crc32.c:95-190 -- what acip_send_ascii_frame puts
+   * into ascii_frame_packet_t.checksum, lib/network/acip/server.c:186-214) rides the drain: every wave checksums its
+   * block while the bytes are in its staging area, the last wave to finish combines the blocks (a CRC is linear over
+   * GF(2): raw(A || B) = raw(A) * x^(8|B|) xor raw(B)) and writes crc_out[frame].  crc_tab: the constant tables
+   * (crc_tables_init_kernel's image, SLds::TAB_BYTES).  Both unused otherwise. */
   /* prof (diagnostics, NULL in production launches): 8 timestamps of the 100 MHz wall clock per wave, for the wave's
    * FIRST block -- prof[(frame*WAVES + wave)*8 + k]: 0 kernel entry, 1 prologue barrier passed, 2 samples requested,
    * 3 samples arrived, 4 tokens + scan done, 5 look-back done, 6 token bytes in LDS, 7 stores issued */
@@ -188,7 +326,7 @@ __global__ void __launch_bounds__(WAVES * 64)
   } while (0)
 #endif
   static_assert(mode_is_cell(MODE), "run-structured modes use render_frames_kernel");
-  using L = SLds<MODE, WAVES, CPL>;
+  using L = SLds<MODE, WAVES, CPL, CRC>;
   constexpr int BLOCK = WAVES * 64;
   constexpr int BLK = L::BLK;
 
@@ -205,11 +343,23 @@ __global__ void __launch_bounds__(WAVES * 64)
                "s"(uni.enabled), "s"(uni.flags), "s"(uni.src_pitch), "s"(uni.f.src), "s"(uni.f.comp));
   asm volatile("" ::"s"(uni.f.src_w), "s"(uni.f.src_h), "s"(uni.f.out_w), "s"(uni.f.out_h), "s"(uni.f.pad_left),
                "s"(uni.f.pad_top), "s"(uni.f.x_ratio), "s"(uni.f.y_ratio), "s"(uni.f.src_stride), "s"(uni.f.ops));
+  if (CRC)
+    asm volatile("" ::"s"(crc_out), "s"(crc_tab));
 #endif
   if (fidx >= n_frames)
     return;
   bool first_block = true;
   ACHIP_SSTAMP(0);
+  /* CRC: the constant tables are requested before anything else (L2 hits after a process's first launch) and go to
+   * LDS in front of the barrier below; nothing of them is computed here */
+  constexpr int TABV = L::TAB_BYTES / 16, TABN = (TABV + BLOCK - 1) / BLOCK;
+  typedef uint32_t tab4_t __attribute__((vector_size(16))); /* a native vector: HIP's uint4 class keeps the array in scratch */
+  tab4_t tabv[TABN > 0 ? TABN : 1];
+  if (CRC) {
+#pragma unroll
+    for (int k = 0; k < TABN; k++) /* clamped, not predicated: the values stay in registers */
+      tabv[k] = reinterpret_cast<const tab4_t *>(crc_tab)[tid + k * BLOCK < TABV ? tid + k * BLOCK : TABV - 1];
+  }
 
   /* glyph tables are requested first, the first block's samples right behind (the descriptor came with the kernel
    * arguments for uniform batches): one overlapped latency in front of the only barrier */
@@ -236,13 +386,18 @@ __global__ void __launch_bounds__(WAVES * 64)
   const long long cells_ll = (long long)rows * (long long)wp;
   if (f.out_w <= 0 || f.out_h <= 0 || f.src_w <= 0 || f.src_h <= 0 || f.pad_left < 0 || f.pad_top < 0 ||
       (!f.src && !f.comp) || (!GENERIC && (f.comp || f.src_w * f.src_h == 1)) ||
-      cells_ll > (long long)ACHIP_STREAM_MAXBLK * BLK || out_stride > (uint64_t)ACHIP_STREAM_MAX_STRIDE) {
-    if (tid == 0)
+      cells_ll > (long long)stream_maxblk(uni.flags, BLK) * BLK || out_stride > (uint64_t)ACHIP_STREAM_MAX_STRIDE) {
+    if (tid == 0) {
       out_len[fidx] = ACHIP_LEN_BADDESC;
+      if (CRC)
+        crc_out[fidx] = 0u;
+    }
     return;
   }
   const uint32_t ncells = (uint32_t)cells_ll;
   const int nblk = (int)((ncells + BLK - 1) / BLK);
+  const int nblk_cap = stream_maxblk(uni.flags, BLK); /* words in each per-block LDS array of this launch */
+  (void)nblk_cap;
   const uint32_t cap_bytes = (uint32_t)out_stride;
   const uint32_t pad_left = (uint32_t)f.pad_left, uwp = (uint32_t)wp;
   StreamSrc src;
@@ -345,6 +500,16 @@ __global__ void __launch_bounds__(WAVES * 64)
   for (int k = tid; k < nblk; k += BLOCK)
     slots[k] = 0u;
   (void)ramp;
+  if (CRC) {
+#pragma unroll
+    for (int k = 0; k < TABN; k++)
+      if (tid + k * BLOCK < TABV)
+        lds_ptr<tab4_t>(L::o_tab)[tid + k * BLOCK] = tabv[k];
+    for (int k = tid; k < nblk; k += BLOCK)
+      slots[nblk_cap + k] = 0u; /* raw CRCs of blocks that could not be placed */
+    if (tid < 4)
+      lds_ptr<uint32_t>(L::o_crcacc)[tid] = 0u;
+  }
   /* ascii_pad_frame_height (ascii.c:902-941): pad_top bare newlines in front of the frame */
   const uint32_t first_base = (uint32_t)f.pad_top;
   if (first_base > 0u && first_base <= cap_bytes)
@@ -478,6 +643,9 @@ __global__ void __launch_bounds__(WAVES * 64)
     if (ok) {
       /* ---- token bytes into this wave's staging area: stream offset g0 (16-byte aligned) sits at its byte 0 */
       const uint32_t g0 = base & ~15u;
+      if (CRC && lane == 0) /* the bytes in front of the block inside its first 16-byte group read as zero for the
+                               checksum: leading zeros do not move a zero register (program order: before the tokens) */
+        *lds_ptr<uint4>((int)stage_off) = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
       for (int k = 0; k < CPL; k++)
         if (len[k] != 0u) {
@@ -489,7 +657,8 @@ __global__ void __launch_bounds__(WAVES * 64)
 #endif
         }
       lds_store_fence(); /* DS operations of one wave complete in order: the reads below see every lane's bytes */
-      ACHIP_SSTAMP(6);
+      if (!CRC)
+        ACHIP_SSTAMP(6);
 
       /* ---- staging -> HBM: whole 16-byte groups as uint4, the shared first / last group as bytes */
       const unsigned char *stage = lds_ptr<const unsigned char>((int)stage_off);
@@ -510,13 +679,115 @@ __global__ void __launch_bounds__(WAVES * 64)
       if (lane >= 32 && tail_begin + (uint32_t)(lane - 32) < end)
         dst[tail_begin + (uint32_t)(lane - 32)] = stage[tail_begin + (uint32_t)(lane - 32) - g0];
     }
-    ACHIP_SSTAMP(7);
+    ACHIP_SSTAMP(CRC ? 6 : 7); /* CRC instantiations: 6 = stores issued, 7 = block checksummed and placed */
+    const bool stamp_crc = first_block;
     first_block = false;
     if (blk == nblk - 1 && lane == 0) {
       out_len[fidx] = ok ? base + total : ACHIP_LEN_OVERFLOW;
       if (ok && (uint64_t)base + total < out_stride)
         dst[base + total] = 0; /* NUL behind the frame when the slot has room, as the reference's strings carry */
     }
+    if (CRC) {
+      /* ---- raw CRC of the block, from the staging area (after the stores to HBM have been issued).  Its bytes sit
+       * at [p0, end_off) of the area; [0, p0) is zero.  Whole 16-byte groups: lane l folds GPL consecutive groups
+       * Horner-style, the groups aligned to the END of the block so that absent ones are leading zeros; a 6-level
+       * wave tree with constant multipliers combines the lanes; the < 16 tail bytes come in through the slicing
+       * tables with one variable multiplication. */
+      const uint32_t *slice = lds_ptr<const uint32_t>(L::o_slice);
+      const uint32_t *pw = lds_ptr<const uint32_t>(L::o_pow);
+      uint32_t *crcval = slots + nblk_cap;
+      uint32_t *crcacc = lds_ptr<uint32_t>(L::o_crcacc);
+      const uint32_t xk = lds_ptr<const uint32_t>(L::o_xk)[lane];
+      if (ok) {
+        const unsigned char *stage = lds_ptr<const unsigned char>((int)stage_off);
+        const uint32_t end_off = (base & 15u) + total;
+        const int m_full = (int)(end_off >> 4), tail = (int)(end_off & 15u);
+        constexpr int GPL = L::GPL;
+        const int shift = 64 * GPL - m_full;
+        uint32_t sreg = 0;
+#pragma unroll
+        for (int k = 0; k < GPL; k++) {
+          const int g = lane * GPL + k - shift;
+          uint4 d = make_uint4(0u, 0u, 0u, 0u);
+          if (g >= 0)
+            d = *reinterpret_cast<const uint4 *>(stage + 16 * g);
+          d.x ^= sreg; /* the register so far goes in with the next 16 bytes: slicing-by-16, no multiplication */
+          sreg = crc_raw16(slice, d);
+        }
+        /* sreg * K_l through the window tables, xor over the lanes = raw CRC of the whole groups */
+        const uint32_t *nib = lds_ptr<const uint32_t>(L::o_lanek);
+        uint32_t term = 0;
+#pragma unroll
+        for (int j = 0; j < L::NWIN; j++)
+          term ^= nib[(j * (1 << L::WIN) + (int)((sreg >> (32 - L::WIN * (j + 1))) & ((1u << L::WIN) - 1u))) * 64 + lane];
+        const uint32_t full = wave_read_lane(wave_xor_to_last(term), 63);
+        /* the < 16 tail bytes: the register moves on by `tail` bytes; tail byte j is followed by tail-1-j bytes */
+        uint32_t tb = 0;
+        if (lane < tail)
+          tb = slice[(tail - 1 - lane) * 256 + stage[16 * m_full + lane]];
+        const uint32_t braw = crc_advance16(slice, full, tail) ^ wave_read_lane(wave_xor_to_last(tb), 63);
+        /* place the block in the frame: * x^(8 * bytes behind it).  The frame's length is the last block's prefix,
+         * known as soon as every wave has tokenised -- usually long before a wave gets here; a block that cannot be
+         * placed yet leaves its raw value for the wave that finishes the frame. */
+        const uint32_t lastw = slot_load(&slots[nblk - 1]);
+        if ((lastw >> 30) == 2u) {
+          const uint32_t n_total = lastw & ACHIP_SLOT_VALUE;
+          if (n_total <= cap_bytes) {
+            const uint32_t placed =
+                wave_mulmod_uniform(braw, wave_x8_pow_uniform(pw, n_total - (base + total), lane, xk), lane, xk);
+            if (lane == 0)
+              slot_xor(&crcacc[0], placed);
+
+          }
+        } else if (lane == 0) {
+          crcval[blk] = braw;
+          (void)slot_fetch_add(&crcacc[1], 1u);
+        }
+      }
+      uint32_t arrived = 0;
+      if (lane == 0)
+        arrived = slot_fetch_add(&crcacc[2], 1u);
+      arrived = wave_read_lane(arrived, 0);
+      if (arrived == (uint32_t)nblk - 1u) {
+        /* the last block to finish completes the frame: crc(M) = ~(0xFFFFFFFF * x^(8|M|) xor raw(M)), M = pad_top
+         * newlines || block 0 || block 1 || ...  Every prefix is in the look-back words by now. */
+        const uint32_t n_total = slot_load(&slots[nblk - 1]) & ACHIP_SLOT_VALUE;
+        const bool fits = n_total <= cap_bytes;
+        uint32_t total_raw = 0;
+        if (fits) {
+          total_raw = wave_mulmod_uniform(0xFFFFFFFFu, wave_x8_pow_uniform(pw, n_total, lane, xk), lane, xk);
+          if (first_base > 0u) { /* ascii_pad_frame_height's newlines in front: lanes take runs of them */
+            const uint32_t per = (first_base + 63u) / 64u;
+            const uint32_t lo = (uint32_t)lane * per, hi = lo + per < first_base ? lo + per : first_base;
+            uint32_t st = 0;
+            for (uint32_t k = lo; k < hi; k++)
+              st = (st >> 8) ^ slice[(st ^ (uint32_t)'\n') & 0xFFu];
+            if (lo < hi)
+              st = crc_mulmod(st, crc_x8_pow_len(n_total - hi));
+            total_raw ^= wave_read_lane(wave_xor_to_last(lo < hi ? st : 0u), 63);
+          }
+          if (slot_load(&crcacc[1]) != 0u) { /* blocks that finished before the frame's length was known */
+            uint32_t acc = 0;
+            for (int b0 = 0; b0 < nblk; b0 += 64) {
+              const int b = b0 + lane;
+              const uint32_t v = b < nblk ? crcval[b] : 0u;
+              if (v != 0u)
+                acc ^= crc_mulmod(v, crc_x8_pow_len(n_total - (slot_load(&slots[b]) & ACHIP_SLOT_VALUE)));
+            }
+            total_raw ^= wave_read_lane(wave_xor_to_last(acc), 63);
+          }
+          total_raw ^= slot_load(&crcacc[0]);
+        }
+        if (lane == 0)
+          crc_out[fidx] = fits ? ~total_raw : 0u;
+      }
+    }
+
+#ifndef ACHIP_HIPEMU
+    if (CRC && prof && lane == 0 && stamp_crc)
+      prof[((size_t)fidx * WAVES + wave) * 8u + 7] = wall_clock64();
+#endif
+    (void)stamp_crc;
 
     /* ---- next block */
     cell0 = cell0_next;

@@ -5,6 +5,8 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include "render_inst.h"
 #define ACHIP_FRAME_KERNEL_ONLY
 #include "render_stream.hpp"
@@ -25,11 +27,40 @@ ACHIP_STREAM_VARIANTS(X)
 #undef X
 using G = SGeometry<ACHIP_SINST>;
 
-template <int MODE, bool COMP>
+/* the frame CRC rides the drain (CRC = true) in the two geometries the policy picks by itself */
+constexpr bool HAS_CRC = ACHIP_SINST == 16 || ACHIP_SINST == 17;
+
+/* the constant tables of <MODE>'s CRC instantiation: built on the device once per process, then read-only */
+template <int MODE> hipError_t crc_tables(const uint4 **out) {
+  using L = achip::SLds<MODE, G::WAVES, G::CPL, true>;
+  static std::mutex mu;
+  static uint32_t *tab = nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!tab) {
+    uint32_t *t = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&t), (size_t)L::TAB_BYTES);
+    if (e != hipSuccess)
+      return e;
+    hipLaunchKernelGGL((achip::crc_tables_init_kernel<MODE, G::WAVES, G::CPL>), dim3(1), dim3(256), 0, nullptr, t);
+    e = hipGetLastError();
+    if (e == hipSuccess)
+      e = hipDeviceSynchronize(); /* launches on every stream may read it from here on */
+    if (e != hipSuccess) {
+      (void)hipFree(t);
+      return e;
+    }
+    tab = t;
+  }
+  *out = reinterpret_cast<const uint4 *>(tab);
+  return hipSuccess;
+}
+
+template <int MODE, bool COMP, bool CRC>
 hipError_t launch_one(const achip_frame_t *frames, int n, const achip_lut_t *lut, uint8_t *out, uint64_t stride,
-                      uint32_t *len, const achip_uniform_t &uni, unsigned long long *prof, hipStream_t stream) {
-  using L = achip::SLds<MODE, G::WAVES, G::CPL>;
-  auto kern = achip::render_stream_kernel<MODE, G::WAVES, G::CPL, COMP>;
+                      uint32_t *len, const achip_uniform_t &uni, unsigned long long *prof, uint32_t *crc_out,
+                      hipStream_t stream) {
+  using L = achip::SLds<MODE, G::WAVES, G::CPL, CRC>;
+  auto kern = achip::render_stream_kernel<MODE, G::WAVES, G::CPL, COMP, CRC>;
   static bool attr_set = false; /* one flag per instantiation; benign race (idempotent call) */
   if (!attr_set) {
     if (L::bytes > 48 * 1024) {
@@ -40,8 +71,17 @@ hipError_t launch_one(const achip_frame_t *frames, int n, const achip_lut_t *lut
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(G::WAVES * 64), (size_t)L::bytes, stream, frames, lut, out, stride,
-                     len, n, uni, prof);
+  const uint4 *tab = nullptr;
+  if constexpr (CRC) {
+    hipError_t e = crc_tables<MODE>(&tab);
+    if (e != hipSuccess)
+      return e;
+  }
+  /* the per-block words are sized by the launch's largest frame when the host states it: a small footprint lets
+   * workgroups of launches in flight on other streams share a CU */
+  const size_t lds = (size_t)((L::bytes_for(achip::stream_maxblk(uni.flags, L::BLK)) + 15) & ~15);
+  hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(G::WAVES * 64), lds, stream, frames, lut, out, stride, len, n, uni,
+                     prof, crc_out, tab);
   return hipGetLastError();
 }
 
@@ -53,7 +93,8 @@ hipError_t launch_one(const achip_frame_t *frames, int n, const achip_lut_t *lut
 extern "C" int ACHIP_CAT(achip_render_sinst_launch_, ACHIP_SINST)(int mode, int comp, const achip_frame_t *frames, int n,
                                                                   const achip_lut_t *lut, uint8_t *out, uint64_t stride,
                                                                   uint32_t *len, const achip_uniform_t *uniform,
-                                                                  unsigned long long *prof, void *stream) {
+                                                                  unsigned long long *prof, uint32_t *crc_out,
+                                                                  void *stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   achip_uniform_t uni = {};
   if (uniform && uniform->enabled && !comp)
@@ -63,8 +104,15 @@ extern "C" int ACHIP_CAT(achip_render_sinst_launch_, ACHIP_SINST)(int mode, int 
   switch (mode) {
 #define M(m)                                                                                                           \
   case m:                                                                                                              \
-    return (int)(comp ? launch_one<m, true>(frames, n, lut, out, stride, len, uni, prof, s)                                  \
-                      : launch_one<m, false>(frames, n, lut, out, stride, len, uni, prof, s));
+    if (crc_out) {                                                                                                     \
+      if constexpr (HAS_CRC)                                                                                           \
+        return (int)(comp ? launch_one<m, true, true>(frames, n, lut, out, stride, len, uni, prof, crc_out, s)         \
+                          : launch_one<m, false, true>(frames, n, lut, out, stride, len, uni, prof, crc_out, s));      \
+      else                                                                                                             \
+        return (int)hipErrorInvalidValue;                                                                              \
+    }                                                                                                                  \
+    return (int)(comp ? launch_one<m, true, false>(frames, n, lut, out, stride, len, uni, prof, nullptr, s)            \
+                      : launch_one<m, false, false>(frames, n, lut, out, stride, len, uni, prof, nullptr, s));
     M(ACHIP_MODE_TRUE_FG)
     M(ACHIP_MODE_256_FG)
     M(ACHIP_MODE_16_FG)

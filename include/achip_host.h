@@ -87,6 +87,7 @@ int achip_frame_blob_parse(const void *blob, size_t size, bool exact, uint32_t *
  *   forced_variant   >= 0: use this geometry (tuning), -1: choose
  * Outputs the geometry id, bands per frame (1 = no split) and text rows per band.  Returns 0, or -1 when a
  * padded row does not fit the geometry. */
+long achip_max_cells(const achip_frame_t *frames, int n_frames);
 int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, bool palette_ascii_only,
                           const int *variant_caps, int n_cus, int split_request, int forced_variant, int *variant,
                           int *parts, int *rows_per_part);

@@ -72,6 +72,10 @@ typedef struct {
   uint32_t flags; /* ACHIP_UNIFORM_*: launch-wide facts that travel with the kernel arguments even when enabled == 0 */
 } achip_uniform_t;
 #define ACHIP_UNIFORM_PALETTE_ASCII 1u /* every glyph of the launch's palette is a single byte < 0x80 */
+/* bits 31..8: cells ((pad_left + out_w) * out_h) of the launch's largest frame, 0 = not stated.  The stream kernel
+ * sizes its per-block LDS words from it (a frame with more cells than stated is refused: ACHIP_LEN_BADDESC). */
+#define ACHIP_UNIFORM_MAX_CELLS_SHIFT 8
+#define ACHIP_UNIFORM_MAX_CELLS(cells) ((uint32_t)((cells) > 0 && (cells) < (1l << 24) ? (cells) : 0) << ACHIP_UNIFORM_MAX_CELLS_SHIFT)
 
 /* achip_frame_t.ops: the client display path flips the frame and applies a monochrome tint on full-frame
  * copies before rendering (src/common/session/display.c:546-623, lib/video/rgba/color_filter.c:246-345).

@@ -246,6 +246,23 @@ const achip_composite_t *asciichat_hip_grid_composite_dev(const asciichat_hip_gr
 const achip_composite_t *asciichat_hip_grid_geometry(const asciichat_hip_grid_t *grid);      /* host copy: canvas size .. */
 void asciichat_hip_grid_destroy(asciichat_hip_grid_t *grid);
 
+/*
+ * Render + checksum in one launch: crc_out_dev[i] = asciichat_crc32(frame i) (0 for a frame that did not fit its slot).
+ * For whole-frame launches of the per-cell modes (plan_has_fused_crc() == 1) the CRC rides the render kernel's drain --
+ * the frame's bytes are checksummed while they sit in LDS on their way out -- instead of a second pass over the slab;
+ * any other plan renders and then runs asciichat_hip_crc32c, with the same results.  packets_from_crc() then builds the
+ * 24-byte ascii_frame_packet_t headers and the header || frame CRCs from lengths + frame CRCs (one thread per frame),
+ * the rest of what asciichat_hip_frame_packets does.
+ */
+int asciichat_hip_plan_render_crc(asciichat_hip_plan_t *plan, uint8_t *out_dev, size_t out_stride, uint32_t *out_len_dev,
+                                  uint32_t *crc_out_dev, void *stream);
+int asciichat_hip_plan_render_crc_profiled(asciichat_hip_plan_t *plan, uint8_t *out_dev, size_t out_stride,
+                                           uint32_t *out_len_dev, uint32_t *crc_out_dev,
+                                           unsigned long long *phase_cycles_dev, void *stream); /* diagnostics */
+int asciichat_hip_plan_has_fused_crc(const asciichat_hip_plan_t *plan);
+int asciichat_hip_packets_from_crc(const uint32_t *len_dev, const uint32_t *crc_dev, int n, const uint32_t *dims_dev,
+                                   uint8_t *hdr_out_dev, uint32_t *packet_crc_out_dev, void *stream);
+
 /* Upload a composite descriptor for use as achip_frame_t.comp; free with asciichat_hip_free. */
 int asciichat_hip_composite_upload(const achip_composite_t *comp_host, achip_composite_t **comp_dev);
 void asciichat_hip_free(void *dev_ptr);

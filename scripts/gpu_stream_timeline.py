@@ -19,6 +19,9 @@ def main():
     torch.cuda.set_device(0)
     name = sys.argv[1] if len(sys.argv) > 1 else "1080p_80x24_truecolor"
     variant = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+    with_crc = len(sys.argv) > 3 and sys.argv[3] == "crc"  # the instantiation that carries the frame CRC
+    if with_crc:
+        NAMES[6], NAMES[7] = "stores issued", "block checksummed + placed"
     sw, sh, W, H, cl, rm = bench.WORKLOADS[name]
     sets = [bench.make_frames(torch, 256, sw, sh, 900 + s) for s in range(6)]
     plans = [bench.build_plan(pkg, t, W, H, cl, rm)[0] for t in sets]
@@ -28,16 +31,22 @@ def main():
     out = torch.empty(256 * plans[0].stride, dtype=torch.uint8, device="cuda")
     ln = torch.zeros(256, dtype=torch.int32, device="cuda")
     prof = torch.zeros(256 * waves * 8, dtype=torch.int64, device="cuda")
+    crc = torch.zeros(256, dtype=torch.int32, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
     acc = []
     for k in range(12):
         prof.zero_()
         torch.cuda.synchronize()
-        plans[k % len(plans)].render_profiled(out.data_ptr(), plans[0].stride, ln.data_ptr(), prof.data_ptr(), st)
+        if with_crc:
+            rc = pkg.lib().asciichat_hip_plan_render_crc_profiled(plans[k % len(plans)]._h, out.data_ptr(), plans[0].stride,
+                                                                  ln.data_ptr(), crc.data_ptr(), prof.data_ptr(), st)
+            assert rc == 0, pkg.last_error()
+        else:
+            plans[k % len(plans)].render_profiled(out.data_ptr(), plans[0].stride, ln.data_ptr(), prof.data_ptr(), st)
         torch.cuda.synchronize()
         if k >= 4:
             acc.append(prof.cpu().numpy().reshape(256, waves, 8).astype(np.int64))
-    print(f"# {name} variant {variant}: {waves} waves per frame, 100 MHz wall clock -> us; per stamp over all active waves of 8 launches")
+    print(f"# {name} variant {variant}{' + fused frame CRC' if with_crc else ''}: {waves} waves per frame, 100 MHz wall clock -> us; per stamp over all active waves of 8 launches")
     print(f"# {'stamp':28s} {'min':>7s} {'p10':>7s} {'median':>7s} {'p90':>7s} {'max':>7s}")
     rows = [[] for _ in range(8)]
     for a in acc:

@@ -81,7 +81,7 @@ def main():
         scratch = int(k.get("private_segment_fixed_size", 0))
         limit, why = None, ""
         m = re.search(r"render_frames_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb([01])ELb([01])E", name)
-        ms = re.search(r"render_stream_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb([01])E", name)
+        ms = re.search(r"render_stream_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb([01])ELb([01])E", name)
         if m:
             mode, block = int(m.group(1)), int(m.group(2))
             short = f"render_frames_kernel<mode {mode}, {block} thr, cap {m.group(3)}, comp {m.group(5)}, split {m.group(6)}>"
@@ -89,8 +89,13 @@ def main():
                 limit, why = 128, "two (four) workgroups per CU"
         elif ms:
             mode, waves, cpl = int(ms.group(1)), int(ms.group(2)), int(ms.group(3))
-            short = f"render_stream_kernel<mode {mode}, {waves} waves, {cpl} cells/lane, generic {ms.group(4)}>"
-            limit, why = (72, "7 waves per SIMD") if mode == 4 else (64, "8 waves per SIMD")
+            crc = ms.group(5) == "1"
+            short = (f"render_stream_kernel<mode {mode}, {waves} waves, {cpl} cells/lane, generic {ms.group(4)}"
+                     f"{', +crc' if crc else ''}>")
+            if crc:  # the checksum's 16-byte groups are in flight next to the following block's samples
+                limit, why = 128, "4 waves per SIMD: one 16-wave or two 8-wave workgroups per CU (LDS allows no more)"
+            else:
+                limit, why = (72, "7 waves per SIMD") if mode == 4 else (64, "8 waves per SIMD")
         else:
             short = demangle(name).split("(")[0][-70:]
         problems = []

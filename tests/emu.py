@@ -18,7 +18,7 @@ _lib = None
 
 def build():
     srcs = [os.path.join(EMU_DIR, "emu_driver.cpp"), os.path.join(EMU_DIR, "hip_emu.h"),
-            os.path.join(CSRC, "render_kernels.hpp"), os.path.join(CSRC, "render_stream.hpp"), os.path.join(CSRC, "stream_kernels.hpp"), os.path.join(CSRC, "crc_kernels.hpp"),
+            os.path.join(CSRC, "render_kernels.hpp"), os.path.join(CSRC, "render_stream.hpp"), os.path.join(CSRC, "stream_kernels.hpp"), os.path.join(CSRC, "crc_kernels.hpp"), os.path.join(CSRC, "crc_math.hpp"),
             os.path.join(CSRC, "render_variants.h"),
             os.path.join(INC, "achip_types.h"), os.path.join(CSRC, "achip_host.c"), os.path.join(INC, "achip_host.h")]
     if os.path.exists(EMU_SO) and all(os.path.getmtime(s) <= os.path.getmtime(EMU_SO) for s in srcs):
@@ -39,6 +39,9 @@ def lib():
         _lib.emu_render_batch.restype = C.c_int
         _lib.emu_render_batch.argtypes = [C.c_int, C.c_int, C.POINTER(Frame), C.c_int, C.POINTER(Lut), C.c_void_p,
                                           C.c_uint64, C.c_void_p]
+        _lib.emu_render_stream_crc.restype = C.c_int
+        _lib.emu_render_stream_crc.argtypes = [C.c_int, C.c_int, C.POINTER(Frame), C.c_int, C.POINTER(Lut), C.c_void_p,
+                                               C.c_uint64, C.c_void_p, C.c_void_p]
         _lib.emu_set_uniform.restype = C.c_int
         _lib.emu_set_uniform.argtypes = [C.c_int]
         _lib.emu_set_parts.restype = None
@@ -110,6 +113,24 @@ def render_frames(mode, frames, palette, variant=0, stride=None, rows_per_part=0
         else:
             res.append(C.string_at(base + i * stride, int(ln[i])))
     return res
+
+
+def render_frames_crc(mode, frames, palette, variant=20, stride=None):
+    """The stream kernel with the frame CRC riding its drain: returns ([bytes | code], [crc])."""
+    L = lib()
+    n = len(frames)
+    arr = (Frame * n)(*frames)
+    lut = make_lut(palette)
+    if stride is None:
+        stride = max(int(L.achip_out_bound(mode, C.byref(arr[i]))) for i in range(n))
+        stride = (stride + 1 + 15) // 16 * 16
+    out = np.full(n * stride + 64, 0xEE, dtype=np.uint8)
+    base = (out.ctypes.data + 15) // 16 * 16
+    ln = np.zeros(n, dtype=np.uint32)
+    crc = np.full(n, 0xDEADBEEF, dtype=np.uint32)
+    assert L.emu_render_stream_crc(mode, variant, arr, n, C.byref(lut), base, stride, ln.ctypes.data, crc.ctypes.data) == 0
+    res = [int(ln[i]) if ln[i] >= 0xFFFFFFF0 else C.string_at(base + i * stride, int(ln[i])) for i in range(n)]
+    return res, [int(c) for c in crc]
 
 
 def frame_for_convert(img, width, height, render_mode, wants_padding=False, use_aspect=False, stretch=False):

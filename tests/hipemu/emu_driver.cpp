@@ -79,9 +79,11 @@ static void run_stream(const achip_frame_t *frames, int n, const achip_lut_t *lu
   achip_uniform_t uni = {};
   if (g_uniform)
     (void)achip_frames_uniform(frames, n, &uni);
-  uni.flags = (lut->flags & ACHIP_LUT_MULTIBYTE) ? 0u : ACHIP_UNIFORM_PALETTE_ASCII; /* what plan.c / dropin.c pass */
-  hipemu::launch(dim3((unsigned)n), dim3(WAVES * 64), (size_t)L::bytes, [&] {
-    achip::render_stream_kernel<MODE, WAVES, CPL, true>(frames, lut, out, stride, len, n, uni, nullptr);
+  uni.flags = ((lut->flags & ACHIP_LUT_MULTIBYTE) ? 0u : ACHIP_UNIFORM_PALETTE_ASCII) |
+              ACHIP_UNIFORM_MAX_CELLS(achip_max_cells(frames, n)); /* what plan.c / dropin.c pass */
+  const size_t lds = (size_t)((L::bytes_for(achip::stream_maxblk(uni.flags, L::BLK)) + 15) & ~15);
+  hipemu::launch(dim3((unsigned)n), dim3(WAVES * 64), lds, [&] {
+    achip::render_stream_kernel<MODE, WAVES, CPL, true>(frames, lut, out, stride, len, n, uni, nullptr, nullptr, nullptr);
   });
 }
 template <int WAVES, int CPL>
@@ -98,6 +100,45 @@ static int stream_by_mode(int mode, const achip_frame_t *frames, int n, const ac
     M(ACHIP_MODE_TRUE_BG)
 #undef M
   }
+  return -1;
+}
+
+/* the stream kernel with the frame CRC riding its drain (what asciichat_hip_plan_render_crc launches) */
+template <int MODE, int WAVES, int CPL>
+static void run_stream_crc(const achip_frame_t *frames, int n, const achip_lut_t *lut, uint8_t *out, uint64_t stride,
+                           uint32_t *len, uint32_t *crc) {
+  using L = achip::SLds<MODE, WAVES, CPL, true>;
+  achip_uniform_t uni = {};
+  /* as the product's launcher: tables built once by the init kernel, per-block words sized by the largest frame */
+  uni.flags = ((lut->flags & ACHIP_LUT_MULTIBYTE) ? 0u : ACHIP_UNIFORM_PALETTE_ASCII) |
+              ACHIP_UNIFORM_MAX_CELLS(achip_max_cells(frames, n));
+  static std::vector<uint32_t> tab;
+  if (tab.empty()) {
+    tab.resize(L::TAB_BYTES / 4 + 4);
+    uint32_t *t = tab.data();
+    hipemu::launch(dim3(1), dim3(256), 0, [&] { achip::crc_tables_init_kernel<MODE, WAVES, CPL>(t); });
+  }
+  const uint4 *tabv = reinterpret_cast<const uint4 *>(tab.data());
+  const size_t lds = (size_t)((L::bytes_for(achip::stream_maxblk(uni.flags, L::BLK)) + 15) & ~15);
+  hipemu::launch(dim3((unsigned)n), dim3(WAVES * 64), lds, [&] {
+    achip::render_stream_kernel<MODE, WAVES, CPL, true, true>(frames, lut, out, stride, len, n, uni, nullptr, crc, tabv);
+  });
+}
+extern "C" int emu_render_stream_crc(int mode, int variant, const achip_frame_t *frames, int n, const achip_lut_t *lut,
+                                     uint8_t *out, uint64_t stride, uint32_t *len, uint32_t *crc) {
+#define M(m, W, C)                                                                                                     \
+  if (mode == m) {                                                                                                     \
+    run_stream_crc<m, W, C>(frames, n, lut, out, stride, len, crc);                                                    \
+    return 0;                                                                                                          \
+  }
+  if (variant == 20) {
+    M(ACHIP_MODE_TRUE_FG, 2, 1) M(ACHIP_MODE_256_FG, 2, 1) M(ACHIP_MODE_16_FG, 2, 1) M(ACHIP_MODE_TRUE_BG, 2, 1)
+  } else if (variant == 17) {
+    M(ACHIP_MODE_TRUE_FG, 8, 2) M(ACHIP_MODE_256_FG, 8, 2) M(ACHIP_MODE_16_FG, 8, 2) M(ACHIP_MODE_TRUE_BG, 8, 2)
+  } else if (variant == 16) {
+    M(ACHIP_MODE_TRUE_FG, 16, 2) M(ACHIP_MODE_256_FG, 16, 2)
+  }
+#undef M
   return -1;
 }
 
@@ -146,6 +187,7 @@ extern "C" void emu_flip(const uint8_t *src, uint8_t *dst, int w, int h, uint32_
     hipemu::launch(dim3(3), dim3(256), 0, [&] { achip::flip_pixels_kernel(src, dst, w, h, 3 * w, 3 * w, ops); });
 }
 
+#include <vector>
 #include "crc_kernels.hpp"
 
 /* the launcher's geometry (hip_launch.hip: achip_launch_crc32c) restated for the emulator; force_parts > 1

@@ -383,6 +383,65 @@ def test_wire_stage_crc_and_headers(gpu):
     assert L.asciichat_hip_crc32c(None, stride, None, 16, 16, 1, crc.data_ptr(), stream) != 0
 
 
+@pytest.mark.gpu
+def test_render_with_fused_frame_crc(gpu):
+    """plan_render_crc: the frame CRC-32C rides the stream kernel's drain for whole-frame launches of the per-cell
+    modes; any other plan renders, then checksums the slab.  Bytes, checksums, headers and packet CRCs against the
+    oracle either way (asciichat_crc32 lib/network/crc32.c:95-190, acip_send_ascii_frame server.c:186-214)."""
+    pkg, torch = gpu
+    L = pkg.lib()
+    stream = torch.cuda.current_stream().cuda_stream
+    imgs = [TORTURE] + [orc.frame_hash_noise(320, 240, 3 + k) for k in range(6)]
+    dims = [(80, 24), (60, 7), (33, 40), (80, 1), (200, 60), (97, 31), (1, 1)]
+    # variant -1: the plan's own choice (row bands for so few frames: not fused); 16 / 17 carry the fused CRC
+    for mode, variant, want_fused, pad in ((1, 17, True, False), (2, 17, True, False), (3, 17, True, True), (4, 17, True, False),
+                                           (1, 16, True, True), (2, 16, True, False), (4, 16, True, False),
+                                           (1, 18, False, False), (1, -1, None, False), (0, -1, False, False),
+                                           (5, -1, False, False)):
+        rm = MODE_CAPS.get(mode, (3, 0))[1]
+        dev = [torch.from_numpy(np.ascontiguousarray(i)).cuda() for i in imgs]
+        asp = pad and mode != 4
+        frames = [pkg.frame_setup(d.data_ptr(), i.shape[1], i.shape[0], w, h, rm, pad and mode != 4, asp, False)
+                  for i, d, (w, h) in zip(imgs, dev, dims)]
+        plan = pkg.Plan(mode, orc.PALETTE_STANDARD, frames)
+        if variant >= 0:
+            plan.set_variant(variant)
+        if want_fused is not None:
+            assert plan.fused_crc == want_fused, (mode, variant, plan.variant)
+        n = len(imgs)
+        out = torch.full((n * plan.stride,), 0xEE, dtype=torch.uint8, device="cuda")
+        ln = torch.zeros(n, dtype=torch.int32, device="cuda")
+        crc = torch.full((n,), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
+        for _ in range(2):  # a second launch finds the LDS words of the first one gone, the slab already written
+            plan.render_crc(out.data_ptr(), plan.stride, ln.data_ptr(), crc.data_ptr(), stream)
+        d32 = torch.tensor(dims, dtype=torch.int32, device="cuda")
+        hdr = torch.zeros(n * 24, dtype=torch.uint8, device="cuda")
+        pkt = torch.zeros(n, dtype=torch.int32, device="cuda")
+        assert L.asciichat_hip_packets_from_crc(ln.data_ptr(), crc.data_ptr(), n, d32.data_ptr(), hdr.data_ptr(),
+                                                pkt.data_ptr(), stream) == 0, pkg.last_error()
+        torch.cuda.synchronize()
+        host, lens = out.cpu().numpy(), ln.cpu().numpy().astype(np.uint32)
+        crc_h, pkt_h, hdr_h = crc.cpu().numpy().astype(np.uint32), pkt.cpu().numpy().astype(np.uint32), hdr.cpu().numpy()
+        for k in range(n):
+            fr = host[k * plan.stride:k * plan.stride + int(lens[k])].tobytes()
+            assert fr == oracle_convert(imgs[k], mode, dims[k][0], dims[k][1], orc.PALETTE_STANDARD, pad and mode != 4, asp), (mode, k)
+            eh, ep = orc.ascii_frame_packet(fr, *dims[k])
+            assert int(crc_h[k]) == orc.crc32c(fr), (mode, variant, k)
+            assert hdr_h[24 * k:24 * k + 24].tobytes() == eh and int(pkt_h[k]) == ep, (mode, variant, k)
+        plan.close()
+    # a slab whose slots are smaller than the plan needs is refused on the host (the in-kernel overflow path -> CRC 0 is
+    # covered under the emulator, tests/test_kernels_emulated.py)
+    d = torch.from_numpy(np.ascontiguousarray(imgs[1])).cuda()
+    f = pkg.frame_setup(d.data_ptr(), 320, 240, 80, 24, 0)
+    plan = pkg.Plan(1, orc.PALETTE_STANDARD, [f])
+    small = 1024
+    out = torch.zeros(small, dtype=torch.uint8, device="cuda")
+    ln = torch.zeros(1, dtype=torch.int32, device="cuda")
+    crc = torch.full((1,), 77, dtype=torch.int32, device="cuda")
+    assert L.asciichat_hip_plan_render_crc(plan._h, out.data_ptr(), small, ln.data_ptr(), crc.data_ptr(), stream) != 0  # stride < plan's
+    plan.close()
+
+
 # ------------------------------------------------------------------------------------------------
 # ingest: device-resident latest-frame table (SURVEY 8f.2)
 # ------------------------------------------------------------------------------------------------

@@ -273,3 +273,35 @@ def test_stream_kernel_ragged_batch_flips_tint_and_overflow():
     f = emu.frame_for_convert(img, 80, 24, 0)
     got = emu.render_frames(MODE_TRUE_FG, [f], orc.PALETTE_STANDARD, 20, stride=1024)
     assert got[0] == 0xFFFFFFFF
+
+
+@pytest.mark.parametrize("mode", STREAM_MODES, ids=["true_fg", "256_fg", "16_fg", "true_bg"])
+def test_stream_kernel_fused_frame_crc(mode):
+    """asciichat_crc32 of the frame (lib/network/crc32.c:95-190) computed inside the render kernel while the frame's
+    bytes sit in LDS on their way out: bytes AND checksum must match the oracle -- blocks that straddle rows, top
+    padding (newlines nobody stages), one-block frames, a ragged batch, and a slot that is too small (CRC 0)."""
+    cases = [(80, 24, False, False, 20), (97, 31, False, False, 17), (3, 2, False, False, 20), (1, 1, False, False, 20),
+             (200, 60, True, True, 20), (60, 40, True, True, 20), (64, 1, False, False, 17), (5, 300, True, True, 20)]
+    if mode in (MODE_TRUE_FG, MODE_256_FG):
+        cases.append((80, 24, False, False, 16))
+    for (W, H, asp, pad, variant) in cases:
+        if mode == MODE_TRUE_BG and asp:
+            continue  # the background renderer is not reached through the aspect / padding front end
+        exp = oracle_convert(TORTURE, mode, W, H, orc.PALETTE_STANDARD, pad, asp)
+        f = emu.frame_for_convert(TORTURE, W, H, MODE_CAPS.get(mode, (3, 0))[1], pad, asp)
+        got, crc = emu.render_frames_crc(mode, [f], orc.PALETTE_STANDARD, variant)
+        assert got[0] == exp, (MODE_NAMES[mode], W, H, variant)
+        assert crc[0] == orc.crc32c(exp), (MODE_NAMES[mode], W, H, variant, hex(crc[0]))
+    imgs = [orc.frame_hash_noise(120, 90, i) for i in range(4)]
+    dims = [(80, 24), (60, 7), (33, 40), (1, 50)]
+    frames = [emu.frame_for_convert(im, w, h, 0) for im, (w, h) in zip(imgs, dims)]
+    got, crc = emu.render_frames_crc(mode, frames, orc.PALETTE_STANDARD, 20)
+    for k, (im, (w, h)) in enumerate(zip(imgs, dims)):
+        exp = oracle_convert(im, mode, w, h, orc.PALETTE_STANDARD)
+        assert got[k] == exp and crc[k] == orc.crc32c(exp), (mode, k)
+    if mode != MODE_TRUE_FG:  # multi-byte glyphs: token lengths vary inside a block
+        f = emu.frame_for_convert(TORTURE, 61, 17, MODE_CAPS.get(mode, (3, 0))[1])
+        got, crc = emu.render_frames_crc(mode, [f], "é漢😀 .", 20)
+        assert got[0] == oracle_convert(TORTURE, mode, 61, 17, "é漢😀 .") and crc[0] == orc.crc32c(got[0])
+    got, crc = emu.render_frames_crc(mode, [frames[0]], orc.PALETTE_STANDARD, 20, stride=1024)
+    assert got[0] == 0xFFFFFFFF and crc[0] == 0
