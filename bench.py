@@ -238,7 +238,7 @@ def run_workload(torch, pkg, name, batch, steps, warmup, regions, dist=None, see
                out_bytes_per_frame=out_mean / batch, alg_bytes_per_launch=alg_bytes, variant=plans[0].variant,
                input_sets=nsets, streams=streams, kind=kind, aspect=aspect, verify=ver, streams_autotune=tune,
                cells_per_frame=(f0.pad_left + f0.out_w) * ((f0.out_h + 1) // 2 if rm == 2 else f0.out_h),
-               serial=None, plans=plans, sets=sets)
+               serial=None, plans=plans, sets=sets, forced_variant=variant)
     if serial_leg:
         # the same steps one launch at a time (each plan re-chooses its geometry for the whole GPU), and the same
         # batch rendered every step (its sampled lines then come out of the Infinity Cache)
@@ -408,6 +408,87 @@ def run_grid9(torch, pkg, steps, regions, targets=256, dist=None, world=1, rank=
     return out
 
 
+def wire_stage(torch, pkg, res, steps=160):
+    """SURVEY 8(f).3 behind the metric's render, measured in this run: GPU time per step (HIP events, same schedule as
+    the main leg: res['streams'] launches in flight, a fresh input batch every step) of (a) render alone, (b) render +
+    the stand-alone checksum / packet-header kernel (a second pass over the slab), (c) render with the frame CRC-32C
+    riding the drain + the header kernel.  The fused checksums are compared with the stand-alone kernel's on a whole
+    batch and with the oracle's CRC-32C on 8 frames."""
+    import numpy as np
+
+    import orc
+
+    L = pkg.lib()
+    plans, batch, S = res["plans"], res["batch"], res["streams"]
+    for p in plans:  # the serial leg left them at one launch in flight
+        p.set_concurrency(S)
+        if res.get("forced_variant", -1) >= 0:
+            p.set_variant(res["forced_variant"])
+    stride = plans[0].stride
+    lanes = [torch.cuda.current_stream()] + _LANE_POOL[:S - 1]
+    outs = [torch.empty(batch * stride, dtype=torch.uint8, device="cuda") for _ in range(S)]
+    lns = [torch.zeros(batch, dtype=torch.int32, device="cuda") for _ in range(S)]
+    crcs = [torch.zeros(batch, dtype=torch.int32, device="cuda") for _ in range(S)]
+    hdrs = [torch.zeros(batch * 24, dtype=torch.uint8, device="cuda") for _ in range(S)]
+    pkts = [torch.zeros(batch, dtype=torch.int32, device="cuda") for _ in range(S)]
+    sw, sh, W, H, cl, rm = WORKLOADS[res["name"]]
+    dims = torch.tensor([[W, H]] * batch, dtype=torch.int32, device="cuda")
+
+    def step(kind, k):
+        s, p = k % S, plans[k % len(plans)]
+        st = lanes[s].cuda_stream
+        if kind == "fused":
+            p.render_crc(outs[s].data_ptr(), stride, lns[s].data_ptr(), crcs[s].data_ptr(), st)
+            rc = L.asciichat_hip_packets_from_crc(lns[s].data_ptr(), crcs[s].data_ptr(), batch, dims.data_ptr(),
+                                                  hdrs[s].data_ptr(), pkts[s].data_ptr(), st)
+        else:
+            p.render(outs[s].data_ptr(), stride, lns[s].data_ptr(), st)
+            rc = 0
+            if kind == "separate":
+                rc = L.asciichat_hip_frame_packets(outs[s].data_ptr(), stride, lns[s].data_ptr(), stride, batch,
+                                                   dims.data_ptr(), crcs[s].data_ptr(), hdrs[s].data_ptr(),
+                                                   pkts[s].data_ptr(), st)
+        assert rc == 0, pkg.last_error()
+
+    def timed(kind):
+        for k in range(2 * S):
+            step(kind, k)
+        torch.cuda.synchronize()
+        b = [torch.cuda.Event(enable_timing=True) for _ in range(S)]
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(S)]
+        for s in range(S):
+            step(kind, s)
+            b[s].record(lanes[s])
+        for k in range(steps):
+            step(kind, k)
+        for s in range(S):
+            e[s].record(lanes[s])
+        torch.cuda.synchronize()
+        return max(b[s].elapsed_time(e[t]) for s in range(S) for t in range(S)) / steps
+
+    got = {}
+    for kind in ("separate", "fused"):
+        step(kind, 0)
+        torch.cuda.synchronize()
+        got[kind] = (crcs[0].cpu().numpy().astype("uint32").copy(), pkts[0].cpu().numpy().astype("uint32").copy(),
+                     hdrs[0].cpu().numpy().copy())
+    same = all((a == b).all() for a, b in zip(got["separate"], got["fused"]))
+    host, lens = outs[0].cpu().numpy(), lns[0].cpu().numpy().astype("uint32")
+    idx = sorted(set(int(round(i * (batch - 1) / 7)) for i in range(min(8, batch))))
+    oracle_ok = all(int(got["fused"][0][i]) == orc.crc32c(host[i * stride:i * stride + int(lens[i])].tobytes()) for i in idx)
+    if not (same and oracle_ok):
+        raise SystemExit("bench.py: fused frame checksums differ from the stand-alone kernel's / the oracle's")
+    t = {kind: statistics.median(timed(kind) for _ in range(3)) for kind in ("render", "separate", "fused")}
+    return {"launches_in_flight": S, "steps": steps, "fused_crc_in_render_kernel": bool(plans[0].fused_crc),
+            "kernel_variant": plans[0].variant,
+            "render_ms_per_step": t["render"], "render_plus_packet_kernel_ms_per_step": t["separate"],
+            "render_with_fused_crc_plus_headers_ms_per_step": t["fused"],
+            "extra_ms_separate": t["separate"] - t["render"], "extra_ms_fused": t["fused"] - t["render"],
+            "checked": {"frames_vs_standalone_kernel": batch, "frames_vs_oracle_crc32c": len(idx), "identical": True},
+            "note": "ascii_frame_packet_t.checksum + 24-byte headers + packet CRCs for every frame of the step "
+                    "(lib/network/acip/server.c:186-214); calls issued from Python, two per step"}
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -474,6 +555,7 @@ def main():
                     help="'default' = every BASELINE config + the input / aspect variants of SURVEY 8(d) (N=1 only); '' = none; "
                          "or a comma list of workload names")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-wire", action="store_true", help="skip the wire-stage leg (frame CRC + packet headers)")
     ap.add_argument("--no-d2h", action="store_true", help="skip the PCIe-inclusive with_d2h leg (profiling runs)")
     ap.add_argument("--variant", type=int, default=-1)
     ap.add_argument("--input-sets", type=int, default=12,
@@ -484,6 +566,18 @@ def main():
     ap.add_argument("--no-hot", action="store_true",
                     help="skip the one-launch-at-a-time / same-batch comparison legs (profiling runs)")
     args = ap.parse_args()
+    # stdout carries ONE line, the JSON: libraries that print to the process's stdout on their own (RCCL's version
+    # banner, through C stdio, flushed at exit) go to stderr instead -- fd 1 is pointed at fd 2 until the line is printed
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)  # whatever C code buffered for "stdout" so far lands on stderr
+        os.write(real_stdout, (json.dumps(obj) + "\n").encode())
+
     if args.others in ("none", "''", '""'):
         args.others = ""
     regions = args.regions if args.regions > 0 else max(5, min(60, 1200 // max(1, args.steps)))
@@ -518,7 +612,7 @@ def main():
         g = run_grid9(torch, pkg, args.steps, regions, args.batch, dist, world, rank, backend)
         e = g[f"{args.batch}_targets"]
         if rank == 0:
-            print(json.dumps({
+            emit({
                 "metric": "frames/sec, nine 1080p sources -> 3x3 grid at 160x48 truecolor, one frame per target client",
                 "value": e["frames_per_s"], "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": 5,
                 "ms_per_step": e["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -529,7 +623,7 @@ def main():
                 "roofline": {"bound": "hbm", "achieved": e["roofline_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": e["roofline_frac"], "traffic": None, "kernel_ms": e["kernel_ms"],
                              "alg_bytes_per_launch": e["alg_bytes_per_launch"]},
-                "grid9": g}))
+                "grid9": g})
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -586,6 +680,11 @@ def main():
             line["with_d2h"] = {"ms_per_step": d2h_s * 1e3, "frames_per_s": args.batch / d2h_s,
                                 "copied_bytes_per_step": d2h_bytes, "GBps": d2h_bytes / d2h_s / 1e9,
                                 "note": "whole fixed-stride slab + lengths to pinned host memory after every launch; PCIe-bound"}
+        if not args.no_wire:
+            try:
+                line["wire_stage"] = wire_stage(torch, pkg, res)
+            except (RuntimeError, AssertionError) as e:  # a plan without the entry point, an out-of-memory slab, ...
+                line["wire_stage"] = {"error": str(e)[:200]}
         free_workload(torch, res)
         if not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(args.workload)
@@ -597,7 +696,7 @@ def main():
             todo += [(args.workload, k, False) for k in INPUT_KINDS if k != "noise"]
             todo += [(n, "noise", True) for n in WORKLOADS]
         else:
-            todo = [(n, "noise", False) for n in args.others.split(",") if n and n != args.workload]
+            todo = [(n, "noise", False) for n in args.others.split(",") if n in WORKLOADS and n != args.workload]
         for name, kind, aspect in todo:
             big = WORKLOADS[name][0] > 3000
             b = 1 if name == "640x480_80x24_mono" else args.batch  # K1 is a single frame (configs[0])
@@ -615,7 +714,7 @@ def main():
     else:
         free_workload(torch, res)
     if rank == 0:
-        print(json.dumps(line))
+        emit(line)
     if dist is not None:
         dist.destroy_process_group()
 
