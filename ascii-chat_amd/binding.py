@@ -121,6 +121,9 @@ def lib():
     L.asciichat_hip_plan_render_profiled.argtypes = [vp, vp, sz, vp, vp, vp]
     L.asciichat_hip_plan_destroy.restype = None
     L.asciichat_hip_plan_destroy.argtypes = [vp]
+    L.asciichat_hip_render_many_profiled.restype = ci
+    L.asciichat_hip_render_many_profiled.argtypes = [C.POINTER(vp), ci, C.POINTER(vp), C.POINTER(vp), sz, C.POINTER(vp), ci,
+                                                     ci, ci, vp, sz]
     L.asciichat_hip_render_many.restype = ci
     L.asciichat_hip_render_many.argtypes = [C.POINTER(vp), ci, C.POINTER(vp), C.POINTER(vp), sz, C.POINTER(vp), ci, ci, ci]
     L.asciichat_hip_streams_wait.restype = ci
@@ -407,6 +410,13 @@ class Schedule:
                                              self.S, first_step, n_steps)
         if rc != 0:
             raise RuntimeError(f"render_many failed ({rc}): {last_error()}")
+
+    def issue_profiled(self, first_step, n_steps, prof_ptr, prof_stride_words):
+        rc = lib().asciichat_hip_render_many_profiled(self._plans, self.P, self._outs, self._lens, self.stride,
+                                                      self._streams, self.S, first_step, n_steps, prof_ptr,
+                                                      prof_stride_words)
+        if rc != 0:
+            raise RuntimeError(f"render_many_profiled failed ({rc}): {last_error()}")
 
     def wait(self):
         rc = lib().asciichat_hip_streams_wait(self._streams, self.S)

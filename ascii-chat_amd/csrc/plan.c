@@ -506,6 +506,26 @@ int asciichat_hip_render_many(asciichat_hip_plan_t *const *plans, int n_plans, u
   return 0;
 }
 
+/* diagnostics: the same loop with the kernels' per-wave timestamps, step k writing prof_dev + k * prof_stride_words
+ * (scripts/gpu_burst_timeline.py: when does each launch of a short burst start and end on the device?) */
+int asciichat_hip_render_many_profiled(asciichat_hip_plan_t *const *plans, int n_plans, uint8_t *const *out_dev,
+                                       uint32_t *const *out_len_dev, size_t out_stride, void *const *streams,
+                                       int n_streams, int first_step, int n_steps, unsigned long long *prof_dev,
+                                       size_t prof_stride_words) {
+  if (!plans || !out_dev || !out_len_dev || !streams || n_plans <= 0 || n_streams <= 0 || first_step < 0 || n_steps < 0 ||
+      n_plans % n_streams != 0 || !prof_dev)
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "render_many_profiled: bad arguments");
+  for (int k = first_step; k < first_step + n_steps; k++) {
+    const int s = k % n_streams;
+    asciichat_hip_plan_t *p = plans[k % n_plans];
+    const int rc = render_range(p, 0, p ? p->n : 0, out_dev[s], out_stride, out_len_dev[s],
+                                prof_dev + (size_t)(k - first_step) * prof_stride_words, streams[s]);
+    if (rc)
+      return rc;
+  }
+  return 0;
+}
+
 /* ------------------------------------------------------------------------------------------- */
 /* A tick loop captured once and replayed: the n_steps launches of asciichat_hip_render_many as ONE hipGraph       */
 /* (n_lanes parallel branches, one per independent batch stream).  A replay costs one graph launch instead of      */
@@ -605,18 +625,26 @@ void asciichat_hip_schedule_destroy(asciichat_hip_schedule_t *s) {
   free(s);
 }
 
-/* Spin until every stream has drained (hipStreamQuery polling: a blocking hipStreamSynchronize sleeps in the driver and
- * wakes tens of microseconds late, which is most of a 20-step timed region). */
+/* Spin until every stream has drained.  Polling, because a blocking hipStreamSynchronize sleeps in the driver and wakes
+ * tens of microseconds late (most of a 20-step timed region); and ROUND ROBIN over the streams, because the first query
+ * of a stream with work outstanding costs a round trip of its own that proceeds asynchronously: queried one after the
+ * other (each spun to completion before the next is touched) those round trips add up -- 4 streams, bursts of 4 / 20
+ * steps: 83 / 205 us stream by stream, 58 / 189 us round robin (profiles/r02_wait_modes.txt). */
 int asciichat_hip_streams_wait(void *const *streams, int n_streams) {
-  if (!streams || n_streams <= 0)
+  if (!streams || n_streams <= 0 || n_streams > 64)
     return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "streams_wait: bad arguments");
-  for (int s = 0; s < n_streams; s++) {
-    hipError_t e;
-    while ((e = hipStreamQuery((hipStream_t)streams[s])) == hipErrorNotReady)
-      ;
-    if (e != hipSuccess)
-      return achip_hip_check((int)e, "hipStreamQuery");
-  }
+  unsigned long long pending = n_streams == 64 ? ~0ull : (1ull << n_streams) - 1ull;
+  while (pending)
+    for (int s = 0; s < n_streams; s++) {
+      if (!(pending >> s & 1ull))
+        continue;
+      const hipError_t e = hipStreamQuery((hipStream_t)streams[s]);
+      if (e == hipErrorNotReady)
+        continue;
+      if (e != hipSuccess)
+        return achip_hip_check((int)e, "hipStreamQuery");
+      pending &= ~(1ull << s);
+    }
   return 0;
 }
 

@@ -137,7 +137,7 @@ class Runner:
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
         return time.perf_counter() - t0
 
     def gpu_ms_per_step(self, n):

@@ -115,6 +115,11 @@ int asciichat_hip_plan_render_profiled(asciichat_hip_plan_t *plan, uint8_t *out_
 int asciichat_hip_render_many(asciichat_hip_plan_t *const *plans, int n_plans, uint8_t *const *out_dev,
                               uint32_t *const *out_len_dev, size_t out_stride, void *const *streams, int n_streams,
                               int first_step, int n_steps);
+/* diagnostics: the same loop, step k writing the kernels' per-wave timestamps to prof_dev + k * prof_stride_words */
+int asciichat_hip_render_many_profiled(asciichat_hip_plan_t *const *plans, int n_plans, uint8_t *const *out_dev,
+                                       uint32_t *const *out_len_dev, size_t out_stride, void *const *streams,
+                                       int n_streams, int first_step, int n_steps, unsigned long long *prof_dev,
+                                       size_t prof_stride_words);
 int asciichat_hip_streams_wait(void *const *streams, int n_streams);
 
 /*
