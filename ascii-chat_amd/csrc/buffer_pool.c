@@ -35,8 +35,9 @@ typedef struct pool_node {
   uint64_t returned_at_ns;
   struct buffer_pool *pool;
   void *device_alias; /* pinned blocks: device address of the payload */
-  uint64_t _reserved;
+  uint64_t _reserved[2];
 } pool_node_t; /* 64 bytes: payloads stay 64-byte aligned */
+_Static_assert(sizeof(pool_node_t) == 64, "the header keeps payloads 64-byte aligned");
 
 struct buffer_pool {
   pthread_mutex_t mu;

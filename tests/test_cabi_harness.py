@@ -33,3 +33,31 @@ def test_reference_unit_test_assertions_through_the_c_abi():
     r = subprocess.run([build()], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.strip().splitlines()[-1].startswith("ok:")
+
+
+# ---- buffer_pool_* : the invariants of the reference's tests/unit/util/buffer_pool_test.c + this library's additions ----
+POOL_SRC = os.path.join(ROOT, "tests", "cabi", "buffer_pool_test_port.c")
+POOL_EXE = os.path.join(ROOT, "tests", "cabi", "buffer_pool_test_port")
+
+
+def build_pool():
+    subprocess.check_call(["gcc", "-std=gnu11", "-O1", "-Wall", "-Wextra", "-Werror", "-pthread",
+                           "-I" + os.path.join(ROOT, "include"), POOL_SRC, "-o", POOL_EXE, "-L" + LIBDIR,
+                           "-lasciichat_hip", "-Wl,-rpath," + LIBDIR])
+    return POOL_EXE
+
+
+def test_buffer_pool_invariants_host_blocks():
+    """Runs everywhere: without a GPU the frame class hands out plain host blocks (the reference's malloc fallback)."""
+    import ctypes
+    have_gpu = ctypes.CDLL(os.path.join(LIBDIR, "libasciichat_hip.so")).asciichat_hip_device_count() > 0
+    r = subprocess.run([build_pool()] + (["gpu"] if have_gpu else []), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.strip().splitlines()[-1].startswith("ok:")
+
+
+@pytest.mark.gpu
+def test_buffer_pool_invariants_with_pinned_frames():
+    r = subprocess.run([build_pool(), "gpu"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "with the pinned frame class" in r.stdout
