@@ -28,23 +28,14 @@
  * pseudo-cells that emit one space each, top padding as a cooperative fill, so
  * ascii_pad_frame_width/_height (ascii.c:457-517, 902-941) cost no extra pass.
  *
- * The file is plain HIP C++; tests compile it against tests/hipemu/hip_emu.h (-DACHIP_HIPEMU) to run
- * the same source on the CPU test box.  The product library only ever contains the hipcc build.
+ * Everything written for the machine rather than in portable HIP C++ (inline DS instructions, DPP wave operations,
+ * scoped atomics, cache-policy loads and stores) lives in gfx950_ops.hpp; this file has no conditional compilation.
+ * The CPU tests compile the same source against tests/hipemu/gfx950_ops.hpp (a fiber emulation of that interface,
+ * found first on their include path); the product library only ever contains the hipcc build.
  */
 #pragma once
 
-#ifdef ACHIP_HIPEMU
-#include "hip_emu.h"
-#define ACHIP_SMEM (hipemu::g_smem.data())
-#else
-#include <hip/hip_runtime.h>
-/* The one dynamic-LDS block of the frame kernel.  Every LDS access below is derived from this symbol
- * (never from a pointer stored in a struct), so the compiler keeps the accesses in the LDS address
- * space: ds_read/ds_write instead of flat_load/flat_store. */
-extern __shared__ __attribute__((aligned(16))) unsigned char achip_smem[];
-#define ACHIP_SMEM achip_smem
-#endif
-
+#include <gfx950_ops.hpp>
 #include <stdint.h>
 
 #include "achip_types.h"
@@ -56,63 +47,24 @@ extern __shared__ __attribute__((aligned(16))) unsigned char achip_smem[];
 
 namespace achip {
 
-/* pointers read out of descriptors are generic; tell the compiler they are global memory so that it
- * emits global_load (vmcnt only) rather than flat_load (vmcnt + lgkmcnt, shared with the LDS queue) */
-#ifdef ACHIP_HIPEMU
-#define ACHIP_GLOBAL
-#else
-#define ACHIP_GLOBAL __attribute__((address_space(1)))
-#endif
-struct __attribute__((packed)) unaligned_u32 {
-  uint32_t v;
-};
-
 template <class T> __device__ inline T *lds_ptr(int byte_off) { return reinterpret_cast<T *>(ACHIP_SMEM + byte_off); }
 
-/* one LDS byte store at (LDS byte address `addr`) + OFF; HI selects bits 23..16 of `v` instead of 7..0.
- * Written as asm so that neighbouring byte stores are never fused into a misaligned wide store. */
+/* one LDS byte store at (LDS byte address `addr`) + OFF; HI selects bits 23..16 of `v` instead of 7..0 */
 template <int OFF, bool HI> __device__ inline void lds_store_byte(uint32_t addr, uint32_t v) {
 #if defined(ACHIP_ABLATE) && ACHIP_ABLATE == 1
-  asm volatile("" ::"v"(addr), "v"(v)); /* diagnostics: keep the operands alive, issue no store */
+  keep_alive(addr, v); /* diagnostics build: keep the operands alive, issue no store */
   return;
 #endif
-#ifdef ACHIP_HIPEMU
-  ACHIP_SMEM[addr + OFF] = (unsigned char)(HI ? v >> 16 : v);
-#else
-  if (HI)
-    asm volatile("ds_write_b8_d16_hi %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
-  else
-    asm volatile("ds_write_b8 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
-#endif
+  ds_store_byte<OFF, HI>(addr, v);
 }
 /* LDS atomic OR of an aligned dword (no return value): tokens built in registers are OR-ed into a pre-zeroed
  * staging buffer, so that neighbouring tokens can share a dword without byte stores */
 __device__ inline void lds_or_u32(uint32_t addr, uint32_t v) {
 #if defined(ACHIP_ABLATE) && ACHIP_ABLATE == 1
-  asm volatile("" ::"v"(addr), "v"(v));
+  keep_alive(addr, v);
   return;
 #endif
-#ifdef ACHIP_HIPEMU
-  *reinterpret_cast<uint32_t *>(ACHIP_SMEM + addr) |= v;
-#else
-  asm volatile("ds_or_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
-#endif
-}
-/* LDS byte address of ACHIP_SMEM[0] (0 for a kernel without static LDS, but do not assume) */
-__device__ inline uint32_t lds_base_addr() {
-#ifdef ACHIP_HIPEMU
-  return 0u;
-#else
-  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(achip_smem);
-#endif
-}
-/* all DS operations issued by inline asm must have landed before other waves read the ring */
-__device__ inline void lds_store_fence() {
-#ifndef ACHIP_HIPEMU
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#else
-  hipemu::wave_barrier(); /* a wave's lanes run in lockstep on the GPU: every lane's stores precede the reads behind */
-#endif
+  ds_or_u32(addr, v);
 }
 
 /* ------------------------------------------------------------------------------------------- */
@@ -122,44 +74,19 @@ __device__ inline void lds_store_fence() {
 /* the reader's L1), so the word is its own payload and needs no fence (MI355X guide, G16 form R2).  */
 /* ------------------------------------------------------------------------------------------- */
 __device__ inline void part_publish(unsigned long long *slot, uint32_t epoch, uint32_t value) {
-  const unsigned long long w = ((unsigned long long)epoch << 32) | (unsigned long long)value;
-#ifdef ACHIP_HIPEMU
-  *slot = w;
-#else
-  __hip_atomic_store(slot, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
+  agent_store_u64(slot, ((unsigned long long)epoch << 32) | (unsigned long long)value);
 }
 /* value published for this launch, or 0xFFFFFFFF after ~0.2 s of polling (never spins unbounded) */
 __device__ inline uint32_t part_wait(const unsigned long long *slot, uint32_t epoch) {
   for (int spin = 0; spin < (1 << 21); spin++) {
-#ifdef ACHIP_HIPEMU
-    const unsigned long long w = *slot;
-#else
-    const unsigned long long w = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
+    const unsigned long long w = agent_load_u64(slot);
     if ((uint32_t)(w >> 32) == epoch)
       return (uint32_t)w;
-#ifndef ACHIP_HIPEMU
-    __builtin_amdgcn_s_sleep(2);
-#endif
+    spin_nap<2>();
   }
   return 0xFFFFFFFFu;
 }
 #define ACHIP_PART_POISON 0xFFFFFFF1u /* a predecessor failed / timed out: propagate, do not emit */
-
-/* ------------------------------------------------------------------------------------------- */
-/* wave64 primitives                                                                             */
-/* ------------------------------------------------------------------------------------------- */
-#ifdef ACHIP_HIPEMU
-__device__ inline uint64_t wave_ballot(bool p) { return hipemu::ballot(p); }
-__device__ inline uint32_t wave_shfl_up(uint32_t v, int d) {
-  int l = hipemu::lane();
-  return hipemu::shfl_from(v, l - d); /* src < 0 -> own value, like __shfl_up */
-}
-#else
-__device__ inline uint64_t wave_ballot(bool p) { return __ballot(p); }
-__device__ inline uint32_t wave_shfl_up(uint32_t v, int d) { return __shfl_up(v, d, 64); }
-#endif
 
 /* ------------------------------------------------------------------------------------------- */
 /* per-pixel integer maps                                                                        */
@@ -245,65 +172,6 @@ __device__ inline bool rep_profitable(uint32_t run) {
   const uint32_t k = run - 1u;
   return k > digits_u32(k) + 3u;
 }
-
-/* ------------------------------------------------------------------------------------------- */
-/* wave64 inclusive scan without LDS: DPP row shifts + row broadcasts (the ds_bpermute that        */
-/* __shfl_up compiles to costs an LDS round trip per step)                                        */
-/* ------------------------------------------------------------------------------------------- */
-#ifdef ACHIP_HIPEMU
-__device__ inline uint32_t wave_inclusive_scan(uint32_t v) {
-  const int l = hipemu::lane();
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t t = hipemu::shfl_from(v, l - d);
-    if (l >= d)
-      v += t;
-  }
-  return v;
-}
-__device__ inline uint32_t wave_read_lane(uint32_t v, int lane) { return hipemu::shfl_from(v, lane); }
-__device__ inline int wave_uniform(int v) { return v; }
-/* xor over the wave; the result is valid in lane 63 */
-__device__ inline uint32_t wave_xor_to_last(uint32_t v) {
-  const int l = hipemu::lane();
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t t = hipemu::shfl_from(v, l - d);
-    if (l >= d)
-      v ^= t;
-  }
-  return v;
-}
-#else
-template <int CTRL, int ROW_MASK> __device__ inline uint32_t dpp_add(uint32_t v) {
-  /* lanes whose DPP source is invalid (or whose row is masked off) add 0 */
-  return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
-}
-__device__ inline uint32_t wave_inclusive_scan(uint32_t v) {
-  v = dpp_add<0x111, 0xF>(v); /* row_shr:1  */
-  v = dpp_add<0x112, 0xF>(v); /* row_shr:2  */
-  v = dpp_add<0x114, 0xF>(v); /* row_shr:4  */
-  v = dpp_add<0x118, 0xF>(v); /* row_shr:8  : every 16-lane row now holds its own inclusive scan */
-  v = dpp_add<0x142, 0xA>(v); /* row_bcast:15 into rows 1 and 3 */
-  v = dpp_add<0x143, 0xC>(v); /* row_bcast:31 into rows 2 and 3 */
-  return v;
-}
-template <int CTRL, int ROW_MASK> __device__ inline uint32_t dpp_xor(uint32_t v) {
-  return v ^ (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
-}
-/* xor over the wave; the result is valid in lane 63 */
-__device__ inline uint32_t wave_xor_to_last(uint32_t v) {
-  v = dpp_xor<0x111, 0xF>(v);
-  v = dpp_xor<0x112, 0xF>(v);
-  v = dpp_xor<0x114, 0xF>(v);
-  v = dpp_xor<0x118, 0xF>(v);
-  v = dpp_xor<0x142, 0xA>(v);
-  v = dpp_xor<0x143, 0xC>(v);
-  return v;
-}
-__device__ inline uint32_t wave_read_lane(uint32_t v, int lane) {
-  return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
-}
-__device__ inline int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
-#endif
 
 /* ------------------------------------------------------------------------------------------- */
 /* token sinks.  A token is a short sequence of FIELDS of <= 4 bytes (packed little-endian in a   */
@@ -501,17 +369,11 @@ __device__ inline uint32_t load_rgb_raw(const uint8_t *__restrict__ src, int32_t
     return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
   }
   kind = a != 0u ? RAW_BACK : RAW_FIRST;
-#ifndef ACHIP_HIPEMU
   /* samples a cache line apart or more share no line with their neighbours: a non-temporal load keeps them out of
    * the L2 (1080p -> 80 columns, 72-byte stride: 13.1 -> 12.0 us per 256 frames); closer samples do share lines
    * and want the cache (4K -> 200 / 400 columns get 3-5 % slower without it) -- profiles/r01_nontemporal.txt */
-  if (stream) {
-    typedef uint32_t u32_unaligned __attribute__((aligned(1)));
-    uint32_t back = a != 0u ? 1u : 0u;
-    asm volatile("" : "+v"(back)); /* keeps this load distinct: merged with the cached one it would lose its hint */
-    return __builtin_nontemporal_load((const ACHIP_GLOBAL u32_unaligned *)(p - back));
-  }
-#endif
+  if (stream) /* opaque(): keeps this load distinct -- merged with the cached one it would lose its hint */
+    return load_u32_unaligned_nt((const uint8_t *)p - opaque(a != 0u ? 1u : 0u));
   return ((const ACHIP_GLOBAL unaligned_u32 *)(p - (a != 0u ? 1u : 0u)))->v;
 }
 __device__ inline uint32_t finish_rgb(uint32_t v, uint32_t kind) {
@@ -941,17 +803,8 @@ template <int MODE> __device__ inline bool same_run(const uint32_t *pixT, const 
 /* ------------------------------------------------------------------------------------------- */
 /* the frame kernel                                                                              */
 /* ------------------------------------------------------------------------------------------- */
-/* 16 output bytes to HBM.  The stream is written once and never read back by the kernel: a non-temporal
- * store lets the lines leave the L2 during the kernel instead of in the write-back at its end. */
-__device__ inline void store_out16(uint8_t *__restrict__ p, uint4 v) {
-#if defined(ACHIP_HIPEMU) || defined(ACHIP_NO_NT_STORE)
-  *reinterpret_cast<uint4 *>(p) = v;
-#else
-  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-  u32x4 w = {v.x, v.y, v.z, v.w};
-  __builtin_nontemporal_store(w, reinterpret_cast<u32x4 *>(p));
-#endif
-}
+/* 16 output bytes to HBM: written once and never read back by the kernel, hence non-temporal (gfx950_ops.hpp) */
+__device__ inline void store_out16(uint8_t *__restrict__ p, uint4 v) { store_u4_nt(p, v); }
 
 template <int BLOCK, bool REZERO = false>
 __device__ inline void drain_ring(int ring_off, uint8_t *__restrict__ out, uint32_t from, uint32_t to, uint32_t own_from,
@@ -1080,11 +933,6 @@ __device__ inline void dither16_rows(int lane, int chunk_rows, int wp, int pad_l
 
 /* optional per-phase cycle accounting (diagnostics: prof == NULL in production launches).
  * prof[frame*8 + k]: 0 setup+pad_top, 1 gather, 2 heads, 3 tokens+lengths, 4 scan, 5 token stores, 6 drain, 7 total */
-#ifdef ACHIP_HIPEMU
-__device__ inline unsigned long long cycle_now() { return 0ull; }
-#else
-__device__ inline unsigned long long cycle_now() { return (unsigned long long)clock64(); }
-#endif
 #define ACHIP_STAMP(slot)                                                                                              \
   do {                                                                                                                 \
     if (prof && tid == 0) { /* accumulators live in LDS: no registers are held for diagnostics */                     \
@@ -1099,14 +947,10 @@ __device__ inline unsigned long long cycle_now() { return (unsigned long long)cl
  * non-half-block kernels sit right at that edge (125-130 depending on unrelated code motion: at 130 only ONE 512-thread
  * workgroup fits and the step time doubles).  Pin it.  The half-block kernels need 160-185 there and are never
  * launched in these geometries by the host policy. */
-#ifdef ACHIP_HIPEMU /* the CPU emulator (g++) has no such attribute */
-#define ACHIP_PIN_OCCUPANCY(M, B)
-#else
-#define ACHIP_PIN_OCCUPANCY(M, B) __attribute__((amdgpu_waves_per_eu(MinWaves<M, B>::value)))
-#endif
 template <int MODE, int BLOCK> struct MinWaves {
   static constexpr int value = (BLOCK <= 512 && BLOCK >= 256 && !mode_is_halfblock(MODE)) ? 4 : 1;
 };
+#define ACHIP_PIN_OCCUPANCY(M, B) ACHIP_WAVES_PER_EU((MinWaves<M, B>::value))
 
 template <int MODE, int BLOCK, int CAP, int RING, bool COMP, bool SPLIT = true>
 __global__ void __launch_bounds__(BLOCK) ACHIP_PIN_OCCUPANCY(MODE, BLOCK)
@@ -1128,12 +972,9 @@ __global__ void __launch_bounds__(BLOCK) ACHIP_PIN_OCCUPANCY(MODE, BLOCK)
    * samples per thread fit the 128-VGPR budget (4K -> 200x60: 58 -> 47 us, 4K -> 400x120 half-block: 314 -> 287 us,
    * profiles/r01_prefetch.txt); the smaller geometries would drop to half the waves per CU, and a row band is a
    * single chunk anyway. */
-#ifdef ACHIP_HIPEMU /* tests: the request-ahead order in every geometry, so that tiny inputs exercise it -- except in
-                       the 512 x 4 geometry, which keeps its product configuration (PRE_ISSUE without PREFETCH) */
-  constexpr bool PREFETCH = !SPLIT && !(BLOCK == 512 && CAP == 2048);
-#else
-  constexpr bool PREFETCH = BLOCK == 1024 && CAP == 2048 && !SPLIT;
-#endif
+  /* (the emulated test build takes the request-ahead order in every geometry, so that tiny inputs exercise it --
+   * except in the 512 x 4 geometry, which keeps its product configuration: PRE_ISSUE without PREFETCH) */
+  constexpr bool PREFETCH = ACHIP_EMULATED ? !SPLIT && !(BLOCK == 512 && CAP == 2048) : BLOCK == 1024 && CAP == 2048 && !SPLIT;
   /* A wave waits AT the request until the memory pipeline has room for its lines, so the requests of a chunk are
    * not issued in one burst behind phase A's barrier but at four points of B/C: in the half-block modes every
    * thread issues one of its four requests per point (4K -> 400x120: 281 -> 266 us); in the other modes a

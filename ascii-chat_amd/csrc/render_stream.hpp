@@ -91,51 +91,14 @@ __host__ __device__ constexpr int stream_maxblk(uint32_t uniform_flags, int blk_
   return cells == 0u || nb > (uint32_t)ACHIP_STREAM_MAXBLK ? ACHIP_STREAM_MAXBLK : (int)nb;
 }
 
-/* ---- workgroup-scope LDS words of the look-back ------------------------------------------------- */
-__device__ inline void slot_store(uint32_t *p, uint32_t v) {
-#ifdef ACHIP_HIPEMU
-  *reinterpret_cast<volatile uint32_t *>(p) = v;
-#else
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
-}
-__device__ inline uint32_t slot_load(const uint32_t *p) {
-#ifdef ACHIP_HIPEMU
-  return *reinterpret_cast<const volatile uint32_t *>(p);
-#else
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
-}
-__device__ inline uint32_t slot_fetch_add(uint32_t *p, uint32_t v) {
-#ifdef ACHIP_HIPEMU
-  const uint32_t old = *reinterpret_cast<volatile uint32_t *>(p); /* fibers of one thread: no switch in between */
-  *reinterpret_cast<volatile uint32_t *>(p) = old + v;
-  return old;
-#else
-  return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
-}
-__device__ inline void slot_xor(uint32_t *p, uint32_t v) {
-#ifdef ACHIP_HIPEMU
-  *reinterpret_cast<volatile uint32_t *>(p) = *reinterpret_cast<volatile uint32_t *>(p) ^ v;
-#else
-  (void)__hip_atomic_fetch_xor(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
-}
+/* ---- workgroup-scope LDS words of the look-back (gfx950_ops.hpp: relaxed workgroup-scope atomics) ---------------- */
+__device__ inline void slot_store(uint32_t *p, uint32_t v) { wg_store_u32(p, v); }
+__device__ inline uint32_t slot_load(const uint32_t *p) { return wg_load_u32(p); }
+__device__ inline uint32_t slot_fetch_add(uint32_t *p, uint32_t v) { return wg_fetch_add_u32(p, v); }
+__device__ inline void slot_xor(uint32_t *p, uint32_t v) { wg_xor_u32(p, v); }
 #define ACHIP_SLOT_AGG (1u << 30)
 #define ACHIP_SLOT_PREFIX (2u << 30)
 #define ACHIP_SLOT_VALUE 0x3FFFFFFFu
-
-/* lane l receives lane l-1's value; lane 0 receives `first` (one DPP move, no LDS round trip) */
-__device__ inline uint32_t wave_shift_up1(uint32_t v, uint32_t first) {
-#ifdef ACHIP_HIPEMU
-  const int l = hipemu::lane();
-  const uint32_t t = hipemu::shfl_from(v, l - 1);
-  return l == 0 ? first : t;
-#else
-  return (uint32_t)__builtin_amdgcn_update_dpp((int)first, (int)v, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
-#endif
-}
 
 /* bytes of the frame in front of block `blk` (blk >= 1): sums the predecessors' words, newest first, 64 per
  * poll, until an inclusive prefix is met.  Returns 0xFFFFFFFF if a predecessor never publishes (bounded). */
@@ -160,9 +123,7 @@ __device__ inline uint32_t stream_lookback(const uint32_t *slots, int blk, int l
       continue;
     }
     spin++;
-#ifndef ACHIP_HIPEMU
-    __builtin_amdgcn_s_sleep(1);
-#endif
+    spin_nap<1>();
   }
   return 0xFFFFFFFFu;
 }
@@ -195,12 +156,8 @@ __device__ inline uint32_t stream_request(const achip_frame_t &f, const StreamSr
   const uint32_t back = a != 0u ? 1u : 0u; /* byte before the pixel + the pixel: never past the last pixel */
   kind = back ? RAW_BACK : RAW_FIRST;
   const ACHIP_GLOBAL uint8_t *p = (const ACHIP_GLOBAL uint8_t *)s.base + (a - back);
-#ifndef ACHIP_HIPEMU
-  if (NT) {
-    typedef uint32_t u32_unaligned __attribute__((aligned(1)));
-    return __builtin_nontemporal_load((const ACHIP_GLOBAL u32_unaligned *)p);
-  }
-#endif
+  if (NT)
+    return load_u32_unaligned_nt((const uint8_t *)p);
   return ((const ACHIP_GLOBAL unaligned_u32 *)p)->v;
 }
 
@@ -218,13 +175,7 @@ struct StreamTagCached {
 __device__ inline uint32_t wave_mulmod_uniform(uint32_t a, uint32_t b, int lane, uint32_t xk) {
   /* reflected order: bit 31-i of a word is the coefficient of x^i.  Coefficient k of the product pairs bit p of a
    * with bit 62-k-p of b: the parity of a & m_k, m_k = bitreverse(b) slid so that its bit 31 lands on bit 62-k */
-#ifdef ACHIP_HIPEMU /* g++ has no bit-reverse builtin */
-  uint32_t rb = 0;
-  for (int i = 0; i < 32; i++)
-    rb |= ((b >> i) & 1u) << (31 - i);
-#else
-  const uint32_t rb = __builtin_bitreverse32(b);
-#endif
+  const uint32_t rb = bitreverse32(b);
   const uint32_t m = (uint32_t)((((uint64_t)rb) << 31) >> lane);
   const uint32_t c = (uint32_t)__builtin_popcount(a & m) & 1u;
   return wave_read_lane(wave_xor_to_last((0u - c) & xk), 63);
@@ -316,15 +267,11 @@ __global__ void __launch_bounds__(WAVES * 64)
   /* prof (diagnostics, NULL in production launches): 8 timestamps of the 100 MHz wall clock per wave, for the wave's
    * FIRST block -- prof[(frame*WAVES + wave)*8 + k]: 0 kernel entry, 1 prologue barrier passed, 2 samples requested,
    * 3 samples arrived, 4 tokens + scan done, 5 look-back done, 6 token bytes in LDS, 7 stores issued */
-#ifdef ACHIP_HIPEMU
-#define ACHIP_SSTAMP(slot) do { } while (0)
-#else
 #define ACHIP_SSTAMP(slot)                                                                                             \
   do {                                                                                                                 \
     if (prof && lane == 0 && first_block)                                                                              \
-      prof[((size_t)fidx * WAVES + wave) * 8u + (slot)] = wall_clock64();                                              \
+      prof[((size_t)fidx * WAVES + wave) * 8u + (slot)] = wall_now();                                                  \
   } while (0)
-#endif
   static_assert(mode_is_cell(MODE), "run-structured modes use render_frames_kernel");
   using L = SLds<MODE, WAVES, CPL, CRC>;
   constexpr int BLOCK = WAVES * 64;
@@ -335,17 +282,15 @@ __global__ void __launch_bounds__(WAVES * 64)
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63, wave = wave_uniform(tid >> 6);
   const int fidx = (int)blockIdx.x;
-#ifndef ACHIP_HIPEMU
   /* Every kernel argument the prologue needs is requested HERE, in one burst of scalar loads: left to itself the
    * compiler loads each argument at its first use, behind the branches above it -- six dependent round trips to
    * the kernarg segment in front of the first gather (profiles/r02_stream_timeline.txt). */
-  asm volatile("" ::"s"(n_frames), "s"(lut), "s"(out), "s"(out_stride), "s"(out_len), "s"(prof), "s"(frames),
-               "s"(uni.enabled), "s"(uni.flags), "s"(uni.src_pitch), "s"(uni.f.src), "s"(uni.f.comp));
-  asm volatile("" ::"s"(uni.f.src_w), "s"(uni.f.src_h), "s"(uni.f.out_w), "s"(uni.f.out_h), "s"(uni.f.pad_left),
-               "s"(uni.f.pad_top), "s"(uni.f.x_ratio), "s"(uni.f.y_ratio), "s"(uni.f.src_stride), "s"(uni.f.ops));
-  if (CRC)
-    asm volatile("" ::"s"(crc_out), "s"(crc_tab));
-#endif
+  ACHIP_DEVICE_ONLY(
+      asm volatile("" ::"s"(n_frames), "s"(lut), "s"(out), "s"(out_stride), "s"(out_len), "s"(prof), "s"(frames),
+                   "s"(uni.enabled), "s"(uni.flags), "s"(uni.src_pitch), "s"(uni.f.src), "s"(uni.f.comp));
+      asm volatile("" ::"s"(uni.f.src_w), "s"(uni.f.src_h), "s"(uni.f.out_w), "s"(uni.f.out_h), "s"(uni.f.pad_left),
+                   "s"(uni.f.pad_top), "s"(uni.f.x_ratio), "s"(uni.f.y_ratio), "s"(uni.f.src_stride), "s"(uni.f.ops));
+      if (CRC) asm volatile("" ::"s"(crc_out), "s"(crc_tab));)
   if (fidx >= n_frames)
     return;
   bool first_block = true;
@@ -532,9 +477,7 @@ __global__ void __launch_bounds__(WAVES * 64)
       issue_any(cell0_next, pos_next, raw_n, ext_n, kinds_n);
 
     if (prof) { /* diagnostics only: make "samples arrived" a point in time */
-#ifndef ACHIP_HIPEMU
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
+      wait_vmem_all();
       ACHIP_SSTAMP(3);
     }
     /* ---- tokens and lengths (registers).  Written select-style: per-lane conditions become v_cndmask, not
@@ -783,11 +726,8 @@ __global__ void __launch_bounds__(WAVES * 64)
       }
     }
 
-#ifndef ACHIP_HIPEMU
     if (CRC && prof && lane == 0 && stamp_crc)
-      prof[((size_t)fidx * WAVES + wave) * 8u + 7] = wall_clock64();
-#endif
-    (void)stamp_crc;
+      prof[((size_t)fidx * WAVES + wave) * 8u + 7] = wall_now();
 
     /* ---- next block */
     cell0 = cell0_next;

@@ -18,7 +18,7 @@ _lib = None
 
 def build():
     srcs = [os.path.join(EMU_DIR, "emu_driver.cpp"), os.path.join(EMU_DIR, "hip_emu.h"),
-            os.path.join(CSRC, "render_kernels.hpp"), os.path.join(CSRC, "render_stream.hpp"), os.path.join(CSRC, "stream_kernels.hpp"), os.path.join(CSRC, "crc_kernels.hpp"), os.path.join(CSRC, "crc_math.hpp"),
+            os.path.join(CSRC, "render_kernels.hpp"), os.path.join(CSRC, "render_stream.hpp"), os.path.join(CSRC, "stream_kernels.hpp"), os.path.join(CSRC, "crc_kernels.hpp"), os.path.join(CSRC, "crc_math.hpp"), os.path.join(EMU_DIR, "gfx950_ops.hpp"),
             os.path.join(CSRC, "render_variants.h"),
             os.path.join(INC, "achip_types.h"), os.path.join(CSRC, "achip_host.c"), os.path.join(INC, "achip_host.h")]
     if os.path.exists(EMU_SO) and all(os.path.getmtime(s) <= os.path.getmtime(EMU_SO) for s in srcs):
@@ -27,7 +27,7 @@ def build():
     obj = os.path.join(os.path.dirname(EMU_SO), "achip_host.o")
     subprocess.check_call(["gcc", "-std=gnu11", "-O2", "-fPIC", "-I" + INC, "-c", os.path.join(CSRC, "achip_host.c"), "-o", obj])
     extra = os.environ.get("ACHIP_EMU_DEFS", "").split()  # e.g. -DACHIP_EMIT_OR_MODES=0x3FF to test an experiment
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-shared", "-fPIC", *extra, "-I" + CSRC, "-I" + INC, "-I" + EMU_DIR,
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-shared", "-fPIC", *extra, "-I" + EMU_DIR, "-I" + CSRC, "-I" + INC,  # EMU_DIR first: <gfx950_ops.hpp> = the emulator's twin
                            os.path.join(EMU_DIR, "emu_driver.cpp"), obj, "-o", EMU_SO])
     return EMU_SO
 

@@ -1,0 +1,91 @@
+/*
+ * gfx950_ops.hpp (emulator twin) -- the interface of ascii-chat_amd/csrc/gfx950_ops.hpp on top of hip_emu.h's fibers, so
+ * that the kernel sources compile unchanged under g++ and run on the CPU test box.  TESTS ONLY: found ahead of the
+ * product header because the emulator build lists this directory first on the include path.
+ */
+#pragma once
+
+#include "hip_emu.h"
+
+#define ACHIP_SMEM (hipemu::g_smem.data())
+#define ACHIP_GLOBAL
+#define ACHIP_EMULATED 1
+#define ACHIP_DEVICE_ONLY(...)
+#define ACHIP_WAVES_PER_EU(n)
+
+namespace achip {
+
+template <int OFF, bool HI> inline void ds_store_byte(uint32_t addr, uint32_t v) {
+  ACHIP_SMEM[addr + OFF] = (unsigned char)(HI ? v >> 16 : v);
+}
+inline void ds_or_u32(uint32_t addr, uint32_t v) { *reinterpret_cast<uint32_t *>(ACHIP_SMEM + addr) |= v; }
+inline void keep_alive(uint32_t, uint32_t) {}
+inline uint32_t lds_base_addr() { return 0u; }
+/* a wave's lanes run in lockstep on the GPU: every lane's stores precede the reads behind the fence */
+inline void lds_store_fence() { hipemu::wave_barrier(); }
+inline void wait_vmem_all() {}
+
+/* fibers of one OS thread: no switch inside a plain read-modify-write */
+inline void agent_store_u64(unsigned long long *p, unsigned long long w) { *reinterpret_cast<volatile unsigned long long *>(p) = w; }
+inline unsigned long long agent_load_u64(const unsigned long long *p) {
+  return *reinterpret_cast<const volatile unsigned long long *>(p);
+}
+template <int N> inline void spin_nap() {}
+inline void wg_store_u32(uint32_t *p, uint32_t v) { *reinterpret_cast<volatile uint32_t *>(p) = v; }
+inline uint32_t wg_load_u32(const uint32_t *p) { return *reinterpret_cast<const volatile uint32_t *>(p); }
+inline uint32_t wg_fetch_add_u32(uint32_t *p, uint32_t v) {
+  const uint32_t old = *reinterpret_cast<volatile uint32_t *>(p);
+  *reinterpret_cast<volatile uint32_t *>(p) = old + v;
+  return old;
+}
+inline void wg_xor_u32(uint32_t *p, uint32_t v) {
+  *reinterpret_cast<volatile uint32_t *>(p) = *reinterpret_cast<volatile uint32_t *>(p) ^ v;
+}
+
+inline uint64_t wave_ballot(bool p) { return hipemu::ballot(p); }
+inline uint32_t wave_shfl_up(uint32_t v, int d) {
+  return hipemu::shfl_from(v, hipemu::lane() - d); /* src < 0 -> own value, like __shfl_up */
+}
+inline uint32_t wave_read_lane(uint32_t v, int lane) { return hipemu::shfl_from(v, lane); }
+inline int wave_uniform(int v) { return v; }
+inline uint32_t wave_inclusive_scan(uint32_t v) {
+  const int l = hipemu::lane();
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t t = hipemu::shfl_from(v, l - d);
+    if (l >= d)
+      v += t;
+  }
+  return v;
+}
+inline uint32_t wave_xor_to_last(uint32_t v) {
+  const int l = hipemu::lane();
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t t = hipemu::shfl_from(v, l - d);
+    if (l >= d)
+      v ^= t;
+  }
+  return v;
+}
+inline uint32_t wave_shift_up1(uint32_t v, uint32_t first) {
+  const int l = hipemu::lane();
+  const uint32_t t = hipemu::shfl_from(v, l - 1);
+  return l == 0 ? first : t;
+}
+inline uint32_t bitreverse32(uint32_t v) {
+  uint32_t r = 0;
+  for (int i = 0; i < 32; i++)
+    r |= ((v >> i) & 1u) << (31 - i);
+  return r;
+}
+
+struct __attribute__((packed)) unaligned_u32 {
+  uint32_t v;
+};
+inline uint32_t load_u32_unaligned_nt(const uint8_t *p) { return reinterpret_cast<const unaligned_u32 *>(p)->v; }
+inline uint32_t opaque(uint32_t v) { return v; }
+inline void store_u4_nt(uint8_t *p, uint4 v) { *reinterpret_cast<uint4 *>(p) = v; }
+
+inline unsigned long long cycle_now() { return 0ull; }
+inline unsigned long long wall_now() { return 0ull; }
+
+} // namespace achip

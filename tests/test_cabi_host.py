@@ -87,8 +87,8 @@ def test_product_and_oracle_do_not_share_code(pkg):
             if fn.endswith((".c", ".h", ".hpp", ".hip", ".py")) or fn == "Makefile":
                 src = open(os.path.join(root, fn), encoding="utf-8", errors="replace").read()
                 assert "oracle/" not in src and "orc_" not in src, fn
-                if fn == "Makefile":
-                    assert "HIPEMU" not in src  # the CPU fiber emulator is a test-only build of the kernel source
+                # the CPU fiber emulator is a test-only build of the same kernel sources: nothing of it in the product tree
+                assert "ACHIP_HIPEMU" not in src and "hip_emu.h" not in src and "hipemu::" not in src, fn
     assert "hipemu" not in subprocess.run(["nm", "-C", pkg.LIB_PATH], capture_output=True, text=True).stdout
 
 
