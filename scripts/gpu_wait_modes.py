@@ -1,5 +1,5 @@
 """Wall time of a K-step burst (barrier + synchronize on both sides, as bench.py's regions) for one completion-wait
-mode (env ASCIICHAT_HIP_WAIT_MODE, read once per process) and S streams."""
+mode (env ASCIICHAT_HIP_WAIT_MODE (experimental builds only), read once per process) and S streams."""
 import os, sys, time, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -25,7 +25,7 @@ for S in (4, 2, 1):
             torch.cuda.synchronize(); t3 = time.perf_counter()
             parts.append((t1 - t0, t2 - t1, t3 - t2, t3 - t0))
         m = [statistics.median(p[i] for p in parts) * 1e6 for i in range(4)]
-        print(f"mode {os.environ.get('ASCIICHAT_HIP_WAIT_MODE', 'default')} streams {S} K={K:3d}: issue {m[0]:6.1f} wait {m[1]:6.1f} "
+        print(f"mode {os.environ.get('ASCIICHAT_HIP_WAIT_MODE (experimental builds only)', 'default')} streams {S} K={K:3d}: issue {m[0]:6.1f} wait {m[1]:6.1f} "
               f"sync {m[2]:5.1f} total {m[3]:6.1f} us = {m[3] / K:6.2f} us/step", flush=True)
     run.sched.close()
     for p in plans:
