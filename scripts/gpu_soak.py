@@ -59,7 +59,7 @@ def main():
         if not frames:
             continue
         plan = pkg.Plan(mode, palette, frames)
-        choice = int(rng.integers(0, 5))
+        choice = int(rng.integers(0, 8))
         try:
             if choice == 1:
                 plan.set_split(-1)
@@ -70,6 +70,8 @@ def main():
             elif choice == 4:
                 plan.set_variant(int(rng.choice([1, 2, 4])))
                 plan.set_split(int(rng.integers(1, 6)))
+            elif choice >= 5:  # the stream kernel's geometries (per-cell modes; refused for the others)
+                plan.set_variant(int(rng.choice([16, 17, 17, 18, 19])))
         except RuntimeError:
             pass  # geometry cannot hold this batch's rows: keep the automatic one
         out = torch.full((len(frames) * plan.stride,), 0xAB, dtype=torch.uint8, device="cuda")
@@ -104,6 +106,26 @@ def main():
                 eh, ep = orc.ascii_frame_packet(got, W, H)
                 assert int(crc_h[k]) == orc.crc32c(got) and hdr_h[24 * k:24 * k + 24].tobytes() == eh and int(pkt_h[k]) == ep, ("crc", rnd, k, len(got))
             checked += 1
+        # render + frame CRC in one go (fused into the stream kernel where the plan's geometry carries it, the
+        # stand-alone kernel behind the render otherwise): same bytes, same checksums, same headers
+        out_c = torch.full((len(frames) * plan.stride,), 0x5C, dtype=torch.uint8, device="cuda")
+        ln_c = torch.zeros(nfr, dtype=torch.int32, device="cuda")
+        crc_c = torch.full((nfr,), 0x7E7E7E7E, dtype=torch.int32, device="cuda")
+        hdr_c = torch.zeros(nfr * 24, dtype=torch.uint8, device="cuda")
+        pkt_c = torch.zeros(nfr, dtype=torch.int32, device="cuda")
+        st_c = torch.cuda.current_stream().cuda_stream
+        plan.render_crc(out_c.data_ptr(), plan.stride, ln_c.data_ptr(), crc_c.data_ptr(), st_c)
+        assert pkg.lib().asciichat_hip_packets_from_crc(ln_c.data_ptr(), crc_c.data_ptr(), nfr, dims_t.data_ptr(), hdr_c.data_ptr(),
+                                                        pkt_c.data_ptr(), st_c) == 0, pkg.last_error()
+        torch.cuda.synchronize()
+        lens_c = ln_c.cpu().numpy().astype(np.uint32)
+        assert (lens_c == lens).all(), ("render_crc lengths", rnd, plan.variant)
+        host_c = out_c.cpu().numpy()
+        for k in range(nfr):
+            assert host_c[k * plan.stride:k * plan.stride + int(lens[k])].tobytes() == host[k * plan.stride:k * plan.stride + int(lens[k])].tobytes(), ("render_crc bytes", rnd, k)
+        assert (crc_c.cpu().numpy().astype(np.uint32) == crc_h).all(), ("fused crc", rnd, plan.variant, plan.fused_crc)
+        assert (pkt_c.cpu().numpy().astype(np.uint32) == pkt_h).all() and (hdr_c.cpu().numpy() == hdr_h).all(), ("fused packets", rnd)
+        fused_rounds = locals().get("fused_rounds", 0) + int(plan.fused_crc)
         # the same plan after an update to new terminal sizes (the tick when clients resize), rendered as two
         # sub-ranges into the slab (what the ranks of a sharded batch do)
         if rnd % 3 == 0 and (flt or fx or fy) == 0:
@@ -134,7 +156,8 @@ def main():
                     got2 = host2[k * plan.stride:k * plan.stride + int(lens2[k])].tobytes()
                     assert got2 == oracle_case(img, W2, H2, mode, aspect, pad, palette), ("update", rnd, k, W2, H2, plan.variant, plan.parts)
                     checked += 1
-        print(f"round {rnd:3d}: {MODE_NAMES[mode]:10s} frames {len(frames):3d} geometry v{plan.variant} bands {plan.parts:3d} ok", flush=True)
+        print(f"round {rnd:3d}: {MODE_NAMES[mode]:10s} frames {len(frames):3d} geometry v{plan.variant} bands {plan.parts:3d} "
+              f"{'crc fused' if plan.fused_crc else 'crc separate'} ok", flush=True)
         plan.close()
     # pixel-space composites (the server's multi-source grid): random source counts / sizes / terminal sizes,
     # rendered fused (canvas never built) for several client modes at once
