@@ -162,6 +162,8 @@ def lib():
     L.asciichat_hip_grid_destroy.argtypes = [vp]
     L.asciichat_hip_plan_render_crc.restype = ci
     L.asciichat_hip_plan_render_crc.argtypes = [vp, vp, sz, vp, vp, vp]
+    L.asciichat_hip_plan_render_packets.restype = ci
+    L.asciichat_hip_plan_render_packets.argtypes = [vp, vp, sz, vp, vp, vp, vp, vp, vp]
     L.asciichat_hip_plan_render_crc_profiled.restype = ci
     L.asciichat_hip_plan_render_crc_profiled.argtypes = [vp, vp, sz, vp, vp, vp, vp]
     L.asciichat_hip_plan_has_fused_crc.restype = ci
@@ -370,6 +372,12 @@ class Plan:
         rc = lib().asciichat_hip_plan_render_crc(self._h, out_ptr, out_stride, len_ptr, crc_ptr, stream)
         if rc != 0:
             raise RuntimeError(f"plan_render_crc failed ({rc}): {last_error()}")
+
+    def render_packets(self, out_ptr, out_stride, len_ptr, dims_ptr, crc_ptr, hdr_ptr, pkt_ptr, stream=0):
+        rc = lib().asciichat_hip_plan_render_packets(self._h, out_ptr, out_stride, len_ptr, dims_ptr, crc_ptr, hdr_ptr,
+                                                     pkt_ptr, stream)
+        if rc != 0:
+            raise RuntimeError(f"plan_render_packets failed ({rc}): {last_error()}")
 
     @property
     def fused_crc(self):

@@ -21,10 +21,12 @@ int achip_launch_render(int mode, int variant, int has_composite, const achip_fr
                         const achip_uniform_t *uniform /* NULL, or the batch's common descriptor (achip_frames_uniform) */,
                         void *stream);
 /* the same for a whole-frame launch of a per-cell mode in a stream geometry that carries the fused frame CRC
- * (achip_variant_has_crc): crc_out[i] = asciichat_crc32(frame i), 0 for a frame that did not fit its slot */
+ * (achip_variant_has_crc): wire->crc[i] = asciichat_crc32(frame i), 0 for a frame that did not fit its slot; with
+ * wire->hdr / wire->pkt_crc also the 24-byte packet headers and the CRCs of header || frame */
 int achip_launch_render_crc(int mode, int variant, int has_composite, const achip_frame_t *frames_dev, int n_frames,
                             const achip_lut_t *lut_dev, uint8_t *out, uint64_t out_stride, uint32_t *out_len,
-                            uint32_t *crc_out, const achip_uniform_t *uniform, unsigned long long *prof, void *stream);
+                            const achip_wire_t *wire, const achip_uniform_t *uniform, unsigned long long *prof,
+                            void *stream);
 int achip_variant_has_crc(int variant);
 /* 24-byte ascii_frame_packet_t headers and header || frame CRCs from lengths + frame CRCs that are already known */
 int achip_launch_packets_from_crc(const uint32_t *len_dev, const uint32_t *crc_dev, const uint32_t *dims_dev, int n,

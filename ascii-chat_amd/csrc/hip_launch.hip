@@ -48,17 +48,17 @@ extern "C" int achip_launch_render(int mode, int variant, int has_composite, con
 /* whole-frame launch of a per-cell mode with the frame CRC-32C riding the drain (stream geometries 16 / 17) */
 extern "C" int achip_launch_render_crc(int mode, int variant, int has_composite, const achip_frame_t *frames_dev,
                                        int n_frames, const achip_lut_t *lut_dev, uint8_t *out, uint64_t out_stride,
-                                       uint32_t *out_len, uint32_t *crc_out, const achip_uniform_t *uniform,
+                                       uint32_t *out_len, const achip_wire_t *wire, const achip_uniform_t *uniform,
                                        unsigned long long *prof, void *stream) {
   if (n_frames <= 0)
     return (int)hipSuccess;
-  if (!crc_out)
+  if (!wire || !wire->crc)
     return (int)hipErrorInvalidValue;
   switch (variant) {
 #define X(id, W, C)                                                                                                    \
   case id:                                                                                                             \
     return achip_render_sinst_launch_##id(mode, has_composite, frames_dev, n_frames, lut_dev, out, out_stride, out_len, \
-                                          uniform, prof, crc_out, stream);
+                                          uniform, prof, wire, stream);
     ACHIP_STREAM_VARIANTS(X)
 #undef X
   }

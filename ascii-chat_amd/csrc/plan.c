@@ -437,38 +437,60 @@ int asciichat_hip_plan_render(asciichat_hip_plan_t *p, uint8_t *out_dev, size_t 
 /* Render + frame CRC-32C in one go ("a CRC over the output slab can ride the emit kernel").  Whole-frame
  * launches of the per-cell modes carry the checksum inside the stream kernel's drain; every other plan renders and
  * then runs the stand-alone CRC kernel on the slab -- same results either way. */
-static int plan_render_crc(asciichat_hip_plan_t *p, uint8_t *out_dev, size_t out_stride, uint32_t *out_len_dev,
-                           uint32_t *crc_out_dev, unsigned long long *prof, void *stream) {
-  if (!p || !out_dev || !out_len_dev || !crc_out_dev)
-    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "plan_render_crc: bad arguments");
+static int plan_render_wire(asciichat_hip_plan_t *p, uint8_t *out_dev, size_t out_stride, uint32_t *out_len_dev,
+                            const achip_wire_t *wire, unsigned long long *prof, void *stream) {
+  if (!p || !out_dev || !out_len_dev || !wire->crc)
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "plan_render_crc / plan_render_packets: bad arguments");
   if (((uintptr_t)out_dev & 15u) || (out_stride & 15u) || out_stride < p->stride)
     return achip_fail(ASCIICHAT_HIP_ERR_BUFFER, "output slab must be 16-byte aligned with stride >= %zu (multiple of 16)",
                       p->stride);
+  if (((uintptr_t)wire->hdr & 7u))
+    return achip_fail(ASCIICHAT_HIP_ERR_BUFFER, "packet headers must be 8-byte aligned");
   if (p->parts == 1 && achip_variant_has_crc(p->variant)) {
     achip_uniform_t uni = p->uniform;
     if (p->uniform_off)
       uni.enabled = 0;
     uni.flags = (p->palette_ascii ? ACHIP_UNIFORM_PALETTE_ASCII : 0u) | ACHIP_UNIFORM_MAX_CELLS(p->max_cells);
     return achip_hip_check(achip_launch_render_crc(p->mode, p->variant, p->has_comp, p->frames_dev, p->n, p->lut_dev, out_dev,
-                                                   (uint64_t)out_stride, out_len_dev, crc_out_dev, &uni, prof, stream),
+                                                   (uint64_t)out_stride, out_len_dev, wire, &uni, prof, stream),
                            "render + crc kernel launch");
   }
   int rc = render_range(p, 0, p->n, out_dev, out_stride, out_len_dev, prof, stream);
   if (!rc)
-    rc = asciichat_hip_crc32c(out_dev, out_stride, out_len_dev, 0, (uint32_t)out_stride, p->n, crc_out_dev, stream);
+    rc = wire->hdr || wire->pkt_crc
+             ? asciichat_hip_frame_packets(out_dev, out_stride, out_len_dev, (uint32_t)out_stride, p->n, wire->dims, wire->crc,
+                                           wire->hdr, wire->pkt_crc, stream)
+             : asciichat_hip_crc32c(out_dev, out_stride, out_len_dev, 0, (uint32_t)out_stride, p->n, wire->crc, stream);
   return rc;
 }
 
+/* Render + frame CRC-32C in one go ("a CRC over the output slab can ride the emit kernel").  Whole-frame
+ * launches of the per-cell modes carry the checksum inside the stream kernel's drain; every other plan renders and
+ * then runs the stand-alone CRC kernel on the slab -- same results either way. */
 int asciichat_hip_plan_render_crc(asciichat_hip_plan_t *p, uint8_t *out_dev, size_t out_stride, uint32_t *out_len_dev,
                                   uint32_t *crc_out_dev, void *stream) {
-  return plan_render_crc(p, out_dev, out_stride, out_len_dev, crc_out_dev, NULL, stream);
+  const achip_wire_t wire = {crc_out_dev, NULL, NULL, NULL};
+  return plan_render_wire(p, out_dev, out_stride, out_len_dev, &wire, NULL, stream);
+}
+
+/* ... and the whole wire stage: frames, frame CRCs, 24-byte ascii_frame_packet_t headers, CRCs of header || frame --
+ * ONE launch where the plan's geometry carries the fused CRC (the wave that finishes a frame writes its header and
+ * packet CRC too), render + asciichat_hip_frame_packets otherwise. */
+int asciichat_hip_plan_render_packets(asciichat_hip_plan_t *p, uint8_t *out_dev, size_t out_stride, uint32_t *out_len_dev,
+                                      const uint32_t *dims_dev, uint32_t *crc_out_dev, uint8_t *hdr_out_dev,
+                                      uint32_t *packet_crc_out_dev, void *stream) {
+  if (!hdr_out_dev)
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "plan_render_packets: no header buffer");
+  const achip_wire_t wire = {crc_out_dev, dims_dev, hdr_out_dev, packet_crc_out_dev};
+  return plan_render_wire(p, out_dev, out_stride, out_len_dev, &wire, NULL, stream);
 }
 
 /* diagnostics: the same launch with the per-wave timestamps of plan_render_profiled */
 int asciichat_hip_plan_render_crc_profiled(asciichat_hip_plan_t *p, uint8_t *out_dev, size_t out_stride,
                                            uint32_t *out_len_dev, uint32_t *crc_out_dev,
                                            unsigned long long *phase_cycles_dev, void *stream) {
-  return plan_render_crc(p, out_dev, out_stride, out_len_dev, crc_out_dev, phase_cycles_dev, stream);
+  const achip_wire_t wire = {crc_out_dev, NULL, NULL, NULL};
+  return plan_render_wire(p, out_dev, out_stride, out_len_dev, &wire, phase_cycles_dev, stream);
 }
 
 int asciichat_hip_plan_has_fused_crc(const asciichat_hip_plan_t *p) {

@@ -24,7 +24,7 @@ ACHIP_VARIANTS(X)
 #define X(id, W, C)                                                                                                    \
   int achip_render_sinst_launch_##id(int mode, int comp, const achip_frame_t *frames, int n, const achip_lut_t *lut,   \
                                      uint8_t *out, uint64_t stride, uint32_t *len, const achip_uniform_t *uniform,     \
-                                     unsigned long long *prof, uint32_t *crc_out, void *stream);                                                                    \
+                                     unsigned long long *prof, const achip_wire_t *wire, void *stream);                                                                    \
   int achip_render_sinst_lds_##id(int mode);
 ACHIP_STREAM_VARIANTS(X)
 #undef X

@@ -257,12 +257,13 @@ template <int MODE, int WAVES, int CPL, bool GENERIC, bool CRC = false>
 __global__ void __launch_bounds__(WAVES * 64)
     render_stream_kernel(const achip_frame_t *__restrict__ frames, const achip_lut_t *__restrict__ lut,
                          uint8_t *__restrict__ out, uint64_t out_stride, uint32_t *__restrict__ out_len, int n_frames,
-                         achip_uniform_t uni, unsigned long long *__restrict__ prof, uint32_t *__restrict__ crc_out,
+                         achip_uniform_t uni, unsigned long long *__restrict__ prof, achip_wire_t wire,
                          const uint4 *__restrict__ crc_tab) {
   /* CRC = true: the frame's CRC-32C (asciichat_crc32, lib/network/crc32.c:95-190 -- what acip_send_ascii_frame puts
    * into ascii_frame_packet_t.checksum, lib/network/acip/server.c:186-214) rides the drain: every wave checksums its
    * block while the bytes are in its staging area, the last wave to finish combines the blocks (a CRC is linear over
-   * GF(2): raw(A || B) = raw(A) * x^(8|B|) xor raw(B)) and writes crc_out[frame].  crc_tab: the constant tables
+   * GF(2): raw(A || B) = raw(A) * x^(8|B|) xor raw(B)) and writes wire.crc[frame] -- and, when asked for, the frame's
+   * 24-byte network-order header and the CRC of header || frame (acip_send_ascii_frame).  crc_tab: the constant tables
    * (crc_tables_init_kernel's image, SLds::TAB_BYTES).  Both unused otherwise. */
   /* prof (diagnostics, NULL in production launches): 8 timestamps of the 100 MHz wall clock per wave, for the wave's
    * FIRST block -- prof[(frame*WAVES + wave)*8 + k]: 0 kernel entry, 1 prologue barrier passed, 2 samples requested,
@@ -290,7 +291,7 @@ __global__ void __launch_bounds__(WAVES * 64)
                    "s"(uni.enabled), "s"(uni.flags), "s"(uni.src_pitch), "s"(uni.f.src), "s"(uni.f.comp));
       asm volatile("" ::"s"(uni.f.src_w), "s"(uni.f.src_h), "s"(uni.f.out_w), "s"(uni.f.out_h), "s"(uni.f.pad_left),
                    "s"(uni.f.pad_top), "s"(uni.f.x_ratio), "s"(uni.f.y_ratio), "s"(uni.f.src_stride), "s"(uni.f.ops));
-      if (CRC) asm volatile("" ::"s"(crc_out), "s"(crc_tab));)
+      if (CRC) asm volatile("" ::"s"(wire.crc), "s"(wire.dims), "s"(wire.hdr), "s"(wire.pkt_crc), "s"(crc_tab));)
   if (fidx >= n_frames)
     return;
   bool first_block = true;
@@ -300,6 +301,11 @@ __global__ void __launch_bounds__(WAVES * 64)
   constexpr int TABV = L::TAB_BYTES / 16, TABN = (TABV + BLOCK - 1) / BLOCK;
   typedef uint32_t tab4_t __attribute__((vector_size(16))); /* a native vector: HIP's uint4 class keeps the array in scratch */
   tab4_t tabv[TABN > 0 ? TABN : 1];
+  uint32_t dim_w = 0, dim_h = 0; /* header fields of this frame: every wave may be the one that finishes it */
+  if (CRC && wire.dims) {
+    dim_w = wire.dims[2 * fidx];
+    dim_h = wire.dims[2 * fidx + 1];
+  }
   if (CRC) {
 #pragma unroll
     for (int k = 0; k < TABN; k++) /* clamped, not predicated: the values stay in registers */
@@ -334,8 +340,14 @@ __global__ void __launch_bounds__(WAVES * 64)
       cells_ll > (long long)stream_maxblk(uni.flags, BLK) * BLK || out_stride > (uint64_t)ACHIP_STREAM_MAX_STRIDE) {
     if (tid == 0) {
       out_len[fidx] = ACHIP_LEN_BADDESC;
-      if (CRC)
-        crc_out[fidx] = 0u;
+      if (CRC) {
+        wire.crc[fidx] = 0u;
+        if (wire.hdr) /* as the stand-alone kernel reports an unusable frame: a header of zeros, its CRC behind it */
+          for (int j = 0; j < 24; j++)
+            wire.hdr[(size_t)fidx * 24u + j] = 0;
+        if (wire.pkt_crc)
+          wire.pkt_crc[fidx] = ~crc_mulmod(0xFFFFFFFFu, crc_pow(CRC_X8, 24u));
+      }
     }
     return;
   }
@@ -696,9 +708,9 @@ __global__ void __launch_bounds__(WAVES * 64)
          * newlines || block 0 || block 1 || ...  Every prefix is in the look-back words by now. */
         const uint32_t n_total = slot_load(&slots[nblk - 1]) & ACHIP_SLOT_VALUE;
         const bool fits = n_total <= cap_bytes;
-        uint32_t total_raw = 0;
+        const uint32_t xn = fits ? wave_x8_pow_uniform(pw, n_total, lane, xk) : CRC_X0; /* x^(8 * frame length) */
+        uint32_t fraw = 0; /* raw(M): the register after the frame starting from 0 */
         if (fits) {
-          total_raw = wave_mulmod_uniform(0xFFFFFFFFu, wave_x8_pow_uniform(pw, n_total, lane, xk), lane, xk);
           if (first_base > 0u) { /* ascii_pad_frame_height's newlines in front: lanes take runs of them */
             const uint32_t per = (first_base + 63u) / 64u;
             const uint32_t lo = (uint32_t)lane * per, hi = lo + per < first_base ? lo + per : first_base;
@@ -707,7 +719,7 @@ __global__ void __launch_bounds__(WAVES * 64)
               st = (st >> 8) ^ slice[(st ^ (uint32_t)'\n') & 0xFFu];
             if (lo < hi)
               st = crc_mulmod(st, crc_x8_pow_len(n_total - hi));
-            total_raw ^= wave_read_lane(wave_xor_to_last(lo < hi ? st : 0u), 63);
+            fraw ^= wave_read_lane(wave_xor_to_last(lo < hi ? st : 0u), 63);
           }
           if (slot_load(&crcacc[1]) != 0u) { /* blocks that finished before the frame's length was known */
             uint32_t acc = 0;
@@ -717,12 +729,36 @@ __global__ void __launch_bounds__(WAVES * 64)
               if (v != 0u)
                 acc ^= crc_mulmod(v, crc_x8_pow_len(n_total - (slot_load(&slots[b]) & ACHIP_SLOT_VALUE)));
             }
-            total_raw ^= wave_read_lane(wave_xor_to_last(acc), 63);
+            fraw ^= wave_read_lane(wave_xor_to_last(acc), 63);
           }
-          total_raw ^= slot_load(&crcacc[0]);
+          fraw ^= slot_load(&crcacc[0]);
         }
+        const uint32_t crc = fits ? ~(wave_mulmod_uniform(0xFFFFFFFFu, xn, lane, xk) ^ fraw) : 0u;
         if (lane == 0)
-          crc_out[fidx] = fits ? ~total_raw : 0u;
+          wire.crc[fidx] = crc;
+        if (wire.hdr || wire.pkt_crc) {
+          /* ascii_frame_packet_t in network byte order (lib/network/acip/server.c:186-214): {width, height,
+           * original_size, compressed_size = 0, checksum, flags = 0}; an unusable frame gets a header of zeros, as the
+           * stand-alone kernel reports it.  Lane j < 24 owns header byte j. */
+          const int wi = lane >> 2;
+          const uint32_t word = !fits ? 0u : wi == 0 ? dim_w : wi == 1 ? dim_h : wi == 2 ? n_total : wi == 4 ? crc : 0u;
+          const uint32_t hb = lane < 24 ? (word >> (8 * (3 - (lane & 3)))) & 0xFFu : 0u;
+          if (wire.hdr && lane < 24)
+            wire.hdr[(size_t)fidx * 24u + (size_t)lane] = (uint8_t)hb;
+          if (wire.pkt_crc) {
+            /* CRC of header || frame (packet_send_via_transport, send.c:59-69) = ~(S_h * x^(8n) xor raw(M)) with S_h the
+             * register after the header from 0xFFFFFFFF: bytes 0..7 through slicing rows 7..0 and on by 16 bytes,
+             * bytes 8..23 through rows 15..0 */
+            const uint32_t v = lane < 8 ? slice[(7 - lane) * 256 + hb] : lane < 24 ? slice[(23 - lane) * 256 + hb] : 0u;
+            const uint32_t ra = wave_read_lane(wave_xor_to_last(lane < 8 ? v : 0u), 63);
+            const uint32_t rb = wave_read_lane(wave_xor_to_last(lane >= 8 ? v : 0u), 63);
+            constexpr uint32_t INIT24 = crc_mulmod(0xFFFFFFFFu, crc_pow(CRC_X8, 24u));
+            const uint32_t sh = INIT24 ^ crc_advance16(slice, ra, 16) ^ rb;
+            const uint32_t pkt = ~(wave_mulmod_uniform(sh, xn, lane, xk) ^ fraw);
+            if (lane == 0)
+              wire.pkt_crc[fidx] = pkt;
+          }
+        }
       }
     }
 

@@ -57,7 +57,7 @@ template <int MODE> hipError_t crc_tables(const uint4 **out) {
 
 template <int MODE, bool COMP, bool CRC>
 hipError_t launch_one(const achip_frame_t *frames, int n, const achip_lut_t *lut, uint8_t *out, uint64_t stride,
-                      uint32_t *len, const achip_uniform_t &uni, unsigned long long *prof, uint32_t *crc_out,
+                      uint32_t *len, const achip_uniform_t &uni, unsigned long long *prof, const achip_wire_t &wire,
                       hipStream_t stream) {
   using L = achip::SLds<MODE, G::WAVES, G::CPL, CRC>;
   auto kern = achip::render_stream_kernel<MODE, G::WAVES, G::CPL, COMP, CRC>;
@@ -81,7 +81,7 @@ hipError_t launch_one(const achip_frame_t *frames, int n, const achip_lut_t *lut
    * workgroups of launches in flight on other streams share a CU */
   const size_t lds = (size_t)((L::bytes_for(achip::stream_maxblk(uni.flags, L::BLK)) + 15) & ~15);
   hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(G::WAVES * 64), lds, stream, frames, lut, out, stride, len, n, uni,
-                     prof, crc_out, tab);
+                     prof, wire, tab);
   return hipGetLastError();
 }
 
@@ -93,7 +93,7 @@ hipError_t launch_one(const achip_frame_t *frames, int n, const achip_lut_t *lut
 extern "C" int ACHIP_CAT(achip_render_sinst_launch_, ACHIP_SINST)(int mode, int comp, const achip_frame_t *frames, int n,
                                                                   const achip_lut_t *lut, uint8_t *out, uint64_t stride,
                                                                   uint32_t *len, const achip_uniform_t *uniform,
-                                                                  unsigned long long *prof, uint32_t *crc_out,
+                                                                  unsigned long long *prof, const achip_wire_t *wire,
                                                                   void *stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   achip_uniform_t uni = {};
@@ -104,15 +104,16 @@ extern "C" int ACHIP_CAT(achip_render_sinst_launch_, ACHIP_SINST)(int mode, int 
   switch (mode) {
 #define M(m)                                                                                                           \
   case m:                                                                                                              \
-    if (crc_out) {                                                                                                     \
+    if (wire) {                                                                                                        \
       if constexpr (HAS_CRC)                                                                                           \
-        return (int)(comp ? launch_one<m, true, true>(frames, n, lut, out, stride, len, uni, prof, crc_out, s)         \
-                          : launch_one<m, false, true>(frames, n, lut, out, stride, len, uni, prof, crc_out, s));      \
+        return (int)(!wire->crc ? hipErrorInvalidValue                                                                 \
+                     : comp     ? launch_one<m, true, true>(frames, n, lut, out, stride, len, uni, prof, *wire, s)     \
+                                : launch_one<m, false, true>(frames, n, lut, out, stride, len, uni, prof, *wire, s));  \
       else                                                                                                             \
         return (int)hipErrorInvalidValue;                                                                              \
     }                                                                                                                  \
-    return (int)(comp ? launch_one<m, true, false>(frames, n, lut, out, stride, len, uni, prof, nullptr, s)            \
-                      : launch_one<m, false, false>(frames, n, lut, out, stride, len, uni, prof, nullptr, s));
+    return (int)(comp ? launch_one<m, true, false>(frames, n, lut, out, stride, len, uni, prof, achip_wire_t{}, s)     \
+                      : launch_one<m, false, false>(frames, n, lut, out, stride, len, uni, prof, achip_wire_t{}, s));
     M(ACHIP_MODE_TRUE_FG)
     M(ACHIP_MODE_256_FG)
     M(ACHIP_MODE_16_FG)

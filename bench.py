@@ -411,8 +411,8 @@ def run_grid9(torch, pkg, steps, regions, targets=256, dist=None, world=1, rank=
 def wire_stage(torch, pkg, res, steps=160):
     """SURVEY 8(f).3 behind the metric's render, measured in this run: GPU time per step (HIP events, same schedule as
     the main leg: res['streams'] launches in flight, a fresh input batch every step) of (a) render alone, (b) render +
-    the stand-alone checksum / packet-header kernel (a second pass over the slab), (c) render with the frame CRC-32C
-    riding the drain + the header kernel.  The fused checksums are compared with the stand-alone kernel's on a whole
+    the stand-alone checksum / packet-header kernel (a second pass over the slab), (c) the render launch that also
+    leaves frame CRC-32Cs, packet headers and packet CRCs (asciichat_hip_plan_render_packets).  The fused checksums are compared with the stand-alone kernel's on a whole
     batch and with the oracle's CRC-32C on 8 frames."""
     import numpy as np
 
@@ -437,10 +437,10 @@ def wire_stage(torch, pkg, res, steps=160):
     def step(kind, k):
         s, p = k % S, plans[k % len(plans)]
         st = lanes[s].cuda_stream
-        if kind == "fused":
-            p.render_crc(outs[s].data_ptr(), stride, lns[s].data_ptr(), crcs[s].data_ptr(), st)
-            rc = L.asciichat_hip_packets_from_crc(lns[s].data_ptr(), crcs[s].data_ptr(), batch, dims.data_ptr(),
-                                                  hdrs[s].data_ptr(), pkts[s].data_ptr(), st)
+        if kind == "fused":  # ONE call, one launch: frames + frame CRCs + headers + packet CRCs
+            p.render_packets(outs[s].data_ptr(), stride, lns[s].data_ptr(), dims.data_ptr(), crcs[s].data_ptr(),
+                             hdrs[s].data_ptr(), pkts[s].data_ptr(), st)
+            rc = 0
         else:
             p.render(outs[s].data_ptr(), stride, lns[s].data_ptr(), st)
             rc = 0
@@ -482,11 +482,12 @@ def wire_stage(torch, pkg, res, steps=160):
     return {"launches_in_flight": S, "steps": steps, "fused_crc_in_render_kernel": bool(plans[0].fused_crc),
             "kernel_variant": plans[0].variant,
             "render_ms_per_step": t["render"], "render_plus_packet_kernel_ms_per_step": t["separate"],
-            "render_with_fused_crc_plus_headers_ms_per_step": t["fused"],
+            "render_with_fused_crc_and_headers_ms_per_step": t["fused"],
             "extra_ms_separate": t["separate"] - t["render"], "extra_ms_fused": t["fused"] - t["render"],
             "checked": {"frames_vs_standalone_kernel": batch, "frames_vs_oracle_crc32c": len(idx), "identical": True},
             "note": "ascii_frame_packet_t.checksum + 24-byte headers + packet CRCs for every frame of the step "
-                    "(lib/network/acip/server.c:186-214); calls issued from Python, two per step"}
+                    "(lib/network/acip/server.c:186-214); calls issued from Python: render + asciichat_hip_frame_packets "
+                    "(two launches) vs asciichat_hip_plan_render_packets (one launch)"}
 
 
 def cpu_model():

@@ -71,6 +71,15 @@ typedef struct {
   uint32_t enabled;
   uint32_t flags; /* ACHIP_UNIFORM_*: launch-wide facts that travel with the kernel arguments even when enabled == 0 */
 } achip_uniform_t;
+/* Where the stream kernel's CRC instantiation leaves the wire stage's results (device pointers; by value in the kernel
+ * arguments).  crc is required; hdr / pkt_crc (24-byte ascii_frame_packet_t headers, CRC of header || frame) and dims
+ * ({width, height} per frame for the headers) are optional. */
+typedef struct {
+  uint32_t *crc;
+  const uint32_t *dims;
+  uint8_t *hdr;
+  uint32_t *pkt_crc;
+} achip_wire_t;
 #define ACHIP_UNIFORM_PALETTE_ASCII 1u /* every glyph of the launch's palette is a single byte < 0x80 */
 /* bits 31..8: cells ((pad_left + out_w) * out_h) of the launch's largest frame, 0 = not stated.  The stream kernel
  * sizes its per-block LDS words from it (a frame with more cells than stated is refused: ACHIP_LEN_BADDESC). */

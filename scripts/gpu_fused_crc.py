@@ -3,7 +3,8 @@ step, 12 input sets), per 256-frame step on one stream and round-robin on 4 stre
   (a) render only                                   plan.render
   (b) render + stand-alone CRC/packet kernel       plan.render ; asciichat_hip_frame_packets   (a second pass over the slab)
   (c) render with the CRC riding the drain + hdrs  plan.render_crc ; asciichat_hip_packets_from_crc
-and checks (c)'s checksums against (b)'s.  Calls are issued from Python here (ctypes, ~3 us each): the one-stream rows
+  (d) all of it in the render launch                plan.render_packets
+and checks (c)'s and (d)'s checksums / headers / packet CRCs against (b)'s.  Calls are issued from Python here (ctypes, ~3 us each): the one-stream rows
 of (b) and (c) are two calls per step and may be issue-bound; the 4-stream rows show the device cost."""
 import os
 import sys
@@ -50,14 +51,17 @@ def main():
                     p.render(outs[s].data_ptr(), stride, lns[s].data_ptr(), st)
                     L.asciichat_hip_frame_packets(outs[s].data_ptr(), stride, lns[s].data_ptr(), stride, n, dims.data_ptr(),
                                                   crcs[s].data_ptr(), hdrs[s].data_ptr(), pkts[s].data_ptr(), st)
-                else:
+                elif kind == "c":
                     p.render_crc(outs[s].data_ptr(), stride, lns[s].data_ptr(), crcs[s].data_ptr(), st)
                     L.asciichat_hip_packets_from_crc(lns[s].data_ptr(), crcs[s].data_ptr(), n, dims.data_ptr(),
                                                      hdrs[s].data_ptr(), pkts[s].data_ptr(), st)
+                else:
+                    p.render_packets(outs[s].data_ptr(), stride, lns[s].data_ptr(), dims.data_ptr(), crcs[s].data_ptr(),
+                                     hdrs[s].data_ptr(), pkts[s].data_ptr(), st)
 
             ref = {}
             for rnd in range(2):
-                for kind in ("a", "b", "c", "c-only"):
+                for kind in ("a", "b", "c", "c-only", "d"):
                     steps = 240
                     kk = "c" if kind == "c-only" else kind
                     if kind == "c-only":
@@ -85,7 +89,7 @@ def main():
                     torch.cuda.synchronize()
                     us = e0.elapsed_time(e1) * 1000 / steps
                     print(f"  streams {nstreams} round {rnd} ({kind:6s}): {us:7.2f} us per 256-frame step", flush=True)
-                    if kind in ("b", "c"):
+                    if kind in ("b", "c", "d"):
                         # last step on stream 0 rendered plan (steps - nstreams ...) -- compare b vs c on one fixed plan
                         step(kk, 0)
                         torch.cuda.synchronize()

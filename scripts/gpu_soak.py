@@ -114,9 +114,13 @@ def main():
         hdr_c = torch.zeros(nfr * 24, dtype=torch.uint8, device="cuda")
         pkt_c = torch.zeros(nfr, dtype=torch.int32, device="cuda")
         st_c = torch.cuda.current_stream().cuda_stream
-        plan.render_crc(out_c.data_ptr(), plan.stride, ln_c.data_ptr(), crc_c.data_ptr(), st_c)
-        assert pkg.lib().asciichat_hip_packets_from_crc(ln_c.data_ptr(), crc_c.data_ptr(), nfr, dims_t.data_ptr(), hdr_c.data_ptr(),
-                                                        pkt_c.data_ptr(), st_c) == 0, pkg.last_error()
+        if rnd % 2:  # everything in the render launch (where the geometry carries the fused CRC)
+            plan.render_packets(out_c.data_ptr(), plan.stride, ln_c.data_ptr(), dims_t.data_ptr(), crc_c.data_ptr(),
+                                hdr_c.data_ptr(), pkt_c.data_ptr(), st_c)
+        else:
+            plan.render_crc(out_c.data_ptr(), plan.stride, ln_c.data_ptr(), crc_c.data_ptr(), st_c)
+            assert pkg.lib().asciichat_hip_packets_from_crc(ln_c.data_ptr(), crc_c.data_ptr(), nfr, dims_t.data_ptr(), hdr_c.data_ptr(),
+                                                            pkt_c.data_ptr(), st_c) == 0, pkg.last_error()
         torch.cuda.synchronize()
         lens_c = ln_c.cpu().numpy().astype(np.uint32)
         assert (lens_c == lens).all(), ("render_crc lengths", rnd, plan.variant)

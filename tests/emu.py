@@ -41,7 +41,7 @@ def lib():
                                           C.c_uint64, C.c_void_p]
         _lib.emu_render_stream_crc.restype = C.c_int
         _lib.emu_render_stream_crc.argtypes = [C.c_int, C.c_int, C.POINTER(Frame), C.c_int, C.POINTER(Lut), C.c_void_p,
-                                               C.c_uint64, C.c_void_p, C.c_void_p]
+                                               C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.emu_set_uniform.restype = C.c_int
         _lib.emu_set_uniform.argtypes = [C.c_int]
         _lib.emu_set_parts.restype = None
@@ -115,8 +115,9 @@ def render_frames(mode, frames, palette, variant=0, stride=None, rows_per_part=0
     return res
 
 
-def render_frames_crc(mode, frames, palette, variant=20, stride=None):
-    """The stream kernel with the frame CRC riding its drain: returns ([bytes | code], [crc])."""
+def render_frames_crc(mode, frames, palette, variant=20, stride=None, dims=None):
+    """The stream kernel with the frame CRC riding its drain: returns ([bytes | code], [crc]); with dims ([(w, h)] per
+    frame) also the 24-byte packet headers and the CRCs of header || frame: ([..], [crc], [hdr bytes], [pkt crc])."""
     L = lib()
     n = len(frames)
     arr = (Frame * n)(*frames)
@@ -128,9 +129,16 @@ def render_frames_crc(mode, frames, palette, variant=20, stride=None):
     base = (out.ctypes.data + 15) // 16 * 16
     ln = np.zeros(n, dtype=np.uint32)
     crc = np.full(n, 0xDEADBEEF, dtype=np.uint32)
-    assert L.emu_render_stream_crc(mode, variant, arr, n, C.byref(lut), base, stride, ln.ctypes.data, crc.ctypes.data) == 0
+    d = np.array(dims, dtype=np.uint32).reshape(n, 2) if dims is not None else None
+    hdr = np.full(n * 24, 0xEE, dtype=np.uint8)
+    pkt = np.full(n, 0xDEADBEEF, dtype=np.uint32)
+    assert L.emu_render_stream_crc(mode, variant, arr, n, C.byref(lut), base, stride, ln.ctypes.data, crc.ctypes.data,
+                                   d.ctypes.data if d is not None else None, hdr.ctypes.data if d is not None else None,
+                                   pkt.ctypes.data if d is not None else None) == 0
     res = [int(ln[i]) if ln[i] >= 0xFFFFFFF0 else C.string_at(base + i * stride, int(ln[i])) for i in range(n)]
-    return res, [int(c) for c in crc]
+    if d is None:
+        return res, [int(c) for c in crc]
+    return res, [int(c) for c in crc], [hdr[24 * i:24 * i + 24].tobytes() for i in range(n)], [int(c) for c in pkt]
 
 
 def frame_for_convert(img, width, height, render_mode, wants_padding=False, use_aspect=False, stretch=False):

@@ -83,7 +83,7 @@ static void run_stream(const achip_frame_t *frames, int n, const achip_lut_t *lu
               ACHIP_UNIFORM_MAX_CELLS(achip_max_cells(frames, n)); /* what plan.c / dropin.c pass */
   const size_t lds = (size_t)((L::bytes_for(achip::stream_maxblk(uni.flags, L::BLK)) + 15) & ~15);
   hipemu::launch(dim3((unsigned)n), dim3(WAVES * 64), lds, [&] {
-    achip::render_stream_kernel<MODE, WAVES, CPL, true>(frames, lut, out, stride, len, n, uni, nullptr, nullptr, nullptr);
+    achip::render_stream_kernel<MODE, WAVES, CPL, true>(frames, lut, out, stride, len, n, uni, nullptr, achip_wire_t{}, nullptr);
   });
 }
 template <int WAVES, int CPL>
@@ -106,7 +106,7 @@ static int stream_by_mode(int mode, const achip_frame_t *frames, int n, const ac
 /* the stream kernel with the frame CRC riding its drain (what asciichat_hip_plan_render_crc launches) */
 template <int MODE, int WAVES, int CPL>
 static void run_stream_crc(const achip_frame_t *frames, int n, const achip_lut_t *lut, uint8_t *out, uint64_t stride,
-                           uint32_t *len, uint32_t *crc) {
+                           uint32_t *len, const achip_wire_t &wire) {
   using L = achip::SLds<MODE, WAVES, CPL, true>;
   achip_uniform_t uni = {};
   /* as the product's launcher: tables built once by the init kernel, per-block words sized by the largest frame */
@@ -121,14 +121,16 @@ static void run_stream_crc(const achip_frame_t *frames, int n, const achip_lut_t
   const uint4 *tabv = reinterpret_cast<const uint4 *>(tab.data());
   const size_t lds = (size_t)((L::bytes_for(achip::stream_maxblk(uni.flags, L::BLK)) + 15) & ~15);
   hipemu::launch(dim3((unsigned)n), dim3(WAVES * 64), lds, [&] {
-    achip::render_stream_kernel<MODE, WAVES, CPL, true, true>(frames, lut, out, stride, len, n, uni, nullptr, crc, tabv);
+    achip::render_stream_kernel<MODE, WAVES, CPL, true, true>(frames, lut, out, stride, len, n, uni, nullptr, wire, tabv);
   });
 }
 extern "C" int emu_render_stream_crc(int mode, int variant, const achip_frame_t *frames, int n, const achip_lut_t *lut,
-                                     uint8_t *out, uint64_t stride, uint32_t *len, uint32_t *crc) {
+                                     uint8_t *out, uint64_t stride, uint32_t *len, uint32_t *crc, const uint32_t *dims,
+                                     uint8_t *hdr, uint32_t *pkt) {
+  const achip_wire_t wire = {crc, dims, hdr, pkt};
 #define M(m, W, C)                                                                                                     \
   if (mode == m) {                                                                                                     \
-    run_stream_crc<m, W, C>(frames, n, lut, out, stride, len, crc);                                                    \
+    run_stream_crc<m, W, C>(frames, n, lut, out, stride, len, wire);                                                    \
     return 0;                                                                                                          \
   }
   if (variant == 20) {

@@ -419,7 +419,19 @@ def test_render_with_fused_frame_crc(gpu):
         pkt = torch.zeros(n, dtype=torch.int32, device="cuda")
         assert L.asciichat_hip_packets_from_crc(ln.data_ptr(), crc.data_ptr(), n, d32.data_ptr(), hdr.data_ptr(),
                                                 pkt.data_ptr(), stream) == 0, pkg.last_error()
+        # the same in ONE call: frames + checksums + headers + packet CRCs (one launch when the CRC is fused)
+        out1 = torch.full((n * plan.stride,), 0xEE, dtype=torch.uint8, device="cuda")
+        ln1 = torch.zeros(n, dtype=torch.int32, device="cuda")
+        crc1 = torch.full((n,), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
+        hdr1 = torch.full((n * 24,), 0xEE, dtype=torch.uint8, device="cuda")
+        pkt1 = torch.full((n,), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
+        plan.render_packets(out1.data_ptr(), plan.stride, ln1.data_ptr(), d32.data_ptr(), crc1.data_ptr(), hdr1.data_ptr(),
+                            pkt1.data_ptr(), stream)
         torch.cuda.synchronize()
+        assert torch.equal(ln1, ln) and torch.equal(crc1, crc) and torch.equal(hdr1, hdr) and torch.equal(pkt1, pkt), (mode, variant)
+        assert torch.equal(out1, out) or all(
+            torch.equal(out1[k * plan.stride:k * plan.stride + int(ln[k])], out[k * plan.stride:k * plan.stride + int(ln[k])])
+            for k in range(n)), (mode, variant)
         host, lens = out.cpu().numpy(), ln.cpu().numpy().astype(np.uint32)
         crc_h, pkt_h, hdr_h = crc.cpu().numpy().astype(np.uint32), pkt.cpu().numpy().astype(np.uint32), hdr.cpu().numpy()
         for k in range(n):

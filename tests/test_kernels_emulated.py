@@ -299,6 +299,16 @@ def test_stream_kernel_fused_frame_crc(mode):
     for k, (im, (w, h)) in enumerate(zip(imgs, dims)):
         exp = oracle_convert(im, mode, w, h, orc.PALETTE_STANDARD)
         assert got[k] == exp and crc[k] == orc.crc32c(exp), (mode, k)
+    # the wave that finishes a frame also writes its ascii_frame_packet_t header and the CRC of header || frame
+    # (acip_send_ascii_frame, lib/network/acip/server.c:186-214; packet_send_via_transport, send.c:59-69)
+    for variant in (20, 17):
+        got, crc, hdr, pkt = emu.render_frames_crc(mode, frames, orc.PALETTE_STANDARD, variant, dims=dims)
+        for k, (w, h) in enumerate(dims):
+            eh, ep = orc.ascii_frame_packet(got[k], w, h)
+            assert crc[k] == orc.crc32c(got[k]) and hdr[k] == eh and pkt[k] == ep, (mode, variant, k)
+    got, crc, hdr, pkt = emu.render_frames_crc(mode, [frames[0]], orc.PALETTE_STANDARD, 20, stride=1024, dims=[(80, 24)])
+    eh, ep = orc.ascii_frame_packet(b"", 0, 0)  # a frame that did not fit: zeros in the header, CRC 0 inside it
+    assert got[0] == 0xFFFFFFFF and crc[0] == 0 and hdr[0] == eh and pkt[0] == ep
     if mode != MODE_TRUE_FG:  # multi-byte glyphs: token lengths vary inside a block
         f = emu.frame_for_convert(TORTURE, 61, 17, MODE_CAPS.get(mode, (3, 0))[1])
         got, crc = emu.render_frames_crc(mode, [f], "é漢😀 .", 20)
