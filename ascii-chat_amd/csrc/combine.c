@@ -279,6 +279,8 @@ static void cb_run(cb_t *cb, cb_gen_t *G) {
   }
   if (e != hipSuccess) {
     (void)hipGetLastError();
+    (void)hipStreamSynchronize(S->stream); /* groups launched before the failure still write this generation's slab */
+    (void)hipGetLastError();
     G->failed = 1;
     const char *msg = hipGetErrorString(e);
     size_t k = 0;
