@@ -257,6 +257,8 @@ int asciichat_hip_grid_create(asciichat_hip_grid_t **grid, asciichat_hip_comm_t 
   rc = achip_hip_check((int)hipMalloc((void **)&g->tiles_dev, bytes), "hipMalloc(grid tiles)");
   if (!rc)
     rc = achip_hip_check((int)hipMemset(g->tiles_dev, 0, bytes), "hipMemset(grid tiles)");
+  if (!rc) /* the memset runs on the null stream, which the callers' (non-blocking) streams do not wait for */
+    rc = achip_hip_check((int)hipDeviceSynchronize(), "hipDeviceSynchronize(grid tiles)");
   if (!rc) { /* the composite that samples the gathered tiles */
     achip_composite_t c2 = g->geom;
     for (int k = 0; k < n_src; k++) {
