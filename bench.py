@@ -125,7 +125,9 @@ class Runner:
         self.step += n
 
     def region(self, K, dist=None):
-        """EXACTLY K steps, barrier + synchronize on both sides; returns wall seconds."""
+        """EXACTLY K steps, barrier + synchronize on both sides; returns THIS rank's wall seconds from the opening
+        bracket to the completion of its own K steps (the caller takes the MAX over ranks of every region: the time the
+        slowest rank needed; the closing barrier's own latency is not a step and is not counted)."""
         torch = self.torch
         torch.cuda.synchronize()
         if dist is not None:
@@ -135,10 +137,11 @@ class Runner:
         self.issue(K)
         self.sched.wait()  # spin on hipStreamQuery: no driver sleep in a ~170 us region
         torch.cuda.synchronize()
-        if dist is not None:
+        t1 = time.perf_counter()  # this rank's K steps are done; the MAX over ranks is taken by the caller
+        if dist is not None:  # closing bracket: nobody starts the next region before everybody has finished this one
             dist.barrier()
             torch.cuda.synchronize()
-        return time.perf_counter() - t0
+        return t1 - t0
 
     def gpu_ms_per_step(self, n):
         """GPU time per step over n back-to-back steps: HIP events on every launch stream, first begin -> last end."""
@@ -362,10 +365,11 @@ def run_grid9(torch, pkg, steps, regions, targets=256, dist=None, world=1, rank=
             for _ in range(K):
                 step()
             torch.cuda.synchronize()
+            t1 = time.perf_counter()  # this rank's K steps (each with its all-gather) are done; MAX over ranks below
             if dist is not None:
                 dist.barrier()
-            torch.cuda.synchronize()
-            return time.perf_counter() - t0
+                torch.cuda.synchronize()
+            return t1 - t0
 
         for _ in range(5):
             step()
