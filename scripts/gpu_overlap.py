@@ -31,7 +31,12 @@ def main():
                     p.set_variant(variant)
             except RuntimeError:
                 continue
-            streams = [torch.cuda.Stream() for _ in range(nstreams)]
+            # ONE pool of streams for the whole process (bench.py's): HIP maps streams onto hardware queues round robin,
+            # and a fresh set of stream objects per configuration made the first configuration of a run measure 20-30 %
+            # slow (profiles/r02_geometry_ab.txt shows the artefact next to the repeat)
+            while len(bench._LANE_POOL) < nstreams - 1:
+                bench._LANE_POOL.append(torch.cuda.Stream())
+            streams = [torch.cuda.current_stream()] + bench._LANE_POOL[:nstreams - 1]
             outs = [torch.empty(256 * plans[0].stride, dtype=torch.uint8, device="cuda") for _ in range(nstreams)]
             lns = [torch.zeros(256, dtype=torch.int32, device="cuda") for _ in range(nstreams)]
 
