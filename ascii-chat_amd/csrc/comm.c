@@ -299,20 +299,30 @@ int asciichat_hip_grid_exchange(asciichat_hip_grid_t *g, const uint8_t *const *l
     return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "grid_exchange: bad arguments");
   int first = 0, count = 0;
   achip_shard_bounds(g->n_src, g->world, g->rank, &first, &count);
-  for (int k = first; k < first + count; k++) {
-    if (g->placed_of[k] < 0)
+  achip_resize_batch_t batch; /* every tile this rank owns in ONE launch: the tiles are KBs, a launch each costs more */
+  batch.n = 0;
+  for (int k = first; k <= first + count; k++) {
+    if (batch.n == ACHIP_RESIZE_BATCH_MAX || (k == first + count && batch.n > 0)) {
+      const int rc = achip_hip_check(achip_launch_resize_batch(&batch, stream), "resize launch");
+      if (rc)
+        return rc;
+      batch.n = 0;
+    }
+    if (k == first + count || g->placed_of[k] < 0)
       continue; /* no video in this slot (or beyond the ninth placed source) */
     const achip_comp_src_t *s = &g->geom.s[g->placed_of[k]];
     if (!s->src)
       continue;
     if (!local_src_dev[k])
       return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "grid_exchange: source %d is owned by this rank but NULL", k);
-    const int rc = achip_hip_check(achip_launch_resize(local_src_dev[k], s->src_w, s->src_h,
-                                                       g->tiles_dev + grid_slot_of(g, k) * g->tile_stride, s->tile_w,
-                                                       s->tile_h, stream),
-                                   "resize launch");
-    if (rc)
-      return rc;
+    achip_resize_item_t *it = &batch.item[batch.n++];
+    it->src = local_src_dev[k];
+    it->dst = g->tiles_dev + grid_slot_of(g, k) * g->tile_stride;
+    it->sw = s->src_w;
+    it->sh = s->src_h;
+    it->dw = s->tile_w;
+    it->dh = s->tile_h;
+    it->x_ratio = it->y_ratio = 0;
   }
   if (!g->comm || g->world == 1)
     return g->comm ? asciichat_hip_comm_all_gather(g->comm, g->tiles_dev, g->tiles_dev,

@@ -32,6 +32,8 @@ int achip_variant_has_crc(int variant);
 int achip_launch_packets_from_crc(const uint32_t *len_dev, const uint32_t *crc_dev, const uint32_t *dims_dev, int n,
                                   uint8_t *hdr_out, uint32_t *pkt_crc_out, void *stream);
 int achip_launch_resize(const uint8_t *src, int sw, int sh, uint8_t *dst, int dw, int dh, void *stream);
+/* up to ACHIP_RESIZE_BATCH_MAX resizes in ONE launch (src / dst / sizes filled in; the ratios are computed here) */
+int achip_launch_resize_batch(const achip_resize_batch_t *batch, void *stream);
 int achip_launch_composite(const achip_composite_t *comp_dev, int canvas_w, int canvas_h, uint8_t *dst, void *stream);
 
 /* display-path streaming passes (stream_kernels.hpp); ops as in achip_frame_t.ops */

@@ -154,6 +154,31 @@ extern "C" int achip_launch_resize(const uint8_t *src, int sw, int sh, uint8_t *
   return (int)hipGetLastError();
 }
 
+extern "C" int achip_launch_resize_batch(const achip_resize_batch_t *batch, void *stream) {
+  if (!batch || batch->n <= 0)
+    return (int)hipSuccess;
+  if (batch->n > ACHIP_RESIZE_BATCH_MAX)
+    return (int)hipErrorInvalidValue;
+  achip_resize_batch_t b = *batch;
+  uint64_t most = 1;
+  for (int k = 0; k < b.n; k++) {
+    achip_resize_item_t *it = &b.item[k];
+    if (!it->src || !it->dst || it->sw <= 0 || it->sh <= 0 || it->dw <= 0 || it->dh <= 0)
+      return (int)hipErrorInvalidValue;
+    it->x_ratio = (uint32_t)((((uint64_t)it->sw << 16) / (uint64_t)it->dw) + 1u);
+    it->y_ratio = (uint32_t)((((uint64_t)it->sh << 16) / (uint64_t)it->dh) + 1u);
+    const uint64_t total = (uint64_t)it->dw * (uint64_t)it->dh;
+    if (total > most)
+      most = total;
+  }
+  unsigned blocks = (unsigned)((most + 255) / 256);
+  if (blocks > 2048u)
+    blocks = 2048u;
+  hipLaunchKernelGGL(achip::resize_nn_batch_kernel, dim3(blocks, (unsigned)b.n), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), b);
+  return (int)hipGetLastError();
+}
+
 extern "C" int achip_launch_composite(const achip_composite_t *comp_dev, int canvas_w, int canvas_h, uint8_t *dst,
                                       void *stream) {
   const uint64_t total = (uint64_t)canvas_w * (uint64_t)canvas_h;

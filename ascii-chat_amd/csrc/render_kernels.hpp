@@ -1470,6 +1470,24 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+/* the same for up to ACHIP_RESIZE_BATCH_MAX images in one launch: blockIdx.y selects the image (the grid path's per-tick
+ * tile resizes: nine ~5 KB outputs, where nine launches cost more than the work) */
+__global__ void __launch_bounds__(256) resize_nn_batch_kernel(achip_resize_batch_t b) {
+  const achip_resize_item_t it = b.item[blockIdx.y];
+  const uint32_t total = (uint32_t)it.dw * (uint32_t)it.dh;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const uint32_t y = i / (uint32_t)it.dw, x = i - y * (uint32_t)it.dw;
+    uint32_t sx = (x * it.x_ratio) >> 16, sy = (y * it.y_ratio) >> 16;
+    sx = min(sx, (uint32_t)it.sw - 1u);
+    sy = min(sy, (uint32_t)it.sh - 1u);
+    const uint32_t p = load_rgb(it.src, 3 * it.sw, sx, sy, it.sw * it.sh == 1);
+    uint8_t *d = it.dst + (size_t)i * 3u;
+    d[0] = (uint8_t)p;
+    d[1] = (uint8_t)(p >> 8);
+    d[2] = (uint8_t)(p >> 16);
+  }
+}
+
 /* materialise the W x 2H composite canvas (only needed by callers that want the image itself) */
 __global__ void __launch_bounds__(256)
     composite_kernel(const achip_composite_t *__restrict__ comp, uint8_t *__restrict__ dst) {

@@ -80,6 +80,19 @@ typedef struct {
   uint8_t *hdr;
   uint32_t *pkt_crc;
 } achip_wire_t;
+/* Several nearest-neighbour resizes in one launch (the grid path resizes every source a rank owns per tick): by value in
+ * the kernel arguments, workgroup (x, k) works on entry k. */
+#define ACHIP_RESIZE_BATCH_MAX 16
+typedef struct {
+  const uint8_t *src;
+  uint8_t *dst;
+  int32_t sw, sh, dw, dh;
+  uint32_t x_ratio, y_ratio; /* ((s << 16) / d) + 1, image.c:282-283 */
+} achip_resize_item_t;
+typedef struct {
+  achip_resize_item_t item[ACHIP_RESIZE_BATCH_MAX];
+  int32_t n, _pad;
+} achip_resize_batch_t;
 #define ACHIP_UNIFORM_PALETTE_ASCII 1u /* every glyph of the launch's palette is a single byte < 0x80 */
 /* bits 31..8: cells ((pad_left + out_w) * out_h) of the launch's largest frame, 0 = not stated.  The stream kernel
  * sizes its per-block LDS words from it (a frame with more cells than stated is refused: ACHIP_LEN_BADDESC). */

@@ -169,6 +169,10 @@ extern "C" void emu_resize_nn(const uint8_t *src, int sw, int sh, uint8_t *dst, 
   hipemu::launch(dim3(3), dim3(256), 0, [&] { achip::resize_nn_kernel(src, sw, sh, 3 * sw, dst, dw, dh, xr, yr); });
 }
 
+extern "C" void emu_resize_batch(const achip_resize_batch_t *b) {
+  hipemu::launch(dim3(2, (unsigned)b->n), dim3(256), 0, [&] { achip::resize_nn_batch_kernel(*b); });
+}
+
 extern "C" void emu_composite(const achip_composite_t *comp, uint8_t *dst) {
   hipemu::launch(dim3(2), dim3(256), 0, [&] { achip::composite_kernel(comp, dst); });
 }

@@ -443,3 +443,24 @@ def test_resize_kernel_emulated():
         emu.lib().emu_resize_nn(img.ctypes.data, 193, 109, out.ctypes.data, dw, dh,
                                 emu.lib().achip_nn_ratio(193, dw), emu.lib().achip_nn_ratio(109, dh))
         assert np.array_equal(out, orc.resize_nn(img, dw, dh))
+    # several resizes in one launch (what the grid path issues per tick): blockIdx.y selects the image
+    import ctypes as C
+
+    class Item(C.Structure):
+        _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("sw", C.c_int32), ("sh", C.c_int32), ("dw", C.c_int32),
+                    ("dh", C.c_int32), ("xr", C.c_uint32), ("yr", C.c_uint32)]
+
+    class Batch(C.Structure):
+        _fields_ = [("item", Item * 16), ("n", C.c_int32), ("_pad", C.c_int32)]
+
+    imgs = [orc.frame_hash_noise(50 + 17 * k, 40 + 9 * k, k) for k in range(5)]
+    dims = [(53, 30), (1, 1), (7, 90), (64, 2), (33, 33)]
+    outs = [np.zeros((h, w, 3), np.uint8) for (w, h) in dims]
+    b = Batch()
+    b.n = len(imgs)
+    for k, (im, (w, h)) in enumerate(zip(imgs, dims)):
+        b.item[k] = Item(im.ctypes.data, outs[k].ctypes.data, im.shape[1], im.shape[0], w, h,
+                         emu.lib().achip_nn_ratio(im.shape[1], w), emu.lib().achip_nn_ratio(im.shape[0], h))
+    emu.lib().emu_resize_batch(C.byref(b))
+    for k, (im, (w, h)) in enumerate(zip(imgs, dims)):
+        assert np.array_equal(outs[k], orc.resize_nn(im, w, h)), k
