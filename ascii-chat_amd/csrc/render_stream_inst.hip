@@ -33,12 +33,19 @@ constexpr bool HAS_CRC = ACHIP_SINST == 16 || ACHIP_SINST == 17;
 /* the constant tables of <MODE>'s CRC instantiation: built on the device once per process, then read-only */
 template <int MODE> hipError_t crc_tables(const uint4 **out) {
   using L = achip::SLds<MODE, G::WAVES, G::CPL, true>;
+  constexpr int MAX_DEVICES = 16;
   static std::mutex mu;
-  static uint32_t *tab = nullptr;
+  static uint32_t *tab[MAX_DEVICES] = {}; /* one image per device of the process */
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess)
+    return e;
+  if (dev < 0 || dev >= MAX_DEVICES)
+    return hipErrorInvalidDevice;
   std::lock_guard<std::mutex> lock(mu);
-  if (!tab) {
+  if (!tab[dev]) {
     uint32_t *t = nullptr;
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&t), (size_t)L::TAB_BYTES);
+    e = hipMalloc(reinterpret_cast<void **>(&t), (size_t)L::TAB_BYTES);
     if (e != hipSuccess)
       return e;
     hipLaunchKernelGGL((achip::crc_tables_init_kernel<MODE, G::WAVES, G::CPL>), dim3(1), dim3(256), 0, nullptr, t);
@@ -49,9 +56,9 @@ template <int MODE> hipError_t crc_tables(const uint4 **out) {
       (void)hipFree(t);
       return e;
     }
-    tab = t;
+    tab[dev] = t;
   }
-  *out = reinterpret_cast<const uint4 *>(tab);
+  *out = reinterpret_cast<const uint4 *>(tab[dev]);
   return hipSuccess;
 }
 
