@@ -3,7 +3,8 @@
  * re-designed for a GPU renderer:
  *
  *  - small objects (64 B .. 4 MiB) keep the reference's scheme: one header+payload malloc block, recycled
- *    through a free list, freed for real by buffer_pool_shrink() after shrink_delay_ns of idleness;
+ *    through a LOCK-FREE LIFO (a tagged-pointer Treiber stack, like the reference's lock-free pop/push,
+ *    lib/buffer_pool.c:122-200), freed for real by buffer_pool_shrink() after shrink_delay_ns of idleness;
  *  - objects above 4 MiB -- every 1080p (6.2 MB) / 4K (24.9 MB) frame, which the reference hands to the
  *    malloc fallback -- come from a new PINNED size class: hipHostMalloc(mapped) blocks kept in
  *    per-size free lists, so the GPU gathers its ~2 K samples per frame straight out of the producer's
@@ -40,8 +41,9 @@ typedef struct pool_node {
 _Static_assert(sizeof(pool_node_t) == 64, "the header keeps payloads 64-byte aligned");
 
 struct buffer_pool {
-  pthread_mutex_t mu;
-  pool_node_t *free_small;
+  pthread_mutex_t mu;       /* the pinned class (best fit over a short list) and nothing else */
+  uint64_t free_small;      /* lock-free LIFO head: {node pointer : 48, ABA tag : 16} */
+  int small_pops;           /* threads inside a pop: shrink waits for 0 before it frees detached nodes */
   pool_node_t *free_pinned;
   size_t max_bytes;
   uint64_t shrink_delay_ns;
@@ -49,6 +51,45 @@ struct buffer_pool {
   size_t pinned_bytes, pinned_live;
   uint64_t hits, allocs, returns, shrink_freed, fallbacks;
 };
+
+/* ---- the small class: a Treiber stack with a tagged head.  Nodes are only ever FREED by shrink / destroy, and shrink
+ * detaches the whole list and waits until no pop is in flight before it frees anything, so a pop may always read
+ * n->next of the node it saw at the head; the tag makes a stale compare-and-swap fail. */
+#define HEAD_PTR(v) ((pool_node_t *)(uintptr_t)((v) & 0x0000FFFFFFFFFFFFull))
+#define HEAD_PACK(n, old) (((uint64_t)(uintptr_t)(n) & 0x0000FFFFFFFFFFFFull) | ((((old) >> 48) + 1ull) << 48))
+
+static void small_push(buffer_pool_t *pool, pool_node_t *n) {
+  uint64_t old = __atomic_load_n(&pool->free_small, __ATOMIC_RELAXED);
+  do {
+    __atomic_store_n(&n->next, HEAD_PTR(old), __ATOMIC_RELAXED);
+  } while (!__atomic_compare_exchange_n(&pool->free_small, &old, HEAD_PACK(n, old), 1, __ATOMIC_RELEASE, __ATOMIC_RELAXED));
+}
+
+/* the head node if it is large enough (LIFO head only, like the reference), else NULL */
+static pool_node_t *small_pop(buffer_pool_t *pool, size_t size) {
+  __atomic_add_fetch(&pool->small_pops, 1, __ATOMIC_ACQUIRE);
+  pool_node_t *n;
+  uint64_t old = __atomic_load_n(&pool->free_small, __ATOMIC_ACQUIRE);
+  for (;;) {
+    n = HEAD_PTR(old);
+    /* relaxed atomics: another thread may win this node and clear its link while we look (the tag then fails our swap) */
+    if (!n || __atomic_load_n(&n->size, __ATOMIC_RELAXED) < size) {
+      n = NULL;
+      break;
+    }
+    pool_node_t *next = __atomic_load_n(&n->next, __ATOMIC_RELAXED);
+    if (__atomic_compare_exchange_n(&pool->free_small, &old, HEAD_PACK(next, old), 1, __ATOMIC_ACQUIRE, __ATOMIC_ACQUIRE))
+      break;
+  }
+  __atomic_sub_fetch(&pool->small_pops, 1, __ATOMIC_RELEASE);
+  return n;
+}
+
+static void note_peak(buffer_pool_t *pool, size_t used) {
+  size_t peak = __atomic_load_n(&pool->peak_bytes, __ATOMIC_RELAXED);
+  while (used > peak && !__atomic_compare_exchange_n(&pool->peak_bytes, &peak, used, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED))
+    ;
+}
 
 static buffer_pool_t *g_pool;
 static pthread_mutex_t g_pool_mu = PTHREAD_MUTEX_INITIALIZER;
@@ -178,7 +219,7 @@ static void release_node(pool_node_t *n) {
 void buffer_pool_destroy(buffer_pool_t *pool) {
   if (!pool)
     return;
-  for (pool_node_t *n = pool->free_small; n;) {
+  for (pool_node_t *n = HEAD_PTR(pool->free_small); n;) {
     pool_node_t *nx = n->next;
     release_node(n);
     n = nx;
@@ -214,10 +255,10 @@ static void *alloc_pinned(buffer_pool_t *pool, size_t size) {
     pool_node_t *n = *best;
     *best = n->next;
     n->next = NULL;
-    pool->used_bytes += n->size;
     pool->pinned_live++;
-    pool->hits++;
     pthread_mutex_unlock(&pool->mu);
+    note_peak(pool, __atomic_add_fetch(&pool->used_bytes, n->size, __ATOMIC_RELAXED)); /* shared with the lock-free class */
+    __atomic_add_fetch(&pool->hits, 1, __ATOMIC_RELAXED);
     return payload_of(n);
   }
   const int room = pool->pinned_bytes + size + sizeof(pool_node_t) <= BUFFER_POOL_PINNED_MAX_BYTES;
@@ -244,13 +285,15 @@ static void *alloc_pinned(buffer_pool_t *pool, size_t size) {
   pthread_mutex_lock(&pool->mu);
   if (n) {
     pool->pinned_bytes += sizeof(pool_node_t) + size;
-    pool->used_bytes += size;
     pool->pinned_live++;
-    pool->allocs++;
-  } else {
-    pool->fallbacks++;
   }
   pthread_mutex_unlock(&pool->mu);
+  if (n) {
+    note_peak(pool, __atomic_add_fetch(&pool->used_bytes, size, __ATOMIC_RELAXED));
+    __atomic_add_fetch(&pool->allocs, 1, __ATOMIC_RELAXED);
+  } else {
+    __atomic_add_fetch(&pool->fallbacks, 1, __ATOMIC_RELAXED);
+  }
   if (!n) {
     n = fallback_node(pool, size);
     if (!n)
@@ -269,24 +312,17 @@ void *buffer_pool_alloc(buffer_pool_t *pool, size_t size) {
   if (size > BUFFER_POOL_MAX_SINGLE_SIZE)
     return alloc_pinned(pool, size);
 
-  pthread_mutex_lock(&pool->mu);
-  pool_node_t *n = pool->free_small;
-  if (n && n->size >= size) { /* LIFO head only, like the reference's lock-free pop */
-    pool->free_small = n->next;
-    n->next = NULL;
-    pool->used_bytes += n->size;
-    pool->hits++;
-    if (pool->used_bytes > pool->peak_bytes)
-      pool->peak_bytes = pool->used_bytes;
-    pthread_mutex_unlock(&pool->mu);
+  pool_node_t *n = small_pop(pool, size);
+  if (n) {
+    __atomic_store_n(&n->next, (pool_node_t *)NULL, __ATOMIC_RELAXED);
+    note_peak(pool, __atomic_add_fetch(&pool->used_bytes, n->size, __ATOMIC_RELAXED));
+    __atomic_add_fetch(&pool->hits, 1, __ATOMIC_RELAXED);
     return payload_of(n);
   }
   const size_t total = sizeof(pool_node_t) + size;
-  const int room = pool->current_bytes + total <= pool->max_bytes;
-  if (room)
-    pool->current_bytes += total;
-  pthread_mutex_unlock(&pool->mu);
-
+  const int room = __atomic_add_fetch(&pool->current_bytes, total, __ATOMIC_RELAXED) <= pool->max_bytes;
+  if (!room)
+    __atomic_sub_fetch(&pool->current_bytes, total, __ATOMIC_RELAXED);
   if (room) {
     void *raw = NULL;
     if (posix_memalign(&raw, 64, total) == 0) {
@@ -295,21 +331,13 @@ void *buffer_pool_alloc(buffer_pool_t *pool, size_t size) {
       n->magic = MAGIC_POOLED;
       n->size = size;
       n->pool = pool;
-      pthread_mutex_lock(&pool->mu);
-      pool->used_bytes += size;
-      pool->allocs++;
-      if (pool->used_bytes > pool->peak_bytes)
-        pool->peak_bytes = pool->used_bytes;
-      pthread_mutex_unlock(&pool->mu);
+      note_peak(pool, __atomic_add_fetch(&pool->used_bytes, size, __ATOMIC_RELAXED));
+      __atomic_add_fetch(&pool->allocs, 1, __ATOMIC_RELAXED);
       return payload_of(n);
     }
-    pthread_mutex_lock(&pool->mu);
-    pool->current_bytes -= total;
-    pthread_mutex_unlock(&pool->mu);
+    __atomic_sub_fetch(&pool->current_bytes, total, __ATOMIC_RELAXED);
   }
-  pthread_mutex_lock(&pool->mu);
-  pool->fallbacks++;
-  pthread_mutex_unlock(&pool->mu);
+  __atomic_add_fetch(&pool->fallbacks, 1, __ATOMIC_RELAXED);
   n = fallback_node(pool, size);
   return n ? payload_of(n) : NULL;
 }
@@ -332,21 +360,18 @@ void buffer_pool_free(buffer_pool_t *pool, const void *data, size_t size) {
     pool = n->pool;
   if (!pool)
     return;
-  int do_shrink = 0;
-  pthread_mutex_lock(&pool->mu);
-  pool->used_bytes -= n->size;
-  pool->returns++;
+  __atomic_sub_fetch(&pool->used_bytes, n->size, __ATOMIC_RELAXED);
+  const int do_shrink = __atomic_add_fetch(&pool->returns, 1, __ATOMIC_RELAXED) % 100 == 0;
   n->returned_at_ns = now_ns();
   if (n->magic == MAGIC_PINNED) {
+    pthread_mutex_lock(&pool->mu);
     n->next = pool->free_pinned;
     pool->free_pinned = n;
     pool->pinned_live--;
+    pthread_mutex_unlock(&pool->mu);
   } else {
-    n->next = pool->free_small;
-    pool->free_small = n;
+    small_push(pool, n);
   }
-  do_shrink = pool->returns % 100 == 0;
-  pthread_mutex_unlock(&pool->mu);
   if (do_shrink)
     buffer_pool_shrink(pool);
 }
@@ -357,23 +382,42 @@ void buffer_pool_shrink(buffer_pool_t *pool) {
   const uint64_t now = now_ns();
   const uint64_t cutoff = now > pool->shrink_delay_ns ? now - pool->shrink_delay_ns : 0;
   pool_node_t *doomed = NULL;
+  /* small class: take the whole list, wait for the pops that may still look at its nodes, keep the young ones */
+  uint64_t old = __atomic_load_n(&pool->free_small, __ATOMIC_ACQUIRE);
+  while (!__atomic_compare_exchange_n(&pool->free_small, &old, HEAD_PACK(NULL, old), 1, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE))
+    ;
+  while (__atomic_load_n(&pool->small_pops, __ATOMIC_ACQUIRE) != 0)
+    __builtin_ia32_pause();
+  pool_node_t *keep = NULL;
+  for (pool_node_t *n = HEAD_PTR(old); n;) {
+    pool_node_t *nx = n->next;
+    if (n->returned_at_ns < cutoff) {
+      __atomic_sub_fetch(&pool->current_bytes, sizeof(pool_node_t) + n->size, __ATOMIC_RELAXED);
+      __atomic_add_fetch(&pool->shrink_freed, 1, __ATOMIC_RELAXED);
+      n->next = doomed;
+      doomed = n;
+    } else {
+      n->next = keep; /* reversed here, reversed again by the pushes below: the LIFO order survives */
+      keep = n;
+    }
+    n = nx;
+  }
+  while (keep) {
+    pool_node_t *nx = keep->next;
+    small_push(pool, keep);
+    keep = nx;
+  }
   pthread_mutex_lock(&pool->mu);
-  pool_node_t **lists[2] = {&pool->free_small, &pool->free_pinned};
-  for (int k = 0; k < 2; k++) {
-    for (pool_node_t **pp = lists[k]; *pp;) {
-      pool_node_t *n = *pp;
-      if (n->returned_at_ns < cutoff) {
-        *pp = n->next;
-        if (n->magic == MAGIC_PINNED)
-          pool->pinned_bytes -= sizeof(pool_node_t) + n->size;
-        else
-          pool->current_bytes -= sizeof(pool_node_t) + n->size;
-        pool->shrink_freed++;
-        n->next = doomed;
-        doomed = n;
-      } else {
-        pp = &n->next;
-      }
+  for (pool_node_t **pp = &pool->free_pinned; *pp;) {
+    pool_node_t *n = *pp;
+    if (n->returned_at_ns < cutoff) {
+      *pp = n->next;
+      pool->pinned_bytes -= sizeof(pool_node_t) + n->size;
+      __atomic_add_fetch(&pool->shrink_freed, 1, __ATOMIC_RELAXED);
+      n->next = doomed;
+      doomed = n;
+    } else {
+      pp = &n->next;
     }
   }
   pthread_mutex_unlock(&pool->mu);
@@ -388,9 +432,9 @@ void buffer_pool_get_stats(buffer_pool_t *pool, size_t *current_bytes, size_t *u
   size_t cur = 0, used = 0;
   if (pool) {
     pthread_mutex_lock(&pool->mu);
-    cur = pool->current_bytes + pool->pinned_bytes;
-    used = pool->used_bytes;
+    cur = __atomic_load_n(&pool->current_bytes, __ATOMIC_RELAXED) + pool->pinned_bytes;
     pthread_mutex_unlock(&pool->mu);
+    used = __atomic_load_n(&pool->used_bytes, __ATOMIC_RELAXED);
   }
   if (current_bytes)
     *current_bytes = cur;

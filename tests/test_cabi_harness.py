@@ -61,3 +61,19 @@ def test_buffer_pool_invariants_with_pinned_frames():
     r = subprocess.run([build_pool(), "gpu"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "with the pinned frame class" in r.stdout
+
+
+@pytest.mark.parametrize("san", ["thread", "address,undefined"])
+def test_buffer_pool_under_sanitizers(san, tmp_path):
+    """The pool's source compiled together with the harness under TSan / ASan + UBSan (host blocks only: the lock-free
+    small-object list, statistics, shrink, eight threads)."""
+    exe = str(tmp_path / "pool_san")
+    cmd = ["gcc", "-std=gnu11", "-O1", "-g", "-fsanitize=" + san, "-pthread", "-I" + os.path.join(ROOT, "include"),
+           "-I" + os.path.join(LIBDIR, "csrc"), "-I/opt/rocm/include", POOL_SRC, os.path.join(LIBDIR, "csrc", "buffer_pool.c"),
+           "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    b = subprocess.run(cmd, capture_output=True, text=True)
+    if b.returncode != 0:
+        pytest.skip("sanitizer build not available here: " + b.stderr[-300:])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", TSAN_OPTIONS="halt_on_error=1")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "ok:" in r.stdout and "Sanitizer" not in r.stderr, r.stdout[-500:] + r.stderr[-3000:]
