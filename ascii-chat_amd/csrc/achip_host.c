@@ -310,6 +310,18 @@ bool achip_palette_ascii_only(const char *palette_chars) {
 #define ACHIP_HOST_STREAM_FIRST 16
 #define ACHIP_HOST_STREAM_MAXBLK 2048
 
+/* The kernels address a source with 32-bit byte offsets (a frame is at most tens of MB): a descriptor whose last pixel
+ * lies 4 GiB or more behind its first -- only possible with an absurd explicit row stride -- is refused on the host. */
+bool achip_frame_extent_ok(const achip_frame_t *f) {
+  if (!f || f->comp)
+    return true; /* composites carry their own (tile-sized) sources */
+  const uint64_t stride = f->src_stride > 0 ? (uint64_t)f->src_stride : 3ull * (uint64_t)(f->src_w > 0 ? f->src_w : 0);
+  if (f->src_stride < 0)
+    return false;
+  const uint64_t extent = (uint64_t)(f->src_h > 0 ? f->src_h - 1 : 0) * stride + 3ull * (uint64_t)(f->src_w > 0 ? f->src_w : 0);
+  return extent < 0xFFFFFFF0ull && stride < (1ull << 24);
+}
+
 /* cells ((pad_left + out_w) * out_h) of the largest frame: what ACHIP_UNIFORM_MAX_CELLS carries to the stream kernel */
 long achip_max_cells(const achip_frame_t *frames, int n_frames) {
   long max_cells = 0;

@@ -298,6 +298,10 @@ static char *render_one(int mode, const char *palette, achip_frame_t *f, size_t 
 static char *render_unpadded_one(int mode, const char *palette, achip_frame_t *f, size_t src_bytes) {
   if (achip_require_device())
     return NULL;
+  if (!achip_frame_extent_ok(f)) {
+    (void)achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "image spans 4 GiB or more (row stride %d)", f->src_stride);
+    return NULL;
+  }
   const achip_lut_t *lut = NULL;
   if (achip_lut_get(palette, &lut))
     return NULL;

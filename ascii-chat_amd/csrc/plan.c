@@ -249,6 +249,9 @@ static int plan_measure(asciichat_hip_plan_t *p, const achip_frame_t *frames) {
     if (f->out_w <= 0 || f->out_h <= 0 || f->src_w <= 0 || f->src_h <= 0 || f->pad_left < 0 || f->pad_top < 0 ||
         (!f->src && !f->comp))
       return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame %d: bad descriptor", i);
+    if (!achip_frame_extent_ok(f))
+      return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame %d: source spans 4 GiB or more (row stride %d)", i,
+                        f->src_stride);
     size_t b = achip_out_bound(q.mode, f) + 1;
     if (b > stride)
       stride = b;

@@ -152,7 +152,9 @@ __device__ inline uint32_t stream_request(const achip_frame_t &f, const StreamSr
   uint32_t sx = min((x * s.xr) >> 16, s.w1), sy = min((y * s.yr) >> 16, s.h1);
   sx = s.flip_x ? s.w1 - sx : sx;
   sy = s.flip_y ? s.h1 - sy : sy;
-  const uint32_t a = sy * s.stride + sx * 3u;
+  /* sy, sx < 10 000 and the row stride < 2^24 (checked on the host): full-rate 24-bit multiplies; the 32-bit
+   * v_mul_lo_u32 the compiler would pick runs at a quarter of the rate */
+  const uint32_t a = __umul24(sy, s.stride) + __umul24(sx, 3u);
   const uint32_t back = a != 0u ? 1u : 0u; /* byte before the pixel + the pixel: never past the last pixel */
   kind = back ? RAW_BACK : RAW_FIRST;
   const ACHIP_GLOBAL uint8_t *p = (const ACHIP_GLOBAL uint8_t *)s.base + (a - back);

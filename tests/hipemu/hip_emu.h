@@ -182,6 +182,7 @@ template <class F> void launch(dim3 grid, dim3 block, size_t smem_bytes, F body)
 
 static inline void __syncthreads() { hipemu::block_barrier(); }
 static inline uint32_t __umulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+static inline uint32_t __umul24(uint32_t a, uint32_t b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); } /* low 32 bits */
 static inline int __popcll(uint64_t v) { return __builtin_popcountll(v); }
 static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
 static inline int __clzll(long long v) { return v ? __builtin_clzll(v) : 64; }

@@ -464,3 +464,25 @@ def test_resize_kernel_emulated():
     emu.lib().emu_resize_batch(C.byref(b))
     for k, (im, (w, h)) in enumerate(zip(imgs, dims)):
         assert np.array_equal(outs[k], orc.resize_nn(im, w, h)), k
+
+
+def test_descriptors_the_32_bit_source_offsets_cannot_address_are_refused():
+    """The kernels address a source with 32-bit byte offsets and multiply the row stride as a 24-bit value: a descriptor
+    whose explicit stride puts the last pixel 4 GiB or more behind the first is refused on the host."""
+    import ctypes as C
+    L = emu.lib()
+    L.achip_frame_extent_ok.restype = C.c_bool
+    L.achip_frame_extent_ok.argtypes = [C.POINTER(emu.Frame)]
+    img = orc.frame_hash_noise(64, 48, 1)
+    f = emu.frame_for_convert(img, 20, 10, 0)
+    assert L.achip_frame_extent_ok(C.byref(f))
+    f.src_stride = 3 * 64 + 5  # a padded row: fine
+    assert L.achip_frame_extent_ok(C.byref(f))
+    f.src_w, f.src_h, f.src_stride = 10000, 10000, 0  # the largest image ascii_convert accepts: 300 MB
+    assert L.achip_frame_extent_ok(C.byref(f))
+    f.src_stride = 1 << 24  # 16 MiB rows
+    assert not L.achip_frame_extent_ok(C.byref(f))
+    f.src_stride = 500000   # 10 000 rows x 500 KB = 5 GB
+    assert not L.achip_frame_extent_ok(C.byref(f))
+    f.src_stride = -192
+    assert not L.achip_frame_extent_ok(C.byref(f))
