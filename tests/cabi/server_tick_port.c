@@ -1,0 +1,180 @@
+/*
+ * server_tick_port.c -- one tick of a many-client server in plain C against the BATCH layer of the C-ABI
+ * (include/asciichat_hip.h + achip_host.h) and the HIP runtime's C API, the way INTEGRATION.md section 2 describes it:
+ *
+ *   receive side   every client's latest camera frame arrives as the reference's blob [u32 BE width][u32 BE height][RGB24]
+ *                  (src/server/stream.c:330-372) and is PUBLISHED once into the device-resident frame table
+ *   render tick    one plan renders every client's frame for its terminal (sizes as ascii_convert_with_capabilities,
+ *                  lib/video/ascii/ascii.c:194-387), and the same launch leaves the wire stage's results: frame CRC-32C,
+ *                  the 24-byte ascii_frame_packet_t headers (lib/network/acip/server.c:186-214) and the CRC of
+ *                  header || frame (lib/network/acip/send.c:59-69)
+ *   send side      one copy back; every packet is checked HERE, on the host, with this file's own bit-serial CRC-32C:
+ *                  the frame against what the drop-in entry point returns for the same image, the header field by field,
+ *                  both checksums
+ *
+ * No Python, no PyTorch: gcc, libasciichat_hip.so, libamdhip64.  Exit status 0 and a last line "ok: <n> checks".
+ */
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "achip_host.h"
+#include "asciichat_hip.h"
+#include "asciichat_render.h"
+
+static int g_checks;
+#define CHECK(cond, ...)                                                                                               \
+  do {                                                                                                                 \
+    g_checks++;                                                                                                        \
+    if (!(cond)) {                                                                                                     \
+      fprintf(stderr, "FAILED %s:%d: %s -- ", __FILE__, __LINE__, #cond);                                              \
+      fprintf(stderr, __VA_ARGS__);                                                                                    \
+      fprintf(stderr, " [%s]\n", asciichat_hip_last_error());                                                          \
+      exit(1);                                                                                                         \
+    }                                                                                                                  \
+  } while (0)
+#define HIP(call) CHECK((call) == hipSuccess, "%s", #call)
+
+/* CRC-32C (Castagnoli), reflected, init and final xor 0xFFFFFFFF: asciichat_crc32 (lib/network/crc32.c:95-190), bit by bit */
+static uint32_t crc32c(const uint8_t *p, size_t n, uint32_t crc) {
+  crc = ~crc;
+  for (size_t i = 0; i < n; i++) {
+    crc ^= p[i];
+    for (int k = 0; k < 8; k++)
+      crc = (crc & 1u) ? (crc >> 1) ^ 0x82F63B78u : crc >> 1;
+  }
+  return ~crc;
+}
+
+static uint32_t be32(const uint8_t *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+
+enum { CLIENTS = 12 };
+
+static void run_tick(int force_variant) {
+  static const int src_w[CLIENTS] = {320, 640, 160, 320, 1280, 64, 320, 333, 640, 2, 320, 800};
+  static const int src_h[CLIENTS] = {240, 480, 120, 200, 720, 48, 240, 111, 360, 2, 240, 600};
+  static const int term_w[CLIENTS] = {80, 120, 40, 80, 200, 20, 80, 97, 132, 10, 80, 100};
+  static const int term_h[CLIENTS] = {24, 40, 12, 24, 60, 10, 50, 31, 43, 5, 24, 30};
+  const char *palette = "   ...',;:clodxkO0KXNWM";
+  terminal_capabilities_t caps;
+  memset(&caps, 0, sizeof caps);
+  caps.color_level = 3; /* truecolor */
+  caps.render_mode = RENDER_MODE_FOREGROUND;
+  caps.utf8_support = true;
+  caps.wants_padding = true;
+
+  hipStream_t upload, render;
+  HIP(hipStreamCreateWithFlags(&upload, hipStreamNonBlocking));
+  HIP(hipStreamCreateWithFlags(&render, hipStreamNonBlocking));
+
+  /* ---- receive side */
+  asciichat_hip_frame_table_t *table = NULL;
+  CHECK(asciichat_hip_frame_table_create(&table, CLIENTS) == 0, "frame table");
+  uint8_t *blob[CLIENTS];
+  uint32_t seed = 2463534242u;
+  for (int c = 0; c < CLIENTS; c++) {
+    const size_t px = (size_t)src_w[c] * (size_t)src_h[c] * 3u;
+    blob[c] = (uint8_t *)malloc(8 + px);
+    CHECK(blob[c] != NULL, "malloc");
+    const uint32_t w = (uint32_t)src_w[c], h = (uint32_t)src_h[c];
+    blob[c][0] = (uint8_t)(w >> 24), blob[c][1] = (uint8_t)(w >> 16), blob[c][2] = (uint8_t)(w >> 8), blob[c][3] = (uint8_t)w;
+    blob[c][4] = (uint8_t)(h >> 24), blob[c][5] = (uint8_t)(h >> 16), blob[c][6] = (uint8_t)(h >> 8), blob[c][7] = (uint8_t)h;
+    for (size_t i = 0; i < px; i++) { /* blocks of flat colour with noise on top: runs, repeats and changes */
+      seed ^= seed << 13, seed ^= seed >> 17, seed ^= seed << 5;
+      const size_t pixel = i / 3u, x = pixel % (size_t)src_w[c], y = pixel / (size_t)src_w[c];
+      const uint8_t flat = (uint8_t)(((x / 23u) * 37u + (y / 17u) * 91u + (i % 3u) * 60u + (size_t)c * 11u) & 0xFFu);
+      blob[c][8 + i] = (seed & 7u) ? flat : (uint8_t)(seed >> 11);
+    }
+    CHECK(asciichat_hip_frame_table_publish(table, c, blob[c], 8 + px, upload) == 0, "publish client %d", c);
+  }
+  /* a blob the reference would skip is refused and leaves the slot untouched */
+  CHECK(asciichat_hip_frame_table_publish(table, 0, blob[0], 11, upload) != 0, "short blob must be refused");
+
+  /* ---- render tick */
+  achip_frame_t frames[CLIENTS];
+  uint32_t dims_host[2 * CLIENTS];
+  for (int c = 0; c < CLIENTS; c++) {
+    const uint8_t *px = NULL;
+    int w = 0, h = 0;
+    uint64_t gen = 0;
+    CHECK(asciichat_hip_frame_table_latest(table, c, render, &px, &w, &h, &gen) == 0 && px && w == src_w[c] && h == src_h[c] && gen == 1,
+          "latest frame of client %d", c);
+    CHECK(achip_frame_setup(&frames[c], px, w, h, term_w[c], term_h[c], caps.render_mode, caps.wants_padding, true, false) == 0,
+          "frame_setup client %d", c);
+    dims_host[2 * c] = (uint32_t)term_w[c];
+    dims_host[2 * c + 1] = (uint32_t)term_h[c];
+  }
+  asciichat_hip_plan_t *plan = NULL;
+  CHECK(asciichat_hip_plan_create(&plan, achip_mode_from_caps(caps.color_level, caps.render_mode), palette, frames, CLIENTS) == 0,
+        "plan_create");
+  if (force_variant >= 0)
+    CHECK(asciichat_hip_plan_set_variant(plan, force_variant) == 0, "set_variant %d", force_variant);
+  const size_t stride = asciichat_hip_plan_out_stride(plan);
+  uint8_t *slab = NULL, *hdr = NULL;
+  uint32_t *len = NULL, *crc = NULL, *pkt = NULL, *dims = NULL;
+  HIP(hipMalloc((void **)&slab, stride * CLIENTS));
+  HIP(hipMalloc((void **)&hdr, 24 * CLIENTS));
+  HIP(hipMalloc((void **)&len, 4 * CLIENTS));
+  HIP(hipMalloc((void **)&crc, 4 * CLIENTS));
+  HIP(hipMalloc((void **)&pkt, 4 * CLIENTS));
+  HIP(hipMalloc((void **)&dims, 8 * CLIENTS));
+  HIP(hipMemcpy(dims, dims_host, 8 * CLIENTS, hipMemcpyHostToDevice));
+  CHECK(asciichat_hip_plan_render_packets(plan, slab, stride, len, dims, crc, hdr, pkt, render) == 0, "render_packets");
+
+  /* ---- send side */
+  uint8_t *slab_h = (uint8_t *)malloc(stride * CLIENTS), hdr_h[24 * CLIENTS];
+  uint32_t len_h[CLIENTS], crc_h[CLIENTS], pkt_h[CLIENTS];
+  CHECK(slab_h != NULL, "malloc");
+  void *streams[1] = {render};
+  CHECK(asciichat_hip_streams_wait(streams, 1) == 0, "streams_wait");
+  HIP(hipMemcpy(slab_h, slab, stride * CLIENTS, hipMemcpyDeviceToHost));
+  HIP(hipMemcpy(hdr_h, hdr, sizeof hdr_h, hipMemcpyDeviceToHost));
+  HIP(hipMemcpy(len_h, len, sizeof len_h, hipMemcpyDeviceToHost));
+  HIP(hipMemcpy(crc_h, crc, sizeof crc_h, hipMemcpyDeviceToHost));
+  HIP(hipMemcpy(pkt_h, pkt, sizeof pkt_h, hipMemcpyDeviceToHost));
+  for (int c = 0; c < CLIENTS; c++) {
+    const uint8_t *frame = slab_h + (size_t)c * stride, *h = hdr_h + 24 * c;
+    CHECK(len_h[c] < 0xFFFFFFF0u && len_h[c] < stride && frame[len_h[c]] == 0, "client %d: length %u, NUL behind it", c, len_h[c]);
+    /* the same image through the reference's own entry point (the drop-in layer) */
+    image_t img = {src_w[c], src_h[c], (rgb_pixel_t *)(blob[c] + 8), IMAGE_ALLOC_SIMD};
+    char *ref = ascii_convert_with_capabilities(&img, term_w[c], term_h[c], &caps, true, false, palette);
+    CHECK(ref != NULL, "drop-in render of client %d", c);
+    CHECK(strlen(ref) == len_h[c] && memcmp(ref, frame, len_h[c]) == 0, "client %d: batch frame == drop-in frame (%zu vs %u bytes)", c,
+          strlen(ref), len_h[c]);
+    free(ref);
+    const uint32_t want = crc32c(frame, len_h[c], 0);
+    CHECK(crc_h[c] == want, "client %d: frame CRC %08x, expected %08x", c, crc_h[c], want);
+    CHECK(be32(h) == (uint32_t)term_w[c] && be32(h + 4) == (uint32_t)term_h[c] && be32(h + 8) == len_h[c] && be32(h + 12) == 0 &&
+              be32(h + 16) == want && be32(h + 20) == 0,
+          "client %d: packet header fields", c);
+    uint32_t p = crc32c(h, 24, 0);            /* CRC over header || frame, continued across the two pieces */
+    p = crc32c(frame, len_h[c], p);
+    CHECK(pkt_h[c] == p, "client %d: packet CRC %08x, expected %08x", c, pkt_h[c], p);
+  }
+  printf("tick (geometry %d, fused CRC %s): %d clients, frames == drop-in renders, headers and both checksums verified on the host\n",
+         asciichat_hip_plan_get_variant(plan), asciichat_hip_plan_has_fused_crc(plan) ? "yes" : "no", CLIENTS);
+
+  asciichat_hip_plan_destroy(plan);
+  asciichat_hip_frame_table_destroy(table);
+  (void)hipFree(slab), (void)hipFree(hdr), (void)hipFree(len), (void)hipFree(crc), (void)hipFree(pkt), (void)hipFree(dims);
+  free(slab_h);
+  for (int c = 0; c < CLIENTS; c++)
+    free(blob[c]);
+  HIP(hipStreamDestroy(upload));
+  HIP(hipStreamDestroy(render));
+}
+
+int main(void) {
+  if (asciichat_hip_device_count() <= 0) {
+    fprintf(stderr, "no HIP device: %s\n", asciichat_hip_last_error());
+    return 2;
+  }
+  run_tick(-1); /* the plan's own choice: row bands for twelve frames, the stand-alone wire kernel behind them */
+  run_tick(17); /* whole frames on the stream kernel: CRC, headers and packet CRCs leave the render launch */
+  printf("ok: %d checks\n", g_checks);
+  return 0;
+}

@@ -77,3 +77,29 @@ def test_buffer_pool_under_sanitizers(san, tmp_path):
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", TSAN_OPTIONS="halt_on_error=1")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "ok:" in r.stdout and "Sanitizer" not in r.stderr, r.stdout[-500:] + r.stderr[-3000:]
+
+
+# ---- the batch layer from plain C: one server tick (frame table -> plan -> render + wire stage -> host-side verification) ----
+TICK_SRC = os.path.join(ROOT, "tests", "cabi", "server_tick_port.c")
+TICK_EXE = os.path.join(ROOT, "tests", "cabi", "server_tick_port")
+
+
+def build_tick():
+    subprocess.check_call(["gcc", "-std=gnu11", "-O1", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           "-I/opt/rocm/include", TICK_SRC, "-o", TICK_EXE, "-L" + LIBDIR, "-lasciichat_hip", "-L/opt/rocm/lib",
+                           "-lamdhip64", "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,/opt/rocm/lib"])
+    return TICK_EXE
+
+
+def test_server_tick_harness_compiles_in_plain_c():
+    build_tick()
+
+
+@pytest.mark.gpu
+def test_server_tick_in_plain_c():
+    """No Python in the data path: a C program publishes twelve clients' frames, renders them with one plan (once as row
+    bands + the stand-alone wire kernel, once as whole frames with the fused CRC / headers), copies the packets back and
+    verifies frames (== the drop-in entry point's output), header fields and both CRC-32Cs with its own bit-serial CRC."""
+    r = subprocess.run([build_tick()], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.strip().splitlines()[-1].startswith("ok:") and "fused CRC yes" in r.stdout
