@@ -12,6 +12,8 @@
  *                  the frame against what the drop-in entry point returns for the same image, the header field by field,
  *                  both checksums
  *
+ * A second tick renders the server's 3x3 grid with the tiles exchanged through the library's RCCL layer (world of one).
+ *
  * No Python, no PyTorch: gcc, libasciichat_hip.so, libamdhip64.  Exit status 0 and a last line "ok: <n> checks".
  */
 #define __HIP_PLATFORM_AMD__ 1
@@ -168,6 +170,93 @@ static void run_tick(int force_variant) {
   HIP(hipStreamDestroy(render));
 }
 
+/* The server's pixel-space grid (create_multi_source_composite + convert_composite_to_ascii, src/server/stream.c:664-854)
+ * with the sources spread over GPUs -- here a world of ONE rank, so that the real RCCL collective runs on one GPU: the
+ * tiles go through asciichat_hip_grid_exchange (one batched resize launch + one ncclAllGather), every target client is
+ * rendered from the gathered tiles, and the result must equal the single-GPU composite path (achip_composite_setup:
+ * the same geometry, sampled straight from the sources) byte for byte. */
+static void run_grid_tick(void) {
+  enum { SOURCES = 9, TARGETS = 4, TW = 160, TH = 48 };
+  int sw[SOURCES], sh[SOURCES];
+  uint8_t *src_dev[SOURCES];
+  const uint8_t *src_c[SOURCES];
+  uint32_t seed = 88172645u;
+  for (int k = 0; k < SOURCES; k++) {
+    sw[k] = 320 + 64 * (k % 3);
+    sh[k] = 180 + 36 * (k / 3);
+    const size_t px = (size_t)sw[k] * (size_t)sh[k] * 3u;
+    uint8_t *h = (uint8_t *)malloc(px);
+    CHECK(h != NULL, "malloc");
+    for (size_t i = 0; i < px; i++) {
+      seed ^= seed << 13, seed ^= seed >> 17, seed ^= seed << 5;
+      h[i] = (uint8_t)(seed >> 9);
+    }
+    HIP(hipMalloc((void **)&src_dev[k], px));
+    HIP(hipMemcpy(src_dev[k], h, px, hipMemcpyHostToDevice));
+    src_c[k] = src_dev[k];
+    free(h);
+  }
+  hipStream_t st;
+  HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  uint8_t id[ASCIICHAT_HIP_COMM_ID_BYTES];
+  asciichat_hip_comm_t *comm = NULL;
+  CHECK(asciichat_hip_comm_unique_id(id, sizeof id) == 0, "comm_unique_id");
+  CHECK(asciichat_hip_comm_init(&comm, 1, 0, id, sizeof id) == 0 && asciichat_hip_comm_world(comm) == 1, "comm_init");
+  asciichat_hip_grid_t *grid = NULL;
+  CHECK(asciichat_hip_grid_create(&grid, comm, sw, sh, NULL, SOURCES, TW, TH) == 0, "grid_create");
+  for (int k = 0; k < SOURCES; k++)
+    CHECK(asciichat_hip_grid_owner(grid, k) == 0, "one rank owns every source");
+  CHECK(asciichat_hip_grid_exchange(grid, src_c, st) == 0, "grid_exchange");
+
+  achip_composite_t local, *local_dev = NULL; /* the single-GPU path: the same grid sampled straight from the sources */
+  achip_composite_setup(&local, src_c, sw, sh, SOURCES, TW, TH);
+  CHECK(asciichat_hip_composite_upload(&local, &local_dev) == 0, "composite_upload");
+
+  uint8_t *slab[2] = {NULL, NULL};
+  uint32_t *len[2] = {NULL, NULL};
+  size_t stride = 0;
+  for (int path = 0; path < 2; path++) {
+    achip_frame_t f[TARGETS];
+    for (int t = 0; t < TARGETS; t++) { /* every target looks at the W x 2H canvas (stream.c:790-854: aspect + padding on) */
+      CHECK(achip_frame_setup(&f[t], NULL, TW, 2 * TH, TW - 8 * t, TH - 3 * t, RENDER_MODE_FOREGROUND, true, true, false) == 0,
+            "frame_setup target %d", t);
+      f[t].comp = path == 0 ? asciichat_hip_grid_composite_dev(grid) : local_dev;
+    }
+    asciichat_hip_plan_t *plan = NULL;
+    CHECK(asciichat_hip_plan_create(&plan, achip_mode_from_caps(3, RENDER_MODE_FOREGROUND), "   ...',;:clodxkO0KXNWM", f, TARGETS) == 0,
+          "plan_create (grid, path %d)", path);
+    stride = asciichat_hip_plan_out_stride(plan);
+    HIP(hipMalloc((void **)&slab[path], stride * TARGETS));
+    HIP(hipMalloc((void **)&len[path], 4 * TARGETS));
+    CHECK(asciichat_hip_plan_render(plan, slab[path], stride, len[path], st) == 0, "plan_render (grid, path %d)", path);
+    void *streams[1] = {st};
+    CHECK(asciichat_hip_streams_wait(streams, 1) == 0, "streams_wait");
+    asciichat_hip_plan_destroy(plan);
+  }
+  uint8_t *a = (uint8_t *)malloc(stride * TARGETS), *b = (uint8_t *)malloc(stride * TARGETS);
+  uint32_t la[TARGETS], lb[TARGETS];
+  CHECK(a && b, "malloc");
+  HIP(hipMemcpy(a, slab[0], stride * TARGETS, hipMemcpyDeviceToHost));
+  HIP(hipMemcpy(b, slab[1], stride * TARGETS, hipMemcpyDeviceToHost));
+  HIP(hipMemcpy(la, len[0], sizeof la, hipMemcpyDeviceToHost));
+  HIP(hipMemcpy(lb, len[1], sizeof lb, hipMemcpyDeviceToHost));
+  for (int t = 0; t < TARGETS; t++) {
+    CHECK(la[t] < 0xFFFFFFF0u && la[t] == lb[t] && la[t] > 100u, "target %d: lengths %u / %u", t, la[t], lb[t]);
+    CHECK(memcmp(a + (size_t)t * stride, b + (size_t)t * stride, la[t]) == 0, "target %d: exchanged tiles == direct composite", t);
+  }
+  printf("grid tick: %d sources -> tiles through one ncclAllGather (world 1) -> %d targets, identical to the direct composite\n", SOURCES,
+         TARGETS);
+  free(a), free(b);
+  for (int p = 0; p < 2; p++)
+    (void)hipFree(slab[p]), (void)hipFree(len[p]);
+  asciichat_hip_free(local_dev);
+  asciichat_hip_grid_destroy(grid);
+  asciichat_hip_comm_destroy(comm);
+  for (int k = 0; k < SOURCES; k++)
+    (void)hipFree(src_dev[k]);
+  HIP(hipStreamDestroy(st));
+}
+
 int main(void) {
   if (asciichat_hip_device_count() <= 0) {
     fprintf(stderr, "no HIP device: %s\n", asciichat_hip_last_error());
@@ -175,6 +264,7 @@ int main(void) {
   }
   run_tick(-1); /* the plan's own choice: row bands for twelve frames, the stand-alone wire kernel behind them */
   run_tick(17); /* whole frames on the stream kernel: CRC, headers and packet CRCs leave the render launch */
+  run_grid_tick();
   printf("ok: %d checks\n", g_checks);
   return 0;
 }

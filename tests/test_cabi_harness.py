@@ -103,3 +103,4 @@ def test_server_tick_in_plain_c():
     r = subprocess.run([build_tick()], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.strip().splitlines()[-1].startswith("ok:") and "fused CRC yes" in r.stdout
+    assert "grid tick: 9 sources" in r.stdout  # the 3x3 grid with its tiles through the library's RCCL layer (world of one)
