@@ -136,6 +136,19 @@ def lib():
     L.asciichat_hip_comm_world.argtypes = [vp]
     L.asciichat_hip_comm_rank.restype = ci
     L.asciichat_hip_comm_rank.argtypes = [vp]
+    L.asciichat_hip_comm_count.restype = ci
+    L.asciichat_hip_comm_count.argtypes = [vp]
+    L.asciichat_hip_comm_all_gather_packed.restype = ci
+    L.asciichat_hip_comm_all_gather_packed.argtypes = [vp, vp, sz, vp, ci, vp, sz, C.POINTER(C.c_uint64),
+                                                       C.POINTER(C.c_uint32), C.POINTER(sz), vp]
+    L.asciichat_hip_pack_frames.restype = ci
+    L.asciichat_hip_pack_frames.argtypes = [vp, sz, vp, ci, vp, sz, vp, vp, vp]
+    L.asciichat_hip_plan_render_packed.restype = ci
+    L.asciichat_hip_plan_render_packed.argtypes = [vp, vp, sz, vp, vp, sz, vp, vp, vp]
+    L.asciichat_hip_host_alloc.restype = ci
+    L.asciichat_hip_host_alloc.argtypes = [sz, C.POINTER(vp), C.POINTER(vp)]
+    L.asciichat_hip_host_free.restype = None
+    L.asciichat_hip_host_free.argtypes = [vp]
     L.asciichat_hip_comm_destroy.restype = None
     L.asciichat_hip_comm_destroy.argtypes = [vp]
     L.asciichat_hip_comm_all_gather.restype = ci
@@ -368,6 +381,13 @@ class Plan:
         if rc != 0:
             raise RuntimeError(f"plan_render failed ({rc}): {last_error()}")
 
+    def render_packed(self, slab_ptr, out_stride, len_ptr, dst_ptr, dst_capacity, off_ptr=None, len_out_ptr=None, stream=0):
+        """render + compaction (asciichat_hip_plan_render_packed): frame i -> dst + off[i], off[n] = total bytes"""
+        rc = lib().asciichat_hip_plan_render_packed(self._h, slab_ptr, out_stride, len_ptr, dst_ptr, dst_capacity, off_ptr,
+                                                    len_out_ptr, stream)
+        if rc != 0:
+            raise RuntimeError(f"plan_render_packed failed ({rc}): {last_error()}")
+
     def render_crc(self, out_ptr, out_stride, len_ptr, crc_ptr, stream=0):
         rc = lib().asciichat_hip_plan_render_crc(self._h, out_ptr, out_stride, len_ptr, crc_ptr, stream)
         if rc != 0:
@@ -454,6 +474,34 @@ class Schedule:
             lib().asciichat_hip_schedule_destroy(h)
 
 
+def pack_frames(slab_ptr, stride, len_ptr, n, dst_ptr, dst_capacity, off_ptr=None, len_out_ptr=None, stream=0):
+    rc = lib().asciichat_hip_pack_frames(slab_ptr, stride, len_ptr, n, dst_ptr, dst_capacity, off_ptr, len_out_ptr, stream)
+    if rc != 0:
+        raise RuntimeError(f"pack_frames failed ({rc}): {last_error()}")
+
+
+class HostBuffer:
+    """Mapped pinned host memory (asciichat_hip_host_alloc): .host for the CPU, .dev for kernels."""
+
+    def __init__(self, nbytes):
+        h, d = C.c_void_p(), C.c_void_p()
+        rc = lib().asciichat_hip_host_alloc(nbytes, C.byref(h), C.byref(d))
+        if rc != 0:
+            raise RuntimeError(f"host_alloc failed ({rc}): {last_error()}")
+        self.host, self.dev, self.nbytes = h.value, d.value, nbytes
+
+    def view(self, offset=0, nbytes=None):
+        """numpy uint8 view of the host side"""
+        import numpy as np
+        n = self.nbytes - offset if nbytes is None else nbytes
+        return np.ctypeslib.as_array((C.c_uint8 * n).from_address(self.host + offset))
+
+    def close(self):
+        if self.host:
+            lib().asciichat_hip_host_free(self.host)
+            self.host = self.dev = None
+
+
 COMM_ID_BYTES = 128
 
 
@@ -480,6 +528,21 @@ class Comm:
         rc = lib().asciichat_hip_comm_all_gather(self._h, send_ptr, recv_ptr, bytes_per_rank, stream)
         if rc != 0:
             raise RuntimeError(f"comm_all_gather failed ({rc}): {last_error()}")
+
+    @property
+    def count(self):
+        """ranks the communicator itself reports (ncclCommCount)"""
+        return lib().asciichat_hip_comm_count(self._h)
+
+    def all_gather_packed(self, slab_ptr, stride, len_ptr, slots_per_rank, packed_ptr, capacity_per_rank, stream=0):
+        """-> (offsets[world*slots], lengths[world*slots], bytes every rank contributed)"""
+        n = self.world * slots_per_rank
+        off, ln, blk = (C.c_uint64 * n)(), (C.c_uint32 * n)(), C.c_size_t()
+        rc = lib().asciichat_hip_comm_all_gather_packed(self._h, slab_ptr, stride, len_ptr, slots_per_rank, packed_ptr,
+                                                        capacity_per_rank, off, ln, C.byref(blk), stream)
+        if rc != 0:
+            raise RuntimeError(f"comm_all_gather_packed failed ({rc}): {last_error()}")
+        return list(off), list(ln), blk.value
 
     def all_gather_slab(self, slab_ptr, stride, len_ptr, slots_per_rank, stream=0):
         rc = lib().asciichat_hip_comm_all_gather_slab(self._h, slab_ptr, stride, len_ptr, slots_per_rank, stream)

@@ -17,10 +17,10 @@
  */
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
-#include <rccl/rccl.h>
 
 #include <dlfcn.h>
 #include <pthread.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -30,50 +30,73 @@
 #include "internal.h"
 
 /* ------------------------------------------------------------------------------------------- */
-/* librccl, resolved on first use                                                                  */
+/* librccl, resolved on first use.  The handful of types and prototypes this file needs are declared here instead of  */
+/* including <rccl/rccl.h>: the library is dlopen'ed, so hosts without the RCCL development headers can still build    */
+/* the drop-in library.  Values follow nccl.h (ncclUniqueId = 128 opaque bytes, ncclUint8 = 1,         */
+/* ncclSuccess = 0), which RCCL keeps ABI-stable.                                                                      */
 /* ------------------------------------------------------------------------------------------- */
+typedef struct {
+  char internal[ASCIICHAT_HIP_COMM_ID_BYTES];
+} rccl_unique_id_t;
+typedef struct ncclComm *rccl_comm_t;
+typedef int rccl_result_t; /* ncclResult_t: 0 = ncclSuccess */
+enum { RCCL_SUCCESS = 0, RCCL_UINT8 = 1 /* RCCL_UINT8 */ };
+
 static struct {
   void *handle;
-  ncclResult_t (*GetUniqueId)(ncclUniqueId *);
-  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
-  ncclResult_t (*CommDestroy)(ncclComm_t);
-  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
-  ncclResult_t (*GroupStart)(void);
-  ncclResult_t (*GroupEnd)(void);
-  const char *(*GetErrorString)(ncclResult_t);
+  rccl_result_t (*GetUniqueId)(rccl_unique_id_t *);
+  rccl_result_t (*CommInitRank)(rccl_comm_t *, int, rccl_unique_id_t, int);
+  rccl_result_t (*CommDestroy)(rccl_comm_t);
+  rccl_result_t (*CommCount)(rccl_comm_t, int *);
+  rccl_result_t (*AllGather)(const void *, void *, size_t, int, rccl_comm_t, hipStream_t);
+  rccl_result_t (*GroupStart)(void);
+  rccl_result_t (*GroupEnd)(void);
+  const char *(*GetErrorString)(rccl_result_t);
   int state; /* 0 = not tried, 1 = ready, -1 = unavailable */
+  char why[160]; /* the loader's message, kept from the one attempt (dlerror() is NULL on later calls) */
 } g_rccl;
 static pthread_mutex_t g_rccl_mu = PTHREAD_MUTEX_INITIALIZER;
 
 static int rccl_load(void) {
   pthread_mutex_lock(&g_rccl_mu);
   if (g_rccl.state == 0) {
-    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (size_t i = 0; i < sizeof(names) / sizeof(names[0]) && !g_rccl.handle; i++)
+    /* ASCIICHAT_HIP_RCCL_LIB names another library with the same seven entry points: the tests use it to run this
+     * file with a world of two on a one-GPU box over a stand-in transport (tests/cabi/loopback_rccl.c) */
+    const char *env = getenv("ASCIICHAT_HIP_RCCL_LIB");
+    const char *names[] = {env && env[0] ? env : "librccl.so.1", "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    const size_t n_names = env && env[0] ? 1 : sizeof(names) / sizeof(names[0]);
+    for (size_t i = 0; i < n_names && !g_rccl.handle; i++)
       g_rccl.handle = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
     g_rccl.state = -1;
     if (g_rccl.handle) {
       *(void **)&g_rccl.GetUniqueId = dlsym(g_rccl.handle, "ncclGetUniqueId");
       *(void **)&g_rccl.CommInitRank = dlsym(g_rccl.handle, "ncclCommInitRank");
       *(void **)&g_rccl.CommDestroy = dlsym(g_rccl.handle, "ncclCommDestroy");
+      *(void **)&g_rccl.CommCount = dlsym(g_rccl.handle, "ncclCommCount");
       *(void **)&g_rccl.AllGather = dlsym(g_rccl.handle, "ncclAllGather");
       *(void **)&g_rccl.GroupStart = dlsym(g_rccl.handle, "ncclGroupStart");
       *(void **)&g_rccl.GroupEnd = dlsym(g_rccl.handle, "ncclGroupEnd");
       *(void **)&g_rccl.GetErrorString = dlsym(g_rccl.handle, "ncclGetErrorString");
-      if (g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.CommDestroy && g_rccl.AllGather && g_rccl.GroupStart &&
-          g_rccl.GroupEnd && g_rccl.GetErrorString)
+      if (g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.CommDestroy && g_rccl.CommCount && g_rccl.AllGather &&
+          g_rccl.GroupStart && g_rccl.GroupEnd && g_rccl.GetErrorString)
         g_rccl.state = 1;
+      else
+        snprintf(g_rccl.why, sizeof(g_rccl.why), "%s lacks an nccl* entry point", names[0]);
+    } else {
+      const char *e = dlerror();
+      snprintf(g_rccl.why, sizeof(g_rccl.why), "%s", e ? e : "dlopen failed");
     }
   }
   const int ok = g_rccl.state == 1;
   pthread_mutex_unlock(&g_rccl_mu);
-  return ok ? 0 : achip_fail(ASCIICHAT_HIP_ERR_NOT_SUPPORTED, "librccl.so.1 is not loadable: %s", dlerror());
+  return ok ? 0 : achip_fail(ASCIICHAT_HIP_ERR_NOT_SUPPORTED, "librccl.so.1 is not loadable: %s", g_rccl.why);
 }
 
-static int rccl_check(ncclResult_t r, const char *what) {
-  if (r == ncclSuccess)
+/* a failed collective is a broken communicator, not a missing device (ERR_NO_DEVICE always prints to stderr) */
+static int rccl_check(rccl_result_t r, const char *what) {
+  if (r == RCCL_SUCCESS)
     return 0;
-  return achip_fail(ASCIICHAT_HIP_ERR_NO_DEVICE, "%s failed: %s", what, g_rccl.GetErrorString(r));
+  return achip_fail(ASCIICHAT_HIP_ERR_INVALID_STATE, "%s failed: %s", what, g_rccl.GetErrorString(r));
 }
 
 /* ------------------------------------------------------------------------------------------- */
@@ -115,7 +138,7 @@ int achip_shard_slots(int n_items, int world) {
 /* communicator                                                                                   */
 /* ------------------------------------------------------------------------------------------- */
 struct asciichat_hip_comm {
-  ncclComm_t comm;
+  rccl_comm_t comm;
   int world, rank;
 };
 
@@ -125,7 +148,7 @@ int asciichat_hip_comm_unique_id(void *id_out, size_t id_bytes) {
   int rc = rccl_load();
   if (rc)
     return rc;
-  ncclUniqueId id;
+  rccl_unique_id_t id;
   rc = rccl_check(g_rccl.GetUniqueId(&id), "ncclGetUniqueId");
   if (!rc)
     memcpy(id_out, &id, sizeof(id));
@@ -144,7 +167,7 @@ int asciichat_hip_comm_init(asciichat_hip_comm_t **comm, int world, int rank, co
   asciichat_hip_comm_t *c = (asciichat_hip_comm_t *)calloc(1, sizeof(*c));
   if (!c)
     return achip_fail(ASCIICHAT_HIP_ERR_MEMORY, "out of memory");
-  ncclUniqueId uid;
+  rccl_unique_id_t uid;
   memcpy(&uid, id, sizeof(uid));
   rc = rccl_check(g_rccl.CommInitRank(&c->comm, world, uid, rank), "ncclCommInitRank");
   if (rc) {
@@ -158,6 +181,13 @@ int asciichat_hip_comm_init(asciichat_hip_comm_t **comm, int world, int rank, co
 }
 
 int asciichat_hip_comm_world(const asciichat_hip_comm_t *c) { return c ? c->world : 1; }
+/* ranks the communicator itself reports (ncclCommCount) -- what bench.py prints next to n_gpus */
+int asciichat_hip_comm_count(const asciichat_hip_comm_t *c) {
+  int n = 0;
+  if (!c || !c->comm || g_rccl.state != 1 || rccl_check(g_rccl.CommCount(c->comm, &n), "ncclCommCount"))
+    return -1;
+  return n;
+}
 int asciichat_hip_comm_rank(const asciichat_hip_comm_t *c) { return c ? c->rank : 0; }
 
 void asciichat_hip_comm_destroy(asciichat_hip_comm_t *c) {
@@ -174,7 +204,7 @@ int asciichat_hip_comm_all_gather(asciichat_hip_comm_t *c, const void *send_dev,
     return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "comm_all_gather: bad arguments");
   if (bytes_per_rank == 0)
     return 0;
-  return rccl_check(g_rccl.AllGather(send_dev, recv_dev, bytes_per_rank, ncclUint8, c->comm, (hipStream_t)stream),
+  return rccl_check(g_rccl.AllGather(send_dev, recv_dev, bytes_per_rank, RCCL_UINT8, c->comm, (hipStream_t)stream),
                     "ncclAllGather");
 }
 
@@ -191,14 +221,82 @@ int asciichat_hip_comm_all_gather_slab(asciichat_hip_comm_t *c, uint8_t *slab_de
   int rc = rccl_check(g_rccl.GroupStart(), "ncclGroupStart");
   if (rc)
     return rc;
-  ncclResult_t a = g_rccl.AllGather(slab_dev + (size_t)c->rank * block, slab_dev, block, ncclUint8, c->comm,
+  rccl_result_t a = g_rccl.AllGather(slab_dev + (size_t)c->rank * block, slab_dev, block, RCCL_UINT8, c->comm,
                                     (hipStream_t)stream);
-  ncclResult_t b = g_rccl.AllGather(len_dev + (size_t)c->rank * (size_t)slots_per_rank, len_dev,
-                                    (size_t)slots_per_rank * sizeof(uint32_t), ncclUint8, c->comm, (hipStream_t)stream);
-  ncclResult_t e = g_rccl.GroupEnd();
+  rccl_result_t b = g_rccl.AllGather(len_dev + (size_t)c->rank * (size_t)slots_per_rank, len_dev,
+                                    (size_t)slots_per_rank * sizeof(uint32_t), RCCL_UINT8, c->comm, (hipStream_t)stream);
+  rccl_result_t e = g_rccl.GroupEnd();
   if ((rc = rccl_check(a, "ncclAllGather(slab)")) || (rc = rccl_check(b, "ncclAllGather(lengths)")))
     return rc;
   return rccl_check(e, "ncclGroupEnd");
+}
+
+/* The same exchange with compacted blocks: what crosses xGMI is the bytes in use, not the worst-case stride (SURVEY 8e:
+ * "prefer gathering compacted per-rank buffers ... lengths first").  Three steps on `stream`: (1) in-place all-gather
+ * of the lengths, read back by the host (the one synchronisation: collectives need equal sizes on every rank, and only
+ * the host can size them); (2) pack_frames of this rank's block to its place in packed_dev; (3) in-place all-gather of
+ * max-over-ranks packed bytes. */
+int asciichat_hip_comm_all_gather_packed(asciichat_hip_comm_t *c, const uint8_t *slab_dev, size_t stride, uint32_t *len_dev,
+                                         int slots_per_rank, uint8_t *packed_dev, size_t packed_capacity_per_rank,
+                                         uint64_t *off_host, uint32_t *len_host, size_t *block_bytes, void *stream) {
+  if (!c || !slab_dev || !len_dev || !packed_dev || !off_host || slots_per_rank < 0 || (packed_capacity_per_rank & 15u) ||
+      ((uintptr_t)packed_dev & 15u))
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "comm_all_gather_packed: bad arguments");
+  if (block_bytes)
+    *block_bytes = 0;
+  if (slots_per_rank == 0)
+    return 0;
+  const size_t slots = (size_t)slots_per_rank, total = slots * (size_t)c->world;
+  int rc = rccl_check(g_rccl.AllGather(len_dev + (size_t)c->rank * slots, len_dev, slots * sizeof(uint32_t), RCCL_UINT8,
+                                       c->comm, (hipStream_t)stream),
+                      "ncclAllGather(lengths)");
+  if (rc)
+    return rc;
+  uint32_t *lens = len_host ? len_host : (uint32_t *)malloc(total * sizeof(uint32_t));
+  if (!lens)
+    return achip_fail(ASCIICHAT_HIP_ERR_MEMORY, "out of memory");
+  rc = achip_hip_check((int)hipMemcpyAsync(lens, len_dev, total * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream),
+                       "hipMemcpyAsync(lengths)");
+  if (!rc)
+    rc = achip_hip_check((int)hipStreamSynchronize((hipStream_t)stream), "hipStreamSynchronize");
+  size_t block = 0;
+  if (!rc) {
+    for (int r = 0; r < c->world; r++) { /* every rank computes the same table */
+      size_t b = 0;
+      for (size_t i = 0; i < slots; i++) {
+        const uint32_t l = lens[(size_t)r * slots + i];
+        b += l >= 0xFFFFFFF0u ? 0u : ((size_t)l + 15u) & ~(size_t)15;
+      }
+      if (b > block)
+        block = b;
+    }
+    if (block == 0)
+      block = 16; /* an all-gather of nothing is still a well-formed exchange */
+    if (block > packed_capacity_per_rank)
+      rc = achip_fail(ASCIICHAT_HIP_ERR_BUFFER, "comm_all_gather_packed: a rank's block needs %zu bytes, capacity is %zu", block,
+                      packed_capacity_per_rank);
+  }
+  if (!rc) {
+    for (int r = 0; r < c->world; r++) {
+      size_t o = (size_t)r * block;
+      for (size_t i = 0; i < slots; i++) {
+        const uint32_t l = lens[(size_t)r * slots + i];
+        off_host[(size_t)r * slots + i] = o;
+        o += l >= 0xFFFFFFF0u ? 0u : ((size_t)l + 15u) & ~(size_t)15;
+      }
+    }
+    rc = asciichat_hip_pack_frames(slab_dev + (size_t)c->rank * slots * stride, stride, len_dev + (size_t)c->rank * slots,
+                                   slots_per_rank, packed_dev + (size_t)c->rank * block, block, NULL, NULL, stream);
+  }
+  if (!rc)
+    rc = rccl_check(g_rccl.AllGather(packed_dev + (size_t)c->rank * block, packed_dev, block, RCCL_UINT8, c->comm,
+                                     (hipStream_t)stream),
+                    "ncclAllGather(packed)");
+  if (!len_host)
+    free(lens);
+  if (!rc && block_bytes)
+    *block_bytes = block;
+  return rc;
 }
 
 /* ------------------------------------------------------------------------------------------- */

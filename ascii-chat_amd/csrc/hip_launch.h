@@ -41,6 +41,11 @@ int achip_launch_tint(uint8_t *px, int w, int h, int stride, uint32_t ops, void 
 int achip_launch_flip(const uint8_t *src, uint8_t *dst, int w, int h, int src_stride, int dst_stride, uint32_t ops,
                       void *stream);
 
+/* compacted copy of a slab: frame i -> dst + off[i], off[i] = sum_{j<i} round16(len[j]); off_out (n + 1 entries, [n] =
+ * total) and len_out (n) may be NULL; dst / off_out / len_out may be device memory or mapped pinned host memory */
+int achip_launch_pack(const uint8_t *slab, uint64_t stride, const uint32_t *len_dev, int n, uint8_t *dst,
+                      uint64_t dst_capacity, uint64_t *off_out, uint32_t *len_out, void *stream);
+
 /* wire stage (crc_kernels.hpp): CRC-32C of n buffers at base + i*stride (len_dev[i] bytes, or fixed_len when
  * len_dev == NULL; every length <= max_len) and, when hdr_out != NULL, the 24-byte ascii_frame_packet_t headers
  * (dims_dev = n x {width, height}) and the CRC of header || frame.  partial: n * achip_crc_parts(max_len) u32 of

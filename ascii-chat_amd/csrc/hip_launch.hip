@@ -225,6 +225,27 @@ extern "C" int achip_launch_flip(const uint8_t *src, uint8_t *dst, int w, int h,
   return (int)hipGetLastError();
 }
 
+/* compaction of a rendered slab (stream_kernels.hpp: pack_frames_kernel).  Workgroups per frame: enough slices that the
+ * launch has a few workgroups per CU whatever the batch size, never slices below 4 KB */
+extern "C" int achip_launch_pack(const uint8_t *slab, uint64_t stride, const uint32_t *len_dev, int n, uint8_t *dst,
+                                 uint64_t dst_capacity, uint64_t *off_out, uint32_t *len_out, void *stream) {
+  if (n <= 0)
+    return (int)hipSuccess;
+  if (n > 65535 * 16)
+    return (int)hipErrorInvalidValue;
+  unsigned slices = (unsigned)((1024 + n - 1) / n);
+  const unsigned max_slices = (unsigned)((stride + 4095u) / 4096u);
+  if (slices > max_slices)
+    slices = max_slices;
+  if (slices < 1u)
+    slices = 1u;
+  if (slices > 64u)
+    slices = 64u;
+  hipLaunchKernelGGL(achip::pack_frames_kernel, dim3((unsigned)n, slices), dim3(256), 64, static_cast<hipStream_t>(stream),
+                     slab, stride, len_dev, n, dst, dst_capacity, off_out, len_out);
+  return (int)hipGetLastError();
+}
+
 /* CRC-32C of n buffers + optional wire headers (crc_kernels.hpp).  Buffers up to 128 KB are checksummed by one
  * workgroup each, which also finishes them; larger ones are cut into 64 KB spans and finished by a second
  * kernel, which needs `partial` = n * achip_crc_parts(max_len) u32 of device scratch. */

@@ -793,6 +793,56 @@ int asciichat_hip_frame_packets(const uint8_t *base_dev, size_t stride, const ui
                     stream);
 }
 
+/* ---- compacted output (lib/network/acip/server.c:190-222 ships frame_size bytes, not a stride) ------------- */
+int asciichat_hip_pack_frames(const uint8_t *slab_dev, size_t stride, const uint32_t *len_dev, int n, uint8_t *dst,
+                              size_t dst_capacity, uint64_t *off_out, uint32_t *len_out, void *stream) {
+  if (!slab_dev || !len_dev || !dst || n <= 0 || ((uintptr_t)slab_dev & 15u) || (stride & 15u) || ((uintptr_t)dst & 15u) ||
+      ((uintptr_t)off_out & 7u) || ((uintptr_t)len_out & 3u))
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM,
+                      "pack_frames: bad arguments (slab, stride and dst 16-byte aligned, offsets 8-byte aligned)");
+  int rc = achip_require_device();
+  if (rc)
+    return rc;
+  return achip_hip_check(achip_launch_pack(slab_dev, (uint64_t)stride, len_dev, n, dst, (uint64_t)dst_capacity, off_out,
+                                           len_out, stream),
+                         "pack launch");
+}
+
+int asciichat_hip_plan_render_packed(asciichat_hip_plan_t *p, uint8_t *slab_dev, size_t out_stride, uint32_t *out_len_dev,
+                                     uint8_t *dst, size_t dst_capacity, uint64_t *off_out, uint32_t *len_out, void *stream) {
+  int rc = asciichat_hip_plan_render(p, slab_dev, out_stride, out_len_dev, stream);
+  if (!rc)
+    rc = asciichat_hip_pack_frames(slab_dev, out_stride, out_len_dev, p->n, dst, dst_capacity, off_out, len_out, stream);
+  return rc;
+}
+
+/* pinned host memory that kernels can address (the packed output's destination on the host side of PCIe) */
+int asciichat_hip_host_alloc(size_t bytes, void **host_ptr, void **device_alias) {
+  if (!host_ptr || !device_alias || bytes == 0)
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "host_alloc: bad arguments");
+  *host_ptr = *device_alias = NULL;
+  int rc = achip_require_device();
+  if (rc)
+    return rc;
+  void *h = NULL, *d = NULL;
+  rc = achip_hip_check((int)hipHostMalloc(&h, bytes, hipHostMallocMapped | hipHostMallocPortable), "hipHostMalloc(mapped)");
+  if (!rc)
+    rc = achip_hip_check((int)hipHostGetDevicePointer(&d, h, 0), "hipHostGetDevicePointer");
+  if (rc) {
+    if (h)
+      (void)hipHostFree(h);
+    return rc;
+  }
+  *host_ptr = h;
+  *device_alias = d;
+  return 0;
+}
+
+void asciichat_hip_host_free(void *host_ptr) {
+  if (host_ptr)
+    (void)hipHostFree(host_ptr);
+}
+
 void asciichat_hip_free(void *dev_ptr) {
   if (dev_ptr)
     (void)hipFree(dev_ptr);

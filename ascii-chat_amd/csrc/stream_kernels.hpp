@@ -131,4 +131,72 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+
+/* ------------------------------------------------------------------------------------------- */
+/* Compaction of a rendered slab ("prefer gathering compacted per-rank buffers ... lengths first").  The     */
+/* render kernels leave frame i at slab + i*stride (stride = the worst case: 44.5 KB for 80x24 truecolor, where real    */
+/* video is 2-4 KB); what a consumer on the other side of PCIe or xGMI wants is the bytes that are used -- the reference */
+/* ships exactly frame_size bytes per client (lib/network/acip/server.c:190-222).  Frame i goes to                      */
+/* dst + off[i], off[i] = sum over j < i of round16(len[j]): frame starts stay 16-byte aligned, so every byte moves in  */
+/* uint4 accesses (<= 15 bytes of padding per frame).  dst may be device memory or PINNED HOST memory mapped into the   */
+/* device: the kernel's stores then ARE the transfer -- exact length, no second DMA, no host round trip for a size.     */
+/* Workgroup (i, y) handles slice y of frame i; every workgroup recomputes the prefix it needs from len[] (n <= a few   */
+/* thousand L2-resident words), so there is no inter-workgroup hand-off.  A frame whose length is a render error code   */
+/* (>= 0xFFFFFFF0) takes no room.  A frame that would end beyond dst_capacity is not copied (the caller sees            */
+/* off[n] > dst_capacity).                                                                                              */
+/* ------------------------------------------------------------------------------------------- */
+__device__ inline uint32_t pack_len_ok(uint32_t l) { return l >= 0xFFFFFFF0u ? 0u : l; }
+
+__global__ void __launch_bounds__(256)
+    pack_frames_kernel(const uint8_t *__restrict__ slab, uint64_t stride, const uint32_t *__restrict__ len, int n,
+                       uint8_t *__restrict__ dst, uint64_t dst_capacity, uint64_t *__restrict__ off_out,
+                       uint32_t *__restrict__ len_out) {
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = (int)blockIdx.x;
+  uint32_t *wsum = lds_ptr<uint32_t>(0); /* 4 wave totals x {below i, all} in units of 16 bytes */
+  /* 16-byte groups in front of frame i, and (workgroup (n-1, 0) only needs it) of the whole slab */
+  uint32_t below = 0, all = 0;
+  for (int j = tid; j < n; j += 256) {
+    const uint32_t g = (pack_len_ok(len[j]) + 15u) >> 4;
+    below += j < i ? g : 0u;
+    all += g;
+  }
+  below = wave_read_lane(wave_inclusive_scan(below), 63);
+  all = wave_read_lane(wave_inclusive_scan(all), 63);
+  if (lane == 0) {
+    wsum[wave] = below;
+    wsum[4 + wave] = all;
+  }
+  __syncthreads();
+  const uint64_t off = 16ull * ((uint64_t)wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+  const uint64_t total = 16ull * ((uint64_t)wsum[4] + wsum[5] + wsum[6] + wsum[7]);
+  const uint32_t l = pack_len_ok(len[i]);
+  if (blockIdx.y == 0 && tid == 0) {
+    if (off_out) {
+      off_out[i] = off;
+      if (i == n - 1)
+        off_out[n] = total;
+    }
+    if (len_out)
+      len_out[i] = len[i]; /* error codes travel as they are */
+  }
+  if (off + l > dst_capacity)
+    return;
+  /* slice y of the frame's 16-byte groups; the last group may carry up to 15 stale bytes of the slot behind the frame's
+   * end (the slot is stride >= round16(len) wide), which the padding rule allows */
+  const uint32_t groups = (l + 15u) >> 4;
+  const uint32_t per = (groups + gridDim.y - 1u) / gridDim.y;
+  const uint32_t g0 = blockIdx.y * per, g1 = min(groups, g0 + per);
+  const uint4 *src4 = reinterpret_cast<const uint4 *>(slab + (uint64_t)i * stride);
+  uint4 *dst4 = reinterpret_cast<uint4 *>(dst + off);
+  uint32_t g = g0 + (uint32_t)tid;
+  for (; g + 256u < g1; g += 512u) { /* two groups per trip: both loads in flight */
+    const uint4 a = src4[g], b = src4[g + 256u];
+    dst4[g] = a;
+    dst4[g + 256u] = b;
+  }
+  if (g < g1)
+    dst4[g] = src4[g];
+}
+
 } // namespace achip

@@ -396,7 +396,7 @@ def run_grid9(torch, pkg, steps, regions, targets=256, dist=None, world=1, rank=
                  "roofline_GBps": alg / (g * 1e-3) / 1e9, "roofline_frac": alg / (g * 1e-3) / 1e9 / HBM_PEAK_GBS,
                  "kernel_variant": plan.variant, "bands_per_frame": plan.parts, "targets_per_rank": nt,
                  "collective": "ncclAllGather of the composite tiles inside every step (C-ABI, comm.c)" if comm else "none (gloo run)",
-                 "sources_owned_by_rank0": len(own)}
+                 "sources_owned_by_rank0": len(own), "rccl_ranks": comm.count if comm else None}
         if rank == 0 and world == 1:  # the composite every rank renders from is the oracle's, byte for byte
             allsrc = [np.ascontiguousarray(make_frames(torch, 1, sw, sh, 4321 + k)[0].cpu().numpy()) for k in range(n)]
             exp = orc.convert_with_caps(orc.composite(allsrc, tw, th), tw, th, 3, 0, True, True, False)
@@ -544,6 +544,130 @@ def committed_profile(workload):
     return ent
 
 
+def maybe_spawn_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: become N ranks, one per GPU, under
+    torch.distributed.run (the reference's model is one render thread per client, src/server/render.c:1233; here one
+    process per GPU).  Fails loudly when fewer than N devices are visible.  Under a launcher (WORLD_SIZE set) the flag
+    must agree with the world the launcher made."""
+    backend = os.environ.get("ASCIICHAT_BENCH_BACKEND", "nccl")
+    if "WORLD_SIZE" in os.environ:
+        if int(os.environ["WORLD_SIZE"]) != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher created WORLD_SIZE={os.environ['WORLD_SIZE']} rank(s)")
+        return
+    if args.gpus <= 1:
+        return
+    import socket
+
+    import torch
+
+    have = torch.cuda.device_count()
+    if backend == "nccl" and have < args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} needs {args.gpus} HIP devices, {have} visible (one process per GPU; "
+                         "RCCL refuses two ranks on one device)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
+def rank_comm(torch, pkg, dist, world, rank, backend):
+    """The C-ABI's RCCL communicator over the ranks of this run (comm.c), its unique id broadcast through
+    torch.distributed.  None for a single rank or a gloo test run."""
+    if world <= 1 or backend != "nccl":
+        return None
+    uid = torch.zeros(pkg.COMM_ID_BYTES, dtype=torch.uint8, device="cuda")
+    if rank == 0:
+        uid.copy_(torch.frombuffer(bytearray(pkg.comm_unique_id()), dtype=torch.uint8))
+    dist.broadcast(uid, 0)
+    return pkg.Comm(world, rank, bytes(uid.cpu().numpy()))
+
+
+def gather_leg(torch, pkg, comm, plan, batch, world, rank, reps=10):
+    """What a consumer that needs every rank's frames pays: this rank's rendered block all-gathered through
+    comm.c, once at the fixed slab stride and once compacted (lengths first, then max-over-ranks packed bytes)."""
+    st = torch.cuda.current_stream().cuda_stream
+    stride = plan.stride
+    slab = torch.zeros(world * batch * stride, dtype=torch.uint8, device="cuda")
+    ln = torch.zeros(world * batch, dtype=torch.int32, device="cuda")
+    packed = torch.zeros(world * batch * stride, dtype=torch.uint8, device="cuda")
+    mine, mylen = slab.data_ptr() + rank * batch * stride, ln.data_ptr() + 4 * rank * batch
+    out = {}
+    for kind in ("fixed_stride", "packed"):
+        ts = []
+        for _ in range(reps + 2):
+            plan.render(mine, stride, mylen, st)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            if kind == "packed":
+                off, lens, blk = comm.all_gather_packed(slab.data_ptr(), stride, ln.data_ptr(), batch, packed.data_ptr(),
+                                                        batch * stride, st)
+            else:
+                comm.all_gather_slab(slab.data_ptr(), stride, ln.data_ptr(), batch, st)
+                blk = batch * stride
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        out[kind] = {"ms": statistics.median(ts[2:]) * 1e3, "bytes_per_rank": int(blk), "bytes_total": int(blk) * world}
+    # the two must agree: every frame of every rank, byte for byte
+    host_s, host_p, hl = slab.cpu().numpy(), packed.cpu().numpy(), ln.cpu().numpy().astype("uint32")
+    for i in range(0, world * batch, max(1, world * batch // 64)):
+        a = host_s[i * stride:i * stride + int(hl[i])]
+        b = host_p[off[i]:off[i] + lens[i]]
+        if int(hl[i]) != lens[i] or not (a == b).all():
+            raise RuntimeError(f"all-gather legs disagree on frame {i}")
+    out["frames_compared"] = len(range(0, world * batch, max(1, world * batch // 64)))
+    return out
+
+
+def time_with_d2h_packed(torch, pkg, plans, n, steps, lanes=2):
+    """The PCIe-inclusive rate with exact-length transfers: render, then the pack kernel writes the frames in use (and their
+    offset / length tables) straight into mapped pinned host memory -- its stores are the transfer.  `lanes` batches in
+    flight on separate streams so that one batch's render hides behind another's PCIe time.  After the run the host-side
+    bytes of the last step are compared with a device-side render."""
+    stride = plans[0].stride
+    tab = (8 * (n + 1) + 4 * n + 15) // 16 * 16
+    st = [torch.cuda.current_stream()] + _LANE_POOL[:lanes - 1]
+    while len(st) < lanes:
+        _LANE_POOL.append(torch.cuda.Stream())
+        st.append(_LANE_POOL[-1])
+    slabs = [torch.empty(n * stride, dtype=torch.uint8, device="cuda") for _ in range(lanes)]
+    lns = [torch.zeros(n, dtype=torch.int32, device="cuda") for _ in range(lanes)]
+    hbs = [pkg.HostBuffer(tab + n * stride) for _ in range(lanes)]
+
+    def step(k):
+        l, p = k % lanes, plans[(k % lanes) + lanes * ((k // lanes) % (len(plans) // lanes))]
+        p.render_packed(slabs[l].data_ptr(), stride, lns[l].data_ptr(), hbs[l].dev + tab, n * stride, hbs[l].dev,
+                        hbs[l].dev + 8 * (n + 1), st[l].cuda_stream)
+
+    for k in range(4 * lanes):
+        step(k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step(k)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    import numpy as np
+    last = (steps - 1) % lanes
+    v = hbs[last].view()
+    off = v[:8 * (n + 1)].view(np.uint64)
+    ln = v[8 * (n + 1):8 * (n + 1) + 4 * n].view(np.uint32)
+    dev_slab, dev_len = slabs[last].cpu().numpy(), lns[last].cpu().numpy().astype("uint32")
+    for i in range(0, n, max(1, n // 16)):
+        if int(ln[i]) != int(dev_len[i]) or not (v[tab + int(off[i]):tab + int(off[i]) + int(ln[i])] ==
+                                                  dev_slab[i * stride:i * stride + int(ln[i])]).all():
+            raise SystemExit(f"bench.py: packed host copy of frame {i} differs from the device slab")
+    total = int(off[n])
+    for hb in hbs:
+        hb.close()
+    return {"ms_per_step": dt * 1e3, "frames_per_s": n / dt, "bytes_over_pcie_per_step": total + tab,
+            "GBps": (total + tab) / dt / 1e9, "fixed_stride_bytes_per_step": n * stride + 4 * n, "lanes": lanes,
+            "note": "render + pack kernel storing the bytes in use (16-byte aligned frame starts) and the offset / length "
+                    "tables straight into mapped pinned host memory; no DMA, no host round trip for a size"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -571,6 +695,7 @@ def main():
     ap.add_argument("--no-hot", action="store_true",
                     help="skip the one-launch-at-a-time / same-batch comparison legs (profiling runs)")
     args = ap.parse_args()
+    maybe_spawn_ranks(args)
     # stdout carries ONE line, the JSON: libraries that print to the process's stdout on their own (RCCL's version
     # banner, through C stdio, flushed at exit) go to stderr instead -- fd 1 is pointed at fd 2 until the line is printed
     sys.stdout.flush()
@@ -613,13 +738,16 @@ def main():
             d.init_process_group(backend)
         dist = d
 
+    if world > 1 and backend == "nccl" and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: {world} ranks but {torch.cuda.device_count()} HIP device(s) visible")
     if args.workload == "grid9":
         g = run_grid9(torch, pkg, args.steps, regions, args.batch, dist, world, rank, backend)
         e = g[f"{args.batch}_targets"]
         if rank == 0:
             emit({
                 "metric": "frames/sec, nine 1080p sources -> 3x3 grid at 160x48 truecolor, one frame per target client",
-                "value": e["frames_per_s"], "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": 5,
+                "value": e["frames_per_s"], "unit": "frames/s", "n_gpus": world, "rccl_ranks": e.get("rccl_ranks"),
+                "steps": args.steps, "warmup": 5,
                 "ms_per_step": e["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "u8", "data": "synthetic (nine uniform-random 1080p RGB24 sources, resident in HBM on their owner rank)",
                 "config": {"workload": "grid9", "targets_per_gpu": args.batch, "sources": 9, "grid": "160x48",
@@ -637,11 +765,28 @@ def main():
                        aspect=args.aspect, serial_leg=not args.no_hot,
                        streams_auto=(1, 2, 3, 4) if args.streams == 0 and world == 1 else None)
     walls = res["walls"]
+    per_rank_fps, multi = None, None
     if dist is not None:  # MAX over ranks of every region's wall time
-        t = torch.tensor(walls, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        devt = "cuda" if backend == "nccl" else "cpu"
+        mine = torch.tensor([args.batch * args.steps / statistics.median(walls)], dtype=torch.float64, device=devt)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank_fps = [float(v.item()) for v in allr]
+        t = torch.tensor(walls, dtype=torch.float64, device=devt)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         walls = [float(v) for v in t.tolist()]
         res["walls"] = walls
+        # the C-ABI's own communicator over these ranks (comm.c): how many ranks RCCL sees, and what gathering every
+        # rank's frames costs -- outside the timed regions (the metric's path has no collective)
+        multi = {"torch_distributed_backend": backend, "per_rank_frames_per_s": per_rank_fps}
+        try:
+            comm = rank_comm(torch, pkg, dist, world, rank, backend)
+            if comm is not None:
+                multi["rccl_ranks"] = comm.count
+                multi["all_gather_of_rendered_frames"] = gather_leg(torch, pkg, comm, res["plans"][0], args.batch, world, rank)
+                comm.close()
+        except Exception as e:  # never lose the timing line to the optional leg
+            multi["error"] = str(e)[:300]
     wall = statistics.median(walls)
     main_d = summarize(res, world, wall)
     sw, sh, W, H, cl, rm = WORKLOADS[args.workload]
@@ -676,6 +821,9 @@ def main():
         line["timing"]["launches_in_flight_autotune_ms_per_step"] = {str(k): v for k, v in res["streams_autotune"].items()}
     if res["serial"] is not None:
         line["one_launch_at_a_time"] = res["serial"]
+    if multi is not None:
+        line["multi_gpu"] = multi
+        line["rccl_ranks"] = multi.get("rccl_ranks")
     cp = committed_profile(args.workload)
     if cp is not None:
         line["committed_profile"] = cp
@@ -685,6 +833,10 @@ def main():
             line["with_d2h"] = {"ms_per_step": d2h_s * 1e3, "frames_per_s": args.batch / d2h_s,
                                 "copied_bytes_per_step": d2h_bytes, "GBps": d2h_bytes / d2h_s / 1e9,
                                 "note": "whole fixed-stride slab + lengths to pinned host memory after every launch; PCIe-bound"}
+            try:
+                line["with_d2h_packed"] = time_with_d2h_packed(torch, pkg, res["plans"], args.batch, 60)
+            except RuntimeError as e:
+                line["with_d2h_packed"] = {"error": str(e)[:200]}
         if not args.no_wire:
             try:
                 line["wire_stage"] = wire_stage(torch, pkg, res)
@@ -712,6 +864,11 @@ def main():
             print(f"[bench] {name} {kind} aspect={aspect}: {time.perf_counter() - t_w:.1f} s", file=sys.stderr)
             key = name + ("" if kind == "noise" else f"+{kind}") + ("+aspect_pad" if aspect else "")
             others[key] = summarize(r)
+            if kind in ("bars", "gray") and not args.no_d2h:  # low-entropy video: where exact-length transfers pay most
+                try:
+                    others[key]["with_d2h_packed"] = time_with_d2h_packed(torch, pkg, r["plans"], b, 60)
+                except RuntimeError as e:
+                    others[key]["with_d2h_packed"] = {"error": str(e)[:200]}
             free_workload(torch, r)
         if args.others:
             others["grid9_1080p_160x48_truecolor"] = run_grid9(torch, pkg, 20, 5)

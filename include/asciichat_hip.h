@@ -210,6 +210,26 @@ int asciichat_hip_frame_packets(const uint8_t *base_dev, size_t stride, const ui
                                 uint32_t *packet_crc_out_dev, void *stream);
 
 /*
+ * Compacted output (SURVEY.md 8e "prefer gathering compacted per-rank buffers ... lengths first").  A render leaves frame
+ * i at slab + i*stride, stride = the worst case (44.5 KB for 80x24 truecolor; real video is 2-4 KB per frame).  What
+ * crosses PCIe or xGMI should be the bytes in use -- the reference ships exactly frame_size bytes per client
+ * (lib/network/acip/server.c:190-222).  pack_frames copies frame i to dst + off[i], off[i] = sum over j < i of
+ * round16(len[j]) (frame starts stay 16-byte aligned: <= 15 bytes of padding per frame); frames whose length is a render
+ * error code take no room.  off_out (n + 1 entries; [n] = total bytes) and len_out (n, copy of the lengths) may be NULL.
+ * dst, off_out and len_out may be device memory or the device alias of mapped pinned host memory (host_alloc below): the
+ * kernel's stores are then the transfer itself -- exact length, no second DMA, no host round trip to learn a size.  A
+ * frame that would end beyond dst_capacity is not copied (off_out[n] > dst_capacity tells).  plan_render_packed =
+ * plan_render + pack_frames on the same stream.
+ */
+int asciichat_hip_pack_frames(const uint8_t *slab_dev, size_t stride, const uint32_t *len_dev, int n, uint8_t *dst,
+                              size_t dst_capacity, uint64_t *off_out, uint32_t *len_out, void *stream);
+int asciichat_hip_plan_render_packed(asciichat_hip_plan_t *plan, uint8_t *slab_dev, size_t out_stride,
+                                     uint32_t *out_len_dev, uint8_t *dst, size_t dst_capacity, uint64_t *off_out,
+                                     uint32_t *len_out, void *stream);
+int asciichat_hip_host_alloc(size_t bytes, void **host_ptr, void **device_alias);
+void asciichat_hip_host_free(void *host_ptr);
+
+/*
  * Multi-GPU (comm.c): one process per GPU, RCCL over xGMI (librccl is dlopen'ed on first use).
  * Frames are independent, so the render path needs no collective -- a batch is partitioned over the ranks
  * (achip_shard_bounds, balanced and contiguous) and every rank renders its block.  Collectives exist where a consumer
@@ -232,11 +252,25 @@ int asciichat_hip_comm_unique_id(void *id_out, size_t id_bytes);
 int asciichat_hip_comm_init(asciichat_hip_comm_t **comm, int world, int rank, const void *id, size_t id_bytes);
 int asciichat_hip_comm_world(const asciichat_hip_comm_t *comm);
 int asciichat_hip_comm_rank(const asciichat_hip_comm_t *comm);
+int asciichat_hip_comm_count(const asciichat_hip_comm_t *comm); /* ncclCommCount of the communicator; -1 on error */
 void asciichat_hip_comm_destroy(asciichat_hip_comm_t *comm);
 int asciichat_hip_comm_all_gather(asciichat_hip_comm_t *comm, const void *send_dev, void *recv_dev, size_t bytes_per_rank,
                                   void *stream);
 int asciichat_hip_comm_all_gather_slab(asciichat_hip_comm_t *comm, uint8_t *slab_dev, size_t stride, uint32_t *len_dev,
                                        int slots_per_rank, void *stream);
+/* The same exchange moving only the bytes in use: lengths first (one small in-place all-gather + a host read of them),
+ * then every rank packs its block (pack_frames) and ONE all-gather of max-over-ranks packed bytes moves the blocks.
+ *   slab_dev / len_dev   as for all_gather_slab (this rank's block rendered at slots [rank*slots, ..)); len_dev holds
+ *                        all world*slots lengths afterwards, the slab is NOT gathered
+ *   packed_dev           world * packed_capacity_per_rank bytes; rank r's packed block arrives at r * (*block_bytes)
+ *   off_host             world*slots entries (host): byte offset in packed_dev of every frame after the gather
+ *   len_host             world*slots entries (host, may be NULL): the gathered lengths
+ *   block_bytes          bytes every rank contributed = what crossed the links per rank (max over ranks, multiple of 16)
+ * Synchronises `stream` once (the host must know the sizes).  ERR_BUFFER when a block exceeds the capacity. */
+int asciichat_hip_comm_all_gather_packed(asciichat_hip_comm_t *comm, const uint8_t *slab_dev, size_t stride,
+                                         uint32_t *len_dev, int slots_per_rank, uint8_t *packed_dev,
+                                         size_t packed_capacity_per_rank, uint64_t *off_host, uint32_t *len_host,
+                                         size_t *block_bytes, void *stream);
 /* partition of n independent items: rank's [first, first+count); owner of an item; slots every rank reserves */
 void achip_shard_bounds(int n_items, int world, int rank, int *first, int *count);
 int achip_shard_owner(int n_items, int world, int item);

@@ -62,6 +62,9 @@ def lib():
         _lib.emu_crc_pow.argtypes = [C.c_uint32, C.c_uint64]
         _lib.emu_crc_x8_pow2.restype = C.c_uint32
         _lib.emu_crc_x8_pow2.argtypes = [C.c_int]
+        _lib.emu_pack.restype = None
+        _lib.emu_pack.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p,
+                                  C.c_void_p, C.c_int]
         _lib.emu_composite.restype = None
         _lib.emu_composite.argtypes = [C.POINTER(Composite), C.c_void_p]
     return _lib

@@ -193,6 +193,13 @@ extern "C" void emu_flip(const uint8_t *src, uint8_t *dst, int w, int h, uint32_
     hipemu::launch(dim3(3), dim3(256), 0, [&] { achip::flip_pixels_kernel(src, dst, w, h, 3 * w, 3 * w, ops); });
 }
 
+/* compaction of a slab (stream_kernels.hpp), with the launcher's (n, slices) grid */
+extern "C" void emu_pack(const uint8_t *slab, uint64_t stride, const uint32_t *len, int n, uint8_t *dst, uint64_t cap,
+                         uint64_t *off_out, uint32_t *len_out, int slices) {
+  hipemu::launch(dim3((unsigned)n, (unsigned)slices), dim3(256), 64,
+                 [&] { achip::pack_frames_kernel(slab, stride, len, n, dst, cap, off_out, len_out); });
+}
+
 #include <vector>
 #include "crc_kernels.hpp"
 

@@ -88,3 +88,84 @@ def test_tint_and_flip_kernels_gpu():
             exp = orc.rainbow_replace(orc.display_convert(img, 120, 40, cl, rm, True, True, False, True, 0), t)
             assert got == exp, (mode, t)
             plan.close()
+
+
+# ---- compaction of a rendered slab ("compacted per-rank buffers, lengths first") ------------------------------
+def packed_reference(slab, stride, lens):
+    """off[i] = sum_{j<i} round16(len_ok[j]); frame i's bytes at off[i]"""
+    off, out = [], bytearray()
+    for i, l in enumerate(lens):
+        l = 0 if l >= 0xFFFFFFF0 else int(l)
+        off.append(len(out))
+        out += slab[i * stride:i * stride + l].tobytes()
+        out += bytes((-l) % 16)
+    return off + [len(out)], bytes(out)
+
+
+def test_pack_frames_kernel_emulated():
+    rng = np.random.default_rng(5)
+    for n, stride, slices in ((1, 64, 1), (5, 256, 1), (37, 1024, 3), (300, 128, 2), (3, 16384, 4)):
+        slab = rng.integers(1, 256, n * stride, dtype=np.uint8)
+        lens = rng.integers(0, stride + 1, n).astype(np.uint32)
+        if n > 2:
+            lens[1] = 0xFFFFFFFF  # a frame that overflowed its slot takes no room
+            lens[2] = 0
+        off_ref, bytes_ref = packed_reference(slab, stride, lens)
+        cap = n * stride
+        dst = np.zeros(cap, dtype=np.uint8)
+        off = np.zeros(n + 1, dtype=np.uint64)
+        lo = np.zeros(n, dtype=np.uint32)
+        emu.lib().emu_pack(slab.ctypes.data, stride, lens.ctypes.data, n, dst.ctypes.data, cap, off.ctypes.data,
+                           lo.ctypes.data, slices)
+        assert list(off) == off_ref and np.array_equal(lo, lens), (n, stride)
+        for i in range(n):  # the bytes of every frame (padding bytes are unspecified)
+            l = 0 if lens[i] >= 0xFFFFFFF0 else int(lens[i])
+            assert dst[off_ref[i]:off_ref[i] + l].tobytes() == bytes_ref[off_ref[i]:off_ref[i] + l], (n, stride, i)
+        # a destination that is too small: frames that fit are copied, the total still tells the caller
+        small = int(off_ref[n // 2 + 1]) if n > 1 else 0
+        dst2 = np.zeros(cap, dtype=np.uint8)
+        emu.lib().emu_pack(slab.ctypes.data, stride, lens.ctypes.data, n, dst2.ctypes.data, small, off.ctypes.data, None, slices)
+        assert int(off[n]) == off_ref[n] and not dst2[small:].any()
+
+
+@pytest.mark.gpu
+def test_pack_frames_gpu_device_and_mapped_host_destinations():
+    import torch
+
+    from __graft_entry__ import load_package
+
+    pkg = load_package()
+    torch.cuda.set_device(0)
+    imgs = [orc.frame_hash_noise(192, 108, 70 + i) if i % 4 else orc.frame_bars(192, 108, i) for i in range(40)]
+    dev = [torch.from_numpy(i).cuda() for i in imgs]
+    frames = [pkg.frame_setup(d.data_ptr(), 192, 108, 80, 24, 0, False, False, False) for d in dev]
+    plan = pkg.Plan(pkg.MODE_TRUE_FG, orc.PALETTE_STANDARD, frames)
+    n, stride = len(imgs), plan.stride
+    slab = torch.zeros(n * stride, dtype=torch.uint8, device="cuda")
+    ln = torch.zeros(n, dtype=torch.int32, device="cuda")
+    exp = [orc.convert_with_caps(im, 80, 24, 3, 0, False, False, False) for im in imgs]
+    st = torch.cuda.current_stream().cuda_stream
+    # (a) device destination
+    dst = torch.zeros(n * stride, dtype=torch.uint8, device="cuda")
+    off = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
+    plan.render_packed(slab.data_ptr(), stride, ln.data_ptr(), dst.data_ptr(), dst.numel(), off.data_ptr(), None, st)
+    torch.cuda.synchronize()
+    o, l, d = off.cpu().numpy(), ln.cpu().numpy(), dst.cpu().numpy()
+    assert int(o[n]) == sum((len(e) + 15) // 16 * 16 for e in exp) and int(o[n]) < n * stride // 2
+    for i in range(n):
+        assert int(l[i]) == len(exp[i]) and d[int(o[i]):int(o[i]) + int(l[i])].tobytes() == exp[i], i
+    # (b) mapped pinned host destination: the kernel's stores are the transfer; tables in the same block
+    tab = 8 * (n + 1) + 4 * n
+    tab = (tab + 15) // 16 * 16
+    hb = pkg.HostBuffer(tab + n * stride)
+    hb.view()[:] = 0
+    plan.render_packed(slab.data_ptr(), stride, ln.data_ptr(), hb.dev + tab, n * stride, hb.dev, hb.dev + 8 * (n + 1), st)
+    torch.cuda.synchronize()
+    v = hb.view()
+    o2 = v[:8 * (n + 1)].view(np.uint64)
+    l2 = v[8 * (n + 1):8 * (n + 1) + 4 * n].view(np.uint32)
+    assert np.array_equal(o2, o.astype(np.uint64)) and np.array_equal(l2, l.astype(np.uint32))
+    for i in range(n):
+        assert v[tab + int(o2[i]):tab + int(o2[i]) + int(l2[i])].tobytes() == exp[i], i
+    hb.close()
+    plan.close()
