@@ -104,6 +104,8 @@ def lib():
     L.asciichat_hip_frame_table_destroy.argtypes = [vp]
     L.asciichat_hip_frame_table_publish.restype = ci
     L.asciichat_hip_frame_table_publish.argtypes = [vp, ci, C.c_char_p, C.c_size_t, vp]
+    L.asciichat_hip_frame_table_publish_rows.restype = ci
+    L.asciichat_hip_frame_table_publish_rows.argtypes = [vp, ci, vp, C.c_size_t, C.POINTER(Frame), ci, vp]
     L.asciichat_hip_frame_table_latest.restype = ci
     L.asciichat_hip_frame_table_latest.argtypes = [vp, ci, vp, C.POINTER(vp), C.POINTER(ci), C.POINTER(ci),
                                                    C.POINTER(C.c_uint64)]
@@ -171,6 +173,8 @@ def lib():
     L.asciichat_hip_grid_composite_dev.argtypes = [vp]
     L.asciichat_hip_grid_geometry.restype = C.POINTER(Composite)
     L.asciichat_hip_grid_geometry.argtypes = [vp]
+    L.asciichat_hip_grid_set_direct.restype = ci
+    L.asciichat_hip_grid_set_direct.argtypes = [vp, ci]
     L.asciichat_hip_grid_destroy.restype = None
     L.asciichat_hip_grid_destroy.argtypes = [vp]
     L.asciichat_hip_plan_render_crc.restype = ci
@@ -575,6 +579,13 @@ class Grid:
     def owner(self, source):
         return lib().asciichat_hip_grid_owner(self._h, source)
 
+    def set_direct(self, on):
+        """one GPU: render straight from the sources (no tiles, no resize, no collective); refreshes composite_dev"""
+        rc = lib().asciichat_hip_grid_set_direct(self._h, 1 if on else 0)
+        if rc != 0:
+            raise RuntimeError(f"grid_set_direct failed ({rc}): {last_error()}")
+        self.composite_dev = lib().asciichat_hip_grid_composite_dev(self._h)
+
     def exchange(self, local_ptrs, stream=0):
         """local_ptrs: {source index: device pointer} for the sources this rank owns"""
         arr = (C.c_void_p * self.n)(*[local_ptrs.get(k) for k in range(self.n)])
@@ -598,6 +609,24 @@ class FrameTable:
 
     def publish(self, slot, blob, stream=0):
         rc = lib().asciichat_hip_frame_table_publish(self._h, slot, bytes(blob), len(blob), stream)
+        if rc != 0:
+            raise RuntimeError(f"frame_table_publish failed: {last_error()}")
+
+    def publish_rows(self, slot, blob, targets, stream=0):
+        """publish only the rows that renders described by `targets` (Frame descriptors) will sample; blob: bytes, or
+        (address, size) of a host buffer"""
+        arr = (Frame * len(targets))(*targets)
+        if isinstance(blob, tuple):
+            rc = lib().asciichat_hip_frame_table_publish_rows(self._h, slot, blob[0], blob[1], arr, len(targets), stream)
+        else:
+            b = bytes(blob)
+            rc = lib().asciichat_hip_frame_table_publish_rows(self._h, slot, b, len(b), arr, len(targets), stream)
+        if rc != 0:
+            raise RuntimeError(f"frame_table_publish_rows failed: {last_error()}")
+
+    def publish_at(self, slot, address, size, stream=0):
+        """publish a blob that already sits in host memory at `address` (e.g. a block of the pinned pool)"""
+        rc = lib().asciichat_hip_frame_table_publish(self._h, slot, C.c_char_p(address), size, stream)
         if rc != 0:
             raise RuntimeError(f"frame_table_publish failed: {last_error()}")
 

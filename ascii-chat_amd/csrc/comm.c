@@ -310,6 +310,12 @@ struct asciichat_hip_grid {
   int placed_of[ASCIICHAT_HIP_GRID_MAX_SOURCES]; /* source -> index into geom.s, -1 = no video / beyond the ninth */
   uint8_t *tiles_dev;     /* world * slots * tile_stride bytes: slot of source k = owner(k)*slots + (k - first(owner)) */
   achip_composite_t *comp_dev; /* samples the gathered tiles: identity ratios, tile-sized "sources" */
+  /* direct mode (one GPU): no tiles, no resize launch, no collective -- the render samples the clients' frames themselves
+   * through comp_direct_dev (the reference's geometry with real ratios); a tick only refreshes its nine source pointers */
+  int direct;
+  achip_composite_t *comp_direct_dev;
+  achip_comp_poke_t poked; /* the pointers comp_direct_dev currently holds */
+  int poked_valid;
 };
 
 static size_t grid_slot_of(const asciichat_hip_grid_t *g, int k) {
@@ -373,6 +379,12 @@ int asciichat_hip_grid_create(asciichat_hip_grid_t **grid, asciichat_hip_comm_t 
     }
     rc = asciichat_hip_composite_upload(&c2, &g->comp_dev);
   }
+  if (!rc && g->world == 1) { /* the direct form: sources NULL until the first exchange names them */
+    achip_composite_t c3 = g->geom;
+    for (int k = 0; k < 9; k++)
+      c3.s[k].src = NULL;
+    rc = asciichat_hip_composite_upload(&c3, &g->comp_direct_dev);
+  }
   if (rc) {
     asciichat_hip_grid_destroy(g);
     return rc;
@@ -385,7 +397,22 @@ int asciichat_hip_grid_owner(const asciichat_hip_grid_t *g, int source) {
   return g ? achip_shard_owner(g->n_src, g->world, source) : -1;
 }
 
-const achip_composite_t *asciichat_hip_grid_composite_dev(const asciichat_hip_grid_t *g) { return g ? g->comp_dev : NULL; }
+const achip_composite_t *asciichat_hip_grid_composite_dev(const asciichat_hip_grid_t *g) {
+  return !g ? NULL : g->direct ? g->comp_direct_dev : g->comp_dev;
+}
+
+/* One GPU only: on = render straight from the sources (a tick is a pointer refresh; pays while the targets are few:
+ * every target's workgroups gather from the full-size frames), off = through the resized tiles (one resize per source
+ * and tick, dense samples for every target).  Changes what grid_composite_dev() returns: fetch it again. */
+int asciichat_hip_grid_set_direct(asciichat_hip_grid_t *g, int on) {
+  if (!g)
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "grid_set_direct: bad arguments");
+  if (on && (g->world != 1 || !g->comp_direct_dev))
+    return achip_fail(ASCIICHAT_HIP_ERR_NOT_SUPPORTED, "grid_set_direct: the sources of a %d-rank grid live on other GPUs",
+                      g->world);
+  g->direct = on ? 1 : 0;
+  return 0;
+}
 
 const achip_composite_t *asciichat_hip_grid_geometry(const asciichat_hip_grid_t *g) { return g ? &g->geom : NULL; }
 
@@ -395,6 +422,25 @@ const achip_composite_t *asciichat_hip_grid_geometry(const asciichat_hip_grid_t 
 int asciichat_hip_grid_exchange(asciichat_hip_grid_t *g, const uint8_t *const *local_src_dev, void *stream) {
   if (!g || !local_src_dev)
     return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "grid_exchange: bad arguments");
+  if (g->direct) { /* one GPU: name the sources; nothing to launch when they are the ones already named */
+    achip_comp_poke_t poke;
+    memset(&poke, 0, sizeof(poke));
+    for (int k = 0; k < g->n_src; k++) {
+      if (g->placed_of[k] < 0 || !g->geom.s[g->placed_of[k]].src)
+        continue;
+      if (!local_src_dev[k])
+        return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "grid_exchange: source %d is owned by this rank but NULL", k);
+      poke.src[g->placed_of[k]] = local_src_dev[k];
+    }
+    if (g->poked_valid && memcmp(&poke, &g->poked, sizeof(poke)) == 0)
+      return 0;
+    const int rc = achip_hip_check(achip_launch_comp_poke(g->comp_direct_dev, &poke, stream), "composite pointer launch");
+    if (!rc) {
+      g->poked = poke;
+      g->poked_valid = 1;
+    }
+    return rc;
+  }
   int first = 0, count = 0;
   achip_shard_bounds(g->n_src, g->world, g->rank, &first, &count);
   achip_resize_batch_t batch; /* every tile this rank owns in ONE launch: the tiles are KBs, a launch each costs more */
@@ -437,5 +483,7 @@ void asciichat_hip_grid_destroy(asciichat_hip_grid_t *g) {
     (void)hipFree(g->tiles_dev);
   if (g->comp_dev)
     (void)hipFree(g->comp_dev);
+  if (g->comp_direct_dev)
+    (void)hipFree(g->comp_direct_dev);
   free(g);
 }

@@ -24,6 +24,7 @@
 
 #include "achip_host.h"
 #include "asciichat_hip.h"
+#include "hip_launch.h"
 #include "internal.h"
 
 #define FT_MAX_READERS 32 /* consumer streams remembered per buffer; beyond that a publish synchronises the device */
@@ -39,6 +40,8 @@ typedef struct {
   hipEvent_t ready[2];  /* recorded after the upload of buffer k                      */
   uint8_t *stage[2];    /* pinned staging for blobs that are not in the pinned pool   */
   size_t stage_cap[2];
+  uint8_t *rows_dev[2]; /* publish_rows: device side of the staged [index table][rows] block */
+  size_t rows_cap[2];
   int cur;              /* buffer holding the latest complete frame, -1 = none yet    */
   int w, h;
   uint64_t generation;
@@ -91,13 +94,59 @@ void asciichat_hip_frame_table_destroy(asciichat_hip_frame_table_t *t) {
         (void)hipFree(s->dev[k]);
       if (s->stage[k])
         (void)hipHostFree(s->stage[k]);
+      if (s->rows_dev[k])
+        (void)hipFree(s->rows_dev[k]);
     }
   free(t->slot);
   free(t);
 }
 
+/* the source rows that the targets sample (the sampler's own rule: render_stream.hpp stream_request / render_kernels.hpp
+ * sample_frame_raw -- sy = min((y * y_ratio) >> 16, src_h - 1), mirrored under ACHIP_OP_FLIP_Y), ascending, unique.
+ * Returns their number, or -1 when a target does not describe an h-row source. */
+static int sampled_rows(const achip_frame_t *targets, int n_targets, uint32_t h, uint32_t *rows_out, uint8_t *mark) {
+  memset(mark, 0, h);
+  for (int i = 0; i < n_targets; i++) {
+    const achip_frame_t *f = &targets[i];
+    if (f->comp || (uint32_t)f->src_h != h || f->out_h <= 0)
+      return -1;
+    for (uint32_t y = 0; y < (uint32_t)f->out_h; y++) {
+      uint32_t sy = (uint32_t)(((uint64_t)y * f->y_ratio) >> 16);
+      if (sy > h - 1u)
+        sy = h - 1u;
+      if (f->ops & ACHIP_OP_FLIP_Y)
+        sy = h - 1u - sy;
+      mark[sy] = 1;
+    }
+  }
+  int n = 0;
+  for (uint32_t r = 0; r < h; r++)
+    if (mark[r])
+      rows_out[n++] = r;
+  return n;
+}
+
+static int publish_common(asciichat_hip_frame_table_t *t, int slot, const void *blob, size_t blob_size,
+                          const achip_frame_t *targets, int n_targets, void *stream);
+
 int asciichat_hip_frame_table_publish(asciichat_hip_frame_table_t *t, int slot, const void *blob, size_t blob_size,
                                       void *stream) {
+  return publish_common(t, slot, blob, blob_size, NULL, 0, stream);
+}
+
+/* The same publish moving only the rows that the given targets will sample (138 KB instead of 6.2 MB for 1080p ->
+ * 80x24; collect_video_sources copies the whole blob twice per render thread, src/server/stream.c:221-463).  The frame
+ * buffer keeps the full frame's layout, so descriptors, plans and output bytes are those of a full publish -- for
+ * renders whose (out_h, y_ratio, flip) are among `targets`; any other row of the buffer is stale. */
+int asciichat_hip_frame_table_publish_rows(asciichat_hip_frame_table_t *t, int slot, const void *blob, size_t blob_size,
+                                           const achip_frame_t *targets, int n_targets, void *stream) {
+  if (!targets || n_targets <= 0)
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame_table_publish_rows: no targets");
+  return publish_common(t, slot, blob, blob_size, targets, n_targets, stream);
+}
+
+static int publish_common(asciichat_hip_frame_table_t *t, int slot, const void *blob, size_t blob_size,
+                          const achip_frame_t *targets, int n_targets, void *stream) {
   if (!t || slot < 0 || slot >= t->n || !blob)
     return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame_table_publish: bad arguments");
   uint32_t w = 0, h = 0;
@@ -140,8 +189,55 @@ int asciichat_hip_frame_table_publish(asciichat_hip_frame_table_t *t, int slot, 
   }
   if (!rc && !s->ready[k])
     rc = achip_hip_check((int)hipEventCreateWithFlags(&s->ready[k], hipEventDisableTiming), "hipEventCreate");
+  if (!rc && targets) {
+    /* sampled rows only: [index table][rows] packed into pinned staging by the host, ONE DMA, one scatter launch */
+    const size_t row_bytes = (size_t)w * 3u;
+    uint32_t *rows = (uint32_t *)malloc((size_t)h * sizeof(uint32_t));
+    uint8_t *mark = (uint8_t *)malloc(h);
+    const int n_rows = rows && mark ? sampled_rows(targets, n_targets, h, rows, mark) : -2;
+    free(mark);
+    if (n_rows < 0) {
+      free(rows);
+      pthread_mutex_unlock(&s->mu);
+      return n_rows == -2 ? achip_fail(ASCIICHAT_HIP_ERR_MEMORY, "out of memory")
+                          : achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM,
+                                       "frame_table_publish_rows: a target does not describe this %ux%u frame", w, h);
+    }
+    const size_t table = ((size_t)n_rows * 4u + 15u) & ~(size_t)15;
+    const size_t staged = table + (size_t)n_rows * row_bytes;
+    if (s->stage_cap[k] < staged) {
+      if (s->stage[k])
+        (void)hipHostFree(s->stage[k]);
+      s->stage[k] = NULL;
+      s->stage_cap[k] = 0;
+      rc = achip_hip_check((int)hipHostMalloc((void **)&s->stage[k], staged, hipHostMallocDefault), "hipHostMalloc(stage)");
+      if (!rc)
+        s->stage_cap[k] = staged;
+    }
+    if (!rc && s->rows_cap[k] < staged) {
+      if (s->rows_dev[k])
+        (void)hipFree(s->rows_dev[k]);
+      s->rows_dev[k] = NULL;
+      s->rows_cap[k] = 0;
+      rc = achip_hip_check((int)hipMalloc((void **)&s->rows_dev[k], staged), "hipMalloc(row staging)");
+      if (!rc)
+        s->rows_cap[k] = staged;
+    }
+    if (!rc) {
+      memcpy(s->stage[k], rows, (size_t)n_rows * 4u);
+      for (int r = 0; r < n_rows; r++)
+        memcpy(s->stage[k] + table + (size_t)r * row_bytes, pixels + (size_t)rows[r] * row_bytes, row_bytes);
+      rc = achip_hip_check((int)hipMemcpyAsync(s->rows_dev[k], s->stage[k], staged, hipMemcpyHostToDevice, (hipStream_t)stream),
+                           "hipMemcpyAsync(rows)");
+    }
+    if (!rc)
+      rc = achip_hip_check(achip_launch_scatter_rows(s->rows_dev[k], (uint32_t)n_rows, (uint32_t)row_bytes, s->dev[k],
+                                                     (uint64_t)row_bytes, stream),
+                           "row scatter launch");
+    free(rows);
+  }
   const void *src = pixels;
-  if (!rc && !achip_pool_device_ptr(pixels)) { /* pageable blob: one copy into pinned staging, then DMA */
+  if (!rc && !targets && !achip_pool_device_ptr(pixels)) { /* pageable blob: one copy into pinned staging, then DMA */
     if (s->stage_cap[k] < bytes) {
       if (s->stage[k])
         (void)hipHostFree(s->stage[k]);
@@ -156,7 +252,7 @@ int asciichat_hip_frame_table_publish(asciichat_hip_frame_table_t *t, int slot, 
       src = s->stage[k];
     }
   }
-  if (!rc)
+  if (!rc && !targets)
     rc = achip_hip_check((int)hipMemcpyAsync(s->dev[k], src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream),
                          "hipMemcpyAsync(frame)");
   if (!rc)

@@ -34,6 +34,8 @@ int achip_launch_packets_from_crc(const uint32_t *len_dev, const uint32_t *crc_d
 int achip_launch_resize(const uint8_t *src, int sw, int sh, uint8_t *dst, int dw, int dh, void *stream);
 /* up to ACHIP_RESIZE_BATCH_MAX resizes in ONE launch (src / dst / sizes filled in; the ratios are computed here) */
 int achip_launch_resize_batch(const achip_resize_batch_t *batch, void *stream);
+/* comp_dev->s[k].src = poke->src[k] for k < 9 (stream-ordered, one wave) */
+int achip_launch_comp_poke(achip_composite_t *comp_dev, const achip_comp_poke_t *poke, void *stream);
 int achip_launch_composite(const achip_composite_t *comp_dev, int canvas_w, int canvas_h, uint8_t *dst, void *stream);
 
 /* display-path streaming passes (stream_kernels.hpp); ops as in achip_frame_t.ops */
@@ -45,6 +47,10 @@ int achip_launch_flip(const uint8_t *src, uint8_t *dst, int w, int h, int src_st
  * total) and len_out (n) may be NULL; dst / off_out / len_out may be device memory or mapped pinned host memory */
 int achip_launch_pack(const uint8_t *slab, uint64_t stride, const uint32_t *len_dev, int n, uint8_t *dst,
                       uint64_t dst_capacity, uint64_t *off_out, uint32_t *len_out, void *stream);
+
+/* staged_dev = [n_rows x u32 row index, padded to 16][n_rows x row_bytes]: row i goes to frame_dev + index[i] * frame_pitch */
+int achip_launch_scatter_rows(const uint8_t *staged_dev, uint32_t n_rows, uint32_t row_bytes, uint8_t *frame_dev,
+                              uint64_t frame_pitch, void *stream);
 
 /* wire stage (crc_kernels.hpp): CRC-32C of n buffers at base + i*stride (len_dev[i] bytes, or fixed_len when
  * len_dev == NULL; every length <= max_len) and, when hdr_out != NULL, the 24-byte ascii_frame_packet_t headers

@@ -225,6 +225,28 @@ extern "C" int achip_launch_flip(const uint8_t *src, uint8_t *dst, int w, int h,
   return (int)hipGetLastError();
 }
 
+namespace achip {
+__global__ void __launch_bounds__(64) comp_poke_kernel(achip_composite_t *comp, achip_comp_poke_t poke) {
+  if (threadIdx.x < 9u)
+    comp->s[threadIdx.x].src = poke.src[threadIdx.x];
+}
+} // namespace achip
+extern "C" int achip_launch_comp_poke(achip_composite_t *comp_dev, const achip_comp_poke_t *poke, void *stream) {
+  hipLaunchKernelGGL(achip::comp_poke_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), comp_dev, *poke);
+  return (int)hipGetLastError();
+}
+
+/* rows of a frame, staged behind their index table, to their places in the frame buffer (frame_table_publish_rows) */
+extern "C" int achip_launch_scatter_rows(const uint8_t *staged_dev, uint32_t n_rows, uint32_t row_bytes, uint8_t *frame_dev,
+                                         uint64_t frame_pitch, void *stream) {
+  if (n_rows == 0u)
+    return (int)hipSuccess;
+  const unsigned slices = row_bytes > 16384u ? 4u : row_bytes > 4096u ? 2u : 1u;
+  hipLaunchKernelGGL(achip::scatter_rows_kernel, dim3(slices, n_rows), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     staged_dev, n_rows, row_bytes, frame_dev, frame_pitch);
+  return (int)hipGetLastError();
+}
+
 /* compaction of a rendered slab (stream_kernels.hpp: pack_frames_kernel).  Workgroups per frame: enough slices that the
  * launch has a few workgroups per CU whatever the batch size, never slices below 4 KB */
 extern "C" int achip_launch_pack(const uint8_t *slab, uint64_t stride, const uint32_t *len_dev, int n, uint8_t *dst,

@@ -325,6 +325,8 @@ __host__ __device__ constexpr bool mode_row_reset(int m) {
          m == ACHIP_MODE_HB_256 || m == ACHIP_MODE_HB_16 || m == ACHIP_MODE_16_DITHER_BG;
 }
 
+#define ACHIP_COMP_LDS_BYTES 480 /* achip_composite_t (464 bytes) + the two reciprocals of cell_w / cell_h */
+
 template <int MODE, int BLOCK, int CAP, int RING> struct Lds {
   static constexpr int MASKW = CAP / 64 + 1;
   static constexpr int SEG = CAP / BLOCK; /* cells per thread per chunk */
@@ -343,7 +345,8 @@ template <int MODE, int BLOCK, int CAP, int RING> struct Lds {
                                                      count (multi-part frames), [4] dummy store target */
   static constexpr int o_prof = o_flags + 32;     /* 8 x u64 diagnostics accumulators */
   static constexpr int o_carry = o_prof + 8 * 8;             /* dither: error sums entering the next row, 3 x int per column */
-  static constexpr int bytes = o_carry + (MODE == ACHIP_MODE_16_DITHER_BG ? CAP * 12 : 0);
+  static constexpr int o_comp = o_carry + (MODE == ACHIP_MODE_16_DITHER_BG ? CAP * 12 : 0); /* composite descriptor (COMP launches) */
+  static constexpr int bytes = o_comp + ACHIP_COMP_LDS_BYTES;
   static_assert(SEG * NW <= 64, "wave-total table must fit one wave");
 };
 
@@ -426,10 +429,55 @@ __device__ inline uint32_t sample_composite(const achip_composite_t *__restrict_
   return load_rgb(s->src, s->src_stride, sx, sy, s->src_w * s->src_h == 1);
 }
 
+/* The same sampler with the descriptor in LDS (byte offset O of the kernel's LDS block).  The global version above costs
+ * every sample two integer divisions and a chain of DEPENDENT global loads (c->cell_w -> c->s[idx] -> pixel): three L2
+ * round trips where the single-source sampler has one (r02: 42 G cells/s on the grid against 63-70 G on plain frames).
+ * Here the workgroup copies the 464-byte descriptor into LDS once, in front of its first barrier (comp_stage), together
+ * with the reciprocals of the two cell sizes; a sample is then two multiply-highs, three ds_read_b128 and ONE global
+ * request, returned raw (kind) like every other sample so that nothing waits between requests. */
+static_assert(sizeof(achip_composite_t) == 464 && sizeof(achip_comp_src_t) == 48, "LDS image of the composite descriptor");
+template <int O, int BLOCK> __device__ inline void comp_stage(const achip_composite_t *__restrict__ cgen, int tid) {
+  const ACHIP_GLOBAL uint32_t *g = (const ACHIP_GLOBAL uint32_t *)cgen;
+  for (int k = tid; k < (int)(sizeof(achip_composite_t) / 4u); k += BLOCK)
+    lds_ptr<uint32_t>(O)[k] = g[k];
+  if (tid == 32 || tid == 33) { /* floor(2^32 / d) + 1: X / d == umulhi(X, m) or one less, fixed up by the user */
+    const ACHIP_GLOBAL achip_composite_t *c = (const ACHIP_GLOBAL achip_composite_t *)cgen;
+    const uint32_t d = (uint32_t)(tid == 32 ? c->cell_w : c->cell_h);
+    lds_ptr<uint32_t>(O + (int)sizeof(achip_composite_t))[tid - 32] = d > 1u ? (uint32_t)(0x100000000ull / d) + 1u : 0u;
+  }
+}
+__device__ inline uint32_t div_by_magic(uint32_t x, uint32_t d, uint32_t m) {
+  if (m == 0u) /* d <= 1 */
+    return x;
+  const uint32_t q = __umulhi(x, m); /* floor(x / d) or one more (m overshoots 2^32 / d by less than one unit) */
+  return q * d > x ? q - 1u : q;
+}
+template <int O> __device__ inline uint32_t sample_composite_lds(uint32_t X, uint32_t Y, uint32_t &kind) {
+  const achip_composite_t *c = lds_ptr<const achip_composite_t>(O);
+  const uint32_t *magic = lds_ptr<const uint32_t>(O + (int)sizeof(achip_composite_t));
+  kind = RAW_FINAL;
+  const int col = (int)div_by_magic(X, (uint32_t)c->cell_w, magic[0]), row = (int)div_by_magic(Y, (uint32_t)c->cell_h, magic[1]);
+  if (col >= c->cols || row >= c->rows)
+    return 0u;
+  const int idx = row * c->cols + col;
+  if (idx >= c->n_src)
+    return 0u;
+  const achip_comp_src_t *s = &lds_ptr<const achip_composite_t>(O)->s[idx];
+  const uint8_t *src = s->src;
+  const int lx = (int)X - s->org_x, ly = (int)Y - s->org_y;
+  if (!src || lx < 0 || ly < 0 || lx >= s->tile_w || ly >= s->tile_h)
+    return 0u;
+  uint32_t sx = ((uint32_t)lx * s->x_ratio) >> 16, sy = ((uint32_t)ly * s->y_ratio) >> 16;
+  sx = min(sx, (uint32_t)s->src_w - 1u);
+  sy = min(sy, (uint32_t)s->src_h - 1u);
+  return load_rgb_raw(src, s->src_stride, sx, sy, s->src_w * s->src_h == 1, kind);
+}
+
 /* sample (x, y) of the out_w x out_h resized image that the reference would have built.
  * COMP selects the virtual-composite sampler at compile time (its own kernel instantiation), so the
  * common single-source kernels carry none of its address arithmetic. */
-template <bool COMP>
+/* O_COMP >= 0: the composite descriptor was staged at that LDS offset (comp_stage, behind a barrier) */
+template <bool COMP, int O_COMP = -1>
 __device__ inline uint32_t sample_frame_raw(const achip_frame_t &f, uint32_t x, uint32_t y, uint32_t &kind) {
   uint32_t sx = (x * f.x_ratio) >> 16, sy = (y * f.y_ratio) >> 16;
   sx = min(sx, (uint32_t)f.src_w - 1u);
@@ -438,8 +486,11 @@ __device__ inline uint32_t sample_frame_raw(const achip_frame_t &f, uint32_t x, 
 #if defined(ACHIP_ABLATE) && ACHIP_ABLATE == 3
   return (sx * 2654435761u + sy * 40503u) & 0x00FFFFFFu; /* diagnostics: no memory access */
 #endif
-  if (COMP && f.comp)
+  if (COMP && f.comp) {
+    if (O_COMP >= 0)
+      return sample_composite_lds<(O_COMP >= 0 ? O_COMP : 0)>(sx, sy, kind);
     return sample_composite(f.comp, sx, sy);
+  }
   /* display-path flips folded in (uniform per frame): an index map */
   if (f.ops & ACHIP_OP_FLIP_X)
     sx = (uint32_t)f.src_w - 1u - sx;
@@ -1106,9 +1157,9 @@ __global__ void __launch_bounds__(BLOCK) ACHIP_PIN_OCCUPANCY(MODE, BLOCK)
       const uint32_t r = (uint32_t)(row0 + rr);
       uint32_t kind = RAW_FINAL;
       if (!bottom) {
-        gt[k] = sample_frame_raw<COMP>(f, x, HB ? 2u * r : r, kind);
+        gt[k] = sample_frame_raw<COMP, COMP ? L::o_comp : -1>(f, x, HB ? 2u * r : r, kind);
       } else if (2u * r + 1u < (uint32_t)f.out_h) {
-        gb[k] = sample_frame_raw<COMP>(f, x, 2u * r + 1u, kind);
+        gb[k] = sample_frame_raw<COMP, COMP ? L::o_comp : -1>(f, x, 2u * r + 1u, kind);
       } else {
         kind = RAW_TOP; /* odd height: the last text row's bottom half repeats the top (halfblock.c:81-88) */
       }
@@ -1128,7 +1179,11 @@ __global__ void __launch_bounds__(BLOCK) ACHIP_PIN_OCCUPANCY(MODE, BLOCK)
    * and the table fetch, the LDS set-up and the first barrier all run under their latency */
   /* without request-ahead (512 x 4 geometry) only single-chunk frames do this: with the prologue request in front of
    * it the chunk loop of a multi-chunk frame runs 1.5x slower (4K -> 200x60, profiles/r01_overlap.txt) */
-  const bool pre_issued = PRE_ISSUE && (PREFETCH || row_end - row_begin <= rows_per_chunk);
+  /* (composite frames sample through the LDS copy of their descriptor, staged below: their first requests follow the
+   * prologue's barrier) */
+  const bool pre_issued = PRE_ISSUE && (PREFETCH || row_end - row_begin <= rows_per_chunk) && !(COMP && f.comp);
+  if (COMP && f.comp)
+    comp_stage<L::o_comp, BLOCK>(f.comp, tid);
   if (pre_issued)
     gather_issue(row_begin, (min(row_end, row_begin + rows_per_chunk) - row_begin) * wp);
   /* glyph tables -> LDS */

@@ -66,7 +66,8 @@ template <int MODE, int WAVES, int CPL, bool CRC = false> struct SLds {
   /* CRC instantiations: constant tables, copied from global memory where crc_tables_init_kernel put them -- the 16
    * slicing tables; window tables of the lanes' multipliers; x^(8v), x^(8*256v), x^(8*65536v); x^k (k = 0..62) -- then
    * accumulator, deferred and finished counts */
-  static constexpr int o_tab = o_flags + 32 + 64 * 4;
+  static constexpr int o_comp = o_flags + 32 + 64 * 4; /* composite descriptor of a GENERIC launch (comp_stage) */
+  static constexpr int o_tab = o_comp + ACHIP_COMP_LDS_BYTES;
   static constexpr int o_slice = o_tab;
   static constexpr int o_lanek = o_slice + (CRC ? 16 * 1024 : 0);
   static constexpr int base_crc = o_lanek + (CRC ? 3 * 1024 + 256 + 16 + 2 * ACHIP_STREAM_MAXBLK * 4 : 0);
@@ -144,11 +145,11 @@ struct StreamSrc {
 /* GENERIC = false: the fast sampler -- one unaligned dword per sample with the flips folded into the index, no
  * branches (nothing between two requests waits for memory); requires a single source of >= 2 pixels.
  * GENERIC = true: sample_frame_raw's full repertoire (virtual composite canvas, 1x1 sources). */
-template <bool GENERIC, bool NT>
+template <bool GENERIC, bool NT, int O_COMP>
 __device__ inline uint32_t stream_request(const achip_frame_t &f, const StreamSrc &s, uint32_t x, uint32_t y,
                                           uint32_t &kind) {
   if (GENERIC)
-    return sample_frame_raw<true>(f, x, y, kind);
+    return sample_frame_raw<true, O_COMP>(f, x, y, kind);
   uint32_t sx = min((x * s.xr) >> 16, s.w1), sy = min((y * s.yr) >> 16, s.h1);
   sx = s.flip_x ? s.w1 - sx : sx;
   sy = s.flip_y ? s.h1 - sy : sy;
@@ -403,7 +404,7 @@ __global__ void __launch_bounds__(WAVES * 64)
 #if defined(ACHIP_STREAM_ABLATE) && ACHIP_STREAM_ABLATE == 2 /* diagnostics: no gather */
         raw[k] = ((p.xp * 2654435761u) ^ (p.rr * 40503u) ^ (uint32_t)fidx) & 0x00FFFFFFu;
 #else
-        raw[k] = stream_request<GENERIC, NT>(f, src, p.xp - pad_left, p.rr, kind);
+        raw[k] = stream_request<GENERIC, NT, L::o_comp>(f, src, p.xp - pad_left, p.rr, kind);
 #endif
         kinds |= kind << (2 * k);
       }
@@ -416,7 +417,7 @@ __global__ void __launch_bounds__(WAVES * 64)
         if (cell0 + 64u * k < ncells && p.xp >= pad_left && wants_ext(p, k)) {
           const bool rowstart = p.xp == pad_left;
           uint32_t kd = RAW_FINAL;
-          ext[k] = stream_request<GENERIC, NT>(f, src, rowstart ? (uint32_t)f.out_w - 1u : p.xp - pad_left - 1u,
+          ext[k] = stream_request<GENERIC, NT, L::o_comp>(f, src, rowstart ? (uint32_t)f.out_w - 1u : p.xp - pad_left - 1u,
                                                rowstart ? p.rr - 1u : p.rr, kd);
           kinds |= kd << (2 * (CPL + k));
         }
@@ -436,7 +437,11 @@ __global__ void __launch_bounds__(WAVES * 64)
   pos.rr = cell0 / uwp;
   pos.xp = cell0 - pos.rr * uwp;
   uint32_t raw[CPL], ext[CPL], kinds = 0;
-  if (wave < nblk)
+  /* a composite frame samples through the LDS copy of its descriptor: its first requests follow the barrier */
+  const bool late_first = GENERIC && f.comp != nullptr;
+  if (late_first)
+    comp_stage<L::o_comp, BLOCK>(f.comp, tid);
+  else if (wave < nblk)
     issue_any(cell0, pos, raw, ext, kinds);
   ACHIP_SSTAMP(2);
 
@@ -476,6 +481,8 @@ __global__ void __launch_bounds__(WAVES * 64)
       dst[o] = '\n';
   __syncthreads(); /* the only workgroup barrier */
   ACHIP_SSTAMP(1);
+  if (late_first && wave < nblk)
+    issue_any(cell0, pos, raw, ext, kinds);
 
   const uint32_t stage_off = (uint32_t)(L::o_stage + wave * L::STAGE);
   const uint32_t stage_addr = lds_base_addr() + stage_off;

@@ -199,4 +199,35 @@ __global__ void __launch_bounds__(256)
     dst4[g] = src4[g];
 }
 
+
+/* ------------------------------------------------------------------------------------------- */
+/* Ingest of the SAMPLED rows only (frame_table_publish_rows).  The renderer point-samples out_h of a      */
+/* frame's src_h rows (image.c:293-325): 24 of 1080 for an 80x24 target -- 138 KB of a 6.2 MB frame.  The host packs     */
+/* those rows behind a table of their indices and sends ONE DMA; this kernel puts them where the frame's descriptor       */
+/* expects them (the buffer keeps the full frame's layout, so plans and their output do not change).                      */
+/* staged = [n_rows x u32 row index, padded to 16 bytes][n_rows x row_bytes].  Workgroup (x, r) copies slice x of row r.   */
+/* ------------------------------------------------------------------------------------------- */
+__global__ void __launch_bounds__(256)
+    scatter_rows_kernel(const uint8_t *__restrict__ staged, uint32_t n_rows, uint32_t row_bytes, uint8_t *__restrict__ frame,
+                        uint64_t frame_pitch) {
+  const uint32_t r = blockIdx.y;
+  if (r >= n_rows)
+    return;
+  const uint32_t table = (n_rows * 4u + 15u) & ~15u;
+  const uint32_t row = reinterpret_cast<const uint32_t *>(staged)[r];
+  const uint8_t *src = staged + table + (uint64_t)r * row_bytes;
+  uint8_t *dst = frame + (uint64_t)row * frame_pitch;
+  const uint32_t i0 = blockIdx.x * 256u + threadIdx.x, step = gridDim.x * 256u;
+  if ((((uintptr_t)src | (uintptr_t)dst) & 15u) == 0u) {
+    const uint32_t groups = row_bytes >> 4;
+    for (uint32_t g = i0; g < groups; g += step)
+      reinterpret_cast<uint4 *>(dst)[g] = reinterpret_cast<const uint4 *>(src)[g];
+    for (uint32_t b = (groups << 4) + i0; b < row_bytes; b += step)
+      dst[b] = src[b];
+  } else {
+    for (uint32_t b = i0; b < row_bytes; b += step)
+      dst[b] = src[b];
+  }
+}
+
 } // namespace achip

@@ -342,7 +342,11 @@ def run_grid9(torch, pkg, steps, regions, targets=256, dist=None, world=1, rank=
     ptrs = {k: t.data_ptr() for k, t in src.items()}
     out = {}
     cur = torch.cuda.current_stream()
-    for label, nt in (("nine_targets", 9), (f"{targets}_targets", targets)):
+    legs = [("nine_targets", 9, False), (f"{targets}_targets", targets, False)]
+    if world == 1:  # one GPU: the tick without tiles, resize launch or collective (asciichat_hip_grid_set_direct)
+        legs += [("nine_targets_direct", 9, True), (f"{targets}_targets_direct", targets, True)]
+    for label, nt, direct in legs:
+        grid.set_direct(direct)
         descs = []
         for _ in range(nt):  # every client looks at the same grid (stream.c:790-854: aspect + padding on)
             f = pkg.frame_setup(None, tw, 2 * th, tw, th, 0, True, True, False)
@@ -395,7 +399,8 @@ def run_grid9(torch, pkg, steps, regions, targets=256, dist=None, world=1, rank=
                  "out_bytes_per_frame": float(lens.mean()), "alg_bytes_per_launch": alg,
                  "roofline_GBps": alg / (g * 1e-3) / 1e9, "roofline_frac": alg / (g * 1e-3) / 1e9 / HBM_PEAK_GBS,
                  "kernel_variant": plan.variant, "bands_per_frame": plan.parts, "targets_per_rank": nt,
-                 "collective": "ncclAllGather of the composite tiles inside every step (C-ABI, comm.c)" if comm else "none (gloo run)",
+                 "collective": ("none: plans sample the sources directly, a tick refreshes nine pointers" if direct else
+                                "ncclAllGather of the composite tiles inside every step (C-ABI, comm.c)") if comm else "none (gloo run)",
                  "sources_owned_by_rank0": len(own), "rccl_ranks": comm.count if comm else None}
         if rank == 0 and world == 1:  # the composite every rank renders from is the oracle's, byte for byte
             allsrc = [np.ascontiguousarray(make_frames(torch, 1, sw, sh, 4321 + k)[0].cpu().numpy()) for k in range(n)]

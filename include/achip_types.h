@@ -93,6 +93,11 @@ typedef struct {
   achip_resize_item_t item[ACHIP_RESIZE_BATCH_MAX];
   int32_t n, _pad;
 } achip_resize_batch_t;
+/* new source pointers for the (<= 9) placed tiles of a device-resident composite descriptor, by value in the kernel
+ * arguments of a one-wave launch (the single-GPU grid path: the render samples the clients' frames directly) */
+typedef struct {
+  const uint8_t *src[9];
+} achip_comp_poke_t;
 #define ACHIP_UNIFORM_PALETTE_ASCII 1u /* every glyph of the launch's palette is a single byte < 0x80 */
 /* bits 31..8: cells ((pad_left + out_w) * out_h) of the launch's largest frame, 0 = not stated.  The stream kernel
  * sizes its per-block LDS words from it (a frame with more cells than stated is refused: ACHIP_LEN_BADDESC). */

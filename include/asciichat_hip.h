@@ -185,6 +185,12 @@ int asciichat_hip_frame_table_create(asciichat_hip_frame_table_t **table, int n_
 void asciichat_hip_frame_table_destroy(asciichat_hip_frame_table_t *table);
 int asciichat_hip_frame_table_publish(asciichat_hip_frame_table_t *table, int slot, const void *blob, size_t blob_size,
                                       void *stream);
+/* publish moving only the source rows that renders described by `targets` (their out_h, y_ratio, src_h and the FLIP_Y
+ * bit of ops; src is ignored) will sample: 24 of 1080 rows for an 80x24 target, 138 KB instead of 6.2 MB over PCIe.  The
+ * buffer keeps the full frame's layout, so descriptors, plans and output bytes are those of a full publish for such
+ * renders; rows nobody named are stale. */
+int asciichat_hip_frame_table_publish_rows(asciichat_hip_frame_table_t *table, int slot, const void *blob, size_t blob_size,
+                                           const achip_frame_t *targets, int n_targets, void *stream);
 int asciichat_hip_frame_table_latest(asciichat_hip_frame_table_t *table, int slot, void *consumer_stream,
                                      const uint8_t **pixels_dev, int *width, int *height, uint64_t *generation);
 void asciichat_hip_frame_table_forget_stream(asciichat_hip_frame_table_t *table, void *consumer_stream);
@@ -283,6 +289,12 @@ int asciichat_hip_grid_owner(const asciichat_hip_grid_t *grid, int source); /* r
 int asciichat_hip_grid_exchange(asciichat_hip_grid_t *grid, const uint8_t *const *local_src_dev, void *stream);
 const achip_composite_t *asciichat_hip_grid_composite_dev(const asciichat_hip_grid_t *grid); /* for achip_frame_t.comp */
 const achip_composite_t *asciichat_hip_grid_geometry(const asciichat_hip_grid_t *grid);      /* host copy: canvas size .. */
+/* One GPU (world == 1) only.  on: no tiles, no resize launch, no collective -- plans render straight from the clients'
+ * frames and grid_exchange only refreshes the (<= 9) source pointers of the descriptor (a one-wave launch, or nothing
+ * when they did not change): the whole tick is the render launch.  Pays while the target clients are few (every target's
+ * workgroups then gather from the full-size frames; with hundreds of targets the resized tiles are the better source).
+ * Changes what grid_composite_dev() returns -- fetch it again after switching.  ERR_NOT_SUPPORTED when world > 1. */
+int asciichat_hip_grid_set_direct(asciichat_hip_grid_t *grid, int on);
 void asciichat_hip_grid_destroy(asciichat_hip_grid_t *grid);
 
 /*

@@ -370,8 +370,12 @@ def test_composite_geometry_and_kernel_emulated(pkg):
             f = emu.Frame()
             assert EL.achip_frame_setup(C.byref(f), None, tw, 2 * th, tw, h, rm, True, True, False) == 0
             f.comp = C.addressof(comp)
-            got = emu.render_frames(mode, [f], orc.PALETTE_STANDARD, 2)[0]
-            assert got == orc.convert_with_caps(ref, tw, h, cl, rm, True, True, False), (n, mode)
+            exp = orc.convert_with_caps(ref, tw, h, cl, rm, True, True, False)
+            # the phase kernel (whole frame, and cut into row bands) and the stream kernel's composite instantiations:
+            # all sample through the LDS copy of the descriptor (comp_stage / sample_composite_lds)
+            for variant, rpp in ((2, 0), (2, 5)) + (((20, 0), (17, 0)) if mode == 1 else ()):
+                got = emu.render_frames(mode, [f, f], orc.PALETTE_STANDARD, variant, rows_per_part=rpp)
+                assert got[0] == exp and got[1] == exp, (n, mode, variant, rpp)
 
 
 def test_composite_skips_clients_without_video(pkg):

@@ -702,8 +702,68 @@ def test_rccl_comm_and_grid_exchange_world1(gpu):
                 n = int(l5[i].item())
                 assert bytes(out[i * plan.stride:i * plan.stride + n].cpu().numpy()) == exp, (mode, i, has_video is None)
             plan.close()
+        # the one-GPU direct form: no tiles, no resize, no collective -- plans sample the clients' frames themselves and a
+        # tick only names the sources (asciichat_hip_grid_set_direct); new pointers on the second tick
+        grid.set_direct(True)
+        f = pkg.frame_setup(None, 160, 96, 160, 48, 0, True, True, False)
+        f.comp = grid.composite_dev
+        plan = pkg.Plan(MODE_TRUE_FG, orc.PALETTE_STANDARD, [f] * 9)
+        out = torch.zeros(9 * plan.stride, dtype=torch.uint8, device="cuda")
+        l9 = torch.zeros(9, dtype=torch.int32, device="cuda")
+        rolled = dsrc[1:] + dsrc[:1]
+        for tick, cur in enumerate((dsrc, dsrc, rolled)):
+            grid.exchange({k: cur[k].data_ptr() for k in range(9)}, st)
+            plan.render(out.data_ptr(), plan.stride, l9.data_ptr(), st)
+            torch.cuda.synchronize()
+            cur_np = srcs if tick < 2 else srcs[1:] + srcs[:1]
+            live2 = [s if (has_video is None or has_video[k]) else None for k, s in enumerate(cur_np)]
+            exp = orc.convert_with_caps(orc.composite(live2, 160, 48), 160, 48, 3, 0, True, True, False)
+            for i in (0, 8):
+                n = int(l9[i].item())
+                assert bytes(out[i * plan.stride:i * plan.stride + n].cpu().numpy()) == exp, ("direct", tick, i)
+        plan.close()
         grid.close()
     comm.close()
+
+
+def test_frame_table_publish_rows_uploads_only_sampled_rows(gpu):
+    """frame_table_publish_rows: only the rows that the named targets sample cross PCIe; renders of
+    those targets are byte-identical to the oracle (and to a full publish); two target heights and a flipped target share
+    one publish; odd widths (row pitch not a multiple of 16) take the byte path of the scatter kernel."""
+    import struct
+    pkg, torch = gpu
+    stream = torch.cuda.current_stream().cuda_stream
+    for (w, h) in ((1920, 1080), (333, 201)):
+        img = orc.frame_hash_noise(w, h, 77)
+        blob = struct.pack(">II", w, h) + np.ascontiguousarray(img).tobytes()
+        table = pkg.FrameTable(1)
+        t_a = pkg.frame_setup(None, w, h, 80, 24, 0, False, False, False)         # 80x24 foreground
+        t_b = pkg.frame_setup(None, w, h, 100, 37, 2, True, True, False)          # half-block, aspect + padding
+        t_c = pkg.frame_setup(None, w, h, 80, 24, 0, False, False, False)
+        assert pkg.lib().achip_frame_set_display_ops(C.byref(t_c), False, True, 0) == 0   # flipped vertically
+        for round_ in range(3):  # both buffers of the slot, and a buffer reused
+            table.publish_rows(0, blob, [t_a, t_b, t_c], stream)
+            ptr, pw, ph, gen = table.latest(0, stream)
+            assert (pw, ph) == (w, h)
+            # the rows nobody named are not what the blob holds: count rows that arrived
+            dev_img = torch.empty((h, w, 3), dtype=torch.uint8, device="cuda")
+            assert pkg.lib().asciichat_hip_resize(ptr, w, h, dev_img.data_ptr(), w, h, stream) == 0  # identity: a copy
+            torch.cuda.synchronize()
+            same = (dev_img.cpu().numpy() == img).all(axis=(1, 2))
+            assert 24 <= int(same.sum()) <= 24 + 2 * 37 + 24, int(same.sum())
+            for tmpl, mode, cl, rm, args in ((t_a, 1, 3, 0, (80, 24, False, False)), (t_b, 5, 3, 2, (100, 37, True, True))):
+                f = pkg.Frame.from_buffer_copy(tmpl)
+                f.src = ptr
+                got = render_descs(gpu, mode, [f])[0]
+                assert got == orc.convert_with_caps(img, args[0], args[1], cl, rm, args[2], args[3], False), (w, h, mode, round_)
+            f = pkg.Frame.from_buffer_copy(t_c)
+            f.src = ptr
+            assert render_descs(gpu, 1, [f])[0] == orc.convert_with_caps(orc.flip(img, False, True), 80, 24, 3, 0, False, False, False)
+        # a target that does not describe this frame is refused
+        bad = pkg.frame_setup(None, w, h + 1, 80, 24, 0, False, False, False)
+        with pytest.raises(RuntimeError):
+            table.publish_rows(0, blob, [bad], stream)
+        table.close()
 
 
 def test_frame_table_upload_waits_for_queued_readers(gpu):
