@@ -364,9 +364,11 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
   const bool cell_mode = mode == ACHIP_MODE_256_FG || mode == ACHIP_MODE_16_FG || mode == ACHIP_MODE_TRUE_BG ||
                          (mode == ACHIP_MODE_TRUE_FG && palette_ascii_only);
   const bool stream_forced = forced_variant >= ACHIP_HOST_STREAM_FIRST;
+  /* cells a block owns: 64 per lane slot, minus the ghost slot of truecolor-fg (render_stream.hpp: SLds::EFF) */
+  const int ghost = mode == ACHIP_MODE_TRUE_FG ? 1 : 0;
   if (stream_forced) {
     const int cpl = forced_variant == 19 || forced_variant == 20 ? 1 : 2;
-    if (!cell_mode || forced_variant > 20 || max_cells > (long)ACHIP_HOST_STREAM_MAXBLK * 64 * cpl)
+    if (!cell_mode || forced_variant > 20 || max_cells > (long)ACHIP_HOST_STREAM_MAXBLK * (64 * cpl - ghost))
       return -1;
     *variant = forced_variant;
     return 0; /* whole frames only */
@@ -375,13 +377,13 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
   const bool may_split = mode != ACHIP_MODE_16_DITHER_BG && !(mode == ACHIP_MODE_TRUE_FG && !palette_ascii_only) &&
                          split_request >= 0 && max_rows > 1 && !(split_request == 0 && 4 * n_frames >= 3 * n_cus);
   if (forced_variant < 0 && cell_mode && (!may_split || max_wp > variant_caps[0]) &&
-      max_cells <= (long)ACHIP_HOST_STREAM_MAXBLK * 128) {
+      max_cells <= (long)ACHIP_HOST_STREAM_MAXBLK * (128 - ghost)) {
     /* measured (profiles/r02_stream_sweep.txt): 1024 threads x 2 cells -- one block per wave for a 1080p -> 80x24
      * frame -- is the shortest single launch while every frame has a CU to itself; with more frames than CUs in
      * flight (a large batch, or several launches kept in flight: the caller passes its share of the CUs), or frames
      * of several blocks per wave, 512-thread workgroups pack better (four launches in flight, us per step, 16 vs 17: 1080p -> 80x24 truecolor
      * 10.9 vs 8.2, ANSI-256 7.0 vs 6.6, 4K -> 200x60 equal within noise) */
-    *variant = (max_cells <= 2048 && n_frames <= n_cus) ? 16 : 17;
+    *variant = (max_cells <= 16 * (128 - ghost) && n_frames <= n_cus) ? 16 : 17;
     return 0;
   }
   if (forced_variant >= 0) {

@@ -704,9 +704,11 @@ int asciichat_hip_composite_upload(const achip_composite_t *comp_host, achip_com
   if (rc)
     return rc;
   achip_composite_t *d = NULL;
+  achip_composite_t copy = *comp_host;
+  copy._pad = 0; /* the kernels read this word as the pixel of a sample that hits no tile (sample_composite_lds) */
   rc = achip_hip_check((int)hipMalloc((void **)&d, sizeof(*d)), "hipMalloc(composite)");
   if (!rc)
-    rc = achip_hip_check((int)hipMemcpy(d, comp_host, sizeof(*d), hipMemcpyHostToDevice), "hipMemcpy(composite)");
+    rc = achip_hip_check((int)hipMemcpy(d, &copy, sizeof(*d), hipMemcpyHostToDevice), "hipMemcpy(composite)");
   if (rc) {
     if (d)
       (void)hipFree(d);

@@ -36,6 +36,7 @@
 #pragma once
 
 #include <gfx950_ops.hpp>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "achip_types.h"
@@ -452,25 +453,54 @@ __device__ inline uint32_t div_by_magic(uint32_t x, uint32_t d, uint32_t m) {
   const uint32_t q = __umulhi(x, m); /* floor(x / d) or one more (m overshoots 2^32 / d by less than one unit) */
   return q * d > x ? q - 1u : q;
 }
-template <int O> __device__ inline uint32_t sample_composite_lds(uint32_t X, uint32_t Y, uint32_t &kind) {
+/* the wave-uniform head of the staged descriptor, read ONCE per frame behind the staging barrier and kept in scalar
+ * registers: read per sample, every field was its own dependent LDS round trip in front of the request */
+struct CompHead {
+  uint32_t cell_w, cell_h, cols, rows, n_src, m_w, m_h;
+};
+template <int O> __device__ inline CompHead comp_head() {
   const achip_composite_t *c = lds_ptr<const achip_composite_t>(O);
   const uint32_t *magic = lds_ptr<const uint32_t>(O + (int)sizeof(achip_composite_t));
-  kind = RAW_FINAL;
-  const int col = (int)div_by_magic(X, (uint32_t)c->cell_w, magic[0]), row = (int)div_by_magic(Y, (uint32_t)c->cell_h, magic[1]);
-  if (col >= c->cols || row >= c->rows)
-    return 0u;
-  const int idx = row * c->cols + col;
-  if (idx >= c->n_src)
-    return 0u;
-  const achip_comp_src_t *s = &lds_ptr<const achip_composite_t>(O)->s[idx];
-  const uint8_t *src = s->src;
-  const int lx = (int)X - s->org_x, ly = (int)Y - s->org_y;
-  if (!src || lx < 0 || ly < 0 || lx >= s->tile_w || ly >= s->tile_h)
-    return 0u;
-  uint32_t sx = ((uint32_t)lx * s->x_ratio) >> 16, sy = ((uint32_t)ly * s->y_ratio) >> 16;
-  sx = min(sx, (uint32_t)s->src_w - 1u);
-  sy = min(sy, (uint32_t)s->src_h - 1u);
-  return load_rgb_raw(src, s->src_stride, sx, sy, s->src_w * s->src_h == 1, kind);
+  CompHead h;
+  h.cell_w = (uint32_t)wave_uniform(c->cell_w);
+  h.cell_h = (uint32_t)wave_uniform(c->cell_h);
+  h.cols = (uint32_t)wave_uniform(c->cols);
+  h.rows = (uint32_t)wave_uniform(c->rows);
+  h.n_src = (uint32_t)wave_uniform(c->n_src);
+  h.m_w = (uint32_t)wave_uniform((int)magic[0]);
+  h.m_h = (uint32_t)wave_uniform((int)magic[1]);
+  return h;
+}
+template <int O>
+__device__ inline uint32_t sample_composite_lds(const CompHead &h, const achip_composite_t *__restrict__ cgen, uint32_t X,
+                                                uint32_t Y, uint32_t &kind) {
+  /* Straight-line: every lane runs the same instructions and issues exactly one request; the tile's 48-byte record
+   * comes out of LDS as three 16-byte reads issued together.  A sample that falls outside every tile (the black
+   * margins, empty cells) reads the descriptor's own zero padding word instead of branching around the load. */
+  const uint32_t col = div_by_magic(X, h.cell_w, h.m_w), row = div_by_magic(Y, h.cell_h, h.m_h);
+  const uint32_t idx = __umul24(row, h.cols) + col;
+  const bool in_grid = (col < h.cols) & (row < h.rows) & (idx < h.n_src);
+  const uint4 *t = lds_ptr<const uint4>(O + (int)offsetof(achip_composite_t, s)) + 3u * (in_grid ? idx : 0u);
+  const uint4 q0 = t[0], q1 = t[1], q2 = t[2]; /* {src, src_w, src_h} {stride, -, tile_w, tile_h} {org_x, org_y, xr, yr} */
+  const uint8_t *src = reinterpret_cast<const uint8_t *>((uint64_t)q0.x | ((uint64_t)q0.y << 32));
+  /* unsigned: a sample left of / above the tile wraps to a huge value and fails the same comparison */
+  const uint32_t lx = X - q2.x, ly = Y - q2.y;
+  const bool valid = in_grid & ((q0.x | q0.y) != 0u) & (lx < q1.z) & (ly < q1.w);
+  const uint32_t sx = min((lx * q2.z) >> 16, q0.z - 1u);
+  const uint32_t sy = min((ly * q2.w) >> 16, q0.w - 1u);
+  if (valid && q0.z * q0.w == 1u) { /* a 1x1 source is 3 bytes: no dword to read (practically never taken) */
+    kind = RAW_FINAL;
+    const ACHIP_GLOBAL uint8_t *p = (const ACHIP_GLOBAL uint8_t *)src;
+    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+  }
+  const uint32_t a = sy * q1.x + __umul24(sx, 3u);
+  const uint32_t back = a != 0u ? 1u : 0u;
+  kind = (valid & (back != 0u)) ? RAW_BACK : RAW_FIRST;
+  /* outside: the descriptor's _pad word (zero: achip_composite_setup clears it, composite_upload enforces it),
+   * finished as RAW_FIRST = its low 24 bits */
+  const uint8_t *zero = reinterpret_cast<const uint8_t *>(cgen) + offsetof(achip_composite_t, _pad);
+  const ACHIP_GLOBAL uint8_t *p = (const ACHIP_GLOBAL uint8_t *)(valid ? src + (a - back) : zero);
+  return ((const ACHIP_GLOBAL unaligned_u32 *)p)->v;
 }
 
 /* sample (x, y) of the out_w x out_h resized image that the reference would have built.
@@ -478,7 +508,8 @@ template <int O> __device__ inline uint32_t sample_composite_lds(uint32_t X, uin
  * common single-source kernels carry none of its address arithmetic. */
 /* O_COMP >= 0: the composite descriptor was staged at that LDS offset (comp_stage, behind a barrier) */
 template <bool COMP, int O_COMP = -1>
-__device__ inline uint32_t sample_frame_raw(const achip_frame_t &f, uint32_t x, uint32_t y, uint32_t &kind) {
+__device__ inline uint32_t sample_frame_raw(const achip_frame_t &f, uint32_t x, uint32_t y, uint32_t &kind,
+                                            const CompHead *head = nullptr) {
   uint32_t sx = (x * f.x_ratio) >> 16, sy = (y * f.y_ratio) >> 16;
   sx = min(sx, (uint32_t)f.src_w - 1u);
   sy = min(sy, (uint32_t)f.src_h - 1u);
@@ -488,7 +519,7 @@ __device__ inline uint32_t sample_frame_raw(const achip_frame_t &f, uint32_t x, 
 #endif
   if (COMP && f.comp) {
     if (O_COMP >= 0)
-      return sample_composite_lds<(O_COMP >= 0 ? O_COMP : 0)>(sx, sy, kind);
+      return sample_composite_lds<(O_COMP >= 0 ? O_COMP : 0)>(*head, f.comp, sx, sy, kind);
     return sample_composite(f.comp, sx, sy);
   }
   /* display-path flips folded in (uniform per frame): an index map */
@@ -1141,6 +1172,7 @@ __global__ void __launch_bounds__(BLOCK) ACHIP_PIN_OCCUPANCY(MODE, BLOCK)
    * up to 2*SEG sparse fetches in flight; cell i_k = tid + k*BLOCK (lane <-> consecutive cells) */
   uint32_t gt[SEG], gb[SEG];
   uint32_t gkind = 0; /* 2 bits per sample: top of cell k at bit 2k, bottom at bit 2(SEG+k) */
+  CompHead chead = {}; /* composite frames: filled behind the prologue's barrier, before any request */
   /* request ONE sample of cell k (top, or the half-block bottom row) of the chunk starting at text row row0 */
   auto gather_one = [&](int k, bool bottom, int row0, int cells) {
     const int i = tid + k * BLOCK;
@@ -1157,9 +1189,9 @@ __global__ void __launch_bounds__(BLOCK) ACHIP_PIN_OCCUPANCY(MODE, BLOCK)
       const uint32_t r = (uint32_t)(row0 + rr);
       uint32_t kind = RAW_FINAL;
       if (!bottom) {
-        gt[k] = sample_frame_raw<COMP, COMP ? L::o_comp : -1>(f, x, HB ? 2u * r : r, kind);
+        gt[k] = sample_frame_raw<COMP, COMP ? L::o_comp : -1>(f, x, HB ? 2u * r : r, kind, &chead);
       } else if (2u * r + 1u < (uint32_t)f.out_h) {
-        gb[k] = sample_frame_raw<COMP, COMP ? L::o_comp : -1>(f, x, 2u * r + 1u, kind);
+        gb[k] = sample_frame_raw<COMP, COMP ? L::o_comp : -1>(f, x, 2u * r + 1u, kind, &chead);
       } else {
         kind = RAW_TOP; /* odd height: the last text row's bottom half repeats the top (halfblock.c:81-88) */
       }
@@ -1239,6 +1271,8 @@ __global__ void __launch_bounds__(BLOCK) ACHIP_PIN_OCCUPANCY(MODE, BLOCK)
     }
   }
   __syncthreads();
+  if (COMP && f.comp)
+    chead = comp_head<L::o_comp>();
 
   ACHIP_STAMP(0);
 

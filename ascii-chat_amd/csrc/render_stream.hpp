@@ -56,6 +56,10 @@ __host__ __device__ constexpr int stream_max_token(int m) {
 
 template <int MODE, int WAVES, int CPL, bool CRC = false> struct SLds {
   static constexpr int BLK = 64 * CPL;
+  /* cells a block OWNS.  Truecolor-fg decides its SGR against the raster predecessor (ansi_rle_add_pixel): slot
+   * (k = 0, lane 0) of every block is a ghost that samples the cell in front of the block and owns no token, so that
+   * every cell finds its predecessor one lane down (one DPP move) and no cell needs a second sampler pass. */
+  static constexpr int EFF = BLK - (MODE == ACHIP_MODE_TRUE_FG ? 1 : 0);
   static constexpr int STAGE = BLK * stream_max_token(MODE) + 16; /* + the 16-byte group the block starts in */
   static constexpr int GPL = (STAGE / 16 + 63) / 64; /* 16-byte groups of a block per lane when it is checksummed */
   static constexpr int o_stage = 0;
@@ -147,9 +151,9 @@ struct StreamSrc {
  * GENERIC = true: sample_frame_raw's full repertoire (virtual composite canvas, 1x1 sources). */
 template <bool GENERIC, bool NT, int O_COMP>
 __device__ inline uint32_t stream_request(const achip_frame_t &f, const StreamSrc &s, uint32_t x, uint32_t y,
-                                          uint32_t &kind) {
+                                          uint32_t &kind, const CompHead &head) {
   if (GENERIC)
-    return sample_frame_raw<true, O_COMP>(f, x, y, kind);
+    return sample_frame_raw<true, O_COMP>(f, x, y, kind, &head);
   uint32_t sx = min((x * s.xr) >> 16, s.w1), sy = min((y * s.yr) >> 16, s.h1);
   sx = s.flip_x ? s.w1 - sx : sx;
   sy = s.flip_y ? s.h1 - sy : sy;
@@ -280,6 +284,8 @@ __global__ void __launch_bounds__(WAVES * 64)
   using L = SLds<MODE, WAVES, CPL, CRC>;
   constexpr int BLOCK = WAVES * 64;
   constexpr int BLK = L::BLK;
+  constexpr int SH = BLK - L::EFF; /* 1: slot (k = 0, lane 0) is the ghost of the cell in front of the block */
+  constexpr int EFF = L::EFF;
 
   uint32_t *slots = lds_ptr<uint32_t>(L::o_slots);
 
@@ -340,7 +346,7 @@ __global__ void __launch_bounds__(WAVES * 64)
   const long long cells_ll = (long long)rows * (long long)wp;
   if (f.out_w <= 0 || f.out_h <= 0 || f.src_w <= 0 || f.src_h <= 0 || f.pad_left < 0 || f.pad_top < 0 ||
       (!f.src && !f.comp) || (!GENERIC && (f.comp || f.src_w * f.src_h == 1)) ||
-      cells_ll > (long long)stream_maxblk(uni.flags, BLK) * BLK || out_stride > (uint64_t)ACHIP_STREAM_MAX_STRIDE) {
+      cells_ll > (long long)stream_maxblk(uni.flags, EFF) * EFF || out_stride > (uint64_t)ACHIP_STREAM_MAX_STRIDE) {
     if (tid == 0) {
       out_len[fidx] = ACHIP_LEN_BADDESC;
       if (CRC) {
@@ -355,8 +361,8 @@ __global__ void __launch_bounds__(WAVES * 64)
     return;
   }
   const uint32_t ncells = (uint32_t)cells_ll;
-  const int nblk = (int)((ncells + BLK - 1) / BLK);
-  const int nblk_cap = stream_maxblk(uni.flags, BLK); /* words in each per-block LDS array of this launch */
+  const int nblk = (int)((ncells + EFF - 1) / EFF);
+  const int nblk_cap = stream_maxblk(uni.flags, EFF); /* words in each per-block LDS array of this launch */
   (void)nblk_cap;
   const uint32_t cap_bytes = (uint32_t)out_stride;
   const uint32_t pad_left = (uint32_t)f.pad_left, uwp = (uint32_t)wp;
@@ -373,9 +379,10 @@ __global__ void __launch_bounds__(WAVES * 64)
    * L2; closer samples do share lines and want the cache (profiles/r01_nontemporal.txt) */
   src.nt = f.x_ratio >= ((64u << 16) + 2u) / 3u;
 
+  CompHead chead = {}; /* composite frames: filled behind the barrier, before their first request */
   /* cell -> (row, column) without a division per cell: one division per lane here, then constant steps */
   const uint32_t q64 = 64u / uwp, r64 = 64u - q64 * uwp;                                         /* k -> k+1 */
-  const uint32_t qit = (uint32_t)(WAVES * BLK) / uwp, rit = (uint32_t)(WAVES * BLK) - qit * uwp; /* block -> block + WAVES */
+  const uint32_t qit = (uint32_t)(WAVES * EFF) / uwp, rit = (uint32_t)(WAVES * EFF) - qit * uwp; /* block -> block + WAVES */
   auto advance = [&](CellPos p, uint32_t q, uint32_t r) {
     p.xp += r;
     p.rr += q;
@@ -384,65 +391,55 @@ __global__ void __launch_bounds__(WAVES * 64)
     p.rr += wrap ? 1u : 0u;
     return p;
   };
-  /* truecolor-fg: which cells take their raster predecessor from an extra sample instead of the neighbouring lane --
-   * lane 0 of the block (its predecessor belongs to another wave) and, with left padding, the first pixel cell of
-   * every row (its predecessor is the last pixel of the row above, pad_left cells back) */
-  auto wants_ext = [&](CellPos p, int k) {
-    return p.xp == pad_left ? (p.rr > 0u && (pad_left > 0u || (k == 0 && lane == 0))) : (k == 0 && lane == 0);
-  };
+  /* truecolor-fg, left padding: the pad cell in front of a row's first pixel has nothing to sample for itself and
+   * fetches what that pixel needs instead -- the last pixel of the row above, its raster predecessor */
+  auto pred_pad = [&](CellPos p) { return SH != 0 && pad_left > 0u && p.xp == pad_left - 1u && p.rr > 0u; };
   /* request the samples of the block whose cell (k = 0, this lane) is cell0 at p0: nothing here consumes loaded data */
-  auto issue = [&](auto nt_tag, uint32_t cell0, CellPos p0, uint32_t (&raw)[CPL], uint32_t (&ext)[CPL], uint32_t &kinds) {
+  auto issue = [&](auto nt_tag, uint32_t cell0, CellPos p0, uint32_t (&raw)[CPL], uint32_t &kinds) {
     constexpr bool NT = decltype(nt_tag)::value;
     kinds = 0;
     CellPos p = p0;
 #pragma unroll
     for (int k = 0; k < CPL; k++) {
       raw[k] = 0;
-      ext[k] = 0;
-      if (cell0 + 64u * k < ncells && p.xp >= pad_left) {
+      const bool pixc = p.xp >= pad_left;
+      if (cell0 + 64u * k < ncells && (pixc || pred_pad(p))) {
         uint32_t kind = RAW_FINAL;
 #if defined(ACHIP_STREAM_ABLATE) && ACHIP_STREAM_ABLATE == 2 /* diagnostics: no gather */
         raw[k] = ((p.xp * 2654435761u) ^ (p.rr * 40503u) ^ (uint32_t)fidx) & 0x00FFFFFFu;
 #else
-        raw[k] = stream_request<GENERIC, NT, L::o_comp>(f, src, p.xp - pad_left, p.rr, kind);
+        raw[k] = stream_request<GENERIC, NT, L::o_comp>(f, src, pixc ? p.xp - pad_left : (uint32_t)f.out_w - 1u,
+                                                        pixc ? p.rr : p.rr - 1u, kind, chead);
 #endif
         kinds |= kind << (2 * k);
       }
       p = advance(p, q64, r64);
     }
-    if (MODE == ACHIP_MODE_TRUE_FG) { /* the few extra samples behind the bulk, so that the bulk is one clause */
-      p = p0;
-#pragma unroll
-      for (int k = 0; k < CPL; k++) {
-        if (cell0 + 64u * k < ncells && p.xp >= pad_left && wants_ext(p, k)) {
-          const bool rowstart = p.xp == pad_left;
-          uint32_t kd = RAW_FINAL;
-          ext[k] = stream_request<GENERIC, NT, L::o_comp>(f, src, rowstart ? (uint32_t)f.out_w - 1u : p.xp - pad_left - 1u,
-                                               rowstart ? p.rr - 1u : p.rr, kd);
-          kinds |= kd << (2 * (CPL + k));
-        }
-        p = advance(p, q64, r64);
-      }
-    }
   };
-  auto issue_any = [&](uint32_t cell0, CellPos p0, uint32_t (&raw)[CPL], uint32_t (&ext)[CPL], uint32_t &kinds) {
+  auto issue_any = [&](uint32_t cell0, CellPos p0, uint32_t (&raw)[CPL], uint32_t &kinds) {
     if (!GENERIC && src.nt)
-      issue(StreamTagNT{}, cell0, p0, raw, ext, kinds);
+      issue(StreamTagNT{}, cell0, p0, raw, kinds);
     else
-      issue(StreamTagCached{}, cell0, p0, raw, ext, kinds);
+      issue(StreamTagCached{}, cell0, p0, raw, kinds);
   };
 
-  uint32_t cell0 = (uint32_t)(wave * BLK + lane);
+  /* lane's cell of slot k = 0; the ghost of block 0 is "cell -1" = the last cell of row -1 (modulo 2^32: the steps
+   * below carry it to the right place, and it fails every `< ncells` test) */
+  uint32_t cell0 = (uint32_t)(wave * EFF + lane) - (uint32_t)SH;
   CellPos pos;
   pos.rr = cell0 / uwp;
   pos.xp = cell0 - pos.rr * uwp;
-  uint32_t raw[CPL], ext[CPL], kinds = 0;
+  if (SH && cell0 == 0xFFFFFFFFu) {
+    pos.rr = 0xFFFFFFFFu;
+    pos.xp = uwp - 1u;
+  }
+  uint32_t raw[CPL], kinds = 0;
   /* a composite frame samples through the LDS copy of its descriptor: its first requests follow the barrier */
   const bool late_first = GENERIC && f.comp != nullptr;
   if (late_first)
     comp_stage<L::o_comp, BLOCK>(f.comp, tid);
   else if (wave < nblk)
-    issue_any(cell0, pos, raw, ext, kinds);
+    issue_any(cell0, pos, raw, kinds);
   ACHIP_SSTAMP(2);
 
   if (MODE == ACHIP_MODE_TRUE_FG && !ascii_only) { /* the host sends such plans to render_frames_kernel */
@@ -481,8 +478,11 @@ __global__ void __launch_bounds__(WAVES * 64)
       dst[o] = '\n';
   __syncthreads(); /* the only workgroup barrier */
   ACHIP_SSTAMP(1);
-  if (late_first && wave < nblk)
-    issue_any(cell0, pos, raw, ext, kinds);
+  if (late_first) {
+    chead = comp_head<L::o_comp>();
+    if (wave < nblk)
+      issue_any(cell0, pos, raw, kinds);
+  }
 
   const uint32_t stage_off = (uint32_t)(L::o_stage + wave * L::STAGE);
   const uint32_t stage_addr = lds_base_addr() + stage_off;
@@ -491,11 +491,11 @@ __global__ void __launch_bounds__(WAVES * 64)
 
   for (int blk = wave; blk < nblk; blk += WAVES) {
     /* ---- request the next block's samples: they stay in flight while this block is tokenised and drained */
-    const uint32_t cell0_next = cell0 + (uint32_t)(WAVES * BLK);
+    const uint32_t cell0_next = cell0 + (uint32_t)(WAVES * EFF);
     const CellPos pos_next = advance(pos, qit, rit);
-    uint32_t raw_n[CPL], ext_n[CPL], kinds_n = 0;
+    uint32_t raw_n[CPL], kinds_n = 0;
     if (blk + WAVES < nblk)
-      issue_any(cell0_next, pos_next, raw_n, ext_n, kinds_n);
+      issue_any(cell0_next, pos_next, raw_n, kinds_n);
 
     if (prof) { /* diagnostics only: make "samples arrived" a point in time */
       wait_vmem_all();
@@ -510,10 +510,11 @@ __global__ void __launch_bounds__(WAVES * 64)
       CellPos p = pos;
 #pragma unroll
       for (int k = 0; k < CPL; k++) {
-        is_valid[k] = cell0 + 64u * k < ncells;
+        const bool inb = cell0 + 64u * k < ncells;
+        is_valid[k] = inb && !(SH && k == 0 && lane == 0); /* the ghost owns no token */
         is_pix[k] = is_valid[k] && p.xp >= pad_left;
         const uint32_t v = sample_finish<GENERIC>(f, raw[k], (kinds >> (2 * k)) & 3u);
-        px[k] = is_pix[k] ? v : 0u;
+        px[k] = inb && (p.xp >= pad_left || pred_pad(p)) ? v : 0u;
         p = advance(p, q64, r64);
       }
     }
@@ -533,9 +534,9 @@ __global__ void __launch_bounds__(WAVES * 64)
         if (MODE == ACHIP_MODE_TRUE_FG) {
           /* image_print_color + ansi_rle_add_pixel (foreground.c:268-303, ansi.c:261-300): the SGR only when the
            * colour differs from the previous pixel in raster order (the state survives row ends) */
-          const uint32_t nbr = wave_shift_up1(pt, k > 0 ? wave_read_lane(px[k > 0 ? k - 1 : 0], 63) : 0u);
-          const uint32_t pe = sample_finish<GENERIC>(f, ext[k], (kinds >> (2 * (CPL + k))) & 3u);
-          const uint32_t prev = wants_ext(p, k) ? pe : nbr;
+          /* the raster predecessor sits one slot down: the neighbouring lane (the ghost for lane 1 of slot 0; with left
+           * padding the pad cell in front of the row, which fetched the row above's last pixel) */
+          const uint32_t prev = wave_shift_up1(pt, k > 0 ? wave_read_lane(px[k > 0 ? k - 1 : 0], 63) : 0u);
           const bool have_prev = !(p.xp == pad_left && p.rr == 0u);
           const bool sgr = !have_prev || px_rgb(prev) != px_rgb(pt);
           t.glyph = glyph[Y];
@@ -779,10 +780,8 @@ __global__ void __launch_bounds__(WAVES * 64)
     pos = pos_next;
     kinds = kinds_n;
 #pragma unroll
-    for (int k = 0; k < CPL; k++) {
+    for (int k = 0; k < CPL; k++)
       raw[k] = raw_n[k];
-      ext[k] = ext_n[k];
-    }
   }
 }
 

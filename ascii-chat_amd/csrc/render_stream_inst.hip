@@ -86,7 +86,7 @@ hipError_t launch_one(const achip_frame_t *frames, int n, const achip_lut_t *lut
   }
   /* the per-block words are sized by the launch's largest frame when the host states it: a small footprint lets
    * workgroups of launches in flight on other streams share a CU */
-  const size_t lds = (size_t)((L::bytes_for(achip::stream_maxblk(uni.flags, L::BLK)) + 15) & ~15);
+  const size_t lds = (size_t)((L::bytes_for(achip::stream_maxblk(uni.flags, L::EFF)) + 15) & ~15);
   hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(G::WAVES * 64), lds, stream, frames, lut, out, stride, len, n, uni,
                      prof, wire, tab);
   return hipGetLastError();

@@ -499,6 +499,100 @@ def wire_stage(torch, pkg, res, steps=160):
                     "(two launches) vs asciichat_hip_plan_render_packets (one launch)"}
 
 
+def tick_e2e(torch, pkg, n=256, distinct=32, ticks=(2, 4)):
+    """The end-to-end server tick (SURVEY 8f.2 + path + 8f.3), PCIe included on both sides: n clients' host blobs
+    [u32 BE w][u32 BE h][RGB24] (blocks of the pinned pool, as the receive path would fill them) -> frame table ->
+    plan_render_packets -> frames in use + headers packed into mapped pinned host memory.  Two publish forms: the whole
+    blob (frame_table_publish: one in-place DMA of 6.2 MB per client) and the sampled rows only
+    (frame_table_publish_rows: 24 of 1080 rows).  Never `value`: this is PCIe- and host-bound (the per-client calls are
+    issued from this interpreter; tests/cabi/server_tick_port.c is the same tick in C)."""
+    import numpy as np
+
+    import orc
+
+    sw, sh, W, H = 1920, 1080, 80, 24
+    L = pkg.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    blob_bytes = 8 + sw * sh * 3
+    rng = np.random.default_rng(99)
+    blobs, imgs = [], []
+    for k in range(distinct):
+        p = L.buffer_pool_alloc(None, blob_bytes)  # > 4 MiB: the pinned, device-mapped class
+        if not p:
+            raise RuntimeError("buffer_pool_alloc failed")
+        v = np.ctypeslib.as_array((C.c_uint8 * blob_bytes).from_address(p))
+        v[:8] = np.frombuffer(sw.to_bytes(4, "big") + sh.to_bytes(4, "big"), dtype=np.uint8)
+        img = rng.integers(0, 256, (sh, sw, 3), dtype=np.uint8)
+        v[8:] = img.reshape(-1)
+        blobs.append(p)
+        imgs.append(img)
+    table = pkg.FrameTable(n)
+    tmpl = pkg.frame_setup(None, sw, sh, W, H, 0, False, False, False)
+    mode = L.achip_mode_from_caps(3, 0)
+    plan = None
+    tab = (8 * (n + 1) + 4 * n + 15) // 16 * 16
+    dims = torch.tensor([[W, H]] * n, dtype=torch.int32, device="cuda")
+    crc = torch.zeros(n, dtype=torch.int32, device="cuda")
+    hdr = torch.zeros(n * 24, dtype=torch.uint8, device="cuda")
+    pkt = torch.zeros(n, dtype=torch.int32, device="cuda")
+    out = {}
+    for form in ("whole_blob", "sampled_rows"):
+        t_pub = t_all = 0.0
+        n_ticks = ticks[0] if form == "whole_blob" else ticks[1]
+        for tick in range(n_ticks + 1):  # the first tick allocates (frame buffers, staging): untimed
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(n):
+                if form == "whole_blob":
+                    table.publish_at(i, blobs[(i + tick) % distinct], blob_bytes, st)
+                else:
+                    table.publish_rows(i, (blobs[(i + tick) % distinct], blob_bytes), [tmpl], st)
+            t1 = time.perf_counter()
+            descs = []
+            for i in range(n):
+                f = pkg.Frame.from_buffer_copy(tmpl)
+                f.src = table.latest(i, st)[0]
+                descs.append(f)
+            if plan is None:
+                plan = pkg.Plan(mode, PALETTE_STANDARD, descs)
+                slab = torch.empty(n * plan.stride, dtype=torch.uint8, device="cuda")
+                ln = torch.zeros(n, dtype=torch.int32, device="cuda")
+                hb = pkg.HostBuffer(tab + n * plan.stride)
+            else:
+                plan.update(descs, st)
+            plan.render_packets(slab.data_ptr(), plan.stride, ln.data_ptr(), dims.data_ptr(), crc.data_ptr(), hdr.data_ptr(),
+                                pkt.data_ptr(), st)
+            pkg.pack_frames(slab.data_ptr(), plan.stride, ln.data_ptr(), n, hb.dev + tab, n * plan.stride, hb.dev,
+                            hb.dev + 8 * (n + 1), st)
+            hdr_host = hdr.cpu()  # 6 KB of headers (a blocking copy: also the tick's synchronisation point)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            if tick > 0:
+                t_pub += t1 - t0
+                t_all += t2 - t0
+        v = hb.view()
+        off = v[:8 * (n + 1)].view(np.uint64)
+        lh = v[8 * (n + 1):8 * (n + 1) + 4 * n].view(np.uint32)
+        for i in (0, n - 1):  # what arrived on the host is the oracle's frame of that client's blob
+            exp = orc.convert_with_caps(imgs[(i + n_ticks) % distinct], W, H, 3, 0, False, False, False)
+            if v[tab + int(off[i]):tab + int(off[i]) + int(lh[i])].tobytes() != exp:
+                raise SystemExit(f"bench.py: tick_e2e ({form}) frame {i} differs from the oracle")
+        rows = H
+        up = n * (blob_bytes - 8) if form == "whole_blob" else n * (rows * sw * 3 + 16 * ((rows * 4 + 15) // 16))
+        out[form] = {"frames_per_s": n * n_ticks / t_all, "ms_per_tick": t_all / n_ticks * 1e3,
+                     "publish_ms_per_tick": t_pub / n_ticks * 1e3, "ticks_timed": n_ticks,
+                     "pcie_bytes_up_per_tick": int(up), "pcie_bytes_down_per_tick": int(off[n]) + tab + 24 * n,
+                     "verified_frames_vs_oracle": 2}
+    plan.close()
+    hb.close()
+    table.close()
+    for p in blobs:
+        L.buffer_pool_free(None, p, blob_bytes)
+    out["note"] = (f"{n} clients, 1080p -> 80x24 truecolor, blobs in the pinned pool; publish + latest + plan_update + "
+                   "plan_render_packets + pack_frames into mapped host memory per tick; calls issued from Python")
+    return out
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -848,6 +942,11 @@ def main():
             except (RuntimeError, AssertionError) as e:  # a plan without the entry point, an out-of-memory slab, ...
                 line["wire_stage"] = {"error": str(e)[:200]}
         free_workload(torch, res)
+        if not args.no_d2h and args.workload == "1080p_80x24_truecolor" and args.batch == 256:
+            try:
+                line["tick_e2e"] = tick_e2e(torch, pkg)
+            except RuntimeError as e:
+                line["tick_e2e"] = {"error": str(e)[:200]}
         if not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(args.workload)
         others = {}

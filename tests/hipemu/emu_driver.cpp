@@ -81,7 +81,7 @@ static void run_stream(const achip_frame_t *frames, int n, const achip_lut_t *lu
     (void)achip_frames_uniform(frames, n, &uni);
   uni.flags = ((lut->flags & ACHIP_LUT_MULTIBYTE) ? 0u : ACHIP_UNIFORM_PALETTE_ASCII) |
               ACHIP_UNIFORM_MAX_CELLS(achip_max_cells(frames, n)); /* what plan.c / dropin.c pass */
-  const size_t lds = (size_t)((L::bytes_for(achip::stream_maxblk(uni.flags, L::BLK)) + 15) & ~15);
+  const size_t lds = (size_t)((L::bytes_for(achip::stream_maxblk(uni.flags, L::EFF)) + 15) & ~15);
   hipemu::launch(dim3((unsigned)n), dim3(WAVES * 64), lds, [&] {
     achip::render_stream_kernel<MODE, WAVES, CPL, true>(frames, lut, out, stride, len, n, uni, nullptr, achip_wire_t{}, nullptr);
   });
@@ -119,7 +119,7 @@ static void run_stream_crc(const achip_frame_t *frames, int n, const achip_lut_t
     hipemu::launch(dim3(1), dim3(256), 0, [&] { achip::crc_tables_init_kernel<MODE, WAVES, CPL>(t); });
   }
   const uint4 *tabv = reinterpret_cast<const uint4 *>(tab.data());
-  const size_t lds = (size_t)((L::bytes_for(achip::stream_maxblk(uni.flags, L::BLK)) + 15) & ~15);
+  const size_t lds = (size_t)((L::bytes_for(achip::stream_maxblk(uni.flags, L::EFF)) + 15) & ~15);
   hipemu::launch(dim3((unsigned)n), dim3(WAVES * 64), lds, [&] {
     achip::render_stream_kernel<MODE, WAVES, CPL, true, true>(frames, lut, out, stride, len, n, uni, nullptr, wire, tabv);
   });
