@@ -183,6 +183,8 @@ def lib():
     L.asciichat_hip_plan_render_packets.argtypes = [vp, vp, sz, vp, vp, vp, vp, vp, vp]
     L.asciichat_hip_plan_render_crc_profiled.restype = ci
     L.asciichat_hip_plan_render_crc_profiled.argtypes = [vp, vp, sz, vp, vp, vp, vp]
+    L.asciichat_hip_plan_set_fused_crc.restype = ci
+    L.asciichat_hip_plan_set_fused_crc.argtypes = [vp, ci]
     L.asciichat_hip_plan_has_fused_crc.restype = ci
     L.asciichat_hip_plan_has_fused_crc.argtypes = [vp]
     L.asciichat_hip_packets_from_crc.restype = ci
@@ -402,6 +404,12 @@ class Plan:
                                                      pkt_ptr, stream)
         if rc != 0:
             raise RuntimeError(f"plan_render_packets failed ({rc}): {last_error()}")
+
+    def set_fused_crc(self, mode):
+        """-1 automatic (fused where it is the faster form), 0 never, 1 wherever the geometry carries it"""
+        rc = lib().asciichat_hip_plan_set_fused_crc(self._h, mode)
+        if rc != 0:
+            raise RuntimeError(f"set_fused_crc({mode}) failed: {last_error()}")
 
     @property
     def fused_crc(self):

@@ -333,6 +333,29 @@ long achip_max_cells(const achip_frame_t *frames, int n_frames) {
   return max_cells;
 }
 
+/* the rows-kernel family (render_variants.h: ACHIP_ROWS_VARIANTS): a block is a whole number of text rows */
+#define ACHIP_HOST_ROWS_FIRST 24
+static int rows_variant_cpl(int variant) { return variant == 24 ? 7 : variant == 25 ? 4 : variant == 28 ? 2 : 0; }
+
+/* what the ACHIP_UNIFORM_MAX_CELLS field of a launch carries: cells of the largest frame for the stream geometries,
+ * BLOCKS of the frame with the most blocks for the rows geometries (rows / (64 * CPL / row width), rounded up) */
+long achip_uniform_extent(int mode, int variant, const achip_frame_t *frames, int n_frames) {
+  const int cpl = rows_variant_cpl(variant);
+  if (!cpl)
+    return achip_max_cells(frames, n_frames);
+  const bool hb = mode >= ACHIP_MODE_HB_TRUE && mode <= ACHIP_MODE_HB_MONO;
+  long most = 0;
+  for (int i = 0; i < n_frames; i++) {
+    const long wp = (long)frames[i].pad_left + frames[i].out_w;
+    const long rows = hb ? ((long)frames[i].out_h + 1) / 2 : frames[i].out_h;
+    const long rpb = wp > 0 ? (64L * cpl) / wp : 0;
+    const long blocks = rpb > 0 ? (rows + rpb - 1) / rpb : 0;
+    if (blocks > most)
+      most = blocks;
+  }
+  return most;
+}
+
 int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, bool palette_ascii_only,
                           const int *variant_caps, int n_cus, int split_request, int forced_variant, int *variant,
                           int *parts, int *rows_per_part) {
@@ -363,12 +386,23 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
   const long max_cells = achip_max_cells(frames, n_frames);
   const bool cell_mode = mode == ACHIP_MODE_256_FG || mode == ACHIP_MODE_16_FG || mode == ACHIP_MODE_TRUE_BG ||
                          (mode == ACHIP_MODE_TRUE_FG && palette_ascii_only);
-  const bool stream_forced = forced_variant >= ACHIP_HOST_STREAM_FIRST;
+  const bool stream_forced = forced_variant >= ACHIP_HOST_STREAM_FIRST && forced_variant < ACHIP_HOST_ROWS_FIRST;
   /* cells a block owns: 64 per lane slot, minus the ghost slot of truecolor-fg (render_stream.hpp: SLds::EFF) */
   const int ghost = mode == ACHIP_MODE_TRUE_FG ? 1 : 0;
   if (stream_forced) {
     const int cpl = forced_variant == 19 || forced_variant == 20 ? 1 : 2;
     if (!cell_mode || forced_variant > 20 || max_cells > (long)ACHIP_HOST_STREAM_MAXBLK * (64 * cpl - ghost))
+      return -1;
+    *variant = forced_variant;
+    return 0; /* whole frames only */
+  }
+  /* The run-structured renderers (mono, half blocks) start a run at every row's first cell, so a whole number of text
+   * rows is a self-contained block that ONE wave can take through the path (render_rows.hpp): whole-frame launches of
+   * them take that kernel whenever the widest padded row fits a block (64 * CPL cells). */
+  const bool run_mode = mode == ACHIP_MODE_MONO || hb;
+  if (forced_variant >= ACHIP_HOST_ROWS_FIRST) {
+    const int cpl = rows_variant_cpl(forced_variant);
+    if (!run_mode || !cpl || max_wp > 64 * cpl || achip_uniform_extent(mode, forced_variant, frames, n_frames) > ACHIP_HOST_STREAM_MAXBLK)
       return -1;
     *variant = forced_variant;
     return 0; /* whole frames only */
@@ -385,6 +419,19 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
      * 10.9 vs 8.2, ANSI-256 7.0 vs 6.6, 4K -> 200x60 equal within noise) */
     *variant = (max_cells <= 16 * (128 - ghost) && n_frames <= n_cus) ? 16 : 17;
     return 0;
+  }
+  if (forced_variant < 0 && run_mode && !may_split && max_wp <= 64 * 7) {
+    /* the geometry whose blocks waste fewer lane slots on this row width; the smaller one on a tie.  Measured
+     * (profiles/r03_rows_kernel.txt, 256 frames per launch): 1080p -> 80x24 half blocks 15.7 us per step with four
+     * launches in flight / 22.6 one at a time (phase kernel: 22.6 / 24.1); 4K -> 400x120 half blocks 212 us with four in
+     * flight (phase: 244) but 308 one at a time (phase: 256) -- its 7-slot blocks run at eight waves per CU, so ONE launch
+     * of at most a frame per CU stays with the phase kernel's sixteen. */
+    const int used4 = max_wp <= 256 ? (256 / max_wp) * max_wp : 0, used7 = (448 / max_wp) * max_wp;
+    const int v = used4 * 448 >= used7 * 256 ? 25 : 24;
+    if ((v == 25 || n_frames > n_cus) && achip_uniform_extent(mode, v, frames, n_frames) <= ACHIP_HOST_STREAM_MAXBLK) {
+      *variant = v;
+      return 0;
+    }
   }
   if (forced_variant >= 0) {
     if (max_wp > variant_caps[forced_variant])

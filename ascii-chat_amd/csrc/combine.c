@@ -263,7 +263,7 @@ static void cb_run(cb_t *cb, cb_gen_t *G) {
     S->epoch = S->epoch + 1u ? S->epoch + 1u : 1u;
     achip_uniform_t uni;
     (void)achip_frames_uniform(G->descs_host + base, n, &uni);
-    uni.flags = (G->req[i].ascii ? ACHIP_UNIFORM_PALETTE_ASCII : 0u) | ACHIP_UNIFORM_MAX_CELLS(achip_max_cells(G->descs_host + base, n));
+    uni.flags = (G->req[i].ascii ? ACHIP_UNIFORM_PALETTE_ASCII : 0u) | ACHIP_UNIFORM_MAX_CELLS(achip_uniform_extent(G->req[i].mode, variant, G->descs_host + base, n));
     e = (hipError_t)achip_launch_render(G->req[i].mode, variant, generic, G->descs_dev + base, n, G->req[i].lut,
                                         G->slab_dev + cursor, (uint64_t)stride, G->lens_dev + base, NULL, parts, rpp,
                                         parts > 1 ? S->part_sync : NULL, S->epoch, &uni, S->stream);

@@ -243,7 +243,7 @@ static char *render_with_lut(tls_ctx_t *c, const achip_lut_t *lut, int mode, con
   *len_host = ACHIP_LEN_BADDESC;
   achip_uniform_t uni; /* one frame: its descriptor rides in the kernel arguments (no PCIe read of the pinned copy) */
   (void)achip_frames_uniform(desc, 1, &uni);
-  uni.flags = (achip_palette_ascii_only(palette) ? ACHIP_UNIFORM_PALETTE_ASCII : 0u) | ACHIP_UNIFORM_MAX_CELLS(achip_max_cells(desc, 1));
+  uni.flags = (achip_palette_ascii_only(palette) ? ACHIP_UNIFORM_PALETTE_ASCII : 0u) | ACHIP_UNIFORM_MAX_CELLS(achip_uniform_extent(mode, variant, desc, 1));
   const int generic = (long)desc->src_w * (long)desc->src_h == 1; /* 1x1 sources need the kernels' general sampler */
   if (achip_hip_check(achip_launch_render(mode, variant, generic, (const achip_frame_t *)(c->pin_dev + PIN_DESC_OFF), 1, lut,
                                           c->pin_dev + PIN_OUT_OFF, (uint64_t)stride,

@@ -46,6 +46,10 @@ __device__ inline uint32_t lds_base_addr() {
 }
 /* all DS operations issued by inline asm must have landed before they are read back */
 __device__ inline void lds_store_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+/* The lanes of a wave execute in lockstep and a wave's DS operations complete in order: what every lane read from LDS
+ * above this point was read before anything below it is stored.  Nothing to emit on the machine; the emulator's twin
+ * lines its fibers up here. */
+__device__ inline void wave_lockstep() {}
 /* every outstanding vector-memory load of this wave has returned (diagnostics: a point in time for a stamp) */
 __device__ inline void wait_vmem_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 

@@ -28,6 +28,7 @@ int achip_launch_render_crc(int mode, int variant, int has_composite, const achi
                             const achip_wire_t *wire, const achip_uniform_t *uniform, unsigned long long *prof,
                             void *stream);
 int achip_variant_has_crc(int variant);
+int achip_variant_crc_pays(int variant); /* the fused form is the faster one: what plans pick by themselves */
 /* 24-byte ascii_frame_packet_t headers and header || frame CRCs from lengths + frame CRCs that are already known */
 int achip_launch_packets_from_crc(const uint32_t *len_dev, const uint32_t *crc_dev, const uint32_t *dims_dev, int n,
                                   uint8_t *hdr_out, uint32_t *pkt_crc_out, void *stream);

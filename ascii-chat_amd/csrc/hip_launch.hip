@@ -21,6 +21,19 @@ extern "C" int achip_launch_render(int mode, int variant, int has_composite, con
     return (int)hipSuccess;
   if (parts < 1 || (parts > 1 && (!part_sync || rows_per_part < 1)))
     return (int)hipErrorInvalidValue;
+  if (ACHIP_IS_ROWS_VARIANT(variant)) { /* wave-autonomous kernel of the run-structured modes (render_rows.hpp) */
+    if (parts != 1) /* (the profiled entry points' per-wave stamps do not exist here: prof is ignored) */
+      return (int)hipErrorInvalidValue;
+    switch (variant) {
+#define X(id, W, C)                                                                                                    \
+  case id:                                                                                                             \
+    return achip_render_rinst_launch_##id(mode, has_composite, frames_dev, n_frames, lut_dev, out, out_stride, out_len, \
+                                          uniform, nullptr, stream);
+      ACHIP_ROWS_VARIANTS(X)
+#undef X
+    }
+    return (int)hipErrorInvalidValue;
+  }
   if (ACHIP_IS_STREAM_VARIANT(variant)) { /* wave-autonomous kernel: per-cell modes, whole frames (render_stream.hpp) */
     if (parts != 1)
       return (int)hipErrorInvalidValue;
@@ -61,10 +74,21 @@ extern "C" int achip_launch_render_crc(int mode, int variant, int has_composite,
                                           uniform, prof, wire, stream);
     ACHIP_STREAM_VARIANTS(X)
 #undef X
+#define X(id, W, C)                                                                                                    \
+  case id:                                                                                                             \
+    return achip_render_rinst_launch_##id(mode, has_composite, frames_dev, n_frames, lut_dev, out, out_stride, out_len,  \
+                                          uniform, wire, stream);
+    ACHIP_ROWS_VARIANTS(X)
+#undef X
   }
   return (int)hipErrorInvalidValue;
 }
-extern "C" int achip_variant_has_crc(int variant) { return variant == 16 || variant == 17; }
+extern "C" int achip_variant_has_crc(int variant) { return variant == 16 || variant == 17 || ACHIP_IS_ROWS_VARIANT(variant); }
+/* ... and whether riding the drain beats a second pass over the slab there (measured, profiles/r03_rows_kernel.txt): yes
+ * for the per-cell modes' stream kernel (+2.4 us against +8.3 us per 256-frame step); no for the rows kernel, whose
+ * per-slice checksum chains cost more than the stand-alone kernel's pass (+12 against +8 us on 80x24 half blocks, +240
+ * against +99 us on 400x120) -- there the fused form only runs when asked for (asciichat_hip_plan_set_fused_crc) */
+extern "C" int achip_variant_crc_pays(int variant) { return variant == 16 || variant == 17; }
 
 /* headers + packet CRCs from frame CRCs that are already known (the fused render): one thread per frame */
 namespace achip {
@@ -100,6 +124,7 @@ extern "C" int achip_variant_block(int variant) {
   case id:                                                                                                             \
     return 64 * W;
     ACHIP_STREAM_VARIANTS(X)
+    ACHIP_ROWS_VARIANTS(X)
 #undef X
 #define X(id, B, C, R)                                                                                                 \
   case id:                                                                                                             \
@@ -117,6 +142,11 @@ extern "C" int achip_variant_cap(int variant) {
     return ACHIP_STREAM_MAXBLK * 64 * C;
     ACHIP_STREAM_VARIANTS(X)
 #undef X
+#define X(id, W, C) /* rows geometries: cells of the widest padded row a block can hold */                           \
+  case id:                                                                                                             \
+    return 64 * C;
+    ACHIP_ROWS_VARIANTS(X)
+#undef X
 #define X(id, B, C, R)                                                                                                 \
   case id:                                                                                                             \
     return C;
@@ -132,6 +162,11 @@ extern "C" int achip_variant_lds_bytes(int mode, int variant) {
   case id:                                                                                                             \
     return achip_render_sinst_lds_##id(mode);
     ACHIP_STREAM_VARIANTS(X)
+#undef X
+#define X(id, W, C)                                                                                                    \
+  case id:                                                                                                             \
+    return achip_render_rinst_lds_##id(mode);
+    ACHIP_ROWS_VARIANTS(X)
 #undef X
 #define X(id, B, C, R)                                                                                                 \
   case id:                                                                                                             \

@@ -198,6 +198,7 @@ struct asciichat_hip_plan {
   achip_uniform_t uniform; /* the batch's common descriptor, when it has one (achip_frames_uniform) */
   int concurrency;         /* launches the caller keeps in flight on separate streams (>= 1) */
   int uniform_off;         /* asciichat_hip_plan_set_uniform(plan, 0): always read the device array */
+  int fused_crc;           /* -1 = where it is the faster form (default), 0 = never, 1 = wherever the geometry carries it */
   size_t stride;
   achip_frame_t *frames_dev;
   achip_frame_t *frames_pinned; /* staging for async updates */
@@ -225,12 +226,12 @@ static int choose_geometry(asciichat_hip_plan_t *p, const achip_frame_t *frames)
   const int cus = device_cus() / (p->concurrency > 1 ? p->concurrency : 1);
   if (achip_choose_geometry(p->mode, frames, p->n, p->palette_ascii != 0, caps, cus > 0 ? cus : 1,
                             forced >= 0 && p->split_request == 0 ? -1 : p->split_request, /* explicit geometry alone: whole frames */
-                            forced < ACHIP_VARIANT_COUNT || (ACHIP_IS_STREAM_VARIANT(forced) && achip_variant_block(forced) > 0) ? forced : -1, &variant, &parts, &rpp) != 0)
+                            forced < ACHIP_VARIANT_COUNT || (forced >= ACHIP_STREAM_VARIANT_FIRST && achip_variant_block(forced) > 0) ? forced : -1, &variant, &parts, &rpp) != 0)
     return -1;
   p->variant = variant;
   p->parts = parts;
   p->rows_per_part = rpp;
-  p->max_cells = achip_max_cells(frames, p->n);
+  p->max_cells = achip_uniform_extent(p->mode, variant, frames, p->n);
   return 0;
 }
 
@@ -304,6 +305,7 @@ int asciichat_hip_plan_create(asciichat_hip_plan_t **plan, int mode, const char 
   p->mode = mode;
   p->n = n_frames;
   p->variant_user = -1;
+  p->fused_crc = -1;
   p->concurrency = 1;
   p->palette_ascii = achip_palette_ascii_only(palette_chars) ? 1 : 0;
   rc = plan_measure(p, frames);
@@ -449,7 +451,7 @@ static int plan_render_wire(asciichat_hip_plan_t *p, uint8_t *out_dev, size_t ou
                       p->stride);
   if (((uintptr_t)wire->hdr & 7u))
     return achip_fail(ASCIICHAT_HIP_ERR_BUFFER, "packet headers must be 8-byte aligned");
-  if (p->parts == 1 && achip_variant_has_crc(p->variant)) {
+  if (asciichat_hip_plan_has_fused_crc(p)) {
     achip_uniform_t uni = p->uniform;
     if (p->uniform_off)
       uni.enabled = 0;
@@ -497,7 +499,16 @@ int asciichat_hip_plan_render_crc_profiled(asciichat_hip_plan_t *p, uint8_t *out
 }
 
 int asciichat_hip_plan_has_fused_crc(const asciichat_hip_plan_t *p) {
-  return p && p->parts == 1 && achip_variant_has_crc(p->variant);
+  if (!p || p->parts != 1 || p->fused_crc == 0 || !achip_variant_has_crc(p->variant))
+    return 0;
+  return p->fused_crc > 0 || achip_variant_crc_pays(p->variant);
+}
+
+int asciichat_hip_plan_set_fused_crc(asciichat_hip_plan_t *p, int mode) {
+  if (!p || mode < -1 || mode > 1)
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "plan_set_fused_crc: -1 (automatic), 0 (never) or 1 (always)");
+  p->fused_crc = mode;
+  return 0;
 }
 
 int asciichat_hip_packets_from_crc(const uint32_t *len_dev, const uint32_t *crc_dev, int n, const uint32_t *dims_dev,

@@ -29,6 +29,15 @@ ACHIP_VARIANTS(X)
 ACHIP_STREAM_VARIANTS(X)
 #undef X
 
+/* the rows-kernel geometries (render_rows_inst.hip, -DACHIP_RINST=id): run-structured modes, whole frames */
+#define X(id, W, C)                                                                                                    \
+  int achip_render_rinst_launch_##id(int mode, int comp, const achip_frame_t *frames, int n, const achip_lut_t *lut,   \
+                                     uint8_t *out, uint64_t stride, uint32_t *len, const achip_uniform_t *uniform,     \
+                                     const achip_wire_t *wire, void *stream);                                          \
+  int achip_render_rinst_lds_##id(int mode);
+ACHIP_ROWS_VARIANTS(X)
+#undef X
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,631 @@
+/*
+ * render_rows.hpp -- the wave-autonomous frame kernel for the RUN-STRUCTURED renderers of the path:
+ *   image_print (monochrome, REP runs)                             lib/video/ascii/scalar/foreground.c:27-138
+ *   rgb_to_truecolor_halfblocks_scalar                             lib/video/ascii/scalar/halfblock.c:48-165
+ *   rgb_to_256color_halfblocks_scalar / rgb_to_16color_...         halfblock.c:416-524 / 297-405
+ *   rgb_to_halfblocks_scalar (monochrome half blocks)              halfblock.c:184-286
+ * whose tokens depend on runs of equal cells: a run's head carries the SGRs and the REP count, the cells behind it
+ * are swallowed by the REP or repeat the glyph, a head's SGRs are suppressed against the state the previous run left.
+ *
+ * render_stream.hpp takes the per-cell modes through the path one wave at a time; what kept the run modes on the
+ * barrier-fenced phase kernel (render_kernels.hpp) was that a cell needs the NEXT run head, which may belong to
+ * another wave.  The observation that removes the problem: every renderer starts a new run at the first cell of a
+ * text row (the `x == 0` / state-reset rules of the reference's row loops), so run structure never crosses a row.  A
+ * block here is therefore a whole number of text rows -- floor(64 * CPL / row width), at least one -- and ONE WAVE
+ * owns it: run heads are wave ballots (CPL 64-bit masks in scalar registers), a cell finds its head, the next head and
+ * the previous run's head with bit scans over those masks, the left neighbour arrives by one DPP move.  No LDS pixel
+ * arrays, no head-mask phase, no barrier: everything the stream kernel does -- request-ahead gather, wave scan,
+ * decoupled look-back over LDS words, private staging, 16-byte non-temporal drain, the frame CRC riding the drain -- is
+ * the same code (this file includes render_stream.hpp and shares its helpers).  A row that does not fit 64 * CPL cells
+ * is the phase kernel's (the host decides: achip_choose_geometry).
+ *
+ * Staging is per SLICE (the 64 cells of one lane slot k), not per block: a 448-cell block of 53-byte half-block tokens
+ * would need 25 KB per wave; a slice needs 3.6 KB, so sixteen waves fit a CU's LDS and the CRC tables besides.  Slices
+ * drain like the stream kernel's blocks do (whole 16-byte groups as uint4, the shared first / last group as bytes).
+ */
+#pragma once
+
+#include "render_stream.hpp"
+
+namespace achip {
+
+#ifndef ACHIP_ROWS_EMIT_OR_MODES
+#define ACHIP_ROWS_EMIT_OR_MODES 0 /* bit m set: mode m stores its tokens through PackSink here.  Off: this kernel is bound
+                                      by VALU issue (profiles/r03_k5_sq_counters.txt: 130 M VALU instructions per 256-frame
+                                      launch with the OR sink, 110 M with byte stores; 250 vs 231 us), unlike the phase
+                                      kernel, whose store phase is fenced by barriers and bound by the LDS pipe */
+#endif
+
+/* longest token of a run-structured mode, bytes, rounded up (SURVEY 8a "per-token byte lengths") */
+__host__ __device__ constexpr int rows_max_token(int m) {
+  return m == ACHIP_MODE_HB_TRUE  ? 56   /* 19 + 19 + 3-byte half block + ESC[4095b (7) + reset 4 + NL */
+         : m == ACHIP_MODE_HB_256 ? 40   /* 11 + 11 + 3 + 7 + 4 + 1                                     */
+         : m == ACHIP_MODE_HB_16  ? 32   /* 5 + 6 + 3 + 7 + 4 + 1                                       */
+                                  : 16;  /* mono / mono half blocks: glyph <= 4 + 7 + NL                */
+}
+
+template <int MODE, int WAVES, bool CRC = false> struct RLds {
+  static constexpr int STAGE = 64 * rows_max_token(MODE) + 16; /* one slice + the 16-byte group it starts in */
+  static constexpr int GPL = (STAGE / 16 + 63) / 64;
+  static constexpr int o_stage = 0;
+  static constexpr int o_glyph = WAVES * STAGE;
+  static constexpr int o_glyph64 = o_glyph + 256 * 4;
+  static constexpr int o_ramp = o_glyph64 + 64 * 4;
+  static constexpr int o_dec = o_ramp + 64;
+  static constexpr int o_flags = o_dec + 256 * 4; /* [+16 ..] swallows predicated-off byte stores */
+  static constexpr int o_comp = o_flags + 32 + 64 * 4;
+  static constexpr int o_tab = o_comp + ACHIP_COMP_LDS_BYTES;
+  static constexpr int o_slice = o_tab;
+  static constexpr int o_lanek = o_slice + (CRC ? 16 * 1024 : 0);
+  static constexpr int base_crc = o_lanek + (CRC ? 3 * 1024 + 256 + 16 + 2 * ACHIP_STREAM_MAXBLK * 4 : 0);
+  static constexpr int WIN = base_crc + 32 * 1024 <= 160 * 1024 ? 4 : 2;
+  static constexpr int NWIN = 32 / WIN;
+  static constexpr int o_pow = o_lanek + (CRC ? NWIN * (1 << WIN) * 64 * 4 : 0);
+  static constexpr int o_xk = o_pow + (CRC ? 3 * 1024 : 0);
+  static constexpr int TAB_BYTES = (CRC ? o_xk + 256 : o_tab) - o_tab;
+  static constexpr int o_crcacc = o_tab + TAB_BYTES;
+  static constexpr int o_slots = o_crcacc + (CRC ? 16 : 0);
+  static constexpr int bytes_for(int maxblk) { return o_slots + maxblk * 4 * (CRC ? 2 : 1); }
+  static constexpr int bytes = bytes_for(ACHIP_STREAM_MAXBLK);
+  static_assert(STAGE % 16 == 0 && o_tab % 16 == 0 && TAB_BYTES % 16 == 0, "16-byte aligned areas");
+  static_assert(bytes <= 160 * 1024, "one workgroup's LDS");
+};
+
+/* run key comparison of two cells (render_kernels.hpp same_run, on registers) */
+template <int MODE> __device__ inline bool rows_same_run(uint32_t aT, uint32_t aB, uint32_t bT, uint32_t bB) {
+  if (MODE == ACHIP_MODE_MONO)
+    return px_key(aT) == px_key(bT);
+  if (MODE == ACHIP_MODE_HB_TRUE || MODE == ACHIP_MODE_HB_MONO)
+    return px_rgb(aT) == px_rgb(bT) && px_rgb(aB) == px_rgb(bB);
+  return px_key(aT) == px_key(bT) && px_key(aB) == px_key(bB); /* HB_256 / HB_16 */
+}
+
+/* What a cell of a run-structured mode needs to know about its surroundings -- all of it derived from the wave's head
+ * masks (rows kernel) exactly as build_token derives it from the LDS masks (phase kernel). */
+struct RunCtx {
+  bool is_head;          /* the cell starts a run                                                          */
+  uint32_t run;          /* cells in the cell's run                                                        */
+  bool head_transparent; /* HT/H256/H16: the run's HEAD is raw black over raw black (halfblock.c:357,476)  */
+  bool state_set;        /* head, not first in its row: the previous run left fg/bg state (was not transparent) */
+  uint32_t prevT, prevB; /* head, not first in its row: a cell of the previous run (same keys / rgb as its head) */
+};
+
+/* the token of one cell: the run-structured branch of build_token (render_kernels.hpp), cited there */
+template <int MODE>
+__device__ inline Tok rows_token(const RunCtx &c, uint32_t pt, uint32_t pb, uint32_t ops, const uint32_t *glyph64, bool pad,
+                                 bool row_end, bool last_row) {
+  Tok t;
+  t.flags = 0;
+  t.fg = t.bg = t.glyph = t.rep = 0;
+  if (pad) { /* ascii_pad_frame_width: pad_left spaces in front of every row */
+    t.flags = TF_PAD;
+    return t;
+  }
+  const bool rep = rep_profitable(c.run);
+  if (c.is_head && rep) {
+    t.flags |= TF_REP;
+    t.rep = c.run - 1u;
+  }
+  if (MODE == ACHIP_MODE_MONO) {
+    /* image_print (foreground.c:86-127): key = ramp[Y>>2], glyph = cache64[key] (double mapping; clamped as in the
+     * phase kernel for palettes of more than 64 characters) */
+    t.glyph = glyph64[min(px_key(pt), 63u)];
+    if (c.is_head || !rep)
+      t.flags |= TF_GLYPH;
+  } else if (MODE == ACHIP_MODE_HB_MONO) {
+    /* rgb_to_halfblocks_scalar (halfblock.c:203-275): 76/150/29 luminance, no rounding term */
+    const uint32_t lt = (76u * px_r(pt) + 150u * px_g(pt) + 29u * px_b(pt)) >> 8;
+    const uint32_t lb = (76u * px_r(pb) + 150u * px_g(pb) + 29u * px_b(pb)) >> 8;
+    if (lt < 16u && lb < 16u) {
+      t.flags = TF_SPACE; /* no REP for padding */
+    } else {
+      const uint32_t sh = lt >> 6; /* U+2591 U+2592 U+2593 U+2588 = E2 96 91|92|93|88 */
+      t.glyph = 0x0096E2u | ((sh == 3u ? 0x88u : 0x91u + sh) << 16);
+      if (c.is_head || !rep)
+        t.flags |= TF_GLYPH;
+    }
+  } else {
+    /* HT / H256 / H16 (halfblock.c:48-165, 297-524): transparency is decided by the run HEAD's raw rgb; fg/bg SGRs only
+     * when they differ from the state left by the previous run in this row (unset at row start and after a transparent
+     * run) */
+    if (c.head_transparent) {
+      t.flags = TF_SPACE | ((c.is_head && c.state_set) ? TF_RESET_PRE : 0u);
+    } else {
+      t.glyph = 0x8096E2u; /* U+2580 upper half block = E2 96 80 */
+      if (c.is_head || !rep)
+        t.flags |= TF_GLYPH;
+      if (c.is_head) {
+        if (MODE == ACHIP_MODE_HB_TRUE) {
+          if (!c.state_set || px_rgb(c.prevT) != px_rgb(pt)) {
+            t.flags |= TF_SGR_FG;
+            t.fg = px_rgb(pt);
+          }
+          if (!c.state_set || px_rgb(c.prevB) != px_rgb(pb)) {
+            t.flags |= TF_SGR_BG;
+            t.bg = px_rgb(pb);
+          }
+        } else {
+          const bool is256 = MODE == ACHIP_MODE_HB_256;
+          if (!c.state_set || px_key(c.prevT) != px_key(pt)) {
+            t.flags |= TF_SGR_FG;
+            t.fg = is256 ? px_key(pt) : sgr16_code(false, px_key(pt));
+          }
+          if (!c.state_set || px_key(c.prevB) != px_key(pb)) {
+            t.flags |= TF_SGR_BG;
+            t.bg = is256 ? px_key(pb) : sgr16_code(true, px_key(pb));
+          }
+        }
+      }
+    }
+  }
+  /* rainbow_replace_ansi_colors (color_filter.c:348-408) rewrites every ESC[38;2;..m of the finished frame */
+  if (MODE == ACHIP_MODE_HB_TRUE && (ops & ACHIP_OP_FG_OVERRIDE) && (t.flags & TF_SGR_FG))
+    t.fg = ops >> ACHIP_OP_TINT_SHIFT;
+  if (row_end) {
+    if (mode_row_reset(MODE))
+      t.flags |= TF_ROW_RESET;
+    if (!last_row)
+      t.flags |= TF_NL;
+  }
+  return t;
+}
+
+/* the payload of a token whose flags are known: colours and glyph follow from the cell's own pixels (a head's SGRs carry
+ * its own colours; every cell of a run shows its own glyph).  The store pass rebuilds tokens with this from one packed
+ * word per slot {flags:12, rep:12, length:6} instead of holding five registers per slot or deciding everything twice. */
+template <int MODE>
+__device__ inline Tok rows_token_payload(uint32_t flags, uint32_t rep, uint32_t pt, uint32_t pb, uint32_t ops,
+                                         const uint32_t *glyph64) {
+  Tok t;
+  t.flags = flags;
+  t.rep = rep;
+  t.fg = t.bg = t.glyph = 0;
+  if (MODE == ACHIP_MODE_MONO) {
+    t.glyph = glyph64[min(px_key(pt), 63u)];
+  } else if (MODE == ACHIP_MODE_HB_MONO) {
+    const uint32_t lt = (76u * px_r(pt) + 150u * px_g(pt) + 29u * px_b(pt)) >> 8;
+    const uint32_t sh = lt >> 6;
+    t.glyph = 0x0096E2u | ((sh == 3u ? 0x88u : 0x91u + sh) << 16);
+  } else {
+    t.glyph = 0x8096E2u;
+    if (MODE == ACHIP_MODE_HB_TRUE) {
+      t.fg = (ops & ACHIP_OP_FG_OVERRIDE) ? ops >> ACHIP_OP_TINT_SHIFT : px_rgb(pt);
+      t.bg = px_rgb(pb);
+    } else if (MODE == ACHIP_MODE_HB_256) {
+      t.fg = px_key(pt);
+      t.bg = px_key(pb);
+    } else {
+      t.fg = sgr16_code(false, px_key(pt));
+      t.bg = sgr16_code(true, px_key(pb));
+    }
+  }
+  return t;
+}
+
+/* index of the highest set bit of m strictly below bit position `lane`, or -1 */
+__device__ inline int rows_prev_bit(uint64_t m, int lane) {
+  const uint64_t v = m & ((1ull << lane) - 1ull);
+  return v ? 63 - __clzll((long long)v) : -1;
+}
+/* index of the lowest set bit of m strictly above bit position `lane`, or -1 */
+__device__ inline int rows_next_bit(uint64_t m, int lane) {
+  const uint64_t v = lane < 63 ? (m >> (lane + 1)) << (lane + 1) : 0ull;
+  return v ? __ffsll((unsigned long long)v) - 1 : -1;
+}
+
+/* two 512-thread workgroups per CU need <= 128 VGPRs (4 waves per SIMD): left alone the compiler spreads the 7-slot
+ * geometry over 140-180 registers for scheduling freedom it has no use for (the kernel waits on memory, not on issue) */
+/* (not the CRC instantiations: their tables leave room for one workgroup per CU anyway, so they may spread out; nor the
+ * one composite instantiation that would have to spill to get there) */
+template <int MODE, int CPL, bool GENERIC, bool CRC> struct RowsMinWaves {
+  static constexpr int value = (!CRC && !(GENERIC && MODE == ACHIP_MODE_HB_16 && CPL > 4)) ? 4 : 1;
+};
+template <int MODE, int WAVES, int CPL, bool GENERIC, bool CRC = false>
+__global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<MODE, CPL, GENERIC, CRC>::value))
+    render_rows_kernel(const achip_frame_t *__restrict__ frames, const achip_lut_t *__restrict__ lut,
+                       uint8_t *__restrict__ out, uint64_t out_stride, uint32_t *__restrict__ out_len, int n_frames,
+                       achip_uniform_t uni, achip_wire_t wire, const uint4 *__restrict__ crc_tab) {
+  /* uni.flags bits 31..8 (ACHIP_UNIFORM_MAX_CELLS' field) carry the BLOCKS of the launch's largest frame here: the host
+   * knows every frame's row width and rows, and the per-block LDS words are sized by it */
+  static_assert(mode_has_runs(MODE), "per-cell modes use render_stream_kernel");
+  using L = RLds<MODE, WAVES, CRC>;
+  constexpr bool HB = mode_is_halfblock(MODE);
+  constexpr bool HBC = MODE == ACHIP_MODE_HB_TRUE || MODE == ACHIP_MODE_HB_256 || MODE == ACHIP_MODE_HB_16;
+  constexpr int BLOCK = WAVES * 64;
+  constexpr int SLOTS = 64 * CPL;
+  /* token stores as aligned atomic ORs of register-built dwords (PackSink) into a pre-zeroed staging area instead of
+   * byte stores (FastSink): 12 instead of 41 LDS instructions for a half-block truecolor token -- the byte stores of 64
+   * lanes land 41 bytes apart and serialise on bank conflicts (profiles/r01_emit_or.txt; the same switch as the phase
+   * kernel's) */
+  constexpr bool EMIT_OR = ((ACHIP_ROWS_EMIT_OR_MODES) >> MODE) & 1;
+
+  uint32_t *slots = lds_ptr<uint32_t>(L::o_slots);
+  const int tid = (int)threadIdx.x;
+  const int lane = tid & 63, wave = wave_uniform(tid >> 6);
+  const int fidx = (int)blockIdx.x;
+  ACHIP_DEVICE_ONLY(
+      asm volatile("" ::"s"(n_frames), "s"(lut), "s"(out), "s"(out_stride), "s"(out_len), "s"(frames), "s"(uni.enabled),
+                   "s"(uni.flags), "s"(uni.src_pitch), "s"(uni.f.src), "s"(uni.f.comp));
+      asm volatile("" ::"s"(uni.f.src_w), "s"(uni.f.src_h), "s"(uni.f.out_w), "s"(uni.f.out_h), "s"(uni.f.pad_left),
+                   "s"(uni.f.pad_top), "s"(uni.f.x_ratio), "s"(uni.f.y_ratio), "s"(uni.f.src_stride), "s"(uni.f.ops));
+      if (CRC) asm volatile("" ::"s"(wire.crc), "s"(wire.dims), "s"(wire.hdr), "s"(wire.pkt_crc), "s"(crc_tab));)
+  if (fidx >= n_frames)
+    return;
+  constexpr int TABV = L::TAB_BYTES / 16, TABN = (TABV + BLOCK - 1) / BLOCK;
+  typedef uint32_t tab4_t __attribute__((vector_size(16)));
+  tab4_t tabv[TABN > 0 ? TABN : 1];
+  uint32_t dim_w = 0, dim_h = 0;
+  if (CRC && wire.dims) {
+    dim_w = wire.dims[2 * fidx];
+    dim_h = wire.dims[2 * fidx + 1];
+  }
+  if (CRC) {
+#pragma unroll
+    for (int k = 0; k < TABN; k++)
+      tabv[k] = reinterpret_cast<const tab4_t *>(crc_tab)[tid + k * BLOCK < TABV ? tid + k * BLOCK : TABV - 1];
+  }
+  constexpr int LUTN = (256 + BLOCK - 1) / BLOCK;
+  uint32_t lut_g[LUTN];
+#pragma unroll
+  for (int k = 0; k < LUTN; k++)
+    lut_g[k] = tid + k * BLOCK < 256 ? lut->glyph[tid + k * BLOCK] : 0u;
+  const uint32_t lut_g64 = tid < 64 ? lut->glyph64[tid] : 0u;
+  const uint32_t lut_ramp = tid < 64 ? lut->ramp[tid] : 0u;
+  const bool ascii_only = (uni.flags & ACHIP_UNIFORM_PALETTE_ASCII) != 0u;
+  achip_frame_t f = uni.f;
+  if (uni.enabled)
+    f.src = uni.f.src + (int64_t)fidx * uni.src_pitch;
+  else
+    f = frames[fidx];
+  if (f.src_stride == 0)
+    f.src_stride = 3 * f.src_w;
+  uint8_t *dst = out + (size_t)fidx * out_stride;
+
+  const int wp = f.pad_left + f.out_w;
+  const int rows = HB ? (f.out_h + 1) / 2 : f.out_h;
+  const int nblk_cap = stream_maxblk(uni.flags, 1); /* words in each per-block LDS array of this launch */
+  const int rpb = wp > 0 ? SLOTS / wp : 0;          /* text rows per block */
+  const int nblk = rpb > 0 ? (rows + rpb - 1) / rpb : 0;
+  auto bad_frame = [&]() {
+    if (tid == 0) {
+      out_len[fidx] = ACHIP_LEN_BADDESC;
+      if (CRC) {
+        wire.crc[fidx] = 0u;
+        if (wire.hdr)
+          for (int j = 0; j < 24; j++)
+            wire.hdr[(size_t)fidx * 24u + j] = 0;
+        if (wire.pkt_crc)
+          wire.pkt_crc[fidx] = ~crc_mulmod(0xFFFFFFFFu, crc_pow(CRC_X8, 24u));
+      }
+    }
+  };
+  if (f.out_w <= 0 || f.out_h <= 0 || f.src_w <= 0 || f.src_h <= 0 || f.pad_left < 0 || f.pad_top < 0 ||
+      (!f.src && !f.comp) || (!GENERIC && (f.comp || f.src_w * f.src_h == 1)) || rpb < 1 || nblk > nblk_cap ||
+      out_stride > (uint64_t)ACHIP_STREAM_MAX_STRIDE) {
+    bad_frame();
+    return;
+  }
+  const uint32_t cap_bytes = (uint32_t)out_stride;
+  const uint32_t pad_left = (uint32_t)f.pad_left, uwp = (uint32_t)wp;
+  StreamSrc src;
+  src.base = f.src;
+  src.stride = (uint32_t)f.src_stride;
+  src.xr = f.x_ratio;
+  src.yr = f.y_ratio;
+  src.w1 = (uint32_t)f.src_w - 1u;
+  src.h1 = (uint32_t)f.src_h - 1u;
+  src.flip_x = (f.ops & ACHIP_OP_FLIP_X) != 0u;
+  src.flip_y = (f.ops & ACHIP_OP_FLIP_Y) != 0u;
+  src.nt = f.x_ratio >= ((64u << 16) + 2u) / 3u;
+  CompHead chead = {};
+
+  /* slot s = k * 64 + lane of a block is cell s of its rows: row s / wp, column s % wp -- the same for every block, so
+   * one division per lane per frame, then constant steps */
+  const uint32_t q64 = 64u / uwp, r64 = 64u - q64 * uwp;
+  auto advance = [&](CellPos p) {
+    p.xp += r64;
+    p.rr += q64;
+    const bool wrap = p.xp >= uwp;
+    p.xp -= wrap ? uwp : 0u;
+    p.rr += wrap ? 1u : 0u;
+    return p;
+  };
+  CellPos pos0; /* slot k = 0 of this lane, row relative to the block */
+  pos0.rr = (uint32_t)lane / uwp;
+  pos0.xp = (uint32_t)lane - pos0.rr * uwp;
+  auto block_cells = [&](int blk) { return (uint32_t)min(rpb, rows - blk * rpb) * uwp; };
+
+  /* request the samples of block `blk`: nothing here consumes loaded data */
+  auto issue = [&](auto nt_tag, int blk, uint32_t (&rawT)[CPL], uint32_t (&rawB)[CPL], uint32_t &kinds) {
+    constexpr bool NT = decltype(nt_tag)::value;
+    kinds = 0;
+    const uint32_t ncb = block_cells(blk), row0 = (uint32_t)(blk * rpb);
+    CellPos p = pos0;
+#pragma unroll
+    for (int k = 0; k < CPL; k++) {
+      rawT[k] = 0;
+      rawB[k] = 0;
+      if ((uint32_t)(64 * k + lane) < ncb && p.xp >= pad_left) {
+        const uint32_t x = p.xp - pad_left, r = row0 + p.rr;
+        uint32_t kind = RAW_FINAL;
+        rawT[k] = stream_request<GENERIC, NT, L::o_comp>(f, src, x, HB ? 2u * r : r, kind, chead);
+        kinds |= kind << (2 * k);
+        if (HB) {
+          uint32_t kb = RAW_TOP; /* odd height: the last text row's bottom half repeats the top (halfblock.c:81-88) */
+          if (2u * r + 1u < (uint32_t)f.out_h)
+            rawB[k] = stream_request<GENERIC, NT, L::o_comp>(f, src, x, 2u * r + 1u, kb, chead);
+          kinds |= kb << (2 * (CPL + k));
+        }
+      }
+      p = advance(p);
+    }
+  };
+  auto issue_any = [&](int blk, uint32_t (&rawT)[CPL], uint32_t (&rawB)[CPL], uint32_t &kinds) {
+    if (!GENERIC && src.nt)
+      issue(StreamTagNT{}, blk, rawT, rawB, kinds);
+    else
+      issue(StreamTagCached{}, blk, rawT, rawB, kinds);
+  };
+  static_assert(4 * CPL <= 32, "two bits per sample in one word");
+
+  uint32_t rawT[CPL], rawB[CPL], kinds = 0;
+  const bool late_first = GENERIC && f.comp != nullptr;
+  if (late_first)
+    comp_stage<L::o_comp, BLOCK>(f.comp, tid);
+  else if (wave < nblk)
+    issue_any(wave, rawT, rawB, kinds);
+
+  /* tables -> LDS; look-back words of this frame cleared */
+  uint32_t *glyph = lds_ptr<uint32_t>(L::o_glyph);
+  uint32_t *glyph64 = lds_ptr<uint32_t>(L::o_glyph64);
+  uint8_t *ramp = lds_ptr<uint8_t>(L::o_ramp);
+#pragma unroll
+  for (int k = 0; k < LUTN; k++)
+    if (tid + k * BLOCK < 256) {
+      glyph[tid + k * BLOCK] = lut_g[k];
+      lds_ptr<uint32_t>(L::o_dec)[tid + k * BLOCK] = dec_table_entry((uint32_t)(tid + k * BLOCK));
+    }
+  if (tid < 64) {
+    glyph64[tid] = lut_g64;
+    ramp[tid] = (uint8_t)lut_ramp;
+  }
+  for (int k = tid; k < nblk; k += BLOCK)
+    slots[k] = 0u;
+  if (EMIT_OR) /* the OR-filled staging areas start out zero; every slice clears what it used */
+    for (int k = tid; k < WAVES * L::STAGE / 16; k += BLOCK)
+      lds_ptr<uint4>(L::o_stage)[k] = make_uint4(0u, 0u, 0u, 0u);
+  if (CRC) {
+#pragma unroll
+    for (int k = 0; k < TABN; k++)
+      if (tid + k * BLOCK < TABV)
+        lds_ptr<tab4_t>(L::o_tab)[tid + k * BLOCK] = tabv[k];
+    for (int k = tid; k < nblk; k += BLOCK)
+      slots[nblk_cap + k] = 0u;
+    if (tid < 4)
+      lds_ptr<uint32_t>(L::o_crcacc)[tid] = 0u;
+  }
+  const uint32_t first_base = (uint32_t)f.pad_top;
+  if (first_base > 0u && first_base <= cap_bytes)
+    for (uint32_t o = (uint32_t)tid; o < first_base; o += BLOCK)
+      dst[o] = '\n';
+  __syncthreads(); /* the only workgroup barrier */
+  if (late_first) {
+    chead = comp_head<L::o_comp>();
+    if (wave < nblk)
+      issue_any(wave, rawT, rawB, kinds);
+  }
+
+  const uint32_t stage_off = (uint32_t)(L::o_stage + wave * L::STAGE);
+  const uint32_t stage_addr = lds_base_addr() + stage_off;
+  const uint32_t dummy_addr = lds_base_addr() + (uint32_t)L::o_flags + 16u + 4u * (uint32_t)lane;
+  const unsigned char *stage = lds_ptr<const unsigned char>((int)stage_off);
+
+  for (int blk = wave; blk < nblk; blk += WAVES) {
+    uint32_t rawT_n[CPL], rawB_n[CPL], kinds_n = 0;
+    if (blk + WAVES < nblk)
+      issue_any(blk + WAVES, rawT_n, rawB_n, kinds_n);
+
+    const uint32_t ncb = block_cells(blk), row0 = (uint32_t)(blk * rpb);
+    /* ---- samples -> pixels with the mode's run key in bits 31..24 (as the phase kernel parks them in LDS) */
+    uint32_t pt[CPL], pb[CPL];
+    {
+      CellPos p = pos0;
+#pragma unroll
+      for (int k = 0; k < CPL; k++) {
+        const bool pix = (uint32_t)(64 * k + lane) < ncb && p.xp >= pad_left;
+        const uint32_t kt = (kinds >> (2 * k)) & 3u, kb = (kinds >> (2 * (CPL + k))) & 3u;
+        uint32_t t = 0, b = 0;
+        if (pix) {
+          t = sample_finish<GENERIC>(f, rawT[k], kt);
+          if (HB)
+            b = kb == RAW_TOP ? t : sample_finish<GENERIC>(f, rawB[k], kb);
+          if (MODE == ACHIP_MODE_HB_256) {
+            t |= quant256(t) << 24;
+            b |= quant256(b) << 24;
+          } else if (MODE == ACHIP_MODE_HB_16) {
+            t |= quant16(t) << 24;
+            b |= quant16(b) << 24;
+          } else if (MODE == ACHIP_MODE_MONO) {
+            t |= (uint32_t)ramp[luma601(t) >> 2] << 24;
+          }
+        }
+        pt[k] = t;
+        pb[k] = b;
+        p = advance(p);
+      }
+    }
+    /* ---- run heads: one ballot per slot; a cell starts a run at or in front of its row's first pixel, or where its
+     * key differs from its left neighbour's (the lane below; lane 0 takes lane 63 of the slot before) */
+    uint64_t hm[CPL], tm[CPL];
+    auto left_T = [&](int k) { return wave_shift_up1(pt[k], k > 0 ? wave_read_lane(pt[k > 0 ? k - 1 : 0], 63) : 0u); };
+    auto left_B = [&](int k) { return HB ? wave_shift_up1(pb[k], k > 0 ? wave_read_lane(pb[k > 0 ? k - 1 : 0], 63) : 0u) : 0u; };
+    {
+      CellPos p = pos0;
+#pragma unroll
+      for (int k = 0; k < CPL; k++) {
+        const bool valid = (uint32_t)(64 * k + lane) < ncb;
+        const uint32_t lT = left_T(k), lB = left_B(k); /* wave operations: outside the short-circuit below */
+        const bool head = valid && (p.xp <= pad_left || !rows_same_run<MODE>(pt[k], pb[k], lT, lB));
+        hm[k] = wave_ballot(head);
+        const bool thead = head && (px_rgb(pt[k]) | px_rgb(pb[k])) == 0u;
+        tm[k] = HBC ? wave_ballot(thead) : 0ull;
+        p = advance(p);
+      }
+    }
+    /* what the words in front of / behind slot k contribute (wave-uniform): the last head below word k and its
+     * transparency, the first head above word k (the block's end closes the last run) */
+    int h_in[CPL], e_out[CPL];
+    bool t_in[CPL];
+    {
+      int last = -1;
+      bool lt = false;
+#pragma unroll
+      for (int k = 0; k < CPL; k++) {
+        h_in[k] = last;
+        t_in[k] = lt;
+        if (hm[k] != 0ull) {
+          const int b = 63 - __clzll((long long)hm[k]);
+          last = 64 * k + b;
+          lt = ((tm[k] >> b) & 1ull) != 0ull;
+        }
+      }
+      int next = (int)ncb;
+#pragma unroll
+      for (int k = CPL - 1; k >= 0; k--) {
+        e_out[k] = next;
+        if (hm[k] != 0ull)
+          next = 64 * k + __ffsll((unsigned long long)hm[k]) - 1;
+      }
+    }
+    /* ---- the token of slot k.  Built twice -- once for its length, once for the store pass -- from the pixels and the
+     * masks, instead of being held: five registers per slot would put the 7-slot geometry beyond 128 VGPRs, i.e. at one
+     * workgroup per CU instead of two */
+    auto make_tok = [&](int k, CellPos p) {
+      const int s = 64 * k + lane;
+      RunCtx c;
+      c.is_head = ((hm[k] >> lane) & 1ull) != 0ull;
+      const int below = rows_prev_bit(hm[k], lane); /* nearest head strictly below in this word */
+      const int h = c.is_head ? s : (below >= 0 ? 64 * k + below : h_in[k]);
+      const int above = rows_next_bit(hm[k], lane);
+      const int e = above >= 0 ? 64 * k + above : e_out[k];
+      c.run = (uint32_t)(e - h);
+      /* transparency of the run's head; and, for a head behind its row's first pixel, of the previous run's head */
+      const bool t_below = below >= 0 ? ((tm[k] >> below) & 1ull) != 0ull : t_in[k];
+      c.head_transparent = HBC && (c.is_head ? ((tm[k] >> lane) & 1ull) != 0ull : t_below);
+      c.state_set = HBC && c.is_head && p.xp > pad_left && !t_below;
+      c.prevT = left_T(k); /* one DPP move each: cheaper than holding 2 x CPL registers across the block */
+      c.prevB = left_B(k);
+      const bool row_end = (uint32_t)s < ncb && p.xp == uwp - 1u;
+      return rows_token<MODE>(c, pt[k], pb[k], f.ops, glyph64, p.xp < pad_left, row_end, row0 + p.rr >= (uint32_t)rows - 1u);
+    };
+    /* ---- the slices' byte totals (wave-uniform); a cell's own length and offset are recomputed in the store pass --
+     * fourteen registers less across the block than holding them */
+    auto tok_len = [&](int k, const Tok &t) {
+      uint32_t n = 0;
+      if ((uint32_t)(64 * k + lane) < ncb) {
+        CountSink cs{0u};
+        token_fields<MODE>(cs, t, ascii_only);
+        n = cs.n;
+      }
+      return n;
+    };
+    uint32_t stot[CPL], meta[CPL]; /* meta = {flags:12, rep:12, length:6}: what the store pass cannot re-derive cheaply */
+    uint32_t total = 0;
+    {
+      CellPos p = pos0;
+#pragma unroll
+      for (int k = 0; k < CPL; k++) {
+        const Tok t = make_tok(k, p);
+        const uint32_t n = tok_len(k, t);
+        meta[k] = (n ? t.flags : 0u) | (t.rep << 12) | (n << 24);
+        stot[k] = wave_read_lane(wave_inclusive_scan(n), 63);
+        total += stot[k];
+        p = advance(p);
+      }
+    }
+    /* ---- where the block starts in the frame (decoupled look-back over LDS words, as the stream kernel) */
+    uint32_t base = first_base;
+    if (blk > 0) {
+      if (lane == 0)
+        slot_store(&slots[blk], ACHIP_SLOT_AGG | total);
+      base = stream_lookback(slots, blk, lane);
+    }
+    const bool ok = base != 0xFFFFFFFFu && (uint64_t)base + total <= cap_bytes;
+    if (lane == 0)
+      slot_store(&slots[blk], ACHIP_SLOT_PREFIX | (ok ? base + total : cap_bytes + 1u));
+
+    uint32_t braw = 0; /* CRC: register after the block's bytes, starting from 0 */
+    if (ok) {
+      uint32_t a = base; /* stream offset of the slice */
+#pragma unroll
+      for (int k = 0; k < CPL; k++) {
+        const uint32_t n = stot[k];
+        if (n == 0u)
+          continue;
+        const uint32_t len_k = meta[k] >> 24;
+        const uint32_t off_k = wave_inclusive_scan(len_k) - len_k; /* within the slice */
+        const Tok tk = rows_token_payload<MODE>(meta[k] & 0xFFFu, (meta[k] >> 12) & 0xFFFu, pt[k], pb[k], f.ops, glyph64);
+        /* ---- the slice's tokens into this wave's staging area: stream offset g0 (16-byte aligned) sits at its byte 0 */
+        const uint32_t g0 = a & ~15u;
+        if (CRC && !EMIT_OR && lane == 0) /* the bytes in front of the slice inside its first group read as zero for the checksum */
+          *lds_ptr<uint4>((int)stage_off) = make_uint4(0u, 0u, 0u, 0u);
+        if (len_k != 0u) {
+          if (EMIT_OR) {
+            PackSink<L::o_dec> ps(stage_addr + (a + off_k - g0));
+            token_fields<MODE>(ps, tk, ascii_only);
+            ps.finish();
+          } else {
+            FastSink<L::o_dec, L::o_flags + 16> fs{stage_addr + (a + off_k - g0), dummy_addr};
+            token_fields<MODE>(fs, tk, ascii_only);
+          }
+        }
+        lds_store_fence();
+        /* ---- staging -> HBM: whole 16-byte groups as uint4, the shared first / last group as bytes */
+        const uint32_t end = a + n;
+        const uint32_t vec_begin = (a + 15u) & ~15u, vec_end = end & ~15u;
+        for (uint32_t o = vec_begin + 16u * (uint32_t)lane; o < vec_end; o += 1024u)
+          store_out16(dst + o, *reinterpret_cast<const uint4 *>(stage + (o - g0)));
+        const uint32_t head_end = min(vec_begin, end);
+        if (a + (uint32_t)lane < head_end)
+          dst[a + (uint32_t)lane] = stage[a + (uint32_t)lane - g0];
+        const uint32_t tail_begin = max(vec_end, head_end);
+        if (lane >= 32 && tail_begin + (uint32_t)(lane - 32) < end)
+          dst[tail_begin + (uint32_t)(lane - 32)] = stage[tail_begin + (uint32_t)(lane - 32) - g0];
+        wave_lockstep(); /* the next slice's tokens go where these bytes were read from */
+        if (CRC) { /* raw(block so far || slice) = raw(block so far) * x^(8 n) xor raw(slice): both wave-uniform */
+          const uint32_t xk = lds_ptr<const uint32_t>(L::o_xk)[lane];
+          const uint32_t sraw = stream_crc_staged<L>(stage, (a & 15u) + n, lane);
+          braw = braw ? wave_mulmod_uniform(braw, wave_x8_pow_uniform(lds_ptr<const uint32_t>(L::o_pow), n, lane, xk), lane, xk) ^ sraw
+                      : sraw;
+        }
+        if (EMIT_OR) { /* the next slice ORs into zeros */
+          const uint32_t used = ((a & 15u) + n + 15u) >> 4;
+          for (uint32_t g = (uint32_t)lane; g < used; g += 64u)
+            lds_ptr<uint4>((int)stage_off)[g] = make_uint4(0u, 0u, 0u, 0u);
+          wave_lockstep();
+        }
+        a = end;
+      }
+    }
+    if (blk == nblk - 1 && lane == 0) {
+      out_len[fidx] = ok ? base + total : ACHIP_LEN_OVERFLOW;
+      if (ok && (uint64_t)base + total < out_stride)
+        dst[base + total] = 0; /* NUL behind the frame when the slot has room, as the reference's strings carry */
+    }
+    if (CRC) {
+      if (ok)
+        stream_crc_place<L>(slots, nblk, nblk_cap, blk, braw, base + total, cap_bytes, lane);
+      stream_crc_finish<L>(slots, nblk, nblk_cap, cap_bytes, first_base, fidx, dim_w, dim_h, wire, lane);
+    }
+
+    kinds = kinds_n;
+#pragma unroll
+    for (int k = 0; k < CPL; k++) {
+      rawT[k] = rawT_n[k];
+      rawB[k] = rawB_n[k];
+    }
+  }
+  (void)glyph;
+}
+
+} // namespace achip

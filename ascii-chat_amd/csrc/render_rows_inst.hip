@@ -1,7 +1,7 @@
 /*
- * render_stream_inst.hip -- instantiates the stream kernel (render_stream.hpp) for ONE geometry
- * (-DACHIP_SINST=<variant id>): four per-cell modes x {plain, composite sampler}.  One translation unit per
- * geometry so that the build runs in parallel.  Built only with hipcc --offload-arch=gfx950.
+ * render_rows_inst.hip -- instantiates the rows kernel (render_rows.hpp) for ONE geometry (-DACHIP_RINST=<variant id>):
+ * the five run-structured modes x {plain, composite sampler} x {plain, frame CRC riding the drain}.  One translation unit
+ * per geometry so that the build runs in parallel.  Built only with hipcc --offload-arch=gfx950.
  */
 #include <hip/hip_runtime.h>
 
@@ -9,33 +9,32 @@
 
 #include "render_inst.h"
 #define ACHIP_FRAME_KERNEL_ONLY
-#include "render_stream.hpp"
+#include "render_rows.hpp"
 #include "render_variants.h"
 
-#ifndef ACHIP_SINST
-#error "compile with -DACHIP_SINST=<stream variant id>"
+#ifndef ACHIP_RINST
+#error "compile with -DACHIP_RINST=<rows variant id>"
 #endif
 
 namespace {
 
-template <int ID> struct SGeometry;
+template <int ID> struct RGeometry;
 #define X(id, W, C)                                                                                                    \
-  template <> struct SGeometry<id> {                                                                                   \
+  template <> struct RGeometry<id> {                                                                                   \
     static constexpr int WAVES = W, CPL = C;                                                                           \
   };
-ACHIP_STREAM_VARIANTS(X)
+ACHIP_ROWS_VARIANTS(X)
 #undef X
-using G = SGeometry<ACHIP_SINST>;
+using G = RGeometry<ACHIP_RINST>;
 
-/* the frame CRC rides the drain (CRC = true) in the two geometries the policy picks by itself */
-constexpr bool HAS_CRC = ACHIP_SINST == 16 || ACHIP_SINST == 17;
+constexpr bool HAS_CRC = true, HAS_COMP = true; /* (a 1024-thread geometry would have neither: 128-VGPR cap) */
 
 /* the constant tables of <MODE>'s CRC instantiation: built on the device once per process, then read-only */
 template <int MODE> hipError_t crc_tables(const uint4 **out) {
-  using L = achip::SLds<MODE, G::WAVES, G::CPL, true>;
+  using L = achip::RLds<MODE, G::WAVES, true>;
   constexpr int MAX_DEVICES = 16;
   static std::mutex mu;
-  static uint32_t *tab[MAX_DEVICES] = {}; /* one image per device of the process */
+  static uint32_t *tab[MAX_DEVICES] = {};
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess)
@@ -51,7 +50,7 @@ template <int MODE> hipError_t crc_tables(const uint4 **out) {
     hipLaunchKernelGGL((achip::crc_tables_init_kernel<L>), dim3(1), dim3(256), 0, nullptr, t);
     e = hipGetLastError();
     if (e == hipSuccess)
-      e = hipDeviceSynchronize(); /* launches on every stream may read it from here on */
+      e = hipDeviceSynchronize();
     if (e != hipSuccess) {
       (void)hipFree(t);
       return e;
@@ -64,10 +63,9 @@ template <int MODE> hipError_t crc_tables(const uint4 **out) {
 
 template <int MODE, bool COMP, bool CRC>
 hipError_t launch_one(const achip_frame_t *frames, int n, const achip_lut_t *lut, uint8_t *out, uint64_t stride,
-                      uint32_t *len, const achip_uniform_t &uni, unsigned long long *prof, const achip_wire_t &wire,
-                      hipStream_t stream) {
-  using L = achip::SLds<MODE, G::WAVES, G::CPL, CRC>;
-  auto kern = achip::render_stream_kernel<MODE, G::WAVES, G::CPL, COMP, CRC>;
+                      uint32_t *len, const achip_uniform_t &uni, const achip_wire_t &wire, hipStream_t stream) {
+  using L = achip::RLds<MODE, G::WAVES, CRC>;
+  auto kern = achip::render_rows_kernel<MODE, G::WAVES, G::CPL, COMP, CRC>;
   static bool attr_set = false; /* one flag per instantiation; benign race (idempotent call) */
   if (!attr_set) {
     if (L::bytes > 48 * 1024) {
@@ -84,11 +82,10 @@ hipError_t launch_one(const achip_frame_t *frames, int n, const achip_lut_t *lut
     if (e != hipSuccess)
       return e;
   }
-  /* the per-block words are sized by the launch's largest frame when the host states it: a small footprint lets
-   * workgroups of launches in flight on other streams share a CU */
-  const size_t lds = (size_t)((L::bytes_for(achip::stream_maxblk(uni.flags, L::EFF)) + 15) & ~15);
-  hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(G::WAVES * 64), lds, stream, frames, lut, out, stride, len, n, uni,
-                     prof, wire, tab);
+  /* uni.flags carries the blocks of the launch's largest frame (achip_rows_max_blocks): the per-block words */
+  const size_t lds = (size_t)((L::bytes_for(achip::stream_maxblk(uni.flags, 1)) + 15) & ~15);
+  hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(G::WAVES * 64), lds, stream, frames, lut, out, stride, len, n, uni, wire,
+                     tab);
   return hipGetLastError();
 }
 
@@ -97,48 +94,54 @@ hipError_t launch_one(const achip_frame_t *frames, int n, const achip_lut_t *lut
 #define ACHIP_CAT2(a, b) a##b
 #define ACHIP_CAT(a, b) ACHIP_CAT2(a, b)
 
-extern "C" int ACHIP_CAT(achip_render_sinst_launch_, ACHIP_SINST)(int mode, int comp, const achip_frame_t *frames, int n,
+extern "C" int ACHIP_CAT(achip_render_rinst_launch_, ACHIP_RINST)(int mode, int comp, const achip_frame_t *frames, int n,
                                                                   const achip_lut_t *lut, uint8_t *out, uint64_t stride,
                                                                   uint32_t *len, const achip_uniform_t *uniform,
-                                                                  unsigned long long *prof, const achip_wire_t *wire,
-                                                                  void *stream) {
+                                                                  const achip_wire_t *wire, void *stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   achip_uniform_t uni = {};
   if (uniform && uniform->enabled && !comp)
     uni = *uniform;
   if (uniform)
-    uni.flags = uniform->flags; /* launch-wide facts travel even when the descriptors come from the device array */
+    uni.flags = uniform->flags;
   switch (mode) {
 #define M(m)                                                                                                           \
   case m:                                                                                                              \
     if (wire) {                                                                                                        \
       if constexpr (HAS_CRC)                                                                                           \
         return (int)(!wire->crc ? hipErrorInvalidValue                                                                 \
-                     : comp     ? launch_one<m, true, true>(frames, n, lut, out, stride, len, uni, prof, *wire, s)     \
-                                : launch_one<m, false, true>(frames, n, lut, out, stride, len, uni, prof, *wire, s));  \
+                     : comp     ? launch_one<m, true, true>(frames, n, lut, out, stride, len, uni, *wire, s)           \
+                                : launch_one<m, false, true>(frames, n, lut, out, stride, len, uni, *wire, s));        \
       else                                                                                                             \
         return (int)hipErrorInvalidValue;                                                                              \
     }                                                                                                                  \
-    return (int)(comp ? launch_one<m, true, false>(frames, n, lut, out, stride, len, uni, prof, achip_wire_t{}, s)     \
-                      : launch_one<m, false, false>(frames, n, lut, out, stride, len, uni, prof, achip_wire_t{}, s));
-    M(ACHIP_MODE_TRUE_FG)
-    M(ACHIP_MODE_256_FG)
-    M(ACHIP_MODE_16_FG)
-    M(ACHIP_MODE_TRUE_BG)
+    if (comp) {                                                                                                        \
+      if constexpr (HAS_COMP)                                                                                          \
+        return (int)launch_one<m, true, false>(frames, n, lut, out, stride, len, uni, achip_wire_t{}, s);              \
+      else                                                                                                             \
+        return (int)hipErrorInvalidValue;                                                                              \
+    }                                                                                                                  \
+    return (int)launch_one<m, false, false>(frames, n, lut, out, stride, len, uni, achip_wire_t{}, s);
+    M(ACHIP_MODE_MONO)
+    M(ACHIP_MODE_HB_TRUE)
+    M(ACHIP_MODE_HB_256)
+    M(ACHIP_MODE_HB_16)
+    M(ACHIP_MODE_HB_MONO)
 #undef M
   }
   return (int)hipErrorInvalidValue;
 }
 
-extern "C" int ACHIP_CAT(achip_render_sinst_lds_, ACHIP_SINST)(int mode) {
+extern "C" int ACHIP_CAT(achip_render_rinst_lds_, ACHIP_RINST)(int mode) {
   switch (mode) {
 #define M(m)                                                                                                           \
   case m:                                                                                                              \
-    return achip::SLds<m, G::WAVES, G::CPL>::bytes;
-    M(ACHIP_MODE_TRUE_FG)
-    M(ACHIP_MODE_256_FG)
-    M(ACHIP_MODE_16_FG)
-    M(ACHIP_MODE_TRUE_BG)
+    return achip::RLds<m, G::WAVES>::bytes;
+    M(ACHIP_MODE_MONO)
+    M(ACHIP_MODE_HB_TRUE)
+    M(ACHIP_MODE_HB_256)
+    M(ACHIP_MODE_HB_16)
+    M(ACHIP_MODE_HB_MONO)
 #undef M
   }
   return -1;

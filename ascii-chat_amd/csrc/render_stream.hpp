@@ -208,11 +208,10 @@ __device__ inline uint32_t crc_advance16(const uint32_t *slice, uint32_t s, int 
   return r;
 }
 
-/* The constant tables of the CRC instantiation <MODE, WAVES, CPL>, written once per process into global memory (one
- * workgroup of 256 threads; render_stream_inst.hip runs it before the first such launch); every launch copies the
- * image into LDS.  Layout = SLds<.., true> from o_tab on. */
-template <int MODE, int WAVES, int CPL> __global__ void __launch_bounds__(256) crc_tables_init_kernel(uint32_t *tab) {
-  using L = SLds<MODE, WAVES, CPL, true>;
+/* The constant tables of a CRC instantiation with LDS layout L (SLds<.., true> here, RLds<.., true> in render_rows.hpp),
+ * written once per process into global memory (one workgroup of 256 threads; the launchers run it before the first such
+ * launch); every launch copies the image into LDS.  Layout = L from o_tab on. */
+template <class L> __global__ void __launch_bounds__(256) crc_tables_init_kernel(uint32_t *tab) {
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   uint32_t *slice = tab + (L::o_slice - L::o_tab) / 4;
   uint32_t *nib = tab + (L::o_lanek - L::o_tab) / 4;
@@ -257,6 +256,134 @@ template <int MODE, int WAVES, int CPL> __global__ void __launch_bounds__(256) c
   for (int k = 1; k < 16; k++) {
     v = (v >> 8) ^ slice[v & 0xFFu];
     slice[k * 256 + tid] = v;
+  }
+}
+
+/* ---- the fused frame CRC, shared by the wave-autonomous kernels (this file and render_rows.hpp).  L = the kernel's
+ * LDS layout: o_slice / o_lanek / o_pow / o_xk (constant tables), o_crcacc ([0] accumulator, [1] deferred blocks,
+ * [2] finished blocks), GPL / WIN / NWIN ------------------------------------------------------------------------------ */
+/* Raw CRC (the register after the bytes, starting from 0) of the bytes a wave has staged at [p0, end_off) of `stage`;
+ * [0, p0) reads as zero (leading zeros do not move a zero register).  Whole 16-byte groups: lane l folds GPL consecutive
+ * groups Horner-style, the groups aligned to the END of the bytes so that absent ones are leading zeros; sreg * K_l
+ * through the window tables, one xor reduction over the lanes; the < 16 tail bytes come in through the slicing rows. */
+template <class L> __device__ inline uint32_t stream_crc_staged(const unsigned char *stage, uint32_t end_off, int lane) {
+  const uint32_t *slice = lds_ptr<const uint32_t>(L::o_slice);
+  const int m_full = (int)(end_off >> 4), tail = (int)(end_off & 15u);
+  constexpr int GPL = L::GPL;
+  const int shift = 64 * GPL - m_full;
+  uint32_t sreg = 0;
+#pragma unroll
+  for (int k = 0; k < GPL; k++) {
+    const int g = lane * GPL + k - shift;
+    uint4 d = make_uint4(0u, 0u, 0u, 0u);
+    if (g >= 0)
+      d = *reinterpret_cast<const uint4 *>(stage + 16 * g);
+    d.x ^= sreg; /* the register so far goes in with the next 16 bytes: slicing-by-16, no multiplication */
+    sreg = crc_raw16(slice, d);
+  }
+  const uint32_t *nib = lds_ptr<const uint32_t>(L::o_lanek);
+  uint32_t term = 0;
+#pragma unroll
+  for (int j = 0; j < L::NWIN; j++)
+    term ^= nib[(j * (1 << L::WIN) + (int)((sreg >> (32 - L::WIN * (j + 1))) & ((1u << L::WIN) - 1u))) * 64 + lane];
+  const uint32_t full = wave_read_lane(wave_xor_to_last(term), 63);
+  /* the < 16 tail bytes: the register moves on by `tail` bytes; tail byte j is followed by tail-1-j bytes */
+  uint32_t tb = 0;
+  if (lane < tail)
+    tb = slice[(tail - 1 - lane) * 256 + stage[16 * m_full + lane]];
+  return crc_advance16(slice, full, tail) ^ wave_read_lane(wave_xor_to_last(tb), 63);
+}
+/* Place a block's raw CRC in the frame: * x^(8 * bytes behind it).  The frame's length is the last block's prefix, known
+ * as soon as every wave has tokenised -- usually long before a wave gets here; a block that cannot be placed yet leaves
+ * its raw value (in the words behind the look-back words) for the wave that finishes the frame. */
+template <class L>
+__device__ inline void stream_crc_place(uint32_t *slots, int nblk, int nblk_cap, int blk, uint32_t braw, uint32_t block_end,
+                                        uint32_t cap_bytes, int lane) {
+  const uint32_t *pw = lds_ptr<const uint32_t>(L::o_pow);
+  uint32_t *crcacc = lds_ptr<uint32_t>(L::o_crcacc);
+  const uint32_t xk = lds_ptr<const uint32_t>(L::o_xk)[lane];
+  const uint32_t lastw = slot_load(&slots[nblk - 1]);
+  if ((lastw >> 30) == 2u) {
+    const uint32_t n_total = lastw & ACHIP_SLOT_VALUE;
+    if (n_total <= cap_bytes) {
+      const uint32_t placed = wave_mulmod_uniform(braw, wave_x8_pow_uniform(pw, n_total - block_end, lane, xk), lane, xk);
+      if (lane == 0)
+        slot_xor(&crcacc[0], placed);
+    }
+  } else if (lane == 0) {
+    (slots + nblk_cap)[blk] = braw;
+    (void)slot_fetch_add(&crcacc[1], 1u);
+  }
+}
+/* Every block reports here once it is done; the last one completes the frame: crc(M) = ~(0xFFFFFFFF * x^(8|M|) xor
+ * raw(M)), M = pad_top newlines || block 0 || block 1 || ...  (every prefix is in the look-back words by then), and --
+ * when asked for -- the frame's 24-byte network-order header and the CRC of header || frame. */
+template <class L>
+__device__ inline void stream_crc_finish(uint32_t *slots, int nblk, int nblk_cap, uint32_t cap_bytes, uint32_t first_base,
+                                         int fidx, uint32_t dim_w, uint32_t dim_h, const achip_wire_t &wire, int lane) {
+  const uint32_t *slice = lds_ptr<const uint32_t>(L::o_slice);
+  const uint32_t *pw = lds_ptr<const uint32_t>(L::o_pow);
+  uint32_t *crcval = slots + nblk_cap;
+  uint32_t *crcacc = lds_ptr<uint32_t>(L::o_crcacc);
+  const uint32_t xk = lds_ptr<const uint32_t>(L::o_xk)[lane];
+  uint32_t arrived = 0;
+  if (lane == 0)
+    arrived = slot_fetch_add(&crcacc[2], 1u);
+  arrived = wave_read_lane(arrived, 0);
+  if (arrived != (uint32_t)nblk - 1u)
+    return;
+  const uint32_t n_total = slot_load(&slots[nblk - 1]) & ACHIP_SLOT_VALUE;
+  const bool fits = n_total <= cap_bytes;
+  const uint32_t xn = fits ? wave_x8_pow_uniform(pw, n_total, lane, xk) : CRC_X0; /* x^(8 * frame length) */
+  uint32_t fraw = 0; /* raw(M): the register after the frame starting from 0 */
+  if (fits) {
+    if (first_base > 0u) { /* ascii_pad_frame_height's newlines in front: lanes take runs of them */
+      const uint32_t per = (first_base + 63u) / 64u;
+      const uint32_t lo = (uint32_t)lane * per, hi = lo + per < first_base ? lo + per : first_base;
+      uint32_t st = 0;
+      for (uint32_t k = lo; k < hi; k++)
+        st = (st >> 8) ^ slice[(st ^ (uint32_t)'\n') & 0xFFu];
+      if (lo < hi)
+        st = crc_mulmod(st, crc_x8_pow_len(n_total - hi));
+      fraw ^= wave_read_lane(wave_xor_to_last(lo < hi ? st : 0u), 63);
+    }
+    if (slot_load(&crcacc[1]) != 0u) { /* blocks that finished before the frame's length was known */
+      uint32_t acc = 0;
+      for (int b0 = 0; b0 < nblk; b0 += 64) {
+        const int b = b0 + lane;
+        const uint32_t v = b < nblk ? crcval[b] : 0u;
+        if (v != 0u)
+          acc ^= crc_mulmod(v, crc_x8_pow_len(n_total - (slot_load(&slots[b]) & ACHIP_SLOT_VALUE)));
+      }
+      fraw ^= wave_read_lane(wave_xor_to_last(acc), 63);
+    }
+    fraw ^= slot_load(&crcacc[0]);
+  }
+  const uint32_t crc = fits ? ~(wave_mulmod_uniform(0xFFFFFFFFu, xn, lane, xk) ^ fraw) : 0u;
+  if (lane == 0)
+    wire.crc[fidx] = crc;
+  if (wire.hdr || wire.pkt_crc) {
+    /* ascii_frame_packet_t in network byte order (lib/network/acip/server.c:186-214): {width, height, original_size,
+     * compressed_size = 0, checksum, flags = 0}; an unusable frame gets a header of zeros, as the stand-alone kernel
+     * reports it.  Lane j < 24 owns header byte j. */
+    const int wi = lane >> 2;
+    const uint32_t word = !fits ? 0u : wi == 0 ? dim_w : wi == 1 ? dim_h : wi == 2 ? n_total : wi == 4 ? crc : 0u;
+    const uint32_t hb = lane < 24 ? (word >> (8 * (3 - (lane & 3)))) & 0xFFu : 0u;
+    if (wire.hdr && lane < 24)
+      wire.hdr[(size_t)fidx * 24u + (size_t)lane] = (uint8_t)hb;
+    if (wire.pkt_crc) {
+      /* CRC of header || frame (packet_send_via_transport, send.c:59-69) = ~(S_h * x^(8n) xor raw(M)) with S_h the
+       * register after the header from 0xFFFFFFFF: bytes 0..7 through slicing rows 7..0 and on by 16 bytes, bytes
+       * 8..23 through rows 15..0 */
+      const uint32_t v = lane < 8 ? slice[(7 - lane) * 256 + hb] : lane < 24 ? slice[(23 - lane) * 256 + hb] : 0u;
+      const uint32_t ra = wave_read_lane(wave_xor_to_last(lane < 8 ? v : 0u), 63);
+      const uint32_t rb = wave_read_lane(wave_xor_to_last(lane >= 8 ? v : 0u), 63);
+      constexpr uint32_t INIT24 = crc_mulmod(0xFFFFFFFFu, crc_pow(CRC_X8, 24u));
+      const uint32_t sh = INIT24 ^ crc_advance16(slice, ra, 16) ^ rb;
+      const uint32_t pkt = ~(wave_mulmod_uniform(sh, xn, lane, xk) ^ fraw);
+      if (lane == 0)
+        wire.pkt_crc[fidx] = pkt;
+    }
   }
 }
 
@@ -653,123 +780,13 @@ __global__ void __launch_bounds__(WAVES * 64)
         dst[base + total] = 0; /* NUL behind the frame when the slot has room, as the reference's strings carry */
     }
     if (CRC) {
-      /* ---- raw CRC of the block, from the staging area (after the stores to HBM have been issued).  Its bytes sit
-       * at [p0, end_off) of the area; [0, p0) is zero.  Whole 16-byte groups: lane l folds GPL consecutive groups
-       * Horner-style, the groups aligned to the END of the block so that absent ones are leading zeros; a 6-level
-       * wave tree with constant multipliers combines the lanes; the < 16 tail bytes come in through the slicing
-       * tables with one variable multiplication. */
-      const uint32_t *slice = lds_ptr<const uint32_t>(L::o_slice);
-      const uint32_t *pw = lds_ptr<const uint32_t>(L::o_pow);
-      uint32_t *crcval = slots + nblk_cap;
-      uint32_t *crcacc = lds_ptr<uint32_t>(L::o_crcacc);
-      const uint32_t xk = lds_ptr<const uint32_t>(L::o_xk)[lane];
+      /* ---- raw CRC of the block, from the staging area (after the stores to HBM have been issued), placed in the
+       * frame; the last block to finish completes the frame (stream_crc_* above) */
       if (ok) {
-        const unsigned char *stage = lds_ptr<const unsigned char>((int)stage_off);
-        const uint32_t end_off = (base & 15u) + total;
-        const int m_full = (int)(end_off >> 4), tail = (int)(end_off & 15u);
-        constexpr int GPL = L::GPL;
-        const int shift = 64 * GPL - m_full;
-        uint32_t sreg = 0;
-#pragma unroll
-        for (int k = 0; k < GPL; k++) {
-          const int g = lane * GPL + k - shift;
-          uint4 d = make_uint4(0u, 0u, 0u, 0u);
-          if (g >= 0)
-            d = *reinterpret_cast<const uint4 *>(stage + 16 * g);
-          d.x ^= sreg; /* the register so far goes in with the next 16 bytes: slicing-by-16, no multiplication */
-          sreg = crc_raw16(slice, d);
-        }
-        /* sreg * K_l through the window tables, xor over the lanes = raw CRC of the whole groups */
-        const uint32_t *nib = lds_ptr<const uint32_t>(L::o_lanek);
-        uint32_t term = 0;
-#pragma unroll
-        for (int j = 0; j < L::NWIN; j++)
-          term ^= nib[(j * (1 << L::WIN) + (int)((sreg >> (32 - L::WIN * (j + 1))) & ((1u << L::WIN) - 1u))) * 64 + lane];
-        const uint32_t full = wave_read_lane(wave_xor_to_last(term), 63);
-        /* the < 16 tail bytes: the register moves on by `tail` bytes; tail byte j is followed by tail-1-j bytes */
-        uint32_t tb = 0;
-        if (lane < tail)
-          tb = slice[(tail - 1 - lane) * 256 + stage[16 * m_full + lane]];
-        const uint32_t braw = crc_advance16(slice, full, tail) ^ wave_read_lane(wave_xor_to_last(tb), 63);
-        /* place the block in the frame: * x^(8 * bytes behind it).  The frame's length is the last block's prefix,
-         * known as soon as every wave has tokenised -- usually long before a wave gets here; a block that cannot be
-         * placed yet leaves its raw value for the wave that finishes the frame. */
-        const uint32_t lastw = slot_load(&slots[nblk - 1]);
-        if ((lastw >> 30) == 2u) {
-          const uint32_t n_total = lastw & ACHIP_SLOT_VALUE;
-          if (n_total <= cap_bytes) {
-            const uint32_t placed =
-                wave_mulmod_uniform(braw, wave_x8_pow_uniform(pw, n_total - (base + total), lane, xk), lane, xk);
-            if (lane == 0)
-              slot_xor(&crcacc[0], placed);
-
-          }
-        } else if (lane == 0) {
-          crcval[blk] = braw;
-          (void)slot_fetch_add(&crcacc[1], 1u);
-        }
+        const uint32_t braw = stream_crc_staged<L>(lds_ptr<const unsigned char>((int)stage_off), (base & 15u) + total, lane);
+        stream_crc_place<L>(slots, nblk, nblk_cap, blk, braw, base + total, cap_bytes, lane);
       }
-      uint32_t arrived = 0;
-      if (lane == 0)
-        arrived = slot_fetch_add(&crcacc[2], 1u);
-      arrived = wave_read_lane(arrived, 0);
-      if (arrived == (uint32_t)nblk - 1u) {
-        /* the last block to finish completes the frame: crc(M) = ~(0xFFFFFFFF * x^(8|M|) xor raw(M)), M = pad_top
-         * newlines || block 0 || block 1 || ...  Every prefix is in the look-back words by now. */
-        const uint32_t n_total = slot_load(&slots[nblk - 1]) & ACHIP_SLOT_VALUE;
-        const bool fits = n_total <= cap_bytes;
-        const uint32_t xn = fits ? wave_x8_pow_uniform(pw, n_total, lane, xk) : CRC_X0; /* x^(8 * frame length) */
-        uint32_t fraw = 0; /* raw(M): the register after the frame starting from 0 */
-        if (fits) {
-          if (first_base > 0u) { /* ascii_pad_frame_height's newlines in front: lanes take runs of them */
-            const uint32_t per = (first_base + 63u) / 64u;
-            const uint32_t lo = (uint32_t)lane * per, hi = lo + per < first_base ? lo + per : first_base;
-            uint32_t st = 0;
-            for (uint32_t k = lo; k < hi; k++)
-              st = (st >> 8) ^ slice[(st ^ (uint32_t)'\n') & 0xFFu];
-            if (lo < hi)
-              st = crc_mulmod(st, crc_x8_pow_len(n_total - hi));
-            fraw ^= wave_read_lane(wave_xor_to_last(lo < hi ? st : 0u), 63);
-          }
-          if (slot_load(&crcacc[1]) != 0u) { /* blocks that finished before the frame's length was known */
-            uint32_t acc = 0;
-            for (int b0 = 0; b0 < nblk; b0 += 64) {
-              const int b = b0 + lane;
-              const uint32_t v = b < nblk ? crcval[b] : 0u;
-              if (v != 0u)
-                acc ^= crc_mulmod(v, crc_x8_pow_len(n_total - (slot_load(&slots[b]) & ACHIP_SLOT_VALUE)));
-            }
-            fraw ^= wave_read_lane(wave_xor_to_last(acc), 63);
-          }
-          fraw ^= slot_load(&crcacc[0]);
-        }
-        const uint32_t crc = fits ? ~(wave_mulmod_uniform(0xFFFFFFFFu, xn, lane, xk) ^ fraw) : 0u;
-        if (lane == 0)
-          wire.crc[fidx] = crc;
-        if (wire.hdr || wire.pkt_crc) {
-          /* ascii_frame_packet_t in network byte order (lib/network/acip/server.c:186-214): {width, height,
-           * original_size, compressed_size = 0, checksum, flags = 0}; an unusable frame gets a header of zeros, as the
-           * stand-alone kernel reports it.  Lane j < 24 owns header byte j. */
-          const int wi = lane >> 2;
-          const uint32_t word = !fits ? 0u : wi == 0 ? dim_w : wi == 1 ? dim_h : wi == 2 ? n_total : wi == 4 ? crc : 0u;
-          const uint32_t hb = lane < 24 ? (word >> (8 * (3 - (lane & 3)))) & 0xFFu : 0u;
-          if (wire.hdr && lane < 24)
-            wire.hdr[(size_t)fidx * 24u + (size_t)lane] = (uint8_t)hb;
-          if (wire.pkt_crc) {
-            /* CRC of header || frame (packet_send_via_transport, send.c:59-69) = ~(S_h * x^(8n) xor raw(M)) with S_h the
-             * register after the header from 0xFFFFFFFF: bytes 0..7 through slicing rows 7..0 and on by 16 bytes,
-             * bytes 8..23 through rows 15..0 */
-            const uint32_t v = lane < 8 ? slice[(7 - lane) * 256 + hb] : lane < 24 ? slice[(23 - lane) * 256 + hb] : 0u;
-            const uint32_t ra = wave_read_lane(wave_xor_to_last(lane < 8 ? v : 0u), 63);
-            const uint32_t rb = wave_read_lane(wave_xor_to_last(lane >= 8 ? v : 0u), 63);
-            constexpr uint32_t INIT24 = crc_mulmod(0xFFFFFFFFu, crc_pow(CRC_X8, 24u));
-            const uint32_t sh = INIT24 ^ crc_advance16(slice, ra, 16) ^ rb;
-            const uint32_t pkt = ~(wave_mulmod_uniform(sh, xn, lane, xk) ^ fraw);
-            if (lane == 0)
-              wire.pkt_crc[fidx] = pkt;
-          }
-        }
-      }
+      stream_crc_finish<L>(slots, nblk, nblk_cap, cap_bytes, first_base, fidx, dim_w, dim_h, wire, lane);
     }
 
     if (CRC && prof && lane == 0 && stamp_crc)

@@ -39,6 +39,24 @@
   X(18, 4, 2)  /* 256 threads                                                                                   */ \
   X(19, 16, 1) /* 1024 threads, one cell per lane: fewest registers                                             */ \
   ACHIP_STREAM_TEST_VARIANT(X)
-#define ACHIP_IS_STREAM_VARIANT(v) ((v) >= ACHIP_STREAM_VARIANT_FIRST)
+#define ACHIP_ROWS_VARIANT_FIRST 24
+#define ACHIP_IS_STREAM_VARIANT(v) ((v) >= ACHIP_STREAM_VARIANT_FIRST && (v) < ACHIP_ROWS_VARIANT_FIRST)
+
+/* Geometries of the wave-autonomous kernel of the run-structured modes (render_rows.hpp; mono, half blocks; whole-frame
+ * launches): a block is a whole number of text rows taken through the path by ONE wave, so a padded row must fit
+ * 64 * CPL cells.
+ *   WAVES  waves per workgroup (one workgroup renders one frame)
+ *   CPL    cells per lane per block
+ * X(id, WAVES, CPL) */
+#ifdef ACHIP_TEST_GEOMETRY /* emulator builds only: two-row blocks of tiny frames, many blocks per wave */
+#define ACHIP_ROWS_TEST_VARIANT(X) X(28, 2, 2)
+#else
+#define ACHIP_ROWS_TEST_VARIANT(X)
+#endif
+#define ACHIP_ROWS_VARIANTS(X)                                                                                    \
+  X(24, 8, 7) /* rows up to 448 cells: 4K -> 400x120 half blocks is one row per block (89 % of the slots)        */ \
+  X(25, 8, 4) /* rows up to 256 cells: 200x60, 160x48 one row per block; three 80-cell rows per block             */ \
+  ACHIP_ROWS_TEST_VARIANT(X)
+#define ACHIP_IS_ROWS_VARIANT(v) ((v) >= ACHIP_ROWS_VARIANT_FIRST)
 
 #endif

@@ -49,6 +49,7 @@ WORKLOADS = {
     "1080p_80x24_ansi256": (1920, 1080, 80, 24, 2, 0),    # configs[1] (K2)
     "4k_200x60_truecolor": (3840, 2160, 200, 60, 3, 0),   # configs[2] (K3)
     "4k_400x120_halfblock": (3840, 2160, 400, 120, 3, 2),  # configs[4] (K5)
+    "1080p_80x24_halfblock": (1920, 1080, 80, 24, 3, 2),   # the metric's shape in half blocks (fg + bg per cell)
     "640x480_80x24_mono": (640, 480, 80, 24, 0, 0),       # configs[0] (K1)
 }
 INPUT_KINDS = ("noise", "smooth", "bars", "gray")
@@ -417,7 +418,7 @@ def run_grid9(torch, pkg, steps, regions, targets=256, dist=None, world=1, rank=
     return out
 
 
-def wire_stage(torch, pkg, res, steps=160):
+def wire_stage(torch, pkg, res, steps=None):
     """SURVEY 8(f).3 behind the metric's render, measured in this run: GPU time per step (HIP events, same schedule as
     the main leg: res['streams'] launches in flight, a fresh input batch every step) of (a) render alone, (b) render +
     the stand-alone checksum / packet-header kernel (a second pass over the slab), (c) the render launch that also
@@ -429,6 +430,8 @@ def wire_stage(torch, pkg, res, steps=160):
 
     L = pkg.lib()
     plans, batch, S = res["plans"], res["batch"], res["streams"]
+    if steps is None:  # ~10 ms of GPU time per timing whatever the workload
+        steps = max(12, min(160, int(10.0 / max(res["gpu_ms"], 1e-3))))
     for p in plans:  # the serial leg left them at one launch in flight
         p.set_concurrency(S)
         if res.get("forced_variant", -1) >= 0:
@@ -488,7 +491,16 @@ def wire_stage(torch, pkg, res, steps=160):
     if not (same and oracle_ok):
         raise SystemExit("bench.py: fused frame checksums differ from the stand-alone kernel's / the oracle's")
     t = {kind: statistics.median(timed(kind) for _ in range(3)) for kind in ("render", "separate", "fused")}
+    forced = None
+    if not plans[0].fused_crc:  # a geometry that carries the fused CRC without it being the faster form (the rows kernel)
+        for p in plans:
+            p.set_fused_crc(1)
+        if plans[0].fused_crc:
+            forced = statistics.median(timed("fused") for _ in range(3))
+        for p in plans:
+            p.set_fused_crc(-1)
     return {"launches_in_flight": S, "steps": steps, "fused_crc_in_render_kernel": bool(plans[0].fused_crc),
+            "render_with_fused_crc_forced_ms_per_step": forced,
             "kernel_variant": plans[0].variant,
             "render_ms_per_step": t["render"], "render_plus_packet_kernel_ms_per_step": t["separate"],
             "render_with_fused_crc_and_headers_ms_per_step": t["fused"],
@@ -968,6 +980,11 @@ def main():
             print(f"[bench] {name} {kind} aspect={aspect}: {time.perf_counter() - t_w:.1f} s", file=sys.stderr)
             key = name + ("" if kind == "noise" else f"+{kind}") + ("+aspect_pad" if aspect else "")
             others[key] = summarize(r)
+            if name in ("4k_400x120_halfblock", "1080p_80x24_halfblock") and kind == "noise" and not aspect and not args.no_wire:
+                try:  # the wire stage behind the run-structured modes (rows kernel: fused form available, not the default)
+                    others[key]["wire_stage"] = wire_stage(torch, pkg, r)
+                except (RuntimeError, AssertionError) as e:
+                    others[key]["wire_stage"] = {"error": str(e)[:200]}
             if kind in ("bars", "gray") and not args.no_d2h:  # low-entropy video: where exact-length transfers pay most
                 try:
                     others[key]["with_d2h_packed"] = time_with_d2h_packed(torch, pkg, r["plans"], b, 60)

@@ -88,6 +88,9 @@ int achip_frame_blob_parse(const void *blob, size_t size, bool exact, uint32_t *
  * Outputs the geometry id, bands per frame (1 = no split) and text rows per band.  Returns 0, or -1 when a
  * padded row does not fit the geometry. */
 long achip_max_cells(const achip_frame_t *frames, int n_frames);
+/* what a launch states in the ACHIP_UNIFORM_MAX_CELLS field for geometry `variant`: the largest frame's cells (stream
+ * geometries) or the most blocks any frame has (rows geometries: whole text rows per block) */
+long achip_uniform_extent(int mode, int variant, const achip_frame_t *frames, int n_frames);
 /* false for a descriptor the kernels' 32-bit source offsets (and 24-bit row-stride multiply) cannot address */
 bool achip_frame_extent_ok(const achip_frame_t *f);
 int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, bool palette_ascii_only,

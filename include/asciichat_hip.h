@@ -312,6 +312,10 @@ int asciichat_hip_plan_render_crc(asciichat_hip_plan_t *plan, uint8_t *out_dev, 
 int asciichat_hip_plan_render_packets(asciichat_hip_plan_t *plan, uint8_t *out_dev, size_t out_stride,
                                       uint32_t *out_len_dev, const uint32_t *dims_dev, uint32_t *crc_out_dev,
                                       uint8_t *hdr_out_dev, uint32_t *packet_crc_out_dev, void *stream);
+/* Which form plan_render_crc / plan_render_packets take: -1 (default) the fused one where it is the faster form (the
+ * per-cell modes' stream kernel), 1 wherever the plan's geometry carries it (also the rows kernel of the run-structured
+ * modes, where the stand-alone pass is measured faster), 0 never.  plan_has_fused_crc() tells what a call will do. */
+int asciichat_hip_plan_set_fused_crc(asciichat_hip_plan_t *plan, int mode);
 int asciichat_hip_plan_render_crc_profiled(asciichat_hip_plan_t *plan, uint8_t *out_dev, size_t out_stride,
                                            uint32_t *out_len_dev, uint32_t *crc_out_dev,
                                            unsigned long long *phase_cycles_dev, void *stream); /* diagnostics */

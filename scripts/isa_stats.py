@@ -58,7 +58,8 @@ def kernels_of(lib):
 
 def demangle(name):
     try:
-        return subprocess.run([os.path.join(LLVM, "llvm-cxxfilt"), name], capture_output=True, text=True).stdout.strip() or name
+        tool = os.path.join(LLVM, "llvm-cxxfilt")
+        return subprocess.run([tool if os.path.exists(tool) else "c++filt", name], capture_output=True, text=True).stdout.strip() or name
     except OSError:
         return name
 
@@ -82,7 +83,15 @@ def main():
         limit, why = None, ""
         m = re.search(r"render_frames_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb([01])ELb([01])E", name)
         ms = re.search(r"render_stream_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb([01])ELb([01])E", name)
-        if m:
+        mr = re.search(r"render_rows_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb([01])ELb([01])E", name)
+        if mr:
+            mode, waves, cpl = int(mr.group(1)), int(mr.group(2)), int(mr.group(3))
+            crc = mr.group(5) == "1"
+            short = (f"render_rows_kernel<mode {mode}, {waves} waves, {cpl} cells/lane, generic {mr.group(4)}"
+                     f"{', +crc' if crc else ''}>")
+            if not crc and not (mr.group(4) == "1" and mode == 7 and cpl > 4):
+                limit, why = 128, "4 waves per SIMD: two 8-wave workgroups per CU"
+        elif m:
             mode, block = int(m.group(1)), int(m.group(2))
             short = f"render_frames_kernel<mode {mode}, {block} thr, cap {m.group(3)}, comp {m.group(5)}, split {m.group(6)}>"
             if block in (256, 512) and mode not in HALFBLOCK:
@@ -101,11 +110,9 @@ def main():
         problems = []
         if limit is not None and vg > limit:
             problems.append(f"{vg} VGPRs > {limit} ({why})")
-        if m and limit is not None and vs > 24:
-            problems.append(f"{vs} VGPRs spilled (> 24)")
-        if not m and vs > 0:
+        if vs > 0:
             problems.append(f"{vs} VGPRs spilled")
-        if ms and scratch > 0:
+        if scratch > 0:  # no product kernel touches scratch memory
             problems.append(f"{scratch} B scratch")
         rows.append((short, vg, sg, vs, ss, scratch, lds, "; ".join(problems)))
         if problems:

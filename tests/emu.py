@@ -18,7 +18,7 @@ _lib = None
 
 def build():
     srcs = [os.path.join(EMU_DIR, "emu_driver.cpp"), os.path.join(EMU_DIR, "hip_emu.h"),
-            os.path.join(CSRC, "render_kernels.hpp"), os.path.join(CSRC, "render_stream.hpp"), os.path.join(CSRC, "stream_kernels.hpp"), os.path.join(CSRC, "crc_kernels.hpp"), os.path.join(CSRC, "crc_math.hpp"), os.path.join(EMU_DIR, "gfx950_ops.hpp"),
+            os.path.join(CSRC, "render_kernels.hpp"), os.path.join(CSRC, "render_stream.hpp"), os.path.join(CSRC, "render_rows.hpp"), os.path.join(CSRC, "stream_kernels.hpp"), os.path.join(CSRC, "crc_kernels.hpp"), os.path.join(CSRC, "crc_math.hpp"), os.path.join(EMU_DIR, "gfx950_ops.hpp"),
             os.path.join(CSRC, "render_variants.h"),
             os.path.join(INC, "achip_types.h"), os.path.join(CSRC, "achip_host.c"), os.path.join(INC, "achip_host.h")]
     if os.path.exists(EMU_SO) and all(os.path.getmtime(s) <= os.path.getmtime(EMU_SO) for s in srcs):
@@ -42,6 +42,8 @@ def lib():
         _lib.emu_render_stream_crc.restype = C.c_int
         _lib.emu_render_stream_crc.argtypes = [C.c_int, C.c_int, C.POINTER(Frame), C.c_int, C.POINTER(Lut), C.c_void_p,
                                                C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.emu_render_rows_crc.restype = C.c_int
+        _lib.emu_render_rows_crc.argtypes = _lib.emu_render_stream_crc.argtypes
         _lib.emu_set_uniform.restype = C.c_int
         _lib.emu_set_uniform.argtypes = [C.c_int]
         _lib.emu_set_parts.restype = None
@@ -135,7 +137,8 @@ def render_frames_crc(mode, frames, palette, variant=20, stride=None, dims=None)
     d = np.array(dims, dtype=np.uint32).reshape(n, 2) if dims is not None else None
     hdr = np.full(n * 24, 0xEE, dtype=np.uint8)
     pkt = np.full(n, 0xDEADBEEF, dtype=np.uint32)
-    assert L.emu_render_stream_crc(mode, variant, arr, n, C.byref(lut), base, stride, ln.ctypes.data, crc.ctypes.data,
+    entry = L.emu_render_rows_crc if variant >= 24 else L.emu_render_stream_crc
+    assert entry(mode, variant, arr, n, C.byref(lut), base, stride, ln.ctypes.data, crc.ctypes.data,
                                    d.ctypes.data if d is not None else None, hdr.ctypes.data if d is not None else None,
                                    pkt.ctypes.data if d is not None else None) == 0
     res = [int(ln[i]) if ln[i] >= 0xFFFFFFF0 else C.string_at(base + i * stride, int(ln[i])) for i in range(n)]

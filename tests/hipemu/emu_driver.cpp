@@ -6,7 +6,8 @@
 #ifndef ACHIP_TEST_GEOMETRY
 #define ACHIP_TEST_GEOMETRY 1 /* the tiny stream geometry exists in emulator builds only */
 #endif
-#include "render_stream.hpp"
+#include <vector>
+#include "render_rows.hpp"
 #include "render_variants.h"
 #include "achip_host.h"
 
@@ -116,7 +117,7 @@ static void run_stream_crc(const achip_frame_t *frames, int n, const achip_lut_t
   if (tab.empty()) {
     tab.resize(L::TAB_BYTES / 4 + 4);
     uint32_t *t = tab.data();
-    hipemu::launch(dim3(1), dim3(256), 0, [&] { achip::crc_tables_init_kernel<MODE, WAVES, CPL>(t); });
+    hipemu::launch(dim3(1), dim3(256), 0, [&] { achip::crc_tables_init_kernel<L>(t); });
   }
   const uint4 *tabv = reinterpret_cast<const uint4 *>(tab.data());
   const size_t lds = (size_t)((L::bytes_for(achip::stream_maxblk(uni.flags, L::EFF)) + 15) & ~15);
@@ -144,6 +145,62 @@ extern "C" int emu_render_stream_crc(int mode, int variant, const achip_frame_t 
   return -1;
 }
 
+/* the rows kernel (render_rows.hpp): run-structured modes, whole frames; wire != nullptr: its CRC instantiation */
+template <int MODE, int WAVES, int CPL, bool CRC>
+static void run_rows(int variant, const achip_frame_t *frames, int n, const achip_lut_t *lut, uint8_t *out, uint64_t stride,
+                     uint32_t *len, const achip_wire_t &wire) {
+  using L = achip::RLds<MODE, WAVES, CRC>;
+  achip_uniform_t uni = {};
+  if (g_uniform)
+    (void)achip_frames_uniform(frames, n, &uni);
+  uni.flags = ((lut->flags & ACHIP_LUT_MULTIBYTE) ? 0u : ACHIP_UNIFORM_PALETTE_ASCII) |
+              ACHIP_UNIFORM_MAX_CELLS(achip_uniform_extent(MODE, variant, frames, n)); /* what plan.c passes */
+  static std::vector<uint32_t> tab;
+  const uint4 *tabv = nullptr;
+  if (CRC) {
+    if (tab.empty()) {
+      tab.resize(L::TAB_BYTES / 4 + 4);
+      uint32_t *t = tab.data();
+      hipemu::launch(dim3(1), dim3(256), 0, [&] { achip::crc_tables_init_kernel<L>(t); });
+    }
+    tabv = reinterpret_cast<const uint4 *>(tab.data());
+  }
+  const size_t lds = (size_t)((L::bytes_for(achip::stream_maxblk(uni.flags, 1)) + 15) & ~15);
+  hipemu::launch(dim3((unsigned)n), dim3(WAVES * 64), lds, [&] {
+    achip::render_rows_kernel<MODE, WAVES, CPL, true, CRC>(frames, lut, out, stride, len, n, uni, wire, tabv);
+  });
+}
+template <int WAVES, int CPL, bool CRC>
+static int rows_by_mode(int mode, int variant, const achip_frame_t *frames, int n, const achip_lut_t *lut, uint8_t *out,
+                        uint64_t stride, uint32_t *len, const achip_wire_t &wire) {
+  switch (mode) {
+#define M(m)                                                                                                           \
+  case m:                                                                                                              \
+    run_rows<m, WAVES, CPL, CRC>(variant, frames, n, lut, out, stride, len, wire);                                      \
+    return 0;
+    M(ACHIP_MODE_MONO)
+    M(ACHIP_MODE_HB_TRUE)
+    M(ACHIP_MODE_HB_256)
+    M(ACHIP_MODE_HB_16)
+    M(ACHIP_MODE_HB_MONO)
+#undef M
+  }
+  return -1;
+}
+extern "C" int emu_render_rows_crc(int mode, int variant, const achip_frame_t *frames, int n, const achip_lut_t *lut,
+                                   uint8_t *out, uint64_t stride, uint32_t *len, uint32_t *crc, const uint32_t *dims,
+                                   uint8_t *hdr, uint32_t *pkt) {
+  const achip_wire_t wire = {crc, dims, hdr, pkt};
+  switch (variant) {
+#define X(id, W, C)                                                                                                    \
+  case id:                                                                                                             \
+    return rows_by_mode<W, C, true>(mode, variant, frames, n, lut, out, stride, len, wire);
+    ACHIP_ROWS_VARIANTS(X)
+#undef X
+  }
+  return -1;
+}
+
 extern "C" int emu_render_batch(int mode, int variant, const achip_frame_t *frames, int n, const achip_lut_t *lut,
                                 uint8_t *out, uint64_t stride, uint32_t *len) {
   if (g_parts == 1)
@@ -152,6 +209,11 @@ extern "C" int emu_render_batch(int mode, int variant, const achip_frame_t *fram
   case id:                                                                                                             \
     return stream_by_mode<W, C>(mode, frames, n, lut, out, stride, len);
       ACHIP_STREAM_VARIANTS(X)
+#undef X
+#define X(id, W, C)                                                                                                    \
+  case id:                                                                                                             \
+    return rows_by_mode<W, C, false>(mode, variant, frames, n, lut, out, stride, len, achip_wire_t{});
+      ACHIP_ROWS_VARIANTS(X)
 #undef X
     }
   switch (variant) {

@@ -23,6 +23,7 @@ inline void keep_alive(uint32_t, uint32_t) {}
 inline uint32_t lds_base_addr() { return 0u; }
 /* a wave's lanes run in lockstep on the GPU: every lane's stores precede the reads behind the fence */
 inline void lds_store_fence() { hipemu::wave_barrier(); }
+inline void wave_lockstep() { hipemu::wave_barrier(); }
 inline void wait_vmem_all() {}
 
 /* fibers of one OS thread: no switch inside a plain read-modify-write */

@@ -95,6 +95,8 @@ def test_torture_all_modes_all_variants(gpu, mode):
     # every geometry of the phase kernel that the product library carries (the 64-thread test geometry exists in the
     # emulator build only), and for the per-cell modes every geometry of the stream kernel
     variants = (2, 1, 0, 4) + ((16, 17, 18, 19) if mode in (MODE_TRUE_FG, 2, 3, MODE_TRUE_BG) else ())
+    if mode in (0, 5, 6, 7, 8):  # the run-structured modes: both geometries of the rows kernel (rows up to 256 / 448 cells)
+        variants += (25, 24)
     for variant in variants:
         for (W, H) in [(80, 24), (97, 31), (200, 60)]:
             got = render_batch(gpu, mode, [TORTURE], W, H, variant=variant)[0]
@@ -397,7 +399,10 @@ def test_render_with_fused_frame_crc(gpu):
     for mode, variant, want_fused, pad in ((1, 17, True, False), (2, 17, True, False), (3, 17, True, True), (4, 17, True, False),
                                            (1, 16, True, True), (2, 16, True, False), (4, 16, True, False),
                                            (1, 18, False, False), (1, -1, None, False), (0, -1, False, False),
-                                           (5, -1, False, False)):
+                                           (5, -1, False, False),
+                                           # the rows kernel (run-structured modes, whole frames) carries the fused CRC too
+                                           (0, 25, True, False), (5, 25, True, True), (6, 25, True, False), (7, 24, True, True),
+                                           (8, 24, True, False), (5, 24, True, False)):
         rm = MODE_CAPS.get(mode, (3, 0))[1]
         dev = [torch.from_numpy(np.ascontiguousarray(i)).cuda() for i in imgs]
         asp = pad and mode != 4
@@ -406,6 +411,9 @@ def test_render_with_fused_frame_crc(gpu):
         plan = pkg.Plan(mode, orc.PALETTE_STANDARD, frames)
         if variant >= 0:
             plan.set_variant(variant)
+        if variant >= 24:  # the rows kernel carries the fused CRC but plans do not pick it by themselves (slower there)
+            assert not plan.fused_crc
+            plan.set_fused_crc(1)
         if want_fused is not None:
             assert plan.fused_crc == want_fused, (mode, variant, plan.variant)
         n = len(imgs)

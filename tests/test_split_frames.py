@@ -68,11 +68,16 @@ def test_split_ragged_batch_and_policy():
     assert choose(1, one * 256, cus=256 // 3) == (17, 1, 24)  # ... or several launches in flight sharing the CUs
     assert choose(1, one * 256, cus=256 // 4) == (17, 1, 24)
     assert choose(2, one * 256) == (16, 1, 24) and choose(3, one * 256) == (16, 1, 24) and choose(4, one * 300) == (17, 1, 24)
-    assert choose(0, one * 256) == (4, 1, 24)                 # run-structured modes stay on the phase kernel
-    assert choose(0, one * 600) == (1, 1, 24)
+    # whole-frame launches of the run-structured modes take the rows kernel (render_rows.hpp) when the padded row fits a
+    # block: the geometry whose blocks waste fewer lane slots (three 80-cell rows fill 240 of 256 slots, five fill 400 of 448)
+    assert choose(0, one * 256) == (25, 1, 24)
+    assert choose(0, one * 600) == (25, 1, 24)
+    assert choose(0, one * 256, forced=4) == (4, 1, 24) and choose(0, one * 256, forced=24) == (24, 1, 24)
+    with pytest.raises(AssertionError):
+        choose(1, one * 256, forced=24)                       # a per-cell mode has no rows kernel
     assert choose(1, one * 256, ascii_only=False) == (4, 1, 24)  # truecolor-fg with multi-byte glyphs too
     assert choose(1, one * 256, forced=4) == (4, 1, 24) and choose(1, one * 256, forced=19) == (19, 1, 24)
-    assert choose(5, [emu.frame_for_convert(imgs[0], 80, 24, 2)] * 600) == (4, 1, 24)  # half-block: never the small geometries
+    assert choose(5, [emu.frame_for_convert(imgs[0], 80, 24, 2)] * 600) == (25, 1, 24)  # half-block whole frames: rows kernel
     assert choose(9, one) == (4, 1, 24)                       # serial dither: never split
     assert choose(1, one, ascii_only=False) == (4, 1, 24)     # truecolor-fg with multi-byte glyphs: never split
     assert choose(2, one, ascii_only=False) == (4, 24, 1)
@@ -85,7 +90,12 @@ def test_split_ragged_batch_and_policy():
     k3 = [emu.frame_for_convert(imgs[0], 200, 60, 0)]
     assert choose(1, k3 * 64) == (1, 6, 10)                   # bands limited by the 2048-cell chunk
     k5 = [emu.frame_for_convert(imgs[0], 400, 120, 2)]        # half-block: 120 text rows of 400 cells
-    assert choose(5, k5 * 32) == (4, 24, 5)
+    assert choose(5, k5 * 32) == (4, 24, 5)                   # few frames: row bands on the phase kernel
+    # BASELINE configs[4]: one 400-cell row per 448-slot block when launches share the GPU (or frames outnumber CUs); ONE
+    # launch of a frame per CU stays on the phase kernel (sixteen waves per CU against the 7-slot geometry's eight)
+    assert choose(5, k5 * 300) == (24, 1, 120) and choose(5, k5 * 256, cus=64) == (24, 1, 120)
+    assert choose(5, k5 * 256) == (4, 1, 120)                # BASELINE configs[4]: one 400-cell row per 448-slot block
+    assert choose(5, [emu.frame_for_convert(imgs[0], 449, 20, 2)] * 256) == (4, 1, 20)  # a row wider than a block: phase kernel
     wide = [emu.frame_for_convert(imgs[0], 3000, 4, 0)]
     assert choose(0, wide) == (0, 1, 4)                       # rows wider than the band geometries: no split
     assert L.achip_palette_ascii_only(orc.PALETTE_STANDARD.encode()) and not L.achip_palette_ascii_only(orc.PALETTE_COOL.encode())
