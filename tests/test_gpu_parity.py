@@ -637,8 +637,8 @@ def test_launches_in_flight_on_three_streams(gpu):
             plan.set_concurrency(3)
             if mode != MODE_HB_TRUE:  # per-cell modes: the stream kernel, 1024 threads alone / 512 when sharing the CUs
                 assert v0 == 16 and plan.variant == 17, (v0, plan.variant)   # 200 frames on a third of 256 CUs
-            else:
-                assert plan.variant == 4
+            else:  # half blocks, whole frames: the rows kernel (three 80-cell rows per 256-slot block)
+                assert plan.variant == 25
             plans.append(plan)
             picks.append(pick)
             keep.append(dev)
