@@ -436,6 +436,8 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
   if (forced_variant >= 0) {
     if (max_wp > variant_caps[forced_variant])
       return -1;
+    if (hb && (forced_variant == 1 || forced_variant == 2))
+      return -1; /* no half-block instantiations in the 512- / 256-thread geometries (render_inst.hip: has_mode) */
     *variant = forced_variant;
   } else if (!hb && n_frames > (3 * n_cus) / 2 && max_wp <= variant_caps[1]) {
     *variant = 1;

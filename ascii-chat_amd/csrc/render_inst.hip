@@ -27,6 +27,12 @@ using G = Geometry<ACHIP_INST>;
 
 /* row bands are only ever launched with the geometries the host policy picks for them (achip_choose_geometry) */
 constexpr bool HAS_SPLIT = ACHIP_INST == 1 || ACHIP_INST == 2 || ACHIP_INST == 4;
+/* the half-block modes never run in the 512- / 256-thread geometries (they need more than the 128 VGPRs that make those
+ * geometries worthwhile; the host policy sends them to the 1024-thread one, the wide one or the rows kernel): those
+ * instantiations do not exist */
+template <int MODE> constexpr bool has_mode() {
+  return !(achip::mode_is_halfblock(MODE) && (ACHIP_INST == 1 || ACHIP_INST == 2));
+}
 
 template <int MODE, bool COMP, bool SPLIT>
 hipError_t launch_one(const achip_frame_t *frames, int n, const achip_lut_t *lut, uint8_t *out, uint64_t stride,
@@ -87,7 +93,11 @@ extern "C" int ACHIP_CAT(achip_render_inst_launch_, ACHIP_INST)(int mode, int co
   switch (mode) {
 #define M(m)                                                                                                           \
   case m:                                                                                                              \
-    return (int)launch_mode<m>(comp != 0, frames, n, lut, out, stride, len, prof, parts, rows_per_part, part_sync, epoch, uni, s);
+    if constexpr (has_mode<m>())                                                                                       \
+      return (int)launch_mode<m>(comp != 0, frames, n, lut, out, stride, len, prof, parts, rows_per_part, part_sync,   \
+                                 epoch, uni, s);                                                                       \
+    else                                                                                                               \
+      return (int)hipErrorInvalidValue;
     M(ACHIP_MODE_MONO)
     M(ACHIP_MODE_TRUE_FG)
     M(ACHIP_MODE_256_FG)

@@ -344,8 +344,8 @@ template <int MODE, int BLOCK, int CAP, int RING> struct Lds {
   static constexpr int o_wsum = o_dec + 256 * 4; /* SEG*NW wave totals (<= 64) */
   static constexpr int o_flags = o_wsum + 64 * 4; /* [0] unused, [1],[2] window cut (ping-pong), [3] predecessors' byte
                                                      count (multi-part frames), [4] dummy store target */
-  static constexpr int o_prof = o_flags + 32;     /* 8 x u64 diagnostics accumulators */
-  static constexpr int o_carry = o_prof + 8 * 8;             /* dither: error sums entering the next row, 3 x int per column */
+  static constexpr int o_prof = o_flags + 32;     /* 8 x u64 diagnostics accumulators + the kernel's start stamp */
+  static constexpr int o_carry = o_prof + 10 * 8;            /* dither: error sums entering the next row, 3 x int per column */
   static constexpr int o_comp = o_carry + (MODE == ACHIP_MODE_16_DITHER_BG ? CAP * 12 : 0); /* composite descriptor (COMP launches) */
   static constexpr int bytes = o_comp + ACHIP_COMP_LDS_BYTES;
   static_assert(SEG * NW <= 64, "wave-total table must fit one wave");
@@ -759,6 +759,70 @@ template <int MODE, class L> __device__ inline Tok build_token(const Chunk &c, i
   return t;
 }
 
+/* The payload of a token whose flags and REP count are known: colours and glyph follow from the cell's OWN sample (a
+ * run head's SGRs carry its own colours).  The geometries that hold four or more cells per thread keep ONE packed word per
+ * cell {flags:12, rep:12, length:6} between the length pass and the store pass and rebuild the rest here -- five
+ * registers per cell put them over their 128-VGPR budget (scratch spills; scripts/isa_stats.py allows none). */
+template <int MODE, class L> __device__ inline Tok token_payload(uint32_t flags, uint32_t rep, int i, uint32_t ops) {
+  const uint32_t *glyph = lds_ptr<const uint32_t>(L::o_glyph);
+  const uint32_t *glyph64 = lds_ptr<const uint32_t>(L::o_glyph64);
+  const uint8_t *ramp = lds_ptr<const uint8_t>(L::o_ramp);
+  (void)glyph; (void)glyph64; (void)ramp;
+  Tok t;
+  t.flags = flags;
+  t.rep = rep;
+  t.fg = t.bg = t.glyph = 0;
+  if (flags & TF_PAD)
+    return t;
+  const uint32_t pt = lds_ptr<const uint32_t>(L::o_pixT)[i];
+  const uint32_t pb = mode_is_halfblock(MODE) ? lds_ptr<const uint32_t>(L::o_pixB)[i] : 0u;
+  const bool given = (ops & ACHIP_OP_FG_OVERRIDE) != 0u;
+  if (MODE == ACHIP_MODE_TRUE_FG) {
+    t.glyph = glyph[luma601(pt)];
+    t.fg = given ? ops >> ACHIP_OP_TINT_SHIFT : px_rgb(pt);
+  } else if (MODE == ACHIP_MODE_256_FG) {
+    t.fg = quant256(pt);
+    t.glyph = glyph[luma601(pt)];
+  } else if (MODE == ACHIP_MODE_16_FG) {
+    t.fg = sgr16_code(false, quant16(pt));
+    t.glyph = glyph[ramp[luma601(pt) >> 2]];
+  } else if (MODE == ACHIP_MODE_TRUE_BG) {
+    t.bg = px_rgb(pt);
+    t.glyph = glyph[luma601(pt)];
+    t.fg = given ? ops >> ACHIP_OP_TINT_SHIFT : 0u;
+  } else if (MODE == ACHIP_MODE_16_DITHER_BG) {
+    const uint32_t idx = px_key(pt), pal = ansi16_rgb(idx);
+    const uint32_t bl = (77u * px_r(pal) + 150u * px_g(pal) + 29u * px_b(pal)) / 256u;
+    if (ops & ACHIP_OP_DITHER_FG) {
+      t.fg = sgr16_code(false, idx);
+      t.glyph = (ops & ACHIP_OP_DITHER_RAMP) ? glyph[ramp[luma601(pt) >> 2]] : glyph[luma601(pt)];
+    } else {
+      t.bg = sgr16_code(true, idx);
+      t.fg = bl < 127u ? 97u : 30u;
+      t.glyph = glyph[luma601(pt)];
+    }
+  } else if (MODE == ACHIP_MODE_MONO) {
+    t.glyph = glyph64[min(px_key(pt), 63u)];
+  } else if (MODE == ACHIP_MODE_HB_MONO) {
+    const uint32_t lt = (76u * px_r(pt) + 150u * px_g(pt) + 29u * px_b(pt)) >> 8;
+    const uint32_t sh = lt >> 6;
+    t.glyph = 0x0096E2u | ((sh == 3u ? 0x88u : 0x91u + sh) << 16);
+  } else {
+    t.glyph = 0x8096E2u;
+    if (MODE == ACHIP_MODE_HB_TRUE) {
+      t.fg = given ? ops >> ACHIP_OP_TINT_SHIFT : px_rgb(pt);
+      t.bg = px_rgb(pb);
+    } else if (MODE == ACHIP_MODE_HB_256) {
+      t.fg = px_key(pt);
+      t.bg = px_key(pb);
+    } else {
+      t.fg = sgr16_code(false, px_key(pt));
+      t.bg = sgr16_code(true, px_key(pb));
+    }
+  }
+  return t;
+}
+
 /* ESC[38;2;R;G;Bm / ESC[48;2;R;G;Bm  (append_truecolor_fg/bg ansi.c:143-193; emit_set_fg/bg output_buffer.c:186-214).
  * ROOM = bytes of the same token guaranteed to follow the SGR. */
 template <int ROOM, class S> __device__ inline void put_sgr_true(S &s, bool bg, uint32_t rgb) {
@@ -1029,13 +1093,13 @@ __device__ inline void dither16_rows(int lane, int chunk_rows, int wp, int pad_l
  * non-half-block kernels sit right at that edge (125-130 depending on unrelated code motion: at 130 only ONE 512-thread
  * workgroup fits and the step time doubles).  Pin it.  The half-block kernels need 160-185 there and are never
  * launched in these geometries by the host policy. */
-template <int MODE, int BLOCK> struct MinWaves {
-  static constexpr int value = (BLOCK <= 512 && BLOCK >= 256 && !mode_is_halfblock(MODE)) ? 4 : 1;
+template <int MODE, int BLOCK, int CAP> struct MinWaves { /* (not the wide geometry: eight cells per thread, one workgroup per CU) */
+  static constexpr int value = (BLOCK <= 512 && BLOCK >= 256 && CAP <= 2048 && !mode_is_halfblock(MODE)) ? 4 : 1;
 };
-#define ACHIP_PIN_OCCUPANCY(M, B) ACHIP_WAVES_PER_EU((MinWaves<M, B>::value))
+#define ACHIP_PIN_OCCUPANCY(M, B, C) ACHIP_WAVES_PER_EU((MinWaves<M, B, C>::value))
 
 template <int MODE, int BLOCK, int CAP, int RING, bool COMP, bool SPLIT = true>
-__global__ void __launch_bounds__(BLOCK) ACHIP_PIN_OCCUPANCY(MODE, BLOCK)
+__global__ void __launch_bounds__(BLOCK) ACHIP_PIN_OCCUPANCY(MODE, BLOCK, CAP)
     render_frames_kernel(const achip_frame_t *__restrict__ frames, const achip_lut_t *__restrict__ lut,
                          uint8_t *__restrict__ out, uint64_t out_stride, uint32_t *__restrict__ out_len, int n_frames,
                          unsigned long long *__restrict__ prof, int parts, int rows_per_part,
@@ -1056,7 +1120,10 @@ __global__ void __launch_bounds__(BLOCK) ACHIP_PIN_OCCUPANCY(MODE, BLOCK)
    * single chunk anyway. */
   /* (the emulated test build takes the request-ahead order in every geometry, so that tiny inputs exercise it --
    * except in the 512 x 4 geometry, which keeps its product configuration: PRE_ISSUE without PREFETCH) */
-  constexpr bool PREFETCH = ACHIP_EMULATED ? !SPLIT && !(BLOCK == 512 && CAP == 2048) : BLOCK == 1024 && CAP == 2048 && !SPLIT;
+  /* (not the composite half-block instantiations: their four requests-ahead per thread are the registers that would
+   * spill, and their sources -- composite tiles -- come out of the L2) */
+  constexpr bool PREFETCH = ACHIP_EMULATED ? !SPLIT && !(BLOCK == 512 && CAP == 2048)
+                                           : BLOCK == 1024 && CAP == 2048 && !SPLIT && !(COMP && HB);
   /* A wave waits AT the request until the memory pipeline has room for its lines, so the requests of a chunk are
    * not issued in one burst behind phase A's barrier but at four points of B/C: in the half-block modes every
    * thread issues one of its four requests per point (4K -> 400x120: 281 -> 266 us); in the other modes a
@@ -1130,12 +1197,11 @@ __global__ void __launch_bounds__(BLOCK) ACHIP_PIN_OCCUPANCY(MODE, BLOCK)
     return; /* this frame has fewer parts than the launch provides: nobody waits for them */
   const bool last_part = row_end >= rows;
 
-  unsigned long long t_start = 0ull;
-  if (prof && tid == 0) {
+  if (prof && tid == 0) { /* (the start stamp lives in LDS too: two registers less across the whole kernel) */
     unsigned long long *pa = lds_ptr<unsigned long long>(L::o_prof);
     for (int k = 0; k < 7; k++)
       pa[k] = 0ull;
-    pa[7] = t_start = cycle_now();
+    pa[8] = pa[7] = cycle_now();
   }
 
   /* i / wp == umulhi(i, magic) for i, wp <= CAP (i * wp < 2^32); wp == 1 would need magic 2^32 */
@@ -1364,18 +1430,29 @@ __global__ void __launch_bounds__(BLOCK) ACHIP_PIN_OCCUPANCY(MODE, BLOCK)
       gather_issue(r1, pf_cells);
 
     /* ---- C: build the tokens (registers) and their lengths ------------------------------------ */
-    Tok tok[SEG];
+    /* four or more cells per thread: one packed word per cell instead of the token (token_payload rebuilds the rest) */
+    constexpr bool PACK_TOK = SEG >= 4 || (HB && (COMP || MODE == ACHIP_MODE_HB_16)); /* (.. and the two-cell half-block
+                                        instantiations that would otherwise spill a handful of registers) */
+    Tok tok[PACK_TOK ? 1 : SEG];
+    uint32_t meta[PACK_TOK ? SEG : 1];
     uint32_t len[SEG];
 #pragma unroll
     for (int k = 0; k < SEG; k++) {
       const int i = tid + k * BLOCK;
       len[k] = 0;
-      tok[k].flags = 0;
+      if (PACK_TOK)
+        meta[k] = 0;
+      else
+        tok[k].flags = 0;
       if (i < n) {
-        tok[k] = build_token<MODE, L>(c, i, r0 + ACHIP_CELL_RR(k), ACHIP_CELL_RR(k), ACHIP_CELL_XP(k));
+        const Tok t = build_token<MODE, L>(c, i, r0 + ACHIP_CELL_RR(k), ACHIP_CELL_RR(k), ACHIP_CELL_XP(k));
         CountSink cs{0u};
-        token_fields<MODE>(cs, tok[k], ascii_only);
+        token_fields<MODE>(cs, t, ascii_only);
         len[k] = cs.n;
+        if (PACK_TOK)
+          meta[k] = t.flags | (t.rep << 12);
+        else
+          tok[k] = t;
       }
       if (pf && SPREAD && k + 1 < SEG)
         gather_one(k + 1, false, r1, pf_cells);
@@ -1476,17 +1553,20 @@ __global__ void __launch_bounds__(BLOCK) ACHIP_PIN_OCCUPANCY(MODE, BLOCK)
         const uint32_t b = a + len[k];
         if (len[k] != 0u && a >= done) {
           if (b <= hi) {
+            const Tok tk = PACK_TOK ? token_payload<MODE, L>(meta[PACK_TOK ? k : 0] & 0xFFFu, meta[PACK_TOK ? k : 0] >> 12,
+                                                             tid + k * BLOCK, f.ops)
+                                    : tok[PACK_TOK ? 0 : k];
 #if !defined(ACHIP_ABLATE) || ACHIP_ABLATE != 2
             if (EMIT_OR) {
               PackSink<L::o_dec> ps(ring_addr + (a - lo));
-              token_fields<MODE>(ps, tok[k], ascii_only);
+              token_fields<MODE>(ps, tk, ascii_only);
               ps.finish();
             } else {
               FastSink<L::o_dec, L::o_flags + 16> fs{ring_addr + (a - lo), dummy_addr};
-              token_fields<MODE>(fs, tok[k], ascii_only);
+              token_fields<MODE>(fs, tk, ascii_only);
             }
 #else
-            asm volatile("" ::"v"(a), "v"(tok[k].flags), "v"(tok[k].fg), "v"(tok[k].glyph));
+            asm volatile("" ::"v"(a), "v"(tk.flags), "v"(tk.fg), "v"(tk.glyph));
 #endif
           } else if (a <= hi) {
             *cut_slot = a; /* the unique token that starts inside the window but does not fit: the cut */
@@ -1529,7 +1609,7 @@ __global__ void __launch_bounds__(BLOCK) ACHIP_PIN_OCCUPANCY(MODE, BLOCK)
     const unsigned long long *pa = lds_ptr<const unsigned long long>(L::o_prof);
     for (int k = 0; k < 7; k++)
       prof[(size_t)fidx * 8u + (size_t)k] = pa[k];
-    prof[(size_t)fidx * 8u + 7u] = cycle_now() - t_start;
+    prof[(size_t)fidx * 8u + 7u] = cycle_now() - pa[8];
   }
   if (tid == 0 && last_part) {
     out_len[fidx] = overflow ? ACHIP_LEN_OVERFLOW : base;

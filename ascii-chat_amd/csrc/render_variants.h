@@ -14,7 +14,8 @@
 #define ACHIP_TEST_VARIANT(X)
 #endif
 #define ACHIP_VARIANTS(X)                                                                                         \
-  X(0, 1024, 4096, 65536) /* wide: any row up to 4096 cells, 1 workgroup per CU                                */ \
+  X(0, 512, 4096, 65536)  /* wide: any row up to 4096 cells; eight cells per thread in 512-thread workgroups, which may
+                             use 256 VGPRs (a 1024-thread workgroup is capped at 128: its four cells per thread spilled) */ \
   X(1, 512, 2048, 32768)  /* narrow: rows up to 2048 cells, 2-3 workgroups per CU                               */ \
   X(2, 256, 1024, 16384)  /* small grids (<= 1024-cell rows): 4+ workgroups per CU                              */ \
   ACHIP_TEST_VARIANT(X)   /* id 3 does not exist in the product library                                         */ \

@@ -94,7 +94,7 @@ def main():
         elif m:
             mode, block = int(m.group(1)), int(m.group(2))
             short = f"render_frames_kernel<mode {mode}, {block} thr, cap {m.group(3)}, comp {m.group(5)}, split {m.group(6)}>"
-            if block in (256, 512) and mode not in HALFBLOCK:
+            if block in (256, 512) and int(m.group(3)) <= 2048 and mode not in HALFBLOCK:
                 limit, why = 128, "two (four) workgroups per CU"
         elif ms:
             mode, waves, cpl = int(ms.group(1)), int(ms.group(2)), int(ms.group(3))
