@@ -50,6 +50,41 @@ void get_16color_rgb(uint8_t color_index, uint8_t *r, uint8_t *g, uint8_t *b) {
   *b = ansi16_rgb[color_index][2];
 }
 
+/* rgb_to_16color_dithered (lib/video/terminal/ansi.c:511-583): ONE pixel of the Floyd-Steinberg pass against a
+ * caller-held error buffer (width x height rgb_error_t) -- take the error parked for (x, y), quantise the clamped sum,
+ * park 7/16, 3/16, 5/16, 1/16 of the UNclamped difference for the right / lower-left / lower / lower-right neighbours that
+ * exist (C division: each share truncates toward zero).  error_buffer == NULL: plain rgb_to_16color of the clamped input.
+ * The renderers do not go through this function (the device pass is dither16_rows); it is part of the API surface. */
+static uint8_t clamp_u8(int v) { return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); }
+
+uint8_t rgb_to_16color_dithered(int r, int g, int b, int x, int y, int width, int height, rgb_error_t *error_buffer) {
+  rgb_error_t *here = error_buffer ? &error_buffer[(size_t)y * (size_t)width + (size_t)x] : NULL;
+  if (here) {
+    r += here->r;
+    g += here->g;
+    b += here->b;
+    here->r = here->g = here->b = 0;
+  }
+  const uint8_t idx = rgb_to_16color(clamp_u8(r), clamp_u8(g), clamp_u8(b));
+  if (!here)
+    return idx;
+  uint8_t pr, pg, pb;
+  get_16color_rgb(idx, &pr, &pg, &pb);
+  const int e[3] = {r - (int)pr, g - (int)pg, b - (int)pb};
+  /* neighbour (dx, dy) and its sixteenths */
+  static const int nb[4][3] = {{1, 0, 7}, {-1, 1, 3}, {0, 1, 5}, {1, 1, 1}};
+  for (int k = 0; k < 4; k++) {
+    const int nx = x + nb[k][0], ny = y + nb[k][1];
+    if (nx < 0 || nx >= width || ny >= height)
+      continue;
+    rgb_error_t *t = &error_buffer[(size_t)ny * (size_t)width + (size_t)nx];
+    t->r += (e[0] * nb[k][2]) / 16;
+    t->g += (e[1] * nb[k][2]) / 16;
+    t->b += (e[2] * nb[k][2]) / 16;
+  }
+  return idx;
+}
+
 /* ---- SGR builders (ansi.c:143-246, 326-435) --------------------------------------------------- */
 static char *dec_u32(char *p, uint32_t v) {
   char rev[10];

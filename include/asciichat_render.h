@@ -185,6 +185,14 @@ typedef struct {
 uint8_t rgb_to_256color(uint8_t r, uint8_t g, uint8_t b);
 uint8_t rgb_to_16color(uint8_t r, uint8_t g, uint8_t b);
 void get_16color_rgb(uint8_t color_index, uint8_t *r, uint8_t *g, uint8_t *b);
+/* ansi.h:62-67, 272: one pixel of the Floyd-Steinberg 16-colour pass against a caller-held width x height error buffer
+ * (NULL = no dithering) */
+typedef struct {
+  int r;
+  int g;
+  int b;
+} rgb_error_t;
+uint8_t rgb_to_16color_dithered(int r, int g, int b, int x, int y, int width, int height, rgb_error_t *error_buffer);
 char *append_truecolor_fg(char *dst, uint8_t r, uint8_t g, uint8_t b);
 char *append_truecolor_bg(char *dst, uint8_t r, uint8_t g, uint8_t b);
 char *append_truecolor_fg_bg(char *dst, uint8_t fg_r, uint8_t fg_g, uint8_t fg_b, uint8_t bg_r, uint8_t bg_g,

@@ -45,6 +45,13 @@ def prod():
     L.ansi_rle_finish.argtypes = [C.POINTER(RleCtx)]
     L.achip_palette_ascii_only.restype = C.c_bool
     L.achip_palette_ascii_only.argtypes = [C.c_char_p]
+    for f in (L.append_16color_fg, L.append_16color_bg, L.append_256color_fg, L.append_256color_bg):
+        f.restype = C.c_void_p
+        f.argtypes = [C.c_void_p, C.c_uint8]
+    L.get_16color_rgb.restype = None
+    L.get_16color_rgb.argtypes = [C.c_uint8] + [C.POINTER(C.c_uint8)] * 3
+    L.rgb_to_16color_dithered.restype = C.c_uint8
+    L.rgb_to_16color_dithered.argtypes = [C.c_int] * 7 + [C.c_void_p]
     return L
 
 
@@ -96,6 +103,54 @@ def test_colour_helpers(prod):
         k = O.orc_sgr_truecolor(ob, 1 if bg else 0, r, g, b)
         assert ob.raw[:k] == s.encode()
     assert len(KATS["rgb_to_16color"]) == 9 and len(KATS["truecolor_sgr"]) == 14
+
+
+def test_indexed_colour_helpers_and_dither_pixel(prod):
+    """ansi_fast_test.c:289-456 (append_256color_* / append_16color_* strings incl. the defaults an invalid index takes),
+    :495-530 (get_16color_rgb, invalid index -> light grey), :550-572 (rgb_to_16color_dithered: NULL buffer, right edge,
+    bottom edge, corner).  Checked on the oracle and on the product's exported functions."""
+    O = orc.lib()
+    buf = C.create_string_buffer(64)
+    for kind, where, n, st in KATS["indexed_sgr"]:
+        fn = getattr(prod, "append_%scolor_%s" % (kind, where))
+        end = fn(buf, n)
+        assert buf.raw[:end - C.addressof(buf)] == st.encode(), (kind, where, n)
+        ob = C.create_string_buffer(64)
+        k = (O.orc_sgr_16 if kind == "16" else O.orc_sgr_256)(ob, 1 if where == "bg" else 0, n)
+        assert ob.raw[:k] == st.encode(), (kind, where, n)
+    for i, r, g, b in KATS["get_16color_rgb"]:
+        got = [C.c_uint8() for _ in range(3)]
+        prod.get_16color_rgb(i, *[C.byref(v) for v in got])
+        assert [v.value for v in got] == [r, g, b], i
+    for r, g, b, x, y, w, h, with_buffer, idx in KATS["rgb_to_16color_dithered"]:
+        err = (C.c_int * (3 * w * h))() if with_buffer else None
+        assert prod.rgb_to_16color_dithered(r, g, b, x, y, w, h, err) == idx, (x, y, with_buffer)
+        if with_buffer:  # nothing leaves the 10 x 10 buffer at an edge, and what (255,0,0) -> bright red leaves is zero
+            assert not any(err)
+    # the exported per-pixel step chained over a whole image equals the oracle's dithered renderer (which the GPU pass is
+    # tested against): same colour index for every pixel of a 23 x 9 noise image
+    img = orc.frame_hash_noise(23, 9, 4)
+    h, w, _ = img.shape
+    err = (C.c_int * (3 * w * h))()
+    idx = [[prod.rgb_to_16color_dithered(int(img[y, x, 0]), int(img[y, x, 1]), int(img[y, x, 2]), x, y, w, h, err)
+            for x in range(w)] for y in range(h)]
+    ref = orc.print_16_dithered(img, True)  # ESC[4x/10xm ESC[97|30m glyph per cell: the background code is the index
+    import re as _re
+    codes = [int(m) for m in _re.findall(rb"\x1b\[(4[0-7]|10[0-7])m", ref)]
+    flat = [c - 40 if c < 100 else c - 92 for c in codes]
+    assert flat == [v for row in idx for v in row]
+    assert len(KATS["indexed_sgr"]) == 15 and len(KATS["get_16color_rgb"]) == 5 and len(KATS["rgb_to_16color_dithered"]) == 4
+
+
+def test_colour_filter_tints_from_the_reference_table():
+    """color_filter_test.c:197-218: the tint of each filter, in color_filter_t order (BLACK = 1 ... YELLOW = 11): a white
+    pixel takes exactly the filter's colour (BLACK is black-on-white: white stays white)."""
+    px = np.array([[[255, 255, 255]]], dtype=np.uint8)
+    assert [t[0] for t in KATS["color_filter_tints"]] == ["BLACK", "WHITE", "GREEN", "MAGENTA", "FUCHSIA", "ORANGE", "TEAL",
+                                                         "CYAN", "PINK", "RED", "YELLOW"]
+    for flt, (name, r, g, b) in enumerate(KATS["color_filter_tints"], start=1):
+        got = tuple(int(v) for v in orc.color_filter(px, flt)[0, 0])
+        assert got == ((255, 255, 255) if name == "BLACK" else (r, g, b)), name
 
 
 def test_builtin_palettes(prod):
