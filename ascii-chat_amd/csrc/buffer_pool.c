@@ -44,6 +44,7 @@ struct buffer_pool {
   pthread_mutex_t mu;       /* the pinned class (best fit over a short list) and nothing else */
   uint64_t free_small;      /* lock-free LIFO head: {node pointer : 48, ABA tag : 16} */
   int small_pops;           /* threads inside a pop: shrink waits for 0 before it frees detached nodes */
+  int shrinking;            /* a shrink is in progress (try-lock) */
   pool_node_t *free_pinned;
   size_t max_bytes;
   uint64_t shrink_delay_ns;
@@ -66,10 +67,21 @@ static void small_push(buffer_pool_t *pool, pool_node_t *n) {
 }
 
 /* the head node if it is large enough (LIFO head only, like the reference), else NULL */
+static inline void cpu_relax(void) {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#elif defined(__aarch64__)
+  __asm__ __volatile__("yield");
+#endif
+}
+
 static pool_node_t *small_pop(buffer_pool_t *pool, size_t size) {
-  __atomic_add_fetch(&pool->small_pops, 1, __ATOMIC_ACQUIRE);
+  /* Dekker-style handshake with buffer_pool_shrink (announce, THEN look at the head; shrink detaches the head, THEN
+   * looks at the announcements): both sides need their store ordered before their load, i.e. sequential consistency --
+   * acquire / release alone only worked because x86's locked instructions are full barriers */
+  __atomic_add_fetch(&pool->small_pops, 1, __ATOMIC_SEQ_CST);
   pool_node_t *n;
-  uint64_t old = __atomic_load_n(&pool->free_small, __ATOMIC_ACQUIRE);
+  uint64_t old = __atomic_load_n(&pool->free_small, __ATOMIC_SEQ_CST);
   for (;;) {
     n = HEAD_PTR(old);
     /* relaxed atomics: another thread may win this node and clear its link while we look (the tag then fails our swap) */
@@ -164,7 +176,7 @@ const void *achip_pool_device_ptr(const void *host_ptr) {
   for (;;) {
     const unsigned s0 = __atomic_load_n(&g_pin_seq, __ATOMIC_ACQUIRE);
     if (s0 & 1u) { /* a writer is inside: it holds the mutex only for a few dozen stores */
-      __builtin_ia32_pause();
+      cpu_relax();
       continue;
     }
     /* the entry with the greatest lo <= p; indices stay inside the static array whatever a concurrent writer does,
@@ -382,12 +394,35 @@ void buffer_pool_shrink(buffer_pool_t *pool) {
   const uint64_t now = now_ns();
   const uint64_t cutoff = now > pool->shrink_delay_ns ? now - pool->shrink_delay_ns : 0;
   pool_node_t *doomed = NULL;
-  /* small class: take the whole list, wait for the pops that may still look at its nodes, keep the young ones */
+  /* one shrinker at a time; a caller that finds one at work skips its turn (it runs on every 100th free) */
+  int expected = 0;
+  if (!__atomic_compare_exchange_n(&pool->shrinking, &expected, 1, 0, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED))
+    return;
+  /* small class: take the whole list, wait -- a bounded while -- for the pops that may still look at its nodes, keep the
+   * young ones.  While the list is detached every alloc misses it, so the wait must not depend on the callers going
+   * quiet: pops that started AFTER the detach cannot see a detached node, but they are counted too, and under a steady
+   * stream of them the count may never read zero.  After the bound nothing is freed this time. */
   uint64_t old = __atomic_load_n(&pool->free_small, __ATOMIC_ACQUIRE);
-  while (!__atomic_compare_exchange_n(&pool->free_small, &old, HEAD_PACK(NULL, old), 1, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE))
+  while (!__atomic_compare_exchange_n(&pool->free_small, &old, HEAD_PACK(NULL, old), 1, __ATOMIC_SEQ_CST, __ATOMIC_ACQUIRE))
     ;
-  while (__atomic_load_n(&pool->small_pops, __ATOMIC_ACQUIRE) != 0)
-    __builtin_ia32_pause();
+  bool quiet = false;
+  for (int spin = 0; spin < 20000 && !quiet; spin++) {
+    quiet = __atomic_load_n(&pool->small_pops, __ATOMIC_SEQ_CST) == 0;
+    if (!quiet)
+      cpu_relax();
+  }
+  if (!quiet && HEAD_PTR(old)) {
+    /* poppers are still about: they may be looking at any detached node, so no node is freed and no link inside the
+     * chain is written -- the chain goes back as it is (only its tail is linked to the current head, atomically) */
+    pool_node_t *first = HEAD_PTR(old), *tail = first;
+    while (tail->next)
+      tail = tail->next;
+    uint64_t cur = __atomic_load_n(&pool->free_small, __ATOMIC_RELAXED);
+    do {
+      __atomic_store_n(&tail->next, HEAD_PTR(cur), __ATOMIC_RELAXED);
+    } while (!__atomic_compare_exchange_n(&pool->free_small, &cur, HEAD_PACK(first, cur), 1, __ATOMIC_RELEASE, __ATOMIC_RELAXED));
+    old = HEAD_PACK(NULL, old); /* nothing left to sort below */
+  }
   pool_node_t *keep = NULL;
   for (pool_node_t *n = HEAD_PTR(old); n;) {
     pool_node_t *nx = n->next;
@@ -426,6 +461,7 @@ void buffer_pool_shrink(buffer_pool_t *pool) {
     release_node(doomed);
     doomed = nx;
   }
+  __atomic_store_n(&pool->shrinking, 0, __ATOMIC_RELEASE);
 }
 
 void buffer_pool_get_stats(buffer_pool_t *pool, size_t *current_bytes, size_t *used_bytes, size_t *free_bytes) {

@@ -32,10 +32,15 @@
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
 
+#include <errno.h>
+#include <limits.h>
+#include <linux/futex.h>
 #include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/syscall.h>
 #include <time.h>
+#include <unistd.h>
 
 #include "achip_host.h"
 #include "asciichat_hip.h"
@@ -47,9 +52,16 @@
 #define CB_ARENA ((size_t)16 << 20)    /* pinned staging bytes per generation (sampled source rows)  */
 #define CB_SLAB ((size_t)8 << 20)     /* pinned output bytes per generation                         */
 #define CB_DEVICES 16
-#define CB_GENS 4      /* generations per device                                                     */
-#define CB_INFLIGHT 3  /* generations that may be in flight at once (each on its own stream): below that a caller
+#define CB_GENS 8      /* generations per device                                                     */
+#define CB_INFLIGHT 6  /* generations that may be in flight at once (each on its own stream): below that a caller
                           launches at once, like the direct path; above it callers accumulate into batches      */
+#define CB_FILL 16     /* members after which callers start the next generation instead of joining this one: a generation
+                          is an upload, a launch and a read-back in sequence (~40 us + 20 us per MB of rows), so sixty-four
+                          callers in ONE generation wait ~300 us with the link idle half of the time, while four
+                          generations of sixteen keep upload, kernels and read-back of different generations overlapped
+                          (profiles/r03_dropin_threads.txt: 64 threads 153 k -> calls/s) */
+#define CB_RUN_DEADLINE_S 10 /* a generation whose stream has not drained by then is reported as failed (a wedged GPU
+                                must not hang every caller of the library for ever) */
 
 enum { GEN_FREE = 0, GEN_OPEN, GEN_CLOSED, GEN_DONE };
 
@@ -61,6 +73,7 @@ typedef struct {
   size_t stage_off; /* (size_t)-1: read in place */
   size_t out_off;
   uint32_t len;
+  int failed; /* the launch of this request's (mode, palette) group failed: only its members get the error */
 } cb_req_t;
 
 typedef struct {
@@ -84,20 +97,26 @@ typedef struct {
   cb_gen_t gen[CB_GENS];
   int open; /* index of the OPEN generation, -1 = none */
   int inflight; /* generations between CLOSED and DONE */
+  int turnover; /* bumped whenever a generation changes state in a way that may let a waiting caller in (futex word) */
+  int launch_seq; /* bumped when an in-flight slot frees up: members of OPEN generations waiting to launch (futex word) */
   int ready; /* 0 = untried, 1 = usable, -1 = initialisation failed (callers use the direct path) */
   int cus;
 } cb_t;
 
 /* Waiting.  A generation is in flight for ~30 us and a futex sleep + wake costs about as much, so nobody sleeps at
- * first: a member polls ITS generation's state word (an atomic; no lock, no shared wake-up word -- sixteen waiters
- * re-taking one mutex at every state change was what the first version of this file spent its time on), and only after
- * CB_SPINS polls falls back to short timed sleeps on the condition variable. */
-#define CB_SPINS 4000
+ * first: a member polls ITS generation's state word (an atomic; no lock, no shared word).  After CB_SPINS polls it parks
+ * on a FUTEX on that very word -- no mutex, no timed re-polling: round 2 fell back to 100 us timed waits on one condition
+ * variable under the table's mutex, and from ~32 callers on those re-takes starved the combiners (72 k calls/s at 64
+ * threads where 16 threads reached 160 k; profiles/r02_dropin_threads.txt).  Callers that find every generation busy
+ * park the same way on the table's turnover counter. */
+#define CB_SPINS 2000
 
 static cb_t g_cb[CB_DEVICES];
 static pthread_once_t g_cb_once = PTHREAD_ONCE_INIT;
 static int g_cb_enabled = 1;
-static int g_cb_min_callers = 24; /* calls in flight from which coalescing pays (profiles/r02_dropin_threads.txt) */
+static int g_cb_min_callers = 12; /* calls in flight from which coalescing pays (profiles/r03_dropin_threads.txt: at 16
+                                     threads 174 k / 247 k calls/s combined against 99 k / 160 k direct; at 8 threads generations of
+                                     one or two members are slower than the direct path's 95-105 k) */
 static int g_cb_callers;          /* drop-in render calls currently inside achip_combine_render / the direct path */
 
 static void cb_global_init(void) {
@@ -106,7 +125,7 @@ static void cb_global_init(void) {
     pthread_cond_init(&g_cb[d].cv, NULL);
     g_cb[d].open = -1;
   }
-  /* ASCIICHAT_HIP_COALESCE: 0 = never, 1 = always, N >= 2 = from N concurrent callers on (default 24: below that
+  /* ASCIICHAT_HIP_COALESCE: 0 = never, 1 = always, N >= 2 = from N concurrent callers on (default 12: below that
    * every call launching on its own thread's stream is as fast or faster, above it the HIP runtime's serialised
    * per-launch work makes throughput collapse and shared launches hold it) */
   const char *e = getenv("ASCIICHAT_HIP_COALESCE");
@@ -135,6 +154,7 @@ void achip_combine_enter(void) {
   __atomic_add_fetch(&g_cb_callers, 1, __ATOMIC_RELAXED);
 }
 void achip_combine_leave(void) { __atomic_sub_fetch(&g_cb_callers, 1, __ATOMIC_RELAXED); }
+int achip_combine_callers(void) { return __atomic_load_n(&g_cb_callers, __ATOMIC_RELAXED); }
 
 static int pinned_mapped(void **host, void **dev, size_t bytes) {
   if (hipHostMalloc(host, bytes, hipHostMallocMapped) != hipSuccess)
@@ -180,28 +200,39 @@ static void cb_device_init(cb_t *cb) {
 #define LOAD(x) __atomic_load_n(&(x), __ATOMIC_ACQUIRE)
 #define STORE(x, v) __atomic_store_n(&(x), (v), __ATOMIC_RELEASE)
 
-/* one poll step: a pause while spinning, a short timed sleep afterwards (mu NOT held) */
-static void cb_backoff(cb_t *cb, int *spins) {
-  if (++*spins < CB_SPINS) {
-    __builtin_ia32_pause();
-    return;
-  }
-  struct timespec ts;
-  clock_gettime(CLOCK_REALTIME, &ts);
-  ts.tv_nsec += 100000; /* 100 us */
-  if (ts.tv_nsec >= 1000000000L) {
-    ts.tv_nsec -= 1000000000L;
-    ts.tv_sec++;
-  }
-  pthread_mutex_lock(&cb->mu);
-  (void)pthread_cond_timedwait(&cb->cv, &cb->mu, &ts);
-  pthread_mutex_unlock(&cb->mu);
+static inline void cpu_relax(void) {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#elif defined(__aarch64__)
+  __asm__ __volatile__("yield");
+#endif
 }
 
-static void cb_wake_sleepers(cb_t *cb) {
-  pthread_mutex_lock(&cb->mu);
-  pthread_cond_broadcast(&cb->cv);
-  pthread_mutex_unlock(&cb->mu);
+/* park until *word != seen (or a spurious wake-up; the callers re-check).  A bounded wait: a lost wake-up costs 2 ms,
+ * not a hang. */
+static void futex_park(int *word, int seen) {
+  const struct timespec ts = {0, 2000000};
+  (void)syscall(SYS_futex, word, FUTEX_WAIT_PRIVATE, seen, &ts, NULL, 0);
+}
+static void futex_wake_all(int *word) { (void)syscall(SYS_futex, word, FUTEX_WAKE_PRIVATE, INT_MAX, NULL, NULL, 0); }
+
+/* one poll step on a word that still holds `seen`: a pause while spinning, parked on the word afterwards (mu NOT held) */
+static void cb_backoff(int *word, int seen, int *spins) {
+  if (++*spins < CB_SPINS)
+    cpu_relax();
+  else
+    futex_park(word, seen);
+}
+
+/* a generation became FREE, or left the OPEN state: callers waiting for a slot may try again */
+static void cb_turnover(cb_t *cb) {
+  __atomic_add_fetch(&cb->turnover, 1, __ATOMIC_RELEASE);
+  futex_wake_all(&cb->turnover); /* (waking only a generation's worth was tried: at 128 callers the rest then sit out their
+                                    2 ms timeouts -- 92 k -> 59 k calls/s) */
+}
+static void cb_launch_slot(cb_t *cb) {
+  __atomic_add_fetch(&cb->launch_seq, 1, __ATOMIC_RELEASE);
+  futex_wake_all(&cb->launch_seq);
 }
 
 /* the generation's launches: one DMA for the staged rows, one kernel per (mode, palette) group, one wait */
@@ -239,7 +270,12 @@ static void cb_run(cb_t *cb, cb_gen_t *G) {
       G->lens_host[base + k] = ACHIP_LEN_BADDESC;
     }
     int variant = -1, parts = 1, rpp = 1;
-    if (achip_choose_geometry(G->req[i].mode, G->descs_host + base, n, G->req[i].ascii != 0, caps, cb->cus, 0, -1, &variant,
+    /* whole frames, never row bands: the bands of a frame wait for each other across workgroups, which is safe for ONE
+     * launch (a launch dispatches in order) but not for six generations and a crowd of direct callers in flight at once --
+     * workgroups of different launches then fill the CUs of one XCD while the bands they wait for queue on another, and
+     * the bounded wait turns the stall into ACHIP_LEN_OVERFLOW (seen at 128 calling threads; the guide: dispatch order
+     * across XCDs is undefined).  A generation's launch is latency-bound either way (~10 us). */
+    if (achip_choose_geometry(G->req[i].mode, G->descs_host + base, n, G->req[i].ascii != 0, caps, cb->cus, -1, -1, &variant,
                               &parts, &rpp) != 0 ||
         variant < 0) {
       e = hipErrorInvalidValue, what = "geometry selection";
@@ -272,15 +308,37 @@ static void cb_run(cb_t *cb, cb_gen_t *G) {
     n_of_group[groups++] = n;
     cursor += (size_t)n * stride;
   }
-  if (e == hipSuccess) {
-    while ((e = hipStreamQuery(S->stream)) == hipErrorNotReady)
-      ; /* the callers of this generation are asleep on it: do not add a driver wake-up to their latency */
-    what = "hipStreamQuery";
+  const int groups_launched = e == hipSuccess ? groups : groups - 1; /* the group whose launch failed is the last one */
+  if (groups_launched > 0 || e == hipSuccess) {
+    /* the callers of this generation are parked on it: poll, do not add a driver wake-up to their latency -- but not for
+     * ever: past the deadline the stream is synchronised (which reports a wedged queue) and the generation fails */
+    hipError_t q;
+    struct timespec t0, t;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    unsigned polls = 0;
+    while ((q = hipStreamQuery(S->stream)) == hipErrorNotReady) {
+      if ((++polls & 0xFFFu) == 0u) {
+        clock_gettime(CLOCK_MONOTONIC, &t);
+        if (t.tv_sec - t0.tv_sec >= CB_RUN_DEADLINE_S) {
+          q = hipStreamSynchronize(S->stream);
+          if (q == hipSuccess)
+            q = hipErrorNotReady; /* it did drain, but far too late for anyone to trust this queue */
+          break;
+        }
+      }
+    }
+    if (q != hipSuccess && e == hipSuccess)
+      e = q, what = "hipStreamQuery", groups = 0; /* nothing of this generation can be trusted */
   }
   if (e != hipSuccess) {
     (void)hipGetLastError();
-    (void)hipStreamSynchronize(S->stream); /* groups launched before the failure still write this generation's slab */
-    (void)hipGetLastError();
+    /* groups that were launched before the failure completed above: their members get their frames; the members of the
+     * failing group and of the groups never launched get the error (one bad group used to fail them all) */
+    for (int g = 0; g < (groups_launched > 0 && groups > 0 ? groups_launched : 0); g++)
+      for (int k = 0; k < n_of_group[g]; k++)
+        G->req[order[base_of_group[g] + k]].len = G->lens_host[base_of_group[g] + k];
+    for (int i = 0; i < G->n; i++)
+      G->req[i].failed = G->req[i].len == ACHIP_LEN_BADDESC;
     G->failed = 1;
     const char *msg = hipGetErrorString(e);
     size_t k = 0;
@@ -305,8 +363,22 @@ char *achip_combine_render(int mode, const char *palette, const achip_lut_t *lut
                            int *handled) {
   *handled = 0;
   pthread_once(&g_cb_once, cb_global_init);
-  if (!g_cb_enabled || f->comp || __atomic_load_n(&g_cb_callers, __ATOMIC_RELAXED) < g_cb_min_callers)
+  if (!g_cb_enabled || f->comp)
     return NULL;
+  { /* with hysteresis: coalescing starts at min_callers calls in flight and stops below half of that.  The count of T
+     * steadily calling threads hovers a little below T (they also free strings and loop), and a threshold without
+     * memory made T = min_callers threads flip between the two paths call by call -- slower than either (80 k calls/s at 8
+     * threads against 94 k direct and 126 k combined; profiles/r03_dropin_threads.txt) */
+    static int engaged;
+    const int callers = __atomic_load_n(&g_cb_callers, __ATOMIC_RELAXED);
+    int on = __atomic_load_n(&engaged, __ATOMIC_RELAXED);
+    if (!on && callers >= g_cb_min_callers)
+      __atomic_store_n(&engaged, on = 1, __ATOMIC_RELAXED);
+    else if (on && 2 * callers < g_cb_min_callers)
+      __atomic_store_n(&engaged, on = 0, __ATOMIC_RELAXED);
+    if (!on)
+      return NULL;
+  }
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= CB_DEVICES)
     return NULL;
@@ -356,12 +428,21 @@ char *achip_combine_render(int mode, const char *palette, const achip_lut_t *lut
     if (cb->open >= 0) {
       G = &cb->gen[cb->open];
       const size_t mb = bound > G->max_bound ? bound : G->max_bound;
-      if (G->n < CB_MAX && G->arena_used + need_al <= CB_ARENA && (size_t)(G->n + 1) * mb <= CB_SLAB)
+      if (G->n < CB_FILL && G->arena_used + need_al <= CB_ARENA && (size_t)(G->n + 1) * mb <= CB_SLAB)
         break;
+      /* full: its members launch it; the next generation opens now if one is free */
+      cb->open = -1;
+      int have_free = 0;
+      for (int g = 0; g < CB_GENS; g++)
+        have_free |= LOAD(cb->gen[g].state) == GEN_FREE;
+      if (have_free)
+        continue;
     }
-    /* every generation is busy, or the open one is full (its members are about to launch it): poll */
+    /* every generation is busy, or the open one is full (its members are about to launch it): wait for a turnover */
+    const int seen = LOAD(cb->turnover);
     pthread_mutex_unlock(&cb->mu);
-    cb_backoff(cb, &spins);
+    if (LOAD(cb->turnover) == seen)
+      cb_backoff(&cb->turnover, seen, &spins);
     pthread_mutex_lock(&cb->mu);
   }
   cb_req_t *r = &G->req[G->n++];
@@ -370,6 +451,7 @@ char *achip_combine_render(int mode, const char *palette, const achip_lut_t *lut
   r->ascii = achip_palette_ascii_only(palette) ? 1 : 0;
   r->bound = bound;
   r->len = ACHIP_LEN_BADDESC;
+  r->failed = 0;
   r->stage_off = alias ? (size_t)-1 : G->arena_used;
   G->arena_used += need_al;
   if (bound > G->max_bound)
@@ -401,28 +483,46 @@ char *achip_combine_render(int mode, const char *palette, const achip_lut_t *lut
   r->desc = d;
 
   __atomic_add_fetch(&G->filled, 1, __ATOMIC_RELEASE);
-  for (int spins = 0; LOAD(G->state) != GEN_DONE;) {
-    if (LOAD(G->state) == GEN_OPEN && LOAD(cb->inflight) < CB_INFLIGHT && pthread_mutex_trylock(&cb->mu) == 0) {
+  for (int spins = 0;;) {
+    const int st = LOAD(G->state);
+    if (st == GEN_DONE)
+      break;
+    if (st == GEN_OPEN && LOAD(cb->inflight) < CB_INFLIGHT && pthread_mutex_trylock(&cb->mu) == 0) {
       if (LOAD(G->state) == GEN_OPEN && cb->inflight < CB_INFLIGHT) { /* become the combiner of this generation */
-        STORE(cb->inflight, cb->inflight + 1);
+        __atomic_add_fetch(&cb->inflight, 1, __ATOMIC_ACQ_REL); /* (an atomic RMW: the decrement below runs outside the
+                                                                   mutex, and a plain read-add-store here lost decrements --
+                                                                   the count crept up until no generation could launch) */
         STORE(G->state, GEN_CLOSED);
         if (cb->open >= 0 && &cb->gen[cb->open] == G)
           cb->open = -1;
         const int members = G->n; /* final from here on */
         pthread_mutex_unlock(&cb->mu);
+        cb_turnover(cb); /* the next caller opens a fresh generation */
+        futex_wake_all(&G->state); /* members parked on OPEN re-park on CLOSED */
         while (LOAD(G->filled) < members) /* members still copying their rows: a memcpy away */
-          __builtin_ia32_pause();
+          cpu_relax();
         cb_run(cb, G);
         STORE(G->state, GEN_DONE);
+        futex_wake_all(&G->state);
         __atomic_sub_fetch(&cb->inflight, 1, __ATOMIC_RELEASE);
-        cb_wake_sleepers(cb);
+        cb_launch_slot(cb); /* an OPEN generation may now be launched by one of its members */
         break;
       }
       pthread_mutex_unlock(&cb->mu);
     }
-    cb_backoff(cb, &spins);
+    /* an OPEN generation that cannot launch yet (all in-flight slots taken) re-checks on every turnover; a CLOSED one
+     * only changes to DONE */
+    if (st == GEN_OPEN) {
+      const int seen = LOAD(cb->launch_seq);
+      if (LOAD(G->state) == GEN_OPEN && LOAD(cb->inflight) >= CB_INFLIGHT)
+        cb_backoff(&cb->launch_seq, seen, &spins);
+      else
+        cpu_relax();
+    } else {
+      cb_backoff(&G->state, st, &spins);
+    }
   }
-  const int failed = G->failed;
+  const int failed = G->failed && r->failed;
   const uint32_t len = r->len;
   const size_t out_off = r->out_off;
   char errbuf[160];
@@ -441,9 +541,13 @@ char *achip_combine_render(int mode, const char *palette, const achip_lut_t *lut
     memcpy(out, G->slab_host + out_off, len);
     out[len] = '\0';
   }
-  if (__atomic_add_fetch(&G->copied, 1, __ATOMIC_ACQ_REL) == G->n) { /* last one out */
+  /* (the member count is read BEFORE this member counts itself out: once it has, the others may finish, the generation
+   * may be recycled and G->n may belong to its next life -- a member that then compared its count with the new n could
+   * "free" a generation in use; with sixteen-member generations cycling fast that happened within seconds) */
+  const int members_out = G->n;
+  if (__atomic_add_fetch(&G->copied, 1, __ATOMIC_ACQ_REL) == members_out) { /* last one out */
     STORE(G->state, GEN_FREE);
-    cb_wake_sleepers(cb);
+    cb_turnover(cb);
   }
   return out;
 }

@@ -211,8 +211,12 @@ static char *render_with_lut(tls_ctx_t *c, const achip_lut_t *lut, int mode, con
   int caps[ACHIP_VARIANT_COUNT], variant = -1, parts = 1, rows_per_part = 1;
   for (int v = 0; v < ACHIP_VARIANT_COUNT; v++)
     caps[v] = achip_variant_cap(v);
-  if (achip_choose_geometry(mode, f, 1, achip_palette_ascii_only(palette), caps, device_cu_count(), 0, -1, &variant, &parts,
-                            &rows_per_part) != 0 ||
+  /* row bands (the single frame cut over many workgroups that wait for each other) only while few calls are in flight:
+   * with many launches from many threads on the GPU at once the bands of one frame can end up waiting behind other
+   * launches' waiters (dispatch order across XCDs is undefined); whole-frame launches have no such dependency */
+  const int split_request = achip_combine_callers() > 4 ? -1 : 0;
+  if (achip_choose_geometry(mode, f, 1, achip_palette_ascii_only(palette), caps, device_cu_count(), split_request, -1, &variant,
+                            &parts, &rows_per_part) != 0 ||
       variant < 0 || parts > DROPIN_MAX_PARTS) {
     achip_fail(ASCIICHAT_HIP_ERR_NOT_SUPPORTED, "row of %d cells exceeds the kernel chunk", f->pad_left + f->out_w);
     return NULL;

@@ -308,7 +308,9 @@ int asciichat_hip_frame_table_latest(asciichat_hip_frame_table_t *t, int slot, v
   return rc;
 }
 
-/* A consumer that destroys a stream it passed to latest() calls this first (or simply stops: a dead stream is skipped). */
+/* A consumer that destroys a stream it passed to latest() MUST call this first: publish() records events on the remembered
+ * handles, and using a destroyed hipStream_t is undefined (ROCm happens to validate handles, which is what the skip in
+ * publish() relies on as a last resort; a handle recycled by a later stream would make uploads wait on unrelated work). */
 void asciichat_hip_frame_table_forget_stream(asciichat_hip_frame_table_t *t, void *consumer_stream) {
   if (!t)
     return;

@@ -25,6 +25,7 @@ void achip_lut_put(const achip_lut_t *dev);
  * direct path; else the malloc'd string or NULL (achip_fail has the reason). */
 void achip_combine_enter(void);
 void achip_combine_leave(void);
+int achip_combine_callers(void); /* drop-in render calls in flight right now */
 char *achip_combine_render(int mode, const char *palette, const achip_lut_t *lut, const achip_frame_t *f, size_t src_bytes,
                            int *handled);
 

@@ -224,9 +224,16 @@ static int choose_geometry(asciichat_hip_plan_t *p, const achip_frame_t *frames)
   const char *env = getenv("ASCIICHAT_HIP_VARIANT");
   const int forced = p->variant_user >= 0 ? p->variant_user : (env && env[0] ? atoi(env) : -1);
   const int cus = device_cus() / (p->concurrency > 1 ? p->concurrency : 1);
-  if (achip_choose_geometry(p->mode, frames, p->n, p->palette_ascii != 0, caps, cus > 0 ? cus : 1,
-                            forced >= 0 && p->split_request == 0 ? -1 : p->split_request, /* explicit geometry alone: whole frames */
-                            forced < ACHIP_VARIANT_COUNT || (forced >= ACHIP_STREAM_VARIANT_FIRST && achip_variant_block(forced) > 0) ? forced : -1, &variant, &parts, &rpp) != 0)
+  const int known = forced < ACHIP_VARIANT_COUNT || (forced >= ACHIP_STREAM_VARIANT_FIRST && achip_variant_block(forced) > 0);
+  int rc = achip_choose_geometry(p->mode, frames, p->n, p->palette_ascii != 0, caps, cus > 0 ? cus : 1,
+                                 forced >= 0 && p->split_request == 0 ? -1 : p->split_request, /* explicit geometry alone: whole frames */
+                                 known ? forced : -1, &variant, &parts, &rpp);
+  if (rc != 0 && forced >= 0 && p->variant_user < 0) /* ASCIICHAT_HIP_VARIANT names a geometry that does not apply to this
+                                                        plan's mode or size: the override is process-wide, the plan is
+                                                        not -- choose automatically */
+    rc = achip_choose_geometry(p->mode, frames, p->n, p->palette_ascii != 0, caps, cus > 0 ? cus : 1, p->split_request, -1,
+                               &variant, &parts, &rpp);
+  if (rc != 0)
     return -1;
   p->variant = variant;
   p->parts = parts;
@@ -265,9 +272,16 @@ static int plan_measure(asciichat_hip_plan_t *p, const achip_frame_t *frames) {
   q.stride = stride;
   q.max_wp = max_wp;
   (void)achip_frames_uniform(frames, q.n, &q.uniform);
-  if (choose_geometry(&q, frames) != 0 || q.variant < 0 || achip_variant_cap(q.variant) < max_wp)
+  if (choose_geometry(&q, frames) != 0 || q.variant < 0 || achip_variant_cap(q.variant) < max_wp) {
+    if (q.variant_user >= 0) /* a geometry forced with set_variant: say why it does not apply */
+      return achip_fail(ASCIICHAT_HIP_ERR_NOT_SUPPORTED,
+                        "geometry %d does not apply to this plan (mode %d, widest padded row %d cells, %ld cells in the largest "
+                        "frame): stream geometries 16-19 take the per-cell modes, rows geometries 24-25 the run-structured "
+                        "modes with rows of at most %d cells, 1-2 no half-block mode",
+                        q.variant_user, q.mode, max_wp, achip_max_cells(frames, q.n), 64 * 7);
     return achip_fail(ASCIICHAT_HIP_ERR_NOT_SUPPORTED, "padded row of %d cells exceeds the kernel chunk (max %d)",
                       max_wp, achip_variant_cap(0));
+  }
   unsigned long long *new_sync = NULL;
   if (q.parts > 1 && q.parts > q.parts_cap) { /* hand-off words for the multi-workgroup frames */
     const size_t bytes = (size_t)q.n * (size_t)q.parts * sizeof(unsigned long long);
@@ -333,14 +347,15 @@ int asciichat_hip_plan_create(asciichat_hip_plan_t **plan, int mode, const char 
 int asciichat_hip_plan_update(asciichat_hip_plan_t *p, const achip_frame_t *frames, void *stream) {
   if (!p || !frames)
     return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "plan_update: bad arguments");
-  int rc = plan_measure(p, frames);
+  /* the pinned staging copy may still be in flight from the previous update on this stream: wait for it BEFORE the new
+   * geometry is committed, so that a failure here leaves the plan as it was */
+  int rc = achip_hip_check((int)hipStreamSynchronize((hipStream_t)stream), "hipStreamSynchronize");
+  if (rc)
+    return rc;
+  rc = plan_measure(p, frames);
   if (rc)
     return rc;
   const size_t bytes = (size_t)p->n * sizeof(achip_frame_t);
-  /* the pinned staging copy may still be in flight from the previous update on this stream */
-  rc = achip_hip_check((int)hipStreamSynchronize((hipStream_t)stream), "hipStreamSynchronize");
-  if (rc)
-    return rc;
   memcpy(p->frames_pinned, frames, bytes);
   return achip_hip_check(
       (int)hipMemcpyAsync(p->frames_dev, p->frames_pinned, bytes, hipMemcpyHostToDevice, (hipStream_t)stream),
@@ -352,7 +367,8 @@ size_t asciichat_hip_plan_out_stride(const asciichat_hip_plan_t *p) { return p ?
 int asciichat_hip_plan_set_variant(asciichat_hip_plan_t *p, int variant) {
   if (!p)
     return ASCIICHAT_HIP_ERR_INVALID_PARAM;
-  if (variant >= 0 && achip_variant_cap(variant) < p->max_wp)
+  if (variant >= 0 && !ACHIP_IS_STREAM_VARIANT(variant) && achip_variant_cap(variant) < p->max_wp) /* (a stream geometry's
+                                                             "cap" is cells per frame: plan_measure judges those) */
     return achip_fail(ASCIICHAT_HIP_ERR_NOT_SUPPORTED, "variant %d cannot hold a %d-cell row", variant, p->max_wp);
   const int before = p->variant_user;
   p->variant_user = variant;

@@ -142,8 +142,8 @@ void asciichat_hip_plan_destroy(asciichat_hip_plan_t *plan);
  * Drop-in layer: coalescing of concurrent calls (combine.c).  The reference's server calls
  * ascii_convert_with_capabilities from one render thread per client; from `n` calls in flight on, those calls share
  * launches (flat combining: one upload, one kernel per (mode, palette) group, one wait per generation of callers).
- * n = 0 never, 1 always, default 24 -- below that every call launching on its own thread's stream is as fast or faster
- * (profiles/r02_dropin_threads.txt).  Also settable with the environment variable ASCIICHAT_HIP_COALESCE.  Returns the
+ * n = 0 never, 1 always, default 12 (with hysteresis: off again below 6) -- below that every call launching on its own thread's stream is as fast or faster
+ * (profiles/r03_dropin_threads.txt).  Also settable with the environment variable ASCIICHAT_HIP_COALESCE.  Returns the
  * previous setting.
  */
 int asciichat_hip_set_coalesce_min_callers(int n);
@@ -178,7 +178,8 @@ int asciichat_hip_image_flip(const uint8_t *src_dev, uint8_t *dst_dev, int width
  *             consumer_stream was handed this buffer: the upload that will overwrite it (the publish after next on
  *             the slot) is ordered behind everything enqueued on consumer_stream up to that publish.  The pointer is
  *             therefore good for work enqueued before the publish after next; call latest() again every tick.
- *   forget_stream  before destroying a stream that was passed to latest()
+ *   forget_stream  REQUIRED before destroying a stream that was passed to latest(): the table records events on the streams
+ *             it remembers, and a destroyed handle (or one recycled by a later stream) must not be among them
  */
 typedef struct asciichat_hip_frame_table asciichat_hip_frame_table_t;
 int asciichat_hip_frame_table_create(asciichat_hip_frame_table_t **table, int n_slots);

@@ -47,12 +47,17 @@ static double now(void) {
 }
 
 int main(int argc, char **argv) {
+  setvbuf(stdout, NULL, _IOLBF, 0); /* a run that is cut off keeps the lines it produced */
   const int max_threads = argc > 1 ? atoi(argv[1]) : 32;
   const int sw = argc > 7 ? atoi(argv[2]) : 1920, sh = argc > 7 ? atoi(argv[3]) : 1080;
   const int tw = argc > 7 ? atoi(argv[4]) : 80, th = argc > 7 ? atoi(argv[5]) : 24;
   const int cl = argc > 7 ? atoi(argv[6]) : TERM_COLOR_TRUECOLOR, rm = argc > 7 ? atoi(argv[7]) : RENDER_MODE_FOREGROUND;
+  const int min_threads = getenv("DT_MIN_T") ? atoi(getenv("DT_MIN_T")) : 1; /* start the sweep here */
+  const int only = getenv("DT_POOLED") ? atoi(getenv("DT_POOLED")) : -1;       /* 0 pageable, 1 pooled, unset both */
   for (int pooled = 0; pooled <= 1; pooled++) {
-    for (int T = 1; T <= max_threads; T *= 2) {
+    if (only >= 0 && pooled != only)
+      continue;
+    for (int T = min_threads; T <= max_threads; T *= 2) {
       job_t *jobs = (job_t *)calloc((size_t)T, sizeof(job_t));
       pthread_t *tid = (pthread_t *)calloc((size_t)T, sizeof(pthread_t));
       pthread_barrier_init(&gate, NULL, (unsigned)T + 1);
