@@ -70,8 +70,10 @@ def main():
             elif choice == 4:
                 plan.set_variant(int(rng.choice([1, 2, 4])))
                 plan.set_split(int(rng.integers(1, 6)))
-            elif choice >= 5:  # the stream kernel's geometries (per-cell modes; refused for the others)
-                plan.set_variant(int(rng.choice([16, 17, 17, 18, 19])))
+            elif choice >= 5:  # the wave-autonomous kernels: stream geometries (per-cell modes) / rows geometries (run-structured
+                # modes); refused for the other family and for rows wider than a block, with the fused CRC forced on
+                plan.set_variant(int(rng.choice([24, 25, 25]) if mode in (0, 5, 6, 7, 8) else rng.choice([16, 17, 17, 18, 19])))
+                plan.set_fused_crc(1)
         except RuntimeError:
             pass  # geometry cannot hold this batch's rows: keep the automatic one
         out = torch.full((len(frames) * plan.stride,), 0xAB, dtype=torch.uint8, device="cuda")
@@ -87,8 +89,16 @@ def main():
         assert pkg.lib().asciichat_hip_frame_packets(out.data_ptr(), plan.stride, ln.data_ptr(), plan.stride, nfr, dims_t.data_ptr(),
                                                      crc_t.data_ptr(), hdr_t.data_ptr(), pkt_t.data_ptr(),
                                                      torch.cuda.current_stream().cuda_stream) == 0, pkg.last_error()
+        packed_t = torch.full((len(frames) * plan.stride,), 0xCD, dtype=torch.uint8, device="cuda")
+        off_t = torch.zeros(nfr + 1, dtype=torch.int64, device="cuda")
+        pkg.pack_frames(out.data_ptr(), plan.stride, ln.data_ptr(), nfr, packed_t.data_ptr(), packed_t.numel(), off_t.data_ptr(), None,
+                        torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         host, lens = out.cpu().numpy(), ln.cpu().numpy().astype(np.uint32)
+        ph, oh = packed_t.cpu().numpy(), off_t.cpu().numpy()
+        for k in range(nfr):
+            assert oh[k] % 16 == 0 and (ph[oh[k]:oh[k] + int(lens[k])] == host[k * plan.stride:k * plan.stride + int(lens[k])]).all(), ("pack", rnd, k)
+        assert int(oh[nfr]) == sum((int(v) + 15) // 16 * 16 for v in lens), ("pack total", rnd)
         crc_h, pkt_h, hdr_h = crc_t.cpu().numpy().astype(np.uint32), pkt_t.cpu().numpy().astype(np.uint32), hdr_t.cpu().numpy()
         memo = {}
         for k, (img, W, H) in enumerate(cases):

@@ -11,7 +11,7 @@ import sys
 
 def main():
     rows = [r for r in csv.DictReader(open(sys.argv[1]))
-            if "render_frames_kernel" in r["Kernel_Name"] or "render_stream_kernel" in r["Kernel_Name"]]
+            if any(k in r["Kernel_Name"] for k in ("render_frames_kernel", "render_stream_kernel", "render_rows_kernel"))]
     by = {}
     for r in rows:
         by.setdefault(r["Kernel_Name"].split("(")[0], []).append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
