@@ -106,6 +106,9 @@ def lib():
     L.asciichat_hip_frame_table_publish.argtypes = [vp, ci, C.c_char_p, C.c_size_t, vp]
     L.asciichat_hip_frame_table_publish_rows.restype = ci
     L.asciichat_hip_frame_table_publish_rows.argtypes = [vp, ci, vp, C.c_size_t, C.POINTER(Frame), ci, vp]
+    L.asciichat_hip_frame_table_publish_rows_batch.restype = ci
+    L.asciichat_hip_frame_table_publish_rows_batch.argtypes = [vp, C.POINTER(ci), C.POINTER(vp), C.POINTER(C.c_size_t), ci,
+                                                               C.POINTER(Frame), ci, vp]
     L.asciichat_hip_frame_table_latest.restype = ci
     L.asciichat_hip_frame_table_latest.argtypes = [vp, ci, vp, C.POINTER(vp), C.POINTER(ci), C.POINTER(ci),
                                                    C.POINTER(C.c_uint64)]
@@ -631,6 +634,16 @@ class FrameTable:
             rc = lib().asciichat_hip_frame_table_publish_rows(self._h, slot, b, len(b), arr, len(targets), stream)
         if rc != 0:
             raise RuntimeError(f"frame_table_publish_rows failed: {last_error()}")
+
+    def publish_rows_batch(self, slots, blobs, targets, stream=0):
+        """one call for a whole tick: blobs = [(address, size)] of host buffers, slots = their table slots"""
+        n = len(slots)
+        arr = (Frame * len(targets))(*targets)
+        rc = lib().asciichat_hip_frame_table_publish_rows_batch(
+            self._h, (C.c_int * n)(*slots), (C.c_void_p * n)(*[b[0] for b in blobs]), (C.c_size_t * n)(*[b[1] for b in blobs]), n,
+            arr, len(targets), stream)
+        if rc != 0:
+            raise RuntimeError(f"frame_table_publish_rows_batch failed: {last_error()}")
 
     def publish_at(self, slot, address, size, stream=0):
         """publish a blob that already sits in host memory at `address` (e.g. a block of the pinned pool)"""

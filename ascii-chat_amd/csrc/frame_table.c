@@ -50,6 +50,13 @@ typedef struct {
 struct asciichat_hip_frame_table {
   int n;
   ft_slot_t *slot;
+  /* publish_rows_batch: one pinned staging block and its device twin per parity (a tick's block is still being DMA'd
+   * while the next tick's is filled), guarded by batch_mu */
+  pthread_mutex_t batch_mu;
+  uint8_t *batch_host[2], *batch_dev[2];
+  size_t batch_cap[2];
+  hipEvent_t batch_done[2];
+  unsigned batch_no;
 };
 
 int asciichat_hip_frame_table_create(asciichat_hip_frame_table_t **table, int n_slots) {
@@ -67,6 +74,7 @@ int asciichat_hip_frame_table_create(asciichat_hip_frame_table_t **table, int n_
     return achip_fail(ASCIICHAT_HIP_ERR_MEMORY, "out of memory");
   }
   t->n = n_slots;
+  pthread_mutex_init(&t->batch_mu, NULL);
   for (int i = 0; i < n_slots; i++) {
     t->slot[i].cur = -1;
     pthread_mutex_init(&t->slot[i].mu, NULL);
@@ -97,6 +105,17 @@ void asciichat_hip_frame_table_destroy(asciichat_hip_frame_table_t *t) {
       if (s->rows_dev[k])
         (void)hipFree(s->rows_dev[k]);
     }
+  for (int k = 0; k < 2; k++) {
+    if (t->batch_done[k]) {
+      (void)hipEventSynchronize(t->batch_done[k]);
+      (void)hipEventDestroy(t->batch_done[k]);
+    }
+    if (t->batch_host[k])
+      (void)hipHostFree(t->batch_host[k]);
+    if (t->batch_dev[k])
+      (void)hipFree(t->batch_dev[k]);
+  }
+  pthread_mutex_destroy(&t->batch_mu);
   free(t->slot);
   free(t);
 }
@@ -128,6 +147,7 @@ static int sampled_rows(const achip_frame_t *targets, int n_targets, uint32_t h,
 
 static int publish_common(asciichat_hip_frame_table_t *t, int slot, const void *blob, size_t blob_size,
                           const achip_frame_t *targets, int n_targets, void *stream);
+static int slot_prepare(ft_slot_t *s, size_t bytes, void *stream, int *k_out);
 
 int asciichat_hip_frame_table_publish(asciichat_hip_frame_table_t *t, int slot, const void *blob, size_t blob_size,
                                       void *stream) {
@@ -159,36 +179,8 @@ static int publish_common(asciichat_hip_frame_table_t *t, int slot, const void *
   const size_t bytes = (size_t)w * (size_t)h * 3u;
   ft_slot_t *s = &t->slot[slot];
   pthread_mutex_lock(&s->mu);
-  const int k = s->cur == 0 ? 1 : 0; /* the buffer that does not hold the latest frame */
-  int rc = 0;
-  if (s->ready[k]) /* the previous upload into this buffer reads the same pinned staging block: let it finish */
-    rc = achip_hip_check((int)hipEventSynchronize(s->ready[k]), "hipEventSynchronize(frame buffer)");
-  /* renders that were handed this buffer (one publish ago it was the latest frame) may still be queued or running:
-   * the upload goes behind everything enqueued so far on their streams */
-  if (!rc && s->n_readers[k] > 0 && !s->reader_done)
-    rc = achip_hip_check((int)hipEventCreateWithFlags(&s->reader_done, hipEventDisableTiming), "hipEventCreate");
-  for (int r = 0; r < s->n_readers[k] && !rc; r++) {
-    if (hipEventRecord(s->reader_done, s->reader[k][r]) != hipSuccess) {
-      (void)hipGetLastError(); /* the consumer destroyed its stream: nothing of it is left to wait for */
-      continue;
-    }
-    rc = achip_hip_check((int)hipStreamWaitEvent((hipStream_t)stream, s->reader_done, 0), "hipStreamWaitEvent(readers)");
-  }
-  if (!rc && s->readers_overflow[k])
-    rc = achip_hip_check((int)hipDeviceSynchronize(), "hipDeviceSynchronize(readers)");
-  s->n_readers[k] = 0;
-  s->readers_overflow[k] = 0;
-  if (!rc && s->cap[k] < bytes) {
-    if (s->dev[k])
-      (void)hipFree(s->dev[k]);
-    s->dev[k] = NULL;
-    s->cap[k] = 0;
-    rc = achip_hip_check((int)hipMalloc((void **)&s->dev[k], bytes), "hipMalloc(frame)");
-    if (!rc)
-      s->cap[k] = bytes;
-  }
-  if (!rc && !s->ready[k])
-    rc = achip_hip_check((int)hipEventCreateWithFlags(&s->ready[k], hipEventDisableTiming), "hipEventCreate");
+  int k = 0; /* the buffer that does not hold the latest frame */
+  int rc = slot_prepare(s, bytes, stream, &k);
   if (!rc && targets) {
     /* sampled rows only: [index table][rows] packed into pinned staging by the host, ONE DMA, one scatter launch */
     const size_t row_bytes = (size_t)w * 3u;
@@ -264,6 +256,189 @@ static int publish_common(asciichat_hip_frame_table_t *t, int slot, const void *
     s->generation++;
   }
   pthread_mutex_unlock(&s->mu);
+  return rc;
+}
+
+/* the part of a publish that happens under the slot's lock before the upload: pick the buffer that does not hold the
+ * latest frame; the previous upload into it reads the same pinned staging block: let it finish; renders that were handed
+ * this buffer (one publish ago it was the latest frame) may still be queued or running: the upload goes behind
+ * everything enqueued so far on their streams; make room.  Returns the buffer index through *k_out; the caller enqueues the upload and calls slot_commit. */
+static int slot_prepare(ft_slot_t *s, size_t bytes, void *stream, int *k_out) {
+  const int k = s->cur == 0 ? 1 : 0;
+  int rc = 0;
+  if (s->ready[k])
+    rc = achip_hip_check((int)hipEventSynchronize(s->ready[k]), "hipEventSynchronize(frame buffer)");
+  if (!rc && s->n_readers[k] > 0 && !s->reader_done)
+    rc = achip_hip_check((int)hipEventCreateWithFlags(&s->reader_done, hipEventDisableTiming), "hipEventCreate");
+  for (int r = 0; r < s->n_readers[k] && !rc; r++) {
+    if (hipEventRecord(s->reader_done, s->reader[k][r]) != hipSuccess) {
+      (void)hipGetLastError();
+      continue;
+    }
+    rc = achip_hip_check((int)hipStreamWaitEvent((hipStream_t)stream, s->reader_done, 0), "hipStreamWaitEvent(readers)");
+  }
+  if (!rc && s->readers_overflow[k])
+    rc = achip_hip_check((int)hipDeviceSynchronize(), "hipDeviceSynchronize(readers)");
+  s->n_readers[k] = 0;
+  s->readers_overflow[k] = 0;
+  if (!rc && s->cap[k] < bytes) {
+    if (s->dev[k])
+      (void)hipFree(s->dev[k]);
+    s->dev[k] = NULL;
+    s->cap[k] = 0;
+    rc = achip_hip_check((int)hipMalloc((void **)&s->dev[k], bytes), "hipMalloc(frame)");
+    if (!rc)
+      s->cap[k] = bytes;
+  }
+  if (!rc && !s->ready[k])
+    rc = achip_hip_check((int)hipEventCreateWithFlags(&s->ready[k], hipEventDisableTiming), "hipEventCreate");
+  *k_out = k;
+  return rc;
+}
+
+/* A whole tick's clients at once: every client's sampled rows are packed into ONE pinned
+ * block behind a table of 32-byte records, sent with ONE DMA and put in place by ONE launch -- instead of a DMA and a
+ * launch per client (256 clients: ~12 ms of per-call latencies for 35 MB; profiles/r03_bench.json tick_e2e).  Slots must
+ * be distinct; they are locked in ascending order.  All blobs must describe frames that `targets` describe (same
+ * height).  Semantics per slot are those of frame_table_publish_rows. */
+int asciichat_hip_frame_table_publish_rows_batch(asciichat_hip_frame_table_t *t, const int *slots, const void *const *blobs,
+                                                 const size_t *blob_sizes, int n, const achip_frame_t *targets, int n_targets,
+                                                 void *stream) {
+  if (!t || !slots || !blobs || !blob_sizes || n <= 0 || n > 65535 || !targets || n_targets <= 0)
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame_table_publish_rows_batch: bad arguments");
+  typedef struct {
+    int slot, k, n_rows;
+    uint32_t w, h;
+    const uint8_t *pixels;
+    size_t off;
+  } item_t;
+  item_t *it = (item_t *)calloc((size_t)n, sizeof(item_t));
+  int *order = (int *)malloc((size_t)n * sizeof(int));
+  uint32_t *rows = NULL;
+  uint8_t *mark = NULL;
+  if (!it || !order) {
+    free(it);
+    free(order);
+    return achip_fail(ASCIICHAT_HIP_ERR_MEMORY, "out of memory");
+  }
+  int rc = 0;
+  uint32_t max_h = 0;
+  for (int i = 0; i < n && !rc; i++) {
+    it[i].slot = slots[i];
+    if (slots[i] < 0 || slots[i] >= t->n || !blobs[i])
+      rc = achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame_table_publish_rows_batch: bad slot or blob at %d", i);
+    else if (achip_frame_blob_parse(blobs[i], blob_sizes[i], false, &it[i].w, &it[i].h, &it[i].pixels) != 0)
+      rc = achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame blob %d rejected", i);
+    if (it[i].h > max_h)
+      max_h = it[i].h;
+    order[i] = i;
+  }
+  /* ascending slot order (insertion sort: n is a tick's client count), duplicates refused */
+  for (int i = 1; i < n && !rc; i++)
+    for (int j = i; j > 0 && it[order[j - 1]].slot > it[order[j]].slot; j--) {
+      const int tmp = order[j];
+      order[j] = order[j - 1];
+      order[j - 1] = tmp;
+    }
+  for (int i = 1; i < n && !rc; i++)
+    if (it[order[i]].slot == it[order[i - 1]].slot)
+      rc = achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame_table_publish_rows_batch: slot %d named twice", it[order[i]].slot);
+  if (!rc) {
+    rows = (uint32_t *)malloc((size_t)max_h * sizeof(uint32_t));
+    mark = (uint8_t *)malloc(max_h ? max_h : 1);
+    if (!rows || !mark)
+      rc = achip_fail(ASCIICHAT_HIP_ERR_MEMORY, "out of memory");
+  }
+  /* sizes first: the block's layout */
+  size_t total = ((size_t)n * 32u + 15u) & ~(size_t)15;
+  uint32_t max_rows = 0, max_row_bytes = 0;
+  for (int i = 0; i < n && !rc; i++) {
+    const int nr = sampled_rows(targets, n_targets, it[i].h, rows, mark);
+    if (nr < 0) {
+      rc = achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame_table_publish_rows_batch: a target does not describe blob %d (%ux%u)", i,
+                      it[i].w, it[i].h);
+      break;
+    }
+    it[i].n_rows = nr;
+    it[i].off = total;
+    total += (((size_t)nr * 4u + 15u) & ~(size_t)15) + (((size_t)nr * it[i].w * 3u + 15u) & ~(size_t)15);
+    if ((uint32_t)nr > max_rows)
+      max_rows = (uint32_t)nr;
+    if (it[i].w * 3u > max_row_bytes)
+      max_row_bytes = it[i].w * 3u;
+  }
+  if (!rc && total > 0xFFFFFFF0u)
+    rc = achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame_table_publish_rows_batch: staged block exceeds 4 GiB");
+  int locked = 0, have_batch = 0, par = 0;
+  if (!rc) {
+    pthread_mutex_lock(&t->batch_mu);
+    have_batch = 1;
+    par = (int)(t->batch_no++ & 1u);
+    if (t->batch_done[par]) /* the DMA of two batches ago read this block */
+      rc = achip_hip_check((int)hipEventSynchronize(t->batch_done[par]), "hipEventSynchronize(batch staging)");
+    if (!rc && t->batch_cap[par] < total) {
+      if (t->batch_host[par])
+        (void)hipHostFree(t->batch_host[par]);
+      if (t->batch_dev[par])
+        (void)hipFree(t->batch_dev[par]);
+      t->batch_host[par] = t->batch_dev[par] = NULL;
+      t->batch_cap[par] = 0;
+      const size_t cap = total + total / 4;
+      rc = achip_hip_check((int)hipHostMalloc((void **)&t->batch_host[par], cap, hipHostMallocDefault), "hipHostMalloc(batch staging)");
+      if (!rc)
+        rc = achip_hip_check((int)hipMalloc((void **)&t->batch_dev[par], cap), "hipMalloc(batch staging)");
+      if (!rc)
+        t->batch_cap[par] = cap;
+    }
+    if (!rc && !t->batch_done[par])
+      rc = achip_hip_check((int)hipEventCreateWithFlags(&t->batch_done[par], hipEventDisableTiming), "hipEventCreate");
+  }
+  /* per slot, in ascending order: lock, prepare the target buffer, pack the record and the rows */
+  for (int q = 0; q < n && !rc; q++) {
+    item_t *I = &it[order[q]];
+    ft_slot_t *s = &t->slot[I->slot];
+    pthread_mutex_lock(&s->mu);
+    locked = q + 1;
+    rc = slot_prepare(s, (size_t)I->w * I->h * 3u, stream, &I->k);
+    if (rc)
+      break;
+    const int nr = sampled_rows(targets, n_targets, I->h, rows, mark);
+    uint8_t *blk = t->batch_host[par] + I->off;
+    const size_t table = ((size_t)nr * 4u + 15u) & ~(size_t)15, row_bytes = (size_t)I->w * 3u;
+    memcpy(blk, rows, (size_t)nr * 4u);
+    for (int r = 0; r < nr; r++)
+      memcpy(blk + table + (size_t)r * row_bytes, I->pixels + (size_t)rows[r] * row_bytes, row_bytes);
+    struct {
+      uint64_t frame;
+      uint32_t off, n_rows, row_bytes, pad[3];
+    } rec = {(uint64_t)(uintptr_t)s->dev[I->k], (uint32_t)I->off, (uint32_t)nr, (uint32_t)row_bytes, {0, 0, 0}};
+    memcpy(t->batch_host[par] + (size_t)order[q] * 32u, &rec, 32);
+  }
+  if (!rc)
+    rc = achip_hip_check((int)hipMemcpyAsync(t->batch_dev[par], t->batch_host[par], total, hipMemcpyHostToDevice, (hipStream_t)stream),
+                         "hipMemcpyAsync(batch rows)");
+  if (!rc)
+    rc = achip_hip_check(achip_launch_scatter_rows_batch(t->batch_dev[par], (uint32_t)n, max_rows, max_row_bytes, stream),
+                         "batched row scatter launch");
+  if (!rc)
+    rc = achip_hip_check((int)hipEventRecord(t->batch_done[par], (hipStream_t)stream), "hipEventRecord(batch)");
+  for (int q = 0; q < locked; q++) { /* commit (or leave untouched on failure) and unlock */
+    item_t *I = &it[order[q]];
+    ft_slot_t *s = &t->slot[I->slot];
+    if (!rc && hipEventRecord(s->ready[I->k], (hipStream_t)stream) == hipSuccess) {
+      s->cur = I->k;
+      s->w = (int)I->w;
+      s->h = (int)I->h;
+      s->generation++;
+    }
+    pthread_mutex_unlock(&s->mu);
+  }
+  if (have_batch)
+    pthread_mutex_unlock(&t->batch_mu);
+  free(rows);
+  free(mark);
+  free(order);
+  free(it);
   return rc;
 }
 

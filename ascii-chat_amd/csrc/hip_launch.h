@@ -53,6 +53,11 @@ int achip_launch_pack(const uint8_t *slab, uint64_t stride, const uint32_t *len_
 int achip_launch_scatter_rows(const uint8_t *staged_dev, uint32_t n_rows, uint32_t row_bytes, uint8_t *frame_dev,
                               uint64_t frame_pitch, void *stream);
 
+/* staged_dev = [n_clients x {u64 frame, u32 off, u32 n_rows, u32 row_bytes, 12 bytes pad}][per client at `off`: index
+ * table padded to 16, rows]: every client's rows to their places in ITS frame buffer, one launch */
+int achip_launch_scatter_rows_batch(const uint8_t *staged_dev, uint32_t n_clients, uint32_t max_rows, uint32_t max_row_bytes,
+                                    void *stream);
+
 /* wire stage (crc_kernels.hpp): CRC-32C of n buffers at base + i*stride (len_dev[i] bytes, or fixed_len when
  * len_dev == NULL; every length <= max_len) and, when hdr_out != NULL, the 24-byte ascii_frame_packet_t headers
  * (dims_dev = n x {width, height}) and the CRC of header || frame.  partial: n * achip_crc_parts(max_len) u32 of

@@ -282,6 +282,19 @@ extern "C" int achip_launch_scatter_rows(const uint8_t *staged_dev, uint32_t n_r
   return (int)hipGetLastError();
 }
 
+/* ... of a whole tick's clients in one launch: staged_dev = [n_clients x 32-byte records][per client: index table, rows] */
+extern "C" int achip_launch_scatter_rows_batch(const uint8_t *staged_dev, uint32_t n_clients, uint32_t max_rows,
+                                               uint32_t max_row_bytes, void *stream) {
+  if (n_clients == 0u || max_rows == 0u)
+    return (int)hipSuccess;
+  if (max_rows > 65535u || n_clients > 65535u)
+    return (int)hipErrorInvalidValue;
+  const unsigned slices = max_row_bytes > 16384u ? 4u : max_row_bytes > 4096u ? 2u : 1u;
+  hipLaunchKernelGGL(achip::scatter_rows_batch_kernel, dim3(slices, max_rows, n_clients), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), staged_dev, n_clients);
+  return (int)hipGetLastError();
+}
+
 /* compaction of a rendered slab (stream_kernels.hpp: pack_frames_kernel).  Workgroups per frame: enough slices that the
  * launch has a few workgroups per CU whatever the batch size, never slices below 4 KB */
 extern "C" int achip_launch_pack(const uint8_t *slab, uint64_t stride, const uint32_t *len_dev, int n, uint8_t *dst,

@@ -230,4 +230,38 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+
+/* The same for a whole tick's clients in ONE launch (frame_table_publish_rows_batch): the staged block starts with one
+ * 32-byte record per client {frame pointer, offset of its [index table][rows] block, rows, row bytes}; workgroup
+ * (x, r, c) copies slice x of row r of client c. */
+struct scatter_client_t {
+  uint64_t frame;
+  uint32_t off, n_rows, row_bytes, _pad[3];
+};
+__global__ void __launch_bounds__(256) scatter_rows_batch_kernel(const uint8_t *__restrict__ staged, uint32_t n_clients) {
+  const uint32_t c = blockIdx.z;
+  if (c >= n_clients)
+    return;
+  const scatter_client_t cl = reinterpret_cast<const scatter_client_t *>(staged)[c];
+  const uint32_t r = blockIdx.y;
+  if (r >= cl.n_rows)
+    return;
+  const uint32_t table = (cl.n_rows * 4u + 15u) & ~15u;
+  const uint8_t *blk = staged + cl.off;
+  const uint32_t row = reinterpret_cast<const uint32_t *>(blk)[r];
+  const uint8_t *src = blk + table + (uint64_t)r * cl.row_bytes;
+  uint8_t *dst = reinterpret_cast<uint8_t *>(cl.frame) + (uint64_t)row * cl.row_bytes;
+  const uint32_t i0 = blockIdx.x * 256u + threadIdx.x, step = gridDim.x * 256u;
+  if ((((uintptr_t)src | (uintptr_t)dst) & 15u) == 0u) {
+    const uint32_t groups = cl.row_bytes >> 4;
+    for (uint32_t g = i0; g < groups; g += step)
+      reinterpret_cast<uint4 *>(dst)[g] = reinterpret_cast<const uint4 *>(src)[g];
+    for (uint32_t b = (groups << 4) + i0; b < cl.row_bytes; b += step)
+      dst[b] = src[b];
+  } else {
+    for (uint32_t b = i0; b < cl.row_bytes; b += step)
+      dst[b] = src[b];
+  }
+}
+
 } // namespace achip

@@ -548,13 +548,15 @@ def tick_e2e(torch, pkg, n=256, distinct=32, ticks=(2, 4)):
     hdr = torch.zeros(n * 24, dtype=torch.uint8, device="cuda")
     pkt = torch.zeros(n, dtype=torch.int32, device="cuda")
     out = {}
-    for form in ("whole_blob", "sampled_rows"):
+    for form in ("whole_blob", "sampled_rows", "sampled_rows_batched"):
         t_pub = t_all = 0.0
-        n_ticks = ticks[0] if form == "whole_blob" else ticks[1]
+        n_ticks = ticks[0] if form == "whole_blob" else ticks[1] * (2 if form == "sampled_rows_batched" else 1)
         for tick in range(n_ticks + 1):  # the first tick allocates (frame buffers, staging): untimed
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for i in range(n):
+            if form == "sampled_rows_batched":  # one packed block, one DMA, one scatter launch for the whole tick
+                table.publish_rows_batch(list(range(n)), [(blobs[(i + tick) % distinct], blob_bytes) for i in range(n)], [tmpl], st)
+            for i in range(n if form != "sampled_rows_batched" else 0):
                 if form == "whole_blob":
                     table.publish_at(i, blobs[(i + tick) % distinct], blob_bytes, st)
                 else:

@@ -192,6 +192,11 @@ int asciichat_hip_frame_table_publish(asciichat_hip_frame_table_t *table, int sl
  * renders; rows nobody named are stale. */
 int asciichat_hip_frame_table_publish_rows(asciichat_hip_frame_table_t *table, int slot, const void *blob, size_t blob_size,
                                            const achip_frame_t *targets, int n_targets, void *stream);
+/* ... for a whole tick's clients at once: ONE packed block, ONE DMA, ONE launch instead of one of each per client (slots
+ * distinct; every blob a frame that `targets` describe).  Per slot the semantics of publish_rows. */
+int asciichat_hip_frame_table_publish_rows_batch(asciichat_hip_frame_table_t *table, const int *slots, const void *const *blobs,
+                                                 const size_t *blob_sizes, int n, const achip_frame_t *targets, int n_targets,
+                                                 void *stream);
 int asciichat_hip_frame_table_latest(asciichat_hip_frame_table_t *table, int slot, void *consumer_stream,
                                      const uint8_t **pixels_dev, int *width, int *height, uint64_t *generation);
 void asciichat_hip_frame_table_forget_stream(asciichat_hip_frame_table_t *table, void *consumer_stream);

@@ -776,6 +776,46 @@ def test_frame_table_publish_rows_uploads_only_sampled_rows(gpu):
         table.close()
 
 
+def test_frame_table_publish_rows_batch(gpu):
+    """frame_table_publish_rows_batch: a tick's clients in ONE packed block, ONE DMA, ONE scatter launch -- the renders of
+    every client equal the oracle's (and a full publish's), across three ticks (both buffers of every slot, staging
+    parity reused), clients of two widths in one batch, duplicates / wrong heights refused."""
+    import struct
+    pkg, torch = gpu
+    stream = torch.cuda.current_stream().cuda_stream
+    n = 12
+    dims = [(1920, 1080) if i % 3 else (640, 1080) for i in range(n)]  # same height (what the targets describe), two widths
+    table = pkg.FrameTable(n + 2)
+    t_fg = pkg.frame_setup(None, 1920, 1080, 80, 24, 0, False, False, False)
+    t_hb = pkg.frame_setup(None, 1920, 1080, 60, 20, 2, False, False, False)
+    keep = []
+    for tick in range(3):
+        imgs = [orc.frame_hash_noise(w, h, 300 + 17 * tick + i) for i, (w, h) in enumerate(dims)]
+        blobs = [struct.pack(">II", im.shape[1], im.shape[0]) + np.ascontiguousarray(im).tobytes() for im in imgs]
+        bufs = [C.create_string_buffer(b, len(b)) for b in blobs]
+        keep.append(bufs)
+        slots = [(5 * i + tick) % (n + 2) for i in range(n)]
+        assert len(set(slots)) == n
+        table.publish_rows_batch(slots, [(C.addressof(b), len(b)) for b in bufs], [t_fg, t_hb], stream)
+        for mode, tmpl, (W, H, cl, rm) in ((1, t_fg, (80, 24, 3, 0)), (5, t_hb, (60, 20, 3, 2))):
+            frames = []
+            for i, sl in enumerate(slots):
+                ptr, w, h, gen = table.latest(sl, stream)
+                assert (w, h) == dims[i] and ptr
+                f = pkg.frame_setup(ptr, w, h, W, H, rm, False, False, False)
+                frames.append(f)
+            got = render_descs(gpu, mode, frames)
+            for i in range(n):
+                assert got[i] == orc.convert_with_caps(imgs[i], W, H, cl, rm, False, False, False), (tick, mode, i)
+    b0 = keep[-1][0]
+    with pytest.raises(RuntimeError):  # a slot named twice
+        table.publish_rows_batch([1, 1], [(C.addressof(b0), len(b0))] * 2, [t_fg], stream)
+    bad = pkg.frame_setup(None, 1920, 1081, 80, 24, 0, False, False, False)
+    with pytest.raises(RuntimeError):  # a target that does not describe the blobs
+        table.publish_rows_batch([0], [(C.addressof(b0), len(b0))], [bad], stream)
+    table.close()
+
+
 def test_frame_table_upload_waits_for_queued_readers(gpu):
     """the publish after next on a slot overwrites the buffer that renders handed out by latest() may still
     be reading.  A consumer stream is kept busy, a render of frame A is queued behind that work, then B and C are
