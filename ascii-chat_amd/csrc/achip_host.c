@@ -1,7 +1,9 @@
 /* achip_host.c -- see achip_host.h.  Plain C11, no GPU calls. */
 #include "achip_host.h"
+#include "internal.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 /* ROUND(), include/ascii-chat/util/math.h:53; result floored at MIN_DIMENSION (aspect_ratio.c:18-36) */
@@ -254,6 +256,71 @@ int achip_frame_setup(achip_frame_t *f, const uint8_t *src_dev, int src_w, int s
   f->x_ratio = achip_nn_ratio(src_w, (int)rw);
   f->y_ratio = achip_nn_ratio(src_h, (int)rh);
   return 0;
+}
+
+/* ---- staging of host images (drop-in layer): only what the sampler will read crosses PCIe ------------------------- */
+static int g_stage_columns = -1; /* ASCIICHAT_HIP_STAGE_COLUMNS=0: sampled rows only (diagnostics / A-B) */
+
+size_t achip_stage_extent(const achip_frame_t *f, int *w, int *h) {
+  if (g_stage_columns < 0) {
+    const char *e = getenv("ASCIICHAT_HIP_STAGE_COLUMNS");
+    g_stage_columns = !(e && e[0] == '0');
+  }
+  const int cy = f->out_h < f->src_h;
+  const int cx = g_stage_columns && f->out_w > 0 && f->out_w <= 3840 && 2 * (long)f->out_w <= (long)f->src_w;
+  *w = cx ? f->out_w : f->src_w;
+  *h = cy ? f->out_h : f->src_h;
+  return cx || cy ? (size_t)*w * (size_t)*h * 3u : 0;
+}
+
+void achip_stage_gather(const achip_frame_t *f, const uint8_t *host_px, uint8_t *dst, achip_frame_t *d) {
+  int w, h;
+  (void)achip_stage_extent(f, &w, &h);
+  const int cx = w != f->src_w, cy = h != f->src_h;
+  const size_t stride = f->src_stride ? (size_t)f->src_stride : (size_t)f->src_w * 3u;
+  const size_t row_bytes = (size_t)w * 3u;
+  uint32_t off[3840]; /* a resized image is at most 3840 wide (achip_frame_setup; image.c:100-113) */
+  if (cx) { /* byte offset of every sampled column, once (image.c:293-312; a horizontal flip is folded in) */
+    for (int x = 0; x < w; x++) {
+      uint32_t sx = (uint32_t)(((uint64_t)(uint32_t)x * f->x_ratio) >> 16);
+      if (sx > (uint32_t)f->src_w - 1u)
+        sx = (uint32_t)f->src_w - 1u;
+      if (f->ops & ACHIP_OP_FLIP_X)
+        sx = (uint32_t)f->src_w - 1u - sx;
+      off[x] = sx * 3u;
+    }
+  }
+  for (int y = 0; y < h; y++) {
+    uint32_t sy = (uint32_t)y;
+    if (cy) {
+      sy = (uint32_t)(((uint64_t)(uint32_t)y * f->y_ratio) >> 16);
+      if (sy > (uint32_t)f->src_h - 1u)
+        sy = (uint32_t)f->src_h - 1u;
+      if (f->ops & ACHIP_OP_FLIP_Y)
+        sy = (uint32_t)f->src_h - 1u - sy;
+    }
+    const uint8_t *row = host_px + (size_t)sy * stride;
+    uint8_t *o = dst + (size_t)y * row_bytes;
+    if (!cx) {
+      memcpy(o, row, row_bytes);
+    } else {
+      for (int x = 0; x < w; x++, o += 3) {
+        const uint8_t *p = row + off[x];
+        o[0] = p[0], o[1] = p[1], o[2] = p[2];
+      }
+    }
+  }
+  if (cx) {
+    d->src_w = w;
+    d->x_ratio = 1u << 16; /* sampled column x = column x of the compacted image */
+    d->ops &= ~ACHIP_OP_FLIP_X;
+  }
+  if (cy) {
+    d->src_h = h;
+    d->y_ratio = 1u << 16;
+    d->ops &= ~ACHIP_OP_FLIP_Y;
+  }
+  d->src_stride = (int32_t)row_bytes;
 }
 
 size_t achip_out_bound(int mode, const achip_frame_t *f) {

@@ -25,9 +25,18 @@ void achip_lut_put(const achip_lut_t *dev);
  * direct path; else the malloc'd string or NULL (achip_fail has the reason). */
 void achip_combine_enter(void);
 void achip_combine_leave(void);
+unsigned long long achip_combine_stats_clock(void); /* 0 unless ASCIICHAT_HIP_COMBINE_STATS */
+void achip_combine_stats_call(unsigned long long t0);
 int achip_combine_callers(void); /* drop-in render calls in flight right now */
 char *achip_combine_render(int mode, const char *palette, const achip_lut_t *lut, const achip_frame_t *f, size_t src_bytes,
                            int *handled);
+
+/* achip_host.c: the part of a HOST image a frame's point sampler reads.  stage_extent() gives the size of the compacted
+ * image (sampled rows; sampled columns too when the frame is at most half as wide as its source) and returns its bytes, or 0
+ * when the whole image is needed; stage_gather() copies that part to dst (row-major, tight) and rewrites d (a copy of the
+ * descriptor; d->src is left for the caller) so that sampling the compacted image gives the pixels the original would. */
+size_t achip_stage_extent(const achip_frame_t *f, int *w, int *h);
+void achip_stage_gather(const achip_frame_t *f, const uint8_t *host_px, uint8_t *dst, achip_frame_t *d);
 
 /* buffer_pool.c: device alias of a pointer inside a pinned pool block, or NULL */
 const void *achip_pool_device_ptr(const void *host_ptr);

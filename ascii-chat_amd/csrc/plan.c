@@ -95,7 +95,10 @@ typedef struct {
 static lut_entry_t g_luts[LUT_CACHE_MAX];
 static int g_lut_count;
 static unsigned long g_lut_clock;
-static pthread_mutex_t g_lut_mu = PTHREAD_MUTEX_INITIALIZER;
+/* readers (a hit: every drop-in call, twice) share the lock and touch the entry with atomics; building, uploading and
+ * recycling an entry take it exclusively.  It was a mutex: at 128 calling threads the two acquisitions per call cost
+ * more than the render (profiles/r03_dropin_stats.txt). */
+static pthread_rwlock_t g_lut_rw = PTHREAD_RWLOCK_INITIALIZER;
 
 /* Pins the device tables of `palette` (building and uploading them on first use); release with achip_lut_put
  * once no queued work reads them any more. */
@@ -105,20 +108,31 @@ int achip_lut_get(const char *palette, const achip_lut_t **out_dev) {
   int device = 0;
   if (achip_hip_check((int)hipGetDevice(&device), "hipGetDevice"))
     return ASCIICHAT_HIP_ERR_NO_DEVICE;
-  pthread_mutex_lock(&g_lut_mu);
-  g_lut_clock++;
+  pthread_rwlock_rdlock(&g_lut_rw);
   for (int i = 0; i < g_lut_count; i++) {
+    if (g_luts[i].device == device && strcmp(g_luts[i].palette, palette) == 0) {
+      __atomic_add_fetch(&g_luts[i].pins, 1, __ATOMIC_ACQ_REL);
+      __atomic_store_n(&g_luts[i].age, __atomic_add_fetch(&g_lut_clock, 1, __ATOMIC_RELAXED), __ATOMIC_RELAXED);
+      *out_dev = g_luts[i].dev;
+      pthread_rwlock_unlock(&g_lut_rw);
+      return 0;
+    }
+  }
+  pthread_rwlock_unlock(&g_lut_rw);
+  pthread_rwlock_wrlock(&g_lut_rw);
+  g_lut_clock++;
+  for (int i = 0; i < g_lut_count; i++) { /* somebody else may have built it in between */
     if (g_luts[i].device == device && strcmp(g_luts[i].palette, palette) == 0) {
       g_luts[i].pins++;
       g_luts[i].age = g_lut_clock;
       *out_dev = g_luts[i].dev;
-      pthread_mutex_unlock(&g_lut_mu);
+      pthread_rwlock_unlock(&g_lut_rw);
       return 0;
     }
   }
   achip_lut_t host;
   if (achip_lut_build(palette, &host) != 0) {
-    pthread_mutex_unlock(&g_lut_mu);
+    pthread_rwlock_unlock(&g_lut_rw);
     return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "bad palette");
   }
   int slot = g_lut_count;
@@ -128,7 +142,7 @@ int achip_lut_get(const char *palette, const achip_lut_t **out_dev) {
       if (g_luts[i].pins == 0 && (slot < 0 || g_luts[i].age < g_luts[slot].age))
         slot = i;
     if (slot < 0) {
-      pthread_mutex_unlock(&g_lut_mu);
+      pthread_rwlock_unlock(&g_lut_rw);
       return achip_fail(ASCIICHAT_HIP_ERR_MEMORY, "%d palettes are in use at once", LUT_CACHE_MAX);
     }
     (void)hipFree(g_luts[slot].dev); /* unpinned: no queued work reads it */
@@ -151,7 +165,7 @@ int achip_lut_get(const char *palette, const achip_lut_t **out_dev) {
       g_luts[slot] = g_luts[g_lut_count - 1];
       g_lut_count--;
     }
-    pthread_mutex_unlock(&g_lut_mu);
+    pthread_rwlock_unlock(&g_lut_rw);
     return rc;
   }
   g_luts[slot].palette = copy;
@@ -162,21 +176,21 @@ int achip_lut_get(const char *palette, const achip_lut_t **out_dev) {
   if (slot == g_lut_count)
     g_lut_count++;
   *out_dev = dev;
-  pthread_mutex_unlock(&g_lut_mu);
+  pthread_rwlock_unlock(&g_lut_rw);
   return 0;
 }
 
 void achip_lut_put(const achip_lut_t *dev) {
   if (!dev)
     return;
-  pthread_mutex_lock(&g_lut_mu);
+  pthread_rwlock_rdlock(&g_lut_rw);
   for (int i = 0; i < g_lut_count; i++)
     if (g_luts[i].dev == dev) {
-      if (g_luts[i].pins > 0)
-        g_luts[i].pins--;
+      if (__atomic_sub_fetch(&g_luts[i].pins, 1, __ATOMIC_ACQ_REL) < 0) /* a put without a get: undo, stay at zero */
+        __atomic_add_fetch(&g_luts[i].pins, 1, __ATOMIC_ACQ_REL);
       break;
     }
-  pthread_mutex_unlock(&g_lut_mu);
+  pthread_rwlock_unlock(&g_lut_rw);
 }
 
 /* ------------------------------------------------------------------------------------------- */

@@ -23,6 +23,10 @@ static pthread_barrier_t gate;
 
 static void *worker(void *arg) {
   job_t *j = (job_t *)arg;
+  /* the first result is the thread's reference: every later call on the same image must return the same bytes (the GPU
+   * tests compare against the oracle; this catches a race that hands a caller somebody else's or a torn frame) */
+  char *first = ascii_convert_with_capabilities(j->img, j->w, j->h, &j->caps, false, false, PALETTE_CHARS_STANDARD);
+  const size_t first_len = first ? strlen(first) : 0;
   for (int k = 0; k < 20; k++)
     free(ascii_convert_with_capabilities(j->img, j->w, j->h, &j->caps, false, false, PALETTE_CHARS_STANDARD));
   pthread_barrier_wait(&gate);
@@ -33,9 +37,15 @@ static void *worker(void *arg) {
       fprintf(stderr, "render failed: %s\n", asciichat_hip_last_error());
       exit(1);
     }
-    j->bytes += strlen(s);
+    const size_t len = strlen(s);
+    if (len != first_len || memcmp(s, first, len) != 0) {
+      fprintf(stderr, "call %d returned a different frame (%zu bytes, expected %zu)\n", k, len, first_len);
+      exit(1);
+    }
+    j->bytes += len;
     free(s);
   }
+  free(first);
   pthread_barrier_wait(&gate);
   return NULL;
 }
