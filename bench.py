@@ -617,6 +617,29 @@ def cpu_model():
     return platform.processor() or "unknown"
 
 
+def usable_cpus():
+    """CPUs this process may keep busy: the affinity mask capped by the cgroup's CPU quota (the GPU boxes show 256 hardware
+    threads and grant 16 CPUs' worth of time: more runnable threads than that only get the process throttled)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = -(-int(q) // int(period))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and period > 0:
+                quota = -(-q // period)
+        except (OSError, ValueError):
+            pass
+    return max(1, min(n, quota) if quota else n), quota
+
+
 def cpu_baseline(name, budget_s=12.0):
     """Times the CPU oracle (port of the reference's scalar path) on this host: 1 thread and all cores,
     on a bounded sample of the same workload (same frame shape, S-noise input, same caps)."""
@@ -635,15 +658,17 @@ def cpu_baseline(name, budget_s=12.0):
     it1 = max(50, int(budget_s * 0.4 / per))
     t1 = L.orc_bench_convert(img.ctypes.data, sw, sh, W, H, cl, rm, pal, it1, 1, C.byref(nb))
     cores = os.cpu_count() or 1
-    th = min(cores, 256)
-    itn = max(20, int(budget_s * 0.6 / per))
+    th, quota = usable_cpus()
+    th = min(th, 256)
+    itn = max(20, int(budget_s * 0.6 / per * 16 / max(16, th)))
     tn = L.orc_bench_convert(img.ctypes.data, sw, sh, W, H, cl, rm, pal, itn, th, C.byref(nb))
     return {
         "value": it1 / t1, "unit": "frames/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
-        "host_threads": cores,
+        "host_threads": cores, "cgroup_cpu_quota": quota,
         "sample": f"{it1} x ({sw}x{sh}->{W}x{H}, color_level={cl}, render_mode={rm}, uniform-noise frame) on 1 thread; "
                   f"{itn} per thread on {th} threads",
-        "all_cores": {"value": itn * th / tn, "cores": th},
+        "all_cores": {"value": itn * th / tn, "cores": th,
+                      "note": "as many threads as the process may keep busy (affinity mask, cgroup CPU quota)"},
     }
 
 
