@@ -113,6 +113,8 @@ def lib():
     L.asciichat_hip_frame_table_latest.argtypes = [vp, ci, vp, C.POINTER(vp), C.POINTER(ci), C.POINTER(ci),
                                                    C.POINTER(C.c_uint64)]
     L.asciichat_hip_frame_table_forget_stream.restype = None
+    L.asciichat_hip_frame_table_latest_frames.restype = ci
+    L.asciichat_hip_frame_table_latest_frames.argtypes = [vp, C.POINTER(ci), ci, vp, C.POINTER(Frame)]
     L.asciichat_hip_frame_table_forget_stream.argtypes = [vp, vp]
     L.asciichat_hip_crc32c.restype = ci
     L.asciichat_hip_crc32c.argtypes = [vp, C.c_size_t, vp, C.c_uint32, C.c_uint32, ci, vp, vp]
@@ -378,7 +380,7 @@ class Plan:
             raise RuntimeError(f"set_split({rows_per_part}) failed: {last_error()}")
 
     def update(self, frames, stream=0):
-        self._arr = (Frame * self.n)(*frames)
+        self._arr = frames if isinstance(frames, C.Array) else (Frame * self.n)(*frames)
         rc = lib().asciichat_hip_plan_update(self._h, self._arr, stream)
         if rc != 0:
             raise RuntimeError(f"plan_update failed: {last_error()}")
@@ -636,14 +638,28 @@ class FrameTable:
             raise RuntimeError(f"frame_table_publish_rows failed: {last_error()}")
 
     def publish_rows_batch(self, slots, blobs, targets, stream=0):
-        """one call for a whole tick: blobs = [(address, size)] of host buffers, slots = their table slots"""
+        """one call for a whole tick: blobs = [(address, size)] of host buffers (or a prepared (c_void_p array, c_size_t
+        array) pair), slots = their table slots (a list or a prepared c_int array)"""
         n = len(slots)
-        arr = (Frame * len(targets))(*targets)
-        rc = lib().asciichat_hip_frame_table_publish_rows_batch(
-            self._h, (C.c_int * n)(*slots), (C.c_void_p * n)(*[b[0] for b in blobs]), (C.c_size_t * n)(*[b[1] for b in blobs]), n,
-            arr, len(targets), stream)
+        arr = targets if isinstance(targets, C.Array) else (Frame * len(targets))(*targets)
+        sl = slots if isinstance(slots, C.Array) else (C.c_int * n)(*slots)
+        if isinstance(blobs, tuple) and isinstance(blobs[0], C.Array):
+            ptrs, sizes = blobs
+        else:
+            ptrs, sizes = (C.c_void_p * n)(*[b[0] for b in blobs]), (C.c_size_t * n)(*[b[1] for b in blobs])
+        rc = lib().asciichat_hip_frame_table_publish_rows_batch(self._h, sl, ptrs, sizes, n, arr, len(arr), stream)
         if rc != 0:
             raise RuntimeError(f"frame_table_publish_rows_batch failed: {last_error()}")
+
+    def latest_frames(self, slots, frames, stream=0):
+        """frames[i].src = the latest device frame of slots[i] (None when it has none of that descriptor's geometry);
+        slots: c_int array, frames: (Frame * n) array updated in place.  -> number of descriptors with a source"""
+        n = len(slots)
+        sl = slots if isinstance(slots, C.Array) else (C.c_int * n)(*slots)
+        rc = lib().asciichat_hip_frame_table_latest_frames(self._h, sl, n, stream, frames)
+        if rc < 0:
+            raise RuntimeError(f"frame_table_latest_frames failed: {last_error()}")
+        return rc
 
     def publish_at(self, slot, address, size, stream=0):
         """publish a blob that already sits in host memory at `address` (e.g. a block of the pinned pool)"""

@@ -323,6 +323,116 @@ void achip_stage_gather(const achip_frame_t *f, const uint8_t *host_px, uint8_t 
   d->src_stride = (int32_t)row_bytes;
 }
 
+/* ---- ingest (frame_table.c): what a set of render targets reads of a source frame ---------------------------------- */
+/* the source rows that the targets sample (the sampler's own rule: render_stream.hpp stream_request / render_kernels.hpp
+ * sample_frame_raw -- sy = min((y * y_ratio) >> 16, src_h - 1), mirrored under ACHIP_OP_FLIP_Y), ascending, unique.
+ * Returns their number, or -1 when a target does not describe an h-row source. */
+int achip_sampled_rows(const achip_frame_t *targets, int n_targets, uint32_t h, uint32_t *rows_out, uint8_t *mark) {
+  memset(mark, 0, h);
+  for (int i = 0; i < n_targets; i++) {
+    const achip_frame_t *f = &targets[i];
+    if (f->comp || (uint32_t)f->src_h != h || f->out_h <= 0)
+      return -1;
+    for (uint32_t y = 0; y < (uint32_t)f->out_h; y++) {
+      uint32_t sy = (uint32_t)(((uint64_t)y * f->y_ratio) >> 16);
+      if (sy > h - 1u)
+        sy = h - 1u;
+      if (f->ops & ACHIP_OP_FLIP_Y)
+        sy = h - 1u - sy;
+      mark[sy] = 1;
+    }
+  }
+  int n = 0;
+  for (uint32_t r = 0; r < h; r++)
+    if (mark[r])
+      rows_out[n++] = r;
+  return n;
+}
+
+/* ... and the source columns (sx = min((x * x_ratio) >> 16, src_w - 1), mirrored under ACHIP_OP_FLIP_X); -1 when a target
+ * does not describe a w-column source */
+static int sampled_cols(const achip_frame_t *targets, int n_targets, uint32_t w, uint32_t *cols_out, uint8_t *mark) {
+  memset(mark, 0, w);
+  for (int i = 0; i < n_targets; i++) {
+    const achip_frame_t *f = &targets[i];
+    if (f->comp || (uint32_t)f->src_w != w || f->out_w <= 0)
+      return -1;
+    for (uint32_t x = 0; x < (uint32_t)f->out_w; x++) {
+      uint32_t sx = (uint32_t)(((uint64_t)x * f->x_ratio) >> 16);
+      if (sx > w - 1u)
+        sx = w - 1u;
+      if (f->ops & ACHIP_OP_FLIP_X)
+        sx = w - 1u - sx;
+      mark[sx] = 1;
+    }
+  }
+  int n = 0;
+  for (uint32_t c = 0; c < w; c++)
+    if (mark[c])
+      cols_out[n++] = c;
+  return n;
+}
+
+/* what the targets read of a w x h frame: the sampled rows, and the sampled columns when they are at most half of the
+ * frame's (n_cols = 0 otherwise: whole rows are staged -- a per-pixel gather would cost more than it saves).  A tick's
+ * clients mostly share one geometry: the set is built once per distinct (w, h). */
+void achip_sample_set_free(achip_sample_set_t *S) {
+  free(S->rows);
+  free(S->cols);
+  memset(S, 0, sizeof(*S));
+}
+/* 0, -1 (a target does not describe this frame) or -2 (memory) */
+int achip_sample_set_build(achip_sample_set_t *S, const achip_frame_t *targets, int n_targets, uint32_t w, uint32_t h) {
+  memset(S, 0, sizeof(*S));
+  S->w = w;
+  S->h = h;
+  S->rows = (uint32_t *)malloc((size_t)h * sizeof(uint32_t));
+  S->cols = (uint32_t *)malloc((size_t)w * sizeof(uint32_t));
+  uint8_t *mark = (uint8_t *)malloc(w > h ? w : h);
+  int rc = 0;
+  if (!S->rows || !S->cols || !mark) {
+    rc = -2;
+  } else {
+    S->n_rows = achip_sampled_rows(targets, n_targets, h, S->rows, mark);
+    if (S->n_rows < 0)
+      rc = -1;
+    else {
+      const int nc = sampled_cols(targets, n_targets, w, S->cols, mark);
+      S->n_cols = nc > 0 && 2u * (uint32_t)nc <= w ? nc : 0;
+    }
+  }
+  free(mark);
+  if (rc)
+    achip_sample_set_free(S);
+  return rc;
+}
+size_t achip_sample_set_block_bytes(const achip_sample_set_t *S) {
+  const size_t tr = ((size_t)S->n_rows * 4u + 15u) & ~(size_t)15;
+  if (!S->n_cols)
+    return tr + (((size_t)S->n_rows * S->w * 3u + 15u) & ~(size_t)15);
+  return tr + (((size_t)S->n_cols * 4u + 15u) & ~(size_t)15) + (((size_t)S->n_rows * (size_t)S->n_cols * 3u + 15u) & ~(size_t)15);
+}
+/* [row table][column table, if any][rows or pixels] of one frame into blk */
+void achip_sample_set_pack(const achip_sample_set_t *S, const uint8_t *pixels, uint8_t *blk) {
+  const size_t tr = ((size_t)S->n_rows * 4u + 15u) & ~(size_t)15, row_bytes = (size_t)S->w * 3u;
+  memcpy(blk, S->rows, (size_t)S->n_rows * 4u);
+  if (!S->n_cols) {
+    for (int r = 0; r < S->n_rows; r++)
+      memcpy(blk + tr + (size_t)r * row_bytes, pixels + (size_t)S->rows[r] * row_bytes, row_bytes);
+    return;
+  }
+  const size_t tc = ((size_t)S->n_cols * 4u + 15u) & ~(size_t)15;
+  memcpy(blk + tr, S->cols, (size_t)S->n_cols * 4u);
+  uint8_t *o = blk + tr + tc;
+  for (int r = 0; r < S->n_rows; r++) {
+    const uint8_t *row = pixels + (size_t)S->rows[r] * row_bytes;
+    for (int c = 0; c < S->n_cols; c++, o += 3) {
+      const uint8_t *px = row + (size_t)S->cols[c] * 3u;
+      o[0] = px[0], o[1] = px[1], o[2] = px[2];
+    }
+  }
+}
+
 size_t achip_out_bound(int mode, const achip_frame_t *f) {
   const bool hb = mode >= ACHIP_MODE_HB_TRUE && mode <= ACHIP_MODE_HB_MONO;
   const size_t rows = hb ? ((size_t)f->out_h + 1) / 2 : (size_t)f->out_h;

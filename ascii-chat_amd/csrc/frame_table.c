@@ -27,6 +27,7 @@
 #include "hip_launch.h"
 #include "internal.h"
 
+#define FT_RING 8
 #define FT_MAX_READERS 32 /* consumer streams remembered per buffer; beyond that a publish synchronises the device */
 
 typedef struct {
@@ -37,7 +38,9 @@ typedef struct {
   hipEvent_t reader_done; /* scratch event: "everything enqueued on a reader stream so far" */
   uint8_t *dev[2];      /* frame buffers in HBM                                       */
   size_t cap[2];        /* bytes allocated                                            */
-  hipEvent_t ready[2];  /* recorded after the upload of buffer k                      */
+  hipEvent_t ready[2];  /* recorded after the upload of buffer k (single-slot publishes)  */
+  unsigned batch_of[2]; /* != 0: buffer k was uploaded by batch publish number batch_of[k]; that batch's event (the
+                           table's ring) stands for `ready[k]`, which was not recorded                        */
   uint8_t *stage[2];    /* pinned staging for blobs that are not in the pinned pool   */
   size_t stage_cap[2];
   uint8_t *rows_dev[2]; /* publish_rows: device side of the staged [index table][rows] block */
@@ -57,6 +60,13 @@ struct asciichat_hip_frame_table {
   size_t batch_cap[2];
   hipEvent_t batch_done[2];
   unsigned batch_no;
+  /* completion of batch publishes: ONE event per batch (not one per slot: 256 hipEventRecord calls and then 256
+   * hipStreamWaitEvent calls per tick were most of a tick's host time).  A ring: slot B % FT_RING holds batch B's event
+   * while ring_seq says so; before the slot is re-recorded for batch B + FT_RING the host waits for batch B, so a
+   * buffer whose batch is no longer in the ring is known to be complete. */
+  pthread_mutex_t ev_mu;
+  hipEvent_t ring[FT_RING];
+  unsigned ring_seq[FT_RING];
 };
 
 int asciichat_hip_frame_table_create(asciichat_hip_frame_table_t **table, int n_slots) {
@@ -75,6 +85,7 @@ int asciichat_hip_frame_table_create(asciichat_hip_frame_table_t **table, int n_
   }
   t->n = n_slots;
   pthread_mutex_init(&t->batch_mu, NULL);
+  pthread_mutex_init(&t->ev_mu, NULL);
   for (int i = 0; i < n_slots; i++) {
     t->slot[i].cur = -1;
     pthread_mutex_init(&t->slot[i].mu, NULL);
@@ -115,39 +126,47 @@ void asciichat_hip_frame_table_destroy(asciichat_hip_frame_table_t *t) {
     if (t->batch_dev[k])
       (void)hipFree(t->batch_dev[k]);
   }
+  for (int k = 0; k < FT_RING; k++)
+    if (t->ring[k]) {
+      (void)hipEventSynchronize(t->ring[k]);
+      (void)hipEventDestroy(t->ring[k]);
+    }
   pthread_mutex_destroy(&t->batch_mu);
+  pthread_mutex_destroy(&t->ev_mu);
   free(t->slot);
   free(t);
 }
 
-/* the source rows that the targets sample (the sampler's own rule: render_stream.hpp stream_request / render_kernels.hpp
- * sample_frame_raw -- sy = min((y * y_ratio) >> 16, src_h - 1), mirrored under ACHIP_OP_FLIP_Y), ascending, unique.
- * Returns their number, or -1 when a target does not describe an h-row source. */
-static int sampled_rows(const achip_frame_t *targets, int n_targets, uint32_t h, uint32_t *rows_out, uint8_t *mark) {
-  memset(mark, 0, h);
-  for (int i = 0; i < n_targets; i++) {
-    const achip_frame_t *f = &targets[i];
-    if (f->comp || (uint32_t)f->src_h != h || f->out_h <= 0)
-      return -1;
-    for (uint32_t y = 0; y < (uint32_t)f->out_h; y++) {
-      uint32_t sy = (uint32_t)(((uint64_t)y * f->y_ratio) >> 16);
-      if (sy > h - 1u)
-        sy = h - 1u;
-      if (f->ops & ACHIP_OP_FLIP_Y)
-        sy = h - 1u - sy;
-      mark[sy] = 1;
-    }
+/* the upload of buffer k is complete (host-side wait), or work queued on `consumer` later will see it complete */
+static int upload_wait(asciichat_hip_frame_table_t *t, ft_slot_t *s, int k, int on_stream, hipStream_t consumer) {
+  if (!s->batch_of[k]) {
+    if (!s->ready[k])
+      return 0;
+    return on_stream ? achip_hip_check((int)hipStreamWaitEvent(consumer, s->ready[k], 0), "hipStreamWaitEvent")
+                     : achip_hip_check((int)hipEventSynchronize(s->ready[k]), "hipEventSynchronize(frame buffer)");
   }
-  int n = 0;
-  for (uint32_t r = 0; r < h; r++)
-    if (mark[r])
-      rows_out[n++] = r;
-  return n;
+  const unsigned B = s->batch_of[k];
+  int rc = 0;
+  pthread_mutex_lock(&t->ev_mu);
+  if (t->ring_seq[B % FT_RING] == B) /* else: out of the ring, so it was waited for when its ring slot was reused */
+    rc = on_stream ? achip_hip_check((int)hipStreamWaitEvent(consumer, t->ring[B % FT_RING], 0), "hipStreamWaitEvent")
+                   : achip_hip_check((int)hipEventSynchronize(t->ring[B % FT_RING]), "hipEventSynchronize(batch)");
+  pthread_mutex_unlock(&t->ev_mu);
+  return rc;
 }
 
+/* reader streams collected over a batch's slots: one "everything enqueued so far" event per distinct stream */
+typedef struct {
+  hipStream_t s[64];
+  int n;
+  unsigned done_batch; /* a batch publish known to be complete (the slots of a tick were mostly uploaded by one batch) */
+} reader_set_t;
+
+static int latest_one(asciichat_hip_frame_table_t *t, int slot, void *consumer_stream, const uint8_t **pixels_dev, int *width,
+                      int *height, uint64_t *generation, unsigned *waited_batch);
 static int publish_common(asciichat_hip_frame_table_t *t, int slot, const void *blob, size_t blob_size,
                           const achip_frame_t *targets, int n_targets, void *stream);
-static int slot_prepare(ft_slot_t *s, size_t bytes, void *stream, int *k_out);
+static int slot_prepare(asciichat_hip_frame_table_t *t, ft_slot_t *s, size_t bytes, void *stream, int *k_out, reader_set_t *defer);
 
 int asciichat_hip_frame_table_publish(asciichat_hip_frame_table_t *t, int slot, const void *blob, size_t blob_size,
                                       void *stream) {
@@ -180,13 +199,13 @@ static int publish_common(asciichat_hip_frame_table_t *t, int slot, const void *
   ft_slot_t *s = &t->slot[slot];
   pthread_mutex_lock(&s->mu);
   int k = 0; /* the buffer that does not hold the latest frame */
-  int rc = slot_prepare(s, bytes, stream, &k);
+  int rc = slot_prepare(t, s, bytes, stream, &k, NULL);
   if (!rc && targets) {
     /* sampled rows only: [index table][rows] packed into pinned staging by the host, ONE DMA, one scatter launch */
     const size_t row_bytes = (size_t)w * 3u;
     uint32_t *rows = (uint32_t *)malloc((size_t)h * sizeof(uint32_t));
     uint8_t *mark = (uint8_t *)malloc(h);
-    const int n_rows = rows && mark ? sampled_rows(targets, n_targets, h, rows, mark) : -2;
+    const int n_rows = rows && mark ? achip_sampled_rows(targets, n_targets, h, rows, mark) : -2;
     free(mark);
     if (n_rows < 0) {
       free(rows);
@@ -250,6 +269,7 @@ static int publish_common(asciichat_hip_frame_table_t *t, int slot, const void *
   if (!rc)
     rc = achip_hip_check((int)hipEventRecord(s->ready[k], (hipStream_t)stream), "hipEventRecord");
   if (!rc) {
+    s->batch_of[k] = 0;
     s->cur = k;
     s->w = (int)w;
     s->h = (int)h;
@@ -263,14 +283,32 @@ static int publish_common(asciichat_hip_frame_table_t *t, int slot, const void *
  * latest frame; the previous upload into it reads the same pinned staging block: let it finish; renders that were handed
  * this buffer (one publish ago it was the latest frame) may still be queued or running: the upload goes behind
  * everything enqueued so far on their streams; make room.  Returns the buffer index through *k_out; the caller enqueues the upload and calls slot_commit. */
-static int slot_prepare(ft_slot_t *s, size_t bytes, void *stream, int *k_out) {
+static int slot_prepare(asciichat_hip_frame_table_t *t, ft_slot_t *s, size_t bytes, void *stream, int *k_out, reader_set_t *defer) {
   const int k = s->cur == 0 ? 1 : 0;
   int rc = 0;
-  if (s->ready[k])
-    rc = achip_hip_check((int)hipEventSynchronize(s->ready[k]), "hipEventSynchronize(frame buffer)");
-  if (!rc && s->n_readers[k] > 0 && !s->reader_done)
+  if (!(defer && s->batch_of[k] && s->batch_of[k] == defer->done_batch)) {
+    rc = upload_wait(t, s, k, 0, NULL);
+    if (!rc && defer)
+      defer->done_batch = s->batch_of[k];
+  }
+  if (!rc && s->n_readers[k] > 0 && !s->reader_done && !defer)
     rc = achip_hip_check((int)hipEventCreateWithFlags(&s->reader_done, hipEventDisableTiming), "hipEventCreate");
   for (int r = 0; r < s->n_readers[k] && !rc; r++) {
+    if (defer) { /* a batch: the caller makes `stream` wait for every distinct reader stream once */
+      int known = 0;
+      for (int q = 0; q < defer->n; q++)
+        known |= defer->s[q] == s->reader[k][r];
+      if (known)
+        continue;
+      if (defer->n < (int)(sizeof(defer->s) / sizeof(defer->s[0]))) {
+        defer->s[defer->n++] = s->reader[k][r];
+        continue;
+      }
+      if (!s->reader_done)
+        rc = achip_hip_check((int)hipEventCreateWithFlags(&s->reader_done, hipEventDisableTiming), "hipEventCreate");
+      if (rc)
+        break;
+    }
     if (hipEventRecord(s->reader_done, s->reader[k][r]) != hipSuccess) {
       (void)hipGetLastError();
       continue;
@@ -290,7 +328,7 @@ static int slot_prepare(ft_slot_t *s, size_t bytes, void *stream, int *k_out) {
     if (!rc)
       s->cap[k] = bytes;
   }
-  if (!rc && !s->ready[k])
+  if (!rc && !s->ready[k] && !defer)
     rc = achip_hip_check((int)hipEventCreateWithFlags(&s->ready[k], hipEventDisableTiming), "hipEventCreate");
   *k_out = k;
   return rc;
@@ -307,30 +345,28 @@ int asciichat_hip_frame_table_publish_rows_batch(asciichat_hip_frame_table_t *t,
   if (!t || !slots || !blobs || !blob_sizes || n <= 0 || n > 65535 || !targets || n_targets <= 0)
     return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame_table_publish_rows_batch: bad arguments");
   typedef struct {
-    int slot, k, n_rows;
-    uint32_t w, h;
+    int slot, k, n_rows, set;
+    uint32_t w, h, set_w;
     const uint8_t *pixels;
     size_t off;
   } item_t;
   item_t *it = (item_t *)calloc((size_t)n, sizeof(item_t));
   int *order = (int *)malloc((size_t)n * sizeof(int));
-  uint32_t *rows = NULL;
-  uint8_t *mark = NULL;
+  enum { SETS_MAX = 8 };
+  achip_sample_set_t sets[SETS_MAX];
+  int n_sets = 0;
   if (!it || !order) {
     free(it);
     free(order);
     return achip_fail(ASCIICHAT_HIP_ERR_MEMORY, "out of memory");
   }
   int rc = 0;
-  uint32_t max_h = 0;
   for (int i = 0; i < n && !rc; i++) {
     it[i].slot = slots[i];
     if (slots[i] < 0 || slots[i] >= t->n || !blobs[i])
       rc = achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame_table_publish_rows_batch: bad slot or blob at %d", i);
     else if (achip_frame_blob_parse(blobs[i], blob_sizes[i], false, &it[i].w, &it[i].h, &it[i].pixels) != 0)
       rc = achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame blob %d rejected", i);
-    if (it[i].h > max_h)
-      max_h = it[i].h;
     order[i] = i;
   }
   /* ascending slot order (insertion sort: n is a tick's client count), duplicates refused */
@@ -343,37 +379,51 @@ int asciichat_hip_frame_table_publish_rows_batch(asciichat_hip_frame_table_t *t,
   for (int i = 1; i < n && !rc; i++)
     if (it[order[i]].slot == it[order[i - 1]].slot)
       rc = achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame_table_publish_rows_batch: slot %d named twice", it[order[i]].slot);
-  if (!rc) {
-    rows = (uint32_t *)malloc((size_t)max_h * sizeof(uint32_t));
-    mark = (uint8_t *)malloc(max_h ? max_h : 1);
-    if (!rows || !mark)
-      rc = achip_fail(ASCIICHAT_HIP_ERR_MEMORY, "out of memory");
-  }
-  /* sizes first: the block's layout */
+  /* sizes first: the block's layout (what is sampled depends on a frame's geometry only: one set per distinct w x h) */
   size_t total = ((size_t)n * 32u + 15u) & ~(size_t)15;
   uint32_t max_rows = 0, max_row_bytes = 0;
   for (int i = 0; i < n && !rc; i++) {
-    const int nr = sampled_rows(targets, n_targets, it[i].h, rows, mark);
-    if (nr < 0) {
-      rc = achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame_table_publish_rows_batch: a target does not describe blob %d (%ux%u)", i,
-                      it[i].w, it[i].h);
-      break;
+    int si = 0;
+    while (si < n_sets && (sets[si].w != it[i].w || sets[si].h != it[i].h))
+      si++;
+    if (si == n_sets) {
+      if (n_sets == SETS_MAX) { /* more geometries than this in one tick: rebuild the last set as needed */
+        achip_sample_set_free(&sets[SETS_MAX - 1]);
+        n_sets--;
+        si = n_sets;
+      }
+      const int b = achip_sample_set_build(&sets[si], targets, n_targets, it[i].w, it[i].h);
+      if (b) {
+        rc = b == -2 ? achip_fail(ASCIICHAT_HIP_ERR_MEMORY, "out of memory")
+                     : achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM,
+                                  "frame_table_publish_rows_batch: a target does not describe blob %d (%ux%u)", i, it[i].w, it[i].h);
+        break;
+      }
+      n_sets++;
     }
-    it[i].n_rows = nr;
+    it[i].set = si;
+    it[i].set_w = sets[si].w; /* (a set slot may be rebuilt for another geometry later: re-checked when packing) */
+    it[i].n_rows = sets[si].n_rows;
     it[i].off = total;
-    total += (((size_t)nr * 4u + 15u) & ~(size_t)15) + (((size_t)nr * it[i].w * 3u + 15u) & ~(size_t)15);
-    if ((uint32_t)nr > max_rows)
-      max_rows = (uint32_t)nr;
-    if (it[i].w * 3u > max_row_bytes)
-      max_row_bytes = it[i].w * 3u;
+    total += achip_sample_set_block_bytes(&sets[si]);
+    if ((uint32_t)sets[si].n_rows > max_rows)
+      max_rows = (uint32_t)sets[si].n_rows;
+    const uint32_t work = sets[si].n_cols ? (uint32_t)sets[si].n_cols * 3u : it[i].w * 3u;
+    if (work > max_row_bytes)
+      max_row_bytes = work;
   }
   if (!rc && total > 0xFFFFFFF0u)
     rc = achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame_table_publish_rows_batch: staged block exceeds 4 GiB");
   int locked = 0, have_batch = 0, par = 0;
+  unsigned batch_seq = 0;
+  reader_set_t readers;
+  readers.n = 0;
+  readers.done_batch = 0;
   if (!rc) {
     pthread_mutex_lock(&t->batch_mu);
     have_batch = 1;
     par = (int)(t->batch_no++ & 1u);
+    batch_seq = t->batch_no ? t->batch_no : (t->batch_no = 1u); /* never 0: that means "own event" */
     if (t->batch_done[par]) /* the DMA of two batches ago read this block */
       rc = achip_hip_check((int)hipEventSynchronize(t->batch_done[par]), "hipEventSynchronize(batch staging)");
     if (!rc && t->batch_cap[par] < total) {
@@ -393,26 +443,47 @@ int asciichat_hip_frame_table_publish_rows_batch(asciichat_hip_frame_table_t *t,
     if (!rc && !t->batch_done[par])
       rc = achip_hip_check((int)hipEventCreateWithFlags(&t->batch_done[par], hipEventDisableTiming), "hipEventCreate");
   }
-  /* per slot, in ascending order: lock, prepare the target buffer, pack the record and the rows */
+  /* per slot, in ascending order: lock, prepare the target buffer, pack the record and the sampled part */
   for (int q = 0; q < n && !rc; q++) {
     item_t *I = &it[order[q]];
     ft_slot_t *s = &t->slot[I->slot];
     pthread_mutex_lock(&s->mu);
     locked = q + 1;
-    rc = slot_prepare(s, (size_t)I->w * I->h * 3u, stream, &I->k);
+    rc = slot_prepare(t, s, (size_t)I->w * I->h * 3u, stream, &I->k, &readers);
     if (rc)
       break;
-    const int nr = sampled_rows(targets, n_targets, I->h, rows, mark);
-    uint8_t *blk = t->batch_host[par] + I->off;
-    const size_t table = ((size_t)nr * 4u + 15u) & ~(size_t)15, row_bytes = (size_t)I->w * 3u;
-    memcpy(blk, rows, (size_t)nr * 4u);
-    for (int r = 0; r < nr; r++)
-      memcpy(blk + table + (size_t)r * row_bytes, I->pixels + (size_t)rows[r] * row_bytes, row_bytes);
+    achip_sample_set_t *S = &sets[I->set];
+    achip_sample_set_t tmp;
+    if (S->w != I->w || S->h != I->h) { /* its slot was recycled for another geometry (more than SETS_MAX in this tick) */
+      if (achip_sample_set_build(&tmp, targets, n_targets, I->w, I->h)) {
+        rc = achip_fail(ASCIICHAT_HIP_ERR_MEMORY, "out of memory");
+        break;
+      }
+      S = &tmp;
+    }
+    achip_sample_set_pack(S, I->pixels, t->batch_host[par] + I->off);
     struct {
       uint64_t frame;
-      uint32_t off, n_rows, row_bytes, pad[3];
-    } rec = {(uint64_t)(uintptr_t)s->dev[I->k], (uint32_t)I->off, (uint32_t)nr, (uint32_t)row_bytes, {0, 0, 0}};
+      uint32_t off, n_rows, row_bytes, n_cols, pad[2];
+    } rec = {(uint64_t)(uintptr_t)s->dev[I->k], (uint32_t)I->off, (uint32_t)S->n_rows, I->w * 3u, (uint32_t)S->n_cols, {0, 0}};
     memcpy(t->batch_host[par] + (size_t)order[q] * 32u, &rec, 32);
+    if (S == &tmp)
+      achip_sample_set_free(&tmp);
+  }
+  /* renders that were handed the buffers about to be overwritten: the uploads go behind everything enqueued so far on
+   * their streams -- once per distinct stream, not once per slot */
+  if (!rc && readers.n > 0) {
+    hipEvent_t ev = NULL;
+    rc = achip_hip_check((int)hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
+    for (int q = 0; q < readers.n && !rc; q++) {
+      if (hipEventRecord(ev, readers.s[q]) != hipSuccess) { /* a stream destroyed without forget_stream: see there */
+        (void)hipGetLastError();
+        continue;
+      }
+      rc = achip_hip_check((int)hipStreamWaitEvent((hipStream_t)stream, ev, 0), "hipStreamWaitEvent(readers)");
+    }
+    if (ev)
+      (void)hipEventDestroy(ev); /* (released once the recorded work has completed) */
   }
   if (!rc)
     rc = achip_hip_check((int)hipMemcpyAsync(t->batch_dev[par], t->batch_host[par], total, hipMemcpyHostToDevice, (hipStream_t)stream),
@@ -422,10 +493,24 @@ int asciichat_hip_frame_table_publish_rows_batch(asciichat_hip_frame_table_t *t,
                          "batched row scatter launch");
   if (!rc)
     rc = achip_hip_check((int)hipEventRecord(t->batch_done[par], (hipStream_t)stream), "hipEventRecord(batch)");
+  if (!rc) { /* the batch's completion event, for every slot of it */
+    pthread_mutex_lock(&t->ev_mu);
+    const unsigned ri = batch_seq % FT_RING;
+    if (t->ring[ri] && t->ring_seq[ri]) /* the batch this slot stood for leaves the ring: make "not in the ring" mean "done" */
+      rc = achip_hip_check((int)hipEventSynchronize(t->ring[ri]), "hipEventSynchronize(batch ring)");
+    if (!rc && !t->ring[ri])
+      rc = achip_hip_check((int)hipEventCreateWithFlags(&t->ring[ri], hipEventDisableTiming), "hipEventCreate");
+    if (!rc)
+      rc = achip_hip_check((int)hipEventRecord(t->ring[ri], (hipStream_t)stream), "hipEventRecord(batch ring)");
+    if (!rc)
+      t->ring_seq[ri] = batch_seq;
+    pthread_mutex_unlock(&t->ev_mu);
+  }
   for (int q = 0; q < locked; q++) { /* commit (or leave untouched on failure) and unlock */
     item_t *I = &it[order[q]];
     ft_slot_t *s = &t->slot[I->slot];
-    if (!rc && hipEventRecord(s->ready[I->k], (hipStream_t)stream) == hipSuccess) {
+    if (!rc) {
+      s->batch_of[I->k] = batch_seq;
       s->cur = I->k;
       s->w = (int)I->w;
       s->h = (int)I->h;
@@ -435,17 +520,41 @@ int asciichat_hip_frame_table_publish_rows_batch(asciichat_hip_frame_table_t *t,
   }
   if (have_batch)
     pthread_mutex_unlock(&t->batch_mu);
-  free(rows);
-  free(mark);
+  for (int i = 0; i < n_sets; i++)
+    achip_sample_set_free(&sets[i]);
   free(order);
   free(it);
   return rc;
 }
 
-int asciichat_hip_frame_table_latest(asciichat_hip_frame_table_t *t, int slot, void *consumer_stream,
-                                     const uint8_t **pixels_dev, int *width, int *height, uint64_t *generation) {
-  if (!t || slot < 0 || slot >= t->n || !pixels_dev)
-    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame_table_latest: bad arguments");
+/* The latest frames of a tick's clients straight into their render descriptors: frames[i].src = the device frame of
+ * slots[i] when it has one AND its geometry is what the descriptor was set up for (src_w x src_h), else NULL (no video yet,
+ * or the client changed its resolution: set the descriptor up again).  The consumer stream is registered with every
+ * frame handed out, as frame_table_latest does.  Returns the number of descriptors that got a source, < 0 on error. */
+int asciichat_hip_frame_table_latest_frames(asciichat_hip_frame_table_t *t, const int *slots, int n, void *consumer_stream,
+                                            achip_frame_t *frames) {
+  if (!t || !slots || !frames || n < 0)
+    return -achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame_table_latest_frames: bad arguments");
+  int with_video = 0;
+  unsigned waited_batch = 0; /* frames of one batch publish share its event: the consumer stream waits for it once */
+  for (int i = 0; i < n; i++) {
+    const uint8_t *px = NULL;
+    int w = 0, h = 0;
+    if (slots[i] < 0 || slots[i] >= t->n)
+      return -achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame_table_latest_frames: bad slot at %d", i);
+    const int rc = latest_one(t, slots[i], consumer_stream, &px, &w, &h, NULL, &waited_batch);
+    if (rc)
+      return -rc;
+    const int fits = px && w == frames[i].src_w && h == frames[i].src_h;
+    frames[i].src = fits ? px : NULL;
+    with_video += fits;
+  }
+  return with_video;
+}
+
+/* latest() of one slot; *waited_batch (optional): a batch publish `consumer_stream` already waits for */
+static int latest_one(asciichat_hip_frame_table_t *t, int slot, void *consumer_stream, const uint8_t **pixels_dev, int *width,
+                      int *height, uint64_t *generation, unsigned *waited_batch) {
   ft_slot_t *s = &t->slot[slot];
   pthread_mutex_lock(&s->mu);
   int rc = 0;
@@ -459,9 +568,13 @@ int asciichat_hip_frame_table_latest(asciichat_hip_frame_table_t *t, int slot, v
       *generation = 0;
   } else {
     /* work queued on consumer_stream after this call sees the complete upload */
-    rc = achip_hip_check((int)hipStreamWaitEvent((hipStream_t)consumer_stream, s->ready[s->cur], 0), "hipStreamWaitEvent");
-    /* remember the reader: the upload that will overwrite this buffer (the publish after next) waits for it */
     const int k = s->cur;
+    if (!(waited_batch && s->batch_of[k] && s->batch_of[k] == *waited_batch)) {
+      rc = upload_wait(t, s, k, 1, (hipStream_t)consumer_stream);
+      if (!rc && waited_batch)
+        *waited_batch = s->batch_of[k];
+    }
+    /* remember the reader: the upload that will overwrite this buffer (the publish after next) waits for it */
     int known = 0;
     for (int r = 0; r < s->n_readers[k]; r++)
       known |= s->reader[k][r] == (hipStream_t)consumer_stream;
@@ -481,6 +594,13 @@ int asciichat_hip_frame_table_latest(asciichat_hip_frame_table_t *t, int slot, v
   }
   pthread_mutex_unlock(&s->mu);
   return rc;
+}
+
+int asciichat_hip_frame_table_latest(asciichat_hip_frame_table_t *t, int slot, void *consumer_stream,
+                                     const uint8_t **pixels_dev, int *width, int *height, uint64_t *generation) {
+  if (!t || slot < 0 || slot >= t->n || !pixels_dev)
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame_table_latest: bad arguments");
+  return latest_one(t, slot, consumer_stream, pixels_dev, width, height, generation, NULL);
 }
 
 /* A consumer that destroys a stream it passed to latest() MUST call this first: publish() records events on the remembered

@@ -38,6 +38,21 @@ char *achip_combine_render(int mode, const char *palette, const achip_lut_t *lut
 size_t achip_stage_extent(const achip_frame_t *f, int *w, int *h);
 void achip_stage_gather(const achip_frame_t *f, const uint8_t *host_px, uint8_t *dst, achip_frame_t *d);
 
+/* achip_host.c: what a set of render targets reads of a w x h source frame (frame_table_publish_rows*): the sampled rows
+ * (ascending, unique), and the sampled columns when they are at most half of the frame's (n_cols = 0: whole rows).
+ * build: 0, -1 (a target does not describe this frame), -2 (memory).  pack writes [row table][column table, if
+ * any][rows, or rows x columns pixels] (tables padded to 16 bytes) -- the block scatter_rows_batch_kernel puts in place. */
+typedef struct {
+  uint32_t w, h;
+  int n_rows, n_cols;
+  uint32_t *rows, *cols;
+} achip_sample_set_t;
+int achip_sampled_rows(const achip_frame_t *targets, int n_targets, uint32_t h, uint32_t *rows_out, uint8_t *mark);
+int achip_sample_set_build(achip_sample_set_t *S, const achip_frame_t *targets, int n_targets, uint32_t w, uint32_t h);
+void achip_sample_set_free(achip_sample_set_t *S);
+size_t achip_sample_set_block_bytes(const achip_sample_set_t *S);
+void achip_sample_set_pack(const achip_sample_set_t *S, const uint8_t *pixels, uint8_t *blk);
+
 /* buffer_pool.c: device alias of a pointer inside a pinned pool block, or NULL */
 const void *achip_pool_device_ptr(const void *host_ptr);
 

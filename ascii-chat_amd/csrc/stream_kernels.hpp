@@ -232,11 +232,13 @@ __global__ void __launch_bounds__(256)
 
 
 /* The same for a whole tick's clients in ONE launch (frame_table_publish_rows_batch): the staged block starts with one
- * 32-byte record per client {frame pointer, offset of its [index table][rows] block, rows, row bytes}; workgroup
- * (x, r, c) copies slice x of row r of client c. */
+ * 32-byte record per client {frame pointer, offset of its block, rows, frame row bytes, columns}; workgroup (x, r, c)
+ * copies slice x of row r of client c.  columns = 0: the block is [row table][rows], whole rows are copied; otherwise it
+ * is [row table][column table][rows x columns pixels] -- only the pixels the targets sample were staged (a frame at most
+ * half as wide as its source) -- and every pixel goes to its place in the full-geometry frame. */
 struct scatter_client_t {
   uint64_t frame;
-  uint32_t off, n_rows, row_bytes, _pad[3];
+  uint32_t off, n_rows, row_bytes, n_cols, _pad[2];
 };
 __global__ void __launch_bounds__(256) scatter_rows_batch_kernel(const uint8_t *__restrict__ staged, uint32_t n_clients) {
   const uint32_t c = blockIdx.z;
@@ -249,9 +251,18 @@ __global__ void __launch_bounds__(256) scatter_rows_batch_kernel(const uint8_t *
   const uint32_t table = (cl.n_rows * 4u + 15u) & ~15u;
   const uint8_t *blk = staged + cl.off;
   const uint32_t row = reinterpret_cast<const uint32_t *>(blk)[r];
-  const uint8_t *src = blk + table + (uint64_t)r * cl.row_bytes;
   uint8_t *dst = reinterpret_cast<uint8_t *>(cl.frame) + (uint64_t)row * cl.row_bytes;
   const uint32_t i0 = blockIdx.x * 256u + threadIdx.x, step = gridDim.x * 256u;
+  if (cl.n_cols) {
+    const uint32_t *cols = reinterpret_cast<const uint32_t *>(blk + table);
+    const uint8_t *src = blk + table + ((cl.n_cols * 4u + 15u) & ~15u) + (uint64_t)r * cl.n_cols * 3u;
+    for (uint32_t i = i0; i < cl.n_cols; i += step) {
+      uint8_t *d = dst + (uint64_t)cols[i] * 3u;
+      d[0] = src[3u * i], d[1] = src[3u * i + 1u], d[2] = src[3u * i + 2u];
+    }
+    return;
+  }
+  const uint8_t *src = blk + table + (uint64_t)r * cl.row_bytes;
   if ((((uintptr_t)src | (uintptr_t)dst) & 15u) == 0u) {
     const uint32_t groups = cl.row_bytes >> 4;
     for (uint32_t g = i0; g < groups; g += step)

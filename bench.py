@@ -34,6 +34,7 @@ import os
 import platform
 import statistics
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -41,6 +42,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 PALETTE_STANDARD = "   ...',;:clodxkO0KXNWM"  # PALETTE_CHARS_STANDARD (palette.h:161)
+MULTI_LEG_TIMEOUT_S = 180  # the optional all-gather leg of an N > 1 run (after the timing line is complete)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 
 WORKLOADS = {
@@ -514,9 +516,10 @@ def wire_stage(torch, pkg, res, steps=None):
 def tick_e2e(torch, pkg, n=256, distinct=32, ticks=(2, 4)):
     """The end-to-end server tick (SURVEY 8f.2 + path + 8f.3), PCIe included on both sides: n clients' host blobs
     [u32 BE w][u32 BE h][RGB24] (blocks of the pinned pool, as the receive path would fill them) -> frame table ->
-    plan_render_packets -> frames in use + headers packed into mapped pinned host memory.  Two publish forms: the whole
-    blob (frame_table_publish: one in-place DMA of 6.2 MB per client) and the sampled rows only
-    (frame_table_publish_rows: 24 of 1080 rows).  Never `value`: this is PCIe- and host-bound (the per-client calls are
+    plan_render_packets -> frames in use + headers packed into mapped pinned host memory.  Three publish forms: the whole
+    blob (frame_table_publish: one in-place DMA of 6.2 MB per client), the sampled rows only (frame_table_publish_rows:
+    24 of 1080 rows, a DMA and a launch per client) and the whole tick in one call (frame_table_publish_rows_batch: the
+    sampled pixels of every client in one block, one DMA, one launch).  Never `value`: this is PCIe- and host-bound (the per-client calls are
     issued from this interpreter; tests/cabi/server_tick_port.c is the same tick in C)."""
     import numpy as np
 
@@ -548,32 +551,35 @@ def tick_e2e(torch, pkg, n=256, distinct=32, ticks=(2, 4)):
     hdr = torch.zeros(n * 24, dtype=torch.uint8, device="cuda")
     pkt = torch.zeros(n, dtype=torch.int32, device="cuda")
     out = {}
-    for form in ("whole_blob", "sampled_rows", "sampled_rows_batched"):
+    slot_arr = (C.c_int * n)(*range(n))
+    size_arr = (C.c_size_t * n)(*([blob_bytes] * n))
+    ptr_arrs = [(C.c_void_p * n)(*[blobs[(i + t) % distinct] for i in range(n)]) for t in range(distinct)]
+    tmpl_arr = (pkg.Frame * 1)(tmpl)
+    frames = (pkg.Frame * n)(*[pkg.Frame.from_buffer_copy(tmpl) for _ in range(n)])
+    for form in ("whole_blob", "sampled_rows", "sampled_pixels_batched"):
         t_pub = t_all = 0.0
-        n_ticks = ticks[0] if form == "whole_blob" else ticks[1] * (2 if form == "sampled_rows_batched" else 1)
+        batched = form == "sampled_pixels_batched"
+        n_ticks = ticks[0] if form == "whole_blob" else ticks[1] * (5 if batched else 1)
         for tick in range(n_ticks + 1):  # the first tick allocates (frame buffers, staging): untimed
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            if form == "sampled_rows_batched":  # one packed block, one DMA, one scatter launch for the whole tick
-                table.publish_rows_batch(list(range(n)), [(blobs[(i + tick) % distinct], blob_bytes) for i in range(n)], [tmpl], st)
-            for i in range(n if form != "sampled_rows_batched" else 0):
+            if batched:  # one packed block (sampled pixels), one DMA, one scatter launch for the whole tick
+                table.publish_rows_batch(slot_arr, (ptr_arrs[tick % distinct], size_arr), tmpl_arr, st)
+            for i in range(0 if batched else n):
                 if form == "whole_blob":
                     table.publish_at(i, blobs[(i + tick) % distinct], blob_bytes, st)
                 else:
                     table.publish_rows(i, (blobs[(i + tick) % distinct], blob_bytes), [tmpl], st)
             t1 = time.perf_counter()
-            descs = []
-            for i in range(n):
-                f = pkg.Frame.from_buffer_copy(tmpl)
-                f.src = table.latest(i, st)[0]
-                descs.append(f)
+            if table.latest_frames(slot_arr, frames, st) != n:  # one call: every descriptor's source pointer
+                raise SystemExit("bench.py: tick_e2e: a client without a frame")
             if plan is None:
-                plan = pkg.Plan(mode, PALETTE_STANDARD, descs)
+                plan = pkg.Plan(mode, PALETTE_STANDARD, list(frames))
                 slab = torch.empty(n * plan.stride, dtype=torch.uint8, device="cuda")
                 ln = torch.zeros(n, dtype=torch.int32, device="cuda")
                 hb = pkg.HostBuffer(tab + n * plan.stride)
             else:
-                plan.update(descs, st)
+                plan.update(frames, st)
             plan.render_packets(slab.data_ptr(), plan.stride, ln.data_ptr(), dims.data_ptr(), crc.data_ptr(), hdr.data_ptr(),
                                 pkt.data_ptr(), st)
             pkg.pack_frames(slab.data_ptr(), plan.stride, ln.data_ptr(), n, hb.dev + tab, n * plan.stride, hb.dev,
@@ -593,6 +599,8 @@ def tick_e2e(torch, pkg, n=256, distinct=32, ticks=(2, 4)):
                 raise SystemExit(f"bench.py: tick_e2e ({form}) frame {i} differs from the oracle")
         rows = H
         up = n * (blob_bytes - 8) if form == "whole_blob" else n * (rows * sw * 3 + 16 * ((rows * 4 + 15) // 16))
+        if batched:  # [record][row table][column table][H x W sampled pixels] per client
+            up = n * (32 + 16 * ((rows * 4 + 15) // 16) + 16 * ((W * 4 + 15) // 16) + 16 * ((rows * W * 3 + 15) // 16))
         out[form] = {"frames_per_s": n * n_ticks / t_all, "ms_per_tick": t_all / n_ticks * 1e3,
                      "publish_ms_per_tick": t_pub / n_ticks * 1e3, "ticks_timed": n_ticks,
                      "pcie_bytes_up_per_tick": int(up), "pcie_bytes_down_per_tick": int(off[n]) + tab + 24 * n,
@@ -914,17 +922,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         walls = [float(v) for v in t.tolist()]
         res["walls"] = walls
-        # the C-ABI's own communicator over these ranks (comm.c): how many ranks RCCL sees, and what gathering every
-        # rank's frames costs -- outside the timed regions (the metric's path has no collective)
         multi = {"torch_distributed_backend": backend, "per_rank_frames_per_s": per_rank_fps}
-        try:
-            comm = rank_comm(torch, pkg, dist, world, rank, backend)
-            if comm is not None:
-                multi["rccl_ranks"] = comm.count
-                multi["all_gather_of_rendered_frames"] = gather_leg(torch, pkg, comm, res["plans"][0], args.batch, world, rank)
-                comm.close()
-        except Exception as e:  # never lose the timing line to the optional leg
-            multi["error"] = str(e)[:300]
     wall = statistics.median(walls)
     main_d = summarize(res, world, wall)
     sw, sh, W, H, cl, rm = WORKLOADS[args.workload]
@@ -960,7 +958,33 @@ def main():
     if res["serial"] is not None:
         line["one_launch_at_a_time"] = res["serial"]
     if multi is not None:
+        # the C-ABI's own communicator over these ranks (comm.c): how many ranks RCCL sees, and what gathering every
+        # rank's frames costs -- outside the timed regions (the metric's path has no collective), AFTER the line is
+        # complete and under a watchdog: if the optional leg wedges (a rank that cannot join a collective blocks the
+        # others inside RCCL, where no exception can reach them) every rank gives up after MULTI_LEG_TIMEOUT_S and rank 0
+        # still prints the timing line
         line["multi_gpu"] = multi
+        line["rccl_ranks"] = None
+
+        def give_up():
+            multi["error"] = f"the all-gather leg did not finish within {MULTI_LEG_TIMEOUT_S} s; timing line printed without it"
+            if rank == 0:
+                emit(line)
+            sys.stdout.flush()
+            os._exit(0)
+
+        watchdog = threading.Timer(MULTI_LEG_TIMEOUT_S, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            comm = rank_comm(torch, pkg, dist, world, rank, backend)
+            if comm is not None:
+                multi["rccl_ranks"] = comm.count
+                multi["all_gather_of_rendered_frames"] = gather_leg(torch, pkg, comm, res["plans"][0], args.batch, world, rank)
+                comm.close()
+        except Exception as e:  # never lose the timing line to the optional leg
+            multi["error"] = str(e)[:300]
+        watchdog.cancel()
         line["rccl_ranks"] = multi.get("rccl_ranks")
     cp = committed_profile(args.workload)
     if cp is not None:

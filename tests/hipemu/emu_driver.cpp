@@ -262,6 +262,12 @@ extern "C" void emu_pack(const uint8_t *slab, uint64_t stride, const uint32_t *l
                  [&] { achip::pack_frames_kernel(slab, stride, len, n, dst, cap, off_out, len_out); });
 }
 
+/* the batched row / pixel scatter of ingest (stream_kernels.hpp), with the launcher's (slices, rows, clients) grid */
+extern "C" void emu_scatter_rows_batch(const uint8_t *staged, uint32_t n_clients, uint32_t max_rows, int slices) {
+  hipemu::launch(dim3((unsigned)slices, max_rows, n_clients), dim3(256), 0,
+                 [&] { achip::scatter_rows_batch_kernel(staged, n_clients); });
+}
+
 #include <vector>
 #include "crc_kernels.hpp"
 

@@ -109,9 +109,9 @@ template <class F> void launch(dim3 grid, dim3 block, size_t smem_bytes, F body)
     if (!f.stack)
       f.stack = malloc(stack_bytes);
   g_body = body;
-  for (unsigned bb = 0; bb < grid.x * grid.y; bb++) { /* workgroups one at a time, x fastest */
+  for (unsigned bb = 0; bb < grid.x * grid.y * grid.z; bb++) { /* workgroups one at a time, x fastest */
     const unsigned b = bb % grid.x;
-    g_blockIdx = idx3{b, bb / grid.x, 0};
+    g_blockIdx = idx3{b, (bb / grid.x) % grid.y, bb / (grid.x * grid.y)};
     std::fill(g_smem.begin(), g_smem.end(), 0xCD);
     for (unsigned t = 0; t < block.x; t++) {
       Fiber &f = g_fibers[t];

@@ -807,7 +807,40 @@ def test_frame_table_publish_rows_batch(gpu):
             got = render_descs(gpu, mode, frames)
             for i in range(n):
                 assert got[i] == orc.convert_with_caps(imgs[i], W, H, cl, rm, False, False, False), (tick, mode, i)
-    b0 = keep[-1][0]
+    # sampled PIXELS (targets at most half as wide as the source) next to sampled ROWS (a wider target joins: every column
+    # is needed), a horizontally flipped target, odd geometry; descriptors filled by frame_table_latest_frames
+    w, h = 333, 201
+    t_a = pkg.frame_setup(None, w, h, 100, 37, 0, False, False, False)
+    t_b = pkg.frame_setup(None, w, h, 80, 24, 2, False, False, False)
+    t_x = pkg.frame_setup(None, w, h, 100, 37, 0, False, False, False)
+    assert pkg.lib().achip_frame_set_display_ops(C.byref(t_x), True, False, 0) == 0   # flipped horizontally
+    t_wide = pkg.frame_setup(None, w, h, 200, 60, 0, False, False, False)
+    for targets in ([t_a, t_b, t_x], [t_a, t_b, t_x, t_wide]):
+        imgs = [orc.frame_hash_noise(w, h, 900 + i + len(targets)) for i in range(5)]
+        bufs = [C.create_string_buffer(struct.pack(">II", w, h) + np.ascontiguousarray(im).tobytes(), 8 + im.size) for im in imgs]
+        keep.append(bufs)
+        slots = (C.c_int * 5)(2, 4, 6, 8, 10)
+        table.publish_rows_batch(slots, [(C.addressof(b), len(b)) for b in bufs], targets, stream)
+        for tmpl, mode, exp in ((t_a, 1, lambda im: orc.convert_with_caps(im, 100, 37, 3, 0, False, False, False)),
+                                (t_b, 5, lambda im: orc.convert_with_caps(im, 80, 24, 3, 2, False, False, False)),
+                                (t_x, 1, lambda im: orc.convert_with_caps(orc.flip(im, True, False), 100, 37, 3, 0, False, False, False)),
+                                (t_wide, 1, lambda im: orc.convert_with_caps(im, 200, 60, 3, 0, False, False, False)))[:len(targets)]:
+            frames = (pkg.Frame * 5)(*[pkg.Frame.from_buffer_copy(tmpl) for _ in range(5)])
+            assert table.latest_frames(slots, frames, stream) == 5
+            got = render_descs(gpu, mode, list(frames))
+            for i in range(5):
+                assert got[i] == exp(imgs[i]), (len(targets), mode, i)
+        if len(targets) == 3:  # what arrived: only sampled pixels (the rest of the buffer is not the blob's)
+            ptr = table.latest(2, stream)[0]
+            dev_img = torch.empty((h, w, 3), dtype=torch.uint8, device="cuda")
+            assert pkg.lib().asciichat_hip_resize(ptr, w, h, dev_img.data_ptr(), w, h, stream) == 0
+            torch.cuda.synchronize()
+            same = (dev_img.cpu().numpy() == imgs[0]).all(axis=2)
+            assert 100 * 37 <= int(same.sum()) < w * h // 3, int(same.sum())
+    # a descriptor set up for another geometry gets no source (the client changed its resolution)
+    stale = (pkg.Frame * 1)(pkg.frame_setup(None, 640, 480, 80, 24, 0, False, False, False))
+    assert table.latest_frames((C.c_int * 1)(2), stale, stream) == 0 and not stale[0].src
+    b0 = keep[0][0]
     with pytest.raises(RuntimeError):  # a slot named twice
         table.publish_rows_batch([1, 1], [(C.addressof(b0), len(b0))] * 2, [t_fg], stream)
     bad = pkg.frame_setup(None, 1920, 1081, 80, 24, 0, False, False, False)
@@ -858,3 +891,69 @@ def test_frame_table_upload_waits_for_queued_readers(gpu):
         plan.close()
         busy.close()
         table.close()
+
+
+def test_frame_table_batch_publish_waits_for_queued_readers_and_mixes_with_single(gpu):
+    """The batch form of the test above: a tick's buffers are guarded by ONE event per batch (not one per slot) and the
+    reader streams of all its slots are waited for once each.  A render of tick A's frames is queued behind a busy consumer
+    stream; ticks B and C are batch-published on another stream (C overwrites A's buffers): the render must still see A.
+    Then single-slot and batch publishes alternate on one slot (own event <-> batch event hand-over), and more batches than
+    the event ring holds."""
+    import struct
+    pkg, torch = gpu
+    n = 6
+    w, h = 1920, 1080
+    ticks = [[orc.frame_hash_noise(w, h, 4000 + 10 * t + i) for i in range(n)] for t in range(3)]
+    bufs = [[C.create_string_buffer(struct.pack(">II", w, h) + np.ascontiguousarray(im).tobytes(), 8 + im.size) for im in tk]
+            for tk in ticks]
+    tmpl = pkg.frame_setup(None, w, h, 80, 24, 0, False, False, False)
+    slots = (C.c_int * n)(*range(n))
+    busy_src = torch.from_numpy(np.ascontiguousarray(orc.frame_hash_noise(3840, 2160, 5))).cuda()
+    pub, cons = torch.cuda.Stream(), torch.cuda.Stream()
+
+    def publish(table, t):
+        table.publish_rows_batch(slots, [(C.addressof(b), len(b)) for b in bufs[t]], [tmpl], pub.cuda_stream)
+
+    exp = [oracle_convert(im, MODE_TRUE_FG, 80, 24, orc.PALETTE_STANDARD) for im in ticks[0]]
+    for round_ in range(4):
+        table = pkg.FrameTable(n)
+        publish(table, 0)
+        frames = (pkg.Frame * n)(*[pkg.Frame.from_buffer_copy(tmpl) for _ in range(n)])
+        assert table.latest_frames(slots, frames, cons.cuda_stream) == n
+        busy = pkg.Plan(MODE_HB_TRUE, orc.PALETTE_STANDARD,
+                        [pkg.frame_setup(busy_src.data_ptr(), 3840, 2160, 400, 120, 2, False, False, False)] * 256)
+        bout = torch.empty(256 * busy.stride, dtype=torch.uint8, device="cuda")
+        bln = torch.zeros(256, dtype=torch.int32, device="cuda")
+        for _ in range(8):
+            busy.render(bout.data_ptr(), busy.stride, bln.data_ptr(), cons.cuda_stream)
+        plan = pkg.Plan(MODE_TRUE_FG, orc.PALETTE_STANDARD, list(frames))
+        out = torch.zeros(n * plan.stride, dtype=torch.uint8, device="cuda")
+        ln = torch.zeros(n, dtype=torch.int32, device="cuda")
+        plan.render(out.data_ptr(), plan.stride, ln.data_ptr(), cons.cuda_stream)   # queued, not yet running
+        publish(table, 1)
+        publish(table, 2)                                                           # overwrites tick A's buffers
+        torch.cuda.synchronize()
+        host, lens = out.cpu().numpy(), ln.cpu().numpy()
+        for k in range(n):
+            assert host[k * plan.stride:k * plan.stride + int(lens[k])].tobytes() == exp[k], (round_, k)
+        table.forget_stream(cons.cuda_stream)
+        plan.close()
+        busy.close()
+        table.close()
+    # own event <-> batch event on the same slot, and more batches than the ring of batch events holds
+    table = pkg.FrameTable(n)
+    st = torch.cuda.current_stream().cuda_stream
+    for step in range(24):
+        t = step % 3
+        if step % 4 == 3:
+            table.publish(0, bufs[t][0].raw[:8 + w * h * 3], st)
+            for i in range(1, n):
+                table.publish_rows(i, (C.addressof(bufs[t][i]), len(bufs[t][i])), [tmpl], st)
+        else:
+            publish(table, t)
+        frames = (pkg.Frame * n)(*[pkg.Frame.from_buffer_copy(tmpl) for _ in range(n)])
+        assert table.latest_frames(slots, frames, st) == n
+        got = render_descs(gpu, MODE_TRUE_FG, list(frames))
+        for k in range(n):
+            assert got[k] == oracle_convert(ticks[t][k], MODE_TRUE_FG, 80, 24, orc.PALETTE_STANDARD), (step, k)
+    table.close()

@@ -169,3 +169,78 @@ def test_pack_frames_gpu_device_and_mapped_host_destinations():
         assert v[tab + int(o2[i]):tab + int(o2[i]) + int(l2[i])].tobytes() == exp[i], i
     hb.close()
     plan.close()
+
+
+def _sample_all(img, f):
+    """what the device sampler reads for every cell of the out_w x out_h image (render_kernels.hpp sample_frame_raw)"""
+    h, w, _ = img.shape
+    xs = np.minimum((np.arange(f.out_w, dtype=np.uint64) * f.x_ratio) >> 16, w - 1).astype(np.int64)
+    ys = np.minimum((np.arange(f.out_h, dtype=np.uint64) * f.y_ratio) >> 16, h - 1).astype(np.int64)
+    if f.ops & 1:
+        xs = w - 1 - xs
+    if f.ops & 2:
+        ys = h - 1 - ys
+    return img[ys][:, xs]
+
+
+class _SampleSet(C.Structure):
+    _fields_ = [("w", C.c_uint32), ("h", C.c_uint32), ("n_rows", C.c_int), ("n_cols", C.c_int),
+                ("rows", C.POINTER(C.c_uint32)), ("cols", C.POINTER(C.c_uint32))]
+
+
+@pytest.mark.parametrize("case", [
+    (1920, 1080, [(80, 24, 0, 0)]),                                  # sampled pixels: 80 x 24 of 1920 x 1080
+    (1920, 1080, [(80, 24, 0, 0), (60, 20, 2, 1), (100, 37, 0, 2)]),  # three targets, flips: union of rows x union of columns
+    (333, 201, [(100, 37, 0, 3), (80, 24, 2, 0)]),                   # odd geometry
+    (333, 201, [(100, 37, 0, 0), (200, 60, 0, 0)]),                  # a wide target: whole rows
+    (40, 30, [(80, 24, 0, 0)]),                                      # upscale: every row and column
+], ids=["pixels", "union", "odd", "rows", "upscale"])
+def test_ingest_sample_set_and_scatter_emulated(case):
+    """frame_table_publish_rows_batch without a GPU: the host's sample set + packed block (achip_host.c) and the scatter
+    kernel under the emulator put exactly what every target's sampler reads into a full-geometry frame."""
+    w, h, targets = case
+    L = emu.lib()
+    rng = np.random.default_rng(w + 7 * len(targets))
+    n_clients = 3
+    imgs = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for _ in range(n_clients)]
+    tf = (emu.Frame * len(targets))()
+    for i, (tw, th, rm, ops) in enumerate(targets):
+        assert L.achip_frame_setup(C.byref(tf[i]), None, w, h, tw, th, rm, False, False, True) == 0
+        tf[i].ops = ops
+    S = _SampleSet()
+    L.achip_sample_set_build.argtypes = [C.POINTER(_SampleSet), C.POINTER(emu.Frame), C.c_int, C.c_uint32, C.c_uint32]
+    L.achip_sample_set_block_bytes.restype = C.c_size_t
+    L.achip_sample_set_block_bytes.argtypes = [C.POINTER(_SampleSet)]
+    L.achip_sample_set_pack.restype = None
+    L.achip_sample_set_pack.argtypes = [C.POINTER(_SampleSet), C.c_void_p, C.c_void_p]
+    L.achip_sample_set_free.argtypes = [C.POINTER(_SampleSet)]
+    L.emu_scatter_rows_batch.restype = None
+    L.emu_scatter_rows_batch.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int]
+    assert L.achip_sample_set_build(C.byref(S), tf, len(targets), w, h) == 0
+    need_cols = sorted({int(x) for f in tf for x in (_sample_all(np.arange(w)[None, :, None].repeat(h, 0), f)[0, :, 0])})
+    need_rows = sorted({int(y) for f in tf for y in (_sample_all(np.arange(h)[:, None, None].repeat(w, 1), f)[:, 0, 0])})
+    assert [S.rows[i] for i in range(S.n_rows)] == need_rows
+    if 2 * len(need_cols) <= w:
+        assert [S.cols[i] for i in range(S.n_cols)] == need_cols
+    else:
+        assert S.n_cols == 0
+    blk_bytes = L.achip_sample_set_block_bytes(C.byref(S))
+    head = (n_clients * 32 + 15) // 16 * 16
+    staged = np.zeros(head + n_clients * blk_bytes, dtype=np.uint8)
+    frames = [np.full((h, w, 3), 0xEE, dtype=np.uint8) for _ in range(n_clients)]
+    for c in range(n_clients):
+        off = head + c * blk_bytes
+        L.achip_sample_set_pack(C.byref(S), imgs[c].ctypes.data, staged.ctypes.data + off)
+        rec = np.zeros(8, dtype=np.uint32)
+        rec[0], rec[1] = frames[c].ctypes.data & 0xFFFFFFFF, frames[c].ctypes.data >> 32
+        rec[2], rec[3], rec[4], rec[5] = off, S.n_rows, 3 * w, S.n_cols
+        staged[32 * c:32 * c + 32] = rec.view(np.uint8)
+    for slices in (1, 2):
+        L.emu_scatter_rows_batch(staged.ctypes.data, n_clients, S.n_rows, slices)
+        for c in range(n_clients):
+            for f in tf:
+                assert np.array_equal(_sample_all(frames[c], f), _sample_all(imgs[c], f))
+            arrived = (frames[c] == imgs[c]).all(axis=2)
+            expect = len(need_rows) * (len(need_cols) if S.n_cols else w)
+            assert expect <= int(arrived.sum()) <= expect + w * h // 200  # (+ chance matches with the 0xEE fill: none in practice)
+    L.achip_sample_set_free(C.byref(S))
