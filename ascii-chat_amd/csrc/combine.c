@@ -314,6 +314,7 @@ void achip_combine_enter(void) {
 }
 void achip_combine_leave(void) { __atomic_sub_fetch(&g_cb_callers, 1, __ATOMIC_RELAXED); }
 int achip_combine_callers(void) { return __atomic_load_n(&g_cb_callers, __ATOMIC_RELAXED); }
+int achip_combine_crowded(void) { return cb_crowded(); }
 
 static int pinned_mapped(void **host, void **dev, size_t bytes) {
   if (hipHostMalloc(host, bytes, hipHostMallocMapped) != hipSuccess)

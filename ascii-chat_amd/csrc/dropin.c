@@ -30,6 +30,8 @@
 #define PIN_DESC_OFF 0
 #define PIN_LEN_OFF 64
 #define PIN_OUT_OFF 128
+#define DROPIN_INPLACE_MAX ((size_t)64 << 10) /* staged images up to this size are read in place (mapped pinned memory) */
+#define DROPIN_POLLS 20000u /* hipStreamQuery polls (~0.3 us each) before the wait turns into a blocking synchronize */
 #define PIN_KEEP_MAX ((size_t)32 << 20) /* pinned output blocks above 32 MiB are released after the call that needed them */
 
 typedef struct {
@@ -39,7 +41,8 @@ typedef struct {
   size_t pin_cap;
   uint8_t *stage;    /* device staging for sources that are not device-visible */
   size_t stage_cap;
-  uint8_t *hstage;   /* pinned host staging: the sampled rows of such a source, gathered for one DMA */
+  uint8_t *hstage;   /* pinned, device-mapped host staging: the sampled pixels of such a source */
+  uint8_t *hstage_dev; /* its device alias: small staged images are read in place, larger ones sent with one DMA */
   size_t hstage_cap;
   uint8_t *scratch;  /* device scratch for image_resize() destinations */
   size_t scratch_cap;
@@ -164,16 +167,25 @@ static const uint8_t *stage_source(tls_ctx_t *c, achip_frame_t *d, size_t src_by
     if (c->hstage)
       (void)hipHostFree(c->hstage);
     c->hstage = NULL;
+    c->hstage_dev = NULL;
     c->hstage_cap = 0;
-    if (achip_hip_check((int)hipHostMalloc((void **)&c->hstage, need + need / 4, hipHostMallocDefault),
-                        "hipHostMalloc(row staging)"))
+    void *dev = NULL;
+    if (achip_hip_check((int)hipHostMalloc((void **)&c->hstage, need + need / 4 + 16, hipHostMallocMapped),
+                        "hipHostMalloc(pixel staging)"))
       return NULL;
+    if (hipHostGetDevicePointer(&dev, c->hstage, 0) != hipSuccess)
+      dev = c->hstage;
+    c->hstage_dev = (uint8_t *)dev;
     c->hstage_cap = need + need / 4;
   }
-  if (ensure_dev(&c->stage, &c->stage_cap, need + 16))
-    return NULL;
   const achip_frame_t orig = *d;
   achip_stage_gather(&orig, host_px, c->hstage, d);
+  /* a few KB of densely packed samples: the kernel reads them where they are (the DMA's set-up costs more than the
+   * kernel's PCIe reads: 23 -> 6 us of issue time per launch in combine.c) */
+  if (need <= DROPIN_INPLACE_MAX)
+    return c->hstage_dev;
+  if (ensure_dev(&c->stage, &c->stage_cap, need + 16))
+    return NULL;
   if (achip_hip_check((int)hipMemcpyAsync(c->stage, c->hstage, need, hipMemcpyHostToDevice, c->stream),
                       "hipMemcpyAsync(sampled pixels)"))
     return NULL;
@@ -245,7 +257,15 @@ static char *render_with_lut(tls_ctx_t *c, const achip_lut_t *lut, int mode, con
                                           parts > 1 ? c->part_sync : NULL, c->epoch, &uni, c->stream),
                       "render kernel launch"))
     return NULL;
-  if (achip_hip_check((int)hipStreamSynchronize(c->stream), "hipStreamSynchronize"))
+  /* the caller is blocked on this frame: poll while it can have a CPU to itself (a blocking synchronize wakes tens of us
+   * late), sleep in the runtime otherwise or when the frame takes long */
+  hipError_t q = hipErrorNotReady;
+  if (!achip_combine_crowded())
+    for (unsigned polls = 0; polls < DROPIN_POLLS && (q = hipStreamQuery(c->stream)) == hipErrorNotReady; polls++) {
+    }
+  if (q == hipErrorNotReady)
+    q = hipStreamSynchronize(c->stream);
+  if (achip_hip_check((int)q, "hipStreamSynchronize"))
     return NULL;
   const uint32_t len = *len_host;
   if (len >= 0xFFFFFFF0u) {
