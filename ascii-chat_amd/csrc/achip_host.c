@@ -326,13 +326,16 @@ void achip_stage_gather(const achip_frame_t *f, const uint8_t *host_px, uint8_t 
 /* ---- ingest (frame_table.c): what a set of render targets reads of a source frame ---------------------------------- */
 /* the source rows that the targets sample (the sampler's own rule: render_stream.hpp stream_request / render_kernels.hpp
  * sample_frame_raw -- sy = min((y * y_ratio) >> 16, src_h - 1), mirrored under ACHIP_OP_FLIP_Y), ascending, unique.
- * Returns their number, or -1 when a target does not describe an h-row source. */
+ * Targets are a tick's render descriptors: those set up for sources of another height belong to other clients and are
+ * passed over.  Returns the number of rows, or -1 when no target describes an h-row source. */
 int achip_sampled_rows(const achip_frame_t *targets, int n_targets, uint32_t h, uint32_t *rows_out, uint8_t *mark) {
   memset(mark, 0, h);
+  int matched = 0;
   for (int i = 0; i < n_targets; i++) {
     const achip_frame_t *f = &targets[i];
     if (f->comp || (uint32_t)f->src_h != h || f->out_h <= 0)
-      return -1;
+      continue;
+    matched++;
     for (uint32_t y = 0; y < (uint32_t)f->out_h; y++) {
       uint32_t sy = (uint32_t)(((uint64_t)y * f->y_ratio) >> 16);
       if (sy > h - 1u)
@@ -342,6 +345,8 @@ int achip_sampled_rows(const achip_frame_t *targets, int n_targets, uint32_t h, 
       mark[sy] = 1;
     }
   }
+  if (!matched)
+    return -1;
   int n = 0;
   for (uint32_t r = 0; r < h; r++)
     if (mark[r])
@@ -349,13 +354,15 @@ int achip_sampled_rows(const achip_frame_t *targets, int n_targets, uint32_t h, 
   return n;
 }
 
-/* ... and the source columns (sx = min((x * x_ratio) >> 16, src_w - 1), mirrored under ACHIP_OP_FLIP_X); -1 when a target
- * does not describe a w-column source */
-static int sampled_cols(const achip_frame_t *targets, int n_targets, uint32_t w, uint32_t *cols_out, uint8_t *mark) {
+/* ... and the source columns (sx = min((x * x_ratio) >> 16, src_w - 1), mirrored under ACHIP_OP_FLIP_X) of the targets that
+ * describe h-row sources; -1 when one of those is not w columns wide (its columns on this frame are unknown: whole rows) */
+static int sampled_cols(const achip_frame_t *targets, int n_targets, uint32_t w, uint32_t h, uint32_t *cols_out, uint8_t *mark) {
   memset(mark, 0, w);
   for (int i = 0; i < n_targets; i++) {
     const achip_frame_t *f = &targets[i];
-    if (f->comp || (uint32_t)f->src_w != w || f->out_w <= 0)
+    if (f->comp || (uint32_t)f->src_h != h || f->out_h <= 0)
+      continue;
+    if ((uint32_t)f->src_w != w || f->out_w <= 0)
       return -1;
     for (uint32_t x = 0; x < (uint32_t)f->out_w; x++) {
       uint32_t sx = (uint32_t)(((uint64_t)x * f->x_ratio) >> 16);
@@ -397,7 +404,7 @@ int achip_sample_set_build(achip_sample_set_t *S, const achip_frame_t *targets, 
     if (S->n_rows < 0)
       rc = -1;
     else {
-      const int nc = sampled_cols(targets, n_targets, w, S->cols, mark);
+      const int nc = sampled_cols(targets, n_targets, w, h, S->cols, mark);
       S->n_cols = nc > 0 && 2u * (uint32_t)nc <= w ? nc : 0;
     }
   }

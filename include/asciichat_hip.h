@@ -187,13 +187,14 @@ void asciichat_hip_frame_table_destroy(asciichat_hip_frame_table_t *table);
 int asciichat_hip_frame_table_publish(asciichat_hip_frame_table_t *table, int slot, const void *blob, size_t blob_size,
                                       void *stream);
 /* publish moving only the source rows that renders described by `targets` (their out_h, y_ratio, src_h and the FLIP_Y
- * bit of ops; src is ignored) will sample: 24 of 1080 rows for an 80x24 target, 138 KB instead of 6.2 MB over PCIe.  The
+ * bit of ops; src is ignored; targets for sources of another height are passed over, at least one must fit) will sample: 24 of 1080 rows for an 80x24 target, 138 KB instead of 6.2 MB over PCIe.  The
  * buffer keeps the full frame's layout, so descriptors, plans and output bytes are those of a full publish for such
  * renders; rows nobody named are stale. */
 int asciichat_hip_frame_table_publish_rows(asciichat_hip_frame_table_t *table, int slot, const void *blob, size_t blob_size,
                                            const achip_frame_t *targets, int n_targets, void *stream);
 /* ... for a whole tick's clients at once: ONE packed block, ONE DMA, ONE launch instead of one of each per client (slots
- * distinct; every blob a frame that `targets` describe).  Per slot the semantics of publish_rows; when the targets sample
+ * distinct).  `targets` may simply be the tick's render descriptors: a blob is matched with the targets set up for sources
+ * of its height (of its size, for the columns); a blob none of them describes is refused.  Per slot the semantics of publish_rows; when the targets sample
  * at most half of a frame's columns (x_ratio, src_w, out_w and the FLIP_X bit) only the sampled PIXELS are staged -- 5.6 KB
  * of a 1080p frame for an 80x24 target -- and pixels nobody named are stale like rows nobody named. */
 int asciichat_hip_frame_table_publish_rows_batch(asciichat_hip_frame_table_t *table, const int *slots, const void *const *blobs,

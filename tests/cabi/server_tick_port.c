@@ -160,6 +160,44 @@ static void run_tick(int force_variant) {
   printf("tick (geometry %d, fused CRC %s): %d clients, frames == drop-in renders, headers and both checksums verified on the host\n",
          asciichat_hip_plan_get_variant(plan), asciichat_hip_plan_has_fused_crc(plan) ? "yes" : "no", CLIENTS);
 
+  /* ---- the next tick through the whole-tick forms: every client's SAMPLED pixels in one packed
+   * block / one DMA / one launch (the targets are simply the tick's render descriptors: every blob is matched with the
+   * descriptors of its own geometry), every descriptor's source pointer in one call, and the frames delivered at their
+   * exact lengths into mapped host memory.  Same blobs, so the frames must equal tick one's. */
+  int slots[CLIENTS];
+  const void *blobs[CLIENTS];
+  size_t blob_sizes[CLIENTS];
+  for (int c = 0; c < CLIENTS; c++) {
+    slots[c] = c;
+    blobs[c] = blob[c];
+    blob_sizes[c] = 8 + (size_t)src_w[c] * (size_t)src_h[c] * 3u;
+  }
+  CHECK(asciichat_hip_frame_table_publish_rows_batch(table, slots, blobs, blob_sizes, CLIENTS, frames, CLIENTS, upload) == 0,
+        "publish_rows_batch");
+  CHECK(asciichat_hip_frame_table_latest_frames(table, slots, CLIENTS, render, frames) == CLIENTS, "latest_frames");
+  CHECK(asciichat_hip_plan_update(plan, frames, render) == 0, "plan_update");
+  const size_t cap = stride * CLIENTS, tab = ((size_t)(CLIENTS + 1) * 8u + (size_t)CLIENTS * 4u + 15u) & ~(size_t)15;
+  void *host = NULL, *alias = NULL;
+  CHECK(asciichat_hip_host_alloc(tab + cap, &host, &alias) == 0, "host_alloc");
+  uint64_t *off_h = (uint64_t *)host;
+  uint32_t *plen_h = (uint32_t *)((uint8_t *)host + 8u * (CLIENTS + 1));
+  CHECK(asciichat_hip_plan_render_packed(plan, slab, stride, len, (uint8_t *)alias + tab, cap, (uint64_t *)alias,
+                                         (uint32_t *)((uint8_t *)alias + 8u * (CLIENTS + 1)), render) == 0,
+        "render_packed");
+  CHECK(asciichat_hip_streams_wait(streams, 1) == 0, "streams_wait");
+  size_t packed_bytes = 0;
+  for (int c = 0; c < CLIENTS; c++) {
+    CHECK(plen_h[c] == len_h[c] && (off_h[c] & 15u) == 0 && off_h[c] + plen_h[c] <= cap, "client %d: packed length %u at %llu", c,
+          plen_h[c], (unsigned long long)off_h[c]);
+    CHECK(memcmp((uint8_t *)host + tab + off_h[c], slab_h + (size_t)c * stride, len_h[c]) == 0,
+          "client %d: frame of the sampled-pixel tick == frame of the whole-blob tick", c);
+    packed_bytes = (size_t)off_h[c] + plen_h[c];
+  }
+  CHECK(off_h[CLIENTS] >= packed_bytes && off_h[CLIENTS] <= cap, "packed total");
+  printf("tick two (sampled pixels in one batch, latest_frames, packed output in mapped host memory): %d frames identical, %zu of %zu "
+         "slab bytes crossed PCIe\n", CLIENTS, (size_t)off_h[CLIENTS], cap);
+  asciichat_hip_host_free(host);
+
   asciichat_hip_plan_destroy(plan);
   asciichat_hip_frame_table_destroy(table);
   (void)hipFree(slab), (void)hipFree(hdr), (void)hipFree(len), (void)hipFree(crc), (void)hipFree(pkt), (void)hipFree(dims);
