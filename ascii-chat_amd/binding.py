@@ -72,7 +72,12 @@ def lib():
         pass
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc, gfx950) first")
-    L = C.CDLL(LIB_PATH)
+    _lib = _bind(C.CDLL(LIB_PATH))
+    return _lib
+
+
+def _bind(L):
+    """argument and result types of every entry point the classes below call"""
     vp, ci, ss, sz = C.c_void_p, C.c_int, C.c_ssize_t, C.c_size_t
     L.asciichat_hip_device_count.restype = ci
     L.asciichat_hip_last_error.restype = C.c_char_p
@@ -310,7 +315,6 @@ def lib():
     L.buffer_pool_cleanup_global.restype = None
     L.free = C.CDLL(None).free
     L.free.argtypes = [vp]
-    _lib = L
     return L
 
 

@@ -262,12 +262,14 @@ int achip_frame_setup(achip_frame_t *f, const uint8_t *src_dev, int src_w, int s
 static int g_stage_columns = -1; /* ASCIICHAT_HIP_STAGE_COLUMNS=0: sampled rows only (diagnostics / A-B) */
 
 size_t achip_stage_extent(const achip_frame_t *f, int *w, int *h) {
-  if (g_stage_columns < 0) {
+  int columns = __atomic_load_n(&g_stage_columns, __ATOMIC_RELAXED);
+  if (columns < 0) { /* idempotent: every thread that gets here stores the same value */
     const char *e = getenv("ASCIICHAT_HIP_STAGE_COLUMNS");
-    g_stage_columns = !(e && e[0] == '0');
+    columns = !(e && e[0] == '0');
+    __atomic_store_n(&g_stage_columns, columns, __ATOMIC_RELAXED);
   }
   const int cy = f->out_h < f->src_h;
-  const int cx = g_stage_columns && f->out_w > 0 && f->out_w <= 3840 && 2 * (long)f->out_w <= (long)f->src_w;
+  const int cx = columns && f->out_w > 0 && f->out_w <= 3840 && 2 * (long)f->out_w <= (long)f->src_w;
   *w = cx ? f->out_w : f->src_w;
   *h = cy ? f->out_h : f->src_h;
   return cx || cy ? (size_t)*w * (size_t)*h * 3u : 0;

@@ -720,7 +720,7 @@ char *achip_combine_render(int mode, const char *palette, const achip_lut_t *lut
       const int seen = LOAD(cb->launch_seq);
       if (LOAD(cb->inflight) < g_cb_inflight) {
         pthread_mutex_lock(&cb->mu);
-        if (cb->inflight < g_cb_inflight)
+        if (LOAD(cb->inflight) < g_cb_inflight) /* (decremented outside the mutex: an atomic read) */
           break;
         pthread_mutex_unlock(&cb->mu);
       }

@@ -57,9 +57,12 @@ int asciichat_hip_device_count(void) {
 }
 
 int achip_require_device(void) {
-  static int cached = -1; /* benign race: idempotent */
-  if (cached < 0)
+  static int cached_count = -1; /* idempotent: whoever gets there first stores the same value */
+  int cached = __atomic_load_n(&cached_count, __ATOMIC_RELAXED);
+  if (cached < 0) {
     cached = asciichat_hip_device_count();
+    __atomic_store_n(&cached_count, cached, __ATOMIC_RELAXED);
+  }
   if (cached <= 0)
     return achip_fail(ASCIICHAT_HIP_ERR_NO_DEVICE,
                       "no HIP device visible: this library has no CPU fallback (built for gfx950)");

@@ -1,0 +1,127 @@
+/*
+ * mock_launch.cpp -- hip_launch.hip's entry points on the CPU fiber emulator.  TESTS ONLY (see mock_hip.c).
+ * Every launch runs the product kernel (tests/hipemu/emu_driver.cpp includes the unmodified kernel headers) at the call,
+ * one launch at a time (the emulator's launch state is global: a mutex), so "streams" are trivially ordered.
+ */
+#include "../hipemu/emu_driver.cpp"
+
+#include <mutex>
+
+#include "hip_launch.h"
+
+static std::mutex g_emu_mu;
+enum { MOCK_OK = 0, MOCK_INVALID = 1 /* hipErrorInvalidValue */, MOCK_UNSUPPORTED = 801 /* hipErrorNotSupported */ };
+
+extern "C" int achip_launch_render(int mode, int variant, int has_composite, const achip_frame_t *frames_dev, int n_frames,
+                                   const achip_lut_t *lut_dev, uint8_t *out, uint64_t out_stride, uint32_t *out_len,
+                                   unsigned long long *phase_cycles, int parts, int rows_per_part, unsigned long long *part_sync,
+                                   uint32_t epoch, const achip_uniform_t *uniform, void *stream) {
+  (void)has_composite, (void)phase_cycles, (void)stream;
+  if (n_frames <= 0)
+    return MOCK_OK;
+  std::lock_guard<std::mutex> lock(g_emu_mu);
+  const int was = emu_set_uniform(uniform && uniform->enabled ? 1 : 0);
+  emu_set_parts(parts > 1 ? parts : 1, rows_per_part, part_sync, epoch);
+  const int rc = emu_render_batch(mode, variant, frames_dev, n_frames, lut_dev, out, out_stride, out_len);
+  emu_set_parts(1, 0, nullptr, 1);
+  (void)emu_set_uniform(was);
+  return rc == 0 ? MOCK_OK : MOCK_INVALID;
+}
+
+extern "C" int achip_launch_resize(const uint8_t *src, int sw, int sh, uint8_t *dst, int dw, int dh, void *stream) {
+  (void)stream;
+  std::lock_guard<std::mutex> lock(g_emu_mu);
+  emu_resize_nn(src, sw, sh, dst, dw, dh, achip_nn_ratio(sw, dw), achip_nn_ratio(sh, dh));
+  return MOCK_OK;
+}
+
+extern "C" int achip_launch_scatter_rows(const uint8_t *staged, uint32_t n_rows, uint32_t row_bytes, uint8_t *frame,
+                                         uint64_t frame_pitch, void *stream) {
+  (void)stream;
+  if (n_rows == 0u)
+    return MOCK_OK;
+  std::lock_guard<std::mutex> lock(g_emu_mu);
+  hipemu::launch(dim3(row_bytes > 4096u ? 2u : 1u, n_rows), dim3(256), 0,
+                 [&] { achip::scatter_rows_kernel(staged, n_rows, row_bytes, frame, frame_pitch); });
+  return MOCK_OK;
+}
+
+extern "C" int achip_launch_scatter_rows_batch(const uint8_t *staged, uint32_t n_clients, uint32_t max_rows,
+                                               uint32_t max_row_bytes, void *stream) {
+  (void)stream;
+  if (n_clients == 0u || max_rows == 0u)
+    return MOCK_OK;
+  std::lock_guard<std::mutex> lock(g_emu_mu);
+  emu_scatter_rows_batch(staged, n_clients, max_rows, max_row_bytes > 4096u ? 2 : 1);
+  return MOCK_OK;
+}
+
+extern "C" int achip_launch_pack(const uint8_t *slab, uint64_t stride, const uint32_t *len, int n, uint8_t *dst, uint64_t cap,
+                                 uint64_t *off_out, uint32_t *len_out, void *stream) {
+  (void)stream;
+  if (n <= 0)
+    return MOCK_OK;
+  std::lock_guard<std::mutex> lock(g_emu_mu);
+  emu_pack(slab, stride, len, n, dst, cap, off_out, len_out, 2);
+  return MOCK_OK;
+}
+
+/* not modelled: the wire stage, image-space passes, composites materialised on the device */
+extern "C" int achip_launch_render_crc(int, int, int, const achip_frame_t *, int, const achip_lut_t *, uint8_t *, uint64_t, uint32_t *,
+                                       const achip_wire_t *, const achip_uniform_t *, unsigned long long *, void *) {
+  return MOCK_UNSUPPORTED;
+}
+extern "C" int achip_launch_packets_from_crc(const uint32_t *, const uint32_t *, const uint32_t *, int, uint8_t *, uint32_t *, void *) {
+  return MOCK_UNSUPPORTED;
+}
+extern "C" int achip_launch_resize_batch(const achip_resize_batch_t *, void *) { return MOCK_UNSUPPORTED; }
+extern "C" int achip_launch_comp_poke(achip_composite_t *, const achip_comp_poke_t *, void *) { return MOCK_UNSUPPORTED; }
+extern "C" int achip_launch_composite(const achip_composite_t *, int, int, uint8_t *, void *) { return MOCK_UNSUPPORTED; }
+extern "C" int achip_launch_tint(uint8_t *, int, int, int, uint32_t, void *) { return MOCK_UNSUPPORTED; }
+extern "C" int achip_launch_flip(const uint8_t *, uint8_t *, int, int, int, int, uint32_t, void *) { return MOCK_UNSUPPORTED; }
+extern "C" int achip_launch_crc32c(const uint8_t *, uint64_t, const uint32_t *, uint32_t, uint32_t, int, uint32_t *, const uint32_t *,
+                                   uint32_t *, uint8_t *, uint32_t *, void *) {
+  return MOCK_UNSUPPORTED;
+}
+extern "C" int achip_crc_parts(uint32_t) { return 1; }
+extern "C" int achip_variant_has_crc(int) { return 0; } /* plans fall back to the stand-alone wire stage, which reports "unsupported" */
+extern "C" int achip_variant_crc_pays(int) { return 0; }
+
+/* geometry facts of hip_launch.hip, from the same table (render_variants.h) */
+extern "C" int achip_variant_block(int variant) {
+  switch (variant) {
+#define X(id, W, C)                                                                                                    \
+  case id:                                                                                                             \
+    return 64 * W;
+    ACHIP_STREAM_VARIANTS(X)
+    ACHIP_ROWS_VARIANTS(X)
+#undef X
+#define X(id, B, C, R)                                                                                                 \
+  case id:                                                                                                             \
+    return B;
+    ACHIP_VARIANTS(X)
+#undef X
+  }
+  return -1;
+}
+extern "C" int achip_variant_cap(int variant) {
+  switch (variant) {
+#define X(id, W, C)                                                                                                    \
+  case id:                                                                                                             \
+    return ACHIP_STREAM_MAXBLK * 64 * C;
+    ACHIP_STREAM_VARIANTS(X)
+#undef X
+#define X(id, W, C)                                                                                                    \
+  case id:                                                                                                             \
+    return 64 * C;
+    ACHIP_ROWS_VARIANTS(X)
+#undef X
+#define X(id, B, C, R)                                                                                                 \
+  case id:                                                                                                             \
+    return C;
+    ACHIP_VARIANTS(X)
+#undef X
+  }
+  return -1;
+}
+extern "C" int achip_variant_lds_bytes(int, int) { return 0; }

@@ -1,0 +1,165 @@
+"""The product's host C on a mock HIP runtime (tests/mockgpu.py, tests/mockhip): device memory is host memory and every
+launch runs the product kernels under the CPU fiber emulator.  CPU only.  Covers what otherwise needs a GPU box: the drop-in
+entry points end to end (staging of the sampled pixels, direct path, the flat-combining layer with callers that poll and
+callers that sleep), plans, and the frame table's publish forms -- all against the oracle, byte for byte."""
+import ctypes as C
+import os
+import struct
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import mockgpu  # noqa: E402
+import orc  # noqa: E402
+
+PAL = orc.PALETTE_STANDARD.encode()
+
+
+@pytest.fixture(scope="module")
+def mock():
+    pkg = mockgpu.package()
+    assert pkg.lib().asciichat_hip_device_count() == 1
+    return pkg
+
+
+def as_image(pkg, arr):
+    arr = np.ascontiguousarray(arr, dtype=np.uint8)
+    im = pkg.Image(arr.shape[1], arr.shape[0], arr.ctypes.data, 0)
+    im._keep = arr
+    return im
+
+
+def caps(pkg, color_level, render_mode, wants_padding=False):
+    c = pkg.TermCaps()
+    c.color_level = color_level
+    c.render_mode = render_mode
+    c.wants_padding = wants_padding
+    c.utf8_support = True
+    return c
+
+
+def test_dropin_direct_path_stages_sampled_pixels(mock):
+    """one caller at a time: every colour level x render mode, downscales (sampled rows AND columns staged), a mild
+    downscale (rows only), an upscale (the whole image), aspect + padding"""
+    L = mock.lib()
+    for (w, h, W, H) in ((333, 201, 40, 12), (333, 201, 200, 40), (40, 30, 64, 20), (160, 120, 40, 12)):
+        img = orc.frame_hash_noise(w, h, w + H)
+        im = as_image(mock, img)
+        for cl, rm in ((0, 0), (1, 0), (2, 0), (3, 0), (3, 2), (2, 2), (3, 1)):
+            for aspect in (False, True):
+                c = caps(mock, cl, rm, aspect)
+                got = mock.take_string(L.ascii_convert_with_capabilities(C.byref(im), W, H, C.byref(c), aspect, False, PAL))
+                assert got == orc.convert_with_caps(img, W, H, cl, rm, aspect, aspect, False), (w, h, W, H, cl, rm, aspect)
+
+
+@pytest.mark.parametrize("threads", [4, 12, 24])
+def test_dropin_calls_through_the_combiner(mock, threads):
+    """combine.c on the CPU: `threads` concurrent callers with different images, sizes, modes and palettes, coalescing
+    forced -- fewer callers than CPUs (they poll), then more (they sleep on futexes and are woken as a tree; the launcher
+    takes the blocking wait) -- every result against the oracle, over several rounds of generations"""
+    L = mock.lib()
+    L.asciichat_hip_set_coalesce_min_callers.restype = C.c_int
+    L.asciichat_hip_set_coalesce_min_callers.argtypes = [C.c_int]
+    jobs = []
+    for k in range(threads):
+        w, h = [(160, 120), (97, 61), (320, 200), (64, 48)][k % 4]
+        img = orc.frame_hash_noise(w, h, 500 + k) if k % 3 else orc.frame_bars(w, h, k)
+        cl, rm = [(3, 0), (2, 0), (3, 2), (0, 0), (1, 0), (2, 2)][k % 6]
+        W, H = [(40, 12), (33, 17), (20, 10)][k % 3]
+        pal = [PAL, b"ab", orc.PALETTE_BLOCKS.encode()][k % 3] if cl else PAL
+        asp = bool(k & 1)
+        jobs.append((img, cl, rm, W, H, pal, asp, orc.convert_with_caps(img, W, H, cl, rm, asp, asp, False, pal.decode())))
+    before = L.asciichat_hip_set_coalesce_min_callers(1)
+    errors = []
+
+    def worker(k):
+        img, cl, rm, W, H, pal, asp, exp = jobs[k]
+        im = as_image(mock, img)
+        c = caps(mock, cl, rm, asp)
+        for it in range(6):
+            got = mock.take_string(L.ascii_convert_with_capabilities(C.byref(im), W, H, C.byref(c), asp, False, pal))
+            if got != exp:
+                errors.append((k, it, None if got is None else len(got), len(exp)))
+                return
+
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(threads)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    L.asciichat_hip_set_coalesce_min_callers(before)
+    assert not errors, errors[:4]
+
+
+def test_plans_and_packed_output_on_the_mock(mock):
+    """plan_create / update / render / render_packed through the emulator: mixed geometries in one batch, exact-length
+    frames behind 16-byte aligned offsets"""
+    imgs = [orc.frame_hash_noise(120 + 8 * i, 90 + 4 * i, 40 + i) for i in range(5)]
+    keep = [np.ascontiguousarray(im) for im in imgs]
+    frames = [mock.frame_setup(k.ctypes.data, k.shape[1], k.shape[0], 40, 12, 0, False, False, False) for k in keep]
+    plan = mock.Plan(1, orc.PALETTE_STANDARD, frames)
+    n, stride = len(frames), plan.stride
+    slab = np.zeros(n * stride, dtype=np.uint8)
+    ln = np.zeros(n, dtype=np.uint32)
+    dst = np.zeros(n * stride, dtype=np.uint8)
+    off = np.zeros(n + 1, dtype=np.uint64)
+    ln2 = np.zeros(n, dtype=np.uint32)
+    plan.render_packed(slab.ctypes.data, stride, ln.ctypes.data, dst.ctypes.data, dst.size, off.ctypes.data, ln2.ctypes.data)
+    for i in range(n):
+        exp = orc.convert_with_caps(imgs[i], 40, 12, 3, 0, False, False, False)
+        assert slab[i * stride:i * stride + int(ln[i])].tobytes() == exp
+        assert int(off[i]) % 16 == 0 and dst[int(off[i]):int(off[i]) + int(ln2[i])].tobytes() == exp
+    plan.close()
+
+
+def test_frame_table_publish_forms_on_the_mock(mock):
+    """frame_table.c on the CPU: whole blobs, sampled rows, a tick's sampled pixels in one batch (the targets are the render
+    descriptors of clients of three geometries), single-slot and batch publishes alternating on the same slots,
+    latest_frames, more batches than the event ring holds -- renders against the oracle"""
+    geos = [(160, 120), (97, 61), (160, 120), (64, 48), (160, 120)]
+    n = len(geos)
+    table = mock.FrameTable(n)
+    slots = (C.c_int * n)(*range(n))
+    frames = (mock.Frame * n)(*[mock.frame_setup(None, w, h, 40, 12, 0, False, False, False) for (w, h) in geos])
+    for step in range(12):
+        imgs = [orc.frame_hash_noise(w, h, 1000 + 31 * step + i) for i, (w, h) in enumerate(geos)]
+        bufs = [C.create_string_buffer(struct.pack(">II", im.shape[1], im.shape[0]) + np.ascontiguousarray(im).tobytes(), 8 + im.size)
+                for im in imgs]
+        if step % 3 == 0:
+            for i in range(n):
+                table.publish(i, bufs[i].raw[:8 + imgs[i].size])
+        elif step % 3 == 1:
+            for i in range(n):
+                table.publish_rows(i, (C.addressof(bufs[i]), len(bufs[i])), [frames[i]])
+        else:
+            table.publish_rows_batch(slots, [(C.addressof(b), len(b)) for b in bufs], frames)
+        assert table.latest_frames(slots, frames) == n
+        plan = mock.Plan(1, orc.PALETTE_STANDARD, list(frames))
+        out = np.zeros(n * plan.stride, dtype=np.uint8)
+        ln = np.zeros(n, dtype=np.uint32)
+        plan.render(out.ctypes.data, plan.stride, ln.ctypes.data)
+        for i in range(n):
+            exp = orc.convert_with_caps(imgs[i], 40, 12, 3, 0, False, False, False)
+            assert out[i * plan.stride:i * plan.stride + int(ln[i])].tobytes() == exp, (step, i)
+        plan.close()
+    with pytest.raises(RuntimeError):  # nobody's descriptor describes a 50x50 frame
+        b = C.create_string_buffer(struct.pack(">II", 50, 50) + bytes(50 * 50 * 3), 8 + 7500)
+        table.publish_rows_batch((C.c_int * 1)(0), [(C.addressof(b), len(b))], frames)
+    table.close()
+
+
+@pytest.mark.parametrize("san", ["thread", "address,undefined"])
+def test_combiner_under_sanitizers(san):
+    """tests/mockhip/dropin_threads_mock.c: the host C compiled with the sanitizer, an arithmetic stand-in for the kernels (no
+    fibers), 6 / 24 / 48 threads x 300 self-checking calls with coalescing forced: callers that poll, callers that sleep"""
+    exe = mockgpu.build_thread_harness(san)
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1", ASAN_OPTIONS="detect_leaks=0")
+    for budget, nthreads in (("1000", "6"), ("2", "24"), ("2", "48")):
+        env["ASCIICHAT_HIP_CPU_BUDGET"] = budget
+        p = subprocess.run([exe, nthreads, "300"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert p.returncode == 0, (san, budget, p.stdout.decode()[-400:], p.stderr.decode()[-3000:])
+        assert b"ok:" in p.stdout
