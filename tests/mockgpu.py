@@ -46,11 +46,11 @@ def build_library():
     return so
 
 
-def build_thread_harness(sanitizer=None):
-    """-> path of the plain-C harness (tests/mockhip/dropin_threads_mock.c) linked with the host C, the mock runtime and
-    the arithmetic stand-in for the kernels (mock_launch_simple.c: no fibers, so ThreadSanitizer can follow everything)"""
+def build_thread_harness(sanitizer=None, harness="dropin_threads_mock"):
+    """-> path of a plain-C harness (tests/mockhip/<harness>.c) linked with the host C, the mock runtime and the arithmetic
+    stand-in for the kernels (mock_launch_simple.c: no fibers, so ThreadSanitizer can follow everything)"""
     tag = sanitizer or "plain"
-    exe = os.path.join(BUILD, f"dropin_threads_mock_{tag}")
+    exe = os.path.join(BUILD, f"{harness}_{tag.replace(',', '_')}")
     if _newer(exe, _deps()):
         return exe
     os.makedirs(BUILD, exist_ok=True)
@@ -58,7 +58,7 @@ def build_thread_harness(sanitizer=None):
     if sanitizer:
         flags += ["-fsanitize=" + sanitizer, "-fno-omit-frame-pointer", "-Wno-tsan"]
     srcs = [os.path.join(CSRC, f) for f in HOST_C] + [os.path.join(MOCK, f) for f in
-                                                        ("mock_hip.c", "mock_launch_simple.c", "dropin_threads_mock.c")]
+                                                        ("mock_hip.c", "mock_launch_simple.c", harness + ".c")]
     subprocess.check_call(["gcc", *flags, *srcs, "-o", exe, "-lm", "-ldl"])
     return exe
 

@@ -105,13 +105,37 @@ int achip_launch_pack(const uint8_t *slab, uint64_t stride, const uint32_t *len,
   (void)slab, (void)stride, (void)len, (void)n, (void)dst, (void)cap, (void)off, (void)len_out, (void)s;
   return MOCK_UNSUPPORTED;
 }
+/* the row / pixel scatter of ingest as plain loops over the same staged layout (stream_kernels.hpp) */
 int achip_launch_scatter_rows(const uint8_t *st, uint32_t n_rows, uint32_t row_bytes, uint8_t *frame, uint64_t pitch, void *s) {
-  (void)st, (void)n_rows, (void)row_bytes, (void)frame, (void)pitch, (void)s;
-  return MOCK_UNSUPPORTED;
+  (void)s;
+  const uint32_t table = (n_rows * 4u + 15u) & ~15u;
+  for (uint32_t r = 0; r < n_rows; r++)
+    memcpy(frame + (uint64_t)((const uint32_t *)st)[r] * pitch, st + table + (uint64_t)r * row_bytes, row_bytes);
+  return MOCK_OK;
 }
 int achip_launch_scatter_rows_batch(const uint8_t *st, uint32_t n, uint32_t mr, uint32_t mb, void *s) {
-  (void)st, (void)n, (void)mr, (void)mb, (void)s;
-  return MOCK_UNSUPPORTED;
+  (void)mr, (void)mb, (void)s;
+  for (uint32_t c = 0; c < n; c++) {
+    struct {
+      uint64_t frame;
+      uint32_t off, n_rows, row_bytes, n_cols, pad[2];
+    } cl;
+    memcpy(&cl, st + 32u * c, 32);
+    const uint8_t *blk = st + cl.off;
+    const uint32_t tr = (cl.n_rows * 4u + 15u) & ~15u, tc = (cl.n_cols * 4u + 15u) & ~15u;
+    const uint32_t *rows = (const uint32_t *)blk, *cols = (const uint32_t *)(blk + tr);
+    for (uint32_t r = 0; r < cl.n_rows; r++) {
+      uint8_t *dst = (uint8_t *)(uintptr_t)cl.frame + (uint64_t)rows[r] * cl.row_bytes;
+      if (!cl.n_cols) {
+        memcpy(dst, blk + tr + (uint64_t)r * cl.row_bytes, cl.row_bytes);
+        continue;
+      }
+      const uint8_t *src = blk + tr + tc + (uint64_t)r * cl.n_cols * 3u;
+      for (uint32_t i = 0; i < cl.n_cols; i++)
+        memcpy(dst + (uint64_t)cols[i] * 3u, src + 3u * i, 3);
+    }
+  }
+  return MOCK_OK;
 }
 int achip_launch_crc32c(const uint8_t *base, uint64_t stride, const uint32_t *len, uint32_t fixed, uint32_t max, int n, uint32_t *partial,
                         const uint32_t *dims, uint32_t *crc, uint8_t *hdr, uint32_t *pkt, void *s) {

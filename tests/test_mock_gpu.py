@@ -163,3 +163,16 @@ def test_combiner_under_sanitizers(san):
         p = subprocess.run([exe, nthreads, "300"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
         assert p.returncode == 0, (san, budget, p.stdout.decode()[-400:], p.stderr.decode()[-3000:])
         assert b"ok:" in p.stdout
+
+
+@pytest.mark.parametrize("san", ["thread", "address,undefined"])
+def test_frame_table_locking_under_sanitizers(san):
+    """tests/mockhip/frame_table_threads_mock.c: four publishers (whole blobs, sampled rows, whole-tick batches over
+    overlapping slot sets named in descending order) against four readers (latest, latest_frames) -- frame_table.c's own
+    synchronisation (slot locks in ascending order under the batch lock, the ring of batch events, reader bookkeeping) under the
+    sanitizer; afterwards every slot renders to the line of a published image"""
+    exe = mockgpu.build_thread_harness(san, "frame_table_threads_mock")
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1", ASAN_OPTIONS="detect_leaks=0")
+    p = subprocess.run([exe, "2"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, (san, p.stdout.decode()[-400:], p.stderr.decode()[-3000:])
+    assert b"ok:" in p.stdout
