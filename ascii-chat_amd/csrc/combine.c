@@ -30,11 +30,11 @@
  * that polled froze the whole process (CFS throttling) from 64 threads on.
  *
  * Measured (scripts/dropin_threads.c, 1080p -> 80x24 truecolor, one MI355X box with that 16-CPU quota;
- * profiles/r03_dropin_threads.txt), calls/s pageable / pooled images: 39 k / 41 k from one thread, 120 k / 121 k from 4
+ * profiles/r03_dropin_threads.txt), calls/s pageable / pooled images: 37 k / 39 k from one thread, 127 k / 118 k from 4
  * (each call its own launch on the thread's stream: below ASCIICHAT_HIP_COALESCE = 6 calls in flight that is faster),
- * 320 k / 281 k from 16, 451 k / 412 k from 32, 545 k / 527 k from 64, 574 k / 552 k from 128 with the process confined
+ * 378 k / 444 k from 16, 505 k / 476 k from 32, 483 k / 509 k from 64, 559 k / 517 k from 128 with the process confined
  * to 16 CPUs (taskset); free to roam over all 256 the kernel's per-CPU quota slices run dry and throughput falls again
- * past 32 threads (409 k, 348 k, 143 k) -- ASCIICHAT_HIP_CONFINE=1 applies that confinement to the calling threads.
+ * past 32-64 threads (407 k, 461 k, 169 k) -- ASCIICHAT_HIP_CONFINE=1 applies that confinement to the calling threads.
  * Round 2: 105 k / 161 k at the peak, 72 k / 64 k at 64 threads.
  */
 #define _GNU_SOURCE /* CPU_COUNT, sched_getaffinity */
@@ -193,7 +193,7 @@ static void cpu_budget_init(void) {
 /* ASCIICHAT_HIP_CONFINE=1: a calling thread is confined (once, on its first call) to the first g_cpu_budget CPUs of its
  * affinity mask when the cgroup quota is smaller than the mask.  CFS hands the quota out in per-CPU slices; a hundred
  * threads that sleep and wake all over a 256-CPU box strand it on CPUs that have nothing to run, and the process is
- * throttled at a fraction of its quota (128 callers: 143 k calls/s roaming, 574 k confined to 16 CPUs).  Opt-in: a
+ * throttled at a fraction of its quota (128 callers: 169 k calls/s roaming, 559 k confined to 16 CPUs).  Opt-in: a
  * library does not rearrange its host's threads unasked; `taskset` on the server does the same from outside. */
 static void cb_confine_thread(void) {
   static __thread int done;
