@@ -215,4 +215,21 @@ __global__ void __launch_bounds__(64)
   }
 }
 
+/* headers + packet CRCs from frame CRCs that are already known (the fused render): one thread per frame */
+__global__ void __launch_bounds__(256)
+    crc_packets_kernel(const uint32_t *__restrict__ len, const uint32_t *__restrict__ crc_in, const uint32_t *__restrict__ dims,
+                       int n, uint8_t *__restrict__ hdr_out, uint32_t *__restrict__ pkt_crc_out) {
+  const int i = (int)(blockIdx.x * 256u + threadIdx.x);
+  if (i >= n)
+    return;
+  uint32_t L = len[i];
+  const bool bad = L >= 0xFFFFFFF0u;
+  if (bad)
+    L = 0;
+  const uint32_t w = dims && !bad ? dims[2 * i] : 0u, h = dims && !bad ? dims[2 * i + 1] : 0u;
+  const uint32_t crc = bad ? 0u : crc_in[i];
+  /* ~crc is the CRC register after the frame (from 0xFFFFFFFF): what crc32c_frame_kernel hands to crc_emit_packet */
+  crc_emit_packet(crc_header_state16(w, h, L), crc_x8_pow_len(L), ~crc, crc, w, h, L, bad, i, nullptr, hdr_out, pkt_crc_out);
+}
+
 } // namespace achip

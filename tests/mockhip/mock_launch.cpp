@@ -66,26 +66,51 @@ extern "C" int achip_launch_pack(const uint8_t *slab, uint64_t stride, const uin
   return MOCK_OK;
 }
 
-/* not modelled: the wire stage, image-space passes, composites materialised on the device */
-extern "C" int achip_launch_render_crc(int, int, int, const achip_frame_t *, int, const achip_lut_t *, uint8_t *, uint64_t, uint32_t *,
-                                       const achip_wire_t *, const achip_uniform_t *, unsigned long long *, void *) {
-  return MOCK_UNSUPPORTED;
+/* the wire stage: stand-alone CRC + headers, headers from known CRCs, and the render with the CRC riding its drain */
+extern "C" int achip_crc_parts(uint32_t max_len) { return max_len <= 32u * 4096u ? 1 : (int)(((uint64_t)max_len + 65535u) / 65536u); }
+extern "C" int achip_launch_crc32c(const uint8_t *base, uint64_t stride, const uint32_t *len, uint32_t fixed_len, uint32_t max_len,
+                                   int n, uint32_t *partial, const uint32_t *dims, uint32_t *crc_out, uint8_t *hdr_out,
+                                   uint32_t *pkt_out, void *stream) {
+  (void)partial, (void)stream;
+  if (n <= 0)
+    return MOCK_OK;
+  std::lock_guard<std::mutex> lock(g_emu_mu);
+  emu_crc32c(base, stride, len, fixed_len, max_len, n, 0, 0, dims, crc_out, hdr_out, pkt_out);
+  return MOCK_OK;
 }
-extern "C" int achip_launch_packets_from_crc(const uint32_t *, const uint32_t *, const uint32_t *, int, uint8_t *, uint32_t *, void *) {
-  return MOCK_UNSUPPORTED;
+extern "C" int achip_launch_packets_from_crc(const uint32_t *len, const uint32_t *crc, const uint32_t *dims, int n, uint8_t *hdr_out,
+                                             uint32_t *pkt_out, void *stream) {
+  (void)stream;
+  if (n <= 0)
+    return MOCK_OK;
+  std::lock_guard<std::mutex> lock(g_emu_mu);
+  hipemu::launch(dim3((unsigned)(n + 255) / 256u), dim3(256), 0,
+                 [&] { achip::crc_packets_kernel(len, crc, dims, n, hdr_out, pkt_out); });
+  return MOCK_OK;
 }
+extern "C" int achip_variant_has_crc(int variant) { return variant == 16 || variant == 17 || ACHIP_IS_ROWS_VARIANT(variant); }
+extern "C" int achip_variant_crc_pays(int variant) { return variant == 16 || variant == 17; }
+extern "C" int achip_launch_render_crc(int mode, int variant, int has_composite, const achip_frame_t *frames, int n,
+                                       const achip_lut_t *lut, uint8_t *out, uint64_t stride, uint32_t *out_len,
+                                       const achip_wire_t *wire, const achip_uniform_t *uniform, unsigned long long *prof, void *stream) {
+  (void)has_composite, (void)uniform, (void)prof, (void)stream;
+  if (n <= 0)
+    return MOCK_OK;
+  if (!wire || !wire->crc)
+    return MOCK_INVALID;
+  std::lock_guard<std::mutex> lock(g_emu_mu);
+  const int rc = ACHIP_IS_ROWS_VARIANT(variant)
+                     ? emu_render_rows_crc(mode, variant, frames, n, lut, out, stride, out_len, wire->crc, wire->dims, wire->hdr, wire->pkt_crc)
+                     : emu_render_stream_crc(mode, variant, frames, n, lut, out, stride, out_len, wire->crc, wire->dims, wire->hdr, wire->pkt_crc);
+  return rc == 0 ? MOCK_OK : MOCK_INVALID;
+}
+
+/* not modelled: image-space passes, composites materialised on the device */
 extern "C" int achip_launch_resize_batch(const achip_resize_batch_t *, void *) { return MOCK_UNSUPPORTED; }
 extern "C" int achip_launch_comp_poke(achip_composite_t *, const achip_comp_poke_t *, void *) { return MOCK_UNSUPPORTED; }
 extern "C" int achip_launch_composite(const achip_composite_t *, int, int, uint8_t *, void *) { return MOCK_UNSUPPORTED; }
 extern "C" int achip_launch_tint(uint8_t *, int, int, int, uint32_t, void *) { return MOCK_UNSUPPORTED; }
 extern "C" int achip_launch_flip(const uint8_t *, uint8_t *, int, int, int, int, uint32_t, void *) { return MOCK_UNSUPPORTED; }
-extern "C" int achip_launch_crc32c(const uint8_t *, uint64_t, const uint32_t *, uint32_t, uint32_t, int, uint32_t *, const uint32_t *,
-                                   uint32_t *, uint8_t *, uint32_t *, void *) {
-  return MOCK_UNSUPPORTED;
-}
-extern "C" int achip_crc_parts(uint32_t) { return 1; }
-extern "C" int achip_variant_has_crc(int) { return 0; } /* plans fall back to the stand-alone wire stage, which reports "unsupported" */
-extern "C" int achip_variant_crc_pays(int) { return 0; }
 
 /* geometry facts of hip_launch.hip, from the same table (render_variants.h) */
 extern "C" int achip_variant_block(int variant) {

@@ -116,6 +116,41 @@ def test_plans_and_packed_output_on_the_mock(mock):
     plan.close()
 
 
+def test_wire_stage_on_the_mock(mock):
+    """plan_render_packets through plan.c's own choice between the fused form (the CRC rides the stream kernel's drain) and a
+    second pass over the slab (the rows kernel, row bands): frame CRC-32C, the 24-byte ascii_frame_packet_t headers and the
+    packet CRCs against the oracle (lib/network/crc32.c:171-189, lib/network/acip/server.c:186-214)"""
+    imgs = [orc.frame_hash_noise(120 + 8 * i, 90 + 4 * i, 70 + i) for i in range(4)]
+    keep = [np.ascontiguousarray(im) for im in imgs]
+    dims = [(40, 12), (33, 17), (20, 10), (40, 12)]
+    for mode, cl, rm, variant, fused in ((1, 3, 0, 17, True), (2, 2, 0, 16, True), (1, 3, 0, -1, None), (5, 3, 2, 25, False)):
+        frames = [mock.frame_setup(k.ctypes.data, k.shape[1], k.shape[0], w, h, rm, False, False, False)
+                  for k, (w, h) in zip(keep, dims)]
+        plan = mock.Plan(mode, orc.PALETTE_STANDARD, frames)
+        if variant >= 0:
+            plan.set_variant(variant)
+        if fused is not None:
+            assert plan.fused_crc == fused, (mode, variant)
+        n, stride = len(frames), plan.stride
+        out = np.zeros(n * stride, dtype=np.uint8)
+        ln = np.zeros(n, dtype=np.uint32)
+        d32 = np.array(dims, dtype=np.uint32)
+        crc = np.zeros(n, dtype=np.uint32)
+        hdr = np.zeros(n * 24, dtype=np.uint8)
+        pkt = np.zeros(n, dtype=np.uint32)
+        plan.render_packets(out.ctypes.data, stride, ln.ctypes.data, d32.ctypes.data, crc.ctypes.data, hdr.ctypes.data,
+                            pkt.ctypes.data)
+        for i in range(n):
+            exp = orc.convert_with_caps(imgs[i], dims[i][0], dims[i][1], cl, rm, False, False, False)
+            assert out[i * stride:i * stride + int(ln[i])].tobytes() == exp, (mode, variant, i)
+            want_crc = orc.crc32c(exp)
+            assert int(crc[i]) == want_crc, (mode, variant, i)
+            h = struct.pack(">IIIIII", dims[i][0], dims[i][1], len(exp), 0, want_crc, 0)
+            assert hdr[24 * i:24 * i + 24].tobytes() == h, (mode, variant, i)
+            assert int(pkt[i]) == orc.crc32c(h + exp), (mode, variant, i)
+        plan.close()
+
+
 def test_frame_table_publish_forms_on_the_mock(mock):
     """frame_table.c on the CPU: whole blobs, sampled rows, a tick's sampled pixels in one batch (the targets are the render
     descriptors of clients of three geometries), single-slot and batch publishes alternating on the same slots,
