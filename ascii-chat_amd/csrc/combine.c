@@ -60,7 +60,7 @@
 #include "render_variants.h"
 
 #define CB_MAX 64                      /* requests per generation                                  */
-#define CB_ARENA ((size_t)16 << 20)    /* pinned staging bytes per generation (sampled source rows)  */
+#define CB_ARENA ((size_t)16 << 20)    /* pinned staging bytes per generation (sampled pixels)        */
 #define CB_SLAB ((size_t)8 << 20)     /* pinned output bytes per generation                         */
 #define CB_DEVICES 16
 #define CB_GENS 16     /* generations per device, at most: CB_GENS_START are set up when the layer first engages, more only
@@ -68,8 +68,8 @@
                           copied its string out, and a crowd of sleepers takes a while to wake) -- joining a generation
                           should never have to wait, so that a call sleeps once (for its frame), not twice */
 #define CB_GENS_START 4
-#define CB_INFLIGHT 6  /* generations that may be in flight at once (each on its own stream): below that a caller
-                          launches at once, like the direct path; above it callers accumulate into batches      */
+#define CB_INFLIGHT 6  /* generations that may be in flight at once (each on its own stream); a ripe generation whose
+                          launcher finds them all taken waits for a launch slot and keeps filling meanwhile          */
 #define CB_SHARE 3     /* a generation is launched once it holds 1/CB_SHARE of the calls in flight (at least one, at most
                           CB_MAX): round 3's first form launched an OPEN generation as soon as one member had filled its slot
                           and a launch slot was free, so generations held 3-7 members whatever the load, a generation is
@@ -86,7 +86,7 @@
 enum { GEN_FREE = 0, GEN_OPEN, GEN_CLOSED, GEN_DONE };
 
 typedef struct {
-  achip_frame_t desc; /* src: device-visible (pool alias, or the device arena at stage_off) */
+  achip_frame_t desc; /* src: device-visible (pool alias, the mapped arena or its HBM twin at stage_off) */
   int mode, ascii;
   const achip_lut_t *lut;
   size_t bound;     /* worst-case bytes incl. NUL, multiple of 16 */
@@ -121,7 +121,6 @@ typedef struct {
 
 typedef struct {
   pthread_mutex_t mu;
-  pthread_cond_t cv;
   cb_gen_t gen[CB_GENS];
   int n_gens, grow_failed; /* generations set up so far; a set-up failed: stay with these */
   int open; /* index of the OPEN generation, -1 = none */
@@ -267,7 +266,6 @@ static void cb_global_init(void) {
     g_cb_inplace = 0;
   for (int d = 0; d < CB_DEVICES; d++) {
     pthread_mutex_init(&g_cb[d].mu, NULL);
-    pthread_cond_init(&g_cb[d].cv, NULL);
     g_cb[d].open = -1;
   }
   /* ASCIICHAT_HIP_COALESCE: 0 = never, 1 = always, N >= 2 = from N concurrent callers on (default 6: below that
@@ -580,8 +578,7 @@ char *achip_combine_render(int mode, const char *palette, const achip_lut_t *lut
     return NULL;
   { /* with hysteresis: coalescing starts at min_callers calls in flight and stops below half of that.  The count of T
      * steadily calling threads hovers a little below T (they also free strings and loop), and a threshold without
-     * memory made T = min_callers threads flip between the two paths call by call -- slower than either (80 k calls/s at 8
-     * threads against 94 k direct and 126 k combined; profiles/r03_dropin_threads.txt) */
+     * memory made T = min_callers threads flip between the two paths call by call -- slower than either */
     static int engaged;
     const int callers = __atomic_load_n(&g_cb_callers, __ATOMIC_RELAXED);
     int on = __atomic_load_n(&engaged, __ATOMIC_RELAXED);
@@ -597,13 +594,14 @@ char *achip_combine_render(int mode, const char *palette, const achip_lut_t *lut
     return NULL;
   cb_t *cb = &g_cb[dev];
 
-  /* what has to be staged: a pool-pinned image is read in place; of any other image only the rows the sampler asks
-   * for (out_h of src_h; image.c:293-312), all of it when every row is needed */
+  /* what has to be staged: of an image that is sampled sparsely only the pixels the sampler asks for (achip_stage_gather:
+   * the sampled rows; their sampled columns too when the frame is at most half as wide as the source; image.c:293-312) --
+   * of a pool-pinned image as well: 1920 three-byte samples picked up by the CPU and read densely by the kernel beat 1920
+   * sparse reads across PCIe (pooled 199 k calls/s in place against 250 k staged at 32 callers); an image every pixel of
+   * which is needed is read in place when it is pool-pinned and copied whole otherwise */
   achip_frame_t d = *f;
   const uint8_t *host_px = f->src;
   const void *alias = achip_pool_device_ptr(host_px);
-  /* ... a pool-pinned image too when it can be compacted: 1920 three-byte samples picked up by the CPU and read densely by
-   * the kernel beat 1920 sparse reads across PCIe (pooled 199 k calls/s in place against 250 k staged at 32 callers) */
   int sw, sh;
   const size_t part = achip_stage_extent(&d, &sw, &sh);
   if (part)
