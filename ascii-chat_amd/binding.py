@@ -125,6 +125,10 @@ def _bind(L):
     L.asciichat_hip_crc32c.argtypes = [vp, C.c_size_t, vp, C.c_uint32, C.c_uint32, ci, vp, vp]
     L.asciichat_hip_frame_packets.restype = ci
     L.asciichat_hip_frame_packets.argtypes = [vp, C.c_size_t, vp, C.c_uint32, ci, vp, vp, vp, vp, vp]
+    L.asciichat_hip_frame_packets_packed.restype = ci
+    L.asciichat_hip_frame_packets_packed.argtypes = [vp, C.c_size_t, vp, C.c_uint32, ci, vp, vp, vp, vp, vp, C.c_size_t, vp, vp, vp]
+    L.asciichat_hip_plan_render_packets_packed.restype = ci
+    L.asciichat_hip_plan_render_packets_packed.argtypes = [vp, vp, C.c_size_t, vp, vp, vp, vp, vp, vp, C.c_size_t, vp, vp, vp]
     L.asciichat_hip_plan_render.restype = ci
     L.asciichat_hip_plan_render.argtypes = [vp, vp, sz, vp, vp]
     L.asciichat_hip_plan_render_range.restype = ci
@@ -413,6 +417,14 @@ class Plan:
                                                      pkt_ptr, stream)
         if rc != 0:
             raise RuntimeError(f"plan_render_packets failed ({rc}): {last_error()}")
+
+    def render_packets_packed(self, slab_ptr, out_stride, len_ptr, dims_ptr, crc_ptr, hdr_ptr, pkt_ptr, dst_ptr, dst_capacity,
+                              off_ptr=None, len_out_ptr=None, stream=0):
+        """render + wire stage + compaction (asciichat_hip_plan_render_packets_packed)"""
+        rc = lib().asciichat_hip_plan_render_packets_packed(self._h, slab_ptr, out_stride, len_ptr, dims_ptr, crc_ptr, hdr_ptr,
+                                                            pkt_ptr, dst_ptr, dst_capacity, off_ptr, len_out_ptr, stream)
+        if rc != 0:
+            raise RuntimeError(f"plan_render_packets_packed failed ({rc}): {last_error()}")
 
     def set_fused_crc(self, mode):
         """-1 automatic (fused where it is the faster form), 0 never, 1 wherever the geometry carries it"""

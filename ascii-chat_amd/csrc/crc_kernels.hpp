@@ -34,16 +34,61 @@
 namespace achip {
 
 /*
+ * COPY instantiations: the pass that checksums a slab also COMPACTS it (stream_kernels.hpp pack_frames_kernel's layout:
+ * frame i at dst + off[i], off[i] = sum over j < i of round16(len[j]); dst may be mapped pinned host memory) -- every
+ * 16-byte group is stored where it was loaded for the checksum, so "checksums + headers + exact-length frames on the host"
+ * is ONE pass over the slab instead of two (a rows-kernel plan's tick: render -> this; profiles/r03_bench.json wire_stage).
+ * The last group of a frame travels whole (up to 15 bytes of the slot behind the frame's end: the padding the layout allows).
+ */
+struct CrcPack {
+  uint8_t *dst;
+  uint64_t capacity;
+  uint64_t *off_out; /* n + 1 offsets, or NULL */
+  uint32_t *len_out; /* n lengths (error codes as they are), or NULL */
+};
+__device__ inline uint32_t crc_pack_len_ok(uint32_t l) { return l >= 0xFFFFFFF0u ? 0u : l; }
+/* off[i] and the total, recomputed by every workgroup from len[] (as pack_frames_kernel does); called by all BLOCK threads
+ * BEFORE the workgroup's first barrier, read back (crc_pack_offset_read) after it */
+template <int BLOCK>
+__device__ inline void crc_pack_offset_post(const uint32_t *len, uint32_t fixed_len, int n, int i, int tid) {
+  uint32_t *wsum = lds_ptr<uint32_t>(CrcLds::o_pack);
+  uint32_t below = 0, all = 0;
+  for (int j = tid; j < n; j += BLOCK) {
+    const uint32_t g = (crc_pack_len_ok(len ? len[j] : fixed_len) + 15u) >> 4;
+    below += j < i ? g : 0u;
+    all += g;
+  }
+  below = wave_read_lane(wave_inclusive_scan(below), 63);
+  all = wave_read_lane(wave_inclusive_scan(all), 63);
+  if ((tid & 63) == 0) {
+    wsum[tid >> 6] = below;
+    wsum[16 + (tid >> 6)] = all;
+  }
+}
+template <int BLOCK> __device__ inline void crc_pack_offset_read(uint64_t &off, uint64_t &total) {
+  const uint32_t *wsum = lds_ptr<const uint32_t>(CrcLds::o_pack);
+  uint64_t a = 0, b = 0;
+#pragma unroll
+  for (int w = 0; w < BLOCK / 64; w++) {
+    a += wsum[w];
+    b += wsum[16 + w];
+  }
+  off = 16ull * a;
+  total = 16ull * b;
+}
+
+/*
  * One workgroup of BLOCK threads per frame of at most 128 KB.  len == NULL: every frame is fixed_len bytes.
  * Lengths >= 0xFFFFFFF0 are the render kernel's error codes: such a frame gets CRC 0 and a header with zero
  * dimensions.  The group grid of ceil(full_groups / BLOCK) rounds is padded with zero groups in front; loads are
  * requested four rounds ahead of the table lookups that consume them.
  */
-template <int BLOCK>
+template <int BLOCK, bool COPY = false>
 __global__ void __launch_bounds__(BLOCK)
     crc32c_frame_kernel(const uint8_t *__restrict__ base, uint64_t stride, const uint32_t *__restrict__ len,
                         uint32_t fixed_len, int n_frames, const uint32_t *__restrict__ dims,
-                        uint32_t *__restrict__ crc_out, uint8_t *__restrict__ hdr_out, uint32_t *__restrict__ pkt_crc_out) {
+                        uint32_t *__restrict__ crc_out, uint8_t *__restrict__ hdr_out, uint32_t *__restrict__ pkt_crc_out,
+                        CrcPack pack = CrcPack{nullptr, 0, nullptr, nullptr}) {
   static_assert(BLOCK == 256 || BLOCK == 1024, "tree constants");
   uint32_t *slice = lds_ptr<uint32_t>(CrcLds::o_slice);
   uint32_t *mulh = lds_ptr<uint32_t>(CrcLds::o_mulh);
@@ -70,14 +115,37 @@ __global__ void __launch_bounds__(BLOCK)
     else if (tid == BLOCK - 128)
       pw[1] = crc_x8_pow_len(L);
   }
+  if (COPY)
+    crc_pack_offset_post<BLOCK>(len, fixed_len, n_frames, i, tid);
   crc_build_tables<BLOCK>(slice, mulh, tid);
   __syncthreads();
+  uint4 *dst4 = nullptr; /* COPY: where this frame's groups go; stays NULL for a frame that does not fit */
+  if (COPY) {
+    uint64_t off, total;
+    crc_pack_offset_read<BLOCK>(off, total);
+    if (tid == 0) {
+      if (pack.off_out) {
+        pack.off_out[i] = off;
+        if (i == n_frames - 1)
+          pack.off_out[n_frames] = total;
+      }
+      if (pack.len_out)
+        pack.len_out[i] = len ? len[i] : fixed_len; /* error codes travel as they are */
+    }
+    if (off + L <= pack.capacity)
+      dst4 = reinterpret_cast<uint4 *>(pack.dst + off);
+    /* the frame's last, partial group travels whole, like every other one (the checksum takes its bytes one by one) */
+    if (dst4 && (L & 15u) && tid == BLOCK - 1)
+      dst4[full] = *reinterpret_cast<const uint4 *>(src + (size_t)full * 16u);
+  }
 
   auto load_group = [&](int j) -> uint4 {
     const int g = j * BLOCK + tid - lead;
     uint4 d = make_uint4(0u, 0u, 0u, 0u);
     if (j < rounds && g >= 0) {
       d = *reinterpret_cast<const uint4 *>(src + (size_t)g * 16u);
+      if (COPY && dst4)
+        dst4[g] = d;
       if (g == 0)
         d.x = ~d.x; /* initial value 0xFFFFFFFF = the first four message bytes complemented */
     }
@@ -111,9 +179,11 @@ __global__ void __launch_bounds__(BLOCK)
  * [p*span, (p+1)*span) of frame i, span = rounds * 4 KB, parts*span >= every length (zeros behind the end of
  * the frame), and stores its raw register (initial value 0) in partial[i*parts + p].
  */
+template <bool COPY = false>
 __global__ void __launch_bounds__(256)
     crc32c_span_kernel(const uint8_t *__restrict__ base, uint64_t stride, const uint32_t *__restrict__ len,
-                       uint32_t fixed_len, int n_frames, int parts, int rounds, uint32_t *__restrict__ partial) {
+                       uint32_t fixed_len, int n_frames, int parts, int rounds, uint32_t *__restrict__ partial,
+                       CrcPack pack = CrcPack{nullptr, 0, nullptr, nullptr}) {
   constexpr int BLOCK = 256;
   uint32_t *slice = lds_ptr<uint32_t>(CrcLds::o_slice);
   uint32_t *mulh = lds_ptr<uint32_t>(CrcLds::o_mulh);
@@ -126,20 +196,40 @@ __global__ void __launch_bounds__(256)
   if (L >= 0xFFFFFFF0u)
     L = 0;
   const uint64_t lo = (uint64_t)p * (uint64_t)rounds * (16u * BLOCK);
-  if (lo >= L) { /* nothing but zeros: raw() of zeros from 0 is 0 */
+  if (lo >= L && !(COPY && p == 0)) { /* nothing but zeros: raw() of zeros from 0 is 0 */
     if (tid == 0)
       partial[(size_t)i * parts + p] = 0u;
     return;
   }
-  const uint64_t avail = (uint64_t)L - lo; /* bytes of the frame from the start of this span (may exceed the span) */
+  const uint64_t avail = lo < L ? (uint64_t)L - lo : 0u; /* bytes of the frame from the start of this span (may exceed the span) */
+  if (COPY)
+    crc_pack_offset_post<BLOCK>(len, fixed_len, n_frames, i, tid);
   crc_build_tables<BLOCK>(slice, mulh, tid);
   __syncthreads();
+  uint8_t *dstb = nullptr; /* COPY: where this span's groups go; stays NULL for a frame that does not fit */
+  if (COPY) {
+    uint64_t off, total;
+    crc_pack_offset_read<BLOCK>(off, total);
+    if (p == 0 && tid == 0) {
+      if (pack.off_out) {
+        pack.off_out[i] = off;
+        if (i == n_frames - 1)
+          pack.off_out[n_frames] = total;
+      }
+      if (pack.len_out)
+        pack.len_out[i] = len ? len[i] : fixed_len;
+    }
+    if (off + L <= pack.capacity)
+      dstb = pack.dst + off + lo;
+  }
   const uint8_t *src = base + (size_t)i * stride + lo;
   auto load_group = [&](int j) -> uint4 {
     const uint64_t off = ((uint64_t)j * BLOCK + (uint64_t)tid) * 16u;
     uint4 d = make_uint4(0u, 0u, 0u, 0u);
     if (j < rounds && off < avail) {
       const uint64_t left = avail - off;
+      if (COPY && dstb) /* whole groups, the frame's last one included (padding the layout allows) */
+        *reinterpret_cast<uint4 *>(dstb + off) = *reinterpret_cast<const uint4 *>(src + off);
       if (left >= 16u) {
         d = *reinterpret_cast<const uint4 *>(src + off);
       } else { /* the frame ends inside this group: byte loads, the bytes behind the end count as zeros */

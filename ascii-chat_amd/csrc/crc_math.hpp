@@ -69,7 +69,8 @@ struct CrcLds {
   static constexpr int o_mulh = o_slice + 16 * 1024; /* uint32 [4][256]: (v << 8k) * x^(128*256)         */
   static constexpr int o_tree = o_mulh + 4 * 1024;   /* uint32 [1024]                                     */
   static constexpr int o_pow = o_tree + 4096;        /* uint32 [64]: product trees x^(8*len), x^(-8*surplus) */
-  static constexpr int bytes = o_pow + 256;
+  static constexpr int o_pack = o_pow + 256;         /* uint32 [2][16]: wave totals of the packed-offset prefix */
+  static constexpr int bytes = o_pack + 128;
 };
 
 /* raw() of 16 bytes held little-endian in four dwords */

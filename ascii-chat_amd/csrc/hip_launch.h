@@ -67,6 +67,12 @@ int achip_launch_crc32c(const uint8_t *base, uint64_t stride, const uint32_t *le
                         uint32_t max_len, int n, uint32_t *partial, const uint32_t *dims_dev, uint32_t *crc_out,
                         uint8_t *hdr_out, uint32_t *pkt_crc_out, void *stream);
 
+/* the same pass also compacting the slab: frame i to dst + off[i], off[i] = sum of round16(len[j]), j < i (achip_launch_pack's layout) */
+int achip_launch_crc32c_pack(const uint8_t *base, uint64_t stride, const uint32_t *len_dev, uint32_t max_len, int n,
+                             uint32_t *partial, const uint32_t *dims_dev, uint32_t *crc_out, uint8_t *hdr_out,
+                             uint32_t *pkt_crc_out, uint8_t *dst, uint64_t dst_capacity, uint64_t *off_out, uint32_t *len_out,
+                             void *stream);
+
 int achip_variant_block(int variant); /* threads per workgroup, -1 for an unknown id */
 int achip_variant_cap(int variant);   /* cells per chunk                               */
 int achip_variant_lds_bytes(int mode, int variant);

@@ -304,22 +304,49 @@ extern "C" int achip_crc_parts(uint32_t max_len) {
   return max_len <= 32u * 4096u ? 1 : (int)(((uint64_t)max_len + 65535u) / 65536u);
 }
 
-extern "C" int achip_launch_crc32c(const uint8_t *base, uint64_t stride, const uint32_t *len_dev, uint32_t fixed_len,
-                                   uint32_t max_len, int n, uint32_t *partial, const uint32_t *dims_dev,
-                                   uint32_t *crc_out, uint8_t *hdr_out, uint32_t *pkt_crc_out, void *stream) {
-  hipStream_t s = static_cast<hipStream_t>(stream);
+/* pack != NULL: the same pass also compacts the slab (crc_kernels.hpp COPY instantiations) */
+static int launch_crc32c(const uint8_t *base, uint64_t stride, const uint32_t *len_dev, uint32_t fixed_len, uint32_t max_len,
+                         int n, uint32_t *partial, const uint32_t *dims_dev, uint32_t *crc_out, uint8_t *hdr_out,
+                         uint32_t *pkt_crc_out, const achip::CrcPack *pack, hipStream_t s) {
   const int parts = achip_crc_parts(max_len);
   if (parts == 1) { /* 1024 threads per frame; every workgroup runs only the rounds its own frame needs */
-    hipLaunchKernelGGL(achip::crc32c_frame_kernel<1024>, dim3((unsigned)n), dim3(1024), (size_t)achip::CrcLds::bytes, s,
-                       base, stride, len_dev, fixed_len, n, dims_dev, crc_out, hdr_out, pkt_crc_out);
+    if (pack)
+      hipLaunchKernelGGL((achip::crc32c_frame_kernel<1024, true>), dim3((unsigned)n), dim3(1024), (size_t)achip::CrcLds::bytes,
+                         s, base, stride, len_dev, fixed_len, n, dims_dev, crc_out, hdr_out, pkt_crc_out, *pack);
+    else
+      hipLaunchKernelGGL((achip::crc32c_frame_kernel<1024, false>), dim3((unsigned)n), dim3(1024), (size_t)achip::CrcLds::bytes,
+                         s, base, stride, len_dev, fixed_len, n, dims_dev, crc_out, hdr_out, pkt_crc_out,
+                         achip::CrcPack{nullptr, 0, nullptr, nullptr});
     return (int)hipGetLastError();
   }
   const int rounds = 16; /* 64 KB spans of 256-thread workgroups */
   const uint64_t v_bytes = (uint64_t)parts * (uint64_t)rounds * 4096u;
-  hipLaunchKernelGGL(achip::crc32c_span_kernel, dim3((unsigned)n * (unsigned)parts), dim3(256),
-                     (size_t)achip::CrcLds::bytes, s, base, stride, len_dev, fixed_len, n, parts, rounds, partial);
+  if (pack)
+    hipLaunchKernelGGL(achip::crc32c_span_kernel<true>, dim3((unsigned)n * (unsigned)parts), dim3(256),
+                       (size_t)achip::CrcLds::bytes, s, base, stride, len_dev, fixed_len, n, parts, rounds, partial, *pack);
+  else
+    hipLaunchKernelGGL(achip::crc32c_span_kernel<false>, dim3((unsigned)n * (unsigned)parts), dim3(256),
+                       (size_t)achip::CrcLds::bytes, s, base, stride, len_dev, fixed_len, n, parts, rounds, partial,
+                       achip::CrcPack{nullptr, 0, nullptr, nullptr});
   hipLaunchKernelGGL(achip::crc32c_finish_kernel, dim3((unsigned)n), dim3(64), 256, s, partial, parts,
                      achip::crc_pow(achip::CRC_X8, (uint64_t)rounds * 4096u), achip::crc_pow(achip::CRC_XINV8, v_bytes),
                      len_dev, fixed_len, n, dims_dev, crc_out, hdr_out, pkt_crc_out);
   return (int)hipGetLastError();
+}
+
+extern "C" int achip_launch_crc32c(const uint8_t *base, uint64_t stride, const uint32_t *len_dev, uint32_t fixed_len,
+                                   uint32_t max_len, int n, uint32_t *partial, const uint32_t *dims_dev,
+                                   uint32_t *crc_out, uint8_t *hdr_out, uint32_t *pkt_crc_out, void *stream) {
+  return launch_crc32c(base, stride, len_dev, fixed_len, max_len, n, partial, dims_dev, crc_out, hdr_out, pkt_crc_out, nullptr,
+                       static_cast<hipStream_t>(stream));
+}
+
+/* checksums + headers + compaction in ONE pass over the slab: frame i also goes to dst + off[i] (pack_frames' layout) */
+extern "C" int achip_launch_crc32c_pack(const uint8_t *base, uint64_t stride, const uint32_t *len_dev, uint32_t max_len, int n,
+                                        uint32_t *partial, const uint32_t *dims_dev, uint32_t *crc_out, uint8_t *hdr_out,
+                                        uint32_t *pkt_crc_out, uint8_t *dst, uint64_t dst_capacity, uint64_t *off_out,
+                                        uint32_t *len_out, void *stream) {
+  const achip::CrcPack pack = {dst, dst_capacity, off_out, len_out};
+  return launch_crc32c(base, stride, len_dev, 0u, max_len, n, partial, dims_dev, crc_out, hdr_out, pkt_crc_out, &pack,
+                       static_cast<hipStream_t>(stream));
 }

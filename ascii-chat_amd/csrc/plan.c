@@ -523,6 +523,29 @@ int asciichat_hip_plan_render_packets(asciichat_hip_plan_t *p, uint8_t *out_dev,
   return plan_render_wire(p, out_dev, out_stride, out_len_dev, &wire, NULL, stream);
 }
 
+/* ... and the frames at their exact lengths behind it (pack_frames' layout; dst may be mapped host memory): a plan whose
+ * kernel carries the fused CRC renders (one launch) and packs; any other plan renders and then checksums AND packs in one
+ * pass over the slab (asciichat_hip_frame_packets_packed) -- two launches either way. */
+int asciichat_hip_plan_render_packets_packed(asciichat_hip_plan_t *p, uint8_t *slab_dev, size_t out_stride, uint32_t *out_len_dev,
+                                             const uint32_t *dims_dev, uint32_t *crc_out_dev, uint8_t *hdr_out_dev,
+                                             uint32_t *packet_crc_out_dev, uint8_t *dst, size_t dst_capacity, uint64_t *off_out,
+                                             uint32_t *len_out, void *stream) {
+  if (!p || !hdr_out_dev || !dst)
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "plan_render_packets_packed: no header buffer or destination");
+  if (asciichat_hip_plan_has_fused_crc(p)) {
+    int rc = asciichat_hip_plan_render_packets(p, slab_dev, out_stride, out_len_dev, dims_dev, crc_out_dev, hdr_out_dev,
+                                               packet_crc_out_dev, stream);
+    if (!rc)
+      rc = asciichat_hip_pack_frames(slab_dev, out_stride, out_len_dev, p->n, dst, dst_capacity, off_out, len_out, stream);
+    return rc;
+  }
+  int rc = asciichat_hip_plan_render(p, slab_dev, out_stride, out_len_dev, stream);
+  if (!rc)
+    rc = asciichat_hip_frame_packets_packed(slab_dev, out_stride, out_len_dev, (uint32_t)out_stride, p->n, dims_dev, crc_out_dev,
+                                            hdr_out_dev, packet_crc_out_dev, dst, dst_capacity, off_out, len_out, stream);
+  return rc;
+}
+
 /* diagnostics: the same launch with the per-wave timestamps of plan_render_profiled */
 int asciichat_hip_plan_render_crc_profiled(asciichat_hip_plan_t *p, uint8_t *out_dev, size_t out_stride,
                                            uint32_t *out_len_dev, uint32_t *crc_out_dev,
@@ -794,9 +817,16 @@ int asciichat_hip_image_flip(const uint8_t *src_dev, uint8_t *dst_dev, int width
 }
 
 /* ---- wire stage -------------------------------------------------------------------------------- */
+typedef struct {
+  uint8_t *dst;
+  size_t capacity;
+  uint64_t *off_out;
+  uint32_t *len_out;
+} crc_pack_t;
+
 static int crc_common(const uint8_t *base_dev, size_t stride, const uint32_t *len_dev, uint32_t fixed_len,
                       uint32_t max_len, int n, const uint32_t *dims_dev, uint32_t *crc_out_dev, uint8_t *hdr_out_dev,
-                      uint32_t *packet_crc_out_dev, void *stream) {
+                      uint32_t *packet_crc_out_dev, const crc_pack_t *pack, void *stream) {
   if (!base_dev || !crc_out_dev || n <= 0 || ((uintptr_t)base_dev & 15u) || (stride & 15u) ||
       (len_dev ? max_len == 0 : fixed_len > max_len) || max_len >= 0xFFFFFFF0u || (n > 1 && stride < max_len))
     return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "crc32c: bad arguments");
@@ -814,8 +844,11 @@ static int crc_common(const uint8_t *base_dev, size_t stride, const uint32_t *le
     if (rc)
       return rc;
   }
-  rc = achip_hip_check(achip_launch_crc32c(base_dev, stride, len_dev, fixed_len, max_len, n, scratch, dims_dev,
-                                           crc_out_dev, hdr_out_dev, packet_crc_out_dev, stream),
+  rc = achip_hip_check(pack ? achip_launch_crc32c_pack(base_dev, stride, len_dev, max_len, n, scratch, dims_dev, crc_out_dev,
+                                                       hdr_out_dev, packet_crc_out_dev, pack->dst, (uint64_t)pack->capacity,
+                                                       pack->off_out, pack->len_out, stream)
+                            : achip_launch_crc32c(base_dev, stride, len_dev, fixed_len, max_len, n, scratch, dims_dev,
+                                                  crc_out_dev, hdr_out_dev, packet_crc_out_dev, stream),
                        "crc32c launch");
   if (scratch) {
     const int fr = achip_hip_check((int)hipFreeAsync(scratch, (hipStream_t)stream), "hipFreeAsync(crc scratch)");
@@ -827,7 +860,7 @@ static int crc_common(const uint8_t *base_dev, size_t stride, const uint32_t *le
 
 int asciichat_hip_crc32c(const uint8_t *base_dev, size_t stride, const uint32_t *len_dev, uint32_t fixed_len,
                          uint32_t max_len, int n, uint32_t *crc_out_dev, void *stream) {
-  return crc_common(base_dev, stride, len_dev, fixed_len, max_len, n, NULL, crc_out_dev, NULL, NULL, stream);
+  return crc_common(base_dev, stride, len_dev, fixed_len, max_len, n, NULL, crc_out_dev, NULL, NULL, NULL, stream);
 }
 
 int asciichat_hip_frame_packets(const uint8_t *base_dev, size_t stride, const uint32_t *len_dev, uint32_t max_len, int n,
@@ -835,7 +868,20 @@ int asciichat_hip_frame_packets(const uint8_t *base_dev, size_t stride, const ui
                                 uint32_t *packet_crc_out_dev, void *stream) {
   if (!len_dev || !hdr_out_dev)
     return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame_packets: lengths and a header buffer are required");
-  return crc_common(base_dev, stride, len_dev, 0, max_len, n, dims_dev, crc_out_dev, hdr_out_dev, packet_crc_out_dev,
+  return crc_common(base_dev, stride, len_dev, 0, max_len, n, dims_dev, crc_out_dev, hdr_out_dev, packet_crc_out_dev, NULL,
+                    stream);
+}
+
+/* the wire stage AND the compaction in one pass over the slab (crc_kernels.hpp COPY instantiations) */
+int asciichat_hip_frame_packets_packed(const uint8_t *base_dev, size_t stride, const uint32_t *len_dev, uint32_t max_len, int n,
+                                       const uint32_t *dims_dev, uint32_t *crc_out_dev, uint8_t *hdr_out_dev,
+                                       uint32_t *packet_crc_out_dev, uint8_t *dst, size_t dst_capacity, uint64_t *off_out,
+                                       uint32_t *len_out, void *stream) {
+  if (!len_dev || !hdr_out_dev || !dst || ((uintptr_t)dst & 15u) || ((uintptr_t)off_out & 7u) || ((uintptr_t)len_out & 3u))
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM,
+                      "frame_packets_packed: lengths, a header buffer and a 16-byte aligned destination are required");
+  const crc_pack_t pack = {dst, dst_capacity, off_out, len_out};
+  return crc_common(base_dev, stride, len_dev, 0, max_len, n, dims_dev, crc_out_dev, hdr_out_dev, packet_crc_out_dev, &pack,
                     stream);
 }
 

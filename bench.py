@@ -447,10 +447,25 @@ def wire_stage(torch, pkg, res, steps=None):
     pkts = [torch.zeros(batch, dtype=torch.int32, device="cuda") for _ in range(S)]
     sw, sh, W, H, cl, rm = WORKLOADS[res["name"]]
     dims = torch.tensor([[W, H]] * batch, dtype=torch.int32, device="cuda")
+    # compacted copies (device memory here: the passes over HBM are what is compared; with_d2h_packed has the PCIe side)
+    pks = [torch.empty(batch * stride, dtype=torch.uint8, device="cuda") for _ in range(S)]
+    offs = [torch.zeros(batch + 1, dtype=torch.int64, device="cuda") for _ in range(S)]
+    plens = [torch.zeros(batch, dtype=torch.int32, device="cuda") for _ in range(S)]
 
     def step(kind, k):
         s, p = k % S, plans[k % len(plans)]
         st = lanes[s].cuda_stream
+        if kind == "packets_then_pack":  # the wire stage, then the compaction as a pass of its own
+            p.render_packets(outs[s].data_ptr(), stride, lns[s].data_ptr(), dims.data_ptr(), crcs[s].data_ptr(),
+                             hdrs[s].data_ptr(), pkts[s].data_ptr(), st)
+            pkg.pack_frames(outs[s].data_ptr(), stride, lns[s].data_ptr(), batch, pks[s].data_ptr(), batch * stride,
+                            offs[s].data_ptr(), plens[s].data_ptr(), st)
+            return
+        if kind == "packets_packed":  # ... in the library's own form: one pass checksums AND packs where the CRC is not fused
+            p.render_packets_packed(outs[s].data_ptr(), stride, lns[s].data_ptr(), dims.data_ptr(), crcs[s].data_ptr(),
+                                    hdrs[s].data_ptr(), pkts[s].data_ptr(), pks[s].data_ptr(), batch * stride,
+                                    offs[s].data_ptr(), plens[s].data_ptr(), st)
+            return
         if kind == "fused":  # ONE call, one launch: frames + frame CRCs + headers + packet CRCs
             p.render_packets(outs[s].data_ptr(), stride, lns[s].data_ptr(), dims.data_ptr(), crcs[s].data_ptr(),
                              hdrs[s].data_ptr(), pkts[s].data_ptr(), st)
@@ -492,7 +507,19 @@ def wire_stage(torch, pkg, res, steps=None):
     oracle_ok = all(int(got["fused"][0][i]) == orc.crc32c(host[i * stride:i * stride + int(lens[i])].tobytes()) for i in idx)
     if not (same and oracle_ok):
         raise SystemExit("bench.py: fused frame checksums differ from the stand-alone kernel's / the oracle's")
-    t = {kind: statistics.median(timed(kind) for _ in range(3)) for kind in ("render", "separate", "fused")}
+    t = {kind: statistics.median(timed(kind) for _ in range(3))
+         for kind in ("render", "separate", "fused", "packets_then_pack", "packets_packed")}
+    # the compacted copies of the two forms agree (offsets, lengths, every frame's bytes)
+    ref = {}
+    for kind in ("packets_then_pack", "packets_packed"):
+        step(kind, 0)
+        torch.cuda.synchronize()
+        o, l = offs[0].cpu().numpy().copy(), plens[0].cpu().numpy().astype("uint32").copy()
+        pk = pks[0].cpu().numpy()
+        ref[kind] = (o, l, [pk[int(o[i]):int(o[i]) + int(l[i])].tobytes() for i in idx])
+    if not ((ref["packets_then_pack"][0] == ref["packets_packed"][0]).all() and (ref["packets_then_pack"][1] == ref["packets_packed"][1]).all()
+            and ref["packets_then_pack"][2] == ref["packets_packed"][2]):
+        raise SystemExit("bench.py: the one-pass checksum + pack differs from wire stage + pack_frames")
     forced = None
     if not plans[0].fused_crc:  # a geometry that carries the fused CRC without it being the faster form (the rows kernel)
         for p in plans:
@@ -507,6 +534,11 @@ def wire_stage(torch, pkg, res, steps=None):
             "render_ms_per_step": t["render"], "render_plus_packet_kernel_ms_per_step": t["separate"],
             "render_with_fused_crc_and_headers_ms_per_step": t["fused"],
             "extra_ms_separate": t["separate"] - t["render"], "extra_ms_fused": t["fused"] - t["render"],
+            "packed": {"wire_stage_then_pack_frames_ms_per_step": t["packets_then_pack"],
+                       "render_packets_packed_ms_per_step": t["packets_packed"],
+                       "note": "the frames also compacted (device destination): plan_render_packets + pack_frames against "
+                               "plan_render_packets_packed -- behind a fused render the same two launches, otherwise ONE pass "
+                               "that checksums and packs instead of two passes over the slab"},
             "checked": {"frames_vs_standalone_kernel": batch, "frames_vs_oracle_crc32c": len(idx), "identical": True},
             "note": "ascii_frame_packet_t.checksum + 24-byte headers + packet CRCs for every frame of the step "
                     "(lib/network/acip/server.c:186-214); calls issued from Python: render + asciichat_hip_frame_packets "

@@ -228,6 +228,14 @@ int asciichat_hip_crc32c(const uint8_t *base_dev, size_t stride, const uint32_t 
 int asciichat_hip_frame_packets(const uint8_t *base_dev, size_t stride, const uint32_t *len_dev, uint32_t max_len, int n,
                                 const uint32_t *dims_dev, uint32_t *crc_out_dev, uint8_t *hdr_out_dev,
                                 uint32_t *packet_crc_out_dev, void *stream);
+/* ... and, in the same pass over the slab, the frames at their exact lengths: frame i also goes to dst + off_out[i]
+ * (asciichat_hip_pack_frames' layout below: 16-byte aligned starts, off_out[n] = bytes used, dst may be the device alias of
+ * mapped pinned host memory).  What a send thread needs of a tick -- checksums, headers, frame bytes -- for one read of
+ * the slab instead of two. */
+int asciichat_hip_frame_packets_packed(const uint8_t *base_dev, size_t stride, const uint32_t *len_dev, uint32_t max_len, int n,
+                                       const uint32_t *dims_dev, uint32_t *crc_out_dev, uint8_t *hdr_out_dev,
+                                       uint32_t *packet_crc_out_dev, uint8_t *dst, size_t dst_capacity, uint64_t *off_out,
+                                       uint32_t *len_out, void *stream);
 
 /*
  * Compacted output (SURVEY.md 8e "prefer gathering compacted per-rank buffers ... lengths first").  A render leaves frame
@@ -326,6 +334,12 @@ int asciichat_hip_plan_render_crc(asciichat_hip_plan_t *plan, uint8_t *out_dev, 
 int asciichat_hip_plan_render_packets(asciichat_hip_plan_t *plan, uint8_t *out_dev, size_t out_stride,
                                       uint32_t *out_len_dev, const uint32_t *dims_dev, uint32_t *crc_out_dev,
                                       uint8_t *hdr_out_dev, uint32_t *packet_crc_out_dev, void *stream);
+/* ... plus the compaction: render (+ fused wire stage) and pack where the kernel carries the CRC, render and ONE pass that
+ * checksums and packs otherwise (plans of the run-structured modes, row bands) */
+int asciichat_hip_plan_render_packets_packed(asciichat_hip_plan_t *plan, uint8_t *slab_dev, size_t out_stride,
+                                             uint32_t *out_len_dev, const uint32_t *dims_dev, uint32_t *crc_out_dev,
+                                             uint8_t *hdr_out_dev, uint32_t *packet_crc_out_dev, uint8_t *dst,
+                                             size_t dst_capacity, uint64_t *off_out, uint32_t *len_out, void *stream);
 /* Which form plan_render_crc / plan_render_packets take: -1 (default) the fused one where it is the faster form (the
  * per-cell modes' stream kernel), 1 wherever the plan's geometry carries it (also the rows kernel of the run-structured
  * modes, where the stand-alone pass is measured faster), 0 never.  plan_has_fused_crc() tells what a call will do. */

@@ -291,11 +291,39 @@ extern "C" void emu_crc32c(const uint8_t *base, uint64_t stride, const uint32_t 
   const uint64_t v_bytes = (uint64_t)parts * rounds * 4096u;
   std::vector<uint32_t> partial((size_t)n * parts);
   hipemu::launch(dim3((unsigned)(n * parts)), dim3(256), achip::CrcLds::bytes, [&] {
-    achip::crc32c_span_kernel(base, stride, len, fixed_len, n, parts, rounds, partial.data());
+    achip::crc32c_span_kernel<false>(base, stride, len, fixed_len, n, parts, rounds, partial.data());
   });
   hipemu::launch(dim3((unsigned)n), dim3(64), 256, [&] {
     achip::crc32c_finish_kernel(partial.data(), parts, achip::crc_pow(achip::CRC_X8, (uint64_t)rounds * 4096u),
                                 achip::crc_pow(achip::CRC_XINV8, v_bytes), len, fixed_len, n, dims, crc_out, hdr_out, pkt_out);
+  });
+}
+
+/* ... with the slab compacted in the same pass (COPY instantiations); geometry as above */
+extern "C" void emu_crc32c_pack(const uint8_t *base, uint64_t stride, const uint32_t *len, uint32_t max_len, int n,
+                                int force_parts, int force_rounds, const uint32_t *dims, uint32_t *crc_out, uint8_t *hdr_out,
+                                uint32_t *pkt_out, uint8_t *dst, uint64_t cap, uint64_t *off_out, uint32_t *len_out) {
+  int parts = max_len <= 32u * 4096u ? 1 : (int)(((uint64_t)max_len + 65535u) / 65536u);
+  int rounds = 16;
+  if (force_parts > 0) {
+    parts = force_parts;
+    rounds = force_rounds;
+  }
+  const achip::CrcPack pack = {dst, cap, off_out, len_out};
+  if (parts == 1) {
+    hipemu::launch(dim3((unsigned)n), dim3(1024), achip::CrcLds::bytes, [&] {
+      achip::crc32c_frame_kernel<1024, true>(base, stride, len, 0u, n, dims, crc_out, hdr_out, pkt_out, pack);
+    });
+    return;
+  }
+  const uint64_t v_bytes = (uint64_t)parts * rounds * 4096u;
+  std::vector<uint32_t> partial((size_t)n * parts);
+  hipemu::launch(dim3((unsigned)(n * parts)), dim3(256), achip::CrcLds::bytes, [&] {
+    achip::crc32c_span_kernel<true>(base, stride, len, 0u, n, parts, rounds, partial.data(), pack);
+  });
+  hipemu::launch(dim3((unsigned)n), dim3(64), 256, [&] {
+    achip::crc32c_finish_kernel(partial.data(), parts, achip::crc_pow(achip::CRC_X8, (uint64_t)rounds * 4096u),
+                                achip::crc_pow(achip::CRC_XINV8, v_bytes), len, 0u, n, dims, crc_out, hdr_out, pkt_out);
   });
 }
 

@@ -78,6 +78,17 @@ extern "C" int achip_launch_crc32c(const uint8_t *base, uint64_t stride, const u
   emu_crc32c(base, stride, len, fixed_len, max_len, n, 0, 0, dims, crc_out, hdr_out, pkt_out);
   return MOCK_OK;
 }
+extern "C" int achip_launch_crc32c_pack(const uint8_t *base, uint64_t stride, const uint32_t *len, uint32_t max_len, int n,
+                                        uint32_t *partial, const uint32_t *dims, uint32_t *crc_out, uint8_t *hdr_out,
+                                        uint32_t *pkt_out, uint8_t *dst, uint64_t cap, uint64_t *off_out, uint32_t *len_out,
+                                        void *stream) {
+  (void)partial, (void)stream;
+  if (n <= 0)
+    return MOCK_OK;
+  std::lock_guard<std::mutex> lock(g_emu_mu);
+  emu_crc32c_pack(base, stride, len, max_len, n, 0, 0, dims, crc_out, hdr_out, pkt_out, dst, cap, off_out, len_out);
+  return MOCK_OK;
+}
 extern "C" int achip_launch_packets_from_crc(const uint32_t *len, const uint32_t *crc, const uint32_t *dims, int n, uint8_t *hdr_out,
                                              uint32_t *pkt_out, void *stream) {
   (void)stream;

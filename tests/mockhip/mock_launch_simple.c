@@ -142,6 +142,13 @@ int achip_launch_crc32c(const uint8_t *base, uint64_t stride, const uint32_t *le
   (void)base, (void)stride, (void)len, (void)fixed, (void)max, (void)n, (void)partial, (void)dims, (void)crc, (void)hdr, (void)pkt, (void)s;
   return MOCK_UNSUPPORTED;
 }
+int achip_launch_crc32c_pack(const uint8_t *base, uint64_t stride, const uint32_t *len, uint32_t max, int n, uint32_t *partial,
+                             const uint32_t *dims, uint32_t *crc, uint8_t *hdr, uint32_t *pkt, uint8_t *dst, uint64_t cap,
+                             uint64_t *off, uint32_t *len_out, void *s) {
+  (void)base, (void)stride, (void)len, (void)max, (void)n, (void)partial, (void)dims, (void)crc, (void)hdr, (void)pkt, (void)dst,
+      (void)cap, (void)off, (void)len_out, (void)s;
+  return MOCK_UNSUPPORTED;
+}
 int achip_crc_parts(uint32_t max_len) {
   (void)max_len;
   return 1;

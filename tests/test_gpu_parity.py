@@ -957,3 +957,60 @@ def test_frame_table_batch_publish_waits_for_queued_readers_and_mixes_with_singl
         for k in range(n):
             assert got[k] == oracle_convert(ticks[t][k], MODE_TRUE_FG, 80, 24, orc.PALETTE_STANDARD), (step, k)
     table.close()
+
+
+def test_render_packets_packed_one_pass(gpu):
+    """plan_render_packets_packed / frame_packets_packed: checksums, headers, packet CRCs AND the frames at their exact lengths
+    in mapped host memory.  Behind a fused render it is render + pack; behind any other plan ONE pass over the slab
+    checksums and packs (crc_kernels.hpp COPY instantiations: the one-workgroup-per-frame kernel for frames up to 128 KB, the
+    span kernels above).  Everything must equal plan_render_packets + pack_frames."""
+    pkg, torch = gpu
+    stream = torch.cuda.current_stream().cuda_stream
+    src = torch.from_numpy(np.ascontiguousarray(orc.frame_hash_noise(1920, 1080, 77))).cuda()
+    big = torch.from_numpy(np.ascontiguousarray(orc.frame_hash_noise(3840, 2160, 78))).cuda()
+    cases = [  # mode, render_mode, source, (w, h) list, forced variant
+        (1, 0, src, [(80, 24), (60, 7), (1, 1), (132, 43)], 17),        # fused CRC: render + pack
+        (5, 2, src, [(80, 24), (100, 37), (33, 17), (80, 24)], -1),     # rows kernel / bands: one pass, frames < 128 KB
+        (0, 0, src, [(80, 24), (200, 60), (10, 5)], -1),
+        (5, 2, big, [(400, 120), (380, 100), (80, 24)], -1),            # 1.8 MB frames: the span kernels
+    ]
+    for mode, rm, img, dims, variant in cases:
+        ih, iw = img.shape[0], img.shape[1]
+        frames = [pkg.frame_setup(img.data_ptr(), iw, ih, w, h, rm, False, False, False) for (w, h) in dims]
+        plan = pkg.Plan(mode, orc.PALETTE_STANDARD, frames)
+        if variant >= 0:
+            plan.set_variant(variant)
+        n, stride = len(frames), plan.stride
+        d32 = torch.tensor(dims, dtype=torch.int32, device="cuda")
+
+        def bufs():
+            return (torch.full((n * stride,), 0xEE, dtype=torch.uint8, device="cuda"), torch.zeros(n, dtype=torch.int32, device="cuda"),
+                    torch.zeros(n, dtype=torch.int32, device="cuda"), torch.zeros(n * 24, dtype=torch.uint8, device="cuda"),
+                    torch.zeros(n, dtype=torch.int32, device="cuda"))
+
+        tab = (8 * (n + 1) + 4 * n + 15) // 16 * 16
+        out_a, ln_a, crc_a, hdr_a, pkt_a = bufs()
+        hb_a = pkg.HostBuffer(tab + n * stride)
+        plan.render_packets(out_a.data_ptr(), stride, ln_a.data_ptr(), d32.data_ptr(), crc_a.data_ptr(), hdr_a.data_ptr(),
+                            pkt_a.data_ptr(), stream)
+        pkg.pack_frames(out_a.data_ptr(), stride, ln_a.data_ptr(), n, hb_a.dev + tab, n * stride, hb_a.dev, hb_a.dev + 8 * (n + 1), stream)
+        out_b, ln_b, crc_b, hdr_b, pkt_b = bufs()
+        hb_b = pkg.HostBuffer(tab + n * stride)
+        plan.render_packets_packed(out_b.data_ptr(), stride, ln_b.data_ptr(), d32.data_ptr(), crc_b.data_ptr(), hdr_b.data_ptr(),
+                                   pkt_b.data_ptr(), hb_b.dev + tab, n * stride, hb_b.dev, hb_b.dev + 8 * (n + 1), stream)
+        torch.cuda.synchronize()
+        assert torch.equal(ln_a, ln_b) and torch.equal(crc_a, crc_b) and torch.equal(hdr_a, hdr_b) and torch.equal(pkt_a, pkt_b), (mode, dims)
+        va, vb = hb_a.view(), hb_b.view()
+        off_a, off_b = va[:8 * (n + 1)].view(np.uint64), vb[:8 * (n + 1)].view(np.uint64)
+        la = va[8 * (n + 1):8 * (n + 1) + 4 * n].view(np.uint32)
+        assert np.array_equal(off_a, off_b) and np.array_equal(la, vb[8 * (n + 1):8 * (n + 1) + 4 * n].view(np.uint32))
+        ih_np = img.cpu().numpy()
+        for i, (w, h) in enumerate(dims):
+            a = va[tab + int(off_a[i]):tab + int(off_a[i]) + int(la[i])].tobytes()
+            assert a == vb[tab + int(off_b[i]):tab + int(off_b[i]) + int(la[i])].tobytes(), (mode, i)
+            if w * h <= 200 * 60:  # (the oracle takes its time on the largest frames: they are compared with the two-pass form)
+                cl = {1: 3, 5: 3, 0: 0}[mode]
+                assert a == orc.convert_with_caps(ih_np, w, h, cl, rm, False, False, False), (mode, i)
+        hb_a.close()
+        hb_b.close()
+        plan.close()

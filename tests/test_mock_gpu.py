@@ -148,6 +148,20 @@ def test_wire_stage_on_the_mock(mock):
             h = struct.pack(">IIIIII", dims[i][0], dims[i][1], len(exp), 0, want_crc, 0)
             assert hdr[24 * i:24 * i + 24].tobytes() == h, (mode, variant, i)
             assert int(pkt[i]) == orc.crc32c(h + exp), (mode, variant, i)
+        # the same plus the compaction: one more launch (pack) behind a fused render, ONE pass that checksums and packs otherwise
+        out2, ln2, crc2, hdr2, pkt2 = np.zeros_like(out), np.zeros_like(ln), np.zeros_like(crc), np.zeros_like(hdr), np.zeros_like(pkt)
+        dst = np.zeros(n * stride + 16, dtype=np.uint8)
+        dbase = dst.ctypes.data + (-dst.ctypes.data % 16)
+        off = np.zeros(n + 1, dtype=np.uint64)
+        lo = np.zeros(n, dtype=np.uint32)
+        plan.render_packets_packed(out2.ctypes.data, stride, ln2.ctypes.data, d32.ctypes.data, crc2.ctypes.data, hdr2.ctypes.data,
+                                   pkt2.ctypes.data, dbase, n * stride, off.ctypes.data, lo.ctypes.data)
+        assert np.array_equal(ln2, ln) and np.array_equal(crc2, crc) and np.array_equal(hdr2, hdr) and np.array_equal(pkt2, pkt)
+        assert np.array_equal(lo, ln) and int(off[0]) == 0
+        dv = np.ctypeslib.as_array((C.c_uint8 * (n * stride)).from_address(dbase))
+        for i in range(n):
+            assert int(off[i]) % 16 == 0 and int(off[i + 1]) == int(off[i]) + ((int(ln[i]) + 15) & ~15)
+            assert dv[int(off[i]):int(off[i]) + int(ln[i])].tobytes() == out[i * stride:i * stride + int(ln[i])].tobytes(), (mode, variant, i)
         plan.close()
 
 

@@ -1,6 +1,7 @@
 """The display path's full-frame passes as stand-alone kernels: colour filter and flips."""
 import ctypes as C
 import os
+import struct
 import sys
 
 import numpy as np
@@ -244,3 +245,56 @@ def test_ingest_sample_set_and_scatter_emulated(case):
             expect = len(need_rows) * (len(need_cols) if S.n_cols else w)
             assert expect <= int(arrived.sum()) <= expect + w * h // 200  # (+ chance matches with the 0xEE fill: none in practice)
     L.achip_sample_set_free(C.byref(S))
+
+
+@pytest.mark.parametrize("force", [None, (3, 1), (5, 2)], ids=["frame-kernel", "spans-3x4K", "spans-5x8K"])
+def test_checksum_and_pack_in_one_pass_emulated(force):
+    """crc_kernels.hpp COPY instantiations: the pass that checksums a slab also compacts it.  Checksums, headers and packet
+    CRCs as the plain pass computes them (and the oracle), offsets and bytes as pack_frames_kernel lays them out -- for
+    frames of every length class (empty, < 16 bytes, ends on / next to a group or span boundary, an overflowed slot), through
+    the one-workgroup-per-frame kernel and through the span kernels (forced small spans), and with a destination too small."""
+    L = emu.lib()
+    L.emu_crc32c_pack.restype = None
+    L.emu_crc32c_pack.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(11)
+    span = force[1] * 4096 if force else 0
+    sizes = [0, 1, 15, 16, 17, 4095, 4096, 4097, 12000, 0xFFFFFFFF]
+    if force:
+        sizes += [span - 1, span, span + 1, 2 * span + 5, force[0] * span - 3, force[0] * span]
+    stride = (max(s for s in sizes if s < 0xFFFFFFF0) + 16 + 15) & ~15
+    n = len(sizes)
+    slab = rng.integers(1, 256, n * stride + 16, dtype=np.uint8)
+    base = slab.ctypes.data + (-slab.ctypes.data % 16)
+    view = np.ctypeslib.as_array((C.c_uint8 * (n * stride)).from_address(base))
+    lens = np.array(sizes, dtype=np.uint32)
+    dims = np.array([(80 + i, 24 + i) for i in range(n)], dtype=np.uint32)
+    off_ref, bytes_ref = packed_reference(view, stride, lens)
+    fp, fr = force if force else (0, 0)
+    for cap in (n * stride, off_ref[n // 2]):
+        crc = np.zeros(n, dtype=np.uint32)
+        hdr = np.zeros(n * 24, dtype=np.uint8)
+        pkt = np.zeros(n, dtype=np.uint32)
+        dst = np.zeros(n * stride + 16, dtype=np.uint8)
+        dbase = dst.ctypes.data + (-dst.ctypes.data % 16)
+        dview = np.ctypeslib.as_array((C.c_uint8 * (n * stride)).from_address(dbase))
+        off = np.zeros(n + 1, dtype=np.uint64)
+        lo = np.zeros(n, dtype=np.uint32)
+        mx = stride if not force else force[0] * span
+        L.emu_crc32c_pack(base, stride, lens.ctypes.data, mx, n, fp, fr, dims.ctypes.data, crc.ctypes.data, hdr.ctypes.data,
+                          pkt.ctypes.data, dbase, cap, off.ctypes.data, lo.ctypes.data)
+        assert list(off) == off_ref and np.array_equal(lo, lens)
+        for i, s in enumerate(sizes):
+            l = 0 if s >= 0xFFFFFFF0 else s
+            frame = view[i * stride:i * stride + l].tobytes()
+            want = 0 if s >= 0xFFFFFFF0 else orc.crc32c(frame)
+            assert int(crc[i]) == want, (force, i, s)
+            w, h = (0, 0) if s >= 0xFFFFFFF0 else (int(dims[i][0]), int(dims[i][1]))
+            hd = struct.pack(">IIIIII", w, h, l, 0, want, 0)
+            assert hdr[24 * i:24 * i + 24].tobytes() == hd, (force, i, s)
+            if s < 0xFFFFFFF0:
+                assert int(pkt[i]) == orc.crc32c(hd + frame), (force, i, s)
+            if off_ref[i] + l <= cap:
+                assert dview[off_ref[i]:off_ref[i] + l].tobytes() == frame, (force, i, s, cap)
+        if cap < n * stride:  # nothing behind the capacity, beyond the last group of a frame that fits, is touched
+            assert not dview[((cap + 15) & ~15):].any()
