@@ -72,8 +72,28 @@ def lib():
         pass
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc, gfx950) first")
-    _lib = _bind(C.CDLL(LIB_PATH))
+    L = C.CDLL(LIB_PATH)
+    # ASCIICHAT_HIP_LIB names another build of THIS library (A/B runs against an older commit's .so): entry points that
+    # build does not have yet are skipped while binding and raise when called
+    _lib = _bind(_OlderBuild(L) if os.environ.get("ASCIICHAT_HIP_LIB") else L)
     return _lib
+
+
+class _OlderBuild:
+    def __init__(self, L):
+        object.__setattr__(self, "_L", L)
+
+    def __getattr__(self, name):
+        try:
+            return getattr(self._L, name)
+        except AttributeError:
+            def missing(*a, **k):
+                raise RuntimeError(f"{LIB_PATH} has no {name}")
+            object.__setattr__(self, name, missing)
+            return missing
+
+    def __setattr__(self, name, value):
+        setattr(self._L, name, value)
 
 
 def _bind(L):
