@@ -334,11 +334,13 @@ static int slot_prepare(asciichat_hip_frame_table_t *t, ft_slot_t *s, size_t byt
   return rc;
 }
 
-/* A whole tick's clients at once: every client's sampled rows are packed into ONE pinned
- * block behind a table of 32-byte records, sent with ONE DMA and put in place by ONE launch -- instead of a DMA and a
- * launch per client (256 clients: ~12 ms of per-call latencies for 35 MB; profiles/r03_bench.json tick_e2e).  Slots must
- * be distinct; they are locked in ascending order.  All blobs must describe frames that `targets` describe (same
- * height).  Semantics per slot are those of frame_table_publish_rows. */
+/* A whole tick's clients at once: every client's sampled part -- the sampled rows, or only the
+ * sampled pixels when the targets read at most half of the frame's columns (achip_sample_set_*) -- is packed into ONE
+ * pinned block behind a table of 32-byte records, sent with ONE DMA and put in place by ONE launch, instead of a DMA and
+ * a launch per client (256 clients: ~12 ms of per-call latencies; profiles/r03_bench.json tick_e2e).  The batch is guarded
+ * by ONE event (the table's ring) and waits once per distinct reader stream.  Slots must be distinct; they are locked in
+ * ascending order.  `targets` may be the tick's render descriptors: a blob is matched with those set up for its geometry,
+ * a blob none of them describes is refused.  Semantics per slot are those of frame_table_publish_rows. */
 int asciichat_hip_frame_table_publish_rows_batch(asciichat_hip_frame_table_t *t, const int *slots, const void *const *blobs,
                                                  const size_t *blob_sizes, int n, const achip_frame_t *targets, int n_targets,
                                                  void *stream) {
@@ -346,7 +348,7 @@ int asciichat_hip_frame_table_publish_rows_batch(asciichat_hip_frame_table_t *t,
     return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame_table_publish_rows_batch: bad arguments");
   typedef struct {
     int slot, k, n_rows, set;
-    uint32_t w, h, set_w;
+    uint32_t w, h;
     const uint8_t *pixels;
     size_t off;
   } item_t;
@@ -401,8 +403,7 @@ int asciichat_hip_frame_table_publish_rows_batch(asciichat_hip_frame_table_t *t,
       }
       n_sets++;
     }
-    it[i].set = si;
-    it[i].set_w = sets[si].w; /* (a set slot may be rebuilt for another geometry later: re-checked when packing) */
+    it[i].set = si; /* (the last set slot may be rebuilt for another geometry later: re-checked when packing) */
     it[i].n_rows = sets[si].n_rows;
     it[i].off = total;
     total += achip_sample_set_block_bytes(&sets[si]);
