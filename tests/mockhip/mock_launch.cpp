@@ -1,7 +1,8 @@
 /*
  * mock_launch.cpp -- hip_launch.hip's entry points on the CPU fiber emulator.  TESTS ONLY (see mock_hip.c).
  * Every launch runs the product kernel (tests/hipemu/emu_driver.cpp includes the unmodified kernel headers) at the call,
- * one launch at a time (the emulator's launch state is global: a mutex), so "streams" are trivially ordered.
+ * one launch at a time (the emulator's launch state is global: a mutex), so "streams" are trivially ordered.  Not
+ * modelled: RCCL (comm.c's collectives) and stream capture.
  */
 #include "../hipemu/emu_driver.cpp"
 
@@ -116,12 +117,48 @@ extern "C" int achip_launch_render_crc(int mode, int variant, int has_composite,
   return rc == 0 ? MOCK_OK : MOCK_INVALID;
 }
 
-/* not modelled: image-space passes, composites materialised on the device */
-extern "C" int achip_launch_resize_batch(const achip_resize_batch_t *, void *) { return MOCK_UNSUPPORTED; }
-extern "C" int achip_launch_comp_poke(achip_composite_t *, const achip_comp_poke_t *, void *) { return MOCK_UNSUPPORTED; }
-extern "C" int achip_launch_composite(const achip_composite_t *, int, int, uint8_t *, void *) { return MOCK_UNSUPPORTED; }
-extern "C" int achip_launch_tint(uint8_t *, int, int, int, uint32_t, void *) { return MOCK_UNSUPPORTED; }
-extern "C" int achip_launch_flip(const uint8_t *, uint8_t *, int, int, int, int, uint32_t, void *) { return MOCK_UNSUPPORTED; }
+/* image-space passes and composites, with the launchers' own choice between the vector and the per-pixel kernels */
+extern "C" int achip_launch_tint(uint8_t *px, int w, int h, int stride, uint32_t ops, void *stream) {
+  (void)stream;
+  std::lock_guard<std::mutex> lock(g_emu_mu);
+  if (stride == 3 * w && (reinterpret_cast<uintptr_t>(px) & 15u) == 0)
+    emu_tint(px, w, h, stride, ops, 1);
+  else
+    emu_tint(px, w, h, stride, ops, 0);
+  return MOCK_OK;
+}
+extern "C" int achip_launch_flip(const uint8_t *src, uint8_t *dst, int w, int h, int src_stride, int dst_stride, uint32_t ops,
+                                 void *stream) {
+  (void)stream;
+  std::lock_guard<std::mutex> lock(g_emu_mu);
+  const bool vec = w % 16 == 0 && src_stride == 3 * w && dst_stride == 3 * w &&
+                   ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0;
+  if (vec)
+    emu_flip(src, dst, w, h, ops, 1);
+  else
+    hipemu::launch(dim3(3), dim3(256), 0, [&] { achip::flip_pixels_kernel(src, dst, w, h, src_stride, dst_stride, ops); });
+  return MOCK_OK;
+}
+extern "C" int achip_launch_composite(const achip_composite_t *comp, int canvas_w, int canvas_h, uint8_t *dst, void *stream) {
+  (void)canvas_w, (void)canvas_h, (void)stream;
+  std::lock_guard<std::mutex> lock(g_emu_mu);
+  emu_composite(comp, dst);
+  return MOCK_OK;
+}
+extern "C" int achip_launch_resize_batch(const achip_resize_batch_t *b, void *stream) {
+  (void)stream;
+  if (!b || b->n <= 0)
+    return MOCK_OK;
+  std::lock_guard<std::mutex> lock(g_emu_mu);
+  emu_resize_batch(b);
+  return MOCK_OK;
+}
+extern "C" int achip_launch_comp_poke(achip_composite_t *comp, const achip_comp_poke_t *poke, void *stream) {
+  (void)stream;
+  for (int k = 0; k < 9; k++) /* comp_poke_kernel (hip_launch.hip): nine pointers */
+    comp->s[k].src = poke->src[k];
+  return MOCK_OK;
+}
 
 /* geometry facts of hip_launch.hip, from the same table (render_variants.h) */
 extern "C" int achip_variant_block(int variant) {

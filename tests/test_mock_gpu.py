@@ -95,6 +95,82 @@ def test_dropin_calls_through_the_combiner(mock, threads):
     assert not errors, errors[:4]
 
 
+def test_dropin_fuzz_on_the_mock(mock):
+    """random sizes, colour levels, render modes, stretch / aspect / padding through the drop-in entry point on the mock: the
+    two-axis pixel gather at every kind of ratio (downscale in one axis and upscale in the other, 1-pixel images, frames wider
+    than their source) against the oracle"""
+    L = mock.lib()
+    rng = np.random.default_rng(2024)
+    for it in range(40):
+        w, h = int(rng.integers(1, 200)), int(rng.integers(1, 150))
+        W, H = int(rng.integers(1, 90)), int(rng.integers(1, 40))
+        cl, rm = int(rng.integers(0, 4)), int(rng.choice([0, 0, 2, 1]))
+        aspect, stretch, pad = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        img = orc.frame_hash_noise(w, h, 3000 + it) if it % 4 else orc.frame_bars(w, h, it)
+        im = as_image(mock, img)
+        c = caps(mock, cl, rm, pad)
+        got = mock.take_string(L.ascii_convert_with_capabilities(C.byref(im), W, H, C.byref(c), aspect, stretch, PAL))
+        exp = orc.convert_with_caps(img, W, H, cl, rm, pad, aspect, stretch)
+        assert got == exp, (it, w, h, W, H, cl, rm, aspect, stretch, pad)
+
+
+def test_display_passes_and_composite_on_the_mock(mock):
+    """the image-space neighbours of the path through the host API on the mock: colour filters and flips as device passes
+    (vector and per-pixel kernels), the display ops folded into a frame's descriptor, the materialised grid composite and the
+    render straight from its sources"""
+    L = mock.lib()
+    for (w, h) in ((64, 20), (37, 11)):  # 16-pixel multiples take the vector kernels
+        img = orc.frame_hash_noise(w, h, w)
+        for flt in (1, 2, 5, 9, 11):
+            buf = np.ascontiguousarray(img).copy()
+            assert L.asciichat_hip_apply_color_filter(buf.ctypes.data, w, h, 3 * w, flt, None) == 0
+            assert np.array_equal(buf, orc.color_filter(img, flt)), (w, h, flt)
+        for fx, fy in ((True, False), (False, True), (True, True)):
+            src = np.ascontiguousarray(img)
+            dst = np.zeros_like(src)
+            assert L.asciichat_hip_image_flip(src.ctypes.data, dst.ctypes.data, w, h, fx, fy, None) == 0
+            assert np.array_equal(dst, orc.flip(img, fx, fy)), (w, h, fx, fy)
+    # display ops folded into the sampler (session_display_convert_to_ascii: flips + colour filter)
+    img = orc.frame_hash_noise(160, 120, 9)
+    keep = np.ascontiguousarray(img)
+    for fx, fy, flt in ((True, False, 0), (False, True, 3), (True, True, 7)):
+        f = mock.frame_setup(keep.ctypes.data, 160, 120, 40, 12, 0, False, False, False)
+        assert L.achip_frame_set_display_ops(C.byref(f), fx, fy, flt) == 0
+        plan = mock.Plan(1, orc.PALETTE_STANDARD, [f])
+        out = np.zeros(plan.stride, dtype=np.uint8)
+        ln = np.zeros(1, dtype=np.uint32)
+        plan.render(out.ctypes.data, plan.stride, ln.ctypes.data)
+        pre = orc.flip(img, fx, fy)
+        pre = orc.color_filter(pre, flt) if flt else pre
+        assert out[:int(ln[0])].tobytes() == orc.convert_with_caps(pre, 40, 12, 3, 0, False, False, False), (fx, fy, flt)
+        plan.close()
+    # grid composite: four sources -> 2x2
+    imgs = [orc.frame_hash_noise(120, 90, 50 + i) if i % 2 else orc.frame_bars(120, 90, i) for i in range(4)]
+    keeps = [np.ascontiguousarray(i) for i in imgs]
+    n = len(imgs)
+    ptrs = (C.c_void_p * n)(*[k.ctypes.data for k in keeps])
+    ws, hs = (C.c_int * n)(*[120] * n), (C.c_int * n)(*[90] * n)
+    comp = mock.Composite()
+    L.achip_composite_setup(C.byref(comp), ptrs, ws, hs, n, 80, 24)
+    ref_canvas = orc.composite(imgs, 80, 24)
+    canvas = np.zeros(ref_canvas.shape, dtype=np.uint8)
+    assert L.asciichat_hip_composite(C.byref(comp), canvas.ctypes.data, None) == 0
+    assert np.array_equal(canvas, ref_canvas)
+    comp_dev = C.c_void_p()
+    assert L.asciichat_hip_composite_upload(C.byref(comp), C.byref(comp_dev)) == 0
+    for mode, cl, rm in ((1, 3, 0), (5, 3, 2)):
+        hh = 48 if rm == 2 else 24
+        f = mock.frame_setup(None, 80, 48, 80, hh, rm, True, True, False)
+        f.comp = comp_dev.value
+        plan = mock.Plan(mode, orc.PALETTE_STANDARD, [f])
+        out = np.zeros(plan.stride, dtype=np.uint8)
+        ln = np.zeros(1, dtype=np.uint32)
+        plan.render(out.ctypes.data, plan.stride, ln.ctypes.data)
+        assert out[:int(ln[0])].tobytes() == orc.convert_with_caps(ref_canvas, 80, hh, cl, rm, True, True, False), mode
+        plan.close()
+    L.asciichat_hip_free(comp_dev)
+
+
 def test_plans_and_packed_output_on_the_mock(mock):
     """plan_create / update / render / render_packed through the emulator: mixed geometries in one batch, exact-length
     frames behind 16-byte aligned offsets"""
