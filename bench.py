@@ -612,10 +612,10 @@ def tick_e2e(torch, pkg, n=256, distinct=32, ticks=(2, 4)):
                 hb = pkg.HostBuffer(tab + n * plan.stride)
             else:
                 plan.update(frames, st)
-            plan.render_packets(slab.data_ptr(), plan.stride, ln.data_ptr(), dims.data_ptr(), crc.data_ptr(), hdr.data_ptr(),
-                                pkt.data_ptr(), st)
-            pkg.pack_frames(slab.data_ptr(), plan.stride, ln.data_ptr(), n, hb.dev + tab, n * plan.stride, hb.dev,
-                            hb.dev + 8 * (n + 1), st)
+            # the send side in one call: frames + checksums + headers, and the frames at their exact lengths in host memory
+            plan.render_packets_packed(slab.data_ptr(), plan.stride, ln.data_ptr(), dims.data_ptr(), crc.data_ptr(),
+                                       hdr.data_ptr(), pkt.data_ptr(), hb.dev + tab, n * plan.stride, hb.dev,
+                                       hb.dev + 8 * (n + 1), st)
             hdr_host = hdr.cpu()  # 6 KB of headers (a blocking copy: also the tick's synchronisation point)
             torch.cuda.synchronize()
             t2 = time.perf_counter()
@@ -643,7 +643,7 @@ def tick_e2e(torch, pkg, n=256, distinct=32, ticks=(2, 4)):
     for p in blobs:
         L.buffer_pool_free(None, p, blob_bytes)
     out["note"] = (f"{n} clients, 1080p -> 80x24 truecolor, blobs in the pinned pool; publish + latest + plan_update + "
-                   "plan_render_packets + pack_frames into mapped host memory per tick; calls issued from Python")
+                   "plan_render_packets_packed (frames + wire stage, exact-length frames into mapped host memory) per tick; calls issued from Python")
     return out
 
 
