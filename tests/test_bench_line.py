@@ -1,0 +1,59 @@
+"""The stdout line of bench.py must be something the driver can parse: one compact JSON
+object, the contract's keys + roofline + cpu_baseline + verify, under 4 KB whatever the run measured -- the 24 KB
+record of round 3 (profiles/r03_bench_driver_flags.json) did not survive the driver's capture."""
+import importlib.util
+import json
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "rccl_ranks", "steps", "warmup", "ms_per_step", "higher_is_better",
+                 "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "verify")
+
+
+@pytest.mark.parametrize("record", ["r03_bench_driver_flags.json", "r03_bench.json", "r02_bench_driver_flags.json"])
+def test_compact_line_of_a_full_record_is_small_and_complete(record, tmp_path):
+    b = _bench()
+    full = json.load(open(os.path.join(ROOT, "profiles", record)))
+    assert len(json.dumps(full)) > 12000  # these are the records that were too large
+    extra = tmp_path / "bench_extra.json"
+    text = b.emit_text(full, str(extra))
+    assert "\n" not in text and len(text) <= b.LINE_TARGET_BYTES < b.LINE_HARD_LIMIT_BYTES
+    line = json.loads(text)
+    for k in CONTRACT_KEYS:
+        assert k in line, k
+    assert line["value"] == pytest.approx(full["value"], rel=1e-5)
+    assert line["config"]["workload"] == full["config"]["workload"]
+    r = line["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "alg_bytes_per_launch", "kernel_ms"):
+        assert k in r, k
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-4)
+    # the fraction follows from the line's own numbers: algorithmic bytes / kernel time / peak
+    assert r["frac"] == pytest.approx(r["alg_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9 / r["peak"], rel=1e-4)
+    c = line["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    # nothing is lost: the side file holds the whole record
+    assert json.load(open(extra)) == full
+    assert line["extra"] == "bench_extra.json"
+
+
+def test_line_shrinks_before_it_fails_and_fails_above_the_hard_limit():
+    b = _bench()
+    full = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_driver_flags.json")))
+    full["other_workloads"] = {f"w{i}" * 8: {"frames_per_s": 1.0 * i, "roofline_frac": 0.1} for i in range(400)}
+    text = b.emit_text(full, "")
+    assert len(text) <= b.LINE_TARGET_BYTES and "other_workloads_fps_frac" not in json.loads(text)
+    full["config"] = {"workload": "x", **{f"k{i}": "v" * 90 for i in range(200)}}
+    with pytest.raises(SystemExit):
+        b.emit_text(full, "")
