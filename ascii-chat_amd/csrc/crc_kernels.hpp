@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(BLOCK)
       if (pack.len_out)
         pack.len_out[i] = len ? len[i] : fixed_len; /* error codes travel as they are */
     }
-    if (off + L <= pack.capacity)
+    if (off + 16ull * ((L + 15u) >> 4) <= pack.capacity) /* whole groups travel: the last one must fit too */
       dst4 = reinterpret_cast<uint4 *>(pack.dst + off);
     /* the frame's last, partial group travels whole, like every other one (the checksum takes its bytes one by one) */
     if (dst4 && (L & 15u) && tid == BLOCK - 1)
@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(256)
       if (pack.len_out)
         pack.len_out[i] = len ? len[i] : fixed_len;
     }
-    if (off + L <= pack.capacity)
+    if (off + 16ull * (((uint64_t)L + 15u) >> 4) <= pack.capacity) /* whole groups travel: the last one must fit too */
       dstb = pack.dst + off + lo;
   }
   const uint8_t *src = base + (size_t)i * stride + lo;

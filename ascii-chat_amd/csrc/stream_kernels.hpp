@@ -142,8 +142,8 @@ __global__ void __launch_bounds__(256)
 /* device: the kernel's stores then ARE the transfer -- exact length, no second DMA, no host round trip for a size.     */
 /* Workgroup (i, y) handles slice y of frame i; every workgroup recomputes the prefix it needs from len[] (n <= a few   */
 /* thousand L2-resident words), so there is no inter-workgroup hand-off.  A frame whose length is a render error code   */
-/* (>= 0xFFFFFFF0) takes no room.  A frame that would end beyond dst_capacity is not copied (the caller sees            */
-/* off[n] > dst_capacity).                                                                                              */
+/* (>= 0xFFFFFFF0) takes no room.  A frame whose last 16-byte group would end beyond dst_capacity is not copied (the      */
+/* caller sees off[n] > dst_capacity).                                                                                  */
 /* ------------------------------------------------------------------------------------------- */
 __device__ inline uint32_t pack_len_ok(uint32_t l) { return l >= 0xFFFFFFF0u ? 0u : l; }
 
@@ -180,11 +180,12 @@ __global__ void __launch_bounds__(256)
     if (len_out)
       len_out[i] = len[i]; /* error codes travel as they are */
   }
-  if (off + l > dst_capacity)
-    return;
   /* slice y of the frame's 16-byte groups; the last group may carry up to 15 stale bytes of the slot behind the frame's
-   * end (the slot is stride >= round16(len) wide), which the padding rule allows */
+   * end (the slot is stride >= round16(len) wide), which the padding rule allows -- so the frame fits only if its last
+   * WHOLE group does: no store ever lands behind dst_capacity, whatever its alignment */
   const uint32_t groups = (l + 15u) >> 4;
+  if (off + 16ull * groups > dst_capacity)
+    return;
   const uint32_t per = (groups + gridDim.y - 1u) / gridDim.y;
   const uint32_t g0 = blockIdx.y * per, g1 = min(groups, g0 + per);
   const uint4 *src4 = reinterpret_cast<const uint4 *>(slab + (uint64_t)i * stride);

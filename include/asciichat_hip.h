@@ -142,7 +142,7 @@ void asciichat_hip_plan_destroy(asciichat_hip_plan_t *plan);
  * Drop-in layer: coalescing of concurrent calls (combine.c).  The reference's server calls
  * ascii_convert_with_capabilities from one render thread per client; from `n` calls in flight on, those calls share
  * launches (flat combining: one upload, one kernel per (mode, palette) group, one wait per generation of callers).
- * n = 0 never, 1 always, default 12 (with hysteresis: off again below 6) -- below that every call launching on its own thread's stream is as fast or faster
+ * n = 0 never, 1 always, default 6 (with hysteresis: off again below 3) -- below that every call launching on its own thread's stream is as fast or faster
  * (profiles/r03_dropin_threads.txt).  Also settable with the environment variable ASCIICHAT_HIP_COALESCE.  Returns the
  * previous setting.
  */
@@ -245,9 +245,10 @@ int asciichat_hip_frame_packets_packed(const uint8_t *base_dev, size_t stride, c
  * round16(len[j]) (frame starts stay 16-byte aligned: <= 15 bytes of padding per frame); frames whose length is a render
  * error code take no room.  off_out (n + 1 entries; [n] = total bytes) and len_out (n, copy of the lengths) may be NULL.
  * dst, off_out and len_out may be device memory or the device alias of mapped pinned host memory (host_alloc below): the
- * kernel's stores are then the transfer itself -- exact length, no second DMA, no host round trip to learn a size.  A
- * frame that would end beyond dst_capacity is not copied (off_out[n] > dst_capacity tells).  plan_render_packed =
- * plan_render + pack_frames on the same stream.
+ * kernel's stores are then the transfer itself -- exact length, no second DMA, no host round trip to learn a size.  Frames
+ * travel in whole 16-byte groups: a frame whose last group (round16(len) bytes from its start) would end beyond
+ * dst_capacity is not copied, and nothing is ever stored at or behind dst + dst_capacity, whatever the capacity's
+ * alignment (off_out[n] > dst_capacity tells).  plan_render_packed = plan_render + pack_frames on the same stream.
  */
 int asciichat_hip_pack_frames(const uint8_t *slab_dev, size_t stride, const uint32_t *len_dev, int n, uint8_t *dst,
                               size_t dst_capacity, uint64_t *off_out, uint32_t *len_out, void *stream);

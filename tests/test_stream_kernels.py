@@ -127,6 +127,22 @@ def test_pack_frames_kernel_emulated():
         dst2 = np.zeros(cap, dtype=np.uint8)
         emu.lib().emu_pack(slab.ctypes.data, stride, lens.ctypes.data, n, dst2.ctypes.data, small, off.ctypes.data, None, slices)
         assert int(off[n]) == off_ref[n] and not dst2[small:].any()
+        # a capacity that is NOT a multiple of 16 -- the exact sum of the lengths up to some frame.  Frames
+        # travel in whole 16-byte groups, so a frame whose last group would cross the capacity is not copied and nothing
+        # is stored at or behind dst + capacity
+        for k in range(n):
+            l = 0 if lens[k] >= 0xFFFFFFF0 else int(lens[k])
+            exact = off_ref[k] + l
+            if exact % 16 == 0:
+                continue
+            guard = np.full(cap + 16, 0xEE, dtype=np.uint8)
+            emu.lib().emu_pack(slab.ctypes.data, stride, lens.ctypes.data, n, guard.ctypes.data, exact, off.ctypes.data, None, slices)
+            assert (guard[exact:] == 0xEE).all(), (n, stride, k)
+            for i in range(k):  # every frame whose last group fits arrived
+                li = 0 if lens[i] >= 0xFFFFFFF0 else int(lens[i])
+                if off_ref[i] + (li + 15) // 16 * 16 <= exact:
+                    assert guard[off_ref[i]:off_ref[i] + li].tobytes() == bytes_ref[off_ref[i]:off_ref[i] + li]
+            break
 
 
 @pytest.mark.gpu
@@ -271,7 +287,7 @@ def test_checksum_and_pack_in_one_pass_emulated(force):
     dims = np.array([(80 + i, 24 + i) for i in range(n)], dtype=np.uint32)
     off_ref, bytes_ref = packed_reference(view, stride, lens)
     fp, fr = force if force else (0, 0)
-    for cap in (n * stride, off_ref[n // 2]):
+    for cap in (n * stride, off_ref[n // 2], off_ref[2] + sizes[2], off_ref[5] + sizes[5], off_ref[7] + sizes[7]):
         crc = np.zeros(n, dtype=np.uint32)
         hdr = np.zeros(n * 24, dtype=np.uint8)
         pkt = np.zeros(n, dtype=np.uint32)
@@ -294,7 +310,7 @@ def test_checksum_and_pack_in_one_pass_emulated(force):
             assert hdr[24 * i:24 * i + 24].tobytes() == hd, (force, i, s)
             if s < 0xFFFFFFF0:
                 assert int(pkt[i]) == orc.crc32c(hd + frame), (force, i, s)
-            if off_ref[i] + l <= cap:
+            if off_ref[i] + (l + 15) // 16 * 16 <= cap:  # frames travel in whole groups: the last one must fit too
                 assert dview[off_ref[i]:off_ref[i] + l].tobytes() == frame, (force, i, s, cap)
-        if cap < n * stride:  # nothing behind the capacity, beyond the last group of a frame that fits, is touched
-            assert not dview[((cap + 15) & ~15):].any()
+        if cap < n * stride:  # nothing at or behind the capacity is touched, whatever its alignment
+            assert not dview[cap:].any()
