@@ -138,6 +138,14 @@ def _bind(L):
     L.asciichat_hip_frame_table_latest.argtypes = [vp, ci, vp, C.POINTER(vp), C.POINTER(ci), C.POINTER(ci),
                                                    C.POINTER(C.c_uint64)]
     L.asciichat_hip_frame_table_forget_stream.restype = None
+    L.asciichat_hip_frame_table_stage.restype = ci
+    L.asciichat_hip_frame_table_stage.argtypes = [vp, ci, vp, sz, C.POINTER(Frame)]
+    L.asciichat_hip_frame_table_commit.restype = ci
+    L.asciichat_hip_frame_table_commit.argtypes = [vp, vp]
+    L.asciichat_hip_frame_table_publish_sampled_batch.restype = ci
+    L.asciichat_hip_frame_table_publish_sampled_batch.argtypes = [vp, C.POINTER(ci), C.POINTER(vp), C.POINTER(C.c_size_t), ci,
+                                                                  C.POINTER(Frame), ci, vp]
+    L.asciichat_hip_ingest_threads.restype = ci
     L.asciichat_hip_frame_table_latest_frames.restype = ci
     L.asciichat_hip_frame_table_latest_frames.argtypes = [vp, C.POINTER(ci), ci, vp, C.POINTER(Frame)]
     L.asciichat_hip_frame_table_forget_stream.argtypes = [vp, vp]
@@ -686,6 +694,35 @@ class FrameTable:
         rc = lib().asciichat_hip_frame_table_publish_rows_batch(self._h, sl, ptrs, sizes, n, arr, len(arr), stream)
         if rc != 0:
             raise RuntimeError(f"frame_table_publish_rows_batch failed: {last_error()}")
+
+    def stage(self, slot, blob, target):
+        """gather what `target` samples of the blob ((address, size) or bytes) into the tick's pinned block; any thread"""
+        t = target if isinstance(target, C.Array) else (Frame * 1)(target)
+        if isinstance(blob, tuple):
+            rc = lib().asciichat_hip_frame_table_stage(self._h, slot, blob[0], blob[1], t)
+        else:
+            b = bytes(blob)
+            rc = lib().asciichat_hip_frame_table_stage(self._h, slot, C.cast(C.c_char_p(b), C.c_void_p), len(b), t)
+        if rc != 0:
+            raise RuntimeError(f"frame_table_stage failed: {last_error()}")
+
+    def commit(self, stream=0):
+        """one DMA for everything staged since the last commit"""
+        if lib().asciichat_hip_frame_table_commit(self._h, stream) != 0:
+            raise RuntimeError(f"frame_table_commit failed: {last_error()}")
+
+    def publish_sampled_batch(self, slots, blobs, targets, stream=0):
+        """a whole tick: stage every blob (on the library's ingest threads) + commit; targets: one Frame for all, or one per blob"""
+        n = len(slots)
+        arr = targets if isinstance(targets, C.Array) else (Frame * len(targets))(*targets)
+        sl = slots if isinstance(slots, C.Array) else (C.c_int * n)(*slots)
+        if isinstance(blobs, tuple) and isinstance(blobs[0], C.Array):
+            ptrs, sizes = blobs
+        else:
+            ptrs, sizes = (C.c_void_p * n)(*[b[0] for b in blobs]), (C.c_size_t * n)(*[b[1] for b in blobs])
+        rc = lib().asciichat_hip_frame_table_publish_sampled_batch(self._h, sl, ptrs, sizes, n, arr, len(arr), stream)
+        if rc != 0:
+            raise RuntimeError(f"frame_table_publish_sampled_batch failed: {last_error()}")
 
     def latest_frames(self, slots, frames, stream=0):
         """frames[i].src = the latest device frame of slots[i] (None when it has none of that descriptor's geometry);

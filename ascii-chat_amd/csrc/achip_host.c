@@ -306,7 +306,18 @@ void achip_stage_gather(const achip_frame_t *f, const uint8_t *host_px, uint8_t 
     if (!cx) {
       memcpy(o, row, row_bytes);
     } else {
-      for (int x = 0; x < w; x++, o += 3) {
+      /* four bytes in, four bytes out per sample (the fourth is overwritten by the next sample): one load and one store
+       * instead of three of each.  The load may reach one byte into the next source row, so the image's last row -- nothing
+       * is known to lie behind it -- and every row's last sample (its fourth byte would land in the next row of dst, or behind
+       * dst) go byte by byte. */
+      int x = 0;
+      if (sy + 1u < (uint32_t)f->src_h)
+        for (; x + 1 < w; x++, o += 3) {
+          uint32_t v;
+          memcpy(&v, row + off[x], 4);
+          memcpy(o, &v, 4);
+        }
+      for (; x < w; x++, o += 3) {
         const uint8_t *p = row + off[x];
         o[0] = p[0], o[1] = p[1], o[2] = p[2];
       }

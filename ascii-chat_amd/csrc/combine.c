@@ -211,6 +211,11 @@ static void cb_confine_thread(void) {
     }
   (void)sched_setaffinity(0, sizeof(keep), &keep);
 }
+static void cb_global_init(void);
+int achip_cpu_budget(void) {
+  pthread_once(&g_cb_once, cb_global_init);
+  return g_cpu_budget;
+}
 static inline int cb_crowded(void) { return __atomic_load_n(&g_cb_callers, __ATOMIC_RELAXED) > g_cpu_budget; }
 
 /* tuning knobs (environment, read once): ASCIICHAT_HIP_CB_{SPIN_US,INFLIGHT,SHARE,LINGER_US,POLL_PAUSE} */
@@ -493,12 +498,18 @@ static void cb_run(cb_t *cb, cb_gen_t *G) {
                                         G->slab_dev + cursor, (uint64_t)stride, G->lens_dev + base, NULL, parts, rpp,
                                         parts > 1 ? S->part_sync : NULL, S->epoch, &uni, S->stream);
     what = "render kernel launch";
+    if (e != hipSuccess)
+      break; /* this group is not counted: `groups` is exactly the number of launches that were enqueued */
     base_of_group[groups] = base;
     n_of_group[groups++] = n;
     cursor += (size_t)n * stride;
   }
-  const int groups_launched = e == hipSuccess ? groups : groups - 1; /* the group whose launch failed is the last one */
-  if (groups_launched > 0 || e == hipSuccess) {
+  /* every path that leaves the loop early (geometry selection, part_sync allocation, the launch itself) does so BEFORE
+   * counting its group, so the groups counted are the groups whose kernels are in the queue -- and whenever anything
+   * at all was enqueued (a kernel, the arena DMA) the stream is drained before the generation may be recycled */
+  const int groups_launched = groups;
+  const int enqueued = groups > 0 || (G->arena_used && G->need_dma);
+  if (enqueued || e == hipSuccess) {
     /* the callers of this generation are parked on it: poll, do not add a driver wake-up to their latency -- but not for
      * ever: past the deadline the stream is synchronised (which reports a wedged queue) and the generation fails */
     hipError_t q;

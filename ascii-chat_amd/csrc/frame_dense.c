@@ -1,0 +1,591 @@
+/*
+ * frame_dense.c -- ingest of SAMPLED IMAGES (VERDICT r3 "next round" 3).
+ *
+ * The renderer point-samples out_w x out_h pixels of a client's frame (image.c:293-325): 1 920 of a 1080p frame's
+ * 2 073 600 for an 80x24 target.  frame_table_publish_rows_batch already uploads only those pixels -- and then a kernel
+ * scatters them back to their 1080p positions so that the render can gather them again from 128-byte lines it mostly
+ * wastes (36 MB fetched for 1.5 MB of samples per 256 clients).  Here the sampled image IS the frame the render reads:
+ *
+ *   stage(slot, blob, target)   any thread (one call per received frame, from the receive thread that holds the blob, or the
+ *                               internal pool of publish_sampled_batch): validates the blob as collect_video_sources does
+ *                               (src/server/stream.c:330-372) and gathers what `target` samples of it -- flips folded in --
+ *                               into the tick's pinned block, W x Hs x 3 bytes, raster order;
+ *   commit(stream)              once per tick: ONE DMA of the block into its twin in HBM, no kernel.  From here on
+ *                               latest_frames() rewrites a descriptor that asks for the staged target onto the sampled image
+ *                               (src_w x src_h = sampled size, ratios 1.0: x * 65536 >> 16 == x, image.c:293-294), so the
+ *                               render's gather is a dense read of 5.6 KB per frame.
+ *
+ * Blocks form a ring of FT_DENSE_RING; a slot that was not staged in a tick keeps pointing at the block of its last
+ * frame, and one commit before that block comes round again the frame is carried forward (host copy of a few KB), so a
+ * pointer handed out by latest_frames() stays good for FT_DENSE_RING - 1 commits.  The DMA into a twin waits, on the GPU,
+ * for every stream that was handed a pointer into it.
+ */
+#define _GNU_SOURCE
+#include <limits.h>
+#include <linux/futex.h>
+#include <sched.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/syscall.h>
+#include <time.h>
+#include <unistd.h>
+
+#include "achip_host.h"
+#include "asciichat_hip.h"
+#include "hip_launch.h"
+#include "internal.h"
+
+#include "frame_table_priv.h"
+
+#define R16(x) (((size_t)(x) + 15u) & ~(size_t)15)
+
+/* ---- the worker pool of publish_sampled_batch ---------------------------------------------------------------------- */
+/* Static partition: a job's items are cut into one contiguous chunk per thread (the caller takes chunk 0), every worker
+ * reports the job number it finished, the poster waits for all of them -- no shared cursor, nothing to reset between jobs.
+ * Workers poll for ASCIICHAT_HIP_INGEST_SPIN_US after a job and then sleep on a futex. */
+#define FT_POOL_MAX 15
+typedef struct {
+  pthread_mutex_t mu; /* one job at a time */
+  pthread_t th[FT_POOL_MAX];
+  int n_workers, started;
+  int seq;    /* futex word: number of the job posted last */
+  int parked; /* workers asleep on seq */
+  int stop;
+  int done[FT_POOL_MAX][16]; /* done[w][0] = last job worker w finished (one cache line each) */
+  void (*fn)(void *ctx, int first, int last);
+  void *ctx;
+  int n_items, n_chunks;
+  long spin_ns;
+} ft_pool_t;
+static ft_pool_t g_pool = {.mu = PTHREAD_MUTEX_INITIALIZER};
+
+static inline void ft_relax(void) {
+#if defined(__x86_64__)
+  __builtin_ia32_pause();
+#elif defined(__aarch64__)
+  __asm__ volatile("yield");
+#endif
+}
+static long long ft_now_ns(void) {
+  struct timespec t;
+  clock_gettime(CLOCK_MONOTONIC, &t);
+  return (long long)t.tv_sec * 1000000000ll + t.tv_nsec;
+}
+static void ft_chunk(int n_items, int n_chunks, int c, int *first, int *last) {
+  *first = (int)((long long)n_items * c / n_chunks);
+  *last = (int)((long long)n_items * (c + 1) / n_chunks);
+}
+static void *ft_worker(void *arg) {
+  ft_pool_t *P = &g_pool;
+  const int w = (int)(intptr_t)arg;
+  int mine = 0;
+  for (;;) {
+    long long t0 = 0;
+    unsigned polls = 0;
+    int s;
+    while ((s = __atomic_load_n(&P->seq, __ATOMIC_ACQUIRE)) == mine) {
+      if (__atomic_load_n(&P->stop, __ATOMIC_RELAXED))
+        return NULL;
+      if ((++polls & 63u) == 0u) {
+        const long long t = ft_now_ns();
+        if (!t0)
+          t0 = t;
+        if (t - t0 >= P->spin_ns) {
+          __atomic_add_fetch(&P->parked, 1, __ATOMIC_SEQ_CST);
+          if (__atomic_load_n(&P->seq, __ATOMIC_SEQ_CST) == mine && !__atomic_load_n(&P->stop, __ATOMIC_RELAXED))
+            (void)syscall(SYS_futex, &P->seq, FUTEX_WAIT_PRIVATE, mine, NULL, NULL, 0);
+          __atomic_sub_fetch(&P->parked, 1, __ATOMIC_SEQ_CST);
+          t0 = 0;
+        }
+      }
+      ft_relax();
+    }
+    mine = s;
+    if (w + 1 < P->n_chunks) { /* chunk 0 is the poster's */
+      int a, b;
+      ft_chunk(P->n_items, P->n_chunks, w + 1, &a, &b);
+      if (b > a)
+        P->fn(P->ctx, a, b);
+    }
+    __atomic_store_n(&P->done[w][0], mine, __ATOMIC_RELEASE);
+  }
+}
+static void ft_pool_start(void) { /* under P->mu */
+  ft_pool_t *P = &g_pool;
+  if (P->started)
+    return;
+  P->started = 1;
+  int n = achip_cpu_budget() / 2; /* half of what the process may keep busy: the receive and send sides want the rest */
+  if (n > 8)
+    n = 8;
+  const char *e = getenv("ASCIICHAT_HIP_INGEST_THREADS");
+  if (e && atoi(e) >= 1)
+    n = atoi(e);
+  if (n > FT_POOL_MAX + 1)
+    n = FT_POOL_MAX + 1;
+  e = getenv("ASCIICHAT_HIP_INGEST_SPIN_US");
+  P->spin_ns = (e && atol(e) >= 0 ? atol(e) : 50) * 1000l;
+  for (int w = 0; w < n - 1; w++) {
+    if (pthread_create(&P->th[w], NULL, ft_worker, (void *)(intptr_t)w) != 0)
+      break;
+    P->n_workers = w + 1;
+  }
+}
+/* fn(ctx, first, last) over [0, n_items) on the pool + the calling thread; returns when every item is done */
+static void ft_pool_run(void (*fn)(void *, int, int), void *ctx, int n_items, int min_per_thread) {
+  ft_pool_t *P = &g_pool;
+  pthread_mutex_lock(&P->mu);
+  ft_pool_start();
+  int chunks = P->n_workers + 1;
+  if (min_per_thread > 0 && chunks > (n_items + min_per_thread - 1) / min_per_thread)
+    chunks = (n_items + min_per_thread - 1) / min_per_thread;
+  if (chunks <= 1) {
+    pthread_mutex_unlock(&P->mu);
+    fn(ctx, 0, n_items);
+    return;
+  }
+  P->fn = fn;
+  P->ctx = ctx;
+  P->n_items = n_items;
+  P->n_chunks = chunks;
+  const int job = __atomic_add_fetch(&P->seq, 1, __ATOMIC_SEQ_CST);
+  if (__atomic_load_n(&P->parked, __ATOMIC_SEQ_CST) > 0)
+    (void)syscall(SYS_futex, &P->seq, FUTEX_WAKE_PRIVATE, INT_MAX, NULL, NULL, 0);
+  int a, b;
+  ft_chunk(n_items, chunks, 0, &a, &b);
+  fn(ctx, a, b);
+  for (int w = 0; w < P->n_workers; w++) { /* every worker acknowledges every job (those without a chunk at once) */
+    unsigned polls = 0;
+    while (__atomic_load_n(&P->done[w][0], __ATOMIC_ACQUIRE) != job) {
+      if ((++polls & 0x3FFu) == 0u)
+        sched_yield();
+      ft_relax();
+    }
+  }
+  pthread_mutex_unlock(&P->mu);
+}
+int asciichat_hip_ingest_threads(void) {
+  ft_pool_t *P = &g_pool;
+  pthread_mutex_lock(&P->mu);
+  ft_pool_start();
+  const int n = P->n_workers + 1;
+  pthread_mutex_unlock(&P->mu);
+  return n;
+}
+
+/* ---- blocks ------------------------------------------------------------------------------------------------------------ */
+void ft_dense_init(asciichat_hip_frame_table_t *t) {
+  pthread_mutex_init(&t->dense_mu, NULL);
+  t->dense_open = -1;
+  const char *e = getenv("ASCIICHAT_HIP_INGEST_ZERO_COPY");
+  t->dense_zero_copy = e && e[0] && e[0] != '0';
+}
+static void blk_free(asciichat_hip_frame_table_t *t, ft_dense_blk_t *b) {
+  if (b->host)
+    (void)hipHostFree(b->host);
+  if (b->dev && !t->dense_zero_copy)
+    (void)hipFree(b->dev);
+  b->host = b->dev = NULL;
+  b->cap = b->dev_cap = 0;
+}
+void ft_dense_destroy(asciichat_hip_frame_table_t *t) {
+  for (int r = 0; r < FT_DENSE_RING; r++) {
+    ft_dense_blk_t *b = &t->dense[r];
+    if (b->done) {
+      (void)hipEventSynchronize(b->done);
+      (void)hipEventDestroy(b->done);
+    }
+    blk_free(t, b);
+  }
+  pthread_mutex_destroy(&t->dense_mu);
+}
+void ft_dense_forget_stream(asciichat_hip_frame_table_t *t, hipStream_t s) {
+  pthread_mutex_lock(&t->dense_mu);
+  for (int r = 0; r < FT_DENSE_RING; r++) {
+    ft_dense_blk_t *b = &t->dense[r];
+    for (int q = 0; q < b->n_readers;)
+      if (b->reader[q] == s)
+        b->reader[q] = b->reader[--b->n_readers];
+      else
+        q++;
+  }
+  pthread_mutex_unlock(&t->dense_mu);
+}
+/* (dense_mu held, nobody gathering into b) room for `cap` bytes in the pinned block; its contents up to `keep` survive */
+static int blk_reserve_host(asciichat_hip_frame_table_t *t, ft_dense_blk_t *b, size_t cap, size_t keep) {
+  if (b->cap >= cap)
+    return 0;
+  uint8_t *h = NULL, *d = NULL;
+  const unsigned flags = t->dense_zero_copy ? hipHostMallocMapped | hipHostMallocPortable : hipHostMallocDefault;
+  int rc = achip_hip_check((int)hipHostMalloc((void **)&h, cap, flags), "hipHostMalloc(sampled-image block)");
+  if (!rc && t->dense_zero_copy)
+    rc = achip_hip_check((int)hipHostGetDevicePointer((void **)&d, h, 0), "hipHostGetDevicePointer");
+  if (rc) {
+    if (h)
+      (void)hipHostFree(h);
+    return rc;
+  }
+  if (keep)
+    memcpy(h, b->host, keep);
+  if (t->dense_zero_copy && b->host) /* renders may still read the old block: nothing of it is reused before they are done */
+    (void)hipDeviceSynchronize();
+  if (b->host)
+    (void)hipHostFree(b->host);
+  b->host = h;
+  b->cap = cap;
+  if (t->dense_zero_copy) {
+    b->dev = d;
+    b->dev_cap = cap;
+  }
+  return 0;
+}
+/* (dense_mu held) the block of the current tick, opened on demand with room for at least `need` bytes */
+static int dense_open(asciichat_hip_frame_table_t *t, size_t need, ft_dense_blk_t **out) {
+  if (t->dense_open >= 0) {
+    *out = &t->dense[t->dense_open];
+    return 0;
+  }
+  ft_dense_blk_t *b = &t->dense[t->dense_next];
+  int rc = 0;
+  if (b->done && b->seq) /* the DMA that read this pinned block FT_DENSE_RING commits ago */
+    rc = achip_hip_check((int)hipEventSynchronize(b->done), "hipEventSynchronize(sampled-image block)");
+  if (t->dense_zero_copy && b->seq && !rc) { /* renders read the pinned block itself: those handed a pointer into it must be done */
+    for (int q = 0; q < b->n_readers && !rc; q++)
+      rc = achip_hip_check((int)hipStreamSynchronize(b->reader[q]), "hipStreamSynchronize(reader)");
+    if (!rc && b->readers_overflow)
+      rc = achip_hip_check((int)hipDeviceSynchronize(), "hipDeviceSynchronize(readers)");
+    b->n_readers = b->readers_overflow = 0;
+  }
+  size_t cap = need > t->dense_want ? need : t->dense_want;
+  cap = R16(cap + cap / 4 + 4096);
+  if (!rc)
+    rc = blk_reserve_host(t, b, cap, 0);
+  if (!rc && !b->done)
+    rc = achip_hip_check((int)hipEventCreateWithFlags(&b->done, hipEventDisableTiming), "hipEventCreate");
+  if (rc)
+    return rc;
+  b->used = 0;
+  t->dense_open = t->dense_next;
+  *out = b;
+  return 0;
+}
+
+/* (dense_mu held) `room` bytes of the open block for a gather that starts now (dense_inflight is raised for it).  A block
+ * that is too small -- a tick of larger targets, or of more publishers, than it was sized for -- grows in place once the
+ * gathers in flight have finished: they never need dense_mu to finish, and nobody can start one without it. */
+static int blk_take(asciichat_hip_frame_table_t *t, ft_dense_blk_t *b, size_t room, size_t *off) {
+  if (b->used + room > b->cap) {
+    for (unsigned polls = 0; __atomic_load_n(&t->dense_inflight, __ATOMIC_ACQUIRE) > 0; polls++) {
+      if ((polls & 0xFFu) == 0xFFu)
+        sched_yield();
+      ft_relax();
+    }
+    const int rc = blk_reserve_host(t, b, R16(2 * (b->used + room)), b->used);
+    if (rc)
+      return rc;
+    if (t->dense_want < b->cap)
+      t->dense_want = b->cap; /* the next tick's block starts out this large */
+  }
+  *off = b->used;
+  b->used += room;
+  __atomic_add_fetch(&t->dense_inflight, 1, __ATOMIC_ACQ_REL);
+  return 0;
+}
+
+/* what `target` samples of a w x h frame: 0 when it takes the frame as it is (nothing to compact: publish the blob) */
+static size_t dense_extent(const achip_frame_t *target, uint32_t w, uint32_t h) {
+  if (!target || target->comp || (uint32_t)target->src_w != w || (uint32_t)target->src_h != h || target->out_w <= 0 ||
+      target->out_h <= 0 || (target->src_stride && target->src_stride != (int32_t)(w * 3u)))
+    return 0;
+  int dw, dh;
+  return achip_stage_extent(target, &dw, &dh);
+}
+
+/* one frame into the open block at `off` (no lock held: this is the part that runs on many threads) */
+static void dense_gather(ft_dense_blk_t *b, size_t off, const achip_frame_t *target, const uint8_t *pixels, achip_frame_t *geo) {
+  *geo = *target;
+  geo->src = NULL;
+  achip_stage_gather(target, pixels, b->host + off, geo);
+}
+static void slot_set_pending(ft_slot_t *s, size_t off, size_t bytes, const achip_frame_t *target, const achip_frame_t *geo,
+                             uint32_t w, uint32_t h) {
+  pthread_mutex_lock(&s->mu);
+  s->pend = 1;
+  s->pend_off = (uint32_t)off;
+  s->pend_bytes = (uint32_t)bytes;
+  s->pend_key = *target;
+  s->pend_key.src = NULL;
+  s->pend_geo = *geo;
+  s->pend_w = (int)w;
+  s->pend_h = (int)h;
+  pthread_mutex_unlock(&s->mu);
+}
+
+int asciichat_hip_frame_table_stage(asciichat_hip_frame_table_t *t, int slot, const void *blob, size_t blob_size,
+                                    const achip_frame_t *target) {
+  if (!t || slot < 0 || slot >= t->n || !blob || !target)
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame_table_stage: bad arguments");
+  uint32_t w = 0, h = 0;
+  const uint8_t *pixels = NULL;
+  if (achip_frame_blob_parse(blob, blob_size, false, &w, &h, &pixels) != 0)
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame_table_stage: frame blob rejected");
+  const size_t bytes = dense_extent(target, w, h);
+  if (!bytes)
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM,
+                      "frame_table_stage: the target does not describe this %ux%u frame, or takes all of it (publish the blob)", w, h);
+  const size_t room = R16(bytes);
+  ft_dense_blk_t *b = NULL;
+  pthread_mutex_lock(&t->dense_mu);
+  int rc = dense_open(t, (size_t)t->n * room, &b);
+  size_t off = 0;
+  if (!rc)
+    rc = blk_take(t, b, room, &off);
+  pthread_mutex_unlock(&t->dense_mu);
+  if (rc)
+    return rc;
+  achip_frame_t geo;
+  dense_gather(b, off, target, pixels, &geo);
+  slot_set_pending(&t->slot[slot], off, bytes, target, &geo, w, h);
+  __atomic_sub_fetch(&t->dense_inflight, 1, __ATOMIC_ACQ_REL);
+  return 0;
+}
+
+/* (dense_mu held, nothing in flight) frames whose block comes round at the NEXT commit move into the open one */
+static int dense_carry_forward(asciichat_hip_frame_table_t *t, ft_dense_blk_t **open) {
+  const int victim = (t->dense_next + 1) % FT_DENSE_RING; /* dense_next == the open block's index (or the one about to open) */
+  if (!t->dense[victim].seq)
+    return 0;
+  int rc = 0;
+  for (int i = 0; i < t->n && !rc; i++) {
+    ft_slot_t *s = &t->slot[i];
+    pthread_mutex_lock(&s->mu);
+    if (s->dense && s->dense_blk == victim && !s->pend) {
+      const size_t room = R16(s->dense_bytes);
+      if (!*open)
+        rc = dense_open(t, (size_t)t->n * room, open);
+      ft_dense_blk_t *b = *open;
+      if (!rc && b->used + room > b->cap)
+        rc = blk_reserve_host(t, b, R16(2 * b->cap + room), b->used);
+      if (!rc) {
+        memcpy(b->host + b->used, t->dense[victim].host + s->dense_off, s->dense_bytes);
+        s->pend = 1;
+        s->pend_off = (uint32_t)b->used;
+        s->pend_bytes = s->dense_bytes;
+        s->pend_key = s->dense_key;
+        s->pend_geo = s->dense_geo;
+        s->pend_w = s->w;
+        s->pend_h = s->h;
+        b->used += room;
+      }
+    }
+    pthread_mutex_unlock(&s->mu);
+  }
+  return rc;
+}
+
+int asciichat_hip_frame_table_commit(asciichat_hip_frame_table_t *t, void *stream) {
+  if (!t)
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame_table_commit: bad arguments");
+  pthread_mutex_lock(&t->dense_mu);
+  for (unsigned polls = 0; __atomic_load_n(&t->dense_inflight, __ATOMIC_ACQUIRE) > 0; polls++) { /* the caller's contract is */
+    if ((polls & 0xFFu) == 0xFFu)                                                               /* "after every stage()";  */
+      sched_yield();                                                                            /* a straggler is waited for */
+    ft_relax();
+  }
+  if (t->dense_open < 0) { /* nothing was staged: no block turns over, nothing needs carrying */
+    pthread_mutex_unlock(&t->dense_mu);
+    return 0;
+  }
+  ft_dense_blk_t *b = &t->dense[t->dense_open];
+  int rc = dense_carry_forward(t, &b);
+  const size_t used = b->used;
+  if (!t->dense_zero_copy) {
+    if (b->dev_cap < b->cap) { /* (hipFree waits for the device: nothing still reads the old twin afterwards) */
+      if (b->dev)
+        (void)hipFree(b->dev);
+      b->dev = NULL;
+      b->dev_cap = 0;
+      rc = achip_hip_check((int)hipMalloc((void **)&b->dev, b->cap), "hipMalloc(sampled-image block)");
+      if (!rc)
+        b->dev_cap = b->cap;
+      b->n_readers = b->readers_overflow = 0;
+    }
+    /* renders that were handed pointers into this twin FT_DENSE_RING commits ago: the DMA goes behind everything enqueued so
+     * far on their streams -- once per distinct stream */
+    if (!rc && b->n_readers > 0) {
+      hipEvent_t ev = NULL;
+      rc = achip_hip_check((int)hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
+      for (int q = 0; q < b->n_readers && !rc; q++) {
+        if (b->reader[q] == (hipStream_t)stream)
+          continue; /* stream order does it */
+        if (hipEventRecord(ev, b->reader[q]) != hipSuccess) { /* a stream destroyed without forget_stream */
+          (void)hipGetLastError();
+          continue;
+        }
+        rc = achip_hip_check((int)hipStreamWaitEvent((hipStream_t)stream, ev, 0), "hipStreamWaitEvent(readers)");
+      }
+      if (ev)
+        (void)hipEventDestroy(ev);
+    }
+    if (!rc && b->readers_overflow)
+      rc = achip_hip_check((int)hipDeviceSynchronize(), "hipDeviceSynchronize(readers)");
+    b->n_readers = b->readers_overflow = 0;
+    if (!rc && used)
+      rc = achip_hip_check((int)hipMemcpyAsync(b->dev, b->host, used, hipMemcpyHostToDevice, (hipStream_t)stream),
+                           "hipMemcpyAsync(sampled images)");
+  }
+  if (!rc)
+    rc = achip_hip_check((int)hipEventRecord(b->done, (hipStream_t)stream), "hipEventRecord(sampled images)");
+  if (!rc) {
+    b->seq = ++t->dense_seq ? t->dense_seq : (t->dense_seq = 1u);
+    for (int i = 0; i < t->n; i++) {
+      ft_slot_t *s = &t->slot[i];
+      pthread_mutex_lock(&s->mu);
+      if (s->pend) {
+        s->pend = 0;
+        s->dense = 1;
+        s->dense_blk = t->dense_open;
+        s->dense_off = s->pend_off;
+        s->dense_bytes = s->pend_bytes;
+        s->dense_key = s->pend_key;
+        s->dense_geo = s->pend_geo;
+        s->w = s->pend_w;
+        s->h = s->pend_h;
+        s->generation++;
+      }
+      pthread_mutex_unlock(&s->mu);
+    }
+    t->dense_next = (t->dense_open + 1) % FT_DENSE_RING;
+    t->dense_open = -1;
+  } else { /* the tick's frames are dropped; the block is filled again from its start */
+    for (int i = 0; i < t->n; i++) {
+      pthread_mutex_lock(&t->slot[i].mu);
+      t->slot[i].pend = 0;
+      pthread_mutex_unlock(&t->slot[i].mu);
+    }
+    t->dense_open = -1;
+  }
+  pthread_mutex_unlock(&t->dense_mu);
+  return rc;
+}
+
+/* ---- a whole tick in one call ------------------------------------------------------------------------------------------ */
+typedef struct {
+  asciichat_hip_frame_table_t *t;
+  ft_dense_blk_t *b;
+  const int *slots;
+  const achip_frame_t *targets;
+  int targets_stride; /* 0: one target for every blob, 1: one per blob */
+  const uint8_t **pixels;
+  const uint32_t *w, *h;
+  const size_t *off, *bytes;
+} dense_job_t;
+static void dense_job(void *ctx, int first, int last) {
+  dense_job_t *J = (dense_job_t *)ctx;
+  for (int i = first; i < last; i++) {
+    const achip_frame_t *tg = &J->targets[(size_t)i * J->targets_stride];
+    achip_frame_t geo;
+    dense_gather(J->b, J->off[i], tg, J->pixels[i], &geo);
+    slot_set_pending(&J->t->slot[J->slots[i]], J->off[i], J->bytes[i], tg, &geo, J->w[i], J->h[i]);
+  }
+}
+
+int asciichat_hip_frame_table_publish_sampled_batch(asciichat_hip_frame_table_t *t, const int *slots, const void *const *blobs,
+                                                    const size_t *blob_sizes, int n, const achip_frame_t *targets, int n_targets,
+                                                    void *stream) {
+  if (!t || !slots || !blobs || !blob_sizes || n <= 0 || !targets || (n_targets != 1 && n_targets != n))
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame_table_publish_sampled_batch: bad arguments (one target, or one per blob)");
+  const uint8_t **pixels = (const uint8_t **)malloc((size_t)n * sizeof(*pixels));
+  uint32_t *wh = (uint32_t *)malloc((size_t)n * 2 * sizeof(uint32_t));
+  size_t *ob = (size_t *)malloc((size_t)n * 2 * sizeof(size_t));
+  int rc = 0;
+  if (!pixels || !wh || !ob)
+    rc = achip_fail(ASCIICHAT_HIP_ERR_MEMORY, "out of memory");
+  size_t total = 0;
+  for (int i = 0; i < n && !rc; i++) {
+    if (slots[i] < 0 || slots[i] >= t->n || !blobs[i])
+      rc = achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame_table_publish_sampled_batch: bad slot or blob at %d", i);
+    else if (achip_frame_blob_parse(blobs[i], blob_sizes[i], false, &wh[i], &wh[n + i], &pixels[i]) != 0)
+      rc = achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame blob %d rejected", i);
+    else {
+      const size_t bytes = dense_extent(&targets[n_targets == 1 ? 0 : i], wh[i], wh[n + i]);
+      if (!bytes)
+        rc = achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM,
+                        "frame_table_publish_sampled_batch: target %d does not describe blob %d (%ux%u), or takes all of it",
+                        n_targets == 1 ? 0 : i, i, wh[i], wh[n + i]);
+      ob[i] = total; /* offsets in call order: clients of one geometry end up at a constant pitch (uniform launches) */
+      ob[n + i] = bytes;
+      total += R16(bytes);
+    }
+  }
+  ft_dense_blk_t *b = NULL;
+  if (!rc) {
+    pthread_mutex_lock(&t->dense_mu);
+    rc = dense_open(t, total, &b);
+    size_t base = 0;
+    if (!rc)
+      rc = blk_take(t, b, total, &base);
+    for (int i = 0; i < n && !rc; i++)
+      ob[i] += base;
+    pthread_mutex_unlock(&t->dense_mu);
+  }
+  if (!rc) {
+    dense_job_t J = {t, b, slots, targets, n_targets == 1 ? 0 : 1, pixels, wh, wh + n, ob, ob + n};
+    ft_pool_run(dense_job, &J, n, 8);
+    __atomic_sub_fetch(&t->dense_inflight, 1, __ATOMIC_ACQ_REL);
+    rc = asciichat_hip_frame_table_commit(t, stream);
+  }
+  free(pixels);
+  free(wh);
+  free(ob);
+  return rc;
+}
+
+/* ---- the getter's side ------------------------------------------------------------------------------------------------- */
+static int same_sampling(const achip_frame_t *a, const achip_frame_t *b) {
+  return !a->comp && a->src_w == b->src_w && a->src_h == b->src_h && a->out_w == b->out_w && a->out_h == b->out_h &&
+         a->x_ratio == b->x_ratio && a->y_ratio == b->y_ratio &&
+         ((a->ops ^ b->ops) & (ACHIP_OP_FLIP_X | ACHIP_OP_FLIP_Y)) == 0 &&
+         (a->src_stride ? a->src_stride : a->src_w * 3) == (b->src_stride ? b->src_stride : b->src_w * 3);
+}
+
+int ft_dense_latest(asciichat_hip_frame_table_t *t, const ft_dense_ref_t *s, void *consumer_stream, achip_frame_t *f,
+                    unsigned *waited, int *rc_out) {
+  /* the caller's descriptor either asks for the staged target (as achip_frame_setup made it) or is the one this function
+   * wrote a tick ago: either way it ends up on the sampled image; padding, tints and the rest of `ops` stay the caller's.
+   * (`s` is a snapshot taken under the slot's lock, which is NOT held here: commit() takes dense_mu, then slot locks.) */
+  *rc_out = 0;
+  if (!same_sampling(f, &s->dense_key) && !same_sampling(f, &s->dense_geo))
+    return 0;
+  ft_dense_blk_t *b = &t->dense[s->dense_blk];
+  pthread_mutex_lock(&t->dense_mu);
+  int rc = 0;
+  if (!(*waited & (1u << s->dense_blk))) { /* work queued on the consumer stream from here on sees the complete DMA */
+    if (!t->dense_zero_copy)
+      rc = achip_hip_check((int)hipStreamWaitEvent((hipStream_t)consumer_stream, b->done, 0), "hipStreamWaitEvent");
+    *waited |= 1u << s->dense_blk;
+    int known = 0;
+    for (int q = 0; q < b->n_readers; q++)
+      known |= b->reader[q] == (hipStream_t)consumer_stream;
+    if (!known) {
+      if (b->n_readers < FT_MAX_READERS)
+        b->reader[b->n_readers++] = (hipStream_t)consumer_stream;
+      else
+        b->readers_overflow = 1;
+    }
+  }
+  const uint8_t *src = b->dev + s->dense_off;
+  pthread_mutex_unlock(&t->dense_mu);
+  *rc_out = rc;
+  if (rc)
+    return 0;
+  f->src = src;
+  f->comp = NULL;
+  f->src_w = s->dense_geo.src_w;
+  f->src_h = s->dense_geo.src_h;
+  f->x_ratio = s->dense_geo.x_ratio;
+  f->y_ratio = s->dense_geo.y_ratio;
+  f->src_stride = s->dense_geo.src_stride;
+  f->ops = (f->ops & ~(uint32_t)(ACHIP_OP_FLIP_X | ACHIP_OP_FLIP_Y)) | (s->dense_geo.ops & (ACHIP_OP_FLIP_X | ACHIP_OP_FLIP_Y));
+  return 1;
+}

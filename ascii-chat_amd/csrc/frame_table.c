@@ -27,47 +27,9 @@
 #include "hip_launch.h"
 #include "internal.h"
 
-#define FT_RING 8
-#define FT_MAX_READERS 32 /* consumer streams remembered per buffer; beyond that a publish synchronises the device */
+#include "frame_table_priv.h"
 
-typedef struct {
-  pthread_mutex_t mu;   /* guards this slot only                                       */
-  hipStream_t reader[2][FT_MAX_READERS]; /* streams that were handed buffer k by latest() since its last upload */
-  int n_readers[2];
-  int readers_overflow[2];
-  hipEvent_t reader_done; /* scratch event: "everything enqueued on a reader stream so far" */
-  uint8_t *dev[2];      /* frame buffers in HBM                                       */
-  size_t cap[2];        /* bytes allocated                                            */
-  hipEvent_t ready[2];  /* recorded after the upload of buffer k (single-slot publishes)  */
-  unsigned batch_of[2]; /* != 0: buffer k was uploaded by batch publish number batch_of[k]; that batch's event (the
-                           table's ring) stands for `ready[k]`, which was not recorded                        */
-  uint8_t *stage[2];    /* pinned staging for blobs that are not in the pinned pool   */
-  size_t stage_cap[2];
-  uint8_t *rows_dev[2]; /* publish_rows: device side of the staged [index table][rows] block */
-  size_t rows_cap[2];
-  int cur;              /* buffer holding the latest complete frame, -1 = none yet    */
-  int w, h;
-  uint64_t generation;
-} ft_slot_t;
-
-struct asciichat_hip_frame_table {
-  int n;
-  ft_slot_t *slot;
-  /* publish_rows_batch: one pinned staging block and its device twin per parity (a tick's block is still being DMA'd
-   * while the next tick's is filled), guarded by batch_mu */
-  pthread_mutex_t batch_mu;
-  uint8_t *batch_host[2], *batch_dev[2];
-  size_t batch_cap[2];
-  hipEvent_t batch_done[2];
-  unsigned batch_no;
-  /* completion of batch publishes: ONE event per batch (not one per slot: 256 hipEventRecord calls and then 256
-   * hipStreamWaitEvent calls per tick were most of a tick's host time).  A ring: slot B % FT_RING holds batch B's event
-   * while ring_seq says so; before the slot is re-recorded for batch B + FT_RING the host waits for batch B, so a
-   * buffer whose batch is no longer in the ring is known to be complete. */
-  pthread_mutex_t ev_mu;
-  hipEvent_t ring[FT_RING];
-  unsigned ring_seq[FT_RING];
-};
+#define FT_SLOT_TURNED_DENSE (-1000) /* latest_one() to latest_frames(): look at the slot again */
 
 int asciichat_hip_frame_table_create(asciichat_hip_frame_table_t **table, int n_slots) {
   if (!table || n_slots <= 0)
@@ -86,6 +48,7 @@ int asciichat_hip_frame_table_create(asciichat_hip_frame_table_t **table, int n_
   t->n = n_slots;
   pthread_mutex_init(&t->batch_mu, NULL);
   pthread_mutex_init(&t->ev_mu, NULL);
+  ft_dense_init(t);
   for (int i = 0; i < n_slots; i++) {
     t->slot[i].cur = -1;
     pthread_mutex_init(&t->slot[i].mu, NULL);
@@ -131,6 +94,7 @@ void asciichat_hip_frame_table_destroy(asciichat_hip_frame_table_t *t) {
       (void)hipEventSynchronize(t->ring[k]);
       (void)hipEventDestroy(t->ring[k]);
     }
+  ft_dense_destroy(t);
   pthread_mutex_destroy(&t->batch_mu);
   pthread_mutex_destroy(&t->ev_mu);
   free(t->slot);
@@ -271,6 +235,7 @@ static int publish_common(asciichat_hip_frame_table_t *t, int slot, const void *
   if (!rc) {
     s->batch_of[k] = 0;
     s->cur = k;
+    s->dense = 0;
     s->w = (int)w;
     s->h = (int)h;
     s->generation++;
@@ -513,6 +478,7 @@ int asciichat_hip_frame_table_publish_rows_batch(asciichat_hip_frame_table_t *t,
     if (!rc) {
       s->batch_of[I->k] = batch_seq;
       s->cur = I->k;
+      s->dense = 0;
       s->w = (int)I->w;
       s->h = (int)I->h;
       s->generation++;
@@ -538,12 +504,31 @@ int asciichat_hip_frame_table_latest_frames(asciichat_hip_frame_table_t *t, cons
     return -achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame_table_latest_frames: bad arguments");
   int with_video = 0;
   unsigned waited_batch = 0; /* frames of one batch publish share its event: the consumer stream waits for it once */
+  unsigned waited_dense = 0; /* ... and so do the sampled images of one commit (one bit per ring block) */
   for (int i = 0; i < n; i++) {
     const uint8_t *px = NULL;
     int w = 0, h = 0;
     if (slots[i] < 0 || slots[i] >= t->n)
       return -achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame_table_latest_frames: bad slot at %d", i);
+    ft_slot_t *s = &t->slot[slots[i]];
+  again:
+    pthread_mutex_lock(&s->mu);
+    if (s->dense) { /* the latest frame is the image one target samples of it (frame_dense.c) */
+      const ft_dense_ref_t ref = {s->dense_blk, s->dense_off, s->dense_key, s->dense_geo};
+      pthread_mutex_unlock(&s->mu);
+      int drc = 0;
+      const int got = ft_dense_latest(t, &ref, consumer_stream, &frames[i], &waited_dense, &drc);
+      if (drc)
+        return -drc;
+      if (!got)
+        frames[i].src = NULL;
+      with_video += got;
+      continue;
+    }
+    pthread_mutex_unlock(&s->mu);
     const int rc = latest_one(t, slots[i], consumer_stream, &px, &w, &h, NULL, &waited_batch);
+    if (rc == FT_SLOT_TURNED_DENSE) /* a commit slipped in between the two looks at the slot */
+      goto again;
     if (rc)
       return -rc;
     const int fits = px && w == frames[i].src_w && h == frames[i].src_h;
@@ -559,6 +544,14 @@ static int latest_one(asciichat_hip_frame_table_t *t, int slot, void *consumer_s
   ft_slot_t *s = &t->slot[slot];
   pthread_mutex_lock(&s->mu);
   int rc = 0;
+  if (s->dense) { /* no full frame to point at: the slot holds what one render target samples of it */
+    *pixels_dev = NULL;
+    pthread_mutex_unlock(&s->mu);
+    if (waited_batch) /* latest_frames(): it serves such slots itself */
+      return FT_SLOT_TURNED_DENSE;
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM,
+                      "frame_table_latest: slot %d holds a sampled image (frame_table_stage); use frame_table_latest_frames", slot);
+  }
   if (s->cur < 0) {
     *pixels_dev = NULL; /* has_video = false (stream.c:272-274) */
     if (width)
@@ -610,6 +603,7 @@ int asciichat_hip_frame_table_latest(asciichat_hip_frame_table_t *t, int slot, v
 void asciichat_hip_frame_table_forget_stream(asciichat_hip_frame_table_t *t, void *consumer_stream) {
   if (!t)
     return;
+  ft_dense_forget_stream(t, (hipStream_t)consumer_stream);
   for (int i = 0; i < t->n; i++) {
     ft_slot_t *s = &t->slot[i];
     pthread_mutex_lock(&s->mu);

@@ -28,6 +28,7 @@ void achip_combine_leave(void);
 unsigned long long achip_combine_stats_clock(void); /* 0 unless ASCIICHAT_HIP_COMBINE_STATS */
 void achip_combine_stats_call(unsigned long long t0);
 int achip_combine_callers(void); /* drop-in render calls in flight right now */
+int achip_cpu_budget(void);      /* CPUs this process may keep busy: affinity mask capped by the cgroup quota */
 int achip_combine_crowded(void); /* ... more of them than CPUs this process may keep busy: sleep, do not poll */
 char *achip_combine_render(int mode, const char *palette, const achip_lut_t *lut, const achip_frame_t *f, size_t src_bytes,
                            int *handled);

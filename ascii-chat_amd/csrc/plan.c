@@ -219,6 +219,9 @@ struct asciichat_hip_plan {
   size_t stride;
   achip_frame_t *frames_dev;
   achip_frame_t *frames_pinned; /* staging for async updates */
+  int frames_dev_stale;         /* plan_update skipped the upload (a uniform launch carries its descriptor in the kernel
+                                   arguments): frames_dev is brought up to date before the first launch that reads it */
+  int frames_dma_queued;        /* a DMA out of frames_pinned may still be in flight on the stream of the last update */
   const achip_lut_t *lut_dev;
 };
 
@@ -361,22 +364,45 @@ int asciichat_hip_plan_create(asciichat_hip_plan_t **plan, int mode, const char 
   return 0;
 }
 
+/* frames_pinned -> frames_dev on `stream` (launches of a plan are ordered on one stream, updates included) */
+static int plan_upload_frames(asciichat_hip_plan_t *p, void *stream) {
+  const int rc = achip_hip_check((int)hipMemcpyAsync(p->frames_dev, p->frames_pinned, (size_t)p->n * sizeof(achip_frame_t),
+                                                     hipMemcpyHostToDevice, (hipStream_t)stream),
+                                 "hipMemcpyAsync(frames)");
+  if (!rc) {
+    p->frames_dev_stale = 0;
+    p->frames_dma_queued = 1;
+  }
+  return rc;
+}
+/* before a launch that reads the descriptor array: make it current */
+static int plan_frames_current(asciichat_hip_plan_t *p, void *stream) {
+  if (!p->frames_dev_stale || asciichat_hip_plan_get_uniform(p))
+    return 0;
+  return plan_upload_frames(p, stream);
+}
+
 int asciichat_hip_plan_update(asciichat_hip_plan_t *p, const achip_frame_t *frames, void *stream) {
   if (!p || !frames)
     return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "plan_update: bad arguments");
   /* the pinned staging copy may still be in flight from the previous update on this stream: wait for it BEFORE the new
    * geometry is committed, so that a failure here leaves the plan as it was */
-  int rc = achip_hip_check((int)hipStreamSynchronize((hipStream_t)stream), "hipStreamSynchronize");
+  int rc = 0;
+  if (p->frames_dma_queued)
+    rc = achip_hip_check((int)hipStreamSynchronize((hipStream_t)stream), "hipStreamSynchronize");
   if (rc)
     return rc;
+  p->frames_dma_queued = 0;
   rc = plan_measure(p, frames);
   if (rc)
     return rc;
-  const size_t bytes = (size_t)p->n * sizeof(achip_frame_t);
-  memcpy(p->frames_pinned, frames, bytes);
-  return achip_hip_check(
-      (int)hipMemcpyAsync(p->frames_dev, p->frames_pinned, bytes, hipMemcpyHostToDevice, (hipStream_t)stream),
-      "hipMemcpyAsync(frames)");
+  memcpy(p->frames_pinned, frames, (size_t)p->n * sizeof(achip_frame_t));
+  p->frames_dev_stale = 1;
+  /* descriptors that differ only by a constant source pitch (a tick's sampled images in one block, a batch of frames in
+   * one slab) travel in the kernel arguments: nothing reads frames_dev, so a tick pays neither the wait nor the DMA */
+  if (asciichat_hip_plan_get_uniform(p))
+    return 0;
+  return plan_upload_frames(p, stream);
 }
 
 size_t asciichat_hip_plan_out_stride(const asciichat_hip_plan_t *p) { return p ? p->stride : 0; }
@@ -444,6 +470,9 @@ static int render_range(asciichat_hip_plan_t *p, int first, int count, uint8_t *
   /* a different epoch per launch makes last launch's hand-off words stale without clearing them; launches of
    * one plan must therefore be ordered (one stream), which updating its descriptors requires anyway */
   p->epoch = p->epoch + 1u ? p->epoch + 1u : 1u;
+  const int fc = plan_frames_current(p, stream);
+  if (fc)
+    return fc;
   achip_uniform_t uni = p->uniform;
   if (p->uniform_off)
     uni.enabled = 0;
@@ -485,6 +514,9 @@ static int plan_render_wire(asciichat_hip_plan_t *p, uint8_t *out_dev, size_t ou
   if (((uintptr_t)wire->hdr & 7u))
     return achip_fail(ASCIICHAT_HIP_ERR_BUFFER, "packet headers must be 8-byte aligned");
   if (asciichat_hip_plan_has_fused_crc(p)) {
+    const int fc = plan_frames_current(p, stream);
+    if (fc)
+      return fc;
     achip_uniform_t uni = p->uniform;
     if (p->uniform_off)
       uni.enabled = 0;

@@ -547,7 +547,7 @@ def wire_stage(torch, pkg, res, steps=None):
                     "(two launches) vs asciichat_hip_plan_render_packets (one launch)"}
 
 
-def tick_e2e(torch, pkg, n=256, distinct=32, ticks=(2, 4)):
+def tick_e2e(torch, pkg, n=256, distinct=32, ticks=(2, 4), forms=("whole_blob", "sampled_rows", "sampled_pixels_batched", "sampled_images")):
     """The end-to-end server tick (SURVEY 8f.2 + path + 8f.3), PCIe included on both sides: n clients' host blobs
     [u32 BE w][u32 BE h][RGB24] (blocks of the pinned pool, as the receive path would fill them) -> frame table ->
     plan_render_packets -> frames in use + headers packed into mapped pinned host memory.  Three publish forms: the whole
@@ -590,14 +590,19 @@ def tick_e2e(torch, pkg, n=256, distinct=32, ticks=(2, 4)):
     ptr_arrs = [(C.c_void_p * n)(*[blobs[(i + t) % distinct] for i in range(n)]) for t in range(distinct)]
     tmpl_arr = (pkg.Frame * 1)(tmpl)
     frames = (pkg.Frame * n)(*[pkg.Frame.from_buffer_copy(tmpl) for _ in range(n)])
-    for form in ("whole_blob", "sampled_rows", "sampled_pixels_batched"):
+    for form in forms:
         t_pub = t_all = 0.0
-        batched = form == "sampled_pixels_batched"
-        n_ticks = ticks[0] if form == "whole_blob" else ticks[1] * (5 if batched else 1)
-        for tick in range(n_ticks + 1):  # the first tick allocates (frame buffers, staging): untimed
+        dense = form == "sampled_images"
+        batched = form == "sampled_pixels_batched" or dense
+        n_ticks = ticks[0] if form == "whole_blob" else ticks[1] * (5 if batched else 1) * (4 if dense else 1)
+        if dense:  # fresh descriptors: latest_frames rewrites them onto the sampled images
+            frames = (pkg.Frame * n)(*[pkg.Frame.from_buffer_copy(tmpl) for _ in range(n)])
+        for tick in range(n_ticks + 2):  # the first ticks allocate (frame buffers, staging, ring blocks): untimed
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            if batched:  # one packed block (sampled pixels), one DMA, one scatter launch for the whole tick
+            if dense:  # the images the targets sample, gathered on the ingest pool: one block, one DMA, NO launch
+                table.publish_sampled_batch(slot_arr, (ptr_arrs[tick % distinct], size_arr), tmpl_arr, st)
+            elif batched:  # one packed block (sampled pixels), one DMA, one scatter launch for the whole tick
                 table.publish_rows_batch(slot_arr, (ptr_arrs[tick % distinct], size_arr), tmpl_arr, st)
             for i in range(0 if batched else n):
                 if form == "whole_blob":
@@ -621,9 +626,10 @@ def tick_e2e(torch, pkg, n=256, distinct=32, ticks=(2, 4)):
             hdr_host = hdr.cpu()  # 6 KB of headers (a blocking copy: also the tick's synchronisation point)
             torch.cuda.synchronize()
             t2 = time.perf_counter()
-            if tick > 0:
+            if tick > 1:
                 t_pub += t1 - t0
                 t_all += t2 - t0
+        n_ticks += 1  # (index of the last tick, for the check below)
         v = hb.view()
         off = v[:8 * (n + 1)].view(np.uint64)
         lh = v[8 * (n + 1):8 * (n + 1) + 4 * n].view(np.uint32)
@@ -635,10 +641,58 @@ def tick_e2e(torch, pkg, n=256, distinct=32, ticks=(2, 4)):
         up = n * (blob_bytes - 8) if form == "whole_blob" else n * (rows * sw * 3 + 16 * ((rows * 4 + 15) // 16))
         if batched:  # [record][row table][column table][H x W sampled pixels] per client
             up = n * (32 + 16 * ((rows * 4 + 15) // 16) + 16 * ((W * 4 + 15) // 16) + 16 * ((rows * W * 3 + 15) // 16))
+        n_ticks -= 1
+        if dense:
+            up = n * 16 * ((rows * W * 3 + 15) // 16)
         out[form] = {"frames_per_s": n * n_ticks / t_all, "ms_per_tick": t_all / n_ticks * 1e3,
                      "publish_ms_per_tick": t_pub / n_ticks * 1e3, "ticks_timed": n_ticks,
                      "pcie_bytes_up_per_tick": int(up), "pcie_bytes_down_per_tick": int(off[n]) + tab + 24 * n,
                      "verified_frames_vs_oracle": 2}
+    if "sampled_images" not in forms:
+        raise ValueError("tick_e2e: the pipelined leg follows the sampled_images form")
+    out["sampled_images"]["ingest_threads"] = L.asciichat_hip_ingest_threads()
+    # the same tick PIPELINED, as a server runs it: tick k+1 is gathered and uploaded (one stream) while tick k renders and
+    # crosses PCIe on its way out (another stream, its own output buffers); the host waits for tick k-1's output only
+    s2 = torch.cuda.Stream()
+    lanes2 = [torch.cuda.current_stream(), s2]
+    plans = [plan, pkg.Plan(mode, PALETTE_STANDARD, list(frames))]
+    slabs = [slab, torch.empty_like(slab)]
+    lns = [ln, torch.zeros_like(ln)]
+    crcs, hdrs, pkts = [crc, torch.zeros_like(crc)], [hdr, torch.zeros_like(hdr)], [pkt, torch.zeros_like(pkt)]
+    hbs = [hb, pkg.HostBuffer(tab + n * plan.stride)]
+    evs = [torch.cuda.Event(), torch.cuda.Event()]
+    n_pipe = ticks[1] * 40
+    t_start = None
+    for tick in range(n_pipe + 4):
+        if tick == 4:
+            torch.cuda.synchronize()
+            t_start = time.perf_counter()
+        k = tick & 1
+        stq = lanes2[k].cuda_stream
+        if tick >= 2:
+            evs[k].synchronize()  # tick - 2 used these buffers: its frames are on the host now (the consumer's cue)
+        table.publish_sampled_batch(slot_arr, (ptr_arrs[tick % distinct], size_arr), tmpl_arr, stq)
+        if table.latest_frames(slot_arr, frames, stq) != n:
+            raise SystemExit("bench.py: tick_e2e: a client without a frame")
+        plans[k].update(frames, stq)
+        plans[k].render_packets_packed(slabs[k].data_ptr(), plan.stride, lns[k].data_ptr(), dims.data_ptr(), crcs[k].data_ptr(),
+                                       hdrs[k].data_ptr(), pkts[k].data_ptr(), hbs[k].dev + tab, n * plan.stride, hbs[k].dev,
+                                       hbs[k].dev + 8 * (n + 1), stq)
+        evs[k].record(lanes2[k])
+    torch.cuda.synchronize()
+    t_pipe = time.perf_counter() - t_start
+    last = (n_pipe + 3)
+    v = hbs[last & 1].view()
+    off = v[:8 * (n + 1)].view(np.uint64)
+    lh = v[8 * (n + 1):8 * (n + 1) + 4 * n].view(np.uint32)
+    for i in (0, n - 1):
+        exp = orc.convert_with_caps(imgs[(i + last) % distinct], W, H, 3, 0, False, False, False)
+        if v[tab + int(off[i]):tab + int(off[i]) + int(lh[i])].tobytes() != exp:
+            raise SystemExit(f"bench.py: tick_e2e (pipelined) frame {i} differs from the oracle")
+    out["sampled_images_pipelined"] = {"frames_per_s": n * n_pipe / t_pipe, "ms_per_tick": t_pipe / n_pipe * 1e3,
+                                       "ticks_timed": n_pipe, "ticks_in_flight": 2, "verified_frames_vs_oracle": 2}
+    plans[1].close()
+    hbs[1].close()
     plan.close()
     hb.close()
     table.close()

@@ -200,6 +200,35 @@ int asciichat_hip_frame_table_publish_rows(asciichat_hip_frame_table_t *table, i
 int asciichat_hip_frame_table_publish_rows_batch(asciichat_hip_frame_table_t *table, const int *slots, const void *const *blobs,
                                                  const size_t *blob_sizes, int n, const achip_frame_t *targets, int n_targets,
                                                  void *stream);
+/*
+ * Ingest of SAMPLED IMAGES (frame_dense.c): the table keeps, per slot, the W x Hs pixels ONE render target samples of the
+ * client's frame (image.c:293-325: 1 920 of a 1080p frame's 2 073 600 for an 80x24 target), in target raster order with
+ * the flips folded in, and latest_frames() points the descriptor at that image (src_w x src_h = sampled size, ratios 1.0:
+ * (x * 65536) >> 16 == x) -- no scatter back to full-frame positions, and the render's gather is a dense read.
+ *   stage    any thread, e.g. each receive thread for the blob it holds (the replacement of collect_video_sources' two
+ *            copies, src/server/stream.c:221-463): validates the blob like publish and gathers what `target` (src_w x src_h
+ *            = the blob's size, no composite; src ignored) samples of it into the tick's pinned block.  ERR_INVALID_PARAM
+ *            when the target takes the frame as it is (nothing to compact: publish the blob).  The block grows as needed.
+ *            A slot staged twice in a tick keeps the later frame.
+ *   commit   once per tick, after every stage() of the tick has returned: ONE DMA of the block into HBM on `stream`, no
+ *            kernel.  The staged slots' latest frame is now the sampled image; a tick without stage() is a no-op.
+ *   publish_sampled_batch = stage for n blobs on the library's own pool of ingest threads (the caller's included;
+ *            ASCIICHAT_HIP_INGEST_THREADS, default half of the CPUs the process may keep busy, at most 8) + commit.
+ *            n_targets == 1 (every blob is rendered to the same target) or == n (targets[i] belongs to blobs[i]).
+ * Getter: frame_table_latest_frames() -- a descriptor that asks for the staged target (the sampling fields: src_w, src_h,
+ * out_w, out_h, ratios, flips), or that latest_frames() itself rewrote a tick ago, is rewritten onto the image; padding,
+ * tints and the other ops stay the caller's; any other descriptor gets src = NULL (stage that target).  A pointer handed
+ * out stays good for work enqueued before the THIRD commit after the one that uploaded it; frame_table_latest() has no
+ * full frame to return for such a slot and fails.  ASCIICHAT_HIP_INGEST_ZERO_COPY=1: no DMA and no twin, renders read
+ * the mapped pinned block itself.
+ */
+int asciichat_hip_frame_table_stage(asciichat_hip_frame_table_t *table, int slot, const void *blob, size_t blob_size,
+                                    const achip_frame_t *target);
+int asciichat_hip_frame_table_commit(asciichat_hip_frame_table_t *table, void *stream);
+int asciichat_hip_frame_table_publish_sampled_batch(asciichat_hip_frame_table_t *table, const int *slots,
+                                                    const void *const *blobs, const size_t *blob_sizes, int n,
+                                                    const achip_frame_t *targets, int n_targets, void *stream);
+int asciichat_hip_ingest_threads(void); /* threads publish_sampled_batch gathers on (starts the pool) */
 int asciichat_hip_frame_table_latest(asciichat_hip_frame_table_t *table, int slot, void *consumer_stream,
                                      const uint8_t **pixels_dev, int *width, int *height, uint64_t *generation);
 /* a tick's latest frames straight into the render descriptors: frames[i].src = the device frame of slots[i] when it has

@@ -12,7 +12,7 @@ INC = os.path.join(ROOT, "include")
 MOCK = os.path.join(ROOT, "tests", "mockhip")
 EMU = os.path.join(ROOT, "tests", "hipemu")
 BUILD = os.path.join(MOCK, "_build")
-HOST_C = ["dropin.c", "combine.c", "plan.c", "achip_host.c", "hostutil.c", "buffer_pool.c", "frame_table.c", "comm.c"]
+HOST_C = ["dropin.c", "combine.c", "plan.c", "achip_host.c", "hostutil.c", "buffer_pool.c", "frame_table.c", "frame_dense.c", "comm.c"]
 HIP_INC = "/opt/rocm/include"
 
 

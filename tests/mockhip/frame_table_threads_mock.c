@@ -2,7 +2,8 @@
  * frame_table_threads_mock.c -- the frame table's host-side locking under load, on the mock runtime (events are tokens, so
  * what is exercised is frame_table.c's own synchronisation: slot locks taken in ascending order by batches, the batch
  * staging lock, the ring of batch events, reader bookkeeping).  TESTS ONLY; run under ThreadSanitizer by
- * tests/test_mock_gpu.py.  Publishers (whole blobs, sampled rows, whole-tick batches over overlapping slot sets) race with
+ * tests/test_mock_gpu.py.  Publishers (whole blobs, sampled rows, whole-tick batches over overlapping slot sets, sampled images staged
+ * per blob and per tick -- frame_dense.c's block ring, carry-forward and ingest pool) race with
  * readers (latest, latest_frames + a "render" whose output depends on exactly the pixels the sampler reads).  A reader checks:
  * a frame handed out has the geometry the table reports, generations never go backwards, and the rendered line equals the
  * line of one of the images that can be in that slot.
@@ -69,13 +70,33 @@ static void *publisher(void *arg) {
   target(&tgt);
   while (!stop) {
     x ^= x << 13, x ^= x >> 17, x ^= x << 5;
-    const int img = (int)(x % IMAGES), form = (int)((x >> 8) % 3);
+    const int img = (int)(x % IMAGES), form = (int)((x >> 8) % 5);
     if (form == 0) {
       if (asciichat_hip_frame_table_publish(table, (int)((x >> 16) % SLOTS), blob[img], blob_bytes, NULL) != 0)
         fail("publish");
     } else if (form == 1) {
       if (asciichat_hip_frame_table_publish_rows(table, (int)((x >> 16) % SLOTS), blob[img], blob_bytes, &tgt, 1, NULL) != 0)
         fail("publish_rows");
+    } else if (form == 3) { /* sampled images: a few receive-thread style stage() calls, then the tick's commit -- racing with
+                               the other publishers' stages and commits (a commit waits for gathers in flight) */
+      for (int k = 0; k < 3; k++) {
+        x ^= x << 13, x ^= x >> 17, x ^= x << 5;
+        if (asciichat_hip_frame_table_stage(table, (int)(x % SLOTS), blob[(img + k) % IMAGES], blob_bytes, &tgt) != 0)
+          fail("stage");
+      }
+      if (asciichat_hip_frame_table_commit(table, NULL) != 0)
+        fail("commit");
+    } else if (form == 4) { /* ... and a whole tick on the ingest pool */
+      int slots[SLOTS], n = 0;
+      const void *blobs[SLOTS];
+      size_t sizes[SLOTS];
+      for (int s = (int)((x >> 16) % 2); s < SLOTS; s += 1 + (int)((x >> 20) % 2)) {
+        slots[n] = s;
+        blobs[n] = blob[(img + n) % IMAGES];
+        sizes[n++] = blob_bytes;
+      }
+      if (asciichat_hip_frame_table_publish_sampled_batch(table, slots, blobs, sizes, n, &tgt, 1, NULL) != 0)
+        fail("publish_sampled_batch");
     } else {
       int slots[SLOTS], n = 0;
       const void *blobs[SLOTS];
@@ -111,8 +132,11 @@ static void *reader(void *arg) {
         const uint8_t *px = NULL;
         int w = 0, h = 0;
         uint64_t gen = 0;
-        if (asciichat_hip_frame_table_latest(table, s, stream, &px, &w, &h, &gen) != 0)
-          fail("latest");
+        if (asciichat_hip_frame_table_latest(table, s, stream, &px, &w, &h, &gen) != 0) {
+          if (px) /* a slot whose latest frame is a sampled image has no full frame to hand out: refused, px stays NULL */
+            fail("latest");
+          continue;
+        }
         if (px && (w != W || h != H))
           fail("geometry of a frame handed out");
         if (gen < last_gen[s])
@@ -195,7 +219,7 @@ int main(int argc, char **argv) {
     free(blob[i]);
   if (failures)
     return 1;
-  printf("ok: 4 publishers (blobs, sampled rows, batches) x 4 readers for %.1f s, %d slots with a frame, all of a published image\n",
+  printf("ok: 4 publishers (blobs, sampled rows, batches, staged sampled images) x 4 readers for %.1f s, %d slots with a frame, all of a published image\n",
          seconds, matched);
   return 0;
 }

@@ -849,6 +849,125 @@ def test_frame_table_publish_rows_batch(gpu):
     table.close()
 
 
+def test_frame_table_sampled_image_ingest(gpu):
+    """frame_dense.c on the MI355X: a tick's clients staged as the images their targets sample
+    -- one pinned block, ONE DMA, NO kernel -- and rendered from those images: bytes equal the oracle's on the original
+    1080p / 4K frames.  256 clients of one geometry in one batch (the descriptors then differ by a constant pitch only:
+    a uniform launch), per-blob stage() + commit, half blocks, a flipped + tinted client, aspect + padding, the descriptor
+    array reused across ticks, a client that stops sending while the ring of blocks turns over."""
+    import struct
+    pkg, torch = gpu
+    stream = torch.cuda.current_stream().cuda_stream
+    w, h = 1920, 1080
+    n = 256
+    distinct = 8
+    table = pkg.FrameTable(n)
+    slots = (C.c_int * n)(*range(n))
+    tmpl = pkg.frame_setup(None, w, h, 80, 24, 0, False, False, False)
+    frames = (pkg.Frame * n)(*[pkg.Frame.from_buffer_copy(tmpl) for _ in range(n)])
+    keep = []
+    for tick in range(3):
+        imgs = [orc.frame_hash_noise(w, h, 5000 + 13 * tick + k) for k in range(distinct)]
+        bufs = [C.create_string_buffer(struct.pack(">II", w, h) + np.ascontiguousarray(im).tobytes(), 8 + im.size) for im in imgs]
+        keep.append(bufs)
+        table.publish_sampled_batch(slots, [(C.addressof(bufs[i % distinct]), len(bufs[i % distinct])) for i in range(n)],
+                                    [tmpl], stream)
+        assert table.latest_frames(slots, frames, stream) == n
+        assert frames[0].src_w == 80 and frames[0].src_h == 24 and frames[0].x_ratio == 1 << 16
+        pitch = frames[1].src - frames[0].src
+        assert pitch == 80 * 24 * 3 and all(frames[i + 1].src - frames[i].src == pitch for i in range(n - 1))
+        got = render_descs(gpu, MODE_TRUE_FG, list(frames))
+        exp = [oracle_convert(im, MODE_TRUE_FG, 80, 24, orc.PALETTE_STANDARD) for im in imgs]
+        for i in range(n):
+            assert got[i] == exp[i % distinct], (tick, i)
+    table.close()
+    # mixed clients, staged one by one: half blocks of a 4K frame, flips + tint, aspect + padding
+    geos = [((3840, 2160), (400, 120, 3, 2), False), ((1920, 1080), (80, 24, 3, 0), False), ((1920, 1080), (80, 24, 3, 0), True),
+            ((1280, 720), (100, 37, 2, 0), False), ((1920, 1080), (80, 24, 3, 2), False)]
+    m = len(geos)
+    table = pkg.FrameTable(m)
+    sl = (C.c_int * m)(*range(m))
+
+    def target(i):
+        (sw, sh), (W, H, cl, rm), asp = geos[i]
+        f = pkg.frame_setup(None, sw, sh, W, H, rm, asp, asp, False)
+        if i == 1:
+            assert pkg.lib().achip_frame_set_display_ops(C.byref(f), True, True, 5) == 0
+        return f
+
+    def expect(i, im):
+        (sw, sh), (W, H, cl, rm), asp = geos[i]
+        if i == 1:
+            im = orc.color_filter(orc.flip(im, True, True), 5)
+        return orc.convert_with_caps(im, W, H, cl, rm, asp, asp, False)
+
+    fr = (pkg.Frame * m)(*[target(i) for i in range(m)])
+    last = [None] * m
+    for tick in range(7):
+        live = [i for i in range(m) if not (i == 4 and tick >= 1)]  # client 4 sends once: carried forward twice over
+        imgs = {i: orc.frame_hash_noise(geos[i][0][0], geos[i][0][1], 6000 + 7 * tick + i) for i in live}
+        bufs = {i: C.create_string_buffer(struct.pack(">II", im.shape[1], im.shape[0]) + np.ascontiguousarray(im).tobytes(), 8 + im.size)
+                for i, im in imgs.items()}
+        keep.append(bufs)
+        for i in live:
+            table.stage(i, (C.addressof(bufs[i]), len(bufs[i])), target(i))
+            last[i] = imgs[i]
+        table.commit(stream)
+        assert table.latest_frames(sl, fr, stream) == m
+        for i in range(m):
+            mode = pkg.lib().achip_mode_from_caps(geos[i][1][2], geos[i][1][3])
+            assert render_descs(gpu, mode, [fr[i]])[0] == expect(i, last[i]), (tick, i)
+    table.close()
+
+
+def test_frame_table_sampled_images_wait_for_queued_readers(gpu):
+    """The ring of sampled-image blocks: a render of tick A's images is queued behind a busy consumer stream, then as many
+    ticks as the ring holds are committed on another stream -- the last of them DMAs into the block tick A's images live in.
+    That DMA must go behind the queued render (the table records an event on every stream it handed pointers of the block)."""
+    import struct
+    pkg, torch = gpu
+    n, w, h = 6, 1920, 1080
+    ticks = [[orc.frame_hash_noise(w, h, 8000 + 10 * t + i) for i in range(n)] for t in range(5)]
+    bufs = [[C.create_string_buffer(struct.pack(">II", w, h) + np.ascontiguousarray(im).tobytes(), 8 + im.size) for im in tk]
+            for tk in ticks]
+    tmpl = pkg.frame_setup(None, w, h, 80, 24, 0, False, False, False)
+    slots = (C.c_int * n)(*range(n))
+    busy_src = torch.from_numpy(np.ascontiguousarray(orc.frame_hash_noise(3840, 2160, 5))).cuda()
+    pub, cons = torch.cuda.Stream(), torch.cuda.Stream()
+    exp = [oracle_convert(im, MODE_TRUE_FG, 80, 24, orc.PALETTE_STANDARD) for im in ticks[0]]
+    for round_ in range(4):
+        table = pkg.FrameTable(n)
+        table.publish_sampled_batch(slots, [(C.addressof(b), len(b)) for b in bufs[0]], [tmpl], pub.cuda_stream)
+        frames = (pkg.Frame * n)(*[pkg.Frame.from_buffer_copy(tmpl) for _ in range(n)])
+        assert table.latest_frames(slots, frames, cons.cuda_stream) == n
+        first_src = frames[0].src
+        busy = pkg.Plan(MODE_HB_TRUE, orc.PALETTE_STANDARD,
+                        [pkg.frame_setup(busy_src.data_ptr(), 3840, 2160, 400, 120, 2, False, False, False)] * 256)
+        bout = torch.empty(256 * busy.stride, dtype=torch.uint8, device="cuda")
+        bln = torch.zeros(256, dtype=torch.int32, device="cuda")
+        for _ in range(8):
+            busy.render(bout.data_ptr(), busy.stride, bln.data_ptr(), cons.cuda_stream)
+        plan = pkg.Plan(MODE_TRUE_FG, orc.PALETTE_STANDARD, list(frames))
+        out = torch.zeros(n * plan.stride, dtype=torch.uint8, device="cuda")
+        ln = torch.zeros(n, dtype=torch.int32, device="cuda")
+        plan.render(out.data_ptr(), plan.stride, ln.data_ptr(), cons.cuda_stream)   # queued, not yet running
+        for t in range(1, 5):  # four more ticks: the fourth lands in tick A's block
+            table.publish_sampled_batch(slots, [(C.addressof(b), len(b)) for b in bufs[t]], [tmpl], pub.cuda_stream)
+        torch.cuda.synchronize()
+        host, lens = out.cpu().numpy(), ln.cpu().numpy()
+        for k in range(n):
+            assert host[k * plan.stride:k * plan.stride + int(lens[k])].tobytes() == exp[k], (round_, k)
+        again = (pkg.Frame * n)(*[pkg.Frame.from_buffer_copy(tmpl) for _ in range(n)])
+        assert table.latest_frames(slots, again, cons.cuda_stream) == n and again[0].src == first_src  # the ring came round
+        got = render_descs(gpu, MODE_TRUE_FG, list(again))
+        for k in range(n):
+            assert got[k] == oracle_convert(ticks[4][k], MODE_TRUE_FG, 80, 24, orc.PALETTE_STANDARD), (round_, k)
+        table.forget_stream(cons.cuda_stream)
+        plan.close()
+        busy.close()
+        table.close()
+
+
 def test_frame_table_upload_waits_for_queued_readers(gpu):
     """the publish after next on a slot overwrites the buffer that renders handed out by latest() may still
     be reading.  A consumer stream is kept busy, a render of frame A is queued behind that work, then B and C are

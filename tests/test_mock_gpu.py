@@ -277,6 +277,90 @@ def test_frame_table_publish_forms_on_the_mock(mock):
     table.close()
 
 
+def _blob(im):
+    return C.create_string_buffer(struct.pack(">II", im.shape[1], im.shape[0]) + np.ascontiguousarray(im).tobytes(), 8 + im.size)
+
+
+def test_frame_table_sampled_image_ingest_on_the_mock(mock):
+    """frame_dense.c on the CPU: a tick's clients staged as the images their targets sample (stage from several threads +
+    commit, and the one-call batch on the library's ingest pool), rendered from those images -- against the oracle on the
+    ORIGINAL frames.  Clients of three geometries, flips and a tint in the descriptors, aspect + padding, a client that stops
+    sending (its frame is carried forward while the ring turns over twice), the same descriptor array reused tick after tick
+    (latest_frames rewrites it), whole-blob publishes alternating with staged ones on one slot, and the refusals."""
+    geos = [(160, 120), (97, 61), (160, 120), (64, 48), (160, 120), (160, 120)]
+    n = len(geos)
+    table = mock.FrameTable(n)
+    slots = (C.c_int * n)(*range(n))
+
+    def targets():
+        t = [mock.frame_setup(None, w, h, 40, 12, 0, i == 4, i == 4, False) for i, (w, h) in enumerate(geos)]
+        mock.lib().achip_frame_set_display_ops(C.byref(t[1]), True, False, 0)   # flip_x
+        mock.lib().achip_frame_set_display_ops(C.byref(t[2]), True, True, 3)    # both flips + a tint
+        return t
+
+    def expect(i, im):
+        f = targets()[i]
+        src = im
+        if f.ops & 1:
+            src = src[:, ::-1]
+        if f.ops & 2:
+            src = src[::-1]
+        if i == 2:
+            src = orc.color_filter(np.ascontiguousarray(src), 3)
+        return orc.convert_with_caps(np.ascontiguousarray(src), 40, 12, 3, 0, i == 4, i == 4, False)
+
+    frames = (mock.Frame * n)(*targets())
+    last = [None] * n
+    for step in range(11):
+        imgs = [orc.frame_hash_noise(w, h, 7000 + 37 * step + i) for i, (w, h) in enumerate(geos)]
+        bufs = [_blob(im) for im in imgs]
+        live = [i for i in range(n) if not (i == 5 and step >= 2)]  # client 5 stops sending after two ticks
+        tg = targets()
+        if step % 2 == 0:  # receive threads stage their own blobs, one commit for the tick
+            ths = [threading.Thread(target=table.stage, args=(i, (C.addressof(bufs[i]), len(bufs[i])), tg[i])) for i in live]
+            for th in ths:
+                th.start()
+            for th in ths:
+                th.join()
+            table.commit()
+        else:
+            table.publish_sampled_batch([slots[i] for i in live], [(C.addressof(bufs[i]), len(bufs[i])) for i in live],
+                                        [tg[i] for i in live])
+        if step == 5:  # a whole blob in between: the slot's latest frame is the full one again
+            table.publish(3, bufs[3].raw[:8 + imgs[3].size])
+            frames[3] = tg[3]
+        for i in live:
+            last[i] = imgs[i]
+        assert table.latest_frames(slots, frames) == n, step
+        if step != 5:
+            # on the sampled images: rows always, columns too when the target reads at most half of them (not 64 -> 40)
+            assert all(frames[i].src_h == frames[i].out_h and frames[i].y_ratio == 1 << 16 for i in range(n)), step
+            assert all(frames[i].src_w == frames[i].out_w and frames[i].x_ratio == 1 << 16 for i in range(n) if i != 3), step
+        plan = mock.Plan(1, orc.PALETTE_STANDARD, list(frames))
+        out = np.zeros(n * plan.stride, dtype=np.uint8)
+        ln = np.zeros(n, dtype=np.uint32)
+        plan.render(out.ctypes.data, plan.stride, ln.ctypes.data)
+        for i in range(n):
+            assert out[i * plan.stride:i * plan.stride + int(ln[i])].tobytes() == expect(i, last[i]), (step, i)
+        plan.close()
+    # a descriptor that asks for something else than what was staged gets no source; the rest keep theirs
+    other = (mock.Frame * n)(*targets())
+    other[0] = mock.frame_setup(None, 160, 120, 30, 10, 0, False, False, False)
+    assert table.latest_frames(slots, other) == n - 1 and not other[0].src
+    with pytest.raises(RuntimeError):  # no full frame behind a staged slot
+        table.latest(0)
+    b = _blob(orc.frame_hash_noise(50, 50, 1))
+    with pytest.raises(RuntimeError):  # the target does not describe a 50x50 frame
+        table.stage(0, (C.addressof(b), len(b)), targets()[0])
+    with pytest.raises(RuntimeError):  # a target that takes the frame as it is: nothing to compact
+        table.stage(0, (C.addressof(b), len(b)), mock.frame_setup(None, 50, 50, 50, 50, 0, False, False, False))
+    with pytest.raises(RuntimeError):  # one target, or one per blob
+        table.publish_sampled_batch([0, 1, 2], [(C.addressof(b), len(b))] * 3, targets()[:2])
+    table.commit()  # nothing staged: a no-op
+    assert mock.lib().asciichat_hip_ingest_threads() >= 1
+    table.close()
+
+
 @pytest.mark.parametrize("san", ["thread", "address,undefined"])
 def test_combiner_under_sanitizers(san):
     """tests/mockhip/dropin_threads_mock.c: the host C compiled with the sanitizer, an arithmetic stand-in for the kernels (no
