@@ -1,0 +1,211 @@
+"""tests/golden/hand_kats.json -- micro-frames whose every output byte was derived BY HAND from a cited reference line, for
+the SURVEY 8(a) rows no reference-held vector reaches (H256, H16, HM, PB, C1-C3) -- checked
+against all four implementations this repository has of those rows:
+  * the C oracle (oracle/asciichat_oracle.c),
+  * the third restatement (tests/restatement.py),
+  * the product's kernels run under the CPU emulator (every geometry that carries the mode), the product's host C for the
+    layout / composite geometry,
+  * and, under -m gpu, the product library on the MI355X through the C-ABI.
+The expectations are data in the JSON; nothing here computes them."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import emu
+import orc
+import restatement as rs
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+KATS = json.load(open(os.path.join(HERE, "golden", "hand_kats.json"), encoding="utf-8"))
+
+# renderer -> (achip mode, oracle call, restatement call, emulator geometries: phase kernel 0 / 4 (+ 2 for the per-cell
+# mode), rows kernel 24 / 25, stream kernel 16-19)
+RENDERERS = {
+    "hb256": (6, lambda im: orc.print_with_caps(im, 2, 2), lambda im: rs.halfblock_256(im), (0, 4, 24, 25)),
+    "hb16": (7, lambda im: orc.print_with_caps(im, 1, 2), lambda im: rs.halfblock_16(im), (0, 4, 24, 25)),
+    "hbmono": (8, lambda im: orc.print_with_caps(im, 0, 2), lambda im: rs.halfblock_mono(im), (0, 4, 24, 25)),
+    "true_bg": (4, lambda im: orc.print_truecolor_bg(im), lambda im: rs.truecolor_bg(im, orc.PALETTE_STANDARD),
+                (0, 2, 4, 16, 17, 18, 19)),
+}
+
+
+def image_of(kat):
+    rows = []
+    for row in kat["rows"]:
+        px = []
+        for count, rgb in row:
+            px += [rgb] * count
+        assert len(px) == kat["w"], kat["name"]
+        rows.append(px)
+    return np.ascontiguousarray(np.array(rows, dtype=np.uint8))
+
+
+def expected(kat):
+    return "".join(g["bytes"] * g.get("repeat", 1) for g in kat["groups"]).encode("utf-8")
+
+
+def test_every_unpinned_row_has_three_hand_kats():
+    per_row = {}
+    for k in KATS["frames"] + KATS["layouts"] + KATS["composites"] + KATS["composite_frames"]:
+        per_row[k["row"]] = per_row.get(k["row"], 0) + 1
+    for row in ("H256", "H16", "HM", "PB"):
+        assert per_row.get(row, 0) >= 3, (row, per_row)
+    assert per_row["C1"] >= 3 and per_row["C2"] + per_row["C3"] >= 3
+    for k in KATS["frames"] + KATS["composite_frames"]:
+        assert all(g["ref"].count(":") >= 1 and g["why"] for g in k["groups"]), k["name"]  # a file:line per byte group
+
+
+@pytest.mark.parametrize("kat", KATS["frames"], ids=[k["name"] for k in KATS["frames"]])
+def test_frame_kats_oracle_restatement_and_emulated_kernels(kat):
+    mode, oracle_fn, restate_fn, variants = RENDERERS[kat["renderer"]]
+    img = image_of(kat)
+    want = expected(kat)
+    assert oracle_fn(img) == want, "oracle"
+    assert restate_fn(img) == want, "third restatement"
+    for v in variants:
+        got = emu.render_frames(mode, [emu.frame_identity(img)], orc.PALETTE_STANDARD, v)[0]
+        assert got == want, f"product kernel, geometry {v}"
+
+
+@pytest.mark.parametrize("kat", KATS["layouts"], ids=[k["name"] for k in KATS["layouts"]])
+def test_layout_kats(kat):
+    dims = [tuple(d) for d in kat["dims"]]
+    tw, th = kat["term"]
+    assert orc.grid_layout(dims, tw, th) == (kat["cols"], kat["rows"]), "oracle"
+    n = len(dims)
+    cols, rows = C.c_int(), C.c_int()
+    emu.lib().achip_grid_layout((C.c_int * n)(*[d[0] for d in dims]), (C.c_int * n)(*[d[1] for d in dims]), n, tw, th,
+                                C.byref(cols), C.byref(rows))
+    assert (cols.value, rows.value) == (kat["cols"], kat["rows"]), "product host C"
+
+
+def sources_of(kat):
+    out = []
+    for s in kat["sources"]:
+        if "fill" in s:
+            out.append(np.ascontiguousarray(np.broadcast_to(np.array(s["fill"], dtype=np.uint8), (s["h"], s["w"], 3))))
+        else:
+            a = np.ascontiguousarray(np.array(s["pixels"], dtype=np.uint8))
+            assert a.shape == (s["h"], s["w"], 3), kat["name"]
+            out.append(a)
+    return out
+
+
+def painted_canvas(kat, srcs):
+    w, h = kat["canvas"]
+    canvas = np.zeros((h, w, 3), dtype=np.uint8)
+    for t in kat["tiles"]:
+        ox, oy = t["org"]
+        for j, sy in enumerate(t["row_map"]):
+            for i, sx in enumerate(t["col_map"]):
+                canvas[oy + j, ox + i] = srcs[t["src"]][sy, sx]
+    return canvas
+
+
+def product_composite(srcs, tw, th):
+    n = len(srcs)
+    comp = emu.Composite()
+    emu.lib().achip_composite_setup(C.byref(comp), (C.c_void_p * n)(*[s.ctypes.data for s in srcs]),
+                                    (C.c_int * n)(*[s.shape[1] for s in srcs]), (C.c_int * n)(*[s.shape[0] for s in srcs]), n, tw, th)
+    return comp
+
+
+@pytest.mark.parametrize("kat", KATS["composites"], ids=[k["name"] for k in KATS["composites"]])
+def test_composite_canvas_kats(kat):
+    srcs = sources_of(kat)
+    tw, th = kat["term"]
+    want = painted_canvas(kat, srcs)
+    assert want.shape == (2 * th, tw, 3)
+    assert orc.grid_layout([(s.shape[1], s.shape[0]) for s in srcs], tw, th) == (kat["cols"], kat["rows"])
+    assert np.array_equal(orc.composite(srcs, tw, th), want), "oracle"
+    comp = product_composite(srcs, tw, th)
+    assert (comp.cols, comp.rows) == (kat["cols"], kat["rows"])
+    out = np.zeros_like(want)
+    emu.lib().emu_composite(C.byref(comp), out.ctypes.data)
+    assert np.array_equal(out, want), "product composite kernel (emulated)"
+
+
+@pytest.mark.parametrize("kat", KATS["composite_frames"], ids=[k["name"] for k in KATS["composite_frames"]])
+def test_composite_frame_kats(kat):
+    srcs = sources_of(kat)
+    tw, th = kat["term"]
+    cl, rm, pad = kat["color_level"], kat["render_mode"], kat["wants_padding"]
+    h = 2 * th if rm == 2 else th  # stream.c:831
+    want = expected(kat)
+    canvas = orc.composite(srcs, tw, th)
+    assert orc.convert_with_caps(canvas, tw, h, cl, rm, pad, True, False) == want, "oracle"
+    assert rs.convert_with_caps(canvas, tw, h, cl, rm, pad, True, False, orc.PALETTE_STANDARD) == want, "third restatement"
+    comp = product_composite(srcs, tw, th)
+    f = emu.Frame()
+    assert emu.lib().achip_frame_setup(C.byref(f), None, tw, 2 * th, tw, h, rm, pad, True, False) == 0
+    f.comp = C.addressof(comp)
+    mode = emu.lib().achip_mode_from_caps(cl, rm)
+    for variant in (2, 0):  # the fused composite sampler of the phase kernel: the canvas is never built
+        assert emu.render_frames(mode, [f], orc.PALETTE_STANDARD, variant)[0] == want, f"product kernel, geometry {variant}"
+
+
+# ---- the same known answers through the product library on the MI355X -------------------------------------------------
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+
+    from __graft_entry__ import load_package
+
+    pkg = load_package()
+    assert torch.cuda.is_available() and pkg.lib().asciichat_hip_device_count() > 0, "these tests need a GPU"
+    torch.cuda.set_device(0)
+    return pkg, torch
+
+
+def _render(gpu, mode, frames, variant=-1):
+    pkg, torch = gpu
+    plan = pkg.Plan(mode, orc.PALETTE_STANDARD, frames)
+    if variant >= 0:
+        plan.set_variant(variant)
+    n = len(frames)
+    out = torch.zeros(n * plan.stride, dtype=torch.uint8, device="cuda")
+    ln = torch.zeros(n, dtype=torch.int32, device="cuda")
+    plan.render(out.data_ptr(), plan.stride, ln.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    host, lens = out.cpu().numpy(), ln.cpu().numpy().astype(np.uint32)
+    plan.close()
+    return [host[k * plan.stride:k * plan.stride + int(lens[k])].tobytes() for k in range(n)]
+
+
+@pytest.mark.gpu
+def test_hand_kats_on_the_gpu(gpu):
+    pkg, torch = gpu
+    for kat in KATS["frames"]:
+        mode, _, _, variants = RENDERERS[kat["renderer"]]
+        img = image_of(kat)
+        dev = torch.from_numpy(img).cuda()
+        f = pkg.Frame()
+        assert pkg.lib().achip_frame_identity(C.byref(f), dev.data_ptr(), img.shape[1], img.shape[0]) == 0
+        for v in (-1,) + tuple(variants):
+            assert _render(gpu, mode, [f, f], v) == [expected(kat)] * 2, (kat["name"], v)
+    for kat in KATS["composites"] + KATS["composite_frames"]:
+        srcs = sources_of(kat)
+        tw, th = kat["term"]
+        dev = [torch.from_numpy(s).cuda() for s in srcs]
+        n = len(srcs)
+        comp = pkg.Composite()
+        pkg.lib().achip_composite_setup(C.byref(comp), (C.c_void_p * n)(*[d.data_ptr() for d in dev]),
+                                        (C.c_int * n)(*[s.shape[1] for s in srcs]), (C.c_int * n)(*[s.shape[0] for s in srcs]), n, tw, th)
+        if "tiles" in kat:
+            want = painted_canvas(kat, srcs)
+            dst = torch.zeros(want.size, dtype=torch.uint8, device="cuda")
+            assert pkg.lib().asciichat_hip_composite(C.byref(comp), dst.data_ptr(), None) == 0
+            torch.cuda.synchronize()
+            assert np.array_equal(dst.cpu().numpy().reshape(want.shape), want), kat["name"]
+            continue
+        cl, rm, pad = kat["color_level"], kat["render_mode"], kat["wants_padding"]
+        h = 2 * th if rm == 2 else th
+        comp_dev = C.c_void_p()
+        assert pkg.lib().asciichat_hip_composite_upload(C.byref(comp), C.byref(comp_dev)) == 0
+        f = pkg.frame_setup(None, tw, 2 * th, tw, h, rm, pad, True, False)
+        f.comp = comp_dev.value
+        assert _render(gpu, pkg.lib().achip_mode_from_caps(cl, rm), [f]) == [expected(kat)], kat["name"]
+        pkg.lib().asciichat_hip_free(comp_dev)
