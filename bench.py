@@ -55,6 +55,9 @@ WORKLOADS = {
     "4k_400x120_halfblock": (3840, 2160, 400, 120, 3, 2),  # configs[4] (K5)
     "1080p_80x24_halfblock": (1920, 1080, 80, 24, 3, 2),   # the metric's shape in half blocks (fg + bg per cell)
     "640x480_80x24_mono": (640, 480, 80, 24, 0, 0),       # configs[0] (K1)
+    # what a server tick renders after the sampled-image ingest (frame_dense.c): the source IS the 80x24 image the target
+    # samples of the client's 1080p frame, ratios 1.0 -- 5.6 KB of dense reads per frame instead of 1 920 lone dwords
+    "sampled_80x24_truecolor": (80, 24, 80, 24, 3, 0),
 }
 INPUT_KINDS = ("noise", "smooth", "bars", "gray")
 
