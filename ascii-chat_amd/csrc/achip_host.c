@@ -607,7 +607,13 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
   /* automatic: whenever whole frames are launched anyway (the split policy below decides that first) */
   const bool may_split = mode != ACHIP_MODE_16_DITHER_BG && !(mode == ACHIP_MODE_TRUE_FG && !palette_ascii_only) &&
                          split_request >= 0 && max_rows > 1 && !(split_request == 0 && 4 * n_frames >= 3 * n_cus);
-  if (forced_variant < 0 && cell_mode && (!may_split || max_wp > variant_caps[0]) &&
+  /* frames small enough for ONE block per wave of a wave-autonomous geometry are never cut into row bands, however few
+   * they are: a lone 80x24 frame takes 6.3 us through stream geometry 16 against 8.4 us as 24 bands of the phase kernel
+   * whose workgroups hand their offsets to each other through global memory, a lone mono frame 7.0 against 8.1 us through
+   * rows geometry 25 (profiles/r04_small_batch_variants.txt); the nine 160x48 targets of the grid -- four blocks per
+   * wave -- stay with the bands (9.6 against 20 us) */
+  const bool one_block_per_wave = cell_mode && split_request == 0 && max_cells <= 16 * (128 - ghost);
+  if (forced_variant < 0 && cell_mode && (!may_split || max_wp > variant_caps[0] || one_block_per_wave) &&
       max_cells <= (long)ACHIP_HOST_STREAM_MAXBLK * (128 - ghost)) {
     /* measured (profiles/r02_stream_sweep.txt): 1024 threads x 2 cells -- one block per wave for a 1080p -> 80x24
      * frame -- is the shortest single launch while every frame has a CU to itself; with more frames than CUs in
@@ -615,6 +621,11 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
      * of several blocks per wave, 512-thread workgroups pack better (four launches in flight, us per step, 16 vs 17: 1080p -> 80x24 truecolor
      * 10.9 vs 8.2, ANSI-256 7.0 vs 6.6, 4K -> 200x60 equal within noise) */
     *variant = (max_cells <= 16 * (128 - ghost) && n_frames <= n_cus) ? 16 : 17;
+    return 0;
+  }
+  if (forced_variant < 0 && run_mode && may_split && split_request == 0 && max_wp <= 256 &&
+      achip_uniform_extent(mode, 25, frames, n_frames) <= 8) {
+    *variant = 25; /* one block of whole rows per wave of its eight: see above */
     return 0;
   }
   if (forced_variant < 0 && run_mode && !may_split && max_wp <= 64 * 7) {

@@ -177,23 +177,29 @@ static void cpu_budget_init(void) {
     if (fp)
       fclose(fp);
   }
+  int quota_limited = 0;
   if (quota > 0 && period > 0) {
     const long long cpus = (quota + period - 1) / period;
-    if (cpus < n)
+    if (cpus < n) {
       n = (int)(cpus < 1 ? 1 : cpus);
+      quota_limited = 1;
+    }
   }
   const char *k = getenv("ASCIICHAT_HIP_CPU_BUDGET");
   if (k && atoi(k) >= 1)
     n = atoi(k);
   g_cpu_budget = n;
+  /* default: confine exactly when a cgroup quota is worth fewer CPUs than the affinity mask shows -- the one situation in
+   * which roaming costs throughput (below); ASCIICHAT_HIP_CONFINE=0 / =1 overrides either way */
   k = getenv("ASCIICHAT_HIP_CONFINE");
-  g_cb_confine = k && k[0] && k[0] != '0';
+  g_cb_confine = k && k[0] ? k[0] != '0' : quota_limited;
 }
-/* ASCIICHAT_HIP_CONFINE=1: a calling thread is confined (once, on its first call) to the first g_cpu_budget CPUs of its
- * affinity mask when the cgroup quota is smaller than the mask.  CFS hands the quota out in per-CPU slices; a hundred
- * threads that sleep and wake all over a 256-CPU box strand it on CPUs that have nothing to run, and the process is
- * throttled at a fraction of its quota (128 callers: 169 k calls/s roaming, 559 k confined to 16 CPUs).  Opt-in: a
- * library does not rearrange its host's threads unasked; `taskset` on the server does the same from outside. */
+/* A calling thread is confined (once, on its first call) to the first g_cpu_budget CPUs of its affinity mask when the
+ * cgroup quota is smaller than the mask.  CFS hands the quota out in per-CPU slices; a hundred threads that sleep and
+ * wake all over a 256-CPU box strand it on CPUs that have nothing to run, and the process is throttled at a fraction of
+ * its quota (128 callers: 169 k calls/s roaming, 559 k confined to 16 CPUs).  On by default in exactly that situation
+ * (round 4: the figure should not depend on the operator having read INTEGRATION.md); ASCIICHAT_HIP_CONFINE=0 leaves
+ * the threads alone, =1 forces it; `taskset` on the server does the same from outside. */
 static void cb_confine_thread(void) {
   static __thread int done;
   if (done)

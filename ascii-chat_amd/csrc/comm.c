@@ -247,14 +247,19 @@ int asciichat_hip_comm_all_gather_packed(asciichat_hip_comm_t *c, const uint8_t 
   if (slots_per_rank == 0)
     return 0;
   const size_t slots = (size_t)slots_per_rank, total = slots * (size_t)c->world;
-  int rc = rccl_check(g_rccl.AllGather(len_dev + (size_t)c->rank * slots, len_dev, slots * sizeof(uint32_t), RCCL_UINT8,
-                                       c->comm, (hipStream_t)stream),
-                      "ncclAllGather(lengths)");
-  if (rc)
-    return rc;
+  /* everything that can fail on THIS rank alone happens before the first collective: a rank that returned
+   * between the two all-gathers would leave the others blocked inside RCCL */
   uint32_t *lens = len_host ? len_host : (uint32_t *)malloc(total * sizeof(uint32_t));
   if (!lens)
     return achip_fail(ASCIICHAT_HIP_ERR_MEMORY, "out of memory");
+  int rc = rccl_check(g_rccl.AllGather(len_dev + (size_t)c->rank * slots, len_dev, slots * sizeof(uint32_t), RCCL_UINT8,
+                                       c->comm, (hipStream_t)stream),
+                      "ncclAllGather(lengths)");
+  if (rc) {
+    if (!len_host)
+      free(lens);
+    return rc;
+  }
   rc = achip_hip_check((int)hipMemcpyAsync(lens, len_dev, total * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream),
                        "hipMemcpyAsync(lengths)");
   if (!rc)
@@ -285,13 +290,18 @@ int asciichat_hip_comm_all_gather_packed(asciichat_hip_comm_t *c, const uint8_t 
         o += l >= 0xFFFFFFF0u ? 0u : ((size_t)l + 15u) & ~(size_t)15;
       }
     }
-    rc = asciichat_hip_pack_frames(slab_dev + (size_t)c->rank * slots * stride, stride, len_dev + (size_t)c->rank * slots,
-                                   slots_per_rank, packed_dev + (size_t)c->rank * block, block, NULL, NULL, stream);
-  }
-  if (!rc)
+    /* from here on every rank holds the same table and the same `block` (the capacity must be the same on every rank: a
+     * block that does not fit fails on all of them alike, above, and nobody enters the second collective).  A pack launch
+     * that fails on this rank alone still joins the exchange -- the others are already on their way into it -- and
+     * reports its error afterwards */
+    const int prc = asciichat_hip_pack_frames(slab_dev + (size_t)c->rank * slots * stride, stride, len_dev + (size_t)c->rank * slots,
+                                              slots_per_rank, packed_dev + (size_t)c->rank * block, block, NULL, NULL, stream);
     rc = rccl_check(g_rccl.AllGather(packed_dev + (size_t)c->rank * block, packed_dev, block, RCCL_UINT8, c->comm,
                                      (hipStream_t)stream),
                     "ncclAllGather(packed)");
+    if (prc)
+      rc = prc;
+  }
   if (!len_host)
     free(lens);
   if (!rc && block_bytes)

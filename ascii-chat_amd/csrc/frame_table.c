@@ -161,23 +161,28 @@ static int publish_common(asciichat_hip_frame_table_t *t, int slot, const void *
                                              : (pr == ACHIP_BLOB_DIMS ? "dimensions out of range" : "size below 8 + 3*w*h"));
   const size_t bytes = (size_t)w * (size_t)h * 3u;
   ft_slot_t *s = &t->slot[slot];
+  /* the fallible host-only work first: slot_prepare consumes the buffer's reader list, and a publish that
+   * then failed would leave a later one on another stream unordered against renders still reading the buffer */
+  uint32_t *rows = NULL;
+  int n_rows = 0;
+  if (targets) {
+    rows = (uint32_t *)malloc((size_t)h * sizeof(uint32_t));
+    uint8_t *mark = (uint8_t *)malloc(h);
+    n_rows = rows && mark ? achip_sampled_rows(targets, n_targets, h, rows, mark) : -2;
+    free(mark);
+    if (n_rows < 0) {
+      free(rows);
+      return n_rows == -2 ? achip_fail(ASCIICHAT_HIP_ERR_MEMORY, "out of memory")
+                          : achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM,
+                                       "frame_table_publish_rows: a target does not describe this %ux%u frame", w, h);
+    }
+  }
   pthread_mutex_lock(&s->mu);
   int k = 0; /* the buffer that does not hold the latest frame */
   int rc = slot_prepare(t, s, bytes, stream, &k, NULL);
   if (!rc && targets) {
     /* sampled rows only: [index table][rows] packed into pinned staging by the host, ONE DMA, one scatter launch */
     const size_t row_bytes = (size_t)w * 3u;
-    uint32_t *rows = (uint32_t *)malloc((size_t)h * sizeof(uint32_t));
-    uint8_t *mark = (uint8_t *)malloc(h);
-    const int n_rows = rows && mark ? achip_sampled_rows(targets, n_targets, h, rows, mark) : -2;
-    free(mark);
-    if (n_rows < 0) {
-      free(rows);
-      pthread_mutex_unlock(&s->mu);
-      return n_rows == -2 ? achip_fail(ASCIICHAT_HIP_ERR_MEMORY, "out of memory")
-                          : achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM,
-                                       "frame_table_publish_rows: a target does not describe this %ux%u frame", w, h);
-    }
     const size_t table = ((size_t)n_rows * 4u + 15u) & ~(size_t)15;
     const size_t staged = table + (size_t)n_rows * row_bytes;
     if (s->stage_cap[k] < staged) {
@@ -209,8 +214,8 @@ static int publish_common(asciichat_hip_frame_table_t *t, int slot, const void *
       rc = achip_hip_check(achip_launch_scatter_rows(s->rows_dev[k], (uint32_t)n_rows, (uint32_t)row_bytes, s->dev[k],
                                                      (uint64_t)row_bytes, stream),
                            "row scatter launch");
-    free(rows);
   }
+  free(rows);
   const void *src = pixels;
   if (!rc && !targets && !achip_pool_device_ptr(pixels)) { /* pageable blob: one copy into pinned staging, then DMA */
     if (s->stage_cap[k] < bytes) {

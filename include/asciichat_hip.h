@@ -324,7 +324,9 @@ int asciichat_hip_comm_all_gather_slab(asciichat_hip_comm_t *comm, uint8_t *slab
  *   off_host             world*slots entries (host): byte offset in packed_dev of every frame after the gather
  *   len_host             world*slots entries (host, may be NULL): the gathered lengths
  *   block_bytes          bytes every rank contributed = what crossed the links per rank (max over ranks, multiple of 16)
- * Synchronises `stream` once (the host must know the sizes).  ERR_BUFFER when a block exceeds the capacity. */
+ * Synchronises `stream` once (the host must know the sizes).  ERR_BUFFER when a block exceeds the capacity -- which must
+ * be the SAME on every rank: all of them then fail alike before the second collective; a failure local to one rank
+ * (its pack launch) is reported after that rank has joined the exchange, so no rank is left waiting inside RCCL. */
 int asciichat_hip_comm_all_gather_packed(asciichat_hip_comm_t *comm, const uint8_t *slab_dev, size_t stride,
                                          uint32_t *len_dev, int slots_per_rank, uint8_t *packed_dev,
                                          size_t packed_capacity_per_rank, uint64_t *off_host, uint32_t *len_host,

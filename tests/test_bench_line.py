@@ -57,3 +57,29 @@ def test_line_shrinks_before_it_fails_and_fails_above_the_hard_limit():
     full["config"] = {"workload": "x", **{f"k{i}": "v" * 90 for i in range(200)}}
     with pytest.raises(SystemExit):
         b.emit_text(full, "")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["grid9", "1080p_80x24_truecolor"])
+def test_bench_two_ranks_on_the_shared_gpu_prints_one_compact_line(workload, tmp_path):
+    """`python bench.py --gpus 2` from a plain shell: bench.py becomes two ranks itself (gloo, both on the one GPU: the N > 1
+    control flow -- barriers, MAX over ranks, the sharded grid with its tile exchange -- without a second device; over RCCL
+    the same command refuses a one-GPU box).  One line on stdout, under the size cap, with the N > 1 fields."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, ASCIICHAT_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    extra = tmp_path / "extra.json"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--workload", workload,
+           "--no-cpu", "--no-d2h", "--no-hot", "--no-wire", "--others", "none", "--extra", str(extra)]
+    if workload == "grid9":
+        cmd += ["--batch", "9"]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1 and len(lines[0]) <= 4096, (len(lines), [len(l) for l in lines])
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and "rccl_ranks" in line and line["scaling"] == "weak"
+    if workload != "grid9":
+        assert len(line["multi_gpu"]["per_rank_frames_per_s"]) == 2 and line["multi_gpu"]["backend"] == "gloo"
+    assert json.load(open(extra))["n_gpus"] == 2

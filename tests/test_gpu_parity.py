@@ -216,7 +216,7 @@ FULL = [
     ("K2 1080p->80x24 ANSI-256 b256", 1920, 1080, 80, 24, 2, 256, 6),
     ("K2' 1080p->80x24 truecolor b256", 1920, 1080, 80, 24, 1, 256, 6),
     ("K3 4K->200x60 truecolor b256", 3840, 2160, 200, 60, 1, 256, 4),
-    ("K5 4K->400x120 half-block truecolor b64", 3840, 2160, 400, 120, 5, 64, 3),
+    ("K5 4K->400x120 half-block truecolor b256", 3840, 2160, 400, 120, 5, 256, 3),  # BASELINE configs[4] at the full batch
 ]
 
 

@@ -57,10 +57,14 @@ def test_split_ragged_batch_and_policy():
         return v.value, p.value, r.value
 
     one = [emu.frame_for_convert(imgs[0], 80, 24, 0)]
-    assert choose(1, one) == (4, 24, 1)                       # a single frame: one text row per workgroup
-    assert choose(1, one * 64) == (4, 4, 6)                   # 64 frames on 256 CUs: 4 bands each
-    assert choose(1, one * 128) == (4, 2, 12)
-    assert choose(1, one * 150) == (2, 2, 12)                 # more bands than CUs: the geometry that fits a band
+    # frames of at most one block per wave are never cut into bands (round 4, profiles/r04_small_batch_variants.txt: a lone
+    # 80x24 frame 6.3 us whole on the stream kernel against 8.4 us as 24 bands; a lone mono frame 7.0 against 8.1 us)
+    assert choose(1, one) == (16, 1, 24)
+    assert choose(1, one * 64) == (16, 1, 24) and choose(1, one * 150) == (16, 1, 24)
+    assert choose(0, one) == (25, 1, 24) and choose(0, one * 64) == (25, 1, 24)   # mono: eight blocks of three rows, one per wave
+    assert choose(5, [emu.frame_for_convert(imgs[0], 80, 24, 2)]) == (25, 1, 24)
+    mid = [emu.frame_for_convert(imgs[0], 160, 48, 0)]        # 7 680 cells: four blocks per wave -- bands still win
+    assert choose(1, mid) == (4, 48, 1) and choose(1, mid * 9)[1] > 1 and choose(0, mid)[1] > 1
     # whole-frame launches of the per-cell modes take the stream kernel (render_stream.hpp): 1024 threads while every
     # frame has a CU to itself, 512-thread workgroups beyond that
     assert choose(1, one * 256) == (16, 1, 24)                # BASELINE batch = one frame per CU: whole frames
@@ -80,7 +84,7 @@ def test_split_ragged_batch_and_policy():
     assert choose(5, [emu.frame_for_convert(imgs[0], 80, 24, 2)] * 600) == (25, 1, 24)  # half-block whole frames: rows kernel
     assert choose(9, one) == (4, 1, 24)                       # serial dither: never split
     assert choose(1, one, ascii_only=False) == (4, 1, 24)     # truecolor-fg with multi-byte glyphs: never split
-    assert choose(2, one, ascii_only=False) == (4, 24, 1)
+    assert choose(2, one, ascii_only=False) == (16, 1, 24)    # (the other per-cell modes carry multi-byte glyphs on the stream kernel)
     assert choose(1, one, req=-1) == (16, 1, 24)             # never split: one whole frame -> stream kernel
     assert choose(1, one, req=12) == (4, 2, 12)
     assert choose(1, one, req=3, forced=2) == (2, 8, 3)
