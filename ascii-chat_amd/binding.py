@@ -107,6 +107,10 @@ def _bind(L):
     L.asciichat_hip_plan_update.argtypes = [vp, C.POINTER(Frame), vp]
     L.asciichat_hip_plan_out_stride.restype = sz
     L.asciichat_hip_plan_out_stride.argtypes = [vp]
+    L.asciichat_hip_plan_get_exact_length.restype = ci
+    L.asciichat_hip_plan_get_exact_length.argtypes = [vp]
+    L.asciichat_hip_plan_set_exact_length.restype = ci
+    L.asciichat_hip_plan_set_exact_length.argtypes = [vp, ci]
     L.asciichat_hip_plan_set_variant.restype = ci
     L.asciichat_hip_plan_set_variant.argtypes = [vp, ci]
     L.asciichat_hip_plan_get_variant.restype = ci
@@ -409,6 +413,16 @@ class Plan:
 
     def set_uniform(self, allow):
         lib().asciichat_hip_plan_set_uniform(self._h, 1 if allow else 0)
+
+    @property
+    def exact_length(self):
+        """True when the packed entry points are ONE launch that writes the frames at their exact lengths itself (no slab;
+        frames in completion order, off_out tells where)"""
+        return bool(lib().asciichat_hip_plan_get_exact_length(self._h))
+
+    def set_exact_length(self, mode):
+        if lib().asciichat_hip_plan_set_exact_length(self._h, mode) != 0:
+            raise RuntimeError(f"set_exact_length({mode}) failed: {last_error()}")
 
     def set_split(self, rows_per_part):
         rc = lib().asciichat_hip_plan_set_split(self._h, rows_per_part)

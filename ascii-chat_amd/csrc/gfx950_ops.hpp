@@ -61,6 +61,9 @@ __device__ inline void agent_store_u64(unsigned long long *p, unsigned long long
 __device__ inline unsigned long long agent_load_u64(const unsigned long long *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ inline unsigned long long agent_fetch_add_u64(unsigned long long *p, unsigned long long v) {
+  return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 template <int N> __device__ inline void spin_nap() { __builtin_amdgcn_s_sleep(N); }
 __device__ inline void wg_store_u32(uint32_t *p, uint32_t v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

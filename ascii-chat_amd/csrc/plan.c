@@ -222,6 +222,8 @@ struct asciichat_hip_plan {
   int frames_dev_stale;         /* plan_update skipped the upload (a uniform launch carries its descriptor in the kernel
                                    arguments): frames_dev is brought up to date before the first launch that reads it */
   int frames_dma_queued;        /* a DMA out of frames_pinned may still be in flight on the stream of the last update */
+  int exact_length;             /* -1 = the packed entry points are ONE launch wherever the plan qualifies (default), 0 = never */
+  unsigned long long *pack_cursor; /* two device words of the PACK kernels, zero between launches (allocated on first use) */
   const achip_lut_t *lut_dev;
 };
 
@@ -340,6 +342,7 @@ int asciichat_hip_plan_create(asciichat_hip_plan_t **plan, int mode, const char 
   p->n = n_frames;
   p->variant_user = -1;
   p->fused_crc = -1;
+  p->exact_length = -1;
   p->concurrency = 1;
   p->palette_ascii = achip_palette_ascii_only(palette_chars) ? 1 : 0;
   rc = plan_measure(p, frames);
@@ -558,12 +561,63 @@ int asciichat_hip_plan_render_packets(asciichat_hip_plan_t *p, uint8_t *out_dev,
 /* ... and the frames at their exact lengths behind it (pack_frames' layout; dst may be mapped host memory): a plan whose
  * kernel carries the fused CRC renders (one launch) and packs; any other plan renders and then checksums AND packs in one
  * pass over the slab (asciichat_hip_frame_packets_packed) -- two launches either way. */
+/* ---- frames at their exact lengths straight from the render kernel ------------------------- */
+/* Whole-frame launches of the per-cell foreground modes whose frames fit the kernel's LDS image (48 KB: 1080p -> 80x24
+ * truecolor is 36 KB) go through the PACK instantiations of the stream kernel: ONE launch leaves the frames back to back in
+ * dst -- in the order in which they finish; off_out says where each one went -- together with the checksums and headers;
+ * the slab is not written at all (ship exactly frame_size bytes, lib/network/acip/server.c:190-222). */
+int asciichat_hip_plan_get_exact_length(const asciichat_hip_plan_t *p) {
+  if (!p || p->exact_length == 0 || p->parts != 1 || p->has_comp || !ACHIP_IS_STREAM_VARIANT(p->variant))
+    return 0;
+  if (!(p->mode == ACHIP_MODE_256_FG || p->mode == ACHIP_MODE_16_FG || (p->mode == ACHIP_MODE_TRUE_FG && p->palette_ascii)))
+    return 0;
+  return p->stride <= (size_t)achip_pack_frame_cap();
+}
+int asciichat_hip_plan_set_exact_length(asciichat_hip_plan_t *p, int mode) {
+  if (!p || mode < -1 || mode > 0)
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "plan_set_exact_length: -1 (wherever the plan qualifies) or 0 (never)");
+  p->exact_length = mode;
+  return 0;
+}
+static int plan_render_pack(asciichat_hip_plan_t *p, uint32_t *out_len_dev, const achip_wire_t *wire, uint8_t *dst,
+                            size_t dst_capacity, uint64_t *off_out, uint32_t *len_out, void *stream) {
+  if (!out_len_dev || !dst || ((uintptr_t)dst & 15u) || ((uintptr_t)off_out & 7u) || ((uintptr_t)len_out & 3u) ||
+      (wire && ((uintptr_t)wire->hdr & 7u)))
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "plan_render_*packed: bad arguments (16-byte aligned destination, 8-byte aligned offsets / headers)");
+  if (!p->pack_cursor) {
+    int rc = achip_hip_check((int)hipMalloc((void **)&p->pack_cursor, 2 * sizeof(unsigned long long)), "hipMalloc(pack cursor)");
+    if (!rc)
+      rc = achip_hip_check((int)hipMemset(p->pack_cursor, 0, 2 * sizeof(unsigned long long)), "hipMemset(pack cursor)");
+    if (rc) {
+      if (p->pack_cursor)
+        (void)hipFree(p->pack_cursor);
+      p->pack_cursor = NULL;
+      return rc;
+    }
+  }
+  const int fc = plan_frames_current(p, stream);
+  if (fc)
+    return fc;
+  achip_uniform_t uni = p->uniform;
+  if (p->uniform_off)
+    uni.enabled = 0;
+  uni.flags = (p->palette_ascii ? ACHIP_UNIFORM_PALETTE_ASCII : 0u) | ACHIP_UNIFORM_MAX_CELLS(achip_uniform_extent(p->mode, 16, p->frames_pinned, p->n));
+  const achip_packdev_t pack = {dst, (uint64_t)dst_capacity, off_out, len_out, p->pack_cursor};
+  return achip_hip_check(achip_launch_render_pack(p->mode, p->frames_dev, p->n, p->lut_dev, (uint64_t)p->stride, out_len_dev, wire, &uni,
+                                                  &pack, stream),
+                         "render + pack kernel launch");
+}
+
 int asciichat_hip_plan_render_packets_packed(asciichat_hip_plan_t *p, uint8_t *slab_dev, size_t out_stride, uint32_t *out_len_dev,
                                              const uint32_t *dims_dev, uint32_t *crc_out_dev, uint8_t *hdr_out_dev,
                                              uint32_t *packet_crc_out_dev, uint8_t *dst, size_t dst_capacity, uint64_t *off_out,
                                              uint32_t *len_out, void *stream) {
   if (!p || !hdr_out_dev || !dst)
     return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "plan_render_packets_packed: no header buffer or destination");
+  if (asciichat_hip_plan_get_exact_length(p) && crc_out_dev) {
+    const achip_wire_t wire = {crc_out_dev, dims_dev, hdr_out_dev, packet_crc_out_dev};
+    return plan_render_pack(p, out_len_dev, &wire, dst, dst_capacity, off_out, len_out, stream);
+  }
   if (asciichat_hip_plan_has_fused_crc(p)) {
     int rc = asciichat_hip_plan_render_packets(p, slab_dev, out_stride, out_len_dev, dims_dev, crc_out_dev, hdr_out_dev,
                                                packet_crc_out_dev, stream);
@@ -781,6 +835,8 @@ void asciichat_hip_plan_destroy(asciichat_hip_plan_t *p) {
     (void)hipHostFree(p->frames_pinned);
   if (p->part_sync)
     (void)hipFree(p->part_sync);
+  if (p->pack_cursor)
+    (void)hipFree(p->pack_cursor);
   achip_lut_put(p->lut_dev);
   free(p);
 }
@@ -934,6 +990,8 @@ int asciichat_hip_pack_frames(const uint8_t *slab_dev, size_t stride, const uint
 
 int asciichat_hip_plan_render_packed(asciichat_hip_plan_t *p, uint8_t *slab_dev, size_t out_stride, uint32_t *out_len_dev,
                                      uint8_t *dst, size_t dst_capacity, uint64_t *off_out, uint32_t *len_out, void *stream) {
+  if (asciichat_hip_plan_get_exact_length(p) && dst)
+    return plan_render_pack(p, out_len_dev, NULL, dst, dst_capacity, off_out, len_out, stream);
   int rc = asciichat_hip_plan_render(p, slab_dev, out_stride, out_len_dev, stream);
   if (!rc)
     rc = asciichat_hip_pack_frames(slab_dev, out_stride, out_len_dev, p->n, dst, dst_capacity, off_out, len_out, stream);

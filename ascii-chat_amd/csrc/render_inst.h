@@ -29,6 +29,11 @@ ACHIP_VARIANTS(X)
 ACHIP_STREAM_VARIANTS(X)
 #undef X
 
+/* the PACK instantiations of stream geometry 16 (render_stream_inst.hip with -DACHIP_SINST=16) */
+int achip_render_sinst_pack_launch(int mode, const achip_frame_t *frames, int n, const achip_lut_t *lut, uint64_t stride,
+                                   uint32_t *len, const achip_uniform_t *uniform, const achip_wire_t *wire,
+                                   const achip_packdev_t *pack, void *stream);
+
 /* the rows-kernel geometries (render_rows_inst.hip, -DACHIP_RINST=id): run-structured modes, whole frames */
 #define X(id, W, C)                                                                                                    \
   int achip_render_rinst_launch_##id(int mode, int comp, const achip_frame_t *frames, int n, const achip_lut_t *lut,   \

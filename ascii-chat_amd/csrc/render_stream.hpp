@@ -54,7 +54,11 @@ __host__ __device__ constexpr int stream_max_token(int m) {
 #define ACHIP_STREAM_MAXBLK 2048            /* blocks per frame the look-back table holds              */
 #define ACHIP_STREAM_MAX_STRIDE 0x3F000000u /* block prefixes are 30-bit: slab slots up to ~1 GB        */
 
-template <int MODE, int WAVES, int CPL, bool CRC = false> struct SLds {
+/* PACK instantiations (frames written at their exact length, below): the whole frame is staged in LDS -- this many bytes
+ * at most -- instead of one block per wave */
+#define ACHIP_PACK_FRAME_CAP (48 * 1024)
+
+template <int MODE, int WAVES, int CPL, bool CRC = false, bool PACK = false> struct SLds {
   static constexpr int BLK = 64 * CPL;
   /* cells a block OWNS.  Truecolor-fg decides its SGR against the raster predecessor (ansi_rle_add_pixel): slot
    * (k = 0, lane 0) of every block is a ghost that samples the cell in front of the block and owns no token, so that
@@ -63,7 +67,9 @@ template <int MODE, int WAVES, int CPL, bool CRC = false> struct SLds {
   static constexpr int STAGE = BLK * stream_max_token(MODE) + 16; /* + the 16-byte group the block starts in */
   static constexpr int GPL = (STAGE / 16 + 63) / 64; /* 16-byte groups of a block per lane when it is checksummed */
   static constexpr int o_stage = 0;
-  static constexpr int o_glyph = WAVES * STAGE;
+  /* PACK: [frame bytes (ACHIP_PACK_FRAME_CAP, + the group a last token may reach into)][16 bytes: the frame's offset] */
+  static constexpr int o_packoff = ACHIP_PACK_FRAME_CAP + 64;
+  static constexpr int o_glyph = PACK ? o_packoff + 16 : WAVES * STAGE;
   static constexpr int o_ramp = o_glyph + 256 * 4;
   static constexpr int o_dec = o_ramp + 64;
   static constexpr int o_flags = o_dec + 256 * 4; /* [+16 ..] swallows predicated-off byte stores */
@@ -266,7 +272,10 @@ template <class L> __global__ void __launch_bounds__(256) crc_tables_init_kernel
  * [0, p0) reads as zero (leading zeros do not move a zero register).  Whole 16-byte groups: lane l folds GPL consecutive
  * groups Horner-style, the groups aligned to the END of the bytes so that absent ones are leading zeros; sreg * K_l
  * through the window tables, one xor reduction over the lanes; the < 16 tail bytes come in through the slicing rows. */
-template <class L> __device__ inline uint32_t stream_crc_staged(const unsigned char *stage, uint32_t end_off, int lane) {
+/* LEAD = true (PACK instantiations: blocks sit next to each other in the frame's own LDS image): the first `lead` bytes
+ * of the window belong to the block in front and are masked out here instead of being zero in memory. */
+template <class L, bool LEAD = false>
+__device__ inline uint32_t stream_crc_staged(const unsigned char *stage, uint32_t end_off, int lane, uint32_t lead = 0u) {
   const uint32_t *slice = lds_ptr<const uint32_t>(L::o_slice);
   const int m_full = (int)(end_off >> 4), tail = (int)(end_off & 15u);
   constexpr int GPL = L::GPL;
@@ -278,6 +287,13 @@ template <class L> __device__ inline uint32_t stream_crc_staged(const unsigned c
     uint4 d = make_uint4(0u, 0u, 0u, 0u);
     if (g >= 0)
       d = *reinterpret_cast<const uint4 *>(stage + 16 * g);
+    if (LEAD && g == 0) { /* bytes [0, lead) of the first group are somebody else's */
+      auto keep = [&](uint32_t w, uint32_t i) {
+        const uint32_t gone = lead > 4u * i ? lead - 4u * i : 0u; /* leading bytes of word i to drop */
+        return gone >= 4u ? 0u : (gone ? w & (0xFFFFFFFFu << (8u * gone)) : w);
+      };
+      d.x = keep(d.x, 0u), d.y = keep(d.y, 1u), d.z = keep(d.z, 2u), d.w = keep(d.w, 3u);
+    }
     d.x ^= sreg; /* the register so far goes in with the next 16 bytes: slicing-by-16, no multiplication */
     sreg = crc_raw16(slice, d);
   }
@@ -289,7 +305,7 @@ template <class L> __device__ inline uint32_t stream_crc_staged(const unsigned c
   const uint32_t full = wave_read_lane(wave_xor_to_last(term), 63);
   /* the < 16 tail bytes: the register moves on by `tail` bytes; tail byte j is followed by tail-1-j bytes */
   uint32_t tb = 0;
-  if (lane < tail)
+  if (lane < tail && !(LEAD && m_full == 0 && (uint32_t)lane < lead)) /* (a block shorter than its first group) */
     tb = slice[(tail - 1 - lane) * 256 + stage[16 * m_full + lane]];
   return crc_advance16(slice, full, tail) ^ wave_read_lane(wave_xor_to_last(tb), 63);
 }
@@ -387,12 +403,20 @@ __device__ inline void stream_crc_finish(uint32_t *slots, int nblk, int nblk_cap
   }
 }
 
-template <int MODE, int WAVES, int CPL, bool GENERIC, bool CRC = false>
+template <int MODE, int WAVES, int CPL, bool GENERIC, bool CRC = false, bool PACK = false>
 __global__ void __launch_bounds__(WAVES * 64)
     render_stream_kernel(const achip_frame_t *__restrict__ frames, const achip_lut_t *__restrict__ lut,
                          uint8_t *__restrict__ out, uint64_t out_stride, uint32_t *__restrict__ out_len, int n_frames,
                          achip_uniform_t uni, unsigned long long *__restrict__ prof, achip_wire_t wire,
-                         const uint4 *__restrict__ crc_tab) {
+                         const uint4 *__restrict__ crc_tab, achip_packdev_t pack) {
+  /* PACK = true (lib/network/acip/server.c:190-222 ships exactly frame_size bytes): frames leave
+   * the kernel at their EXACT length, back to back in pack.dst, and the fixed-stride slab is never written.  A frame's
+   * length is only known once its last block has been tokenised, so the whole frame is staged in LDS (frames up to
+   * ACHIP_PACK_FRAME_CAP bytes: 1080p -> 80x24 truecolor is 36 KB), its place in pack.dst is claimed with ONE atomic add of
+   * round16(length) on a launch-wide cursor -- no workgroup ever waits for another: the order of the frames in pack.dst is
+   * the order in which they finish, pack.off_out[i] says where frame i went -- and the workgroup copies it out with
+   * coalesced 16-byte stores.  The last workgroup to finish leaves the total in pack.off_out[n] and clears the cursor
+   * words for the plan's next launch.  `out` / out_stride only bound a frame's length here. */
   /* CRC = true: the frame's CRC-32C (asciichat_crc32, lib/network/crc32.c:95-190 -- what acip_send_ascii_frame puts
    * into ascii_frame_packet_t.checksum, lib/network/acip/server.c:186-214) rides the drain: every wave checksums its
    * block while the bytes are in its staging area, the last wave to finish combines the blocks (a CRC is linear over
@@ -408,7 +432,8 @@ __global__ void __launch_bounds__(WAVES * 64)
       prof[((size_t)fidx * WAVES + wave) * 8u + (slot)] = wall_now();                                                  \
   } while (0)
   static_assert(mode_is_cell(MODE), "run-structured modes use render_frames_kernel");
-  using L = SLds<MODE, WAVES, CPL, CRC>;
+  using L = SLds<MODE, WAVES, CPL, CRC, PACK>;
+  static_assert(!PACK || (!GENERIC && MODE != ACHIP_MODE_TRUE_BG), "exact-length frames: single-source per-cell foreground modes");
   constexpr int BLOCK = WAVES * 64;
   constexpr int BLK = L::BLK;
   constexpr int SH = BLK - L::EFF; /* 1: slot (k = 0, lane 0) is the ghost of the cell in front of the block */
@@ -427,9 +452,26 @@ __global__ void __launch_bounds__(WAVES * 64)
                    "s"(uni.enabled), "s"(uni.flags), "s"(uni.src_pitch), "s"(uni.f.src), "s"(uni.f.comp));
       asm volatile("" ::"s"(uni.f.src_w), "s"(uni.f.src_h), "s"(uni.f.out_w), "s"(uni.f.out_h), "s"(uni.f.pad_left),
                    "s"(uni.f.pad_top), "s"(uni.f.x_ratio), "s"(uni.f.y_ratio), "s"(uni.f.src_stride), "s"(uni.f.ops));
-      if (CRC) asm volatile("" ::"s"(wire.crc), "s"(wire.dims), "s"(wire.hdr), "s"(wire.pkt_crc), "s"(crc_tab));)
+      if (CRC) asm volatile("" ::"s"(wire.crc), "s"(wire.dims), "s"(wire.hdr), "s"(wire.pkt_crc), "s"(crc_tab));
+      if (PACK) asm volatile("" ::"s"(pack.dst), "s"(pack.capacity), "s"(pack.off_out), "s"(pack.len_out), "s"(pack.cursor));)
   if (fidx >= n_frames)
     return;
+  /* PACK: every workgroup of the launch reports in exactly once (thread 0): where its frame went and how long it is (an
+   * error code takes no room); the last one to report publishes the total and re-arms the cursor words */
+  auto pack_report = [&](uint64_t off, uint32_t lenval) {
+    if (pack.off_out)
+      pack.off_out[fidx] = off;
+    if (pack.len_out)
+      pack.len_out[fidx] = lenval;
+    const unsigned long long before = agent_fetch_add_u64(&pack.cursor[1], 1ull);
+    if (before == (unsigned long long)n_frames - 1ull) {
+      const unsigned long long total = agent_fetch_add_u64(&pack.cursor[0], 0ull);
+      if (pack.off_out)
+        pack.off_out[n_frames] = total;
+      agent_store_u64(&pack.cursor[0], 0ull);
+      agent_store_u64(&pack.cursor[1], 0ull);
+    }
+  };
   bool first_block = true;
   ACHIP_SSTAMP(0);
   /* CRC: the constant tables are requested before anything else (L2 hits after a process's first launch) and go to
@@ -484,6 +526,8 @@ __global__ void __launch_bounds__(WAVES * 64)
         if (wire.pkt_crc)
           wire.pkt_crc[fidx] = ~crc_mulmod(0xFFFFFFFFu, crc_pow(CRC_X8, 24u));
       }
+      if (PACK)
+        pack_report(agent_fetch_add_u64(&pack.cursor[0], 0ull), ACHIP_LEN_BADDESC);
     }
     return;
   }
@@ -491,7 +535,8 @@ __global__ void __launch_bounds__(WAVES * 64)
   const int nblk = (int)((ncells + EFF - 1) / EFF);
   const int nblk_cap = stream_maxblk(uni.flags, EFF); /* words in each per-block LDS array of this launch */
   (void)nblk_cap;
-  const uint32_t cap_bytes = (uint32_t)out_stride;
+  /* PACK: the frame must also fit its LDS image */
+  const uint32_t cap_bytes = PACK ? min((uint32_t)out_stride, (uint32_t)ACHIP_PACK_FRAME_CAP) : (uint32_t)out_stride;
   const uint32_t pad_left = (uint32_t)f.pad_left, uwp = (uint32_t)wp;
   StreamSrc src;
   src.base = f.src;
@@ -570,8 +615,11 @@ __global__ void __launch_bounds__(WAVES * 64)
   ACHIP_SSTAMP(2);
 
   if (MODE == ACHIP_MODE_TRUE_FG && !ascii_only) { /* the host sends such plans to render_frames_kernel */
-    if (tid == 0)
+    if (tid == 0) {
       out_len[fidx] = ACHIP_LEN_BADDESC;
+      if (PACK)
+        pack_report(agent_fetch_add_u64(&pack.cursor[0], 0ull), ACHIP_LEN_BADDESC);
+    }
     return;
   }
   /* tables -> LDS; look-back words of this frame cleared */
@@ -601,9 +649,13 @@ __global__ void __launch_bounds__(WAVES * 64)
   /* ascii_pad_frame_height (ascii.c:902-941): pad_top bare newlines in front of the frame */
   const uint32_t first_base = (uint32_t)f.pad_top;
   if (first_base > 0u && first_base <= cap_bytes)
-    for (uint32_t o = (uint32_t)tid; o < first_base; o += BLOCK)
-      dst[o] = '\n';
-  __syncthreads(); /* the only workgroup barrier */
+    for (uint32_t o = (uint32_t)tid; o < first_base; o += BLOCK) {
+      if (PACK)
+        lds_ptr<uint8_t>(L::o_stage)[o] = '\n';
+      else
+        dst[o] = '\n';
+    }
+  __syncthreads(); /* the only workgroup barrier (PACK: the first of three) */
   ACHIP_SSTAMP(1);
   if (late_first) {
     chead = comp_head<L::o_comp>();
@@ -611,7 +663,8 @@ __global__ void __launch_bounds__(WAVES * 64)
       issue_any(cell0, pos, raw, kinds);
   }
 
-  const uint32_t stage_off = (uint32_t)(L::o_stage + wave * L::STAGE);
+  /* PACK: every wave writes into the frame's own image (stream offset o at its byte o) */
+  const uint32_t stage_off = (uint32_t)(L::o_stage + (PACK ? 0 : wave * L::STAGE));
   const uint32_t stage_addr = lds_base_addr() + stage_off;
   /* predicated-off byte stores land in a per-lane dummy word (one address for all lanes would serialise them) */
   const uint32_t dummy_addr = lds_base_addr() + (uint32_t)L::o_flags + 16u + 4u * (uint32_t)lane;
@@ -734,8 +787,8 @@ __global__ void __launch_bounds__(WAVES * 64)
     ACHIP_SSTAMP(5);
     if (ok) {
       /* ---- token bytes into this wave's staging area: stream offset g0 (16-byte aligned) sits at its byte 0 */
-      const uint32_t g0 = base & ~15u;
-      if (CRC && lane == 0) /* the bytes in front of the block inside its first 16-byte group read as zero for the
+      const uint32_t g0 = PACK ? 0u : base & ~15u;
+      if (CRC && !PACK && lane == 0) /* the bytes in front of the block inside its first 16-byte group read as zero for the
                                checksum: leading zeros do not move a zero register (program order: before the tokens) */
         *lds_ptr<uint4>((int)stage_off) = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
@@ -752,10 +805,11 @@ __global__ void __launch_bounds__(WAVES * 64)
       if (!CRC)
         ACHIP_SSTAMP(6);
 
-      /* ---- staging -> HBM: whole 16-byte groups as uint4, the shared first / last group as bytes */
+      /* ---- staging -> HBM: whole 16-byte groups as uint4, the shared first / last group as bytes (PACK: the frame
+       * leaves LDS as a whole, behind the loop) */
       const unsigned char *stage = lds_ptr<const unsigned char>((int)stage_off);
       const uint32_t end = base + total;
-      const uint32_t vec_begin = (base + 15u) & ~15u, vec_end = end & ~15u;
+      const uint32_t vec_begin = PACK ? end : (base + 15u) & ~15u, vec_end = end & ~15u;
       for (uint32_t o = vec_begin + 16u * (uint32_t)lane; o < vec_end; o += 1024u) {
 #if defined(ACHIP_STREAM_ABLATE) && (ACHIP_STREAM_ABLATE == 1 || ACHIP_STREAM_ABLATE == 3) /* diagnostics: no HBM writes */
         const uint4 v = *reinterpret_cast<const uint4 *>(stage + (o - g0));
@@ -764,26 +818,30 @@ __global__ void __launch_bounds__(WAVES * 64)
         store_out16(dst + o, *reinterpret_cast<const uint4 *>(stage + (o - g0)));
 #endif
       }
-      const uint32_t head_end = min(vec_begin, end);
-      if (base + (uint32_t)lane < head_end)
-        dst[base + (uint32_t)lane] = stage[base + (uint32_t)lane - g0];
-      const uint32_t tail_begin = max(vec_end, head_end);
-      if (lane >= 32 && tail_begin + (uint32_t)(lane - 32) < end)
-        dst[tail_begin + (uint32_t)(lane - 32)] = stage[tail_begin + (uint32_t)(lane - 32) - g0];
+      if (!PACK) {
+        const uint32_t head_end = min(vec_begin, end);
+        if (base + (uint32_t)lane < head_end)
+          dst[base + (uint32_t)lane] = stage[base + (uint32_t)lane - g0];
+        const uint32_t tail_begin = max(vec_end, head_end);
+        if (lane >= 32 && tail_begin + (uint32_t)(lane - 32) < end)
+          dst[tail_begin + (uint32_t)(lane - 32)] = stage[tail_begin + (uint32_t)(lane - 32) - g0];
+      }
     }
     ACHIP_SSTAMP(CRC ? 6 : 7); /* CRC instantiations: 6 = stores issued, 7 = block checksummed and placed */
     const bool stamp_crc = first_block;
     first_block = false;
     if (blk == nblk - 1 && lane == 0) {
       out_len[fidx] = ok ? base + total : ACHIP_LEN_OVERFLOW;
-      if (ok && (uint64_t)base + total < out_stride)
+      if (!PACK && ok && (uint64_t)base + total < out_stride)
         dst[base + total] = 0; /* NUL behind the frame when the slot has room, as the reference's strings carry */
     }
     if (CRC) {
       /* ---- raw CRC of the block, from the staging area (after the stores to HBM have been issued), placed in the
        * frame; the last block to finish completes the frame (stream_crc_* above) */
       if (ok) {
-        const uint32_t braw = stream_crc_staged<L>(lds_ptr<const unsigned char>((int)stage_off), (base & 15u) + total, lane);
+        const uint32_t braw = PACK ? stream_crc_staged<L, true>(lds_ptr<const unsigned char>((int)stage_off) + (base & ~15u),
+                                                                (base & 15u) + total, lane, base & 15u)
+                                   : stream_crc_staged<L>(lds_ptr<const unsigned char>((int)stage_off), (base & 15u) + total, lane);
         stream_crc_place<L>(slots, nblk, nblk_cap, blk, braw, base + total, cap_bytes, lane);
       }
       stream_crc_finish<L>(slots, nblk, nblk_cap, cap_bytes, first_base, fidx, dim_w, dim_h, wire, lane);
@@ -799,6 +857,30 @@ __global__ void __launch_bounds__(WAVES * 64)
 #pragma unroll
     for (int k = 0; k < CPL; k++)
       raw[k] = raw_n[k];
+  }
+  if (PACK) {
+    /* ---- the frame is complete in LDS: claim its place, copy it out.  (Every wave gets here exactly once, those without
+     * a block too; the look-back words are final: a block publishes its prefix before it stores its bytes.) */
+    __syncthreads();
+    const uint32_t lastw = slot_load(&slots[nblk - 1]);
+    const uint32_t n_total = lastw & ACHIP_SLOT_VALUE;
+    const bool fits = n_total <= cap_bytes;
+    const uint32_t room = fits ? (n_total + 15u) & ~15u : 0u;
+    unsigned long long *offw = lds_ptr<unsigned long long>(L::o_packoff);
+    if (tid == 0)
+      offw[0] = agent_fetch_add_u64(&pack.cursor[0], (unsigned long long)room);
+    if (tid >= 64 && tid < 80 && n_total + (uint32_t)(tid - 64) < room) /* the <= 15 bytes of padding leave as zeros */
+      lds_ptr<uint8_t>(L::o_stage)[n_total + (uint32_t)(tid - 64)] = 0;
+    __syncthreads();
+    const unsigned long long off = offw[0];
+    if (fits && off + room <= pack.capacity) {
+      uint8_t *to = pack.dst + off;
+      const uint4 *from = lds_ptr<const uint4>(L::o_stage);
+      for (uint32_t g = (uint32_t)tid; g < room / 16u; g += BLOCK)
+        store_out16(to + 16u * g, from[g]);
+    }
+    if (tid == 0)
+      pack_report(off, fits ? n_total : ACHIP_LEN_OVERFLOW);
   }
 }
 

@@ -88,8 +88,42 @@ hipError_t launch_one(const achip_frame_t *frames, int n, const achip_lut_t *lut
    * workgroups of launches in flight on other streams share a CU */
   const size_t lds = (size_t)((L::bytes_for(achip::stream_maxblk(uni.flags, L::EFF)) + 15) & ~15);
   hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(G::WAVES * 64), lds, stream, frames, lut, out, stride, len, n, uni,
-                     prof, wire, tab);
+                     prof, wire, tab, achip_packdev_t{});
   return hipGetLastError();
+}
+
+/* PACK instantiations (exact-length frames straight from the render; geometry 16 only): with or without the frame CRC */
+template <int MODE, bool CRC>
+hipError_t launch_pack(const achip_frame_t *frames, int n, const achip_lut_t *lut, uint64_t stride, uint32_t *len,
+                       const achip_uniform_t &uni, const achip_wire_t &wire, const achip_packdev_t &pack, hipStream_t stream) {
+  if constexpr (ACHIP_SINST == 16 && MODE != ACHIP_MODE_TRUE_BG) {
+    using L = achip::SLds<MODE, G::WAVES, G::CPL, CRC, true>;
+    auto kern = achip::render_stream_kernel<MODE, G::WAVES, G::CPL, false, CRC, true>;
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, L::bytes);
+      if (e != hipSuccess)
+        return e;
+      attr_set = true;
+    }
+    const uint4 *tab = nullptr;
+    if constexpr (CRC) {
+      /* the constant tables sit at the same offsets from o_tab in every layout of a (mode, geometry): one image serves both */
+      static_assert(L::TAB_BYTES == achip::SLds<MODE, G::WAVES, G::CPL, true>::TAB_BYTES && L::GPL == achip::SLds<MODE, G::WAVES, G::CPL, true>::GPL &&
+                        L::WIN == achip::SLds<MODE, G::WAVES, G::CPL, true>::WIN,
+                    "PACK and plain CRC layouts share the table image");
+      hipError_t e = crc_tables<MODE>(&tab);
+      if (e != hipSuccess)
+        return e;
+    }
+    const size_t lds = (size_t)((L::bytes_for(achip::stream_maxblk(uni.flags, L::EFF)) + 15) & ~15);
+    hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(G::WAVES * 64), lds, stream, frames, lut, static_cast<uint8_t *>(nullptr),
+                       stride, len, n, uni, static_cast<unsigned long long *>(nullptr), wire, tab, pack);
+    return hipGetLastError();
+  } else {
+    (void)frames, (void)n, (void)lut, (void)stride, (void)len, (void)uni, (void)wire, (void)pack, (void)stream;
+    return hipErrorInvalidValue;
+  }
 }
 
 } // namespace
@@ -129,6 +163,32 @@ extern "C" int ACHIP_CAT(achip_render_sinst_launch_, ACHIP_SINST)(int mode, int 
   }
   return (int)hipErrorInvalidValue;
 }
+
+#if ACHIP_SINST == 16
+extern "C" int achip_render_sinst_pack_launch(int mode, const achip_frame_t *frames, int n, const achip_lut_t *lut,
+                                              uint64_t stride, uint32_t *len, const achip_uniform_t *uniform,
+                                              const achip_wire_t *wire, const achip_packdev_t *pack, void *stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  achip_uniform_t uni = {};
+  if (uniform && uniform->enabled)
+    uni = *uniform;
+  if (uniform)
+    uni.flags = uniform->flags;
+  if (!pack || !pack->dst || !pack->cursor || (wire && !wire->crc))
+    return (int)hipErrorInvalidValue;
+  switch (mode) {
+#define M(m)                                                                                                           \
+  case m:                                                                                                              \
+    return (int)(wire ? launch_pack<m, true>(frames, n, lut, stride, len, uni, *wire, *pack, s)                        \
+                      : launch_pack<m, false>(frames, n, lut, stride, len, uni, achip_wire_t{}, *pack, s));
+    M(ACHIP_MODE_TRUE_FG)
+    M(ACHIP_MODE_256_FG)
+    M(ACHIP_MODE_16_FG)
+#undef M
+  }
+  return (int)hipErrorInvalidValue;
+}
+#endif
 
 extern "C" int ACHIP_CAT(achip_render_sinst_lds_, ACHIP_SINST)(int mode) {
   switch (mode) {

@@ -512,19 +512,28 @@ def wire_stage(torch, pkg, res, steps=None):
     oracle_ok = all(int(got["fused"][0][i]) == orc.crc32c(host[i * stride:i * stride + int(lens[i])].tobytes()) for i in idx)
     if not (same and oracle_ok):
         raise SystemExit("bench.py: fused frame checksums differ from the stand-alone kernel's / the oracle's")
+    one_launch = bool(plans[0].exact_length)  # the render writes exact-length frames itself (no slab, no second pass)
     t = {kind: statistics.median(timed(kind) for _ in range(3))
          for kind in ("render", "separate", "fused", "packets_then_pack", "packets_packed")}
-    # the compacted copies of the two forms agree (offsets, lengths, every frame's bytes)
+    if one_launch:  # the same entry point with that form switched off: render (+ fused wire stage) + pack_frames
+        for p in plans:
+            p.set_exact_length(0)
+        t["packets_packed_two_launches"] = statistics.median(timed("packets_packed") for _ in range(3))
+        for p in plans:
+            p.set_exact_length(-1)
+    # the compacted copies of the two forms agree: lengths, every frame's bytes at its offset, the destination tiled
     ref = {}
     for kind in ("packets_then_pack", "packets_packed"):
         step(kind, 0)
         torch.cuda.synchronize()
         o, l = offs[0].cpu().numpy().copy(), plens[0].cpu().numpy().astype("uint32").copy()
         pk = pks[0].cpu().numpy()
-        ref[kind] = (o, l, [pk[int(o[i]):int(o[i]) + int(l[i])].tobytes() for i in idx])
-    if not ((ref["packets_then_pack"][0] == ref["packets_packed"][0]).all() and (ref["packets_then_pack"][1] == ref["packets_packed"][1]).all()
+        spans = sorted((int(o[i]), int(o[i]) + (int(l[i]) + 15) // 16 * 16) for i in range(batch))
+        tiled = spans[0][0] == 0 and all(spans[i][1] == spans[i + 1][0] for i in range(batch - 1)) and spans[-1][1] == int(o[batch])
+        ref[kind] = (tiled, l, [pk[int(o[i]):int(o[i]) + int(l[i])].tobytes() for i in idx])
+    if not (ref["packets_then_pack"][0] and ref["packets_packed"][0] and (ref["packets_then_pack"][1] == ref["packets_packed"][1]).all()
             and ref["packets_then_pack"][2] == ref["packets_packed"][2]):
-        raise SystemExit("bench.py: the one-pass checksum + pack differs from wire stage + pack_frames")
+        raise SystemExit("bench.py: the packed output of plan_render_packets_packed differs from wire stage + pack_frames")
     forced = None
     if not plans[0].fused_crc:  # a geometry that carries the fused CRC without it being the faster form (the rows kernel)
         for p in plans:
@@ -541,6 +550,8 @@ def wire_stage(torch, pkg, res, steps=None):
             "extra_ms_separate": t["separate"] - t["render"], "extra_ms_fused": t["fused"] - t["render"],
             "packed": {"wire_stage_then_pack_frames_ms_per_step": t["packets_then_pack"],
                        "render_packets_packed_ms_per_step": t["packets_packed"],
+                       "exact_length_frames_written_by_the_render_kernel": one_launch,
+                       "render_packets_packed_two_launches_ms_per_step": t.get("packets_packed_two_launches"),
                        "note": "the frames also compacted (device destination): plan_render_packets + pack_frames against "
                                "plan_render_packets_packed -- behind a fused render the same two launches, otherwise ONE pass "
                                "that checksums and packs instead of two passes over the slab"},
@@ -891,6 +902,10 @@ def time_with_d2h_packed(torch, pkg, plans, n, steps, lanes=2):
     v = hbs[last].view()
     off = v[:8 * (n + 1)].view(np.uint64)
     ln = v[8 * (n + 1):8 * (n + 1) + 4 * n].view(np.uint32)
+    k_last = steps - 1  # (a plan that writes exact-length frames itself leaves the slab alone: render it for the comparison)
+    p_last = plans[(k_last % lanes) + lanes * ((k_last // lanes) % (len(plans) // lanes))]
+    p_last.render(slabs[last].data_ptr(), stride, lns[last].data_ptr(), st[last].cuda_stream)
+    torch.cuda.synchronize()
     dev_slab, dev_len = slabs[last].cpu().numpy(), lns[last].cpu().numpy().astype("uint32")
     for i in range(0, n, max(1, n // 16)):
         if int(ln[i]) != int(dev_len[i]) or not (v[tab + int(off[i]):tab + int(off[i]) + int(ln[i])] ==
@@ -900,6 +915,7 @@ def time_with_d2h_packed(torch, pkg, plans, n, steps, lanes=2):
     for hb in hbs:
         hb.close()
     return {"ms_per_step": dt * 1e3, "frames_per_s": n / dt, "bytes_over_pcie_per_step": total + tab,
+            "exact_length_frames_written_by_the_render_kernel": bool(plans[0].exact_length),
             "GBps": (total + tab) / dt / 1e9, "fixed_stride_bytes_per_step": n * stride + 4 * n, "lanes": lanes,
             "note": "render + pack kernel storing the bytes in use (16-byte aligned frame starts) and the offset / length "
                     "tables straight into mapped pinned host memory; no DMA, no host round trip for a size"}

@@ -80,6 +80,18 @@ typedef struct {
   uint8_t *hdr;
   uint32_t *pkt_crc;
 } achip_wire_t;
+/* Where a PACK instantiation of the stream kernel leaves its frames (device pointers; by value in the kernel arguments):
+ * frames at their exact lengths, back to back from dst in the order in which they finish, every start 16-byte aligned.
+ * off_out (n + 1 entries, [n] = total bytes) and len_out (n: the length, or the render error code of a frame that takes
+ * no room) may be NULL.  cursor: two 64-bit words owned by the plan, zero between launches ([0] next free byte, [1]
+ * workgroups that have reported); dst / off_out / len_out may be device memory or the device alias of mapped host memory. */
+typedef struct {
+  uint8_t *dst;
+  uint64_t capacity;
+  uint64_t *off_out;
+  uint32_t *len_out;
+  unsigned long long *cursor;
+} achip_packdev_t;
 /* Several nearest-neighbour resizes in one launch (the grid path resizes every source a rank owns per tick): by value in
  * the kernel arguments, workgroup (x, k) works on entry k. */
 #define ACHIP_RESIZE_BATCH_MAX 16

@@ -82,7 +82,7 @@ def main():
         scratch = int(k.get("private_segment_fixed_size", 0))
         limit, why = None, ""
         m = re.search(r"render_frames_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb([01])ELb([01])E", name)
-        ms = re.search(r"render_stream_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb([01])ELb([01])E", name)
+        ms = re.search(r"render_stream_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb([01])ELb([01])ELb([01])E", name)
         mr = re.search(r"render_rows_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb([01])ELb([01])E", name)
         if mr:
             mode, waves, cpl = int(mr.group(1)), int(mr.group(2)), int(mr.group(3))
@@ -98,15 +98,16 @@ def main():
                 limit, why = 128, "two (four) workgroups per CU"
         elif ms:
             mode, waves, cpl = int(ms.group(1)), int(ms.group(2)), int(ms.group(3))
-            crc = ms.group(5) == "1"
+            crc, pack = ms.group(5) == "1", ms.group(6) == "1"
             short = (f"render_stream_kernel<mode {mode}, {waves} waves, {cpl} cells/lane, generic {ms.group(4)}"
-                     f"{', +crc' if crc else ''}>")
-            if crc:  # the checksum's 16-byte groups are in flight next to the following block's samples
+                     f"{', +crc' if crc else ''}{', +pack' if pack else ''}>")
+            if crc or pack:  # the checksum's 16-byte groups are in flight next to the following block's samples; the
+                             # exact-length form stages a whole frame in LDS: one 16-wave workgroup per CU either way
                 limit, why = 128, "4 waves per SIMD: one 16-wave or two 8-wave workgroups per CU (LDS allows no more)"
             else:
                 limit, why = (72, "7 waves per SIMD") if mode == 4 else (64, "8 waves per SIMD")
         else:
-            short = demangle(name).split("(")[0][-70:]
+            short = demangle(name).split("(")[0].replace("void ", "")[-70:]
         problems = []
         if limit is not None and vg > limit:
             problems.append(f"{vg} VGPRs > {limit} ({why})")

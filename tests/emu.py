@@ -147,6 +147,42 @@ def render_frames_crc(mode, frames, palette, variant=20, stride=None, dims=None)
     return res, [int(c) for c in crc], [hdr[24 * i:24 * i + 24].tobytes() for i in range(n)], [int(c) for c in pkt]
 
 
+def render_frames_packed(mode, frames, palette, variant=16, stride=None, dims=None, want_crc=True, capacity=None, cursor=None):
+    """The stream kernel's PACK instantiations (frames at their exact lengths straight from the render, no slab): returns
+    dict(lens=out_len[n], off=off_out[n + 1], plen=len_out[n], dst=bytes of the packed buffer, crc / hdr / pkt when want_crc,
+    cursor=the two cursor words after the launch).  `cursor` may be passed in (a numpy uint64[2]) to launch again on it."""
+    L = lib()
+    L.emu_render_stream_pack.restype = C.c_int
+    L.emu_render_stream_pack.argtypes = [C.c_int, C.c_int, C.POINTER(Frame), C.c_int, C.POINTER(Lut), C.c_uint64, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
+                                         C.c_void_p, C.c_void_p]
+    n = len(frames)
+    arr = (Frame * n)(*frames)
+    lut = make_lut(palette)
+    if stride is None:
+        stride = max(int(L.achip_out_bound(mode, C.byref(arr[i]))) for i in range(n))
+        stride = (stride + 1 + 15) // 16 * 16
+    cap = n * stride if capacity is None else capacity
+    raw = np.full(n * stride + 64, 0xEE, dtype=np.uint8)
+    base = (raw.ctypes.data + 15) // 16 * 16
+    ln = np.zeros(n, dtype=np.uint32)
+    off = np.zeros(n + 1, dtype=np.uint64)
+    plen = np.zeros(n, dtype=np.uint32)
+    cur = np.zeros(2, dtype=np.uint64) if cursor is None else cursor
+    crc = np.zeros(n, dtype=np.uint32)
+    hdr = np.zeros(24 * n, dtype=np.uint8)
+    pkt = np.zeros(n, dtype=np.uint32)
+    d = np.array(dims, dtype=np.uint32) if dims is not None else None
+    rc = L.emu_render_stream_pack(mode, variant, arr, n, C.byref(lut), stride, ln.ctypes.data,
+                                  crc.ctypes.data if want_crc else None, d.ctypes.data if d is not None else None,
+                                  hdr.ctypes.data if (want_crc and d is not None) else None,
+                                  pkt.ctypes.data if (want_crc and d is not None) else None, base, cap, off.ctypes.data,
+                                  plen.ctypes.data, cur.ctypes.data)
+    assert rc == 0
+    view = np.ctypeslib.as_array((C.c_uint8 * (n * stride + 16)).from_address(base)).copy()
+    return dict(lens=ln, off=off, plen=plen, dst=view, crc=crc, hdr=hdr, pkt=pkt, cursor=cur, stride=stride)
+
+
 def frame_for_convert(img, width, height, render_mode, wants_padding=False, use_aspect=False, stretch=False):
     f = Frame()
     rc = lib().achip_frame_setup(C.byref(f), img.ctypes.data, img.shape[1], img.shape[0], width, height, render_mode,

@@ -84,7 +84,7 @@ static void run_stream(const achip_frame_t *frames, int n, const achip_lut_t *lu
               ACHIP_UNIFORM_MAX_CELLS(achip_max_cells(frames, n)); /* what plan.c / dropin.c pass */
   const size_t lds = (size_t)((L::bytes_for(achip::stream_maxblk(uni.flags, L::EFF)) + 15) & ~15);
   hipemu::launch(dim3((unsigned)n), dim3(WAVES * 64), lds, [&] {
-    achip::render_stream_kernel<MODE, WAVES, CPL, true>(frames, lut, out, stride, len, n, uni, nullptr, achip_wire_t{}, nullptr);
+    achip::render_stream_kernel<MODE, WAVES, CPL, true>(frames, lut, out, stride, len, n, uni, nullptr, achip_wire_t{}, nullptr, achip_packdev_t{});
   });
 }
 template <int WAVES, int CPL>
@@ -122,7 +122,7 @@ static void run_stream_crc(const achip_frame_t *frames, int n, const achip_lut_t
   const uint4 *tabv = reinterpret_cast<const uint4 *>(tab.data());
   const size_t lds = (size_t)((L::bytes_for(achip::stream_maxblk(uni.flags, L::EFF)) + 15) & ~15);
   hipemu::launch(dim3((unsigned)n), dim3(WAVES * 64), lds, [&] {
-    achip::render_stream_kernel<MODE, WAVES, CPL, true, true>(frames, lut, out, stride, len, n, uni, nullptr, wire, tabv);
+    achip::render_stream_kernel<MODE, WAVES, CPL, true, true>(frames, lut, out, stride, len, n, uni, nullptr, wire, tabv, achip_packdev_t{});
   });
 }
 extern "C" int emu_render_stream_crc(int mode, int variant, const achip_frame_t *frames, int n, const achip_lut_t *lut,
@@ -140,6 +140,53 @@ extern "C" int emu_render_stream_crc(int mode, int variant, const achip_frame_t 
     M(ACHIP_MODE_TRUE_FG, 8, 2) M(ACHIP_MODE_256_FG, 8, 2) M(ACHIP_MODE_16_FG, 8, 2) M(ACHIP_MODE_TRUE_BG, 8, 2)
   } else if (variant == 16) {
     M(ACHIP_MODE_TRUE_FG, 16, 2) M(ACHIP_MODE_256_FG, 16, 2)
+  }
+#undef M
+  return -1;
+}
+
+/* the stream kernel's PACK instantiations: frames at their exact lengths straight into `dst` (no slab), with or without
+ * the fused frame CRC.  Geometry 16 is the product's; 20 (two waves, one cell per lane) makes tiny frames multi-block. */
+template <int MODE, int WAVES, int CPL, bool CRC>
+static void run_stream_pack(const achip_frame_t *frames, int n, const achip_lut_t *lut, uint64_t stride, uint32_t *len,
+                            const achip_wire_t &wire, const achip_packdev_t &pack) {
+  using L = achip::SLds<MODE, WAVES, CPL, CRC, true>;
+  using LC = achip::SLds<MODE, WAVES, CPL, true, true>;
+  achip_uniform_t uni = {};
+  if (g_uniform)
+    (void)achip_frames_uniform(frames, n, &uni);
+  uni.flags = ((lut->flags & ACHIP_LUT_MULTIBYTE) ? 0u : ACHIP_UNIFORM_PALETTE_ASCII) |
+              ACHIP_UNIFORM_MAX_CELLS(achip_max_cells(frames, n));
+  static std::vector<uint32_t> tab;
+  if (CRC && tab.empty()) {
+    tab.resize(LC::TAB_BYTES / 4 + 4);
+    uint32_t *t = tab.data();
+    hipemu::launch(dim3(1), dim3(256), 0, [&] { achip::crc_tables_init_kernel<LC>(t); });
+  }
+  const uint4 *tabv = CRC ? reinterpret_cast<const uint4 *>(tab.data()) : nullptr;
+  const size_t lds = (size_t)((L::bytes_for(achip::stream_maxblk(uni.flags, L::EFF)) + 15) & ~15);
+  hipemu::launch(dim3((unsigned)n), dim3(WAVES * 64), lds, [&] {
+    achip::render_stream_kernel<MODE, WAVES, CPL, false, CRC, true>(frames, lut, nullptr, stride, len, n, uni, nullptr, wire, tabv, pack);
+  });
+}
+extern "C" int emu_render_stream_pack(int mode, int variant, const achip_frame_t *frames, int n, const achip_lut_t *lut,
+                                      uint64_t stride, uint32_t *len, uint32_t *crc, const uint32_t *dims, uint8_t *hdr,
+                                      uint32_t *pkt, uint8_t *dst, uint64_t capacity, uint64_t *off_out, uint32_t *len_out,
+                                      unsigned long long *cursor) {
+  const achip_wire_t wire = {crc, dims, hdr, pkt};
+  const achip_packdev_t pack = {dst, capacity, off_out, len_out, cursor};
+#define M(m, W, C)                                                                                                     \
+  if (mode == m) {                                                                                                     \
+    if (crc)                                                                                                           \
+      run_stream_pack<m, W, C, true>(frames, n, lut, stride, len, wire, pack);                                          \
+    else                                                                                                               \
+      run_stream_pack<m, W, C, false>(frames, n, lut, stride, len, wire, pack);                                         \
+    return 0;                                                                                                          \
+  }
+  if (variant == 20) {
+    M(ACHIP_MODE_TRUE_FG, 2, 1) M(ACHIP_MODE_256_FG, 2, 1) M(ACHIP_MODE_16_FG, 2, 1)
+  } else if (variant == 16) {
+    M(ACHIP_MODE_TRUE_FG, 16, 2) M(ACHIP_MODE_256_FG, 16, 2) M(ACHIP_MODE_16_FG, 16, 2)
   }
 #undef M
   return -1;

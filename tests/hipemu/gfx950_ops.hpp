@@ -31,6 +31,11 @@ inline void agent_store_u64(unsigned long long *p, unsigned long long w) { *rein
 inline unsigned long long agent_load_u64(const unsigned long long *p) {
   return *reinterpret_cast<const volatile unsigned long long *>(p);
 }
+inline unsigned long long agent_fetch_add_u64(unsigned long long *p, unsigned long long v) {
+  const unsigned long long old = *reinterpret_cast<volatile unsigned long long *>(p);
+  *reinterpret_cast<volatile unsigned long long *>(p) = old + v;
+  return old;
+}
 template <int N> inline void spin_nap() {}
 inline void wg_store_u32(uint32_t *p, uint32_t v) { *reinterpret_cast<volatile uint32_t *>(p) = v; }
 inline uint32_t wg_load_u32(const uint32_t *p) { return *reinterpret_cast<const volatile uint32_t *>(p); }

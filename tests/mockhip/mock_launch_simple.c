@@ -72,6 +72,14 @@ int achip_launch_render_crc(int mode, int variant, int has_composite, const achi
       (void)out_len, (void)wire, (void)uniform, (void)prof, (void)stream;
   return MOCK_UNSUPPORTED;
 }
+int achip_launch_render_pack(int mode, const achip_frame_t *frames_dev, int n_frames, const achip_lut_t *lut_dev, uint64_t bound,
+                             uint32_t *out_len, const achip_wire_t *wire, const achip_uniform_t *uniform,
+                             const achip_packdev_t *pack, void *stream) {
+  (void)mode, (void)frames_dev, (void)n_frames, (void)lut_dev, (void)bound, (void)out_len, (void)wire, (void)uniform, (void)pack,
+      (void)stream;
+  return MOCK_UNSUPPORTED;
+}
+int achip_pack_frame_cap(void) { return 0; } /* no such kernels here: plans keep the two-pass forms */
 int achip_launch_packets_from_crc(const uint32_t *a, const uint32_t *b, const uint32_t *c, int n, uint8_t *h, uint32_t *p, void *s) {
   (void)a, (void)b, (void)c, (void)n, (void)h, (void)p, (void)s;
   return MOCK_UNSUPPORTED;

@@ -849,6 +849,67 @@ def test_frame_table_publish_rows_batch(gpu):
     table.close()
 
 
+def test_exact_length_frames_full_batch(gpu):
+    """BASELINE's metric workload (256 x 1080p -> 80x24 truecolor) through plan_render_packets_packed as ONE launch: the
+    render writes every frame at its exact length (claiming its place with an atomic add: frames lie in completion order),
+    with checksums and headers; repeated launches on the plan's cursor words; also into mapped host memory, also ANSI-256,
+    aspect + padding.  Against the two-launch form for all 256 frames and against the oracle for a sample."""
+    pkg, torch = gpu
+    stream = torch.cuda.current_stream().cuda_stream
+    n, sw, sh = 256, 1920, 1080
+    g = torch.Generator(device="cuda")
+    g.manual_seed(7)
+    frames_t = torch.randint(0, 256, (n, sh, sw, 3), dtype=torch.uint8, device="cuda", generator=g)
+    frames_t[1] = torch.from_numpy(orc.frame_bars(sw, sh, 6)).cuda()  # short frames next to long ones
+    frames_t[2] = 0
+    for mode, cl, (W, H), asp in ((1, 3, (80, 24), False), (2, 2, (80, 24), False), (1, 3, (80, 24), True)):
+        descs = [pkg.frame_setup(frames_t.data_ptr() + i * sh * sw * 3, sw, sh, W, H, 0, asp, asp, False) for i in range(n)]
+        plan = pkg.Plan(mode, orc.PALETTE_STANDARD, descs)
+        assert plan.exact_length and plan.stride <= 48 * 1024
+        stride = plan.stride
+        d32 = torch.tensor([[W, H]] * n, dtype=torch.int32, device="cuda")
+        tab = (8 * (n + 1) + 4 * n + 15) // 16 * 16
+
+        def run(one_launch, host_dst):
+            plan.set_exact_length(-1 if one_launch else 0)
+            slab = torch.full((n * stride,), 0xEE, dtype=torch.uint8, device="cuda")
+            ln = torch.zeros(n, dtype=torch.int32, device="cuda")
+            crc = torch.zeros(n, dtype=torch.int32, device="cuda")
+            hdr = torch.zeros(n * 24, dtype=torch.uint8, device="cuda")
+            pkt = torch.zeros(n, dtype=torch.int32, device="cuda")
+            if host_dst:
+                hb = pkg.HostBuffer(tab + n * stride)
+                dst, off_p, len_p = hb.dev + tab, hb.dev, hb.dev + 8 * (n + 1)
+            else:
+                buf = torch.zeros(tab + n * stride, dtype=torch.uint8, device="cuda")
+                dst, off_p, len_p = buf.data_ptr() + tab, buf.data_ptr(), buf.data_ptr() + 8 * (n + 1)
+            for _ in range(3):  # the cursor words are re-armed by every launch
+                plan.render_packets_packed(slab.data_ptr(), stride, ln.data_ptr(), d32.data_ptr(), crc.data_ptr(), hdr.data_ptr(),
+                                           pkt.data_ptr(), dst, n * stride, off_p, len_p, stream)
+            torch.cuda.synchronize()
+            v = hb.view().copy() if host_dst else buf.cpu().numpy()
+            if host_dst:
+                hb.close()
+            off = v[:8 * (n + 1)].view(np.uint64)
+            pl = v[8 * (n + 1):8 * (n + 1) + 4 * n].view(np.uint32)
+            fr = [v[tab + int(off[i]):tab + int(off[i]) + int(pl[i])].tobytes() for i in range(n)]
+            spans = sorted((int(off[i]), int(off[i]) + (int(pl[i]) + 15) // 16 * 16) for i in range(n))
+            assert spans[0][0] == 0 and all(spans[i][1] == spans[i + 1][0] for i in range(n - 1)) and spans[-1][1] == int(off[n])
+            assert bool((slab == 0xEE).all()) == one_launch
+            return fr, ln.cpu().numpy(), crc.cpu().numpy(), hdr.cpu().numpy(), pkt.cpu().numpy(), pl
+
+        ref = run(False, False)
+        for host_dst in (False, True):
+            got = run(True, host_dst)
+            assert got[0] == ref[0], (mode, host_dst)
+            for a, b in zip(got[1:], ref[1:]):
+                assert np.array_equal(a, b), (mode, host_dst)
+        for i in (0, 1, 2, 3, 100, 255):
+            exp = orc.convert_with_caps(frames_t[i].cpu().numpy(), W, H, cl, 0, asp, asp, False)
+            assert ref[0][i] == exp and int(ref[2][i]) & 0xFFFFFFFF == orc.crc32c(exp), (mode, i)
+        plan.close()
+
+
 def test_frame_table_sampled_image_ingest(gpu):
     """frame_dense.c on the MI355X: a tick's clients staged as the images their targets sample
     -- one pinned block, ONE DMA, NO kernel -- and rendered from those images: bytes equal the oracle's on the original
@@ -1088,12 +1149,14 @@ def test_render_packets_packed_one_pass(gpu):
     src = torch.from_numpy(np.ascontiguousarray(orc.frame_hash_noise(1920, 1080, 77))).cuda()
     big = torch.from_numpy(np.ascontiguousarray(orc.frame_hash_noise(3840, 2160, 78))).cuda()
     cases = [  # mode, render_mode, source, (w, h) list, forced variant
-        (1, 0, src, [(80, 24), (60, 7), (1, 1), (132, 43)], 17),        # fused CRC: render + pack
+        (1, 0, src, [(80, 24), (60, 7), (1, 1), (40, 30), (80, 24), (33, 11)], -1),  # frames <= 48 KB: ONE launch, exact lengths
+        (2, 0, src, [(80, 24), (100, 20), (5, 5)], 17),                 # ... also from a 512-thread plan (the launch is geometry 16)
+        (1, 0, src, [(80, 24), (60, 7), (1, 1), (132, 43)], 17),        # a 136 KB bound: fused CRC render + pack
         (5, 2, src, [(80, 24), (100, 37), (33, 17), (80, 24)], -1),     # rows kernel / bands: one pass, frames < 128 KB
         (0, 0, src, [(80, 24), (200, 60), (10, 5)], -1),
         (5, 2, big, [(400, 120), (380, 100), (80, 24)], -1),            # 1.8 MB frames: the span kernels
     ]
-    for mode, rm, img, dims, variant in cases:
+    for case_no, (mode, rm, img, dims, variant) in enumerate(cases):
         ih, iw = img.shape[0], img.shape[1]
         frames = [pkg.frame_setup(img.data_ptr(), iw, ih, w, h, rm, False, False, False) for (w, h) in dims]
         plan = pkg.Plan(mode, orc.PALETTE_STANDARD, frames)
@@ -1122,13 +1185,23 @@ def test_render_packets_packed_one_pass(gpu):
         va, vb = hb_a.view(), hb_b.view()
         off_a, off_b = va[:8 * (n + 1)].view(np.uint64), vb[:8 * (n + 1)].view(np.uint64)
         la = va[8 * (n + 1):8 * (n + 1) + 4 * n].view(np.uint32)
-        assert np.array_equal(off_a, off_b) and np.array_equal(la, vb[8 * (n + 1):8 * (n + 1) + 4 * n].view(np.uint32))
+        assert np.array_equal(la, vb[8 * (n + 1):8 * (n + 1) + 4 * n].view(np.uint32))
+        one_launch = plan.exact_length
+        assert one_launch == (case_no < 2), (case_no, plan.stride)
+        if one_launch:
+            # the render wrote the frames itself: the slab was never touched, the frames tile the destination in SOME order
+            assert bool((out_b == 0xEE).all())
+            spans = sorted((int(off_b[i]), int(off_b[i]) + (int(la[i]) + 15) // 16 * 16) for i in range(n))
+            assert spans[0][0] == 0 and all(spans[i][1] == spans[i + 1][0] for i in range(n - 1)) and spans[-1][1] == int(off_b[n])
+            assert int(off_b[n]) == int(off_a[n])
+        else:
+            assert np.array_equal(off_a, off_b)
         ih_np = img.cpu().numpy()
         for i, (w, h) in enumerate(dims):
             a = va[tab + int(off_a[i]):tab + int(off_a[i]) + int(la[i])].tobytes()
             assert a == vb[tab + int(off_b[i]):tab + int(off_b[i]) + int(la[i])].tobytes(), (mode, i)
             if w * h <= 200 * 60:  # (the oracle takes its time on the largest frames: they are compared with the two-pass form)
-                cl = {1: 3, 5: 3, 0: 0}[mode]
+                cl = {1: 3, 2: 2, 5: 3, 0: 0}[mode]
                 assert a == orc.convert_with_caps(ih_np, w, h, cl, rm, False, False, False), (mode, i)
         hb_a.close()
         hb_b.close()

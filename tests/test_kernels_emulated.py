@@ -317,6 +317,78 @@ def test_stream_kernel_fused_frame_crc(mode):
     assert got[0] == 0xFFFFFFFF and crc[0] == 0
 
 
+def check_packed(res, expected, what):
+    """frames at their exact lengths, 16-byte aligned starts, tiling [0, total) in SOME order; error frames take no room"""
+    n = len(expected)
+    spans = []
+    for k, exp in enumerate(expected):
+        o = int(res["off"][k])
+        if isinstance(exp, int):  # a render error code
+            assert int(res["plen"][k]) == exp and int(res["lens"][k]) == exp, (what, k)
+            continue
+        assert int(res["plen"][k]) == len(exp) == int(res["lens"][k]), (what, k, int(res["plen"][k]), len(exp))
+        assert o % 16 == 0 and res["dst"][o:o + len(exp)].tobytes() == exp, (what, k)
+        room = (len(exp) + 15) // 16 * 16
+        assert not res["dst"][o + len(exp):o + room].any(), (what, k)  # the padding leaves as zeros
+        spans.append((o, o + room))
+    spans.sort()
+    at = 0
+    for a, b in spans:
+        assert a == at, (what, spans)
+        at = b
+    assert int(res["off"][n]) == at, (what, int(res["off"][n]), at)
+    assert not res["cursor"].any(), what  # re-armed for the plan's next launch
+
+
+@pytest.mark.parametrize("mode", [MODE_TRUE_FG, MODE_256_FG, 3], ids=["true_fg", "256_fg", "16_fg"])
+def test_stream_kernel_exact_length_frames(mode):
+    """PACK instantiations of the stream kernel (acip_send_ascii_frame ships frame_size bytes,
+    lib/network/acip/server.c:190-222): the frame is staged whole in LDS, claims its place with one atomic add and leaves at
+    its exact length -- bytes, lengths, the tiling of the destination, fused CRCs / headers, the cursor re-armed, in the
+    product geometry and in the two-wave test geometry (many blocks per wave), with top / left padding, a ragged batch, a
+    frame that does not fit, a destination that is too small."""
+    imgs = [orc.frame_hash_noise(120, 90, 40 + i) for i in range(5)] + [TORTURE]
+    dims = [(80, 24), (60, 7), (33, 40), (1, 50), (3, 2), (80, 24)]
+    frames = [emu.frame_for_convert(im, w, h, 0) for im, (w, h) in zip(imgs, dims)]
+    expected = [oracle_convert(im, mode, w, h, orc.PALETTE_STANDARD) for im, (w, h) in zip(imgs, dims)]
+    for variant in (20, 16):
+        for want_crc in (True, False):
+            res = emu.render_frames_packed(mode, frames, orc.PALETTE_STANDARD, variant, dims=dims, want_crc=want_crc)
+            check_packed(res, expected, (mode, variant, want_crc))
+            if want_crc:
+                for k, (w, h) in enumerate(dims):
+                    eh, ep = orc.ascii_frame_packet(expected[k], w, h)
+                    assert int(res["crc"][k]) == orc.crc32c(expected[k]), (mode, variant, k)
+                    assert res["hdr"][24 * k:24 * k + 24].tobytes() == eh and int(res["pkt"][k]) == ep, (mode, variant, k)
+            # again on the same cursor words: the last workgroup cleared them
+            res2 = emu.render_frames_packed(mode, frames, orc.PALETTE_STANDARD, variant, dims=dims, want_crc=want_crc,
+                                            cursor=res["cursor"])
+            check_packed(res2, expected, (mode, variant, want_crc, "again"))
+    # aspect + padding (newlines in front that no block stages, pad cells), the uniform-descriptor path
+    padded = [emu.frame_for_convert(TORTURE, W, H, 0, True, True) for (W, H) in ((80, 24), (200, 20), (31, 60))]
+    exp_p = [oracle_convert(TORTURE, mode, W, H, orc.PALETTE_STANDARD, True, True) for (W, H) in ((80, 24), (200, 20), (31, 60))]
+    for variant in (20, 16):
+        check_packed(emu.render_frames_packed(mode, padded, orc.PALETTE_STANDARD, variant), exp_p, (mode, variant, "padded"))
+    # a frame that does not fit its bound takes no room and reports the overflow code; the others are unaffected
+    small = emu.render_frames_packed(mode, frames, orc.PALETTE_STANDARD, 20, stride=2048)
+    exp_s = [e if len(e) <= 2048 else 0xFFFFFFFF for e in expected]
+    assert any(isinstance(e, int) for e in exp_s) and any(not isinstance(e, int) for e in exp_s)
+    check_packed(small, exp_s, (mode, "overflow"))
+    assert int(small["crc"][0]) == 0
+    # a destination too small for everything: frames whose place lies within it arrive, the total still tells
+    total = sum((len(e) + 15) // 16 * 16 for e in expected)
+    cut = emu.render_frames_packed(mode, frames, orc.PALETTE_STANDARD, 20, capacity=total // 2 // 16 * 16)
+    assert int(cut["off"][len(frames)]) == total
+    arrived = 0
+    for k, e in enumerate(expected):
+        o = int(cut["off"][k])
+        if o + (len(e) + 15) // 16 * 16 <= total // 2 // 16 * 16:
+            assert cut["dst"][o:o + len(e)].tobytes() == e
+            arrived += 1
+    assert 0 < arrived < len(frames)
+    assert (cut["dst"][total // 2 // 16 * 16:total] == 0xEE).all()  # nothing stored at or behind the capacity
+
+
 # --------------------------------------------------------------------------------------------------------------- #
 # the rows kernel (render_rows.hpp): the run-structured modes, a block = whole text rows owned by ONE wave.          #
 # Geometry 28 (2 waves x 2 cells per lane = 128-cell blocks, emulator builds only) gives tiny frames many blocks per #

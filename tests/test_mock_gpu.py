@@ -184,11 +184,23 @@ def test_plans_and_packed_output_on_the_mock(mock):
     dst = np.zeros(n * stride, dtype=np.uint8)
     off = np.zeros(n + 1, dtype=np.uint64)
     ln2 = np.zeros(n, dtype=np.uint32)
+    # 40x12 truecolor frames fit the kernel's LDS image: ONE launch writes them at their exact lengths, the slab stays untouched
+    assert plan.exact_length
+    plan.render_packed(slab.ctypes.data, stride, ln.ctypes.data, dst.ctypes.data, dst.size, off.ctypes.data, ln2.ctypes.data)
+    assert not slab.any()
+    for i in range(n):
+        exp = orc.convert_with_caps(imgs[i], 40, 12, 3, 0, False, False, False)
+        assert int(ln[i]) == len(exp)
+        assert int(off[i]) % 16 == 0 and dst[int(off[i]):int(off[i]) + int(ln2[i])].tobytes() == exp
+    # ... and with that form switched off: render + pack_frames, frames in the slab too and in frame order in dst
+    plan.set_exact_length(0)
+    assert not plan.exact_length
+    dst[:] = 0
     plan.render_packed(slab.ctypes.data, stride, ln.ctypes.data, dst.ctypes.data, dst.size, off.ctypes.data, ln2.ctypes.data)
     for i in range(n):
         exp = orc.convert_with_caps(imgs[i], 40, 12, 3, 0, False, False, False)
         assert slab[i * stride:i * stride + int(ln[i])].tobytes() == exp
-        assert int(off[i]) % 16 == 0 and dst[int(off[i]):int(off[i]) + int(ln2[i])].tobytes() == exp
+        assert int(off[i + 1]) == int(off[i]) + ((len(exp) + 15) & ~15) and dst[int(off[i]):int(off[i]) + int(ln2[i])].tobytes() == exp
     plan.close()
 
 
@@ -233,10 +245,14 @@ def test_wire_stage_on_the_mock(mock):
         plan.render_packets_packed(out2.ctypes.data, stride, ln2.ctypes.data, d32.ctypes.data, crc2.ctypes.data, hdr2.ctypes.data,
                                    pkt2.ctypes.data, dbase, n * stride, off.ctypes.data, lo.ctypes.data)
         assert np.array_equal(ln2, ln) and np.array_equal(crc2, crc) and np.array_equal(hdr2, hdr) and np.array_equal(pkt2, pkt)
-        assert np.array_equal(lo, ln) and int(off[0]) == 0
+        assert np.array_equal(lo, ln)
+        assert plan.exact_length == (mode != 5), (mode, variant)  # the per-cell plans: ONE launch, no slab
+        assert out2.any() != plan.exact_length
         dv = np.ctypeslib.as_array((C.c_uint8 * (n * stride)).from_address(dbase))
+        spans = sorted((int(off[i]), int(off[i]) + ((int(ln[i]) + 15) & ~15)) for i in range(n))
+        assert spans[0][0] == 0 and all(spans[i][1] == spans[i + 1][0] for i in range(n - 1)) and spans[-1][1] == int(off[n])
         for i in range(n):
-            assert int(off[i]) % 16 == 0 and int(off[i + 1]) == int(off[i]) + ((int(ln[i]) + 15) & ~15)
+            assert int(off[i]) % 16 == 0
             assert dv[int(off[i]):int(off[i]) + int(ln[i])].tobytes() == out[i * stride:i * stride + int(ln[i])].tobytes(), (mode, variant, i)
         plan.close()
 
