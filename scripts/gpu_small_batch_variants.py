@@ -96,3 +96,15 @@ sweep("configs[3]: nine targets of the 3x3 grid at 160x48 truecolor, one launch 
       descs, bench.PALETTE_STANDARD, exp,
       [("automatic", -1, None), ("stream 16", 16, -1), ("stream 17", 17, -1), ("stream 18", 18, -1), ("stream 19", 19, -1),
        ("phase kernel 4, whole frame", 4, -1), ("phase kernel 4, 8-row bands", 4, 8), ("phase kernel 4, 4-row bands", 4, 4)])
+
+# the policy change checked at batch sizes between one frame and a frame per CU: whole frames (automatic now) against the
+# row bands the automatic choice used to make
+for nb in (8, 64, 128):
+    imgs = bench.make_frames(torch, nb, 640, 480, 99)
+    fr = [pkg.frame_setup(imgs.data_ptr() + i * 640 * 480 * 3, 640, 480, 80, 24, 0, False, False, False) for i in range(nb)]
+    host0 = np.ascontiguousarray(imgs[0].cpu().numpy())
+    for mode, cl, label in ((1, 3, "truecolor"), (0, 0, "mono")):
+        exp = orc.convert_with_caps(host0, 80, 24, cl, 0, False, False, False)
+        bands = max(1, 24 // max(1, (256 + nb - 1) // nb))
+        sweep(f"{nb} x (640x480 -> 80x24 {label}) per launch", mode, fr, bench.PALETTE_STANDARD, exp,
+              [("automatic", -1, None), (f"phase kernel 4, {bands}-row bands", 4, bands), ("phase kernel 4, whole frame", 4, -1)])
