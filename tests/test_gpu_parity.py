@@ -126,9 +126,12 @@ def test_multi_workgroup_frames(gpu, mode):
         got = render_batch(gpu, mode, imgs, W, H, wants_padding=pad, use_aspect=aspect, split=split, repeat=3)
         for k, img in enumerate(imgs):
             assert got[k] == oracle_convert(img, mode, W, H, orc.PALETTE_STANDARD, pad, aspect), (MODE_NAMES[mode], W, H, k)
-    # policy: one 80x24 frame -> 24 single-row workgroups; never when asked not to
-    render_batch(gpu, mode, [TORTURE], 80, 24, split=0, want_parts=24)
-    render_batch(gpu, mode, [TORTURE], 80, 24, split=-1, want_parts=1)
+    # policy: one 160x48 frame -> 48 single-row workgroups; never when asked not to; and never a frame small enough for one
+    # block per wave of a wave-autonomous geometry (80x24: round 4, profiles/r04_small_batch_variants.txt) unless asked to
+    render_batch(gpu, mode, [TORTURE], 160, 48, split=0, want_parts=48)
+    render_batch(gpu, mode, [TORTURE], 160, 48, split=-1, want_parts=1)
+    render_batch(gpu, mode, [TORTURE], 80, 24, split=0, want_parts=1)
+    render_batch(gpu, mode, [TORTURE], 80, 24, split=2, want_parts=12)
 
 
 def test_split_exclusions_and_ragged_parts(gpu):
