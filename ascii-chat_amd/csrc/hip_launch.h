@@ -28,10 +28,10 @@ int achip_launch_render_crc(int mode, int variant, int has_composite, const achi
                             const achip_wire_t *wire, const achip_uniform_t *uniform, unsigned long long *prof,
                             void *stream);
 /* whole-frame launch of a per-cell FOREGROUND mode (truecolor with an all-ASCII palette, 256, 16; single sources) that
- * writes the frames at their exact lengths itself (the PACK instantiations of stream geometry 16): no slab -- `bound` only
+ * writes the frames at their exact lengths itself (the PACK instantiations of stream geometries 16 / 17): no slab -- `bound` only
  * limits a frame's length and must not exceed achip_pack_frame_cap().  wire = NULL: no checksums. */
-int achip_launch_render_pack(int mode, const achip_frame_t *frames_dev, int n_frames, const achip_lut_t *lut_dev, uint64_t bound,
-                             uint32_t *out_len, const achip_wire_t *wire, const achip_uniform_t *uniform,
+int achip_launch_render_pack(int mode, int variant /* 16: 1024-thread workgroups, else 512 */, const achip_frame_t *frames_dev,
+                             int n_frames, const achip_lut_t *lut_dev, uint64_t bound, uint32_t *out_len, const achip_wire_t *wire, const achip_uniform_t *uniform,
                              const achip_packdev_t *pack, void *stream);
 int achip_pack_frame_cap(void); /* bytes of one frame those instantiations can stage; 0 = not available in this build */
 int achip_variant_has_crc(int variant);

@@ -83,14 +83,16 @@ extern "C" int achip_launch_render_crc(int mode, int variant, int has_composite,
   }
   return (int)hipErrorInvalidValue;
 }
-extern "C" int achip_launch_render_pack(int mode, const achip_frame_t *frames_dev, int n_frames, const achip_lut_t *lut_dev,
-                                        uint64_t bound, uint32_t *out_len, const achip_wire_t *wire,
+extern "C" int achip_launch_render_pack(int mode, int variant, const achip_frame_t *frames_dev, int n_frames,
+                                        const achip_lut_t *lut_dev, uint64_t bound, uint32_t *out_len, const achip_wire_t *wire,
                                         const achip_uniform_t *uniform, const achip_packdev_t *pack, void *stream) {
   if (n_frames <= 0)
     return (int)hipSuccess;
   if (bound > (uint64_t)ACHIP_PACK_FRAME_CAP)
     return (int)hipErrorInvalidValue;
-  return achip_render_sinst_pack_launch(mode, frames_dev, n_frames, lut_dev, bound, out_len, uniform, wire, pack, stream);
+  /* 1024 threads while every frame has a CU to itself (variant 16: one block per wave), 512-thread workgroups otherwise */
+  return variant == 16 ? achip_render_sinst_pack_launch_16(mode, frames_dev, n_frames, lut_dev, bound, out_len, uniform, wire, pack, stream)
+                       : achip_render_sinst_pack_launch_17(mode, frames_dev, n_frames, lut_dev, bound, out_len, uniform, wire, pack, stream);
 }
 extern "C" int achip_pack_frame_cap(void) { return ACHIP_PACK_FRAME_CAP; }
 extern "C" int achip_variant_has_crc(int variant) { return variant == 16 || variant == 17 || ACHIP_IS_ROWS_VARIANT(variant); }

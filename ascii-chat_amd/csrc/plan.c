@@ -224,6 +224,8 @@ struct asciichat_hip_plan {
   int frames_dma_queued;        /* a DMA out of frames_pinned may still be in flight on the stream of the last update */
   int exact_length;             /* -1 = the packed entry points are ONE launch wherever the plan qualifies (default), 0 = never */
   unsigned long long *pack_cursor; /* two device words of the PACK kernels, zero between launches (allocated on first use) */
+  const void *pack_dst_seen;       /* the destination the automatic choice looked at last, and what it was */
+  int pack_dst_host;
   const achip_lut_t *lut_dev;
 };
 
@@ -574,10 +576,33 @@ int asciichat_hip_plan_get_exact_length(const asciichat_hip_plan_t *p) {
   return p->stride <= (size_t)achip_pack_frame_cap();
 }
 int asciichat_hip_plan_set_exact_length(asciichat_hip_plan_t *p, int mode) {
-  if (!p || mode < -1 || mode > 0)
-    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "plan_set_exact_length: -1 (wherever the plan qualifies) or 0 (never)");
+  if (!p || mode < -1 || mode > 1)
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM,
+                      "plan_set_exact_length: -1 (where it is the faster form), 0 (never) or 1 (wherever the plan qualifies)");
   p->exact_length = mode;
   return 0;
+}
+/* Whether THIS call takes the one-launch form.  Measured (profiles/r04_exact_length_timing.txt, 256 x 1080p -> 80x24
+ * truecolor, us per step): into DEVICE memory the one launch wins -- frames only 9.4 against 11.5 with four launches in
+ * flight -- but into mapped HOST memory it loses (206 against 176): a workgroup then holds its CU's LDS until its stores
+ * have crossed PCIe, where the two-launch form's render is long gone and only the copy kernel's few registers wait.  So the
+ * automatic choice looks at the destination (one hipPointerGetAttributes per new destination pointer; a tick reuses its
+ * buffers). */
+static int plan_packs_this_call(asciichat_hip_plan_t *p, const void *dst) {
+  if (!asciichat_hip_plan_get_exact_length(p))
+    return 0;
+  if (p->exact_length > 0)
+    return 1;
+  if (p->pack_dst_seen != dst) {
+    hipPointerAttribute_t attr;
+    memset(&attr, 0, sizeof(attr));
+    const hipError_t e = hipPointerGetAttributes(&attr, dst);
+    if (e != hipSuccess)
+      (void)hipGetLastError(); /* an address the runtime knows nothing about: the caller's business, taken for device memory */
+    p->pack_dst_seen = dst;
+    p->pack_dst_host = e == hipSuccess && attr.type == hipMemoryTypeHost;
+  }
+  return !p->pack_dst_host;
 }
 static int plan_render_pack(asciichat_hip_plan_t *p, uint32_t *out_len_dev, const achip_wire_t *wire, uint8_t *dst,
                             size_t dst_capacity, uint64_t *off_out, uint32_t *len_out, void *stream) {
@@ -603,8 +628,8 @@ static int plan_render_pack(asciichat_hip_plan_t *p, uint32_t *out_len_dev, cons
     uni.enabled = 0;
   uni.flags = (p->palette_ascii ? ACHIP_UNIFORM_PALETTE_ASCII : 0u) | ACHIP_UNIFORM_MAX_CELLS(achip_uniform_extent(p->mode, 16, p->frames_pinned, p->n));
   const achip_packdev_t pack = {dst, (uint64_t)dst_capacity, off_out, len_out, p->pack_cursor};
-  return achip_hip_check(achip_launch_render_pack(p->mode, p->frames_dev, p->n, p->lut_dev, (uint64_t)p->stride, out_len_dev, wire, &uni,
-                                                  &pack, stream),
+  return achip_hip_check(achip_launch_render_pack(p->mode, p->variant, p->frames_dev, p->n, p->lut_dev, (uint64_t)p->stride, out_len_dev,
+                                                  wire, &uni, &pack, stream),
                          "render + pack kernel launch");
 }
 
@@ -614,7 +639,7 @@ int asciichat_hip_plan_render_packets_packed(asciichat_hip_plan_t *p, uint8_t *s
                                              uint32_t *len_out, void *stream) {
   if (!p || !hdr_out_dev || !dst)
     return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "plan_render_packets_packed: no header buffer or destination");
-  if (asciichat_hip_plan_get_exact_length(p) && crc_out_dev) {
+  if (crc_out_dev && plan_packs_this_call(p, dst)) {
     const achip_wire_t wire = {crc_out_dev, dims_dev, hdr_out_dev, packet_crc_out_dev};
     return plan_render_pack(p, out_len_dev, &wire, dst, dst_capacity, off_out, len_out, stream);
   }
@@ -990,7 +1015,7 @@ int asciichat_hip_pack_frames(const uint8_t *slab_dev, size_t stride, const uint
 
 int asciichat_hip_plan_render_packed(asciichat_hip_plan_t *p, uint8_t *slab_dev, size_t out_stride, uint32_t *out_len_dev,
                                      uint8_t *dst, size_t dst_capacity, uint64_t *off_out, uint32_t *len_out, void *stream) {
-  if (asciichat_hip_plan_get_exact_length(p) && dst)
+  if (dst && plan_packs_this_call(p, dst))
     return plan_render_pack(p, out_len_dev, NULL, dst, dst_capacity, off_out, len_out, stream);
   int rc = asciichat_hip_plan_render(p, slab_dev, out_stride, out_len_dev, stream);
   if (!rc)

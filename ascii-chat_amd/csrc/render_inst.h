@@ -29,10 +29,13 @@ ACHIP_VARIANTS(X)
 ACHIP_STREAM_VARIANTS(X)
 #undef X
 
-/* the PACK instantiations of stream geometry 16 (render_stream_inst.hip with -DACHIP_SINST=16) */
-int achip_render_sinst_pack_launch(int mode, const achip_frame_t *frames, int n, const achip_lut_t *lut, uint64_t stride,
-                                   uint32_t *len, const achip_uniform_t *uniform, const achip_wire_t *wire,
-                                   const achip_packdev_t *pack, void *stream);
+/* the PACK instantiations of stream geometries 16 and 17 (render_stream_inst.hip with -DACHIP_SINST=16 / 17) */
+int achip_render_sinst_pack_launch_16(int mode, const achip_frame_t *frames, int n, const achip_lut_t *lut, uint64_t stride,
+                                      uint32_t *len, const achip_uniform_t *uniform, const achip_wire_t *wire,
+                                      const achip_packdev_t *pack, void *stream);
+int achip_render_sinst_pack_launch_17(int mode, const achip_frame_t *frames, int n, const achip_lut_t *lut, uint64_t stride,
+                                      uint32_t *len, const achip_uniform_t *uniform, const achip_wire_t *wire,
+                                      const achip_packdev_t *pack, void *stream);
 
 /* the rows-kernel geometries (render_rows_inst.hip, -DACHIP_RINST=id): run-structured modes, whole frames */
 #define X(id, W, C)                                                                                                    \

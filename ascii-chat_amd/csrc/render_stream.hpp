@@ -55,10 +55,13 @@ __host__ __device__ constexpr int stream_max_token(int m) {
 #define ACHIP_STREAM_MAX_STRIDE 0x3F000000u /* block prefixes are 30-bit: slab slots up to ~1 GB        */
 
 /* PACK instantiations (frames written at their exact length, below): the whole frame is staged in LDS -- this many bytes
- * at most -- instead of one block per wave */
+ * at most -- instead of one block per wave.  PACK = 1: frames only; 2: + frame CRC, packet header, packet CRC, computed
+ * from the frame's LDS image by the whole workgroup (crc_kernels.hpp's scheme: 20 KB of tables instead of the 52 KB of
+ * the per-block checksum, so two 8-wave workgroups still share a CU). */
 #define ACHIP_PACK_FRAME_CAP (48 * 1024)
 
-template <int MODE, int WAVES, int CPL, bool CRC = false, bool PACK = false> struct SLds {
+template <int MODE, int WAVES, int CPL, bool CRC = false, int PACK = 0> struct SLds {
+  static_assert(!(CRC && PACK), "exact-length instantiations checksum the frame's LDS image as a whole");
   static constexpr int BLK = 64 * CPL;
   /* cells a block OWNS.  Truecolor-fg decides its SGR against the raster predecessor (ansi_rle_add_pixel): slot
    * (k = 0, lane 0) of every block is a ghost that samples the cell in front of the block and owns no token, so that
@@ -67,9 +70,10 @@ template <int MODE, int WAVES, int CPL, bool CRC = false, bool PACK = false> str
   static constexpr int STAGE = BLK * stream_max_token(MODE) + 16; /* + the 16-byte group the block starts in */
   static constexpr int GPL = (STAGE / 16 + 63) / 64; /* 16-byte groups of a block per lane when it is checksummed */
   static constexpr int o_stage = 0;
-  /* PACK: [frame bytes (ACHIP_PACK_FRAME_CAP, + the group a last token may reach into)][16 bytes: the frame's offset] */
-  static constexpr int o_packoff = ACHIP_PACK_FRAME_CAP + 64;
-  static constexpr int o_glyph = PACK ? o_packoff + 16 : WAVES * STAGE;
+  /* PACK: [16 bytes: the frame's offset in the destination] here; the frame's image lies BEHIND everything else
+   * (frame_off(), as long as the launch's largest frame can be: a small footprint lets workgroups share a CU) */
+  static constexpr int o_packoff = 0;
+  static constexpr int o_glyph = PACK ? 16 : WAVES * STAGE;
   static constexpr int o_ramp = o_glyph + 256 * 4;
   static constexpr int o_dec = o_ramp + 64;
   static constexpr int o_flags = o_dec + 256 * 4; /* [+16 ..] swallows predicated-off byte stores */
@@ -78,7 +82,8 @@ template <int MODE, int WAVES, int CPL, bool CRC = false, bool PACK = false> str
    * accumulator, deferred and finished counts */
   static constexpr int o_comp = o_flags + 32 + 64 * 4; /* composite descriptor of a GENERIC launch (comp_stage) */
   static constexpr int o_tab = o_comp + ACHIP_COMP_LDS_BYTES;
-  static constexpr int o_slice = o_tab;
+  static constexpr int o_fcrc = o_tab; /* PACK == 2: crc_kernels.hpp's tables (CrcLds layout), built by the workgroup */
+  static constexpr int o_slice = o_tab + (PACK == 2 ? CrcLds::bytes : 0);
   static constexpr int o_lanek = o_slice + (CRC ? 16 * 1024 : 0);
   static constexpr int base_crc = o_lanek + (CRC ? 3 * 1024 + 256 + 16 + 2 * ACHIP_STREAM_MAXBLK * 4 : 0);
   static constexpr int WIN = base_crc + 32 * 1024 <= 160 * 1024 ? 4 : 2; /* bits per window of the lane multiply */
@@ -86,13 +91,16 @@ template <int MODE, int WAVES, int CPL, bool CRC = false, bool PACK = false> str
   static constexpr int o_pow = o_lanek + (CRC ? NWIN * (1 << WIN) * 64 * 4 : 0);
   static constexpr int o_xk = o_pow + (CRC ? 3 * 1024 : 0);
   static constexpr int TAB_BYTES = (CRC ? o_xk + 256 : o_tab) - o_tab; /* the image crc_tables_init_kernel writes */
-  static constexpr int o_crcacc = o_tab + TAB_BYTES; /* [0] acc [1] deferred [2] finished */
+  static constexpr int o_crcacc = o_tab + TAB_BYTES + (PACK == 2 ? CrcLds::bytes : 0); /* [0] acc [1] deferred [2] finished */
   /* per-block words, as many as the launch's largest frame has blocks: look-back words {state:2, bytes:30}, and
    * (CRC) behind them the raw CRC of a block that could not be placed yet */
   static constexpr int o_slots = o_crcacc + (CRC ? 16 : 0);
   static constexpr int bytes_for(int maxblk) { return o_slots + maxblk * 4 * (CRC ? 2 : 1); }
-  static constexpr int bytes = bytes_for(ACHIP_STREAM_MAXBLK);
-  static_assert(STAGE % 16 == 0 && o_tab % 16 == 0 && TAB_BYTES % 16 == 0, "16-byte aligned areas");
+  /* PACK: where the frame's image starts, and the LDS of a launch whose frames are at most `bound` bytes */
+  static constexpr int frame_off(int maxblk) { return (bytes_for(maxblk) + 15) & ~15; }
+  static constexpr int bytes_for_pack(int maxblk, int bound) { return frame_off(maxblk) + ((bound + 15) & ~15) + 64; }
+  static constexpr int bytes = PACK ? bytes_for_pack(ACHIP_STREAM_MAXBLK, ACHIP_PACK_FRAME_CAP) : bytes_for(ACHIP_STREAM_MAXBLK);
+  static_assert(STAGE % 16 == 0 && o_tab % 16 == 0 && TAB_BYTES % 16 == 0 && CrcLds::bytes % 16 == 0, "16-byte aligned areas");
   static_assert(bytes <= 160 * 1024, "one workgroup's LDS");
 };
 /* blocks the per-block LDS words of a launch hold: from the largest frame's cells when the host states them */
@@ -265,6 +273,20 @@ template <class L> __global__ void __launch_bounds__(256) crc_tables_init_kernel
   }
 }
 
+/* The constant tables of the PACK == 2 instantiations (the frame checksummed from its LDS image by a workgroup of BLOCK
+ * threads): crc_kernels.hpp's slicing tables and Horner table for x^(128 * BLOCK), the first ACHIP_FRAME_CRC_TAB_BYTES of the
+ * CrcLds layout, written once per process into global memory; every launch copies the image into LDS. */
+#define ACHIP_FRAME_CRC_TAB_BYTES (20 * 1024)
+template <int BLOCK> __global__ void __launch_bounds__(256) crc_frame_tables_init_kernel(uint32_t *tab) {
+  static_assert(CrcLds::o_slice == 0 && CrcLds::o_mulh == 16 * 1024, "slicing tables, then the Horner table");
+  const int tid = (int)threadIdx.x;
+  uint32_t *slice = lds_ptr<uint32_t>(CrcLds::o_slice), *mulh = lds_ptr<uint32_t>(CrcLds::o_mulh);
+  crc_build_tables<BLOCK>(slice, mulh, tid);
+  __syncthreads();
+  for (int k = tid; k < ACHIP_FRAME_CRC_TAB_BYTES / 4; k += 256)
+    tab[k] = lds_ptr<const uint32_t>(0)[k];
+}
+
 /* ---- the fused frame CRC, shared by the wave-autonomous kernels (this file and render_rows.hpp).  L = the kernel's
  * LDS layout: o_slice / o_lanek / o_pow / o_xk (constant tables), o_crcacc ([0] accumulator, [1] deferred blocks,
  * [2] finished blocks), GPL / WIN / NWIN ------------------------------------------------------------------------------ */
@@ -272,10 +294,7 @@ template <class L> __global__ void __launch_bounds__(256) crc_tables_init_kernel
  * [0, p0) reads as zero (leading zeros do not move a zero register).  Whole 16-byte groups: lane l folds GPL consecutive
  * groups Horner-style, the groups aligned to the END of the bytes so that absent ones are leading zeros; sreg * K_l
  * through the window tables, one xor reduction over the lanes; the < 16 tail bytes come in through the slicing rows. */
-/* LEAD = true (PACK instantiations: blocks sit next to each other in the frame's own LDS image): the first `lead` bytes
- * of the window belong to the block in front and are masked out here instead of being zero in memory. */
-template <class L, bool LEAD = false>
-__device__ inline uint32_t stream_crc_staged(const unsigned char *stage, uint32_t end_off, int lane, uint32_t lead = 0u) {
+template <class L> __device__ inline uint32_t stream_crc_staged(const unsigned char *stage, uint32_t end_off, int lane) {
   const uint32_t *slice = lds_ptr<const uint32_t>(L::o_slice);
   const int m_full = (int)(end_off >> 4), tail = (int)(end_off & 15u);
   constexpr int GPL = L::GPL;
@@ -287,13 +306,6 @@ __device__ inline uint32_t stream_crc_staged(const unsigned char *stage, uint32_
     uint4 d = make_uint4(0u, 0u, 0u, 0u);
     if (g >= 0)
       d = *reinterpret_cast<const uint4 *>(stage + 16 * g);
-    if (LEAD && g == 0) { /* bytes [0, lead) of the first group are somebody else's */
-      auto keep = [&](uint32_t w, uint32_t i) {
-        const uint32_t gone = lead > 4u * i ? lead - 4u * i : 0u; /* leading bytes of word i to drop */
-        return gone >= 4u ? 0u : (gone ? w & (0xFFFFFFFFu << (8u * gone)) : w);
-      };
-      d.x = keep(d.x, 0u), d.y = keep(d.y, 1u), d.z = keep(d.z, 2u), d.w = keep(d.w, 3u);
-    }
     d.x ^= sreg; /* the register so far goes in with the next 16 bytes: slicing-by-16, no multiplication */
     sreg = crc_raw16(slice, d);
   }
@@ -305,7 +317,7 @@ __device__ inline uint32_t stream_crc_staged(const unsigned char *stage, uint32_
   const uint32_t full = wave_read_lane(wave_xor_to_last(term), 63);
   /* the < 16 tail bytes: the register moves on by `tail` bytes; tail byte j is followed by tail-1-j bytes */
   uint32_t tb = 0;
-  if (lane < tail && !(LEAD && m_full == 0 && (uint32_t)lane < lead)) /* (a block shorter than its first group) */
+  if (lane < tail)
     tb = slice[(tail - 1 - lane) * 256 + stage[16 * m_full + lane]];
   return crc_advance16(slice, full, tail) ^ wave_read_lane(wave_xor_to_last(tb), 63);
 }
@@ -403,20 +415,22 @@ __device__ inline void stream_crc_finish(uint32_t *slots, int nblk, int nblk_cap
   }
 }
 
-template <int MODE, int WAVES, int CPL, bool GENERIC, bool CRC = false, bool PACK = false>
+template <int MODE, int WAVES, int CPL, bool GENERIC, bool CRC = false, int PACK = 0>
 __global__ void __launch_bounds__(WAVES * 64)
     render_stream_kernel(const achip_frame_t *__restrict__ frames, const achip_lut_t *__restrict__ lut,
                          uint8_t *__restrict__ out, uint64_t out_stride, uint32_t *__restrict__ out_len, int n_frames,
                          achip_uniform_t uni, unsigned long long *__restrict__ prof, achip_wire_t wire,
                          const uint4 *__restrict__ crc_tab, achip_packdev_t pack) {
-  /* PACK = true (lib/network/acip/server.c:190-222 ships exactly frame_size bytes): frames leave
+  /* PACK != 0 (lib/network/acip/server.c:190-222 ships exactly frame_size bytes): frames leave
    * the kernel at their EXACT length, back to back in pack.dst, and the fixed-stride slab is never written.  A frame's
    * length is only known once its last block has been tokenised, so the whole frame is staged in LDS (frames up to
    * ACHIP_PACK_FRAME_CAP bytes: 1080p -> 80x24 truecolor is 36 KB), its place in pack.dst is claimed with ONE atomic add of
    * round16(length) on a launch-wide cursor -- no workgroup ever waits for another: the order of the frames in pack.dst is
    * the order in which they finish, pack.off_out[i] says where frame i went -- and the workgroup copies it out with
-   * coalesced 16-byte stores.  The last workgroup to finish leaves the total in pack.off_out[n] and clears the cursor
-   * words for the plan's next launch.  `out` / out_stride only bound a frame's length here. */
+   * coalesced 16-byte stores.  PACK == 2: while those stores drain, the workgroup checksums the LDS image (wire.crc, and
+   * the packet header / packet CRC when asked for) the way crc32c_frame_kernel checksums a slab slot.  The last workgroup
+   * to finish leaves the total in pack.off_out[n] and clears the cursor words for the plan's next launch.  `out` /
+   * out_stride only bound a frame's length here. */
   /* CRC = true: the frame's CRC-32C (asciichat_crc32, lib/network/crc32.c:95-190 -- what acip_send_ascii_frame puts
    * into ascii_frame_packet_t.checksum, lib/network/acip/server.c:186-214) rides the drain: every wave checksums its
    * block while the bytes are in its staging area, the last wave to finish combines the blocks (a CRC is linear over
@@ -433,7 +447,8 @@ __global__ void __launch_bounds__(WAVES * 64)
   } while (0)
   static_assert(mode_is_cell(MODE), "run-structured modes use render_frames_kernel");
   using L = SLds<MODE, WAVES, CPL, CRC, PACK>;
-  static_assert(!PACK || (!GENERIC && MODE != ACHIP_MODE_TRUE_BG), "exact-length frames: single-source per-cell foreground modes");
+  static_assert(!PACK || (!GENERIC && !CRC && MODE != ACHIP_MODE_TRUE_BG), "exact-length frames: single-source per-cell foreground modes");
+  constexpr bool WIRE = CRC || PACK == 2; /* the launch leaves checksums (and headers) */
   constexpr int BLOCK = WAVES * 64;
   constexpr int BLK = L::BLK;
   constexpr int SH = BLK - L::EFF; /* 1: slot (k = 0, lane 0) is the ghost of the cell in front of the block */
@@ -452,7 +467,7 @@ __global__ void __launch_bounds__(WAVES * 64)
                    "s"(uni.enabled), "s"(uni.flags), "s"(uni.src_pitch), "s"(uni.f.src), "s"(uni.f.comp));
       asm volatile("" ::"s"(uni.f.src_w), "s"(uni.f.src_h), "s"(uni.f.out_w), "s"(uni.f.out_h), "s"(uni.f.pad_left),
                    "s"(uni.f.pad_top), "s"(uni.f.x_ratio), "s"(uni.f.y_ratio), "s"(uni.f.src_stride), "s"(uni.f.ops));
-      if (CRC) asm volatile("" ::"s"(wire.crc), "s"(wire.dims), "s"(wire.hdr), "s"(wire.pkt_crc), "s"(crc_tab));
+      if (WIRE) asm volatile("" ::"s"(wire.crc), "s"(wire.dims), "s"(wire.hdr), "s"(wire.pkt_crc), "s"(crc_tab));
       if (PACK) asm volatile("" ::"s"(pack.dst), "s"(pack.capacity), "s"(pack.off_out), "s"(pack.len_out), "s"(pack.cursor));)
   if (fidx >= n_frames)
     return;
@@ -476,15 +491,17 @@ __global__ void __launch_bounds__(WAVES * 64)
   ACHIP_SSTAMP(0);
   /* CRC: the constant tables are requested before anything else (L2 hits after a process's first launch) and go to
    * LDS in front of the barrier below; nothing of them is computed here */
-  constexpr int TABV = L::TAB_BYTES / 16, TABN = (TABV + BLOCK - 1) / BLOCK;
+  /* (PACK == 2: the 20 KB image crc_frame_tables_init_kernel<BLOCK> wrote: slicing tables + the Horner table) */
+  constexpr bool TABLES = CRC || PACK == 2;
+  constexpr int TABV = (PACK == 2 ? ACHIP_FRAME_CRC_TAB_BYTES : L::TAB_BYTES) / 16, TABN = (TABV + BLOCK - 1) / BLOCK;
   typedef uint32_t tab4_t __attribute__((vector_size(16))); /* a native vector: HIP's uint4 class keeps the array in scratch */
   tab4_t tabv[TABN > 0 ? TABN : 1];
   uint32_t dim_w = 0, dim_h = 0; /* header fields of this frame: every wave may be the one that finishes it */
-  if (CRC && wire.dims) {
+  if (WIRE && wire.dims) {
     dim_w = wire.dims[2 * fidx];
     dim_h = wire.dims[2 * fidx + 1];
   }
-  if (CRC) {
+  if (TABLES) {
 #pragma unroll
     for (int k = 0; k < TABN; k++) /* clamped, not predicated: the values stay in registers */
       tabv[k] = reinterpret_cast<const tab4_t *>(crc_tab)[tid + k * BLOCK < TABV ? tid + k * BLOCK : TABV - 1];
@@ -518,7 +535,7 @@ __global__ void __launch_bounds__(WAVES * 64)
       cells_ll > (long long)stream_maxblk(uni.flags, EFF) * EFF || out_stride > (uint64_t)ACHIP_STREAM_MAX_STRIDE) {
     if (tid == 0) {
       out_len[fidx] = ACHIP_LEN_BADDESC;
-      if (CRC) {
+      if (WIRE) {
         wire.crc[fidx] = 0u;
         if (wire.hdr) /* as the stand-alone kernel reports an unusable frame: a header of zeros, its CRC behind it */
           for (int j = 0; j < 24; j++)
@@ -535,8 +552,10 @@ __global__ void __launch_bounds__(WAVES * 64)
   const int nblk = (int)((ncells + EFF - 1) / EFF);
   const int nblk_cap = stream_maxblk(uni.flags, EFF); /* words in each per-block LDS array of this launch */
   (void)nblk_cap;
-  /* PACK: the frame must also fit its LDS image */
+  /* PACK: the frame must also fit its LDS image, which the launch sized for out_stride bytes (the host keeps that below
+   * ACHIP_PACK_FRAME_CAP) behind the per-block words */
   const uint32_t cap_bytes = PACK ? min((uint32_t)out_stride, (uint32_t)ACHIP_PACK_FRAME_CAP) : (uint32_t)out_stride;
+  const int frame_lds = PACK ? L::frame_off(nblk_cap) : 0;
   const uint32_t pad_left = (uint32_t)f.pad_left, uwp = (uint32_t)wp;
   StreamSrc src;
   src.base = f.src;
@@ -636,11 +655,13 @@ __global__ void __launch_bounds__(WAVES * 64)
   for (int k = tid; k < nblk; k += BLOCK)
     slots[k] = 0u;
   (void)ramp;
-  if (CRC) {
+  if (TABLES) {
 #pragma unroll
     for (int k = 0; k < TABN; k++)
       if (tid + k * BLOCK < TABV)
-        lds_ptr<tab4_t>(L::o_tab)[tid + k * BLOCK] = tabv[k];
+        lds_ptr<tab4_t>(PACK == 2 ? L::o_fcrc : L::o_tab)[tid + k * BLOCK] = tabv[k];
+  }
+  if (CRC) {
     for (int k = tid; k < nblk; k += BLOCK)
       slots[nblk_cap + k] = 0u; /* raw CRCs of blocks that could not be placed */
     if (tid < 4)
@@ -651,7 +672,7 @@ __global__ void __launch_bounds__(WAVES * 64)
   if (first_base > 0u && first_base <= cap_bytes)
     for (uint32_t o = (uint32_t)tid; o < first_base; o += BLOCK) {
       if (PACK)
-        lds_ptr<uint8_t>(L::o_stage)[o] = '\n';
+        lds_ptr<uint8_t>(frame_lds)[o] = '\n';
       else
         dst[o] = '\n';
     }
@@ -664,7 +685,7 @@ __global__ void __launch_bounds__(WAVES * 64)
   }
 
   /* PACK: every wave writes into the frame's own image (stream offset o at its byte o) */
-  const uint32_t stage_off = (uint32_t)(L::o_stage + (PACK ? 0 : wave * L::STAGE));
+  const uint32_t stage_off = (uint32_t)(PACK ? frame_lds : L::o_stage + wave * L::STAGE);
   const uint32_t stage_addr = lds_base_addr() + stage_off;
   /* predicated-off byte stores land in a per-lane dummy word (one address for all lanes would serialise them) */
   const uint32_t dummy_addr = lds_base_addr() + (uint32_t)L::o_flags + 16u + 4u * (uint32_t)lane;
@@ -788,7 +809,7 @@ __global__ void __launch_bounds__(WAVES * 64)
     if (ok) {
       /* ---- token bytes into this wave's staging area: stream offset g0 (16-byte aligned) sits at its byte 0 */
       const uint32_t g0 = PACK ? 0u : base & ~15u;
-      if (CRC && !PACK && lane == 0) /* the bytes in front of the block inside its first 16-byte group read as zero for the
+      if (CRC && lane == 0) /* the bytes in front of the block inside its first 16-byte group read as zero for the
                                checksum: leading zeros do not move a zero register (program order: before the tokens) */
         *lds_ptr<uint4>((int)stage_off) = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
@@ -839,9 +860,7 @@ __global__ void __launch_bounds__(WAVES * 64)
       /* ---- raw CRC of the block, from the staging area (after the stores to HBM have been issued), placed in the
        * frame; the last block to finish completes the frame (stream_crc_* above) */
       if (ok) {
-        const uint32_t braw = PACK ? stream_crc_staged<L, true>(lds_ptr<const unsigned char>((int)stage_off) + (base & ~15u),
-                                                                (base & 15u) + total, lane, base & 15u)
-                                   : stream_crc_staged<L>(lds_ptr<const unsigned char>((int)stage_off), (base & 15u) + total, lane);
+        const uint32_t braw = stream_crc_staged<L>(lds_ptr<const unsigned char>((int)stage_off), (base & 15u) + total, lane);
         stream_crc_place<L>(slots, nblk, nblk_cap, blk, braw, base + total, cap_bytes, lane);
       }
       stream_crc_finish<L>(slots, nblk, nblk_cap, cap_bytes, first_base, fidx, dim_w, dim_h, wire, lane);
@@ -867,17 +886,63 @@ __global__ void __launch_bounds__(WAVES * 64)
     const bool fits = n_total <= cap_bytes;
     const uint32_t room = fits ? (n_total + 15u) & ~15u : 0u;
     unsigned long long *offw = lds_ptr<unsigned long long>(L::o_packoff);
+    uint32_t *fslice = lds_ptr<uint32_t>(L::o_fcrc + CrcLds::o_slice), *fpw = lds_ptr<uint32_t>(L::o_fcrc + CrcLds::o_pow);
     if (tid == 0)
       offw[0] = agent_fetch_add_u64(&pack.cursor[0], (unsigned long long)room);
     if (tid >= 64 && tid < 80 && n_total + (uint32_t)(tid - 64) < room) /* the <= 15 bytes of padding leave as zeros */
-      lds_ptr<uint8_t>(L::o_stage)[n_total + (uint32_t)(tid - 64)] = 0;
+      lds_ptr<uint8_t>(frame_lds)[n_total + (uint32_t)(tid - 64)] = 0;
+    if (PACK == 2 && wire.hdr && wire.pkt_crc && fits) { /* the two scalar jobs of the packet CRC, on waves that idle here */
+      if (tid == BLOCK - 64)
+        fpw[0] = crc_header_state16(dim_w, dim_h, n_total);
+      else if (tid == BLOCK - 128)
+        fpw[1] = crc_x8_pow_len(n_total);
+    }
     __syncthreads();
     const unsigned long long off = offw[0];
+    const uint4 *from = lds_ptr<const uint4>(frame_lds);
     if (fits && off + room <= pack.capacity) {
       uint8_t *to = pack.dst + off;
-      const uint4 *from = lds_ptr<const uint4>(L::o_stage);
       for (uint32_t g = (uint32_t)tid; g < room / 16u; g += BLOCK)
         store_out16(to + 16u * g, from[g]);
+    }
+    if (PACK == 2) {
+      /* ---- the frame's CRC-32C from its LDS image while the stores drain: thread t folds groups t, t + BLOCK, ...
+       * Horner-style (zero groups in FRONT, the initial value folded into the first four bytes), one tree reduction, the
+       * < 16 tail bytes byte-wise -- crc32c_frame_kernel's scheme, on LDS instead of a slab slot */
+      const uint32_t *mulh = lds_ptr<const uint32_t>(L::o_fcrc + CrcLds::o_mulh);
+      uint32_t *tree = lds_ptr<uint32_t>(L::o_fcrc + CrcLds::o_tree);
+      const int full = fits ? (int)(n_total >> 4) : 0;
+      const int rounds = (full + BLOCK - 1) / BLOCK, lead = rounds * BLOCK - full;
+      uint32_t sreg = 0;
+      for (int j = 0; j < rounds; j++) {
+        const int g = j * BLOCK + tid - lead;
+        uint4 d = make_uint4(0u, 0u, 0u, 0u);
+        if (g >= 0) {
+          d = from[g];
+          if (g == 0)
+            d.x = ~d.x;
+        }
+        sreg = crc_mul_table(mulh, sreg) ^ crc_raw16(fslice, d);
+      }
+      crc_tree<BLOCK>(tree, sreg, tid);
+      if (tid == 0) {
+        const unsigned char *fb = lds_ptr<const unsigned char>(frame_lds);
+        uint32_t st = full > 0 ? tree[0] : 0xFFFFFFFFu;
+        for (uint32_t k = (uint32_t)full * 16u; fits && k < n_total; k++)
+          st = (st >> 8) ^ fslice[(st ^ fb[k]) & 0xFFu];
+        const uint32_t crc = fits ? ~st : 0u;
+        wire.crc[fidx] = crc;
+        if (wire.hdr) {
+          if (fits)
+            crc_emit_packet(fpw[0], fpw[1], st, crc, dim_w, dim_h, n_total, false, fidx, fslice, wire.hdr, wire.pkt_crc);
+          else { /* as the fused stream checksum reports a frame that did not fit: a header of zeros, its CRC behind it */
+            for (int j = 0; j < 24; j++)
+              wire.hdr[(size_t)fidx * 24u + j] = 0;
+            if (wire.pkt_crc)
+              wire.pkt_crc[fidx] = ~crc_mulmod(0xFFFFFFFFu, crc_pow(CRC_X8, 24u));
+          }
+        }
+      }
     }
     if (tid == 0)
       pack_report(off, fits ? n_total : ACHIP_LEN_OVERFLOW);

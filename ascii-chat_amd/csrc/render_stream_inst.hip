@@ -92,13 +92,45 @@ hipError_t launch_one(const achip_frame_t *frames, int n, const achip_lut_t *lut
   return hipGetLastError();
 }
 
-/* PACK instantiations (exact-length frames straight from the render; geometry 16 only): with or without the frame CRC */
-template <int MODE, bool CRC>
+/* PACK instantiations (exact-length frames straight from the render; geometries 16 and 17): frames only, or with the
+ * frame checksummed from its LDS image (wire stage) */
+template <int BLOCK> hipError_t frame_crc_tables(const uint4 **out) {
+  constexpr int MAX_DEVICES = 16;
+  static std::mutex mu;
+  static uint32_t *tab[MAX_DEVICES] = {};
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess)
+    return e;
+  if (dev < 0 || dev >= MAX_DEVICES)
+    return hipErrorInvalidDevice;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!tab[dev]) {
+    uint32_t *t = nullptr;
+    e = hipMalloc(reinterpret_cast<void **>(&t), (size_t)ACHIP_FRAME_CRC_TAB_BYTES);
+    if (e != hipSuccess)
+      return e;
+    hipLaunchKernelGGL((achip::crc_frame_tables_init_kernel<BLOCK>), dim3(1), dim3(256), ACHIP_FRAME_CRC_TAB_BYTES, nullptr, t);
+    e = hipGetLastError();
+    if (e == hipSuccess)
+      e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+      (void)hipFree(t);
+      return e;
+    }
+    tab[dev] = t;
+  }
+  *out = reinterpret_cast<const uint4 *>(tab[dev]);
+  return hipSuccess;
+}
+
+template <int MODE, bool WIRE>
 hipError_t launch_pack(const achip_frame_t *frames, int n, const achip_lut_t *lut, uint64_t stride, uint32_t *len,
                        const achip_uniform_t &uni, const achip_wire_t &wire, const achip_packdev_t &pack, hipStream_t stream) {
-  if constexpr (ACHIP_SINST == 16 && MODE != ACHIP_MODE_TRUE_BG) {
-    using L = achip::SLds<MODE, G::WAVES, G::CPL, CRC, true>;
-    auto kern = achip::render_stream_kernel<MODE, G::WAVES, G::CPL, false, CRC, true>;
+  if constexpr ((ACHIP_SINST == 16 || ACHIP_SINST == 17) && MODE != ACHIP_MODE_TRUE_BG) {
+    constexpr int PACK = WIRE ? 2 : 1;
+    using L = achip::SLds<MODE, G::WAVES, G::CPL, false, PACK>;
+    auto kern = achip::render_stream_kernel<MODE, G::WAVES, G::CPL, false, false, PACK>;
     static bool attr_set = false;
     if (!attr_set) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, L::bytes);
@@ -107,16 +139,14 @@ hipError_t launch_pack(const achip_frame_t *frames, int n, const achip_lut_t *lu
       attr_set = true;
     }
     const uint4 *tab = nullptr;
-    if constexpr (CRC) {
-      /* the constant tables sit at the same offsets from o_tab in every layout of a (mode, geometry): one image serves both */
-      static_assert(L::TAB_BYTES == achip::SLds<MODE, G::WAVES, G::CPL, true>::TAB_BYTES && L::GPL == achip::SLds<MODE, G::WAVES, G::CPL, true>::GPL &&
-                        L::WIN == achip::SLds<MODE, G::WAVES, G::CPL, true>::WIN,
-                    "PACK and plain CRC layouts share the table image");
-      hipError_t e = crc_tables<MODE>(&tab);
+    if constexpr (WIRE) {
+      hipError_t e = frame_crc_tables<G::WAVES * 64>(&tab);
       if (e != hipSuccess)
         return e;
     }
-    const size_t lds = (size_t)((L::bytes_for(achip::stream_maxblk(uni.flags, L::EFF)) + 15) & ~15);
+    /* LDS: the tables, the per-block words of the launch's largest frame, then the frame's image -- as long as the
+     * launch's frames can be (`stride`, the plan's bound): two 8-wave workgroups of 1080p -> 80x24 frames share a CU */
+    const size_t lds = (size_t)((L::bytes_for_pack(achip::stream_maxblk(uni.flags, L::EFF), (int)stride) + 15) & ~15);
     hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(G::WAVES * 64), lds, stream, frames, lut, static_cast<uint8_t *>(nullptr),
                        stride, len, n, uni, static_cast<unsigned long long *>(nullptr), wire, tab, pack);
     return hipGetLastError();
@@ -164,8 +194,8 @@ extern "C" int ACHIP_CAT(achip_render_sinst_launch_, ACHIP_SINST)(int mode, int 
   return (int)hipErrorInvalidValue;
 }
 
-#if ACHIP_SINST == 16
-extern "C" int achip_render_sinst_pack_launch(int mode, const achip_frame_t *frames, int n, const achip_lut_t *lut,
+#if ACHIP_SINST == 16 || ACHIP_SINST == 17
+extern "C" int ACHIP_CAT(achip_render_sinst_pack_launch_, ACHIP_SINST)(int mode, const achip_frame_t *frames, int n, const achip_lut_t *lut,
                                               uint64_t stride, uint32_t *len, const achip_uniform_t *uniform,
                                               const achip_wire_t *wire, const achip_packdev_t *pack, void *stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);

@@ -915,7 +915,6 @@ def time_with_d2h_packed(torch, pkg, plans, n, steps, lanes=2):
     for hb in hbs:
         hb.close()
     return {"ms_per_step": dt * 1e3, "frames_per_s": n / dt, "bytes_over_pcie_per_step": total + tab,
-            "exact_length_frames_written_by_the_render_kernel": bool(plans[0].exact_length),
             "GBps": (total + tab) / dt / 1e9, "fixed_stride_bytes_per_step": n * stride + 4 * n, "lanes": lanes,
             "note": "render + pack kernel storing the bytes in use (16-byte aligned frame starts) and the offset / length "
                     "tables straight into mapped pinned host memory; no DMA, no host round trip for a size"}

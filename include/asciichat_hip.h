@@ -369,7 +369,9 @@ int asciichat_hip_plan_render_packets(asciichat_hip_plan_t *plan, uint8_t *out_d
 /* ... plus the compaction.  Three forms, chosen by the plan:
  *   (1) ONE launch that writes the frames at their exact lengths itself -- whole-frame plans of the per-cell foreground
  *       modes (truecolor with an all-ASCII palette, 256, 16 colours; single sources) whose slab stride is at most 48 KB
- *       (asciichat_hip_plan_get_exact_length() != 0; 1080p -> 80x24 truecolor is 36 KB per frame).  The slab is NOT written
+ *       (asciichat_hip_plan_get_exact_length() != 0; 1080p -> 80x24 truecolor is 36 KB per frame) AND, by default, only
+ *       for a destination in device memory (into mapped host memory form (2) is the faster one: a workgroup of (1) holds
+ *       its CU until its stores have crossed PCIe).  The slab is NOT written
  *       (slab_dev may be NULL); frames lie in dst back to back in the order in which they FINISH, every start 16-byte
  *       aligned: off_out[i] says where frame i went (off_out is needed to find a frame), off_out[n] the total.  The
  *       padding behind a frame is zeros.  asciichat_hip_plan_set_exact_length(plan, 0) keeps such a plan on (2).
@@ -378,7 +380,9 @@ int asciichat_hip_plan_render_packets(asciichat_hip_plan_t *plan, uint8_t *out_d
  *       in (2) and (3) frame i lies at off_out[i] = sum over j < i of round16(len[j]) and the slab holds the frames too.
  * asciichat_hip_plan_render_packed (no wire stage) follows the same rule. */
 int asciichat_hip_plan_get_exact_length(const asciichat_hip_plan_t *plan);
-int asciichat_hip_plan_set_exact_length(asciichat_hip_plan_t *plan, int mode); /* -1 wherever the plan qualifies (default), 0 never */
+int asciichat_hip_plan_set_exact_length(asciichat_hip_plan_t *plan, int mode); /* -1 where it is the faster form (default:
+                                                                                   destinations in device memory), 0 never,
+                                                                                   1 wherever the plan qualifies */
 int asciichat_hip_plan_render_packets_packed(asciichat_hip_plan_t *plan, uint8_t *slab_dev, size_t out_stride,
                                              uint32_t *out_len_dev, const uint32_t *dims_dev, uint32_t *crc_out_dev,
                                              uint8_t *hdr_out_dev, uint32_t *packet_crc_out_dev, uint8_t *dst,

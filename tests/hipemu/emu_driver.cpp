@@ -146,27 +146,28 @@ extern "C" int emu_render_stream_crc(int mode, int variant, const achip_frame_t 
 }
 
 /* the stream kernel's PACK instantiations: frames at their exact lengths straight into `dst` (no slab), with or without
- * the fused frame CRC.  Geometry 16 is the product's; 20 (two waves, one cell per lane) makes tiny frames multi-block. */
-template <int MODE, int WAVES, int CPL, bool CRC>
+ * the wire stage (the frame checksummed from its LDS image).  Geometries 16 / 17 are the product's; 20 (two waves, one cell
+ * per lane) makes tiny frames multi-block. */
+template <int MODE, int WAVES, int CPL, bool WIRE>
 static void run_stream_pack(const achip_frame_t *frames, int n, const achip_lut_t *lut, uint64_t stride, uint32_t *len,
                             const achip_wire_t &wire, const achip_packdev_t &pack) {
-  using L = achip::SLds<MODE, WAVES, CPL, CRC, true>;
-  using LC = achip::SLds<MODE, WAVES, CPL, true, true>;
+  constexpr int PACK = WIRE ? 2 : 1;
+  using L = achip::SLds<MODE, WAVES, CPL, false, PACK>;
   achip_uniform_t uni = {};
   if (g_uniform)
     (void)achip_frames_uniform(frames, n, &uni);
   uni.flags = ((lut->flags & ACHIP_LUT_MULTIBYTE) ? 0u : ACHIP_UNIFORM_PALETTE_ASCII) |
               ACHIP_UNIFORM_MAX_CELLS(achip_max_cells(frames, n));
-  static std::vector<uint32_t> tab;
-  if (CRC && tab.empty()) {
-    tab.resize(LC::TAB_BYTES / 4 + 4);
+  static std::vector<uint32_t> tab; /* per block size: the Horner table is x^(128 * BLOCK) */
+  if (WIRE && tab.empty()) {
+    tab.resize(ACHIP_FRAME_CRC_TAB_BYTES / 4 + 4);
     uint32_t *t = tab.data();
-    hipemu::launch(dim3(1), dim3(256), 0, [&] { achip::crc_tables_init_kernel<LC>(t); });
+    hipemu::launch(dim3(1), dim3(256), ACHIP_FRAME_CRC_TAB_BYTES, [&] { achip::crc_frame_tables_init_kernel<WAVES * 64>(t); });
   }
-  const uint4 *tabv = CRC ? reinterpret_cast<const uint4 *>(tab.data()) : nullptr;
-  const size_t lds = (size_t)((L::bytes_for(achip::stream_maxblk(uni.flags, L::EFF)) + 15) & ~15);
+  const uint4 *tabv = WIRE ? reinterpret_cast<const uint4 *>(tab.data()) : nullptr;
+  const size_t lds = (size_t)((L::bytes_for_pack(achip::stream_maxblk(uni.flags, L::EFF), (int)stride) + 15) & ~15);
   hipemu::launch(dim3((unsigned)n), dim3(WAVES * 64), lds, [&] {
-    achip::render_stream_kernel<MODE, WAVES, CPL, false, CRC, true>(frames, lut, nullptr, stride, len, n, uni, nullptr, wire, tabv, pack);
+    achip::render_stream_kernel<MODE, WAVES, CPL, false, false, PACK>(frames, lut, nullptr, stride, len, n, uni, nullptr, wire, tabv, pack);
   });
 }
 extern "C" int emu_render_stream_pack(int mode, int variant, const achip_frame_t *frames, int n, const achip_lut_t *lut,
@@ -187,6 +188,8 @@ extern "C" int emu_render_stream_pack(int mode, int variant, const achip_frame_t
     M(ACHIP_MODE_TRUE_FG, 2, 1) M(ACHIP_MODE_256_FG, 2, 1) M(ACHIP_MODE_16_FG, 2, 1)
   } else if (variant == 16) {
     M(ACHIP_MODE_TRUE_FG, 16, 2) M(ACHIP_MODE_256_FG, 16, 2) M(ACHIP_MODE_16_FG, 16, 2)
+  } else if (variant == 17) {
+    M(ACHIP_MODE_TRUE_FG, 8, 2) M(ACHIP_MODE_256_FG, 8, 2) M(ACHIP_MODE_16_FG, 8, 2)
   }
 #undef M
   return -1;

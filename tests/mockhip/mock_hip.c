@@ -70,6 +70,10 @@ hipError_t hipHostFree(void *p) {
   free(p);
   return hipSuccess;
 }
+hipError_t hipPointerGetAttributes(hipPointerAttribute_t *attr, const void *ptr) { /* nothing is known about any pointer here */
+  (void)attr, (void)ptr;
+  return hipErrorInvalidValue;
+}
 hipError_t hipHostGetDevicePointer(void **dev, void *host, unsigned int flags) {
   (void)flags;
   *dev = host;

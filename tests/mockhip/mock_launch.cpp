@@ -122,7 +122,7 @@ extern "C" int emu_render_stream_pack(int mode, int variant, const achip_frame_t
                                       uint32_t *pkt, uint8_t *dst, uint64_t capacity, uint64_t *off_out, uint32_t *len_out,
                                       unsigned long long *cursor);
 extern "C" int achip_pack_frame_cap(void) { return 48 * 1024; }
-extern "C" int achip_launch_render_pack(int mode, const achip_frame_t *frames, int n, const achip_lut_t *lut, uint64_t bound,
+extern "C" int achip_launch_render_pack(int mode, int variant, const achip_frame_t *frames, int n, const achip_lut_t *lut, uint64_t bound,
                                         uint32_t *out_len, const achip_wire_t *wire, const achip_uniform_t *uniform,
                                         const achip_packdev_t *pack, void *stream) {
   (void)uniform, (void)stream;
@@ -131,7 +131,7 @@ extern "C" int achip_launch_render_pack(int mode, const achip_frame_t *frames, i
   if (!pack || !pack->dst || !pack->cursor || bound > 48 * 1024 || (wire && !wire->crc))
     return MOCK_INVALID;
   std::lock_guard<std::mutex> lock(g_emu_mu);
-  const int rc = emu_render_stream_pack(mode, 16, frames, n, lut, bound, out_len, wire ? wire->crc : nullptr,
+  const int rc = emu_render_stream_pack(mode, variant == 16 ? 16 : 17, frames, n, lut, bound, out_len, wire ? wire->crc : nullptr,
                                         wire ? wire->dims : nullptr, wire ? wire->hdr : nullptr, wire ? wire->pkt_crc : nullptr,
                                         pack->dst, pack->capacity, pack->off_out, pack->len_out, pack->cursor);
   return rc == 0 ? MOCK_OK : MOCK_INVALID;

@@ -72,10 +72,10 @@ int achip_launch_render_crc(int mode, int variant, int has_composite, const achi
       (void)out_len, (void)wire, (void)uniform, (void)prof, (void)stream;
   return MOCK_UNSUPPORTED;
 }
-int achip_launch_render_pack(int mode, const achip_frame_t *frames_dev, int n_frames, const achip_lut_t *lut_dev, uint64_t bound,
+int achip_launch_render_pack(int mode, int variant, const achip_frame_t *frames_dev, int n_frames, const achip_lut_t *lut_dev, uint64_t bound,
                              uint32_t *out_len, const achip_wire_t *wire, const achip_uniform_t *uniform,
                              const achip_packdev_t *pack, void *stream) {
-  (void)mode, (void)frames_dev, (void)n_frames, (void)lut_dev, (void)bound, (void)out_len, (void)wire, (void)uniform, (void)pack,
+  (void)mode, (void)variant, (void)frames_dev, (void)n_frames, (void)lut_dev, (void)bound, (void)out_len, (void)wire, (void)uniform, (void)pack,
       (void)stream;
   return MOCK_UNSUPPORTED;
 }

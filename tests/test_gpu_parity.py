@@ -873,8 +873,9 @@ def test_exact_length_frames_full_batch(gpu):
         d32 = torch.tensor([[W, H]] * n, dtype=torch.int32, device="cuda")
         tab = (8 * (n + 1) + 4 * n + 15) // 16 * 16
 
-        def run(one_launch, host_dst):
-            plan.set_exact_length(-1 if one_launch else 0)
+        def run(one_launch, host_dst, force=True):
+            # 1 = wherever the plan qualifies; -1 = the automatic choice: device destinations only
+            plan.set_exact_length((1 if force else -1) if one_launch else 0)
             slab = torch.full((n * stride,), 0xEE, dtype=torch.uint8, device="cuda")
             ln = torch.zeros(n, dtype=torch.int32, device="cuda")
             crc = torch.zeros(n, dtype=torch.int32, device="cuda")
@@ -898,15 +899,15 @@ def test_exact_length_frames_full_batch(gpu):
             fr = [v[tab + int(off[i]):tab + int(off[i]) + int(pl[i])].tobytes() for i in range(n)]
             spans = sorted((int(off[i]), int(off[i]) + (int(pl[i]) + 15) // 16 * 16) for i in range(n))
             assert spans[0][0] == 0 and all(spans[i][1] == spans[i + 1][0] for i in range(n - 1)) and spans[-1][1] == int(off[n])
-            assert bool((slab == 0xEE).all()) == one_launch
+            assert bool((slab == 0xEE).all()) == (one_launch and (force or not host_dst))
             return fr, ln.cpu().numpy(), crc.cpu().numpy(), hdr.cpu().numpy(), pkt.cpu().numpy(), pl
 
         ref = run(False, False)
-        for host_dst in (False, True):
-            got = run(True, host_dst)
-            assert got[0] == ref[0], (mode, host_dst)
+        for host_dst, force in ((False, True), (True, True), (False, False), (True, False)):
+            got = run(True, host_dst, force)  # (not forced: one launch into device memory, render + pack into host memory)
+            assert got[0] == ref[0], (mode, host_dst, force)
             for a, b in zip(got[1:], ref[1:]):
-                assert np.array_equal(a, b), (mode, host_dst)
+                assert np.array_equal(a, b), (mode, host_dst, force)
         for i in (0, 1, 2, 3, 100, 255):
             exp = orc.convert_with_caps(frames_t[i].cpu().numpy(), W, H, cl, 0, asp, asp, False)
             assert ref[0][i] == exp and int(ref[2][i]) & 0xFFFFFFFF == orc.crc32c(exp), (mode, i)
@@ -1181,6 +1182,7 @@ def test_render_packets_packed_one_pass(gpu):
         pkg.pack_frames(out_a.data_ptr(), stride, ln_a.data_ptr(), n, hb_a.dev + tab, n * stride, hb_a.dev, hb_a.dev + 8 * (n + 1), stream)
         out_b, ln_b, crc_b, hdr_b, pkt_b = bufs()
         hb_b = pkg.HostBuffer(tab + n * stride)
+        plan.set_exact_length(1)  # (the automatic choice keeps mapped host destinations on the two-launch form)
         plan.render_packets_packed(out_b.data_ptr(), stride, ln_b.data_ptr(), d32.data_ptr(), crc_b.data_ptr(), hdr_b.data_ptr(),
                                    pkt_b.data_ptr(), hb_b.dev + tab, n * stride, hb_b.dev, hb_b.dev + 8 * (n + 1), stream)
         torch.cuda.synchronize()

@@ -351,7 +351,7 @@ def test_stream_kernel_exact_length_frames(mode):
     dims = [(80, 24), (60, 7), (33, 40), (1, 50), (3, 2), (80, 24)]
     frames = [emu.frame_for_convert(im, w, h, 0) for im, (w, h) in zip(imgs, dims)]
     expected = [oracle_convert(im, mode, w, h, orc.PALETTE_STANDARD) for im, (w, h) in zip(imgs, dims)]
-    for variant in (20, 16):
+    for variant in (20, 16, 17):
         for want_crc in (True, False):
             res = emu.render_frames_packed(mode, frames, orc.PALETTE_STANDARD, variant, dims=dims, want_crc=want_crc)
             check_packed(res, expected, (mode, variant, want_crc))
@@ -367,7 +367,7 @@ def test_stream_kernel_exact_length_frames(mode):
     # aspect + padding (newlines in front that no block stages, pad cells), the uniform-descriptor path
     padded = [emu.frame_for_convert(TORTURE, W, H, 0, True, True) for (W, H) in ((80, 24), (200, 20), (31, 60))]
     exp_p = [oracle_convert(TORTURE, mode, W, H, orc.PALETTE_STANDARD, True, True) for (W, H) in ((80, 24), (200, 20), (31, 60))]
-    for variant in (20, 16):
+    for variant in (20, 16, 17):
         check_packed(emu.render_frames_packed(mode, padded, orc.PALETTE_STANDARD, variant), exp_p, (mode, variant, "padded"))
     # a frame that does not fit its bound takes no room and reports the overflow code; the others are unaffected
     small = emu.render_frames_packed(mode, frames, orc.PALETTE_STANDARD, 20, stride=2048)
