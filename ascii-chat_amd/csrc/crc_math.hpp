@@ -119,6 +119,25 @@ __device__ inline uint32_t crc_x8_pow_len(uint32_t len) {
   return r;
 }
 
+/* Combining the registers of a workgroup whose thread t checksummed groups t, t + BLOCK, ... (so that its last group is
+ * followed by BLOCK-1 - t groups) WITHOUT a barrier-fenced tree: lane l of a wave multiplies by x^(128 * (63 - l)) -- a
+ * per-lane constant from this table -- one xor reduction gives the wave's register, and the (<= 16) wave registers are
+ * folded with the constant x^(128 * 64) by one wave (render_stream.hpp: crc_reduce_waves).  x^k for the wave-uniform
+ * multiply (wave_mulmod_uniform) rides in the same table. */
+struct CrcLaneTab {
+  uint32_t k[64];  /* x^(128 * (63 - l)) */
+  uint32_t xk[64]; /* x^l mod P, l < 63; 0 for l = 63 */
+};
+__host__ __device__ constexpr CrcLaneTab crc_make_lane_tab() {
+  CrcLaneTab r{};
+  for (int l = 0; l < 64; l++) {
+    r.k[l] = crc_pow(CRC_X8, 16ull * (uint64_t)(63 - l));
+    r.xk[l] = l == 63 ? 0u : (l < 32 ? 0x80000000u >> l : crc_mulmod(1u, 0x80000000u >> (l - 31)));
+  }
+  return r;
+}
+__device__ const CrcLaneTab CRC_LANE_TAB = crc_make_lane_tab();
+
 __device__ inline uint32_t bswap32(uint32_t v) {
   return (v >> 24) | ((v >> 8) & 0xFF00u) | ((v << 8) & 0xFF0000u) | (v << 24);
 }

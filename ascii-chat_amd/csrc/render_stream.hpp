@@ -201,6 +201,26 @@ __device__ inline uint32_t wave_mulmod_uniform(uint32_t a, uint32_t b, int lane,
   const uint32_t c = (uint32_t)__builtin_popcount(a & m) & 1u;
   return wave_read_lane(wave_xor_to_last((0u - c) & xk), 63);
 }
+/* Sum over the workgroup's threads of s_t * x^(128 * (BLOCK-1 - t)) -- the register after all their groups -- valid in
+ * wave 0: one multiplication by the lane's constant, one xor reduction per wave, one hand-off through `scratch`
+ * (BLOCK / 64 words of LDS), WAVES - 1 wave-uniform multiplications.  klane / xk: this lane's entries of CRC_LANE_TAB
+ * (requested at kernel entry).  Replaces crc_tree's log2(BLOCK) barrier-fenced levels in the exact-length instantiations. */
+template <int BLOCK>
+__device__ inline uint32_t crc_reduce_waves(uint32_t *scratch, uint32_t s, int tid, uint32_t klane, uint32_t xk) {
+  constexpr uint32_t WC = crc_pow(CRC_X8, 16ull * 64ull); /* x^(128 * 64): one wave's worth of groups */
+  const int lane = tid & 63, wave = wave_uniform(tid >> 6);
+  const uint32_t v = wave_read_lane(wave_xor_to_last(crc_mulmod(s, klane)), 63);
+  if (lane == 0)
+    scratch[wave] = v;
+  __syncthreads();
+  uint32_t acc = 0;
+  if (wave == 0) {
+    acc = scratch[0];
+    for (int w = 1; w < BLOCK / 64; w++)
+      acc = wave_mulmod_uniform(acc, WC, lane, xk) ^ scratch[w];
+  }
+  return acc;
+}
 /* x^(8n) for wave-uniform n from the LDS copies of CRC_POW_TAB's levels (n < 2^24; above: bit-serial fallback) */
 __device__ inline uint32_t wave_x8_pow_uniform(const uint32_t *pw, uint32_t n, int lane, uint32_t xk) {
   if (n >> 24)
@@ -500,6 +520,11 @@ __global__ void __launch_bounds__(WAVES * 64)
   if (WIRE && wire.dims) {
     dim_w = wire.dims[2 * fidx];
     dim_h = wire.dims[2 * fidx + 1];
+  }
+  uint32_t lane_k = 0, lane_xk = 0; /* PACK == 2: this lane's constants of the final reduction (crc_reduce_waves) */
+  if (PACK == 2) {
+    lane_k = CRC_LANE_TAB.k[lane];
+    lane_xk = CRC_LANE_TAB.xk[lane];
   }
   if (TABLES) {
 #pragma unroll
@@ -924,10 +949,10 @@ __global__ void __launch_bounds__(WAVES * 64)
         }
         sreg = crc_mul_table(mulh, sreg) ^ crc_raw16(fslice, d);
       }
-      crc_tree<BLOCK>(tree, sreg, tid);
+      const uint32_t whole = crc_reduce_waves<BLOCK>(tree, sreg, tid, lane_k, lane_xk);
       if (tid == 0) {
         const unsigned char *fb = lds_ptr<const unsigned char>(frame_lds);
-        uint32_t st = full > 0 ? tree[0] : 0xFFFFFFFFu;
+        uint32_t st = full > 0 ? whole : 0xFFFFFFFFu;
         for (uint32_t k = (uint32_t)full * 16u; fits && k < n_total; k++)
           st = (st >> 8) ^ fslice[(st ^ fb[k]) & 0xFFu];
         const uint32_t crc = fits ? ~st : 0u;

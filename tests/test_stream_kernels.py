@@ -181,7 +181,10 @@ def test_pack_frames_gpu_device_and_mapped_host_destinations():
     v = hb.view()
     o2 = v[:8 * (n + 1)].view(np.uint64)
     l2 = v[8 * (n + 1):8 * (n + 1) + 4 * n].view(np.uint32)
-    assert np.array_equal(o2, o.astype(np.uint64)) and np.array_equal(l2, l.astype(np.uint32))
+    # (the device destination above took the one-launch form: frames in completion order; into mapped host memory the plan
+    # renders and packs: frames in frame order -- the offsets differ, the lengths, the total and every frame's bytes do not)
+    assert int(o2[n]) == int(o[n]) and np.array_equal(l2, l.astype(np.uint32))
+    assert all(int(o2[i + 1]) == int(o2[i]) + (int(l2[i]) + 15) // 16 * 16 for i in range(n))
     for i in range(n):
         assert v[tab + int(o2[i]):tab + int(o2[i]) + int(l2[i])].tobytes() == exp[i], i
     hb.close()
