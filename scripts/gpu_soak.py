@@ -140,6 +140,36 @@ def main():
         assert (crc_c.cpu().numpy().astype(np.uint32) == crc_h).all(), ("fused crc", rnd, plan.variant, plan.fused_crc)
         assert (pkt_c.cpu().numpy().astype(np.uint32) == pkt_h).all() and (hdr_c.cpu().numpy() == hdr_h).all(), ("fused packets", rnd)
         fused_rounds = locals().get("fused_rounds", 0) + int(plan.fused_crc)
+        # frames at their exact lengths straight from the render kernel (per-cell plans whose frames fit the LDS image):
+        # every frame's bytes at its offset, the destination tiled in some order, checksums / headers / packet CRCs
+        if plan.exact_length:
+            exact_rounds = locals().get("exact_rounds", 0) + 1
+            plan.set_exact_length(1)
+            cap_x = nfr * plan.stride
+            dst_x = torch.full((cap_x,), 0x3C, dtype=torch.uint8, device="cuda")
+            off_x = torch.zeros(nfr + 1, dtype=torch.int64, device="cuda")
+            pl_x = torch.zeros(nfr, dtype=torch.int32, device="cuda")
+            ln_x = torch.zeros(nfr, dtype=torch.int32, device="cuda")
+            crc_x = torch.full((nfr,), 0x7E7E7E7E, dtype=torch.int32, device="cuda")
+            hdr_x = torch.zeros(nfr * 24, dtype=torch.uint8, device="cuda")
+            pkt_x = torch.zeros(nfr, dtype=torch.int32, device="cuda")
+            for _ in range(2):
+                if rnd % 2:
+                    plan.render_packets_packed(0, plan.stride, ln_x.data_ptr(), dims_t.data_ptr(), crc_x.data_ptr(), hdr_x.data_ptr(),
+                                               pkt_x.data_ptr(), dst_x.data_ptr(), cap_x, off_x.data_ptr(), pl_x.data_ptr(), st_c)
+                else:
+                    plan.render_packed(0, plan.stride, ln_x.data_ptr(), dst_x.data_ptr(), cap_x, off_x.data_ptr(), pl_x.data_ptr(), st_c)
+            torch.cuda.synchronize()
+            dx, ox, px = dst_x.cpu().numpy(), off_x.cpu().numpy(), pl_x.cpu().numpy().astype(np.uint32)
+            assert (px == lens).all() and (ln_x.cpu().numpy().astype(np.uint32) == lens).all(), ("exact lengths", rnd)
+            spans = sorted((int(ox[k]), int(ox[k]) + (int(lens[k]) + 15) // 16 * 16) for k in range(nfr))
+            assert spans[0][0] == 0 and all(spans[k][1] == spans[k + 1][0] for k in range(nfr - 1)) and spans[-1][1] == int(ox[nfr]), ("exact tiling", rnd)
+            for k in range(nfr):
+                assert dx[int(ox[k]):int(ox[k]) + int(lens[k])].tobytes() == host[k * plan.stride:k * plan.stride + int(lens[k])].tobytes(), ("exact bytes", rnd, k)
+            if rnd % 2:
+                assert (crc_x.cpu().numpy().astype(np.uint32) == crc_h).all(), ("exact crc", rnd, plan.variant)
+                assert (pkt_x.cpu().numpy().astype(np.uint32) == pkt_h).all() and (hdr_x.cpu().numpy() == hdr_h).all(), ("exact packets", rnd)
+            plan.set_exact_length(-1)
         # the same plan after an update to new terminal sizes (the tick when clients resize), rendered as two
         # sub-ranges into the slab (what the ranks of a sharded batch do)
         if rnd % 3 == 0 and (flt or fx or fy) == 0:
