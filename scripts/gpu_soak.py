@@ -247,7 +247,9 @@ def main():
         print(f"composite {rnd:3d}: {MODE_NAMES[mode]:10s} sources {n_src} term {tw}x{th} clients {nclients:2d} v{plan.variant} bands {plan.parts:3d} ok", flush=True)
         plan.close()
         pkg.lib().asciichat_hip_free(comp_dev)
-    print(f"soak OK: {checked} frames + {comp_checked} composite frames byte-identical to the oracle")
+    print(f"soak OK: {checked} frames + {comp_checked} composite frames byte-identical to the oracle; "
+          f"{locals().get('fused_rounds', 0)} batches with the checksum fused into the render, {locals().get('exact_rounds', 0)} "
+          "batches also written at their exact lengths by the render kernel (tiling, bytes, checksums, headers checked)")
 
 
 if __name__ == "__main__":
