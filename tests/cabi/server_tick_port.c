@@ -198,6 +198,84 @@ static void run_tick(int force_variant) {
          "slab bytes crossed PCIe\n", CLIENTS, (size_t)off_h[CLIENTS], cap);
   asciichat_hip_host_free(host);
 
+  /* ---- tick three: the table keeps the IMAGES the targets sample, the render reads them where
+   * the tick's one DMA put them, and the send side -- frames at their exact lengths, checksums, headers -- is one call.
+   * Clients whose target takes their frame as it is (the 2x2 source: nothing to compact) publish the whole blob; the others
+   * are staged, first one by one as receive threads would, then a fourth tick through the batch form. */
+  achip_frame_t targets[CLIENTS], frames3[CLIENTS];
+  for (int c = 0; c < CLIENTS; c++)
+    CHECK(achip_frame_setup(&targets[c], NULL, src_w[c], src_h[c], term_w[c], term_h[c], caps.render_mode, caps.wants_padding, true,
+                            false) == 0,
+          "target of client %d", c);
+  uint8_t *dst3 = NULL;
+  uint64_t *off3 = NULL;
+  uint32_t *plen3 = NULL;
+  HIP(hipMalloc((void **)&dst3, cap));
+  HIP(hipMalloc((void **)&off3, 8 * (CLIENTS + 1)));
+  HIP(hipMalloc((void **)&plen3, 4 * CLIENTS));
+  uint8_t *dst3_h = (uint8_t *)malloc(cap);
+  CHECK(dst3_h != NULL, "malloc");
+  for (int tick = 3; tick <= 4; tick++) {
+    int staged = 0, whole = 0, sslots[CLIENTS];
+    const void *sblobs[CLIENTS];
+    size_t ssizes[CLIENTS];
+    achip_frame_t stargets[CLIENTS];
+    for (int c = 0; c < CLIENTS; c++) {
+      const int compacts = targets[c].out_h < src_h[c] || 2 * targets[c].out_w <= src_w[c];
+      if (!compacts) {
+        CHECK(asciichat_hip_frame_table_stage(table, c, blob[c], blob_sizes[c], &targets[c]) != 0, "client %d: nothing to compact", c);
+        CHECK(asciichat_hip_frame_table_publish(table, c, blob[c], blob_sizes[c], upload) == 0, "publish client %d", c);
+        whole++;
+      } else if (tick == 3) {
+        CHECK(asciichat_hip_frame_table_stage(table, c, blob[c], blob_sizes[c], &targets[c]) == 0, "stage client %d", c);
+        staged++;
+      } else {
+        sslots[staged] = c, sblobs[staged] = blob[c], ssizes[staged] = blob_sizes[c], stargets[staged] = targets[c];
+        staged++;
+      }
+    }
+    if (tick == 3)
+      CHECK(asciichat_hip_frame_table_commit(table, upload) == 0, "commit");
+    else
+      CHECK(asciichat_hip_frame_table_publish_sampled_batch(table, sslots, sblobs, ssizes, staged, stargets, staged, upload) == 0,
+            "publish_sampled_batch");
+    memcpy(frames3, targets, sizeof frames3);
+    CHECK(asciichat_hip_frame_table_latest_frames(table, slots, CLIENTS, render, frames3) == CLIENTS, "latest_frames (tick %d)", tick);
+    int on_images = 0;
+    for (int c = 0; c < CLIENTS; c++)
+      on_images += frames3[c].src_h == frames3[c].out_h && frames3[c].y_ratio == 65536u;
+    CHECK(on_images == staged, "%d of %d staged clients render from their sampled image", on_images, staged);
+    CHECK(asciichat_hip_plan_update(plan, frames3, render) == 0, "plan_update (tick %d)", tick);
+    HIP(hipMemsetAsync(crc, 0, 4 * CLIENTS, render));
+    CHECK(asciichat_hip_plan_render_packets_packed(plan, slab, stride, len, dims, crc, hdr, pkt, dst3, cap, off3, plen3, render) == 0,
+          "render_packets_packed (tick %d)", tick);
+    CHECK(asciichat_hip_streams_wait(streams, 1) == 0, "streams_wait");
+    uint64_t off3_h[CLIENTS + 1];
+    uint32_t plen3_h[CLIENTS], crc3_h[CLIENTS], pkt3_h[CLIENTS];
+    uint8_t hdr3_h[24 * CLIENTS];
+    HIP(hipMemcpy(dst3_h, dst3, cap, hipMemcpyDeviceToHost));
+    HIP(hipMemcpy(off3_h, off3, sizeof off3_h, hipMemcpyDeviceToHost));
+    HIP(hipMemcpy(plen3_h, plen3, sizeof plen3_h, hipMemcpyDeviceToHost));
+    HIP(hipMemcpy(crc3_h, crc, sizeof crc3_h, hipMemcpyDeviceToHost));
+    HIP(hipMemcpy(pkt3_h, pkt, sizeof pkt3_h, hipMemcpyDeviceToHost));
+    HIP(hipMemcpy(hdr3_h, hdr, sizeof hdr3_h, hipMemcpyDeviceToHost));
+    size_t sum = 0;
+    for (int c = 0; c < CLIENTS; c++) { /* every frame at its own offset (any order), its bytes, checksums and header as in tick one */
+      CHECK(plen3_h[c] == len_h[c] && (off3_h[c] & 15u) == 0 && off3_h[c] + plen3_h[c] <= cap, "client %d: exact length %u at %llu", c,
+            plen3_h[c], (unsigned long long)off3_h[c]);
+      CHECK(memcmp(dst3_h + off3_h[c], slab_h + (size_t)c * stride, len_h[c]) == 0, "client %d: frame of tick %d == frame of tick one", c, tick);
+      CHECK(crc3_h[c] == crc_h[c] && pkt3_h[c] == pkt_h[c] && memcmp(hdr3_h + 24 * c, hdr_h + 24 * c, 24) == 0,
+            "client %d: wire stage of tick %d == tick one", c, tick);
+      sum += ((size_t)plen3_h[c] + 15u) & ~(size_t)15;
+    }
+    CHECK(off3_h[CLIENTS] == sum, "frames tile the destination: total %llu, expected %zu", (unsigned long long)off3_h[CLIENTS], sum);
+    printf("tick %d (%s, %d sampled images + %d whole blobs, frames + wire stage %s): %d frames identical\n", tick,
+           tick == 3 ? "stage x N + commit" : "publish_sampled_batch", staged, whole,
+           asciichat_hip_plan_get_exact_length(plan) ? "in ONE launch at their exact lengths" : "packed behind the render", CLIENTS);
+  }
+  (void)hipFree(dst3), (void)hipFree(off3), (void)hipFree(plen3);
+  free(dst3_h);
+
   asciichat_hip_plan_destroy(plan);
   asciichat_hip_frame_table_destroy(table);
   (void)hipFree(slab), (void)hipFree(hdr), (void)hipFree(len), (void)hipFree(crc), (void)hipFree(pkt), (void)hipFree(dims);

@@ -103,4 +103,7 @@ def test_server_tick_in_plain_c():
     r = subprocess.run([build_tick()], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.strip().splitlines()[-1].startswith("ok:") and "fused CRC yes" in r.stdout
+    # round 4: the same frames from the images the targets sample (stage x N + commit, then the one-call batch), the send side
+    # (exact-length frames + wire stage) through plan_render_packets_packed
+    assert "tick 3 (stage x N + commit" in r.stdout and "tick 4 (publish_sampled_batch" in r.stdout
     assert "grid tick: 9 sources" in r.stdout  # the 3x3 grid with its tiles through the library's RCCL layer (world of one)
