@@ -285,6 +285,9 @@ def _bind(L):
     # drop-in layer (asciichat_render.h)
     L.ascii_convert.restype = vp
     L.ascii_convert.argtypes = [C.POINTER(Image), ss, ss, C.c_bool, C.c_bool, C.c_bool, C.c_char_p, C.c_char_p]
+    L.ascii_convert_with_capabilities_into.restype = ci
+    L.ascii_convert_with_capabilities_into.argtypes = [C.POINTER(Image), ss, ss, C.POINTER(TermCaps), C.c_bool, C.c_bool,
+                                                       C.c_char_p, vp, sz, C.POINTER(sz)]
     L.ascii_convert_with_capabilities.restype = vp
     L.ascii_convert_with_capabilities.argtypes = [C.POINTER(Image), ss, ss, C.POINTER(TermCaps), C.c_bool, C.c_bool,
                                                   C.c_char_p]

@@ -778,11 +778,8 @@ char *achip_combine_render(int mode, const char *palette, const achip_lut_t *lut
   } else if (len >= 0xFFFFFFF0u) {
     achip_fail(ASCIICHAT_HIP_ERR_BUFFER, "render kernel reported %s",
                len == ACHIP_LEN_OVERFLOW ? "output overflow" : "a bad descriptor");
-  } else if (!(out = (char *)malloc((size_t)len + 1))) {
-    achip_fail(ASCIICHAT_HIP_ERR_MEMORY, "out of memory");
   } else {
-    memcpy(out, G->slab_host + out_off, len);
-    out[len] = '\0';
+    out = achip_out_take(G->slab_host + out_off, len); /* a malloc block, or the caller's buffer (..._into) */
   }
   /* (the member count is read BEFORE this member counts itself out: once it has, the others may finish, the generation
    * may be recycled and G->n may belong to its next life -- a member that then compared its count with the new n could

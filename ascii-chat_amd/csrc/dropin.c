@@ -274,15 +274,33 @@ static char *render_with_lut(tls_ctx_t *c, const achip_lut_t *lut, int mode, con
     trim_pin(c);
     return NULL;
   }
-  char *out = (char *)malloc((size_t)len + 1);
+  char *out = achip_out_take(c->pin + PIN_OUT_OFF, len);
+  trim_pin(c);
+  return out;
+}
+
+/* ---- where the finished string goes (internal.h) ------------------------------------------------------------------------ */
+static __thread achip_out_target_t *tls_out_target;
+achip_out_target_t *achip_out_target(void) { return tls_out_target; }
+char *achip_out_take(const void *src, size_t len) {
+  achip_out_target_t *t = tls_out_target;
+  if (t) {
+    t->needed = len;
+    if (len + 1 > t->cap) {
+      achip_fail(ASCIICHAT_HIP_ERR_BUFFER, "the frame needs %zu bytes, the caller's buffer holds %zu", len + 1, t->cap);
+      return NULL;
+    }
+    memcpy(t->buf, src, len);
+    t->buf[len] = '\0';
+    return t->buf;
+  }
+  char *out = (char *)malloc(len + 1);
   if (!out) {
     achip_fail(ASCIICHAT_HIP_ERR_MEMORY, "out of memory");
-    trim_pin(c);
     return NULL;
   }
-  memcpy(out, c->pin + PIN_OUT_OFF, len);
+  memcpy(out, src, len);
   out[len] = '\0';
-  trim_pin(c);
   return out;
 }
 
@@ -297,15 +315,19 @@ static char *render_one(int mode, const char *palette, achip_frame_t *f, size_t 
   const size_t pad_left = (size_t)f->pad_left, pad_top = (size_t)f->pad_top;
   f->pad_left = 0;
   f->pad_top = 0;
+  achip_out_target_t *target = tls_out_target; /* the intermediate strings are malloc blocks whatever the caller asked for */
+  tls_out_target = NULL;
   char *plain = render_unpadded_one(mode, palette, f, src_bytes);
-  if (!plain)
-    return NULL;
-  char *wide = ascii_pad_frame_width(plain, pad_left);
+  char *wide = plain ? ascii_pad_frame_width(plain, pad_left) : NULL;
   free(plain);
-  if (!wide)
-    return NULL;
-  char *tall = ascii_pad_frame_height(wide, pad_top);
+  char *tall = wide ? ascii_pad_frame_height(wide, pad_top) : NULL;
   free(wide);
+  tls_out_target = target;
+  if (tall && target) {
+    char *out = achip_out_take(tall, strlen(tall));
+    free(tall);
+    return out;
+  }
   return tall;
 }
 
@@ -629,6 +651,34 @@ char *ascii_convert_with_capabilities(image_t *original, const ssize_t width, co
     return NULL;
   }
   return render_one(mode, palette_chars, &f, (size_t)original->w * (size_t)original->h * 3u);
+}
+
+/* Additive (not in the reference): the same call with the string left in the CALLER's buffer -- no malloc per frame, and a
+ * render thread that reuses one buffer per client never touches the allocator (VERDICT r3 "next" 9).  Returns ASCIICHAT_OK
+ * and the length in *out_len; ERROR_BUFFER when the frame (+ NUL) does not fit -- *out_len then says what it needs --;
+ * the reference's codes for everything ascii_convert_with_capabilities returns NULL for. */
+asciichat_error_t ascii_convert_with_capabilities_into(image_t *original, const ssize_t width, const ssize_t height,
+                                                       const terminal_capabilities_t *caps, const bool use_aspect_ratio,
+                                                       const bool stretch, const char *palette_chars, char *out,
+                                                       size_t out_capacity, size_t *out_len) {
+  if (out_len)
+    *out_len = 0;
+  if (!out || out_capacity == 0) {
+    achip_fail(ERROR_INVALID_PARAM, "ascii_convert_with_capabilities_into: no output buffer");
+    return ERROR_INVALID_PARAM;
+  }
+  achip_out_target_t target = {out, out_capacity, 0};
+  achip_out_target_t *before = tls_out_target;
+  tls_out_target = &target;
+  char *r = ascii_convert_with_capabilities(original, width, height, caps, use_aspect_ratio, stretch, palette_chars);
+  tls_out_target = before;
+  if (out_len)
+    *out_len = target.needed;
+  if (r)
+    return ASCIICHAT_OK;
+  if (target.needed + 1 > out_capacity)
+    return ERROR_BUFFER;
+  return !original || !caps || !palette_chars || !palette_chars[0] ? ERROR_INVALID_PARAM : ERROR_INVALID_STATE;
 }
 
 char *ascii_convert(image_t *original, const ssize_t width, const ssize_t height, const bool color,

@@ -33,6 +33,19 @@ int achip_combine_crowded(void); /* ... more of them than CPUs this process may 
 char *achip_combine_render(int mode, const char *palette, const achip_lut_t *lut, const achip_frame_t *f, size_t src_bytes,
                            int *handled);
 
+/* dropin.c: where a drop-in render leaves its string.  NULL target (the default): a malloc block, the reference's ownership
+ * contract.  ascii_convert_with_capabilities_into() sets a target for the duration of its call: the string goes into the
+ * caller's buffer instead (no malloc; `needed` is set either way) and the buffer's address is returned; a string that does
+ * not fit fails with ASCIICHAT_HIP_ERR_BUFFER.  Thread-local: concurrent callers do not see each other's targets. */
+typedef struct {
+  char *buf;
+  size_t cap;
+  size_t needed; /* strlen of the frame (set even when it did not fit) */
+} achip_out_target_t;
+achip_out_target_t *achip_out_target(void); /* this thread's target, or NULL */
+/* the hand-over itself: `len` bytes at `src` -> the thread's target or a fresh malloc block, NUL-terminated */
+char *achip_out_take(const void *src, size_t len);
+
 /* achip_host.c: the part of a HOST image a frame's point sampler reads.  stage_extent() gives the size of the compacted
  * image (sampled rows; sampled columns too when the frame is at most half as wide as its source) and returns its bytes, or 0
  * when the whole image is needed; stage_gather() copies that part to dst (row-major, tight) and rewrites d (a copy of the

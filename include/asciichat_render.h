@@ -127,6 +127,14 @@ char *ascii_convert(image_t *original, const ssize_t width, const ssize_t height
 char *ascii_convert_with_capabilities(image_t *original, const ssize_t width, const ssize_t height,
                                       const terminal_capabilities_t *caps, const bool use_aspect_ratio,
                                       const bool stretch, const char *palette_chars);
+/* ADDITIVE, not in the reference (declared here because it shares the reference's types): the same call with the frame left
+ * in the caller's buffer, NUL-terminated -- no malloc per frame.  ASCIICHAT_OK and strlen in *out_len (may be NULL);
+ * ERROR_BUFFER when frame + NUL do not fit (*out_len = what it needs, nothing usable in `out`); otherwise the code of the
+ * condition under which ascii_convert_with_capabilities returns NULL (ascii.c:198-212,256-265). */
+asciichat_error_t ascii_convert_with_capabilities_into(image_t *original, const ssize_t width, const ssize_t height,
+                                                       const terminal_capabilities_t *caps, const bool use_aspect_ratio,
+                                                       const bool stretch, const char *palette_chars, char *out,
+                                                       size_t out_capacity, size_t *out_len);
 char *image_print_with_capabilities(const image_t *image, const terminal_capabilities_t *caps, const char *palette);
 char *ascii_pad_frame_width(const char *frame, size_t pad_left);
 char *ascii_pad_frame_height(const char *frame, size_t pad_top);

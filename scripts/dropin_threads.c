@@ -29,9 +29,20 @@ static void *worker(void *arg) {
   const size_t first_len = first ? strlen(first) : 0;
   for (int k = 0; k < 20; k++)
     free(ascii_convert_with_capabilities(j->img, j->w, j->h, &j->caps, false, false, PALETTE_CHARS_STANDARD));
+  /* DT_INTO=1: the additive entry point that leaves the frame in the caller's buffer (one buffer per render thread) */
+  const char *into_env = getenv("DT_INTO");
+  const int into = into_env && into_env[0] == '1';
+  const size_t own_cap = first_len + 64;
+  char *own = into ? (char *)malloc(own_cap) : NULL;
   pthread_barrier_wait(&gate);
   for (int k = 0; k < j->calls; k++) {
-    char *s = ascii_convert_with_capabilities(j->img, j->w, j->h, &j->caps, false, false, PALETTE_CHARS_STANDARD);
+    char *s;
+    if (into) {
+      size_t n = 0;
+      s = ascii_convert_with_capabilities_into(j->img, j->w, j->h, &j->caps, false, false, PALETTE_CHARS_STANDARD, own, own_cap, &n) == ASCIICHAT_OK
+              ? own : NULL;
+    } else
+      s = ascii_convert_with_capabilities(j->img, j->w, j->h, &j->caps, false, false, PALETTE_CHARS_STANDARD);
     if (!s) {
       extern const char *asciichat_hip_last_error(void);
       fprintf(stderr, "render failed: %s\n", asciichat_hip_last_error());
@@ -43,8 +54,10 @@ static void *worker(void *arg) {
       exit(1);
     }
     j->bytes += len;
-    free(s);
+    if (!into)
+      free(s);
   }
+  free(own);
   free(first);
   pthread_barrier_wait(&gate);
   return NULL;

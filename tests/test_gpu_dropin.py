@@ -185,6 +185,46 @@ def test_concurrent_render_threads(api):
     assert not errors
 
 
+def test_into_caller_buffer_from_many_threads(api):
+    """ascii_convert_with_capabilities_into (additive): each render thread keeps ONE buffer and gets every frame in it --
+    direct path (few threads) and through the combiner (many), a buffer too small reports ERROR_BUFFER and the size needed,
+    and plain calls interleaved on the same threads still hand out malloc blocks."""
+    L = api.lib()
+    L.asciichat_hip_set_coalesce_min_callers.restype = C.c_int
+    L.asciichat_hip_set_coalesce_min_callers.argtypes = [C.c_int]
+    imgs = [orc.frame_hash_noise(640, 360, 300 + i) if i % 3 else orc.frame_bars(640, 360, i) for i in range(24)]
+    modes = [(3, 0), (2, 0), (3, 2), (0, 0)]
+    exp = [orc.convert_with_caps(im, 80, 24, *modes[k % 4]) for k, im in enumerate(imgs)]
+    for nthreads, setting in ((3, 0), (24, 1), (24, 6)):
+        L.asciichat_hip_set_coalesce_min_callers(setting)
+        errors = []
+
+        def worker(k):
+            im = as_image(api, imgs[k])
+            c = caps(api, *modes[k % 4])
+            buf = C.create_string_buffer(len(exp[k]) + 1)
+            n = C.c_size_t(0)
+            for it in range(12):
+                rc = L.ascii_convert_with_capabilities_into(C.byref(im), 80, 24, C.byref(c), False, False, PAL, buf, len(buf), C.byref(n))
+                if rc != 0 or n.value != len(exp[k]) or buf.raw[:n.value] != exp[k] or buf.raw[n.value] != 0:
+                    errors.append(("into", k, it, rc, n.value))
+                    return
+                if it % 4 == 3:
+                    if api.take_string(L.ascii_convert_with_capabilities(C.byref(im), 80, 24, C.byref(c), False, False, PAL)) != exp[k]:
+                        errors.append(("plain", k, it))
+                        return
+            small = C.create_string_buffer(len(exp[k]) // 2)
+            rc = L.ascii_convert_with_capabilities_into(C.byref(im), 80, 24, C.byref(c), False, False, PAL, small, len(small), C.byref(n))
+            if rc != 81 or n.value != len(exp[k]):
+                errors.append(("small", k, rc, n.value))
+
+        ts = [threading.Thread(target=worker, args=(k,)) for k in range(nthreads)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        assert not errors, (nthreads, setting, errors[:3])
+    L.asciichat_hip_set_coalesce_min_callers(6)
+
+
 def test_coalesced_calls_from_many_threads(api):
     """combine.c: concurrent drop-in calls share launches.  32 threads with different images, sizes, colour levels, render
     modes and palettes (so that one generation holds several (mode, palette) groups, whole-frame and row-band launches,

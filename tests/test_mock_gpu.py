@@ -95,6 +95,42 @@ def test_dropin_calls_through_the_combiner(mock, threads):
     assert not errors, errors[:4]
 
 
+def test_dropin_into_caller_buffer_on_the_mock(mock):
+    """ascii_convert_with_capabilities_into (additive): the frame in the caller's buffer, no malloc -- the direct path and
+    through the combiner, the padded form that goes through intermediate strings, a buffer that is too small (ERROR_BUFFER and
+    the size it needs), NULL conditions, and the plain entry point right behind it (the thread-local target is gone again)."""
+    L = mock.lib()
+    img = orc.frame_hash_noise(160, 120, 5)
+    im = as_image(mock, img)
+    for (W, H, cl, rm, pad) in ((40, 12, 3, 0, False), (33, 17, 2, 0, True), (40, 12, 3, 2, True), (20, 9, 0, 0, False)):
+        cp = caps(mock, cl, rm, pad)
+        exp = orc.convert_with_caps(img, W, H, cl, rm, pad, True, False)
+        for coalesce in (0, 1):
+            L.asciichat_hip_set_coalesce_min_callers(coalesce)
+            buf = C.create_string_buffer(len(exp) + 1)
+            n = C.c_size_t(0)
+            rc = L.ascii_convert_with_capabilities_into(C.byref(im), W, H, C.byref(cp), True, False, PAL, buf, len(buf), C.byref(n))
+            assert rc == 0 and n.value == len(exp) and buf.raw[:n.value] == exp and buf.raw[n.value] == 0, (W, H, cl, rm, coalesce)
+            small = C.create_string_buffer(len(exp))  # one byte short: the NUL does not fit
+            rc = L.ascii_convert_with_capabilities_into(C.byref(im), W, H, C.byref(cp), True, False, PAL, small, len(small), C.byref(n))
+            assert rc == 81 and n.value == len(exp), (rc, n.value, len(exp))
+            # ... and the plain entry point right behind it hands out a malloc block again
+            assert mock.take_string(L.ascii_convert_with_capabilities(C.byref(im), W, H, C.byref(cp), True, False, PAL)) == exp
+    L.asciichat_hip_set_coalesce_min_callers(6)
+    cp = caps(mock, 3, 0)
+    buf = C.create_string_buffer(64)
+    assert L.ascii_convert_with_capabilities_into(None, 40, 12, C.byref(cp), True, False, PAL, buf, 64, None) == 86
+    assert L.ascii_convert_with_capabilities_into(C.byref(im), 40, 12, C.byref(cp), True, False, PAL, None, 64, None) == 86
+    assert L.ascii_convert_with_capabilities_into(C.byref(im), 40, 12, C.byref(cp), True, False, PAL, buf, 0, None) == 86
+    # a terminal wider than the kernel's row: the frame is padded on the host through intermediate strings, then handed over
+    cpw = caps(mock, 0, 0, True)
+    exp = orc.convert_with_caps(img, 5000, 6, 0, 0, True, True, False)
+    big = C.create_string_buffer(len(exp) + 1)
+    n = C.c_size_t(0)
+    assert L.ascii_convert_with_capabilities_into(C.byref(im), 5000, 6, C.byref(cpw), True, False, PAL, big, len(big), C.byref(n)) == 0
+    assert big.raw[:n.value] == exp
+
+
 def test_dropin_fuzz_on_the_mock(mock):
     """random sizes, colour levels, render modes, stretch / aspect / padding through the drop-in entry point on the mock: the
     two-axis pixel gather at every kind of ratio (downscale in one axis and upscale in the other, 1-pixel images, frames wider
