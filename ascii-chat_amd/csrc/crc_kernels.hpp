@@ -88,8 +88,11 @@ __global__ void __launch_bounds__(BLOCK)
     crc32c_frame_kernel(const uint8_t *__restrict__ base, uint64_t stride, const uint32_t *__restrict__ len,
                         uint32_t fixed_len, int n_frames, const uint32_t *__restrict__ dims,
                         uint32_t *__restrict__ crc_out, uint8_t *__restrict__ hdr_out, uint32_t *__restrict__ pkt_crc_out,
-                        CrcPack pack = CrcPack{nullptr, 0, nullptr, nullptr}) {
-  static_assert(BLOCK == 256 || BLOCK == 1024, "tree constants");
+                        CrcPack pack, const uint4 *__restrict__ tab) {
+  /* tab: the 20 KB image of crc_frame_tables_init_kernel<BLOCK> (slicing tables + Horner table), built once per process
+   * and copied into LDS here -- building it in every workgroup cost ~2 us of a ~8 us launch (round 4; the stream kernel's
+   * checksum went the same way in round 2) */
+  static_assert(BLOCK == 256 || BLOCK == 1024, "Horner table of the prebuilt image");
   uint32_t *slice = lds_ptr<uint32_t>(CrcLds::o_slice);
   uint32_t *mulh = lds_ptr<uint32_t>(CrcLds::o_mulh);
   uint32_t *tree = lds_ptr<uint32_t>(CrcLds::o_tree);
@@ -117,7 +120,9 @@ __global__ void __launch_bounds__(BLOCK)
   }
   if (COPY)
     crc_pack_offset_post<BLOCK>(len, fixed_len, n_frames, i, tid);
-  crc_build_tables<BLOCK>(slice, mulh, tid);
+  const uint32_t lane_k = CRC_LANE_TAB.k[tid & 63], lane_xk = CRC_LANE_TAB.xk[tid & 63]; /* the final reduction's constants */
+  for (int k = tid; k < ACHIP_FRAME_CRC_TAB_BYTES / 16; k += BLOCK)
+    lds_ptr<uint4>(CrcLds::o_slice)[k] = tab[k];
   __syncthreads();
   uint4 *dst4 = nullptr; /* COPY: where this frame's groups go; stays NULL for a frame that does not fit */
   if (COPY) {
@@ -162,9 +167,11 @@ __global__ void __launch_bounds__(BLOCK)
       if (j0 + u < rounds)
         s = crc_mul_table(mulh, s) ^ crc_raw16(slice, d[u]);
   }
-  crc_tree<BLOCK>(tree, s, tid);
+  /* (one multiplication by the lane's constant, one xor reduction per wave, one wave folding the wave registers: the
+   * barrier-fenced tree of log2(BLOCK) levels this replaces was half of a small frame's time) */
+  const uint32_t whole = crc_reduce_waves<BLOCK>(tree, s, tid, lane_k, lane_xk);
   if (tid == 0) {
-    uint32_t st = full > 0 ? tree[0] : 0xFFFFFFFFu;
+    uint32_t st = full > 0 ? whole : 0xFFFFFFFFu;
     for (uint32_t k = (uint32_t)full * 16u; k < L; k++) /* < 16 tail bytes */
       st = (st >> 8) ^ slice[(st ^ src[k]) & 0xFFu];
     const uint32_t crc = bad ? 0u : ~st;

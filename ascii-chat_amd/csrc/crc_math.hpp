@@ -210,4 +210,52 @@ __device__ inline uint32_t crc_header_state16(uint32_t w, uint32_t h, uint32_t l
   return st;
 }
 
+/* ---- wave-level GF(2) helpers (shared by the stand-alone frame kernel and the render kernels) ---------------------------- */
+/* a * b mod P for WAVE-UNIFORM a, b, by the whole wave: lane k owns coefficient k of the 63-term carry-less product
+ * (parity of a's bits against b slid to position k) and contributes x^k mod P (xk, lane 63: 0); one xor reduction.
+ * ~14 instructions where the bit-serial crc_mulmod takes ~220.  Result uniform. */
+__device__ inline uint32_t wave_mulmod_uniform(uint32_t a, uint32_t b, int lane, uint32_t xk) {
+  /* reflected order: bit 31-i of a word is the coefficient of x^i.  Coefficient k of the product pairs bit p of a
+   * with bit 62-k-p of b: the parity of a & m_k, m_k = bitreverse(b) slid so that its bit 31 lands on bit 62-k */
+  const uint32_t rb = bitreverse32(b);
+  const uint32_t m = (uint32_t)((((uint64_t)rb) << 31) >> lane);
+  const uint32_t c = (uint32_t)__builtin_popcount(a & m) & 1u;
+  return wave_read_lane(wave_xor_to_last((0u - c) & xk), 63);
+}
+/* Sum over the workgroup's threads of s_t * x^(128 * (BLOCK-1 - t)) -- the register after all their groups -- valid in
+ * wave 0: one multiplication by the lane's constant, one xor reduction per wave, one hand-off through `scratch`
+ * (BLOCK / 64 words of LDS), WAVES - 1 wave-uniform multiplications.  klane / xk: this lane's entries of CRC_LANE_TAB
+ * (requested at kernel entry).  Replaces crc_tree's log2(BLOCK) barrier-fenced levels in the exact-length instantiations. */
+template <int BLOCK>
+__device__ inline uint32_t crc_reduce_waves(uint32_t *scratch, uint32_t s, int tid, uint32_t klane, uint32_t xk) {
+  constexpr uint32_t WC = crc_pow(CRC_X8, 16ull * 64ull); /* x^(128 * 64): one wave's worth of groups */
+  const int lane = tid & 63, wave = wave_uniform(tid >> 6);
+  const uint32_t v = wave_read_lane(wave_xor_to_last(crc_mulmod(s, klane)), 63);
+  if (lane == 0)
+    scratch[wave] = v;
+  __syncthreads();
+  uint32_t acc = 0;
+  if (wave == 0) {
+    acc = scratch[0];
+    for (int w = 1; w < BLOCK / 64; w++)
+      acc = wave_mulmod_uniform(acc, WC, lane, xk) ^ scratch[w];
+  }
+  return acc;
+}
+
+/* The constant tables of a workgroup of BLOCK threads that checksums one frame (crc32c_frame_kernel; the PACK == 2
+ * instantiations of the stream kernel, which checksum the frame's LDS image): crc_kernels.hpp's slicing tables and Horner table for x^(128 * BLOCK), the first ACHIP_FRAME_CRC_TAB_BYTES of the
+ * CrcLds layout, written once per process into global memory; every launch copies the image into LDS. */
+#define ACHIP_FRAME_CRC_TAB_BYTES (20 * 1024)
+template <int BLOCK> __global__ void __launch_bounds__(256) crc_frame_tables_init_kernel(uint32_t *tab) {
+  static_assert(CrcLds::o_slice == 0 && CrcLds::o_mulh == 16 * 1024, "slicing tables, then the Horner table");
+  const int tid = (int)threadIdx.x;
+  uint32_t *slice = lds_ptr<uint32_t>(CrcLds::o_slice), *mulh = lds_ptr<uint32_t>(CrcLds::o_mulh);
+  crc_build_tables<BLOCK>(slice, mulh, tid);
+  __syncthreads();
+  for (int k = tid; k < ACHIP_FRAME_CRC_TAB_BYTES / 4; k += 256)
+    tab[k] = lds_ptr<const uint32_t>(0)[k];
+}
+
+
 } // namespace achip

@@ -7,6 +7,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include "render_inst.h"
 #include "render_stream.hpp"
 #include "crc_kernels.hpp"
@@ -316,19 +318,54 @@ extern "C" int achip_crc_parts(uint32_t max_len) {
   return max_len <= 32u * 4096u ? 1 : (int)(((uint64_t)max_len + 65535u) / 65536u);
 }
 
+/* the prebuilt tables of crc32c_frame_kernel<1024> (crc_math.hpp: crc_frame_tables_init_kernel), one image per device */
+static hipError_t frame_crc_tables_1024(const uint4 **out) {
+  constexpr int MAX_DEVICES = 16;
+  static std::mutex mu;
+  static uint32_t *tab[MAX_DEVICES] = {};
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess)
+    return e;
+  if (dev < 0 || dev >= MAX_DEVICES)
+    return hipErrorInvalidDevice;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!tab[dev]) {
+    uint32_t *t = nullptr;
+    e = hipMalloc(reinterpret_cast<void **>(&t), (size_t)ACHIP_FRAME_CRC_TAB_BYTES);
+    if (e != hipSuccess)
+      return e;
+    hipLaunchKernelGGL((achip::crc_frame_tables_init_kernel<1024>), dim3(1), dim3(256), ACHIP_FRAME_CRC_TAB_BYTES, nullptr, t);
+    e = hipGetLastError();
+    if (e == hipSuccess)
+      e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+      (void)hipFree(t);
+      return e;
+    }
+    tab[dev] = t;
+  }
+  *out = reinterpret_cast<const uint4 *>(tab[dev]);
+  return hipSuccess;
+}
+
 /* pack != NULL: the same pass also compacts the slab (crc_kernels.hpp COPY instantiations) */
 static int launch_crc32c(const uint8_t *base, uint64_t stride, const uint32_t *len_dev, uint32_t fixed_len, uint32_t max_len,
                          int n, uint32_t *partial, const uint32_t *dims_dev, uint32_t *crc_out, uint8_t *hdr_out,
                          uint32_t *pkt_crc_out, const achip::CrcPack *pack, hipStream_t s) {
   const int parts = achip_crc_parts(max_len);
   if (parts == 1) { /* 1024 threads per frame; every workgroup runs only the rounds its own frame needs */
+    const uint4 *tab = nullptr;
+    const hipError_t te = frame_crc_tables_1024(&tab);
+    if (te != hipSuccess)
+      return (int)te;
     if (pack)
       hipLaunchKernelGGL((achip::crc32c_frame_kernel<1024, true>), dim3((unsigned)n), dim3(1024), (size_t)achip::CrcLds::bytes,
-                         s, base, stride, len_dev, fixed_len, n, dims_dev, crc_out, hdr_out, pkt_crc_out, *pack);
+                         s, base, stride, len_dev, fixed_len, n, dims_dev, crc_out, hdr_out, pkt_crc_out, *pack, tab);
     else
       hipLaunchKernelGGL((achip::crc32c_frame_kernel<1024, false>), dim3((unsigned)n), dim3(1024), (size_t)achip::CrcLds::bytes,
                          s, base, stride, len_dev, fixed_len, n, dims_dev, crc_out, hdr_out, pkt_crc_out,
-                         achip::CrcPack{nullptr, 0, nullptr, nullptr});
+                         achip::CrcPack{nullptr, 0, nullptr, nullptr}, tab);
     return (int)hipGetLastError();
   }
   const int rounds = 16; /* 64 KB spans of 256-thread workgroups */

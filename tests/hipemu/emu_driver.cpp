@@ -14,6 +14,16 @@
 static int g_parts = 1, g_rows_per_part = 0;
 static unsigned long long *g_part_sync = nullptr;
 static uint32_t g_epoch = 1;
+/* the prebuilt tables of crc32c_frame_kernel<1024>, as the product's launcher builds them once per process */
+static const uint4 *frame_crc_tab_1024() {
+  static std::vector<uint32_t> tab;
+  if (tab.empty()) {
+    tab.resize(ACHIP_FRAME_CRC_TAB_BYTES / 4 + 4);
+    uint32_t *t = tab.data();
+    hipemu::launch(dim3(1), dim3(256), ACHIP_FRAME_CRC_TAB_BYTES, [&] { achip::crc_frame_tables_init_kernel<1024>(t); });
+  }
+  return reinterpret_cast<const uint4 *>(tab.data());
+}
 static int g_uniform = 0; /* 1: pass the batch's common descriptor by value when it has one (as plan.c does) */
 
 template <int MODE, int BLOCK, int CAP, int RING>
@@ -333,8 +343,10 @@ extern "C" void emu_crc32c(const uint8_t *base, uint64_t stride, const uint32_t 
     rounds = force_rounds;
   }
   if (parts == 1) {
+    const uint4 *ftab = frame_crc_tab_1024(); /* (a launch of its own: not from inside the one below) */
     hipemu::launch(dim3((unsigned)n), dim3(1024), achip::CrcLds::bytes, [&] {
-      achip::crc32c_frame_kernel<1024>(base, stride, len, fixed_len, n, dims, crc_out, hdr_out, pkt_out);
+      achip::crc32c_frame_kernel<1024>(base, stride, len, fixed_len, n, dims, crc_out, hdr_out, pkt_out,
+                                       achip::CrcPack{nullptr, 0, nullptr, nullptr}, ftab);
     });
     return;
   }
@@ -361,8 +373,9 @@ extern "C" void emu_crc32c_pack(const uint8_t *base, uint64_t stride, const uint
   }
   const achip::CrcPack pack = {dst, cap, off_out, len_out};
   if (parts == 1) {
+    const uint4 *ftab = frame_crc_tab_1024();
     hipemu::launch(dim3((unsigned)n), dim3(1024), achip::CrcLds::bytes, [&] {
-      achip::crc32c_frame_kernel<1024, true>(base, stride, len, 0u, n, dims, crc_out, hdr_out, pkt_out, pack);
+      achip::crc32c_frame_kernel<1024, true>(base, stride, len, 0u, n, dims, crc_out, hdr_out, pkt_out, pack, ftab);
     });
     return;
   }
