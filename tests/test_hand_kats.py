@@ -23,13 +23,31 @@ KATS = json.load(open(os.path.join(HERE, "golden", "hand_kats.json"), encoding="
 
 # renderer -> (achip mode, oracle call, restatement call, emulator geometries: phase kernel 0 / 4 (+ 2 for the per-cell
 # mode), rows kernel 24 / 25, stream kernel 16-19)
+# a KAT may name its own palette ("palette") and its own geometries ("variants": a multi-byte palette keeps the
+# truecolor-foreground renderer on the phase kernel)
 RENDERERS = {
-    "hb256": (6, lambda im: orc.print_with_caps(im, 2, 2), lambda im: rs.halfblock_256(im), (0, 4, 24, 25)),
-    "hb16": (7, lambda im: orc.print_with_caps(im, 1, 2), lambda im: rs.halfblock_16(im), (0, 4, 24, 25)),
-    "hbmono": (8, lambda im: orc.print_with_caps(im, 0, 2), lambda im: rs.halfblock_mono(im), (0, 4, 24, 25)),
-    "true_bg": (4, lambda im: orc.print_truecolor_bg(im), lambda im: rs.truecolor_bg(im, orc.PALETTE_STANDARD),
+    "hb256": (6, lambda im, pal: orc.print_with_caps(im, 2, 2, pal), lambda im, pal: rs.halfblock_256(im), (0, 4, 24, 25)),
+    "hb16": (7, lambda im, pal: orc.print_with_caps(im, 1, 2, pal), lambda im, pal: rs.halfblock_16(im), (0, 4, 24, 25)),
+    "hbmono": (8, lambda im, pal: orc.print_with_caps(im, 0, 2, pal), lambda im, pal: rs.halfblock_mono(im), (0, 4, 24, 25)),
+    "true_bg": (4, lambda im, pal: orc.print_truecolor_bg(im, pal), lambda im, pal: rs.truecolor_bg(im, pal),
                 (0, 2, 4, 16, 17, 18, 19)),
+    # rows the survey's recorded anchors pin as whole-frame hashes; these add byte-level, line-cited answers
+    "mono": (0, lambda im, pal: orc.print_with_caps(im, 0, 0, pal), lambda im, pal: rs.mono(im, pal), (0, 4, 24, 25)),
+    "true_fg": (1, lambda im, pal: orc.print_with_caps(im, 3, 0, pal), lambda im, pal: rs.truecolor_fg(im, pal),
+                (0, 2, 4, 16, 17, 18, 19)),
+    "ansi256_fg": (2, lambda im, pal: orc.print_with_caps(im, 2, 0, pal), lambda im, pal: rs.ansi256_fg(im, pal),
+                   (0, 2, 4, 16, 17, 18, 19)),
+    "ansi16_fg": (3, lambda im, pal: orc.print_with_caps(im, 1, 0, pal), lambda im, pal: rs.ansi16_fg(im, pal),
+                  (0, 2, 4, 16, 17, 18, 19)),
 }
+
+
+def palette_of(kat):
+    return kat.get("palette", orc.PALETTE_STANDARD)
+
+
+def variants_of(kat):
+    return tuple(kat.get("variants", RENDERERS[kat["renderer"]][3]))
 
 
 def image_of(kat):
@@ -51,8 +69,10 @@ def test_every_unpinned_row_has_three_hand_kats():
     per_row = {}
     for k in KATS["frames"] + KATS["layouts"] + KATS["composites"] + KATS["composite_frames"]:
         per_row[k["row"]] = per_row.get(k["row"], 0) + 1
-    for row in ("H256", "H16", "HM", "PB"):
+    for row in ("H256", "H16", "HM", "PB", "PT"):
         assert per_row.get(row, 0) >= 3, (row, per_row)
+    for row in ("P256", "P16", "PM"):
+        assert per_row.get(row, 0) >= 1, (row, per_row)
     assert per_row["C1"] >= 3 and per_row["C2"] + per_row["C3"] >= 3
     for k in KATS["frames"] + KATS["composite_frames"]:
         assert all(g["ref"].count(":") >= 1 and g["why"] for g in k["groups"]), k["name"]  # a file:line per byte group
@@ -60,13 +80,14 @@ def test_every_unpinned_row_has_three_hand_kats():
 
 @pytest.mark.parametrize("kat", KATS["frames"], ids=[k["name"] for k in KATS["frames"]])
 def test_frame_kats_oracle_restatement_and_emulated_kernels(kat):
-    mode, oracle_fn, restate_fn, variants = RENDERERS[kat["renderer"]]
+    mode, oracle_fn, restate_fn, _ = RENDERERS[kat["renderer"]]
     img = image_of(kat)
     want = expected(kat)
-    assert oracle_fn(img) == want, "oracle"
-    assert restate_fn(img) == want, "third restatement"
-    for v in variants:
-        got = emu.render_frames(mode, [emu.frame_identity(img)], orc.PALETTE_STANDARD, v)[0]
+    pal = palette_of(kat)
+    assert oracle_fn(img, pal) == want, "oracle"
+    assert restate_fn(img, pal) == want, "third restatement"
+    for v in variants_of(kat):
+        got = emu.render_frames(mode, [emu.frame_identity(img)], pal, v)[0]
         assert got == want, f"product kernel, geometry {v}"
 
 
@@ -160,9 +181,9 @@ def gpu():
     return pkg, torch
 
 
-def _render(gpu, mode, frames, variant=-1):
+def _render(gpu, mode, frames, variant=-1, palette=orc.PALETTE_STANDARD):
     pkg, torch = gpu
-    plan = pkg.Plan(mode, orc.PALETTE_STANDARD, frames)
+    plan = pkg.Plan(mode, palette, frames)
     if variant >= 0:
         plan.set_variant(variant)
     n = len(frames)
@@ -179,13 +200,14 @@ def _render(gpu, mode, frames, variant=-1):
 def test_hand_kats_on_the_gpu(gpu):
     pkg, torch = gpu
     for kat in KATS["frames"]:
-        mode, _, _, variants = RENDERERS[kat["renderer"]]
+        mode = RENDERERS[kat["renderer"]][0]
+        variants = variants_of(kat)
         img = image_of(kat)
         dev = torch.from_numpy(img).cuda()
         f = pkg.Frame()
         assert pkg.lib().achip_frame_identity(C.byref(f), dev.data_ptr(), img.shape[1], img.shape[0]) == 0
         for v in (-1,) + tuple(variants):
-            assert _render(gpu, mode, [f, f], v) == [expected(kat)] * 2, (kat["name"], v)
+            assert _render(gpu, mode, [f, f], v, palette_of(kat)) == [expected(kat)] * 2, (kat["name"], v)
     for kat in KATS["composites"] + KATS["composite_frames"]:
         srcs = sources_of(kat)
         tw, th = kat["term"]
