@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(BLOCK)
                         uint32_t fixed_len, int n_frames, const uint32_t *__restrict__ dims,
                         uint32_t *__restrict__ crc_out, uint8_t *__restrict__ hdr_out, uint32_t *__restrict__ pkt_crc_out,
                         CrcPack pack, const uint4 *__restrict__ tab) {
-  /* tab: the 20 KB image of crc_frame_tables_init_kernel<BLOCK> (slicing tables + Horner table), built once per process
+  /* tab: the 22 KB image of crc_frame_tables_init_kernel<BLOCK> (slicing tables, Horner table, power tables), built once per process
    * and copied into LDS here -- building it in every workgroup cost ~2 us of a ~8 us launch (round 4; the stream kernel's
    * checksum went the same way in round 2) */
   static_assert(BLOCK == 256 || BLOCK == 1024, "Horner table of the prebuilt image");
@@ -111,19 +111,29 @@ __global__ void __launch_bounds__(BLOCK)
   const int rounds = (full + BLOCK - 1) / BLOCK;      /* 0 for a frame shorter than 16 bytes      */
   const int lead = rounds * BLOCK - full;             /* zero groups in front of the frame        */
 
-  /* the two scalar jobs of the packet CRC run on waves that idle while waves 0..3 build the tables */
-  if (hdr_out && pkt_crc_out) {
-    if (tid == BLOCK - 64)
-      pw[0] = crc_header_state16(w, h, L);
-    else if (tid == BLOCK - 128)
-      pw[1] = crc_x8_pow_len(L);
-  }
   if (COPY)
     crc_pack_offset_post<BLOCK>(len, fixed_len, n_frames, i, tid);
   const uint32_t lane_k = CRC_LANE_TAB.k[tid & 63], lane_xk = CRC_LANE_TAB.xk[tid & 63]; /* the final reduction's constants */
   for (int k = tid; k < ACHIP_FRAME_CRC_TAB_BYTES / 16; k += BLOCK)
     lds_ptr<uint4>(CrcLds::o_slice)[k] = tab[k];
+  const int lane = tid & 63, wave = wave_uniform(tid >> 6);
+  const uint32_t ntail = L & 15u;
+  /* the < 16 tail bytes (lane l of wave 0 takes byte l), requested with the first groups */
+  const uint32_t tail_byte = (uint32_t)tid < ntail ? src[(size_t)full * 16u + (uint32_t)tid] : 0u;
   __syncthreads();
+  /* the header's share of the packet CRC (x^(8 len); the register after {w, h, len, 0}), by the last two waves */
+  const bool want_pkt = hdr_out && pkt_crc_out && !bad;
+  if (want_pkt) {
+    if (wave == BLOCK / 64 - 1) {
+      const uint32_t xl = crc_x8_pow_len_wave(lds_ptr<const uint32_t>(CrcLds::o_powtab), L, lane, lane_xk);
+      if (lane == 0)
+        pw[1] = xl;
+    } else if (wave == BLOCK / 64 - 2) {
+      const uint32_t hp = crc_header_part_wave(slice, w, h, L, lane);
+      if (lane == 0)
+        pw[0] = hp;
+    }
+  }
   uint4 *dst4 = nullptr; /* COPY: where this frame's groups go; stays NULL for a frame that does not fit */
   if (COPY) {
     uint64_t off, total;
@@ -170,14 +180,18 @@ __global__ void __launch_bounds__(BLOCK)
   /* (one multiplication by the lane's constant, one xor reduction per wave, one wave folding the wave registers: the
    * barrier-fenced tree of log2(BLOCK) levels this replaces was half of a small frame's time) */
   const uint32_t whole = crc_reduce_waves<BLOCK>(tree, s, tid, lane_k, lane_xk);
-  if (tid == 0) {
-    uint32_t st = full > 0 ? whole : 0xFFFFFFFFu;
-    for (uint32_t k = (uint32_t)full * 16u; k < L; k++) /* < 16 tail bytes */
-      st = (st >> 8) ^ slice[(st ^ src[k]) & 0xFFu];
-    const uint32_t crc = bad ? 0u : ~st;
-    crc_out[i] = crc;
-    if (hdr_out)
-      crc_emit_packet(pw[0], pw[1], st, crc, w, h, L, bad, i, slice, hdr_out, pkt_crc_out);
+  if (wave == 0) { /* (pw[] was written in front of crc_reduce_waves' barrier) */
+    const CrcClose c = crc_close_wave(slice, lds_ptr<const uint32_t>(CrcLds::o_powtab), full > 0 ? whole : 0xFFFFFFFFu, ntail,
+                                      tail_byte, want_pkt, pw[0], pw[1], lane, lane_xk);
+    if (lane == 0) {
+      const uint32_t crc = bad ? 0u : ~c.st;
+      crc_out[i] = crc;
+      if (hdr_out) {
+        crc_store_header(hdr_out, i, w, h, L, crc);
+        if (pkt_crc_out)
+          pkt_crc_out[i] = bad ? 0u : c.pkt;
+      }
+    }
   }
 }
 

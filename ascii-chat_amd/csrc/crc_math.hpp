@@ -67,7 +67,8 @@ __host__ __device__ constexpr uint32_t crc_byte(uint32_t s, uint32_t byte) {
 struct CrcLds {
   static constexpr int o_slice = 0;                  /* uint32 [16][256]: byte b followed by k zero bytes */
   static constexpr int o_mulh = o_slice + 16 * 1024; /* uint32 [4][256]: (v << 8k) * x^(128*256)         */
-  static constexpr int o_tree = o_mulh + 4 * 1024;   /* uint32 [1024]                                     */
+  static constexpr int o_powtab = o_mulh + 4 * 1024; /* uint32 [2][256]: x^(8i), x^(8*256*i) -- prebuilt images only (CRC_POW_TAB) */
+  static constexpr int o_tree = o_powtab + 2 * 1024; /* uint32 [1024]                                     */
   static constexpr int o_pow = o_tree + 4096;        /* uint32 [64]: product trees x^(8*len), x^(-8*surplus) */
   static constexpr int o_pack = o_pow + 256;         /* uint32 [2][16]: wave totals of the packed-offset prefix */
   static constexpr int bytes = o_pack + 128;
@@ -222,36 +223,106 @@ __device__ inline uint32_t wave_mulmod_uniform(uint32_t a, uint32_t b, int lane,
   const uint32_t c = (uint32_t)__builtin_popcount(a & m) & 1u;
   return wave_read_lane(wave_xor_to_last((0u - c) & xk), 63);
 }
-/* Sum over the workgroup's threads of s_t * x^(128 * (BLOCK-1 - t)) -- the register after all their groups -- valid in
- * wave 0: one multiplication by the lane's constant, one xor reduction per wave, one hand-off through `scratch`
- * (BLOCK / 64 words of LDS), WAVES - 1 wave-uniform multiplications.  klane / xk: this lane's entries of CRC_LANE_TAB
- * (requested at kernel entry).  Replaces crc_tree's log2(BLOCK) barrier-fenced levels in the exact-length instantiations. */
-template <int BLOCK>
+/* Sum over the workgroup's first ACTIVE threads of s_t * x^(128 * (ACTIVE-1 - t)) -- the register after all their groups
+ * -- valid in wave 0: one multiplication by the lane's constant, one xor reduction per wave, one hand-off through `scratch`
+ * (ACTIVE / 64 words of LDS), ACTIVE/64 - 1 wave-uniform multiplications.  klane / xk: this lane's entries of CRC_LANE_TAB
+ * (requested at kernel entry).  Every thread of the workgroup calls it (one barrier); waves behind the ACTIVE ones only
+ * pass the barrier.  Replaces crc_tree's log2(BLOCK) barrier-fenced levels. */
+template <int BLOCK, int ACTIVE = BLOCK>
 __device__ inline uint32_t crc_reduce_waves(uint32_t *scratch, uint32_t s, int tid, uint32_t klane, uint32_t xk) {
+  static_assert(ACTIVE % 64 == 0 && ACTIVE <= BLOCK, "whole waves");
   constexpr uint32_t WC = crc_pow(CRC_X8, 16ull * 64ull); /* x^(128 * 64): one wave's worth of groups */
   const int lane = tid & 63, wave = wave_uniform(tid >> 6);
-  const uint32_t v = wave_read_lane(wave_xor_to_last(crc_mulmod(s, klane)), 63);
-  if (lane == 0)
-    scratch[wave] = v;
+  if (ACTIVE == BLOCK || wave < ACTIVE / 64) {
+    const uint32_t v = wave_read_lane(wave_xor_to_last(crc_mulmod(s, klane)), 63);
+    if (lane == 0)
+      scratch[wave] = v;
+  }
   __syncthreads();
   uint32_t acc = 0;
   if (wave == 0) {
     acc = scratch[0];
-    for (int w = 1; w < BLOCK / 64; w++)
+    for (int w = 1; w < ACTIVE / 64; w++)
       acc = wave_mulmod_uniform(acc, WC, lane, xk) ^ scratch[w];
   }
   return acc;
 }
 
+/* ---- a frame's closing arithmetic by whole waves (uniform operands, all 64 lanes active) instead of one thread's
+ * byte-at-a-time loops and bit-serial multiplications: those were ~2 us at the end of an 11 us launch (round 4) ---------- */
+__device__ inline uint32_t wave_xor_all(uint32_t v) { return wave_read_lane(wave_xor_to_last(v), 63); }
+
+/* x^(8 len): two look-ups in the prebuilt power tables (CrcLds::o_powtab), one multiplication (one more per set bit of
+ * len above 64 KB) */
+__device__ inline uint32_t crc_x8_pow_len_wave(const uint32_t *powtab, uint32_t len, int lane, uint32_t xk) {
+  uint32_t r = wave_mulmod_uniform(powtab[len & 0xFFu], powtab[256u + ((len >> 8) & 0xFFu)], lane, xk);
+  for (int k = 16; (len >> k) != 0u; k++)
+    if ((len >> k) & 1u)
+      r = wave_mulmod_uniform(r, CRC_X8_POW2[k], lane, xk);
+  return r;
+}
+
+/* What the 24-byte header {w, h, len, 0, crc, 0} (network order) contributes to the packet CRC before the frame's own CRC
+ * is known: (register after the 8 bytes {w, h}) clocked through the 16 bytes {len, 0, 0, 0}.  With the checksum's four
+ * bytes added at their place (crc_close_wave) it is the register after the whole header.  slice: the slicing tables. */
+__device__ inline uint32_t crc_header_part_wave(const uint32_t *slice, uint32_t w, uint32_t h, uint32_t len, int lane) {
+  constexpr uint32_t INIT8 = crc_mulmod(0xFFFFFFFFu, crc_pow(CRC_X8, 8u)); /* 0xFFFFFFFF clocked through 8 zero bytes */
+  const int sh = 8 * (3 - (lane & 3));
+  const uint32_t fb = ((lane < 4 ? w : h) >> sh) & 0xFFu; /* header byte `lane`, lane < 8: followed by 7 - lane bytes */
+  const uint32_t st8 = INIT8 ^ wave_xor_all(lane < 8 ? slice[(7 - (lane & 7)) * 256 + fb] : 0u);
+  /* the next 16 bytes: st8 goes into the first four (the length's), twelve zero bytes follow */
+  const uint32_t lb = ((len >> sh) & 0xFFu) ^ ((st8 >> (8 * (lane & 3))) & 0xFFu);
+  return wave_xor_all(lane < 4 ? slice[(15 - (lane & 3)) * 256 + lb] : 0u);
+}
+
+/* reg: the register after the frame's whole 16-byte groups (0xFFFFFFFF when it has none); ntail < 16 bytes follow, lane l
+ * < ntail holding byte l in tail_byte.  Returns the register after the frame; pkt (when want_pkt) = the CRC of header ||
+ * frame from hpart = crc_header_part_wave() and xl = x^(8 len).  powtab: CrcLds::o_powtab. */
+struct CrcClose {
+  uint32_t st, pkt;
+};
+__device__ inline CrcClose crc_close_wave(const uint32_t *slice, const uint32_t *powtab, uint32_t reg, uint32_t ntail,
+                                          uint32_t tail_byte, bool want_pkt, uint32_t hpart, uint32_t xl, int lane,
+                                          uint32_t xk) {
+  CrcClose r{reg, 0u};
+  if (ntail) { /* reg * x^(8 ntail) + raw(tail): byte l of the tail is followed by ntail - 1 - l bytes */
+    const bool mine = (uint32_t)lane < ntail;
+    const uint32_t c = mine ? slice[(mine ? ntail - 1u - (uint32_t)lane : 0u) * 256u + (tail_byte & 0xFFu)] : 0u;
+    r.st = wave_mulmod_uniform(reg, powtab[ntail], lane, xk) ^ wave_xor_all(c);
+  }
+  if (want_pkt) {
+    const uint32_t crc = ~r.st; /* bytes 16..19 of the header, big-endian; byte 16 + k is followed by 7 - k bytes */
+    const uint32_t cb = (crc >> (8 * (3 - (lane & 3)))) & 0xFFu;
+    const uint32_t st24 = hpart ^ wave_xor_all(lane < 4 ? slice[(7 - (lane & 3)) * 256 + cb] : 0u);
+    /* clocking the frame in from register st24: st24 * x^(8 len) + raw(frame); r.st = 0xFFFFFFFF * x^(8 len) + raw(frame) */
+    r.pkt = ~(wave_mulmod_uniform(st24 ^ 0xFFFFFFFFu, xl, lane, xk) ^ r.st);
+  }
+  return r;
+}
+
+/* the 24-byte ascii_frame_packet_t of frame i in network byte order (one thread) */
+__device__ inline void crc_store_header(uint8_t *__restrict__ hdr_out, int i, uint32_t w, uint32_t h, uint32_t len, uint32_t crc) {
+  uint32_t *hp = reinterpret_cast<uint32_t *>(hdr_out + (size_t)i * 24u); /* 8-byte aligned */
+  hp[0] = bswap32(w); /* HOST_TO_NET_U32 */
+  hp[1] = bswap32(h);
+  hp[2] = bswap32(len);
+  hp[3] = 0u;
+  hp[4] = bswap32(crc);
+  hp[5] = 0u;
+}
+
 /* The constant tables of a workgroup of BLOCK threads that checksums one frame (crc32c_frame_kernel; the PACK == 2
- * instantiations of the stream kernel, which checksum the frame's LDS image): crc_kernels.hpp's slicing tables and Horner table for x^(128 * BLOCK), the first ACHIP_FRAME_CRC_TAB_BYTES of the
- * CrcLds layout, written once per process into global memory; every launch copies the image into LDS. */
-#define ACHIP_FRAME_CRC_TAB_BYTES (20 * 1024)
+ * instantiations of the stream kernel, which checksum the frame's LDS image): crc_kernels.hpp's slicing tables, the Horner table for x^(128 * BLOCK)
+ * and the two power tables, the first ACHIP_FRAME_CRC_TAB_BYTES of the CrcLds layout, written once per process into global memory; every launch copies the image into LDS. */
+#define ACHIP_FRAME_CRC_TAB_BYTES (22 * 1024)
 template <int BLOCK> __global__ void __launch_bounds__(256) crc_frame_tables_init_kernel(uint32_t *tab) {
-  static_assert(CrcLds::o_slice == 0 && CrcLds::o_mulh == 16 * 1024, "slicing tables, then the Horner table");
+  static_assert(CrcLds::o_slice == 0 && CrcLds::o_mulh == 16 * 1024 && CrcLds::o_powtab == 20 * 1024 &&
+                    CrcLds::o_tree == ACHIP_FRAME_CRC_TAB_BYTES, "slicing tables, the Horner table, the power tables");
   const int tid = (int)threadIdx.x;
   uint32_t *slice = lds_ptr<uint32_t>(CrcLds::o_slice), *mulh = lds_ptr<uint32_t>(CrcLds::o_mulh);
   crc_build_tables<BLOCK>(slice, mulh, tid);
+  lds_ptr<uint32_t>(CrcLds::o_powtab)[tid] = CRC_POW_TAB.t[0][tid];
+  lds_ptr<uint32_t>(CrcLds::o_powtab)[256 + tid] = CRC_POW_TAB.t[1][tid];
   __syncthreads();
   for (int k = tid; k < ACHIP_FRAME_CRC_TAB_BYTES / 4; k += 256)
     tab[k] = lds_ptr<const uint32_t>(0)[k];

@@ -59,6 +59,12 @@ __host__ __device__ constexpr int stream_max_token(int m) {
  * from the frame's LDS image by the whole workgroup (crc_kernels.hpp's scheme: 20 KB of tables instead of the 52 KB of
  * the per-block checksum, so two 8-wave workgroups still share a CU). */
 #define ACHIP_PACK_FRAME_CAP (48 * 1024)
+/* PACK == 2: how many waves of the workgroup checksum the frame's image (the Horner table of the prebuilt image is the one
+ * of that many threads: crc_frame_tables_init_kernel<64 * pack_crc_waves(WAVES)>) */
+#ifndef ACHIP_PACK_CRCW
+#define ACHIP_PACK_CRCW 4
+#endif
+constexpr int pack_crc_waves(int waves) { return waves >= 8 ? ACHIP_PACK_CRCW : 1; }
 
 template <int MODE, int WAVES, int CPL, bool CRC = false, int PACK = 0> struct SLds {
   static_assert(!(CRC && PACK), "exact-length instantiations checksum the frame's LDS image as a whole");
@@ -466,7 +472,8 @@ __global__ void __launch_bounds__(WAVES * 64)
   ACHIP_SSTAMP(0);
   /* CRC: the constant tables are requested before anything else (L2 hits after a process's first launch) and go to
    * LDS in front of the barrier below; nothing of them is computed here */
-  /* (PACK == 2: the 20 KB image crc_frame_tables_init_kernel<BLOCK> wrote: slicing tables + the Horner table) */
+  /* (PACK == 2: the 22 KB image crc_frame_tables_init_kernel<256> wrote: slicing tables, the Horner table of the four
+   * checksumming waves, the power tables) */
   constexpr bool TABLES = CRC || PACK == 2;
   constexpr int TABV = (PACK == 2 ? ACHIP_FRAME_CRC_TAB_BYTES : L::TAB_BYTES) / 16, TABN = (TABV + BLOCK - 1) / BLOCK;
   typedef uint32_t tab4_t __attribute__((vector_size(16))); /* a native vector: HIP's uint4 class keeps the array in scratch */
@@ -866,56 +873,78 @@ __global__ void __launch_bounds__(WAVES * 64)
     const bool fits = n_total <= cap_bytes;
     const uint32_t room = fits ? (n_total + 15u) & ~15u : 0u;
     unsigned long long *offw = lds_ptr<unsigned long long>(L::o_packoff);
-    uint32_t *fslice = lds_ptr<uint32_t>(L::o_fcrc + CrcLds::o_slice), *fpw = lds_ptr<uint32_t>(L::o_fcrc + CrcLds::o_pow);
+    const uint32_t *fslice = lds_ptr<const uint32_t>(L::o_fcrc + CrcLds::o_slice);
+    const uint32_t *fpow = lds_ptr<const uint32_t>(L::o_fcrc + CrcLds::o_powtab);
+    uint32_t *fpw = lds_ptr<uint32_t>(L::o_fcrc + CrcLds::o_pow);
+    const bool want_pkt = PACK == 2 && wire.hdr && wire.pkt_crc;
     if (tid == 0)
       offw[0] = agent_fetch_add_u64(&pack.cursor[0], (unsigned long long)room);
     if (tid >= 64 && tid < 80 && n_total + (uint32_t)(tid - 64) < room) /* the <= 15 bytes of padding leave as zeros */
       lds_ptr<uint8_t>(frame_lds)[n_total + (uint32_t)(tid - 64)] = 0;
-    if (PACK == 2 && wire.hdr && wire.pkt_crc && fits) { /* the two scalar jobs of the packet CRC, on waves that idle here */
-      if (tid == BLOCK - 64)
-        fpw[0] = crc_header_state16(dim_w, dim_h, n_total);
-      else if (tid == BLOCK - 128)
-        fpw[1] = crc_x8_pow_len(n_total);
+    if (PACK == 2 && want_pkt && fits) { /* the header's share of the packet CRC, on two waves that idle here */
+      if (wave == WAVES - 1) {
+        const uint32_t xl = crc_x8_pow_len_wave(fpow, n_total, lane, lane_xk);
+        if (lane == 0)
+          fpw[1] = xl;
+      } else if (wave == WAVES - 2) {
+        const uint32_t hp = crc_header_part_wave(fslice, dim_w, dim_h, n_total, lane);
+        if (lane == 0)
+          fpw[0] = hp;
+      }
     }
     __syncthreads();
     const unsigned long long off = offw[0];
     const uint4 *from = lds_ptr<const uint4>(frame_lds);
-    if (fits && off + room <= pack.capacity) {
+    /* PACK == 2: the first CRCW waves checksum the image while the others copy it out (a per-thread register costs one
+     * bit-serial multiplication by the lane's constant at the end: few threads with long Horner chains beat many with
+     * short ones) */
+    constexpr int CRCW = PACK == 2 ? pack_crc_waves(WAVES) : 0, CB = CRCW * 64;
+    static_assert(WAVES > CRCW && WAVES >= 2, "waves left for the copy and the header's share");
+    if (tid >= CB && fits && off + room <= pack.capacity) {
       uint8_t *to = pack.dst + off;
-      for (uint32_t g = (uint32_t)tid; g < room / 16u; g += BLOCK)
+      for (uint32_t g = (uint32_t)(tid - CB); g < room / 16u; g += BLOCK - CB)
         store_out16(to + 16u * g, from[g]);
     }
     if (PACK == 2) {
-      /* ---- the frame's CRC-32C from its LDS image while the stores drain: thread t folds groups t, t + BLOCK, ...
-       * Horner-style (zero groups in FRONT, the initial value folded into the first four bytes), one tree reduction, the
-       * < 16 tail bytes byte-wise -- crc32c_frame_kernel's scheme, on LDS instead of a slab slot */
+      /* ---- the frame's CRC-32C from its LDS image: thread t < CB folds groups t, t + CB, ... Horner-style (zero groups
+       * in FRONT, the initial value folded into the first four bytes), one reduction over the CRCW waves, then wave 0
+       * closes the frame: the < 16 tail bytes, the header's checksum field, the packet CRC (crc_close_wave) --
+       * crc32c_frame_kernel's scheme, on LDS instead of a slab slot */
       const uint32_t *mulh = lds_ptr<const uint32_t>(L::o_fcrc + CrcLds::o_mulh);
       uint32_t *tree = lds_ptr<uint32_t>(L::o_fcrc + CrcLds::o_tree);
       const int full = fits ? (int)(n_total >> 4) : 0;
-      const int rounds = (full + BLOCK - 1) / BLOCK, lead = rounds * BLOCK - full;
-      uint32_t sreg = 0;
-      for (int j = 0; j < rounds; j++) {
-        const int g = j * BLOCK + tid - lead;
-        uint4 d = make_uint4(0u, 0u, 0u, 0u);
-        if (g >= 0) {
-          d = from[g];
-          if (g == 0)
-            d.x = ~d.x;
+      const uint32_t ntail = fits ? n_total & 15u : 0u;
+      const int rounds = (full + CB - 1) / CB, lead = rounds * CB - full;
+      uint32_t sreg = 0, tail_byte = 0;
+      if (tid < CB) {
+        if ((uint32_t)tid < ntail)
+          tail_byte = lds_ptr<const uint8_t>(frame_lds)[(uint32_t)full * 16u + (uint32_t)tid];
+        for (int j = 0; j < rounds; j++) {
+          const int g = j * CB + tid - lead;
+          uint4 d = make_uint4(0u, 0u, 0u, 0u);
+          if (g >= 0) {
+            d = from[g];
+            if (g == 0)
+              d.x = ~d.x;
+          }
+          sreg = crc_mul_table(mulh, sreg) ^ crc_raw16(fslice, d);
         }
-        sreg = crc_mul_table(mulh, sreg) ^ crc_raw16(fslice, d);
       }
-      const uint32_t whole = crc_reduce_waves<BLOCK>(tree, sreg, tid, lane_k, lane_xk);
-      if (tid == 0) {
-        const unsigned char *fb = lds_ptr<const unsigned char>(frame_lds);
-        uint32_t st = full > 0 ? whole : 0xFFFFFFFFu;
-        for (uint32_t k = (uint32_t)full * 16u; fits && k < n_total; k++)
-          st = (st >> 8) ^ fslice[(st ^ fb[k]) & 0xFFu];
-        const uint32_t crc = fits ? ~st : 0u;
-        wire.crc[fidx] = crc;
-        if (wire.hdr) {
-          if (fits)
-            crc_emit_packet(fpw[0], fpw[1], st, crc, dim_w, dim_h, n_total, false, fidx, fslice, wire.hdr, wire.pkt_crc);
-          else { /* as the fused stream checksum reports a frame that did not fit: a header of zeros, its CRC behind it */
+      const uint32_t whole = crc_reduce_waves<BLOCK, CB>(tree, sreg, tid, lane_k, lane_xk);
+      if (wave == 0) {
+        if (fits) {
+          const CrcClose c = crc_close_wave(fslice, fpow, full > 0 ? whole : 0xFFFFFFFFu, ntail, tail_byte, want_pkt, fpw[0],
+                                            fpw[1], lane, lane_xk);
+          if (lane == 0) {
+            wire.crc[fidx] = ~c.st;
+            if (wire.hdr)
+              crc_store_header(wire.hdr, fidx, dim_w, dim_h, n_total, ~c.st);
+            if (want_pkt)
+              wire.pkt_crc[fidx] = c.pkt;
+          }
+        } else if (lane == 0) { /* as the fused stream checksum reports a frame that did not fit: a header of zeros, its CRC behind it */
+          wire.crc[fidx] = 0u;
+          if (wire.hdr) {
             for (int j = 0; j < 24; j++)
               wire.hdr[(size_t)fidx * 24u + j] = 0;
             if (wire.pkt_crc)

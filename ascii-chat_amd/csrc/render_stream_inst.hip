@@ -140,7 +140,7 @@ hipError_t launch_pack(const achip_frame_t *frames, int n, const achip_lut_t *lu
     }
     const uint4 *tab = nullptr;
     if constexpr (WIRE) {
-      hipError_t e = frame_crc_tables<G::WAVES * 64>(&tab);
+      hipError_t e = frame_crc_tables<64 * achip::pack_crc_waves(G::WAVES)>(&tab);
       if (e != hipSuccess)
         return e;
     }

@@ -168,11 +168,11 @@ static void run_stream_pack(const achip_frame_t *frames, int n, const achip_lut_
     (void)achip_frames_uniform(frames, n, &uni);
   uni.flags = ((lut->flags & ACHIP_LUT_MULTIBYTE) ? 0u : ACHIP_UNIFORM_PALETTE_ASCII) |
               ACHIP_UNIFORM_MAX_CELLS(achip_max_cells(frames, n));
-  static std::vector<uint32_t> tab; /* per block size: the Horner table is x^(128 * BLOCK) */
+  static std::vector<uint32_t> tab; /* the Horner table of the checksumming waves */
   if (WIRE && tab.empty()) {
     tab.resize(ACHIP_FRAME_CRC_TAB_BYTES / 4 + 4);
     uint32_t *t = tab.data();
-    hipemu::launch(dim3(1), dim3(256), ACHIP_FRAME_CRC_TAB_BYTES, [&] { achip::crc_frame_tables_init_kernel<WAVES * 64>(t); });
+    hipemu::launch(dim3(1), dim3(256), ACHIP_FRAME_CRC_TAB_BYTES, [&] { achip::crc_frame_tables_init_kernel<64 * achip::pack_crc_waves(WAVES)>(t); });
   }
   const uint4 *tabv = WIRE ? reinterpret_cast<const uint4 *>(tab.data()) : nullptr;
   const size_t lds = (size_t)((L::bytes_for_pack(achip::stream_maxblk(uni.flags, L::EFF), (int)stride) + 15) & ~15);
