@@ -612,6 +612,36 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
    * whose workgroups hand their offsets to each other through global memory, a lone mono frame 7.0 against 8.1 us through
    * rows geometry 25 (profiles/r04_small_batch_variants.txt); the nine 160x48 targets of the grid -- four blocks per
    * wave -- stay with the bands (9.6 against 20 us) */
+  /* Small launches of the per-cell modes -- a lone frame, the nine targets of a grid -- share a frame's blocks out over
+   * four-wave workgroups (render_stream.hpp PARTS, geometry 18: one wave per SIMD, one block per wave where the CUs
+   * allow), as long as every workgroup of the launch has a CU to itself (they hand their byte counts to each other
+   * through memory, so all of them must be resident): one workgroup per frame queues all of the frame's waves on the
+   * four SIMDs of ONE CU (profiles/r04_lone_frame_timeline.txt). */
+  if (forced_variant < 0 && cell_mode && split_request == 0 && max_cells <= (long)ACHIP_HOST_STREAM_MAXBLK * (128 - ghost)) {
+    const long nblk = (max_cells + (128 - ghost) - 1) / (128 - ghost);
+    long np = (nblk + 3) / 4;
+    if (np > 64)
+      np = 64;
+    if (np * n_frames > n_cus)
+      np = n_cus / n_frames;
+    { /* ASCIICHAT_HIP_STREAM_PARTS (diagnostics, read once): 1 = never, N = this many where the CUs allow */
+      static int forced = -1;
+      if (forced < 0) {
+        const char *e = getenv("ASCIICHAT_HIP_STREAM_PARTS");
+        forced = e && e[0] ? atoi(e) : 0;
+      }
+      if (forced >= 1 && forced <= 64 && (long)forced * n_frames <= n_cus)
+        np = forced;
+    }
+    /* only while every wave has at most ONE block: with two rounds per wave the four-wave workgroups lose to whole frames
+     * (128 frames in two parts each: 11.7 us against 7.0; profiles/r04_small_batch_parts.txt) */
+    if (np >= 2 && (nblk + np - 1) / np <= 4) {
+      *variant = 18;
+      *parts = (int)np;
+      *rows_per_part = 1;
+      return 0;
+    }
+  }
   const bool one_block_per_wave = cell_mode && split_request == 0 && max_cells <= 16 * (128 - ghost);
   if (forced_variant < 0 && cell_mode && (!may_split || max_wp > variant_caps[0] || one_block_per_wave) &&
       max_cells <= (long)ACHIP_HOST_STREAM_MAXBLK * (128 - ghost)) {

@@ -36,9 +36,14 @@ extern "C" int achip_launch_render(int mode, int variant, int has_composite, con
     }
     return (int)hipErrorInvalidValue;
   }
-  if (ACHIP_IS_STREAM_VARIANT(variant)) { /* wave-autonomous kernel: per-cell modes, whole frames (render_stream.hpp) */
-    if (parts != 1)
-      return (int)hipErrorInvalidValue;
+  if (ACHIP_IS_STREAM_VARIANT(variant)) { /* wave-autonomous kernel: per-cell modes (render_stream.hpp) */
+    if (parts != 1) { /* a frame's blocks shared out over `parts` workgroups (rows_per_part means nothing here) */
+      if (variant != 18 || parts > 64 || epoch == 0u)
+        return (int)hipErrorInvalidValue;
+      const achip_partsdev_t ps = {parts, epoch, part_sync};
+      return achip_render_sinst_parts_launch_18(mode, has_composite, frames_dev, n_frames, lut_dev, out, out_stride, out_len, uniform,
+                                                prof, &ps, stream);
+    }
     switch (variant) {
 #define X(id, W, C)                                                                                                    \
   case id:                                                                                                             \

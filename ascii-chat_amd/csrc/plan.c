@@ -207,6 +207,8 @@ struct asciichat_hip_plan {
   int max_wp;
   int has_comp; /* some frame samples a virtual composite */
   int parts, rows_per_part, split_request; /* multi-workgroup frames (achip_choose_geometry) */
+  int whole_variant; /* the geometry of the wire-stage entry points (frame checksums, exact-length frames: a frame belongs to ONE
+                        workgroup there): `variant`, unless that shares frames out over workgroups of the stream kernel */
   long max_cells;                          /* cells of the largest frame (ACHIP_UNIFORM_MAX_CELLS)  */
   int palette_ascii;
   unsigned long long *part_sync; /* n * parts_cap u64 hand-off words, zeroed once */
@@ -263,6 +265,14 @@ static int choose_geometry(asciichat_hip_plan_t *p, const achip_frame_t *frames)
   p->parts = parts;
   p->rows_per_part = rpp;
   p->max_cells = achip_uniform_extent(p->mode, variant, frames, p->n);
+  p->whole_variant = variant;
+  if (parts > 1 && ACHIP_IS_STREAM_VARIANT(variant)) { /* what the same plan takes when it must not be shared out */
+    int wv = -1, wp = 1, wr = 1;
+    if (achip_choose_geometry(p->mode, frames, p->n, p->palette_ascii != 0, caps, cus > 0 ? cus : 1, -1, -1, &wv, &wp, &wr) != 0 ||
+        wv < 0 || wp != 1)
+      return -1;
+    p->whole_variant = wv;
+  }
   return 0;
 }
 
@@ -526,7 +536,7 @@ static int plan_render_wire(asciichat_hip_plan_t *p, uint8_t *out_dev, size_t ou
     if (p->uniform_off)
       uni.enabled = 0;
     uni.flags = (p->palette_ascii ? ACHIP_UNIFORM_PALETTE_ASCII : 0u) | ACHIP_UNIFORM_MAX_CELLS(p->max_cells);
-    return achip_hip_check(achip_launch_render_crc(p->mode, p->variant, p->has_comp, p->frames_dev, p->n, p->lut_dev, out_dev,
+    return achip_hip_check(achip_launch_render_crc(p->mode, p->whole_variant, p->has_comp, p->frames_dev, p->n, p->lut_dev, out_dev,
                                                    (uint64_t)out_stride, out_len_dev, wire, &uni, prof, stream),
                            "render + crc kernel launch");
   }
@@ -563,13 +573,17 @@ int asciichat_hip_plan_render_packets(asciichat_hip_plan_t *p, uint8_t *out_dev,
 /* ... and the frames at their exact lengths behind it (pack_frames' layout; dst may be mapped host memory): a plan whose
  * kernel carries the fused CRC renders (one launch) and packs; any other plan renders and then checksums AND packs in one
  * pass over the slab (asciichat_hip_frame_packets_packed) -- two launches either way. */
+/* whether a wire-stage launch of this plan has every frame in ONE workgroup: whole-frame plans, and plans whose plain render
+ * shares frames out over workgroups of the stream kernel (those launch whole_variant instead); not row bands */
+static int plan_frames_whole(const asciichat_hip_plan_t *p) { return p->parts == 1 || ACHIP_IS_STREAM_VARIANT(p->variant); }
+
 /* ---- frames at their exact lengths straight from the render kernel ------------------------- */
 /* Whole-frame launches of the per-cell foreground modes whose frames fit the kernel's LDS image (48 KB: 1080p -> 80x24
  * truecolor is 36 KB) go through the PACK instantiations of the stream kernel: ONE launch leaves the frames back to back in
  * dst -- in the order in which they finish; off_out says where each one went -- together with the checksums and headers;
  * the slab is not written at all (ship exactly frame_size bytes, lib/network/acip/server.c:190-222). */
 int asciichat_hip_plan_get_exact_length(const asciichat_hip_plan_t *p) {
-  if (!p || p->exact_length == 0 || p->parts != 1 || p->has_comp || !ACHIP_IS_STREAM_VARIANT(p->variant))
+  if (!p || p->exact_length == 0 || !plan_frames_whole(p) || p->has_comp || !ACHIP_IS_STREAM_VARIANT(p->whole_variant))
     return 0;
   if (!(p->mode == ACHIP_MODE_256_FG || p->mode == ACHIP_MODE_16_FG || (p->mode == ACHIP_MODE_TRUE_FG && p->palette_ascii)))
     return 0;
@@ -628,7 +642,7 @@ static int plan_render_pack(asciichat_hip_plan_t *p, uint32_t *out_len_dev, cons
     uni.enabled = 0;
   uni.flags = (p->palette_ascii ? ACHIP_UNIFORM_PALETTE_ASCII : 0u) | ACHIP_UNIFORM_MAX_CELLS(achip_uniform_extent(p->mode, 16, p->frames_pinned, p->n));
   const achip_packdev_t pack = {dst, (uint64_t)dst_capacity, off_out, len_out, p->pack_cursor};
-  return achip_hip_check(achip_launch_render_pack(p->mode, p->variant, p->frames_dev, p->n, p->lut_dev, (uint64_t)p->stride, out_len_dev,
+  return achip_hip_check(achip_launch_render_pack(p->mode, p->whole_variant, p->frames_dev, p->n, p->lut_dev, (uint64_t)p->stride, out_len_dev,
                                                   wire, &uni, &pack, stream),
                          "render + pack kernel launch");
 }
@@ -666,9 +680,9 @@ int asciichat_hip_plan_render_crc_profiled(asciichat_hip_plan_t *p, uint8_t *out
 }
 
 int asciichat_hip_plan_has_fused_crc(const asciichat_hip_plan_t *p) {
-  if (!p || p->parts != 1 || p->fused_crc == 0 || !achip_variant_has_crc(p->variant))
+  if (!p || !plan_frames_whole(p) || p->fused_crc == 0 || !achip_variant_has_crc(p->whole_variant))
     return 0;
-  return p->fused_crc > 0 || achip_variant_crc_pays(p->variant);
+  return p->fused_crc > 0 || achip_variant_crc_pays(p->whole_variant);
 }
 
 int asciichat_hip_plan_set_fused_crc(asciichat_hip_plan_t *p, int mode) {

@@ -37,6 +37,11 @@ int achip_render_sinst_pack_launch_17(int mode, const achip_frame_t *frames, int
                                       uint32_t *len, const achip_uniform_t *uniform, const achip_wire_t *wire,
                                       const achip_packdev_t *pack, void *stream);
 
+/* the PARTS instantiations of stream geometry 18 (a frame's blocks shared out over ps->parts workgroups, 2..64) */
+int achip_render_sinst_parts_launch_18(int mode, int comp, const achip_frame_t *frames, int n, const achip_lut_t *lut,
+                                       uint8_t *out, uint64_t stride, uint32_t *len, const achip_uniform_t *uniform,
+                                       unsigned long long *prof, const achip_partsdev_t *ps, void *stream);
+
 /* the rows-kernel geometries (render_rows_inst.hip, -DACHIP_RINST=id): run-structured modes, whole frames */
 #define X(id, W, C)                                                                                                    \
   int achip_render_rinst_launch_##id(int mode, int comp, const achip_frame_t *frames, int n, const achip_lut_t *lut,   \

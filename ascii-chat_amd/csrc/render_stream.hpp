@@ -396,12 +396,22 @@ __device__ inline void stream_crc_finish(uint32_t *slots, int nblk, int nblk_cap
   }
 }
 
-template <int MODE, int WAVES, int CPL, bool GENERIC, bool CRC = false, int PACK = 0>
+template <int MODE, int WAVES, int CPL, bool GENERIC, bool CRC = false, int PACK = 0, bool PARTS = false>
 __global__ void __launch_bounds__(WAVES * 64)
     render_stream_kernel(const achip_frame_t *__restrict__ frames, const achip_lut_t *__restrict__ lut,
                          uint8_t *__restrict__ out, uint64_t out_stride, uint32_t *__restrict__ out_len, int n_frames,
                          achip_uniform_t uni, unsigned long long *__restrict__ prof, achip_wire_t wire,
-                         const uint4 *__restrict__ crc_tab, achip_packdev_t pack) {
+                         const uint4 *__restrict__ crc_tab, achip_packdev_t pack, achip_partsdev_t ps) {
+  /* PARTS (small launches: a lone frame, the nine targets of a grid): ONE workgroup per frame puts every wave of the
+   * frame on one CU, whose four SIMDs then issue the sixteen waves' instructions one after the other -- ~3 of a lone
+   * 80x24 frame's 5.4 us are that queue (profiles/r04_lone_frame_timeline.txt) while 255 CUs idle.  Here a frame's blocks
+   * are shared out over ps.parts workgroups (the grid is n_frames * parts; workgroup f * parts + p takes the p-th run of
+   * ceil(blocks / parts) blocks), the look-back inside a workgroup stays in LDS, and ONE hand-off crosses workgroups:
+   * every workgroup publishes the bytes of its blocks (ps.sync[workgroup] = {epoch, bytes}, agent scope) as soon as its
+   * blocks are counted, and the wave that owns a workgroup's first block adds up what the parts in front of it
+   * published -- one round trip through memory behind the slowest predecessor, not a chain.  A launch dispatches its
+   * workgroups in order and the host only asks for parts when all of them are resident at once, so the workgroups a
+   * poller waits for are always running. */
   /* PACK != 0 (lib/network/acip/server.c:190-222 ships exactly frame_size bytes): frames leave
    * the kernel at their EXACT length, back to back in pack.dst, and the fixed-stride slab is never written.  A frame's
    * length is only known once its last block has been tokenised, so the whole frame is staged in LDS (frames up to
@@ -424,11 +434,12 @@ __global__ void __launch_bounds__(WAVES * 64)
 #define ACHIP_SSTAMP(slot)                                                                                             \
   do {                                                                                                                 \
     if (prof && lane == 0 && first_block)                                                                              \
-      prof[((size_t)fidx * WAVES + wave) * 8u + (slot)] = wall_now();                                                  \
+      prof[((size_t)blockIdx.x * WAVES + wave) * 8u + (slot)] = wall_now();                                            \
   } while (0)
   static_assert(mode_is_cell(MODE), "run-structured modes use render_frames_kernel");
   using L = SLds<MODE, WAVES, CPL, CRC, PACK>;
   static_assert(!PACK || (!GENERIC && !CRC && MODE != ACHIP_MODE_TRUE_BG), "exact-length frames: single-source per-cell foreground modes");
+  static_assert(!PARTS || (!CRC && !PACK), "a frame's checksum and its LDS image belong to one workgroup");
   constexpr bool WIRE = CRC || PACK == 2; /* the launch leaves checksums (and headers) */
   constexpr int BLOCK = WAVES * 64;
   constexpr int BLK = L::BLK;
@@ -439,7 +450,10 @@ __global__ void __launch_bounds__(WAVES * 64)
 
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63, wave = wave_uniform(tid >> 6);
-  const int fidx = (int)blockIdx.x;
+  const int wg = (int)blockIdx.x;
+  const int parts = PARTS ? ps.parts : 1;
+  const int fidx = PARTS ? wg / parts : wg;
+  const int part = PARTS ? wg - fidx * parts : 0;
   /* Every kernel argument the prologue needs is requested HERE, in one burst of scalar loads: left to itself the
    * compiler loads each argument at its first use, behind the branches above it -- six dependent round trips to
    * the kernarg segment in front of the first gather (profiles/r02_stream_timeline.txt). */
@@ -539,6 +553,15 @@ __global__ void __launch_bounds__(WAVES * 64)
   const int nblk = (int)((ncells + EFF - 1) / EFF);
   const int nblk_cap = stream_maxblk(uni.flags, EFF); /* words in each per-block LDS array of this launch */
   (void)nblk_cap;
+  /* PARTS: this workgroup's run of blocks [b0, b1); a part behind the frame's last block only reports in */
+  const int bpp = PARTS ? (nblk + parts - 1) / parts : nblk;
+  const int b0 = PARTS ? min(part * bpp, nblk) : 0, b1 = PARTS ? min(b0 + bpp, nblk) : nblk;
+  uint32_t *partacc = lds_ptr<uint32_t>(L::o_flags); /* PARTS: [0] bytes of this workgroup's blocks so far, [1] blocks counted */
+  if (PARTS && b0 >= b1) {
+    if (tid == 0)
+      agent_store_u64(&ps.sync[wg], ((unsigned long long)ps.epoch << 32));
+    return;
+  }
   /* PACK: the frame must also fit its LDS image, which the launch sized for out_stride bytes (the host keeps that below
    * ACHIP_PACK_FRAME_CAP) behind the per-block words */
   const uint32_t cap_bytes = PACK ? min((uint32_t)out_stride, (uint32_t)ACHIP_PACK_FRAME_CAP) : (uint32_t)out_stride;
@@ -603,7 +626,7 @@ __global__ void __launch_bounds__(WAVES * 64)
 
   /* lane's cell of slot k = 0; the ghost of block 0 is "cell -1" = the last cell of row -1 (modulo 2^32: the steps
    * below carry it to the right place, and it fails every `< ncells` test) */
-  uint32_t cell0 = (uint32_t)(wave * EFF + lane) - (uint32_t)SH;
+  uint32_t cell0 = (uint32_t)((b0 + wave) * EFF + lane) - (uint32_t)SH;
   CellPos pos;
   pos.rr = cell0 / uwp;
   pos.xp = cell0 - pos.rr * uwp;
@@ -616,7 +639,7 @@ __global__ void __launch_bounds__(WAVES * 64)
   const bool late_first = GENERIC && f.comp != nullptr;
   if (late_first)
     comp_stage<L::o_comp, BLOCK>(f.comp, tid);
-  else if (wave < nblk)
+  else if (b0 + wave < b1)
     issue_any(cell0, pos, raw, kinds);
   ACHIP_SSTAMP(2);
 
@@ -639,8 +662,10 @@ __global__ void __launch_bounds__(WAVES * 64)
     }
   if (MODE == ACHIP_MODE_16_FG && tid < 64)
     ramp[tid] = (uint8_t)lut_ramp;
-  for (int k = tid; k < nblk; k += BLOCK)
+  for (int k = tid; k < b1 - b0; k += BLOCK) /* (indexed from the workgroup's first block) */
     slots[k] = 0u;
+  if (PARTS && tid < 2)
+    partacc[tid] = 0u;
   (void)ramp;
   if (TABLES) {
 #pragma unroll
@@ -656,7 +681,7 @@ __global__ void __launch_bounds__(WAVES * 64)
   }
   /* ascii_pad_frame_height (ascii.c:902-941): pad_top bare newlines in front of the frame */
   const uint32_t first_base = (uint32_t)f.pad_top;
-  if (first_base > 0u && first_base <= cap_bytes)
+  if (first_base > 0u && first_base <= cap_bytes && part == 0)
     for (uint32_t o = (uint32_t)tid; o < first_base; o += BLOCK) {
       if (PACK)
         lds_ptr<uint8_t>(frame_lds)[o] = '\n';
@@ -667,7 +692,7 @@ __global__ void __launch_bounds__(WAVES * 64)
   ACHIP_SSTAMP(1);
   if (late_first) {
     chead = comp_head<L::o_comp>();
-    if (wave < nblk)
+    if (b0 + wave < b1)
       issue_any(cell0, pos, raw, kinds);
   }
 
@@ -677,12 +702,12 @@ __global__ void __launch_bounds__(WAVES * 64)
   /* predicated-off byte stores land in a per-lane dummy word (one address for all lanes would serialise them) */
   const uint32_t dummy_addr = lds_base_addr() + (uint32_t)L::o_flags + 16u + 4u * (uint32_t)lane;
 
-  for (int blk = wave; blk < nblk; blk += WAVES) {
+  for (int blk = b0 + wave; blk < b1; blk += WAVES) {
     /* ---- request the next block's samples: they stay in flight while this block is tokenised and drained */
     const uint32_t cell0_next = cell0 + (uint32_t)(WAVES * EFF);
     const CellPos pos_next = advance(pos, qit, rit);
     uint32_t raw_n[CPL], kinds_n = 0;
-    if (blk + WAVES < nblk)
+    if (blk + WAVES < b1)
       issue_any(cell0_next, pos_next, raw_n, kinds_n);
 
     if (prof) { /* diagnostics only: make "samples arrived" a point in time */
@@ -781,16 +806,44 @@ __global__ void __launch_bounds__(WAVES * 64)
     ACHIP_SSTAMP(4);
     /* ---- where the block starts in the frame.  Words hold absolute stream offsets (pad_top included). */
     uint32_t base = first_base;
-    if (blk > 0) {
+    const int lb = blk - b0; /* the block's look-back word */
+    if (PARTS) {
+      /* the workgroup's bytes, for the parts behind it: whoever counts the workgroup's last block publishes the sum
+       * (its own add to [0] precedes its add to [1] in the LDS queue, like everybody's: the sum is complete) */
+      uint32_t counted = 0;
+      if (lane == 0) {
+        (void)slot_fetch_add(&partacc[0], total);
+        counted = slot_fetch_add(&partacc[1], 1u);
+        if ((int)counted == b1 - b0 - 1)
+          agent_store_u64(&ps.sync[wg], ((unsigned long long)ps.epoch << 32) | (unsigned long long)slot_load(&partacc[0]));
+      }
+    }
+    if (lb > 0) {
       if (lane == 0)
-        slot_store(&slots[blk], ACHIP_SLOT_AGG | total);
-      base = stream_lookback(slots, blk, lane);
+        slot_store(&slots[lb], ACHIP_SLOT_AGG | total);
+      base = stream_lookback(slots, lb, lane);
+    } else if (PARTS && part > 0) {
+      /* the bytes of the parts in front: lane q waits for part q's word of this launch (bounded, like the look-back) */
+      unsigned long long w = 0ull;
+      bool got = lane >= part;
+      if (!got)
+        for (int spin = 0; spin < (1 << 22); spin++) {
+          w = agent_load_u64(&ps.sync[wg - part + lane]);
+          got = (uint32_t)(w >> 32) == ps.epoch;
+          if (got)
+            break;
+          spin_nap<1>();
+        }
+      const bool lost = wave_ballot(!got) != 0ull;
+      const uint32_t sum = wave_read_lane(wave_inclusive_scan(got ? (uint32_t)w & ACHIP_SLOT_VALUE : 0u), 63);
+      /* (sums of frames that overflow their slots: every part's bytes are < 2^30, their sum is clamped below) */
+      base = lost ? 0xFFFFFFFFu : min(first_base + sum, cap_bytes + 1u);
     }
     const bool ok = base != 0xFFFFFFFFu && (uint64_t)base + total <= cap_bytes;
     /* a frame that overflows its slot (or whose look-back failed) publishes cap+1 from there on, so every later
      * block fails the same test and prefixes stay below 2^30 (stride <= ACHIP_STREAM_MAX_STRIDE) */
     if (lane == 0)
-      slot_store(&slots[blk], ACHIP_SLOT_PREFIX | (ok ? base + total : cap_bytes + 1u));
+      slot_store(&slots[lb], ACHIP_SLOT_PREFIX | (ok ? base + total : cap_bytes + 1u));
 
     ACHIP_SSTAMP(5);
     if (ok) {
@@ -848,7 +901,7 @@ __global__ void __launch_bounds__(WAVES * 64)
        * frame; the last block to finish completes the frame (stream_crc_* above) */
       if (ok) {
         const uint32_t braw = stream_crc_staged<L>(lds_ptr<const unsigned char>((int)stage_off), (base & 15u) + total, lane);
-        stream_crc_place<L>(slots, nblk, nblk_cap, blk, braw, base + total, cap_bytes, lane);
+        stream_crc_place<L>(slots, nblk, nblk_cap, blk, braw, base + total, cap_bytes, lane);  /* (CRC: never PARTS, lb == blk) */
       }
       stream_crc_finish<L>(slots, nblk, nblk_cap, cap_bytes, first_base, fidx, dim_w, dim_h, wire, lane);
     }

@@ -88,8 +88,36 @@ hipError_t launch_one(const achip_frame_t *frames, int n, const achip_lut_t *lut
    * workgroups of launches in flight on other streams share a CU */
   const size_t lds = (size_t)((L::bytes_for(achip::stream_maxblk(uni.flags, L::EFF)) + 15) & ~15);
   hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(G::WAVES * 64), lds, stream, frames, lut, out, stride, len, n, uni,
-                     prof, wire, tab, achip_packdev_t{});
+                     prof, wire, tab, achip_packdev_t{}, achip_partsdev_t{});
   return hipGetLastError();
+}
+
+/* PARTS instantiations (a frame's blocks shared out over several workgroups: small launches; geometry 18 -- four waves,
+ * one per SIMD -- only) */
+constexpr bool HAS_PARTS = ACHIP_SINST == 18;
+template <int MODE, bool COMP>
+hipError_t launch_parts(const achip_frame_t *frames, int n, const achip_lut_t *lut, uint8_t *out, uint64_t stride, uint32_t *len,
+                        const achip_uniform_t &uni, unsigned long long *prof, const achip_partsdev_t &ps, hipStream_t stream) {
+  if constexpr (HAS_PARTS) {
+    using L = achip::SLds<MODE, G::WAVES, G::CPL, false>;
+    auto kern = achip::render_stream_kernel<MODE, G::WAVES, G::CPL, COMP, false, 0, true>;
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (L::bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, L::bytes);
+        if (e != hipSuccess)
+          return e;
+      }
+      attr_set = true;
+    }
+    const size_t lds = (size_t)((L::bytes_for(achip::stream_maxblk(uni.flags, L::EFF)) + 15) & ~15);
+    hipLaunchKernelGGL(kern, dim3((unsigned)n * (unsigned)ps.parts), dim3(G::WAVES * 64), lds, stream, frames, lut, out, stride, len, n,
+                       uni, prof, achip_wire_t{}, static_cast<const uint4 *>(nullptr), achip_packdev_t{}, ps);
+    return hipGetLastError();
+  } else {
+    (void)frames, (void)n, (void)lut, (void)out, (void)stride, (void)len, (void)uni, (void)prof, (void)ps, (void)stream;
+    return hipErrorInvalidValue;
+  }
 }
 
 /* PACK instantiations (exact-length frames straight from the render; geometries 16 and 17): frames only, or with the
@@ -148,7 +176,7 @@ hipError_t launch_pack(const achip_frame_t *frames, int n, const achip_lut_t *lu
      * launch's frames can be (`stride`, the plan's bound): two 8-wave workgroups of 1080p -> 80x24 frames share a CU */
     const size_t lds = (size_t)((L::bytes_for_pack(achip::stream_maxblk(uni.flags, L::EFF), (int)stride) + 15) & ~15);
     hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(G::WAVES * 64), lds, stream, frames, lut, static_cast<uint8_t *>(nullptr),
-                       stride, len, n, uni, static_cast<unsigned long long *>(nullptr), wire, tab, pack);
+                       stride, len, n, uni, static_cast<unsigned long long *>(nullptr), wire, tab, pack, achip_partsdev_t{});
     return hipGetLastError();
   } else {
     (void)frames, (void)n, (void)lut, (void)stride, (void)len, (void)uni, (void)wire, (void)pack, (void)stream;
@@ -214,6 +242,33 @@ extern "C" int ACHIP_CAT(achip_render_sinst_pack_launch_, ACHIP_SINST)(int mode,
     M(ACHIP_MODE_TRUE_FG)
     M(ACHIP_MODE_256_FG)
     M(ACHIP_MODE_16_FG)
+#undef M
+  }
+  return (int)hipErrorInvalidValue;
+}
+#endif
+
+#if ACHIP_SINST == 18
+extern "C" int achip_render_sinst_parts_launch_18(int mode, int comp, const achip_frame_t *frames, int n, const achip_lut_t *lut,
+                                                  uint8_t *out, uint64_t stride, uint32_t *len, const achip_uniform_t *uniform,
+                                                  unsigned long long *prof, const achip_partsdev_t *ps, void *stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  achip_uniform_t uni = {};
+  if (uniform && uniform->enabled && !comp)
+    uni = *uniform;
+  if (uniform)
+    uni.flags = uniform->flags;
+  if (!ps || ps->parts < 2 || ps->parts > 64 || !ps->sync || ps->epoch == 0u)
+    return (int)hipErrorInvalidValue;
+  switch (mode) {
+#define M(m)                                                                                                           \
+  case m:                                                                                                              \
+    return (int)(comp ? launch_parts<m, true>(frames, n, lut, out, stride, len, uni, prof, *ps, s)                     \
+                      : launch_parts<m, false>(frames, n, lut, out, stride, len, uni, prof, *ps, s));
+    M(ACHIP_MODE_TRUE_FG)
+    M(ACHIP_MODE_256_FG)
+    M(ACHIP_MODE_16_FG)
+    M(ACHIP_MODE_TRUE_BG)
 #undef M
   }
   return (int)hipErrorInvalidValue;

@@ -92,6 +92,15 @@ typedef struct {
   uint32_t *len_out;
   unsigned long long *cursor;
 } achip_packdev_t;
+/* PARTS instantiations of the stream kernel (a frame's blocks shared out over `parts` workgroups; by value in the kernel
+ * arguments): sync = n_frames * parts 64-bit words owned by the caller, {epoch:32, bytes:32}; a workgroup publishes the
+ * bytes of its blocks under the launch's epoch, its successors add up what the parts in front of them published.  Words
+ * never need clearing: every launch on them takes a new epoch (never 0). */
+typedef struct {
+  int parts;
+  uint32_t epoch;
+  unsigned long long *sync;
+} achip_partsdev_t;
 /* Several nearest-neighbour resizes in one launch (the grid path resizes every source a rank owns per tick): by value in
  * the kernel arguments, workgroup (x, k) works on entry k. */
 #define ACHIP_RESIZE_BATCH_MAX 16

@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/resource.h>
 #include <time.h>
 
 #include "asciichat_render.h"
@@ -102,9 +103,12 @@ int main(int argc, char **argv) {
         pthread_create(&tid[t], NULL, worker, &jobs[t]);
       }
       pthread_barrier_wait(&gate);
+      struct rusage ru0, ru1;
+      getrusage(RUSAGE_SELF, &ru0);
       const double t0 = now();
       pthread_barrier_wait(&gate);
       const double dt = now() - t0;
+      getrusage(RUSAGE_SELF, &ru1);
       size_t bytes = 0;
       for (int t = 0; t < T; t++) {
         pthread_join(tid[t], NULL);
@@ -118,6 +122,13 @@ int main(int argc, char **argv) {
              "%.1f MB/s of frames)\n",
              sw, sh, tw, th, cl, rm, pooled ? "pool (pinned)" : "pageable     ", T, T * 2000.0 / dt, dt / 2000.0 * 1e6,
              (double)bytes / dt / 1e6);
+      if (getenv("DT_RUSAGE")) { /* CPU time the whole process spent per call (every thread, the library's own included) */
+        const double us = (double)(ru1.ru_utime.tv_sec - ru0.ru_utime.tv_sec) * 1e6 + (double)(ru1.ru_utime.tv_usec - ru0.ru_utime.tv_usec);
+        const double ss = (double)(ru1.ru_stime.tv_sec - ru0.ru_stime.tv_sec) * 1e6 + (double)(ru1.ru_stime.tv_usec - ru0.ru_stime.tv_usec);
+        printf("   CPU per call: user %.1f us, system %.1f us; %.1f CPUs busy; context switches per call: %.2f voluntary, %.2f forced\n",
+               us / (T * 2000.0), ss / (T * 2000.0), (us + ss) / (dt * 1e6), (double)(ru1.ru_nvcsw - ru0.ru_nvcsw) / (T * 2000.0),
+               (double)(ru1.ru_nivcsw - ru0.ru_nivcsw) / (T * 2000.0));
+      }
       pthread_barrier_destroy(&gate);
       free(jobs);
       free(tid);

@@ -23,15 +23,20 @@ def main():
     if with_crc:
         NAMES[6], NAMES[7] = "stores issued", "block checksummed + placed"
     sw, sh, W, H, cl, rm = bench.WORKLOADS[name]
-    sets = [bench.make_frames(torch, 256, sw, sh, 900 + s) for s in range(6)]
+    B = int(os.environ.get("TIMELINE_BATCH", "256"))  # 1: what a lone frame's workgroup does on an idle GPU
+    sets = [bench.make_frames(torch, B, sw, sh, 900 + s) for s in range(6)]
     plans = [bench.build_plan(pkg, t, W, H, cl, rm)[0] for t in sets]
     for p in plans:
-        p.set_variant(variant)
+        if variant >= 0:
+            p.set_variant(variant)
+    variant = plans[0].variant  # -1 on the command line: the automatic choice (small launches: PARTS of geometry 18)
+    parts = max(1, plans[0].parts) if variant >= 16 else 1
     waves = pkg.lib().achip_variant_block(variant) // 64
-    out = torch.empty(256 * plans[0].stride, dtype=torch.uint8, device="cuda")
-    ln = torch.zeros(256, dtype=torch.int32, device="cuda")
-    prof = torch.zeros(256 * waves * 8, dtype=torch.int64, device="cuda")
-    crc = torch.zeros(256, dtype=torch.int32, device="cuda")
+    B *= parts  # one row of stamps per WORKGROUP
+    out = torch.empty((B // parts) * plans[0].stride, dtype=torch.uint8, device="cuda")
+    ln = torch.zeros(B // parts, dtype=torch.int32, device="cuda")
+    prof = torch.zeros(B * waves * 8, dtype=torch.int64, device="cuda")
+    crc = torch.zeros(B, dtype=torch.int32, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
     acc = []
     for k in range(12):
@@ -45,8 +50,17 @@ def main():
             plans[k % len(plans)].render_profiled(out.data_ptr(), plans[0].stride, ln.data_ptr(), prof.data_ptr(), st)
         torch.cuda.synchronize()
         if k >= 4:
-            acc.append(prof.cpu().numpy().reshape(256, waves, 8).astype(np.int64))
-    print(f"# {name} variant {variant}{' + fused frame CRC' if with_crc else ''}: {waves} waves per frame, 100 MHz wall clock -> us; per stamp over all active waves of 8 launches")
+            acc.append(prof.cpu().numpy().reshape(B, waves, 8).astype(np.int64))
+    if B == parts:  # every wave of the last launch, stamp by stamp
+        a = acc[-1]
+        t0 = a[:, :, 0][a[:, :, 0] != 0].min()
+        print(f"# {name} variant {variant} parts {parts}, ONE frame: per workgroup.wave, us since the first wave's entry")
+        print("# wg.wave " + " ".join(f"{n[:12]:>12s}" for n in NAMES))
+        for g in range(a.shape[0]):
+            for w in range(waves):
+                if a[g, w, 7]:
+                    print(f"  {g:3d}.{w:<3d} " + " ".join(f"{(a[g, w, s] - t0) / 100.0:12.2f}" for s in range(8)))
+    print(f"# {name} variant {variant}{' + fused frame CRC' if with_crc else ''}: {B} frame(s), {waves} waves per frame, 100 MHz wall clock -> us; per stamp over all active waves of 8 launches")
     print(f"# {'stamp':28s} {'min':>7s} {'p10':>7s} {'median':>7s} {'p90':>7s} {'max':>7s}")
     rows = [[] for _ in range(8)]
     for a in acc:

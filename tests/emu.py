@@ -82,9 +82,11 @@ def make_lut(palette):
 _EPOCH = [0]
 
 
-def render_frames(mode, frames, palette, variant=0, stride=None, rows_per_part=0, uniform=False):
+def render_frames(mode, frames, palette, variant=0, stride=None, rows_per_part=0, uniform=False, parts=0, sync=None):
     """uniform: pass the batch's common descriptor by value when it has one (what plans do by default).
-    rows_per_part > 0 renders every frame with ceil(rows / rows_per_part) workgroups (multi-part frames)."""
+    rows_per_part > 0 renders every frame with ceil(rows / rows_per_part) workgroups (multi-part frames).
+    parts > 1 (stream geometries): a frame's blocks shared out over that many workgroups; sync (numpy uint64[n * parts])
+    may be passed in to launch again on words that hold an earlier launch's epochs."""
     """frames: ctypes array/list of Frame (src pointers = host numpy memory). Returns list of bytes / int codes."""
     L = lib()
     n = len(frames)
@@ -100,10 +102,16 @@ def render_frames(mode, frames, palette, variant=0, stride=None, rows_per_part=0
     if rows_per_part > 0:
         hb = mode in (5, 6, 7, 8)
         max_rows = max(((f.out_h + 1) // 2 if hb else f.out_h) for f in frames)
-        parts = (max_rows + rows_per_part - 1) // rows_per_part
-        sync = np.zeros(n * parts, dtype=np.uint64)
+        bands = (max_rows + rows_per_part - 1) // rows_per_part
+        band_sync = np.zeros(n * bands, dtype=np.uint64)
         _EPOCH[0] += 1
-        L.emu_set_parts(parts, rows_per_part, sync.ctypes.data, _EPOCH[0])
+        L.emu_set_parts(bands, rows_per_part, band_sync.ctypes.data, _EPOCH[0])
+    elif parts > 1:
+        if sync is None:
+            sync = np.zeros(n * parts, dtype=np.uint64)
+        assert sync.size >= n * parts
+        _EPOCH[0] += 1
+        L.emu_set_parts(parts, 1, sync.ctypes.data, _EPOCH[0])
     L.emu_set_uniform(1 if uniform else 0)
     try:
         rc = L.emu_render_batch(mode, variant, arr, n, C.byref(lut), base, stride, ln.ctypes.data)

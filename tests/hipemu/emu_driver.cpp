@@ -93,8 +93,16 @@ static void run_stream(const achip_frame_t *frames, int n, const achip_lut_t *lu
   uni.flags = ((lut->flags & ACHIP_LUT_MULTIBYTE) ? 0u : ACHIP_UNIFORM_PALETTE_ASCII) |
               ACHIP_UNIFORM_MAX_CELLS(achip_max_cells(frames, n)); /* what plan.c / dropin.c pass */
   const size_t lds = (size_t)((L::bytes_for(achip::stream_maxblk(uni.flags, L::EFF)) + 15) & ~15);
+  if (g_parts > 1) { /* PARTS: a frame's blocks shared out over g_parts workgroups (the product instantiates geometry 18) */
+    const achip_partsdev_t ps = {g_parts, g_epoch, g_part_sync};
+    hipemu::launch(dim3((unsigned)(n * g_parts)), dim3(WAVES * 64), lds, [&] {
+      achip::render_stream_kernel<MODE, WAVES, CPL, true, false, 0, true>(frames, lut, out, stride, len, n, uni, nullptr, achip_wire_t{},
+                                                                          nullptr, achip_packdev_t{}, ps);
+    });
+    return;
+  }
   hipemu::launch(dim3((unsigned)n), dim3(WAVES * 64), lds, [&] {
-    achip::render_stream_kernel<MODE, WAVES, CPL, true>(frames, lut, out, stride, len, n, uni, nullptr, achip_wire_t{}, nullptr, achip_packdev_t{});
+    achip::render_stream_kernel<MODE, WAVES, CPL, true>(frames, lut, out, stride, len, n, uni, nullptr, achip_wire_t{}, nullptr, achip_packdev_t{}, achip_partsdev_t{});
   });
 }
 template <int WAVES, int CPL>
@@ -132,7 +140,7 @@ static void run_stream_crc(const achip_frame_t *frames, int n, const achip_lut_t
   const uint4 *tabv = reinterpret_cast<const uint4 *>(tab.data());
   const size_t lds = (size_t)((L::bytes_for(achip::stream_maxblk(uni.flags, L::EFF)) + 15) & ~15);
   hipemu::launch(dim3((unsigned)n), dim3(WAVES * 64), lds, [&] {
-    achip::render_stream_kernel<MODE, WAVES, CPL, true, true>(frames, lut, out, stride, len, n, uni, nullptr, wire, tabv, achip_packdev_t{});
+    achip::render_stream_kernel<MODE, WAVES, CPL, true, true>(frames, lut, out, stride, len, n, uni, nullptr, wire, tabv, achip_packdev_t{}, achip_partsdev_t{});
   });
 }
 extern "C" int emu_render_stream_crc(int mode, int variant, const achip_frame_t *frames, int n, const achip_lut_t *lut,
@@ -177,7 +185,7 @@ static void run_stream_pack(const achip_frame_t *frames, int n, const achip_lut_
   const uint4 *tabv = WIRE ? reinterpret_cast<const uint4 *>(tab.data()) : nullptr;
   const size_t lds = (size_t)((L::bytes_for_pack(achip::stream_maxblk(uni.flags, L::EFF), (int)stride) + 15) & ~15);
   hipemu::launch(dim3((unsigned)n), dim3(WAVES * 64), lds, [&] {
-    achip::render_stream_kernel<MODE, WAVES, CPL, false, false, PACK>(frames, lut, nullptr, stride, len, n, uni, nullptr, wire, tabv, pack);
+    achip::render_stream_kernel<MODE, WAVES, CPL, false, false, PACK>(frames, lut, nullptr, stride, len, n, uni, nullptr, wire, tabv, pack, achip_partsdev_t{});
   });
 }
 extern "C" int emu_render_stream_pack(int mode, int variant, const achip_frame_t *frames, int n, const achip_lut_t *lut,
@@ -263,13 +271,15 @@ extern "C" int emu_render_rows_crc(int mode, int variant, const achip_frame_t *f
 
 extern "C" int emu_render_batch(int mode, int variant, const achip_frame_t *frames, int n, const achip_lut_t *lut,
                                 uint8_t *out, uint64_t stride, uint32_t *len) {
-  if (g_parts == 1)
-    switch (variant) {
+  switch (variant) { /* (stream geometries take g_parts themselves) */
 #define X(id, W, C)                                                                                                    \
   case id:                                                                                                             \
     return stream_by_mode<W, C>(mode, frames, n, lut, out, stride, len);
-      ACHIP_STREAM_VARIANTS(X)
+    ACHIP_STREAM_VARIANTS(X)
 #undef X
+  }
+  if (g_parts == 1)
+    switch (variant) {
 #define X(id, W, C)                                                                                                    \
   case id:                                                                                                             \
     return rows_by_mode<W, C, false>(mode, variant, frames, n, lut, out, stride, len, achip_wire_t{});

@@ -14,8 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 import orc  # noqa: E402
-from achip_ctypes import (ALL_MODES, MODE_CAPS, MODE_HB_TRUE, MODE_NAMES, MODE_16_DITHER_BG, MODE_TRUE_BG,  # noqa: E402
-                          MODE_TRUE_FG)
+from achip_ctypes import (ALL_MODES, MODE_16_FG, MODE_256_FG, MODE_CAPS, MODE_HB_TRUE, MODE_NAMES, MODE_16_DITHER_BG,  # noqa: E402
+                          MODE_TRUE_BG, MODE_TRUE_FG)
 
 
 @pytest.fixture(scope="module")
@@ -126,12 +126,62 @@ def test_multi_workgroup_frames(gpu, mode):
         got = render_batch(gpu, mode, imgs, W, H, wants_padding=pad, use_aspect=aspect, split=split, repeat=3)
         for k, img in enumerate(imgs):
             assert got[k] == oracle_convert(img, mode, W, H, orc.PALETTE_STANDARD, pad, aspect), (MODE_NAMES[mode], W, H, k)
-    # policy: one 160x48 frame -> 48 single-row workgroups; never when asked not to; and never a frame small enough for one
-    # block per wave of a wave-autonomous geometry (80x24: round 4, profiles/r04_small_batch_variants.txt) unless asked to
-    render_batch(gpu, mode, [TORTURE], 160, 48, split=0, want_parts=48)
+    # policy.  Run-structured modes: one 160x48 frame -> 48 single-row workgroups of the phase kernel, and never a frame small
+    # enough for one block per wave of the rows kernel (80x24: profiles/r04_small_batch_variants.txt) unless asked to.
+    # Per-cell modes: a small launch shares the frame's blocks out over four-wave workgroups of the stream kernel, one block
+    # per wave (PARTS, profiles/r04_small_batch_parts.txt).  Never when asked not to; row bands when asked for rows.
+    cell = mode in (MODE_TRUE_FG, MODE_256_FG, MODE_16_FG, MODE_TRUE_BG)
+    per_block = 127 if mode == MODE_TRUE_FG else 128  # truecolor-fg blocks carry a ghost slot
+
+    def shared_out(cells):
+        return -(-(-(-cells // per_block)) // 4)
+
+    render_batch(gpu, mode, [TORTURE], 160, 48, split=0, want_parts=shared_out(160 * 48) if cell else 48)
     render_batch(gpu, mode, [TORTURE], 160, 48, split=-1, want_parts=1)
-    render_batch(gpu, mode, [TORTURE], 80, 24, split=0, want_parts=1)
+    render_batch(gpu, mode, [TORTURE], 80, 24, split=0, want_parts=shared_out(80 * 24) if cell else 1)
     render_batch(gpu, mode, [TORTURE], 80, 24, split=2, want_parts=12)
+
+
+@pytest.mark.parametrize("mode", [MODE_TRUE_FG, MODE_256_FG, MODE_16_FG, MODE_TRUE_BG], ids=["true_fg", "256_fg", "16_fg", "true_bg"])
+def test_small_launches_share_frames_out_over_workgroups(gpu, mode):
+    """PARTS instantiations of the stream kernel (geometry 18): what small launches of the per-cell modes take by themselves.
+    Lone frames, small and ragged batches, padding, three launches on the same hand-off words (a new epoch each), a range of
+    the plan's frames, and the wire-stage entry points of such a plan (which launch whole frames instead)."""
+    pkg, torch = gpu
+    per_block = 127 if mode == MODE_TRUE_FG else 128
+    for (W, H, n, pad) in [(80, 24, 1, False), (80, 24, 9, False), (160, 48, 9, False), (97, 31, 5, True), (80, 24, 64, False),
+                           (200, 60, 2, False)]:
+        aspect = pad and mode != MODE_TRUE_BG
+        imgs = [TORTURE] + [orc.frame_hash_noise(160, 120, 70 + k) for k in range(n - 1)]
+        got = render_batch(gpu, mode, imgs, W, H, wants_padding=pad, use_aspect=aspect, repeat=3)
+        for k, img in enumerate(imgs):
+            assert got[k] == oracle_convert(img, mode, W, H, orc.PALETTE_STANDARD, pad, aspect), (MODE_NAMES[mode], W, H, n, k)
+    # the geometry really is the shared-out one
+    dev = torch.from_numpy(np.ascontiguousarray(TORTURE)).cuda()
+    fr = [pkg.frame_setup(dev.data_ptr(), TORTURE.shape[1], TORTURE.shape[0], 80, 24, 0, False, False, False) for _ in range(9)]
+    plan = pkg.Plan(mode, orc.PALETTE_STANDARD, fr)
+    assert (plan.variant, plan.parts) == (18, -(-(-(-1920 // per_block)) // 4))
+    want = oracle_convert(TORTURE, mode, 80, 24, orc.PALETTE_STANDARD)
+    # frames [2, 7) only
+    out = torch.full((9 * plan.stride,), 0xEE, dtype=torch.uint8, device="cuda")
+    ln = torch.full((9,), -7, dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(2):
+        plan.render(out.data_ptr(), plan.stride, ln.data_ptr(), st, first=2, count=5)
+    torch.cuda.synchronize()
+    host, lens = out.cpu().numpy(), ln.cpu().numpy()
+    for k in range(5):
+        assert int(lens[k]) == len(want) and host[k * plan.stride:k * plan.stride + len(want)].tobytes() == want, k
+    assert (lens[5:] == -7).all() and (host[5 * plan.stride:] == 0xEE).all()
+    # the frame checksum of such a plan: ONE whole-frame launch with the checksum riding it (not render + a second pass)
+    if mode == MODE_TRUE_FG:
+        assert plan.fused_crc
+    crc = torch.zeros(9, dtype=torch.int32, device="cuda")
+    plan.render_crc(out.data_ptr(), plan.stride, ln.data_ptr(), crc.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert (crc.cpu().numpy().astype(np.uint32) == orc.crc32c(want)).all()
+    assert (ln.cpu().numpy() == len(want)).all()
+    plan.close()
 
 
 def test_split_exclusions_and_ragged_parts(gpu):

@@ -25,6 +25,12 @@ def emu_convert(img, mode, W, H, palette, variant, wants_padding=False, use_aspe
     return emu.render_frames(mode, [f], palette, variant)[0]
 
 
+def emu_convert_parts(img, mode, W, H, palette, variant, parts, wants_padding=False, use_aspect=False):
+    rm = MODE_CAPS.get(mode, (3, 0))[1]
+    f = emu.frame_for_convert(img, W, H, rm, wants_padding, use_aspect)
+    return emu.render_frames(mode, [f], palette, variant, parts=parts)[0]
+
+
 TORTURE = orc.frame_torture()
 
 
@@ -273,6 +279,43 @@ def test_stream_kernel_ragged_batch_flips_tint_and_overflow():
     f = emu.frame_for_convert(img, 80, 24, 0)
     got = emu.render_frames(MODE_TRUE_FG, [f], orc.PALETTE_STANDARD, 20, stride=1024)
     assert got[0] == 0xFFFFFFFF
+
+
+@pytest.mark.parametrize("mode", STREAM_MODES, ids=["true_fg", "256_fg", "16_fg", "true_bg"])
+def test_stream_kernel_frames_shared_out_over_workgroups(mode):
+    """PARTS instantiations (render_stream.hpp): a frame's blocks shared out over several workgroups that hand their
+    byte counts to each other through global words -- what small launches (a lone frame, the grid's nine targets) use in
+    geometry 18.  Part counts that divide the blocks, that do not, and that exceed them (parts without a block only report
+    in); padding; a ragged batch; an overflowing slot; the same words launched on again (a new epoch each time)."""
+    import ctypes as C
+    for (W, H, variant, parts) in [(80, 24, 18, 4), (80, 24, 18, 3), (80, 24, 20, 7), (97, 31, 20, 16), (3, 2, 18, 2), (1, 1, 20, 5),
+                                   (160, 48, 18, 16), (200, 60, 20, 64)]:
+        exp = oracle_convert(TORTURE, mode, W, H, orc.PALETTE_STANDARD)
+        f = emu.frame_for_convert(TORTURE, W, H, 0)
+        got = emu.render_frames(mode, [f], orc.PALETTE_STANDARD, variant, parts=parts)[0]
+        assert got == exp, (MODE_NAMES[mode], W, H, variant, parts)
+    # aspect + padding (pad_top newlines come from part 0 alone; the ghost of a part's first block is another part's cell)
+    for (W, H, variant, parts) in [(80, 24, 18, 4), (60, 40, 20, 9)] if mode != MODE_TRUE_BG else []:
+        exp = oracle_convert(TORTURE, mode, W, H, orc.PALETTE_STANDARD, True, True)
+        got = emu_convert_parts(TORTURE, mode, W, H, orc.PALETTE_STANDARD, variant, parts, True, True)
+        assert got == exp, (MODE_NAMES[mode], W, H, variant, parts, "padded")
+    # a ragged batch on ONE set of words, launched three times (epochs), uniform and not
+    imgs = [orc.frame_hash_noise(120, 90, i) for i in range(4)] + [orc.frame_bars(64, 48, 3)]
+    dims = [(80, 24), (60, 7), (33, 40), (80, 1), (1, 50)]
+    frames = [emu.frame_for_convert(im, w, h, 0) for im, (w, h) in zip(imgs, dims)]
+    sync = np.zeros(len(frames) * 6, dtype=np.uint64)
+    for _ in range(3):
+        got = emu.render_frames(mode, frames, orc.PALETTE_STANDARD, 20, parts=6, sync=sync)
+        for k, (im, (w, h)) in enumerate(zip(imgs, dims)):
+            assert got[k] == oracle_convert(im, mode, w, h, orc.PALETTE_STANDARD), (mode, k)
+    uni = emu.render_frames(mode, [frames[0]] * 3, orc.PALETTE_STANDARD, 18, uniform=True, parts=4)
+    assert uni[0] == uni[1] == uni[2] == oracle_convert(imgs[0], mode, 80, 24, orc.PALETTE_STANDARD)
+    # a slot that is too small: the overflow is found by whichever part holds the block that crosses the bound
+    f = emu.frame_for_convert(imgs[0], 80, 24, 0)
+    for stride in (1024, 4096, 16384):
+        full = oracle_convert(imgs[0], mode, 80, 24, orc.PALETTE_STANDARD)
+        got = emu.render_frames(mode, [f], orc.PALETTE_STANDARD, 18, stride=stride, parts=4)[0]
+        assert got == (full if len(full) <= stride else 0xFFFFFFFF), (mode, stride)
 
 
 @pytest.mark.parametrize("mode", STREAM_MODES, ids=["true_fg", "256_fg", "16_fg", "true_bg"])
