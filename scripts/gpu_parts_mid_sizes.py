@@ -1,0 +1,30 @@
+import os, sys, statistics
+sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+import numpy as np, torch
+import bench, orc
+from __graft_entry__ import load_package
+pkg = load_package(); torch.cuda.set_device(0); cur = torch.cuda.current_stream()
+def time_plan(plan, n, reps=300):
+    out = torch.empty(n * plan.stride, dtype=torch.uint8, device="cuda"); ln = torch.zeros(n, dtype=torch.int32, device="cuda")
+    for _ in range(20): plan.render(out.data_ptr(), plan.stride, ln.data_ptr(), cur.cuda_stream)
+    torch.cuda.synchronize(); ts = []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(cur)
+        for _ in range(reps): plan.render(out.data_ptr(), plan.stride, ln.data_ptr(), cur.cuda_stream)
+        e1.record(cur); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) / reps * 1e3)
+    return statistics.median(ts), out, ln.cpu().numpy().astype("uint32")
+CASES = [(3840, 2160, 200, 60, 1), (3840, 2160, 200, 60, 2), (3840, 2160, 200, 60, 8), (1920, 1080, 120, 40, 1), (1920, 1080, 120, 40, 16), (1920, 1080, 80, 24, 32)]
+if len(sys.argv) > 1 and sys.argv[1] == 'mid':
+    CASES = [(3840, 2160, 200, 60, 16), (3840, 2160, 200, 60, 32), (3840, 2160, 200, 60, 64), (1920, 1080, 120, 40, 48), (1920, 1080, 120, 40, 100), (1920, 1080, 160, 48, 32), (1920, 1080, 80, 24, 100)]
+for (sw, sh, W, H, nb) in CASES:
+    imgs = bench.make_frames(torch, nb, sw, sh, 5)
+    fr = [pkg.frame_setup(imgs.data_ptr() + i * sw * sh * 3, sw, sh, W, H, 0, False, False, False) for i in range(nb)]
+    exp = orc.convert_with_caps(np.ascontiguousarray(imgs[0].cpu().numpy()), W, H, 3, 0, False, False, False)
+    for mode, nm in ((1, "truecolor"), (2, "ansi256")):
+        if mode == 2: exp2 = orc.convert_with_caps(np.ascontiguousarray(imgs[0].cpu().numpy()), W, H, 2, 0, False, False, False)
+        plan = pkg.Plan(mode, bench.PALETTE_STANDARD, fr)
+        t, out, lens = time_plan(plan, nb)
+        got = bytes(out[:int(lens[0])].cpu().numpy())
+        print(f"{nb:3d} x ({sw}x{sh} -> {W}x{H} {nm}): {t:7.2f} us  variant {plan.variant} parts {plan.parts} ok {got == (exp if mode == 1 else exp2)}")
+        plan.close()
