@@ -31,6 +31,8 @@ RENDERERS = {
     "hbmono": (8, lambda im, pal: orc.print_with_caps(im, 0, 2, pal), lambda im, pal: rs.halfblock_mono(im), (0, 4, 24, 25)),
     "true_bg": (4, lambda im, pal: orc.print_truecolor_bg(im, pal), lambda im, pal: rs.truecolor_bg(im, pal),
                 (0, 2, 4, 16, 17, 18, 19)),
+    "hbtrue": (5, lambda im, pal: orc.print_with_caps(im, 3, 2, pal), lambda im, pal: rs.halfblock_true(im), (0, 4, 24, 25)),
+    "dither16_bg": (9, lambda im, pal: orc.print_16_dithered(im, True, pal), lambda im, pal: rs.dither16_bg(im, pal), (0, 2, 4)),
     # rows the survey's recorded anchors pin as whole-frame hashes; these add byte-level, line-cited answers
     "mono": (0, lambda im, pal: orc.print_with_caps(im, 0, 0, pal), lambda im, pal: rs.mono(im, pal), (0, 4, 24, 25)),
     "true_fg": (1, lambda im, pal: orc.print_with_caps(im, 3, 0, pal), lambda im, pal: rs.truecolor_fg(im, pal),
@@ -69,9 +71,9 @@ def test_every_unpinned_row_has_three_hand_kats():
     per_row = {}
     for k in KATS["frames"] + KATS["layouts"] + KATS["composites"] + KATS["composite_frames"]:
         per_row[k["row"]] = per_row.get(k["row"], 0) + 1
-    for row in ("H256", "H16", "HM", "PB", "PT"):
+    for row in ("H256", "H16", "HM", "PB", "PT", "HT"):
         assert per_row.get(row, 0) >= 3, (row, per_row)
-    for row in ("P256", "P16", "PM"):
+    for row in ("P256", "P16", "PM", "PD"):
         assert per_row.get(row, 0) >= 1, (row, per_row)
     assert per_row["C1"] >= 3 and per_row["C2"] + per_row["C3"] >= 3
     for k in KATS["frames"] + KATS["composite_frames"]:
