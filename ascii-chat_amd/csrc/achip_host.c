@@ -655,8 +655,14 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
     *variant = (max_cells <= 16 * (128 - ghost) && n_frames <= n_cus) ? 16 : 17;
     return 0;
   }
+  /* (the coloured half-block modes only from a frame per four CUs on: their tokens are long -- two SGRs and a three-byte glyph
+   * per cell -- and a rows-kernel block is ONE wave taking its cells through the path four at a time, so with few frames the
+   * row bands of the phase kernel, a thread per cell, are shorter: a lone 80x24 half-block truecolor frame 9.0 us as bands
+   * against 12.6 whole, eight of them 9.7 against 12.9, sixty-four in four bands each 10.2 against 13.3, ninety-six 17.9 against
+   * 13.4; profiles/r04_small_run_modes.txt) */
+  const bool short_tokens = mode == ACHIP_MODE_MONO || mode == ACHIP_MODE_HB_MONO;
   if (forced_variant < 0 && run_mode && may_split && split_request == 0 && max_wp <= 256 &&
-      achip_uniform_extent(mode, 25, frames, n_frames) <= 8) {
+      (short_tokens || 4 * n_frames > n_cus) && achip_uniform_extent(mode, 25, frames, n_frames) <= 8) {
     *variant = 25; /* one block of whole rows per wave of its eight: see above */
     return 0;
   }
@@ -707,8 +713,9 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
   int rpp;
   if (split_request > 0) {
     rpp = split_request;
-  } else { /* about one band per CU; more bands than that only when the chunk size forces it */
-    const int want = (n_cus + n_frames - 1) / n_frames;
+  } else { /* about one band per CU and never more bands than CUs unless the chunk size forces it: a launch of 288 bands
+            * takes two turns on 256 CUs (24 half-block frames: 17.0 us in twelve bands each against 9.5 in eight) */
+    const int want = n_cus / n_frames > 1 ? n_cus / n_frames : 1;
     rpp = (max_rows + want - 1) / want;
   }
   if (rpp > rpp_max)

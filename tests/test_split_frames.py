@@ -65,7 +65,13 @@ def test_split_ragged_batch_and_policy():
     assert choose(1, one * 64) == (18, 4, 1) and choose(1, one * 65) == (16, 1, 24) and choose(1, one * 150) == (16, 1, 24)
     assert choose(1, one * 16, cus=64) == (18, 4, 1) and choose(1, one * 17, cus=64) == (16, 1, 24)  # a share of the CUs
     assert choose(0, one) == (25, 1, 24) and choose(0, one * 64) == (25, 1, 24)   # mono: eight blocks of three rows, one per wave
-    assert choose(5, [emu.frame_for_convert(imgs[0], 80, 24, 2)]) == (25, 1, 24)
+    # ... the coloured half-block modes only from a frame per four CUs on: with fewer, row bands of the phase kernel (a thread
+    # per cell) beat one wave taking 256 cells of long tokens through the path (profiles/r04_small_run_modes.txt: a lone 80x24
+    # half-block truecolor frame 9.0 us as bands against 12.6 whole; 64 frames in four bands each 10.2 against 13.3)
+    hb = [emu.frame_for_convert(imgs[0], 80, 24, 2)]
+    assert choose(5, hb) == (4, 24, 1) and choose(6, hb * 8) == (4, 24, 1) and choose(7, hb * 64) == (4, 4, 6)
+    assert choose(5, hb * 65) == (25, 1, 24) and choose(8, hb) == (25, 1, 24)  # (half-block mono: short tokens, whole frames)
+    assert choose(5, hb * 48) == (4, 5, 5)   # never more bands than CUs: five per frame at most (240 workgroups)
     mid = [emu.frame_for_convert(imgs[0], 160, 48, 0)]        # 7 680 cells = 61 blocks: sixteen parts (the grid's nine targets)
     assert choose(1, mid) == (18, 16, 1) and choose(1, mid * 9) == (18, 16, 1) and choose(0, mid)[1] > 1
     assert choose(1, mid * 17)[0] < 16 and choose(1, mid * 17)[1] > 1  # sixteen parts no longer fit: row bands of the phase kernel as before
