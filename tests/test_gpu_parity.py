@@ -138,7 +138,10 @@ def test_multi_workgroup_frames(gpu, mode):
 
     render_batch(gpu, mode, [TORTURE], 160, 48, split=0, want_parts=shared_out(160 * 48) if cell else 48)
     render_batch(gpu, mode, [TORTURE], 160, 48, split=-1, want_parts=1)
-    render_batch(gpu, mode, [TORTURE], 80, 24, split=0, want_parts=shared_out(80 * 24) if cell else 1)
+    # (a frame of one block per wave of the rows kernel goes whole in the short-token modes only; a lone coloured half-block
+    # frame is 24 one-row bands of the phase kernel: profiles/r04_small_run_modes.txt)
+    long_tokens = mode in (MODE_HB_TRUE, MODE_HB_TRUE + 1, MODE_HB_TRUE + 2)
+    render_batch(gpu, mode, [TORTURE], 80, 24, split=0, want_parts=shared_out(80 * 24) if cell else (24 if long_tokens else 1))
     render_batch(gpu, mode, [TORTURE], 80, 24, split=2, want_parts=12)
 
 
