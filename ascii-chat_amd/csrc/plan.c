@@ -473,8 +473,10 @@ int asciichat_hip_plan_get_uniform(const asciichat_hip_plan_t *p) {
 
 int asciichat_hip_plan_get_variant(const asciichat_hip_plan_t *p) { return p ? p->variant : -1; }
 
-static int render_range(asciichat_hip_plan_t *p, int first, int count, uint8_t *out_dev, size_t out_stride,
-                        uint32_t *out_len_dev, unsigned long long *phase_cycles_dev, void *stream) {
+/* whole != 0: every frame in ONE workgroup even where the plan's own choice shares frames out over workgroups of the stream
+ * kernel (the hand-off words of that form carry a per-launch epoch: a captured launch cannot be replayed) */
+static int render_range_as(asciichat_hip_plan_t *p, int first, int count, uint8_t *out_dev, size_t out_stride,
+                           uint32_t *out_len_dev, unsigned long long *phase_cycles_dev, void *stream, int whole) {
   if (!p || !out_dev || !out_len_dev || first < 0 || count < 0 || first + count > p->n)
     return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "plan_render: bad arguments");
   if (((uintptr_t)out_dev & 15u) || (out_stride & 15u) || out_stride < p->stride)
@@ -493,12 +495,20 @@ static int render_range(asciichat_hip_plan_t *p, int first, int count, uint8_t *
     uni.enabled = 0;
   uni.flags = (p->palette_ascii ? ACHIP_UNIFORM_PALETTE_ASCII : 0u) | ACHIP_UNIFORM_MAX_CELLS(p->max_cells);
   uni.f.src = uni.f.src ? uni.f.src + (int64_t)first * uni.src_pitch : NULL;
-  return achip_hip_check(achip_launch_render(p->mode, p->variant, p->has_comp, p->frames_dev + first, count, p->lut_dev,
-                                             out_dev, (uint64_t)out_stride, out_len_dev, phase_cycles_dev, p->parts,
+  const int shared_out = p->parts > 1 && ACHIP_IS_STREAM_VARIANT(p->variant);
+  if (whole && p->parts > 1 && !shared_out)
+    return achip_fail(ASCIICHAT_HIP_ERR_NOT_SUPPORTED, "this plan renders row bands");
+  const int variant = whole && shared_out ? p->whole_variant : p->variant, parts = whole ? 1 : p->parts;
+  return achip_hip_check(achip_launch_render(p->mode, variant, p->has_comp, p->frames_dev + first, count, p->lut_dev,
+                                             out_dev, (uint64_t)out_stride, out_len_dev, phase_cycles_dev, parts,
                                              p->rows_per_part,
-                                             p->part_sync ? p->part_sync + (size_t)first * (size_t)p->parts : NULL,
+                                             parts > 1 && p->part_sync ? p->part_sync + (size_t)first * (size_t)p->parts : NULL,
                                              p->epoch, &uni, stream),
                          "render kernel launch");
+}
+static int render_range(asciichat_hip_plan_t *p, int first, int count, uint8_t *out_dev, size_t out_stride,
+                        uint32_t *out_len_dev, unsigned long long *phase_cycles_dev, void *stream) {
+  return render_range_as(p, first, count, out_dev, out_stride, out_len_dev, phase_cycles_dev, stream, 0);
 }
 
 int asciichat_hip_plan_render_range(asciichat_hip_plan_t *p, int first, int count, uint8_t *out_dev, size_t out_stride,
@@ -764,7 +774,9 @@ int asciichat_hip_schedule_create(asciichat_hip_schedule_t **sched, asciichat_hi
                       "schedule_create: bad arguments (n_plans must be a multiple of n_lanes, n_lanes <= 16)");
   *sched = NULL;
   for (int i = 0; i < n_plans; i++)
-    if (!plans[i] || plans[i]->parts > 1) /* row-band launches carry a per-launch epoch: not replayable */
+    if (!plans[i] || (plans[i]->parts > 1 && !ACHIP_IS_STREAM_VARIANT(plans[i]->variant))) /* row-band launches carry a per-launch
+                                                                       epoch: not replayable (shared-out frames of the
+                                                                       stream kernel are captured whole instead) */
       return achip_fail(ASCIICHAT_HIP_ERR_NOT_SUPPORTED, "schedule_create: plan %d renders row bands (small batch)", i);
   int rc = achip_require_device();
   if (rc)
@@ -793,7 +805,7 @@ int asciichat_hip_schedule_create(asciichat_hip_schedule_t **sched, asciichat_hi
   for (int k = first_step; k < first_step + n_steps && !rc; k++) {
     const int l = k % n_lanes;
     asciichat_hip_plan_t *p = plans[k % n_plans];
-    rc = render_range(p, 0, p->n, out_dev[l], out_stride, out_len_dev[l], NULL, lane[l]);
+    rc = render_range_as(p, 0, p->n, out_dev[l], out_stride, out_len_dev[l], NULL, lane[l], 1);
   }
   for (int l = 1; l < n_lanes && !rc; l++) {
     rc = achip_hip_check((int)hipEventRecord(join[l], lane[l]), "hipEventRecord");

@@ -129,8 +129,10 @@ int asciichat_hip_streams_wait(void *const *streams, int n_streams);
  * The same tick loop captured ONCE into a HIP graph with n_lanes parallel branches (lane l renders into out_dev[l] /
  * out_len_dev[l], step k runs on lane k % n_lanes) and replayed with one graph launch on `stream`.  For a server whose
  * set of client batches is stable from tick to tick this removes the per-launch host cost and the wake-up of n_lanes
- * idle queues that a short burst of launches pays.  Plans must render whole frames (batches of >= 3/4 frame per CU, or
- * set_split(plan, -1)); they must not be updated or rendered elsewhere while a replay is in flight.
+ * idle queues that a short burst of launches pays.  Row-band plans cannot be captured (their hand-off words carry a
+ * per-launch epoch): batches of >= 3/4 frame per CU, or set_split(plan, -1); small plans of the per-cell modes, which
+ * plan_render shares out over several workgroups, are captured in their whole-frame geometry.  Plans must not be updated
+ * or rendered elsewhere while a replay is in flight.
  */
 typedef struct asciichat_hip_schedule asciichat_hip_schedule_t;
 int asciichat_hip_schedule_create(asciichat_hip_schedule_t **sched, asciichat_hip_plan_t *const *plans, int n_plans,

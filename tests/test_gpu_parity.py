@@ -187,6 +187,49 @@ def test_small_launches_share_frames_out_over_workgroups(gpu, mode):
     plan.close()
 
 
+def test_graph_replay_of_small_plans_captures_whole_frames(gpu):
+    """asciichat_hip_schedule_*: a captured launch cannot carry the per-launch epoch of frames shared out over workgroups, so
+    small plans of the per-cell modes are captured in their whole-frame geometry; row-band plans are refused as before."""
+    pkg, torch = gpu
+    imgs = [orc.frame_hash_noise(160, 120, 300 + k) for k in range(4)]
+    dev = [torch.from_numpy(np.ascontiguousarray(i)).cuda() for i in imgs]
+    plans = []
+    for k in range(2):
+        fr = [pkg.frame_setup(dev[(k + j) % 4].data_ptr(), 160, 120, 80, 24, 0, False, False, False) for j in range(3)]
+        plans.append(pkg.Plan(MODE_TRUE_FG, orc.PALETTE_STANDARD, fr))
+    assert all(p.parts > 1 and p.variant == 18 for p in plans)
+    stride = plans[0].stride
+    out = [torch.full((3 * stride,), 0xEE, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    ln = [torch.zeros(3, dtype=torch.int32, device="cuda") for _ in range(2)]
+    lanes = [torch.cuda.current_stream(), torch.cuda.Stream()]
+    sched = pkg.Schedule(plans, [o.data_ptr() for o in out], [x.data_ptr() for x in ln], stride, [s.cuda_stream for s in lanes])
+    for _ in range(3):  # replays of ONE captured graph
+        for o in out:
+            o.fill_(0xEE)
+        torch.cuda.synchronize()
+        sched.replay(0, 2, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        for k in range(2):
+            host, lens = out[k].cpu().numpy(), ln[k].cpu().numpy()
+            for j in range(3):
+                want = oracle_convert(imgs[(k + j) % 4], MODE_TRUE_FG, 80, 24, orc.PALETTE_STANDARD)
+                assert int(lens[j]) == len(want) and host[j * stride:j * stride + len(want)].tobytes() == want, (k, j)
+    sched.close()
+    for p in plans:
+        p.close()
+    # a row-band plan (one coloured half-block frame) still cannot be captured
+    f = pkg.frame_setup(dev[0].data_ptr(), 160, 120, 80, 24, 2, False, False, False)
+    band = pkg.Plan(MODE_HB_TRUE, orc.PALETTE_STANDARD, [f])
+    assert band.parts > 1 and band.variant < 16
+    o = torch.zeros(band.stride, dtype=torch.uint8, device="cuda")
+    x = torch.zeros(1, dtype=torch.int32, device="cuda")
+    sched = pkg.Schedule([band], [o.data_ptr()], [x.data_ptr()], band.stride, [torch.cuda.current_stream().cuda_stream])
+    with pytest.raises(RuntimeError):
+        sched.replay(0, 1, torch.cuda.current_stream().cuda_stream)
+    sched.close()
+    band.close()
+
+
 def test_split_exclusions_and_ragged_parts(gpu):
     # multi-byte glyphs in truecolor-fg and the serial dither stay whole-frame
     render_batch(gpu, 1, [TORTURE], 80, 24, palette=orc.PALETTE_BLOCKS, split=0, want_parts=1)
