@@ -71,8 +71,11 @@ size_t asciichat_hip_plan_out_stride(const asciichat_hip_plan_t *plan);
 int asciichat_hip_plan_set_variant(asciichat_hip_plan_t *plan, int variant);
 int asciichat_hip_plan_get_variant(const asciichat_hip_plan_t *plan);
 
-/* Multi-workgroup frames: 0 = automatic (small batches are cut into row bands so that the whole GPU works on
- * them), < 0 = never, > 0 = this many text rows per workgroup.  get_parts() reports workgroups per frame. */
+/* Multi-workgroup frames: 0 = automatic (small batches are shared out over several workgroups so that more of the GPU works
+ * on them: a frame's blocks over four-wave workgroups of the stream kernel for the per-cell modes, variant 18; row bands of
+ * the phase kernel otherwise), < 0 = never, > 0 = row bands of this many text rows per workgroup.  get_parts() reports
+ * workgroups per frame.  The wire-stage entry points (render_crc, render_packets*, *_packed) of a shared-out plan launch its
+ * whole-frame geometry instead: a frame's checksum and its exact-length image belong to one workgroup. */
 int asciichat_hip_plan_set_split(asciichat_hip_plan_t *plan, int rows_per_part);
 /* Pipelining hint.  One launch is a gather burst (HBM-bound) followed by token work (latency-bound, HBM idle); a caller
  * that keeps `launches_in_flight` independent batches in flight on separate streams -- the reference's model: one render
