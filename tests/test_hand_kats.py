@@ -1,5 +1,6 @@
 """tests/golden/hand_kats.json -- micro-frames whose every output byte was derived BY HAND from a cited reference line, for
-the SURVEY 8(a) rows no reference-held vector reaches (H256, H16, HM, PB, C1-C3) -- checked
+the SURVEY 8(a) rows no reference-held vector reaches (H256, H16, HM, PB, C1-C3) and, on top of
+their survey-recorded hashes, for PT, HT, P256, P16, PM and PD: every rendering row of the table has one -- checked
 against all four implementations this repository has of those rows:
   * the C oracle (oracle/asciichat_oracle.c),
   * the third restatement (tests/restatement.py),
