@@ -619,7 +619,12 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
    * four SIMDs of ONE CU (profiles/r04_lone_frame_timeline.txt). */
   if (forced_variant < 0 && cell_mode && split_request == 0 && max_cells <= (long)ACHIP_HOST_STREAM_MAXBLK * (128 - ghost)) {
     const long nblk = (max_cells + (128 - ghost) - 1) / (128 - ghost);
+    /* four blocks per workgroup (a wave each), but up to sixteen workgroups for a small frame (a lone 80x24 frame: 5.8 us
+     * in 16 parts of one block, 5.9 in four; more than that loses again: 4K -> 200x60 in 64 parts 7.2 us against 6.9 in 24,
+     * the grid's nine targets 8.6 in 28 against 8.0 in 16 -- the first block of a part polls every part in front of it) */
     long np = (nblk + 3) / 4;
+    if (np < 16)
+      np = nblk < 16 ? nblk : 16;
     if (np > 64)
       np = 64;
     if (np * n_frames > n_cus)

@@ -133,8 +133,9 @@ def test_multi_workgroup_frames(gpu, mode):
     cell = mode in (MODE_TRUE_FG, MODE_256_FG, MODE_16_FG, MODE_TRUE_BG)
     per_block = 127 if mode == MODE_TRUE_FG else 128  # truecolor-fg blocks carry a ghost slot
 
-    def shared_out(cells):
-        return -(-(-(-cells // per_block)) // 4)
+    def shared_out(cells):  # four blocks per workgroup, but up to sixteen workgroups for a small frame
+        blocks = -(-cells // per_block)
+        return max(-(-blocks // 4), min(blocks, 16))
 
     render_batch(gpu, mode, [TORTURE], 160, 48, split=0, want_parts=shared_out(160 * 48) if cell else 48)
     render_batch(gpu, mode, [TORTURE], 160, 48, split=-1, want_parts=1)
@@ -163,7 +164,7 @@ def test_small_launches_share_frames_out_over_workgroups(gpu, mode):
     dev = torch.from_numpy(np.ascontiguousarray(TORTURE)).cuda()
     fr = [pkg.frame_setup(dev.data_ptr(), TORTURE.shape[1], TORTURE.shape[0], 80, 24, 0, False, False, False) for _ in range(9)]
     plan = pkg.Plan(mode, orc.PALETTE_STANDARD, fr)
-    assert (plan.variant, plan.parts) == (18, -(-(-(-1920 // per_block)) // 4))
+    assert (plan.variant, plan.parts) == (18, min(-(-1920 // per_block), 16))
     want = oracle_convert(TORTURE, mode, 80, 24, orc.PALETTE_STANDARD)
     # frames [2, 7) only
     out = torch.full((9 * plan.stride,), 0xEE, dtype=torch.uint8, device="cuda")

@@ -61,7 +61,7 @@ def test_split_ragged_batch_and_policy():
     # geometry 18; round 4, profiles/r04_small_batch_parts.txt) while every workgroup has a CU and every wave one block;
     # beyond that, frames of at most one block per wave go whole (a lone 80x24 frame: 5.9 us in four parts, 6.3 us whole on
     # the stream kernel, 8.4 us as 24 bands of the phase kernel; a lone mono frame 7.0 against 8.1 us)
-    assert choose(1, one) == (18, 4, 1)
+    assert choose(1, one) == (18, 16, 1)                      # sixteen blocks: a workgroup each while the CUs allow
     assert choose(1, one * 64) == (18, 4, 1) and choose(1, one * 65) == (16, 1, 24) and choose(1, one * 150) == (16, 1, 24)
     assert choose(1, one * 16, cus=64) == (18, 4, 1) and choose(1, one * 17, cus=64) == (16, 1, 24)  # a share of the CUs
     assert choose(0, one) == (25, 1, 24) and choose(0, one * 64) == (25, 1, 24)   # mono: eight blocks of three rows, one per wave
@@ -94,7 +94,7 @@ def test_split_ragged_batch_and_policy():
     assert choose(5, [emu.frame_for_convert(imgs[0], 80, 24, 2)] * 600) == (25, 1, 24)  # half-block whole frames: rows kernel
     assert choose(9, one) == (4, 1, 24)                       # serial dither: never split
     assert choose(1, one, ascii_only=False) == (4, 1, 24)     # truecolor-fg with multi-byte glyphs: never split
-    assert choose(2, one, ascii_only=False) == (18, 4, 1)     # (the other per-cell modes carry multi-byte glyphs on the stream kernel)
+    assert choose(2, one, ascii_only=False) == (18, 15, 1)    # (the other per-cell modes carry multi-byte glyphs on the stream kernel)
     assert choose(1, one, req=-1) == (16, 1, 24)             # never split: one whole frame -> stream kernel
     assert choose(1, one, req=12) == (4, 2, 12)
     assert choose(1, one, req=3, forced=2) == (2, 8, 3)
