@@ -951,6 +951,19 @@ template <int MODE> __device__ inline bool same_run(const uint32_t *pixT, const 
 /* ------------------------------------------------------------------------------------------- */
 /* 16 output bytes to HBM: written once and never read back by the kernel, hence non-temporal (gfx950_ops.hpp) */
 __device__ inline void store_out16(uint8_t *__restrict__ p, uint4 v) { store_u4_nt(p, v); }
+/* the drains' lane -> group mapping starts at a multiple of this (16 = at the first whole group: the round-3 form, kept
+ * for A/B builds: make EXTRA=-DACHIP_DRAIN_ALIGN=16u) */
+#ifndef ACHIP_DRAIN_ALIGN
+#define ACHIP_DRAIN_ALIGN 128u
+#endif
+
+/* the thread of drain_ring that reads the staging buffer's group 0 -- the one that may overwrite it (with the carry)
+ * right behind the call without a barrier: thread 0 when the window starts with a partial head group (copied bytewise
+ * by thread 0), else the thread whose group sits (from + dmis) mod 128 behind a line boundary */
+__device__ inline uint32_t drain_group0_tid(const uint8_t *out, uint32_t from, uint32_t own_from) {
+  const uint32_t dmis = (uint32_t)(uintptr_t)out & (ACHIP_DRAIN_ALIGN - 1u) & ~15u;
+  return own_from > from ? 0u : ((from + dmis) & (ACHIP_DRAIN_ALIGN - 1u)) >> 4;
+}
 
 template <int BLOCK, bool REZERO = false>
 __device__ inline void drain_ring(int ring_off, uint8_t *__restrict__ out, uint32_t from, uint32_t to, uint32_t own_from,
@@ -965,28 +978,39 @@ __device__ inline void drain_ring(int ring_off, uint8_t *__restrict__ out, uint3
   const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
   const uint32_t vec_begin = (own_from + 15u) & ~15u;
   const uint32_t vec_end = to & ~15u;
-  uint32_t o = vec_begin + 16u * threadIdx.x;
-  for (; o + 16u * BLOCK < vec_end; o += 32u * BLOCK) { /* two groups per trip: both LDS reads in flight */
-    const uint4 v0 = *reinterpret_cast<const uint4 *>(ring + (o - from));
-    const uint4 v1 = *reinterpret_cast<const uint4 *>(ring + (o - from) + 16u * BLOCK);
+  /* thread t takes the group 16 t bytes behind a 128-byte LINE boundary of the address (at most seven threads sit out
+   * the first trip): every wave's store instruction covers whole lines (profiles/r04_rows_floor.txt) */
+  const uint32_t dmis = (uint32_t)(uintptr_t)out & (ACHIP_DRAIN_ALIGN - 1u) & ~15u; /* (slots are 16-byte aligned on the GPU; the emulator's need not be) */
+  uint32_t o = ((vec_begin + dmis) & ~(ACHIP_DRAIN_ALIGN - 1u)) + 16u * threadIdx.x; /* (+ dmis: never below zero) */
+  const uint32_t vb = vec_begin + dmis, ve = vec_end + dmis;
+  uint8_t *const outm = out - dmis;
+  const unsigned char *const ringm = ring - dmis - from; /* ringm + o = ring + (o - dmis - from) */
+  for (; o + 16u * BLOCK < ve; o += 32u * BLOCK) { /* two groups per trip: both LDS reads in flight */
+    const bool first = o >= vb; /* (the second group of a trip lies 16 BLOCK bytes further on: always inside) */
+    uint4 v0 = zero4;
+    if (first)
+      v0 = *reinterpret_cast<const uint4 *>(ringm + o);
+    const uint4 v1 = *reinterpret_cast<const uint4 *>(ringm + o + 16u * BLOCK);
     if (REZERO) {
-      *reinterpret_cast<uint4 *>(ring + (o - from)) = zero4;
-      *reinterpret_cast<uint4 *>(ring + (o - from) + 16u * BLOCK) = zero4;
+      if (first)
+        *reinterpret_cast<uint4 *>(const_cast<unsigned char *>(ringm + o)) = zero4;
+      *reinterpret_cast<uint4 *>(const_cast<unsigned char *>(ringm + o) + 16u * BLOCK) = zero4;
     }
 #if defined(ACHIP_ABLATE) && ACHIP_ABLATE == 4
     asm volatile("" ::"v"(v0.x), "v"(v0.y), "v"(v1.z), "v"(v1.w)); /* diagnostics: no HBM writes */
 #else
-    store_out16(out + o, v0);
-    store_out16(out + o + 16u * BLOCK, v1);
+    if (first)
+      store_out16(outm + o, v0);
+    store_out16(outm + o + 16u * BLOCK, v1);
 #endif
   }
-  if (o < vec_end) {
-    store_out16(out + o, *reinterpret_cast<const uint4 *>(ring + (o - from)));
+  if (o >= vb && o < ve) {
+    store_out16(outm + o, *reinterpret_cast<const uint4 *>(ringm + o));
     if (REZERO)
-      *reinterpret_cast<uint4 *>(ring + (o - from)) = zero4;
+      *reinterpret_cast<uint4 *>(const_cast<unsigned char *>(ringm + o)) = zero4;
   }
-  /* head: [own_from, min(vec_begin, to)), < 16 bytes of the buffer's group 0.  Thread 0 alone touches group 0
-   * (it moves the carry there right after this call), so it copies the head itself. */
+  /* head: [own_from, min(vec_begin, to)), < 16 bytes of the buffer's group 0.  ONE thread touches group 0 in this call
+   * (drain_group0_tid: it moves the carry there right after the call): with a head, thread 0, which copies it itself. */
   if (threadIdx.x == 0)
     for (uint32_t h = own_from; h < min(vec_begin, to); h++) {
       out[h] = ring[h - from];
@@ -1325,7 +1349,7 @@ __global__ void __launch_bounds__(BLOCK) ACHIP_PIN_OCCUPANCY(MODE, BLOCK, CAP)
       __syncthreads();
       drain_ring<BLOCK, EMIT_OR>(L::o_ring, dst, lo, hi, lo, false);
       flushed = hi & ~15u;
-      if (tid == 0 && flushed > lo) {
+      if ((uint32_t)tid == drain_group0_tid(dst, lo, lo) && flushed > lo) {
         for (uint32_t j = 0; j < hi - flushed; j++) {
           ring[j] = ring[flushed - lo + j];
           if (EMIT_OR)
@@ -1584,9 +1608,9 @@ __global__ void __launch_bounds__(BLOCK) ACHIP_PIN_OCCUPANCY(MODE, BLOCK, CAP)
       const bool final_flush = last_chunk && cut == chunk_end; /* the tail bytes go out too: nothing to carry */
       drain_ring<BLOCK, EMIT_OR>(L::o_ring, dst, lo, cut, max(own_from, lo), final_flush);
       flushed = cut & ~15u;
-      if (tid == 0 && flushed > lo && cut > flushed && !final_flush) {
+      if ((uint32_t)tid == drain_group0_tid(dst, lo, max(own_from, lo)) && flushed > lo && cut > flushed && !final_flush) {
         /* the < 16 bytes behind the last flushed group move to the front as ONE 16-byte group (a byte loop here
-         * is a chain of dependent LDS round trips between every two chunks).  tid 0 drained group 0 itself
+         * is a chain of dependent LDS round trips between every two chunks).  This thread drained group 0 itself
          * (program order), so it may overwrite it; the bytes behind `cut` in the group are stale (FastSink: the
          * next window overwrites them) or zero (PackSink: they must stay zero, and the source group is cleared) */
         uint4 *src = reinterpret_cast<uint4 *>(ring + (flushed - lo));

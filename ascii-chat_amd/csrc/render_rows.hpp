@@ -45,7 +45,9 @@ __host__ __device__ constexpr int rows_max_token(int m) {
 }
 
 template <int MODE, int WAVES, bool CRC = false> struct RLds {
-  static constexpr int STAGE = 64 * rows_max_token(MODE) + 16; /* one slice + the 16-byte group it starts in */
+  /* one slice + the 16-byte group it starts in; plain instantiations: + the 128-byte line it starts in (the tail of
+   * the slice before it, carried: whole lines leave the wave) + the 128 bytes the carry's move may read behind it */
+  static constexpr int STAGE = 64 * rows_max_token(MODE) + (CRC ? 16 : 256);
   static constexpr int GPL = (STAGE / 16 + 63) / 64;
   static constexpr int o_stage = 0;
   static constexpr int o_glyph = WAVES * STAGE;
@@ -280,6 +282,7 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
   if (f.src_stride == 0)
     f.src_stride = 3 * f.src_w;
   uint8_t *dst = out + (size_t)fidx * out_stride;
+  const uint32_t dmis = (uint32_t)(uintptr_t)dst & (ACHIP_DRAIN_ALIGN - 1u) & ~15u; /* the slot's own offset inside a line */
 
   const int wp = f.pad_left + f.out_w;
   const int rows = HB ? (f.out_h + 1) / 2 : f.out_h;
@@ -557,6 +560,18 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
     uint32_t braw = 0; /* CRC: register after the block's bytes, starting from 0 */
     if (ok) {
       uint32_t a = base; /* stream offset of the slice */
+      /* CARRY (plain instantiations): a slice hands the bytes behind its last whole 128-byte LINE to the next slice of the
+       * block, which finds them at the front of the staging area -- between a block's first and last byte only whole
+       * lines leave the wave.  Slices are ~2.6 KB: flushed one by one, every tenth line of the frame reached memory in
+       * two pieces (16-byte groups and single bytes on either side of the seam), and the memory side takes lines written
+       * in pieces at 4.4 instead of 5.7 TB/s (profiles/r04_rows_floor.txt).  Coordinates q = stream offset + dmis: line
+       * boundaries of the ADDRESS are the multiples of 128. */
+      constexpr bool CARRY = !CRC && !EMIT_OR && ACHIP_DRAIN_ALIGN >= 128u;
+      int last_k = 0;
+#pragma unroll
+      for (int k = 0; k < CPL; k++)
+        last_k = stot[k] != 0u ? k : last_k;
+      uint32_t own_q = base + dmis; /* first byte of the block that has not left the wave yet */
 #pragma unroll
       for (int k = 0; k < CPL; k++) {
         const uint32_t n = stot[k];
@@ -565,6 +580,42 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
         const uint32_t len_k = meta[k] >> 24;
         const uint32_t off_k = wave_inclusive_scan(len_k) - len_k; /* within the slice */
         const Tok tk = rows_token_payload<MODE>(meta[k] & 0xFFFu, (meta[k] >> 12) & 0xFFFu, pt[k], pb[k], f.ops, glyph64);
+        if (CARRY) {
+          /* the staging area's byte 0 is the line the slice starts in (q0); [own_q, qa) is already there */
+          const uint32_t qa = a + dmis, q0 = qa & ~127u, qend = qa + n;
+          if (len_k != 0u) {
+            FastSink<L::o_dec, L::o_flags + 16> fs{stage_addr + (qa + off_k - q0), dummy_addr};
+            token_fields<MODE>(fs, tk, ascii_only);
+          }
+          lds_store_fence();
+          const bool last = k == last_k;
+          const uint32_t q0n = qend & ~127u;           /* the line the next slice starts in */
+          const uint32_t lim = last ? qend : q0n;      /* bytes [own_q, lim) leave now */
+          if (lim > own_q) {
+            const uint32_t vb = (own_q + 15u) & ~15u, ve = lim & ~15u;
+            for (uint32_t q = (vb & ~127u) + 16u * (uint32_t)lane; q < ve; q += 1024u)
+              if (q >= vb)
+                store_out16(dst + (q - dmis), *reinterpret_cast<const uint4 *>(stage + (q - q0)));
+            const uint32_t head_end = min(vb, lim); /* (own_q is a line boundary from the block's second flush on) */
+            if (own_q + (uint32_t)lane < head_end)
+              dst[own_q + (uint32_t)lane - dmis] = stage[own_q + (uint32_t)lane - q0];
+            const uint32_t tail_begin = max(ve, head_end);
+            if (lane >= 32 && tail_begin + (uint32_t)(lane - 32) < lim)
+              dst[tail_begin + (uint32_t)(lane - 32) - dmis] = stage[tail_begin + (uint32_t)(lane - 32) - q0];
+            own_q = lim;
+          }
+          wave_lockstep(); /* the next slice's tokens (and the move below) go where these bytes were read from */
+          if (!last && q0n != q0) { /* [q0n, qend) moves to the front: < 128 bytes, from at least 128 bytes further up */
+            uint4 c = make_uint4(0u, 0u, 0u, 0u);
+            if (lane < 8)
+              c = *reinterpret_cast<const uint4 *>(stage + (q0n - q0) + 16u * (uint32_t)lane);
+            if (lane < 8)
+              *lds_ptr<uint4>((int)stage_off + 16 * lane) = c;
+            wave_lockstep();
+          }
+          a = a + n;
+          continue;
+        }
         /* ---- the slice's tokens into this wave's staging area: stream offset g0 (16-byte aligned) sits at its byte 0 */
         const uint32_t g0 = a & ~15u;
         if (CRC && !EMIT_OR && lane == 0) /* the bytes in front of the slice inside its first group read as zero for the checksum */
@@ -583,8 +634,10 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
         /* ---- staging -> HBM: whole 16-byte groups as uint4, the shared first / last group as bytes */
         const uint32_t end = a + n;
         const uint32_t vec_begin = (a + 15u) & ~15u, vec_end = end & ~15u;
-        for (uint32_t o = vec_begin + 16u * (uint32_t)lane; o < vec_end; o += 1024u)
-          store_out16(dst + o, *reinterpret_cast<const uint4 *>(stage + (o - g0)));
+        /* (whole 128-byte lines per store instruction, as the stream kernel's drain) */
+        for (uint32_t q = ((vec_begin + dmis) & ~(ACHIP_DRAIN_ALIGN - 1u)) + 16u * (uint32_t)lane; q < vec_end + dmis; q += 1024u)
+          if (q >= vec_begin + dmis)
+            store_out16(dst + (q - dmis), *reinterpret_cast<const uint4 *>(stage + (q - dmis - g0)));
         const uint32_t head_end = min(vec_begin, end);
         if (a + (uint32_t)lane < head_end)
           dst[a + (uint32_t)lane] = stage[a + (uint32_t)lane - g0];

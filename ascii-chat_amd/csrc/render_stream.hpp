@@ -527,6 +527,7 @@ __global__ void __launch_bounds__(WAVES * 64)
   if (f.src_stride == 0)
     f.src_stride = 3 * f.src_w;
   uint8_t *dst = out + (size_t)fidx * out_stride;
+  const uint32_t dmis = (uint32_t)(uintptr_t)dst & (ACHIP_DRAIN_ALIGN - 1u) & ~15u; /* the slot's own offset inside a line */
 
   const int wp = f.pad_left + f.out_w;
   const int rows = f.out_h;
@@ -871,7 +872,13 @@ __global__ void __launch_bounds__(WAVES * 64)
       const unsigned char *stage = lds_ptr<const unsigned char>((int)stage_off);
       const uint32_t end = base + total;
       const uint32_t vec_begin = PACK ? end : (base + 15u) & ~15u, vec_end = end & ~15u;
-      for (uint32_t o = vec_begin + 16u * (uint32_t)lane; o < vec_end; o += 1024u) {
+      /* every store instruction of the wave covers whole 128-byte lines (lane l takes the group 16 l bytes behind a LINE
+       * boundary of the ADDRESS, not behind vec_begin): a 1 KB wave store that straddles lines leaves two of them half written, and
+       * the memory side takes such writes at 4.4 instead of 5.7 TB/s (profiles/r04_rows_floor.txt) */
+      for (uint32_t q = ((vec_begin + dmis) & ~(ACHIP_DRAIN_ALIGN - 1u)) + 16u * (uint32_t)lane; q < vec_end + dmis; q += 1024u) {
+        if (q < vec_begin + dmis)
+          continue;
+        const uint32_t o = q - dmis;
 #if defined(ACHIP_STREAM_ABLATE) && (ACHIP_STREAM_ABLATE == 1 || ACHIP_STREAM_ABLATE == 3) /* diagnostics: no HBM writes */
         const uint4 v = *reinterpret_cast<const uint4 *>(stage + (o - g0));
         asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));

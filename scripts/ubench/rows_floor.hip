@@ -53,6 +53,39 @@ __global__ void __launch_bounds__(THREADS)
     sink[f] = 1u;
 }
 
+// the write side alone, as plainly as it can be asked: `total` bytes, G workgroups, each 16-byte store coalesced with its
+// neighbours; NT = non-temporal
+template <bool NT> __global__ void __launch_bounds__(512) k_fill(u4 *__restrict__ out, size_t n_v, int per_wg_contig) {
+  const u4 val = {(uint32_t)blockIdx.x, (uint32_t)threadIdx.x, 7u, 0x20202020u};
+  if (per_wg_contig) { // every workgroup owns one contiguous share (the render's layout: a frame per workgroup)
+    const size_t share = (n_v + gridDim.x - 1) / gridDim.x, v0 = share * blockIdx.x, v1 = v0 + share < n_v ? v0 + share : n_v;
+    for (size_t v = v0 + threadIdx.x; v < v1; v += 512)
+      if (NT) __builtin_nontemporal_store(val, out + v); else out[v] = val;
+  } else { // grid-stride: the whole grid sweeps the buffer front to back
+    for (size_t v = (size_t)blockIdx.x * 512 + threadIdx.x; v < n_v; v += (size_t)gridDim.x * 512)
+      if (NT) __builtin_nontemporal_store(val, out + v); else out[v] = val;
+  }
+}
+
+// the write side under the render's constraint -- 256 frames, each a contiguous slot written front to back -- with the
+// two freedoms a kernel has: G workgroups share a frame (interleaved 8 KB pieces: the frame's front is G x 8 KB wide and
+// 256 / G... frames are open at a time), and a thread issues BURST stores back to back before anything else
+template <int BURST> __global__ void __launch_bounds__(512) k_frames(u4 *__restrict__ out, size_t frame_v, int frames, int G) {
+  const u4 val = {(uint32_t)blockIdx.x, (uint32_t)threadIdx.x, 7u, 0x20202020u};
+  const int groups = gridDim.x / G, grp = blockIdx.x / G, p = blockIdx.x % G;
+  for (int f = grp; f < frames; f += groups) {
+    u4 *o = out + (size_t)f * frame_v;
+    for (size_t v0 = (size_t)p * 512 * BURST; v0 < frame_v; v0 += (size_t)G * 512 * BURST) {
+#pragma unroll
+      for (int b = 0; b < BURST; b++) {
+        const size_t v = v0 + (size_t)b * 512 + threadIdx.x;
+        if (v < frame_v)
+          __builtin_nontemporal_store(val, o + v);
+      }
+    }
+  }
+}
+
 struct Shape {
   const char *name;
   int src_w, src_h, rows, out_bytes;
@@ -107,6 +140,44 @@ int main(int argc, char **argv) {
     }
     hipFree(src);
     hipFree(out);
+  }
+  // ---- the write side alone: 472 MB (a 4K -> 400x120 launch's frames), fresh buffer every launch
+  {
+    const size_t bytes = (size_t)1845408 / 16 * 16 * 256, n_v = bytes / 16;
+    const int nsets = 6;
+    u4 *buf;
+    hipMalloc(&buf, bytes * nsets);
+    printf("write side alone, %.1f MB per launch, %d launches in flight\n", bytes / 1e6, streams_n);
+    auto timeit = [&](const char *name, auto launch) {
+      for (int i = 0; i < 12; i++) launch(i);
+      hipDeviceSynchronize();
+      const auto t0 = std::chrono::steady_clock::now();
+      for (int i = 0; i < 120; i++) launch(i);
+      hipDeviceSynchronize();
+      const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / 120;
+      printf("   %-58s %8.2f us = %5.2f TB/s\n", name, us, bytes / us / 1e6);
+    };
+    for (int g : {256, 1024, 4096}) {
+      char nm[128];
+      snprintf(nm, sizeof nm, "%d workgroups, contiguous share each, non-temporal", g);
+      timeit(nm, [&](int i) { hipLaunchKernelGGL(k_fill<true>, dim3(g), dim3(512), 0, st[i % streams_n], buf + n_v * (i % nsets), n_v, 1); });
+      snprintf(nm, sizeof nm, "%d workgroups, contiguous share each, plain stores", g);
+      timeit(nm, [&](int i) { hipLaunchKernelGGL(k_fill<false>, dim3(g), dim3(512), 0, st[i % streams_n], buf + n_v * (i % nsets), n_v, 1); });
+      snprintf(nm, sizeof nm, "%d workgroups, grid-stride sweep, non-temporal", g);
+      timeit(nm, [&](int i) { hipLaunchKernelGGL(k_fill<true>, dim3(g), dim3(512), 0, st[i % streams_n], buf + n_v * (i % nsets), n_v, 0); });
+      snprintf(nm, sizeof nm, "%d workgroups, grid-stride sweep, plain stores", g);
+      timeit(nm, [&](int i) { hipLaunchKernelGGL(k_fill<false>, dim3(g), dim3(512), 0, st[i % streams_n], buf + n_v * (i % nsets), n_v, 0); });
+    }
+    for (size_t frame_v : {(size_t)1845408 / 16, (size_t)1845504 / 16})
+    for (int G : {1, 4, 256}) {
+      char nm[128];
+      snprintf(nm, sizeof nm, "256 frame slots of %zu B, %3d workgroups per frame (%3d frames open), burst 1", frame_v * 16, G, 256 / G);
+      timeit(nm, [&](int i) { hipLaunchKernelGGL(k_frames<1>, dim3(256), dim3(512), 0, st[i % streams_n], buf + n_v * (i % nsets), frame_v, 256, G); });
+      snprintf(nm, sizeof nm, "256 frame slots of %zu B, %3d workgroups per frame (%3d frames open), burst 8", frame_v * 16, G, 256 / G);
+      timeit(nm, [&](int i) { hipLaunchKernelGGL(k_frames<8>, dim3(256), dim3(512), 0, st[i % streams_n], buf + n_v * (i % nsets), frame_v, 256, G); });
+    }
+    timeit("hipMemsetAsync", [&](int i) { hipMemsetAsync(buf + n_v * (i % nsets), 0x20, bytes, st[i % streams_n]); });
+    hipFree(buf);
   }
   return 0;
 }

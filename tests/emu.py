@@ -82,7 +82,8 @@ def make_lut(palette):
 _EPOCH = [0]
 
 
-def render_frames(mode, frames, palette, variant=0, stride=None, rows_per_part=0, uniform=False, parts=0, sync=None):
+def render_frames(mode, frames, palette, variant=0, stride=None, rows_per_part=0, uniform=False, parts=0, sync=None,
+                  line_phase=None):
     """uniform: pass the batch's common descriptor by value when it has one (what plans do by default).
     rows_per_part > 0 renders every frame with ceil(rows / rows_per_part) workgroups (multi-part frames).
     parts > 1 (stream geometries): a frame's blocks shared out over that many workgroups; sync (numpy uint64[n * parts])
@@ -95,9 +96,11 @@ def render_frames(mode, frames, palette, variant=0, stride=None, rows_per_part=0
     if stride is None:
         stride = max(int(L.achip_out_bound(mode, C.byref(arr[i]))) for i in range(n))
         stride = (stride + 1 + 15) // 16 * 16
-    out = np.full(n * stride + 64, 0xEE, dtype=np.uint8)
+    out = np.full(n * stride + 64 + 256, 0xEE, dtype=np.uint8)
     # 16-byte align the slab like hipMalloc would
     base = (out.ctypes.data + 15) // 16 * 16
+    if line_phase is not None:  # the slab starts 16 * line_phase bytes behind a 128-byte line boundary (the drains'
+        base = (out.ctypes.data + 127) // 128 * 128 + 16 * line_phase  # lane -> group mapping follows the ADDRESS)
     ln = np.zeros(n, dtype=np.uint32)
     if rows_per_part > 0:
         hb = mode in (5, 6, 7, 8)
@@ -125,6 +128,14 @@ def render_frames(mode, frames, palette, variant=0, stride=None, rows_per_part=0
             res.append(int(ln[i]))
         else:
             res.append(C.string_at(base + i * stride, int(ln[i])))
+    if line_phase is not None:  # nothing outside the frames (and their NULs) was written
+        o0 = base - out.ctypes.data
+        assert (out[:o0] == 0xEE).all(), "bytes in front of the slab were written"
+        for i in range(n):
+            if ln[i] < 0xFFFFFFF0:
+                gap = out[o0 + i * stride + int(ln[i]) + 1:o0 + (i + 1) * stride]
+                assert (gap == 0xEE).all(), f"frame {i}: bytes behind the frame's NUL were written"
+        assert (out[o0 + n * stride:] == 0xEE).all(), "bytes behind the slab were written"
     return res
 
 

@@ -105,6 +105,47 @@ def test_torture_all_modes_all_variants(gpu, mode):
             assert got == oracle_convert(TORTURE, mode, W, H, orc.PALETTE_STANDARD), (MODE_NAMES[mode], variant, W, H)
 
 
+def test_slots_at_every_line_phase(gpu):
+    """The drains map lanes to 16-byte groups from a 128-byte line boundary of the slot's ADDRESS (round 4: whole lines per
+    store instruction; the rows kernel carries partial lines from slice to slice, the phase kernel's carry is moved by the
+    thread that drained group 0).  Slabs that start at each 16-byte phase of a line, strides that walk the slots through
+    the other phases, every kernel family: the oracle's bytes, the NUL behind each frame, and nothing else written."""
+    pkg, torch = gpu
+    imgs = [orc.frame_hash_noise(120, 90, i) for i in range(3)] + [TORTURE]
+    dev = [torch.from_numpy(np.ascontiguousarray(i)).cuda() for i in imgs]
+    st = torch.cuda.current_stream().cuda_stream
+    for (mode, variant, dims) in [(MODE_TRUE_FG, 17, [(80, 24), (97, 31), (3, 2), (200, 60)]),
+                                  (MODE_256_FG, 16, [(80, 24), (61, 7), (1, 1), (130, 9)]),
+                                  (MODE_HB_TRUE, 25, [(80, 24), (60, 7), (33, 40), (100, 50)]),
+                                  (MODE_HB_TRUE, 24, [(440, 3), (97, 31), (5, 60), (400, 120)]),
+                                  (0, 25, [(100, 9), (37, 11), (128, 4), (80, 24)]),
+                                  (MODE_HB_TRUE, 4, [(80, 24), (97, 31), (460, 5), (10, 150)]),
+                                  (0, 1, [(80, 24), (97, 31), (300, 20), (1, 130)]),
+                                  (MODE_TRUE_FG, 2, [(80, 24), (130, 1), (64, 65), (200, 60)])]:
+        rm = MODE_CAPS.get(mode, (3, 0))[1]
+        frames = [pkg.frame_setup(d.data_ptr(), i.shape[1], i.shape[0], w, h, rm, False, False, False)
+                  for i, d, (w, h) in zip(imgs, dev, dims)]
+        want = [oracle_convert(i, mode, w, h, orc.PALETTE_STANDARD) for i, (w, h) in zip(imgs, dims)]
+        plan = pkg.Plan(mode, orc.PALETTE_STANDARD, frames)
+        plan.set_variant(variant)
+        n = len(frames)
+        ln = torch.zeros(n, dtype=torch.int32, device="cuda")
+        for phase in range(8):
+            stride = plan.stride + 16 * (1 + 2 * phase)  # odd multiples of 16: slot k sits at phase + k * (1 + 2 phase) mod 8
+            out = torch.full((n * stride + 512,), 0xEE, dtype=torch.uint8, device="cuda")
+            lead = (-out.data_ptr()) % 128 + 128 + 16 * phase
+            plan.render(out.data_ptr() + lead, stride, ln.data_ptr(), st)
+            torch.cuda.synchronize()
+            host, lens = out.cpu().numpy(), ln.cpu().numpy().astype(np.uint32)
+            assert (host[:lead] == 0xEE).all(), (mode, variant, phase)
+            for k in range(n):
+                o = lead + k * stride
+                assert int(lens[k]) == len(want[k]) and host[o:o + len(want[k])].tobytes() == want[k], (mode, variant, phase, k)
+                assert host[o + len(want[k])] == 0 and (host[o + len(want[k]) + 1:o + stride] == 0xEE).all(), (mode, variant, phase, k)
+            assert (host[lead + n * stride:] == 0xEE).all(), (mode, variant, phase)
+        plan.close()
+
+
 @pytest.mark.parametrize("mode", [m for m in ALL_MODES if m != MODE_TRUE_BG],
                          ids=[MODE_NAMES[m] for m in ALL_MODES if m != MODE_TRUE_BG])
 def test_aspect_and_padding(gpu, mode):

@@ -546,3 +546,27 @@ def test_rows_kernel_fused_frame_crc(mode):
     got, crc, hdr, pkt = emu.render_frames_crc(mode, [frames[0]], orc.PALETTE_STANDARD, 28, stride=256, dims=[(80, 24)])
     eh, ep = orc.ascii_frame_packet(b"", 0, 0)
     assert got[0] == 0xFFFFFFFF and crc[0] == 0 and hdr[0] == eh and pkt[0] == ep
+
+
+@pytest.mark.parametrize("phase", range(8))
+def test_drains_follow_the_line_boundaries_of_the_address(phase):
+    """Round 4: every kernel's drain maps lanes to 16-byte groups from a 128-byte LINE boundary of the slot's ADDRESS (whole
+    lines per store instruction), the rows kernel carries the bytes behind a slice's last whole line to the block's next
+    slice, and the phase kernel's carry is moved by whichever thread drained group 0.  Slabs that start at each of the
+    eight 16-byte phases of a line, with strides that walk the slots through the other phases: the oracle's bytes, and not
+    one byte outside the frames."""
+    imgs = [orc.frame_hash_noise(120, 90, i) for i in range(2)] + [run_frames(160, 90, "blocks"), TORTURE]
+    for (mode, variant, dims) in [
+            (MODE_TRUE_FG, 17, [(80, 24), (97, 31), (3, 2), (200, 60)]), (MODE_256_FG, 16, [(80, 24), (61, 7), (1, 1), (130, 9)]),
+            (MODE_HB_TRUE, 25, [(80, 24), (60, 7), (33, 40), (100, 50)]), (MODE_HB_TRUE, 24, [(440, 3), (97, 31), (5, 60), (300, 9)]),
+            (MODE_MONO, 28, [(100, 9), (37, 11), (128, 4), (80, 24)]), (MODE_HB_256, 24, [(400, 12), (80, 24), (7, 3), (250, 6)]),
+            (MODE_HB_TRUE, 4, [(80, 24), (97, 31), (460, 5), (10, 150)]), (MODE_MONO, 3, [(80, 24), (97, 31), (120, 20), (1, 130)]),
+            (MODE_TRUE_FG, 2, [(80, 24), (130, 1), (64, 65), (200, 60)])]:
+        rm = MODE_CAPS.get(mode, (3, 0))[1]
+        frames = [emu.frame_for_convert(im, w, h, rm) for im, (w, h) in zip(imgs, dims)]
+        bound = max(len(oracle_convert(im, mode, w, h, orc.PALETTE_STANDARD)) for im, (w, h) in zip(imgs, dims))
+        for extra in (16, 48, 112):  # the stride's own phase: slots 1.. start at other phases than slot 0
+            stride = (bound + 1 + 15) // 16 * 16 + 2048 + extra
+            got = emu.render_frames(mode, frames, orc.PALETTE_STANDARD, variant, stride=stride, line_phase=phase)
+            for k, (im, (w, h)) in enumerate(zip(imgs, dims)):
+                assert got[k] == oracle_convert(im, mode, w, h, orc.PALETTE_STANDARD), (mode, variant, k, phase, extra)
