@@ -6,7 +6,7 @@
 // non-temporal stores -- from one workgroup per frame, four launches in flight, a fresh set of frames every launch
 // (sets far beyond the 256 MB Infinity Cache), and reports TB/s.  Forms: rows + frames (the render's mix), rows only,
 // frames only.
-// Build: hipcc --offload-arch=gfx950 -O3 scripts/ubench/rows_floor.hip -o scripts/ubench/rows_floor
+// Build: hipcc --offload-arch=gfx950 -O3 -Wno-unused-result scripts/ubench/rows_floor.hip -o scripts/ubench/rows_floor
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdint>
@@ -43,7 +43,8 @@ __global__ void __launch_bounds__(THREADS)
       }
     }
     if (form & 2) {
-      const int v0 = (int)((long long)out_v * r0 / rows), v1 = (int)((long long)out_v * r1 / rows);
+      // (shares cut at 128-byte lines: a wave's 1 KB store that straddles lines costs a quarter of the write rate, below)
+      const int v0 = (int)((long long)out_v * r0 / rows) & ~7, v1 = r1 == rows ? out_v : (int)((long long)out_v * r1 / rows) & ~7;
       const u4 val = {(uint32_t)r0, (uint32_t)tid, (uint32_t)f, 0x20202020u};
       for (int v = v0 + tid; v < v1; v += THREADS)
         __builtin_nontemporal_store(val, reinterpret_cast<u4 *>(o) + v);
