@@ -300,7 +300,10 @@ static int plan_measure(asciichat_hip_plan_t *p, const achip_frame_t *frames) {
     if (f->pad_left + f->out_w > max_wp)
       max_wp = f->pad_left + f->out_w;
   }
-  stride = (stride + 15) & ~(size_t)15;
+  /* a multiple of the 128-byte line: in a line-aligned slab every slot starts on a line, so the drains' whole-line
+   * stores and the wire stage's 16-byte groups (thread t <-> group t) never straddle one (profiles/r04_rows_floor.txt:
+   * 4.4 vs 5.7 TB/s on the write side).  Callers may pass any multiple of 16 >= this: the kernels follow the address. */
+  stride = (stride + 127) & ~(size_t)127;
   if (stride > 0xFFFFFFF0u)
     return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame output bound exceeds 4 GiB");
   q.stride = stride;

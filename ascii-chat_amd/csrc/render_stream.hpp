@@ -962,8 +962,12 @@ __global__ void __launch_bounds__(WAVES * 64)
     static_assert(WAVES > CRCW && WAVES >= 2, "waves left for the copy and the header's share");
     if (tid >= CB && fits && off + room <= pack.capacity) {
       uint8_t *to = pack.dst + off;
-      for (uint32_t g = (uint32_t)(tid - CB); g < room / 16u; g += BLOCK - CB)
-        store_out16(to + 16u * g, from[g]);
+      /* (frames land at 16-byte granularity: thread t takes the group t groups behind a LINE boundary of the address, so
+       * that every wave's store covers whole 128-byte lines; at most seven threads sit out the first trip) */
+      const uint32_t shift = (uint32_t)((uintptr_t)to >> 4) & ((ACHIP_DRAIN_ALIGN >> 4) - 1u);
+      for (uint32_t a = (uint32_t)(tid - CB); a < room / 16u + shift; a += BLOCK - CB)
+        if (a >= shift)
+          store_out16(to + 16u * (a - shift), from[a - shift]);
     }
     if (PACK == 2) {
       /* ---- the frame's CRC-32C from its LDS image: thread t < CB folds groups t, t + CB, ... Horner-style (zero groups

@@ -190,14 +190,24 @@ __global__ void __launch_bounds__(256)
   const uint32_t g0 = blockIdx.y * per, g1 = min(groups, g0 + per);
   const uint4 *src4 = reinterpret_cast<const uint4 *>(slab + (uint64_t)i * stride);
   uint4 *dst4 = reinterpret_cast<uint4 *>(dst + off);
-  uint32_t g = g0 + (uint32_t)tid;
-  for (; g + 256u < g1; g += 512u) { /* two groups per trip: both loads in flight */
-    const uint4 a = src4[g], b = src4[g + 256u];
-    dst4[g] = a;
-    dst4[g + 256u] = b;
+  /* thread t takes the group that lies t groups behind a 128-byte line boundary of the DESTINATION address (frames are
+   * packed at 16-byte granularity: without this every wave's 1 KB store would straddle lines, which the memory side
+   * takes a quarter slower: profiles/r04_rows_floor.txt); at most seven threads sit out the first trip */
+  const uint32_t shift = (uint32_t)((uintptr_t)dst4 >> 4) & 7u;
+  uint32_t a = ((g0 + shift) & ~7u) + (uint32_t)tid; /* group index + shift */
+  for (; a + 256u < g1 + shift; a += 512u) { /* two groups per trip: both loads in flight */
+    const uint32_t g = a - shift;            /* (wraps below zero only where a < g0 + shift: skipped) */
+    const bool first = a >= g0 + shift;
+    uint4 x = make_uint4(0u, 0u, 0u, 0u);
+    if (first)
+      x = src4[g];
+    const uint4 y = src4[g + 256u];
+    if (first)
+      dst4[g] = x;
+    dst4[g + 256u] = y;
   }
-  if (g < g1)
-    dst4[g] = src4[g];
+  if (a >= g0 + shift && a < g1 + shift)
+    dst4[a - shift] = src4[a - shift];
 }
 
 
