@@ -650,14 +650,25 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
     }
   }
   const bool one_block_per_wave = cell_mode && split_request == 0 && max_cells <= 16 * (128 - ghost);
-  if (forced_variant < 0 && cell_mode && (!may_split || max_wp > variant_caps[0] || one_block_per_wave) &&
+  /* (round 4 audit: from half a frame per CU on, frames of at most three blocks per wave of the sixteen-wave geometry go
+   * whole too -- 128 frames of 120x40, one launch at a time: 12.9 us whole against 16.8 as three bands each) */
+  const bool few_blocks = cell_mode && split_request == 0 && max_cells <= 3 * 16 * (128 - ghost) && 2 * n_frames >= n_cus;
+  if (forced_variant < 0 && cell_mode && (!may_split || max_wp > variant_caps[0] || one_block_per_wave || few_blocks) &&
       max_cells <= (long)ACHIP_HOST_STREAM_MAXBLK * (128 - ghost)) {
     /* measured (profiles/r02_stream_sweep.txt): 1024 threads x 2 cells -- one block per wave for a 1080p -> 80x24
      * frame -- is the shortest single launch while every frame has a CU to itself; with more frames than CUs in
      * flight (a large batch, or several launches kept in flight: the caller passes its share of the CUs), or frames
      * of several blocks per wave, 512-thread workgroups pack better (four launches in flight, us per step, 16 vs 17: 1080p -> 80x24 truecolor
      * 10.9 vs 8.2, ANSI-256 7.0 vs 6.6, 4K -> 200x60 equal within noise) */
-    *variant = (max_cells <= 16 * (128 - ghost) && n_frames <= n_cus) ? 16 : 17;
+    /* round 4 audit (scripts/gpu_policy_audit.py, profiles/r04_policy_audit.txt: six terminal sizes x five batch sizes x
+     * four modes, every geometry forced in turn): the rule is the FRAMES PER CU, not the blocks per wave -- with at most a
+     * frame per CU of the plan's share a CU holds ONE workgroup either way, and sixteen waves fill it better than eight
+     * however many blocks each walks (256 frames, one launch at a time: 120x40 truecolor 17.3 vs 22.3 us, 200x60 34.1 vs
+     * 43.4, 320x90 71.7 vs 94.2; 64 frames with four launches in flight: 20.9 vs 26.1 at 200x60); above that two
+     * 512-thread workgroups share a CU and win or tie (256 frames, four in flight: 35.7 vs 36.9 at 200x60). */
+    /* (up to TWO frames per CU: 128 frames at a share of 64 CUs, 200x60: 23.5 vs 29.6 us; at three they tie, at four
+     * the 512-thread workgroups win by 3-10 %) */
+    *variant = n_frames <= 2 * n_cus ? 16 : 17;
     return 0;
   }
   /* (the coloured half-block modes only from a frame per four CUs on: their tokens are long -- two SGRs and a three-byte glyph
@@ -679,7 +690,15 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
      * of at most a frame per CU stays with the phase kernel's sixteen. */
     const int used4 = max_wp <= 256 ? (256 / max_wp) * max_wp : 0, used7 = (448 / max_wp) * max_wp;
     const int v = used4 * 448 >= used7 * 256 ? 25 : 24;
-    if ((v == 25 || n_frames > n_cus) && achip_uniform_extent(mode, v, frames, n_frames) <= ACHIP_HOST_STREAM_MAXBLK) {
+    /* (round 4 audit: the coloured half-block modes at no more than a frame per CU only while a wave has ONE block --
+     * 256 frames of 120x40, one launch at a time: 42.9 us against the phase kernel's 37.5, 238x70 104 against 95; 80x24,
+     * four blocks a frame, 21.2 against 23.1.  Mono keeps the rows kernel: 238x70 47 against 52.) */
+    const int ext = achip_uniform_extent(mode, v, frames, n_frames);
+    /* (... and up to two frames per CU the phase kernel stays ahead for them: 128 frames of 200x60 at a share of 64 CUs
+     * 43.8 against 50.3; mono rows wider than the four-slot geometry take the seven-slot one at any count: 256 frames of
+     * 320x90 79 against 88) */
+    if ((v == 25 || n_frames > n_cus || (short_tokens && max_wp > 256)) && ext <= ACHIP_HOST_STREAM_MAXBLK &&
+        (short_tokens || n_frames > 2 * n_cus || ext <= 8)) {
       *variant = v;
       return 0;
     }

@@ -64,7 +64,7 @@ int asciichat_hip_plan_create(asciichat_hip_plan_t **plan, int mode, const char 
 /* Replace the frame descriptors (e.g. new source pointers for the next tick); same n_frames. */
 int asciichat_hip_plan_update(asciichat_hip_plan_t *plan, const achip_frame_t *frames, void *stream);
 
-/* Bytes each frame needs in the output slab (worst case incl. NUL, multiple of 16). */
+/* Bytes each frame needs in the output slab (worst case incl. NUL, a multiple of 128: slots of a line-aligned slab start on lines; any multiple of 16 >= this may be passed to the render calls). */
 size_t asciichat_hip_plan_out_stride(const asciichat_hip_plan_t *plan);
 
 /* Kernel geometry: -1 = automatic (by widest padded row), else a variant id from render_variants.h. */

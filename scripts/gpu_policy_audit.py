@@ -1,0 +1,132 @@
+#!/usr/bin/env python3
+"""Policy audit: does achip_choose_geometry pick the fastest geometry away from the five BASELINE shapes?  For a grid of
+terminal sizes x batch sizes x modes (1080p sources; typical terminals, not only 80x24 / 200x60 / 400x120) every geometry
+that can carry the plan is forced in turn -- whole frames on the stream / rows / phase kernels, row bands of the phase kernel
+-- and timed like the automatic choice: HIP events over back-to-back launches on ONE stream (what a lone server tick is) and,
+with --inflight, over four streams (what a saturated server is).  Every forced geometry's frames are compared with the
+automatic choice's on the GPU (all kernels must agree byte for byte; the automatic choice's first frame is checked against
+the oracle).  Prints one line per case: the automatic choice, the best, the regret.  GPU box only.
+usage: gpu_policy_audit.py [--inflight] [--quick]"""
+import os
+import statistics
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+import orc  # noqa: E402
+from __graft_entry__ import load_package  # noqa: E402
+
+pkg = load_package()
+L = pkg.lib()
+torch.cuda.set_device(0)
+INFLIGHT = "--inflight" in sys.argv
+QUICK = "--quick" in sys.argv
+streams = [torch.cuda.Stream() for _ in range(4)] if INFLIGHT else [torch.cuda.current_stream()]
+
+
+def time_plan(plans, n, stride, reps):
+    outs = [torch.empty(n * stride, dtype=torch.uint8, device="cuda") for _ in plans]
+    lns = [torch.zeros(n, dtype=torch.int32, device="cuda") for _ in plans]
+
+    def burst(k):
+        for j in range(k):
+            i = j % len(plans)
+            plans[i].render(outs[i].data_ptr(), stride, lns[i].data_ptr(), streams[i].cuda_stream)
+
+    burst(2 * len(plans))
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if len(plans) == 1:
+            burst(1)
+            e0.record(streams[0])
+            burst(reps)
+            e1.record(streams[0])
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) / reps * 1e3)
+        else:  # wall clock over the burst: the streams' events do not order across streams
+            import time
+            t0 = time.perf_counter()
+            burst(reps)
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) / reps * 1e6)
+    return statistics.median(ts), outs[0], lns[0]
+
+
+MODES = [(0, "mono", 0, 0), (2, "ansi256", 2, 0), (1, "truecolor", 3, 0), (5, "hb_true", 3, 2)]
+SIZES = [(80, 24), (120, 40), (160, 45), (200, 60), (238, 70), (320, 90)]
+BATCHES = [1, 4, 16, 64, 128, 192, 256]
+if QUICK:
+    SIZES, BATCHES = [(120, 40), (200, 60)], [1, 16, 256]
+SRC_W, SRC_H = 1920, 1080
+frames_t = bench.make_frames(torch, 256, SRC_W, SRC_H, 4242)
+host0 = np.ascontiguousarray(frames_t[0].cpu().numpy())
+regrets = []
+print(f"# 1080p sources, {'four streams in flight (wall clock)' if INFLIGHT else 'one stream, back to back (HIP events)'}; us per launch")
+for (mode, mname, cl, rm) in MODES:
+    cell = mode in (1, 2, 3, 4)
+    forced = ([("stream 16", 16, -1), ("stream 17", 17, -1), ("stream 18", 18, -1), ("stream 18 shared", 18, 0), ("stream 19", 19, -1)] if cell
+              else [("rows 25", 25, -1), ("rows 24", 24, -1)])
+    forced += [("phase 4 whole", 4, -1), ("phase 4 bands", 4, 0), ("phase 1 whole", 1, -1), ("phase 0 whole", 0, -1), ("phase 0 bands", 0, 0)]
+    for (W, H) in SIZES:
+        for n in BATCHES:
+            descs = [pkg.frame_setup(frames_t[k].data_ptr(), SRC_W, SRC_H, W, H, rm, False, False, False) for k in range(n)]
+            bytes_per_frame = W * H * (41 if mode == 5 else 20)
+            reps = max(8, min(300, int(4e8 / max(1, bytes_per_frame * n) / 50)))
+            res = []
+            ref = None
+            for (label, variant, split) in [("automatic", -1, None)] + forced:
+                plans = []
+                try:
+                    for _ in streams:
+                        p = pkg.Plan(mode, bench.PALETTE_STANDARD, descs)
+                        plans.append(p)
+                        if INFLIGHT:
+                            p.set_concurrency(len(streams))  # the caller's hint: this plan shares the GPU with three more
+                        if split is not None:
+                            p.set_split(split)
+                        if variant >= 0:
+                            p.set_variant(variant)
+                except RuntimeError:
+                    for p in plans:
+                        p.close()
+                    continue
+                stride = plans[0].stride
+                t, out, ln = time_plan(plans, n, stride, reps)
+                lens = ln.cpu().numpy().astype("uint32")
+                if not (lens < 0xFFFFFFF0).all():
+                    for p in plans:
+                        p.close()
+                    continue
+                view = out.view(n, stride)
+                if ref is None:
+                    ref = (view.clone(), lens.copy())
+                    exp = orc.convert_with_caps(host0, W, H, cl, rm, False, False, False)
+                    assert view[0, :int(lens[0])].cpu().numpy().tobytes() == exp, (mname, W, H, n, "automatic choice differs from the oracle")
+                    label = f"automatic = v{plans[0].variant} parts {plans[0].parts}"
+                else:
+                    assert (lens == ref[1]).all(), (mname, W, H, n, label, "lengths differ")
+                    m = int(lens.max())
+                    idx = torch.arange(m, device="cuda")[None, :] < torch.from_numpy(lens.astype("int64")).cuda()[:, None]
+                    assert bool(((view[:, :m] == ref[0][:, :m]) | ~idx).all()), (mname, W, H, n, label, "bytes differ from the automatic choice's")
+                res.append((t, label, plans[0].variant, plans[0].parts))
+                for p in plans:
+                    p.close()
+            auto = res[0]
+            best = min(res, key=lambda r: r[0])
+            regret = auto[0] / best[0] - 1.0
+            regrets.append((regret, mname, W, H, n, auto, best))
+            flag = "  <-- REGRET" if regret > 0.08 and auto[0] - best[0] > 0.4 else ""
+            print(f"{mname:10s} {W:3d}x{H:<3d} batch {n:3d}: {auto[1]:28s} {auto[0]:8.2f} | best {best[1]:16s} {best[0]:8.2f} (+{100 * regret:5.1f} %){flag}   all: "
+                  + " ".join(f"{r[1].split(' = ')[0]}={r[0]:.1f}" for r in res[1:]), flush=True)
+worst = sorted(regrets, key=lambda r: -r[0])[:10]
+print("# ten largest regrets")
+for (regret, mname, W, H, n, auto, best) in worst:
+    print(f"#   {mname} {W}x{H} batch {n}: automatic {auto[0]:.2f} us, {best[1]} {best[0]:.2f} us (+{100 * regret:.1f} %)")
