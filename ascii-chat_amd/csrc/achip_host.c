@@ -605,8 +605,12 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
     return 0; /* whole frames only */
   }
   /* automatic: whenever whole frames are launched anyway (the split policy below decides that first) */
+  /* automatic splitting only when whole frames would leave CUs idle: below 3/4 frame per CU -- the half-block modes below
+   * half a frame per CU (round 4 audit: 128 frames of 120x40, one launch at a time: mono half blocks 23.9 us in three
+   * bands each against 19.8 whole, 256 colours 29.3 against 26.8; 64 frames: 14.0 against 28.4 the other way) */
+  const bool whole_auto = split_request == 0 && (4 * n_frames >= 3 * n_cus || (hb && 2 * n_frames >= n_cus));
   const bool may_split = mode != ACHIP_MODE_16_DITHER_BG && !(mode == ACHIP_MODE_TRUE_FG && !palette_ascii_only) &&
-                         split_request >= 0 && max_rows > 1 && !(split_request == 0 && 4 * n_frames >= 3 * n_cus);
+                         split_request >= 0 && max_rows > 1 && !whole_auto;
   /* frames small enough for ONE block per wave of a wave-autonomous geometry are never cut into row bands, however few
    * they are: a lone 80x24 frame takes 6.3 us through stream geometry 16 against 8.4 us as 24 bands of the phase kernel
    * whose workgroups hand their offsets to each other through global memory, a lone mono frame 7.0 against 8.1 us through
@@ -694,11 +698,12 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
      * 256 frames of 120x40, one launch at a time: 42.9 us against the phase kernel's 37.5, 238x70 104 against 95; 80x24,
      * four blocks a frame, 21.2 against 23.1.  Mono keeps the rows kernel: 238x70 47 against 52.) */
     const int ext = achip_uniform_extent(mode, v, frames, n_frames);
-    /* (... and up to two frames per CU the phase kernel stays ahead for them: 128 frames of 200x60 at a share of 64 CUs
-     * 43.8 against 50.3; mono rows wider than the four-slot geometry take the seven-slot one at any count: 256 frames of
-     * 320x90 79 against 88) */
-    if ((v == 25 || n_frames > n_cus || (short_tokens && max_wp > 256)) && ext <= ACHIP_HOST_STREAM_MAXBLK &&
-        (short_tokens || n_frames > 2 * n_cus || ext <= 8)) {
+    /* (... the half-block mono mode as well: 256 frames of 238x70 64 against 53; above a frame per CU the rows kernel
+     * wins for all of them -- 4K -> 400x120, 128 frames at a share of 64 CUs, bench.py's schedule: 108 against 118;
+     * mono rows wider than the four-slot geometry take the seven-slot one at any count: 256 frames of 320x90 79 against 88) */
+    const bool mono = mode == ACHIP_MODE_MONO;
+    if ((v == 25 || n_frames > n_cus || (mono && max_wp > 256)) && ext <= ACHIP_HOST_STREAM_MAXBLK &&
+        (mono || n_frames > n_cus || ext <= 8)) {
       *variant = v;
       return 0;
     }
@@ -723,7 +728,7 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
    * idle (fewer than 3/4 frame per CU): at one frame per CU and above it costs more than it gains. */
   const bool splittable = mode != ACHIP_MODE_16_DITHER_BG && !(mode == ACHIP_MODE_TRUE_FG && !palette_ascii_only) &&
                           split_request >= 0 && max_rows > 1;
-  if (!splittable || (split_request == 0 && 4 * n_frames >= 3 * n_cus))
+  if (!splittable || whole_auto)
     return 0;
   if (forced_variant >= 0 && forced_variant != 1 && forced_variant != 2 && forced_variant != 4)
     return 0; /* row-band kernels exist for the geometries this policy picks (render_inst.hip: HAS_SPLIT) */

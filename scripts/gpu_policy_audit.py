@@ -6,7 +6,7 @@ that can carry the plan is forced in turn -- whole frames on the stream / rows /
 with --inflight, over four streams (what a saturated server is).  Every forced geometry's frames are compared with the
 automatic choice's on the GPU (all kernels must agree byte for byte; the automatic choice's first frame is checked against
 the oracle).  Prints one line per case: the automatic choice, the best, the regret.  GPU box only.
-usage: gpu_policy_audit.py [--inflight] [--quick]"""
+usage: gpu_policy_audit.py [--inflight] [--quick] [--other-modes] [--4k]"""
 import os
 import statistics
 import sys
@@ -61,15 +61,19 @@ def time_plan(plans, n, stride, reps):
 
 
 MODES = [(0, "mono", 0, 0), (2, "ansi256", 2, 0), (1, "truecolor", 3, 0), (5, "hb_true", 3, 2)]
+if "--other-modes" in sys.argv:  # the rest of the dispatcher's table (ascii.c:955-1002)
+    MODES = [(3, "ansi16", 1, 0), (6, "hb_256", 2, 2), (7, "hb_16", 1, 2), (8, "hb_mono", 0, 2)]
 SIZES = [(80, 24), (120, 40), (160, 45), (200, 60), (238, 70), (320, 90)]
 BATCHES = [1, 4, 16, 64, 128, 192, 256]
 if QUICK:
     SIZES, BATCHES = [(120, 40), (200, 60)], [1, 16, 256]
-SRC_W, SRC_H = 1920, 1080
+SRC_W, SRC_H = (3840, 2160) if "--4k" in sys.argv else (1920, 1080)
+if "--4k" in sys.argv:
+    SIZES = [(200, 60), (320, 90), (400, 120)]
 frames_t = bench.make_frames(torch, 256, SRC_W, SRC_H, 4242)
 host0 = np.ascontiguousarray(frames_t[0].cpu().numpy())
 regrets = []
-print(f"# 1080p sources, {'four streams in flight (wall clock)' if INFLIGHT else 'one stream, back to back (HIP events)'}; us per launch")
+print(f"# {SRC_W}x{SRC_H} sources, {'four streams in flight (wall clock)' if INFLIGHT else 'one stream, back to back (HIP events)'}; us per launch")
 for (mode, mname, cl, rm) in MODES:
     cell = mode in (1, 2, 3, 4)
     forced = ([("stream 16", 16, -1), ("stream 17", 17, -1), ("stream 18", 18, -1), ("stream 18 shared", 18, 0), ("stream 19", 19, -1)] if cell
