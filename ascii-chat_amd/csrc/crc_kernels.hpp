@@ -281,8 +281,15 @@ __global__ void __launch_bounds__(256)
 /* One 64-thread workgroup per frame combines the span registers.  Register q of the frame is followed by
  * parts-1-q spans: 64 at a time, tree-combined with powers of cspan = x^(8*span); the surplus zero bytes
  * parts*span - len are divided out (xinv_v = x^(-8*parts*span) from the host; x is invertible mod P). */
+/* cspan^(2^k), k = 0..6 (cspan = x^(8 * span bytes)): launch constants, computed on the host -- squaring them here was
+ * twelve bit-serial multiplications in front of everything else the one wave does (round 4: the finish kernel's chain was
+ * most of the 31 us this path cost however little it checksummed) */
+struct CrcSpanPows {
+  uint32_t c[7];
+};
+
 __global__ void __launch_bounds__(64)
-    crc32c_finish_kernel(const uint32_t *__restrict__ partial, int parts, uint32_t cspan, uint32_t xinv_v,
+    crc32c_finish_kernel(const uint32_t *__restrict__ partial, int parts, CrcSpanPows cp, uint32_t xinv_v,
                          const uint32_t *__restrict__ len, uint32_t fixed_len, int n_frames,
                          const uint32_t *__restrict__ dims, uint32_t *__restrict__ crc_out, uint8_t *__restrict__ hdr_out,
                          uint32_t *__restrict__ pkt_crc_out) {
@@ -294,23 +301,21 @@ __global__ void __launch_bounds__(64)
   const bool bad = L >= 0xFFFFFFF0u;
   if (bad)
     L = 0;
-  uint32_t c64 = cspan; /* cspan^64 */
-  for (int k = 0; k < 6; k++)
-    c64 = crc_mulmod(c64, c64);
+  const uint32_t c64 = cp.c[6]; /* cspan^64 */
   uint32_t acc = 0;
   const int lead = (64 - parts % 64) % 64; /* zero registers in front keep every batch of 64 full */
   for (int q0 = -lead; q0 < parts; q0 += 64) {
     const int q = q0 + tid;
     tree[tid] = q >= 0 ? partial[(size_t)i * parts + q] : 0u;
     __syncthreads();
-    uint32_t cx = cspan;
-    for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      const int d = 1 << k;
       if ((tid & (2 * d - 1)) == 0)
-        tree[tid] = crc_mulmod(tree[tid], cx) ^ tree[tid + d];
-      cx = crc_mulmod(cx, cx);
+        tree[tid] = crc_mulmod(tree[tid], cp.c[k]) ^ tree[tid + d];
       __syncthreads();
     }
-    acc = crc_mulmod(acc, c64) ^ tree[0];
+    acc = (acc ? crc_mulmod(acc, c64) : 0u) ^ tree[0];
     __syncthreads();
   }
   if (tid == 0) {

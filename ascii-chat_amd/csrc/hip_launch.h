@@ -67,9 +67,9 @@ int achip_launch_scatter_rows_batch(const uint8_t *staged_dev, uint32_t n_client
 
 /* wire stage (crc_kernels.hpp): CRC-32C of n buffers at base + i*stride (len_dev[i] bytes, or fixed_len when
  * len_dev == NULL; every length <= max_len) and, when hdr_out != NULL, the 24-byte ascii_frame_packet_t headers
- * (dims_dev = n x {width, height}) and the CRC of header || frame.  partial: n * achip_crc_parts(max_len) u32 of
- * device scratch, unused (may be NULL) when achip_crc_parts(max_len) == 1. */
-int achip_crc_parts(uint32_t max_len);
+ * (dims_dev = n x {width, height}) and the CRC of header || frame.  partial: n * achip_crc_parts(max_len, n) u32 of
+ * device scratch, unused (may be NULL) when achip_crc_parts(max_len, n) == 1. */
+int achip_crc_parts(uint32_t max_len, int n);
 int achip_launch_crc32c(const uint8_t *base, uint64_t stride, const uint32_t *len_dev, uint32_t fixed_len,
                         uint32_t max_len, int n, uint32_t *partial, const uint32_t *dims_dev, uint32_t *crc_out,
                         uint8_t *hdr_out, uint32_t *pkt_crc_out, void *stream);

@@ -7,6 +7,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <mutex>
 
 #include "render_inst.h"
@@ -319,8 +320,28 @@ extern "C" int achip_launch_pack(const uint8_t *slab, uint64_t stride, const uin
 /* CRC-32C of n buffers + optional wire headers (crc_kernels.hpp).  Buffers up to 128 KB are checksummed by one
  * workgroup each, which also finishes them; larger ones are cut into 64 KB spans and finished by a second
  * kernel, which needs `partial` = n * achip_crc_parts(max_len) u32 of device scratch. */
-extern "C" int achip_crc_parts(uint32_t max_len) {
-  return max_len <= 32u * 4096u ? 1 : (int)(((uint64_t)max_len + 65535u) / 65536u);
+extern "C" int achip_crc_parts(uint32_t max_len, int n) {
+  /* ASCIICHAT_HIP_CRC_FRAME_MAX (diagnostics, read once): buffers up to this many bytes take the one-workgroup kernel */
+  static long forced = -1;
+  if (forced < 0) {
+    const char *e = getenv("ASCIICHAT_HIP_CRC_FRAME_MAX");
+    forced = e && e[0] ? atol(e) : 0;
+  }
+  const int spans = (int)(((uint64_t)max_len + 65535u) / 65536u);
+  if (forced > 0)
+    return max_len <= (uint32_t)forced ? 1 : spans;
+  if (max_len <= 32u * 4096u)
+    return 1;
+  /* above 128 KB, by measurement (scripts/gpu_crc_sweep.py, profiles/r04_wire_audit.txt; us, one call at a time): the
+   * one-workgroup kernel takes 4.5 + 58 per MB of the longest buffer, whatever the count up to a workgroup per CU (it is
+   * bound by its LDS look-ups: 256 KB 19, 1 MB 62, 1.8 MB 106-141); spans + the finish kernel take a fixed ~22 and 0.28
+   * per MB of ALL buffers (256 x 1.8 MB: 162).  Until this round every buffer above 128 KB went to the spans: a lone
+   * 200x60 truecolor frame's checksum cost 31 us behind a 7 us render. */
+  const uint64_t mb16 = ((uint64_t)max_len + 65535u) >> 16;                 /* longest buffer, in 64 KB          */
+  const uint64_t waves = ((uint64_t)(n > 0 ? n : 1) + 255u) / 256u;         /* rounds of a workgroup per CU     */
+  const uint64_t t_frame = 45u * 16u + 580u * mb16 * waves;                 /* 0.1 us * 16                      */
+  const uint64_t t_spans = 220u * 16u + 28u * mb16 * (uint64_t)(n > 0 ? n : 1) / 10u;
+  return t_frame <= t_spans ? 1 : spans;
 }
 
 /* the prebuilt tables of crc32c_frame_kernel<1024> (crc_math.hpp: crc_frame_tables_init_kernel), one image per device */
@@ -358,7 +379,7 @@ static hipError_t frame_crc_tables_1024(const uint4 **out) {
 static int launch_crc32c(const uint8_t *base, uint64_t stride, const uint32_t *len_dev, uint32_t fixed_len, uint32_t max_len,
                          int n, uint32_t *partial, const uint32_t *dims_dev, uint32_t *crc_out, uint8_t *hdr_out,
                          uint32_t *pkt_crc_out, const achip::CrcPack *pack, hipStream_t s) {
-  const int parts = achip_crc_parts(max_len);
+  const int parts = achip_crc_parts(max_len, n);
   if (parts == 1) { /* 1024 threads per frame; every workgroup runs only the rounds its own frame needs */
     const uint4 *tab = nullptr;
     const hipError_t te = frame_crc_tables_1024(&tab);
@@ -382,8 +403,12 @@ static int launch_crc32c(const uint8_t *base, uint64_t stride, const uint32_t *l
     hipLaunchKernelGGL(achip::crc32c_span_kernel<false>, dim3((unsigned)n * (unsigned)parts), dim3(256),
                        (size_t)achip::CrcLds::bytes, s, base, stride, len_dev, fixed_len, n, parts, rounds, partial,
                        achip::CrcPack{nullptr, 0, nullptr, nullptr});
-  hipLaunchKernelGGL(achip::crc32c_finish_kernel, dim3((unsigned)n), dim3(64), 256, s, partial, parts,
-                     achip::crc_pow(achip::CRC_X8, (uint64_t)rounds * 4096u), achip::crc_pow(achip::CRC_XINV8, v_bytes),
+  achip::CrcSpanPows cp;
+  cp.c[0] = achip::crc_pow(achip::CRC_X8, (uint64_t)rounds * 4096u);
+  for (int k = 1; k < 7; k++)
+    cp.c[k] = achip::crc_mulmod(cp.c[k - 1], cp.c[k - 1]);
+  hipLaunchKernelGGL(achip::crc32c_finish_kernel, dim3((unsigned)n), dim3(64), 256, s, partial, parts, cp,
+                     achip::crc_pow(achip::CRC_XINV8, v_bytes),
                      len_dev, fixed_len, n, dims_dev, crc_out, hdr_out, pkt_crc_out);
   return (int)hipGetLastError();
 }

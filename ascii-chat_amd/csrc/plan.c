@@ -226,6 +226,10 @@ struct asciichat_hip_plan {
   int frames_dma_queued;        /* a DMA out of frames_pinned may still be in flight on the stream of the last update */
   int exact_length;             /* -1 = the packed entry points are ONE launch wherever the plan qualifies (default), 0 = never */
   unsigned long long *pack_cursor; /* two device words of the PACK kernels, zero between launches (allocated on first use) */
+  uint32_t *crc_scratch;           /* span registers of the stand-alone checksum pass behind this plan (frames above 128 KB):
+                                      the plan's own block instead of a stream-ordered allocation per call -- hipMallocAsync +
+                                      hipFreeAsync cost ~25 us of host time per call, four times a small launch's render */
+  size_t crc_scratch_words;
   const void *pack_dst_seen;       /* the destination the automatic choice looked at last, and what it was */
   int pack_dst_host;
   const achip_lut_t *lut_dev;
@@ -532,6 +536,10 @@ int asciichat_hip_plan_render(asciichat_hip_plan_t *p, uint8_t *out_dev, size_t 
 /* Render + frame CRC-32C in one go ("a CRC over the output slab can ride the emit kernel").  Whole-frame
  * launches of the per-cell modes carry the checksum inside the stream kernel's drain; every other plan renders and
  * then runs the stand-alone CRC kernel on the slab -- same results either way. */
+static int plan_wire_pass(asciichat_hip_plan_t *p, const uint8_t *slab_dev, size_t out_stride, const uint32_t *out_len_dev,
+                          const uint32_t *dims_dev, uint32_t *crc_out_dev, uint8_t *hdr_out_dev, uint32_t *packet_crc_out_dev,
+                          uint8_t *dst, size_t dst_capacity, uint64_t *off_out, uint32_t *len_out, void *stream);
+
 static int plan_render_wire(asciichat_hip_plan_t *p, uint8_t *out_dev, size_t out_stride, uint32_t *out_len_dev,
                             const achip_wire_t *wire, unsigned long long *prof, void *stream) {
   if (!p || !out_dev || !out_len_dev || !wire->crc)
@@ -555,10 +563,8 @@ static int plan_render_wire(asciichat_hip_plan_t *p, uint8_t *out_dev, size_t ou
   }
   int rc = render_range(p, 0, p->n, out_dev, out_stride, out_len_dev, prof, stream);
   if (!rc)
-    rc = wire->hdr || wire->pkt_crc
-             ? asciichat_hip_frame_packets(out_dev, out_stride, out_len_dev, (uint32_t)out_stride, p->n, wire->dims, wire->crc,
-                                           wire->hdr, wire->pkt_crc, stream)
-             : asciichat_hip_crc32c(out_dev, out_stride, out_len_dev, 0, (uint32_t)out_stride, p->n, wire->crc, stream);
+    rc = plan_wire_pass(p, out_dev, out_stride, out_len_dev, wire->dims, wire->crc, wire->hdr, wire->pkt_crc, NULL, 0, NULL, NULL,
+                        stream);
   return rc;
 }
 
@@ -677,10 +683,13 @@ int asciichat_hip_plan_render_packets_packed(asciichat_hip_plan_t *p, uint8_t *s
       rc = asciichat_hip_pack_frames(slab_dev, out_stride, out_len_dev, p->n, dst, dst_capacity, off_out, len_out, stream);
     return rc;
   }
+  if (((uintptr_t)dst & 15u) || ((uintptr_t)off_out & 7u) || ((uintptr_t)len_out & 3u))
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM,
+                      "plan_render_packets_packed: a 16-byte aligned destination (8-byte aligned offsets, 4-byte aligned lengths) is required");
   int rc = asciichat_hip_plan_render(p, slab_dev, out_stride, out_len_dev, stream);
   if (!rc)
-    rc = asciichat_hip_frame_packets_packed(slab_dev, out_stride, out_len_dev, (uint32_t)out_stride, p->n, dims_dev, crc_out_dev,
-                                            hdr_out_dev, packet_crc_out_dev, dst, dst_capacity, off_out, len_out, stream);
+    rc = plan_wire_pass(p, slab_dev, out_stride, out_len_dev, dims_dev, crc_out_dev, hdr_out_dev, packet_crc_out_dev, dst,
+                        dst_capacity, off_out, len_out, stream);
   return rc;
 }
 
@@ -695,7 +704,15 @@ int asciichat_hip_plan_render_crc_profiled(asciichat_hip_plan_t *p, uint8_t *out
 int asciichat_hip_plan_has_fused_crc(const asciichat_hip_plan_t *p) {
   if (!p || !plan_frames_whole(p) || p->fused_crc == 0 || !achip_variant_has_crc(p->whole_variant))
     return 0;
-  return p->fused_crc > 0 || achip_variant_crc_pays(p->whole_variant);
+  if (p->fused_crc > 0)
+    return 1;
+  /* a plan whose plain render shares its frames out over workgroups (a small launch) would have to launch them WHOLE for the
+   * fused checksum -- one workgroup per frame: fine while a wave has one block (a lone 80x24 frame: 10.9 us fused against
+   * 13.2 for shared-out render + stand-alone pass), a multiple of the render beyond (a lone 200x60 truecolor frame 49 us
+   * fused, 320x90 116, against a 7 us render + a 19-26 us pass; scripts/gpu_wire_audit.py, profiles/r04_wire_audit.txt) */
+  if (p->parts > 1 && p->max_cells > 16 * 127)
+    return 0;
+  return achip_variant_crc_pays(p->whole_variant);
 }
 
 int asciichat_hip_plan_set_fused_crc(asciichat_hip_plan_t *p, int mode) {
@@ -891,6 +908,8 @@ void asciichat_hip_plan_destroy(asciichat_hip_plan_t *p) {
     (void)hipFree(p->part_sync);
   if (p->pack_cursor)
     (void)hipFree(p->pack_cursor);
+  if (p->crc_scratch)
+    (void)hipFree(p->crc_scratch);
   achip_lut_put(p->lut_dev);
   free(p);
 }
@@ -968,16 +987,16 @@ typedef struct {
 
 static int crc_common(const uint8_t *base_dev, size_t stride, const uint32_t *len_dev, uint32_t fixed_len,
                       uint32_t max_len, int n, const uint32_t *dims_dev, uint32_t *crc_out_dev, uint8_t *hdr_out_dev,
-                      uint32_t *packet_crc_out_dev, const crc_pack_t *pack, void *stream) {
+                      uint32_t *packet_crc_out_dev, const crc_pack_t *pack, uint32_t *own_scratch, void *stream) {
   if (!base_dev || !crc_out_dev || n <= 0 || ((uintptr_t)base_dev & 15u) || (stride & 15u) ||
       (len_dev ? max_len == 0 : fixed_len > max_len) || max_len >= 0xFFFFFFF0u || (n > 1 && stride < max_len))
     return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "crc32c: bad arguments");
   int rc = achip_require_device();
   if (rc)
     return rc;
-  const int parts = achip_crc_parts(max_len);
-  uint32_t *scratch = NULL;
-  if (parts > 1) {
+  const int parts = achip_crc_parts(max_len, n);
+  uint32_t *scratch = own_scratch; /* a plan's own block (n * parts words): launches of one plan are ordered on one stream */
+  if (parts > 1 && !scratch) {
     /* span registers of large buffers: STREAM-ORDERED scratch, so that calls in flight on different streams (the
      * plan API's normal use) never share a block (one thread-local block was shared by every stream) */
     rc = achip_hip_check((int)hipMallocAsync((void **)&scratch, (size_t)n * (size_t)parts * sizeof(uint32_t),
@@ -992,7 +1011,7 @@ static int crc_common(const uint8_t *base_dev, size_t stride, const uint32_t *le
                             : achip_launch_crc32c(base_dev, stride, len_dev, fixed_len, max_len, n, scratch, dims_dev,
                                                   crc_out_dev, hdr_out_dev, packet_crc_out_dev, stream),
                        "crc32c launch");
-  if (scratch) {
+  if (scratch && !own_scratch) {
     const int fr = achip_hip_check((int)hipFreeAsync(scratch, (hipStream_t)stream), "hipFreeAsync(crc scratch)");
     if (!rc)
       rc = fr;
@@ -1002,7 +1021,7 @@ static int crc_common(const uint8_t *base_dev, size_t stride, const uint32_t *le
 
 int asciichat_hip_crc32c(const uint8_t *base_dev, size_t stride, const uint32_t *len_dev, uint32_t fixed_len,
                          uint32_t max_len, int n, uint32_t *crc_out_dev, void *stream) {
-  return crc_common(base_dev, stride, len_dev, fixed_len, max_len, n, NULL, crc_out_dev, NULL, NULL, NULL, stream);
+  return crc_common(base_dev, stride, len_dev, fixed_len, max_len, n, NULL, crc_out_dev, NULL, NULL, NULL, NULL, stream);
 }
 
 int asciichat_hip_frame_packets(const uint8_t *base_dev, size_t stride, const uint32_t *len_dev, uint32_t max_len, int n,
@@ -1011,7 +1030,7 @@ int asciichat_hip_frame_packets(const uint8_t *base_dev, size_t stride, const ui
   if (!len_dev || !hdr_out_dev)
     return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame_packets: lengths and a header buffer are required");
   return crc_common(base_dev, stride, len_dev, 0, max_len, n, dims_dev, crc_out_dev, hdr_out_dev, packet_crc_out_dev, NULL,
-                    stream);
+                    NULL, stream);
 }
 
 /* the wire stage AND the compaction in one pass over the slab (crc_kernels.hpp COPY instantiations) */
@@ -1024,7 +1043,30 @@ int asciichat_hip_frame_packets_packed(const uint8_t *base_dev, size_t stride, c
                       "frame_packets_packed: lengths, a header buffer and a 16-byte aligned destination are required");
   const crc_pack_t pack = {dst, dst_capacity, off_out, len_out};
   return crc_common(base_dev, stride, len_dev, 0, max_len, n, dims_dev, crc_out_dev, hdr_out_dev, packet_crc_out_dev, &pack,
-                    stream);
+                    NULL, stream);
+}
+
+/* the stand-alone wire pass behind a plan's render (dst != NULL: + the compaction), with the plan's own span registers */
+static int plan_wire_pass(asciichat_hip_plan_t *p, const uint8_t *slab_dev, size_t out_stride, const uint32_t *out_len_dev,
+                          const uint32_t *dims_dev, uint32_t *crc_out_dev, uint8_t *hdr_out_dev, uint32_t *packet_crc_out_dev,
+                          uint8_t *dst, size_t dst_capacity, uint64_t *off_out, uint32_t *len_out, void *stream) {
+  if (packet_crc_out_dev && !hdr_out_dev)
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame_packets: lengths and a header buffer are required");
+  const int parts = out_stride < 0xFFFFFFF0u ? achip_crc_parts((uint32_t)out_stride, p->n) : 1;
+  const size_t words = parts > 1 ? (size_t)p->n * (size_t)parts : 0;
+  if (words > p->crc_scratch_words) {
+    if (p->crc_scratch)
+      (void)hipFree(p->crc_scratch); /* synchronises with a launch that still uses the old block */
+    p->crc_scratch = NULL;
+    p->crc_scratch_words = 0;
+    const int rc = achip_hip_check((int)hipMalloc((void **)&p->crc_scratch, words * sizeof(uint32_t)), "hipMalloc(crc scratch)");
+    if (rc)
+      return rc;
+    p->crc_scratch_words = words;
+  }
+  const crc_pack_t pack = {dst, dst_capacity, off_out, len_out};
+  return crc_common(slab_dev, out_stride, out_len_dev, 0, (uint32_t)out_stride, p->n, hdr_out_dev || packet_crc_out_dev ? dims_dev : NULL,
+                    crc_out_dev, hdr_out_dev, packet_crc_out_dev, dst ? &pack : NULL, words ? p->crc_scratch : NULL, stream);
 }
 
 /* ---- compacted output (lib/network/acip/server.c:190-222 ships frame_size bytes, not a stride) ------------- */
