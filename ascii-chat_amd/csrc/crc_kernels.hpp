@@ -204,7 +204,10 @@ template <bool COPY = false>
 __global__ void __launch_bounds__(256)
     crc32c_span_kernel(const uint8_t *__restrict__ base, uint64_t stride, const uint32_t *__restrict__ len,
                        uint32_t fixed_len, int n_frames, int parts, int rounds, uint32_t *__restrict__ partial,
-                       CrcPack pack = CrcPack{nullptr, 0, nullptr, nullptr}) {
+                       const uint4 *__restrict__ tab, CrcPack pack = CrcPack{nullptr, 0, nullptr, nullptr}) {
+  /* tab: the image of crc_frame_tables_init_kernel<256>; its first 20 KB (slicing tables + the Horner table of 256 threads)
+   * are copied into LDS -- building them here was a chain of fifteen dependent LDS round trips and four bit-serial
+   * multiplications in front of every workgroup's first load */
   constexpr int BLOCK = 256;
   uint32_t *slice = lds_ptr<uint32_t>(CrcLds::o_slice);
   uint32_t *mulh = lds_ptr<uint32_t>(CrcLds::o_mulh);
@@ -225,7 +228,10 @@ __global__ void __launch_bounds__(256)
   const uint64_t avail = lo < L ? (uint64_t)L - lo : 0u; /* bytes of the frame from the start of this span (may exceed the span) */
   if (COPY)
     crc_pack_offset_post<BLOCK>(len, fixed_len, n_frames, i, tid);
-  crc_build_tables<BLOCK>(slice, mulh, tid);
+  static_assert(CrcLds::o_slice == 0 && CrcLds::o_mulh == 16 * 1024, "the image's first 20 KB");
+  (void)slice, (void)mulh;
+  for (int k = tid; k < 20 * 1024 / 16; k += BLOCK)
+    lds_ptr<uint4>(CrcLds::o_slice)[k] = tab[k];
   __syncthreads();
   uint8_t *dstb = nullptr; /* COPY: where this span's groups go; stays NULL for a frame that does not fit */
   if (COPY) {
@@ -273,60 +279,82 @@ __global__ void __launch_bounds__(256)
       if (j0 + u < rounds)
         s = crc_mul_table(mulh, s) ^ crc_raw16(slice, d[u]);
   }
-  crc_tree<BLOCK>(tree, s, tid);
+  /* (one multiplication by the lane's constant, one xor reduction per wave, one wave folding the four wave registers, as the
+   * frame kernel: the barrier-fenced tree of eight bit-serial levels this replaces was ~5 us of every span) */
+  const uint32_t whole = crc_reduce_waves<BLOCK>(tree, s, tid, CRC_LANE_TAB.k[tid & 63], CRC_LANE_TAB.xk[tid & 63]);
   if (tid == 0)
-    partial[(size_t)i * parts + p] = tree[0];
+    partial[(size_t)i * parts + p] = whole;
 }
 
 /* One 64-thread workgroup per frame combines the span registers.  Register q of the frame is followed by
  * parts-1-q spans: 64 at a time, tree-combined with powers of cspan = x^(8*span); the surplus zero bytes
  * parts*span - len are divided out (xinv_v = x^(-8*parts*span) from the host; x is invertible mod P). */
-/* cspan^(2^k), k = 0..6 (cspan = x^(8 * span bytes)): launch constants, computed on the host -- squaring them here was
- * twelve bit-serial multiplications in front of everything else the one wave does (round 4: the finish kernel's chain was
- * most of the 31 us this path cost however little it checksummed) */
+/* Launch constants of the finish kernel, computed on the host (crc_span_pows): c[6] = cspan^64 and lane[t] = cspan^(63 - t),
+ * cspan = x^(8 * span bytes).  Squaring and multiplying them up on the device was a chain of bit-serial multiplications in
+ * front of everything else the one wave does. */
 struct CrcSpanPows {
-  uint32_t c[7];
+  uint32_t c[7];     /* cspan^(2^k) */
+  uint32_t lane[64]; /* cspan^(63 - t): what register t of a batch of 64 is followed by */
 };
+__host__ inline CrcSpanPows crc_span_pows(uint64_t span_bytes) {
+  CrcSpanPows cp;
+  cp.c[0] = crc_pow(CRC_X8, span_bytes);
+  for (int k = 1; k < 7; k++)
+    cp.c[k] = crc_mulmod(cp.c[k - 1], cp.c[k - 1]);
+  cp.lane[63] = crc_mulmod(0x80000000u, 0x80000000u); /* 1 (reflected: bit 31 is x^0) */
+  for (int t = 62; t >= 0; t--)
+    cp.lane[t] = crc_mulmod(cp.lane[t + 1], cp.c[0]);
+  return cp;
+}
 
+/* One WAVE per frame combines the span registers (round 4, session 2: by whole-wave arithmetic -- register q is multiplied by
+ * its lane's constant, one xor reduction per 64 registers, the closing multiplications, the header's share and the packet
+ * CRC wave-wide with the prebuilt tables, as crc32c_frame_kernel closes a frame; the one-thread chain of bit-serial
+ * multiplications and byte loops this replaces was most of the 26-31 us the span path cost however little it checksummed).
+ * Register q of the frame is followed by parts-1-q spans; the surplus zero bytes parts*span - len are divided out
+ * (xinv_v = x^(-8*parts*span) from the host; x is invertible mod P).  tab: the image of crc_frame_tables_init_kernel<256>. */
 __global__ void __launch_bounds__(64)
     crc32c_finish_kernel(const uint32_t *__restrict__ partial, int parts, CrcSpanPows cp, uint32_t xinv_v,
                          const uint32_t *__restrict__ len, uint32_t fixed_len, int n_frames,
                          const uint32_t *__restrict__ dims, uint32_t *__restrict__ crc_out, uint8_t *__restrict__ hdr_out,
-                         uint32_t *__restrict__ pkt_crc_out) {
-  uint32_t *tree = lds_ptr<uint32_t>(0);
-  const int i = (int)blockIdx.x, tid = (int)threadIdx.x;
+                         uint32_t *__restrict__ pkt_crc_out, const uint4 *__restrict__ tab) {
+  const uint32_t *slice = lds_ptr<const uint32_t>(CrcLds::o_slice);
+  const uint32_t *powtab = lds_ptr<const uint32_t>(CrcLds::o_powtab);
+  const int i = (int)blockIdx.x, lane = (int)threadIdx.x;
   if (i >= n_frames)
     return;
+  for (int k = lane; k < ACHIP_FRAME_CRC_TAB_BYTES / 16; k += 64)
+    lds_ptr<uint4>(CrcLds::o_slice)[k] = tab[k];
+  const uint32_t lane_xk = CRC_LANE_TAB.xk[lane], lane_pow = cp.lane[lane];
   uint32_t L = len ? len[i] : fixed_len;
   const bool bad = L >= 0xFFFFFFF0u;
   if (bad)
     L = 0;
-  const uint32_t c64 = cp.c[6]; /* cspan^64 */
+  const uint32_t w = dims && !bad ? dims[2 * i] : 0u, h = dims && !bad ? dims[2 * i + 1] : 0u;
   uint32_t acc = 0;
   const int lead = (64 - parts % 64) % 64; /* zero registers in front keep every batch of 64 full */
   for (int q0 = -lead; q0 < parts; q0 += 64) {
-    const int q = q0 + tid;
-    tree[tid] = q >= 0 ? partial[(size_t)i * parts + q] : 0u;
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-      const int d = 1 << k;
-      if ((tid & (2 * d - 1)) == 0)
-        tree[tid] = crc_mulmod(tree[tid], cp.c[k]) ^ tree[tid + d];
-      __syncthreads();
-    }
-    acc = (acc ? crc_mulmod(acc, c64) : 0u) ^ tree[0];
-    __syncthreads();
+    const int q = q0 + lane;
+    const uint32_t v = q >= 0 ? partial[(size_t)i * parts + q] : 0u;
+    const uint32_t batch = wave_xor_all(crc_mulmod(v, lane_pow));
+    acc = (q0 > -lead ? wave_mulmod_uniform(acc, cp.c[6], lane, lane_xk) : 0u) ^ batch;
   }
-  if (tid == 0) {
-    const uint32_t xl = crc_x8_pow_len(L);
-    const uint32_t raw = crc_mulmod(acc, crc_mulmod(xinv_v, xl)); /* raw() of exactly len bytes */
-    const uint32_t st = crc_mulmod(0xFFFFFFFFu, xl) ^ raw;         /* register after the frame from 0xFFFFFFFF */
-    const uint32_t crc = bad ? 0u : ~st;
+  __syncthreads(); /* the tables */
+  const uint32_t xl = crc_x8_pow_len_wave(powtab, L, lane, lane_xk);
+  const uint32_t raw = wave_mulmod_uniform(acc, wave_mulmod_uniform(xinv_v, xl, lane, lane_xk), lane, lane_xk); /* raw() of exactly len bytes */
+  const uint32_t st = wave_mulmod_uniform(0xFFFFFFFFu, xl, lane, lane_xk) ^ raw; /* register after the frame from 0xFFFFFFFF */
+  const uint32_t crc = bad ? 0u : ~st;
+  uint32_t pkt = 0u;
+  if (hdr_out && pkt_crc_out) {
+    const uint32_t hpart = crc_header_part_wave(slice, w, h, L, lane);
+    pkt = crc_close_wave(slice, powtab, bad ? 0xFFFFFFFFu : st, 0u, 0u, true, hpart, xl, lane, lane_xk).pkt;
+  }
+  if (lane == 0) {
     crc_out[i] = crc;
     if (hdr_out) {
-      const uint32_t w = dims && !bad ? dims[2 * i] : 0u, h = dims && !bad ? dims[2 * i + 1] : 0u;
-      crc_emit_packet(crc_header_state16(w, h, L), xl, st, crc, w, h, L, bad, i, nullptr, hdr_out, pkt_crc_out);
+      crc_store_header(hdr_out, i, w, h, L, crc);
+      if (pkt_crc_out)
+        pkt_crc_out[i] = bad ? 0u : pkt;
     }
   }
 }

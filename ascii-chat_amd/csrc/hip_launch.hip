@@ -334,18 +334,21 @@ extern "C" int achip_crc_parts(uint32_t max_len, int n) {
     return 1;
   /* above 128 KB, by measurement (scripts/gpu_crc_sweep.py, profiles/r04_wire_audit.txt; us, one call at a time): the
    * one-workgroup kernel takes 4.5 + 58 per MB of the longest buffer, whatever the count up to a workgroup per CU (it is
-   * bound by its LDS look-ups: 256 KB 19, 1 MB 62, 1.8 MB 106-141); spans + the finish kernel take a fixed ~22 and 0.28
-   * per MB of ALL buffers (256 x 1.8 MB: 162).  Until this round every buffer above 128 KB went to the spans: a lone
-   * 200x60 truecolor frame's checksum cost 31 us behind a 7 us render. */
+   * bound by its LDS look-ups: 256 KB 19, 1 MB 62, 1.8 MB 106-141); spans + the finish kernel take a fixed ~17 and 0.25
+   * per MB of ALL buffers (256 x 1.8 MB: 138).  Until round 4's audit every buffer above 128 KB went to the spans, and
+   * those cost 31 us however little they checksummed (a barrier-fenced tree of bit-serial multiplications in every span
+   * and one thread's chain of them in the finish kernel): a lone 200x60 truecolor frame's checksum took 31 us behind a
+   * 7 us render. */
   const uint64_t mb16 = ((uint64_t)max_len + 65535u) >> 16;                 /* longest buffer, in 64 KB          */
   const uint64_t waves = ((uint64_t)(n > 0 ? n : 1) + 255u) / 256u;         /* rounds of a workgroup per CU     */
   const uint64_t t_frame = 45u * 16u + 580u * mb16 * waves;                 /* 0.1 us * 16                      */
-  const uint64_t t_spans = 220u * 16u + 28u * mb16 * (uint64_t)(n > 0 ? n : 1) / 10u;
+  const uint64_t t_spans = 170u * 16u + 25u * mb16 * (uint64_t)(n > 0 ? n : 1) / 10u;
   return t_frame <= t_spans ? 1 : spans;
 }
 
-/* the prebuilt tables of crc32c_frame_kernel<1024> (crc_math.hpp: crc_frame_tables_init_kernel), one image per device */
-static hipError_t frame_crc_tables_1024(const uint4 **out) {
+/* the prebuilt tables of the checksum kernels (crc_math.hpp: crc_frame_tables_init_kernel<BLOCK>: slicing tables, the Horner
+ * table of a BLOCK-thread workgroup, the power tables), one image per device and BLOCK */
+template <int BLOCK> static hipError_t frame_crc_tables(const uint4 **out) {
   constexpr int MAX_DEVICES = 16;
   static std::mutex mu;
   static uint32_t *tab[MAX_DEVICES] = {};
@@ -361,7 +364,7 @@ static hipError_t frame_crc_tables_1024(const uint4 **out) {
     e = hipMalloc(reinterpret_cast<void **>(&t), (size_t)ACHIP_FRAME_CRC_TAB_BYTES);
     if (e != hipSuccess)
       return e;
-    hipLaunchKernelGGL((achip::crc_frame_tables_init_kernel<1024>), dim3(1), dim3(256), ACHIP_FRAME_CRC_TAB_BYTES, nullptr, t);
+    hipLaunchKernelGGL((achip::crc_frame_tables_init_kernel<BLOCK>), dim3(1), dim3(256), ACHIP_FRAME_CRC_TAB_BYTES, nullptr, t);
     e = hipGetLastError();
     if (e == hipSuccess)
       e = hipDeviceSynchronize();
@@ -382,7 +385,7 @@ static int launch_crc32c(const uint8_t *base, uint64_t stride, const uint32_t *l
   const int parts = achip_crc_parts(max_len, n);
   if (parts == 1) { /* 1024 threads per frame; every workgroup runs only the rounds its own frame needs */
     const uint4 *tab = nullptr;
-    const hipError_t te = frame_crc_tables_1024(&tab);
+    const hipError_t te = frame_crc_tables<1024>(&tab);
     if (te != hipSuccess)
       return (int)te;
     if (pack)
@@ -396,20 +399,21 @@ static int launch_crc32c(const uint8_t *base, uint64_t stride, const uint32_t *l
   }
   const int rounds = 16; /* 64 KB spans of 256-thread workgroups */
   const uint64_t v_bytes = (uint64_t)parts * (uint64_t)rounds * 4096u;
+  const uint4 *tab256 = nullptr;
+  const hipError_t te256 = frame_crc_tables<256>(&tab256);
+  if (te256 != hipSuccess)
+    return (int)te256;
   if (pack)
     hipLaunchKernelGGL(achip::crc32c_span_kernel<true>, dim3((unsigned)n * (unsigned)parts), dim3(256),
-                       (size_t)achip::CrcLds::bytes, s, base, stride, len_dev, fixed_len, n, parts, rounds, partial, *pack);
+                       (size_t)achip::CrcLds::bytes, s, base, stride, len_dev, fixed_len, n, parts, rounds, partial, tab256, *pack);
   else
     hipLaunchKernelGGL(achip::crc32c_span_kernel<false>, dim3((unsigned)n * (unsigned)parts), dim3(256),
-                       (size_t)achip::CrcLds::bytes, s, base, stride, len_dev, fixed_len, n, parts, rounds, partial,
+                       (size_t)achip::CrcLds::bytes, s, base, stride, len_dev, fixed_len, n, parts, rounds, partial, tab256,
                        achip::CrcPack{nullptr, 0, nullptr, nullptr});
-  achip::CrcSpanPows cp;
-  cp.c[0] = achip::crc_pow(achip::CRC_X8, (uint64_t)rounds * 4096u);
-  for (int k = 1; k < 7; k++)
-    cp.c[k] = achip::crc_mulmod(cp.c[k - 1], cp.c[k - 1]);
-  hipLaunchKernelGGL(achip::crc32c_finish_kernel, dim3((unsigned)n), dim3(64), 256, s, partial, parts, cp,
+  static const achip::CrcSpanPows cp = achip::crc_span_pows(16u * 4096u); /* (rounds is 16 here: once per process) */
+  hipLaunchKernelGGL(achip::crc32c_finish_kernel, dim3((unsigned)n), dim3(64), (size_t)ACHIP_FRAME_CRC_TAB_BYTES, s, partial, parts, cp,
                      achip::crc_pow(achip::CRC_XINV8, v_bytes),
-                     len_dev, fixed_len, n, dims_dev, crc_out, hdr_out, pkt_crc_out);
+                     len_dev, fixed_len, n, dims_dev, crc_out, hdr_out, pkt_crc_out, tab256);
   return (int)hipGetLastError();
 }
 

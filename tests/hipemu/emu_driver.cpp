@@ -24,6 +24,16 @@ static const uint4 *frame_crc_tab_1024() {
   }
   return reinterpret_cast<const uint4 *>(tab.data());
 }
+/* ... and of the span kernel's 256-thread workgroups */
+static const uint4 *frame_crc_tab_256() {
+  static std::vector<uint32_t> tab;
+  if (tab.empty()) {
+    tab.resize(ACHIP_FRAME_CRC_TAB_BYTES / 4 + 4);
+    uint32_t *t = tab.data();
+    hipemu::launch(dim3(1), dim3(256), ACHIP_FRAME_CRC_TAB_BYTES, [&] { achip::crc_frame_tables_init_kernel<256>(t); });
+  }
+  return reinterpret_cast<const uint4 *>(tab.data());
+}
 static int g_uniform = 0; /* 1: pass the batch's common descriptor by value when it has one (as plan.c does) */
 
 template <int MODE, int BLOCK, int CAP, int RING>
@@ -341,6 +351,9 @@ extern "C" void emu_scatter_rows_batch(const uint8_t *staged, uint32_t n_clients
 #include <vector>
 #include "crc_kernels.hpp"
 
+/* the span powers the product's launcher computes on the host */
+static achip::CrcSpanPows span_pows(int rounds) { return achip::crc_span_pows((uint64_t)rounds * 4096u); }
+
 /* the launcher's geometry (hip_launch.hip: achip_launch_crc32c) restated for the emulator; force_parts > 1
  * sends small buffers through the multi-span path with spans of force_rounds * 4 KB */
 extern "C" void emu_crc32c(const uint8_t *base, uint64_t stride, const uint32_t *len, uint32_t fixed_len, uint32_t max_len,
@@ -361,13 +374,14 @@ extern "C" void emu_crc32c(const uint8_t *base, uint64_t stride, const uint32_t 
     return;
   }
   const uint64_t v_bytes = (uint64_t)parts * rounds * 4096u;
+  const uint4 *stab = frame_crc_tab_256(); /* (a launch of its own: not from inside the ones below) */
   std::vector<uint32_t> partial((size_t)n * parts);
   hipemu::launch(dim3((unsigned)(n * parts)), dim3(256), achip::CrcLds::bytes, [&] {
-    achip::crc32c_span_kernel<false>(base, stride, len, fixed_len, n, parts, rounds, partial.data());
+    achip::crc32c_span_kernel<false>(base, stride, len, fixed_len, n, parts, rounds, partial.data(), stab);
   });
-  hipemu::launch(dim3((unsigned)n), dim3(64), 256, [&] {
-    achip::crc32c_finish_kernel(partial.data(), parts, achip::crc_pow(achip::CRC_X8, (uint64_t)rounds * 4096u),
-                                achip::crc_pow(achip::CRC_XINV8, v_bytes), len, fixed_len, n, dims, crc_out, hdr_out, pkt_out);
+  hipemu::launch(dim3((unsigned)n), dim3(64), ACHIP_FRAME_CRC_TAB_BYTES, [&] {
+    achip::crc32c_finish_kernel(partial.data(), parts, span_pows(rounds), achip::crc_pow(achip::CRC_XINV8, v_bytes), len, fixed_len, n, dims,
+                                crc_out, hdr_out, pkt_out, stab);
   });
 }
 
@@ -390,13 +404,14 @@ extern "C" void emu_crc32c_pack(const uint8_t *base, uint64_t stride, const uint
     return;
   }
   const uint64_t v_bytes = (uint64_t)parts * rounds * 4096u;
+  const uint4 *stab = frame_crc_tab_256(); /* (a launch of its own: not from inside the ones below) */
   std::vector<uint32_t> partial((size_t)n * parts);
   hipemu::launch(dim3((unsigned)(n * parts)), dim3(256), achip::CrcLds::bytes, [&] {
-    achip::crc32c_span_kernel<true>(base, stride, len, 0u, n, parts, rounds, partial.data(), pack);
+    achip::crc32c_span_kernel<true>(base, stride, len, 0u, n, parts, rounds, partial.data(), stab, pack);
   });
-  hipemu::launch(dim3((unsigned)n), dim3(64), 256, [&] {
-    achip::crc32c_finish_kernel(partial.data(), parts, achip::crc_pow(achip::CRC_X8, (uint64_t)rounds * 4096u),
-                                achip::crc_pow(achip::CRC_XINV8, v_bytes), len, 0u, n, dims, crc_out, hdr_out, pkt_out);
+  hipemu::launch(dim3((unsigned)n), dim3(64), ACHIP_FRAME_CRC_TAB_BYTES, [&] {
+    achip::crc32c_finish_kernel(partial.data(), parts, span_pows(rounds), achip::crc_pow(achip::CRC_XINV8, v_bytes), len, 0u, n, dims, crc_out,
+                                hdr_out, pkt_out, stab);
   });
 }
 
