@@ -68,7 +68,10 @@ extern "C" int achip_launch_pack(const uint8_t *slab, uint64_t stride, const uin
 }
 
 /* the wire stage: stand-alone CRC + headers, headers from known CRCs, and the render with the CRC riding its drain */
-extern "C" int achip_crc_parts(uint32_t max_len) { return max_len <= 32u * 4096u ? 1 : (int)(((uint64_t)max_len + 65535u) / 65536u); }
+extern "C" int achip_crc_parts(uint32_t max_len, int n) { /* (the emulated launcher sizes its own span registers) */
+  (void)n;
+  return max_len <= 32u * 4096u ? 1 : (int)(((uint64_t)max_len + 65535u) / 65536u);
+}
 extern "C" int achip_launch_crc32c(const uint8_t *base, uint64_t stride, const uint32_t *len, uint32_t fixed_len, uint32_t max_len,
                                    int n, uint32_t *partial, const uint32_t *dims, uint32_t *crc_out, uint8_t *hdr_out,
                                    uint32_t *pkt_out, void *stream) {

@@ -81,7 +81,10 @@ def test_split_ragged_batch_and_policy():
     assert choose(1, one * 600) == (17, 1, 24)                # many frames: whole frames, 512-thread workgroups
     assert choose(1, one * 256, cus=256 // 3) == (17, 1, 24)  # ... or several launches in flight sharing the CUs
     assert choose(1, one * 256, cus=256 // 4) == (17, 1, 24)
-    assert choose(2, one * 256) == (16, 1, 24) and choose(3, one * 256) == (16, 1, 24) and choose(4, one * 300) == (17, 1, 24)
+    # round 4 audit (profiles/r04_policy_audit.txt): what decides is the frames per CU of the plan's share, not the blocks per
+    # wave -- sixteen-wave workgroups up to TWO frames per CU (128 frames at a share of 64: 23.5 vs 29.6 us at 200x60)
+    assert choose(1, one * 128, cus=64) == (16, 1, 24) and choose(1, one * 129, cus=64) == (17, 1, 24)
+    assert choose(2, one * 256) == (16, 1, 24) and choose(3, one * 256) == (16, 1, 24) and choose(4, one * 300) == (16, 1, 24) and choose(4, one * 513) == (17, 1, 24)
     # whole-frame launches of the run-structured modes take the rows kernel (render_rows.hpp) when the padded row fits a
     # block: the geometry whose blocks waste fewer lane slots (three 80-cell rows fill 240 of 256 slots, five fill 400 of 448)
     assert choose(0, one * 256) == (25, 1, 24)
@@ -100,7 +103,19 @@ def test_split_ragged_batch_and_policy():
     assert choose(1, one, req=3, forced=2) == (2, 8, 3)
     assert choose(1, one, forced=1, req=-1) == (1, 1, 24)
     k3w = [emu.frame_for_convert(imgs[0], 200, 60, 0)]
-    assert choose(1, k3w * 256) == (17, 1, 60)                # several blocks per wave: 512-thread workgroups
+    assert choose(1, k3w * 256) == (16, 1, 60)                # several blocks per wave, a frame per CU: sixteen waves (34.1 vs 43.4 us)
+    assert choose(1, k3w * 256, cus=64) == (17, 1, 60)        # BASELINE configs[2] with four launches in flight: 512-thread workgroups
+    assert choose(1, k3w * 128, cus=64) == (16, 1, 60)
+    m40 = [emu.frame_for_convert(imgs[0], 120, 40, 0)]        # 4 800 cells = 38 blocks: at most three per wave of sixteen
+    assert choose(1, m40 * 128) == (16, 1, 40)                # ... whole from half a frame per CU on (12.9 us against 16.8 as bands)
+    assert choose(1, m40 * 64)[1] > 1                         # below that: row bands (10.6 against 12.1)
+    hb40 = [emu.frame_for_convert(imgs[0], 120, 40, 2)]       # half blocks (40 text rows): twenty blocks a frame on the four-slot rows geometry
+    assert choose(5, hb40 * 256) == (4, 1, 40)                # a frame per CU, several blocks per wave: the phase kernel (37.5 vs 42.9)
+    assert choose(8, hb40 * 256) == (4, 1, 40)                # ... the mono half-block mode too (26.1 vs 28.9)
+    assert choose(5, hb40 * 256, cus=64) == (25, 1, 40)       # above a frame per CU: the rows kernel
+    assert choose(5, hb40 * 128) == (4, 1, 40)                # half blocks are not cut into bands from half a frame per CU on (30.3 vs 32.1)
+    assert choose(5, hb40 * 64)[1] > 1                        # (64 frames: bands, 14.0 vs 28.4)
+    assert choose(0, [emu.frame_for_convert(imgs[0], 320, 90, 0)] * 256) == (24, 1, 90)  # wide mono rows: seven-slot rows geometry (79 vs 88)
     k3 = [emu.frame_for_convert(imgs[0], 200, 60, 0)]
     assert choose(1, k3 * 64) == (1, 6, 10)                   # bands limited by the 2048-cell chunk
     k5 = [emu.frame_for_convert(imgs[0], 400, 120, 2)]        # half-block: 120 text rows of 400 cells
