@@ -561,7 +561,8 @@ def wire_stage(torch, pkg, res, steps=None):
                     "(two launches) vs asciichat_hip_plan_render_packets (one launch)"}
 
 
-def tick_e2e(torch, pkg, n=256, distinct=32, ticks=(2, 4), forms=("whole_blob", "sampled_rows", "sampled_pixels_batched", "sampled_images")):
+def tick_e2e(torch, pkg, n=256, distinct=32, ticks=(2, 4), forms=("whole_blob", "sampled_rows", "sampled_pixels_batched", "sampled_images"),
+             grid=(80, 24)):
     """The end-to-end server tick (SURVEY 8f.2 + path + 8f.3), PCIe included on both sides: n clients' host blobs
     [u32 BE w][u32 BE h][RGB24] (blocks of the pinned pool, as the receive path would fill them) -> frame table ->
     plan_render_packets -> frames in use + headers packed into mapped pinned host memory.  Three publish forms: the whole
@@ -573,7 +574,7 @@ def tick_e2e(torch, pkg, n=256, distinct=32, ticks=(2, 4), forms=("whole_blob", 
 
     import orc
 
-    sw, sh, W, H = 1920, 1080, 80, 24
+    sw, sh, (W, H) = 1920, 1080, grid
     L = pkg.lib()
     st = torch.cuda.current_stream().cuda_stream
     blob_bytes = 8 + sw * sh * 3
@@ -712,7 +713,7 @@ def tick_e2e(torch, pkg, n=256, distinct=32, ticks=(2, 4), forms=("whole_blob", 
     table.close()
     for p in blobs:
         L.buffer_pool_free(None, p, blob_bytes)
-    out["note"] = (f"{n} clients, 1080p -> 80x24 truecolor, blobs in the pinned pool; publish + latest + plan_update + "
+    out["note"] = (f"{n} clients, 1080p -> {W}x{H} truecolor, blobs in the pinned pool; publish + latest + plan_update + "
                    "plan_render_packets_packed (frames + wire stage, exact-length frames into mapped host memory) per tick; calls issued from Python")
     return out
 
