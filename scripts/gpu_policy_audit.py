@@ -70,8 +70,13 @@ if QUICK:
 SRC_W, SRC_H = (3840, 2160) if "--4k" in sys.argv else (1920, 1080)
 if "--4k" in sys.argv:
     SIZES = [(200, 60), (320, 90), (400, 120)]
-frames_t = bench.make_frames(torch, 256, SRC_W, SRC_H, 4242)
+GRID = "--grid" in sys.argv  # the targets are composite frames: the 3x3 grid of nine 1080p sources (stream.c:523-854), sampled directly
+frames_t = bench.make_frames(torch, 9 if GRID else 256, SRC_W, SRC_H, 4242)
 host0 = np.ascontiguousarray(frames_t[0].cpu().numpy())
+if GRID:
+    BATCHES = [1, 4, 9, 32, 64, 256]
+    SIZES = [(80, 24), (120, 40), (160, 48), (200, 60), (238, 70)]
+    MODES = [(0, "mono", 0, 0), (1, "truecolor", 3, 0), (5, "hb_true", 3, 2)]
 regrets = []
 print(f"# {SRC_W}x{SRC_H} sources, {'four streams in flight (wall clock)' if INFLIGHT else 'one stream, back to back (HIP events)'}; us per launch")
 for (mode, mname, cl, rm) in MODES:
@@ -81,7 +86,17 @@ for (mode, mname, cl, rm) in MODES:
     forced += [("phase 4 whole", 4, -1), ("phase 4 bands", 4, 0), ("phase 1 whole", 1, -1), ("phase 0 whole", 0, -1), ("phase 0 bands", 0, 0)]
     for (W, H) in SIZES:
         for n in BATCHES:
-            descs = [pkg.frame_setup(frames_t[k].data_ptr(), SRC_W, SRC_H, W, H, rm, False, False, False) for k in range(n)]
+            if GRID:
+                grid = pkg.Grid(None, [(SRC_W, SRC_H)] * 9, W, H)
+                grid.set_direct(True)
+                grid.exchange({k: frames_t[k].data_ptr() for k in range(9)}, torch.cuda.current_stream().cuda_stream)
+                descs = []
+                for _ in range(n):  # every client looks at the same grid (stream.c:790-854: aspect + padding on)
+                    f = pkg.frame_setup(None, W, 2 * H, W, H, rm, True, True, False)
+                    f.comp = grid.composite_dev
+                    descs.append(f)
+            else:
+                descs = [pkg.frame_setup(frames_t[k].data_ptr(), SRC_W, SRC_H, W, H, rm, False, False, False) for k in range(n)]
             bytes_per_frame = W * H * (41 if mode == 5 else 20)
             reps = max(8, min(300, int(4e8 / max(1, bytes_per_frame * n) / 50)))
             res = []
@@ -112,8 +127,9 @@ for (mode, mname, cl, rm) in MODES:
                 view = out.view(n, stride)
                 if ref is None:
                     ref = (view.clone(), lens.copy())
-                    exp = orc.convert_with_caps(host0, W, H, cl, rm, False, False, False)
-                    assert view[0, :int(lens[0])].cpu().numpy().tobytes() == exp, (mname, W, H, n, "automatic choice differs from the oracle")
+                    if not GRID:  # (the grid's bytes against the oracle's composite: tests/test_gpu_parity.py)
+                        exp = orc.convert_with_caps(host0, W, H, cl, rm, False, False, False)
+                        assert view[0, :int(lens[0])].cpu().numpy().tobytes() == exp, (mname, W, H, n, "automatic choice differs from the oracle")
                     label = f"automatic = v{plans[0].variant} parts {plans[0].parts}"
                 else:
                     assert (lens == ref[1]).all(), (mname, W, H, n, label, "lengths differ")
@@ -123,6 +139,9 @@ for (mode, mname, cl, rm) in MODES:
                 res.append((t, label, plans[0].variant, plans[0].parts))
                 for p in plans:
                     p.close()
+            if GRID:
+                torch.cuda.synchronize()
+                grid.close()
             auto = res[0]
             best = min(res, key=lambda r: r[0])
             regret = auto[0] / best[0] - 1.0
