@@ -6,7 +6,7 @@ that can carry the plan is forced in turn -- whole frames on the stream / rows /
 with --inflight, over four streams (what a saturated server is).  Every forced geometry's frames are compared with the
 automatic choice's on the GPU (all kernels must agree byte for byte; the automatic choice's first frame is checked against
 the oracle).  Prints one line per case: the automatic choice, the best, the regret.  GPU box only.
-usage: gpu_policy_audit.py [--inflight] [--quick] [--other-modes] [--4k]"""
+usage: gpu_policy_audit.py [--inflight] [--quick] [--other-modes] [--4k] [--grid] [--dense]"""
 import os
 import statistics
 import sys
@@ -70,6 +70,7 @@ if QUICK:
 SRC_W, SRC_H = (3840, 2160) if "--4k" in sys.argv else (1920, 1080)
 if "--4k" in sys.argv:
     SIZES = [(200, 60), (320, 90), (400, 120)]
+DENSE = "--dense" in sys.argv
 GRID = "--grid" in sys.argv  # the targets are composite frames: the 3x3 grid of nine 1080p sources (stream.c:523-854), sampled directly
 frames_t = bench.make_frames(torch, 9 if GRID else 256, SRC_W, SRC_H, 4242)
 host0 = np.ascontiguousarray(frames_t[0].cpu().numpy())
@@ -95,6 +96,11 @@ for (mode, mname, cl, rm) in MODES:
                     f = pkg.frame_setup(None, W, 2 * H, W, H, rm, True, True, False)
                     f.comp = grid.composite_dev
                     descs.append(f)
+            elif DENSE:  # what a server tick renders after the sampled-image ingest: the source IS the image the target samples
+                hs = 2 * H if rm == 2 else H
+                dense_t = bench.make_frames(torch, n, W, hs, 99)
+                host0 = np.ascontiguousarray(dense_t[0].cpu().numpy())
+                descs = [pkg.frame_setup(dense_t[k].data_ptr(), W, hs, W, H, rm, False, False, False) for k in range(n)]
             else:
                 descs = [pkg.frame_setup(frames_t[k].data_ptr(), SRC_W, SRC_H, W, H, rm, False, False, False) for k in range(n)]
             bytes_per_frame = W * H * (41 if mode == 5 else 20)
