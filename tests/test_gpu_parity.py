@@ -105,6 +105,141 @@ def test_torture_all_modes_all_variants(gpu, mode):
             assert got == oracle_convert(TORTURE, mode, W, H, orc.PALETTE_STANDARD), (MODE_NAMES[mode], variant, W, H)
 
 
+def test_every_geometry_renders_a_batch_to_the_same_bytes(gpu):
+    """The geometry policy's audit (scripts/gpu_policy_audit.py) as a test: a plan's bytes must not depend on the
+    geometry it takes.  Batches of 16 and 200 frames at two terminal sizes away from the BASELINE shapes, four modes: every
+    geometry that can carry the plan -- whole frames on the stream / rows / phase kernels, row bands, the shared-out form --
+    against the automatic choice, whose first and last frames are checked against the oracle."""
+    pkg, torch = gpu
+    n_max = 200
+    g = torch.Generator(device="cuda")
+    g.manual_seed(77)
+    src = torch.randint(0, 256, (n_max, 270, 480, 3), dtype=torch.uint8, device="cuda", generator=g)
+    host = {k: np.ascontiguousarray(src[k].cpu().numpy()) for k in (0, 15, n_max - 1)}
+    st = torch.cuda.current_stream().cuda_stream
+    for (mode, cl, rm) in ((0, 0, 0), (MODE_256_FG, 2, 0), (MODE_TRUE_FG, 3, 0), (MODE_HB_TRUE, 3, 2)):
+        cell = mode in (MODE_256_FG, MODE_TRUE_FG)
+        forced = ([(16, -1), (17, -1), (18, 0), (19, -1)] if cell else [(25, -1), (24, -1)]) + [(4, -1), (4, 0), (0, -1), (4, 3)]
+        if mode not in (MODE_HB_TRUE,):
+            forced += [(1, -1), (1, 0)]
+        for (W, H) in ((120, 40), (200, 60)):
+            for n in (16, n_max):
+                frames = [pkg.frame_setup(src[k].data_ptr(), 480, 270, W, H, rm, False, False, False) for k in range(n)]
+                ref = None
+                for (variant, split) in [(-1, None)] + forced:
+                    plan = pkg.Plan(mode, orc.PALETTE_STANDARD, frames)
+                    try:
+                        if split is not None:
+                            plan.set_split(split)
+                        if variant >= 0:
+                            plan.set_variant(variant)
+                    except RuntimeError:  # this geometry cannot carry the plan
+                        plan.close()
+                        continue
+                    out = torch.full((n * plan.stride,), 0xEE, dtype=torch.uint8, device="cuda")
+                    ln = torch.zeros(n, dtype=torch.int32, device="cuda")
+                    plan.render(out.data_ptr(), plan.stride, ln.data_ptr(), st)
+                    torch.cuda.synchronize()
+                    lens = ln.cpu().numpy().astype(np.uint32)
+                    assert (lens < 0xFFFFFFF0).all(), (mode, W, H, n, variant, split)
+                    view = out.view(n, plan.stride)
+                    if ref is None:
+                        for k in (0, n - 1):
+                            want = orc.convert_with_caps(host[k], W, H, cl, rm, False, False, False)
+                            assert view[k, :int(lens[k])].cpu().numpy().tobytes() == want, (mode, W, H, n, "automatic", k)
+                        ref = (view.clone(), lens)
+                    else:
+                        assert (lens == ref[1]).all(), (mode, W, H, n, variant, split)
+                        m = int(lens.max())
+                        valid = torch.arange(m, device="cuda")[None, :] < torch.from_numpy(lens.astype(np.int64)).cuda()[:, None]
+                        assert bool(((view[:, :m] == ref[0][:, :m]) | ~valid).all()), (mode, W, H, n, variant, split)
+                    plan.close()
+
+
+def test_wire_stage_forms_agree_away_from_the_baseline_shapes(gpu):
+    """The send side's audit (scripts/gpu_wire_audit.py) as a test.  (1) Small and mid batches of frames larger
+    than 80x24 -- where the plain render is shared out over workgroups or cut into bands and the checksum pass meets frames
+    above 128 KB: plan_render_packets fused / stand-alone / the plan's choice and plan_render_packets_packed in its three
+    forms leave the oracle's checksums, headers, packet CRCs and frames.  (2) The stand-alone pass on both sides of its cost
+    model (achip_crc_parts): the one-workgroup kernel on buffers above 128 KB and the spans + the whole-wave finish kernel,
+    lengths that are not multiples of 16, error lengths."""
+    pkg, torch = gpu
+    L = pkg.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    src = torch.randint(0, 256, (16, 270, 480, 3), dtype=torch.uint8, device="cuda", generator=g)
+    host = [np.ascontiguousarray(src[k].cpu().numpy()) for k in range(16)]
+    for (mode, cl, rm, W, H, n) in ((MODE_TRUE_FG, 3, 0, 320, 90, 1), (MODE_TRUE_FG, 3, 0, 200, 60, 16), (MODE_256_FG, 2, 0, 160, 45, 3),
+                                    (MODE_HB_TRUE, 3, 2, 200, 60, 8), (0, 0, 0, 320, 90, 2), (MODE_TRUE_FG, 3, 0, 120, 40, 16)):
+        frames = [pkg.frame_setup(src[k].data_ptr(), 480, 270, W, H, rm, False, False, False) for k in range(n)]
+        want = [orc.convert_with_caps(host[k], W, H, cl, rm, False, False, False) for k in range(n)]
+        plan = pkg.Plan(mode, orc.PALETTE_STANDARD, frames)
+        stride = plan.stride
+        dims = torch.tensor([[W, H]] * n, dtype=torch.int32, device="cuda")
+        for fused in (-1, 0, 1):
+            for exact in (None, -1, 0, 1):
+                plan.set_fused_crc(fused)
+                slab = torch.full((n * stride,), 0xEE, dtype=torch.uint8, device="cuda")
+                ln = torch.zeros(n, dtype=torch.int32, device="cuda")
+                crc = torch.zeros(n, dtype=torch.int32, device="cuda")
+                hdr = torch.zeros(n * 24, dtype=torch.uint8, device="cuda")
+                pkt = torch.zeros(n, dtype=torch.int32, device="cuda")
+                if exact is None:
+                    plan.render_packets(slab.data_ptr(), stride, ln.data_ptr(), dims.data_ptr(), crc.data_ptr(), hdr.data_ptr(), pkt.data_ptr(), st)
+                else:
+                    plan.set_exact_length(exact)
+                    dst = torch.full((n * stride,), 0xEE, dtype=torch.uint8, device="cuda")
+                    off = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
+                    lo = torch.zeros(n, dtype=torch.int32, device="cuda")
+                    plan.render_packets_packed(slab.data_ptr(), stride, ln.data_ptr(), dims.data_ptr(), crc.data_ptr(), hdr.data_ptr(),
+                                               pkt.data_ptr(), dst.data_ptr(), n * stride, off.data_ptr(), lo.data_ptr(), st)
+                torch.cuda.synchronize()
+                lens = ln.cpu().numpy().astype(np.uint32)
+                crc_h, pkt_h, hdr_h = crc.cpu().numpy().astype(np.uint32), pkt.cpu().numpy().astype(np.uint32), hdr.cpu().numpy()
+                if exact is not None:
+                    o, l, d = off.cpu().numpy(), lo.cpu().numpy().astype(np.uint32), dst.cpu().numpy()
+                for k in range(n):
+                    tag = (mode, W, H, n, fused, exact, k)
+                    assert int(lens[k]) == len(want[k]), tag
+                    eh, ep = orc.ascii_frame_packet(want[k], W, H)
+                    assert int(crc_h[k]) == orc.crc32c(want[k]) and hdr_h[24 * k:24 * k + 24].tobytes() == eh and int(pkt_h[k]) == ep, tag
+                    if exact is not None:
+                        assert int(l[k]) == len(want[k]) and d[int(o[k]):int(o[k]) + len(want[k])].tobytes() == want[k], tag
+        plan.close()
+    L.achip_crc_parts.restype = C.c_int
+    L.achip_crc_parts.argtypes = [C.c_uint32, C.c_int]
+    seen = set()
+    for (nbytes, nb) in ((277000 - 3, 16), (277000 - 3, 128), (663936 - 7, 1), (540000 + 1, 40), (1 << 20, 3), (131072 + 16, 2), (131072 - 1, 5)):
+        stride = (nbytes + 127) // 128 * 128
+        buf = torch.randint(0, 256, (nb * stride,), dtype=torch.uint8, device="cuda", generator=g)
+        lens_h = np.full(nb, nbytes, dtype=np.uint32)
+        lens_h[nb // 2] = nbytes // 3 + 5          # a short buffer among long ones
+        if nb > 2:
+            lens_h[nb - 1] = 0xFFFFFFF7            # an error length: CRC 0, a header of zeros
+        ln = torch.tensor(lens_h.astype(np.int64).tolist(), dtype=torch.int64, device="cuda").to(torch.int32)  # (error codes wrap to negative ints)
+        dims = torch.tensor([[97, 31]] * nb, dtype=torch.int32, device="cuda")
+        crc = torch.zeros(nb, dtype=torch.int32, device="cuda")
+        hdr = torch.full((nb * 24,), 0xEE, dtype=torch.uint8, device="cuda")
+        pkt = torch.zeros(nb, dtype=torch.int32, device="cuda")
+        rc = L.asciichat_hip_frame_packets(C.c_void_p(buf.data_ptr()), C.c_size_t(stride), C.c_void_p(ln.data_ptr()), C.c_uint32(stride), nb,
+                                           C.c_void_p(dims.data_ptr()), C.c_void_p(crc.data_ptr()), C.c_void_p(hdr.data_ptr()), C.c_void_p(pkt.data_ptr()),
+                                           C.c_void_p(st))
+        assert rc == 0, pkg.last_error()
+        torch.cuda.synchronize()
+        seen.add(L.achip_crc_parts(stride, nb) == 1)
+        hb, crc_h, pkt_h, hdr_h = buf.cpu().numpy(), crc.cpu().numpy().astype(np.uint32), pkt.cpu().numpy().astype(np.uint32), hdr.cpu().numpy()
+        for k in range(nb):
+            if lens_h[k] >= 0xFFFFFFF0:
+                eh, ep = orc.ascii_frame_packet(b"", 0, 0)
+                assert int(crc_h[k]) == 0 and hdr_h[24 * k:24 * k + 24].tobytes() == eh, (nbytes, nb, k)
+                continue
+            fr = hb[k * stride:k * stride + int(lens_h[k])].tobytes()
+            eh, ep = orc.ascii_frame_packet(fr, 97, 31)
+            assert int(crc_h[k]) == orc.crc32c(fr) and hdr_h[24 * k:24 * k + 24].tobytes() == eh and int(pkt_h[k]) == ep, (nbytes, nb, k)
+    assert seen == {True, False} or os.environ.get("ASCIICHAT_HIP_CRC_FRAME_MAX")  # both kernels ran
+
+
 def test_slots_at_every_line_phase(gpu):
     """The drains map lanes to 16-byte groups from a 128-byte line boundary of the slot's ADDRESS (round 4: whole lines per
     store instruction; the rows kernel carries partial lines from slice to slice, the phase kernel's carry is moved by the
