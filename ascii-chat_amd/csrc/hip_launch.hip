@@ -320,6 +320,13 @@ extern "C" int achip_launch_pack(const uint8_t *slab, uint64_t stride, const uin
 /* CRC-32C of n buffers + optional wire headers (crc_kernels.hpp).  Buffers up to 128 KB are checksummed by one
  * workgroup each, which also finishes them; larger ones are cut into 64 KB spans and finished by a second
  * kernel, which needs `partial` = n * achip_crc_parts(max_len) u32 of device scratch. */
+/* rounds of 4 KB per span: 64 KB spans, 16 KB ones while the call has so few of them that the GPU is nearly empty (a lone
+ * 540 KB frame: nine workgroups walking sixteen rounds each; as thirty-three of four rounds the pass is a third shorter) */
+static int crc_span_rounds(uint32_t max_len, int n) {
+  const uint64_t spans64 = ((uint64_t)max_len + 65535u) / 65536u;
+  return (uint64_t)(n > 0 ? n : 1) * spans64 <= 48u ? 4 : 16;
+}
+
 extern "C" int achip_crc_parts(uint32_t max_len, int n) {
   /* ASCIICHAT_HIP_CRC_FRAME_MAX (diagnostics, read once): buffers up to this many bytes take the one-workgroup kernel */
   static long forced = -1;
@@ -327,7 +334,8 @@ extern "C" int achip_crc_parts(uint32_t max_len, int n) {
     const char *e = getenv("ASCIICHAT_HIP_CRC_FRAME_MAX");
     forced = e && e[0] ? atol(e) : 0;
   }
-  const int spans = (int)(((uint64_t)max_len + 65535u) / 65536u);
+  const uint64_t span_bytes = (uint64_t)crc_span_rounds(max_len, n) * 4096u;
+  const int spans = (int)(((uint64_t)max_len + span_bytes - 1u) / span_bytes);
   if (forced > 0)
     return max_len <= (uint32_t)forced ? 1 : spans;
   if (max_len <= 32u * 4096u)
@@ -397,7 +405,7 @@ static int launch_crc32c(const uint8_t *base, uint64_t stride, const uint32_t *l
                          achip::CrcPack{nullptr, 0, nullptr, nullptr}, tab);
     return (int)hipGetLastError();
   }
-  const int rounds = 16; /* 64 KB spans of 256-thread workgroups */
+  const int rounds = crc_span_rounds(max_len, n); /* 64 KB (or, for a handful of buffers, 16 KB) spans of 256-thread workgroups */
   const uint64_t v_bytes = (uint64_t)parts * (uint64_t)rounds * 4096u;
   const uint4 *tab256 = nullptr;
   const hipError_t te256 = frame_crc_tables<256>(&tab256);
@@ -410,8 +418,9 @@ static int launch_crc32c(const uint8_t *base, uint64_t stride, const uint32_t *l
     hipLaunchKernelGGL(achip::crc32c_span_kernel<false>, dim3((unsigned)n * (unsigned)parts), dim3(256),
                        (size_t)achip::CrcLds::bytes, s, base, stride, len_dev, fixed_len, n, parts, rounds, partial, tab256,
                        achip::CrcPack{nullptr, 0, nullptr, nullptr});
-  static const achip::CrcSpanPows cp = achip::crc_span_pows(16u * 4096u); /* (rounds is 16 here: once per process) */
-  hipLaunchKernelGGL(achip::crc32c_finish_kernel, dim3((unsigned)n), dim3(64), (size_t)ACHIP_FRAME_CRC_TAB_BYTES, s, partial, parts, cp,
+  static const achip::CrcSpanPows cp16 = achip::crc_span_pows(16u * 4096u), cp4 = achip::crc_span_pows(4u * 4096u); /* once per process */
+  hipLaunchKernelGGL(achip::crc32c_finish_kernel, dim3((unsigned)n), dim3(64), (size_t)ACHIP_FRAME_CRC_TAB_BYTES, s, partial, parts,
+                     rounds == 16 ? cp16 : cp4,
                      achip::crc_pow(achip::CRC_XINV8, v_bytes),
                      len_dev, fixed_len, n, dims_dev, crc_out, hdr_out, pkt_crc_out, tab256);
   return (int)hipGetLastError();

@@ -60,6 +60,6 @@ for i in range(0, len(a), 3):
     plan.set_fused_crc(0)
     t_p = timed(lambda: plan.render_packets(slab.data_ptr(), stride, ln.data_ptr(), dims.data_ptr(), crc.data_ptr(), hdr.data_ptr(), pkt.data_ptr(), st))
     print(f"{W}x{H} x {n}: variant {plan.variant} parts {plan.parts} stride {stride} longest frame {max_len}: render {t_r:.1f} us | frame_packets "
-          f"(max_len = stride: {L.achip_crc_parts(u32(stride))} spans) {t_w:.1f} us, (max_len = longest frame: {L.achip_crc_parts(u32(max_len))} spans) {t_w2:.1f} us | "
+          f"(max_len = stride: {L.achip_crc_parts(u32(stride), C.c_int(n))} spans) {t_w:.1f} us, (max_len = longest frame: {L.achip_crc_parts(u32(max_len), C.c_int(n))} spans) {t_w2:.1f} us | "
           f"render_packets, separate {t_p:.1f} us", flush=True)
     plan.close()

@@ -509,6 +509,7 @@ def test_checksum_pass_picks_its_kernel_by_cost(pkg):
     assert L.achip_crc_parts(166400, 64) == 1            # sixty-four 160x45 frames
     assert L.achip_crc_parts(540000, 256) == 1           # a workgroup per CU: 44 us against 56
     assert L.achip_crc_parts(1845408, 256) == 1          # the configs[4] shape: 136 against 138 (a tie)
-    assert L.achip_crc_parts(663936, 1) == spans(663936)     # a lone 320x90 truecolor frame: 18 us of spans against 42
+    assert L.achip_crc_parts(663936, 1) == (663936 + 16383) // 16384  # a lone 320x90 truecolor frame: spans (against 42 us), of 16 KB while
+    assert L.achip_crc_parts(1 << 20, 3) == 64                        # the call has fewer than 48 of the 64 KB ones (a nearly empty GPU)
     assert L.achip_crc_parts(1 << 20, 64) == spans(1 << 20)  # 36 against 72
     assert L.achip_crc_parts(6220808, 64) == spans(6220808)  # 1080p ingest payloads
