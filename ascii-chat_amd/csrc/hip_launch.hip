@@ -320,11 +320,18 @@ extern "C" int achip_launch_pack(const uint8_t *slab, uint64_t stride, const uin
 /* CRC-32C of n buffers + optional wire headers (crc_kernels.hpp).  Buffers up to 128 KB are checksummed by one
  * workgroup each, which also finishes them; larger ones are cut into 64 KB spans and finished by a second
  * kernel, which needs `partial` = n * achip_crc_parts(max_len) u32 of device scratch. */
-/* rounds of 4 KB per span: 64 KB spans, 16 KB ones while the call has so few of them that the GPU is nearly empty (a lone
- * 540 KB frame: nine workgroups walking sixteen rounds each; as thirty-three of four rounds the pass is a third shorter) */
+/* rounds of 4 KB per span: 64 KB spans, 16 KB ones while the call has so few of them that the GPU is not full (a lone
+ * 540 KB frame: nine workgroups walking sixteen rounds each; as thirty-three of four rounds the pass is a third shorter --
+ * and sixteen 256 KB frames 20.0 -> 15.5 us, sixty-four 19.2 against 24.3; from ~512 spans of 64 KB on the larger spans win:
+ * 256 x 1.8 MB 141 against 179 us; scripts/gpu_crc_sweep.py, profiles/r04_wire_audit.txt) */
 static int crc_span_rounds(uint32_t max_len, int n) {
+  static long few = -1; /* ASCIICHAT_HIP_CRC_SMALL_SPANS (diagnostics, read once): 16 KB spans up to this many 64 KB ones */
+  if (few < 0) {
+    const char *e = getenv("ASCIICHAT_HIP_CRC_SMALL_SPANS");
+    few = e && e[0] ? atol(e) : 512;
+  }
   const uint64_t spans64 = ((uint64_t)max_len + 65535u) / 65536u;
-  return (uint64_t)(n > 0 ? n : 1) * spans64 <= 48u ? 4 : 16;
+  return (uint64_t)(n > 0 ? n : 1) * spans64 <= (uint64_t)few ? 4 : 16;
 }
 
 extern "C" int achip_crc_parts(uint32_t max_len, int n) {
@@ -342,7 +349,7 @@ extern "C" int achip_crc_parts(uint32_t max_len, int n) {
     return 1;
   /* above 128 KB, by measurement (scripts/gpu_crc_sweep.py, profiles/r04_wire_audit.txt; us, one call at a time): the
    * one-workgroup kernel takes 4.5 + 58 per MB of the longest buffer, whatever the count up to a workgroup per CU (it is
-   * bound by its LDS look-ups: 256 KB 19, 1 MB 62, 1.8 MB 106-141); spans + the finish kernel take a fixed ~17 and 0.25
+   * bound by its LDS look-ups: 256 KB 19, 1 MB 62, 1.8 MB 106-141); spans + the finish kernel take a fixed ~15 and 0.25
    * per MB of ALL buffers (256 x 1.8 MB: 138).  Until round 4's audit every buffer above 128 KB went to the spans, and
    * those cost 31 us however little they checksummed (a barrier-fenced tree of bit-serial multiplications in every span
    * and one thread's chain of them in the finish kernel): a lone 200x60 truecolor frame's checksum took 31 us behind a
@@ -350,7 +357,7 @@ extern "C" int achip_crc_parts(uint32_t max_len, int n) {
   const uint64_t mb16 = ((uint64_t)max_len + 65535u) >> 16;                 /* longest buffer, in 64 KB          */
   const uint64_t waves = ((uint64_t)(n > 0 ? n : 1) + 255u) / 256u;         /* rounds of a workgroup per CU     */
   const uint64_t t_frame = 45u * 16u + 580u * mb16 * waves;                 /* 0.1 us * 16                      */
-  const uint64_t t_spans = 170u * 16u + 25u * mb16 * (uint64_t)(n > 0 ? n : 1) / 10u;
+  const uint64_t t_spans = 150u * 16u + 25u * mb16 * (uint64_t)(n > 0 ? n : 1) / 10u;
   return t_frame <= t_spans ? 1 : spans;
 }
 
