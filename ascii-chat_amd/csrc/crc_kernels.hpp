@@ -195,6 +195,77 @@ __global__ void __launch_bounds__(BLOCK)
   }
 }
 
+/* Launch constants of the span checksum's finish, computed on the host (crc_span_pows): c[6] = cspan^64 and lane[t] =
+ * cspan^(63 - t), cspan = x^(8 * span bytes).  Squaring and multiplying them up on the device was a chain of bit-serial
+ * multiplications in front of everything else the one wave does. */
+struct CrcSpanPows {
+  uint32_t c[7];     /* cspan^(2^k) */
+  uint32_t lane[64]; /* cspan^(63 - t): what register t of a batch of 64 is followed by */
+};
+__host__ inline CrcSpanPows crc_span_pows(uint64_t span_bytes) {
+  CrcSpanPows cp;
+  cp.c[0] = crc_pow(CRC_X8, span_bytes);
+  for (int k = 1; k < 7; k++)
+    cp.c[k] = crc_mulmod(cp.c[k - 1], cp.c[k - 1]);
+  cp.lane[63] = crc_mulmod(0x80000000u, 0x80000000u); /* 1 (reflected: bit 31 is x^0) */
+  for (int t = 62; t >= 0; t--)
+    cp.lane[t] = crc_mulmod(cp.lane[t + 1], cp.c[0]);
+  return cp;
+}
+/* where a span launch leaves its frames' results when it finishes them itself (counters != NULL: one word per frame, zero
+ * between launches) */
+struct CrcFinish {
+  uint32_t *counters;
+  CrcSpanPows cp;
+  uint32_t xinv_v;
+  const uint32_t *dims;
+  uint32_t *crc_out;
+  uint8_t *hdr_out;
+  uint32_t *pkt_crc_out;
+};
+
+/* ONE WAVE combines a frame's span registers (all 64 lanes active; slice / powtab: the prebuilt tables in LDS).  Register q of
+ * the frame is followed by parts-1-q spans: it is multiplied by its lane's constant, one xor reduction per 64 registers, then
+ * the closing multiplications, the header's share and the packet CRC wave-wide, as crc32c_frame_kernel closes a frame -- the
+ * one-thread chain of bit-serial multiplications and byte loops this replaces (round 4, session 2) was most of the 26-31 us
+ * the span path cost however little it checksummed.  The surplus zero bytes parts*span - len are divided out (xinv_v =
+ * x^(-8*parts*span) from the host; x is invertible mod P).  AGENT: the registers were written by other workgroups of THIS
+ * launch (loads past the reader's caches). */
+template <bool AGENT>
+__device__ inline void crc_finish_wave(const uint32_t *slice, const uint32_t *powtab, const uint32_t *__restrict__ partial, int parts,
+                                       const CrcSpanPows &cp, uint32_t xinv_v, uint32_t L, bool bad, uint32_t w, uint32_t h, int i,
+                                       uint32_t *__restrict__ crc_out, uint8_t *__restrict__ hdr_out,
+                                       uint32_t *__restrict__ pkt_crc_out, int lane) {
+  const uint32_t lane_xk = CRC_LANE_TAB.xk[lane], lane_pow = cp.lane[lane];
+  uint32_t acc = 0;
+  const int lead = (64 - parts % 64) % 64; /* zero registers in front keep every batch of 64 full */
+  for (int q0 = -lead; q0 < parts; q0 += 64) {
+    const int q = q0 + lane;
+    uint32_t v = 0u;
+    if (q >= 0)
+      v = AGENT ? agent_load_u32(&partial[(size_t)i * parts + q]) : partial[(size_t)i * parts + q];
+    const uint32_t batch = wave_xor_all(crc_mulmod(v, lane_pow));
+    acc = (q0 > -lead ? wave_mulmod_uniform(acc, cp.c[6], lane, lane_xk) : 0u) ^ batch;
+  }
+  const uint32_t xl = crc_x8_pow_len_wave(powtab, L, lane, lane_xk);
+  const uint32_t raw = wave_mulmod_uniform(acc, wave_mulmod_uniform(xinv_v, xl, lane, lane_xk), lane, lane_xk); /* raw() of exactly len bytes */
+  const uint32_t st = wave_mulmod_uniform(0xFFFFFFFFu, xl, lane, lane_xk) ^ raw; /* register after the frame from 0xFFFFFFFF */
+  const uint32_t crc = bad ? 0u : ~st;
+  uint32_t pkt = 0u;
+  if (hdr_out && pkt_crc_out) {
+    const uint32_t hpart = crc_header_part_wave(slice, w, h, L, lane);
+    pkt = crc_close_wave(slice, powtab, bad ? 0xFFFFFFFFu : st, 0u, 0u, true, hpart, xl, lane, lane_xk).pkt;
+  }
+  if (lane == 0) {
+    crc_out[i] = crc;
+    if (hdr_out) {
+      crc_store_header(hdr_out, i, w, h, L, crc);
+      if (pkt_crc_out)
+        pkt_crc_out[i] = bad ? 0u : pkt;
+    }
+  }
+}
+
 /*
  * Large buffers: grid = n_frames * parts workgroups of 256 threads; workgroup (i, p) reduces the fixed span
  * [p*span, (p+1)*span) of frame i, span = rounds * 4 KB, parts*span >= every length (zeros behind the end of
@@ -204,7 +275,11 @@ template <bool COPY = false>
 __global__ void __launch_bounds__(256)
     crc32c_span_kernel(const uint8_t *__restrict__ base, uint64_t stride, const uint32_t *__restrict__ len,
                        uint32_t fixed_len, int n_frames, int parts, int rounds, uint32_t *__restrict__ partial,
-                       const uint4 *__restrict__ tab, CrcPack pack = CrcPack{nullptr, 0, nullptr, nullptr}) {
+                       const uint4 *__restrict__ tab, CrcFinish fin, CrcPack pack = CrcPack{nullptr, 0, nullptr, nullptr}) {
+  /* fin.counters != NULL: ONE launch -- every workgroup reports its register and arrives at its frame's counter; the last one
+   * to arrive finishes the frame (crc_finish_wave) and leaves the counter at zero for the next launch.  The second launch
+   * (crc32c_finish_kernel) this saves is worth ~2 us of a small call (render + wire stage of a lone 320x90 truecolor frame: 18.6 -> 16.7 us);
+   * the launcher asks for it only while the call has at most 128 spans -- an arrival is an L2 write-back + invalidate. */
   /* tab: the image of crc_frame_tables_init_kernel<256>; its first 20 KB (slicing tables + the Horner table of 256 threads)
    * are copied into LDS -- building them here was a chain of fifteen dependent LDS round trips and four bit-serial
    * multiplications in front of every workgroup's first load */
@@ -219,22 +294,26 @@ __global__ void __launch_bounds__(256)
   uint32_t L = len ? len[i] : fixed_len;
   if (L >= 0xFFFFFFF0u)
     L = 0;
+  const bool bad = (len ? len[i] : fixed_len) >= 0xFFFFFFF0u;
   const uint64_t lo = (uint64_t)p * (uint64_t)rounds * (16u * BLOCK);
-  if (lo >= L && !(COPY && p == 0)) { /* nothing but zeros: raw() of zeros from 0 is 0 */
+  const bool empty = lo >= L && !(COPY && p == 0); /* nothing but zeros: raw() of zeros from 0 is 0 */
+  if (empty && !fin.counters) {
     if (tid == 0)
       partial[(size_t)i * parts + p] = 0u;
     return;
   }
+  /* (one-launch form: a span behind the frame's end still arrives -- it may be the one that finishes the frame -- and takes
+   * the tables along for that) */
   const uint64_t avail = lo < L ? (uint64_t)L - lo : 0u; /* bytes of the frame from the start of this span (may exceed the span) */
-  if (COPY)
+  if (COPY && !empty)
     crc_pack_offset_post<BLOCK>(len, fixed_len, n_frames, i, tid);
-  static_assert(CrcLds::o_slice == 0 && CrcLds::o_mulh == 16 * 1024, "the image's first 20 KB");
+  static_assert(CrcLds::o_slice == 0 && CrcLds::o_mulh == 16 * 1024 && CrcLds::o_powtab == 20 * 1024, "the image's first 20 (22) KB");
   (void)slice, (void)mulh;
-  for (int k = tid; k < 20 * 1024 / 16; k += BLOCK)
+  for (int k = tid; k < (fin.counters ? ACHIP_FRAME_CRC_TAB_BYTES : 20 * 1024) / 16; k += BLOCK) /* (the finish wants the power tables too) */
     lds_ptr<uint4>(CrcLds::o_slice)[k] = tab[k];
   __syncthreads();
   uint8_t *dstb = nullptr; /* COPY: where this span's groups go; stays NULL for a frame that does not fit */
-  if (COPY) {
+  if (COPY && !empty) {
     uint64_t off, total;
     crc_pack_offset_read<BLOCK>(off, total);
     if (p == 0 && tid == 0) {
@@ -269,7 +348,7 @@ __global__ void __launch_bounds__(256)
     return d;
   };
   uint32_t s = 0;
-  for (int j0 = 0; j0 < rounds; j0 += 4) {
+  for (int j0 = 0; j0 < (empty ? 0 : rounds); j0 += 4) {
     uint4 d[4];
 #pragma unroll
     for (int u = 0; u < 4; u++)
@@ -281,83 +360,50 @@ __global__ void __launch_bounds__(256)
   }
   /* (one multiplication by the lane's constant, one xor reduction per wave, one wave folding the four wave registers, as the
    * frame kernel: the barrier-fenced tree of eight bit-serial levels this replaces was ~5 us of every span) */
-  const uint32_t whole = crc_reduce_waves<BLOCK>(tree, s, tid, CRC_LANE_TAB.k[tid & 63], CRC_LANE_TAB.xk[tid & 63]);
-  if (tid == 0)
-    partial[(size_t)i * parts + p] = whole;
+  const uint32_t whole = empty ? 0u : crc_reduce_waves<BLOCK>(tree, s, tid, CRC_LANE_TAB.k[tid & 63], CRC_LANE_TAB.xk[tid & 63]);
+  if (!fin.counters) {
+    if (tid == 0)
+      partial[(size_t)i * parts + p] = whole;
+    return;
+  }
+  uint32_t *last_flag = tree + BLOCK / 64; /* (behind crc_reduce_waves' wave registers) */
+  if (tid == 0) {
+    agent_store_u32(&partial[(size_t)i * parts + p], whole);
+    const bool last = agent_arrive_u32(&fin.counters[i]) == (uint32_t)parts - 1u; /* release + acquire, agent scope */
+    if (last)
+      agent_store_u32(&fin.counters[i], 0u); /* re-armed: the plan's next launch follows in stream order */
+    *last_flag = last ? 1u : 0u;
+  }
+  __syncthreads();
+  if (*last_flag != 0u && tid < 64) {
+    const uint32_t w = fin.dims && !bad ? fin.dims[2 * i] : 0u, h = fin.dims && !bad ? fin.dims[2 * i + 1] : 0u;
+    crc_finish_wave<true>(slice, lds_ptr<const uint32_t>(CrcLds::o_powtab), partial, parts, fin.cp, fin.xinv_v, L, bad, w, h, i, fin.crc_out,
+                          fin.hdr_out, fin.pkt_crc_out, tid);
+  }
 }
 
-/* One 64-thread workgroup per frame combines the span registers.  Register q of the frame is followed by
- * parts-1-q spans: 64 at a time, tree-combined with powers of cspan = x^(8*span); the surplus zero bytes
- * parts*span - len are divided out (xinv_v = x^(-8*parts*span) from the host; x is invertible mod P). */
-/* Launch constants of the finish kernel, computed on the host (crc_span_pows): c[6] = cspan^64 and lane[t] = cspan^(63 - t),
- * cspan = x^(8 * span bytes).  Squaring and multiplying them up on the device was a chain of bit-serial multiplications in
- * front of everything else the one wave does. */
-struct CrcSpanPows {
-  uint32_t c[7];     /* cspan^(2^k) */
-  uint32_t lane[64]; /* cspan^(63 - t): what register t of a batch of 64 is followed by */
-};
-__host__ inline CrcSpanPows crc_span_pows(uint64_t span_bytes) {
-  CrcSpanPows cp;
-  cp.c[0] = crc_pow(CRC_X8, span_bytes);
-  for (int k = 1; k < 7; k++)
-    cp.c[k] = crc_mulmod(cp.c[k - 1], cp.c[k - 1]);
-  cp.lane[63] = crc_mulmod(0x80000000u, 0x80000000u); /* 1 (reflected: bit 31 is x^0) */
-  for (int t = 62; t >= 0; t--)
-    cp.lane[t] = crc_mulmod(cp.lane[t + 1], cp.c[0]);
-  return cp;
-}
-
-/* One WAVE per frame combines the span registers (round 4, session 2: by whole-wave arithmetic -- register q is multiplied by
- * its lane's constant, one xor reduction per 64 registers, the closing multiplications, the header's share and the packet
- * CRC wave-wide with the prebuilt tables, as crc32c_frame_kernel closes a frame; the one-thread chain of bit-serial
- * multiplications and byte loops this replaces was most of the 26-31 us the span path cost however little it checksummed).
- * Register q of the frame is followed by parts-1-q spans; the surplus zero bytes parts*span - len are divided out
- * (xinv_v = x^(-8*parts*span) from the host; x is invertible mod P).  tab: the image of crc_frame_tables_init_kernel<256>. */
+/* One WAVE per frame combines the span registers of a two-launch call (crc_finish_wave).  tab: the image of
+ * crc_frame_tables_init_kernel<256>. */
 __global__ void __launch_bounds__(64)
     crc32c_finish_kernel(const uint32_t *__restrict__ partial, int parts, CrcSpanPows cp, uint32_t xinv_v,
                          const uint32_t *__restrict__ len, uint32_t fixed_len, int n_frames,
                          const uint32_t *__restrict__ dims, uint32_t *__restrict__ crc_out, uint8_t *__restrict__ hdr_out,
                          uint32_t *__restrict__ pkt_crc_out, const uint4 *__restrict__ tab) {
-  const uint32_t *slice = lds_ptr<const uint32_t>(CrcLds::o_slice);
-  const uint32_t *powtab = lds_ptr<const uint32_t>(CrcLds::o_powtab);
   const int i = (int)blockIdx.x, lane = (int)threadIdx.x;
   if (i >= n_frames)
     return;
   for (int k = lane; k < ACHIP_FRAME_CRC_TAB_BYTES / 16; k += 64)
     lds_ptr<uint4>(CrcLds::o_slice)[k] = tab[k];
-  const uint32_t lane_xk = CRC_LANE_TAB.xk[lane], lane_pow = cp.lane[lane];
   uint32_t L = len ? len[i] : fixed_len;
   const bool bad = L >= 0xFFFFFFF0u;
   if (bad)
     L = 0;
   const uint32_t w = dims && !bad ? dims[2 * i] : 0u, h = dims && !bad ? dims[2 * i + 1] : 0u;
-  uint32_t acc = 0;
-  const int lead = (64 - parts % 64) % 64; /* zero registers in front keep every batch of 64 full */
-  for (int q0 = -lead; q0 < parts; q0 += 64) {
-    const int q = q0 + lane;
-    const uint32_t v = q >= 0 ? partial[(size_t)i * parts + q] : 0u;
-    const uint32_t batch = wave_xor_all(crc_mulmod(v, lane_pow));
-    acc = (q0 > -lead ? wave_mulmod_uniform(acc, cp.c[6], lane, lane_xk) : 0u) ^ batch;
-  }
   __syncthreads(); /* the tables */
-  const uint32_t xl = crc_x8_pow_len_wave(powtab, L, lane, lane_xk);
-  const uint32_t raw = wave_mulmod_uniform(acc, wave_mulmod_uniform(xinv_v, xl, lane, lane_xk), lane, lane_xk); /* raw() of exactly len bytes */
-  const uint32_t st = wave_mulmod_uniform(0xFFFFFFFFu, xl, lane, lane_xk) ^ raw; /* register after the frame from 0xFFFFFFFF */
-  const uint32_t crc = bad ? 0u : ~st;
-  uint32_t pkt = 0u;
-  if (hdr_out && pkt_crc_out) {
-    const uint32_t hpart = crc_header_part_wave(slice, w, h, L, lane);
-    pkt = crc_close_wave(slice, powtab, bad ? 0xFFFFFFFFu : st, 0u, 0u, true, hpart, xl, lane, lane_xk).pkt;
-  }
-  if (lane == 0) {
-    crc_out[i] = crc;
-    if (hdr_out) {
-      crc_store_header(hdr_out, i, w, h, L, crc);
-      if (pkt_crc_out)
-        pkt_crc_out[i] = bad ? 0u : pkt;
-    }
-  }
+  crc_finish_wave<false>(lds_ptr<const uint32_t>(CrcLds::o_slice), lds_ptr<const uint32_t>(CrcLds::o_powtab), partial, parts, cp, xinv_v, L, bad,
+                         w, h, i, crc_out, hdr_out, pkt_crc_out, lane);
 }
+
 
 /* headers + packet CRCs from frame CRCs that are already known (the fused render): one thread per frame */
 __global__ void __launch_bounds__(256)

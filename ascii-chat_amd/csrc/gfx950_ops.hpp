@@ -64,6 +64,12 @@ __device__ inline unsigned long long agent_load_u64(const unsigned long long *p)
 __device__ inline unsigned long long agent_fetch_add_u64(unsigned long long *p, unsigned long long v) {
   return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+/* a hand-off through memory between workgroups of one launch (the span checksum's last arriver): the data word goes out
+ * relaxed, the arrival counter is bumped with release + acquire at agent scope -- every arrival's data is visible to
+ * whoever sees its count -- and the collector reads the data words past its own L1 / L2 */
+__device__ inline void agent_store_u32(uint32_t *p, uint32_t w) { __hip_atomic_store(p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline uint32_t agent_load_u32(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline uint32_t agent_arrive_u32(uint32_t *p) { return __hip_atomic_fetch_add(p, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT); }
 template <int N> __device__ inline void spin_nap() { __builtin_amdgcn_s_sleep(N); }
 __device__ inline void wg_store_u32(uint32_t *p, uint32_t v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

@@ -71,12 +71,14 @@ int achip_launch_scatter_rows_batch(const uint8_t *staged_dev, uint32_t n_client
  * device scratch, unused (may be NULL) when achip_crc_parts(max_len, n) == 1. */
 int achip_crc_parts(uint32_t max_len, int n);
 int achip_launch_crc32c(const uint8_t *base, uint64_t stride, const uint32_t *len_dev, uint32_t fixed_len,
-                        uint32_t max_len, int n, uint32_t *partial, const uint32_t *dims_dev, uint32_t *crc_out,
+                        uint32_t max_len, int n, uint32_t *partial, uint32_t *counters, const uint32_t *dims_dev, uint32_t *crc_out,
                         uint8_t *hdr_out, uint32_t *pkt_crc_out, void *stream);
+/* counters: NULL, or n device words that are zero between launches (a plan's own): the span form then finishes its frames in
+ * the same launch -- the last span of a frame to arrive combines the registers -- instead of a second kernel */
 
 /* the same pass also compacting the slab: frame i to dst + off[i], off[i] = sum of round16(len[j]), j < i (achip_launch_pack's layout) */
 int achip_launch_crc32c_pack(const uint8_t *base, uint64_t stride, const uint32_t *len_dev, uint32_t max_len, int n,
-                             uint32_t *partial, const uint32_t *dims_dev, uint32_t *crc_out, uint8_t *hdr_out,
+                             uint32_t *partial, uint32_t *counters, const uint32_t *dims_dev, uint32_t *crc_out, uint8_t *hdr_out,
                              uint32_t *pkt_crc_out, uint8_t *dst, uint64_t dst_capacity, uint64_t *off_out, uint32_t *len_out,
                              void *stream);
 

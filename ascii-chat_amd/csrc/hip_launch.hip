@@ -394,8 +394,9 @@ template <int BLOCK> static hipError_t frame_crc_tables(const uint4 **out) {
 }
 
 /* pack != NULL: the same pass also compacts the slab (crc_kernels.hpp COPY instantiations) */
+/* counters != NULL (n zero words the caller owns: a plan's): the span form finishes its frames in the SAME launch */
 static int launch_crc32c(const uint8_t *base, uint64_t stride, const uint32_t *len_dev, uint32_t fixed_len, uint32_t max_len,
-                         int n, uint32_t *partial, const uint32_t *dims_dev, uint32_t *crc_out, uint8_t *hdr_out,
+                         int n, uint32_t *partial, uint32_t *counters, const uint32_t *dims_dev, uint32_t *crc_out, uint8_t *hdr_out,
                          uint32_t *pkt_crc_out, const achip::CrcPack *pack, hipStream_t s) {
   const int parts = achip_crc_parts(max_len, n);
   if (parts == 1) { /* 1024 threads per frame; every workgroup runs only the rounds its own frame needs */
@@ -418,34 +419,46 @@ static int launch_crc32c(const uint8_t *base, uint64_t stride, const uint32_t *l
   const hipError_t te256 = frame_crc_tables<256>(&tab256);
   if (te256 != hipSuccess)
     return (int)te256;
+  static const achip::CrcSpanPows cp16 = achip::crc_span_pows(16u * 4096u), cp4 = achip::crc_span_pows(4u * 4096u); /* once per process */
+  /* the one-launch form only for SMALL calls: an arrival is a release + acquire at agent scope -- an L2 write-back and
+   * invalidate -- and thousands of workgroups doing that to each other cost far more than the launch they save (128 frames
+   * of 320x90: 94 -> 140 us; a lone frame: 18.6 -> 16 us) */
+  if ((uint64_t)n * (uint64_t)parts > 128u)
+    counters = nullptr;
+  achip::CrcFinish fin;
+  fin.counters = counters;
+  fin.cp = rounds == 16 ? cp16 : cp4;
+  fin.xinv_v = achip::crc_pow(achip::CRC_XINV8, v_bytes);
+  fin.dims = dims_dev;
+  fin.crc_out = crc_out;
+  fin.hdr_out = hdr_out;
+  fin.pkt_crc_out = pkt_crc_out;
   if (pack)
     hipLaunchKernelGGL(achip::crc32c_span_kernel<true>, dim3((unsigned)n * (unsigned)parts), dim3(256),
-                       (size_t)achip::CrcLds::bytes, s, base, stride, len_dev, fixed_len, n, parts, rounds, partial, tab256, *pack);
+                       (size_t)achip::CrcLds::bytes, s, base, stride, len_dev, fixed_len, n, parts, rounds, partial, tab256, fin, *pack);
   else
     hipLaunchKernelGGL(achip::crc32c_span_kernel<false>, dim3((unsigned)n * (unsigned)parts), dim3(256),
-                       (size_t)achip::CrcLds::bytes, s, base, stride, len_dev, fixed_len, n, parts, rounds, partial, tab256,
+                       (size_t)achip::CrcLds::bytes, s, base, stride, len_dev, fixed_len, n, parts, rounds, partial, tab256, fin,
                        achip::CrcPack{nullptr, 0, nullptr, nullptr});
-  static const achip::CrcSpanPows cp16 = achip::crc_span_pows(16u * 4096u), cp4 = achip::crc_span_pows(4u * 4096u); /* once per process */
-  hipLaunchKernelGGL(achip::crc32c_finish_kernel, dim3((unsigned)n), dim3(64), (size_t)ACHIP_FRAME_CRC_TAB_BYTES, s, partial, parts,
-                     rounds == 16 ? cp16 : cp4,
-                     achip::crc_pow(achip::CRC_XINV8, v_bytes),
-                     len_dev, fixed_len, n, dims_dev, crc_out, hdr_out, pkt_crc_out, tab256);
+  if (!counters)
+    hipLaunchKernelGGL(achip::crc32c_finish_kernel, dim3((unsigned)n), dim3(64), (size_t)ACHIP_FRAME_CRC_TAB_BYTES, s, partial, parts, fin.cp,
+                       fin.xinv_v, len_dev, fixed_len, n, dims_dev, crc_out, hdr_out, pkt_crc_out, tab256);
   return (int)hipGetLastError();
 }
 
 extern "C" int achip_launch_crc32c(const uint8_t *base, uint64_t stride, const uint32_t *len_dev, uint32_t fixed_len,
-                                   uint32_t max_len, int n, uint32_t *partial, const uint32_t *dims_dev,
+                                   uint32_t max_len, int n, uint32_t *partial, uint32_t *counters, const uint32_t *dims_dev,
                                    uint32_t *crc_out, uint8_t *hdr_out, uint32_t *pkt_crc_out, void *stream) {
-  return launch_crc32c(base, stride, len_dev, fixed_len, max_len, n, partial, dims_dev, crc_out, hdr_out, pkt_crc_out, nullptr,
+  return launch_crc32c(base, stride, len_dev, fixed_len, max_len, n, partial, counters, dims_dev, crc_out, hdr_out, pkt_crc_out, nullptr,
                        static_cast<hipStream_t>(stream));
 }
 
 /* checksums + headers + compaction in ONE pass over the slab: frame i also goes to dst + off[i] (pack_frames' layout) */
 extern "C" int achip_launch_crc32c_pack(const uint8_t *base, uint64_t stride, const uint32_t *len_dev, uint32_t max_len, int n,
-                                        uint32_t *partial, const uint32_t *dims_dev, uint32_t *crc_out, uint8_t *hdr_out,
+                                        uint32_t *partial, uint32_t *counters, const uint32_t *dims_dev, uint32_t *crc_out, uint8_t *hdr_out,
                                         uint32_t *pkt_crc_out, uint8_t *dst, uint64_t dst_capacity, uint64_t *off_out,
                                         uint32_t *len_out, void *stream) {
   const achip::CrcPack pack = {dst, dst_capacity, off_out, len_out};
-  return launch_crc32c(base, stride, len_dev, 0u, max_len, n, partial, dims_dev, crc_out, hdr_out, pkt_crc_out, &pack,
+  return launch_crc32c(base, stride, len_dev, 0u, max_len, n, partial, counters, dims_dev, crc_out, hdr_out, pkt_crc_out, &pack,
                        static_cast<hipStream_t>(stream));
 }

@@ -1005,10 +1005,12 @@ static int crc_common(const uint8_t *base_dev, size_t stride, const uint32_t *le
     if (rc)
       return rc;
   }
-  rc = achip_hip_check(pack ? achip_launch_crc32c_pack(base_dev, stride, len_dev, max_len, n, scratch, dims_dev, crc_out_dev,
+  /* a plan's own block carries n arrival counters (zero between launches) behind its n * parts span registers: ONE launch */
+  uint32_t *counters = own_scratch && parts > 1 ? own_scratch + (size_t)n * (size_t)parts : NULL;
+  rc = achip_hip_check(pack ? achip_launch_crc32c_pack(base_dev, stride, len_dev, max_len, n, scratch, counters, dims_dev, crc_out_dev,
                                                        hdr_out_dev, packet_crc_out_dev, pack->dst, (uint64_t)pack->capacity,
                                                        pack->off_out, pack->len_out, stream)
-                            : achip_launch_crc32c(base_dev, stride, len_dev, fixed_len, max_len, n, scratch, dims_dev,
+                            : achip_launch_crc32c(base_dev, stride, len_dev, fixed_len, max_len, n, scratch, counters, dims_dev,
                                                   crc_out_dev, hdr_out_dev, packet_crc_out_dev, stream),
                        "crc32c launch");
   if (scratch && !own_scratch) {
@@ -1053,13 +1055,17 @@ static int plan_wire_pass(asciichat_hip_plan_t *p, const uint8_t *slab_dev, size
   if (packet_crc_out_dev && !hdr_out_dev)
     return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame_packets: lengths and a header buffer are required");
   const int parts = out_stride < 0xFFFFFFF0u ? achip_crc_parts((uint32_t)out_stride, p->n) : 1;
-  const size_t words = parts > 1 ? (size_t)p->n * (size_t)parts : 0;
-  if (words > p->crc_scratch_words) {
+  /* span registers + one arrival counter per frame (zero between launches: the last span to arrive re-arms it).  The block is
+   * laid out for THIS parts count: a call with another out_stride gets a fresh, zeroed one */
+  const size_t words = parts > 1 ? (size_t)p->n * ((size_t)parts + 1u) : 0;
+  if (words && (words != p->crc_scratch_words)) {
     if (p->crc_scratch)
       (void)hipFree(p->crc_scratch); /* synchronises with a launch that still uses the old block */
     p->crc_scratch = NULL;
     p->crc_scratch_words = 0;
-    const int rc = achip_hip_check((int)hipMalloc((void **)&p->crc_scratch, words * sizeof(uint32_t)), "hipMalloc(crc scratch)");
+    int rc = achip_hip_check((int)hipMalloc((void **)&p->crc_scratch, words * sizeof(uint32_t)), "hipMalloc(crc scratch)");
+    if (!rc)
+      rc = achip_hip_check((int)hipMemset(p->crc_scratch, 0, words * sizeof(uint32_t)), "hipMemset(crc scratch)");
     if (rc)
       return rc;
     p->crc_scratch_words = words;

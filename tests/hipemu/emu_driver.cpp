@@ -353,6 +353,22 @@ extern "C" void emu_scatter_rows_batch(const uint8_t *staged, uint32_t n_clients
 
 /* the span powers the product's launcher computes on the host */
 static achip::CrcSpanPows span_pows(int rounds) { return achip::crc_span_pows((uint64_t)rounds * 4096u); }
+/* 1: the span form finishes its frames in the same launch (the last span of a frame to arrive combines the registers), as
+ * the product does behind a plan; 0: spans + crc32c_finish_kernel (the stand-alone entry points) */
+static int g_crc_one_launch = 0;
+extern "C" void emu_set_crc_one_launch(int on) { g_crc_one_launch = on; }
+static achip::CrcFinish span_finish(uint32_t *counters, int rounds, uint64_t v_bytes, const uint32_t *dims, uint32_t *crc_out, uint8_t *hdr_out,
+                                    uint32_t *pkt_out) {
+  achip::CrcFinish fin;
+  fin.counters = counters;
+  fin.cp = span_pows(rounds);
+  fin.xinv_v = achip::crc_pow(achip::CRC_XINV8, v_bytes);
+  fin.dims = dims;
+  fin.crc_out = crc_out;
+  fin.hdr_out = hdr_out;
+  fin.pkt_crc_out = pkt_out;
+  return fin;
+}
 
 /* the launcher's geometry (hip_launch.hip: achip_launch_crc32c) restated for the emulator; force_parts > 1
  * sends small buffers through the multi-span path with spans of force_rounds * 4 KB */
@@ -376,9 +392,17 @@ extern "C" void emu_crc32c(const uint8_t *base, uint64_t stride, const uint32_t 
   const uint64_t v_bytes = (uint64_t)parts * rounds * 4096u;
   const uint4 *stab = frame_crc_tab_256(); /* (a launch of its own: not from inside the ones below) */
   std::vector<uint32_t> partial((size_t)n * parts);
+  std::vector<uint32_t> counters((size_t)n, 0u);
+  const achip::CrcFinish fin = span_finish(g_crc_one_launch ? counters.data() : nullptr, rounds, v_bytes, dims, crc_out, hdr_out, pkt_out);
   hipemu::launch(dim3((unsigned)(n * parts)), dim3(256), achip::CrcLds::bytes, [&] {
-    achip::crc32c_span_kernel<false>(base, stride, len, fixed_len, n, parts, rounds, partial.data(), stab);
+    achip::crc32c_span_kernel<false>(base, stride, len, fixed_len, n, parts, rounds, partial.data(), stab, fin);
   });
+  if (g_crc_one_launch) {
+    for (uint32_t c : counters)
+      if (c != 0u)
+        abort(); /* every frame's counter is re-armed by its last arrival */
+    return;
+  }
   hipemu::launch(dim3((unsigned)n), dim3(64), ACHIP_FRAME_CRC_TAB_BYTES, [&] {
     achip::crc32c_finish_kernel(partial.data(), parts, span_pows(rounds), achip::crc_pow(achip::CRC_XINV8, v_bytes), len, fixed_len, n, dims,
                                 crc_out, hdr_out, pkt_out, stab);
@@ -406,9 +430,17 @@ extern "C" void emu_crc32c_pack(const uint8_t *base, uint64_t stride, const uint
   const uint64_t v_bytes = (uint64_t)parts * rounds * 4096u;
   const uint4 *stab = frame_crc_tab_256(); /* (a launch of its own: not from inside the ones below) */
   std::vector<uint32_t> partial((size_t)n * parts);
+  std::vector<uint32_t> counters((size_t)n, 0u);
+  const achip::CrcFinish fin = span_finish(g_crc_one_launch ? counters.data() : nullptr, rounds, v_bytes, dims, crc_out, hdr_out, pkt_out);
   hipemu::launch(dim3((unsigned)(n * parts)), dim3(256), achip::CrcLds::bytes, [&] {
-    achip::crc32c_span_kernel<true>(base, stride, len, 0u, n, parts, rounds, partial.data(), stab, pack);
+    achip::crc32c_span_kernel<true>(base, stride, len, 0u, n, parts, rounds, partial.data(), stab, fin, pack);
   });
+  if (g_crc_one_launch) {
+    for (uint32_t c : counters)
+      if (c != 0u)
+        abort();
+    return;
+  }
   hipemu::launch(dim3((unsigned)n), dim3(64), ACHIP_FRAME_CRC_TAB_BYTES, [&] {
     achip::crc32c_finish_kernel(partial.data(), parts, span_pows(rounds), achip::crc_pow(achip::CRC_XINV8, v_bytes), len, 0u, n, dims, crc_out,
                                 hdr_out, pkt_out, stab);

@@ -36,6 +36,13 @@ inline unsigned long long agent_fetch_add_u64(unsigned long long *p, unsigned lo
   *reinterpret_cast<volatile unsigned long long *>(p) = old + v;
   return old;
 }
+inline void agent_store_u32(uint32_t *p, uint32_t w) { *reinterpret_cast<volatile uint32_t *>(p) = w; }
+inline uint32_t agent_load_u32(const uint32_t *p) { return *reinterpret_cast<const volatile uint32_t *>(p); }
+inline uint32_t agent_arrive_u32(uint32_t *p) {
+  const uint32_t old = *reinterpret_cast<volatile uint32_t *>(p);
+  *reinterpret_cast<volatile uint32_t *>(p) = old + 1u;
+  return old;
+}
 template <int N> inline void spin_nap() {}
 inline void wg_store_u32(uint32_t *p, uint32_t v) { *reinterpret_cast<volatile uint32_t *>(p) = v; }
 inline uint32_t wg_load_u32(const uint32_t *p) { return *reinterpret_cast<const volatile uint32_t *>(p); }

@@ -73,9 +73,9 @@ extern "C" int achip_crc_parts(uint32_t max_len, int n) { /* (the emulated launc
   return max_len <= 32u * 4096u ? 1 : (int)(((uint64_t)max_len + 65535u) / 65536u);
 }
 extern "C" int achip_launch_crc32c(const uint8_t *base, uint64_t stride, const uint32_t *len, uint32_t fixed_len, uint32_t max_len,
-                                   int n, uint32_t *partial, const uint32_t *dims, uint32_t *crc_out, uint8_t *hdr_out,
+                                   int n, uint32_t *partial, uint32_t *counters, const uint32_t *dims, uint32_t *crc_out, uint8_t *hdr_out,
                                    uint32_t *pkt_out, void *stream) {
-  (void)partial, (void)stream;
+  (void)partial, (void)counters, (void)stream;
   if (n <= 0)
     return MOCK_OK;
   std::lock_guard<std::mutex> lock(g_emu_mu);
@@ -83,10 +83,10 @@ extern "C" int achip_launch_crc32c(const uint8_t *base, uint64_t stride, const u
   return MOCK_OK;
 }
 extern "C" int achip_launch_crc32c_pack(const uint8_t *base, uint64_t stride, const uint32_t *len, uint32_t max_len, int n,
-                                        uint32_t *partial, const uint32_t *dims, uint32_t *crc_out, uint8_t *hdr_out,
+                                        uint32_t *partial, uint32_t *counters, const uint32_t *dims, uint32_t *crc_out, uint8_t *hdr_out,
                                         uint32_t *pkt_out, uint8_t *dst, uint64_t cap, uint64_t *off_out, uint32_t *len_out,
                                         void *stream) {
-  (void)partial, (void)stream;
+  (void)partial, (void)counters, (void)stream;
   if (n <= 0)
     return MOCK_OK;
   std::lock_guard<std::mutex> lock(g_emu_mu);

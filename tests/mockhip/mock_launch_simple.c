@@ -146,14 +146,14 @@ int achip_launch_scatter_rows_batch(const uint8_t *st, uint32_t n, uint32_t mr, 
   return MOCK_OK;
 }
 int achip_launch_crc32c(const uint8_t *base, uint64_t stride, const uint32_t *len, uint32_t fixed, uint32_t max, int n, uint32_t *partial,
-                        const uint32_t *dims, uint32_t *crc, uint8_t *hdr, uint32_t *pkt, void *s) {
-  (void)base, (void)stride, (void)len, (void)fixed, (void)max, (void)n, (void)partial, (void)dims, (void)crc, (void)hdr, (void)pkt, (void)s;
+                        uint32_t *counters, const uint32_t *dims, uint32_t *crc, uint8_t *hdr, uint32_t *pkt, void *s) {
+  (void)base, (void)stride, (void)len, (void)fixed, (void)max, (void)n, (void)partial, (void)counters, (void)dims, (void)crc, (void)hdr, (void)pkt, (void)s;
   return MOCK_UNSUPPORTED;
 }
 int achip_launch_crc32c_pack(const uint8_t *base, uint64_t stride, const uint32_t *len, uint32_t max, int n, uint32_t *partial,
-                             const uint32_t *dims, uint32_t *crc, uint8_t *hdr, uint32_t *pkt, uint8_t *dst, uint64_t cap,
+                             uint32_t *counters, const uint32_t *dims, uint32_t *crc, uint8_t *hdr, uint32_t *pkt, uint8_t *dst, uint64_t cap,
                              uint64_t *off, uint32_t *len_out, void *s) {
-  (void)base, (void)stride, (void)len, (void)max, (void)n, (void)partial, (void)dims, (void)crc, (void)hdr, (void)pkt, (void)dst,
+  (void)base, (void)stride, (void)len, (void)max, (void)n, (void)partial, (void)counters, (void)dims, (void)crc, (void)hdr, (void)pkt, (void)dst,
       (void)cap, (void)off, (void)len_out, (void)s;
   return MOCK_UNSUPPORTED;
 }

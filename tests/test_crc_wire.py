@@ -51,9 +51,18 @@ def _frames():
     return frames, dims
 
 
+@pytest.fixture(params=[0, 1], ids=["spans+finish", "one launch"])
+def one_launch(request):
+    """the span form with crc32c_finish_kernel behind it (the stand-alone entry points) / finishing its frames itself: the
+    last span of a frame to arrive combines the registers (what a plan's wire pass launches; round 4, session 2)"""
+    emu.lib().emu_set_crc_one_launch(request.param)
+    yield request.param
+    emu.lib().emu_set_crc_one_launch(0)
+
+
 @pytest.mark.parametrize("force", [None, (3, 6), (2, 16), (70, 1), (130, 1)],
                          ids=["launcher", "3x6", "2x16", "70x1", "130x1"])
-def test_crc_and_packet_headers_emulated(force):
+def test_crc_and_packet_headers_emulated(force, one_launch):
     frames, dims = _frames()
     crc, hdr, pkt = emu.crc32c_frames(frames, dims, force=force)
     for i, f in enumerate(frames):
@@ -65,7 +74,7 @@ def test_crc_and_packet_headers_emulated(force):
     assert (crc2 == crc).all()
 
 
-def test_large_buffer_spans_emulated():
+def test_large_buffer_spans_emulated(one_launch):
     # > 128 KB: the launcher cuts the buffer into 64 KB spans finished by the second kernel (ingest payload sizes)
     rng = np.random.default_rng(9)
     for n in (131073, 300000, 640 * 480 * 3):

@@ -266,8 +266,16 @@ def test_ingest_sample_set_and_scatter_emulated(case):
     L.achip_sample_set_free(C.byref(S))
 
 
+@pytest.fixture(params=[0, 1], ids=["spans+finish", "one launch"])
+def one_launch(request):
+    """the span form followed by crc32c_finish_kernel / finishing its frames itself (the last span to arrive combines)"""
+    emu.lib().emu_set_crc_one_launch(request.param)
+    yield request.param
+    emu.lib().emu_set_crc_one_launch(0)
+
+
 @pytest.mark.parametrize("force", [None, (3, 1), (5, 2)], ids=["frame-kernel", "spans-3x4K", "spans-5x8K"])
-def test_checksum_and_pack_in_one_pass_emulated(force):
+def test_checksum_and_pack_in_one_pass_emulated(force, one_launch):
     """crc_kernels.hpp COPY instantiations: the pass that checksums a slab also compacts it.  Checksums, headers and packet
     CRCs as the plain pass computes them (and the oracle), offsets and bytes as pack_frames_kernel lays them out -- for
     frames of every length class (empty, < 16 bytes, ends on / next to a group or span boundary, an overflowed slot), through
