@@ -553,7 +553,7 @@ def test_drains_follow_the_line_boundaries_of_the_address(phase):
     """Round 4: every kernel's drain maps lanes to 16-byte groups from a 128-byte LINE boundary of the slot's ADDRESS (whole
     lines per store instruction), the rows kernel carries the bytes behind a slice's last whole line to the block's next
     slice, and the phase kernel's carry is moved by whichever thread drained group 0.  Slabs that start at each of the
-    eight 16-byte phases of a line, with strides that walk the slots through the other phases: the oracle's bytes, and not
+    eight 16-byte phases of a line, with a stride that walks the slots through other phases: the oracle's bytes, and not
     one byte outside the frames."""
     imgs = [orc.frame_hash_noise(120, 90, i) for i in range(2)] + [run_frames(160, 90, "blocks"), TORTURE]
     for (mode, variant, dims) in [
@@ -565,7 +565,7 @@ def test_drains_follow_the_line_boundaries_of_the_address(phase):
         rm = MODE_CAPS.get(mode, (3, 0))[1]
         frames = [emu.frame_for_convert(im, w, h, rm) for im, (w, h) in zip(imgs, dims)]
         bound = max(len(oracle_convert(im, mode, w, h, orc.PALETTE_STANDARD)) for im, (w, h) in zip(imgs, dims))
-        for extra in (16, 48, 112):  # the stride's own phase: slots 1.. start at other phases than slot 0
+        for extra in ((16, 48, 112, 80)[phase % 4],):  # the stride's own phase: slots 1.. start at other phases than slot 0
             stride = (bound + 1 + 15) // 16 * 16 + 2048 + extra
             got = emu.render_frames(mode, frames, orc.PALETTE_STANDARD, variant, stride=stride, line_phase=phase)
             for k, (im, (w, h)) in enumerate(zip(imgs, dims)):
