@@ -396,8 +396,10 @@ int asciichat_hip_plan_render_packets_packed(asciichat_hip_plan_t *plan, uint8_t
                                              uint8_t *hdr_out_dev, uint32_t *packet_crc_out_dev, uint8_t *dst,
                                              size_t dst_capacity, uint64_t *off_out, uint32_t *len_out, void *stream);
 /* Which form plan_render_crc / plan_render_packets take: -1 (default) the fused one where it is the faster form (the
- * per-cell modes' stream kernel), 1 wherever the plan's geometry carries it (also the rows kernel of the run-structured
- * modes, where the stand-alone pass is measured faster), 0 never.  plan_has_fused_crc() tells what a call will do. */
+ * per-cell modes' stream kernel -- for a small launch whose render is shared out over workgroups only while a wave has one
+ * block: fusing means one workgroup per frame, and a lone 320x90 frame then takes 116 us where render + stand-alone pass
+ * take 17), 1 wherever the plan's geometry carries it (also the rows kernel of the run-structured modes, where the
+ * stand-alone pass is measured faster), 0 never.  plan_has_fused_crc() tells what a call will do. */
 int asciichat_hip_plan_set_fused_crc(asciichat_hip_plan_t *plan, int mode);
 int asciichat_hip_plan_render_crc_profiled(asciichat_hip_plan_t *plan, uint8_t *out_dev, size_t out_stride,
                                            uint32_t *out_len_dev, uint32_t *crc_out_dev,
