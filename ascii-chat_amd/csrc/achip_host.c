@@ -693,7 +693,14 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
      * flight (phase: 244) but 308 one at a time (phase: 256) -- its 7-slot blocks run at eight waves per CU, so ONE launch
      * of at most a frame per CU stays with the phase kernel's sixteen. */
     const int used4 = max_wp <= 256 ? (256 / max_wp) * max_wp : 0, used7 = (448 / max_wp) * max_wp;
-    const int v = used4 * 448 >= used7 * 256 ? 25 : 24;
+    int v = used4 * 448 >= used7 * 256 ? 25 : 24;
+    /* (round 4, the audit with launches in flight through bench.py's schedule: above two frames per CU of the share the
+     * four-slot geometry wins whatever the slots it wastes -- its workgroups need fewer registers and more of them share a
+     * CU: 256 mono frames of 160x45 at a share of 64 CUs 14.3 against 17.3 us, 200x60 20.7 against 24.7, half-block
+     * truecolor 38.4 against 40.8; at two frames per CU the seven-slot one is still ahead, 9.0 against 10.6) */
+    if (short_tokens && max_wp <= 256 && n_frames > 2 * n_cus) /* (mono and mono half blocks, 200x60: 29.0 against 35.3; the coloured
+                                                                   half-block modes differ by -14 .. +5 % and keep the slot rule) */
+      v = 25;
     /* (round 4 audit: the coloured half-block modes at no more than a frame per CU only while a wave has ONE block --
      * 256 frames of 120x40, one launch at a time: 42.9 us against the phase kernel's 37.5, 238x70 104 against 95; 80x24,
      * four blocks a frame, 21.2 against 23.1.  Mono keeps the rows kernel: 238x70 47 against 52.) */
@@ -702,8 +709,14 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
      * wins for all of them -- 4K -> 400x120, 128 frames at a share of 64 CUs, bench.py's schedule: 108 against 118;
      * mono rows wider than the four-slot geometry take the seven-slot one at any count: 256 frames of 320x90 79 against 88) */
     const bool mono = mode == ACHIP_MODE_MONO;
-    if ((v == 25 || n_frames > n_cus || (mono && max_wp > 256)) && ext <= ACHIP_HOST_STREAM_MAXBLK &&
-        (mono || n_frames > n_cus || ext <= 8)) {
+    /* (... and on a GPU that is SHARED -- the caller keeps launches in flight and passed a share of at most half the CUs --
+     * mono frames of several blocks per wave follow the half-block rule too: 64 frames of 238x70 at a share of 64 CUs 13.8 us
+     * on the phase kernel against 17.3, 320x90 22.6 against 27.1; with the GPU to itself the rows kernel stays ahead, above) */
+    /* (the half-block modes' frames of one block per wave as well: 64 frames of 80x24 at a share of 64 CUs 5.2-5.9 us on the
+     * phase kernel against 6.2-6.9, all four of them) */
+    const bool shared_gpu = n_cus <= 128;
+    const bool take = n_frames > n_cus ? true : mono ? !(shared_gpu && ext > 8) : (ext <= 8 && !shared_gpu);
+    if ((v == 25 || n_frames > n_cus || (mono && max_wp > 256)) && ext <= ACHIP_HOST_STREAM_MAXBLK && take) {
       *variant = v;
       return 0;
     }

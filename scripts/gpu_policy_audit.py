@@ -3,7 +3,7 @@
 terminal sizes x batch sizes x modes (1080p sources; typical terminals, not only 80x24 / 200x60 / 400x120) every geometry
 that can carry the plan is forced in turn -- whole frames on the stream / rows / phase kernels, row bands of the phase kernel
 -- and timed like the automatic choice: HIP events over back-to-back launches on ONE stream (what a lone server tick is) and,
-with --inflight, over four streams (what a saturated server is).  Every forced geometry's frames are compared with the
+with --inflight, four plans in flight through bench.py's C-issued schedule (what a saturated server is).  Every forced geometry's frames are compared with the
 automatic choice's on the GPU (all kernels must agree byte for byte; the automatic choice's first frame is checked against
 the oracle).  Prints one line per case: the automatic choice, the best, the regret.  GPU box only.
 usage: gpu_policy_audit.py [--inflight] [--quick] [--other-modes] [--4k] [--grid] [--dense]"""
@@ -26,10 +26,17 @@ L = pkg.lib()
 torch.cuda.set_device(0)
 INFLIGHT = "--inflight" in sys.argv
 QUICK = "--quick" in sys.argv
-streams = [torch.cuda.Stream() for _ in range(4)] if INFLIGHT else [torch.cuda.current_stream()]
+streams = [None] * 4 if INFLIGHT else [torch.cuda.current_stream()]  # (--inflight: bench.Runner owns the lanes)
 
 
 def time_plan(plans, n, stride, reps):
+    if INFLIGHT:  # bench.py's own schedule: the steps issued from C (asciichat_hip_render_many), four lanes of ONE stream pool
+        r = bench.Runner(torch, pkg, plans, n, len(plans))
+        r.issue(2 * len(plans))
+        torch.cuda.synchronize()
+        ts = [r.gpu_ms_per_step(max(reps, 4 * len(plans))) * 1e3 for _ in range(3)]
+        torch.cuda.synchronize()
+        return statistics.median(ts), r.outs[0], r.lns[0]
     outs = [torch.empty(n * stride, dtype=torch.uint8, device="cuda") for _ in plans]
     lns = [torch.zeros(n, dtype=torch.int32, device="cuda") for _ in plans]
 
@@ -79,7 +86,7 @@ if GRID:
     SIZES = [(80, 24), (120, 40), (160, 48), (200, 60), (238, 70)]
     MODES = [(0, "mono", 0, 0), (1, "truecolor", 3, 0), (5, "hb_true", 3, 2)]
 regrets = []
-print(f"# {SRC_W}x{SRC_H} sources, {'four streams in flight (wall clock)' if INFLIGHT else 'one stream, back to back (HIP events)'}; us per launch")
+print(f"# {SRC_W}x{SRC_H} sources, {'four launches in flight through the C-issued schedule of bench.py (HIP events on every lane)' if INFLIGHT else 'one stream, back to back (HIP events)'}; us per launch")
 for (mode, mname, cl, rm) in MODES:
     cell = mode in (1, 2, 3, 4)
     forced = ([("stream 16", 16, -1), ("stream 17", 17, -1), ("stream 18", 18, -1), ("stream 18 shared", 18, 0), ("stream 19", 19, -1)] if cell
