@@ -621,8 +621,13 @@ int asciichat_hip_plan_set_exact_length(asciichat_hip_plan_t *p, int mode) {
  * have crossed PCIe, where the two-launch form's render is long gone and only the copy kernel's few registers wait.  So the
  * automatic choice looks at the destination (one hipPointerGetAttributes per new destination pointer; a tick reuses its
  * buffers). */
-static int plan_packs_this_call(asciichat_hip_plan_t *p, const void *dst) {
+static int plan_packs_this_call(asciichat_hip_plan_t *p, const void *dst, const uint64_t *off_out) {
   if (!asciichat_hip_plan_get_exact_length(p))
+    return 0;
+  /* the one-launch form leaves the frames in COMPLETION order: only a caller that receives off_out can find them.  A
+   * caller relying on pack_frames' documented layout (off_out == NULL: frame i behind the 16-byte rounded lengths of
+   * frames 0..i-1) keeps the ordered two-pass form, whatever set_exact_length says */
+  if (!off_out)
     return 0;
   if (p->exact_length > 0)
     return 1;
@@ -639,7 +644,7 @@ static int plan_packs_this_call(asciichat_hip_plan_t *p, const void *dst) {
 }
 static int plan_render_pack(asciichat_hip_plan_t *p, uint32_t *out_len_dev, const achip_wire_t *wire, uint8_t *dst,
                             size_t dst_capacity, uint64_t *off_out, uint32_t *len_out, void *stream) {
-  if (!out_len_dev || !dst || ((uintptr_t)dst & 15u) || ((uintptr_t)off_out & 7u) || ((uintptr_t)len_out & 3u) ||
+  if (!out_len_dev || !dst || !off_out || ((uintptr_t)dst & 15u) || ((uintptr_t)off_out & 7u) || ((uintptr_t)len_out & 3u) ||
       (wire && ((uintptr_t)wire->hdr & 7u)))
     return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "plan_render_*packed: bad arguments (16-byte aligned destination, 8-byte aligned offsets / headers)");
   if (!p->pack_cursor) {
@@ -672,7 +677,7 @@ int asciichat_hip_plan_render_packets_packed(asciichat_hip_plan_t *p, uint8_t *s
                                              uint32_t *len_out, void *stream) {
   if (!p || !hdr_out_dev || !dst)
     return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "plan_render_packets_packed: no header buffer or destination");
-  if (crc_out_dev && plan_packs_this_call(p, dst)) {
+  if (crc_out_dev && plan_packs_this_call(p, dst, off_out)) {
     const achip_wire_t wire = {crc_out_dev, dims_dev, hdr_out_dev, packet_crc_out_dev};
     return plan_render_pack(p, out_len_dev, &wire, dst, dst_capacity, off_out, len_out, stream);
   }
@@ -1092,7 +1097,7 @@ int asciichat_hip_pack_frames(const uint8_t *slab_dev, size_t stride, const uint
 
 int asciichat_hip_plan_render_packed(asciichat_hip_plan_t *p, uint8_t *slab_dev, size_t out_stride, uint32_t *out_len_dev,
                                      uint8_t *dst, size_t dst_capacity, uint64_t *off_out, uint32_t *len_out, void *stream) {
-  if (dst && plan_packs_this_call(p, dst))
+  if (dst && plan_packs_this_call(p, dst, off_out))
     return plan_render_pack(p, out_len_dev, NULL, dst, dst_capacity, off_out, len_out, stream);
   int rc = asciichat_hip_plan_render(p, slab_dev, out_stride, out_len_dev, stream);
   if (!rc)

@@ -58,7 +58,14 @@ WORKLOADS = {
     # what a server tick renders after the sampled-image ingest (frame_dense.c): the source IS the 80x24 image the target
     # samples of the client's 1080p frame, ratios 1.0 -- 5.6 KB of dense reads per frame instead of 1 920 lone dwords
     "sampled_80x24_truecolor": (80, 24, 80, 24, 3, 0),
+    # configs[2] / configs[4] from sampled images: the kernels where HBM line fills are NOT the limit
+    "sampled_200x60_truecolor": (200, 60, 200, 60, 3, 0),
+    "sampled_400x240_halfblock": (400, 240, 400, 120, 3, 2),
 }
+# batch-size axis: the 1-GPU stand-in for a scaling curve -- where each kernel saturates
+SWEEP_WORKLOADS = ("1080p_80x24_truecolor", "4k_200x60_truecolor", "sampled_80x24_truecolor", "sampled_200x60_truecolor",
+                   "sampled_400x240_halfblock")
+SWEEP_MAX_SET_BYTES = 110e9  # one input set of the largest point (4096 x 4K RGB24 = 102 GB of the 288 GB HBM)
 INPUT_KINDS = ("noise", "smooth", "bars", "gray")
 
 
@@ -296,6 +303,44 @@ def free_workload(torch, res):
         p.close()
     res.pop("sets", None)
     torch.cuda.empty_cache()
+
+
+def batch_sweep(torch, pkg, batches, names=SWEEP_WORKLOADS, streams=4):
+    """frames/s and roofline fraction over the batch size (frames per launch): every BASELINE number is quoted at 256
+    frames = one workgroup per CU = ONE wave of workgroups; larger launches show the kernels' asymptotic rate.  Input
+    sets shrink with the batch so that a point's sources stay below SWEEP_MAX_SET_BYTES in total."""
+    out = {}
+    for name in names:
+        sw, sh = WORKLOADS[name][:2]
+        row = {}
+        for b in batches:
+            set_bytes = b * sw * sh * 3
+            if set_bytes > SWEEP_MAX_SET_BYTES:
+                row[str(b)] = {"skipped": f"one input set would be {set_bytes / 1e9:.0f} GB"}
+                continue
+            nsets = streams * max(1, min(3, int(SWEEP_MAX_SET_BYTES // (streams * set_bytes))))
+            if nsets * set_bytes > SWEEP_MAX_SET_BYTES:
+                nsets, st = 1, 1
+            else:
+                st = streams
+            steps = max(4, min(40, 40 * 256 // b))
+            t_w = time.perf_counter()
+            try:
+                r = run_workload(torch, pkg, name, b, steps, 4, 5, None, nsets=nsets, streams=st, serial_leg=False,
+                                 verify=(b == batches[0]))
+            except (RuntimeError, AssertionError) as e:
+                row[str(b)] = {"error": str(e)[:160]}
+                torch.cuda.empty_cache()
+                continue
+            d = summarize(r)
+            row[str(b)] = {"frames_per_s": d["frames_per_s"], "kernel_ms": d["kernel_ms"], "roofline_frac": d["roofline_frac"],
+                           "roofline_GBps": d["roofline_GBps"], "launches_in_flight": st, "input_sets": nsets,
+                           "steps_per_region": steps, "kernel_variant": d["kernel_variant"],
+                           "alg_bytes_per_launch": d["alg_bytes_per_launch"]}
+            free_workload(torch, r)
+            print(f"[bench] sweep {name} batch {b}: {time.perf_counter() - t_w:.1f} s", file=sys.stderr)
+        out[name] = row
+    return out
 
 
 def time_with_d2h(torch, plan, n, steps):
@@ -925,8 +970,8 @@ LINE_TARGET_BYTES = 4096  # the stdout line the driver parses: small enough to s
 LINE_HARD_LIMIT_BYTES = 8192
 _COMPACT_TOP = ("metric", "value", "unit", "n_gpus", "rccl_ranks", "steps", "warmup", "ms_per_step", "higher_is_better",
                 "scaling", "vs_baseline", "dtype", "data")
-_COMPACT_ROOFLINE = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "alg_bytes_per_launch",
-                     "kernel_ms", "launches_in_flight")
+_COMPACT_ROOFLINE = ("bound", "achieved", "peak", "unit", "frac", "frac_profile", "frac_profile_source", "traffic",
+                     "traffic_source", "alg_bytes_per_launch", "kernel_ms", "launches_in_flight")
 _COMPACT_CPU = ("value", "unit", "cores", "kind", "sample", "cpu_model")
 
 
@@ -977,6 +1022,11 @@ def compact_line(full):
             digest[f"grid9:{leg}"] = [_r(g["frames_per_s"], 4), _r(g.get("roofline_frac"), 3)]
     if digest:
         line["other_workloads_fps_frac"] = digest
+    sw = full.get("batch_sweep")
+    if sw:  # per workload: [frames/s, roofline fraction] at every batch size, in the order of "batches"
+        line["batch_sweep"] = {"batches": sw.get("batches"),
+                               "fps_frac": {n: [[_r(p.get("frames_per_s"), 4), _r(p.get("roofline_frac"), 3)] for p in row.values()]
+                                            for n, row in (sw.get("workloads") or {}).items()}}
     for leg in ("tick_e2e", "wire_stage", "with_d2h_packed"):
         e = full.get(leg)
         if not isinstance(e, dict):
@@ -1005,8 +1055,8 @@ def emit_text(full, extra_path):
     line = compact_line(full)
     if extra_path:
         line["extra"] = os.path.basename(extra_path)
-    for drop in (None, "other_workloads_fps_frac", "tick_e2e", "wire_stage", "with_d2h_packed", "one_launch_at_a_time",
-                 "multi_gpu"):
+    for drop in (None, "tick_e2e", "with_d2h_packed", "wire_stage", "other_workloads_fps_frac", "batch_sweep",
+                 "one_launch_at_a_time", "multi_gpu"):
         if drop:
             line.pop(drop, None)
         text = json.dumps(line, separators=(",", ":"))
@@ -1044,6 +1094,9 @@ def main():
                          "the requested burst length (--steps) in an untimed calibration; 1 = one launch at a time")
     ap.add_argument("--extra", default=os.path.join(ROOT, "bench_extra.json"),
                     help="side file for everything that is not the contract's line (legs, tables, notes); '' = none")
+    ap.add_argument("--batch-sweep", default="256,1024,4096",
+                    help="frames per launch for the batch-size axis of the headline, configs[2] and the sampled-image shapes "
+                         "(N = 1, the default workload only); '' = none")
     ap.add_argument("--no-hot", action="store_true",
                     help="skip the one-launch-at-a-time / same-batch comparison legs (profiling runs)")
     args = ap.parse_args()
@@ -1200,6 +1253,12 @@ def main():
             # WRITE_SIZE) of this very command: not collected by this run, labelled with its file
             line["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
             line["roofline"]["traffic_source"] = "committed rocprofv3 --pmc passes: " + tr.get("file", "profiles/")
+        fp = cp.get("frac_profile") or {}
+        if "busy_us_per_launch" in fp and args.batch == 256 and args.input == "noise" and not args.aspect:
+            # the same fraction from the COMMITTED kernel trace instead of this run's HIP events: algorithmic bytes of this
+            # run / busy time per launch of the trace (union of the dispatch intervals / launches, scripts/trace_stats.py)
+            line["roofline"]["frac_profile"] = res["alg_bytes_per_launch"] / (fp["busy_us_per_launch"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+            line["roofline"]["frac_profile_source"] = fp.get("file", "profiles/")
     if rank == 0 and world == 1:
         if not args.no_d2h:
             d2h_s, d2h_bytes = time_with_d2h(torch, res["plans"][0], args.batch, 50)
@@ -1256,6 +1315,11 @@ def main():
         if args.others:
             others["grid9_1080p_160x48_truecolor"] = run_grid9(torch, pkg, 20, 5)
         line["other_workloads"] = others
+        if args.batch_sweep and args.workload == "1080p_80x24_truecolor" and args.input == "noise" and not args.aspect:
+            bl = [int(v) for v in args.batch_sweep.split(",") if v.strip()]
+            line["batch_sweep"] = {"batches": bl, "workloads": batch_sweep(torch, pkg, bl, streams=args.streams or 4),
+                                   "note": "frames per launch; uniform-noise inputs, four launches in flight where the input "
+                                           "sets fit; roofline_frac = algorithmic bytes per launch / HIP-event time / 8 TB/s"}
     else:
         free_workload(torch, res)
     if rank == 0:

@@ -381,7 +381,9 @@ int asciichat_hip_plan_render_packets(asciichat_hip_plan_t *plan, uint8_t *out_d
  *       for a destination in device memory (into mapped host memory form (2) is the faster one: a workgroup of (1) holds
  *       its CU until its stores have crossed PCIe).  The slab is NOT written
  *       (slab_dev may be NULL); frames lie in dst back to back in the order in which they FINISH, every start 16-byte
- *       aligned: off_out[i] says where frame i went (off_out is needed to find a frame), off_out[n] the total.  The
+ *       aligned: off_out[i] says where frame i went, off_out[n] the total.  off_out is the only way to find a frame of
+ *       this form, so a call WITHOUT off_out never takes it: it keeps forms (2) / (3), whose layout pack_frames documents
+ *       (frame i behind the 16-byte rounded lengths of frames 0..i-1), whatever set_exact_length says.  The
  *       padding behind a frame is zeros.  asciichat_hip_plan_set_exact_length(plan, 0) keeps such a plan on (2).
  *   (2) render (+ fused wire stage) and pack_frames where the render kernel carries the CRC,
  *   (3) render and ONE pass that checksums and packs otherwise (plans of the run-structured modes, row bands);

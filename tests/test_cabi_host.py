@@ -61,6 +61,21 @@ def test_library_exports_every_declared_symbol(pkg):
     assert " g_default_luminance_palette" in nm
 
 
+def test_library_exports_only_the_abi(pkg):
+    """ascii-chat_amd/exports.map: the defined dynamic symbols are the drop-in surface the public headers declare, the
+    batch API (asciichat_hip_*) and the host helpers (achip_*) -- no kernel launch stubs, no cross-file helpers."""
+    nm = subprocess.run(["nm", "-D", "--defined-only", pkg.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    syms = [l.split()[-1] for l in nm.splitlines() if l.strip()]
+    declared = set()
+    for h in ("asciichat_hip.h", "asciichat_render.h", "achip_host.h"):
+        declared.update(declared_functions(os.path.join(ROOT, "include", h)))
+    declared.add("g_default_luminance_palette")
+    stray = [s for s in syms if not s.startswith(("asciichat_hip_", "achip_")) and s not in declared]
+    assert not stray, stray
+    assert not [s for s in syms if s.startswith("_Z")], "C++ symbols leave the library"
+    assert len(syms) < 260, len(syms)
+
+
 def test_no_gpu_means_loud_failure_not_fallback(pkg):
     L = pkg.lib()
     if L.asciichat_hip_device_count() > 0:

@@ -1187,6 +1187,50 @@ def test_exact_length_frames_full_batch(gpu):
         plan.close()
 
 
+def test_packed_without_offsets_keeps_the_documented_order(gpu):
+    """A caller that passes no off_out relies on pack_frames' layout (frame i behind the 16-byte rounded lengths of the
+    frames before it).  The one-launch form lays frames out in completion order, so such a call must not take it -- not by
+    default and not under set_exact_length(1)."""
+    pkg, torch = gpu
+    stream = torch.cuda.current_stream().cuda_stream
+    n, sw, sh, W, H = 64, 640, 360, 80, 24
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    frames_t = torch.randint(0, 256, (n, sh, sw, 3), dtype=torch.uint8, device="cuda", generator=g)
+    frames_t[3] = 0  # short frames between long ones: completion order differs from index order
+    frames_t[7] = torch.from_numpy(orc.frame_bars(sw, sh, 6)).cuda()
+    descs = [pkg.frame_setup(frames_t.data_ptr() + i * sh * sw * 3, sw, sh, W, H, 0, False, False, False) for i in range(n)]
+    plan = pkg.Plan(1, orc.PALETTE_STANDARD, descs)
+    assert plan.exact_length
+    stride = plan.stride
+    exp = [orc.convert_with_caps(frames_t[i].cpu().numpy(), W, H, 3, 0, False, False, False) for i in range(n)]
+    d32 = torch.tensor([[W, H]] * n, dtype=torch.int32, device="cuda")
+    for force in (-1, 1):
+        plan.set_exact_length(force)
+        for wire in (False, True):
+            slab = torch.zeros(n * stride, dtype=torch.uint8, device="cuda")
+            ln = torch.zeros(n, dtype=torch.int32, device="cuda")
+            dst = torch.full((n * stride,), 0xEE, dtype=torch.uint8, device="cuda")
+            if wire:
+                crc = torch.zeros(n, dtype=torch.int32, device="cuda")
+                hdr = torch.zeros(n * 24, dtype=torch.uint8, device="cuda")
+                plan.render_packets_packed(slab.data_ptr(), stride, ln.data_ptr(), d32.data_ptr(), crc.data_ptr(), hdr.data_ptr(),
+                                           None, dst.data_ptr(), n * stride, None, None, stream)
+            else:
+                plan.render_packed(slab.data_ptr(), stride, ln.data_ptr(), dst.data_ptr(), n * stride, None, None, stream)
+            torch.cuda.synchronize()
+            v = dst.cpu().numpy()
+            lens = ln.cpu().numpy().astype(np.uint32)
+            at = 0
+            for i in range(n):
+                assert int(lens[i]) == len(exp[i])
+                assert v[at:at + len(exp[i])].tobytes() == exp[i], (force, wire, i)
+                at += (len(exp[i]) + 15) // 16 * 16
+            if wire:
+                assert [int(c) & 0xFFFFFFFF for c in crc.cpu().numpy()] == [orc.crc32c(e) for e in exp]
+    plan.close()
+
+
 def test_frame_table_sampled_image_ingest(gpu):
     """frame_dense.c on the MI355X: a tick's clients staged as the images their targets sample
     -- one pinned block, ONE DMA, NO kernel -- and rendered from those images: bytes equal the oracle's on the original
