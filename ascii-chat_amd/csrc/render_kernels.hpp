@@ -209,6 +209,7 @@ __device__ inline uint32_t dec_table_entry(uint32_t v) {
 }
 
 struct CountSink {
+  static constexpr bool FAST_DEC = false; /* (render_rows.hpp's sinks take a truecolor SGR's numbers from wider tables) */
   uint32_t n;
   __device__ inline uint32_t lookup(uint32_t v) const { return 1u + (v >= 10u) + (v >= 100u); } /* digit count */
   template <int K> __device__ inline void c(uint32_t) { n += (uint32_t)K; }
@@ -217,6 +218,7 @@ struct CountSink {
 };
 
 template <int DEC_OFF, int DUMMY_OFF> struct FastSink {
+  static constexpr bool FAST_DEC = false;
   uint32_t a;     /* LDS byte address of the next byte; the token neither wraps nor leaves the window */
   uint32_t dummy; /* LDS byte address that swallows predicated-off stores */
   __device__ inline uint32_t lookup(uint32_t v) const { return lds_ptr<const uint32_t>(DEC_OFF)[v]; }
@@ -259,6 +261,7 @@ template <int DEC_OFF, int DUMMY_OFF> struct FastSink {
  * bank conflicts (64 lanes land 19-41 bytes apart), so fewer instructions win even though each field costs a
  * few more VALU operations.  Every field is at most 4 bytes, so at most one dword completes per field. */
 template <int DEC_OFF> struct PackSink {
+  static constexpr bool FAST_DEC = false;
   uint32_t a;   /* LDS byte address (4-byte aligned) of the window's first byte */
   uint32_t nb;  /* bytes pending in the window, 0..3 between fields                */
   uint64_t acc; /* pending bytes, first in the low byte                            */
@@ -826,6 +829,10 @@ template <int MODE, class L> __device__ inline Tok token_payload(uint32_t flags,
 /* ESC[38;2;R;G;Bm / ESC[48;2;R;G;Bm  (append_truecolor_fg/bg ansi.c:143-193; emit_set_fg/bg output_buffer.c:186-214).
  * ROOM = bytes of the same token guaranteed to follow the SGR. */
 template <int ROOM, class S> __device__ inline void put_sgr_true(S &s, bool bg, uint32_t rgb) {
+  if constexpr (S::FAST_DEC) {
+    s.template sgr_true<ROOM>(bg, rgb);
+    return;
+  }
   const uint32_t e0 = s.lookup(px_r(rgb)), e1 = s.lookup(px_g(rgb)), e2 = s.lookup(px_b(rgb));
   s.template c<4>(bg ? 0x38345B1Bu : 0x38335B1Bu); /* ESC [ 3|4 8 */
   s.template c<3>(0x003B323Bu);                    /* ; 2 ;       */

@@ -54,7 +54,13 @@ template <int MODE, int WAVES, bool CRC = false> struct RLds {
   static constexpr int o_glyph64 = o_glyph + 256 * 4;
   static constexpr int o_ramp = o_glyph64 + 64 * 4;
   static constexpr int o_dec = o_ramp + 64;
-  static constexpr int o_flags = o_dec + 256 * 4; /* [+16 ..] swallows predicated-off byte stores */
+  /* truecolor half blocks: a channel's decimal field ready to store -- {digits + terminator, zero padded; byte count} per
+   * value for ';' (R, G) and for 'm' (B) -- and the byte counts alone for the length pass (RowsFastSink / RowsCountSink) */
+  static constexpr bool NUM8 = MODE == ACHIP_MODE_HB_TRUE;
+  static constexpr int o_num_semi = o_dec + 256 * 4;
+  static constexpr int o_num_m = o_num_semi + (NUM8 ? 256 * 8 : 0);
+  static constexpr int o_num_len = o_num_m + (NUM8 ? 256 * 8 : 0);
+  static constexpr int o_flags = o_num_len + (NUM8 ? 256 : 0); /* [+16 ..] swallows predicated-off byte stores */
   static constexpr int o_comp = o_flags + 32 + 64 * 4;
   static constexpr int o_tab = o_comp + ACHIP_COMP_LDS_BYTES;
   static constexpr int o_slice = o_tab;
@@ -71,6 +77,49 @@ template <int MODE, int WAVES, bool CRC = false> struct RLds {
   static constexpr int bytes = bytes_for(ACHIP_STREAM_MAXBLK);
   static_assert(STAGE % 16 == 0 && o_tab % 16 == 0 && TAB_BYTES % 16 == 0, "16-byte aligned areas");
   static_assert(bytes <= 160 * 1024, "one workgroup's LDS");
+};
+
+/* The rows kernel is bound by VALU issue, not by the LDS pipe (profiles/r03_k5_sq_counters.txt), so its sinks trade vector
+ * arithmetic for table reads: a truecolor SGR's three decimal fields come out of LDS ready to store (text with its
+ * terminator + byte count: one ds_read_b64, one shift, one add per field instead of the six operations FastSink::num
+ * assembles it with), and the length pass adds three byte counts instead of running six compare / add-carry pairs. */
+template <int LEN_OFF> struct RowsCountSink : CountSink {
+  static constexpr bool FAST_DEC = LEN_OFF >= 0;
+  template <int ROOM> __device__ inline void sgr_true(bool, uint32_t rgb) {
+    const uint8_t *len = lds_ptr<const uint8_t>(LEN_OFF >= 0 ? LEN_OFF : 0);
+    n += 7u + len[px_r(rgb)] + len[px_g(rgb)] + len[px_b(rgb)];
+  }
+};
+template <int DEC_OFF, int DUMMY_OFF, int SEMI_OFF, int M_OFF> struct RowsFastSink : FastSink<DEC_OFF, DUMMY_OFF> {
+  static constexpr bool FAST_DEC = SEMI_OFF >= 0;
+  using FastSink<DEC_OFF, DUMMY_OFF>::a;
+  __device__ inline void field4(uint2 e) { /* <= 4 bytes; whatever lies behind the field's own is overwritten by the token's next field */
+    const uint32_t w = e.x >> 8;
+    lds_store_byte<0, false>(a, e.x);
+    lds_store_byte<1, false>(a, w);
+    lds_store_byte<2, true>(a, e.x);
+    lds_store_byte<3, true>(a, w);
+    a += e.y;
+  }
+  template <int ROOM> __device__ inline void sgr_true(bool bg, uint32_t rgb) {
+    if constexpr (ROOM < 2) { /* (the per-cell modes' SGRs, compiled for no mode of this kernel: the last field would store four bytes) */
+      const uint32_t e0 = this->lookup(px_r(rgb)), e1 = this->lookup(px_g(rgb)), e2 = this->lookup(px_b(rgb));
+      this->template c<4>(bg ? 0x38345B1Bu : 0x38335B1Bu);
+      this->template c<3>(0x003B323Bu);
+      this->template num<2>(e0, ';');
+      this->template num<2>(e1, ';');
+      this->template num<ROOM>(e2, 'm');
+      return;
+    }
+    const uint2 e0 = lds_ptr<const uint2>(SEMI_OFF >= 0 ? SEMI_OFF : 0)[px_r(rgb)];
+    const uint2 e1 = lds_ptr<const uint2>(SEMI_OFF >= 0 ? SEMI_OFF : 0)[px_g(rgb)];
+    const uint2 e2 = lds_ptr<const uint2>(M_OFF >= 0 ? M_OFF : 0)[px_b(rgb)];
+    this->template c<4>(bg ? 0x38345B1Bu : 0x38335B1Bu); /* ESC [ 3|4 8 */
+    this->template c<3>(0x003B323Bu);                    /* ; 2 ;       */
+    field4(e0);
+    field4(e1);
+    field4(e2);
+  }
 };
 
 /* run key comparison of two cells (render_kernels.hpp same_run, on registers) */
@@ -204,15 +253,24 @@ __device__ inline Tok rows_token_payload(uint32_t flags, uint32_t rep, uint32_t 
   return t;
 }
 
-/* index of the highest set bit of m strictly below bit position `lane`, or -1 */
-__device__ inline int rows_prev_bit(uint64_t m, int lane) {
-  const uint64_t v = m & ((1ull << lane) - 1ull);
-  return v ? 63 - __clzll((long long)v) : -1;
+/* the bits strictly below / above a lane's own, made once per kernel: the scans below then cost two ANDs with the
+ * (scalar) mask instead of 64-bit shifts by the lane number */
+struct LaneMasks {
+  uint32_t below_lo, below_hi, above_lo, above_hi;
+};
+__device__ inline LaneMasks lane_masks(int lane) {
+  const uint64_t below = (1ull << lane) - 1ull, above = ~(below | (1ull << lane));
+  return LaneMasks{(uint32_t)below, (uint32_t)(below >> 32), (uint32_t)above, (uint32_t)(above >> 32)};
 }
-/* index of the lowest set bit of m strictly above bit position `lane`, or -1 */
-__device__ inline int rows_next_bit(uint64_t m, int lane) {
-  const uint64_t v = lane < 63 ? (m >> (lane + 1)) << (lane + 1) : 0ull;
-  return v ? __ffsll((unsigned long long)v) - 1 : -1;
+/* index of the highest set bit of m strictly below the lane's bit position, or -1 */
+__device__ inline int rows_prev_bit(uint64_t m, const LaneMasks &lm) {
+  const uint32_t lo = (uint32_t)m & lm.below_lo, hi = (uint32_t)(m >> 32) & lm.below_hi;
+  return hi ? 63 - __clz((int)hi) : (lo ? 31 - __clz((int)lo) : -1);
+}
+/* index of the lowest set bit of m strictly above the lane's bit position, or -1 */
+__device__ inline int rows_next_bit(uint64_t m, const LaneMasks &lm) {
+  const uint32_t lo = (uint32_t)m & lm.above_lo, hi = (uint32_t)(m >> 32) & lm.above_hi;
+  return lo ? __ffs((int)lo) - 1 : (hi ? 31 + __ffs((int)hi) : -1);
 }
 
 /* two 512-thread workgroups per CU need <= 128 VGPRs (4 waves per SIMD): left alone the compiler spreads the 7-slot
@@ -322,51 +380,119 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
   src.nt = f.x_ratio >= ((64u << 16) + 2u) / 3u;
   CompHead chead = {};
 
-  /* slot s = k * 64 + lane of a block is cell s of its rows: row s / wp, column s % wp -- the same for every block, so
-   * one division per lane per frame, then constant steps */
-  const uint32_t q64 = 64u / uwp, r64 = 64u - q64 * uwp;
-  auto advance = [&](CellPos p) {
-    p.xp += r64;
-    p.rr += q64;
-    const bool wrap = p.xp >= uwp;
-    p.xp -= wrap ? uwp : 0u;
-    p.rr += wrap ? 1u : 0u;
-    return p;
+  /* slot s = k * 64 + lane of a block is cell s of its rows: row s / wp, column s % wp -- the same for every block.  So
+   * everything a cell's position decides is decided ONCE per frame and kept in one register per slot (the passes below
+   * recomputed row and column five times per block: ~200 of the block's 4 400 VALU instructions, and the sampler's
+   * horizontal index ~300 more):
+   *   bits 15..0   the sample's byte offset in its source row, 3 * min(x * x_ratio >> 16, src_w - 1) with the flip folded
+   *                in (image.c:293-325; < 30 000: the host checks the source size) -- GENERIC: the column x itself
+   *   bit  16      padding pseudo-cell (column < pad_left)         bit 17   first pixel of the row, or in front of it
+   *   bit  18      last cell of the row                            bits 31..23   text row inside the block
+   * A cell exists in block b iff its row is below the block's row count: ONE unsigned compare of the whole word. */
+  constexpr uint32_t CM_PAD = 1u << 16, CM_FIRST = 1u << 17, CM_END = 1u << 18;
+  constexpr int CM_ROW = 23;
+  uint32_t cm[CPL];
+  {
+    const uint32_t q64 = 64u / uwp, r64 = 64u - q64 * uwp;
+    uint32_t rr = (uint32_t)lane / uwp, xp = (uint32_t)lane - rr * uwp; /* one division per lane per frame, then constant steps */
+#pragma unroll
+    for (int k = 0; k < CPL; k++) {
+      uint32_t lo = 0;
+      if (xp >= pad_left) {
+        lo = xp - pad_left;
+        if (!GENERIC) {
+          const uint32_t sx = min((lo * src.xr) >> 16, src.w1);
+          lo = __umul24(src.flip_x ? src.w1 - sx : sx, 3u);
+        }
+      }
+      cm[k] = lo | (xp < pad_left ? CM_PAD : 0u) | (xp <= pad_left ? CM_FIRST : 0u) | (xp == uwp - 1u ? CM_END : 0u) |
+              (min(rr, 511u) << CM_ROW);
+      xp += r64;
+      rr += q64;
+      const bool wrap = xp >= uwp;
+      xp -= wrap ? uwp : 0u;
+      rr += wrap ? 1u : 0u;
+    }
+  }
+  auto block_rows = [&](int blk) { return (uint32_t)min(rpb, rows - blk * rpb); };
+  /* ROW1: every block is exactly one text row (4K -> 400x120 half blocks in 448 slots, 200x60 in 256): the source rows of
+   * a block are wave-uniform, so a sample's address is (scalar row base) + (the slot's byte offset) and costs no vector
+   * arithmetic at all.  The dword is requested one byte early (finish: >> 8) so that the last pixel's request stays inside
+   * the buffer; only the buffer's very first pixel cannot be (row offset 0, byte offset 0): it asks for offset 1 of the
+   * early base -- the pixel itself -- and is finished by masking. */
+#ifdef ACHIP_ROWS_COUNT_ROW1 /* diagnostics (scripts/isa_lines.py): only the one-row path with cached loads is compiled, so that
+                               the listing's static instruction counts are the counts a 4K -> 400x120 block executes */
+  const bool row1 = true;
+#else
+  const bool row1 = !GENERIC && rpb == 1;
+#endif
+  auto src_row = [&](uint32_t y) { /* wave-uniform */
+    const uint32_t sy = min((y * src.yr) >> 16, src.h1);
+    return (src.flip_y ? src.h1 - sy : sy) * src.stride;
   };
-  CellPos pos0; /* slot k = 0 of this lane, row relative to the block */
-  pos0.rr = (uint32_t)lane / uwp;
-  pos0.xp = (uint32_t)lane - pos0.rr * uwp;
-  auto block_cells = [&](int blk) { return (uint32_t)min(rpb, rows - blk * rpb) * uwp; };
 
   /* request the samples of block `blk`: nothing here consumes loaded data */
   auto issue = [&](auto nt_tag, int blk, uint32_t (&rawT)[CPL], uint32_t (&rawB)[CPL], uint32_t &kinds) {
     constexpr bool NT = decltype(nt_tag)::value;
     kinds = 0;
-    const uint32_t ncb = block_cells(blk), row0 = (uint32_t)(blk * rpb);
-    CellPos p = pos0;
+    const uint32_t vlim = block_rows(blk) << CM_ROW, row0 = (uint32_t)(blk * rpb);
+    if (row1) {
+      const uint32_t yt = HB ? 2u * row0 : row0;
+      const bool two = HB && yt + 1u < (uint32_t)f.out_h; /* odd height: the last row's bottom half repeats the top (halfblock.c:81-88) */
+      const uint32_t rot = src_row(yt), rob = two ? src_row(yt + 1u) : rot;
+      const uint8_t *bt = src.base + rot - 1, *bb = src.base + rob - 1;
+      const uint32_t ft = rot == 0u ? 1u : 0u, fb = rob == 0u ? 1u : 0u;
+#pragma unroll
+      for (int k = 0; k < CPL; k++) {
+        rawT[k] = 0;
+        rawB[k] = 0;
+        if (cm[k] < vlim && !(cm[k] & CM_PAD)) {
+          const uint32_t xo = cm[k] & 0xFFFFu;
+          const ACHIP_GLOBAL uint8_t *pt_ = (const ACHIP_GLOBAL uint8_t *)bt + max(xo, ft);
+          rawT[k] = NT ? load_u32_unaligned_nt((const uint8_t *)pt_) : ((const ACHIP_GLOBAL unaligned_u32 *)pt_)->v;
+          if (two) {
+            const ACHIP_GLOBAL uint8_t *pb_ = (const ACHIP_GLOBAL uint8_t *)bb + max(xo, fb);
+            rawB[k] = NT ? load_u32_unaligned_nt((const uint8_t *)pb_) : ((const ACHIP_GLOBAL unaligned_u32 *)pb_)->v;
+          }
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int k = 0; k < CPL; k++) {
       rawT[k] = 0;
       rawB[k] = 0;
-      if ((uint32_t)(64 * k + lane) < ncb && p.xp >= pad_left) {
-        const uint32_t x = p.xp - pad_left, r = row0 + p.rr;
+      if (cm[k] < vlim && !(cm[k] & CM_PAD)) {
+        const uint32_t lo = cm[k] & 0xFFFFu, r = row0 + (cm[k] >> CM_ROW);
+        auto request = [&](uint32_t y, uint32_t &kind) {
+          if (GENERIC)
+            return stream_request<true, NT, L::o_comp>(f, src, lo, y, kind, chead);
+          uint32_t sy = min((y * src.yr) >> 16, src.h1);
+          sy = src.flip_y ? src.h1 - sy : sy;
+          const uint32_t a = __umul24(sy, src.stride) + lo; /* stream_request's address, the horizontal part from the record */
+          const uint32_t back = a != 0u ? 1u : 0u;
+          kind = back ? RAW_BACK : RAW_FIRST;
+          const ACHIP_GLOBAL uint8_t *q = (const ACHIP_GLOBAL uint8_t *)src.base + (a - back);
+          return NT ? load_u32_unaligned_nt((const uint8_t *)q) : ((const ACHIP_GLOBAL unaligned_u32 *)q)->v;
+        };
         uint32_t kind = RAW_FINAL;
-        rawT[k] = stream_request<GENERIC, NT, L::o_comp>(f, src, x, HB ? 2u * r : r, kind, chead);
+        rawT[k] = request(HB ? 2u * r : r, kind);
         kinds |= kind << (2 * k);
         if (HB) {
           uint32_t kb = RAW_TOP; /* odd height: the last text row's bottom half repeats the top (halfblock.c:81-88) */
           if (2u * r + 1u < (uint32_t)f.out_h)
-            rawB[k] = stream_request<GENERIC, NT, L::o_comp>(f, src, x, 2u * r + 1u, kb, chead);
+            rawB[k] = request(2u * r + 1u, kb);
           kinds |= kb << (2 * (CPL + k));
         }
       }
-      p = advance(p);
     }
   };
   auto issue_any = [&](int blk, uint32_t (&rawT)[CPL], uint32_t (&rawB)[CPL], uint32_t &kinds) {
+#ifndef ACHIP_ROWS_COUNT_ROW1
     if (!GENERIC && src.nt)
       issue(StreamTagNT{}, blk, rawT, rawB, kinds);
     else
+#endif
       issue(StreamTagCached{}, blk, rawT, rawB, kinds);
   };
   static_assert(4 * CPL <= 32, "two bits per sample in one word");
@@ -387,6 +513,12 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
     if (tid + k * BLOCK < 256) {
       glyph[tid + k * BLOCK] = lut_g[k];
       lds_ptr<uint32_t>(L::o_dec)[tid + k * BLOCK] = dec_table_entry((uint32_t)(tid + k * BLOCK));
+      if (L::NUM8) {
+        const uint32_t e = dec_entry((uint32_t)(tid + k * BLOCK)), nd = e >> 24, dg = e & 0x00FFFFFFu;
+        lds_ptr<uint2>(L::o_num_semi)[tid + k * BLOCK] = make_uint2(dg | ((uint32_t)';' << (8u * nd)), nd + 1u);
+        lds_ptr<uint2>(L::o_num_m)[tid + k * BLOCK] = make_uint2(dg | ((uint32_t)'m' << (8u * nd)), nd + 1u);
+        lds_ptr<uint8_t>(L::o_num_len)[tid + k * BLOCK] = (uint8_t)(nd + 1u);
+      }
     }
   if (tid < 64) {
     glyph64[tid] = lut_g64;
@@ -418,6 +550,7 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
       issue_any(wave, rawT, rawB, kinds);
   }
 
+  const LaneMasks lm = lane_masks(lane);
   const uint32_t stage_off = (uint32_t)(L::o_stage + wave * L::STAGE);
   const uint32_t stage_addr = lds_base_addr() + stage_off;
   const uint32_t dummy_addr = lds_base_addr() + (uint32_t)L::o_flags + 16u + 4u * (uint32_t)lane;
@@ -428,20 +561,39 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
     if (blk + WAVES < nblk)
       issue_any(blk + WAVES, rawT_n, rawB_n, kinds_n);
 
-    const uint32_t ncb = block_cells(blk), row0 = (uint32_t)(blk * rpb);
+    const uint32_t nrb = block_rows(blk), ncb = nrb * uwp, row0 = (uint32_t)(blk * rpb), vlim = nrb << CM_ROW;
     /* ---- samples -> pixels with the mode's run key in bits 31..24 (as the phase kernel parks them in LDS) */
     uint32_t pt[CPL], pb[CPL];
     {
-      CellPos p = pos0;
+      const uint32_t yt = HB ? 2u * row0 : row0;
+      const bool two = HB && yt + 1u < (uint32_t)f.out_h;
+      const bool ft = row1 && src_row(yt) == 0u, fb = row1 && two && src_row(yt + 1u) == 0u; /* wave-uniform */
+      const bool tint = !GENERIC && (f.ops & ACHIP_OP_TINT) != 0u;
 #pragma unroll
       for (int k = 0; k < CPL; k++) {
-        const bool pix = (uint32_t)(64 * k + lane) < ncb && p.xp >= pad_left;
-        const uint32_t kt = (kinds >> (2 * k)) & 3u, kb = (kinds >> (2 * (CPL + k))) & 3u;
+        const bool pix = cm[k] < vlim && !(cm[k] & CM_PAD);
         uint32_t t = 0, b = 0;
         if (pix) {
-          t = sample_finish<GENERIC>(f, rawT[k], kt);
-          if (HB)
-            b = kb == RAW_TOP ? t : sample_finish<GENERIC>(f, rawB[k], kb);
+          if (row1) { /* requested one byte early (issue) -- except the buffer's first pixel */
+            t = rawT[k] >> 8;
+            if (ft && (cm[k] & 0xFFFFu) == 0u)
+              t = rawT[k] & 0x00FFFFFFu;
+            if (tint)
+              t = tint_pixel(t, f.ops);
+            b = t;
+            if (two) {
+              b = rawB[k] >> 8;
+              if (fb && (cm[k] & 0xFFFFu) == 0u)
+                b = rawB[k] & 0x00FFFFFFu;
+              if (tint)
+                b = tint_pixel(b, f.ops);
+            }
+          } else {
+            const uint32_t kt = (kinds >> (2 * k)) & 3u, kb = (kinds >> (2 * (CPL + k))) & 3u;
+            t = sample_finish<GENERIC>(f, rawT[k], kt);
+            if (HB)
+              b = kb == RAW_TOP ? t : sample_finish<GENERIC>(f, rawB[k], kb);
+          }
           if (MODE == ACHIP_MODE_HB_256) {
             t |= quant256(t) << 24;
             b |= quant256(b) << 24;
@@ -453,8 +605,7 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
           }
         }
         pt[k] = t;
-        pb[k] = b;
-        p = advance(p);
+        pb[k] = HB ? b : 0u;
       }
     }
     /* ---- run heads: one ballot per slot; a cell starts a run at or in front of its row's first pixel, or where its
@@ -462,18 +613,14 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
     uint64_t hm[CPL], tm[CPL];
     auto left_T = [&](int k) { return wave_shift_up1(pt[k], k > 0 ? wave_read_lane(pt[k > 0 ? k - 1 : 0], 63) : 0u); };
     auto left_B = [&](int k) { return HB ? wave_shift_up1(pb[k], k > 0 ? wave_read_lane(pb[k > 0 ? k - 1 : 0], 63) : 0u) : 0u; };
-    {
-      CellPos p = pos0;
 #pragma unroll
-      for (int k = 0; k < CPL; k++) {
-        const bool valid = (uint32_t)(64 * k + lane) < ncb;
-        const uint32_t lT = left_T(k), lB = left_B(k); /* wave operations: outside the short-circuit below */
-        const bool head = valid && (p.xp <= pad_left || !rows_same_run<MODE>(pt[k], pb[k], lT, lB));
-        hm[k] = wave_ballot(head);
-        const bool thead = head && (px_rgb(pt[k]) | px_rgb(pb[k])) == 0u;
-        tm[k] = HBC ? wave_ballot(thead) : 0ull;
-        p = advance(p);
-      }
+    for (int k = 0; k < CPL; k++) {
+      const bool valid = cm[k] < vlim;
+      const uint32_t lT = left_T(k), lB = left_B(k); /* wave operations: outside the short-circuit below */
+      const bool head = valid && ((cm[k] & CM_FIRST) != 0u || !rows_same_run<MODE>(pt[k], pb[k], lT, lB));
+      hm[k] = wave_ballot(head);
+      const bool thead = head && (px_rgb(pt[k]) | px_rgb(pb[k])) == 0u;
+      tm[k] = HBC ? wave_ballot(thead) : 0ull;
     }
     /* what the words in front of / behind slot k contribute (wave-uniform): the last head below word k and its
      * transparency, the first head above word k (the block's end closes the last run) */
@@ -503,48 +650,59 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
     /* ---- the token of slot k.  Built twice -- once for its length, once for the store pass -- from the pixels and the
      * masks, instead of being held: five registers per slot would put the 7-slot geometry beyond 128 VGPRs, i.e. at one
      * workgroup per CU instead of two */
-    auto make_tok = [&](int k, CellPos p) {
+    const uint32_t lastlim = (uint32_t)min(rows - 1 - (int)row0, 511) << CM_ROW; /* cells of the frame's last text row: record >= this */
+    auto make_tok = [&](int k) {
       const int s = 64 * k + lane;
       RunCtx c;
       c.is_head = ((hm[k] >> lane) & 1ull) != 0ull;
-      const int below = rows_prev_bit(hm[k], lane); /* nearest head strictly below in this word */
+      const int below = rows_prev_bit(hm[k], lm); /* nearest head strictly below in this word */
       const int h = c.is_head ? s : (below >= 0 ? 64 * k + below : h_in[k]);
-      const int above = rows_next_bit(hm[k], lane);
+      const int above = rows_next_bit(hm[k], lm);
       const int e = above >= 0 ? 64 * k + above : e_out[k];
       c.run = (uint32_t)(e - h);
       /* transparency of the run's head; and, for a head behind its row's first pixel, of the previous run's head */
       const bool t_below = below >= 0 ? ((tm[k] >> below) & 1ull) != 0ull : t_in[k];
       c.head_transparent = HBC && (c.is_head ? ((tm[k] >> lane) & 1ull) != 0ull : t_below);
-      c.state_set = HBC && c.is_head && p.xp > pad_left && !t_below;
+      c.state_set = HBC && c.is_head && (cm[k] & CM_FIRST) == 0u && !t_below;
       c.prevT = left_T(k); /* one DPP move each: cheaper than holding 2 x CPL registers across the block */
       c.prevB = left_B(k);
-      const bool row_end = (uint32_t)s < ncb && p.xp == uwp - 1u;
-      return rows_token<MODE>(c, pt[k], pb[k], f.ops, glyph64, p.xp < pad_left, row_end, row0 + p.rr >= (uint32_t)rows - 1u);
+      const bool row_end = cm[k] < vlim && (cm[k] & CM_END) != 0u;
+      return rows_token<MODE>(c, pt[k], pb[k], f.ops, glyph64, (cm[k] & CM_PAD) != 0u, row_end, cm[k] >= lastlim);
     };
-    /* ---- the slices' byte totals (wave-uniform); a cell's own length and offset are recomputed in the store pass --
-     * fourteen registers less across the block than holding them */
+    /* ---- the slices' byte totals (wave-uniform).  Two slots' lengths share one scan (a slice is at most 64 x 56 bytes:
+     * 16 bits each); the scans are KEPT for the store pass, which takes a cell's offset inside its slice from them */
     auto tok_len = [&](int k, const Tok &t) {
       uint32_t n = 0;
-      if ((uint32_t)(64 * k + lane) < ncb) {
-        CountSink cs{0u};
+      if (cm[k] < vlim) {
+        RowsCountSink<L::NUM8 ? L::o_num_len : -1> cs{{0u}};
         token_fields<MODE>(cs, t, ascii_only);
         n = cs.n;
       }
       return n;
     };
+    constexpr int NPK = (CPL + 1) / 2;
     uint32_t stot[CPL], meta[CPL]; /* meta = {flags:12, rep:12, length:6}: what the store pass cannot re-derive cheaply */
+    uint32_t pk[NPK];
     uint32_t total = 0;
-    {
-      CellPos p = pos0;
 #pragma unroll
-      for (int k = 0; k < CPL; k++) {
-        const Tok t = make_tok(k, p);
-        const uint32_t n = tok_len(k, t);
-        meta[k] = (n ? t.flags : 0u) | (t.rep << 12) | (n << 24);
-        stot[k] = wave_read_lane(wave_inclusive_scan(n), 63);
-        total += stot[k];
-        p = advance(p);
+    for (int j = 0; j < NPK; j++) {
+      uint32_t two_n = 0;
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int k = 2 * j + h;
+        if (k < CPL) {
+          const Tok t = make_tok(k);
+          const uint32_t n = tok_len(k, t);
+          meta[k] = (n ? t.flags : 0u) | (t.rep << 12) | (n << 24);
+          two_n |= n << (16 * h);
+        }
       }
+      pk[j] = wave_inclusive_scan(two_n);
+      const uint32_t tot2 = wave_read_lane(pk[j], 63);
+      stot[2 * j] = tot2 & 0xFFFFu;
+      if (2 * j + 1 < CPL)
+        stot[2 * j + 1] = tot2 >> 16;
+      total += (tot2 & 0xFFFFu) + (tot2 >> 16);
     }
     /* ---- where the block starts in the frame (decoupled look-back over LDS words, as the stream kernel) */
     uint32_t base = first_base;
@@ -578,13 +736,13 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
         if (n == 0u)
           continue;
         const uint32_t len_k = meta[k] >> 24;
-        const uint32_t off_k = wave_inclusive_scan(len_k) - len_k; /* within the slice */
+        const uint32_t off_k = ((pk[k / 2] >> (16 * (k & 1))) & 0xFFFFu) - len_k; /* within the slice */
         const Tok tk = rows_token_payload<MODE>(meta[k] & 0xFFFu, (meta[k] >> 12) & 0xFFFu, pt[k], pb[k], f.ops, glyph64);
         if (CARRY) {
           /* the staging area's byte 0 is the line the slice starts in (q0); [own_q, qa) is already there */
           const uint32_t qa = a + dmis, q0 = qa & ~127u, qend = qa + n;
           if (len_k != 0u) {
-            FastSink<L::o_dec, L::o_flags + 16> fs{stage_addr + (qa + off_k - q0), dummy_addr};
+            RowsFastSink<L::o_dec, L::o_flags + 16, L::NUM8 ? L::o_num_semi : -1, L::NUM8 ? L::o_num_m : -1> fs{{stage_addr + (qa + off_k - q0), dummy_addr}};
             token_fields<MODE>(fs, tk, ascii_only);
           }
           lds_store_fence();
@@ -626,7 +784,7 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
             token_fields<MODE>(ps, tk, ascii_only);
             ps.finish();
           } else {
-            FastSink<L::o_dec, L::o_flags + 16> fs{stage_addr + (a + off_k - g0), dummy_addr};
+            RowsFastSink<L::o_dec, L::o_flags + 16, L::NUM8 ? L::o_num_semi : -1, L::NUM8 ? L::o_num_m : -1> fs{{stage_addr + (a + off_k - g0), dummy_addr}};
             token_fields<MODE>(fs, tk, ascii_only);
           }
         }

@@ -37,6 +37,10 @@ struct uint4 {
   uint32_t x, y, z, w;
 };
 static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
+struct uint2 {
+  uint32_t x, y;
+};
+static inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
 
 namespace hipemu {
 
@@ -186,6 +190,8 @@ static inline uint32_t __umul24(uint32_t a, uint32_t b) { return (a & 0xFFFFFFu)
 static inline int __popcll(uint64_t v) { return __builtin_popcountll(v); }
 static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
 static inline int __clzll(long long v) { return v ? __builtin_clzll(v) : 64; }
+static inline int __ffs(int v) { return __builtin_ffs(v); }
+static inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
 using std::max;
 using std::min;
 static inline uint32_t atomicAdd(uint32_t *p, uint32_t v) { /* fibers run one at a time */
