@@ -278,7 +278,11 @@ __device__ inline int rows_next_bit(uint64_t m, const LaneMasks &lm) {
 /* (not the CRC instantiations: their tables leave room for one workgroup per CU anyway, so they may spread out; nor the
  * one composite instantiation that would have to spill to get there) */
 template <int MODE, int CPL, bool GENERIC, bool CRC> struct RowsMinWaves {
+#ifdef ACHIP_ROWS_MIN_WAVES /* A/B builds: fewer resident waves, more registers each */
+  static constexpr int value = ACHIP_ROWS_MIN_WAVES;
+#else
   static constexpr int value = (!CRC && !(GENERIC && MODE == ACHIP_MODE_HB_16 && CPL > 4)) ? 4 : 1;
+#endif
 };
 template <int MODE, int WAVES, int CPL, bool GENERIC, bool CRC = false>
 __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<MODE, CPL, GENERIC, CRC>::value))
@@ -556,61 +560,80 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
   const uint32_t dummy_addr = lds_base_addr() + (uint32_t)L::o_flags + 16u + 4u * (uint32_t)lane;
   const unsigned char *stage = lds_ptr<const unsigned char>((int)stage_off);
 
+  /* ---- samples -> pixels with the mode's run key in bits 31..24 (as the phase kernel parks them in LDS), in place */
+  auto to_pixels = [&](int blk, uint32_t (&pt)[CPL], uint32_t (&pb)[CPL], uint32_t kinds) {
+    const uint32_t row0 = (uint32_t)(blk * rpb), vlim = block_rows(blk) << CM_ROW;
+    const uint32_t yt = HB ? 2u * row0 : row0;
+    const bool two = HB && yt + 1u < (uint32_t)f.out_h;
+    const bool ft = row1 && src_row(yt) == 0u, fb = row1 && two && src_row(yt + 1u) == 0u; /* wave-uniform */
+    const bool tint = !GENERIC && (f.ops & ACHIP_OP_TINT) != 0u;
+#pragma unroll
+    for (int k = 0; k < CPL; k++) {
+      const bool pix = cm[k] < vlim && !(cm[k] & CM_PAD);
+      const uint32_t rawT = pt[k], rawB = pb[k];
+      uint32_t t = 0, b = 0;
+      if (pix) {
+        if (row1) { /* requested one byte early (issue) -- except the buffer's first pixel */
+          t = rawT >> 8;
+          if (ft && (cm[k] & 0xFFFFu) == 0u)
+            t = rawT & 0x00FFFFFFu;
+          if (tint)
+            t = tint_pixel(t, f.ops);
+          b = t;
+          if (two) {
+            b = rawB >> 8;
+            if (fb && (cm[k] & 0xFFFFu) == 0u)
+              b = rawB & 0x00FFFFFFu;
+            if (tint)
+              b = tint_pixel(b, f.ops);
+          }
+        } else {
+          const uint32_t kt = (kinds >> (2 * k)) & 3u, kb = (kinds >> (2 * (CPL + k))) & 3u;
+          t = sample_finish<GENERIC>(f, rawT, kt);
+          if (HB)
+            b = kb == RAW_TOP ? t : sample_finish<GENERIC>(f, rawB, kb);
+        }
+        if (MODE == ACHIP_MODE_HB_256) {
+          t |= quant256(t) << 24;
+          b |= quant256(b) << 24;
+        } else if (MODE == ACHIP_MODE_HB_16) {
+          t |= quant16(t) << 24;
+          b |= quant16(b) << 24;
+        } else if (MODE == ACHIP_MODE_MONO) {
+          t |= (uint32_t)ramp[luma601(t) >> 2] << 24;
+        }
+      }
+      pt[k] = t;
+      pb[k] = HB ? b : 0u;
+    }
+  };
+
+  /* The loop holds a block's PIXELS (pt / pb), not its samples: the samples of block b + WAVES are requested at the top of
+   * block b's turn and turned into pixels in the middle of it, behind the length pass and in front of the drain.  That is
+   * the turn's only wait for vector memory, and it waits for nothing: the requests have had the whole length pass to
+   * return, and the previous turn's stores are long acknowledged.  (Converted at the top of the NEXT turn, as rounds 3
+   * and 4 had it, the conversion sat right behind the next requests and the drain's stores -- the compiler cannot count
+   * the stores of a loop, so it waited for everything, the requests it had just made included.) */
+  uint32_t (&pt)[CPL] = rawT, (&pb)[CPL] = rawB;
+  if (wave < nblk)
+    to_pixels(wave, pt, pb, kinds);
   for (int blk = wave; blk < nblk; blk += WAVES) {
-    uint32_t rawT_n[CPL], rawB_n[CPL], kinds_n = 0;
-    if (blk + WAVES < nblk)
-      issue_any(blk + WAVES, rawT_n, rawB_n, kinds_n);
+    uint32_t pt_n[CPL], pb_n[CPL], kinds_n = 0;
+    const bool more = blk + WAVES < nblk;
+    if (more)
+      issue_any(blk + WAVES, pt_n, pb_n, kinds_n);
 
     const uint32_t nrb = block_rows(blk), ncb = nrb * uwp, row0 = (uint32_t)(blk * rpb), vlim = nrb << CM_ROW;
-    /* ---- samples -> pixels with the mode's run key in bits 31..24 (as the phase kernel parks them in LDS) */
-    uint32_t pt[CPL], pb[CPL];
-    {
-      const uint32_t yt = HB ? 2u * row0 : row0;
-      const bool two = HB && yt + 1u < (uint32_t)f.out_h;
-      const bool ft = row1 && src_row(yt) == 0u, fb = row1 && two && src_row(yt + 1u) == 0u; /* wave-uniform */
-      const bool tint = !GENERIC && (f.ops & ACHIP_OP_TINT) != 0u;
+    /* the records do not change, but the compiler must not know: it would hoist every flag test out of the loop as a lane
+     * mask (four scalar pairs per slot) and spill most of them -- two lane reads per use instead of the AND + compare */
+#ifndef ACHIP_ROWS_HOIST_FLAGS /* A/B builds: make EXTRA=-DACHIP_ROWS_HOIST_FLAGS */
 #pragma unroll
-      for (int k = 0; k < CPL; k++) {
-        const bool pix = cm[k] < vlim && !(cm[k] & CM_PAD);
-        uint32_t t = 0, b = 0;
-        if (pix) {
-          if (row1) { /* requested one byte early (issue) -- except the buffer's first pixel */
-            t = rawT[k] >> 8;
-            if (ft && (cm[k] & 0xFFFFu) == 0u)
-              t = rawT[k] & 0x00FFFFFFu;
-            if (tint)
-              t = tint_pixel(t, f.ops);
-            b = t;
-            if (two) {
-              b = rawB[k] >> 8;
-              if (fb && (cm[k] & 0xFFFFu) == 0u)
-                b = rawB[k] & 0x00FFFFFFu;
-              if (tint)
-                b = tint_pixel(b, f.ops);
-            }
-          } else {
-            const uint32_t kt = (kinds >> (2 * k)) & 3u, kb = (kinds >> (2 * (CPL + k))) & 3u;
-            t = sample_finish<GENERIC>(f, rawT[k], kt);
-            if (HB)
-              b = kb == RAW_TOP ? t : sample_finish<GENERIC>(f, rawB[k], kb);
-          }
-          if (MODE == ACHIP_MODE_HB_256) {
-            t |= quant256(t) << 24;
-            b |= quant256(b) << 24;
-          } else if (MODE == ACHIP_MODE_HB_16) {
-            t |= quant16(t) << 24;
-            b |= quant16(b) << 24;
-          } else if (MODE == ACHIP_MODE_MONO) {
-            t |= (uint32_t)ramp[luma601(t) >> 2] << 24;
-          }
-        }
-        pt[k] = t;
-        pb[k] = HB ? b : 0u;
-      }
-    }
+    for (int k = 0; k < CPL; k++)
+      cm[k] = opaque(cm[k]);
+#endif
     /* ---- run heads: one ballot per slot; a cell starts a run at or in front of its row's first pixel, or where its
      * key differs from its left neighbour's (the lane below; lane 0 takes lane 63 of the slot before) */
-    uint64_t hm[CPL], tm[CPL];
+    uint64_t hm[CPL];
     auto left_T = [&](int k) { return wave_shift_up1(pt[k], k > 0 ? wave_read_lane(pt[k > 0 ? k - 1 : 0], 63) : 0u); };
     auto left_B = [&](int k) { return HB ? wave_shift_up1(pb[k], k > 0 ? wave_read_lane(pb[k > 0 ? k - 1 : 0], 63) : 0u) : 0u; };
 #pragma unroll
@@ -619,50 +642,39 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
       const uint32_t lT = left_T(k), lB = left_B(k); /* wave operations: outside the short-circuit below */
       const bool head = valid && ((cm[k] & CM_FIRST) != 0u || !rows_same_run<MODE>(pt[k], pb[k], lT, lB));
       hm[k] = wave_ballot(head);
-      const bool thead = head && (px_rgb(pt[k]) | px_rgb(pb[k])) == 0u;
-      tm[k] = HBC ? wave_ballot(thead) : 0ull;
     }
-    /* what the words in front of / behind slot k contribute (wave-uniform): the last head below word k and its
-     * transparency, the first head above word k (the block's end closes the last run) */
-    int h_in[CPL], e_out[CPL];
-    bool t_in[CPL];
+    /* what the words behind slot k contribute (wave-uniform): the first head above word k (the block's end closes the last
+     * run), nine bits per slot in one scalar pair.  What the words in FRONT of slot k contribute -- the last head below
+     * word k and its transparency -- is carried along by the length pass below.  (Held as arrays of scalars, these and
+     * the transparency masks were 42 of the 96 scalar registers the seven-slot geometry spilled.) */
+    static_assert(64 * CPL < 512 && 9 * CPL <= 64, "nine bits per slot");
+    uint64_t e_pack = 0;
     {
-      int last = -1;
-      bool lt = false;
-#pragma unroll
-      for (int k = 0; k < CPL; k++) {
-        h_in[k] = last;
-        t_in[k] = lt;
-        if (hm[k] != 0ull) {
-          const int b = 63 - __clzll((long long)hm[k]);
-          last = 64 * k + b;
-          lt = ((tm[k] >> b) & 1ull) != 0ull;
-        }
-      }
-      int next = (int)ncb;
+      uint32_t next = ncb;
 #pragma unroll
       for (int k = CPL - 1; k >= 0; k--) {
-        e_out[k] = next;
+        e_pack |= (uint64_t)next << (9 * k);
         if (hm[k] != 0ull)
-          next = 64 * k + __ffsll((unsigned long long)hm[k]) - 1;
+          next = (uint32_t)(64 * k + __ffsll((unsigned long long)hm[k]) - 1);
       }
     }
     /* ---- the token of slot k.  Built twice -- once for its length, once for the store pass -- from the pixels and the
      * masks, instead of being held: five registers per slot would put the 7-slot geometry beyond 128 VGPRs, i.e. at one
      * workgroup per CU instead of two */
     const uint32_t lastlim = (uint32_t)min(rows - 1 - (int)row0, 511) << CM_ROW; /* cells of the frame's last text row: record >= this */
-    auto make_tok = [&](int k) {
+    /* tmk: the transparent heads of word k (raw black over raw black: halfblock.c:357,476), remade from the pixels */
+    auto make_tok = [&](int k, uint64_t tmk, int h_in, bool t_in) {
       const int s = 64 * k + lane;
       RunCtx c;
       c.is_head = ((hm[k] >> lane) & 1ull) != 0ull;
       const int below = rows_prev_bit(hm[k], lm); /* nearest head strictly below in this word */
-      const int h = c.is_head ? s : (below >= 0 ? 64 * k + below : h_in[k]);
+      const int h = c.is_head ? s : (below >= 0 ? 64 * k + below : h_in);
       const int above = rows_next_bit(hm[k], lm);
-      const int e = above >= 0 ? 64 * k + above : e_out[k];
+      const int e = above >= 0 ? 64 * k + above : (int)((e_pack >> (9 * k)) & 0x1FFull);
       c.run = (uint32_t)(e - h);
       /* transparency of the run's head; and, for a head behind its row's first pixel, of the previous run's head */
-      const bool t_below = below >= 0 ? ((tm[k] >> below) & 1ull) != 0ull : t_in[k];
-      c.head_transparent = HBC && (c.is_head ? ((tm[k] >> lane) & 1ull) != 0ull : t_below);
+      const bool t_below = below >= 0 ? ((tmk >> below) & 1ull) != 0ull : t_in;
+      c.head_transparent = HBC && (c.is_head ? ((tmk >> lane) & 1ull) != 0ull : t_below);
       c.state_set = HBC && c.is_head && (cm[k] & CM_FIRST) == 0u && !t_below;
       c.prevT = left_T(k); /* one DPP move each: cheaper than holding 2 x CPL registers across the block */
       c.prevB = left_B(k);
@@ -681,29 +693,37 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
       return n;
     };
     constexpr int NPK = (CPL + 1) / 2;
-    uint32_t stot[CPL], meta[CPL]; /* meta = {flags:12, rep:12, length:6}: what the store pass cannot re-derive cheaply */
-    uint32_t pk[NPK];
+    uint32_t meta[CPL]; /* meta = {flags:12, rep:12, length:6}: what the store pass cannot re-derive cheaply */
+    uint32_t pk[NPK], tot2[NPK];
     uint32_t total = 0;
+    {
+      int last = -1;   /* the last head below the word being processed, and whether it is transparent */
+      bool lt = false;
 #pragma unroll
-    for (int j = 0; j < NPK; j++) {
-      uint32_t two_n = 0;
+      for (int j = 0; j < NPK; j++) {
+        uint32_t two_n = 0;
 #pragma unroll
-      for (int h = 0; h < 2; h++) {
-        const int k = 2 * j + h;
-        if (k < CPL) {
-          const Tok t = make_tok(k);
-          const uint32_t n = tok_len(k, t);
-          meta[k] = (n ? t.flags : 0u) | (t.rep << 12) | (n << 24);
-          two_n |= n << (16 * h);
+        for (int h = 0; h < 2; h++) {
+          const int k = 2 * j + h;
+          if (k < CPL) {
+            const uint64_t tmk = HBC ? hm[k] & wave_ballot((px_rgb(pt[k]) | px_rgb(pb[k])) == 0u) : 0ull;
+            const Tok t = make_tok(k, tmk, last, lt);
+            const uint32_t n = tok_len(k, t);
+            meta[k] = (n ? t.flags : 0u) | (t.rep << 12) | (n << 24);
+            two_n |= n << (16 * h);
+            if (hm[k] != 0ull) {
+              const int b = 63 - __clzll((long long)hm[k]);
+              last = 64 * k + b;
+              lt = ((tmk >> b) & 1ull) != 0ull;
+            }
+          }
         }
+        pk[j] = wave_inclusive_scan(two_n);
+        tot2[j] = wave_read_lane(pk[j], 63);
+        total += (tot2[j] & 0xFFFFu) + (tot2[j] >> 16);
       }
-      pk[j] = wave_inclusive_scan(two_n);
-      const uint32_t tot2 = wave_read_lane(pk[j], 63);
-      stot[2 * j] = tot2 & 0xFFFFu;
-      if (2 * j + 1 < CPL)
-        stot[2 * j + 1] = tot2 >> 16;
-      total += (tot2 & 0xFFFFu) + (tot2 >> 16);
     }
+    auto stot = [&](int k) { return (tot2[k / 2] >> (16 * (k & 1))) & 0xFFFFu; };
     /* ---- where the block starts in the frame (decoupled look-back over LDS words, as the stream kernel) */
     uint32_t base = first_base;
     if (blk > 0) {
@@ -714,6 +734,9 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
     const bool ok = base != 0xFFFFFFFFu && (uint64_t)base + total <= cap_bytes;
     if (lane == 0)
       slot_store(&slots[blk], ACHIP_SLOT_PREFIX | (ok ? base + total : cap_bytes + 1u));
+
+    if (more)
+      to_pixels(blk + WAVES, pt_n, pb_n, kinds_n);
 
     uint32_t braw = 0; /* CRC: register after the block's bytes, starting from 0 */
     if (ok) {
@@ -728,11 +751,11 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
       int last_k = 0;
 #pragma unroll
       for (int k = 0; k < CPL; k++)
-        last_k = stot[k] != 0u ? k : last_k;
+        last_k = stot(k) != 0u ? k : last_k;
       uint32_t own_q = base + dmis; /* first byte of the block that has not left the wave yet */
 #pragma unroll
       for (int k = 0; k < CPL; k++) {
-        const uint32_t n = stot[k];
+        const uint32_t n = stot(k);
         if (n == 0u)
           continue;
         const uint32_t len_k = meta[k] >> 24;
@@ -829,11 +852,10 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
       stream_crc_finish<L>(slots, nblk, nblk_cap, cap_bytes, first_base, fidx, dim_w, dim_h, wire, lane);
     }
 
-    kinds = kinds_n;
 #pragma unroll
     for (int k = 0; k < CPL; k++) {
-      rawT[k] = rawT_n[k];
-      rawB[k] = rawB_n[k];
+      pt[k] = pt_n[k];
+      pb[k] = pb_n[k];
     }
   }
   (void)glyph;

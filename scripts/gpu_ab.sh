@@ -9,7 +9,7 @@ for w in $WL; do
   for rep in 1 2; do
     for lib in "" "$OTHER"; do
       name=${lib:-HEAD}
-      ASCIICHAT_HIP_LIB=${lib:+$PWD/$lib} python3 bench.py --workload $w --others '' --no-cpu --no-wire --no-d2h --no-hot --steps 100 --warmup 20 \
+      ASCIICHAT_HIP_LIB=${lib:+$PWD/$lib} python3 bench.py --workload $w --others '' --no-cpu --no-wire --no-d2h --no-hot --batch-sweep '' --steps 100 --warmup 20 \
          --extra $O/extra_${w}_$(basename $name)_$rep.json > $O/line_${w}_$(basename $name)_$rep.txt 2>> $O/stderr.txt
       python3 - "$O/extra_${w}_$(basename $name)_$rep.json" "$w" "$name" <<'PY'
 import json,sys

@@ -2,7 +2,11 @@
 """Static attribution of a kernel's gfx950 instructions to source lines.
 
     hipcc --offload-arch=gfx950 -O3 -gline-tables-only -S --cuda-device-only -o k.s one_kernel.hip
-    isa_lines.py k.s [kernel-name-substring] [--top N] [--by-func]
+    isa_lines.py k.s [kernel-name-substring] [--top N] [--loop]
+
+--loop: only the instructions of the kernel's LARGEST loop (the basic blocks LLVM annotates "in Loop: Header=<label>", the
+header and every nested loop included): for the wave-autonomous kernels that is the per-block loop, so the totals are what
+one block executes when every branch is taken.
 
 Counts VALU / SALU / LDS / VMEM instructions per `.loc file line` of the (first matching) kernel.  Static counts: a line
 inside the unrolled per-slot loops appears once per slot, code under a skipped branch still counts.
@@ -26,6 +30,52 @@ def classify(op):
     return None
 
 
+def loop_blocks(lines, want):
+    """labels of the basic blocks of the largest depth-1 loop of the first matching kernel (nested loops included)"""
+    inside = False
+    size = collections.Counter()
+    member = collections.defaultdict(set)
+    parent = {}
+    label, hdr = None, None
+    for line in lines:
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            inside = want is None or want in m.group(1)
+            continue
+        if not inside:
+            continue
+        if line.startswith(".Lfunc_end"):
+            break
+        m = re.match(r"^(\.LBB\d+_\d+):(.*)$", line)
+        if m:
+            label = m.group(1)
+            hdr = None
+            h = re.search(r"in Loop: Header=(BB\d+_\d+) Depth=(\d+)", m.group(2))
+            if h:
+                hdr = ".L" + h.group(1)
+            continue
+        if label is None:
+            continue
+        if "Loop Header: Depth=" in line:  # "=>This Loop Header" / "Parent Loop BBx_y Depth=1" comment lines under a label
+            hdr = label
+            continue
+        pm = re.search(r"Parent Loop (BB\d+_\d+) Depth=", line)
+        if pm:
+            parent[label] = ".L" + pm.group(1)
+            continue
+        if re.match(r"\s+[a-z]\w+", line) and hdr:
+            member[hdr].add(label)
+            size[hdr] += 1
+    # fold inner loops into their parents
+    for inner, outer in parent.items():
+        member[outer] |= member.get(inner, set()) | {inner}
+        size[outer] += size.get(inner, 0)
+    if not size:
+        return set()
+    top = max(size, key=size.get)
+    return member[top] | {top}
+
+
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     path = args[0]
@@ -36,7 +86,15 @@ def main():
     cur = None
     inside = False
     tot = collections.Counter()
-    for line in open(path):
+    lines = open(path).read().splitlines()
+    keep = None
+    if "--loop" in sys.argv:
+        keep = loop_blocks(lines, want)
+    label = None
+    for line in lines:
+        mlab = re.match(r"^(\.LBB\d+_\d+):", line)
+        if mlab:
+            label = mlab.group(1)
         m = re.match(r'\s*\.file\s+(\d+)\s+"([^"]*)"(?:\s+"([^"]*)")?', line)
         if m:
             files[int(m.group(1))] = (m.group(3) or m.group(2)).split("/")[-1]
@@ -55,7 +113,7 @@ def main():
             cur = (int(m.group(1)), int(m.group(2)))
             continue
         m = re.match(r"\s+([a-z]\w+)", line)
-        if m and cur:
+        if m and cur and (keep is None or label in keep):
             c = classify(m.group(1))
             if c:
                 per[cur][c] += 1
