@@ -735,7 +735,10 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
     if (lane == 0)
       slot_store(&slots[blk], ACHIP_SLOT_PREFIX | (ok ? base + total : cap_bytes + 1u));
 
-    if (more)
+    /* (the 16-colour quantiser's temporaries do not fit next to the store pass's registers in the seven-slot geometry:
+     * there the conversion waits for the end of the turn) */
+    constexpr bool MID_TURN = !(MODE == ACHIP_MODE_HB_16 && CPL > 4);
+    if (MID_TURN && more)
       to_pixels(blk + WAVES, pt_n, pb_n, kinds_n);
 
     uint32_t braw = 0; /* CRC: register after the block's bytes, starting from 0 */
@@ -852,6 +855,8 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
       stream_crc_finish<L>(slots, nblk, nblk_cap, cap_bytes, first_base, fidx, dim_w, dim_h, wire, lane);
     }
 
+    if (!MID_TURN && more)
+      to_pixels(blk + WAVES, pt_n, pb_n, kinds_n);
 #pragma unroll
     for (int k = 0; k < CPL; k++) {
       pt[k] = pt_n[k];
