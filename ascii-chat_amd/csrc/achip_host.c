@@ -778,7 +778,7 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
     else if (cells > variant_caps[2])
       *variant = 1;
     else
-      *variant = 2;
+      *variant = variant_caps[2] >= cells ? 2 : 1; /* (geometry 2 is not in the default build: render_variants.h) */
   }
   *parts = np;
   *rows_per_part = rpp;

@@ -215,7 +215,17 @@ static void cb_confine_thread(void) {
       CPU_SET(c, &keep);
       kept++;
     }
-  (void)sched_setaffinity(0, sizeof(keep), &keep);
+  const int rc = sched_setaffinity(0, sizeof(keep), &keep);
+  /* the host application's threads are touched without having asked: say so, once per process */
+  static int said;
+  if (!__atomic_exchange_n(&said, 1, __ATOMIC_RELAXED)) {
+    const char *q = getenv("ASCIICHAT_HIP_QUIET");
+    if (!(q && q[0] && q[0] != '0'))
+      fprintf(stderr,
+              "libasciichat_hip: threads that call the render entry points are confined to %d of their %d CPUs (the cgroup CPU quota; "
+              "threads they start later inherit the mask)%s -- ASCIICHAT_HIP_CONFINE=0 leaves them alone, ASCIICHAT_HIP_QUIET=1 drops this line\n",
+              g_cpu_budget, CPU_COUNT(&set), rc ? " [sched_setaffinity failed: not applied]" : "");
+  }
 }
 static void cb_global_init(void);
 int achip_cpu_budget(void) {

@@ -445,6 +445,7 @@ int asciichat_hip_frame_table_commit(asciichat_hip_frame_table_t *t, void *strea
         s->pend = 0;
         s->dense = 1;
         s->dense_blk = t->dense_open;
+        s->dense_seq = b->seq;
         s->dense_off = s->pend_off;
         s->dense_bytes = s->pend_bytes;
         s->dense_key = s->pend_key;
@@ -559,6 +560,10 @@ int ft_dense_latest(asciichat_hip_frame_table_t *t, const ft_dense_ref_t *s, voi
     return 0;
   ft_dense_blk_t *b = &t->dense[s->dense_blk];
   pthread_mutex_lock(&t->dense_mu);
+  if (b->seq != s->dense_seq) { /* the snapshot's offset points into a block that has been refilled since */
+    pthread_mutex_unlock(&t->dense_mu);
+    return -1;
+  }
   int rc = 0;
   if (!(*waited & (1u << s->dense_blk))) { /* work queued on the consumer stream from here on sees the complete DMA */
     if (!t->dense_zero_copy)

@@ -241,6 +241,7 @@ static int publish_common(asciichat_hip_frame_table_t *t, int slot, const void *
     s->batch_of[k] = 0;
     s->cur = k;
     s->dense = 0;
+    s->pend = 0; /* a staged sampled image that was not committed yet is older than this frame: it must not win at the commit */
     s->w = (int)w;
     s->h = (int)h;
     s->generation++;
@@ -484,6 +485,7 @@ int asciichat_hip_frame_table_publish_rows_batch(asciichat_hip_frame_table_t *t,
       s->batch_of[I->k] = batch_seq;
       s->cur = I->k;
       s->dense = 0;
+      s->pend = 0;
       s->w = (int)I->w;
       s->h = (int)I->h;
       s->generation++;
@@ -519,12 +521,14 @@ int asciichat_hip_frame_table_latest_frames(asciichat_hip_frame_table_t *t, cons
   again:
     pthread_mutex_lock(&s->mu);
     if (s->dense) { /* the latest frame is the image one target samples of it (frame_dense.c) */
-      const ft_dense_ref_t ref = {s->dense_blk, s->dense_off, s->dense_key, s->dense_geo};
+      const ft_dense_ref_t ref = {s->dense_blk, s->dense_seq, s->dense_off, s->dense_key, s->dense_geo};
       pthread_mutex_unlock(&s->mu);
       int drc = 0;
       const int got = ft_dense_latest(t, &ref, consumer_stream, &frames[i], &waited_dense, &drc);
       if (drc)
         return -drc;
+      if (got < 0) /* its ring block was refilled between the two looks */
+        goto again;
       if (!got)
         frames[i].src = NULL;
       with_video += got;

@@ -36,6 +36,7 @@ typedef struct {
    * it, somewhere in a ring block -- `dense` says which kind is the latest */
   int dense;               /* 1: the latest frame is the sampled image below; the full-frame buffers are stale */
   int dense_blk;           /* ring block it lives in                                                     */
+  unsigned dense_seq;      /* number of the commit that put it there (the block's seq at that time)       */
   uint32_t dense_off, dense_bytes;
   achip_frame_t dense_key; /* the target it was gathered for (src unused)                                 */
   achip_frame_t dense_geo; /* that target rewritten onto the sampled image (achip_stage_gather; src unused) */
@@ -92,11 +93,13 @@ void ft_dense_forget_stream(struct asciichat_hip_frame_table *t, hipStream_t s);
 /* what latest_frames() copies out of a slot (under its lock) whose latest frame is a sampled image */
 typedef struct {
   int dense_blk;
+  unsigned dense_seq; /* the block's commit number when the snapshot was taken: a block refilled since then is stale */
   uint32_t dense_off;
   achip_frame_t dense_key, dense_geo;
 } ft_dense_ref_t;
 /* rewrites *f onto that sampled image when f asks for what was staged (or is last tick's rewritten descriptor); *waited:
- * bit r set = the consumer stream already waits for ring block r.  1 = source handed out, 0 = no match or *rc != 0 */
+ * bit r set = the consumer stream already waits for ring block r.  1 = source handed out, 0 = no match or *rc != 0,
+ * -1 = the block was refilled after the snapshot was taken (two commits slipped in): look at the slot again */
 int ft_dense_latest(struct asciichat_hip_frame_table *t, const ft_dense_ref_t *s, void *consumer_stream, achip_frame_t *f,
                     unsigned *waited, int *rc);
 

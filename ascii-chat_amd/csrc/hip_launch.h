@@ -82,6 +82,7 @@ int achip_launch_crc32c_pack(const uint8_t *base, uint64_t stride, const uint32_
                              uint32_t *pkt_crc_out, uint8_t *dst, uint64_t dst_capacity, uint64_t *off_out, uint32_t *len_out,
                              void *stream);
 
+int achip_launch_warm_crc_tables(void); /* the checksum kernels' table images of the current device, built eagerly */
 int achip_variant_block(int variant); /* threads per workgroup, -1 for an unknown id */
 int achip_variant_cap(int variant);   /* cells per chunk                               */
 int achip_variant_lds_bytes(int mode, int variant);

@@ -30,7 +30,7 @@ extern "C" int achip_launch_render(int mode, int variant, int has_composite, con
     switch (variant) {
 #define X(id, W, C)                                                                                                    \
   case id:                                                                                                             \
-    return achip_render_rinst_launch_##id(mode, has_composite, frames_dev, n_frames, lut_dev, out, out_stride, out_len, \
+    return achipk_render_rinst_launch_##id(mode, has_composite, frames_dev, n_frames, lut_dev, out, out_stride, out_len, \
                                           uniform, nullptr, stream);
       ACHIP_ROWS_VARIANTS(X)
 #undef X
@@ -42,13 +42,13 @@ extern "C" int achip_launch_render(int mode, int variant, int has_composite, con
       if (variant != 18 || parts > 64 || epoch == 0u)
         return (int)hipErrorInvalidValue;
       const achip_partsdev_t ps = {parts, epoch, part_sync};
-      return achip_render_sinst_parts_launch_18(mode, has_composite, frames_dev, n_frames, lut_dev, out, out_stride, out_len, uniform,
+      return achipk_render_sinst_parts_launch_18(mode, has_composite, frames_dev, n_frames, lut_dev, out, out_stride, out_len, uniform,
                                                 prof, &ps, stream);
     }
     switch (variant) {
 #define X(id, W, C)                                                                                                    \
   case id:                                                                                                             \
-    return achip_render_sinst_launch_##id(mode, has_composite, frames_dev, n_frames, lut_dev, out, out_stride, out_len, \
+    return achipk_render_sinst_launch_##id(mode, has_composite, frames_dev, n_frames, lut_dev, out, out_stride, out_len, \
                                           uniform, prof, nullptr, stream);
       ACHIP_STREAM_VARIANTS(X)
 #undef X
@@ -58,7 +58,7 @@ extern "C" int achip_launch_render(int mode, int variant, int has_composite, con
   switch (variant) { /* one translation unit per geometry: render_inst.hip */
 #define X(id, B, C, R)                                                                                                 \
   case id:                                                                                                             \
-    return achip_render_inst_launch_##id(mode, has_composite, frames_dev, n_frames, lut_dev, out, out_stride, out_len, \
+    return achipk_render_inst_launch_##id(mode, has_composite, frames_dev, n_frames, lut_dev, out, out_stride, out_len, \
                                          prof, parts, rows_per_part, part_sync, epoch, uniform, stream);
     ACHIP_VARIANTS(X)
 #undef X
@@ -78,13 +78,13 @@ extern "C" int achip_launch_render_crc(int mode, int variant, int has_composite,
   switch (variant) {
 #define X(id, W, C)                                                                                                    \
   case id:                                                                                                             \
-    return achip_render_sinst_launch_##id(mode, has_composite, frames_dev, n_frames, lut_dev, out, out_stride, out_len, \
+    return achipk_render_sinst_launch_##id(mode, has_composite, frames_dev, n_frames, lut_dev, out, out_stride, out_len, \
                                           uniform, prof, wire, stream);
     ACHIP_STREAM_VARIANTS(X)
 #undef X
 #define X(id, W, C)                                                                                                    \
   case id:                                                                                                             \
-    return achip_render_rinst_launch_##id(mode, has_composite, frames_dev, n_frames, lut_dev, out, out_stride, out_len,  \
+    return achipk_render_rinst_launch_##id(mode, has_composite, frames_dev, n_frames, lut_dev, out, out_stride, out_len,  \
                                           uniform, wire, stream);
     ACHIP_ROWS_VARIANTS(X)
 #undef X
@@ -99,11 +99,15 @@ extern "C" int achip_launch_render_pack(int mode, int variant, const achip_frame
   if (bound > (uint64_t)ACHIP_PACK_FRAME_CAP)
     return (int)hipErrorInvalidValue;
   /* 1024 threads while every frame has a CU to itself (variant 16: one block per wave), 512-thread workgroups otherwise */
-  return variant == 16 ? achip_render_sinst_pack_launch_16(mode, frames_dev, n_frames, lut_dev, bound, out_len, uniform, wire, pack, stream)
-                       : achip_render_sinst_pack_launch_17(mode, frames_dev, n_frames, lut_dev, bound, out_len, uniform, wire, pack, stream);
+  return variant == 16 ? achipk_render_sinst_pack_launch_16(mode, frames_dev, n_frames, lut_dev, bound, out_len, uniform, wire, pack, stream)
+                       : achipk_render_sinst_pack_launch_17(mode, frames_dev, n_frames, lut_dev, bound, out_len, uniform, wire, pack, stream);
 }
 extern "C" int achip_pack_frame_cap(void) { return ACHIP_PACK_FRAME_CAP; }
+#ifdef ACHIP_ALL_GEOMETRIES
 extern "C" int achip_variant_has_crc(int variant) { return variant == 16 || variant == 17 || ACHIP_IS_ROWS_VARIANT(variant); }
+#else
+extern "C" int achip_variant_has_crc(int variant) { return variant == 16 || variant == 17; }
+#endif
 /* ... and whether riding the drain beats a second pass over the slab there (measured, profiles/r03_rows_kernel.txt): yes
  * for the per-cell modes' stream kernel (+2.4 us against +8.3 us per 256-frame step); no for the rows kernel, whose
  * per-slice checksum chains cost more than the stand-alone kernel's pass (+12 against +8 us on 80x24 half blocks, +240
@@ -161,17 +165,17 @@ extern "C" int achip_variant_lds_bytes(int mode, int variant) {
   switch (variant) {
 #define X(id, W, C)                                                                                                    \
   case id:                                                                                                             \
-    return achip_render_sinst_lds_##id(mode);
+    return achipk_render_sinst_lds_##id(mode);
     ACHIP_STREAM_VARIANTS(X)
 #undef X
 #define X(id, W, C)                                                                                                    \
   case id:                                                                                                             \
-    return achip_render_rinst_lds_##id(mode);
+    return achipk_render_rinst_lds_##id(mode);
     ACHIP_ROWS_VARIANTS(X)
 #undef X
 #define X(id, B, C, R)                                                                                                 \
   case id:                                                                                                             \
-    return achip_render_inst_lds_##id(mode);
+    return achipk_render_inst_lds_##id(mode);
     ACHIP_VARIANTS(X)
 #undef X
   }
@@ -391,6 +395,17 @@ template <int BLOCK> static hipError_t frame_crc_tables(const uint4 **out) {
   }
   *out = reinterpret_cast<const uint4 *>(tab[dev]);
   return hipSuccess;
+}
+
+/* Builds this device's table images NOW (plan_create calls it): the first checksum / wire / pack call of a process would
+ * otherwise allocate, launch on the null stream and synchronise the device in the middle of a tick -- or inside a stream
+ * capture, where all three are illegal */
+extern "C" int achip_launch_warm_crc_tables(void) {
+  const uint4 *tab = nullptr;
+  hipError_t e = frame_crc_tables<1024>(&tab);
+  if (e == hipSuccess)
+    e = frame_crc_tables<256>(&tab);
+  return (int)e;
 }
 
 /* pack != NULL: the same pass also compacts the slab (crc_kernels.hpp COPY instantiations) */

@@ -229,7 +229,8 @@ struct asciichat_hip_plan {
   uint32_t *crc_scratch;           /* span registers of the stand-alone checksum pass behind this plan (frames above 128 KB):
                                       the plan's own block instead of a stream-ordered allocation per call -- hipMallocAsync +
                                       hipFreeAsync cost ~25 us of host time per call, four times a small launch's render */
-  size_t crc_scratch_words;
+  size_t crc_scratch_words;        /* the layout the block's counters were last zeroed for */
+  size_t crc_scratch_cap;          /* words allocated */
   const void *pack_dst_seen;       /* the destination the automatic choice looked at last, and what it was */
   int pack_dst_host;
   const achip_lut_t *lut_dev;
@@ -354,6 +355,9 @@ int asciichat_hip_plan_create(asciichat_hip_plan_t **plan, int mode, const char 
   int rc = achip_require_device();
   if (rc)
     return rc;
+  rc = achip_hip_check(achip_launch_warm_crc_tables(), "checksum tables"); /* (first plan of a device only; then a mutex and a look) */
+  if (rc)
+    return rc;
   asciichat_hip_plan_t *p = (asciichat_hip_plan_t *)calloc(1, sizeof(*p));
   if (!p)
     return achip_fail(ASCIICHAT_HIP_ERR_MEMORY, "out of memory");
@@ -435,6 +439,8 @@ int asciichat_hip_plan_set_variant(asciichat_hip_plan_t *p, int variant) {
   if (variant >= 0 && !ACHIP_IS_STREAM_VARIANT(variant) && achip_variant_cap(variant) < p->max_wp) /* (a stream geometry's
                                                              "cap" is cells per frame: plan_measure judges those) */
     return achip_fail(ASCIICHAT_HIP_ERR_NOT_SUPPORTED, "variant %d cannot hold a %d-cell row", variant, p->max_wp);
+  if (variant >= ACHIP_STREAM_VARIANT_FIRST && achip_variant_block(variant) <= 0)
+    return achip_fail(ASCIICHAT_HIP_ERR_NOT_SUPPORTED, "geometry %d is not in this build (render_variants.h: make EXTRA=-DACHIP_ALL_GEOMETRIES)", variant);
   const int before = p->variant_user;
   p->variant_user = variant;
   const int rc = plan_measure(p, p->frames_pinned);
@@ -1060,17 +1066,25 @@ static int plan_wire_pass(asciichat_hip_plan_t *p, const uint8_t *slab_dev, size
   if (packet_crc_out_dev && !hdr_out_dev)
     return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame_packets: lengths and a header buffer are required");
   const int parts = out_stride < 0xFFFFFFF0u ? achip_crc_parts((uint32_t)out_stride, p->n) : 1;
-  /* span registers + one arrival counter per frame (zero between launches: the last span to arrive re-arms it).  The block is
-   * laid out for THIS parts count: a call with another out_stride gets a fresh, zeroed one */
+  /* span registers + one arrival counter per frame (zero between launches: the last span to arrive re-arms it), laid out
+   * for THIS parts count.  The block is kept at the largest layout seen: a call with another out_stride only re-zeroes the
+   * counters at their new place, in stream order (a caller alternating strides paid a device-synchronising hipFree per call:
+   * ADVICE r4).  Launches of one plan are ordered on ONE stream (asciichat_hip.h): the counters are the plan's. */
   const size_t words = parts > 1 ? (size_t)p->n * ((size_t)parts + 1u) : 0;
-  if (words && (words != p->crc_scratch_words)) {
+  if (words && words > p->crc_scratch_cap) {
     if (p->crc_scratch)
       (void)hipFree(p->crc_scratch); /* synchronises with a launch that still uses the old block */
     p->crc_scratch = NULL;
-    p->crc_scratch_words = 0;
+    p->crc_scratch_words = p->crc_scratch_cap = 0;
     int rc = achip_hip_check((int)hipMalloc((void **)&p->crc_scratch, words * sizeof(uint32_t)), "hipMalloc(crc scratch)");
-    if (!rc)
-      rc = achip_hip_check((int)hipMemset(p->crc_scratch, 0, words * sizeof(uint32_t)), "hipMemset(crc scratch)");
+    if (rc)
+      return rc;
+    p->crc_scratch_cap = words;
+  }
+  if (words && words != p->crc_scratch_words) {
+    const int rc = achip_hip_check((int)hipMemsetAsync(p->crc_scratch + (size_t)p->n * (size_t)parts, 0, (size_t)p->n * sizeof(uint32_t),
+                                                       (hipStream_t)stream),
+                                   "hipMemsetAsync(crc arrival counters)");
     if (rc)
       return rc;
     p->crc_scratch_words = words;

@@ -1,4 +1,5 @@
-/* render_inst.h -- entry points of the per-geometry translation units (render_inst.hip, -DACHIP_INST=id). */
+/* render_inst.h -- entry points of the per-geometry translation units (render_inst.hip, -DACHIP_INST=id).  Their names
+ * start with achipk_, not achip_: they are the library's own plumbing and stay local (exports.map). */
 #ifndef ACHIP_RENDER_INST_H
 #define ACHIP_RENDER_INST_H
 
@@ -11,45 +12,83 @@
 extern "C" {
 #endif
 
+/* two translation units per geometry: _p0 = modes 0..4 (mono, the per-cell modes), _p1 = modes 5..9 (half blocks, dither) */
+#define ACHIP_INST_ARGS                                                                                                \
+  int mode, int comp, const achip_frame_t *frames, int n, const achip_lut_t *lut, uint8_t *out, uint64_t stride,       \
+      uint32_t *len, unsigned long long *prof, int parts, int rows_per_part, unsigned long long *part_sync,            \
+      uint32_t epoch, const achip_uniform_t *uniform, void *stream
 #define X(id, B, C, R)                                                                                                 \
-  int achip_render_inst_launch_##id(int mode, int comp, const achip_frame_t *frames, int n, const achip_lut_t *lut,    \
-                                    uint8_t *out, uint64_t stride, uint32_t *len, unsigned long long *prof, int parts, \
-                                    int rows_per_part, unsigned long long *part_sync, uint32_t epoch,                  \
-                                    const achip_uniform_t *uniform, void *stream);                                     \
-  int achip_render_inst_lds_##id(int mode);
+  int achipk_render_inst_launch_##id##_p0(ACHIP_INST_ARGS);                                                             \
+  int achipk_render_inst_launch_##id##_p1(ACHIP_INST_ARGS);                                                             \
+  int achipk_render_inst_lds_##id##_p0(int mode);                                                                       \
+  int achipk_render_inst_lds_##id##_p1(int mode);                                                                       \
+  static inline int achipk_render_inst_launch_##id(ACHIP_INST_ARGS) {                                                   \
+    return mode >= ACHIP_MODE_HB_TRUE                                                                                  \
+               ? achipk_render_inst_launch_##id##_p1(mode, comp, frames, n, lut, out, stride, len, prof, parts,         \
+                                                    rows_per_part, part_sync, epoch, uniform, stream)                  \
+               : achipk_render_inst_launch_##id##_p0(mode, comp, frames, n, lut, out, stride, len, prof, parts,         \
+                                                    rows_per_part, part_sync, epoch, uniform, stream);                 \
+  }                                                                                                                    \
+  static inline int achipk_render_inst_lds_##id(int mode) {                                                             \
+    return mode >= ACHIP_MODE_HB_TRUE ? achipk_render_inst_lds_##id##_p1(mode) : achipk_render_inst_lds_##id##_p0(mode); \
+  }
 ACHIP_VARIANTS(X)
 #undef X
 
 /* the stream-kernel geometries (render_stream_inst.hip, -DACHIP_SINST=id) */
 #define X(id, W, C)                                                                                                    \
-  int achip_render_sinst_launch_##id(int mode, int comp, const achip_frame_t *frames, int n, const achip_lut_t *lut,   \
+  int achipk_render_sinst_launch_##id(int mode, int comp, const achip_frame_t *frames, int n, const achip_lut_t *lut,   \
                                      uint8_t *out, uint64_t stride, uint32_t *len, const achip_uniform_t *uniform,     \
                                      unsigned long long *prof, const achip_wire_t *wire, void *stream);                                                                    \
-  int achip_render_sinst_lds_##id(int mode);
+  int achipk_render_sinst_lds_##id(int mode);
 ACHIP_STREAM_VARIANTS(X)
 #undef X
 
 /* the PACK instantiations of stream geometries 16 and 17 (render_stream_inst.hip with -DACHIP_SINST=16 / 17) */
-int achip_render_sinst_pack_launch_16(int mode, const achip_frame_t *frames, int n, const achip_lut_t *lut, uint64_t stride,
+int achipk_render_sinst_pack_launch_16(int mode, const achip_frame_t *frames, int n, const achip_lut_t *lut, uint64_t stride,
                                       uint32_t *len, const achip_uniform_t *uniform, const achip_wire_t *wire,
                                       const achip_packdev_t *pack, void *stream);
-int achip_render_sinst_pack_launch_17(int mode, const achip_frame_t *frames, int n, const achip_lut_t *lut, uint64_t stride,
+int achipk_render_sinst_pack_launch_17(int mode, const achip_frame_t *frames, int n, const achip_lut_t *lut, uint64_t stride,
                                       uint32_t *len, const achip_uniform_t *uniform, const achip_wire_t *wire,
                                       const achip_packdev_t *pack, void *stream);
 
 /* the PARTS instantiations of stream geometry 18 (a frame's blocks shared out over ps->parts workgroups, 2..64) */
-int achip_render_sinst_parts_launch_18(int mode, int comp, const achip_frame_t *frames, int n, const achip_lut_t *lut,
+int achipk_render_sinst_parts_launch_18(int mode, int comp, const achip_frame_t *frames, int n, const achip_lut_t *lut,
                                        uint8_t *out, uint64_t stride, uint32_t *len, const achip_uniform_t *uniform,
                                        unsigned long long *prof, const achip_partsdev_t *ps, void *stream);
 
-/* the rows-kernel geometries (render_rows_inst.hip, -DACHIP_RINST=id): run-structured modes, whole frames */
-#define X(id, W, C)                                                                                                    \
-  int achip_render_rinst_launch_##id(int mode, int comp, const achip_frame_t *frames, int n, const achip_lut_t *lut,   \
-                                     uint8_t *out, uint64_t stride, uint32_t *len, const achip_uniform_t *uniform,     \
-                                     const achip_wire_t *wire, void *stream);                                          \
-  int achip_render_rinst_lds_##id(int mode);
+/* the rows-kernel geometries (render_rows_inst.hip, -DACHIP_RINST=id -DACHIP_RMODE=mode): run-structured modes, whole
+ * frames; one translation unit per (geometry, mode) */
+#define ACHIP_RINST_ARGS                                                                                               \
+  int mode, int comp, const achip_frame_t *frames, int n, const achip_lut_t *lut, uint8_t *out, uint64_t stride,       \
+      uint32_t *len, const achip_uniform_t *uniform, const achip_wire_t *wire, void *stream
+#define ACHIP_RINST_MODES(Y, id) Y(id, 0) Y(id, 5) Y(id, 6) Y(id, 7) Y(id, 8) /* mono, the four half-block modes */
+#define Y(id, m)                                                                                                       \
+  int achipk_render_rinst_launch_##id##_m##m(ACHIP_RINST_ARGS);                                                         \
+  int achipk_render_rinst_lds_##id##_m##m(int mode);
+#define X(id, W, C) ACHIP_RINST_MODES(Y, id)
 ACHIP_ROWS_VARIANTS(X)
 #undef X
+#undef Y
+#define Y(id, m)                                                                                                       \
+  case m:                                                                                                              \
+    return achipk_render_rinst_launch_##id##_m##m(mode, comp, frames, n, lut, out, stride, len, uniform, wire, stream);
+#define Z(id, m)                                                                                                       \
+  case m:                                                                                                              \
+    return achipk_render_rinst_lds_##id##_m##m(mode);
+#define X(id, W, C)                                                                                                    \
+  static inline int achipk_render_rinst_launch_##id(ACHIP_RINST_ARGS) {                                                 \
+    switch (mode) { ACHIP_RINST_MODES(Y, id) }                                                                         \
+    return 1; /* hipErrorInvalidValue */                                                                               \
+  }                                                                                                                    \
+  static inline int achipk_render_rinst_lds_##id(int mode) {                                                            \
+    switch (mode) { ACHIP_RINST_MODES(Z, id) }                                                                         \
+    return -1;                                                                                                         \
+  }
+ACHIP_ROWS_VARIANTS(X)
+#undef X
+#undef Y
+#undef Z
 
 #ifdef __cplusplus
 }

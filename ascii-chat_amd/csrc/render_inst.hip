@@ -10,9 +10,10 @@
 #include "render_kernels.hpp"
 #include "render_variants.h"
 
-#ifndef ACHIP_INST
-#error "compile with -DACHIP_INST=<variant id>"
+#if !defined(ACHIP_INST) || !defined(ACHIP_PART)
+#error "compile with -DACHIP_INST=<variant id> -DACHIP_PART=<0: modes 0..4 (mono, the per-cell modes) | 1: modes 5..9 (half blocks, dither)>"
 #endif
+#define ACHIP_IN_PART(m) (((m) >= ACHIP_MODE_HB_TRUE) == (ACHIP_PART == 1))
 
 namespace {
 
@@ -31,7 +32,7 @@ constexpr bool HAS_SPLIT = ACHIP_INST == 1 || ACHIP_INST == 2 || ACHIP_INST == 4
  * geometries worthwhile; the host policy sends them to the 1024-thread one, the wide one or the rows kernel): those
  * instantiations do not exist */
 template <int MODE> constexpr bool has_mode() {
-  return !(achip::mode_is_halfblock(MODE) && (ACHIP_INST == 1 || ACHIP_INST == 2));
+  return ACHIP_IN_PART(MODE) && !(achip::mode_is_halfblock(MODE) && (ACHIP_INST == 1 || ACHIP_INST == 2));
 }
 
 template <int MODE, bool COMP, bool SPLIT>
@@ -80,7 +81,7 @@ hipError_t launch_mode(bool comp, const achip_frame_t *frames, int n, const achi
 #define ACHIP_CAT2(a, b) a##b
 #define ACHIP_CAT(a, b) ACHIP_CAT2(a, b)
 
-extern "C" int ACHIP_CAT(achip_render_inst_launch_, ACHIP_INST)(int mode, int comp, const achip_frame_t *frames, int n,
+extern "C" int ACHIP_CAT(ACHIP_CAT(ACHIP_CAT(achipk_render_inst_launch_, ACHIP_INST), _p), ACHIP_PART)(int mode, int comp, const achip_frame_t *frames, int n,
                                                                 const achip_lut_t *lut, uint8_t *out, uint64_t stride,
                                                                 uint32_t *len, unsigned long long *prof, int parts,
                                                                 int rows_per_part, unsigned long long *part_sync,
@@ -113,11 +114,11 @@ extern "C" int ACHIP_CAT(achip_render_inst_launch_, ACHIP_INST)(int mode, int co
   return (int)hipErrorInvalidValue;
 }
 
-extern "C" int ACHIP_CAT(achip_render_inst_lds_, ACHIP_INST)(int mode) {
+extern "C" int ACHIP_CAT(ACHIP_CAT(ACHIP_CAT(achipk_render_inst_lds_, ACHIP_INST), _p), ACHIP_PART)(int mode) {
   switch (mode) {
 #define M(m)                                                                                                           \
   case m:                                                                                                              \
-    return achip::Lds<m, G::BLOCK, G::CAP, G::RING>::bytes;
+    return ACHIP_IN_PART(m) ? achip::Lds<m, G::BLOCK, G::CAP, G::RING>::bytes : -1;
     M(ACHIP_MODE_MONO)
     M(ACHIP_MODE_TRUE_FG)
     M(ACHIP_MODE_256_FG)

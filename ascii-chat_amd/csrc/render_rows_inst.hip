@@ -1,7 +1,9 @@
 /*
- * render_rows_inst.hip -- instantiates the rows kernel (render_rows.hpp) for ONE geometry (-DACHIP_RINST=<variant id>):
- * the five run-structured modes x {plain, composite sampler} x {plain, frame CRC riding the drain}.  One translation unit
- * per geometry so that the build runs in parallel.  Built only with hipcc --offload-arch=gfx950.
+ * render_rows_inst.hip -- instantiates the rows kernel (render_rows.hpp) for ONE geometry and ONE mode
+ * (-DACHIP_RINST=<variant id> -DACHIP_RMODE=<mode id>): {plain, composite sampler} x {plain, frame CRC riding the drain}.
+ * One translation unit per (geometry, mode) so that the build runs in parallel (the seven-slot geometry's five modes in
+ * one unit were the build's critical path: 55 s); hip_launch.hip dispatches on the mode.  Built only with hipcc
+ * --offload-arch=gfx950.
  */
 #include <hip/hip_runtime.h>
 
@@ -12,8 +14,8 @@
 #include "render_rows.hpp"
 #include "render_variants.h"
 
-#ifndef ACHIP_RINST
-#error "compile with -DACHIP_RINST=<rows variant id>"
+#if !defined(ACHIP_RINST) || !defined(ACHIP_RMODE)
+#error "compile with -DACHIP_RINST=<rows variant id> -DACHIP_RMODE=<mode id>"
 #endif
 
 namespace {
@@ -27,7 +29,14 @@ ACHIP_ROWS_VARIANTS(X)
 #undef X
 using G = RGeometry<ACHIP_RINST>;
 
-constexpr bool HAS_CRC = true, HAS_COMP = true; /* (a 1024-thread geometry would have neither: 128-VGPR cap) */
+/* the frame CRC riding the rows kernel's drain costs more than the stand-alone pass (hip_launch.hip:
+ * achip_variant_crc_pays), so no plan takes it by itself: those instantiations exist in -DACHIP_ALL_GEOMETRIES builds only */
+#ifdef ACHIP_ALL_GEOMETRIES
+constexpr bool HAS_CRC = true;
+#else
+constexpr bool HAS_CRC = false;
+#endif
+constexpr bool HAS_COMP = true;
 
 /* the constant tables of <MODE>'s CRC instantiation: built on the device once per process, then read-only */
 template <int MODE> hipError_t crc_tables(const uint4 **out) {
@@ -94,7 +103,7 @@ hipError_t launch_one(const achip_frame_t *frames, int n, const achip_lut_t *lut
 #define ACHIP_CAT2(a, b) a##b
 #define ACHIP_CAT(a, b) ACHIP_CAT2(a, b)
 
-extern "C" int ACHIP_CAT(achip_render_rinst_launch_, ACHIP_RINST)(int mode, int comp, const achip_frame_t *frames, int n,
+extern "C" int ACHIP_CAT(ACHIP_CAT(ACHIP_CAT(achipk_render_rinst_launch_, ACHIP_RINST), _m), ACHIP_RMODE)(int mode, int comp, const achip_frame_t *frames, int n,
                                                                   const achip_lut_t *lut, uint8_t *out, uint64_t stride,
                                                                   uint32_t *len, const achip_uniform_t *uniform,
                                                                   const achip_wire_t *wire, void *stream) {
@@ -122,26 +131,18 @@ extern "C" int ACHIP_CAT(achip_render_rinst_launch_, ACHIP_RINST)(int mode, int 
         return (int)hipErrorInvalidValue;                                                                              \
     }                                                                                                                  \
     return (int)launch_one<m, false, false>(frames, n, lut, out, stride, len, uni, achip_wire_t{}, s);
-    M(ACHIP_MODE_MONO)
-    M(ACHIP_MODE_HB_TRUE)
-    M(ACHIP_MODE_HB_256)
-    M(ACHIP_MODE_HB_16)
-    M(ACHIP_MODE_HB_MONO)
+    M(ACHIP_RMODE)
 #undef M
   }
   return (int)hipErrorInvalidValue;
 }
 
-extern "C" int ACHIP_CAT(achip_render_rinst_lds_, ACHIP_RINST)(int mode) {
+extern "C" int ACHIP_CAT(ACHIP_CAT(ACHIP_CAT(achipk_render_rinst_lds_, ACHIP_RINST), _m), ACHIP_RMODE)(int mode) {
   switch (mode) {
 #define M(m)                                                                                                           \
   case m:                                                                                                              \
     return achip::RLds<m, G::WAVES>::bytes;
-    M(ACHIP_MODE_MONO)
-    M(ACHIP_MODE_HB_TRUE)
-    M(ACHIP_MODE_HB_256)
-    M(ACHIP_MODE_HB_16)
-    M(ACHIP_MODE_HB_MONO)
+    M(ACHIP_RMODE)
 #undef M
   }
   return -1;

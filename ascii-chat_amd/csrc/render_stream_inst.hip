@@ -189,7 +189,7 @@ hipError_t launch_pack(const achip_frame_t *frames, int n, const achip_lut_t *lu
 #define ACHIP_CAT2(a, b) a##b
 #define ACHIP_CAT(a, b) ACHIP_CAT2(a, b)
 
-extern "C" int ACHIP_CAT(achip_render_sinst_launch_, ACHIP_SINST)(int mode, int comp, const achip_frame_t *frames, int n,
+extern "C" int ACHIP_CAT(achipk_render_sinst_launch_, ACHIP_SINST)(int mode, int comp, const achip_frame_t *frames, int n,
                                                                   const achip_lut_t *lut, uint8_t *out, uint64_t stride,
                                                                   uint32_t *len, const achip_uniform_t *uniform,
                                                                   unsigned long long *prof, const achip_wire_t *wire,
@@ -223,7 +223,7 @@ extern "C" int ACHIP_CAT(achip_render_sinst_launch_, ACHIP_SINST)(int mode, int 
 }
 
 #if ACHIP_SINST == 16 || ACHIP_SINST == 17
-extern "C" int ACHIP_CAT(achip_render_sinst_pack_launch_, ACHIP_SINST)(int mode, const achip_frame_t *frames, int n, const achip_lut_t *lut,
+extern "C" int ACHIP_CAT(achipk_render_sinst_pack_launch_, ACHIP_SINST)(int mode, const achip_frame_t *frames, int n, const achip_lut_t *lut,
                                               uint64_t stride, uint32_t *len, const achip_uniform_t *uniform,
                                               const achip_wire_t *wire, const achip_packdev_t *pack, void *stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -249,7 +249,7 @@ extern "C" int ACHIP_CAT(achip_render_sinst_pack_launch_, ACHIP_SINST)(int mode,
 #endif
 
 #if ACHIP_SINST == 18
-extern "C" int achip_render_sinst_parts_launch_18(int mode, int comp, const achip_frame_t *frames, int n, const achip_lut_t *lut,
+extern "C" int achipk_render_sinst_parts_launch_18(int mode, int comp, const achip_frame_t *frames, int n, const achip_lut_t *lut,
                                                   uint8_t *out, uint64_t stride, uint32_t *len, const achip_uniform_t *uniform,
                                                   unsigned long long *prof, const achip_partsdev_t *ps, void *stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -275,7 +275,7 @@ extern "C" int achip_render_sinst_parts_launch_18(int mode, int comp, const achi
 }
 #endif
 
-extern "C" int ACHIP_CAT(achip_render_sinst_lds_, ACHIP_SINST)(int mode) {
+extern "C" int ACHIP_CAT(achipk_render_sinst_lds_, ACHIP_SINST)(int mode) {
   switch (mode) {
 #define M(m)                                                                                                           \
   case m:                                                                                                              \

@@ -13,11 +13,23 @@
 #else
 #define ACHIP_TEST_VARIANT(X)
 #endif
+/* Geometries the automatic choice (achip_choose_geometry) takes for no plan of the round-4 audit grid (420 plans,
+ * profiles/r04_policy_audit.txt) nor for any BASELINE config are built only with -DACHIP_ALL_GEOMETRIES (make
+ * EXTRA=-DACHIP_ALL_GEOMETRIES; the emulator and the mock runtime of the CPU suite always are): frame geometry 2, stream
+ * geometry 19, the rows kernel's fused-CRC instantiations.  They stay selectable by hand (plan_set_variant /
+ * plan_set_fused_crc) in such a build; in the default build those calls say so. */
+#ifdef ACHIP_ALL_GEOMETRIES
+#define ACHIP_EXTRA_VARIANT(X) X(2, 256, 1024, 16384) /* small grids (<= 1024-cell rows): 4+ workgroups per CU */
+#define ACHIP_STREAM_EXTRA_VARIANT(X) X(19, 16, 1)    /* 1024 threads, one cell per lane: fewest registers     */
+#else
+#define ACHIP_EXTRA_VARIANT(X)
+#define ACHIP_STREAM_EXTRA_VARIANT(X)
+#endif
 #define ACHIP_VARIANTS(X)                                                                                         \
   X(0, 512, 4096, 65536)  /* wide: any row up to 4096 cells; eight cells per thread in 512-thread workgroups, which may
                              use 256 VGPRs (a 1024-thread workgroup is capped at 128: its four cells per thread spilled) */ \
   X(1, 512, 2048, 32768)  /* narrow: rows up to 2048 cells, 2-3 workgroups per CU                               */ \
-  X(2, 256, 1024, 16384)  /* small grids (<= 1024-cell rows): 4+ workgroups per CU                              */ \
+  ACHIP_EXTRA_VARIANT(X)  /* id 2                                                                               */ \
   ACHIP_TEST_VARIANT(X)   /* id 3 does not exist in the product library                                         */ \
   X(4, 1024, 2048, 114688) /* rows up to 2048 cells, 2 cells per thread (no spills); 112 KB staging: one window per
                               chunk even for 41-byte half-block tokens; with the other tables ~132-156 KB of the 160 KB LDS */
@@ -38,7 +50,7 @@
   X(16, 16, 2) /* 1024 threads: a 1080p -> 80x24 frame is one block per wave                                   */ \
   X(17, 8, 2)  /* 512 threads: two to four workgroups per CU                                                    */ \
   X(18, 4, 2)  /* 256 threads                                                                                   */ \
-  X(19, 16, 1) /* 1024 threads, one cell per lane: fewest registers                                             */ \
+  ACHIP_STREAM_EXTRA_VARIANT(X) /* id 19                                                                        */ \
   ACHIP_STREAM_TEST_VARIANT(X)
 #define ACHIP_ROWS_VARIANT_FIRST 24
 #define ACHIP_IS_STREAM_VARIANT(v) ((v) >= ACHIP_STREAM_VARIANT_FIRST && (v) < ACHIP_ROWS_VARIANT_FIRST)

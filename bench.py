@@ -869,10 +869,11 @@ def maybe_spawn_ranks(args):
 
 def rank_comm(torch, pkg, dist, world, rank, backend):
     """The C-ABI's RCCL communicator over the ranks of this run (comm.c), its unique id broadcast through
-    torch.distributed.  None for a single rank or a gloo test run."""
-    if world <= 1 or backend != "nccl":
+    torch.distributed.  None for a single rank, and for a gloo test run unless a stand-in transport is named
+    (ASCIICHAT_HIP_RCCL_LIB = tests/cabi/libloopback_rccl.so: the ranks share one GPU, RCCL itself would refuse them)."""
+    if world <= 1 or (backend != "nccl" and not os.environ.get("ASCIICHAT_HIP_RCCL_LIB")):
         return None
-    uid = torch.zeros(pkg.COMM_ID_BYTES, dtype=torch.uint8, device="cuda")
+    uid = torch.zeros(pkg.COMM_ID_BYTES, dtype=torch.uint8, device="cuda" if backend == "nccl" else "cpu")
     if rank == 0:
         uid.copy_(torch.frombuffer(bytearray(pkg.comm_unique_id()), dtype=torch.uint8))
     dist.broadcast(uid, 0)

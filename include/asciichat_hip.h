@@ -370,7 +370,9 @@ void asciichat_hip_grid_destroy(asciichat_hip_grid_t *grid);
 int asciichat_hip_plan_render_crc(asciichat_hip_plan_t *plan, uint8_t *out_dev, size_t out_stride, uint32_t *out_len_dev,
                                   uint32_t *crc_out_dev, void *stream);
 /* ... and the whole wire stage with the render: one launch where plan_has_fused_crc(), render + frame_packets otherwise.
- * dims_dev ({width, height} per frame) may be NULL (zeros in the headers); packet_crc_out_dev may be NULL. */
+ * dims_dev ({width, height} per frame) may be NULL (zeros in the headers); packet_crc_out_dev may be NULL.
+ * The wire entry points (plan_render_crc / _packets / _packets_packed / _packed) of ONE plan must be called on ONE stream:
+ * the plan owns the span registers, arrival counters and the pack cursor they use between launches. */
 int asciichat_hip_plan_render_packets(asciichat_hip_plan_t *plan, uint8_t *out_dev, size_t out_stride,
                                       uint32_t *out_len_dev, const uint32_t *dims_dev, uint32_t *crc_out_dev,
                                       uint8_t *hdr_out_dev, uint32_t *packet_crc_out_dev, void *stream);

@@ -1,6 +1,9 @@
 """One rank of tests/test_comm_two_ranks.py: drives ascii-chat_amd/csrc/comm.c with a world of `world` ranks.
 
-usage: comm_worker.py <rank> <world> <uid_file> <shared_gpu 0|1>
+usage: comm_worker.py <rank> <world> <uid_file> <shared_gpu 0|1> [full]
+
+"full" (the world-8 test): the batch is BASELINE's 256 frames (32 per rank at world 8), and frames of configs[4]'s size
+(4K -> 400x120 half blocks: 1.8 MB each) go through the packed gather too.
 
 Every rank renders ITS block of a sharded batch, then checks after
   * asciichat_hip_comm_all_gather_slab      -- every frame of every rank against the oracle,
@@ -47,8 +50,10 @@ def main():
     L = pkg.lib()
     import ctypes as C
 
+    full = len(sys.argv) > 5 and sys.argv[5] == "full"
     # ---- (1) a batch of 7 frames sharded (4, 3): slots = 4, the last slot of rank 1 stays empty ------------------------
-    n, W, H = 7, 40, 12
+    # (full: 256 frames, 32 x 8 at world 8)
+    n, W, H = (256 if full else 7), 40, 12
     imgs = [orc.frame_hash_noise(96, 54, 500 + i) if i % 3 else orc.frame_bars(96, 54, i) for i in range(n)]
     slots = L.achip_shard_slots(n, world)
     first, count = C.c_int(), C.c_int()
@@ -87,6 +92,36 @@ def main():
             assert off[s] % 16 == 0 and r * blk <= off[s] and off[s] + plen[s] <= (r + 1) * blk
             assert ph[off[s]:off[s] + plen[s]].tobytes() == exp[f_r.value + i], f"rank {rank}: packed frame {f_r.value + i} differs"
     plan.close()
+    # ---- (2b) frames of configs[4]'s size through the packed gather: 1.8 MB each, one per rank plus one (uneven shards), so
+    # that a rank's block spans several of the transport's chunks and the lengths-first sizing sees megabytes
+    if full:
+        nb, Wb, Hb = world + 1, 400, 120
+        big = [orc.frame_hash_noise(400, 240, 900 + i) for i in range(nb)]
+        slots_b = L.achip_shard_slots(nb, world)
+        fb, cb = C.c_int(), C.c_int()
+        L.achip_shard_bounds(nb, world, rank, C.byref(fb), C.byref(cb))
+        devb = [torch.from_numpy(big[fb.value + i]).cuda() for i in range(cb.value)]
+        fr = [pkg.frame_setup(d.data_ptr(), 400, 240, Wb, Hb, 2, False, False, False) for d in devb]
+        assert fr, "world + 1 frames: every rank owns at least one"
+        planb = pkg.Plan(pkg.MODE_HB_TRUE, orc.PALETTE_STANDARD, fr)
+        sb = planb.stride
+        slabb = torch.zeros(world * slots_b * sb, dtype=torch.uint8, device="cuda")
+        lnb = torch.zeros(world * slots_b, dtype=torch.int32, device="cuda")
+        planb.render(slabb.data_ptr() + rank * slots_b * sb, sb, lnb.data_ptr() + 4 * rank * slots_b, st)
+        packedb = torch.zeros(world * slots_b * sb, dtype=torch.uint8, device="cuda")
+        offb, plenb, blkb = comm.all_gather_packed(slabb.data_ptr(), sb, lnb.data_ptr(), slots_b, packedb.data_ptr(), slots_b * sb, st)
+        torch.cuda.synchronize()
+        pb_h = packedb.cpu().numpy()
+        assert blkb % 16 == 0 and blkb <= slots_b * sb
+        for r in range(world):
+            f_r, c_r = C.c_int(), C.c_int()
+            L.achip_shard_bounds(nb, world, r, C.byref(f_r), C.byref(c_r))
+            for i in range(c_r.value):
+                sl = r * slots_b + i
+                e = orc.convert_with_caps(big[f_r.value + i], Wb, Hb, 3, 2, False, False, False)
+                assert plenb[sl] == len(e) > 1_000_000, (plenb[sl], len(e))
+                assert pb_h[offb[sl]:offb[sl] + plenb[sl]].tobytes() == e, f"rank {rank}: big packed frame {f_r.value + i} differs"
+        planb.close()
     # ---- (3) the pixel-space grid from tiles that live on different ranks -----------------------------------------------
     for n_src, has_video in ((9, None), (5, [True, True, False, True, True]), (3, None)):
         srcs = [orc.frame_hash_noise(320, 180, 40 + k) if k % 2 else orc.frame_bars(320, 180, k) for k in range(n_src)]

@@ -27,7 +27,7 @@ def build():
     obj = os.path.join(os.path.dirname(EMU_SO), "achip_host.o")
     subprocess.check_call(["gcc", "-std=gnu11", "-O2", "-fPIC", "-I" + INC, "-c", os.path.join(CSRC, "achip_host.c"), "-o", obj])
     extra = os.environ.get("ACHIP_EMU_DEFS", "").split()  # e.g. -DACHIP_EMIT_OR_MODES=0x3FF to test an experiment
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-shared", "-fPIC", *extra, "-I" + EMU_DIR, "-I" + CSRC, "-I" + INC,  # EMU_DIR first: <gfx950_ops.hpp> = the emulator's twin
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-shared", "-fPIC", "-DACHIP_ALL_GEOMETRIES", *extra, "-I" + EMU_DIR, "-I" + CSRC, "-I" + INC,  # EMU_DIR first: <gfx950_ops.hpp> = the emulator's twin
                            os.path.join(EMU_DIR, "emu_driver.cpp"), obj, "-o", EMU_SO])
     return EMU_SO
 

@@ -40,7 +40,7 @@ def build_library():
                                "-c", src, "-o", obj])
         objs.append(obj)
     lobj = os.path.join(BUILD, "mock_launch.o")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-I" + EMU, "-I" + CSRC, "-I" + INC, "-c",
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-DACHIP_ALL_GEOMETRIES", "-I" + EMU, "-I" + CSRC, "-I" + INC, "-c",
                            os.path.join(MOCK, "mock_launch.cpp"), "-o", lobj])
     subprocess.check_call(["g++", "-shared", "-o", so, *objs, lobj, "-lpthread", "-lm", "-ldl"])
     return so
@@ -54,7 +54,7 @@ def build_thread_harness(sanitizer=None, harness="dropin_threads_mock"):
     if _newer(exe, _deps()):
         return exe
     os.makedirs(BUILD, exist_ok=True)
-    flags = ["-std=gnu11", "-O1", "-g", "-pthread", "-I" + INC, "-I" + CSRC, "-I" + HIP_INC]
+    flags = ["-std=gnu11", "-O1", "-g", "-pthread", "-DACHIP_ALL_GEOMETRIES", "-I" + INC, "-I" + CSRC, "-I" + HIP_INC]
     if sanitizer:
         flags += ["-fsanitize=" + sanitizer, "-fno-omit-frame-pointer", "-Wno-tsan"]
     srcs = [os.path.join(CSRC, f) for f in HOST_C] + [os.path.join(MOCK, f) for f in

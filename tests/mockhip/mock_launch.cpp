@@ -184,6 +184,7 @@ extern "C" int achip_launch_comp_poke(achip_composite_t *comp, const achip_comp_
 }
 
 /* geometry facts of hip_launch.hip, from the same table (render_variants.h) */
+extern "C" int achip_launch_warm_crc_tables(void) { return 0; } /* (the mock's kernels build their tables per launch) */
 extern "C" int achip_variant_block(int variant) {
   switch (variant) {
 #define X(id, W, C)                                                                                                    \

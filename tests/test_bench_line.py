@@ -83,3 +83,30 @@ def test_bench_two_ranks_on_the_shared_gpu_prints_one_compact_line(workload, tmp
     if workload != "grid9":
         assert len(line["multi_gpu"]["per_rank_frames_per_s"]) == 2 and line["multi_gpu"]["backend"] == "gloo"
     assert json.load(open(extra))["n_gpus"] == 2
+
+
+@pytest.mark.gpu
+def test_bench_eight_ranks_on_the_shared_gpu_prints_one_compact_line(tmp_path):
+    """`python bench.py --gpus 8` -- the driver's largest scaling point -- with the eight ranks on the one GPU (gloo): the
+    control flow of the 8-way run (spawn, barriers, MAX over ranks, the comm.c leg over the stand-in transport) and the
+    line it prints: n_gpus 8, the ranks the communicator counted, a rate per rank, under 4 KB.  NOT a scaling number."""
+    import subprocess
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_comm_two_ranks import build_loopback
+
+    env = dict(os.environ, ASCIICHAT_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", ASCIICHAT_HIP_RCCL_LIB=build_loopback())
+    extra = tmp_path / "extra.json"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "5", "--warmup", "2", "--batch", "64",
+           "--input-sets", "4", "--no-cpu", "--no-d2h", "--no-hot", "--no-wire", "--others", "none", "--extra", str(extra)]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1 and len(lines[0]) <= 4096, (len(lines), [len(l) for l in lines])
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["value"] > 0 and line["scaling"] == "weak"
+    assert len(line["multi_gpu"]["per_rank_frames_per_s"]) == 8 and line["multi_gpu"]["backend"] == "gloo"
+    assert line["rccl_ranks"] == 8, line.get("multi_gpu")
+    assert line["config"]["global_batch"] == 8 * 64
+    assert json.load(open(extra))["n_gpus"] == 8

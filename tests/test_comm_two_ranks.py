@@ -33,10 +33,10 @@ def test_loopback_transport_builds_and_exports_what_comm_c_resolves():
         assert hasattr(so, name), name
 
 
-def run_world(world, env_extra, shared_gpu, tmp_path):
+def run_world(world, env_extra, shared_gpu, tmp_path, full=False):
     uid = str(tmp_path / "uid.bin")
     env = dict(os.environ, **env_extra)
-    procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), uid, "1" if shared_gpu else "0"], env=env,
+    procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), uid, "1" if shared_gpu else "0"] + (["full"] if full else []), env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = []
     for p in procs:
@@ -54,6 +54,15 @@ def run_world(world, env_extra, shared_gpu, tmp_path):
 @pytest.mark.gpu
 def test_comm_world2_over_loopback_transport_on_one_gpu(tmp_path):
     run_world(2, {"ASCIICHAT_HIP_RCCL_LIB": build_loopback()}, True, tmp_path)
+
+
+@pytest.mark.gpu
+def test_comm_world8_over_loopback_transport_on_one_gpu(tmp_path):
+    """The driver's 8-GPU run, de-risked without the hardware: comm.c at world 8 over the stand-in
+    transport, eight processes on the one GPU -- BASELINE's 256 frames sharded 32 x 8 through the slab and packed gathers,
+    frames of configs[4]'s size (1.8 MB) through the packed gather, configs[3]'s nine sources dealt (2, 1, 1, 1, 1, 1, 1, 1)
+    through grid_slot_of (and five / three sources: ranks that own nothing).  No scaling number follows from this."""
+    run_world(8, {"ASCIICHAT_HIP_RCCL_LIB": build_loopback()}, True, tmp_path, full=True)
 
 
 @pytest.mark.gpu

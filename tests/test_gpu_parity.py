@@ -90,6 +90,22 @@ def render_descs(gpu, mode, frames, palette=orc.PALETTE_STANDARD):
 TORTURE = orc.frame_torture()
 
 
+def geometry_built(pkg, variant):
+    """frame geometry 2, stream geometry 19 and the rows kernel's fused CRC exist only in -DACHIP_ALL_GEOMETRIES builds of
+    the library (render_variants.h: no plan takes them by itself); scripts/gpu_r5_*.sh run this suite on both builds"""
+    L = pkg.lib()
+    L.achip_variant_block.restype = C.c_int
+    L.achip_variant_block.argtypes = [C.c_int]
+    return L.achip_variant_block(variant) > 0
+
+
+def rows_crc_built(pkg):
+    L = pkg.lib()
+    L.achip_variant_has_crc.restype = C.c_int
+    L.achip_variant_has_crc.argtypes = [C.c_int]
+    return bool(L.achip_variant_has_crc(24))
+
+
 @pytest.mark.parametrize("mode", ALL_MODES, ids=MODE_NAMES)
 def test_torture_all_modes_all_variants(gpu, mode):
     # every geometry of the phase kernel that the product library carries (the 64-thread test geometry exists in the
@@ -100,6 +116,8 @@ def test_torture_all_modes_all_variants(gpu, mode):
     if mode in (0, 5, 6, 7, 8):  # the run-structured modes: both geometries of the rows kernel (rows up to 256 / 448 cells)
         variants += (25, 24)
     for variant in variants:
+        if not geometry_built(gpu[0], variant):
+            continue
         for (W, H) in [(80, 24), (97, 31), (200, 60)]:
             got = render_batch(gpu, mode, [TORTURE], W, H, variant=variant)[0]
             assert got == oracle_convert(TORTURE, mode, W, H, orc.PALETTE_STANDARD), (MODE_NAMES[mode], variant, W, H)
@@ -122,6 +140,7 @@ def test_every_geometry_renders_a_batch_to_the_same_bytes(gpu):
         forced = ([(16, -1), (17, -1), (18, 0), (19, -1)] if cell else [(25, -1), (24, -1)]) + [(4, -1), (4, 0), (0, -1), (4, 3)]
         if mode not in (MODE_HB_TRUE,):
             forced += [(1, -1), (1, 0)]
+        forced = [(v, sp) for (v, sp) in forced if geometry_built(pkg, v)]
         for (W, H) in ((120, 40), (200, 60)):
             for n in (16, n_max):
                 frames = [pkg.frame_setup(src[k].data_ptr(), 480, 270, W, H, rm, False, False, False) for k in range(n)]
@@ -689,9 +708,10 @@ def test_render_with_fused_frame_crc(gpu):
         plan = pkg.Plan(mode, orc.PALETTE_STANDARD, frames)
         if variant >= 0:
             plan.set_variant(variant)
-        if variant >= 24:  # the rows kernel carries the fused CRC but plans do not pick it by themselves (slower there)
-            assert not plan.fused_crc
+        if variant >= 24:  # the rows kernel carries the fused CRC (in builds with every geometry) but plans do not pick
+            assert not plan.fused_crc  # it by themselves (slower there); asked for in a default build, the stand-alone pass runs
             plan.set_fused_crc(1)
+            want_fused = rows_crc_built(pkg)
         if want_fused is not None:
             assert plan.fused_crc == want_fused, (mode, variant, plan.variant)
         n = len(imgs)
