@@ -436,11 +436,11 @@ size_t asciichat_hip_plan_out_stride(const asciichat_hip_plan_t *p) { return p ?
 int asciichat_hip_plan_set_variant(asciichat_hip_plan_t *p, int variant) {
   if (!p)
     return ASCIICHAT_HIP_ERR_INVALID_PARAM;
+  if (variant >= 0 && achip_variant_block(variant) <= 0)
+    return achip_fail(ASCIICHAT_HIP_ERR_NOT_SUPPORTED, "geometry %d is not in this build (render_variants.h: make EXTRA=-DACHIP_ALL_GEOMETRIES)", variant);
   if (variant >= 0 && !ACHIP_IS_STREAM_VARIANT(variant) && achip_variant_cap(variant) < p->max_wp) /* (a stream geometry's
                                                              "cap" is cells per frame: plan_measure judges those) */
     return achip_fail(ASCIICHAT_HIP_ERR_NOT_SUPPORTED, "variant %d cannot hold a %d-cell row", variant, p->max_wp);
-  if (variant >= ACHIP_STREAM_VARIANT_FIRST && achip_variant_block(variant) <= 0)
-    return achip_fail(ASCIICHAT_HIP_ERR_NOT_SUPPORTED, "geometry %d is not in this build (render_variants.h: make EXTRA=-DACHIP_ALL_GEOMETRIES)", variant);
   const int before = p->variant_user;
   p->variant_user = variant;
   const int rc = plan_measure(p, p->frames_pinned);
