@@ -150,6 +150,37 @@ __device__ inline void store_u4_nt(uint8_t *__restrict__ p, uint4 v) {
 #endif
 }
 
+/* 16 / 8 / 4 / 2 bytes at ANY byte address of global memory (the hardware takes unaligned vector accesses; a piece that
+ * straddles a line becomes two requests).  Plain stores: the pieces of a line meet in the L2 and leave it as a line. */
+__device__ inline void store_u4_unaligned(uint8_t *p, uint4 v) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  struct __attribute__((packed)) U {
+    u32x4 v;
+  };
+  u32x4 w = {v.x, v.y, v.z, v.w};
+  reinterpret_cast<U *>(p)->v = w;
+}
+__device__ inline void store_u2_unaligned(uint8_t *p, uint32_t a, uint32_t b) {
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  struct __attribute__((packed)) U {
+    u32x2 v;
+  };
+  u32x2 w = {a, b};
+  reinterpret_cast<U *>(p)->v = w;
+}
+__device__ inline void store_u1_unaligned(uint8_t *p, uint32_t a) {
+  struct __attribute__((packed)) U {
+    uint32_t v;
+  };
+  reinterpret_cast<U *>(p)->v = a;
+}
+__device__ inline void store_u16_unaligned(uint8_t *p, uint16_t a) {
+  struct __attribute__((packed)) U {
+    uint16_t v;
+  };
+  reinterpret_cast<U *>(p)->v = a;
+}
+
 /* ---- clocks (diagnostics) ------------------------------------------------------------------------------------------ */
 __device__ inline unsigned long long cycle_now() { return (unsigned long long)clock64(); }
 __device__ inline unsigned long long wall_now() { return (unsigned long long)wall_clock64(); } /* 100 MHz */

@@ -29,6 +29,14 @@
 
 namespace achip {
 
+#ifndef ACHIP_ROWS_SLOT_EMIT
+#define ACHIP_ROWS_SLOT_EMIT 0 /* 1 (A/B builds): tokens through per-lane LDS slots and straight to their place in the frame
+                                  (store pass, below) instead of the packed staging area with its line-wise drain.  Measured
+                                  and NOT adopted: the byte stores stop conflicting, but a frame's lines then reach the L2 in
+                                  ~16-byte pieces from seven store instructions per slice, and the write path takes that worse
+                                  than the LDS took the conflicts -- sampled 400x240 half blocks 161.6 -> 201.8 us, from 4K
+                                  sources 201 -> 235 (profiles/r05_rows_slot_emit_ab.txt) */
+#endif
 #ifndef ACHIP_ROWS_EMIT_OR_MODES
 #define ACHIP_ROWS_EMIT_OR_MODES 0 /* bit m set: mode m stores its tokens through PackSink here.  Off: this kernel is bound
                                       by VALU issue (profiles/r03_k5_sq_counters.txt: 130 M VALU instructions per 256-frame
@@ -764,6 +772,50 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
         const uint32_t len_k = meta[k] >> 24;
         const uint32_t off_k = ((pk[k / 2] >> (16 * (k & 1))) & 0xFFFFu) - len_k; /* within the slice */
         const Tok tk = rows_token_payload<MODE>(meta[k] & 0xFFFu, (meta[k] >> 12) & 0xFFFu, pt[k], pb[k], f.ops, glyph64);
+        /* SLOTS: every lane builds its token in a slot of its OWN, an odd number of dwords from its neighbours' -- the byte
+         * stores of a half-wave then fall into distinct banks (packed at the stream's offsets they land ~38 bytes apart at
+         * pseudo-random banks: 56 % of the launch's LDS-active cycles were conflicts, profiles/r05_k5_sampled_sq_counters.txt)
+         * -- reads it back as dwords and stores it at its place in the frame itself: whole 16-byte pieces, then 8 / 4 / 2 / 1
+         * by the bits of its length.  No packed image of the slice, no drain, no carry; the L2 merges the pieces of a line. */
+        constexpr bool SLOTS = !CRC && !EMIT_OR && (ACHIP_ROWS_SLOT_EMIT != 0);
+        if (SLOTS) {
+          constexpr uint32_t PITCH = 4u * (uint32_t)((rows_max_token(MODE) / 4 + 1) | 1); /* odd dwords; >= token + the 3 bytes a field may store past it */
+          static_assert(!SLOTS || 64 * (int)PITCH <= L::STAGE, "slots fit the wave's staging area");
+          const uint32_t slot = PITCH * (uint32_t)lane;
+          if (len_k != 0u) {
+            RowsFastSink<L::o_dec, L::o_flags + 16, L::NUM8 ? L::o_num_semi : -1, L::NUM8 ? L::o_num_m : -1> fs{{stage_addr + slot, dummy_addr}};
+            token_fields<MODE>(fs, tk, ascii_only);
+          }
+          lds_store_fence();
+          if (len_k != 0u) {
+            uint8_t *g = dst + (a + off_k);
+            const unsigned char *sl = stage + slot;
+            const uint32_t *sw = reinterpret_cast<const uint32_t *>(sl);
+            constexpr int BODY = rows_max_token(MODE) / 16; /* whole 16-byte pieces a token can have */
+#pragma unroll
+            for (int j = 0; j < BODY; j++)
+              if (len_k >= 16u * (uint32_t)(j + 1))
+                store_u4_unaligned(g + 16 * j, make_uint4(sw[4 * j], sw[4 * j + 1], sw[4 * j + 2], sw[4 * j + 3]));
+            uint32_t o = len_k & ~15u;
+            if (len_k & 8u) {
+              store_u2_unaligned(g + o, sw[o >> 2], sw[(o >> 2) + 1]);
+              o += 8u;
+            }
+            if (len_k & 4u) {
+              store_u1_unaligned(g + o, sw[o >> 2]);
+              o += 4u;
+            }
+            if (len_k & 2u) {
+              store_u16_unaligned(g + o, *reinterpret_cast<const uint16_t *>(sl + o));
+              o += 2u;
+            }
+            if (len_k & 1u)
+              g[o] = sl[o];
+          }
+          wave_lockstep(); /* the next slice's tokens go where these were read from (a wave's DS operations complete in order) */
+          a = a + n;
+          continue;
+        }
         if (CARRY) {
           /* the staging area's byte 0 is the line the slice starts in (q0); [own_q, qa) is already there */
           const uint32_t qa = a + dmis, q0 = qa & ~127u, qend = qa + n;

@@ -4,6 +4,7 @@
  * product header because the emulator build lists this directory first on the include path.
  */
 #pragma once
+#include <string.h>
 
 #include "hip_emu.h"
 
@@ -97,6 +98,13 @@ struct __attribute__((packed)) unaligned_u32 {
 inline uint32_t load_u32_unaligned_nt(const uint8_t *p) { return reinterpret_cast<const unaligned_u32 *>(p)->v; }
 inline uint32_t opaque(uint32_t v) { return v; }
 inline void store_u4_nt(uint8_t *p, uint4 v) { *reinterpret_cast<uint4 *>(p) = v; }
+inline void store_u4_unaligned(uint8_t *p, uint4 v) { memcpy(p, &v, 16); }
+inline void store_u2_unaligned(uint8_t *p, uint32_t a, uint32_t b) {
+  memcpy(p, &a, 4);
+  memcpy(p + 4, &b, 4);
+}
+inline void store_u1_unaligned(uint8_t *p, uint32_t a) { memcpy(p, &a, 4); }
+inline void store_u16_unaligned(uint8_t *p, uint16_t a) { memcpy(p, &a, 2); }
 
 inline unsigned long long cycle_now() { return 0ull; }
 inline unsigned long long wall_now() { return 0ull; }
