@@ -22,6 +22,15 @@
  * Staging is per SLICE (the 64 cells of one lane slot k), not per block: a 448-cell block of 53-byte half-block tokens
  * would need 25 KB per wave; a slice needs 3.6 KB, so sixteen waves fit a CU's LDS and the CRC tables besides.  Slices
  * drain like the stream kernel's blocks do (whole 16-byte groups as uint4, the shared first / last group as bytes).
+ *
+ * Round 5 (docs/history/round5.md): half the vector instructions per block.  What a cell's POSITION decides is
+ * decided once per frame (one record per slot: the sample's byte offset in its source row, pad / first-pixel / row-end
+ * flags, row inside the block); a block that is one text row takes its source rows from scalar registers, so a sample's
+ * address costs no vector arithmetic; samples become pixels in the MIDDLE of a block's turn (the turn's only wait for
+ * vector memory, and it waits for nothing); two slots share a length scan, kept for the store pass; a truecolor SGR's
+ * decimal fields come out of LDS ready to store.  The kernel then stops being bound by instruction issue alone: the token
+ * byte stores' LDS bank conflicts are what is left (measured; the alternatives that were costed or measured and rejected
+ * are in the round's log).
  */
 #pragma once
 

@@ -237,6 +237,19 @@ def test_plans_and_packed_output_on_the_mock(mock):
         exp = orc.convert_with_caps(imgs[i], 40, 12, 3, 0, False, False, False)
         assert slab[i * stride:i * stride + int(ln[i])].tobytes() == exp
         assert int(off[i + 1]) == int(off[i]) + ((len(exp) + 15) & ~15) and dst[int(off[i]):int(off[i]) + int(ln2[i])].tobytes() == exp
+    # ... and a caller that passes NO offsets relies on that order: it never gets the one-launch form (completion order),
+    # neither by default nor when exact lengths are forced on
+    for force in (-1, 1):
+        plan.set_exact_length(force)
+        slab[:] = 0
+        dst[:] = 0xEE
+        plan.render_packed(slab.ctypes.data, stride, ln.ctypes.data, dst.ctypes.data, dst.size, None, None)
+        at = 0
+        for i in range(n):
+            exp = orc.convert_with_caps(imgs[i], 40, 12, 3, 0, False, False, False)
+            assert dst[at:at + len(exp)].tobytes() == exp, (force, i)
+            assert slab[i * stride:i * stride + len(exp)].tobytes() == exp  # the two-pass form wrote the slab
+            at += (len(exp) + 15) & ~15
     plan.close()
 
 
