@@ -26,8 +26,7 @@
  * Round 5 (docs/history/round5.md): half the vector instructions per block.  What a cell's POSITION decides is
  * decided once per frame (one record per slot: the sample's byte offset in its source row, pad / first-pixel / row-end
  * flags, row inside the block); a block that is one text row takes its source rows from scalar registers, so a sample's
- * address costs no vector arithmetic; samples become pixels in the MIDDLE of a block's turn (the turn's only wait for
- * vector memory, and it waits for nothing); two slots share a length scan, kept for the store pass; a truecolor SGR's
+ * address costs no vector arithmetic; two slots share a length scan, kept for the store pass; a truecolor SGR's
  * decimal fields come out of LDS ready to store.  The kernel then stops being bound by instruction issue alone: the token
  * byte stores' LDS bank conflicts are what is left (measured; the alternatives that were costed or measured and rejected
  * are in the round's log).
@@ -626,11 +625,11 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
   };
 
   /* The loop holds a block's PIXELS (pt / pb), not its samples: the samples of block b + WAVES are requested at the top of
-   * block b's turn and turned into pixels in the middle of it, behind the length pass and in front of the drain.  That is
-   * the turn's only wait for vector memory, and it waits for nothing: the requests have had the whole length pass to
-   * return, and the previous turn's stores are long acknowledged.  (Converted at the top of the NEXT turn, as rounds 3
-   * and 4 had it, the conversion sat right behind the next requests and the drain's stores -- the compiler cannot count
-   * the stores of a loop, so it waited for everything, the requests it had just made included.) */
+   * block b's turn and turned into pixels in the middle of it, behind the length pass and in front of the drain.  (In the
+   * product build the wave still waits right behind the requests: the copies of the request loop -- one row / several rows,
+   * cached / non-temporal -- define the samples in different registers, and the phi moves that join them are moves of
+   * loaded values.  A build with one load per sample has no such wait, measured: no faster here, slower on the metric's
+   * shape in the stream kernel -- docs/history/round5.md 2b.) */
   uint32_t (&pt)[CPL] = rawT, (&pb)[CPL] = rawB;
   if (wave < nblk)
     to_pixels(wave, pt, pb, kinds);
