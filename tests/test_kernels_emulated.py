@@ -486,6 +486,30 @@ def test_rows_kernel_run_structure(mode):
             assert got == exp, (MODE_NAMES[mode], kind, W, H, variant, asp)
 
 
+@pytest.mark.parametrize("mode", ROWS_MODES, ids=ROWS_IDS)
+def test_rows_kernel_one_row_blocks_with_padding_flips_and_tint(mode):
+    """Round 5: a block that is ONE text row takes its source rows from scalar registers and its samples' byte offsets from
+    per-frame cell records (render_rows.hpp).  That path with everything the records fold in: left padding (aspect fit), top
+    padding, flips in both axes, the colour filter, odd half-block heights, sources narrower than the grid (samples repeat),
+    the buffer's first pixel (requested at offset 0, finished by masking) in the first AND -- flipped -- in the last row."""
+    import ctypes as C
+    rm = MODE_CAPS[mode][1]
+    cl = MODE_CAPS[mode][0]
+    imgs = [orc.frame_hash_noise(120, 90, 3), run_frames(37, 29, "blocks"), orc.frame_smooth(300, 7)]
+    one_row = padded = 0
+    for img in imgs:
+        for (W, H, variant) in [(120, 21, 28), (100, 9, 28), (127, 5, 28), (250, 7, 25), (440, 3, 24)]:
+            for fx, fy, flt in [(False, False, 0), (True, True, 3), (False, True, 7)]:
+                f = emu.frame_for_convert(img, W, H, rm, True, True)  # use_aspect_ratio + wants_padding
+                one_row += 64 * {28: 2, 25: 4, 24: 7}[variant] // 2 < f.pad_left + f.out_w <= 64 * {28: 2, 25: 4, 24: 7}[variant]
+                padded += f.pad_left > 0 and 64 * {28: 2, 25: 4, 24: 7}[variant] // 2 < f.pad_left + f.out_w
+                assert emu.lib().achip_frame_set_display_ops(C.byref(f), fx, fy, flt) == 0
+                exp = orc.display_convert(img, W, H, cl, rm, True, True, fx, fy, flt)
+                got = emu.render_frames(mode, [f], orc.PALETTE_STANDARD, variant)[0]
+                assert got == exp, (MODE_NAMES[mode], img.shape, W, H, variant, fx, fy, flt)
+    assert one_row >= 15 and padded >= 6, (one_row, padded)  # (the rest of the cases put several rows into a block)
+
+
 def test_rows_kernel_refuses_rows_wider_than_a_block():
     f = emu.frame_for_convert(TORTURE, 129, 3, 0)
     assert emu.render_frames(MODE_MONO, [f], orc.PALETTE_STANDARD, 28)[0] == 0xFFFFFFFE  # ACHIP_LEN_BADDESC
