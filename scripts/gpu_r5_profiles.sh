@@ -25,6 +25,8 @@ except Exception as e: print("$name: no line", e)
 PY
 }
 trace headline_s4 --steps 400 --regions 3 --streams 4
+trace headline_s4b --steps 2000 --regions 2 --streams 4   # (the tracer serialises short launches to a box- and run-dependent degree:
+trace headline_s4c --steps 2000 --regions 2 --streams 4   #  r5_commit_profiles.py takes the run that kept most launches in flight and lists all)
 trace headline_s1 --steps 400 --regions 3 --streams 1
 trace k3_4k_200x60 --workload 4k_200x60_truecolor --steps 100 --regions 3 --input-sets 4 --streams 4
 trace k5_4k_400x120_hb --workload 4k_400x120_halfblock --steps 40 --regions 3 --input-sets 4 --streams 4
