@@ -69,7 +69,7 @@ def main():
         for suf in ("_kernel_stats.csv", "_trace_overlap.json", "_under_rocprof.json"):
             src = os.path.join(d, nm + suf)
             if os.path.exists(src):
-                dst = os.path.join(PROF, "r05_" + name + suf)
+                dst = os.path.join(PROF, "r05_" + nm + suf)
                 shutil.copy(src, dst)
                 files.append("profiles/" + os.path.basename(dst))
         row["files"] = files
