@@ -183,7 +183,9 @@ int achip_frames_uniform(const achip_frame_t *frames, int n, achip_uniform_t *u)
   if (!u)
     return 0;
   memset(u, 0, sizeof(*u));
-  if (!frames || n <= 0 || frames[0].comp || !frames[0].src)
+  /* (composite frames too, round 5: the grid's target clients share ONE descriptor -- no source of their own, the same
+   * composite -- and a launch that carries it in its arguments spares every workgroup the dependent load of its entry) */
+  if (!frames || n <= 0 || (!frames[0].src && !frames[0].comp) || (frames[0].src && frames[0].comp))
     return 0;
   const int64_t pitch = n > 1 ? (int64_t)((intptr_t)frames[1].src - (intptr_t)frames[0].src) : 0;
   for (int i = 1; i < n; i++) {

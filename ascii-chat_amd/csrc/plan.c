@@ -481,7 +481,7 @@ int asciichat_hip_plan_set_uniform(asciichat_hip_plan_t *p, int allow) {
 }
 
 int asciichat_hip_plan_get_uniform(const asciichat_hip_plan_t *p) {
-  return p && p->uniform.enabled && !p->uniform_off && !p->has_comp;
+  return p && p->uniform.enabled && !p->uniform_off;
 }
 
 int asciichat_hip_plan_get_variant(const asciichat_hip_plan_t *p) { return p ? p->variant : -1; }

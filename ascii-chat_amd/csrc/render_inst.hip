@@ -89,7 +89,7 @@ extern "C" int ACHIP_CAT(ACHIP_CAT(ACHIP_CAT(achipk_render_inst_launch_, ACHIP_I
                                                                 void *stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   achip_uniform_t uni = {};
-  if (uniform && uniform->enabled && !comp)
+  if (uniform && uniform->enabled) /* (composite batches too: achip_frames_uniform) */
     uni = *uniform;
   switch (mode) {
 #define M(m)                                                                                                           \

@@ -109,7 +109,7 @@ extern "C" int ACHIP_CAT(ACHIP_CAT(ACHIP_CAT(achipk_render_rinst_launch_, ACHIP_
                                                                   const achip_wire_t *wire, void *stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   achip_uniform_t uni = {};
-  if (uniform && uniform->enabled && !comp)
+  if (uniform && uniform->enabled) /* (composite batches too: achip_frames_uniform) */
     uni = *uniform;
   if (uniform)
     uni.flags = uniform->flags;

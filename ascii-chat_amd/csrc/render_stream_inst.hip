@@ -196,7 +196,7 @@ extern "C" int ACHIP_CAT(achipk_render_sinst_launch_, ACHIP_SINST)(int mode, int
                                                                   void *stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   achip_uniform_t uni = {};
-  if (uniform && uniform->enabled && !comp)
+  if (uniform && uniform->enabled) /* (composite batches too: achip_frames_uniform) */
     uni = *uniform;
   if (uniform)
     uni.flags = uniform->flags; /* launch-wide facts travel even when the descriptors come from the device array */
@@ -254,7 +254,7 @@ extern "C" int achipk_render_sinst_parts_launch_18(int mode, int comp, const ach
                                                   unsigned long long *prof, const achip_partsdev_t *ps, void *stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   achip_uniform_t uni = {};
-  if (uniform && uniform->enabled && !comp)
+  if (uniform && uniform->enabled) /* (composite batches too: achip_frames_uniform) */
     uni = *uniform;
   if (uniform)
     uni.flags = uniform->flags;

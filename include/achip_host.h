@@ -47,8 +47,9 @@ int achip_frame_set_display_ops(achip_frame_t *f, bool flip_x, bool flip_y, int 
  * image_print_16color_dithered_with_background(img, use_background, pal) (foreground.c:752-846), or with
  * ramp_glyph (and !use_background) image_print_16color_dithered(img, pal) (foreground.c:650-750).
  * Default (never called) = use_background, what image_print_color_simd dispatches to (sgr.c:429-430). */
-/* Fill `u` for frames[0..n): enabled iff no frame samples a composite, every field but `src` is equal and
- * src[i] == src[0] + i * pitch for one pitch (n == 1: always).  Returns u->enabled. */
+/* Fill `u` for frames[0..n): enabled iff every field but `src` is equal and src[i] == src[0] + i * pitch for one pitch
+ * (n == 1: always) -- frames with sources of their own, or frames that all sample the SAME composite (no source, pitch 0:
+ * the grid's target clients).  Returns u->enabled. */
 int achip_frames_uniform(const achip_frame_t *frames, int n, achip_uniform_t *u);
 int achip_frame_set_dither_style(achip_frame_t *f, bool use_background, bool ramp_glyph);
 /* COLOR_FILTER_RAINBOW of the display path: the colour of color_filter_calculate_rainbow(time_seconds)

@@ -169,6 +169,8 @@ def test_composite_frame_kats(kat):
     mode = emu.lib().achip_mode_from_caps(cl, rm)
     for variant in (2, 0):  # the fused composite sampler of the phase kernel: the canvas is never built
         assert emu.render_frames(mode, [f], orc.PALETTE_STANDARD, variant)[0] == want, f"product kernel, geometry {variant}"
+    # target clients of one grid share ONE descriptor: it travels by value in the kernel arguments (round 5)
+    assert emu.render_frames(mode, [f, f, f], orc.PALETTE_STANDARD, 0, uniform=True) == [want] * 3, "uniform composite batch"
 
 
 # ---- the same known answers through the product library on the MI355X -------------------------------------------------
