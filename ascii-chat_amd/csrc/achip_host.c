@@ -598,7 +598,12 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
   /* The run-structured renderers (mono, half blocks) start a run at every row's first cell, so a whole number of text
    * rows is a self-contained block that ONE wave can take through the path (render_rows.hpp): whole-frame launches of
    * them take that kernel whenever the widest padded row fits a block (64 * CPL cells). */
-  const bool run_mode = mode == ACHIP_MODE_MONO || hb;
+  /* (... and whose sources are at most 21 845 pixels wide: render_rows.hpp keeps a sample's byte offset in 16 bits) */
+  int max_src_w = 0;
+  for (int i = 0; i < n_frames; i++)
+    if (!frames[i].comp && frames[i].src_w > max_src_w)
+      max_src_w = frames[i].src_w;
+  const bool run_mode = (mode == ACHIP_MODE_MONO || hb) && max_src_w <= 21845;
   if (forced_variant >= ACHIP_HOST_ROWS_FIRST) {
     const int cpl = rows_variant_cpl(forced_variant);
     if (!run_mode || !cpl || max_wp > 64 * cpl || achip_uniform_extent(mode, forced_variant, frames, n_frames) > ACHIP_HOST_STREAM_MAXBLK)

@@ -37,6 +37,10 @@
 
 namespace achip {
 
+/* a cell's record keeps its sample's byte offset in the source row in 16 bits: 3 * (src_w - 1) < 65 536.  (The reference's
+ * entry points take sources up to 10 000 pixels wide, ascii.c:204; wider hand-built descriptors go to the phase kernel:
+ * achip_choose_geometry.) */
+#define ACHIP_ROWS_MAX_SRC_W 21845
 #ifndef ACHIP_ROWS_SLOT_EMIT
 #define ACHIP_ROWS_SLOT_EMIT 0 /* 1 (A/B builds): tokens through per-lane LDS slots and straight to their place in the frame
                                   (store pass, below) instead of the packed staging area with its line-wise drain.  Measured
@@ -381,7 +385,7 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
     }
   };
   if (f.out_w <= 0 || f.out_h <= 0 || f.src_w <= 0 || f.src_h <= 0 || f.pad_left < 0 || f.pad_top < 0 ||
-      (!f.src && !f.comp) || (!GENERIC && (f.comp || f.src_w * f.src_h == 1)) || rpb < 1 || nblk > nblk_cap ||
+      (!f.src && !f.comp) || (!GENERIC && (f.comp || f.src_w * f.src_h == 1 || f.src_w > ACHIP_ROWS_MAX_SRC_W)) || rpb < 1 || nblk > nblk_cap ||
       out_stride > (uint64_t)ACHIP_STREAM_MAX_STRIDE) {
     bad_frame();
     return;

@@ -92,6 +92,16 @@ static int by_mode(int mode, const achip_frame_t *frames, int n, const achip_lut
   return -1;
 }
 
+/* As the product's launchers: the fast-sampler instantiation (GENERIC = false) unless a frame needs the full repertoire --
+ * a virtual composite or a 1x1 source.  (Until round 5 this driver always took GENERIC = true: the fast sampler, and with it
+ * the rows kernel's scalar-row path, ran on the GPU only.) */
+static bool needs_generic(const achip_frame_t *frames, int n) {
+  for (int i = 0; i < n; i++)
+    if (frames[i].comp || frames[i].src_w * frames[i].src_h == 1)
+      return true;
+  return false;
+}
+
 /* the stream kernel (render_stream.hpp): per-cell modes, whole frames */
 template <int MODE, int WAVES, int CPL>
 static void run_stream(const achip_frame_t *frames, int n, const achip_lut_t *lut, uint8_t *out, uint64_t stride,
@@ -108,6 +118,12 @@ static void run_stream(const achip_frame_t *frames, int n, const achip_lut_t *lu
     hipemu::launch(dim3((unsigned)(n * g_parts)), dim3(WAVES * 64), lds, [&] {
       achip::render_stream_kernel<MODE, WAVES, CPL, true, false, 0, true>(frames, lut, out, stride, len, n, uni, nullptr, achip_wire_t{},
                                                                           nullptr, achip_packdev_t{}, ps);
+    });
+    return;
+  }
+  if (!needs_generic(frames, n)) {
+    hipemu::launch(dim3((unsigned)n), dim3(WAVES * 64), lds, [&] {
+      achip::render_stream_kernel<MODE, WAVES, CPL, false>(frames, lut, out, stride, len, n, uni, nullptr, achip_wire_t{}, nullptr, achip_packdev_t{}, achip_partsdev_t{});
     });
     return;
   }
@@ -244,6 +260,12 @@ static void run_rows(int variant, const achip_frame_t *frames, int n, const achi
     tabv = reinterpret_cast<const uint4 *>(tab.data());
   }
   const size_t lds = (size_t)((L::bytes_for(achip::stream_maxblk(uni.flags, 1)) + 15) & ~15);
+  if (!needs_generic(frames, n)) {
+    hipemu::launch(dim3((unsigned)n), dim3(WAVES * 64), lds, [&] {
+      achip::render_rows_kernel<MODE, WAVES, CPL, false, CRC>(frames, lut, out, stride, len, n, uni, wire, tabv);
+    });
+    return;
+  }
   hipemu::launch(dim3((unsigned)n), dim3(WAVES * 64), lds, [&] {
     achip::render_rows_kernel<MODE, WAVES, CPL, true, CRC>(frames, lut, out, stride, len, n, uni, wire, tabv);
   });

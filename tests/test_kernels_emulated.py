@@ -510,6 +510,42 @@ def test_rows_kernel_one_row_blocks_with_padding_flips_and_tint(mode):
     assert one_row >= 15 and padded >= 6, (one_row, padded)  # (the rest of the cases put several rows into a block)
 
 
+def test_rows_kernel_leaves_very_wide_sources_to_the_phase_kernel():
+    """a cell record keeps the sample's byte offset in 16 bits (3 * (src_w - 1) < 65 536): hand-built descriptors of sources
+    wider than 21 845 pixels (the reference's entry points stop at 10 000, ascii.c:204) are refused by the rows kernel itself
+    and never sent there by achip_choose_geometry -- the phase kernel renders them"""
+    import ctypes as C
+    w = 22000
+    img = np.zeros((2, w, 3), np.uint8)
+    img[:, ::7] = (200, 50, 10)
+    img[:, -40:] = (9, 250, 77)  # the columns a 16-bit offset would alias
+    L = emu.lib()
+    L.achip_nn_ratio.restype = C.c_uint32
+    L.achip_nn_ratio.argtypes = [C.c_int, C.c_int]
+
+    def wide_frame(im):  # (achip_frame_setup refuses sources beyond the reference's 10 000: the descriptor is filled by hand)
+        f = emu.Frame()
+        f.src, f.src_w, f.src_h, f.out_w, f.out_h = im.ctypes.data, im.shape[1], im.shape[0], 80, 2
+        f.x_ratio, f.y_ratio = L.achip_nn_ratio(im.shape[1], 80), L.achip_nn_ratio(im.shape[0], 2)
+        return f
+
+    f = wide_frame(img)
+    assert emu.render_frames(MODE_MONO, [f], orc.PALETTE_STANDARD, 25)[0] == 0xFFFFFFFE  # ACHIP_LEN_BADDESC
+    xs = np.minimum((np.arange(80, dtype=np.int64) * int(f.x_ratio)) >> 16, w - 1)
+    small = np.ascontiguousarray(img[:, xs])  # the resize the reference would have made (image.c:293-325), then scale 1
+    exp = oracle_convert(small, MODE_MONO, 80, 2, orc.PALETTE_STANDARD)
+    assert emu.render_frames(MODE_MONO, [f], orc.PALETTE_STANDARD, 4)[0] == exp
+    caps = (C.c_int * 5)(4096, 2048, 1024, 0, 2048)
+    v, parts, rpp = C.c_int(), C.c_int(), C.c_int()
+    assert L.achip_choose_geometry(MODE_MONO, (emu.Frame * 300)(*([f] * 300)), 300, True, caps, 256, 0, -1, C.byref(v), C.byref(parts), C.byref(rpp)) == 0
+    assert v.value < 16, v.value  # a phase-kernel geometry, not rows 24 / 25
+    narrow = np.ascontiguousarray(img[:, :21845])
+    f2 = wide_frame(narrow)
+    assert emu.render_frames(MODE_MONO, [f2], orc.PALETTE_STANDARD, 25)[0] != 0xFFFFFFFE
+    assert L.achip_choose_geometry(MODE_MONO, (emu.Frame * 300)(*([f2] * 300)), 300, True, caps, 256, 0, -1, C.byref(v), C.byref(parts), C.byref(rpp)) == 0
+    assert v.value in (24, 25), v.value
+
+
 def test_rows_kernel_refuses_rows_wider_than_a_block():
     f = emu.frame_for_convert(TORTURE, 129, 3, 0)
     assert emu.render_frames(MODE_MONO, [f], orc.PALETTE_STANDARD, 28)[0] == 0xFFFFFFFE  # ACHIP_LEN_BADDESC
