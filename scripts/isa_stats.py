@@ -34,10 +34,29 @@ def kernels_of(lib):
         subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", local], check=True, stdout=subprocess.DEVNULL,
                        stderr=subprocess.DEVNULL)
         out = []
-        for f in sorted(os.listdir(tmp)):
-            if "gfx950" not in f:
-                continue
-            notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", os.path.join(tmp, f)], check=True,
+        objs = [os.path.join(tmp, f) for f in sorted(os.listdir(tmp)) if "gfx950" in f]
+        if objs and open(objs[0], "rb").read(4) != b"\x7fELF":
+            # --offload-compress builds (the product's): the fat binary is a sequence of compressed bundles ("CCOB" + a
+            # header that carries the bundle's size) which llvm-objdump does not split; clang-offload-bundler unpacks one
+            objs = []
+            fat = os.path.join(tmp, "fat.bin")
+            subprocess.run(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", local, fat], check=True)
+            data = open(fat, "rb").read()
+            at, k = data.find(b"CCOB"), 0
+            while at >= 0:
+                version = int.from_bytes(data[at + 4:at + 6], "little")
+                size = int.from_bytes(data[at + 8:at + (16 if version >= 3 else 12)], "little") if version >= 2 else 0
+                nxt = data.find(b"CCOB", at + max(size, 4))
+                chunk = os.path.join(tmp, f"bundle{k}.bin")
+                open(chunk, "wb").write(data[at:at + size] if size else data[at:nxt if nxt >= 0 else len(data)])
+                co = os.path.join(tmp, f"bundle{k}.gfx950.co")
+                subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + chunk,
+                                "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co], check=True,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                objs.append(co)
+                at, k = nxt, k + 1
+        for obj in objs:
+            notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", obj], check=True,
                                    capture_output=True, text=True).stdout
             cur = {}
             for line in notes.splitlines():
