@@ -534,7 +534,7 @@ long achip_max_cells(const achip_frame_t *frames, int n_frames) {
 
 /* the rows-kernel family (render_variants.h: ACHIP_ROWS_VARIANTS): a block is a whole number of text rows */
 #define ACHIP_HOST_ROWS_FIRST 24
-static int rows_variant_cpl(int variant) { return variant == 24 ? 7 : variant == 25 ? 4 : variant == 28 ? 2 : 0; }
+static int rows_variant_cpl(int variant) { return variant == 24 || variant == 26 ? 7 : variant == 25 ? 4 : variant == 28 ? 2 : 0; }
 
 /* what the ACHIP_UNIFORM_MAX_CELLS field of a launch carries: cells of the largest frame for the stream geometries,
  * BLOCKS of the frame with the most blocks for the rows geometries (rows / (64 * CPL / row width), rounded up) */
@@ -600,13 +600,19 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
    * them take that kernel whenever the widest padded row fits a block (64 * CPL cells). */
   /* (... and whose sources are at most 21 845 pixels wide: render_rows.hpp keeps a sample's byte offset in 16 bits) */
   int max_src_w = 0;
-  for (int i = 0; i < n_frames; i++)
+  bool general_sampler = false, dense = true; /* composites / 1x1 sources; every source IS the image its target samples */
+  for (int i = 0; i < n_frames; i++) {
     if (!frames[i].comp && frames[i].src_w > max_src_w)
       max_src_w = frames[i].src_w;
+    general_sampler |= frames[i].comp != NULL || (long)frames[i].src_w * (long)frames[i].src_h == 1;
+    dense &= !frames[i].comp && frames[i].src_w == frames[i].out_w && frames[i].src_h == frames[i].out_h;
+  }
   const bool run_mode = (mode == ACHIP_MODE_MONO || hb) && max_src_w <= 21845;
   if (forced_variant >= ACHIP_HOST_ROWS_FIRST) {
     const int cpl = rows_variant_cpl(forced_variant);
     if (!run_mode || !cpl || max_wp > 64 * cpl || achip_uniform_extent(mode, forced_variant, frames, n_frames) > ACHIP_HOST_STREAM_MAXBLK)
+      return -1;
+    if (forced_variant == 26 && general_sampler) /* (geometry 26 carries the fast sampler only) */
       return -1;
     *variant = forced_variant;
     return 0; /* whole frames only */
@@ -722,6 +728,18 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
     /* (the half-block modes' frames of one block per wave as well: 64 frames of 80x24 at a share of 64 CUs 5.2-5.9 us on the
      * phase kernel against 6.2-6.9, all four of them) */
     const bool shared_gpu = n_cus <= 128;
+    /* (round 5: ... unless their sources are DENSE -- the images the targets sample, a server tick's ingest -- and the rows
+     * need the seven-slot geometry: ONE launch of at most a frame per CU then takes that geometry as a single sixteen-wave
+     * workgroup per frame (26), which fills the CU the way two eight-wave workgroups of two launches do: 256 frames of
+     * 400x240 -> 400x120 truecolor half blocks, one launch at a time, 195.9 us against the phase kernel's 241.8 and 258.8 on
+     * geometry 24; from 4K sources the phase kernel stays ahead, 247.6 against 262.3; with launches in flight 24 does,
+     * 163.8 against 190.6 -- profiles/r05_rows_sixteen_waves_ab.txt) */
+    const bool coloured_hb = mode == ACHIP_MODE_HB_TRUE || mode == ACHIP_MODE_HB_256 || mode == ACHIP_MODE_HB_16;
+    if (coloured_hb && dense && !general_sampler && !shared_gpu && n_frames <= n_cus && max_wp > 256 &&
+        achip_uniform_extent(mode, 26, frames, n_frames) >= 32 && achip_uniform_extent(mode, 26, frames, n_frames) <= ACHIP_HOST_STREAM_MAXBLK) {
+      *variant = 26;
+      return 0;
+    }
     const bool take = n_frames > n_cus ? true : mono ? !(shared_gpu && ext > 8) : (ext <= 8 && !shared_gpu);
     if ((v == 25 || n_frames > n_cus || (mono && max_wp > 256)) && ext <= ACHIP_HOST_STREAM_MAXBLK && take) {
       *variant = v;

@@ -104,7 +104,7 @@ extern "C" int achip_launch_render_pack(int mode, int variant, const achip_frame
 }
 extern "C" int achip_pack_frame_cap(void) { return ACHIP_PACK_FRAME_CAP; }
 #ifdef ACHIP_ALL_GEOMETRIES
-extern "C" int achip_variant_has_crc(int variant) { return variant == 16 || variant == 17 || ACHIP_IS_ROWS_VARIANT(variant); }
+extern "C" int achip_variant_has_crc(int variant) { return variant == 16 || variant == 17 || (ACHIP_IS_ROWS_VARIANT(variant) && variant != 26); }
 #else
 extern "C" int achip_variant_has_crc(int variant) { return variant == 16 || variant == 17; }
 #endif

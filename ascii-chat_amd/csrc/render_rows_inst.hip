@@ -32,11 +32,11 @@ using G = RGeometry<ACHIP_RINST>;
 /* the frame CRC riding the rows kernel's drain costs more than the stand-alone pass (hip_launch.hip:
  * achip_variant_crc_pays), so no plan takes it by itself: those instantiations exist in -DACHIP_ALL_GEOMETRIES builds only */
 #ifdef ACHIP_ALL_GEOMETRIES
-constexpr bool HAS_CRC = true;
+constexpr bool HAS_CRC = ACHIP_RINST != 26;
 #else
 constexpr bool HAS_CRC = false;
 #endif
-constexpr bool HAS_COMP = true;
+constexpr bool HAS_COMP = ACHIP_RINST != 26; /* (the sixteen-wave geometry exists for dense single sources only: achip_choose_geometry) */
 
 /* the constant tables of <MODE>'s CRC instantiation: built on the device once per process, then read-only */
 template <int MODE> hipError_t crc_tables(const uint4 **out) {

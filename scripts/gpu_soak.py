@@ -72,7 +72,7 @@ def main():
                 plan.set_split(int(rng.integers(1, 6)))
             elif choice >= 5:  # the wave-autonomous kernels: stream geometries (per-cell modes) / rows geometries (run-structured
                 # modes); refused for the other family and for rows wider than a block, with the fused CRC forced on
-                plan.set_variant(int(rng.choice([24, 25, 25]) if mode in (0, 5, 6, 7, 8) else rng.choice([16, 17, 17, 18, 19])))
+                plan.set_variant(int(rng.choice([24, 25, 25, 26]) if mode in (0, 5, 6, 7, 8) else rng.choice([16, 17, 17, 18, 19])))
                 plan.set_fused_crc(1)
         except RuntimeError:
             pass  # geometry cannot hold this batch's rows: keep the automatic one

@@ -114,7 +114,7 @@ def test_torture_all_modes_all_variants(gpu, mode):
     if mode in (5, 6, 7, 8):  # the half-block modes have no instantiations in the 512- / 256-thread geometries
         variants = (0, 4)
     if mode in (0, 5, 6, 7, 8):  # the run-structured modes: both geometries of the rows kernel (rows up to 256 / 448 cells)
-        variants += (25, 24)
+        variants += (25, 24, 26)
     for variant in variants:
         if not geometry_built(gpu[0], variant):
             continue

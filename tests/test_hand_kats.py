@@ -27,15 +27,15 @@ KATS = json.load(open(os.path.join(HERE, "golden", "hand_kats.json"), encoding="
 # a KAT may name its own palette ("palette") and its own geometries ("variants": a multi-byte palette keeps the
 # truecolor-foreground renderer on the phase kernel)
 RENDERERS = {
-    "hb256": (6, lambda im, pal: orc.print_with_caps(im, 2, 2, pal), lambda im, pal: rs.halfblock_256(im), (0, 4, 24, 25)),
-    "hb16": (7, lambda im, pal: orc.print_with_caps(im, 1, 2, pal), lambda im, pal: rs.halfblock_16(im), (0, 4, 24, 25)),
-    "hbmono": (8, lambda im, pal: orc.print_with_caps(im, 0, 2, pal), lambda im, pal: rs.halfblock_mono(im), (0, 4, 24, 25)),
+    "hb256": (6, lambda im, pal: orc.print_with_caps(im, 2, 2, pal), lambda im, pal: rs.halfblock_256(im), (0, 4, 24, 25, 26)),
+    "hb16": (7, lambda im, pal: orc.print_with_caps(im, 1, 2, pal), lambda im, pal: rs.halfblock_16(im), (0, 4, 24, 25, 26)),
+    "hbmono": (8, lambda im, pal: orc.print_with_caps(im, 0, 2, pal), lambda im, pal: rs.halfblock_mono(im), (0, 4, 24, 25, 26)),
     "true_bg": (4, lambda im, pal: orc.print_truecolor_bg(im, pal), lambda im, pal: rs.truecolor_bg(im, pal),
                 (0, 2, 4, 16, 17, 18, 19)),
-    "hbtrue": (5, lambda im, pal: orc.print_with_caps(im, 3, 2, pal), lambda im, pal: rs.halfblock_true(im), (0, 4, 24, 25)),
+    "hbtrue": (5, lambda im, pal: orc.print_with_caps(im, 3, 2, pal), lambda im, pal: rs.halfblock_true(im), (0, 4, 24, 25, 26)),
     "dither16_bg": (9, lambda im, pal: orc.print_16_dithered(im, True, pal), lambda im, pal: rs.dither16_bg(im, pal), (0, 2, 4)),
     # rows the survey's recorded anchors pin as whole-frame hashes; these add byte-level, line-cited answers
-    "mono": (0, lambda im, pal: orc.print_with_caps(im, 0, 0, pal), lambda im, pal: rs.mono(im, pal), (0, 4, 24, 25)),
+    "mono": (0, lambda im, pal: orc.print_with_caps(im, 0, 0, pal), lambda im, pal: rs.mono(im, pal), (0, 4, 24, 25, 26)),
     "true_fg": (1, lambda im, pal: orc.print_with_caps(im, 3, 0, pal), lambda im, pal: rs.truecolor_fg(im, pal),
                 (0, 2, 4, 16, 17, 18, 19)),
     "ansi256_fg": (2, lambda im, pal: orc.print_with_caps(im, 2, 0, pal), lambda im, pal: rs.ansi256_fg(im, pal),

@@ -462,9 +462,9 @@ def run_frames(w, h, kind):
 
 
 @pytest.mark.parametrize("mode", ROWS_MODES, ids=ROWS_IDS)
-@pytest.mark.parametrize("variant", [28, 25, 24])
+@pytest.mark.parametrize("variant", [28, 25, 24, 26])
 def test_rows_kernel_torture(mode, variant):
-    cap = {28: 128, 25: 256, 24: 448}[variant]
+    cap = {28: 128, 25: 256, 24: 448, 26: 448}[variant]
     for (W, H) in [(80, 24), (97, 31), (3, 2), (1, 1), (64, 1), (65, 3), (128, 5), (200, 7), (448, 3)]:
         if W > cap:
             continue
@@ -480,7 +480,7 @@ def test_rows_kernel_run_structure(mode):
     for kind in ("blocks", "flat", "black", "stripes"):
         img = run_frames(160, 90, kind)
         for (W, H, variant, asp) in [(100, 9, 28, False), (37, 11, 28, False), (128, 4, 28, False), (250, 6, 25, False),
-                                     (440, 4, 24, False), (61, 19, 28, True), (80, 24, 25, True)]:
+                                     (440, 4, 24, False), (61, 19, 28, True), (80, 24, 25, True), (300, 40, 26, False), (90, 33, 26, True)]:
             exp = oracle_convert(img, mode, W, H, orc.PALETTE_STANDARD, asp, asp)
             got = emu_convert(img, mode, W, H, orc.PALETTE_STANDARD, variant, asp, asp)
             assert got == exp, (MODE_NAMES[mode], kind, W, H, variant, asp)
@@ -498,11 +498,12 @@ def test_rows_kernel_one_row_blocks_with_padding_flips_and_tint(mode):
     imgs = [orc.frame_hash_noise(120, 90, 3), run_frames(37, 29, "blocks"), orc.frame_smooth(300, 7)]
     one_row = padded = 0
     for img in imgs:
-        for (W, H, variant) in [(120, 21, 28), (100, 9, 28), (127, 5, 28), (250, 7, 25), (440, 3, 24)]:
+        for (W, H, variant) in [(120, 21, 28), (100, 9, 28), (127, 5, 28), (250, 7, 25), (440, 3, 24), (300, 37, 26)]:
             for fx, fy, flt in [(False, False, 0), (True, True, 3), (False, True, 7)]:
                 f = emu.frame_for_convert(img, W, H, rm, True, True)  # use_aspect_ratio + wants_padding
-                one_row += 64 * {28: 2, 25: 4, 24: 7}[variant] // 2 < f.pad_left + f.out_w <= 64 * {28: 2, 25: 4, 24: 7}[variant]
-                padded += f.pad_left > 0 and 64 * {28: 2, 25: 4, 24: 7}[variant] // 2 < f.pad_left + f.out_w
+                slots = 64 * {28: 2, 25: 4, 24: 7, 26: 7}[variant]
+                one_row += slots // 2 < f.pad_left + f.out_w <= slots
+                padded += f.pad_left > 0 and slots // 2 < f.pad_left + f.out_w
                 assert emu.lib().achip_frame_set_display_ops(C.byref(f), fx, fy, flt) == 0
                 exp = orc.display_convert(img, W, H, cl, rm, True, True, fx, fy, flt)
                 got = emu.render_frames(mode, [f], orc.PALETTE_STANDARD, variant)[0]
@@ -544,6 +545,30 @@ def test_rows_kernel_leaves_very_wide_sources_to_the_phase_kernel():
     assert emu.render_frames(MODE_MONO, [f2], orc.PALETTE_STANDARD, 25)[0] != 0xFFFFFFFE
     assert L.achip_choose_geometry(MODE_MONO, (emu.Frame * 300)(*([f2] * 300)), 300, True, caps, 256, 0, -1, C.byref(v), C.byref(parts), C.byref(rpp)) == 0
     assert v.value in (24, 25), v.value
+
+
+def test_policy_takes_the_sixteen_wave_rows_geometry_for_one_launch_of_dense_half_block_frames():
+    """geometry 26 (round 5): at most a frame per CU, coloured half blocks, rows beyond the four-slot geometry, sources that ARE
+    the images their targets sample (a tick's ingest), the GPU not shared -- and nothing else"""
+    import ctypes as C
+    L = emu.lib()
+    caps = (C.c_int * 5)(4096, 2048, 1024, 0, 2048)
+    dense = np.zeros((240, 400, 3), np.uint8)
+    full = np.zeros((480, 800, 3), np.uint8)
+
+    def choice(img, W, H, rm, mode, n, cus):
+        f = emu.frame_for_convert(img, W, H, rm)
+        v, parts, rpp = C.c_int(), C.c_int(), C.c_int()
+        assert L.achip_choose_geometry(mode, (emu.Frame * n)(*([f] * n)), n, True, caps, cus, 0, -1, C.byref(v), C.byref(parts), C.byref(rpp)) == 0
+        return v.value
+
+    assert choice(dense, 400, 120, 2, MODE_HB_TRUE, 256, 256) == 26
+    assert choice(dense, 400, 120, 2, MODE_HB_256, 200, 256) == 26
+    assert choice(full, 400, 120, 2, MODE_HB_TRUE, 256, 256) != 26      # not dense: the phase kernel stays ahead
+    assert choice(dense, 400, 120, 2, MODE_HB_TRUE, 257, 256) == 24     # more than a frame per CU
+    assert choice(dense, 400, 120, 2, MODE_HB_TRUE, 64, 64) != 26       # a share of the GPU: launches in flight
+    assert choice(dense, 400, 120, 2, MODE_HB_MONO, 256, 256) != 26     # short tokens: not measured, not taken
+    assert choice(np.zeros((120, 200, 3), np.uint8), 200, 60, 2, MODE_HB_TRUE, 256, 256) != 26  # the four-slot geometry's rows
 
 
 def test_rows_kernel_refuses_rows_wider_than_a_block():
