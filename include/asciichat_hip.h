@@ -107,7 +107,7 @@ int asciichat_hip_plan_render_range(asciichat_hip_plan_t *plan, int first, int c
  * phase_cycles_dev[frame*8 + k] = shader-clock cycles spent per kernel phase (0 setup, 1 gather, 2 heads, 3 lengths,
  * 4 scan, 5 emit tokens, 6 drain to HBM, 7 total).  Stream geometries (16-19): eight 100 MHz wall-clock stamps per WAVE of
  * every workgroup, phase_cycles_dev[((frame * parts + part) * waves + wave) * 8 + k] (render_stream.hpp) -- the buffer must
- * hold n_frames * plan_get_parts() * (workgroup size / 64) * 8 words.  Rows geometries (24, 25) write nothing. */
+ * hold n_frames * plan_get_parts() * (workgroup size / 64) * 8 words.  Rows geometries (24, 25, 26) write nothing. */
 int asciichat_hip_plan_render_profiled(asciichat_hip_plan_t *plan, uint8_t *out_dev, size_t out_stride,
                                        uint32_t *out_len_dev, unsigned long long *phase_cycles_dev, void *stream);
 
