@@ -38,6 +38,12 @@ template <int OFF, bool HI> __device__ inline void ds_store_byte(uint32_t addr, 
 __device__ inline void ds_or_u32(uint32_t addr, uint32_t v) {
   asm volatile("ds_or_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
+/* ... at (addr) + OFF, the offset as the instruction's immediate */
+template <int OFF> __device__ inline void ds_or_u32_at(uint32_t addr, uint32_t v) {
+  asm volatile("ds_or_b32 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+/* v_alignbit_b32: the low dword of {hi:lo} >> (sh & 31) */
+__device__ inline uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
 /* keeps operands alive without issuing anything (ablation builds) */
 __device__ inline void keep_alive(uint32_t a, uint32_t b) { asm volatile("" ::"v"(a), "v"(b)); }
 /* LDS byte address of ACHIP_SMEM[0] (0 for a kernel without static LDS, but do not assume) */

@@ -49,6 +49,11 @@ namespace achip {
                                   than the LDS took the conflicts -- sampled 400x240 half blocks 161.6 -> 201.8 us, from 4K
                                   sources 201 -> 235 (profiles/r05_rows_slot_emit_ab.txt) */
 #endif
+#ifndef ACHIP_ROWS_WORD_EMIT
+#define ACHIP_ROWS_WORD_EMIT 1 /* truecolor half blocks: a token of the common shape -- both SGRs and the half block -- is put
+                                  together in registers from ready-made table pieces and leaves them as 13 aligned dword ORs
+                                  instead of 41 byte stores (rows_word_sgr, below); 0 (A/B builds): byte stores only */
+#endif
 #ifndef ACHIP_ROWS_EMIT_OR_MODES
 #define ACHIP_ROWS_EMIT_OR_MODES 0 /* bit m set: mode m stores its tokens through PackSink here.  Off: this kernel is bound
                                       by VALU issue (profiles/r03_k5_sq_counters.txt: 130 M VALU instructions per 256-frame
@@ -69,8 +74,8 @@ template <int MODE, int WAVES, bool CRC = false> struct RLds {
    * the slice before it, carried: whole lines leave the wave) + the 128 bytes the carry's move may read behind it */
   static constexpr int STAGE = 64 * rows_max_token(MODE) + (CRC ? 16 : 256);
   static constexpr int GPL = (STAGE / 16 + 63) / 64;
-  static constexpr int o_stage = 0;
-  static constexpr int o_glyph = WAVES * STAGE;
+  static constexpr int o_stage = 16; /* (a word-built token whose first byte is the area's first ORs a zero dword in front of it) */
+  static constexpr int o_glyph = o_stage + WAVES * STAGE;
   static constexpr int o_glyph64 = o_glyph + 256 * 4;
   static constexpr int o_ramp = o_glyph64 + 64 * 4;
   static constexpr int o_dec = o_ramp + 64;
@@ -80,7 +85,14 @@ template <int MODE, int WAVES, bool CRC = false> struct RLds {
   static constexpr int o_num_semi = o_dec + 256 * 4;
   static constexpr int o_num_m = o_num_semi + (NUM8 ? 256 * 8 : 0);
   static constexpr int o_num_len = o_num_m + (NUM8 ? 256 * 8 : 0);
-  static constexpr int o_flags = o_num_len + (NUM8 ? 256 : 0); /* [+16 ..] swallows predicated-off byte stores */
+  /* ... and for tokens built as words (rows_word_sgr): {text, shift / length terms in bits} of the R, G, B fields and of the
+   * background's B field with the half block behind it */
+  static constexpr bool WORDS = NUM8 && !CRC && (ACHIP_ROWS_WORD_EMIT != 0);
+  static constexpr int o_wr = o_num_len + (NUM8 ? 256 : 0);
+  static constexpr int o_wg = o_wr + (WORDS ? 256 * 8 : 0);
+  static constexpr int o_wm = o_wg + (WORDS ? 256 * 8 : 0);
+  static constexpr int o_wmg = o_wm + (WORDS ? 256 * 8 : 0);
+  static constexpr int o_flags = o_wmg + (WORDS ? 256 * 8 : 0); /* [+16 ..] swallows predicated-off byte stores */
   static constexpr int o_comp = o_flags + 32 + 64 * 4;
   static constexpr int o_tab = o_comp + ACHIP_COMP_LDS_BYTES;
   static constexpr int o_slice = o_tab;
@@ -141,6 +153,60 @@ template <int DEC_OFF, int DUMMY_OFF, int SEMI_OFF, int M_OFF> struct RowsFastSi
     field4(e2);
   }
 };
+
+/* One truecolor SGR -- ESC[38;2;R;G;Bm, or ESC[48;2;R;G;Bm with the half block U+2580 behind it -- built in registers and
+ * OR-ed into the (zeroed) staging area as aligned dwords; `p` = LDS byte address of its first byte.  Returns its length in
+ * BITS.  The three fields come out of LDS as {text, 8 x length} (the G table's term carries -32, the B tables' +88, so that
+ * the shifts and the total are single additions): X = R | G << 8 lr | B << 8 (lr + lg) in three or four dwords, moved up
+ * behind the 7-byte prefix by constant funnel shifts, then moved up by the 1..4 bytes between the dword in front of `p` and
+ * `p` by funnel shifts of one per-lane amount (1..4 and not 0..3: v_alignbit_b32 takes its amount modulo 32, and a move
+ * by a whole dword is the amount 0).  6 / 7 LDS instructions instead of 19 / 22 byte stores; the byte stores of a wave's
+ * tokens lie ~38 bytes apart at pseudo-random banks, the LDS pipe was active for 65 % of the launch and more than half of
+ * that were bank conflicts (profiles/r05_k5_sampled_sq_counters.txt). */
+struct RowsWordFields {
+  uint2 r, g, b;
+};
+template <class L, bool BG> __device__ inline RowsWordFields rows_word_fields(uint32_t rgb) {
+  return RowsWordFields{lds_ptr<const uint2>(L::o_wr)[px_r(rgb)], lds_ptr<const uint2>(L::o_wg)[px_g(rgb)],
+                        lds_ptr<const uint2>(BG ? L::o_wmg : L::o_wm)[px_b(rgb)]};
+}
+template <bool BG> __device__ inline uint32_t rows_word_sgr(uint32_t p, const RowsWordFields &w) {
+  const uint2 r = w.r, g = w.g, b = w.b;
+  const uint64_t rg = (uint64_t)g.x << r.y; /* r.y = 16, 24, 32 */
+  const uint32_t sb = r.y + g.y;            /* 8 (lr + lg) - 32 = 0 .. 32 */
+  const uint32_t x0 = r.x | (uint32_t)rg;
+  uint32_t x1, x2, x3 = 0u, bits;
+  if (!BG) {
+    const uint64_t bb = (uint64_t)b.x << sb;
+    x1 = (uint32_t)(rg >> 32) | (uint32_t)bb;
+    x2 = (uint32_t)(bb >> 32);
+    bits = sb + b.y;
+  } else {
+    const uint64_t b0 = (uint64_t)b.x << sb, b1 = (uint64_t)(b.y & 0x00FFFFFFu) << sb;
+    x1 = (uint32_t)(rg >> 32) | (uint32_t)b0;
+    x2 = (uint32_t)(b0 >> 32) | (uint32_t)b1;
+    x3 = (uint32_t)(b1 >> 32);
+    bits = sb + (b.y >> 24);
+  }
+  const uint32_t a0 = BG ? 0x38345B1Bu : 0x38335B1Bu; /* ESC [ 3|4 8 */
+  const uint32_t a1 = (x0 << 24) | 0x003B323Bu;       /* ; 2 ; + the first digit */
+  const uint32_t a2 = alignbit(x1, x0, 8u), a3 = alignbit(x2, x1, 8u);
+  const uint32_t a4 = BG ? alignbit(x3, x2, 8u) : x2 >> 8;
+  const uint32_t t = p - 1u, base = t & ~3u, sh = (t << 3) ^ 24u;
+  ds_or_u32_at<0>(base, alignbit(a0, 0u, sh));
+  ds_or_u32_at<4>(base, alignbit(a1, a0, sh));
+  ds_or_u32_at<8>(base, alignbit(a2, a1, sh));
+  ds_or_u32_at<12>(base, alignbit(a3, a2, sh));
+  ds_or_u32_at<16>(base, alignbit(a4, a3, sh));
+  if (!BG) {
+    ds_or_u32_at<20>(base, alignbit(0u, a4, sh));
+  } else {
+    const uint32_t a5 = x3 >> 8;
+    ds_or_u32_at<20>(base, alignbit(a5, a4, sh));
+    ds_or_u32_at<24>(base, alignbit(0u, a5, sh));
+  }
+  return bits;
+}
 
 /* run key comparison of two cells (render_kernels.hpp same_run, on registers) */
 template <int MODE> __device__ inline bool rows_same_run(uint32_t aT, uint32_t aB, uint32_t bT, uint32_t bB) {
@@ -542,6 +608,14 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
         lds_ptr<uint2>(L::o_num_semi)[tid + k * BLOCK] = make_uint2(dg | ((uint32_t)';' << (8u * nd)), nd + 1u);
         lds_ptr<uint2>(L::o_num_m)[tid + k * BLOCK] = make_uint2(dg | ((uint32_t)'m' << (8u * nd)), nd + 1u);
         lds_ptr<uint8_t>(L::o_num_len)[tid + k * BLOCK] = (uint8_t)(nd + 1u);
+        if (L::WORDS) { /* rows_word_sgr's pieces */
+          const uint32_t fm = dg | ((uint32_t)'m' << (8u * nd)), l8 = 8u * (nd + 1u);
+          const uint64_t fmg = (uint64_t)fm | (0x8096E2ull << l8); /* + U+2580 = E2 96 80 */
+          lds_ptr<uint2>(L::o_wr)[tid + k * BLOCK] = make_uint2(dg | ((uint32_t)';' << (8u * nd)), l8);
+          lds_ptr<uint2>(L::o_wg)[tid + k * BLOCK] = make_uint2(dg | ((uint32_t)';' << (8u * nd)), l8 - 32u);
+          lds_ptr<uint2>(L::o_wm)[tid + k * BLOCK] = make_uint2(fm, l8 + 88u);
+          lds_ptr<uint2>(L::o_wmg)[tid + k * BLOCK] = make_uint2((uint32_t)fmg, (uint32_t)(fmg >> 32) | ((l8 + 24u + 88u) << 24));
+        }
       }
     }
   if (tid < 64) {
@@ -550,7 +624,7 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
   }
   for (int k = tid; k < nblk; k += BLOCK)
     slots[k] = 0u;
-  if (EMIT_OR) /* the OR-filled staging areas start out zero; every slice clears what it used */
+  if (EMIT_OR || L::WORDS) /* the OR-filled staging areas start out zero; every slice clears what it used */
     for (int k = tid; k < WAVES * L::STAGE / 16; k += BLOCK)
       lds_ptr<uint4>(L::o_stage)[k] = make_uint4(0u, 0u, 0u, 0u);
   if (CRC) {
@@ -771,6 +845,7 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
        * in pieces at 4.4 instead of 5.7 TB/s (profiles/r04_rows_floor.txt).  Coordinates q = stream offset + dmis: line
        * boundaries of the ADDRESS are the multiples of 128. */
       constexpr bool CARRY = !CRC && !EMIT_OR && ACHIP_DRAIN_ALIGN >= 128u;
+      constexpr bool WORDS = CARRY && L::WORDS && !(ACHIP_ROWS_SLOT_EMIT != 0);
       int last_k = 0;
 #pragma unroll
       for (int k = 0; k < CPL; k++)
@@ -831,7 +906,57 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
         if (CARRY) {
           /* the staging area's byte 0 is the line the slice starts in (q0); [own_q, qa) is already there */
           const uint32_t qa = a + dmis, q0 = qa & ~127u, qend = qa + n;
-          if (len_k != 0u) {
+          /* WORDS: the SGRs of a token go out as 6 / 7 dword ORs each (rows_word_sgr; the background's carries the half
+           * block), whatever else a token holds -- the reset in front of a transparent run, its space, a lone half block,
+           * a repeat count, a row's reset and newline, a padding space -- as bytes around them: token_fields' order.  The
+           * area is zero wherever no token has been written (cleared behind every flush, below). */
+          if (WORDS) {
+            const uint32_t fl = meta[k] & 0xFFFu;
+            constexpr uint32_t FULL = (uint32_t)(TF_SGR_FG | TF_SGR_BG | TF_GLYPH);
+            constexpr uint32_t TAIL = (uint32_t)(TF_ROW_RESET | TF_NL);
+            if (wave_ballot(len_k != 0u && (fl & ~TAIL) != FULL) == 0ull) {
+              /* every token of the slice has both SGRs and nothing in front of the row's end (a frame without flat
+               * areas): straight through, no lane branches */
+              if (len_k != 0u) {
+                FastSink<L::o_dec, L::o_flags + 16> fs{stage_addr + (qa + off_k - q0), dummy_addr};
+                const RowsWordFields wf = rows_word_fields<L, false>(tk.fg), wb = rows_word_fields<L, true>(tk.bg);
+                fs.a += rows_word_sgr<false>(fs.a, wf) >> 3;
+                fs.a += rows_word_sgr<true>(fs.a, wb) >> 3;
+                if (fl & TAIL) {
+                  if (fl & TF_ROW_RESET)
+                    put_reset(fs);
+                  if (fl & TF_NL)
+                    fs.template c<1>('\n');
+                }
+              }
+            } else if (len_k != 0u) {
+              FastSink<L::o_dec, L::o_flags + 16> fs{stage_addr + (qa + off_k - q0), dummy_addr};
+              /* (the table reads of both SGRs in front of the lanes' branches: they overlap, and a lane without the SGR reads harmlessly) */
+              const RowsWordFields wf = rows_word_fields<L, false>(tk.fg), wb = rows_word_fields<L, true>(tk.bg);
+              if (fl & TF_PAD) {
+                fs.template c<1>(' ');
+              } else {
+                if (fl & TF_RESET_PRE)
+                  put_reset(fs);
+                if (fl & TF_SGR_FG)
+                  fs.a += rows_word_sgr<false>(fs.a, wf) >> 3;
+                if (fl & TF_SGR_BG) { /* (only in front of a half block: rows_token) */
+                  fs.a += rows_word_sgr<true>(fs.a, wb) >> 3;
+                } else {
+                  if (fl & TF_SPACE)
+                    fs.template c<1>(' ');
+                  if (fl & TF_GLYPH)
+                    fs.template c<3>(0x8096E2u);
+                }
+                if (fl & TF_REP)
+                  put_rep(fs, tk.rep);
+                if (fl & TF_ROW_RESET)
+                  put_reset(fs);
+                if (fl & TF_NL)
+                  fs.template c<1>('\n');
+              }
+            }
+          } else if (len_k != 0u) {
             RowsFastSink<L::o_dec, L::o_flags + 16, L::NUM8 ? L::o_num_semi : -1, L::NUM8 ? L::o_num_m : -1> fs{{stage_addr + (qa + off_k - q0), dummy_addr}};
             token_fields<MODE>(fs, tk, ascii_only);
           }
@@ -857,8 +982,18 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
             uint4 c = make_uint4(0u, 0u, 0u, 0u);
             if (lane < 8)
               c = *reinterpret_cast<const uint4 *>(stage + (q0n - q0) + 16u * (uint32_t)lane);
+            if (WORDS) { /* (a wave's DS operations complete in order: read, clear, write) */
+              wave_lockstep();
+              for (uint32_t g = (uint32_t)lane; g < (qend - q0 + 15u) >> 4; g += 64u)
+                lds_ptr<uint4>((int)stage_off)[g] = make_uint4(0u, 0u, 0u, 0u);
+              wave_lockstep();
+            }
             if (lane < 8)
               *lds_ptr<uint4>((int)stage_off + 16 * lane) = c;
+            wave_lockstep();
+          } else if (WORDS && last) {
+            for (uint32_t g = (uint32_t)lane; g < (qend - q0 + 15u) >> 4; g += 64u)
+              lds_ptr<uint4>((int)stage_off)[g] = make_uint4(0u, 0u, 0u, 0u);
             wave_lockstep();
           }
           a = a + n;

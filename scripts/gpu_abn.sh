@@ -1,7 +1,7 @@
 #!/bin/bash
 # N-way interleaved A/B of builds of the library on one box: scripts/gpu_abn.sh <tag> "<lib .so ...>" "<workloads ...>" [reps]
 # ("HEAD" = the product library).  Prints kernel_ms (HIP events over the timed launches) and ms_per_step per run, and the
-# per-library median at the end (HOT=1: also one launch at a time).  Variant builds: scripts/build_variant.sh.
+# per-library median at the end (HOT=1: also one launch at a time; INPUT=smooth|bars|gray: that synthetic input instead of noise).  Variant builds: scripts/build_variant.sh.
 set -u
 TAG=$1; LIBS=$2; WL=$3; REPS=${4:-2}
 O=gpurun_out/$TAG; mkdir -p $O; export TMPDIR=/tmp
@@ -9,7 +9,7 @@ for w in $WL; do
   for rep in $(seq $REPS); do
     for lib in $LIBS; do
       path=""; [ "$lib" != HEAD ] && path=$PWD/ascii-chat_amd/$lib
-      ASCIICHAT_HIP_LIB=$path timeout 300 python3 bench.py --workload $w --others '' --no-cpu --no-wire --no-d2h $( [ -n "${HOT:-}" ] || echo --no-hot ) --batch-sweep '' --steps 100 --warmup 20 \
+      ASCIICHAT_HIP_LIB=$path timeout 300 python3 bench.py --workload $w --others '' --no-cpu --no-wire --no-d2h $( [ -n "${HOT:-}" ] || echo --no-hot ) --batch-sweep '' --steps 100 --warmup 20 ${INPUT:+--input $INPUT} \
          --extra $O/extra_${w}_${lib}_$rep.json > $O/line_${w}_${lib}_$rep.txt 2>> $O/stderr.txt
       python3 - "$O/extra_${w}_${lib}_$rep.json" "$w" "$lib" <<'PY'
 import json,sys

@@ -20,6 +20,8 @@ template <int OFF, bool HI> inline void ds_store_byte(uint32_t addr, uint32_t v)
   ACHIP_SMEM[addr + OFF] = (unsigned char)(HI ? v >> 16 : v);
 }
 inline void ds_or_u32(uint32_t addr, uint32_t v) { *reinterpret_cast<uint32_t *>(ACHIP_SMEM + addr) |= v; }
+template <int OFF> inline void ds_or_u32_at(uint32_t addr, uint32_t v) { *reinterpret_cast<uint32_t *>(ACHIP_SMEM + addr + OFF) |= v; }
+inline uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> (sh & 31u)); }
 inline void keep_alive(uint32_t, uint32_t) {}
 inline uint32_t lds_base_addr() { return 0u; }
 /* a wave's lanes run in lockstep on the GPU: every lane's stores precede the reads behind the fence */
