@@ -210,6 +210,7 @@ __device__ inline uint32_t dec_table_entry(uint32_t v) {
 
 struct CountSink {
   static constexpr bool FAST_DEC = false; /* (render_rows.hpp's sinks take a truecolor SGR's numbers from wider tables) */
+  static constexpr bool FAST_256 = false;
   uint32_t n;
   __device__ inline uint32_t lookup(uint32_t v) const { return 1u + (v >= 10u) + (v >= 100u); } /* digit count */
   template <int K> __device__ inline void c(uint32_t) { n += (uint32_t)K; }
@@ -219,6 +220,7 @@ struct CountSink {
 
 template <int DEC_OFF, int DUMMY_OFF> struct FastSink {
   static constexpr bool FAST_DEC = false;
+  static constexpr bool FAST_256 = false;
   uint32_t a;     /* LDS byte address of the next byte; the token neither wraps nor leaves the window */
   uint32_t dummy; /* LDS byte address that swallows predicated-off stores */
   __device__ inline uint32_t lookup(uint32_t v) const { return lds_ptr<const uint32_t>(DEC_OFF)[v]; }
@@ -255,6 +257,101 @@ template <int DEC_OFF, int DUMMY_OFF> struct FastSink {
   }
 };
 
+/* ------------------------------------------------------------------------------------------- */
+/* SGRs built as words                                                                           */
+/* ------------------------------------------------------------------------------------------- */
+/* One truecolor SGR -- ESC[38;2;R;G;Bm / ESC[48;2;R;G;Bm, LONGB: with the half block U+2580 behind it -- built in registers
+ * and OR-ed into a ZEROED staging area as aligned dwords; `p` = LDS byte address of its first byte, `pre` = its first four
+ * bytes.  Returns its length in BITS.  The three fields come out of LDS as {text, 8 x length} (the G table's term carries
+ * -32, the B tables' +88, so that the shifts and the total are single additions): X = R | G << 8 lr | B << 8 (lr + lg) in
+ * three or four dwords, moved up behind the 7-byte prefix by constant funnel shifts, then moved up by the 1..4 bytes
+ * between the dword in front of `p` and `p` by funnel shifts of one per-lane amount (1..4 and not 0..3: v_alignbit_b32
+ * takes its amount modulo 32, and a move by a whole dword is the amount 0 -- the dword in front of an aligned `p` gets a
+ * zero OR-ed in).  6 / 7 LDS instructions instead of 19 / 22 byte stores: the byte stores of a wave's tokens lie 20-40
+ * bytes apart at pseudo-random banks -- in the rows kernel the LDS pipe was active for 65 % of a launch, more than half of
+ * it bank conflicts (profiles/r05_k5_sampled_sq_counters.txt; A/B: profiles/r05_rows_word_emit_ab.txt). */
+struct WordFields {
+  uint2 r, g, b;
+};
+template <int WR, int WG, int WB> __device__ inline WordFields word_fields(uint32_t rgb) {
+  return WordFields{lds_ptr<const uint2>(WR)[px_r(rgb)], lds_ptr<const uint2>(WG)[px_g(rgb)], lds_ptr<const uint2>(WB)[px_b(rgb)]};
+}
+/* the tables' entries for the value v: R fields, G fields, the B field with its 'm', the same with the half block behind it */
+__device__ inline void word_table_entries(uint32_t v, uint2 &wr, uint2 &wg, uint2 &wm, uint2 &wmg) {
+  const uint32_t e = dec_entry(v), nd = e >> 24, dg = e & 0x00FFFFFFu, l8 = 8u * (nd + 1u);
+  const uint32_t fm = dg | ((uint32_t)'m' << (8u * nd));
+  const uint64_t fmg = (uint64_t)fm | (0x8096E2ull << l8); /* + U+2580 = E2 96 80 */
+  wr = make_uint2(dg | ((uint32_t)';' << (8u * nd)), l8);
+  wg = make_uint2(wr.x, l8 - 32u);
+  wm = make_uint2(fm, l8 + 88u);
+  wmg = make_uint2((uint32_t)fmg, (uint32_t)(fmg >> 32) | ((l8 + 24u + 88u) << 24));
+}
+/* `n` dwords a[0..n) of a string at LDS byte address p, OR-ed in as n + 1 aligned dwords */
+template <int N> __device__ inline void word_string(uint32_t p, const uint32_t (&a)[N]) {
+  const uint32_t t = p - 1u, base = t & ~3u, sh = (t << 3) ^ 24u;
+  static_assert(N >= 2 && N <= 6, "one OR per dword and one behind them");
+  ds_or_u32_at<0>(base, alignbit(a[0], 0u, sh));
+  ds_or_u32_at<4>(base, alignbit(a[1], a[0], sh));
+  if constexpr (N > 2) ds_or_u32_at<8>(base, alignbit(a[N > 2 ? 2 : 0], a[1], sh));
+  if constexpr (N > 3) ds_or_u32_at<12>(base, alignbit(a[N > 3 ? 3 : 0], a[N > 2 ? 2 : 0], sh));
+  if constexpr (N > 4) ds_or_u32_at<16>(base, alignbit(a[N > 4 ? 4 : 0], a[N > 3 ? 3 : 0], sh));
+  if constexpr (N > 5) ds_or_u32_at<20>(base, alignbit(a[N > 5 ? 5 : 0], a[N > 4 ? 4 : 0], sh));
+  ds_or_u32_at<4 * N>(base, alignbit(0u, a[N - 1], sh));
+}
+template <bool LONGB> __device__ inline uint32_t word_sgr(uint32_t p, const WordFields &w, uint32_t pre) {
+  const uint2 r = w.r, g = w.g, b = w.b;
+  const uint64_t rg = (uint64_t)g.x << r.y; /* r.y = 16, 24, 32 */
+  const uint32_t sb = r.y + g.y;            /* 8 (lr + lg) - 32 = 0 .. 32 */
+  const uint32_t x0 = r.x | (uint32_t)rg;
+  uint32_t x1, x2, x3 = 0u, bits;
+  if (!LONGB) {
+    const uint64_t bb = (uint64_t)b.x << sb;
+    x1 = (uint32_t)(rg >> 32) | (uint32_t)bb;
+    x2 = (uint32_t)(bb >> 32);
+    bits = sb + b.y;
+  } else {
+    const uint64_t b0 = (uint64_t)b.x << sb, b1 = (uint64_t)(b.y & 0x00FFFFFFu) << sb;
+    x1 = (uint32_t)(rg >> 32) | (uint32_t)b0;
+    x2 = (uint32_t)(b0 >> 32) | (uint32_t)b1;
+    x3 = (uint32_t)(b1 >> 32);
+    bits = sb + (b.y >> 24);
+  }
+  const uint32_t a1 = (x0 << 24) | 0x003B323Bu; /* ; 2 ; + the first digit */
+  const uint32_t a2 = alignbit(x1, x0, 8u), a3 = alignbit(x2, x1, 8u);
+  if (!LONGB) {
+    const uint32_t a[5] = {pre, a1, a2, a3, x2 >> 8};
+    word_string<5>(p, a);
+  } else {
+    const uint32_t a[6] = {pre, a1, a2, a3, alignbit(x3, x2, 8u), x3 >> 8};
+    word_string<6>(p, a);
+  }
+  return bits;
+}
+/* ESC[38;5;Nm / ESC[48;5;Nm the same way: e = {digits + 'm', 8 x length}; returns the length in bits */
+__device__ inline uint32_t word_sgr_256(uint32_t p, uint2 e, uint32_t pre) {
+  const uint32_t a[3] = {pre, (e.x << 24) | 0x003B353Bu, e.x >> 8}; /* ; 5 ; */
+  word_string<3>(p, a);
+  return 56u + e.y; /* (+ 88 with the truecolor B table: WordSink) */
+}
+
+/* FastSink whose truecolor / 256-colour SGRs leave as words (tables at WR / WG / WM, < 0: none); everything else of a token
+ * as FastSink's bytes.  No byte field with room behind it (FastSink::num<ROOM >= 1>) may precede an SGR in a token: its
+ * spill would be OR-ed into. */
+template <int DEC_OFF, int DUMMY_OFF, int WR, int WG, int WM, bool TRUE_SGR, bool SGR256>
+struct WordSink : FastSink<DEC_OFF, DUMMY_OFF> {
+  static constexpr bool FAST_DEC = TRUE_SGR;
+  static constexpr bool FAST_256 = SGR256;
+  using FastSink<DEC_OFF, DUMMY_OFF>::a;
+  template <int ROOM> __device__ inline void sgr_true(bool bg, uint32_t rgb) {
+    const WordFields w = word_fields<(WR >= 0 ? WR : 0), (WG >= 0 ? WG : 0), (WM >= 0 ? WM : 0)>(rgb);
+    a += word_sgr<false>(a, w, bg ? 0x38345B1Bu : 0x38335B1Bu) >> 3;
+  }
+  template <int ROOM> __device__ inline void sgr_256(bool bg, uint32_t idx) {
+    const uint2 e = lds_ptr<const uint2>(WM >= 0 ? WM : 0)[idx];
+    a += (word_sgr_256(a, e, bg ? 0x38345B1Bu : 0x38335B1Bu) - 88u) >> 3; /* (the table's term carries word_sgr's + 88) */
+  }
+};
+
 /* PackSink: the token is assembled in a 64-bit register window and leaves it one ALIGNED dword at a time as
  * an LDS atomic OR into the pre-zeroed staging buffer (the drain re-zeroes what it flushes).  Compared with
  * FastSink a 41-byte half-block token costs 12 LDS instructions instead of 41 -- token stores are bound by LDS
@@ -262,6 +359,7 @@ template <int DEC_OFF, int DUMMY_OFF> struct FastSink {
  * few more VALU operations.  Every field is at most 4 bytes, so at most one dword completes per field. */
 template <int DEC_OFF> struct PackSink {
   static constexpr bool FAST_DEC = false;
+  static constexpr bool FAST_256 = false;
   uint32_t a;   /* LDS byte address (4-byte aligned) of the window's first byte */
   uint32_t nb;  /* bytes pending in the window, 0..3 between fields                */
   uint64_t acc; /* pending bytes, first in the low byte                            */
@@ -842,6 +940,10 @@ template <int ROOM, class S> __device__ inline void put_sgr_true(S &s, bool bg, 
 }
 /* ESC[38;5;Nm / ESC[48;5;Nm  (ansi.c:326-357) */
 template <int ROOM, class S> __device__ inline void put_sgr_256(S &s, bool bg, uint32_t idx) {
+  if constexpr (S::FAST_256) {
+    s.template sgr_256<ROOM>(bg, idx);
+    return;
+  }
   const uint32_t e = s.lookup(idx);
   s.template c<4>(bg ? 0x38345B1Bu : 0x38335B1Bu);
   s.template c<3>(0x003B353Bu); /* ; 5 ; */

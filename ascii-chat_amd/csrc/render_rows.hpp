@@ -52,7 +52,7 @@ namespace achip {
 #ifndef ACHIP_ROWS_WORD_EMIT
 #define ACHIP_ROWS_WORD_EMIT 1 /* truecolor half blocks: a token of the common shape -- both SGRs and the half block -- is put
                                   together in registers from ready-made table pieces and leaves them as 13 aligned dword ORs
-                                  instead of 41 byte stores (rows_word_sgr, below); 0 (A/B builds): byte stores only */
+                                  instead of 41 byte stores (word_sgr, below); 0 (A/B builds): byte stores only */
 #endif
 #ifndef ACHIP_ROWS_EMIT_OR_MODES
 #define ACHIP_ROWS_EMIT_OR_MODES 0 /* bit m set: mode m stores its tokens through PackSink here.  Off: this kernel is bound
@@ -85,7 +85,7 @@ template <int MODE, int WAVES, bool CRC = false> struct RLds {
   static constexpr int o_num_semi = o_dec + 256 * 4;
   static constexpr int o_num_m = o_num_semi + (NUM8 ? 256 * 8 : 0);
   static constexpr int o_num_len = o_num_m + (NUM8 ? 256 * 8 : 0);
-  /* ... and for tokens built as words (rows_word_sgr): {text, shift / length terms in bits} of the R, G, B fields and of the
+  /* ... and for tokens built as words (word_sgr): {text, shift / length terms in bits} of the R, G, B fields and of the
    * background's B field with the half block behind it */
   static constexpr bool WORDS = NUM8 && !CRC && (ACHIP_ROWS_WORD_EMIT != 0);
   static constexpr int o_wr = o_num_len + (NUM8 ? 256 : 0);
@@ -153,60 +153,6 @@ template <int DEC_OFF, int DUMMY_OFF, int SEMI_OFF, int M_OFF> struct RowsFastSi
     field4(e2);
   }
 };
-
-/* One truecolor SGR -- ESC[38;2;R;G;Bm, or ESC[48;2;R;G;Bm with the half block U+2580 behind it -- built in registers and
- * OR-ed into the (zeroed) staging area as aligned dwords; `p` = LDS byte address of its first byte.  Returns its length in
- * BITS.  The three fields come out of LDS as {text, 8 x length} (the G table's term carries -32, the B tables' +88, so that
- * the shifts and the total are single additions): X = R | G << 8 lr | B << 8 (lr + lg) in three or four dwords, moved up
- * behind the 7-byte prefix by constant funnel shifts, then moved up by the 1..4 bytes between the dword in front of `p` and
- * `p` by funnel shifts of one per-lane amount (1..4 and not 0..3: v_alignbit_b32 takes its amount modulo 32, and a move
- * by a whole dword is the amount 0).  6 / 7 LDS instructions instead of 19 / 22 byte stores; the byte stores of a wave's
- * tokens lie ~38 bytes apart at pseudo-random banks, the LDS pipe was active for 65 % of the launch and more than half of
- * that were bank conflicts (profiles/r05_k5_sampled_sq_counters.txt). */
-struct RowsWordFields {
-  uint2 r, g, b;
-};
-template <class L, bool BG> __device__ inline RowsWordFields rows_word_fields(uint32_t rgb) {
-  return RowsWordFields{lds_ptr<const uint2>(L::o_wr)[px_r(rgb)], lds_ptr<const uint2>(L::o_wg)[px_g(rgb)],
-                        lds_ptr<const uint2>(BG ? L::o_wmg : L::o_wm)[px_b(rgb)]};
-}
-template <bool BG> __device__ inline uint32_t rows_word_sgr(uint32_t p, const RowsWordFields &w) {
-  const uint2 r = w.r, g = w.g, b = w.b;
-  const uint64_t rg = (uint64_t)g.x << r.y; /* r.y = 16, 24, 32 */
-  const uint32_t sb = r.y + g.y;            /* 8 (lr + lg) - 32 = 0 .. 32 */
-  const uint32_t x0 = r.x | (uint32_t)rg;
-  uint32_t x1, x2, x3 = 0u, bits;
-  if (!BG) {
-    const uint64_t bb = (uint64_t)b.x << sb;
-    x1 = (uint32_t)(rg >> 32) | (uint32_t)bb;
-    x2 = (uint32_t)(bb >> 32);
-    bits = sb + b.y;
-  } else {
-    const uint64_t b0 = (uint64_t)b.x << sb, b1 = (uint64_t)(b.y & 0x00FFFFFFu) << sb;
-    x1 = (uint32_t)(rg >> 32) | (uint32_t)b0;
-    x2 = (uint32_t)(b0 >> 32) | (uint32_t)b1;
-    x3 = (uint32_t)(b1 >> 32);
-    bits = sb + (b.y >> 24);
-  }
-  const uint32_t a0 = BG ? 0x38345B1Bu : 0x38335B1Bu; /* ESC [ 3|4 8 */
-  const uint32_t a1 = (x0 << 24) | 0x003B323Bu;       /* ; 2 ; + the first digit */
-  const uint32_t a2 = alignbit(x1, x0, 8u), a3 = alignbit(x2, x1, 8u);
-  const uint32_t a4 = BG ? alignbit(x3, x2, 8u) : x2 >> 8;
-  const uint32_t t = p - 1u, base = t & ~3u, sh = (t << 3) ^ 24u;
-  ds_or_u32_at<0>(base, alignbit(a0, 0u, sh));
-  ds_or_u32_at<4>(base, alignbit(a1, a0, sh));
-  ds_or_u32_at<8>(base, alignbit(a2, a1, sh));
-  ds_or_u32_at<12>(base, alignbit(a3, a2, sh));
-  ds_or_u32_at<16>(base, alignbit(a4, a3, sh));
-  if (!BG) {
-    ds_or_u32_at<20>(base, alignbit(0u, a4, sh));
-  } else {
-    const uint32_t a5 = x3 >> 8;
-    ds_or_u32_at<20>(base, alignbit(a5, a4, sh));
-    ds_or_u32_at<24>(base, alignbit(0u, a5, sh));
-  }
-  return bits;
-}
 
 /* run key comparison of two cells (render_kernels.hpp same_run, on registers) */
 template <int MODE> __device__ inline bool rows_same_run(uint32_t aT, uint32_t aB, uint32_t bT, uint32_t bB) {
@@ -608,13 +554,13 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
         lds_ptr<uint2>(L::o_num_semi)[tid + k * BLOCK] = make_uint2(dg | ((uint32_t)';' << (8u * nd)), nd + 1u);
         lds_ptr<uint2>(L::o_num_m)[tid + k * BLOCK] = make_uint2(dg | ((uint32_t)'m' << (8u * nd)), nd + 1u);
         lds_ptr<uint8_t>(L::o_num_len)[tid + k * BLOCK] = (uint8_t)(nd + 1u);
-        if (L::WORDS) { /* rows_word_sgr's pieces */
-          const uint32_t fm = dg | ((uint32_t)'m' << (8u * nd)), l8 = 8u * (nd + 1u);
-          const uint64_t fmg = (uint64_t)fm | (0x8096E2ull << l8); /* + U+2580 = E2 96 80 */
-          lds_ptr<uint2>(L::o_wr)[tid + k * BLOCK] = make_uint2(dg | ((uint32_t)';' << (8u * nd)), l8);
-          lds_ptr<uint2>(L::o_wg)[tid + k * BLOCK] = make_uint2(dg | ((uint32_t)';' << (8u * nd)), l8 - 32u);
-          lds_ptr<uint2>(L::o_wm)[tid + k * BLOCK] = make_uint2(fm, l8 + 88u);
-          lds_ptr<uint2>(L::o_wmg)[tid + k * BLOCK] = make_uint2((uint32_t)fmg, (uint32_t)(fmg >> 32) | ((l8 + 24u + 88u) << 24));
+        if (L::WORDS) { /* word_sgr's pieces */
+          uint2 wr, wg, wm, wmg;
+          word_table_entries((uint32_t)(tid + k * BLOCK), wr, wg, wm, wmg);
+          lds_ptr<uint2>(L::o_wr)[tid + k * BLOCK] = wr;
+          lds_ptr<uint2>(L::o_wg)[tid + k * BLOCK] = wg;
+          lds_ptr<uint2>(L::o_wm)[tid + k * BLOCK] = wm;
+          lds_ptr<uint2>(L::o_wmg)[tid + k * BLOCK] = wmg;
         }
       }
     }
@@ -624,7 +570,7 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
   }
   for (int k = tid; k < nblk; k += BLOCK)
     slots[k] = 0u;
-  if (EMIT_OR || L::WORDS) /* the OR-filled staging areas start out zero; every slice clears what it used */
+  if (EMIT_OR) /* the OR-filled staging areas start out zero; every slice clears what it used */
     for (int k = tid; k < WAVES * L::STAGE / 16; k += BLOCK)
       lds_ptr<uint4>(L::o_stage)[k] = make_uint4(0u, 0u, 0u, 0u);
   if (CRC) {
@@ -653,6 +599,11 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
   const uint32_t stage_addr = lds_base_addr() + stage_off;
   const uint32_t dummy_addr = lds_base_addr() + (uint32_t)L::o_flags + 16u + 4u * (uint32_t)lane;
   const unsigned char *stage = lds_ptr<const unsigned char>((int)stage_off);
+  if (L::WORDS) { /* word-built tokens are OR-ed into zeros: every wave clears its own area (its samples are on their way meanwhile) */
+    for (int g = lane; g < L::STAGE / 16; g += 64)
+      lds_ptr<uint4>((int)stage_off)[g] = make_uint4(0u, 0u, 0u, 0u);
+    wave_lockstep();
+  }
 
   /* ---- samples -> pixels with the mode's run key in bits 31..24 (as the phase kernel parks them in LDS), in place */
   auto to_pixels = [&](int blk, uint32_t (&pt)[CPL], uint32_t (&pb)[CPL], uint32_t kinds) {
@@ -906,7 +857,7 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
         if (CARRY) {
           /* the staging area's byte 0 is the line the slice starts in (q0); [own_q, qa) is already there */
           const uint32_t qa = a + dmis, q0 = qa & ~127u, qend = qa + n;
-          /* WORDS: the SGRs of a token go out as 6 / 7 dword ORs each (rows_word_sgr; the background's carries the half
+          /* WORDS: the SGRs of a token go out as 6 / 7 dword ORs each (word_sgr; the background's carries the half
            * block), whatever else a token holds -- the reset in front of a transparent run, its space, a lone half block,
            * a repeat count, a row's reset and newline, a padding space -- as bytes around them: token_fields' order.  The
            * area is zero wherever no token has been written (cleared behind every flush, below). */
@@ -919,9 +870,9 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
                * areas): straight through, no lane branches */
               if (len_k != 0u) {
                 FastSink<L::o_dec, L::o_flags + 16> fs{stage_addr + (qa + off_k - q0), dummy_addr};
-                const RowsWordFields wf = rows_word_fields<L, false>(tk.fg), wb = rows_word_fields<L, true>(tk.bg);
-                fs.a += rows_word_sgr<false>(fs.a, wf) >> 3;
-                fs.a += rows_word_sgr<true>(fs.a, wb) >> 3;
+                const WordFields wf = word_fields<L::o_wr, L::o_wg, L::o_wm>(tk.fg), wb = word_fields<L::o_wr, L::o_wg, L::o_wmg>(tk.bg);
+                fs.a += word_sgr<false>(fs.a, wf, 0x38335B1Bu) >> 3;
+                fs.a += word_sgr<true>(fs.a, wb, 0x38345B1Bu) >> 3;
                 if (fl & TAIL) {
                   if (fl & TF_ROW_RESET)
                     put_reset(fs);
@@ -932,16 +883,16 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
             } else if (len_k != 0u) {
               FastSink<L::o_dec, L::o_flags + 16> fs{stage_addr + (qa + off_k - q0), dummy_addr};
               /* (the table reads of both SGRs in front of the lanes' branches: they overlap, and a lane without the SGR reads harmlessly) */
-              const RowsWordFields wf = rows_word_fields<L, false>(tk.fg), wb = rows_word_fields<L, true>(tk.bg);
+              const WordFields wf = word_fields<L::o_wr, L::o_wg, L::o_wm>(tk.fg), wb = word_fields<L::o_wr, L::o_wg, L::o_wmg>(tk.bg);
               if (fl & TF_PAD) {
                 fs.template c<1>(' ');
               } else {
                 if (fl & TF_RESET_PRE)
                   put_reset(fs);
                 if (fl & TF_SGR_FG)
-                  fs.a += rows_word_sgr<false>(fs.a, wf) >> 3;
+                  fs.a += word_sgr<false>(fs.a, wf, 0x38335B1Bu) >> 3;
                 if (fl & TF_SGR_BG) { /* (only in front of a half block: rows_token) */
-                  fs.a += rows_word_sgr<true>(fs.a, wb) >> 3;
+                  fs.a += word_sgr<true>(fs.a, wb, 0x38345B1Bu) >> 3;
                 } else {
                   if (fl & TF_SPACE)
                     fs.template c<1>(' ');

@@ -58,6 +58,9 @@ __host__ __device__ constexpr int stream_max_token(int m) {
  * at most -- instead of one block per wave.  PACK = 1: frames only; 2: + frame CRC, packet header, packet CRC, computed
  * from the frame's LDS image by the whole workgroup (crc_kernels.hpp's scheme: 20 KB of tables instead of the 52 KB of
  * the per-block checksum, so two 8-wave workgroups still share a CU). */
+#ifndef ACHIP_STREAM_WORD_EMIT
+#define ACHIP_STREAM_WORD_EMIT 1 /* 0 (A/B builds): every token byte as a byte store */
+#endif
 #define ACHIP_PACK_FRAME_CAP (48 * 1024)
 /* PACK == 2: how many waves of the workgroup checksum the frame's image (the Horner table of the prebuilt image is the one
  * of that many threads: crc_frame_tables_init_kernel<64 * pack_crc_waves(WAVES)>) */
@@ -75,14 +78,24 @@ template <int MODE, int WAVES, int CPL, bool CRC = false, int PACK = 0> struct S
   static constexpr int EFF = BLK - (MODE == ACHIP_MODE_TRUE_FG ? 1 : 0);
   static constexpr int STAGE = BLK * stream_max_token(MODE) + 16; /* + the 16-byte group the block starts in */
   static constexpr int GPL = (STAGE / 16 + 63) / 64; /* 16-byte groups of a block per lane when it is checksummed */
-  static constexpr int o_stage = 0;
+  static constexpr int o_stage = 16; /* (a word-built SGR at the area's first byte ORs a zero into the dword in front of it) */
   /* PACK: [16 bytes: the frame's offset in the destination] here; the frame's image lies BEHIND everything else
    * (frame_off(), as long as the launch's largest frame can be: a small footprint lets workgroups share a CU) */
   static constexpr int o_packoff = 0;
-  static constexpr int o_glyph = PACK ? 16 : WAVES * STAGE;
+  static constexpr int o_glyph = PACK ? 16 : o_stage + WAVES * STAGE;
   static constexpr int o_ramp = o_glyph + 256 * 4;
   static constexpr int o_dec = o_ramp + 64;
-  static constexpr int o_flags = o_dec + 256 * 4; /* [+16 ..] swallows predicated-off byte stores */
+  /* WORDS: truecolor / 256-colour SGRs leave the registers as aligned dword ORs (render_kernels.hpp word_sgr): their
+   * tables; the staging areas start out zero and are cleared behind every drain.  (Not the instantiations that checksum
+   * the staged bytes or keep the whole frame in LDS: their staging is read again, or shared by the waves; nor truecolor
+   * backgrounds: one register more than the shared-out form's seven waves per SIMD leave.) */
+  static constexpr bool WORDS_TRUE = !CRC && !PACK && (ACHIP_STREAM_WORD_EMIT != 0) && MODE == ACHIP_MODE_TRUE_FG;
+  static constexpr bool WORDS_256 = !CRC && !PACK && (ACHIP_STREAM_WORD_EMIT != 0) && MODE == ACHIP_MODE_256_FG;
+  static constexpr bool WORDS = WORDS_TRUE || WORDS_256;
+  static constexpr int o_wr = o_dec + 256 * 4;
+  static constexpr int o_wg = o_wr + (WORDS_TRUE ? 256 * 8 : 0);
+  static constexpr int o_wm = o_wg + (WORDS_TRUE ? 256 * 8 : 0);
+  static constexpr int o_flags = o_wm + (WORDS ? 256 * 8 : 0); /* [+16 ..] swallows predicated-off byte stores */
   /* CRC instantiations: constant tables, copied from global memory where crc_tables_init_kernel put them -- the 16
    * slicing tables; window tables of the lanes' multipliers; x^(8v), x^(8*256v), x^(8*65536v); x^k (k = 0..62) -- then
    * accumulator, deferred and finished counts */
@@ -660,6 +673,15 @@ __global__ void __launch_bounds__(WAVES * 64)
     if (tid + k * BLOCK < 256) {
       glyph[tid + k * BLOCK] = lut_g[k];
       lds_ptr<uint32_t>(L::o_dec)[tid + k * BLOCK] = dec_table_entry((uint32_t)(tid + k * BLOCK));
+      if (L::WORDS) {
+        uint2 wr, wg, wm, wmg;
+        word_table_entries((uint32_t)(tid + k * BLOCK), wr, wg, wm, wmg);
+        if (L::WORDS_TRUE) {
+          lds_ptr<uint2>(L::o_wr)[tid + k * BLOCK] = wr;
+          lds_ptr<uint2>(L::o_wg)[tid + k * BLOCK] = wg;
+        }
+        lds_ptr<uint2>(L::o_wm)[tid + k * BLOCK] = wm;
+      }
     }
   if (MODE == ACHIP_MODE_16_FG && tid < 64)
     ramp[tid] = (uint8_t)lut_ramp;
@@ -702,6 +724,11 @@ __global__ void __launch_bounds__(WAVES * 64)
   const uint32_t stage_addr = lds_base_addr() + stage_off;
   /* predicated-off byte stores land in a per-lane dummy word (one address for all lanes would serialise them) */
   const uint32_t dummy_addr = lds_base_addr() + (uint32_t)L::o_flags + 16u + 4u * (uint32_t)lane;
+  if (L::WORDS) { /* every wave clears its own area, behind the barrier: its samples are on their way meanwhile */
+    for (int g = lane; g < L::STAGE / 16; g += 64)
+      lds_ptr<uint4>((int)stage_off)[g] = make_uint4(0u, 0u, 0u, 0u);
+    wave_lockstep();
+  }
 
   for (int blk = b0 + wave; blk < b1; blk += WAVES) {
     /* ---- request the next block's samples: they stay in flight while this block is tokenised and drained */
@@ -859,7 +886,8 @@ __global__ void __launch_bounds__(WAVES * 64)
 #if defined(ACHIP_STREAM_ABLATE) && ACHIP_STREAM_ABLATE == 3 /* diagnostics: no token stores either */
           asm volatile("" ::"v"(tok[k].flags), "v"(tok[k].fg), "v"(tok[k].glyph), "v"(off[k]));
 #else
-          FastSink<L::o_dec, L::o_flags + 16> fs{stage_addr + (base + off[k] - g0), dummy_addr};
+          WordSink<L::o_dec, L::o_flags + 16, L::WORDS_TRUE ? L::o_wr : -1, L::WORDS_TRUE ? L::o_wg : -1, L::WORDS ? L::o_wm : -1,
+                   L::WORDS_TRUE, L::WORDS_256> fs{{stage_addr + (base + off[k] - g0), dummy_addr}};
           token_fields<MODE>(fs, tok[k], ascii_only);
 #endif
         }
@@ -893,6 +921,12 @@ __global__ void __launch_bounds__(WAVES * 64)
         const uint32_t tail_begin = max(vec_end, head_end);
         if (lane >= 32 && tail_begin + (uint32_t)(lane - 32) < end)
           dst[tail_begin + (uint32_t)(lane - 32)] = stage[tail_begin + (uint32_t)(lane - 32) - g0];
+      }
+      if (L::WORDS) { /* the next block's SGRs are OR-ed into zeros (a wave's DS operations complete in order) */
+        wave_lockstep();
+        for (uint32_t g = (uint32_t)lane; g < ((base & 15u) + total + 15u) >> 4; g += 64u)
+          lds_ptr<uint4>((int)stage_off)[g] = make_uint4(0u, 0u, 0u, 0u);
+        wave_lockstep();
       }
     }
     ACHIP_SSTAMP(CRC ? 6 : 7); /* CRC instantiations: 6 = stores issued, 7 = block checksummed and placed */
