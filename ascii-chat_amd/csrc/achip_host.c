@@ -714,6 +714,11 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
     if (short_tokens && max_wp <= 256 && n_frames > 2 * n_cus) /* (mono and mono half blocks, 200x60: 29.0 against 35.3; the coloured
                                                                    half-block modes differ by -14 .. +5 % and keep the slot rule) */
       v = 25;
+    /* (round 5, word-built SGRs: truecolor half blocks from full-frame sources on a shared GPU as well -- 256 frames at a
+     * share of 64 CUs, 1080p -> 160x45 35.8 against 39.0 us, 200x60 53.8 against 57.5, 4K -> 200x60 76.4 against 79.7; from
+     * dense sources the seven-slot geometry keeps its 0-7 %: profiles/r05_policy_audit_hb.txt) */
+    if (mode == ACHIP_MODE_HB_TRUE && !dense && n_cus <= 128 && max_wp <= 256 && n_frames > n_cus)
+      v = 25;
     /* (round 4 audit: the coloured half-block modes at no more than a frame per CU only while a wave has ONE block --
      * 256 frames of 120x40, one launch at a time: 42.9 us against the phase kernel's 37.5, 238x70 104 against 95; 80x24,
      * four blocks a frame, 21.2 against 23.1.  Mono keeps the rows kernel: 238x70 47 against 52.) */
@@ -728,17 +733,33 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
     /* (the half-block modes' frames of one block per wave as well: 64 frames of 80x24 at a share of 64 CUs 5.2-5.9 us on the
      * phase kernel against 6.2-6.9, all four of them) */
     const bool shared_gpu = n_cus <= 128;
-    /* (round 5: ... unless their sources are DENSE -- the images the targets sample, a server tick's ingest -- and the rows
-     * need the seven-slot geometry: ONE launch of at most a frame per CU then takes that geometry as a single sixteen-wave
-     * workgroup per frame (26), which fills the CU the way two eight-wave workgroups of two launches do: 256 frames of
-     * 400x240 -> 400x120 truecolor half blocks, one launch at a time, 195.9 us against the phase kernel's 241.8 and 258.8 on
-     * geometry 24; from 4K sources the phase kernel stays ahead, 247.6 against 262.3; with launches in flight 24 does,
-     * 163.8 against 190.6 -- profiles/r05_rows_sixteen_waves_ab.txt) */
+    /* (round 5: ... or the seven-slot geometry as ONE sixteen-wave workgroup per frame (26), which fills a CU the way two
+     * eight-wave workgroups of two launches do.  First measured for dense sources and rows wider than the four-slot
+     * geometry (256 frames of 400x240 -> 400x120 truecolor half blocks, one launch at a time: 195.9 us against the phase
+     * kernel's 241.8 and 258.8 on geometry 24; profiles/r05_rows_sixteen_waves_ab.txt); with the truecolor SGRs built as
+     * words (render_kernels.hpp word_sgr) it is ahead of the phase kernel for every launch of at most a frame per CU of
+     * the share whose frames are big enough to give each of the sixteen waves a block -- profiles/r05_policy_audit_hb.txt,
+     * 256 / 128 frames one launch at a time, 64 with four launches in flight:
+     *   truecolor, dense sources   120x40 25.3 against 31.2 us, 200x60 46.6 / 64.4, 320x90 (in flight) 26.9 / 37.5
+     *   truecolor, 1080p sources   160x45 44.2 / 49.9, 200x60 63.1 / 69.9, 320x90 124.7 / 154.6; 120x40 level
+     *   truecolor, 4K sources      320x90 and 400x120 up to three quarters of a frame per CU (400x120, 192 frames: 219
+     *                              against 245; 256 frames: 274 against 255 -- the gather, HBM-bound, is what sixteen
+     *                              independent waves do worse than the phase kernel's thousand threads) and in flight
+     *   256 / 16 colours           (byte-built tokens) rows beyond the four-slot geometry, and from 160 columns on when the
+     *                              sources are dense or the launch is at most three quarters of a frame per CU (7-26 %; a
+     *                              full frame per CU from 1080p sources: -6 .. +6 %, left with the phase kernel) */
     const bool coloured_hb = mode == ACHIP_MODE_HB_TRUE || mode == ACHIP_MODE_HB_256 || mode == ACHIP_MODE_HB_16;
-    if (coloured_hb && dense && !general_sampler && !shared_gpu && n_frames <= n_cus && max_wp > 256 &&
-        achip_uniform_extent(mode, 26, frames, n_frames) >= 32 && achip_uniform_extent(mode, 26, frames, n_frames) <= ACHIP_HOST_STREAM_MAXBLK) {
-      *variant = 26;
-      return 0;
+    if (coloured_hb && !general_sampler && n_frames <= n_cus && achip_uniform_extent(mode, 26, frames, n_frames) <= ACHIP_HOST_STREAM_MAXBLK) {
+      const bool big_src = max_src_w > 1920;
+      bool take26;
+      if (mode == ACHIP_MODE_HB_TRUE)
+        take26 = dense ? max_wp >= 120 : !big_src ? max_wp >= 160 : (max_wp > 256 && (shared_gpu || 4 * n_frames <= 3 * n_cus));
+      else
+        take26 = max_wp > 256 || (max_wp >= 160 && (dense || 4 * n_frames <= 3 * n_cus));
+      if (take26) {
+        *variant = 26;
+        return 0;
+      }
     }
     const bool take = n_frames > n_cus ? true : mono ? !(shared_gpu && ext > 8) : (ext <= 8 && !shared_gpu);
     if ((v == 25 || n_frames > n_cus || (mono && max_wp > 256)) && ext <= ACHIP_HOST_STREAM_MAXBLK && take) {

@@ -6,7 +6,7 @@ that can carry the plan is forced in turn -- whole frames on the stream / rows /
 with --inflight, four plans in flight through bench.py's C-issued schedule (what a saturated server is).  Every forced geometry's frames are compared with the
 automatic choice's on the GPU (all kernels must agree byte for byte; the automatic choice's first frame is checked against
 the oracle).  Prints one line per case: the automatic choice, the best, the regret.  GPU box only.
-usage: gpu_policy_audit.py [--inflight] [--quick] [--other-modes] [--4k] [--grid] [--dense]"""
+usage: gpu_policy_audit.py [--inflight] [--quick] [--other-modes] [--4k] [--grid] [--dense] [--modes=name,...]"""
 import os
 import statistics
 import sys
@@ -70,6 +70,9 @@ def time_plan(plans, n, stride, reps):
 MODES = [(0, "mono", 0, 0), (2, "ansi256", 2, 0), (1, "truecolor", 3, 0), (5, "hb_true", 3, 2)]
 if "--other-modes" in sys.argv:  # the rest of the dispatcher's table (ascii.c:955-1002)
     MODES = [(3, "ansi16", 1, 0), (6, "hb_256", 2, 2), (7, "hb_16", 1, 2), (8, "hb_mono", 0, 2)]
+for a in sys.argv:  # --modes=hb_true,truecolor: only these rows of the table
+    if a.startswith("--modes="):
+        MODES = [m for m in MODES if m[1] in a[8:].split(",")]
 SIZES = [(80, 24), (120, 40), (160, 45), (200, 60), (238, 70), (320, 90)]
 BATCHES = [1, 4, 16, 64, 128, 192, 256]
 if QUICK:
@@ -90,7 +93,7 @@ print(f"# {SRC_W}x{SRC_H} sources, {'four launches in flight through the C-issue
 for (mode, mname, cl, rm) in MODES:
     cell = mode in (1, 2, 3, 4)
     forced = ([("stream 16", 16, -1), ("stream 17", 17, -1), ("stream 18", 18, -1), ("stream 18 shared", 18, 0), ("stream 19", 19, -1)] if cell
-              else [("rows 25", 25, -1), ("rows 24", 24, -1)])
+              else [("rows 25", 25, -1), ("rows 24", 24, -1), ("rows 26", 26, -1)])
     forced += [("phase 4 whole", 4, -1), ("phase 4 bands", 4, 0), ("phase 1 whole", 1, -1), ("phase 0 whole", 0, -1), ("phase 0 bands", 0, 0)]
     for (W, H) in SIZES:
         for n in BATCHES:

@@ -548,27 +548,47 @@ def test_rows_kernel_leaves_very_wide_sources_to_the_phase_kernel():
 
 
 def test_policy_takes_the_sixteen_wave_rows_geometry_for_one_launch_of_dense_half_block_frames():
-    """geometry 26 (round 5): at most a frame per CU, coloured half blocks, rows beyond the four-slot geometry, sources that ARE
-    the images their targets sample (a tick's ingest), the GPU not shared -- and nothing else"""
+    """geometry 26 (round 5, re-audited with the word-built SGRs: profiles/r05_policy_audit_hb.txt): whole coloured
+    half-block frames at no more than a frame per CU of the plan's share, big enough for a block per wave -- from 120
+    columns for truecolor from dense sources, 160 from sources up to 1080p, rows beyond the four-slot geometry from larger
+    ones (and there only up to three quarters of a frame per CU, or in flight); 256 / 16 colours: those rows, or from 160
+    columns when the sources are dense or the launch at most three quarters of a frame per CU -- and nothing else"""
     import ctypes as C
     L = emu.lib()
     caps = (C.c_int * 5)(4096, 2048, 1024, 0, 2048)
-    dense = np.zeros((240, 400, 3), np.uint8)
-    full = np.zeros((480, 800, 3), np.uint8)
 
-    def choice(img, W, H, rm, mode, n, cus):
-        f = emu.frame_for_convert(img, W, H, rm)
+    def choice(src_wh, W, H, mode, n, cus):
+        f = emu.frame_for_convert(np.zeros((src_wh[1], src_wh[0], 3), np.uint8), W, H, 2)
         v, parts, rpp = C.c_int(), C.c_int(), C.c_int()
         assert L.achip_choose_geometry(mode, (emu.Frame * n)(*([f] * n)), n, True, caps, cus, 0, -1, C.byref(v), C.byref(parts), C.byref(rpp)) == 0
         return v.value
 
-    assert choice(dense, 400, 120, 2, MODE_HB_TRUE, 256, 256) == 26
-    assert choice(dense, 400, 120, 2, MODE_HB_256, 200, 256) == 26
-    assert choice(full, 400, 120, 2, MODE_HB_TRUE, 256, 256) != 26      # not dense: the phase kernel stays ahead
-    assert choice(dense, 400, 120, 2, MODE_HB_TRUE, 257, 256) == 24     # more than a frame per CU
-    assert choice(dense, 400, 120, 2, MODE_HB_TRUE, 64, 64) != 26       # a share of the GPU: launches in flight
-    assert choice(dense, 400, 120, 2, MODE_HB_MONO, 256, 256) != 26     # short tokens: not measured, not taken
-    assert choice(np.zeros((120, 200, 3), np.uint8), 200, 60, 2, MODE_HB_TRUE, 256, 256) != 26  # the four-slot geometry's rows
+    dense = lambda W, H: (W, 2 * H)  # noqa: E731  (the source IS the image a W x H half-block target samples)
+    hd, uhd = (1920, 1080), (3840, 2160)
+    # truecolor
+    assert choice(dense(400, 120), 400, 120, MODE_HB_TRUE, 256, 256) == 26
+    assert choice(dense(120, 40), 120, 40, MODE_HB_TRUE, 256, 256) == 26
+    assert choice(dense(120, 40), 120, 40, MODE_HB_TRUE, 64, 64) == 26        # a share of the GPU, a frame per CU of it
+    assert choice(dense(80, 24), 80, 24, MODE_HB_TRUE, 256, 256) == 25        # too small for sixteen waves
+    assert choice(hd, 200, 60, MODE_HB_TRUE, 256, 256) == 26
+    assert choice(hd, 200, 60, MODE_HB_TRUE, 64, 64) == 26
+    assert choice(hd, 120, 40, MODE_HB_TRUE, 256, 256) != 26                  # level with the phase kernel: left there
+    assert choice(uhd, 400, 120, MODE_HB_TRUE, 192, 256) == 26
+    assert choice(uhd, 400, 120, MODE_HB_TRUE, 256, 256) != 26                # BASELINE configs[4], one launch at a time: the phase kernel
+    assert choice(uhd, 400, 120, MODE_HB_TRUE, 64, 64) == 26
+    assert choice(uhd, 200, 60, MODE_HB_TRUE, 128, 256) != 26
+    assert choice(dense(400, 120), 400, 120, MODE_HB_TRUE, 257, 256) == 24    # more than a frame per CU
+    assert choice(hd, 200, 60, MODE_HB_TRUE, 256, 64) == 25                   # ... in flight from full frames: the four-slot geometry
+    assert choice(dense(200, 60), 200, 60, MODE_HB_TRUE, 256, 64) == 24       # ... from dense sources: the slot rule
+    # 256 / 16 colours
+    assert choice(dense(400, 120), 400, 120, MODE_HB_256, 200, 256) == 26
+    assert choice(hd, 320, 90, MODE_HB_16, 256, 256) == 26
+    assert choice(dense(200, 60), 200, 60, MODE_HB_256, 256, 256) == 26
+    assert choice(hd, 200, 60, MODE_HB_256, 128, 256) == 26 and choice(hd, 200, 60, MODE_HB_256, 192, 256) == 26
+    assert choice(hd, 200, 60, MODE_HB_256, 256, 256) != 26
+    assert choice(dense(120, 40), 120, 40, MODE_HB_16, 256, 256) != 26
+    # short tokens: not taken
+    assert choice(dense(400, 120), 400, 120, MODE_HB_MONO, 256, 256) != 26
 
 
 def test_rows_kernel_refuses_rows_wider_than_a_block():

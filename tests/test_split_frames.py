@@ -131,7 +131,10 @@ def test_split_ragged_batch_and_policy():
     # BASELINE configs[4]: one 400-cell row per 448-slot block when launches share the GPU (or frames outnumber CUs); ONE
     # launch of a frame per CU stays on the phase kernel (sixteen waves per CU against the 7-slot geometry's eight)
     assert choose(5, k5 * 300) == (24, 1, 120) and choose(5, k5 * 256, cus=64) == (24, 1, 120)
-    assert choose(5, k5 * 256) == (4, 1, 120)                # BASELINE configs[4]: one 400-cell row per 448-slot block
+    assert choose(5, k5 * 256) == (26, 1, 120)               # (round 5: from sources up to 1080p one sixteen-wave workgroup per frame)
+    k5_4k = [emu.frame_for_convert(np.zeros((2160, 3840, 3), np.uint8), 400, 120, 2)]
+    assert choose(5, k5_4k * 256) == (4, 1, 120)             # BASELINE configs[4] itself, a frame per CU from 4K sources: the phase kernel
+    assert choose(5, k5_4k * 192) == (26, 1, 120)            # ... up to three quarters of a frame per CU: 219 against 245 us
     assert choose(5, [emu.frame_for_convert(imgs[0], 449, 20, 2)] * 256) == (4, 1, 20)  # a row wider than a block: phase kernel
     wide = [emu.frame_for_convert(imgs[0], 3000, 4, 0)]
     assert choose(0, wide) == (0, 1, 4)                       # rows wider than the band geometries: no split
