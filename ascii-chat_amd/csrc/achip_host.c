@@ -748,12 +748,18 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
      *   256 / 16 colours           (byte-built tokens) rows beyond the four-slot geometry, and from 160 columns on when the
      *                              sources are dense or the launch is at most three quarters of a frame per CU (7-26 %; a
      *                              full frame per CU from 1080p sources: -6 .. +6 %, left with the phase kernel) */
-    const bool coloured_hb = mode == ACHIP_MODE_HB_TRUE || mode == ACHIP_MODE_HB_256 || mode == ACHIP_MODE_HB_16;
-    if (coloured_hb && !general_sampler && n_frames <= n_cus && achip_uniform_extent(mode, 26, frames, n_frames) <= ACHIP_HOST_STREAM_MAXBLK) {
+    /* (... and the short-token modes, profiles/r05_policy_audit_mono.txt -- mono, whole frames (from three quarters of a
+     * frame per CU on; below that its row bands win): 256 frames one launch at a time, 1080p -> 200x60 32.2 against 38.1 us,
+     * 320x90 59.5 against 81.9, dense 160x45 18.8 against 25.0; 64 frames at a share of 64 CUs: 200x60 7.9 against 10.0,
+     * 320x90 15.6 against 22.6; mono half blocks from dense sources 7-28 %, from full frames only beyond the four-slot
+     * geometry: 320x90 76.7 against 86.6, 200x60 48.0 against 41.5 the other way) */
+    if (!general_sampler && n_frames <= n_cus && achip_uniform_extent(mode, 26, frames, n_frames) <= ACHIP_HOST_STREAM_MAXBLK) {
       const bool big_src = max_src_w > 1920;
       bool take26;
-      if (mode == ACHIP_MODE_HB_TRUE)
+      if (mode == ACHIP_MODE_HB_TRUE || mode == ACHIP_MODE_MONO)
         take26 = dense ? max_wp >= 120 : !big_src ? max_wp >= 160 : (max_wp > 256 && (shared_gpu || 4 * n_frames <= 3 * n_cus));
+      else if (mode == ACHIP_MODE_HB_MONO)
+        take26 = dense ? max_wp >= 120 : (!shared_gpu && max_wp > 256);
       else
         take26 = max_wp > 256 || (max_wp >= 160 && (dense || 4 * n_frames <= 3 * n_cus));
       if (take26) {

@@ -587,8 +587,12 @@ def test_policy_takes_the_sixteen_wave_rows_geometry_for_one_launch_of_dense_hal
     assert choice(hd, 200, 60, MODE_HB_256, 128, 256) == 26 and choice(hd, 200, 60, MODE_HB_256, 192, 256) == 26
     assert choice(hd, 200, 60, MODE_HB_256, 256, 256) != 26
     assert choice(dense(120, 40), 120, 40, MODE_HB_16, 256, 256) != 26
-    # short tokens: not taken
-    assert choice(dense(400, 120), 400, 120, MODE_HB_MONO, 256, 256) != 26
+    # the short-token modes (profiles/r05_policy_audit_mono.txt): mono as truecolor half blocks; mono half blocks from dense
+    # sources, from full frames only rows beyond the four-slot geometry with the GPU to itself
+    assert choice(dense(400, 120), 400, 120, MODE_HB_MONO, 256, 256) == 26
+    assert choice(dense(120, 40), 120, 40, MODE_HB_MONO, 64, 64) == 26
+    assert choice(hd, 320, 90, MODE_HB_MONO, 256, 256) == 26 and choice(hd, 320, 90, MODE_HB_MONO, 64, 64) != 26
+    assert choice(hd, 200, 60, MODE_HB_MONO, 256, 256) != 26
 
 
 def test_rows_kernel_refuses_rows_wider_than_a_block():

@@ -115,12 +115,15 @@ def test_split_ragged_batch_and_policy():
     assert choose(5, hb40 * 256, cus=64) == (25, 1, 40)       # above a frame per CU: the rows kernel
     assert choose(5, hb40 * 128) == (4, 1, 40)                # half blocks are not cut into bands from half a frame per CU on (30.3 vs 32.1)
     assert choose(5, hb40 * 64)[1] > 1                        # (64 frames: bands, 14.0 vs 28.4)
-    assert choose(0, [emu.frame_for_convert(imgs[0], 320, 90, 0)] * 256) == (24, 1, 90)  # wide mono rows: seven-slot rows geometry (79 vs 88)
+    m90 = [emu.frame_for_convert(imgs[0], 320, 90, 0)]
+    assert choose(0, m90 * 256) == (26, 1, 90)                # wide mono rows: seven slots, sixteen waves (round 5: 59.5 us against 81.9 on eight)
+    assert choose(0, m90 * 300) == (24, 1, 90)                # ... more than a frame per CU: two eight-wave workgroups per CU
     # ... and what the audit with launches IN FLIGHT (bench.py's schedule, a share of 64 CUs per plan) added: on a shared GPU mono
     # frames of several blocks per wave and the half-block modes' one-block frames take the phase kernel up to a frame per CU of
     # the share; above two frames per CU mono rows of at most 256 cells take the four-slot rows geometry whatever it wastes
     m70 = [emu.frame_for_convert(imgs[0], 238, 70, 0)]
-    assert choose(0, m70 * 64, cus=64) == (4, 1, 70) and choose(0, m70 * 256) == (25, 1, 70)   # 13.8 vs 17.3 us shared; 47 vs 52 alone
+    assert choose(0, m70 * 64, cus=64) == (26, 1, 70) and choose(0, m70 * 256) == (26, 1, 70)  # (round 5: 11.2 vs 13.8 us shared; 43.2 vs 48.4 alone)
+    assert choose(0, m70 * 128, cus=64) == (25, 1, 70)
     assert choose(5, hb * 64, cus=64) == (4, 1, 24) and choose(5, hb * 256) == (25, 1, 24)     # 5.9 vs 6.9 shared; 21.2 vs 23.1 alone
     m45 = [emu.frame_for_convert(imgs[0], 160, 45, 0)]
     assert choose(0, m45 * 256, cus=64) == (25, 1, 45) and choose(0, m45 * 128, cus=64) == (24, 1, 45)  # 14.3 vs 17.3; 9.0 vs 10.6
