@@ -210,7 +210,6 @@ __device__ inline uint32_t dec_table_entry(uint32_t v) {
 
 struct CountSink {
   static constexpr bool FAST_DEC = false; /* (render_rows.hpp's sinks take a truecolor SGR's numbers from wider tables) */
-  static constexpr bool FAST_256 = false;
   uint32_t n;
   __device__ inline uint32_t lookup(uint32_t v) const { return 1u + (v >= 10u) + (v >= 100u); } /* digit count */
   template <int K> __device__ inline void c(uint32_t) { n += (uint32_t)K; }
@@ -220,7 +219,6 @@ struct CountSink {
 
 template <int DEC_OFF, int DUMMY_OFF> struct FastSink {
   static constexpr bool FAST_DEC = false;
-  static constexpr bool FAST_256 = false;
   uint32_t a;     /* LDS byte address of the next byte; the token neither wraps nor leaves the window */
   uint32_t dummy; /* LDS byte address that swallows predicated-off stores */
   __device__ inline uint32_t lookup(uint32_t v) const { return lds_ptr<const uint32_t>(DEC_OFF)[v]; }
@@ -327,28 +325,16 @@ template <bool LONGB> __device__ inline uint32_t word_sgr(uint32_t p, const Word
   }
   return bits;
 }
-/* ESC[38;5;Nm / ESC[48;5;Nm the same way: e = {digits + 'm', 8 x length}; returns the length in bits */
-__device__ inline uint32_t word_sgr_256(uint32_t p, uint2 e, uint32_t pre) {
-  const uint32_t a[3] = {pre, (e.x << 24) | 0x003B353Bu, e.x >> 8}; /* ; 5 ; */
-  word_string<3>(p, a);
-  return 56u + e.y; /* (+ 88 with the truecolor B table: WordSink) */
-}
-
-/* FastSink whose truecolor / 256-colour SGRs leave as words (tables at WR / WG / WM, < 0: none); everything else of a token
- * as FastSink's bytes.  No byte field with room behind it (FastSink::num<ROOM >= 1>) may precede an SGR in a token: its
- * spill would be OR-ed into. */
-template <int DEC_OFF, int DUMMY_OFF, int WR, int WG, int WM, bool TRUE_SGR, bool SGR256>
-struct WordSink : FastSink<DEC_OFF, DUMMY_OFF> {
-  static constexpr bool FAST_DEC = TRUE_SGR;
-  static constexpr bool FAST_256 = SGR256;
+/* FastSink whose truecolor SGRs leave as words (tables at WR / WG / WM); everything else of a token as FastSink's bytes.
+ * No byte field with room behind it (FastSink::num<ROOM >= 1>) may precede an SGR in a token: its spill would be OR-ed
+ * into.  (The 256-colour SGRs -- 9-11 bytes -- were measured the same way and stay bytes: 1080p -> 80x24 ANSI-256 6.49
+ * against 6.55 us, 256-colour half blocks level too, profiles/r05_rows_word_emit_256_ab.txt.) */
+template <int DEC_OFF, int DUMMY_OFF, int WR, int WG, int WM> struct WordSink : FastSink<DEC_OFF, DUMMY_OFF> {
+  static constexpr bool FAST_DEC = WR >= 0;
   using FastSink<DEC_OFF, DUMMY_OFF>::a;
   template <int ROOM> __device__ inline void sgr_true(bool bg, uint32_t rgb) {
     const WordFields w = word_fields<(WR >= 0 ? WR : 0), (WG >= 0 ? WG : 0), (WM >= 0 ? WM : 0)>(rgb);
     a += word_sgr<false>(a, w, bg ? 0x38345B1Bu : 0x38335B1Bu) >> 3;
-  }
-  template <int ROOM> __device__ inline void sgr_256(bool bg, uint32_t idx) {
-    const uint2 e = lds_ptr<const uint2>(WM >= 0 ? WM : 0)[idx];
-    a += (word_sgr_256(a, e, bg ? 0x38345B1Bu : 0x38335B1Bu) - 88u) >> 3; /* (the table's term carries word_sgr's + 88) */
   }
 };
 
@@ -359,7 +345,6 @@ struct WordSink : FastSink<DEC_OFF, DUMMY_OFF> {
  * few more VALU operations.  Every field is at most 4 bytes, so at most one dword completes per field. */
 template <int DEC_OFF> struct PackSink {
   static constexpr bool FAST_DEC = false;
-  static constexpr bool FAST_256 = false;
   uint32_t a;   /* LDS byte address (4-byte aligned) of the window's first byte */
   uint32_t nb;  /* bytes pending in the window, 0..3 between fields                */
   uint64_t acc; /* pending bytes, first in the low byte                            */
@@ -940,10 +925,6 @@ template <int ROOM, class S> __device__ inline void put_sgr_true(S &s, bool bg, 
 }
 /* ESC[38;5;Nm / ESC[48;5;Nm  (ansi.c:326-357) */
 template <int ROOM, class S> __device__ inline void put_sgr_256(S &s, bool bg, uint32_t idx) {
-  if constexpr (S::FAST_256) {
-    s.template sgr_256<ROOM>(bg, idx);
-    return;
-  }
   const uint32_t e = s.lookup(idx);
   s.template c<4>(bg ? 0x38345B1Bu : 0x38335B1Bu);
   s.template c<3>(0x003B353Bu); /* ; 5 ; */

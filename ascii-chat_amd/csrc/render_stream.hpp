@@ -85,16 +85,14 @@ template <int MODE, int WAVES, int CPL, bool CRC = false, int PACK = 0> struct S
   static constexpr int o_glyph = PACK ? 16 : o_stage + WAVES * STAGE;
   static constexpr int o_ramp = o_glyph + 256 * 4;
   static constexpr int o_dec = o_ramp + 64;
-  /* WORDS: truecolor / 256-colour SGRs leave the registers as aligned dword ORs (render_kernels.hpp word_sgr): their
-   * tables; the staging areas start out zero and are cleared behind every drain.  (Not the instantiations that checksum
-   * the staged bytes or keep the whole frame in LDS: their staging is read again, or shared by the waves; nor truecolor
-   * backgrounds: one register more than the shared-out form's seven waves per SIMD leave.) */
-  static constexpr bool WORDS_TRUE = !CRC && !PACK && (ACHIP_STREAM_WORD_EMIT != 0) && MODE == ACHIP_MODE_TRUE_FG;
-  static constexpr bool WORDS_256 = !CRC && !PACK && (ACHIP_STREAM_WORD_EMIT != 0) && MODE == ACHIP_MODE_256_FG;
-  static constexpr bool WORDS = WORDS_TRUE || WORDS_256;
+  /* WORDS: truecolor-fg SGRs leave the registers as aligned dword ORs (render_kernels.hpp word_sgr): their tables; the
+   * staging areas start out zero and are cleared behind every drain.  (Not the instantiations that checksum the staged
+   * bytes or keep the whole frame in LDS: their staging is read again, or shared by the waves; nor truecolor backgrounds:
+   * one register more than the shared-out form's seven waves per SIMD leave; nor the 256-colour SGRs: level, WordSink.) */
+  static constexpr bool WORDS = !CRC && !PACK && (ACHIP_STREAM_WORD_EMIT != 0) && MODE == ACHIP_MODE_TRUE_FG;
   static constexpr int o_wr = o_dec + 256 * 4;
-  static constexpr int o_wg = o_wr + (WORDS_TRUE ? 256 * 8 : 0);
-  static constexpr int o_wm = o_wg + (WORDS_TRUE ? 256 * 8 : 0);
+  static constexpr int o_wg = o_wr + (WORDS ? 256 * 8 : 0);
+  static constexpr int o_wm = o_wg + (WORDS ? 256 * 8 : 0);
   static constexpr int o_flags = o_wm + (WORDS ? 256 * 8 : 0); /* [+16 ..] swallows predicated-off byte stores */
   /* CRC instantiations: constant tables, copied from global memory where crc_tables_init_kernel put them -- the 16
    * slicing tables; window tables of the lanes' multipliers; x^(8v), x^(8*256v), x^(8*65536v); x^k (k = 0..62) -- then
@@ -676,10 +674,8 @@ __global__ void __launch_bounds__(WAVES * 64)
       if (L::WORDS) {
         uint2 wr, wg, wm, wmg;
         word_table_entries((uint32_t)(tid + k * BLOCK), wr, wg, wm, wmg);
-        if (L::WORDS_TRUE) {
-          lds_ptr<uint2>(L::o_wr)[tid + k * BLOCK] = wr;
-          lds_ptr<uint2>(L::o_wg)[tid + k * BLOCK] = wg;
-        }
+        lds_ptr<uint2>(L::o_wr)[tid + k * BLOCK] = wr;
+        lds_ptr<uint2>(L::o_wg)[tid + k * BLOCK] = wg;
         lds_ptr<uint2>(L::o_wm)[tid + k * BLOCK] = wm;
       }
     }
@@ -886,8 +882,7 @@ __global__ void __launch_bounds__(WAVES * 64)
 #if defined(ACHIP_STREAM_ABLATE) && ACHIP_STREAM_ABLATE == 3 /* diagnostics: no token stores either */
           asm volatile("" ::"v"(tok[k].flags), "v"(tok[k].fg), "v"(tok[k].glyph), "v"(off[k]));
 #else
-          WordSink<L::o_dec, L::o_flags + 16, L::WORDS_TRUE ? L::o_wr : -1, L::WORDS_TRUE ? L::o_wg : -1, L::WORDS ? L::o_wm : -1,
-                   L::WORDS_TRUE, L::WORDS_256> fs{{stage_addr + (base + off[k] - g0), dummy_addr}};
+          WordSink<L::o_dec, L::o_flags + 16, L::WORDS ? L::o_wr : -1, L::WORDS ? L::o_wg : -1, L::WORDS ? L::o_wm : -1> fs{{stage_addr + (base + off[k] - g0), dummy_addr}};
           token_fields<MODE>(fs, tok[k], ascii_only);
 #endif
         }
