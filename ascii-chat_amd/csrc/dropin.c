@@ -209,6 +209,13 @@ static int device_cu_count(void) {
 /* render one frame described by `f` (f->src = HOST pixels, `src_bytes` long) and return the malloc'd string */
 static char *render_with_lut(tls_ctx_t *c, const achip_lut_t *lut, int mode, const char *palette, achip_frame_t *f,
                              size_t src_bytes) {
+  /* what the kernel will see: the image as it is, or the pixels the target samples gathered into an image of their own
+   * (stage_source).  The geometry is chosen for THAT descriptor -- a 1 x 1080 source sampled by a 200 x 1 target becomes a
+   * 1 x 1 image, which needs the kernels' general sampler, and not every geometry carries it (round 5: rows geometry 26) */
+  achip_frame_t staged = *f;
+  const uint8_t *src_dev = stage_source(c, &staged, src_bytes);
+  if (!src_dev)
+    return NULL;
   /* a single frame on a 256-CU device: cut it into row bands so that many workgroups share it */
   int caps[ACHIP_VARIANT_COUNT], variant = -1, parts = 1, rows_per_part = 1;
   for (int v = 0; v < ACHIP_VARIANT_COUNT; v++)
@@ -217,7 +224,7 @@ static char *render_with_lut(tls_ctx_t *c, const achip_lut_t *lut, int mode, con
    * with many launches from many threads on the GPU at once the bands of one frame can end up waiting behind other
    * launches' waiters (dispatch order across XCDs is undefined); whole-frame launches have no such dependency */
   const int split_request = achip_combine_callers() > 4 ? -1 : 0;
-  if (achip_choose_geometry(mode, f, 1, achip_palette_ascii_only(palette), caps, device_cu_count(), split_request, -1, &variant,
+  if (achip_choose_geometry(mode, &staged, 1, achip_palette_ascii_only(palette), caps, device_cu_count(), split_request, -1, &variant,
                             &parts, &rows_per_part) != 0 ||
       variant < 0 || parts > DROPIN_MAX_PARTS) {
     achip_fail(ASCIICHAT_HIP_ERR_NOT_SUPPORTED, "row of %d cells exceeds the kernel chunk", f->pad_left + f->out_w);
@@ -231,10 +238,6 @@ static char *render_with_lut(tls_ctx_t *c, const achip_lut_t *lut, int mode, con
       return NULL;
   }
   c->epoch = c->epoch + 1u ? c->epoch + 1u : 1u;
-  achip_frame_t staged = *f;
-  const uint8_t *src_dev = stage_source(c, &staged, src_bytes);
-  if (!src_dev)
-    return NULL;
   size_t stride = (achip_out_bound(mode, f) + 1 + 15) & ~(size_t)15;
   if (stride > 0xFFFFFFF0u) {
     achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame too large");

@@ -17,9 +17,11 @@ extern "C" int achip_launch_render(int mode, int variant, int has_composite, con
                                    const achip_lut_t *lut_dev, uint8_t *out, uint64_t out_stride, uint32_t *out_len,
                                    unsigned long long *phase_cycles, int parts, int rows_per_part, unsigned long long *part_sync,
                                    uint32_t epoch, const achip_uniform_t *uniform, void *stream) {
-  (void)has_composite, (void)phase_cycles, (void)stream;
+  (void)phase_cycles, (void)stream;
   if (n_frames <= 0)
     return MOCK_OK;
+  if (variant == 26 && has_composite) /* as the product's launcher: the sixteen-wave rows geometry carries the fast sampler only (render_rows_inst.hip) */
+    return MOCK_INVALID;
   std::lock_guard<std::mutex> lock(g_emu_mu);
   const int was = emu_set_uniform(uniform && uniform->enabled ? 1 : 0);
   emu_set_parts(parts > 1 ? parts : 1, rows_per_part, part_sync, epoch);

@@ -58,6 +58,21 @@ def test_dropin_direct_path_stages_sampled_pixels(mock):
                 assert got == orc.convert_with_caps(img, W, H, cl, rm, aspect, aspect, False), (w, h, W, H, cl, rm, aspect)
 
 
+def test_dropin_geometry_is_chosen_for_the_image_the_kernel_will_see(mock):
+    """a source ONE pixel wide sampled by a wide one-row target is staged as a 1 x 1 image, which needs the kernels' general
+    sampler -- and rows geometry 26, which the policy takes for wide mono / half-block rows, does not carry it (the mock's
+    launcher refuses the combination as the product's does).  Found by scripts/gpu_dropin_fuzz.py on the GPU (round 5): the
+    direct path chose its geometry for the caller's descriptor, not for the staged one, and returned NULL."""
+    L = mock.lib()
+    for (w, h) in ((1, 1080), (1, 1), (2, 1080)):
+        img = orc.frame_hash_noise(w, h, 7 + w + h)
+        im = as_image(mock, img)
+        for (W, H, cl, rm, pal) in ((200, 1, 0, 0, b"@"), (200, 1, 0, 0, PAL), (160, 1, 3, 2, PAL), (320, 3, 0, 2, PAL), (200, 3, 3, 2, PAL)):
+            c = caps(mock, cl, rm, True)
+            got = mock.take_string(L.ascii_convert_with_capabilities(C.byref(im), W, H, C.byref(c), False, False, pal))
+            assert got is not None and got == orc.convert_with_caps(img, W, H, cl, rm, True, False, False, pal), (w, h, W, H, cl, rm)
+
+
 @pytest.mark.parametrize("threads", [4, 12, 24])
 def test_dropin_calls_through_the_combiner(mock, threads):
     """combine.c on the CPU: `threads` concurrent callers with different images, sizes, modes and palettes, coalescing
