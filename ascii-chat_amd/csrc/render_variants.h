@@ -66,8 +66,11 @@
 #else
 #define ACHIP_ROWS_TEST_VARIANT(X)
 #endif
+#ifndef ACHIP_ROWS24_WAVES
+#define ACHIP_ROWS24_WAVES 8 /* (A/B builds: other workgroup sizes of the seven-slot geometry) */
+#endif
 #define ACHIP_ROWS_VARIANTS(X)                                                                                    \
-  X(24, 8, 7) /* rows up to 448 cells: 4K -> 400x120 half blocks is one row per block (89 % of the slots)        */ \
+  X(24, ACHIP_ROWS24_WAVES, 7) /* rows up to 448 cells: 4K -> 400x120 half blocks is one row per block (89 % of the slots)        */ \
   X(25, 8, 4) /* rows up to 256 cells: 200x60, 160x48 one row per block; three 80-cell rows per block             */ \
   X(26, 16, 7) /* geometry 24 as ONE sixteen-wave workgroup per frame (round 5): a launch of at most a frame per CU -- a
                   server tick of one group -- from dense (sampled) sources; fast sampler only, no fused CRC         */ \
