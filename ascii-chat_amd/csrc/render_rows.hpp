@@ -726,6 +726,23 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
       const bool row_end = cm[k] < vlim && (cm[k] & CM_END) != 0u;
       return rows_token<MODE>(c, pt[k], pb[k], f.ops, glyph64, (cm[k] & CM_PAD) != 0u, row_end, cm[k] >= lastlim);
     };
+    /* ... of a word in which EVERY cell starts a run (hm[k] = the word's valid cells: a frame without flat areas -- camera
+     * noise alone does that): run = 1, the previous run's head is the left neighbour, and none of the bit scans above is
+     * needed (35 of a slot's ~320 vector instructions; rows_token folds what depends on the run length).  t_in as above:
+     * lane 0's left neighbour lies in the word below, where it need not be a head (the 256 / 16-colour modes compare keys,
+     * a run's cells may differ in raw rgb, and the HEAD's decides transparency). */
+    auto make_tok_heads = [&](int k, bool t_in) {
+      RunCtx c;
+      c.is_head = true;
+      c.run = 1u;
+      c.prevT = left_T(k);
+      c.prevB = left_B(k);
+      c.head_transparent = HBC && (px_rgb(pt[k]) | px_rgb(pb[k])) == 0u;
+      const bool t_left = lane == 0 ? t_in : (px_rgb(c.prevT) | px_rgb(c.prevB)) == 0u;
+      c.state_set = HBC && (cm[k] & CM_FIRST) == 0u && !t_left;
+      const bool row_end = cm[k] < vlim && (cm[k] & CM_END) != 0u;
+      return rows_token<MODE>(c, pt[k], pb[k], f.ops, glyph64, (cm[k] & CM_PAD) != 0u, row_end, cm[k] >= lastlim);
+    };
     /* ---- the slices' byte totals (wave-uniform).  Two slots' lengths share one scan (a slice is at most 64 x 56 bytes:
      * 16 bits each); the scans are KEPT for the store pass, which takes a cell's offset inside its slice from them */
     auto tok_len = [&](int k, const Tok &t) {
@@ -752,7 +769,11 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
           const int k = 2 * j + h;
           if (k < CPL) {
             const uint64_t tmk = HBC ? hm[k] & wave_ballot((px_rgb(pt[k]) | px_rgb(pb[k])) == 0u) : 0ull;
+#ifdef ACHIP_ROWS_NO_HEADS_PATH /* A/B builds */
             const Tok t = make_tok(k, tmk, last, lt);
+#else
+            const Tok t = hm[k] == wave_ballot(cm[k] < vlim) ? make_tok_heads(k, lt) : make_tok(k, tmk, last, lt);
+#endif
             const uint32_t n = tok_len(k, t);
             meta[k] = (n ? t.flags : 0u) | (t.rep << 12) | (n << 24);
             two_n |= n << (16 * h);
@@ -865,7 +886,12 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
             const uint32_t fl = meta[k] & 0xFFFu;
             constexpr uint32_t FULL = (uint32_t)(TF_SGR_FG | TF_SGR_BG | TF_GLYPH);
             constexpr uint32_t TAIL = (uint32_t)(TF_ROW_RESET | TF_NL);
+#ifdef ACHIP_ROWS_COUNT_WORDS /* diagnostics (scripts/isa_lines.py): only the straight-line form is compiled, so that the listing's
+                                 static counts are what a slice of a frame without flat areas executes */
+            if (true) {
+#else
             if (wave_ballot(len_k != 0u && (fl & ~TAIL) != FULL) == 0ull) {
+#endif
               /* every token of the slice has both SGRs and nothing in front of the row's end (a frame without flat
                * areas): straight through, no lane branches */
               if (len_k != 0u) {
