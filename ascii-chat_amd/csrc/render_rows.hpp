@@ -771,6 +771,8 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
             const uint64_t tmk = HBC ? hm[k] & wave_ballot((px_rgb(pt[k]) | px_rgb(pb[k])) == 0u) : 0ull;
 #ifdef ACHIP_ROWS_NO_HEADS_PATH /* A/B builds */
             const Tok t = make_tok(k, tmk, last, lt);
+#elif defined(ACHIP_ROWS_COUNT_WORDS) /* diagnostics: only the all-heads form, as the straight-line word path below */
+            const Tok t = make_tok_heads(k, lt);
 #else
             const Tok t = hm[k] == wave_ballot(cm[k] < vlim) ? make_tok_heads(k, lt) : make_tok(k, tmk, last, lt);
 #endif
