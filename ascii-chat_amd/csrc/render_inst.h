@@ -12,25 +12,38 @@
 extern "C" {
 #endif
 
-/* two translation units per geometry: _p0 = modes 0..4 (mono, the per-cell modes), _p1 = modes 5..9 (half blocks, dither) */
+/* four translation units per geometry: _p0 = modes 0..2 (mono, truecolor / 256-colour foreground), _p1 = 3, 4 (16-colour
+ * foreground, truecolor background), _p2 = 5..7 (the coloured half-block modes), _p3 = 8, 9 (mono half blocks, dither) */
+#define ACHIP_INST_PART_OF(m) ((m) <= 2 ? 0 : (m) <= 4 ? 1 : (m) <= 7 ? 2 : 3)
 #define ACHIP_INST_ARGS                                                                                                \
   int mode, int comp, const achip_frame_t *frames, int n, const achip_lut_t *lut, uint8_t *out, uint64_t stride,       \
       uint32_t *len, unsigned long long *prof, int parts, int rows_per_part, unsigned long long *part_sync,            \
       uint32_t epoch, const achip_uniform_t *uniform, void *stream
+#define ACHIP_INST_PASS mode, comp, frames, n, lut, out, stride, len, prof, parts, rows_per_part, part_sync, epoch, uniform, stream
 #define X(id, B, C, R)                                                                                                 \
   int achipk_render_inst_launch_##id##_p0(ACHIP_INST_ARGS);                                                             \
   int achipk_render_inst_launch_##id##_p1(ACHIP_INST_ARGS);                                                             \
+  int achipk_render_inst_launch_##id##_p2(ACHIP_INST_ARGS);                                                             \
+  int achipk_render_inst_launch_##id##_p3(ACHIP_INST_ARGS);                                                             \
   int achipk_render_inst_lds_##id##_p0(int mode);                                                                       \
   int achipk_render_inst_lds_##id##_p1(int mode);                                                                       \
+  int achipk_render_inst_lds_##id##_p2(int mode);                                                                       \
+  int achipk_render_inst_lds_##id##_p3(int mode);                                                                       \
   static inline int achipk_render_inst_launch_##id(ACHIP_INST_ARGS) {                                                   \
-    return mode >= ACHIP_MODE_HB_TRUE                                                                                  \
-               ? achipk_render_inst_launch_##id##_p1(mode, comp, frames, n, lut, out, stride, len, prof, parts,         \
-                                                    rows_per_part, part_sync, epoch, uniform, stream)                  \
-               : achipk_render_inst_launch_##id##_p0(mode, comp, frames, n, lut, out, stride, len, prof, parts,         \
-                                                    rows_per_part, part_sync, epoch, uniform, stream);                 \
+    switch (ACHIP_INST_PART_OF(mode)) {                                                                                \
+    case 0: return achipk_render_inst_launch_##id##_p0(ACHIP_INST_PASS);                                                \
+    case 1: return achipk_render_inst_launch_##id##_p1(ACHIP_INST_PASS);                                                \
+    case 2: return achipk_render_inst_launch_##id##_p2(ACHIP_INST_PASS);                                                \
+    default: return achipk_render_inst_launch_##id##_p3(ACHIP_INST_PASS);                                               \
+    }                                                                                                                  \
   }                                                                                                                    \
   static inline int achipk_render_inst_lds_##id(int mode) {                                                             \
-    return mode >= ACHIP_MODE_HB_TRUE ? achipk_render_inst_lds_##id##_p1(mode) : achipk_render_inst_lds_##id##_p0(mode); \
+    switch (ACHIP_INST_PART_OF(mode)) {                                                                                \
+    case 0: return achipk_render_inst_lds_##id##_p0(mode);                                                              \
+    case 1: return achipk_render_inst_lds_##id##_p1(mode);                                                              \
+    case 2: return achipk_render_inst_lds_##id##_p2(mode);                                                              \
+    default: return achipk_render_inst_lds_##id##_p3(mode);                                                             \
+    }                                                                                                                  \
   }
 ACHIP_VARIANTS(X)
 #undef X

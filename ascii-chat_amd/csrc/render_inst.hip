@@ -11,9 +11,9 @@
 #include "render_variants.h"
 
 #if !defined(ACHIP_INST) || !defined(ACHIP_PART)
-#error "compile with -DACHIP_INST=<variant id> -DACHIP_PART=<0: modes 0..4 (mono, the per-cell modes) | 1: modes 5..9 (half blocks, dither)>"
+#error "compile with -DACHIP_INST=<variant id> -DACHIP_PART=<0: modes 0..2 | 1: modes 3, 4 | 2: modes 5..7 | 3: modes 8, 9> (render_inst.h: ACHIP_INST_PART_OF)"
 #endif
-#define ACHIP_IN_PART(m) (((m) >= ACHIP_MODE_HB_TRUE) == (ACHIP_PART == 1))
+#define ACHIP_IN_PART(m) (ACHIP_INST_PART_OF(m) == ACHIP_PART)
 
 namespace {
 
