@@ -612,23 +612,29 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
     const bool two = HB && yt + 1u < (uint32_t)f.out_h;
     const bool ft = row1 && src_row(yt) == 0u, fb = row1 && two && src_row(yt + 1u) == 0u; /* wave-uniform */
     const bool tint = !GENERIC && (f.ops & ACHIP_OP_TINT) != 0u;
+    /* (the buffer's first pixel was requested AT its address, not one byte early: moved up a byte here, for the blocks that
+     * read source row 0 and no others, every sample is finished by the same shift below) */
+    if (row1 && (ft || fb)) {
+#pragma unroll
+      for (int k = 0; k < CPL; k++)
+        if ((cm[k] & 0xFFFFu) == 0u) {
+          pt[k] = ft ? pt[k] << 8 : pt[k];
+          pb[k] = fb ? pb[k] << 8 : pb[k];
+        }
+    }
 #pragma unroll
     for (int k = 0; k < CPL; k++) {
       const bool pix = cm[k] < vlim && !(cm[k] & CM_PAD);
       const uint32_t rawT = pt[k], rawB = pb[k];
       uint32_t t = 0, b = 0;
       if (pix) {
-        if (row1) { /* requested one byte early (issue) -- except the buffer's first pixel */
+        if (row1) { /* requested one byte early (issue) */
           t = rawT >> 8;
-          if (ft && (cm[k] & 0xFFFFu) == 0u)
-            t = rawT & 0x00FFFFFFu;
           if (tint)
             t = tint_pixel(t, f.ops);
           b = t;
           if (two) {
             b = rawB >> 8;
-            if (fb && (cm[k] & 0xFFFFu) == 0u)
-              b = rawB & 0x00FFFFFFu;
             if (tint)
               b = tint_pixel(b, f.ops);
           }
