@@ -46,9 +46,12 @@
 #else
 #define ACHIP_STREAM_TEST_VARIANT(X)
 #endif
+#ifndef ACHIP_STREAM17_CPL
+#define ACHIP_STREAM17_CPL 2 /* (A/B builds: more cells per lane and turn) */
+#endif
 #define ACHIP_STREAM_VARIANTS(X)                                                                                  \
   X(16, 16, 2) /* 1024 threads: a 1080p -> 80x24 frame is one block per wave                                   */ \
-  X(17, 8, 2)  /* 512 threads: two to four workgroups per CU                                                    */ \
+  X(17, 8, ACHIP_STREAM17_CPL)  /* 512 threads: two to four workgroups per CU                                  */ \
   X(18, 4, 2)  /* 256 threads                                                                                   */ \
   ACHIP_STREAM_EXTRA_VARIANT(X) /* id 19                                                                        */ \
   ACHIP_STREAM_TEST_VARIANT(X)
