@@ -1,6 +1,6 @@
 #!/bin/bash
 # SQ counter passes of the rows kernel (rocprofv3 --pmc with --kernel-trace only), per-dispatch means:
-#   scripts/gpu_pmc_rows.sh <tag> <workload> [lib .so under ascii-chat_amd/ | HEAD]
+#   [KERNEL=render_stream_kernel] scripts/gpu_pmc_rows.sh <tag> <workload> [lib .so under ascii-chat_amd/ | HEAD]
 TAG=${1:-pmcrows}; WL=${2:-sampled_400x240_halfblock}; LIB=${3:-HEAD}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT
 [ "$LIB" != HEAD ] && export ASCIICHAT_HIP_LIB=$GRAFT_REPO_ROOT/ascii-chat_amd/$LIB
@@ -16,7 +16,7 @@ run sq4 SQ_INSTS_CBRANCH SQ_INSTS_CBRANCH_TAKEN SQ_INSTS_SENDMSG SQ_WAIT_IFETCH 
 cd $GRAFT_REPO_ROOT
 python - <<PY | tee $OUT/summary.txt
 import csv, glob, collections
-print("# $WL, library $LIB: per-dispatch means of render_rows_kernel")
+print("# $WL, library $LIB: per-dispatch means of ${KERNEL:-render_rows_kernel}")
 for name in ("sq1","sq2","sq3","sq4"):
     fs = glob.glob("$OUT/%s/**/*counter_collection.csv" % name, recursive=True)
     if not fs:
@@ -24,7 +24,7 @@ for name in ("sq1","sq2","sq3","sq4"):
     for f in fs:
         acc = collections.defaultdict(lambda: [0.0,0])
         for row in csv.DictReader(open(f)):
-            if "render_rows_kernel" in row["Kernel_Name"]:
+            if "${KERNEL:-render_rows_kernel}" in row["Kernel_Name"]:
                 k = row["Counter_Name"]; acc[k][0] += float(row["Counter_Value"]); acc[k][1] += 1
         for k,(v,n) in sorted(acc.items()):
             print(f"{name:4s} {k:28s} {v/n:16.1f}  (n={n})")
