@@ -203,6 +203,7 @@ def render_frames_packed(mode, frames, palette, variant=16, stride=None, dims=No
 
 
 def frame_for_convert(img, width, height, render_mode, wants_padding=False, use_aspect=False, stretch=False):
+    assert img.flags["C_CONTIGUOUS"] and img.dtype == np.uint8, "the descriptor takes the array's address: tightly packed RGB24"
     f = Frame()
     rc = lib().achip_frame_setup(C.byref(f), img.ctypes.data, img.shape[1], img.shape[0], width, height, render_mode,
                                  wants_padding, use_aspect, stretch)
@@ -210,6 +211,7 @@ def frame_for_convert(img, width, height, render_mode, wants_padding=False, use_
 
 
 def frame_identity(img):
+    assert img.flags["C_CONTIGUOUS"] and img.dtype == np.uint8
     f = Frame()
     assert lib().achip_frame_identity(C.byref(f), img.ctypes.data, img.shape[1], img.shape[0]) == 0
     return f

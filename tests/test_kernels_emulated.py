@@ -473,6 +473,39 @@ def test_rows_kernel_torture(mode, variant):
         assert got == exp, (MODE_NAMES[mode], W, H, variant)
 
 
+def digit_length_image(w, h, seed):
+    """every pixel's channels drawn from values of one, two and three decimal digits (the boundaries included): the SGRs of
+    neighbouring cells differ in length in every combination, so word-built SGRs (render_kernels.hpp word_sgr) meet every
+    (field lengths) x (byte alignment of the token) case"""
+    vals = np.array([0, 5, 9, 10, 55, 99, 100, 200, 255], np.uint8)
+    rng = np.random.default_rng(seed)
+    return vals[rng.integers(0, len(vals), (h, w, 3))]
+
+
+@pytest.mark.parametrize("variant", [24, 25, 26])
+def test_rows_kernel_word_built_sgrs_at_every_field_length_and_alignment(variant):
+    # 27 x 27 digit-length combinations per pixel pair, every cell a run head (the all-heads path), odd widths so that
+    # tokens start at every byte alignment; then the same image with runs in it (doubled columns: the general token path
+    # next to word-built SGRs, lone half blocks, repeat counts)
+    for (w, h, seed) in [(97, 14, 1), (200, 6, 2), (61, 10, 3)]:
+        img = digit_length_image(w, h, seed)
+        for src in (img, np.ascontiguousarray(np.repeat(img, 2, axis=1)[:, :w]), np.ascontiguousarray(np.repeat(img, 5, axis=1)[:, :w])):
+            exp = oracle_convert(src, MODE_HB_TRUE, w, h // 2, orc.PALETTE_STANDARD)
+            assert emu_convert(src, MODE_HB_TRUE, w, h // 2, orc.PALETTE_STANDARD, variant) == exp, (variant, w, h, seed)
+    img = digit_length_image(120, 8, 4)  # with padding: pad cells in front of every row's first SGR
+    exp = oracle_convert(img, MODE_HB_TRUE, 120, 4, orc.PALETTE_STANDARD, True, True)
+    assert emu_convert(img, MODE_HB_TRUE, 120, 4, orc.PALETTE_STANDARD, variant, True, True) == exp
+
+
+@pytest.mark.parametrize("variant", [16, 17, 20])
+def test_stream_kernel_word_built_sgrs_at_every_field_length_and_alignment(variant):
+    for (w, h, seed) in [(97, 7, 5), (200, 3, 6), (61, 5, 7)]:
+        img = digit_length_image(w, h, seed)
+        for src in (img, np.ascontiguousarray(np.repeat(img, 2, axis=1)[:, :w])):  # (doubled columns: cells without an SGR between the others)
+            exp = oracle_convert(src, MODE_TRUE_FG, w, h, orc.PALETTE_STANDARD)
+            assert emu_convert(src, MODE_TRUE_FG, w, h, orc.PALETTE_STANDARD, variant) == exp, (variant, w, h, seed)
+
+
 @pytest.mark.parametrize("mode", ROWS_MODES, ids=ROWS_IDS)
 def test_rows_kernel_run_structure(mode):
     # runs, REP counts, transparent runs and the state they reset, runs cut by row ends -- at widths that put one, two and
