@@ -123,6 +123,31 @@ def test_torture_all_modes_all_variants(gpu, mode):
             assert got == oracle_convert(TORTURE, mode, W, H, orc.PALETTE_STANDARD), (MODE_NAMES[mode], variant, W, H)
 
 
+def test_word_built_sgrs_at_every_field_length_and_alignment(gpu):
+    """round 5: truecolor SGRs leave the registers as aligned dword ORs (render_kernels.hpp word_sgr).  Pixels whose channels
+    have one, two and three decimal digits in every combination, odd widths so that tokens start at every byte alignment;
+    with and without runs (cells without SGRs, lone half blocks, repeat counts between word-built SGRs), a batch of frames
+    per launch, every rows / stream geometry of the build"""
+    vals = np.array([0, 5, 9, 10, 55, 99, 100, 200, 255], np.uint8)
+    rng = np.random.default_rng(11)
+
+    def image(w, h, rep):
+        a = vals[rng.integers(0, len(vals), (h, (w + rep - 1) // rep, 3))]
+        return np.ascontiguousarray(np.repeat(a, rep, axis=1)[:, :w])
+
+    for (mode, variants, rows_per_cell) in ((MODE_HB_TRUE, (24, 25, 26, 4), 2), (MODE_TRUE_FG, (16, 17, 18, 4), 1)):
+        for (W, H) in ((97, 7), (200, 9), (61, 5)):
+            imgs = [image(W, H * rows_per_cell, rep) for rep in (1, 1, 2, 5, 1, 3)]
+            exp = [oracle_convert(im, mode, W, H, orc.PALETTE_STANDARD) for im in imgs]
+            for variant in variants:
+                if not geometry_built(gpu[0], variant):
+                    continue
+                assert render_batch(gpu, mode, imgs, W, H, variant=variant) == exp, (MODE_NAMES[mode], variant, W, H)
+        imgs = [image(120, 8 * rows_per_cell, rep) for rep in (1, 2)]  # aspect + padding: pad cells in front of every row
+        exp = [oracle_convert(im, mode, 120, 8, orc.PALETTE_STANDARD, True, True) for im in imgs]
+        assert render_batch(gpu, mode, imgs, 120, 8, wants_padding=True, use_aspect=True) == exp
+
+
 def test_every_geometry_renders_a_batch_to_the_same_bytes(gpu):
     """The geometry policy's audit (scripts/gpu_policy_audit.py) as a test: a plan's bytes must not depend on the
     geometry it takes.  Batches of 16 and 200 frames at two terminal sizes away from the BASELINE shapes, four modes: every
