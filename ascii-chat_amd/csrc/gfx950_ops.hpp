@@ -92,6 +92,9 @@ __device__ inline void wg_xor_u32(uint32_t *p, uint32_t v) {
 
 /* ---- wave64 ------------------------------------------------------------------------------------------------------ */
 __device__ inline uint64_t wave_ballot(bool p) { return __ballot(p); }
+/* the lane's own bit of a wave-uniform mask, as a predicate: the mask itself becomes the instruction's lane mask (no shift
+ * by the lane number, no vector instruction at all) */
+__device__ inline bool lane_bit(uint64_t wave_uniform_mask) { return __builtin_amdgcn_inverse_ballot_w64(wave_uniform_mask); }
 __device__ inline uint32_t wave_shfl_up(uint32_t v, int d) { return __shfl_up(v, d, 64); }
 __device__ inline uint32_t wave_read_lane(uint32_t v, int lane) {
   return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);

@@ -717,7 +717,7 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
     auto make_tok = [&](int k, uint64_t tmk, int h_in, bool t_in) {
       const int s = 64 * k + lane;
       RunCtx c;
-      c.is_head = ((hm[k] >> lane) & 1ull) != 0ull;
+      c.is_head = lane_bit(hm[k]);
       const int below = rows_prev_bit(hm[k], lm); /* nearest head strictly below in this word */
       const int h = c.is_head ? s : (below >= 0 ? 64 * k + below : h_in);
       const int above = rows_next_bit(hm[k], lm);
@@ -725,7 +725,7 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
       c.run = (uint32_t)(e - h);
       /* transparency of the run's head; and, for a head behind its row's first pixel, of the previous run's head */
       const bool t_below = below >= 0 ? ((tmk >> below) & 1ull) != 0ull : t_in;
-      c.head_transparent = HBC && (c.is_head ? ((tmk >> lane) & 1ull) != 0ull : t_below);
+      c.head_transparent = HBC && (c.is_head ? lane_bit(tmk) : t_below);
       c.state_set = HBC && c.is_head && (cm[k] & CM_FIRST) == 0u && !t_below;
       c.prevT = left_T(k); /* one DPP move each: cheaper than holding 2 x CPL registers across the block */
       c.prevB = left_B(k);

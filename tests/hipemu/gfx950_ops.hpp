@@ -59,6 +59,7 @@ inline void wg_xor_u32(uint32_t *p, uint32_t v) {
 }
 
 inline uint64_t wave_ballot(bool p) { return hipemu::ballot(p); }
+inline bool lane_bit(uint64_t wave_uniform_mask) { return ((wave_uniform_mask >> hipemu::lane()) & 1ull) != 0ull; }
 inline uint32_t wave_shfl_up(uint32_t v, int d) {
   return hipemu::shfl_from(v, hipemu::lane() - d); /* src < 0 -> own value, like __shfl_up */
 }
