@@ -36,7 +36,7 @@ constexpr bool HAS_CRC = ACHIP_RINST != 26;
 #else
 constexpr bool HAS_CRC = false;
 #endif
-constexpr bool HAS_COMP = ACHIP_RINST != 26; /* (the sixteen-wave geometry exists for dense single sources only: achip_choose_geometry) */
+constexpr bool HAS_COMP = ACHIP_RINST != 26; /* (the sixteen-wave geometry carries the fast sampler only: achip_choose_geometry never takes it for composites / 1x1 sources) */
 
 /* the constant tables of <MODE>'s CRC instantiation: built on the device once per process, then read-only */
 template <int MODE> hipError_t crc_tables(const uint4 **out) {

@@ -75,8 +75,8 @@
 #define ACHIP_ROWS_VARIANTS(X)                                                                                    \
   X(24, ACHIP_ROWS24_WAVES, 7) /* rows up to 448 cells: 4K -> 400x120 half blocks is one row per block (89 % of the slots)        */ \
   X(25, 8, 4) /* rows up to 256 cells: 200x60, 160x48 one row per block; three 80-cell rows per block             */ \
-  X(26, 16, 7) /* geometry 24 as ONE sixteen-wave workgroup per frame (round 5): a launch of at most a frame per CU -- a
-                  server tick of one group -- from dense (sampled) sources; fast sampler only, no fused CRC         */ \
+  X(26, 16, 7) /* geometry 24 as ONE sixteen-wave workgroup per frame (round 5): whole-frame launches of at most a frame
+                  per CU of the plan's share (achip_choose_geometry); fast sampler only, no fused CRC              */ \
   ACHIP_ROWS_TEST_VARIANT(X)
 #define ACHIP_IS_ROWS_VARIANT(v) ((v) >= ACHIP_ROWS_VARIANT_FIRST)
 

@@ -67,7 +67,9 @@ int asciichat_hip_plan_update(asciichat_hip_plan_t *plan, const achip_frame_t *f
 /* Bytes each frame needs in the output slab (worst case incl. NUL, a multiple of 128: slots of a line-aligned slab start on lines; any multiple of 16 >= this may be passed to the render calls). */
 size_t asciichat_hip_plan_out_stride(const asciichat_hip_plan_t *plan);
 
-/* Kernel geometry: -1 = automatic (by widest padded row), else a variant id from render_variants.h. */
+/* Kernel geometry: -1 = automatic (achip_choose_geometry: by mode, row width, frames per CU of the plan's share and the kind
+ * of source), else a variant id from render_variants.h; NOT_SUPPORTED when the geometry cannot carry the plan (rows geometry
+ * 26, for one, has no general sampler: no composites, no 1 x 1 sources) or is not in this build. */
 int asciichat_hip_plan_set_variant(asciichat_hip_plan_t *plan, int variant);
 int asciichat_hip_plan_get_variant(const asciichat_hip_plan_t *plan);
 
