@@ -733,14 +733,15 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
       return rows_token<MODE>(c, pt[k], pb[k], f.ops, glyph64, (cm[k] & CM_PAD) != 0u, row_end, cm[k] >= lastlim);
     };
     /* ... of a word in which EVERY cell starts a run (hm[k] = the word's valid cells: a frame without flat areas -- camera
-     * noise alone does that): run = 1, the previous run's head is the left neighbour, and none of the bit scans above is
-     * needed (35 of a slot's ~320 vector instructions; rows_token folds what depends on the run length).  t_in as above:
+     * noise alone does that): run = 1 but for the word's last cell, the previous run's head is the left neighbour, and none
+     * of the bit scans above is needed (35 of a slot's ~320 vector instructions).  t_in as above:
      * lane 0's left neighbour lies in the word below, where it need not be a head (the 256 / 16-colour modes compare keys,
      * a run's cells may differ in raw rgb, and the HEAD's decides transparency). */
     auto make_tok_heads = [&](int k, bool t_in) {
       RunCtx c;
       c.is_head = true;
-      c.run = 1u;
+      /* (the word's LAST head may start a run that goes on in the words above: its end is the first head there) */
+      c.run = lane_bit(hm[k] >> 1) ? 1u : (uint32_t)((int)((e_pack >> (9 * k)) & 0x1FFull) - (64 * k + lane));
       c.prevT = left_T(k);
       c.prevB = left_B(k);
       c.head_transparent = HBC && (px_rgb(pt[k]) | px_rgb(pb[k])) == 0u;

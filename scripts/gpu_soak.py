@@ -111,6 +111,13 @@ def main():
                     memo[key] = orc.display_convert(img, W, H, cl, rmm, pad, aspect, fx, fy, flt, palette)
                 else:
                     memo[key] = oracle_case(img, W, H, mode, aspect, pad, palette)
+            if got != memo[key]:  # keep the case for a replay under the emulator (tests/emu.py) before failing
+                os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                np.savez(os.path.join(ROOT, "gpurun_out", "soak_failure.npz"), mode=mode, palette=palette, pad=pad, aspect=aspect, k=k,
+                         variant=plan.variant, parts=plan.parts, fused_crc=int(plan.fused_crc), choice=choice, flt=flt, fx=fx, fy=fy,
+                         dims=np.array([[c[1], c[2]] for c in cases]), pool_index=np.array([j % len(pool) for j in range(len(cases))]),
+                         got=np.frombuffer(got, np.uint8), exp=np.frombuffer(memo[key], np.uint8),
+                         **{f"img{j}": p_[0] for j, p_ in enumerate(pool)})
             assert got == memo[key], (rnd, MODE_NAMES[mode], k, img.shape, W, H, pad, aspect, palette, plan.variant, plan.parts, flt, fx, fy)
             if k < 24:  # the bit-serial oracle CRC is slow: a sample per batch
                 eh, ep = orc.ascii_frame_packet(got, W, H)

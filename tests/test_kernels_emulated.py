@@ -497,6 +497,33 @@ def test_rows_kernel_word_built_sgrs_at_every_field_length_and_alignment(variant
     assert emu_convert(img, MODE_HB_TRUE, 120, 4, orc.PALETTE_STANDARD, variant, True, True) == exp
 
 
+@pytest.mark.parametrize("mode", ROWS_MODES, ids=ROWS_IDS)
+def test_rows_kernel_a_word_of_heads_whose_last_run_goes_on(mode):
+    """the all-heads path (render_rows.hpp make_tok_heads): 64 cells that each start a run, the last of them a run that goes
+    on in the next word -- its repeat count comes from the words above.  (Found by scripts/gpu_soak.py: a mono row of 63 pad
+    cells and a flat image lost its ESC[6b.)"""
+    rng = np.random.default_rng(3)
+    for (heads, flat, rows) in ((64, 36, 3), (128, 40, 2), (64, 200, 2), (192, 7, 4), (63, 37, 3)):
+        w = heads + flat
+        img = np.zeros((2 * rows, w, 3), np.uint8)
+        img[:, :heads] = rng.integers(1, 256, (2 * rows, heads, 3))
+        img[:, :heads:2, 0] = 255  # (neighbours differ whatever the quantiser: bright red against dark)
+        img[:, 1:heads:2] //= 8
+        img[:, heads:] = img[:, heads - 1:heads]  # the last head's run goes on to the end of the row
+        rm_rows = rows if MODE_CAPS[mode][1] == 2 else 2 * rows
+        exp = oracle_convert(img, mode, w, rm_rows, orc.PALETTE_STANDARD)
+        for variant in (24, 25, 26):
+            if w > {24: 448, 25: 256, 26: 448}[variant]:
+                continue
+            assert emu_convert(img, mode, w, rm_rows, orc.PALETTE_STANDARD, variant) == exp, (MODE_NAMES[mode], variant, heads, flat)
+    # ... and by padding: 63 pad cells in front of a flat row (the soak's case)
+    flat_img = np.full((40, 9, 3), 7, np.uint8)
+    f = emu.frame_for_convert(flat_img, 134, 12, MODE_CAPS[mode][1], True, True)
+    exp = oracle_convert(flat_img, mode, 134, 12, orc.PALETTE_STANDARD, True, True)
+    for variant in (24, 25, 26):
+        assert emu.render_frames(mode, [f], orc.PALETTE_STANDARD, variant)[0] == exp, (MODE_NAMES[mode], variant, f.pad_left)
+
+
 @pytest.mark.parametrize("variant", [16, 17, 20])
 def test_stream_kernel_word_built_sgrs_at_every_field_length_and_alignment(variant):
     for (w, h, seed) in [(97, 7, 5), (200, 3, 6), (61, 5, 7)]:
