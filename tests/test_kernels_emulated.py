@@ -524,6 +524,49 @@ def test_rows_kernel_a_word_of_heads_whose_last_run_goes_on(mode):
         assert emu.render_frames(mode, [f], orc.PALETTE_STANDARD, variant)[0] == exp, (MODE_NAMES[mode], variant, f.pad_left)
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_rows_kernel_random_run_structures_across_word_boundaries(seed):
+    """random rows built from segments -- noise (every cell a run head), flat colour (one long run), black (a transparent
+    run), two-colour stripes -- whose lengths cluster around the 64-cell words the rows kernel's head masks are cut into, at
+    random widths, with and without aspect + padding: every run-structured mode on every rows geometry against the oracle"""
+    rng = np.random.default_rng(1000 + seed)
+    for case in range(10):
+        w = int(rng.choice([64, 65, 100, 128, 129, 191, 192, 200, 256, 300, 384, 447, 448])) if case % 3 else int(rng.integers(1, 449))
+        rows = int(rng.integers(1, 5))
+        img = np.zeros((2 * rows, w, 3), np.uint8)
+        for y in range(2 * rows):
+            x = 0
+            while x < w:
+                n = int(rng.choice([1, 2, 3, 5, 62, 63, 64, 65, 66, 127, 128, 129])) if rng.integers(0, 3) else int(rng.integers(1, 90))
+                n = min(n, w - x)
+                kind = int(rng.integers(0, 4))
+                if kind == 0:
+                    img[y, x:x + n] = rng.integers(0, 256, (n, 3))
+                elif kind == 1:
+                    img[y, x:x + n] = rng.integers(0, 256, 3)
+                elif kind == 2:
+                    img[y, x:x + n] = 0
+                else:
+                    img[y, x:x + n:2] = rng.integers(0, 256, 3)
+                    img[y, x + 1:x + n:2] = rng.integers(0, 256, 3)
+                x += n
+            if y % 2 and rng.integers(0, 2):  # half the half-block rows: bottom = top (runs decided by the top alone)
+                img[y] = img[y - 1]
+        pad = bool(rng.integers(0, 2))
+        for mode in ROWS_MODES:
+            rm = MODE_CAPS[mode][1]
+            H = rows if rm == 2 else 2 * rows
+            W = w if not pad else min(448, w + int(rng.integers(0, 130)))
+            f = emu.frame_for_convert(img, W, H, rm, pad, pad)
+            if f is None or f.pad_left + f.out_w > 448:
+                continue
+            exp = oracle_convert(img, mode, W, H, orc.PALETTE_STANDARD, pad, pad)
+            for variant in (24, 25, 26):
+                if f.pad_left + f.out_w > {24: 448, 25: 256, 26: 448}[variant]:
+                    continue
+                assert emu.render_frames(mode, [f], orc.PALETTE_STANDARD, variant)[0] == exp, (seed, case, MODE_NAMES[mode], variant, w, W, H, pad)
+
+
 @pytest.mark.parametrize("variant", [16, 17, 20])
 def test_stream_kernel_word_built_sgrs_at_every_field_length_and_alignment(variant):
     for (w, h, seed) in [(97, 7, 5), (200, 3, 6), (61, 5, 7)]:
