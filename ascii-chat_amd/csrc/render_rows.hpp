@@ -27,9 +27,10 @@
  * decided once per frame (one record per slot: the sample's byte offset in its source row, pad / first-pixel / row-end
  * flags, row inside the block); a block that is one text row takes its source rows from scalar registers, so a sample's
  * address costs no vector arithmetic; two slots share a length scan, kept for the store pass; a truecolor SGR's
- * decimal fields come out of LDS ready to store.  The kernel then stops being bound by instruction issue alone: the token
- * byte stores' LDS bank conflicts are what is left (measured; the alternatives that were costed or measured and rejected
- * are in the round's log).
+ * decimal fields come out of LDS ready to store.  The kernel then stopped being bound by instruction issue alone -- the token
+ * byte stores' LDS bank conflicts were what was left -- so the truecolor SGRs are built in registers and leave as aligned
+ * dword ORs (render_kernels.hpp word_sgr; the store pass below), and a word of cells that all start a run takes its tokens
+ * without the head bit scans (make_tok_heads).  What was costed or measured and rejected is in the round's log.
  */
 #pragma once
 
@@ -50,9 +51,9 @@ namespace achip {
                                   sources 201 -> 235 (profiles/r05_rows_slot_emit_ab.txt) */
 #endif
 #ifndef ACHIP_ROWS_WORD_EMIT
-#define ACHIP_ROWS_WORD_EMIT 1 /* truecolor half blocks: a token of the common shape -- both SGRs and the half block -- is put
-                                  together in registers from ready-made table pieces and leaves them as 13 aligned dword ORs
-                                  instead of 41 byte stores (word_sgr, below); 0 (A/B builds): byte stores only */
+#define ACHIP_ROWS_WORD_EMIT 1 /* truecolor half blocks: a token's SGRs are put together in registers from ready-made table
+                                  pieces and leave them as 6 / 7 aligned dword ORs each instead of 19 / 22 byte stores
+                                  (render_kernels.hpp word_sgr; the store pass below); 0 (A/B builds): byte stores only */
 #endif
 #ifndef ACHIP_ROWS_EMIT_OR_MODES
 #define ACHIP_ROWS_EMIT_OR_MODES 0 /* bit m set: mode m stores its tokens through PackSink here.  Off: this kernel is bound
