@@ -44,6 +44,14 @@ template <int OFF> __device__ inline void ds_or_u32_at(uint32_t addr, uint32_t v
 }
 /* v_alignbit_b32: the low dword of {hi:lo} >> (sh & 31) */
 __device__ inline uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
+/* v_dot4_u32_u8: a.b0*b.b0 + a.b1*b.b1 + a.b2*b.b2 + a.b3*b.b3 + c -- the BT.601 luminance of a packed pixel is ONE
+ * instruction (a zero coefficient also discards whatever byte 3 holds) */
+__device__ inline uint32_t dot4_u8(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_udot4(a, b, c, false); }
+/* v_bfe_u32: `width` bits of v from bit `off` (both per lane) */
+__device__ inline uint32_t bfe_u32(uint32_t v, uint32_t off, uint32_t width) { return __builtin_amdgcn_ubfe(v, off, width); }
+/* v_mad_i32_i24 / v_mul_u32_u24 / v_mad_u32_u24: full-rate multiplies of 24-bit operands (v_mul_lo_u32 runs at a quarter) */
+__device__ inline int32_t mad_i24(int32_t a, int32_t b, int32_t c) { return __mul24(a, b) + c; }
+__device__ inline uint32_t mul_u24(uint32_t a, uint32_t b) { return __umul24(a, b); }
 /* keeps operands alive without issuing anything (ablation builds) */
 __device__ inline void keep_alive(uint32_t a, uint32_t b) { asm volatile("" ::"v"(a), "v"(b)); }
 /* LDS byte address of ACHIP_SMEM[0] (0 for a kernel without static LDS, but do not assume) */

@@ -296,34 +296,43 @@ template <int N> __device__ inline void word_string(uint32_t p, const uint32_t (
   if constexpr (N > 5) ds_or_u32_at<20>(base, alignbit(a[N > 5 ? 5 : 0], a[N > 4 ? 4 : 0], sh));
   ds_or_u32_at<4 * N>(base, alignbit(0u, a[N - 1], sh));
 }
+/* the two halves of word_sgr<false> for callers that need an SGR's length long before they store it (the stream kernel's
+ * lean loop reads the tables ONCE, in its length pass): the body "R;G;Bm" as up to twelve bytes in three dwords + the length
+ * of the whole SGR in bits ... */
+struct SgrBody {
+  uint32_t x0, x1, x2, bits;
+};
+__device__ inline SgrBody sgr_body(const WordFields &w) {
+  const uint2 r = w.r, g = w.g, b = w.b;
+  const uint64_t rg = (uint64_t)g.x << r.y; /* r.y = 16, 24, 32 */
+  const uint32_t sb = r.y + g.y;            /* 8 (lr + lg) - 32 = 0 .. 32 */
+  const uint64_t bb = (uint64_t)b.x << sb;
+  return SgrBody{r.x | (uint32_t)rg, (uint32_t)(rg >> 32) | (uint32_t)bb, (uint32_t)(bb >> 32), sb + b.y};
+}
+/* ... and its placement at LDS byte address p behind the prefix `pre` (ESC [ 3|4 8): six aligned dword ORs */
+__device__ inline void sgr_place(uint32_t p, uint32_t pre, const SgrBody &s) {
+  const uint32_t a[5] = {pre, (s.x0 << 24) | 0x003B323Bu /* ; 2 ; + the first digit */, alignbit(s.x1, s.x0, 8u),
+                         alignbit(s.x2, s.x1, 8u), s.x2 >> 8};
+  word_string<5>(p, a);
+}
 template <bool LONGB> __device__ inline uint32_t word_sgr(uint32_t p, const WordFields &w, uint32_t pre) {
+  if (!LONGB) {
+    const SgrBody s = sgr_body(w);
+    sgr_place(p, pre, s);
+    return s.bits;
+  }
   const uint2 r = w.r, g = w.g, b = w.b;
   const uint64_t rg = (uint64_t)g.x << r.y; /* r.y = 16, 24, 32 */
   const uint32_t sb = r.y + g.y;            /* 8 (lr + lg) - 32 = 0 .. 32 */
   const uint32_t x0 = r.x | (uint32_t)rg;
-  uint32_t x1, x2, x3 = 0u, bits;
-  if (!LONGB) {
-    const uint64_t bb = (uint64_t)b.x << sb;
-    x1 = (uint32_t)(rg >> 32) | (uint32_t)bb;
-    x2 = (uint32_t)(bb >> 32);
-    bits = sb + b.y;
-  } else {
-    const uint64_t b0 = (uint64_t)b.x << sb, b1 = (uint64_t)(b.y & 0x00FFFFFFu) << sb;
-    x1 = (uint32_t)(rg >> 32) | (uint32_t)b0;
-    x2 = (uint32_t)(b0 >> 32) | (uint32_t)b1;
-    x3 = (uint32_t)(b1 >> 32);
-    bits = sb + (b.y >> 24);
-  }
+  const uint64_t b0 = (uint64_t)b.x << sb, b1 = (uint64_t)(b.y & 0x00FFFFFFu) << sb;
+  const uint32_t x1 = (uint32_t)(rg >> 32) | (uint32_t)b0;
+  const uint32_t x2 = (uint32_t)(b0 >> 32) | (uint32_t)b1;
+  const uint32_t x3 = (uint32_t)(b1 >> 32);
   const uint32_t a1 = (x0 << 24) | 0x003B323Bu; /* ; 2 ; + the first digit */
-  const uint32_t a2 = alignbit(x1, x0, 8u), a3 = alignbit(x2, x1, 8u);
-  if (!LONGB) {
-    const uint32_t a[5] = {pre, a1, a2, a3, x2 >> 8};
-    word_string<5>(p, a);
-  } else {
-    const uint32_t a[6] = {pre, a1, a2, a3, alignbit(x3, x2, 8u), x3 >> 8};
-    word_string<6>(p, a);
-  }
-  return bits;
+  const uint32_t a[6] = {pre, a1, alignbit(x1, x0, 8u), alignbit(x2, x1, 8u), alignbit(x3, x2, 8u), x3 >> 8};
+  word_string<6>(p, a);
+  return sb + (b.y >> 24);
 }
 /* FastSink whose truecolor SGRs leave as words (tables at WR / WG / WM); everything else of a token as FastSink's bytes.
  * No byte field with room behind it (FastSink::num<ROOM >= 1>) may precede an SGR in a token: its spill would be OR-ed

@@ -93,7 +93,8 @@ template <int MODE, int WAVES, int CPL, bool CRC = false, int PACK = 0> struct S
   static constexpr int o_wr = o_dec + 256 * 4;
   static constexpr int o_wg = o_wr + (WORDS ? 256 * 8 : 0);
   static constexpr int o_wm = o_wg + (WORDS ? 256 * 8 : 0);
-  static constexpr int o_flags = o_wm + (WORDS ? 256 * 8 : 0); /* [+16 ..] swallows predicated-off byte stores */
+  static constexpr int o_g8 = o_wm + (WORDS ? 256 * 8 : 0);    /* the lean loop's glyphs as bytes (all-ASCII palettes) */
+  static constexpr int o_flags = o_g8 + (WORDS ? 256 : 0);     /* [+16 ..] swallows predicated-off byte stores */
   /* CRC instantiations: constant tables, copied from global memory where crc_tables_init_kernel put them -- the 16
    * slicing tables; window tables of the lanes' multipliers; x^(8v), x^(8*256v), x^(8*65536v); x^k (k = 0..62) -- then
    * accumulator, deferred and finished counts */
@@ -456,6 +457,7 @@ __global__ void __launch_bounds__(WAVES * 64)
   constexpr int BLK = L::BLK;
   constexpr int SH = BLK - L::EFF; /* 1: slot (k = 0, lane 0) is the ghost of the cell in front of the block */
   constexpr int EFF = L::EFF;
+  constexpr bool LEAN = L::WORDS && !GENERIC; /* the lean per-block loop below (truecolor foreground, single source) */
 
   uint32_t *slots = lds_ptr<uint32_t>(L::o_slots);
 
@@ -636,9 +638,68 @@ __global__ void __launch_bounds__(WAVES * 64)
       issue(StreamTagCached{}, cell0, p0, raw, kinds);
   };
 
+  /* ---- the lean loop (round 6; truecolor foreground with word-built SGRs from a single source: the render of every server
+   * tick) walks a block LANE-major -- lane l owns the CPL consecutive cells c0 .. c0 + CPL - 1, slot (lane 0, j = 0) the
+   * ghost -- so that a cell's raster predecessor is the lane's own previous slot (one DPP move per BLOCK for slot 0), a
+   * block needs ONE wave scan, and positions step by one.  The sampler is multiplications by scalars only: the 16.16
+   * ratio split into halves (24-bit multiplies run at full rate, v_mul_lo_u32 at a quarter), the flips folded into signed
+   * steps; ratio 1.0 (a sampled image, csrc/frame_dense.c) skips it.  A sample is requested one byte early (`sh` = 8) except
+   * the buffer's first pixel (`sh` = 0) and finished by ONE v_bfe_u32.
+   * Sources whose samples lie a cache line apart or more (the non-temporal copy of the loop) keep the old order, slot j =
+   * cell c0 + 64 j: there the lanes of ONE load instruction fetch neighbouring cells, and neighbours that share a line
+   * (1080p -> 80 columns: 72 bytes apart) are one request; lane-major they are two requests of two instructions, and
+   * the metric's launch, bound by requests, takes 9.97 instead of 6.89 us (profiles/r06_stream_lean_ab.txt, visit A). */
+  const bool lean_dense = f.x_ratio == 65537u && f.y_ratio == 65537u; /* (x * 65537) >> 16 = x for x < 65536 */
+  const uint32_t xr_lo = f.x_ratio & 0xFFFFu, xr_hi = f.x_ratio >> 16, yr_lo = f.y_ratio & 0xFFFFu, yr_hi = f.y_ratio >> 16;
+  const int32_t lean_mx = src.flip_x ? -3 : 3;
+  const uint32_t lean_ax = src.flip_x ? 3u * src.w1 : 0u;
+  const uint32_t lean_my = src.flip_y ? ~0u : 0u, lean_ay = src.flip_y ? src.h1 + 1u : 0u; /* h1 - y = (y ^ ~0) + h1 + 1 */
+  auto step1 = [&](CellPos p) {
+    p.xp += 1u;
+    const bool wrap = p.xp == uwp;
+    p.xp = wrap ? 0u : p.xp;
+    p.rr += wrap ? 1u : 0u;
+    return p;
+  };
+  auto lean_issue = [&](auto nt_tag, uint32_t c0, CellPos p0, uint32_t (&raw)[CPL], uint32_t (&sh)[CPL]) {
+    constexpr bool NT = decltype(nt_tag)::value, KM = NT; /* KM: slot j is cell c0 + 64 j (below) */
+    CellPos p = p0;
+#pragma unroll
+    for (int j = 0; j < CPL; j++) {
+      raw[j] = 0;
+      uint32_t x = p.xp, y = p.rr;
+      if (pad_left != 0u) { /* a pad cell fetches the last pixel of the row above: what the row's first pixel is compared with */
+        const bool pixc = p.xp >= pad_left;
+        x = pixc ? p.xp - pad_left : (uint32_t)f.out_w - 1u;
+        y = pixc ? p.rr : p.rr - (p.rr != 0u ? 1u : 0u);
+      }
+      uint32_t sx = x, sy = y;
+      if (!lean_dense) { /* (x * ratio) >> 16 = x * hi + ((x * lo) >> 16), exactly: x < 2^14, lo < 2^16, x * hi <= src_w */
+        sx = min(mul_u24(x, xr_hi) + (mul_u24(x, xr_lo) >> 16), src.w1);
+        sy = min(mul_u24(y, yr_hi) + (mul_u24(y, yr_lo) >> 16), src.h1);
+      }
+      const uint32_t syf = (sy ^ lean_my) + lean_ay;
+      const uint32_t a = (uint32_t)mad_i24((int32_t)sx, lean_mx, (int32_t)(mul_u24(syf, src.stride) + lean_ax));
+      const uint32_t back = a != 0u ? 1u : 0u;
+      sh[j] = 8u * back;
+      if (c0 + (uint32_t)(KM ? 64 * j : j) < ncells) {
+#if defined(ACHIP_STREAM_ABLATE) && ACHIP_STREAM_ABLATE == 2 /* diagnostics: no gather */
+        raw[j] = (((p.xp * 2654435761u) ^ (p.rr * 40503u) ^ (uint32_t)fidx) & 0x00FFFFFFu) << sh[j];
+#else
+        const ACHIP_GLOBAL uint8_t *q = (const ACHIP_GLOBAL uint8_t *)src.base + (a - back);
+        if (NT)
+          raw[j] = load_u32_unaligned_nt((const uint8_t *)q);
+        else
+          raw[j] = ((const ACHIP_GLOBAL unaligned_u32 *)q)->v;
+#endif
+      }
+      p = KM ? advance(p, q64, r64) : step1(p);
+    }
+  };
+
   /* lane's cell of slot k = 0; the ghost of block 0 is "cell -1" = the last cell of row -1 (modulo 2^32: the steps
    * below carry it to the right place, and it fails every `< ncells` test) */
-  uint32_t cell0 = (uint32_t)((b0 + wave) * EFF + lane) - (uint32_t)SH;
+  uint32_t cell0 = (uint32_t)((b0 + wave) * EFF + (LEAN && !src.nt ? lane * CPL : lane)) - (uint32_t)SH;
   CellPos pos;
   pos.rr = cell0 / uwp;
   pos.xp = cell0 - pos.rr * uwp;
@@ -647,12 +708,21 @@ __global__ void __launch_bounds__(WAVES * 64)
     pos.xp = uwp - 1u;
   }
   uint32_t raw[CPL], kinds = 0;
+  uint32_t raw_sh[CPL] = {}; /* LEAN: bit offset of the pixel inside its raw dword */
   /* a composite frame samples through the LDS copy of its descriptor: its first requests follow the barrier */
   const bool late_first = GENERIC && f.comp != nullptr;
   if (late_first)
     comp_stage<L::o_comp, BLOCK>(f.comp, tid);
-  else if (b0 + wave < b1)
-    issue_any(cell0, pos, raw, kinds);
+  else if (b0 + wave < b1) {
+    if constexpr (LEAN) {
+      if (src.nt)
+        lean_issue(StreamTagNT{}, cell0, pos, raw, raw_sh);
+      else
+        lean_issue(StreamTagCached{}, cell0, pos, raw, raw_sh);
+    } else {
+      issue_any(cell0, pos, raw, kinds);
+    }
+  }
   ACHIP_SSTAMP(2);
 
   if (MODE == ACHIP_MODE_TRUE_FG && !ascii_only) { /* the host sends such plans to render_frames_kernel */
@@ -677,6 +747,7 @@ __global__ void __launch_bounds__(WAVES * 64)
         lds_ptr<uint2>(L::o_wr)[tid + k * BLOCK] = wr;
         lds_ptr<uint2>(L::o_wg)[tid + k * BLOCK] = wg;
         lds_ptr<uint2>(L::o_wm)[tid + k * BLOCK] = wm;
+        lds_ptr<uint8_t>(L::o_g8)[tid + k * BLOCK] = (uint8_t)lut_g[k];
       }
     }
   if (MODE == ACHIP_MODE_16_FG && tid < 64)
@@ -726,109 +797,9 @@ __global__ void __launch_bounds__(WAVES * 64)
     wave_lockstep();
   }
 
-  for (int blk = b0 + wave; blk < b1; blk += WAVES) {
-    /* ---- request the next block's samples: they stay in flight while this block is tokenised and drained */
-    const uint32_t cell0_next = cell0 + (uint32_t)(WAVES * EFF);
-    const CellPos pos_next = advance(pos, qit, rit);
-    uint32_t raw_n[CPL], kinds_n = 0;
-    if (blk + WAVES < b1)
-      issue_any(cell0_next, pos_next, raw_n, kinds_n);
-
-    if (prof) { /* diagnostics only: make "samples arrived" a point in time */
-      wait_vmem_all();
-      ACHIP_SSTAMP(3);
-    }
-    /* ---- tokens and lengths (registers).  Written select-style: per-lane conditions become v_cndmask, not
-     * exec-mask branches -- the tail of a launch is ONE wave's instruction stream, every branch is latency. */
-    Tok tok[CPL];
-    uint32_t len[CPL], px[CPL];
-    bool is_pix[CPL], is_valid[CPL];
-    {
-      CellPos p = pos;
-#pragma unroll
-      for (int k = 0; k < CPL; k++) {
-        const bool inb = cell0 + 64u * k < ncells;
-        is_valid[k] = inb && !(SH && k == 0 && lane == 0); /* the ghost owns no token */
-        is_pix[k] = is_valid[k] && p.xp >= pad_left;
-        const uint32_t v = sample_finish<GENERIC>(f, raw[k], (kinds >> (2 * k)) & 3u);
-        px[k] = inb && (p.xp >= pad_left || pred_pad(p)) ? v : 0u;
-        p = advance(p, q64, r64);
-      }
-    }
-    {
-      CellPos p = pos;
-#pragma unroll
-      for (int k = 0; k < CPL; k++) {
-        const bool valid = is_valid[k], pix = is_pix[k];
-        const uint32_t pt = px[k];
-        const uint32_t Y = luma601(pt);
-        Tok t;
-        t.rep = 0;
-        t.bg = 0;
-        uint32_t flags, n;
-        const bool row_end = valid && p.xp == uwp - 1u; /* always a pixel cell: out_w >= 1 */
-        const bool nl = row_end && p.rr < (uint32_t)rows - 1u;
-        if (MODE == ACHIP_MODE_TRUE_FG) {
-          /* image_print_color + ansi_rle_add_pixel (foreground.c:268-303, ansi.c:261-300): the SGR only when the
-           * colour differs from the previous pixel in raster order (the state survives row ends) */
-          /* the raster predecessor sits one slot down: the neighbouring lane (the ghost for lane 1 of slot 0; with left
-           * padding the pad cell in front of the row, which fetched the row above's last pixel) */
-          const uint32_t prev = wave_shift_up1(pt, k > 0 ? wave_read_lane(px[k > 0 ? k - 1 : 0], 63) : 0u);
-          const bool have_prev = !(p.xp == pad_left && p.rr == 0u);
-          const bool sgr = !have_prev || px_rgb(prev) != px_rgb(pt);
-          t.glyph = glyph[Y];
-          t.fg = px_rgb(pt);
-          const bool fin = row_end && !nl; /* ansi_rle_finish: the single trailing ESC[0m */
-          flags = TF_GLYPH | (sgr ? TF_SGR_FG : 0u) | (nl ? TF_NL : 0u) | (fin ? TF_FINAL_RESET : 0u);
-          if (f.ops & ACHIP_OP_FG_OVERRIDE) /* rainbow_replace_ansi_colors (color_filter.c:348-408) folded in */
-            t.fg = f.ops >> ACHIP_OP_TINT_SHIFT;
-          n = (sgr ? 10u + dec_digits(px_r(t.fg)) + dec_digits(px_g(t.fg)) + dec_digits(px_b(t.fg)) : 0u) + 1u +
-              (nl ? 1u : 0u) + (fin ? 4u : 0u);
-        } else if (MODE == ACHIP_MODE_256_FG) { /* foreground.c:475-500 */
-          t.fg = quant256(pt);
-          t.glyph = glyph[Y];
-          flags = TF_SGR_FG | TF_GLYPH | (row_end ? TF_ROW_RESET : 0u) | (nl ? TF_NL : 0u);
-          n = 8u + dec_digits(t.fg) + (ascii_only ? 1u : glyph_len(t.glyph)) + (row_end ? 4u : 0u) + (nl ? 1u : 0u);
-        } else if (MODE == ACHIP_MODE_16_FG) { /* foreground.c:584-612: glyph = cache[ramp[Y>>2]] (sic) */
-          t.fg = sgr16_code(false, quant16(pt));
-          t.glyph = glyph[ramp[Y >> 2]];
-          flags = TF_SGR_FG | TF_GLYPH | (row_end ? TF_ROW_RESET : 0u) | (nl ? TF_NL : 0u);
-          n = 5u + (ascii_only ? 1u : glyph_len(t.glyph)) + (row_end ? 4u : 0u) + (nl ? 1u : 0u);
-        } else { /* background.c:49-68 */
-          t.bg = px_rgb(pt);
-          t.fg = 0;
-          t.glyph = glyph[Y];
-          flags = TF_SGR_BG | TF_SGR_FG | TF_GLYPH | (Y < 128u ? TF_FG_WHITE : 0u) | (row_end ? TF_ROW_RESET : 0u) |
-                  (nl ? TF_NL : 0u);
-          if (f.ops & ACHIP_OP_FG_OVERRIDE) {
-            t.fg = f.ops >> ACHIP_OP_TINT_SHIFT;
-            flags |= TF_FG_GIVEN;
-          }
-          t.flags = flags;
-          CountSink cs{0u};
-          token_fields<MODE>(cs, t, ascii_only);
-          n = cs.n;
-        }
-        /* ascii_pad_frame_width: a pad cell is one space; cells behind the frame own nothing */
-        t.flags = pix ? flags : (valid ? (uint32_t)TF_PAD : 0u);
-        len[k] = pix ? n : (valid ? 1u : 0u);
-        tok[k] = t;
-        p = advance(p, q64, r64);
-      }
-    }
-
-    /* ---- wave scan: cell order is k-major (cell = k*64 + lane) */
-    uint32_t off[CPL];
-    uint32_t total = 0;
-#pragma unroll
-    for (int k = 0; k < CPL; k++) {
-      const uint32_t incl = wave_inclusive_scan(len[k]);
-      off[k] = total + incl - len[k];
-      total += wave_read_lane(incl, 63);
-    }
-
-    ACHIP_SSTAMP(4);
-    /* ---- where the block starts in the frame.  Words hold absolute stream offsets (pad_top included). */
+  /* ---- where a block of `total` bytes starts in the frame (look-back inside the workgroup, the hand-off between the parts
+   * of a shared-out frame), published for the blocks behind it.  Words hold absolute stream offsets (pad_top included). */
+  auto place_block = [&](int blk, uint32_t total, bool &ok) -> uint32_t {
     uint32_t base = first_base;
     const int lb = blk - b0; /* the block's look-back word */
     if (PARTS) {
@@ -863,95 +834,347 @@ __global__ void __launch_bounds__(WAVES * 64)
       /* (sums of frames that overflow their slots: every part's bytes are < 2^30, their sum is clamped below) */
       base = lost ? 0xFFFFFFFFu : min(first_base + sum, cap_bytes + 1u);
     }
-    const bool ok = base != 0xFFFFFFFFu && (uint64_t)base + total <= cap_bytes;
+    ok = base != 0xFFFFFFFFu && (uint64_t)base + total <= cap_bytes;
     /* a frame that overflows its slot (or whose look-back failed) publishes cap+1 from there on, so every later
      * block fails the same test and prefixes stay below 2^30 (stride <= ACHIP_STREAM_MAX_STRIDE) */
     if (lane == 0)
       slot_store(&slots[lb], ACHIP_SLOT_PREFIX | (ok ? base + total : cap_bytes + 1u));
+    return base;
+  };
+  /* ---- a block's bytes, staging -> HBM (g0 = the stream offset that sits at the staging area's byte 0) */
+  auto drain_block = [&](uint32_t base, uint32_t total, uint32_t g0) {
+    /* ---- staging -> HBM: whole 16-byte groups as uint4, the shared first / last group as bytes (PACK: the frame
+     * leaves LDS as a whole, behind the loop) */
+    const unsigned char *stage = lds_ptr<const unsigned char>((int)stage_off);
+    const uint32_t end = base + total;
+    const uint32_t vec_begin = PACK ? end : (base + 15u) & ~15u, vec_end = end & ~15u;
+    /* every store instruction of the wave covers whole 128-byte lines (lane l takes the group 16 l bytes behind a LINE
+     * boundary of the ADDRESS, not behind vec_begin): a 1 KB wave store that straddles lines leaves two of them half written, and
+     * the memory side takes such writes at 4.4 instead of 5.7 TB/s (profiles/r04_rows_floor.txt) */
+    for (uint32_t q = ((vec_begin + dmis) & ~(ACHIP_DRAIN_ALIGN - 1u)) + 16u * (uint32_t)lane; q < vec_end + dmis; q += 1024u) {
+      if (q < vec_begin + dmis)
+        continue;
+      const uint32_t o = q - dmis;
+#if defined(ACHIP_STREAM_ABLATE) && (ACHIP_STREAM_ABLATE == 1 || ACHIP_STREAM_ABLATE == 3) /* diagnostics: no HBM writes */
+      const uint4 v = *reinterpret_cast<const uint4 *>(stage + (o - g0));
+      asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+#else
+      store_out16(dst + o, *reinterpret_cast<const uint4 *>(stage + (o - g0)));
+#endif
+    }
+    if (!PACK) {
+      const uint32_t head_end = min(vec_begin, end);
+      if (base + (uint32_t)lane < head_end)
+        dst[base + (uint32_t)lane] = stage[base + (uint32_t)lane - g0];
+      const uint32_t tail_begin = max(vec_end, head_end);
+      if (lane >= 32 && tail_begin + (uint32_t)(lane - 32) < end)
+        dst[tail_begin + (uint32_t)(lane - 32)] = stage[tail_begin + (uint32_t)(lane - 32) - g0];
+    }
+    if (L::WORDS) { /* the next block's SGRs are OR-ed into zeros (a wave's DS operations complete in order) */
+      wave_lockstep();
+      for (uint32_t g = (uint32_t)lane; g < ((base & 15u) + total + 15u) >> 4; g += 64u)
+        lds_ptr<uint4>((int)stage_off)[g] = make_uint4(0u, 0u, 0u, 0u);
+      wave_lockstep();
+    }
+  };
 
-    ACHIP_SSTAMP(5);
-    if (ok) {
-      /* ---- token bytes into this wave's staging area: stream offset g0 (16-byte aligned) sits at its byte 0 */
-      const uint32_t g0 = PACK ? 0u : base & ~15u;
-      if (CRC && lane == 0) /* the bytes in front of the block inside its first 16-byte group read as zero for the
-                               checksum: leading zeros do not move a zero register (program order: before the tokens) */
-        *lds_ptr<uint4>((int)stage_off) = make_uint4(0u, 0u, 0u, 0u);
+  if constexpr (LEAN) {
+    /* Two copies of the loop, chosen once per frame: a shared loop would merge the cached and the non-temporal load of a
+     * sample, and the copies of a request meeting in phi moves is a wait for memory right behind the requests
+     * (docs/history/round5.md 2b). */
+    auto lean_loop = [&](auto nt_tag) {
+      constexpr bool KM = decltype(nt_tag)::value; /* slot-major cell order (see lean_issue) */
+      uint32_t c0 = cell0;
+      for (int blk = b0 + wave; blk < b1; blk += WAVES) {
+        if (prof) { /* diagnostics only: make "samples arrived" a point in time */
+          wait_vmem_all();
+          ACHIP_SSTAMP(3);
+        }
+        /* ---- this block's samples become pixels (0x00BBGGRR); the next block's are requested into the same registers
+         * and stay in flight while this block is tokenised and drained */
+        uint32_t px[CPL];
+#pragma unroll
+        for (int j = 0; j < CPL; j++) {
+          px[j] = bfe_u32(raw[j], raw_sh[j], 24u);
+          if (f.ops & ACHIP_OP_TINT)
+            px[j] = tint_pixel(px[j], f.ops);
+        }
+        const uint32_t c0_next = c0 + (uint32_t)(WAVES * EFF);
+        const CellPos pos_next = advance(pos, qit, rit);
+        if (blk + WAVES < b1)
+          lean_issue(nt_tag, c0_next, pos_next, raw, raw_sh);
+
+        /* ---- image_print_color + ansi_rle_add_pixel (foreground.c:268-303, ansi.c:261-300) per cell: the SGR only when the
+         * colour differs from the raster predecessor's (the state survives row ends); its body "R;G;Bm" is put together
+         * HERE, from the word tables, and its length falls out of the tables' terms -- the length pass and the store pass
+         * share one set of table reads */
+        SgrBody body[CPL];
+        uint32_t len[CPL], sl[CPL], gl[CPL];
+        bool has_nl[CPL], is_fin[CPL];
+        {
+          CellPos p = pos;
+          uint32_t prev = KM ? 0u : wave_shift_up1(px[CPL - 1], 0u);
+#pragma unroll
+          for (int j = 0; j < CPL; j++) {
+            const uint32_t c = c0 + (uint32_t)(KM ? 64 * j : j);
+            if (KM) /* the neighbouring lane's slot j; lane 0: the slot below's last lane (the ghost for lane 1 of slot 0) */
+              prev = wave_shift_up1(px[j], j > 0 ? wave_read_lane(px[j > 0 ? j - 1 : 0], 63) : 0u);
+            const bool valid = c < ncells && !(j == 0 && lane == 0); /* the ghost owns no token */
+            const bool pix = valid && p.xp >= pad_left;
+            const bool row_end = valid && p.xp == uwp - 1u; /* always a pixel cell: out_w >= 1 */
+            const bool fin = valid && c == ncells - 1u;     /* ansi_rle_finish: the single trailing ESC[0m */
+            const bool sgr = c == pad_left || prev != px[j]; /* (the frame's first pixel: ansi_rle_init's first_pixel) */
+            const uint32_t Y = dot4_u8(px[j], 0x001D964Du, 128u) >> 8; /* (77 R + 150 G + 29 B + 128) >> 8 */
+            /* rainbow_replace_ansi_colors (color_filter.c:348-408) folded in: the colour of every SGR is the given one */
+            const uint32_t colour = (f.ops & ACHIP_OP_FG_OVERRIDE) ? f.ops >> ACHIP_OP_TINT_SHIFT : px[j];
+            body[j] = sgr_body(word_fields<L::o_wr, L::o_wg, L::o_wm>(colour));
+            /* (every lane reads its glyph and takes a select: a cell that is no pixel costs no branch of the wave) */
+            const uint32_t gy = lds_ptr<const uint8_t>(L::o_g8)[Y];
+            /* ascii_pad_frame_width: a pad cell is one space; cells behind the frame own nothing */
+            gl[j] = pix ? gy : (uint32_t)' ';
+            sl[j] = pix && sgr ? body[j].bits >> 3 : 0u;
+            has_nl[j] = row_end && !fin;
+            is_fin[j] = fin;
+            /* SGR + glyph + newline (+ the final reset): the predicates go in as carries */
+            len[j] = sl[j] + (valid ? 1u : 0u) + (row_end ? 1u : 0u) + (fin ? 3u : 0u);
+            prev = px[j];
+            p = KM ? advance(p, q64, r64) : step1(p);
+          }
+        }
+
+        /* ---- lane-major: ONE wave scan of the lanes' sums; slot-major: one per slot */
+        uint32_t off[CPL], total = 0;
+        if (KM) {
+#pragma unroll
+          for (int j = 0; j < CPL; j++) {
+            const uint32_t incl = wave_inclusive_scan(len[j]);
+            off[j] = total + incl - len[j];
+            total += wave_read_lane(incl, 63);
+          }
+        } else {
+          uint32_t mine = 0;
+#pragma unroll
+          for (int j = 0; j < CPL; j++) {
+            off[j] = mine;
+            mine += len[j];
+          }
+          const uint32_t incl = wave_inclusive_scan(mine);
+          total = wave_read_lane(incl, 63);
+#pragma unroll
+          for (int j = 0; j < CPL; j++)
+            off[j] += incl - mine;
+        }
+
+        ACHIP_SSTAMP(4);
+        bool ok;
+        const uint32_t base = place_block(blk, total, ok);
+
+        ACHIP_SSTAMP(5);
+        if (ok) {
+          /* ---- token bytes into this wave's staging area: stream offset g0 (16-byte aligned) sits at its byte 0 */
+          const uint32_t g0 = base & ~15u;
+#pragma unroll
+          for (int j = 0; j < CPL; j++) {
+            const uint32_t a = stage_addr + (base - g0) + off[j];
+#if defined(ACHIP_STREAM_ABLATE) && ACHIP_STREAM_ABLATE == 3 /* diagnostics: no token stores either */
+            asm volatile("" ::"v"(body[j].x0), "v"(body[j].x1), "v"(body[j].x2), "v"(gl[j]), "v"(a));
+#else
+            if (sl[j] != 0u)
+              sgr_place(a, 0x38335B1Bu, body[j]);
+            /* the glyph (a pad cell's space): cells that own nothing store into the lane's dummy word instead of branching */
+            const uint32_t g = len[j] != 0u ? a + sl[j] : dummy_addr;
+            lds_store_byte<0, false>(g, gl[j]);
+            if (has_nl[j])
+              lds_store_byte<1, false>(g, (uint32_t)'\n');
+            if (is_fin[j]) {
+              lds_store_byte<1, false>(g, 0x1Bu);
+              lds_store_byte<2, false>(g, (uint32_t)'[');
+              lds_store_byte<3, false>(g, (uint32_t)'0');
+              lds_store_byte<4, false>(g, (uint32_t)'m');
+            }
+#endif
+          }
+          lds_store_fence(); /* DS operations of one wave complete in order: the reads below see every lane's bytes */
+          ACHIP_SSTAMP(6);
+          drain_block(base, total, g0);
+        }
+        ACHIP_SSTAMP(7);
+        first_block = false;
+        if (blk == nblk - 1 && lane == 0) {
+          out_len[fidx] = ok ? base + total : ACHIP_LEN_OVERFLOW;
+          if (ok && (uint64_t)base + total < out_stride)
+            dst[base + total] = 0; /* NUL behind the frame when the slot has room, as the reference's strings carry */
+        }
+        c0 = c0_next;
+        pos = pos_next;
+      }
+    };
+#ifdef ACHIP_STREAM_COUNT_LM /* instruction-count builds (scripts/isa_lines.py --loop): the lane-major copy alone */
+    lean_loop(StreamTagCached{});
+#else
+    if (src.nt)
+      lean_loop(StreamTagNT{});
+    else
+      lean_loop(StreamTagCached{});
+#endif
+  } else {
+    for (int blk = b0 + wave; blk < b1; blk += WAVES) {
+      /* ---- request the next block's samples: they stay in flight while this block is tokenised and drained */
+      const uint32_t cell0_next = cell0 + (uint32_t)(WAVES * EFF);
+      const CellPos pos_next = advance(pos, qit, rit);
+      uint32_t raw_n[CPL], kinds_n = 0;
+      if (blk + WAVES < b1)
+        issue_any(cell0_next, pos_next, raw_n, kinds_n);
+
+      if (prof) { /* diagnostics only: make "samples arrived" a point in time */
+        wait_vmem_all();
+        ACHIP_SSTAMP(3);
+      }
+      /* ---- tokens and lengths (registers).  Written select-style: per-lane conditions become v_cndmask, not
+       * exec-mask branches -- the tail of a launch is ONE wave's instruction stream, every branch is latency. */
+      Tok tok[CPL];
+      uint32_t len[CPL], px[CPL];
+      bool is_pix[CPL], is_valid[CPL];
+      {
+        CellPos p = pos;
+#pragma unroll
+        for (int k = 0; k < CPL; k++) {
+          const bool inb = cell0 + 64u * k < ncells;
+          is_valid[k] = inb && !(SH && k == 0 && lane == 0); /* the ghost owns no token */
+          is_pix[k] = is_valid[k] && p.xp >= pad_left;
+          const uint32_t v = sample_finish<GENERIC>(f, raw[k], (kinds >> (2 * k)) & 3u);
+          px[k] = inb && (p.xp >= pad_left || pred_pad(p)) ? v : 0u;
+          p = advance(p, q64, r64);
+        }
+      }
+      {
+        CellPos p = pos;
+#pragma unroll
+        for (int k = 0; k < CPL; k++) {
+          const bool valid = is_valid[k], pix = is_pix[k];
+          const uint32_t pt = px[k];
+          const uint32_t Y = luma601(pt);
+          Tok t;
+          t.rep = 0;
+          t.bg = 0;
+          uint32_t flags, n;
+          const bool row_end = valid && p.xp == uwp - 1u; /* always a pixel cell: out_w >= 1 */
+          const bool nl = row_end && p.rr < (uint32_t)rows - 1u;
+          if (MODE == ACHIP_MODE_TRUE_FG) {
+            /* image_print_color + ansi_rle_add_pixel (foreground.c:268-303, ansi.c:261-300): the SGR only when the
+             * colour differs from the previous pixel in raster order (the state survives row ends) */
+            /* the raster predecessor sits one slot down: the neighbouring lane (the ghost for lane 1 of slot 0; with left
+             * padding the pad cell in front of the row, which fetched the row above's last pixel) */
+            const uint32_t prev = wave_shift_up1(pt, k > 0 ? wave_read_lane(px[k > 0 ? k - 1 : 0], 63) : 0u);
+            const bool have_prev = !(p.xp == pad_left && p.rr == 0u);
+            const bool sgr = !have_prev || px_rgb(prev) != px_rgb(pt);
+            t.glyph = glyph[Y];
+            t.fg = px_rgb(pt);
+            const bool fin = row_end && !nl; /* ansi_rle_finish: the single trailing ESC[0m */
+            flags = TF_GLYPH | (sgr ? TF_SGR_FG : 0u) | (nl ? TF_NL : 0u) | (fin ? TF_FINAL_RESET : 0u);
+            if (f.ops & ACHIP_OP_FG_OVERRIDE) /* rainbow_replace_ansi_colors (color_filter.c:348-408) folded in */
+              t.fg = f.ops >> ACHIP_OP_TINT_SHIFT;
+            n = (sgr ? 10u + dec_digits(px_r(t.fg)) + dec_digits(px_g(t.fg)) + dec_digits(px_b(t.fg)) : 0u) + 1u +
+                (nl ? 1u : 0u) + (fin ? 4u : 0u);
+          } else if (MODE == ACHIP_MODE_256_FG) { /* foreground.c:475-500 */
+            t.fg = quant256(pt);
+            t.glyph = glyph[Y];
+            flags = TF_SGR_FG | TF_GLYPH | (row_end ? TF_ROW_RESET : 0u) | (nl ? TF_NL : 0u);
+            n = 8u + dec_digits(t.fg) + (ascii_only ? 1u : glyph_len(t.glyph)) + (row_end ? 4u : 0u) + (nl ? 1u : 0u);
+          } else if (MODE == ACHIP_MODE_16_FG) { /* foreground.c:584-612: glyph = cache[ramp[Y>>2]] (sic) */
+            t.fg = sgr16_code(false, quant16(pt));
+            t.glyph = glyph[ramp[Y >> 2]];
+            flags = TF_SGR_FG | TF_GLYPH | (row_end ? TF_ROW_RESET : 0u) | (nl ? TF_NL : 0u);
+            n = 5u + (ascii_only ? 1u : glyph_len(t.glyph)) + (row_end ? 4u : 0u) + (nl ? 1u : 0u);
+          } else { /* background.c:49-68 */
+            t.bg = px_rgb(pt);
+            t.fg = 0;
+            t.glyph = glyph[Y];
+            flags = TF_SGR_BG | TF_SGR_FG | TF_GLYPH | (Y < 128u ? TF_FG_WHITE : 0u) | (row_end ? TF_ROW_RESET : 0u) |
+                    (nl ? TF_NL : 0u);
+            if (f.ops & ACHIP_OP_FG_OVERRIDE) {
+              t.fg = f.ops >> ACHIP_OP_TINT_SHIFT;
+              flags |= TF_FG_GIVEN;
+            }
+            t.flags = flags;
+            CountSink cs{0u};
+            token_fields<MODE>(cs, t, ascii_only);
+            n = cs.n;
+          }
+          /* ascii_pad_frame_width: a pad cell is one space; cells behind the frame own nothing */
+          t.flags = pix ? flags : (valid ? (uint32_t)TF_PAD : 0u);
+          len[k] = pix ? n : (valid ? 1u : 0u);
+          tok[k] = t;
+          p = advance(p, q64, r64);
+        }
+      }
+
+      /* ---- wave scan: cell order is k-major (cell = k*64 + lane) */
+      uint32_t off[CPL];
+      uint32_t total = 0;
+#pragma unroll
+      for (int k = 0; k < CPL; k++) {
+        const uint32_t incl = wave_inclusive_scan(len[k]);
+        off[k] = total + incl - len[k];
+        total += wave_read_lane(incl, 63);
+      }
+
+      ACHIP_SSTAMP(4);
+      bool ok;
+      const uint32_t base = place_block(blk, total, ok);
+
+      ACHIP_SSTAMP(5);
+      if (ok) {
+        /* ---- token bytes into this wave's staging area: stream offset g0 (16-byte aligned) sits at its byte 0 */
+        const uint32_t g0 = PACK ? 0u : base & ~15u;
+        if (CRC && lane == 0) /* the bytes in front of the block inside its first 16-byte group read as zero for the
+                                 checksum: leading zeros do not move a zero register (program order: before the tokens) */
+          *lds_ptr<uint4>((int)stage_off) = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int k = 0; k < CPL; k++)
+          if (len[k] != 0u) {
+#if defined(ACHIP_STREAM_ABLATE) && ACHIP_STREAM_ABLATE == 3 /* diagnostics: no token stores either */
+            asm volatile("" ::"v"(tok[k].flags), "v"(tok[k].fg), "v"(tok[k].glyph), "v"(off[k]));
+#else
+            WordSink<L::o_dec, L::o_flags + 16, L::WORDS ? L::o_wr : -1, L::WORDS ? L::o_wg : -1, L::WORDS ? L::o_wm : -1> fs{{stage_addr + (base + off[k] - g0), dummy_addr}};
+            token_fields<MODE>(fs, tok[k], ascii_only);
+#endif
+          }
+        lds_store_fence(); /* DS operations of one wave complete in order: the reads below see every lane's bytes */
+        if (!CRC)
+          ACHIP_SSTAMP(6);
+
+        drain_block(base, total, g0);
+      }
+      ACHIP_SSTAMP(CRC ? 6 : 7); /* CRC instantiations: 6 = stores issued, 7 = block checksummed and placed */
+      const bool stamp_crc = first_block;
+      first_block = false;
+      if (blk == nblk - 1 && lane == 0) {
+        out_len[fidx] = ok ? base + total : ACHIP_LEN_OVERFLOW;
+        if (!PACK && ok && (uint64_t)base + total < out_stride)
+          dst[base + total] = 0; /* NUL behind the frame when the slot has room, as the reference's strings carry */
+      }
+      if (CRC) {
+        /* ---- raw CRC of the block, from the staging area (after the stores to HBM have been issued), placed in the
+         * frame; the last block to finish completes the frame (stream_crc_* above) */
+        if (ok) {
+          const uint32_t braw = stream_crc_staged<L>(lds_ptr<const unsigned char>((int)stage_off), (base & 15u) + total, lane);
+          stream_crc_place<L>(slots, nblk, nblk_cap, blk, braw, base + total, cap_bytes, lane);  /* (CRC: never PARTS, lb == blk) */
+        }
+        stream_crc_finish<L>(slots, nblk, nblk_cap, cap_bytes, first_base, fidx, dim_w, dim_h, wire, lane);
+      }
+
+      if (CRC && prof && lane == 0 && stamp_crc)
+        prof[((size_t)fidx * WAVES + wave) * 8u + 7] = wall_now();
+
+      /* ---- next block */
+      cell0 = cell0_next;
+      pos = pos_next;
+      kinds = kinds_n;
 #pragma unroll
       for (int k = 0; k < CPL; k++)
-        if (len[k] != 0u) {
-#if defined(ACHIP_STREAM_ABLATE) && ACHIP_STREAM_ABLATE == 3 /* diagnostics: no token stores either */
-          asm volatile("" ::"v"(tok[k].flags), "v"(tok[k].fg), "v"(tok[k].glyph), "v"(off[k]));
-#else
-          WordSink<L::o_dec, L::o_flags + 16, L::WORDS ? L::o_wr : -1, L::WORDS ? L::o_wg : -1, L::WORDS ? L::o_wm : -1> fs{{stage_addr + (base + off[k] - g0), dummy_addr}};
-          token_fields<MODE>(fs, tok[k], ascii_only);
-#endif
-        }
-      lds_store_fence(); /* DS operations of one wave complete in order: the reads below see every lane's bytes */
-      if (!CRC)
-        ACHIP_SSTAMP(6);
-
-      /* ---- staging -> HBM: whole 16-byte groups as uint4, the shared first / last group as bytes (PACK: the frame
-       * leaves LDS as a whole, behind the loop) */
-      const unsigned char *stage = lds_ptr<const unsigned char>((int)stage_off);
-      const uint32_t end = base + total;
-      const uint32_t vec_begin = PACK ? end : (base + 15u) & ~15u, vec_end = end & ~15u;
-      /* every store instruction of the wave covers whole 128-byte lines (lane l takes the group 16 l bytes behind a LINE
-       * boundary of the ADDRESS, not behind vec_begin): a 1 KB wave store that straddles lines leaves two of them half written, and
-       * the memory side takes such writes at 4.4 instead of 5.7 TB/s (profiles/r04_rows_floor.txt) */
-      for (uint32_t q = ((vec_begin + dmis) & ~(ACHIP_DRAIN_ALIGN - 1u)) + 16u * (uint32_t)lane; q < vec_end + dmis; q += 1024u) {
-        if (q < vec_begin + dmis)
-          continue;
-        const uint32_t o = q - dmis;
-#if defined(ACHIP_STREAM_ABLATE) && (ACHIP_STREAM_ABLATE == 1 || ACHIP_STREAM_ABLATE == 3) /* diagnostics: no HBM writes */
-        const uint4 v = *reinterpret_cast<const uint4 *>(stage + (o - g0));
-        asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
-#else
-        store_out16(dst + o, *reinterpret_cast<const uint4 *>(stage + (o - g0)));
-#endif
-      }
-      if (!PACK) {
-        const uint32_t head_end = min(vec_begin, end);
-        if (base + (uint32_t)lane < head_end)
-          dst[base + (uint32_t)lane] = stage[base + (uint32_t)lane - g0];
-        const uint32_t tail_begin = max(vec_end, head_end);
-        if (lane >= 32 && tail_begin + (uint32_t)(lane - 32) < end)
-          dst[tail_begin + (uint32_t)(lane - 32)] = stage[tail_begin + (uint32_t)(lane - 32) - g0];
-      }
-      if (L::WORDS) { /* the next block's SGRs are OR-ed into zeros (a wave's DS operations complete in order) */
-        wave_lockstep();
-        for (uint32_t g = (uint32_t)lane; g < ((base & 15u) + total + 15u) >> 4; g += 64u)
-          lds_ptr<uint4>((int)stage_off)[g] = make_uint4(0u, 0u, 0u, 0u);
-        wave_lockstep();
-      }
+        raw[k] = raw_n[k];
     }
-    ACHIP_SSTAMP(CRC ? 6 : 7); /* CRC instantiations: 6 = stores issued, 7 = block checksummed and placed */
-    const bool stamp_crc = first_block;
-    first_block = false;
-    if (blk == nblk - 1 && lane == 0) {
-      out_len[fidx] = ok ? base + total : ACHIP_LEN_OVERFLOW;
-      if (!PACK && ok && (uint64_t)base + total < out_stride)
-        dst[base + total] = 0; /* NUL behind the frame when the slot has room, as the reference's strings carry */
-    }
-    if (CRC) {
-      /* ---- raw CRC of the block, from the staging area (after the stores to HBM have been issued), placed in the
-       * frame; the last block to finish completes the frame (stream_crc_* above) */
-      if (ok) {
-        const uint32_t braw = stream_crc_staged<L>(lds_ptr<const unsigned char>((int)stage_off), (base & 15u) + total, lane);
-        stream_crc_place<L>(slots, nblk, nblk_cap, blk, braw, base + total, cap_bytes, lane);  /* (CRC: never PARTS, lb == blk) */
-      }
-      stream_crc_finish<L>(slots, nblk, nblk_cap, cap_bytes, first_base, fidx, dim_w, dim_h, wire, lane);
-    }
-
-    if (CRC && prof && lane == 0 && stamp_crc)
-      prof[((size_t)fidx * WAVES + wave) * 8u + 7] = wall_now();
-
-    /* ---- next block */
-    cell0 = cell0_next;
-    pos = pos_next;
-    kinds = kinds_n;
-#pragma unroll
-    for (int k = 0; k < CPL; k++)
-      raw[k] = raw_n[k];
   }
   if (PACK) {
     /* ---- the frame is complete in LDS: claim its place, copy it out.  (Every wave gets here exactly once, those without

@@ -124,6 +124,8 @@ def main():
             if crc or pack:  # the checksum's 16-byte groups are in flight next to the following block's samples; the
                              # exact-length form stages a whole frame in LDS: one 16-wave workgroup per CU either way
                 limit, why = 128, "4 waves per SIMD: one 16-wave or two 8-wave workgroups per CU (LDS allows no more)"
+            elif ms.group(7) == "1":  # shared-out frames are small launches: a few four-wave workgroups per CU, all resident
+                limit, why = 72, "7 waves per SIMD (small launches: every workgroup is resident anyway)"
             else:
                 limit, why = (72, "7 waves per SIMD") if mode == 4 else (64, "8 waves per SIMD")
         else:

@@ -24,11 +24,13 @@ def build():
     if os.path.exists(EMU_SO) and all(os.path.getmtime(s) <= os.path.getmtime(EMU_SO) for s in srcs):
         return EMU_SO
     os.makedirs(os.path.dirname(EMU_SO), exist_ok=True)
-    obj = os.path.join(os.path.dirname(EMU_SO), "achip_host.o")
+    obj = os.path.join(os.path.dirname(EMU_SO), "achip_host.%d.o" % os.getpid())
+    tmp = EMU_SO + ".%d.tmp" % os.getpid()
     subprocess.check_call(["gcc", "-std=gnu11", "-O2", "-fPIC", "-I" + INC, "-c", os.path.join(CSRC, "achip_host.c"), "-o", obj])
     extra = os.environ.get("ACHIP_EMU_DEFS", "").split()  # e.g. -DACHIP_EMIT_OR_MODES=0x3FF to test an experiment
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-shared", "-fPIC", "-DACHIP_ALL_GEOMETRIES", *extra, "-I" + EMU_DIR, "-I" + CSRC, "-I" + INC,  # EMU_DIR first: <gfx950_ops.hpp> = the emulator's twin
-                           os.path.join(EMU_DIR, "emu_driver.cpp"), obj, "-o", EMU_SO])
+                           os.path.join(EMU_DIR, "emu_driver.cpp"), obj, "-o", tmp])
+    os.replace(tmp, EMU_SO)  # atomic: a concurrent test process (pytest -n) never loads a half-written library
     return EMU_SO
 
 

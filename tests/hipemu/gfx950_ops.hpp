@@ -22,6 +22,20 @@ template <int OFF, bool HI> inline void ds_store_byte(uint32_t addr, uint32_t v)
 inline void ds_or_u32(uint32_t addr, uint32_t v) { *reinterpret_cast<uint32_t *>(ACHIP_SMEM + addr) |= v; }
 template <int OFF> inline void ds_or_u32_at(uint32_t addr, uint32_t v) { *reinterpret_cast<uint32_t *>(ACHIP_SMEM + addr + OFF) |= v; }
 inline uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> (sh & 31u)); }
+inline uint32_t dot4_u8(uint32_t a, uint32_t b, uint32_t c) {
+  return (a & 0xFFu) * (b & 0xFFu) + ((a >> 8) & 0xFFu) * ((b >> 8) & 0xFFu) + ((a >> 16) & 0xFFu) * ((b >> 16) & 0xFFu) +
+         (a >> 24) * (b >> 24) + c;
+}
+inline uint32_t bfe_u32(uint32_t v, uint32_t off, uint32_t width) { /* v_bfe_u32: offset and width modulo 32 */
+  off &= 31u;
+  width &= 31u;
+  return width ? (v >> off) & ((1u << width) - 1u) : 0u;
+}
+inline int32_t mad_i24(int32_t a, int32_t b, int32_t c) { /* operands sign-extended from 24 bits, low 32 bits of the product */
+  const int64_t sa = ((int32_t)((uint32_t)a << 8)) >> 8, sb = ((int32_t)((uint32_t)b << 8)) >> 8;
+  return (int32_t)((uint32_t)(sa * sb) + (uint32_t)c);
+}
+inline uint32_t mul_u24(uint32_t a, uint32_t b) { return (uint32_t)((uint64_t)(a & 0xFFFFFFu) * (uint64_t)(b & 0xFFFFFFu)); }
 inline void keep_alive(uint32_t, uint32_t) {}
 inline uint32_t lds_base_addr() { return 0u; }
 /* a wave's lanes run in lockstep on the GPU: every lane's stores precede the reads behind the fence */

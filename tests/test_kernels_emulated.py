@@ -281,6 +281,48 @@ def test_stream_kernel_ragged_batch_flips_tint_and_overflow():
     assert got[0] == 0xFFFFFFFF
 
 
+@pytest.mark.parametrize("variant", [20, 16, 17, 19])
+def test_stream_kernel_lean_loop_orders_and_samplers(variant):
+    """The lean loop of the truecolor-foreground instantiations (render_stream.hpp, round 6) has two cell orders -- lane-major
+    for sources whose samples share cache lines, slot-major for samples a line apart or more (the non-temporal copy) -- and
+    two samplers -- ratio 1.0 (a sampled image: no multiplications) and the split 16.16 multiply.  Every combination, with
+    flips, the colour filter, the rainbow override, padding, runs of equal pixels (no SGR), and frames whose last block is
+    nearly empty, against the oracle."""
+    import ctypes as C
+    rng = np.random.default_rng(7)
+    wide = orc.frame_hash_noise(1920, 54, 11)                    # 1920 -> 80 columns: samples 72 bytes apart (slot-major)
+    wide[:, 700:1300] = wide[20, 700]                            # a flat band: cells without an SGR
+    dense = orc.frame_hash_noise(97, 31, 5)                      # rendered at its own size: ratio 1.0
+    dense[7:9, :] = (9, 200, 31)
+    dense[8, 40:] = (255, 255, 255)
+    cases = [(wide, 80, 24), (wide, 61, 17), (wide, 3, 2), (dense, 97, 31), (orc.frame_hash_noise(80, 24, 3), 80, 24),
+             (TORTURE, 200, 60), (orc.frame_hash_noise(4000, 8, 2), 130, 8)]
+    for img, W, H in cases:
+        f = emu.frame_for_convert(img, W, H, 0)
+        exp = oracle_convert(img, MODE_TRUE_FG, W, H, orc.PALETTE_STANDARD)
+        assert emu.render_frames(MODE_TRUE_FG, [f], orc.PALETTE_STANDARD, variant)[0] == exp, (W, H, variant)
+        assert emu.render_frames(MODE_TRUE_FG, [f, f], orc.PALETTE_STANDARD, variant, uniform=True)[1] == exp, (W, H, variant, "uniform")
+    for img, W, H in [(wide, 80, 24), (dense, 97, 31)]:  # aspect + padding
+        exp = oracle_convert(img, MODE_TRUE_FG, W, H, orc.PALETTE_STANDARD, True, True)
+        assert emu_convert(img, MODE_TRUE_FG, W, H, orc.PALETTE_STANDARD, variant, True, True) == exp, (W, H, variant, "padded")
+    for img, W, H in [(wide, 80, 24), (dense, 97, 31)]:  # display ops folded into the sampler / the emission
+        for fx, fy, flt in [(True, False, 0), (False, True, 3), (True, True, 7)]:
+            f = emu.frame_for_convert(img, W, H, 0)
+            assert emu.lib().achip_frame_set_display_ops(C.byref(f), fx, fy, flt) == 0
+            exp = orc.display_convert(img, W, H, 3, 0, False, False, fx, fy, flt)
+            assert emu.render_frames(MODE_TRUE_FG, [f], orc.PALETTE_STANDARD, variant)[0] == exp, (W, H, variant, fx, fy, flt)
+        f = emu.frame_for_convert(img, W, H, 0)  # the rainbow override: every SGR carries the colour of the moment
+        assert emu.lib().achip_frame_set_display_ops(C.byref(f), False, True, 0) == 0
+        assert emu.lib().achip_frame_set_rainbow(C.byref(f), 2.05) == 0
+        plain = oracle_convert(np.ascontiguousarray(img[::-1]), MODE_TRUE_FG, W, H, orc.PALETTE_STANDARD)
+        assert emu.render_frames(MODE_TRUE_FG, [f], orc.PALETTE_STANDARD, variant)[0] == orc.rainbow_replace(plain, 2.05), (W, H, variant)
+    if variant in (20, 17):  # ... and shared out over workgroups (the ghost of a part's first block is another part's cell)
+        for img, W, H, parts in [(wide, 80, 24, 4), (dense, 97, 31, 7), (wide, 61, 17, 16)]:
+            exp = oracle_convert(img, MODE_TRUE_FG, W, H, orc.PALETTE_STANDARD)
+            assert emu_convert_parts(img, MODE_TRUE_FG, W, H, orc.PALETTE_STANDARD, variant if variant == 20 else 18, parts) == exp, (W, H, parts)
+    del rng
+
+
 @pytest.mark.parametrize("mode", STREAM_MODES, ids=["true_fg", "256_fg", "16_fg", "true_bg"])
 def test_stream_kernel_frames_shared_out_over_workgroups(mode):
     """PARTS instantiations (render_stream.hpp): a frame's blocks shared out over several workgroups that hand their
