@@ -583,22 +583,6 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
    * (render_stream.hpp), whose waves gather, tokenise and drain independently -- no chunk, so no row-width limit,
    * only a bound on the cells of a frame.  ACHIP_STREAM_* below restate render_variants.h / render_stream.hpp. */
   const long max_cells = achip_max_cells(frames, n_frames);
-  const bool cell_mode = mode == ACHIP_MODE_256_FG || mode == ACHIP_MODE_16_FG || mode == ACHIP_MODE_TRUE_BG ||
-                         (mode == ACHIP_MODE_TRUE_FG && palette_ascii_only);
-  const bool stream_forced = forced_variant >= ACHIP_HOST_STREAM_FIRST && forced_variant < ACHIP_HOST_ROWS_FIRST;
-  /* cells a block owns: 64 per lane slot, minus the ghost slot of truecolor-fg (render_stream.hpp: SLds::EFF) */
-  const int ghost = mode == ACHIP_MODE_TRUE_FG ? 1 : 0;
-  if (stream_forced) {
-    const int cpl = forced_variant == 19 || forced_variant == 20 ? 1 : 2;
-    if (!cell_mode || forced_variant > 20 || max_cells > (long)ACHIP_HOST_STREAM_MAXBLK * (64 * cpl - ghost))
-      return -1;
-    *variant = forced_variant;
-    return 0; /* whole frames only */
-  }
-  /* The run-structured renderers (mono, half blocks) start a run at every row's first cell, so a whole number of text
-   * rows is a self-contained block that ONE wave can take through the path (render_rows.hpp): whole-frame launches of
-   * them take that kernel whenever the widest padded row fits a block (64 * CPL cells). */
-  /* (... and whose sources are at most 21 845 pixels wide: render_rows.hpp keeps a sample's byte offset in 16 bits) */
   int max_src_w = 0;
   bool general_sampler = false, dense = true; /* composites / 1x1 sources; every source IS the image its target samples */
   for (int i = 0; i < n_frames; i++) {
@@ -607,6 +591,28 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
     general_sampler |= frames[i].comp != NULL || (long)frames[i].src_w * (long)frames[i].src_h == 1;
     dense &= !frames[i].comp && frames[i].src_w == frames[i].out_w && frames[i].src_h == frames[i].out_h;
   }
+  /* truecolor foreground with a palette that holds multi-byte glyphs (round 6: the stream kernel's instantiation of its own,
+   * render_stream.hpp ACHIP_STREAM_MODE_TRUE_FG_U8): whole frames of single sources in geometries 16 / 17, never shared out
+   * over workgroups (its RLE state crosses blocks through LDS words); composites and 1x1 sources stay with the phase kernel */
+  const bool u8_true = mode == ACHIP_MODE_TRUE_FG && !palette_ascii_only;
+  const bool cell_mode = mode == ACHIP_MODE_256_FG || mode == ACHIP_MODE_16_FG || mode == ACHIP_MODE_TRUE_BG ||
+                         (mode == ACHIP_MODE_TRUE_FG && (palette_ascii_only || !general_sampler));
+  const bool stream_forced = forced_variant >= ACHIP_HOST_STREAM_FIRST && forced_variant < ACHIP_HOST_ROWS_FIRST;
+  /* cells a block owns: 64 per lane slot, minus the ghost slot of truecolor-fg (render_stream.hpp: SLds::EFF) */
+  const int ghost = mode == ACHIP_MODE_TRUE_FG ? 1 : 0;
+  if (stream_forced) {
+    const int cpl = forced_variant == 19 || forced_variant == 20 ? 1 : 2;
+    if (!cell_mode || forced_variant > 20 || max_cells > (long)ACHIP_HOST_STREAM_MAXBLK * (64 * cpl - ghost))
+      return -1;
+    if (u8_true && forced_variant != 16 && forced_variant != 17 && forced_variant != 20)
+      return -1;
+    *variant = forced_variant;
+    return 0; /* whole frames only */
+  }
+  /* The run-structured renderers (mono, half blocks) start a run at every row's first cell, so a whole number of text
+   * rows is a self-contained block that ONE wave can take through the path (render_rows.hpp): whole-frame launches of
+   * them take that kernel whenever the widest padded row fits a block (64 * CPL cells). */
+  /* (... and whose sources are at most 21 845 pixels wide: render_rows.hpp keeps a sample's byte offset in 16 bits) */
   const bool run_mode = (mode == ACHIP_MODE_MONO || hb) && max_src_w <= 21845;
   if (forced_variant >= ACHIP_HOST_ROWS_FIRST) {
     const int cpl = rows_variant_cpl(forced_variant);
@@ -634,7 +640,7 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
    * allow), as long as every workgroup of the launch has a CU to itself (they hand their byte counts to each other
    * through memory, so all of them must be resident): one workgroup per frame queues all of the frame's waves on the
    * four SIMDs of ONE CU (profiles/r04_lone_frame_timeline.txt). */
-  if (forced_variant < 0 && cell_mode && split_request == 0 && max_cells <= (long)ACHIP_HOST_STREAM_MAXBLK * (128 - ghost)) {
+  if (forced_variant < 0 && cell_mode && !u8_true && split_request == 0 && max_cells <= (long)ACHIP_HOST_STREAM_MAXBLK * (128 - ghost)) {
     const long nblk = (max_cells + (128 - ghost) - 1) / (128 - ghost);
     /* four blocks per workgroup (a wave each), but up to sixteen workgroups for a small frame (a lone 80x24 frame: 5.8 us
      * in 16 parts of one block, 5.9 in four; more than that loses again: 4K -> 200x60 in 64 parts 7.2 us against 6.9 in 24,

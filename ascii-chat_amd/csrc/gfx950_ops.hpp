@@ -104,6 +104,8 @@ __device__ inline uint64_t wave_ballot(bool p) { return __ballot(p); }
  * by the lane number, no vector instruction at all) */
 __device__ inline bool lane_bit(uint64_t wave_uniform_mask) { return __builtin_amdgcn_inverse_ballot_w64(wave_uniform_mask); }
 __device__ inline uint32_t wave_shfl_up(uint32_t v, int d) { return __shfl_up(v, d, 64); }
+/* lane `src`'s value (a per-lane index: ds_bpermute_b32, an LDS crossbar round trip) */
+__device__ inline uint32_t wave_shfl(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, 64); }
 __device__ inline uint32_t wave_read_lane(uint32_t v, int lane) {
   return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
 }

@@ -715,6 +715,8 @@ int asciichat_hip_plan_render_crc_profiled(asciichat_hip_plan_t *p, uint8_t *out
 int asciichat_hip_plan_has_fused_crc(const asciichat_hip_plan_t *p) {
   if (!p || !plan_frames_whole(p) || p->fused_crc == 0 || !achip_variant_has_crc(p->whole_variant))
     return 0;
+  if (p->mode == ACHIP_MODE_TRUE_FG && !p->palette_ascii) /* (the multi-byte-palette instantiation carries no checksum) */
+    return 0;
   if (p->fused_crc > 0)
     return 1;
   /* a plan whose plain render shares its frames out over workgroups (a small launch) would have to launch them WHOLE for the

@@ -40,12 +40,19 @@
 
 namespace achip {
 
+/* The truecolor-foreground renderer with a palette that holds multi-byte glyphs (three of the reference's five built-in
+ * palettes: BLOCKS, DIGITAL, COOL -- palette.h:161-197) is an instantiation of its own (the all-ASCII one keeps its registers):
+ * this tag in the MODE parameter of SLds / render_stream_kernel.  foreground.c:281-296: such a cell always carries its SGR
+ * and leaves the RLE state alone, so an ASCII cell is compared with the nearest EARLIER ASCII cell of the frame. */
+#define ACHIP_STREAM_MODE_TRUE_FG_U8 (16 + ACHIP_MODE_TRUE_FG)
+__host__ __device__ constexpr bool mode_is_true_fg(int m) { return m == ACHIP_MODE_TRUE_FG || m == ACHIP_STREAM_MODE_TRUE_FG_U8; }
 __host__ __device__ constexpr bool mode_is_cell(int m) {
-  return m == ACHIP_MODE_TRUE_FG || m == ACHIP_MODE_256_FG || m == ACHIP_MODE_16_FG || m == ACHIP_MODE_TRUE_BG;
+  return mode_is_true_fg(m) || m == ACHIP_MODE_256_FG || m == ACHIP_MODE_16_FG || m == ACHIP_MODE_TRUE_BG;
 }
 /* longest token of a mode, bytes (SURVEY 8a "per-token byte lengths"): SGR(s) + glyph + row reset + newline */
 __host__ __device__ constexpr int stream_max_token(int m) {
   return m == ACHIP_MODE_TRUE_FG ? 24    /* 19 + 1-byte glyph (all-ASCII palettes only) + max(NL, final reset 4) */
+         : m == ACHIP_STREAM_MODE_TRUE_FG_U8 ? 28 /* 19 + glyph <= 4 + max(NL, final reset 4), rounded up */
          : m == ACHIP_MODE_256_FG ? 20   /* 11 + glyph <= 4 + reset 4 + NL                                      */
          : m == ACHIP_MODE_16_FG ? 16    /* 5 + 4 + 4 + 1 (rounded up)                                           */
                                  : 48;   /* background: 19 + 19 + 4 + 4 + 1 (rounded up)                         */
@@ -75,7 +82,9 @@ template <int MODE, int WAVES, int CPL, bool CRC = false, int PACK = 0> struct S
   /* cells a block OWNS.  Truecolor-fg decides its SGR against the raster predecessor (ansi_rle_add_pixel): slot
    * (k = 0, lane 0) of every block is a ghost that samples the cell in front of the block and owns no token, so that
    * every cell finds its predecessor one lane down (one DPP move) and no cell needs a second sampler pass. */
-  static constexpr int EFF = BLK - (MODE == ACHIP_MODE_TRUE_FG ? 1 : 0);
+  static constexpr bool U8 = MODE == ACHIP_STREAM_MODE_TRUE_FG_U8;
+  static_assert(!U8 || (!CRC && !PACK), "multi-byte palettes: the plain instantiation only");
+  static constexpr int EFF = BLK - (mode_is_true_fg(MODE) ? 1 : 0);
   static constexpr int STAGE = BLK * stream_max_token(MODE) + 16; /* + the 16-byte group the block starts in */
   static constexpr int GPL = (STAGE / 16 + 63) / 64; /* 16-byte groups of a block per lane when it is checksummed */
   static constexpr int o_stage = 16; /* (a word-built SGR at the area's first byte ORs a zero into the dword in front of it) */
@@ -89,11 +98,11 @@ template <int MODE, int WAVES, int CPL, bool CRC = false, int PACK = 0> struct S
    * staging areas start out zero and are cleared behind every drain.  (Not the instantiations that checksum the staged
    * bytes or keep the whole frame in LDS: their staging is read again, or shared by the waves; nor truecolor backgrounds:
    * one register more than the shared-out form's seven waves per SIMD leave; nor the 256-colour SGRs: level, WordSink.) */
-  static constexpr bool WORDS = !CRC && !PACK && (ACHIP_STREAM_WORD_EMIT != 0) && MODE == ACHIP_MODE_TRUE_FG;
+  static constexpr bool WORDS = !CRC && !PACK && (ACHIP_STREAM_WORD_EMIT != 0 || U8) && mode_is_true_fg(MODE);
   static constexpr int o_wr = o_dec + 256 * 4;
   static constexpr int o_wg = o_wr + (WORDS ? 256 * 8 : 0);
   static constexpr int o_wm = o_wg + (WORDS ? 256 * 8 : 0);
-  static constexpr int o_g8 = o_wm + (WORDS ? 256 * 8 : 0);    /* the lean loop's glyphs as bytes (all-ASCII palettes) */
+  static constexpr int o_g8 = o_wm + (WORDS ? 256 * 8 : 0);    /* the lean loop's glyphs as bytes (all-ASCII palettes; U8: length | ASCII << 7) */
   static constexpr int o_flags = o_g8 + (WORDS ? 256 : 0);     /* [+16 ..] swallows predicated-off byte stores */
   /* CRC instantiations: constant tables, copied from global memory where crc_tables_init_kernel put them -- the 16
    * slicing tables; window tables of the lanes' multipliers; x^(8v), x^(8*256v), x^(8*65536v); x^k (k = 0..62) -- then
@@ -113,7 +122,8 @@ template <int MODE, int WAVES, int CPL, bool CRC = false, int PACK = 0> struct S
   /* per-block words, as many as the launch's largest frame has blocks: look-back words {state:2, bytes:30}, and
    * (CRC) behind them the raw CRC of a block that could not be placed yet */
   static constexpr int o_slots = o_crcacc + (CRC ? 16 : 0);
-  static constexpr int bytes_for(int maxblk) { return o_slots + maxblk * 4 * (CRC ? 2 : 1); }
+  /* (U8: behind them the blocks' {state:2, has:1, rgb:24} words of the second look-back, the RLE state) */
+  static constexpr int bytes_for(int maxblk) { return o_slots + maxblk * 4 * (CRC || U8 ? 2 : 1); }
   /* PACK: where the frame's image starts, and the LDS of a launch whose frames are at most `bound` bytes */
   static constexpr int frame_off(int maxblk) { return (bytes_for(maxblk) + 15) & ~15; }
   static constexpr int bytes_for_pack(int maxblk, int bound) { return frame_off(maxblk) + ((bound + 15) & ~15) + 64; }
@@ -156,6 +166,51 @@ __device__ inline uint32_t stream_lookback(const uint32_t *slots, int blk, int l
       }
     } else if (am == ~0ull) { /* 64 own counts and no prefix yet: take them and look further back */
       acc += wave_read_lane(wave_inclusive_scan(v & ACHIP_SLOT_VALUE), 63);
+      hi -= 64;
+      continue;
+    }
+    spin++;
+    spin_nap<1>();
+  }
+  return 0xFFFFFFFFu;
+}
+
+/* ---- the RLE state of truecolor foreground with multi-byte palettes (ACHIP_STREAM_MODE_TRUE_FG_U8) -------------------- */
+/* For every lane: the value of the nearest LOWER lane whose flag is set (found = there is one).  lt_lo / lt_hi = the lane's
+ * "lanes below me" masks. */
+struct NearestLower {
+  bool found;
+  uint32_t val;
+};
+__device__ inline NearestLower nearest_lower(bool flag, uint32_t val, uint32_t lt_lo, uint32_t lt_hi) {
+  const uint64_t m = wave_ballot(flag);
+  const uint32_t a = (uint32_t)m & lt_lo, b = (uint32_t)(m >> 32) & lt_hi;
+  const int src = b ? 63 - __clz((int)b) : 31 - __clz((int)a); /* a == b == 0: lane -1, not taken */
+  return NearestLower{(a | b) != 0u, wave_shfl(val, src < 0 ? 0 : src)};
+}
+/* the flagged lane with the highest number: its value, wave-uniform (m = the ballot of the flags, not zero) */
+__device__ inline uint32_t highest_flagged(uint64_t m, uint32_t val) {
+  const uint32_t hi = (uint32_t)(m >> 32);
+  return wave_read_lane(val, hi ? 63 - __clz((int)hi) : 31 - __clz((int)(uint32_t)m));
+}
+/* One word per block {state:2, has:1 (bit 24), rgb:24}: state 1 = the block's own last ASCII cell (has = it holds one),
+ * 2 = the frame's last ASCII cell up to and including the block.  Returns the state in front of block `lb` (lb >= 1) as
+ * {has, rgb}: the nearest predecessor that decides -- an inclusive word, or an own word that holds a cell -- with every
+ * block between published (own words without a cell are skipped); 0xFFFFFFFF if a predecessor never publishes. */
+#define ACHIP_RLE_HAS (1u << 24)
+__device__ inline uint32_t stream_lookback_rle(const uint32_t *words, int lb, int lane) {
+  int hi = lb - 1;
+  for (int spin = 0; spin < (1 << 22);) {
+    const int j = hi - lane;
+    const uint32_t v = j >= 0 ? slot_load(&words[j]) : ACHIP_SLOT_PREFIX; /* in front of the frame: no cell yet */
+    const uint32_t st = v >> 30;
+    const uint64_t dm = wave_ballot(st == 2u || (st == 1u && (v & ACHIP_RLE_HAS) != 0u)), pm = wave_ballot(st != 0u);
+    if (dm != 0ull) {
+      const int P = __ffsll((unsigned long long)dm) - 1;
+      const uint64_t need = P ? ((1ull << P) - 1ull) : 0ull;
+      if ((pm & need) == need)
+        return wave_read_lane(v, P) & (ACHIP_RLE_HAS | 0x00FFFFFFu);
+    } else if (pm == ~0ull) { /* 64 blocks without an ASCII cell: further back */
       hi -= 64;
       continue;
     }
@@ -450,6 +505,9 @@ __global__ void __launch_bounds__(WAVES * 64)
   } while (0)
   static_assert(mode_is_cell(MODE), "run-structured modes use render_frames_kernel");
   using L = SLds<MODE, WAVES, CPL, CRC, PACK>;
+  constexpr bool U8 = L::U8;                               /* truecolor foreground, palette with multi-byte glyphs */
+  constexpr int RMODE = U8 ? ACHIP_MODE_TRUE_FG : MODE;    /* the renderer (token grammar) */
+  static_assert(!U8 || (!GENERIC && !PARTS), "multi-byte palettes: whole frames of single sources (the host sends the rest to render_frames_kernel)");
   static_assert(!PACK || (!GENERIC && !CRC && MODE != ACHIP_MODE_TRUE_BG), "exact-length frames: single-source per-cell foreground modes");
   static_assert(!PARTS || (!CRC && !PACK), "a frame's checksum and its LDS image belong to one workgroup");
   constexpr bool WIRE = CRC || PACK == 2; /* the launch leaves checksums (and headers) */
@@ -528,7 +586,7 @@ __global__ void __launch_bounds__(WAVES * 64)
 #pragma unroll
   for (int k = 0; k < LUTN; k++)
     lut_g[k] = tid + k * BLOCK < 256 ? lut->glyph[tid + k * BLOCK] : 0u;
-  const uint32_t lut_ramp = (MODE == ACHIP_MODE_16_FG && tid < 64) ? lut->ramp[tid] : 0u;
+  const uint32_t lut_ramp = (RMODE == ACHIP_MODE_16_FG && tid < 64) ? lut->ramp[tid] : 0u;
   /* whether every glyph of the palette is one ASCII byte travels with the launch (the host knows the palette);
    * reading achip_lut_t.flags here would be one more dependent round trip */
   const bool ascii_only = (uni.flags & ACHIP_UNIFORM_PALETTE_ASCII) != 0u;
@@ -725,7 +783,7 @@ __global__ void __launch_bounds__(WAVES * 64)
   }
   ACHIP_SSTAMP(2);
 
-  if (MODE == ACHIP_MODE_TRUE_FG && !ascii_only) { /* the host sends such plans to render_frames_kernel */
+  if (RMODE == ACHIP_MODE_TRUE_FG && ascii_only == U8) { /* (the launchers pick the instantiation by the palette) */
     if (tid == 0) {
       out_len[fidx] = ACHIP_LEN_BADDESC;
       if (PACK)
@@ -747,13 +805,19 @@ __global__ void __launch_bounds__(WAVES * 64)
         lds_ptr<uint2>(L::o_wr)[tid + k * BLOCK] = wr;
         lds_ptr<uint2>(L::o_wg)[tid + k * BLOCK] = wg;
         lds_ptr<uint2>(L::o_wm)[tid + k * BLOCK] = wm;
-        lds_ptr<uint8_t>(L::o_g8)[tid + k * BLOCK] = (uint8_t)lut_g[k];
+        { /* U8: the glyph's length, bit 7 = "single ASCII byte" (foreground.c:282) */
+          const uint32_t gn = glyph_len(lut_g[k]);
+          lds_ptr<uint8_t>(L::o_g8)[tid + k * BLOCK] = U8 ? (uint8_t)(gn | (gn == 1u && (lut_g[k] & 0xFFu) < 128u ? 0x80u : 0u)) : (uint8_t)lut_g[k];
+        }
       }
     }
-  if (MODE == ACHIP_MODE_16_FG && tid < 64)
+  if (RMODE == ACHIP_MODE_16_FG && tid < 64)
     ramp[tid] = (uint8_t)lut_ramp;
   for (int k = tid; k < b1 - b0; k += BLOCK) /* (indexed from the workgroup's first block) */
     slots[k] = 0u;
+  if (U8)
+    for (int k = tid; k < b1 - b0; k += BLOCK)
+      slots[nblk_cap + k] = 0u; /* the RLE-state words */
   if (PARTS && tid < 2)
     partacc[tid] = 0u;
   (void)ramp;
@@ -910,7 +974,9 @@ __global__ void __launch_bounds__(WAVES * 64)
          * share one set of table reads */
         SgrBody body[CPL];
         uint32_t len[CPL], sl[CPL], gl[CPL];
+        uint32_t gn[CPL]; /* U8: bytes of the glyph in gl[] */
         bool has_nl[CPL], is_fin[CPL];
+        if constexpr (!U8)
         {
           CellPos p = pos;
           uint32_t prev = KM ? 0u : wave_shift_up1(px[CPL - 1], 0u);
@@ -939,6 +1005,97 @@ __global__ void __launch_bounds__(WAVES * 64)
             len[j] = sl[j] + (valid ? 1u : 0u) + (row_end ? 1u : 0u) + (fin ? 3u : 0u);
             prev = px[j];
             p = KM ? advance(p, q64, r64) : step1(p);
+          }
+        }
+        else {
+          /* ---- multi-byte palettes (foreground.c:281-296).  A cell whose glyph is not a single ASCII byte always carries
+           * its SGR and leaves the RLE state alone; an ASCII cell carries one iff the frame holds no ASCII cell in front of
+           * it or the nearest one has another colour.  Inside a block that cell is found with ballots (nearest_lower); in
+           * front of it, it is the second look-back's word -- the chain depends on pixels only, never on byte counts, so
+           * every block publishes its own word right behind its samples. */
+          bool valid[CPL], pix[CPL], asc[CPL], rend[CPL];
+          {
+            CellPos p = pos;
+#pragma unroll
+            for (int j = 0; j < CPL; j++) {
+              const uint32_t c = c0 + (uint32_t)(KM ? 64 * j : j);
+              valid[j] = c < ncells && !(j == 0 && lane == 0); /* (the ghost slot is kept: same blocks as the ASCII form) */
+              pix[j] = valid[j] && p.xp >= pad_left;
+              rend[j] = valid[j] && p.xp == uwp - 1u;
+              is_fin[j] = valid[j] && c == ncells - 1u;
+              has_nl[j] = rend[j] && !is_fin[j];
+              const uint32_t Y = dot4_u8(px[j], 0x001D964Du, 128u) >> 8;
+              const uint32_t info = lds_ptr<const uint8_t>(L::o_g8)[Y];
+              const uint32_t gw = glyph[Y];
+              asc[j] = pix[j] && (info & 0x80u) != 0u;
+              gl[j] = pix[j] ? gw : (uint32_t)' ';
+              gn[j] = pix[j] ? info & 7u : 1u;
+              p = KM ? advance(p, q64, r64) : step1(p);
+            }
+          }
+          const uint32_t lt_lo = lane < 32 ? (1u << lane) - 1u : 0xFFFFFFFFu, lt_hi = lane < 32 ? 0u : (1u << (lane - 32)) - 1u;
+          /* the nearest earlier ASCII cell INSIDE the block, per slot: {found, rgb}; and the block's own last one */
+          bool ph[CPL];
+          uint32_t pv[CPL];
+          bool blk_has = false;
+          uint32_t blk_last = 0;
+          if (KM) {
+#pragma unroll
+            for (int j = 0; j < CPL; j++) { /* cell order = slot after slot */
+              const NearestLower nl = nearest_lower(asc[j], px[j], lt_lo, lt_hi);
+              ph[j] = nl.found || blk_has;
+              pv[j] = nl.found ? nl.val : blk_last;
+              const uint64_t m = wave_ballot(asc[j]);
+              if (m != 0ull) {
+                blk_has = true;
+                blk_last = highest_flagged(m, px[j]);
+              }
+            }
+          } else {
+            bool have = false; /* cell order = lane after lane: first the lane's own earlier slots ... */
+            uint32_t last = 0;
+#pragma unroll
+            for (int j = 0; j < CPL; j++) {
+              ph[j] = have;
+              pv[j] = last;
+              have = have || asc[j];
+              last = asc[j] ? px[j] : last;
+            }
+            const NearestLower nl = nearest_lower(have, last, lt_lo, lt_hi); /* ... then the lanes below */
+#pragma unroll
+            for (int j = 0; j < CPL; j++) {
+              pv[j] = ph[j] ? pv[j] : nl.val;
+              ph[j] = ph[j] || nl.found;
+            }
+            const uint64_t m = wave_ballot(have);
+            if (m != 0ull) {
+              blk_has = true;
+              blk_last = highest_flagged(m, last);
+            }
+          }
+          /* the state in front of the block */
+          uint32_t *rle = slots + nblk_cap;
+          const int lbk = blk - b0;
+          uint32_t in = 0u; /* {has, rgb} */
+          if (lbk > 0) {
+            if (lane == 0)
+              slot_store(&rle[lbk], ACHIP_SLOT_AGG | (blk_has ? ACHIP_RLE_HAS | blk_last : 0u));
+            in = stream_lookback_rle(rle, lbk, lane);
+          }
+          const bool rle_lost = in == 0xFFFFFFFFu; /* (bounded polling ran out: the frame is reported as not fitting) */
+          if (lane == 0)
+            slot_store(&rle[lbk], ACHIP_SLOT_PREFIX | (blk_has ? ACHIP_RLE_HAS | blk_last : (rle_lost ? 0u : in)));
+          const bool in_has = !rle_lost && (in & ACHIP_RLE_HAS) != 0u;
+          const uint32_t in_rgb = in & 0x00FFFFFFu;
+#pragma unroll
+          for (int j = 0; j < CPL; j++) {
+            const bool prev_has = ph[j] || in_has;
+            const uint32_t prev_rgb = ph[j] ? pv[j] : in_rgb;
+            const bool sgr = pix[j] && (!asc[j] || !prev_has || prev_rgb != px[j]);
+            const uint32_t colour = (f.ops & ACHIP_OP_FG_OVERRIDE) ? f.ops >> ACHIP_OP_TINT_SHIFT : px[j];
+            body[j] = sgr_body(word_fields<L::o_wr, L::o_wg, L::o_wm>(colour));
+            sl[j] = sgr ? body[j].bits >> 3 : 0u;
+            len[j] = rle_lost ? 0x100000u /* overflows every slot */ : sl[j] + (valid[j] ? gn[j] : 0u) + (rend[j] ? 1u : 0u) + (is_fin[j] ? 3u : 0u);
           }
         }
 
@@ -981,16 +1138,34 @@ __global__ void __launch_bounds__(WAVES * 64)
 #else
             if (sl[j] != 0u)
               sgr_place(a, 0x38335B1Bu, body[j]);
-            /* the glyph (a pad cell's space): cells that own nothing store into the lane's dummy word instead of branching */
-            const uint32_t g = len[j] != 0u ? a + sl[j] : dummy_addr;
-            lds_store_byte<0, false>(g, gl[j]);
-            if (has_nl[j])
-              lds_store_byte<1, false>(g, (uint32_t)'\n');
-            if (is_fin[j]) {
-              lds_store_byte<1, false>(g, 0x1Bu);
-              lds_store_byte<2, false>(g, (uint32_t)'[');
-              lds_store_byte<3, false>(g, (uint32_t)'0');
-              lds_store_byte<4, false>(g, (uint32_t)'m');
+            if constexpr (!U8) {
+              /* the glyph (a pad cell's space): cells that own nothing store into the lane's dummy word instead of branching */
+              const uint32_t g = len[j] != 0u ? a + sl[j] : dummy_addr;
+              lds_store_byte<0, false>(g, gl[j]);
+              if (has_nl[j])
+                lds_store_byte<1, false>(g, (uint32_t)'\n');
+              if (is_fin[j]) {
+                lds_store_byte<1, false>(g, 0x1Bu);
+                lds_store_byte<2, false>(g, (uint32_t)'[');
+                lds_store_byte<3, false>(g, (uint32_t)'0');
+                lds_store_byte<4, false>(g, (uint32_t)'m');
+              }
+            } else if (len[j] != 0u) {
+              /* the glyph's one to four bytes: two aligned dword ORs (the staging area is zero where nothing was written) */
+              const uint32_t g = a + sl[j];
+              const uint32_t gv = gn[j] >= 4u ? gl[j] : gl[j] & ((1u << (8u * gn[j])) - 1u);
+              const uint32_t t = g - 1u, wbase = t & ~3u, wsh = (t << 3) ^ 24u;
+              ds_or_u32_at<0>(wbase, alignbit(gv, 0u, wsh));
+              ds_or_u32_at<4>(wbase, alignbit(0u, gv, wsh));
+              const uint32_t e = g + gn[j];
+              if (has_nl[j])
+                lds_store_byte<0, false>(e, (uint32_t)'\n');
+              if (is_fin[j]) {
+                lds_store_byte<0, false>(e, 0x1Bu);
+                lds_store_byte<1, false>(e, (uint32_t)'[');
+                lds_store_byte<2, false>(e, (uint32_t)'0');
+                lds_store_byte<3, false>(e, (uint32_t)'m');
+              }
             }
 #endif
           }
@@ -1060,7 +1235,7 @@ __global__ void __launch_bounds__(WAVES * 64)
           uint32_t flags, n;
           const bool row_end = valid && p.xp == uwp - 1u; /* always a pixel cell: out_w >= 1 */
           const bool nl = row_end && p.rr < (uint32_t)rows - 1u;
-          if (MODE == ACHIP_MODE_TRUE_FG) {
+          if (RMODE == ACHIP_MODE_TRUE_FG) {
             /* image_print_color + ansi_rle_add_pixel (foreground.c:268-303, ansi.c:261-300): the SGR only when the
              * colour differs from the previous pixel in raster order (the state survives row ends) */
             /* the raster predecessor sits one slot down: the neighbouring lane (the ghost for lane 1 of slot 0; with left
@@ -1076,12 +1251,12 @@ __global__ void __launch_bounds__(WAVES * 64)
               t.fg = f.ops >> ACHIP_OP_TINT_SHIFT;
             n = (sgr ? 10u + dec_digits(px_r(t.fg)) + dec_digits(px_g(t.fg)) + dec_digits(px_b(t.fg)) : 0u) + 1u +
                 (nl ? 1u : 0u) + (fin ? 4u : 0u);
-          } else if (MODE == ACHIP_MODE_256_FG) { /* foreground.c:475-500 */
+          } else if (RMODE == ACHIP_MODE_256_FG) { /* foreground.c:475-500 */
             t.fg = quant256(pt);
             t.glyph = glyph[Y];
             flags = TF_SGR_FG | TF_GLYPH | (row_end ? TF_ROW_RESET : 0u) | (nl ? TF_NL : 0u);
             n = 8u + dec_digits(t.fg) + (ascii_only ? 1u : glyph_len(t.glyph)) + (row_end ? 4u : 0u) + (nl ? 1u : 0u);
-          } else if (MODE == ACHIP_MODE_16_FG) { /* foreground.c:584-612: glyph = cache[ramp[Y>>2]] (sic) */
+          } else if (RMODE == ACHIP_MODE_16_FG) { /* foreground.c:584-612: glyph = cache[ramp[Y>>2]] (sic) */
             t.fg = sgr16_code(false, quant16(pt));
             t.glyph = glyph[ramp[Y >> 2]];
             flags = TF_SGR_FG | TF_GLYPH | (row_end ? TF_ROW_RESET : 0u) | (nl ? TF_NL : 0u);
@@ -1098,7 +1273,7 @@ __global__ void __launch_bounds__(WAVES * 64)
             }
             t.flags = flags;
             CountSink cs{0u};
-            token_fields<MODE>(cs, t, ascii_only);
+            token_fields<RMODE>(cs, t, ascii_only);
             n = cs.n;
           }
           /* ascii_pad_frame_width: a pad cell is one space; cells behind the frame own nothing */
@@ -1137,7 +1312,7 @@ __global__ void __launch_bounds__(WAVES * 64)
             asm volatile("" ::"v"(tok[k].flags), "v"(tok[k].fg), "v"(tok[k].glyph), "v"(off[k]));
 #else
             WordSink<L::o_dec, L::o_flags + 16, L::WORDS ? L::o_wr : -1, L::WORDS ? L::o_wg : -1, L::WORDS ? L::o_wm : -1> fs{{stage_addr + (base + off[k] - g0), dummy_addr}};
-            token_fields<MODE>(fs, tok[k], ascii_only);
+            token_fields<RMODE>(fs, tok[k], ascii_only);
 #endif
           }
         lds_store_fence(); /* DS operations of one wave complete in order: the reads below see every lane's bytes */

@@ -29,6 +29,8 @@ using G = SGeometry<ACHIP_SINST>;
 
 /* the frame CRC rides the drain (CRC = true) in the two geometries the policy picks by itself */
 constexpr bool HAS_CRC = ACHIP_SINST == 16 || ACHIP_SINST == 17;
+/* ... and they carry the multi-byte-palette form of truecolor foreground */
+constexpr bool HAS_U8 = ACHIP_SINST == 16 || ACHIP_SINST == 17 || ACHIP_SINST == 20;
 
 /* the constant tables of <MODE>'s CRC instantiation: built on the device once per process, then read-only */
 template <int MODE> hipError_t crc_tables(const uint4 **out) {
@@ -200,6 +202,17 @@ extern "C" int ACHIP_CAT(achipk_render_sinst_launch_, ACHIP_SINST)(int mode, int
     uni = *uniform;
   if (uniform)
     uni.flags = uniform->flags; /* launch-wide facts travel even when the descriptors come from the device array */
+  /* truecolor foreground with a palette that holds multi-byte glyphs: an instantiation of its own (render_stream.hpp);
+   * whole frames of single sources without the fused checksum (the host plans the rest elsewhere) */
+  if (mode == ACHIP_MODE_TRUE_FG && !(uni.flags & ACHIP_UNIFORM_PALETTE_ASCII)) {
+    if constexpr (HAS_U8) {
+      if (comp || wire)
+        return (int)hipErrorInvalidValue;
+      return (int)launch_one<ACHIP_STREAM_MODE_TRUE_FG_U8, false, false>(frames, n, lut, out, stride, len, uni, prof, achip_wire_t{}, s);
+    } else {
+      return (int)hipErrorInvalidValue;
+    }
+  }
   switch (mode) {
 #define M(m)                                                                                                           \
   case m:                                                                                                              \

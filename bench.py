@@ -61,7 +61,20 @@ WORKLOADS = {
     # configs[2] / configs[4] from sampled images: the kernels where HBM line fills are NOT the limit
     "sampled_200x60_truecolor": (200, 60, 200, 60, 3, 0),
     "sampled_400x240_halfblock": (400, 240, 400, 120, 3, 2),
+    # truecolor foreground with the reference's multi-byte palettes (palette.h:161-197; three of its five built-ins take
+    # foreground.c:281-296's branch): round 6's instantiation of the stream kernel
+    "1080p_80x24_truecolor_blocks": (1920, 1080, 80, 24, 3, 0),
+    "4k_200x60_truecolor_cool": (3840, 2160, 200, 60, 3, 0),
+    "sampled_200x60_truecolor_blocks": (200, 60, 200, 60, 3, 0),
 }
+PALETTE_BLOCKS = "   \u2591\u2591\u2592\u2592\u2593\u2593\u2588\u2588"  # PALETTE_CHARS_BLOCKS (palette.h)
+PALETTE_COOL = "   \u2581\u2582\u2583\u2584\u2585\u2586\u2587\u2588"    # PALETTE_CHARS_COOL
+WORKLOAD_PALETTE = {"1080p_80x24_truecolor_blocks": PALETTE_BLOCKS, "4k_200x60_truecolor_cool": PALETTE_COOL,
+                    "sampled_200x60_truecolor_blocks": PALETTE_BLOCKS}
+
+
+def palette_of(name):
+    return WORKLOAD_PALETTE.get(name, PALETTE_STANDARD)
 # batch-size axis: the 1-GPU stand-in for a scaling curve -- where each kernel saturates
 SWEEP_WORKLOADS = ("1080p_80x24_truecolor", "4k_200x60_truecolor", "sampled_80x24_truecolor", "sampled_200x60_truecolor",
                    "sampled_400x240_halfblock")
@@ -102,14 +115,14 @@ def make_frames(torch, batch, w, h, seed, kind="noise"):
     return out
 
 
-def build_plan(pkg, frames_t, W, H, cl, rm, aspect=False):
+def build_plan(pkg, frames_t, W, H, cl, rm, aspect=False, palette=PALETTE_STANDARD):
     """aspect=False: full W x H (SURVEY 8(d) first variant); aspect=True: use_aspect_ratio + wants_padding, the
     server's call (stream.c:841)."""
     b, h, w, _ = frames_t.shape
     mode = pkg.lib().achip_mode_from_caps(cl, rm)
     base = frames_t.data_ptr()
     descs = [pkg.frame_setup(base + i * h * w * 3, w, h, W, H, rm, aspect, aspect, False) for i in range(b)]
-    return pkg.Plan(mode, PALETTE_STANDARD, descs), mode
+    return pkg.Plan(mode, palette, descs), mode
 
 
 _LANE_POOL = []
@@ -174,7 +187,7 @@ class Runner:
         return max(b[s].elapsed_time(e[t]) for s in range(self.S) for t in range(self.S)) / n
 
 
-def verify_against_oracle(torch, pkg, plan, frames_t, W, H, cl, rm, aspect, n_check=8):
+def verify_against_oracle(torch, pkg, plan, frames_t, W, H, cl, rm, aspect, n_check=8, palette=PALETTE_STANDARD):
     """Renders the batch once more (untimed) and compares n_check frames byte-for-byte with the CPU oracle run on the
     very same input frames (downloaded from the device).  Raises on any difference."""
     import numpy as np
@@ -191,7 +204,7 @@ def verify_against_oracle(torch, pkg, plan, frames_t, W, H, cl, rm, aspect, n_ch
     idx = sorted(set(int(round(i * (b - 1) / max(1, n_check - 1))) for i in range(min(n_check, b))))
     for i in idx:
         img = np.ascontiguousarray(frames_t[i].cpu().numpy())
-        exp = orc.convert_with_caps(img, W, H, cl, rm, aspect, aspect, False)
+        exp = orc.convert_with_caps(img, W, H, cl, rm, aspect, aspect, False, palette)
         got = bytes(out[i * plan.stride:i * plan.stride + int(lens[i])].cpu().numpy())
         if got != exp:
             raise SystemExit(f"bench.py: output of frame {i} differs from the oracle ({len(got)} vs {len(exp)} bytes)")
@@ -205,7 +218,7 @@ def run_workload(torch, pkg, name, batch, steps, warmup, regions, dist=None, see
     sets = [make_frames(torch, batch, sw, sh, seed + 7919 * s, kind) for s in range(nsets)]
     plans = []
     for t in sets:
-        plan, mode = build_plan(pkg, t, W, H, cl, rm, aspect)
+        plan, mode = build_plan(pkg, t, W, H, cl, rm, aspect, palette_of(name))
         plan.set_concurrency(streams)
         if variant >= 0:
             plan.set_variant(variant)
@@ -231,7 +244,7 @@ def run_workload(torch, pkg, name, batch, steps, warmup, regions, dist=None, see
             if variant >= 0:
                 plan.set_variant(variant)
     run = Runner(torch, pkg, plans, batch, streams)
-    ver, lens = (verify_against_oracle(torch, pkg, plans[0], sets[0], W, H, cl, rm, aspect) if verify
+    ver, lens = (verify_against_oracle(torch, pkg, plans[0], sets[0], W, H, cl, rm, aspect, palette=palette_of(name)) if verify
                  else (None, None))
     # exact output bytes of every input set (B_alg = sampled RGB consumed + exact output length)
     out_bytes = []
@@ -1289,7 +1302,7 @@ def main():
             # inputs on the metric's shape and aspect + padding on every workload
             todo = [(n, "noise", False) for n in WORKLOADS if n != args.workload or args.input != "noise" or args.aspect]
             todo += [(args.workload, k, False) for k in INPUT_KINDS if k != "noise"]
-            todo += [(n, "noise", True) for n in WORKLOADS]
+            todo += [(n, "noise", True) for n in WORKLOADS if n not in WORKLOAD_PALETTE]
         else:
             todo = [(n, "noise", False) for n in args.others.split(",") if n in WORKLOADS and n != args.workload]
         for name, kind, aspect in todo:

@@ -127,7 +127,9 @@ def main():
             elif ms.group(7) == "1":  # shared-out frames are small launches: a few four-wave workgroups per CU, all resident
                 limit, why = 72, "7 waves per SIMD (small launches: every workgroup is resident anyway)"
             else:
-                limit, why = (72, "7 waves per SIMD") if mode == 4 else (64, "8 waves per SIMD")
+                # (mode 17 = truecolor foreground with multi-byte glyphs, ACHIP_STREAM_MODE_TRUE_FG_U8: its RLE-state chain next
+                # to the tokens; 4 = truecolor background)
+                limit, why = (72, "7 waves per SIMD") if mode in (4, 17) else (64, "8 waves per SIMD")
         else:
             short = demangle(name).split("(")[0].replace("void ", "")[-70:]
         problems = []

@@ -122,6 +122,16 @@ static void run_stream(const achip_frame_t *frames, int n, const achip_lut_t *lu
     return;
   }
   if (!needs_generic(frames, n)) {
+    if constexpr (MODE == ACHIP_MODE_TRUE_FG) { /* as the product's launcher: the palette picks the instantiation */
+      if (lut->flags & ACHIP_LUT_MULTIBYTE) {
+        using LU = achip::SLds<ACHIP_STREAM_MODE_TRUE_FG_U8, WAVES, CPL>;
+        const size_t ldsu = (size_t)((LU::bytes_for(achip::stream_maxblk(uni.flags, LU::EFF)) + 15) & ~15);
+        hipemu::launch(dim3((unsigned)n), dim3(WAVES * 64), ldsu, [&] {
+          achip::render_stream_kernel<ACHIP_STREAM_MODE_TRUE_FG_U8, WAVES, CPL, false>(frames, lut, out, stride, len, n, uni, nullptr, achip_wire_t{}, nullptr, achip_packdev_t{}, achip_partsdev_t{});
+        });
+        return;
+      }
+    }
     hipemu::launch(dim3((unsigned)n), dim3(WAVES * 64), lds, [&] {
       achip::render_stream_kernel<MODE, WAVES, CPL, false>(frames, lut, out, stride, len, n, uni, nullptr, achip_wire_t{}, nullptr, achip_packdev_t{}, achip_partsdev_t{});
     });

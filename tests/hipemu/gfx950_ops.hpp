@@ -78,6 +78,7 @@ inline uint32_t wave_shfl_up(uint32_t v, int d) {
   return hipemu::shfl_from(v, hipemu::lane() - d); /* src < 0 -> own value, like __shfl_up */
 }
 inline uint32_t wave_read_lane(uint32_t v, int lane) { return hipemu::shfl_from(v, lane); }
+inline uint32_t wave_shfl(uint32_t v, int src) { return hipemu::shfl_from(v, src & 63); }
 inline int wave_uniform(int v) { return v; }
 inline uint32_t wave_inclusive_scan(uint32_t v) {
   const int l = hipemu::lane();

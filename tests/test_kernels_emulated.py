@@ -242,17 +242,53 @@ def test_stream_kernel_aspect_padding_and_many_blocks(mode):
 @pytest.mark.parametrize("palette", [orc.PALETTE_BLOCKS, orc.PALETTE_COOL, "ab", "x", "é漢😀 ."],
                          ids=["blocks", "cool", "ab", "x", "mixed"])
 def test_stream_kernel_palettes(palette):
-    # multi-byte glyphs in the per-cell modes that allow them (truecolor-fg with such a palette stays on the phase
-    # kernel: the stream kernel must refuse it)
-    for mode in (MODE_256_FG, MODE_16_FG, MODE_TRUE_BG):
+    # multi-byte glyphs in every per-cell mode (truecolor-fg with such a palette: the instantiation of its own, round 6)
+    for mode in (MODE_256_FG, MODE_16_FG, MODE_TRUE_BG, MODE_TRUE_FG):
         exp = oracle_convert(TORTURE, mode, 61, 17, palette)
         assert emu_convert(TORTURE, mode, 61, 17, palette, 20) == exp, (MODE_NAMES[mode], palette)
-    ascii_only = all(ord(c) < 128 for c in palette)
-    got = emu_convert(TORTURE, MODE_TRUE_FG, 61, 17, palette, 20)
-    if ascii_only:
-        assert got == oracle_convert(TORTURE, MODE_TRUE_FG, 61, 17, palette)
-    else:
-        assert got == 0xFFFFFFFE  # ACHIP_LEN_BADDESC
+
+
+@pytest.mark.parametrize("palette", [orc.PALETTE_BLOCKS, orc.PALETTE_COOL, orc.PALETTE_DIGITAL, "é漢😀 .m", "a█", "██ "],
+                         ids=["blocks", "cool", "digital", "mixed", "two", "mostly_multibyte"])
+@pytest.mark.parametrize("variant", [20, 16, 17])
+def test_stream_kernel_truecolor_with_multibyte_palettes(palette, variant):
+    """foreground.c:281-296: a cell whose glyph is not one ASCII byte always carries its SGR and leaves the RLE state alone,
+    so an ASCII cell is compared with the nearest EARLIER ASCII cell -- across rows, blocks (the second look-back of
+    ACHIP_STREAM_MODE_TRUE_FG_U8) and long stretches without one.  Both cell orders (sources a cache line apart / closer),
+    padding, flips + the rainbow override, frames of many blocks, flat areas whose colour returns after a multi-byte stretch."""
+    import ctypes as C
+    img = orc.frame_torture()
+    wide = orc.frame_hash_noise(1920, 54, 11)
+    wide[:, 600:1400] = (3, 3, 3)            # dark flat band: ASCII cells (the palettes' leading spaces) of one colour ...
+    wide[10:30, 800:1000] = (250, 250, 250)  # ... interrupted by a bright (multi-byte) island: the colour comes back behind it
+    flat = np.zeros((40, 97, 3), np.uint8)
+    flat[:, :] = (200, 220, 240)             # bright: no ASCII cell at all in most palettes
+    flat[20:, 50:] = (1, 2, 3)
+    far = np.full((50, 120, 3), 240, np.uint8)  # 95 blocks of geometry 20 between two dark corners: the look-back walks more
+    far[0, 0:3] = (2, 2, 2)                     # than 64 words back (and the other way round in the inverted palettes)
+    far[-1, -5:] = (2, 2, 2)
+    cases = [(img, 80, 24), (img, 97, 31), (wide, 80, 24), (wide, 200, 12), (flat, 97, 40), (img, 200, 60), (img, 3, 2), (img, 1, 1),
+             (far, 120, 50), (255 - far, 120, 50)]
+    for im, W, H in cases:
+        if variant != 20 and W * H > 6000:
+            continue
+        exp = oracle_convert(im, MODE_TRUE_FG, W, H, palette)
+        assert emu_convert(im, MODE_TRUE_FG, W, H, palette, variant) == exp, (palette, W, H, variant)
+    for im, W, H in [(img, 80, 24), (wide, 61, 17)]:
+        exp = oracle_convert(im, MODE_TRUE_FG, W, H, palette, True, True)
+        assert emu_convert(im, MODE_TRUE_FG, W, H, palette, variant, True, True) == exp, (palette, W, H, variant, "padded")
+    f = emu.frame_for_convert(wide, 80, 24, 0)
+    assert emu.lib().achip_frame_set_display_ops(C.byref(f), True, True, 0) == 0
+    assert emu.lib().achip_frame_set_rainbow(C.byref(f), 1.3) == 0
+    plain = oracle_convert(np.ascontiguousarray(wide[::-1, ::-1]), MODE_TRUE_FG, 80, 24, palette)
+    assert emu.render_frames(MODE_TRUE_FG, [f], palette, variant)[0] == orc.rainbow_replace(plain, 1.3), (palette, variant)
+    # a ragged batch, and the batch's descriptor by value
+    frames = [emu.frame_for_convert(im, W, H, 0) for im, W, H in cases[:4]]
+    got = emu.render_frames(MODE_TRUE_FG, frames, palette, variant)
+    for k, (im, W, H) in enumerate(cases[:4]):
+        assert got[k] == oracle_convert(im, MODE_TRUE_FG, W, H, palette), (palette, variant, k)
+    uni = emu.render_frames(MODE_TRUE_FG, [frames[2]] * 3, palette, variant, uniform=True)
+    assert uni[0] == uni[1] == uni[2] == got[2]
 
 
 def test_stream_kernel_ragged_batch_flips_tint_and_overflow():
