@@ -474,8 +474,11 @@ class Plan:
     def set_fused_crc(self, mode):
         """-1 automatic (fused where it is the faster form), 0 never, 1 wherever the geometry carries it"""
         rc = lib().asciichat_hip_plan_set_fused_crc(self._h, mode)
+        if rc == 30:  # ASCIICHAT_HIP_ERR_NOT_SUPPORTED: the setting is kept, this geometry / build has no fused form
+            return False
         if rc != 0:
             raise RuntimeError(f"set_fused_crc({mode}) failed: {last_error()}")
+        return True
 
     @property
     def fused_crc(self):

@@ -265,6 +265,9 @@ static int dense_open(asciichat_hip_frame_table_t *t, size_t need, ft_dense_blk_
   if (rc)
     return rc;
   b->used = 0;
+  /* the block is being refilled from here on: a reader whose snapshot still names its previous commit must not be handed a
+   * pointer into it (ft_dense_latest compares the numbers; ADVICE r5: invalid at REOPEN, not only at the next commit) */
+  b->seq = 0;
   t->dense_open = t->dense_next;
   *out = b;
   return 0;

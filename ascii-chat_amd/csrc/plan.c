@@ -355,9 +355,9 @@ int asciichat_hip_plan_create(asciichat_hip_plan_t **plan, int mode, const char 
   int rc = achip_require_device();
   if (rc)
     return rc;
-  rc = achip_hip_check(achip_launch_warm_crc_tables(), "checksum tables"); /* (first plan of a device only; then a mutex and a look) */
-  if (rc)
-    return rc;
+  /* (first plan of a device only; then a mutex and a look.  A failure here is not the plan's: callers that never checksum
+   * must not lose their plan to it, and the wire entry points build the tables themselves and report then -- ADVICE r5) */
+  (void)achip_launch_warm_crc_tables();
   asciichat_hip_plan_t *p = (asciichat_hip_plan_t *)calloc(1, sizeof(*p));
   if (!p)
     return achip_fail(ASCIICHAT_HIP_ERR_MEMORY, "out of memory");
@@ -731,7 +731,13 @@ int asciichat_hip_plan_has_fused_crc(const asciichat_hip_plan_t *p) {
 int asciichat_hip_plan_set_fused_crc(asciichat_hip_plan_t *p, int mode) {
   if (!p || mode < -1 || mode > 1)
     return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "plan_set_fused_crc: -1 (automatic), 0 (never) or 1 (always)");
+  /* "always" on a plan whose geometry has no fused instantiation in this build of the library (the rows kernel's live in
+   * -DACHIP_ALL_GEOMETRIES builds only; truecolor foreground with a multi-byte palette has none) would silently run the two
+   * passes: say so (the setting is kept for a later geometry of the plan; plan_has_fused_crc tells what a call will do) */
   p->fused_crc = mode;
+  if (mode == 1 && !asciichat_hip_plan_has_fused_crc(p))
+    return achip_fail(ASCIICHAT_HIP_ERR_NOT_SUPPORTED, "plan_set_fused_crc(1): this plan's geometry carries no fused checksum in this build; "
+                                                       "plan_render_crc / _packets will run render + stand-alone pass");
   return 0;
 }
 

@@ -405,7 +405,9 @@ int asciichat_hip_plan_render_packets_packed(asciichat_hip_plan_t *plan, uint8_t
  * per-cell modes' stream kernel -- for a small launch whose render is shared out over workgroups only while a wave has one
  * block: fusing means one workgroup per frame, and a lone 320x90 frame then takes 116 us where render + stand-alone pass
  * take 17), 1 wherever the plan's geometry carries it (also the rows kernel of the run-structured modes, where the
- * stand-alone pass is measured faster), 0 never.  plan_has_fused_crc() tells what a call will do. */
+ * stand-alone pass is measured faster), 0 never.  plan_has_fused_crc() tells what a call will do.  Mode 1 on a plan whose
+ * geometry has no fused instantiation in this build (the rows kernel's exist in -DACHIP_ALL_GEOMETRIES builds only) returns
+ * ASCIICHAT_HIP_ERR_NOT_SUPPORTED -- the setting is kept, the calls run render + stand-alone pass. */
 int asciichat_hip_plan_set_fused_crc(asciichat_hip_plan_t *plan, int mode);
 int asciichat_hip_plan_render_crc_profiled(asciichat_hip_plan_t *plan, uint8_t *out_dev, size_t out_stride,
                                            uint32_t *out_len_dev, uint32_t *crc_out_dev,
