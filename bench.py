@@ -66,7 +66,12 @@ WORKLOADS = {
     "1080p_80x24_truecolor_blocks": (1920, 1080, 80, 24, 3, 0),
     "4k_200x60_truecolor_cool": (3840, 2160, 200, 60, 3, 0),
     "sampled_200x60_truecolor_blocks": (200, 60, 200, 60, 3, 0),
+    # rows wider than one block of the rows kernel (448 cells): ascii.c:204 admits terminals up to 10 000 columns, and 4K ->
+    # 640x180 half blocks is a plain use; not part of the default run (1 GB of output per launch)
+    "4k_640x180_halfblock": (3840, 2160, 640, 180, 3, 2),
+    "sampled_640x360_halfblock": (640, 360, 640, 180, 3, 2),
 }
+HEAVY_WORKLOADS = ("4k_640x180_halfblock", "sampled_640x360_halfblock")  # only when asked for by name
 PALETTE_BLOCKS = "   \u2591\u2591\u2592\u2592\u2593\u2593\u2588\u2588"  # PALETTE_CHARS_BLOCKS (palette.h)
 PALETTE_COOL = "   \u2581\u2582\u2583\u2584\u2585\u2586\u2587\u2588"    # PALETTE_CHARS_COOL
 WORKLOAD_PALETTE = {"1080p_80x24_truecolor_blocks": PALETTE_BLOCKS, "4k_200x60_truecolor_cool": PALETTE_COOL,
@@ -984,7 +989,7 @@ LINE_TARGET_BYTES = 4096  # the stdout line the driver parses: small enough to s
 LINE_HARD_LIMIT_BYTES = 8192
 _COMPACT_TOP = ("metric", "value", "unit", "n_gpus", "rccl_ranks", "steps", "warmup", "ms_per_step", "higher_is_better",
                 "scaling", "vs_baseline", "dtype", "data")
-_COMPACT_ROOFLINE = ("bound", "achieved", "peak", "unit", "frac", "frac_profile", "frac_profile_source", "traffic",
+_COMPACT_ROOFLINE = ("bound", "achieved", "peak", "unit", "frac", "frac_profile", "frac_profile_best", "frac_profile_n", "frac_profile_source", "traffic",
                      "traffic_source", "alg_bytes_per_launch", "kernel_ms", "launches_in_flight")
 _COMPACT_CPU = ("value", "unit", "cores", "kind", "sample", "cpu_model")
 
@@ -1269,10 +1274,25 @@ def main():
             line["roofline"]["traffic_source"] = "committed rocprofv3 --pmc passes: " + tr.get("file", "profiles/")
         fp = cp.get("frac_profile") or {}
         if "busy_us_per_launch" in fp and args.batch == 256 and args.input == "noise" and not args.aspect:
-            # the same fraction from the COMMITTED kernel trace instead of this run's HIP events: algorithmic bytes of this
-            # run / busy time per launch of the trace (union of the dispatch intervals / launches, scripts/trace_stats.py)
-            line["roofline"]["frac_profile"] = res["alg_bytes_per_launch"] / (fp["busy_us_per_launch"] * 1e-6) / 1e9 / HBM_PEAK_GBS
-            line["roofline"]["frac_profile_source"] = fp.get("file", "profiles/")
+            # the same fraction from the COMMITTED kernel traces instead of this run's HIP events: algorithmic bytes of this
+            # run / busy time per launch of the traces (union of the dispatch intervals / launches, scripts/trace_stats.py) --
+            # the MEDIAN over every headline trace of the profile visit, the best and the count beside it.
+            # Only while the traces are of THIS code: the entry carries the identity of the sources it was taken on.
+            try:
+                from scripts.source_id import source_id
+                here = source_id()
+            except Exception:
+                here = None
+            if fp.get("source_id") is not None and fp.get("source_id") == here:
+                f_of = lambda us: res["alg_bytes_per_launch"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS
+                line["roofline"]["frac_profile"] = f_of(fp["busy_us_per_launch"])
+                if "busy_us_per_launch_best" in fp:
+                    line["roofline"]["frac_profile_best"] = f_of(fp["busy_us_per_launch_best"])
+                line["roofline"]["frac_profile_n"] = fp.get("n_traces", 1)
+                line["roofline"]["frac_profile_source"] = fp.get("file", "profiles/")
+            else:
+                line["committed_profile_stale"] = {"profile_source_id": fp.get("source_id"), "tree_source_id": here,
+                                                   "note": "the committed traces are of other sources than this tree: no frac_profile"}
     if rank == 0 and world == 1:
         if not args.no_d2h:
             d2h_s, d2h_bytes = time_with_d2h(torch, res["plans"][0], args.batch, 50)
@@ -1300,9 +1320,9 @@ def main():
         if args.others == "default":
             # every BASELINE config at its own shape (noise, full W x H), then SURVEY 8(d)'s variants: the other three
             # inputs on the metric's shape and aspect + padding on every workload
-            todo = [(n, "noise", False) for n in WORKLOADS if n != args.workload or args.input != "noise" or args.aspect]
+            todo = [(n, "noise", False) for n in WORKLOADS if n not in HEAVY_WORKLOADS and (n != args.workload or args.input != "noise" or args.aspect)]
             todo += [(args.workload, k, False) for k in INPUT_KINDS if k != "noise"]
-            todo += [(n, "noise", True) for n in WORKLOADS if n not in WORKLOAD_PALETTE]
+            todo += [(n, "noise", True) for n in WORKLOADS if n not in WORKLOAD_PALETTE and n not in HEAVY_WORKLOADS]
         else:
             todo = [(n, "noise", False) for n in args.others.split(",") if n in WORKLOADS and n != args.workload]
         for name, kind, aspect in todo:

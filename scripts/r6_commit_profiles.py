@@ -1,0 +1,143 @@
+#!/usr/bin/env python3
+"""Copies a round-6 profile visit's reduced files (scripts/gpu_r6_profiles.sh -> gpurun_out/<tag>/) into profiles/r06_* and
+writes the round-6 entries of profiles/committed_profile.json.
+
+VERDICT r5 next 3: the headline's trace-derived fraction is a STATISTIC -- the tracer keeps a run-dependent number of the four
+launches in flight (1.5-3.0), so every headline trace of the visit is recorded ({busy us per launch, launches in flight}) and
+`frac_profile` = the MEDIAN busy time; `frac_profile_best` and `frac_profile_n` stand next to it; three traces are committed as
+files: the median one, the best and the worst.  ADVICE r5: the entry carries the source identity (scripts/source_id.py) the
+traces were taken on; bench.py emits frac_profile only when the tree it runs from has the same one.
+
+usage: r6_commit_profiles.py gpurun_out/<tag>"""
+import csv
+import glob
+import json
+import os
+import re
+import shutil
+import statistics
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROF = os.path.join(ROOT, "profiles")
+NAMES = {  # trace name -> (workload key of bench.py, kernel substring, entry key)
+    "headline_s1": ("1080p_80x24_truecolor", "render_stream_kernel", "one_launch_at_a_time"),
+    "k3_4k_200x60": ("4k_200x60_truecolor", "render_stream_kernel", "four_launches_requested_under_the_tracer"),
+    "k5_4k_400x120_hb": ("4k_400x120_halfblock", "render_rows_kernel", "four_launches_requested_under_the_tracer"),
+    "k3_sampled_200x60": ("sampled_200x60_truecolor", "render_stream_kernel", "four_launches_requested_under_the_tracer"),
+    "k3_sampled_200x60_s1": ("sampled_200x60_truecolor", "render_stream_kernel", "one_launch_at_a_time"),
+    "k5_sampled_400x240_hb": ("sampled_400x240_halfblock", "render_rows_kernel", "four_launches_requested_under_the_tracer"),
+    "headline_sampled_80x24": ("sampled_80x24_truecolor", "render_stream_kernel", "four_launches_requested_under_the_tracer"),
+    "headline_sampled_80x24_s1": ("sampled_80x24_truecolor", "render_stream_kernel", "one_launch_at_a_time"),
+    "u8_1080p_80x24_blocks": ("1080p_80x24_truecolor_blocks", "render_stream_kernel", "four_launches_requested_under_the_tracer"),
+    "u8_4k_200x60_cool": ("4k_200x60_truecolor_cool", "render_stream_kernel", "four_launches_requested_under_the_tracer"),
+}
+SOURCE = ("profiles/r06_* (round 6, one MI355X through gpurun, scripts/gpu_r6_profiles.sh: rocprofv3 --kernel-trace of bench.py, "
+          "reduced by scripts/trace_stats.py; scripts/r6_commit_profiles.py)")
+
+
+def trace_row(d, name, kern):
+    f = os.path.join(d, name + "_kernel_stats.csv")
+    if not os.path.exists(f):
+        return None
+    best = None
+    for r in csv.DictReader(open(f)):
+        if kern in r["Name"] and (best is None or int(r["Calls"]) > int(best["Calls"])):
+            best = r
+    if best is None:
+        return None
+    line = {}
+    try:
+        line = json.load(open(os.path.join(d, name + "_under_rocprof.json")))
+    except Exception:
+        pass
+    return {"kernel": re.sub(r"\(.*", "", best["Name"]).replace("void ", ""), "calls": int(best["Calls"]),
+            "rocprof_avg_dispatch_us": float(best["AverageNs"]) / 1e3, "avg_in_flight": float(best["RunAvgInFlight"]),
+            "busy_us_per_launch": float(best["RunBusyNsPerCall"]) / 1e3,
+            "bench_kernel_ms_in_the_profiled_run": (line.get("roofline") or {}).get("kernel_ms"),
+            "alg_bytes_per_launch": (line.get("roofline") or {}).get("alg_bytes_per_launch")}
+
+
+def copy_files(d, name, as_name):
+    files = []
+    for suf in ("_kernel_stats.csv", "_trace_overlap.json", "_under_rocprof.json"):
+        src = os.path.join(d, name + suf)
+        if os.path.exists(src):
+            dst = os.path.join(PROF, "r06_" + as_name + suf)
+            shutil.copy(src, dst)
+            files.append("profiles/" + os.path.basename(dst))
+    return files
+
+
+def main():
+    d = sys.argv[1].rstrip("/")
+    cp = json.load(open(os.path.join(PROF, "committed_profile.json")))
+    sid = open(os.path.join(d, "source_id.txt")).read().strip() if os.path.exists(os.path.join(d, "source_id.txt")) else None
+    # ---- the headline: every trace counts
+    heads = []
+    for f in sorted(glob.glob(os.path.join(d, "headline_s4_*_kernel_stats.csv"))):
+        name = os.path.basename(f)[:-len("_kernel_stats.csv")]
+        row = trace_row(d, name, "render_stream_kernel")
+        if row:
+            heads.append((name, row))
+    if heads:
+        heads.sort(key=lambda h: h[1]["busy_us_per_launch"])
+        busy = [h[1]["busy_us_per_launch"] for h in heads]
+        med = statistics.median_low(busy)
+        pick = {"median": next(h for h in heads if h[1]["busy_us_per_launch"] == med), "best": heads[0], "worst": heads[-1]}
+        ent = cp.setdefault("1080p_80x24_truecolor", {"not_measured_by_this_run": True})
+        r6 = ent.setdefault("round6", {"source": SOURCE, "not_measured_by_this_run": True, "source_id": sid})
+        r6["source_id"] = sid
+        r6["headline_traces_busy_us_and_in_flight"] = [[round(h[1]["busy_us_per_launch"], 3), round(h[1]["avg_in_flight"], 2)] for h in heads]
+        files = {}
+        for tag, (name, row) in pick.items():
+            files[tag] = copy_files(d, name, "headline_s4_" + tag)
+            r6["four_launches_requested_under_the_tracer_" + tag] = dict(row, files=files[tag])
+        ent["frac_profile"] = {"busy_us_per_launch": med, "busy_us_per_launch_best": busy[0], "busy_us_per_launch_worst": busy[-1],
+                               "n_traces": len(busy), "avg_in_flight": pick["median"][1]["avg_in_flight"], "source_id": sid,
+                               "file": files["median"][0] if files["median"] else "profiles/",
+                               "note": "busy time per launch = union of the dispatch intervals / launches (scripts/trace_stats.py); MEDIAN over "
+                                       "every headline trace of the visit (the tracer keeps 1.5-3.0 of the four launches in flight, run by "
+                                       "run); best and worst beside it"}
+    # ---- the other traces: one each
+    for name, (wl, kern, key) in NAMES.items():
+        row = trace_row(d, name, kern)
+        if not row:
+            continue
+        row["files"] = copy_files(d, name, name)
+        ent = cp.setdefault(wl, {"not_measured_by_this_run": True})
+        r6 = ent.setdefault("round6", {"source": SOURCE, "not_measured_by_this_run": True, "source_id": sid})
+        r6["source_id"] = sid
+        r6[key] = row
+        if key != "one_launch_at_a_time":
+            ent["frac_profile"] = {"busy_us_per_launch": row["busy_us_per_launch"], "n_traces": 1, "avg_in_flight": row["avg_in_flight"],
+                                   "source_id": sid, "file": row["files"][0] if row["files"] else "profiles/",
+                                   "note": "busy time per launch = union of the dispatch intervals / launches of the committed trace"}
+    # ---- counter traffic
+    pmc = os.path.join(d, "pmc_summary.txt")
+    if os.path.exists(pmc):
+        shutil.copy(pmc, os.path.join(PROF, "r06_pmc_summary.txt"))
+        vals = {}
+        for l in open(pmc):
+            m = re.match(r"(\S+)\s+.*?(FETCH_SIZE|WRITE_SIZE)\s+per-dispatch mean\s+([\d.]+)", l)
+            if m:
+                vals[(m.group(1), m.group(2))] = float(m.group(3))
+        for key, wl in (("k5_4k", "4k_400x120_halfblock"), ("k5_sampled", "sampled_400x240_halfblock"), ("headline", "1080p_80x24_truecolor"),
+                        ("k3_sampled", "sampled_200x60_truecolor")):
+            fe, wr = vals.get((key + "_fetch", "FETCH_SIZE")), vals.get((key + "_write", "WRITE_SIZE"))
+            if fe and wr:
+                ent = cp.setdefault(wl, {"not_measured_by_this_run": True})
+                tr = {"fetch_size_kib_per_dispatch": fe, "write_size_kib_per_dispatch": wr, "hbm_bytes_per_launch": 2 * fe * 1024 + wr * 1024,
+                      "file": "profiles/r06_pmc_summary.txt", "source_id": sid,
+                      "note": "FETCH_SIZE on gfx950 tallies 128-byte line fills at 64 B (MI355X_MICROARCH.md): x 2"}
+                ent.setdefault("round6", {"source": SOURCE, "not_measured_by_this_run": True, "source_id": sid})["traffic"] = tr
+                ent["traffic"] = dict(tr, alg_bytes_per_launch=(ent.get("traffic") or {}).get("alg_bytes_per_launch"))
+    json.dump(cp, open(os.path.join(PROF, "committed_profile.json"), "w"), indent=1)
+    for wl, ent in cp.items():
+        fp = ent.get("frac_profile") or {}
+        if fp.get("source_id") == sid:
+            print(wl, fp.get("busy_us_per_launch"), fp.get("busy_us_per_launch_best"), fp.get("n_traces"))
+
+
+if __name__ == "__main__":
+    main()
