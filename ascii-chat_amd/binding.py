@@ -423,6 +423,14 @@ class Plan:
         frames in completion order, off_out tells where)"""
         return bool(lib().asciichat_hip_plan_get_exact_length(self._h))
 
+    @property
+    def length_first(self):
+        """True when render_packed / render_packets_packed may take the length-first form (frames beyond 48 KB, one launch)"""
+        L = lib()
+        L.asciichat_hip_plan_get_length_first.restype = C.c_int
+        L.asciichat_hip_plan_get_length_first.argtypes = [C.c_void_p]
+        return bool(L.asciichat_hip_plan_get_length_first(self._h))
+
     def set_exact_length(self, mode):
         if lib().asciichat_hip_plan_set_exact_length(self._h, mode) != 0:
             raise RuntimeError(f"set_exact_length({mode}) failed: {last_error()}")

@@ -106,7 +106,8 @@ __global__ void __launch_bounds__(BLOCK)
   if (bad)
     L = 0;
   const uint32_t w = dims && !bad ? dims[2 * i] : 0u, h = dims && !bad ? dims[2 * i + 1] : 0u;
-  const uint8_t *src = base + (size_t)i * stride;
+  /* (pack.off_out without COPY: the frames lie packed at base + off[i] -- what the render's exact-length forms leave behind) */
+  const uint8_t *src = !COPY && pack.off_out ? base + pack.off_out[i] : base + (size_t)i * stride;
   const int full = (int)(L >> 4);                     /* whole 16-byte groups                    */
   const int rounds = (full + BLOCK - 1) / BLOCK;      /* 0 for a frame shorter than 16 bytes      */
   const int lead = rounds * BLOCK - full;             /* zero groups in front of the frame        */
@@ -328,7 +329,7 @@ __global__ void __launch_bounds__(256)
     if (off + 16ull * (((uint64_t)L + 15u) >> 4) <= pack.capacity) /* whole groups travel: the last one must fit too */
       dstb = pack.dst + off + lo;
   }
-  const uint8_t *src = base + (size_t)i * stride + lo;
+  const uint8_t *src = (!COPY && pack.off_out ? base + pack.off_out[i] : base + (size_t)i * stride) + lo;
   auto load_group = [&](int j) -> uint4 {
     const uint64_t off = ((uint64_t)j * BLOCK + (uint64_t)tid) * 16u;
     uint4 d = make_uint4(0u, 0u, 0u, 0u);

@@ -33,6 +33,12 @@ int achip_launch_render_crc(int mode, int variant, int has_composite, const achi
 int achip_launch_render_pack(int mode, int variant /* 16: 1024-thread workgroups, else 512 */, const achip_frame_t *frames_dev,
                              int n_frames, const achip_lut_t *lut_dev, uint64_t bound, uint32_t *out_len, const achip_wire_t *wire, const achip_uniform_t *uniform,
                              const achip_packdev_t *pack, void *stream);
+int achip_launch_crc32c_at(const uint8_t *base, const uint64_t *at, const uint32_t *len_dev, uint32_t max_len, int n, uint32_t *partial,
+                           uint32_t *counters, const uint32_t *dims_dev, uint32_t *crc_out, uint8_t *hdr_out, uint32_t *pkt_crc_out,
+                           void *stream);
+/* exact-length truecolor frames of any size in one launch (render_stream.hpp LF; stream geometries 16 / 17) */
+int achip_launch_render_length_first(int variant, const achip_frame_t *frames_dev, int n_frames, const achip_lut_t *lut_dev, uint64_t bound,
+                                     uint32_t *out_len, const achip_uniform_t *uniform, const achip_packdev_t *pack, void *stream);
 int achip_pack_frame_cap(void); /* bytes of one frame those instantiations can stage; 0 = not available in this build */
 int achip_variant_has_crc(int variant);
 int achip_variant_crc_pays(int variant); /* the fused form is the faster one: what plans pick by themselves */

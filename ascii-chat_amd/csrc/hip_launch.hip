@@ -103,6 +103,17 @@ extern "C" int achip_launch_render_pack(int mode, int variant, const achip_frame
                        : achipk_render_sinst_pack_launch_17(mode, frames_dev, n_frames, lut_dev, bound, out_len, uniform, wire, pack, stream);
 }
 extern "C" int achip_pack_frame_cap(void) { return ACHIP_PACK_FRAME_CAP; }
+/* exact-length truecolor frames of any size in ONE launch (render_stream.hpp LF): stream geometries 16 / 17 */
+extern "C" int achipk_render_sinst_lenfirst_launch_16(const achip_frame_t *, int, const achip_lut_t *, uint64_t, uint32_t *, const achip_uniform_t *, const achip_packdev_t *, void *);
+extern "C" int achipk_render_sinst_lenfirst_launch_17(const achip_frame_t *, int, const achip_lut_t *, uint64_t, uint32_t *, const achip_uniform_t *, const achip_packdev_t *, void *);
+extern "C" int achip_launch_render_length_first(int variant, const achip_frame_t *frames_dev, int n_frames, const achip_lut_t *lut_dev,
+                                                uint64_t bound, uint32_t *out_len, const achip_uniform_t *uniform,
+                                                const achip_packdev_t *pack, void *stream) {
+  if (n_frames <= 0)
+    return (int)hipSuccess;
+  return variant == 16 ? achipk_render_sinst_lenfirst_launch_16(frames_dev, n_frames, lut_dev, bound, out_len, uniform, pack, stream)
+                       : achipk_render_sinst_lenfirst_launch_17(frames_dev, n_frames, lut_dev, bound, out_len, uniform, pack, stream);
+}
 #ifdef ACHIP_ALL_GEOMETRIES
 extern "C" int achip_variant_has_crc(int variant) { return variant == 16 || variant == 17 || (ACHIP_IS_ROWS_VARIANT(variant) && variant != 26); }
 #else
@@ -412,7 +423,9 @@ extern "C" int achip_launch_warm_crc_tables(void) {
 /* counters != NULL (n zero words the caller owns: a plan's): the span form finishes its frames in the SAME launch */
 static int launch_crc32c(const uint8_t *base, uint64_t stride, const uint32_t *len_dev, uint32_t fixed_len, uint32_t max_len,
                          int n, uint32_t *partial, uint32_t *counters, const uint32_t *dims_dev, uint32_t *crc_out, uint8_t *hdr_out,
-                         uint32_t *pkt_crc_out, const achip::CrcPack *pack, hipStream_t s) {
+                         uint32_t *pkt_crc_out, const achip::CrcPack *pack, hipStream_t s, const uint64_t *at = nullptr) {
+  /* at != NULL (never with pack): frame i lies at base + at[i] instead of base + i * stride */
+  const achip::CrcPack in_place = {nullptr, 0, const_cast<uint64_t *>(at), nullptr};
   const int parts = achip_crc_parts(max_len, n);
   if (parts == 1) { /* 1024 threads per frame; every workgroup runs only the rounds its own frame needs */
     const uint4 *tab = nullptr;
@@ -424,8 +437,7 @@ static int launch_crc32c(const uint8_t *base, uint64_t stride, const uint32_t *l
                          s, base, stride, len_dev, fixed_len, n, dims_dev, crc_out, hdr_out, pkt_crc_out, *pack, tab);
     else
       hipLaunchKernelGGL((achip::crc32c_frame_kernel<1024, false>), dim3((unsigned)n), dim3(1024), (size_t)achip::CrcLds::bytes,
-                         s, base, stride, len_dev, fixed_len, n, dims_dev, crc_out, hdr_out, pkt_crc_out,
-                         achip::CrcPack{nullptr, 0, nullptr, nullptr}, tab);
+                         s, base, stride, len_dev, fixed_len, n, dims_dev, crc_out, hdr_out, pkt_crc_out, in_place, tab);
     return (int)hipGetLastError();
   }
   const int rounds = crc_span_rounds(max_len, n); /* 64 KB (or, for a handful of buffers, 16 KB) spans of 256-thread workgroups */
@@ -453,8 +465,7 @@ static int launch_crc32c(const uint8_t *base, uint64_t stride, const uint32_t *l
                        (size_t)achip::CrcLds::bytes, s, base, stride, len_dev, fixed_len, n, parts, rounds, partial, tab256, fin, *pack);
   else
     hipLaunchKernelGGL(achip::crc32c_span_kernel<false>, dim3((unsigned)n * (unsigned)parts), dim3(256),
-                       (size_t)achip::CrcLds::bytes, s, base, stride, len_dev, fixed_len, n, parts, rounds, partial, tab256, fin,
-                       achip::CrcPack{nullptr, 0, nullptr, nullptr});
+                       (size_t)achip::CrcLds::bytes, s, base, stride, len_dev, fixed_len, n, parts, rounds, partial, tab256, fin, in_place);
   if (!counters)
     hipLaunchKernelGGL(achip::crc32c_finish_kernel, dim3((unsigned)n), dim3(64), (size_t)ACHIP_FRAME_CRC_TAB_BYTES, s, partial, parts, fin.cp,
                        fin.xinv_v, len_dev, fixed_len, n, dims_dev, crc_out, hdr_out, pkt_crc_out, tab256);
@@ -466,6 +477,14 @@ extern "C" int achip_launch_crc32c(const uint8_t *base, uint64_t stride, const u
                                    uint32_t *crc_out, uint8_t *hdr_out, uint32_t *pkt_crc_out, void *stream) {
   return launch_crc32c(base, stride, len_dev, fixed_len, max_len, n, partial, counters, dims_dev, crc_out, hdr_out, pkt_crc_out, nullptr,
                        static_cast<hipStream_t>(stream));
+}
+
+/* ... of frames that lie packed at base + at[i] (the exact-length forms of the render) */
+extern "C" int achip_launch_crc32c_at(const uint8_t *base, const uint64_t *at, const uint32_t *len_dev, uint32_t max_len, int n,
+                                      uint32_t *partial, uint32_t *counters, const uint32_t *dims_dev, uint32_t *crc_out, uint8_t *hdr_out,
+                                      uint32_t *pkt_crc_out, void *stream) {
+  return launch_crc32c(base, 0, len_dev, 0u, max_len, n, partial, counters, dims_dev, crc_out, hdr_out, pkt_crc_out, nullptr,
+                       static_cast<hipStream_t>(stream), at);
 }
 
 /* checksums + headers + compaction in ONE pass over the slab: frame i also goes to dst + off[i] (pack_frames' layout) */

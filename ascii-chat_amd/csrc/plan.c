@@ -206,6 +206,7 @@ struct asciichat_hip_plan {
   int variant_user; /* -1 = automatic */
   int max_wp;
   int has_comp; /* some frame samples a virtual composite */
+  int all_dense; /* every source IS the image its target samples (ratio 1.0: the sampled-image ingest, frame_dense.c) */
   int parts, rows_per_part, split_request; /* multi-workgroup frames (achip_choose_geometry) */
   int whole_variant; /* the geometry of the wire-stage entry points (frame checksums, exact-length frames: a frame belongs to ONE
                         workgroup there): `variant`, unless that shares frames out over workgroups of the stream kernel */
@@ -289,10 +290,13 @@ static int plan_measure(asciichat_hip_plan_t *p, const achip_frame_t *frames) {
   size_t stride = 0;
   int max_wp = 0;
   q.has_comp = 0;
+  q.all_dense = 1;
   for (int i = 0; i < q.n; i++) {
     const achip_frame_t *f = &frames[i];
     if (f->comp || (long)f->src_w * (long)f->src_h == 1) /* the kernels' general sampler: composites, 1x1 sources */
       q.has_comp = 1;
+    if (f->comp || f->src_w != f->out_w || f->src_h != f->out_h)
+      q.all_dense = 0;
     if (f->out_w <= 0 || f->out_h <= 0 || f->src_w <= 0 || f->src_h <= 0 || f->pad_left < 0 || f->pad_top < 0 ||
         (!f->src && !f->comp))
       return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame %d: bad descriptor", i);
@@ -648,6 +652,27 @@ static int plan_packs_this_call(asciichat_hip_plan_t *p, const void *dst, const 
   }
   return !p->pack_dst_host;
 }
+/* ... and whether it takes the length-first form (frames beyond the PACK form's 48 KB; see plan_render_length_first below) */
+static int plan_dst_is_device(asciichat_hip_plan_t *p, const void *dst) {
+  if (p->pack_dst_seen != dst) {
+    hipPointerAttribute_t attr;
+    memset(&attr, 0, sizeof(attr));
+    const hipError_t e = hipPointerGetAttributes(&attr, dst);
+    if (e != hipSuccess)
+      (void)hipGetLastError();
+    p->pack_dst_seen = dst;
+    p->pack_dst_host = e == hipSuccess && attr.type == hipMemoryTypeHost;
+  }
+  return !p->pack_dst_host;
+}
+static int plan_length_first_ok(const asciichat_hip_plan_t *p);
+static int plan_length_first_this_call(asciichat_hip_plan_t *p, const void *dst, const uint64_t *off_out) {
+  if (p->exact_length == 0 || !off_out || !plan_length_first_ok(p) || asciichat_hip_plan_get_exact_length(p))
+    return 0;
+  if (p->exact_length > 0)
+    return 1;
+  return p->all_dense && plan_dst_is_device(p, dst);
+}
 static int plan_render_pack(asciichat_hip_plan_t *p, uint32_t *out_len_dev, const achip_wire_t *wire, uint8_t *dst,
                             size_t dst_capacity, uint64_t *off_out, uint32_t *len_out, void *stream) {
   if (!out_len_dev || !dst || !off_out || ((uintptr_t)dst & 15u) || ((uintptr_t)off_out & 7u) || ((uintptr_t)len_out & 3u) ||
@@ -677,6 +702,51 @@ static int plan_render_pack(asciichat_hip_plan_t *p, uint32_t *out_len_dev, cons
                          "render + pack kernel launch");
 }
 
+/* ---- exact-length frames beyond the 48 KB of the one-launch PACK form: LENGTH-FIRST (round 6) -------------
+ * The stream kernel's lean loop run twice -- lengths first, then the emission at the place the frame claimed -- for whole-frame
+ * plans of truecolor foreground with an all-ASCII palette (render_stream.hpp LF).  Measured (profiles/r06_length_first_ab.txt,
+ * 256 frames of 200x60): from sampled images 16.5 us against 34.5 for render + pack pass; from 4K sources the second gather
+ * costs more than the pass (71.9 against 60.4) -- so the automatic choice takes it for DENSE sources only, device destinations,
+ * callers that receive off_out (completion order, like the PACK form). */
+static int plan_length_first_ok(const asciichat_hip_plan_t *p) {
+  return p->mode == ACHIP_MODE_TRUE_FG && p->palette_ascii && !p->has_comp && plan_frames_whole(p) &&
+         (p->whole_variant == 16 || p->whole_variant == 17);
+}
+/* whether plan_render_packed / _packets_packed may take the length-first form for this plan (frames beyond the one-launch
+ * form's 48 KB; the automatic setting adds: dense sources, a device destination) */
+int asciichat_hip_plan_get_length_first(const asciichat_hip_plan_t *p) {
+  return p && p->exact_length != 0 && plan_length_first_ok(p) && !asciichat_hip_plan_get_exact_length(p);
+}
+int asciichat_hip_plan_render_length_first(asciichat_hip_plan_t *p, uint32_t *out_len_dev, uint8_t *dst, size_t dst_capacity,
+                                           uint64_t *off_out, uint32_t *len_out, void *stream) {
+  if (!p || !out_len_dev || !dst || !off_out || ((uintptr_t)dst & 15u) || ((uintptr_t)off_out & 7u) || ((uintptr_t)len_out & 3u))
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "plan_render_length_first: bad arguments");
+  if (!plan_length_first_ok(p))
+    return achip_fail(ASCIICHAT_HIP_ERR_NOT_SUPPORTED, "plan_render_length_first: truecolor foreground, all-ASCII palette, whole frames of single sources");
+  if (!p->pack_cursor) {
+    int rc = achip_hip_check((int)hipMalloc((void **)&p->pack_cursor, 2 * sizeof(unsigned long long)), "hipMalloc(pack cursor)");
+    if (!rc)
+      rc = achip_hip_check((int)hipMemset(p->pack_cursor, 0, 2 * sizeof(unsigned long long)), "hipMemset(pack cursor)");
+    if (rc) {
+      if (p->pack_cursor)
+        (void)hipFree(p->pack_cursor);
+      p->pack_cursor = NULL;
+      return rc;
+    }
+  }
+  const int fc = plan_frames_current(p, stream);
+  if (fc)
+    return fc;
+  achip_uniform_t uni = p->uniform;
+  if (p->uniform_off)
+    uni.enabled = 0;
+  uni.flags = ACHIP_UNIFORM_PALETTE_ASCII | ACHIP_UNIFORM_MAX_CELLS(achip_uniform_extent(p->mode, 16, p->frames_pinned, p->n));
+  const achip_packdev_t pack = {dst, (uint64_t)dst_capacity, off_out, len_out, p->pack_cursor};
+  const int e = achip_launch_render_length_first(p->whole_variant, p->frames_dev, p->n, p->lut_dev, (uint64_t)p->stride, out_len_dev, &uni,
+                                                 &pack, stream);
+  return achip_hip_check(e, "length-first render launch");
+}
+
 int asciichat_hip_plan_render_packets_packed(asciichat_hip_plan_t *p, uint8_t *slab_dev, size_t out_stride, uint32_t *out_len_dev,
                                              const uint32_t *dims_dev, uint32_t *crc_out_dev, uint8_t *hdr_out_dev,
                                              uint32_t *packet_crc_out_dev, uint8_t *dst, size_t dst_capacity, uint64_t *off_out,
@@ -686,6 +756,13 @@ int asciichat_hip_plan_render_packets_packed(asciichat_hip_plan_t *p, uint8_t *s
   if (crc_out_dev && plan_packs_this_call(p, dst, off_out)) {
     const achip_wire_t wire = {crc_out_dev, dims_dev, hdr_out_dev, packet_crc_out_dev};
     return plan_render_pack(p, out_len_dev, &wire, dst, dst_capacity, off_out, len_out, stream);
+  }
+  if (crc_out_dev && plan_length_first_this_call(p, dst, off_out)) { /* exact-length frames in one launch, checksummed where they lie */
+    int rc = asciichat_hip_plan_render_length_first(p, out_len_dev, dst, dst_capacity, off_out, len_out, stream);
+    if (!rc)
+      rc = plan_wire_pass(p, dst, p->stride, out_len_dev, dims_dev, crc_out_dev, hdr_out_dev, packet_crc_out_dev, NULL, 0, off_out, NULL,
+                          stream);
+    return rc;
   }
   if (asciichat_hip_plan_has_fused_crc(p)) {
     int rc = asciichat_hip_plan_render_packets(p, slab_dev, out_stride, out_len_dev, dims_dev, crc_out_dev, hdr_out_dev,
@@ -1004,11 +1081,13 @@ typedef struct {
   uint32_t *len_out;
 } crc_pack_t;
 
-static int crc_common(const uint8_t *base_dev, size_t stride, const uint32_t *len_dev, uint32_t fixed_len,
-                      uint32_t max_len, int n, const uint32_t *dims_dev, uint32_t *crc_out_dev, uint8_t *hdr_out_dev,
-                      uint32_t *packet_crc_out_dev, const crc_pack_t *pack, uint32_t *own_scratch, void *stream) {
+/* at_dev != NULL: frame i lies at base_dev + at_dev[i] (16-byte aligned offsets: the exact-length forms of the render) */
+static int crc_common_at(const uint8_t *base_dev, size_t stride, const uint64_t *at_dev, const uint32_t *len_dev, uint32_t fixed_len,
+                         uint32_t max_len, int n, const uint32_t *dims_dev, uint32_t *crc_out_dev, uint8_t *hdr_out_dev,
+                         uint32_t *packet_crc_out_dev, const crc_pack_t *pack, uint32_t *own_scratch, void *stream) {
   if (!base_dev || !crc_out_dev || n <= 0 || ((uintptr_t)base_dev & 15u) || (stride & 15u) ||
-      (len_dev ? max_len == 0 : fixed_len > max_len) || max_len >= 0xFFFFFFF0u || (n > 1 && stride < max_len))
+      (len_dev ? max_len == 0 : fixed_len > max_len) || max_len >= 0xFFFFFFF0u || (!at_dev && n > 1 && stride < max_len) ||
+      (at_dev && (pack || !len_dev)))
     return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "crc32c: bad arguments");
   int rc = achip_require_device();
   if (rc)
@@ -1029,8 +1108,10 @@ static int crc_common(const uint8_t *base_dev, size_t stride, const uint32_t *le
   rc = achip_hip_check(pack ? achip_launch_crc32c_pack(base_dev, stride, len_dev, max_len, n, scratch, counters, dims_dev, crc_out_dev,
                                                        hdr_out_dev, packet_crc_out_dev, pack->dst, (uint64_t)pack->capacity,
                                                        pack->off_out, pack->len_out, stream)
-                            : achip_launch_crc32c(base_dev, stride, len_dev, fixed_len, max_len, n, scratch, counters, dims_dev,
-                                                  crc_out_dev, hdr_out_dev, packet_crc_out_dev, stream),
+                       : at_dev ? achip_launch_crc32c_at(base_dev, at_dev, len_dev, max_len, n, scratch, counters, dims_dev, crc_out_dev,
+                                                         hdr_out_dev, packet_crc_out_dev, stream)
+                                : achip_launch_crc32c(base_dev, stride, len_dev, fixed_len, max_len, n, scratch, counters, dims_dev,
+                                                      crc_out_dev, hdr_out_dev, packet_crc_out_dev, stream),
                        "crc32c launch");
   if (scratch && !own_scratch) {
     const int fr = achip_hip_check((int)hipFreeAsync(scratch, (hipStream_t)stream), "hipFreeAsync(crc scratch)");
@@ -1038,6 +1119,13 @@ static int crc_common(const uint8_t *base_dev, size_t stride, const uint32_t *le
       rc = fr;
   }
   return rc;
+}
+
+static int crc_common(const uint8_t *base_dev, size_t stride, const uint32_t *len_dev, uint32_t fixed_len, uint32_t max_len, int n,
+                      const uint32_t *dims_dev, uint32_t *crc_out_dev, uint8_t *hdr_out_dev, uint32_t *packet_crc_out_dev,
+                      const crc_pack_t *pack, uint32_t *own_scratch, void *stream) {
+  return crc_common_at(base_dev, stride, NULL, len_dev, fixed_len, max_len, n, dims_dev, crc_out_dev, hdr_out_dev, packet_crc_out_dev, pack,
+                       own_scratch, stream);
 }
 
 int asciichat_hip_crc32c(const uint8_t *base_dev, size_t stride, const uint32_t *len_dev, uint32_t fixed_len,
@@ -1098,8 +1186,10 @@ static int plan_wire_pass(asciichat_hip_plan_t *p, const uint8_t *slab_dev, size
     p->crc_scratch_words = words;
   }
   const crc_pack_t pack = {dst, dst_capacity, off_out, len_out};
-  return crc_common(slab_dev, out_stride, out_len_dev, 0, (uint32_t)out_stride, p->n, hdr_out_dev || packet_crc_out_dev ? dims_dev : NULL,
-                    crc_out_dev, hdr_out_dev, packet_crc_out_dev, dst ? &pack : NULL, words ? p->crc_scratch : NULL, stream);
+  /* dst == NULL with off_out: the frames already lie packed at slab_dev + off_out[i] (plan_render_length_first): in place */
+  return crc_common_at(slab_dev, out_stride, !dst ? off_out : NULL, out_len_dev, 0, (uint32_t)out_stride, p->n,
+                       hdr_out_dev || packet_crc_out_dev ? dims_dev : NULL, crc_out_dev, hdr_out_dev, packet_crc_out_dev, dst ? &pack : NULL,
+                       words ? p->crc_scratch : NULL, stream);
 }
 
 /* ---- compacted output (lib/network/acip/server.c:190-222 ships frame_size bytes, not a stride) ------------- */
@@ -1121,6 +1211,8 @@ int asciichat_hip_plan_render_packed(asciichat_hip_plan_t *p, uint8_t *slab_dev,
                                      uint8_t *dst, size_t dst_capacity, uint64_t *off_out, uint32_t *len_out, void *stream) {
   if (dst && plan_packs_this_call(p, dst, off_out))
     return plan_render_pack(p, out_len_dev, NULL, dst, dst_capacity, off_out, len_out, stream);
+  if (dst && plan_length_first_this_call(p, dst, off_out))
+    return asciichat_hip_plan_render_length_first(p, out_len_dev, dst, dst_capacity, off_out, len_out, stream);
   int rc = asciichat_hip_plan_render(p, slab_dev, out_stride, out_len_dev, stream);
   if (!rc)
     rc = asciichat_hip_pack_frames(slab_dev, out_stride, out_len_dev, p->n, dst, dst_capacity, off_out, len_out, stream);

@@ -255,6 +255,9 @@ __device__ inline uint32_t stream_request(const achip_frame_t &f, const StreamSr
   return ((const ACHIP_GLOBAL unaligned_u32 *)p)->v;
 }
 
+template <int P> struct StreamPhase { /* which pass of the lean loop (LENGTH-FIRST builds: 1 = lengths, 2 = emission; else 0) */
+  static constexpr int value = P;
+};
 struct StreamTagNT {
   static constexpr bool value = true;
 };
@@ -463,7 +466,7 @@ __device__ inline void stream_crc_finish(uint32_t *slots, int nblk, int nblk_cap
   }
 }
 
-template <int MODE, int WAVES, int CPL, bool GENERIC, bool CRC = false, int PACK = 0, bool PARTS = false>
+template <int MODE, int WAVES, int CPL, bool GENERIC, bool CRC = false, int PACK = 0, bool PARTS = false, bool LF = false>
 __global__ void __launch_bounds__(WAVES * 64)
     render_stream_kernel(const achip_frame_t *__restrict__ frames, const achip_lut_t *__restrict__ lut,
                          uint8_t *__restrict__ out, uint64_t out_stride, uint32_t *__restrict__ out_len, int n_frames,
@@ -598,7 +601,16 @@ __global__ void __launch_bounds__(WAVES * 64)
   if (f.src_stride == 0)
     f.src_stride = 3 * f.src_w;
   uint8_t *dst = out + (size_t)fidx * out_stride;
-  const uint32_t dmis = (uint32_t)(uintptr_t)dst & (ACHIP_DRAIN_ALIGN - 1u) & ~15u; /* the slot's own offset inside a line */
+  uint32_t dmis = (uint32_t)(uintptr_t)dst & (ACHIP_DRAIN_ALIGN - 1u) & ~15u; /* the slot's own offset inside a line */
+  /* LF = LENGTH-FIRST (round 6; VERDICT r5 next 6, lib/network/acip/server.c:190-222 ships exactly frame_size bytes): exact-length
+   * frames of ANY size in one launch -- PACK stages the whole frame in LDS and stops at 48 KB.  The lean loop runs twice: the first
+   * pass samples, classifies and scans only, every block publishes its prefix; the frame claims its place in pack.dst with one
+   * agent-scope add (completion order, as PACK); the second pass samples again -- out of the caches -- and emits at the claimed
+   * place.  An instantiation of its own (four registers more than the plain one).  Measured (profiles/r06_length_first_ab.txt):
+   * from sampled images 16.5 us against 34.5 for render + pack pass (256 frames of 200x60); from 4K sources the second gather
+   * costs more than the pass (71.9 against 60.4): the plan takes it for dense sources only. */
+  constexpr bool lenfirst = LF;
+  static_assert(!LF || (L::WORDS && !GENERIC && !PARTS && !PACK && !CRC && !L::U8), "length-first: the plain lean truecolor-foreground form");
 
   const int wp = f.pad_left + f.out_w;
   const int rows = f.out_h;
@@ -835,7 +847,7 @@ __global__ void __launch_bounds__(WAVES * 64)
   }
   /* ascii_pad_frame_height (ascii.c:902-941): pad_top bare newlines in front of the frame */
   const uint32_t first_base = (uint32_t)f.pad_top;
-  if (first_base > 0u && first_base <= cap_bytes && part == 0)
+  if (first_base > 0u && first_base <= cap_bytes && part == 0 && !lenfirst)
     for (uint32_t o = (uint32_t)tid; o < first_base; o += BLOCK) {
       if (PACK)
         lds_ptr<uint8_t>(frame_lds)[o] = '\n';
@@ -946,9 +958,16 @@ __global__ void __launch_bounds__(WAVES * 64)
     /* Two copies of the loop, chosen once per frame: a shared loop would merge the cached and the non-temporal load of a
      * sample, and the copies of a request meeting in phi moves is a wait for memory right behind the requests
      * (docs/history/round5.md 2b). */
-    auto lean_loop = [&](auto nt_tag) {
+    const CellPos pos_first = pos;
+    auto lean_loop = [&](auto nt_tag, auto phase_tag) {
       constexpr bool KM = decltype(nt_tag)::value; /* slot-major cell order (see lean_issue) */
+      constexpr int PH = decltype(phase_tag)::value; /* 0: the render; LF: 1 = lengths only, 2 = emit at known prefixes */
       uint32_t c0 = cell0;
+      if (PH == 2) { /* the second pass asks for the wave's first block again */
+        pos = pos_first;
+        if (b0 + wave < b1)
+          lean_issue(nt_tag, cell0, pos, raw, raw_sh);
+      }
       for (int blk = b0 + wave; blk < b1; blk += WAVES) {
         if (prof) { /* diagnostics only: make "samples arrived" a point in time */
           wait_vmem_all();
@@ -1124,10 +1143,17 @@ __global__ void __launch_bounds__(WAVES * 64)
 
         ACHIP_SSTAMP(4);
         bool ok;
-        const uint32_t base = place_block(blk, total, ok);
+        uint32_t base;
+        if (PH == 2) { /* every prefix was published by the first pass (a barrier lies between) */
+          const uint32_t incl = slot_load(&slots[blk - b0]) & ACHIP_SLOT_VALUE;
+          ok = incl <= cap_bytes;
+          base = incl - total;
+        } else {
+          base = place_block(blk, total, ok);
+        }
 
         ACHIP_SSTAMP(5);
-        if (ok) {
+        if (ok && PH != 1) {
           /* ---- token bytes into this wave's staging area: stream offset g0 (16-byte aligned) sits at its byte 0 */
           const uint32_t g0 = base & ~15u;
 #pragma unroll
@@ -1175,7 +1201,7 @@ __global__ void __launch_bounds__(WAVES * 64)
         }
         ACHIP_SSTAMP(7);
         first_block = false;
-        if (blk == nblk - 1 && lane == 0) {
+        if (PH == 0 && blk == nblk - 1 && lane == 0) {
           out_len[fidx] = ok ? base + total : ACHIP_LEN_OVERFLOW;
           if (ok && (uint64_t)base + total < out_stride)
             dst[base + total] = 0; /* NUL behind the frame when the slot has room, as the reference's strings carry */
@@ -1185,12 +1211,46 @@ __global__ void __launch_bounds__(WAVES * 64)
       }
     };
 #ifdef ACHIP_STREAM_COUNT_LM /* instruction-count builds (scripts/isa_lines.py --loop): the lane-major copy alone */
-    lean_loop(StreamTagCached{});
+    lean_loop(StreamTagCached{}, StreamPhase<0>{});
 #else
+    if constexpr (LF) {
+      if (src.nt)
+        lean_loop(StreamTagNT{}, StreamPhase<1>{});
+      else
+        lean_loop(StreamTagCached{}, StreamPhase<1>{});
+      __syncthreads(); /* every block's prefix is in its look-back word */
+      const uint32_t n_total = nblk > 0 ? slot_load(&slots[nblk - 1]) & ACHIP_SLOT_VALUE : first_base;
+      const bool fits = n_total <= cap_bytes;
+      const uint32_t room = fits ? (n_total + 15u) & ~15u : 0u;
+      unsigned long long *offw = lds_ptr<unsigned long long>(L::o_flags);
+      if (tid == 0)
+        offw[0] = agent_fetch_add_u64(&pack.cursor[0], (unsigned long long)room);
+      __syncthreads();
+      const unsigned long long off = offw[0];
+      const bool placed = fits && off + room <= pack.capacity;
+      if (placed) {
+        dst = pack.dst + off;
+        dmis = (uint32_t)(uintptr_t)dst & (ACHIP_DRAIN_ALIGN - 1u) & ~15u;
+        if (first_base > 0u) /* ascii_pad_frame_height's newlines in front */
+          for (uint32_t o = (uint32_t)tid; o < first_base; o += BLOCK)
+            dst[o] = '\n';
+        if (tid >= 64 && tid < 80 && n_total + (uint32_t)(tid - 64) < room) /* the <= 15 bytes of padding leave as zeros */
+          dst[n_total + (uint32_t)(tid - 64)] = 0;
+        if (src.nt)
+          lean_loop(StreamTagNT{}, StreamPhase<2>{});
+        else
+          lean_loop(StreamTagCached{}, StreamPhase<2>{});
+      }
+      if (tid == 0) {
+        out_len[fidx] = placed ? n_total : ACHIP_LEN_OVERFLOW;
+        pack_report(off, placed ? n_total : ACHIP_LEN_OVERFLOW);
+      }
+      return;
+    }
     if (src.nt)
-      lean_loop(StreamTagNT{});
+      lean_loop(StreamTagNT{}, StreamPhase<0>{});
     else
-      lean_loop(StreamTagCached{});
+      lean_loop(StreamTagCached{}, StreamPhase<0>{});
 #endif
   } else {
     for (int blk = b0 + wave; blk < b1; blk += WAVES) {

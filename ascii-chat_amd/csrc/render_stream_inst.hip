@@ -261,6 +261,38 @@ extern "C" int ACHIP_CAT(achipk_render_sinst_pack_launch_, ACHIP_SINST)(int mode
 }
 #endif
 
+#if ACHIP_SINST == 16 || ACHIP_SINST == 17
+/* LENGTH-FIRST: exact-length truecolor frames of any size in ONE launch, the lean loop run twice (render_stream.hpp LF);
+ * `stride` only bounds a frame's length */
+extern "C" int ACHIP_CAT(achipk_render_sinst_lenfirst_launch_, ACHIP_SINST)(const achip_frame_t *frames, int n, const achip_lut_t *lut,
+                                                                            uint64_t stride, uint32_t *len, const achip_uniform_t *uniform,
+                                                                            const achip_packdev_t *pack, void *stream) {
+  achip_uniform_t uni = {};
+  if (uniform && uniform->enabled)
+    uni = *uniform;
+  if (uniform)
+    uni.flags = uniform->flags;
+  if (!pack || !pack->dst || !pack->cursor || !(uni.flags & ACHIP_UNIFORM_PALETTE_ASCII))
+    return (int)hipErrorInvalidValue;
+  using L = achip::SLds<ACHIP_MODE_TRUE_FG, G::WAVES, G::CPL, false>;
+  auto kern = achip::render_stream_kernel<ACHIP_MODE_TRUE_FG, G::WAVES, G::CPL, false, false, 0, false, true>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (L::bytes > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, L::bytes);
+      if (e != hipSuccess)
+        return (int)e;
+    }
+    attr_set = true;
+  }
+  const size_t lds = (size_t)((L::bytes_for(achip::stream_maxblk(uni.flags, L::EFF)) + 15) & ~15);
+  hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(G::WAVES * 64), lds, static_cast<hipStream_t>(stream), frames, lut,
+                     static_cast<uint8_t *>(nullptr), stride, len, n, uni, static_cast<unsigned long long *>(nullptr), achip_wire_t{},
+                     static_cast<const uint4 *>(nullptr), *pack, achip_partsdev_t{});
+  return (int)hipGetLastError();
+}
+#endif
+
 #if ACHIP_SINST == 18
 extern "C" int achipk_render_sinst_parts_launch_18(int mode, int comp, const achip_frame_t *frames, int n, const achip_lut_t *lut,
                                                   uint8_t *out, uint64_t stride, uint32_t *len, const achip_uniform_t *uniform,

@@ -401,6 +401,16 @@ int asciichat_hip_plan_render_packets_packed(asciichat_hip_plan_t *plan, uint8_t
                                              uint32_t *out_len_dev, const uint32_t *dims_dev, uint32_t *crc_out_dev,
                                              uint8_t *hdr_out_dev, uint32_t *packet_crc_out_dev, uint8_t *dst,
                                              size_t dst_capacity, uint64_t *off_out, uint32_t *len_out, void *stream);
+/* Exact-length frames beyond the 48 KB of the one-launch form above: LENGTH-FIRST -- the stream kernel's loop run twice,
+ * lengths first, then the emission at the place the frame claimed (whole-frame plans of truecolor foreground with an all-ASCII
+ * palette; ASCIICHAT_HIP_ERR_NOT_SUPPORTED otherwise).  Frames land in completion order (off_out[i], 16-byte aligned;
+ * off_out[n] = total), lengths in out_len_dev / len_out.  plan_render_packed / plan_render_packets_packed take this form by
+ * themselves for plans whose sources are the sampled images (ratio 1.0: 16.5 us against 34.5 for render + pack pass per 256
+ * frames of 200x60; from full-size sources the second gather costs more than the pass -- profiles/r06_length_first_ab.txt);
+ * plan_set_exact_length(1) forces it wherever it applies, 0 turns it off. */
+int asciichat_hip_plan_render_length_first(asciichat_hip_plan_t *plan, uint32_t *out_len_dev, uint8_t *dst, size_t dst_capacity,
+                                           uint64_t *off_out, uint32_t *len_out, void *stream);
+int asciichat_hip_plan_get_length_first(const asciichat_hip_plan_t *plan); /* 1: the packed entry points may take that form for this plan */
 /* Which form plan_render_crc / plan_render_packets take: -1 (default) the fused one where it is the faster form (the
  * per-cell modes' stream kernel -- for a small launch whose render is shared out over workgroups only while a wave has one
  * block: fusing means one workgroup per frame, and a lone 320x90 frame then takes 116 us where render + stand-alone pass

@@ -101,7 +101,7 @@ def main():
         scratch = int(k.get("private_segment_fixed_size", 0))
         limit, why = None, ""
         m = re.search(r"render_frames_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb([01])ELb([01])E", name)
-        ms = re.search(r"render_stream_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb([01])ELb([01])ELi(\d+)ELb([01])E", name)
+        ms = re.search(r"render_stream_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb([01])ELb([01])ELi(\d+)ELb([01])ELb([01])E", name)
         mr = re.search(r"render_rows_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb([01])ELb([01])E", name)
         if mr:
             mode, waves, cpl = int(mr.group(1)), int(mr.group(2)), int(mr.group(3))
@@ -120,12 +120,14 @@ def main():
             crc, pack = ms.group(5) == "1", int(ms.group(6))
             short = (f"render_stream_kernel<mode {mode}, {waves} waves, {cpl} cells/lane, generic {ms.group(4)}"
                      f"{', +crc' if crc else ''}{', exact-length frames' if pack else ''}{' + frame crc' if pack == 2 else ''}"
-                     f"{', frames shared out' if ms.group(7) == '1' else ''}>")
+                     f"{', frames shared out' if ms.group(7) == '1' else ''}{', length-first' if ms.group(8) == '1' else ''}>")
             if crc or pack:  # the checksum's 16-byte groups are in flight next to the following block's samples; the
                              # exact-length form stages a whole frame in LDS: one 16-wave workgroup per CU either way
                 limit, why = 128, "4 waves per SIMD: one 16-wave or two 8-wave workgroups per CU (LDS allows no more)"
             elif ms.group(7) == "1":  # shared-out frames are small launches: a few four-wave workgroups per CU, all resident
                 limit, why = 72, "7 waves per SIMD (small launches: every workgroup is resident anyway)"
+            elif ms.group(8) == "1":  # exact-length frames, the loop run twice: its own instantiation so that the plain one keeps 8
+                limit, why = 72, "7 waves per SIMD"
             else:
                 # (mode 17 = truecolor foreground with multi-byte glyphs, ACHIP_STREAM_MODE_TRUE_FG_U8: its RLE-state chain next
                 # to the tokens; 4 = truecolor background)

@@ -204,6 +204,37 @@ def render_frames_packed(mode, frames, palette, variant=16, stride=None, dims=No
     return dict(lens=ln, off=off, plen=plen, dst=view, crc=crc, hdr=hdr, pkt=pkt, cursor=cur, stride=stride)
 
 
+def render_frames_length_first(frames, palette, variant=17, stride=None, capacity=None, cursor=None, uniform=False):
+    """The stream kernel's LENGTH-FIRST instantiation (exact-length truecolor-foreground frames of any size in one launch):
+    dict(lens, off, plen, dst, cursor, stride) as render_frames_packed."""
+    L = lib()
+    L.emu_render_stream_lenfirst.restype = C.c_int
+    L.emu_render_stream_lenfirst.argtypes = [C.c_int, C.POINTER(Frame), C.c_int, C.POINTER(Lut), C.c_uint64, C.c_void_p, C.c_void_p,
+                                             C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+    n = len(frames)
+    arr = (Frame * n)(*frames)
+    lut = make_lut(palette)
+    if stride is None:
+        stride = max(int(L.achip_out_bound(1, C.byref(arr[i]))) for i in range(n))
+        stride = (stride + 1 + 15) // 16 * 16
+    cap = n * stride if capacity is None else capacity
+    raw = np.full(n * stride + 64 + 256, 0xEE, dtype=np.uint8)
+    base = (raw.ctypes.data + 15) // 16 * 16
+    ln = np.zeros(n, dtype=np.uint32)
+    off = np.zeros(n + 1, dtype=np.uint64)
+    plen = np.zeros(n, dtype=np.uint32)
+    cur = np.zeros(2, dtype=np.uint64) if cursor is None else cursor
+    L.emu_set_uniform(1 if uniform else 0)
+    try:
+        rc = L.emu_render_stream_lenfirst(variant, arr, n, C.byref(lut), stride, ln.ctypes.data, base, cap, off.ctypes.data,
+                                          plen.ctypes.data, cur.ctypes.data)
+    finally:
+        L.emu_set_uniform(0)
+    assert rc == 0
+    view = np.ctypeslib.as_array((C.c_uint8 * (n * stride + 16)).from_address(base)).copy()
+    return dict(lens=ln, off=off, plen=plen, dst=view, cursor=cur, stride=stride)
+
+
 def frame_for_convert(img, width, height, render_mode, wants_padding=False, use_aspect=False, stretch=False):
     assert img.flags["C_CONTIGUOUS"] and img.dtype == np.uint8, "the descriptor takes the array's address: tightly packed RGB24"
     f = Frame()

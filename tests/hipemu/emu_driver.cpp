@@ -249,6 +249,39 @@ extern "C" int emu_render_stream_pack(int mode, int variant, const achip_frame_t
   return -1;
 }
 
+/* the stream kernel's LENGTH-FIRST instantiation (render_stream.hpp LF): exact-length truecolor frames of any size in one
+ * launch, the lean loop run twice; `stride` only bounds a frame's length */
+template <int WAVES, int CPL>
+static void run_stream_lenfirst(const achip_frame_t *frames, int n, const achip_lut_t *lut, uint64_t stride, uint32_t *len,
+                                const achip_packdev_t &pack) {
+  using L = achip::SLds<ACHIP_MODE_TRUE_FG, WAVES, CPL>;
+  achip_uniform_t uni = {};
+  if (g_uniform)
+    (void)achip_frames_uniform(frames, n, &uni);
+  uni.flags = ACHIP_UNIFORM_PALETTE_ASCII | ACHIP_UNIFORM_MAX_CELLS(achip_max_cells(frames, n));
+  const size_t lds = (size_t)((L::bytes_for(achip::stream_maxblk(uni.flags, L::EFF)) + 15) & ~15);
+  hipemu::launch(dim3((unsigned)n), dim3(WAVES * 64), lds, [&] {
+    achip::render_stream_kernel<ACHIP_MODE_TRUE_FG, WAVES, CPL, false, false, 0, false, true>(frames, lut, nullptr, stride, len, n, uni, nullptr,
+                                                                                            achip_wire_t{}, nullptr, pack, achip_partsdev_t{});
+  });
+}
+extern "C" int emu_render_stream_lenfirst(int variant, const achip_frame_t *frames, int n, const achip_lut_t *lut, uint64_t stride,
+                                          uint32_t *len, uint8_t *dst, uint64_t capacity, uint64_t *off_out, uint32_t *len_out,
+                                          unsigned long long *cursor) {
+  const achip_packdev_t pack = {dst, capacity, off_out, len_out, cursor};
+  if (needs_generic(frames, n) || (lut->flags & ACHIP_LUT_MULTIBYTE))
+    return -1;
+  if (variant == 20)
+    run_stream_lenfirst<2, 1>(frames, n, lut, stride, len, pack);
+  else if (variant == 16)
+    run_stream_lenfirst<16, 2>(frames, n, lut, stride, len, pack);
+  else if (variant == 17)
+    run_stream_lenfirst<8, 2>(frames, n, lut, stride, len, pack);
+  else
+    return -1;
+  return 0;
+}
+
 /* the rows kernel (render_rows.hpp): run-structured modes, whole frames; wire != nullptr: its CRC instantiation */
 template <int MODE, int WAVES, int CPL, bool CRC>
 static void run_rows(int variant, const achip_frame_t *frames, int n, const achip_lut_t *lut, uint8_t *out, uint64_t stride,

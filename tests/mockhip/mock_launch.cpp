@@ -142,6 +142,34 @@ extern "C" int achip_launch_render_pack(int mode, int variant, const achip_frame
   return rc == 0 ? MOCK_OK : MOCK_INVALID;
 }
 
+extern "C" int emu_render_stream_lenfirst(int variant, const achip_frame_t *frames, int n, const achip_lut_t *lut, uint64_t stride,
+                                          uint32_t *len, uint8_t *dst, uint64_t capacity, uint64_t *off_out, uint32_t *len_out,
+                                          unsigned long long *cursor);
+extern "C" int achip_launch_render_length_first(int variant, const achip_frame_t *frames, int n, const achip_lut_t *lut, uint64_t bound,
+                                                uint32_t *out_len, const achip_uniform_t *uniform, const achip_packdev_t *pack,
+                                                void *stream) {
+  (void)uniform, (void)stream;
+  if (n <= 0)
+    return MOCK_OK;
+  if (!pack || !pack->dst || !pack->cursor)
+    return MOCK_INVALID;
+  std::lock_guard<std::mutex> lock(g_emu_mu);
+  const int rc = emu_render_stream_lenfirst(variant == 16 ? 16 : 17, frames, n, lut, bound, out_len, pack->dst, pack->capacity, pack->off_out,
+                                            pack->len_out, pack->cursor);
+  return rc == 0 ? MOCK_OK : MOCK_INVALID;
+}
+/* checksums of frames that lie packed at base + at[i]: frame by frame through the emulated stand-alone kernels */
+extern "C" int achip_launch_crc32c_at(const uint8_t *base, const uint64_t *at, const uint32_t *len, uint32_t max_len, int n, uint32_t *partial,
+                                      uint32_t *counters, const uint32_t *dims, uint32_t *crc_out, uint8_t *hdr_out, uint32_t *pkt_out,
+                                      void *stream) {
+  (void)partial, (void)counters, (void)stream;
+  std::lock_guard<std::mutex> lock(g_emu_mu);
+  for (int i = 0; i < n; i++)
+    emu_crc32c(base + (len[i] < 0xFFFFFFF0u ? at[i] : 0), 0, len + i, 0, max_len, 1, 0, 0, dims ? dims + 2 * i : nullptr, crc_out + i,
+               hdr_out ? hdr_out + 24 * i : nullptr, pkt_out ? pkt_out + i : nullptr);
+  return MOCK_OK;
+}
+
 /* image-space passes and composites, with the launchers' own choice between the vector and the per-pixel kernels */
 extern "C" int achip_launch_tint(uint8_t *px, int w, int h, int stride, uint32_t ops, void *stream) {
   (void)stream;

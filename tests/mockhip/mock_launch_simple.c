@@ -79,6 +79,16 @@ int achip_launch_render_pack(int mode, int variant, const achip_frame_t *frames_
       (void)stream;
   return MOCK_UNSUPPORTED;
 }
+int achip_launch_render_length_first(int variant, const achip_frame_t *frames_dev, int n_frames, const achip_lut_t *lut_dev, uint64_t bound,
+                                     uint32_t *out_len, const achip_uniform_t *uniform, const achip_packdev_t *pack, void *stream) {
+  (void)variant, (void)frames_dev, (void)n_frames, (void)lut_dev, (void)bound, (void)out_len, (void)uniform, (void)pack, (void)stream;
+  return MOCK_UNSUPPORTED;
+}
+int achip_launch_crc32c_at(const uint8_t *base, const uint64_t *at, const uint32_t *len, uint32_t max, int n, uint32_t *partial,
+                           uint32_t *counters, const uint32_t *dims, uint32_t *crc, uint8_t *hdr, uint32_t *pkt, void *s) {
+  (void)base, (void)at, (void)len, (void)max, (void)n, (void)partial, (void)counters, (void)dims, (void)crc, (void)hdr, (void)pkt, (void)s;
+  return MOCK_UNSUPPORTED;
+}
 int achip_pack_frame_cap(void) { return 0; } /* no such kernels here: plans keep the two-pass forms */
 int achip_launch_packets_from_crc(const uint32_t *a, const uint32_t *b, const uint32_t *c, int n, uint8_t *h, uint32_t *p, void *s) {
   (void)a, (void)b, (void)c, (void)n, (void)h, (void)p, (void)s;

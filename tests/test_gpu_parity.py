@@ -1301,6 +1301,76 @@ def test_exact_length_frames_full_batch(gpu):
         plan.close()
 
 
+def test_length_first_exact_length_frames_through_the_plan(gpu):
+    """Frames beyond the 48 KB of the LDS-image form leave ONE launch at their exact lengths (render_stream.hpp LF, round 6):
+    plan_render_packed / plan_render_packets_packed take the form by themselves for sampled-image (dense) sources, on request
+    (set_exact_length 1) for any single source, never without off_out; bytes, lengths, checksums, headers and packet CRCs equal
+    those of render + pass, frames tile the destination (completion order)."""
+    pkg, torch = gpu
+    stream = torch.cuda.current_stream().cuda_stream
+    W, H, n = 200, 60, 200  # (from three quarters of a frame per CU on, plans launch whole frames: the form's precondition)
+    dense = [orc.frame_hash_noise(W, H, 70 + i) for i in range(24)]
+    dense[3][:] = 0
+    dense[4] = orc.frame_smooth(W, H)
+    big = [orc.frame_hash_noise(1920, 1080, 7 + i) for i in range(5)]
+    for pool, auto_takes_it in ((dense, True), (big, False)):
+        dev = [torch.from_numpy(np.ascontiguousarray(i)).cuda() for i in pool]
+        imgs = [pool[i % len(pool)] for i in range(n)]
+        frames = [pkg.frame_setup(dev[i % len(pool)].data_ptr(), imgs[i].shape[1], imgs[i].shape[0], W, H, 0, False, False, False) for i in range(n)]
+        m = len(frames)
+        want_pool = [orc.convert_with_caps(i, W, H, 3, 0, False, False, False) for i in pool]
+        want = [want_pool[i % len(pool)] for i in range(n)]
+        plan = pkg.Plan(MODE_TRUE_FG, orc.PALETTE_STANDARD, frames)
+        assert plan.stride > 48 * 1024 and 16 <= plan.variant <= 17
+        dims = torch.tensor([[W, H]] * m, dtype=torch.int32, device="cuda")
+        ref = None
+        for setting in (0, -1, 1):
+            plan.set_exact_length(setting)
+            for wire in (False, True):
+                slab = torch.full((m * plan.stride,), 0xEE, dtype=torch.uint8, device="cuda")
+                ln = torch.zeros(m, dtype=torch.int32, device="cuda")
+                crc = torch.zeros(m, dtype=torch.int32, device="cuda")
+                hdr = torch.zeros(m * 24, dtype=torch.uint8, device="cuda")
+                pkt = torch.zeros(m, dtype=torch.int32, device="cuda")
+                dst = torch.full((m * plan.stride,), 0xEE, dtype=torch.uint8, device="cuda")
+                off = torch.zeros(m + 1, dtype=torch.int64, device="cuda")
+                plen = torch.zeros(m, dtype=torch.int32, device="cuda")
+                for _ in range(2):  # the second call runs on the cursor words the first one re-armed
+                    if wire:
+                        plan.render_packets_packed(slab.data_ptr(), plan.stride, ln.data_ptr(), dims.data_ptr(), crc.data_ptr(), hdr.data_ptr(),
+                                                   pkt.data_ptr(), dst.data_ptr(), dst.numel(), off.data_ptr(), plen.data_ptr(), stream)
+                    else:
+                        plan.render_packed(slab.data_ptr(), plan.stride, ln.data_ptr(), dst.data_ptr(), dst.numel(), off.data_ptr(), plen.data_ptr(), stream)
+                    torch.cuda.synchronize()
+                o, l, d = off.cpu().numpy().astype(np.uint64), plen.cpu().numpy().astype(np.uint32), dst.cpu().numpy()
+                one_launch = bool((slab.cpu().numpy() == 0xEE).all())  # the slab is never written by the length-first form
+                assert one_launch == (setting == 1 or (setting == -1 and auto_takes_it)), (setting, wire, auto_takes_it)
+                spans = sorted((int(o[i]), int(o[i]) + (len(want[i]) + 15) // 16 * 16) for i in range(m))
+                assert spans[0][0] == 0 and all(spans[i][1] == spans[i + 1][0] for i in range(m - 1)) and spans[-1][1] == int(o[m])
+                for i in range(m):
+                    assert int(l[i]) == len(want[i]) and d[int(o[i]):int(o[i]) + int(l[i])].tobytes() == want[i], (setting, wire, i)
+                if wire:
+                    got = (crc.cpu().numpy().tobytes(), hdr.cpu().numpy().tobytes(), pkt.cpu().numpy().tobytes())
+                    if ref is None:
+                        ref = got
+                        cc = crc.cpu().numpy().astype(np.uint32)
+                        for i in range(len(pool)):
+                            assert int(cc[i]) == orc.crc32c(want[i]), i
+                    assert got == ref, (setting, "checksums / headers / packet CRCs")
+        # without off_out the documented (ordered) two-pass layout stays, whatever the setting
+        plan.set_exact_length(1)
+        slab = torch.full((m * plan.stride,), 0xEE, dtype=torch.uint8, device="cuda")
+        ln = torch.zeros(m, dtype=torch.int32, device="cuda")
+        dst = torch.zeros(m * plan.stride, dtype=torch.uint8, device="cuda")
+        plan.render_packed(slab.data_ptr(), plan.stride, ln.data_ptr(), dst.data_ptr(), dst.numel(), 0, 0, stream)
+        torch.cuda.synchronize()
+        d, pos = dst.cpu().numpy(), 0
+        for i in range(m):
+            assert d[pos:pos + len(want[i])].tobytes() == want[i], i
+            pos += (len(want[i]) + 15) // 16 * 16
+        plan.close()
+
+
 def test_packed_without_offsets_keeps_the_documented_order(gpu):
     """A caller that passes no off_out relies on pack_frames' layout (frame i behind the 16-byte rounded lengths of the
     frames before it).  The one-launch form lays frames out in completion order, so such a call must not take it -- not by
@@ -1586,7 +1656,7 @@ def test_render_packets_packed_one_pass(gpu):
     cases = [  # mode, render_mode, source, (w, h) list, forced variant
         (1, 0, src, [(80, 24), (60, 7), (1, 1), (40, 30), (80, 24), (33, 11)], -1),  # frames <= 48 KB: ONE launch, exact lengths
         (2, 0, src, [(80, 24), (100, 20), (5, 5)], 17),                 # ... also from a 512-thread plan (the launch is geometry 16)
-        (1, 0, src, [(80, 24), (60, 7), (1, 1), (132, 43)], 17),        # a 136 KB bound: fused CRC render + pack
+        (1, 0, src, [(80, 24), (60, 7), (1, 1), (132, 43)], 17),        # a 136 KB bound: length-first (forced below) + checksums in place
         (5, 2, src, [(80, 24), (100, 37), (33, 17), (80, 24)], -1),     # rows kernel / bands: one pass, frames < 128 KB
         (0, 0, src, [(80, 24), (200, 60), (10, 5)], -1),
         (5, 2, big, [(400, 120), (380, 100), (80, 24)], -1),            # 1.8 MB frames: the span kernels
@@ -1622,8 +1692,8 @@ def test_render_packets_packed_one_pass(gpu):
         off_a, off_b = va[:8 * (n + 1)].view(np.uint64), vb[:8 * (n + 1)].view(np.uint64)
         la = va[8 * (n + 1):8 * (n + 1) + 4 * n].view(np.uint32)
         assert np.array_equal(la, vb[8 * (n + 1):8 * (n + 1) + 4 * n].view(np.uint32))
-        one_launch = plan.exact_length
-        assert one_launch == (case_no < 2), (case_no, plan.stride)
+        one_launch = plan.exact_length or plan.length_first  # (frames beyond 48 KB: the length-first form, round 6)
+        assert plan.exact_length == (case_no < 2) and plan.length_first == (case_no == 2), (case_no, plan.stride)
         if one_launch:
             # the render wrote the frames itself: the slab was never touched, the frames tile the destination in SOME order
             assert bool((out_b == 0xEE).all())

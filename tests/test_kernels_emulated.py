@@ -359,6 +359,49 @@ def test_stream_kernel_lean_loop_orders_and_samplers(variant):
     del rng
 
 
+@pytest.mark.parametrize("variant", [20, 16, 17])
+def test_stream_kernel_length_first_exact_length_frames(variant):
+    """LENGTH-FIRST (render_stream.hpp LF; lib/network/acip/server.c:190-222 ships exactly frame_size bytes): frames of any
+    size leave ONE launch at their exact lengths -- the lean loop runs twice, lengths first.  Every frame against the oracle;
+    frames tile the destination in 16-byte-rounded pieces (completion order), the padding bytes are zero, nothing is written
+    behind the total; both cell orders, padding, a ragged batch, frames far beyond the 48 KB of the LDS-image form; a frame
+    that does not fit its bound and a destination that is too small are reported; the cursor re-arms."""
+    wide = orc.frame_hash_noise(1920, 54, 11)
+    dense = orc.frame_hash_noise(200, 60, 5)
+    imgs = [TORTURE, wide, dense, orc.frame_bars(64, 48, 3), orc.frame_smooth(33, 17), orc.frame_hash_noise(80, 24, 9)]
+    dims = [(97, 31), (80, 24), (200, 60), (17, 9), (33, 40), (80, 24)]
+    if variant == 20:
+        imgs, dims = imgs + [TORTURE], dims + [(200, 60)]
+    for pad in (False, True):
+        frames = [emu.frame_for_convert(im, w, h, 0, pad, pad) for im, (w, h) in zip(imgs, dims)]
+        want = [oracle_convert(im, MODE_TRUE_FG, w, h, orc.PALETTE_STANDARD, pad, pad) for im, (w, h) in zip(imgs, dims)]
+        cur = np.zeros(2, dtype=np.uint64)
+        for rep in range(2):  # the second launch runs on the cursor words the first one left
+            r = emu.render_frames_length_first(frames, orc.PALETTE_STANDARD, variant, cursor=cur)
+            n = len(frames)
+            spans = sorted((int(r["off"][i]), int(r["off"][i]) + (len(want[i]) + 15) // 16 * 16) for i in range(n))
+            assert spans[0][0] == 0 and all(spans[i][1] == spans[i + 1][0] for i in range(n - 1)) and spans[-1][1] == int(r["off"][n])
+            for i in range(n):
+                o = int(r["off"][i])
+                assert int(r["lens"][i]) == int(r["plen"][i]) == len(want[i]), (variant, pad, i)
+                assert r["dst"][o:o + len(want[i])].tobytes() == want[i], (variant, pad, i)
+                assert not r["dst"][o + len(want[i]):o + (len(want[i]) + 15) // 16 * 16].any()
+            assert (r["dst"][int(r["off"][n]):int(r["off"][n]) + 16] == 0xEE).all()
+            assert int(cur[0]) == 0 and int(cur[1]) == 0
+    # the batch's descriptor by value
+    f = emu.frame_for_convert(dense, 200, 60, 0)
+    r = emu.render_frames_length_first([f] * 3, orc.PALETTE_STANDARD, variant, uniform=True)
+    exp = oracle_convert(dense, MODE_TRUE_FG, 200, 60, orc.PALETTE_STANDARD)
+    for i in range(3):
+        o = int(r["off"][i])
+        assert r["dst"][o:o + len(exp)].tobytes() == exp
+    # a frame beyond its bound, and a destination that cannot hold every frame
+    r = emu.render_frames_length_first([f, emu.frame_for_convert(TORTURE, 17, 9, 0)], orc.PALETTE_STANDARD, variant, stride=4096)
+    assert int(r["lens"][0]) == 0xFFFFFFFF and int(r["lens"][1]) == len(oracle_convert(TORTURE, MODE_TRUE_FG, 17, 9, orc.PALETTE_STANDARD))
+    r = emu.render_frames_length_first([f, f], orc.PALETTE_STANDARD, variant, capacity=(len(exp) + 15) // 16 * 16 + 64)
+    assert sorted(int(x) for x in r["lens"]) == [len(exp), 0xFFFFFFFF]
+
+
 @pytest.mark.parametrize("mode", STREAM_MODES, ids=["true_fg", "256_fg", "16_fg", "true_bg"])
 def test_stream_kernel_frames_shared_out_over_workgroups(mode):
     """PARTS instantiations (render_stream.hpp): a frame's blocks shared out over several workgroups that hand their

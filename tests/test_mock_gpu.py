@@ -321,6 +321,57 @@ def test_wire_stage_on_the_mock(mock):
         plan.close()
 
 
+def test_length_first_exact_length_frames_on_the_mock(mock):
+    """plan.c's choice of the LENGTH-FIRST form (frames beyond the 48 KB of the LDS-image form; render_stream.hpp LF): by itself
+    for dense sources (the sampled images: ratio 1.0), on request for any single source, never without off_out; checksums,
+    headers and packet CRCs of the frames where they lie (crc32c over offsets) equal those of render + pass."""
+    W, H = 200, 60
+    for dense in (True, False):
+        imgs = [orc.frame_hash_noise(W if dense else 333, H if dense else 201, 90 + i) for i in range(3)]
+        keep = [np.ascontiguousarray(im) for im in imgs]
+        frames = [mock.frame_setup(k.ctypes.data, k.shape[1], k.shape[0], W, H, 0, False, False, False) for k in keep]
+        want = [orc.convert_with_caps(im, W, H, 3, 0, False, False, False) for im in imgs]
+        plan = mock.Plan(1, orc.PALETTE_STANDARD, frames)
+        plan.set_variant(17)  # (whole frames: three frames alone would be cut into row bands)
+        assert not plan.exact_length and plan.length_first and plan.stride > 48 * 1024
+        n, stride = len(frames), plan.stride
+        d32 = np.array([(W, H)] * n, dtype=np.uint32)
+        ref = None
+        for setting in (0, -1, 1):
+            plan.set_exact_length(setting)
+            assert plan.length_first == (setting != 0)
+            for wire in (False, True):
+                slab = np.zeros(n * stride, dtype=np.uint8)
+                ln, crc, hdr, pkt = np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.zeros(24 * n, np.uint8), np.zeros(n, np.uint32)
+                dst = np.zeros(n * stride + 16, dtype=np.uint8)
+                dbase = dst.ctypes.data + (-dst.ctypes.data % 16)
+                off, lo = np.zeros(n + 1, np.uint64), np.zeros(n, np.uint32)
+                if wire:
+                    plan.render_packets_packed(slab.ctypes.data, stride, ln.ctypes.data, d32.ctypes.data, crc.ctypes.data, hdr.ctypes.data,
+                                               pkt.ctypes.data, dbase, n * stride, off.ctypes.data, lo.ctypes.data)
+                else:
+                    plan.render_packed(slab.ctypes.data, stride, ln.ctypes.data, dbase, n * stride, off.ctypes.data, lo.ctypes.data)
+                assert (not slab.any()) == (setting == 1 or (setting == -1 and dense)), (dense, setting, wire)
+                dv = np.ctypeslib.as_array((C.c_uint8 * (n * stride)).from_address(dbase))
+                for i in range(n):
+                    assert int(ln[i]) == int(lo[i]) == len(want[i]) and int(off[i]) % 16 == 0
+                    assert dv[int(off[i]):int(off[i]) + len(want[i])].tobytes() == want[i], (dense, setting, wire, i)
+                if wire:
+                    for i in range(n):
+                        assert int(crc[i]) == orc.crc32c(want[i])
+                        h = struct.pack(">IIIIII", W, H, len(want[i]), 0, int(crc[i]), 0)
+                        assert hdr[24 * i:24 * i + 24].tobytes() == h and int(pkt[i]) == orc.crc32c(h + want[i])
+        plan.set_exact_length(1)  # no off_out: the ordered two-pass layout, whatever the setting
+        slab, ln, dst = np.zeros(n * stride, np.uint8), np.zeros(n, np.uint32), np.zeros(n * stride, np.uint8)
+        plan.render_packed(slab.ctypes.data, stride, ln.ctypes.data, dst.ctypes.data, dst.size, None, None)
+        at = 0
+        for i in range(n):
+            assert dst[at:at + len(want[i])].tobytes() == want[i] and slab[i * stride:i * stride + len(want[i])].tobytes() == want[i]
+            at += (len(want[i]) + 15) & ~15
+        plan.close()
+        del ref
+
+
 def test_frame_table_publish_forms_on_the_mock(mock):
     """frame_table.c on the CPU: whole blobs, sampled rows, a tick's sampled pixels in one batch (the targets are the render
     descriptors of clients of three geometries), single-slot and batch publishes alternating on the same slots,
