@@ -633,6 +633,22 @@ class Comm:
             raise RuntimeError(f"comm_all_gather_packed failed ({rc}): {last_error()}")
         return list(off), list(ln), blk.value
 
+    def all_gather_frames(self, slab_ptr, stride, len_ptr, slots_per_rank, packed_ptr, capacity_per_rank, form=-1, stream=0):
+        """Both gathers behind one entry (form 0 packed, 1 slab, -1: ASCIICHAT_HIP_GATHER) ->
+        (base pointer, offsets[world*slots], lengths[world*slots] or None, bytes every rank contributed, form taken)"""
+        L = lib()
+        L.asciichat_hip_comm_all_gather_frames.restype = C.c_int
+        L.asciichat_hip_comm_all_gather_frames.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p,
+                                                           C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32),
+                                                           C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.c_void_p]
+        n = self.world * slots_per_rank
+        off, ln, blk, base, took = (C.c_uint64 * n)(), (C.c_uint32 * n)(), C.c_size_t(), C.c_void_p(), C.c_int()
+        rc = L.asciichat_hip_comm_all_gather_frames(self._h, form, slab_ptr, stride, len_ptr, slots_per_rank, packed_ptr, capacity_per_rank,
+                                                    C.byref(base), off, ln, C.byref(blk), C.byref(took), stream)
+        if rc != 0:
+            raise RuntimeError(f"comm_all_gather_frames failed ({rc}): {last_error()}")
+        return base.value, list(off), (list(ln) if took.value == 0 else None), blk.value, took.value
+
     def all_gather_slab(self, slab_ptr, stride, len_ptr, slots_per_rank, stream=0):
         rc = lib().asciichat_hip_comm_all_gather_slab(self._h, slab_ptr, stride, len_ptr, slots_per_rank, stream)
         if rc != 0:

@@ -309,6 +309,47 @@ int asciichat_hip_comm_all_gather_packed(asciichat_hip_comm_t *c, const uint8_t 
   return rc;
 }
 
+/* "Every rank needs every rank's frames" behind ONE entry, the form picked per call or by the environment -- so that the first
+ * visit to a real multi-GPU node is a one-shot A/B (src/server/render.c:1233: one render thread per client
+ * there, one process per GPU here):
+ *   form 0 / ASCIICHAT_HIP_GATHER=packed   comm_all_gather_packed: lengths first, the host sizes the second collective -- the
+ *                                          bytes in use cross the links, at the price of one stream synchronisation;
+ *   form 1 / ASCIICHAT_HIP_GATHER=slab     comm_all_gather_slab: lengths + the worst-case-stride slab in ONE group -- no host
+ *                                          synchronisation, stride bytes per frame on the links;
+ *   form -1                                what the environment says (default: packed).
+ * Where the frames are afterwards: *base_out + off_host[i] (the slab itself in form 1, packed_dev in form 0); len_host is
+ * filled in form 0 only (form 1 never visits the host: the lengths are in len_dev).  *form_out = the form taken. */
+int asciichat_hip_comm_all_gather_frames(asciichat_hip_comm_t *c, int form, uint8_t *slab_dev, size_t stride, uint32_t *len_dev,
+                                         int slots_per_rank, uint8_t *packed_dev, size_t packed_capacity_per_rank,
+                                         const uint8_t **base_out, uint64_t *off_host, uint32_t *len_host, size_t *block_bytes,
+                                         int *form_out, void *stream) {
+  if (!c || form < -1 || form > 1 || !off_host || slots_per_rank < 0)
+    return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "comm_all_gather_frames: bad arguments");
+  if (form < 0) {
+    const char *e = getenv("ASCIICHAT_HIP_GATHER");
+    form = e && (strcmp(e, "slab") == 0 || strcmp(e, "1") == 0) ? 1 : 0;
+  }
+  if (form_out)
+    *form_out = form;
+  if (form == 0) {
+    if (base_out)
+      *base_out = packed_dev;
+    return asciichat_hip_comm_all_gather_packed(c, slab_dev, stride, len_dev, slots_per_rank, packed_dev, packed_capacity_per_rank,
+                                                off_host, len_host, block_bytes, stream);
+  }
+  const int rc = asciichat_hip_comm_all_gather_slab(c, slab_dev, stride, len_dev, slots_per_rank, stream);
+  if (rc)
+    return rc;
+  const size_t total = (size_t)slots_per_rank * (size_t)c->world;
+  for (size_t i = 0; i < total; i++)
+    off_host[i] = (uint64_t)i * stride;
+  if (base_out)
+    *base_out = slab_dev;
+  if (block_bytes)
+    *block_bytes = (size_t)slots_per_rank * stride;
+  return 0;
+}
+
 /* ------------------------------------------------------------------------------------------- */
 /* the pixel-space grid across GPUs                                                               */
 /* ------------------------------------------------------------------------------------------- */

@@ -473,6 +473,12 @@ def run_grid9(torch, pkg, steps, regions, targets=256, dist=None, world=1, rank=
                  "collective": ("none: plans sample the sources directly, a tick refreshes nine pointers" if direct else
                                 "ncclAllGather of the composite tiles inside every step (C-ABI, comm.c)") if comm else "none (gloo run)",
                  "sources_owned_by_rank0": len(own), "rccl_ranks": comm.count if comm else None}
+        if comm and not direct and label != "nine_targets":
+            # configs[3]'s consumer side: every rank's rendered target frames all-gathered, both forms
+            try:
+                entry["all_gather_of_rendered_frames"] = gather_leg(torch, pkg, comm, plan, nt, world, rank, reps=6)
+            except Exception as e:  # never lose the leg's timing to the optional exchange
+                entry["all_gather_of_rendered_frames"] = {"error": str(e)[:200]}
         if rank == 0 and world == 1:  # the composite every rank renders from is the oracle's, byte for byte
             allsrc = [np.ascontiguousarray(make_frames(torch, 1, sw, sh, 4321 + k)[0].cpu().numpy()) for k in range(n)]
             exp = orc.convert_with_caps(orc.composite(allsrc, tw, th), tw, th, 3, 0, True, True, False)
@@ -900,33 +906,40 @@ def rank_comm(torch, pkg, dist, world, rank, backend):
 
 def gather_leg(torch, pkg, comm, plan, batch, world, rank, reps=10):
     """What a consumer that needs every rank's frames pays: this rank's rendered block all-gathered through
-    comm.c, once at the fixed slab stride and once compacted (lengths first, then max-over-ranks packed bytes)."""
+    comm.c's one entry (asciichat_hip_comm_all_gather_frames) in BOTH forms -- `packed` (lengths first, the host sizes the
+    second collective: the bytes in use cross the links, one stream synchronisation) and `slab` (lengths + worst-case-stride
+    slab in ONE group: no host synchronisation) -- plus which one ASCIICHAT_HIP_GATHER selects (the first
+    visit to a real multi-GPU node is a one-shot A/B)."""
     st = torch.cuda.current_stream().cuda_stream
     stride = plan.stride
     slab = torch.zeros(world * batch * stride, dtype=torch.uint8, device="cuda")
     ln = torch.zeros(world * batch, dtype=torch.int32, device="cuda")
     packed = torch.zeros(world * batch * stride, dtype=torch.uint8, device="cuda")
     mine, mylen = slab.data_ptr() + rank * batch * stride, ln.data_ptr() + 4 * rank * batch
-    out = {}
-    for kind in ("fixed_stride", "packed"):
+    out, where = {}, {}
+    for kind, form in (("slab", 1), ("packed", 0)):
         ts = []
         for _ in range(reps + 2):
             plan.render(mine, stride, mylen, st)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            if kind == "packed":
-                off, lens, blk = comm.all_gather_packed(slab.data_ptr(), stride, ln.data_ptr(), batch, packed.data_ptr(),
-                                                        batch * stride, st)
-            else:
-                comm.all_gather_slab(slab.data_ptr(), stride, ln.data_ptr(), batch, st)
-                blk = batch * stride
+            base, off, lens, blk, took = comm.all_gather_frames(slab.data_ptr(), stride, ln.data_ptr(), batch, packed.data_ptr(),
+                                                                batch * stride, form, st)
             torch.cuda.synchronize()
             ts.append(time.perf_counter() - t0)
-        out[kind] = {"ms": statistics.median(ts[2:]) * 1e3, "bytes_per_rank": int(blk), "bytes_total": int(blk) * world}
+        assert took == form
+        where[kind] = (off, lens)
+        out[kind] = {"ms": statistics.median(ts[2:]) * 1e3, "bytes_per_rank": int(blk), "bytes_total": int(blk) * world,
+                     "host_synchronisations": 1 if form == 0 else 0}
+    out["fixed_stride"] = out["slab"]  # (the key of rounds 2-5)
+    env_form = comm.all_gather_frames(slab.data_ptr(), stride, ln.data_ptr(), batch, packed.data_ptr(), batch * stride, -1, st)[4]
+    torch.cuda.synchronize()
+    out["selected_by_environment"] = {"ASCIICHAT_HIP_GATHER": os.environ.get("ASCIICHAT_HIP_GATHER"), "form": ("packed", "slab")[env_form]}
     # the two must agree: every frame of every rank, byte for byte
     host_s, host_p, hl = slab.cpu().numpy(), packed.cpu().numpy(), ln.cpu().numpy().astype("uint32")
+    off, lens = where["packed"]
     for i in range(0, world * batch, max(1, world * batch // 64)):
-        a = host_s[i * stride:i * stride + int(hl[i])]
+        a = host_s[where["slab"][0][i]:where["slab"][0][i] + int(hl[i])]
         b = host_p[off[i]:off[i] + lens[i]]
         if int(hl[i]) != lens[i] or not (a == b).all():
             raise RuntimeError(f"all-gather legs disagree on frame {i}")

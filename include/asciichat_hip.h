@@ -341,6 +341,14 @@ int asciichat_hip_comm_all_gather_packed(asciichat_hip_comm_t *comm, const uint8
                                          uint32_t *len_dev, int slots_per_rank, uint8_t *packed_dev,
                                          size_t packed_capacity_per_rank, uint64_t *off_host, uint32_t *len_host,
                                          size_t *block_bytes, void *stream);
+/* Both forms behind one entry, picked per call (form 0 = packed, 1 = slab) or by the environment (form -1:
+ * ASCIICHAT_HIP_GATHER=packed|slab, default packed): the frames are at *base_out + off_host[i] afterwards (packed_dev or the
+ * slab itself), len_host is filled by the packed form only (the slab form never visits the host: lengths stay in len_dev),
+ * *form_out says which form ran.  For the first A/B on a real multi-GPU node (bench.py --gpus N prints both). */
+int asciichat_hip_comm_all_gather_frames(asciichat_hip_comm_t *comm, int form, uint8_t *slab_dev, size_t stride, uint32_t *len_dev,
+                                         int slots_per_rank, uint8_t *packed_dev, size_t packed_capacity_per_rank,
+                                         const uint8_t **base_out, uint64_t *off_host, uint32_t *len_host, size_t *block_bytes,
+                                         int *form_out, void *stream);
 /* partition of n independent items: rank's [first, first+count); owner of an item; slots every rank reserves */
 void achip_shard_bounds(int n_items, int world, int rank, int *first, int *count);
 int achip_shard_owner(int n_items, int world, int item);

@@ -91,6 +91,29 @@ def main():
             s = r * slots + i
             assert off[s] % 16 == 0 and r * blk <= off[s] and off[s] + plen[s] <= (r + 1) * blk
             assert ph[off[s]:off[s] + plen[s]].tobytes() == exp[f_r.value + i], f"rank {rank}: packed frame {f_r.value + i} differs"
+    # ---- (2a) both forms behind the one entry: by argument and by the environment (what the first A/B on a real node runs)
+    for form, env in ((0, None), (1, None), (-1, "slab"), (-1, "packed"), (-1, None)):
+        if env is None:
+            os.environ.pop("ASCIICHAT_HIP_GATHER", None)
+        else:
+            os.environ["ASCIICHAT_HIP_GATHER"] = env
+        slab3, ln3 = slab2.clone(), ln2.clone()
+        packed3 = torch.zeros(world * slots * stride, dtype=torch.uint8, device="cuda")
+        base, off3, len3, blk3, took = comm.all_gather_frames(slab3.data_ptr(), stride, ln3.data_ptr(), slots, packed3.data_ptr(),
+                                                             slots * stride, form, st)
+        torch.cuda.synchronize()
+        assert took == (form if form >= 0 else (1 if env == "slab" else 0)), (form, env, took)
+        where = packed3 if took == 0 else slab3
+        assert base == where.data_ptr() and blk3 == (blk if took == 0 else slots * stride)
+        wh, l3 = where.cpu().numpy(), ln3.cpu().numpy().astype("uint32")
+        for r in range(world):
+            f_r, c_r = C.c_int(), C.c_int()
+            L.achip_shard_bounds(n, world, r, C.byref(f_r), C.byref(c_r))
+            for i in range(c_r.value):
+                s = r * slots + i
+                assert (len3 is None) == (took == 1) and (len3 is None or len3[s] == int(l3[s]))
+                assert wh[off3[s]:off3[s] + int(l3[s])].tobytes() == exp[f_r.value + i], f"rank {rank}: form {took} frame {f_r.value + i} differs"
+    os.environ.pop("ASCIICHAT_HIP_GATHER", None)
     plan.close()
     # ---- (2b) frames of configs[4]'s size through the packed gather: 1.8 MB each, one per rank plus one (uneven shards), so
     # that a rank's block spans several of the transport's chunks and the lengths-first sizing sees megabytes
