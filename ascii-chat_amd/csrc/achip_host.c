@@ -534,10 +534,31 @@ long achip_max_cells(const achip_frame_t *frames, int n_frames) {
 
 /* the rows-kernel family (render_variants.h: ACHIP_ROWS_VARIANTS): a block is a whole number of text rows */
 #define ACHIP_HOST_ROWS_FIRST 24
-static int rows_variant_cpl(int variant) { return variant == 24 || variant == 26 ? 7 : variant == 25 ? 4 : variant == 28 ? 2 : 0; }
+static int rows_variant_cpl(int variant) {
+  return variant == 24 || variant == 26 ? 7 : variant == 25 ? 4 : variant == 27 || variant == 29 ? 6 : variant == 28 ? 2 : variant == 30 ? 1 : 0;
+}
+/* the geometries whose blocks are SEGMENTS of a row (render_variants.h ACHIP_ROWS_VARIANT_WIDE; render_rows.hpp WIDE): rows of
+ * at most `waves` segments of 64 * cpl cells, and of at most ACHIP_ROWS_WIDE_MAX_ROW cells */
+#define ACHIP_HOST_ROWS_WIDE_MAX_ROW 4096
+static int rows_variant_wide_waves(int variant) { return variant == 27 ? 16 : variant == 29 ? 8 : variant == 30 ? 4 : 0; }
+/* segments of a padded row of wp cells (the kernel's own arithmetic: equal widths, the last one shorter, never empty) */
+static long rows_wide_segments(long wp, int cpl) {
+  if (wp <= 0)
+    return 0;
+  const long n0 = (wp + 64L * cpl - 1) / (64L * cpl), segw = (wp + n0 - 1) / n0;
+  return (wp + segw - 1) / segw;
+}
+/* the widest padded row a rows geometry takes */
+static int rows_variant_max_row(int variant) {
+  const int cpl = rows_variant_cpl(variant), waves = rows_variant_wide_waves(variant);
+  if (!waves)
+    return 64 * cpl;
+  return 64 * cpl * waves < ACHIP_HOST_ROWS_WIDE_MAX_ROW ? 64 * cpl * waves : ACHIP_HOST_ROWS_WIDE_MAX_ROW;
+}
 
 /* what the ACHIP_UNIFORM_MAX_CELLS field of a launch carries: cells of the largest frame for the stream geometries,
- * BLOCKS of the frame with the most blocks for the rows geometries (rows / (64 * CPL / row width), rounded up) */
+ * BLOCKS of the frame with the most blocks for the rows geometries (rows / (64 * CPL / row width), rounded up; the
+ * geometries that cut rows into segments: rows x segments) */
 long achip_uniform_extent(int mode, int variant, const achip_frame_t *frames, int n_frames) {
   const int cpl = rows_variant_cpl(variant);
   if (!cpl)
@@ -548,7 +569,7 @@ long achip_uniform_extent(int mode, int variant, const achip_frame_t *frames, in
     const long wp = (long)frames[i].pad_left + frames[i].out_w;
     const long rows = hb ? ((long)frames[i].out_h + 1) / 2 : frames[i].out_h;
     const long rpb = wp > 0 ? (64L * cpl) / wp : 0;
-    const long blocks = rpb > 0 ? (rows + rpb - 1) / rpb : 0;
+    const long blocks = rows_variant_wide_waves(variant) ? rows * rows_wide_segments(wp, cpl) : rpb > 0 ? (rows + rpb - 1) / rpb : 0;
     if (blocks > most)
       most = blocks;
   }
@@ -616,9 +637,9 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
   const bool run_mode = (mode == ACHIP_MODE_MONO || hb) && max_src_w <= 21845;
   if (forced_variant >= ACHIP_HOST_ROWS_FIRST) {
     const int cpl = rows_variant_cpl(forced_variant);
-    if (!run_mode || !cpl || max_wp > 64 * cpl || achip_uniform_extent(mode, forced_variant, frames, n_frames) > ACHIP_HOST_STREAM_MAXBLK)
+    if (!run_mode || !cpl || max_wp > rows_variant_max_row(forced_variant) || achip_uniform_extent(mode, forced_variant, frames, n_frames) > ACHIP_HOST_STREAM_MAXBLK)
       return -1;
-    if (forced_variant == 26 && general_sampler) /* (geometry 26 carries the fast sampler only) */
+    if ((forced_variant == 26 || rows_variant_wide_waves(forced_variant)) && general_sampler) /* (geometry 26 and the segment geometries carry the fast sampler only) */
       return -1;
     *variant = forced_variant;
     return 0; /* whole frames only */
@@ -775,6 +796,16 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
     }
     const bool take = n_frames > n_cus ? true : mono ? !(shared_gpu && ext > 8) : (ext <= 8 && !shared_gpu);
     if ((v == 25 || n_frames > n_cus || (mono && max_wp > 256)) && ext <= ACHIP_HOST_STREAM_MAXBLK && take) {
+      *variant = v;
+      return 0;
+    }
+  }
+  /* Rows beyond one block of the rows kernel (448 cells; round 6): cut into segments, a segment per wave (render_rows.hpp
+   * WIDE) -- whole-frame launches of single sources; rows of up to 4096 cells as sixteen-wave workgroups (27), with more
+   * than a frame per CU two eight-wave workgroups per CU (29) while a row is at most eight segments. */
+  if (forced_variant < 0 && run_mode && !may_split && !general_sampler && max_wp > 64 * 7) {
+    const int v = n_frames > n_cus && max_wp <= rows_variant_max_row(29) ? 29 : 27;
+    if (max_wp <= rows_variant_max_row(v) && achip_uniform_extent(mode, v, frames, n_frames) <= ACHIP_HOST_STREAM_MAXBLK) {
       *variant = v;
       return 0;
     }

@@ -115,7 +115,7 @@ extern "C" int achip_launch_render_length_first(int variant, const achip_frame_t
                        : achipk_render_sinst_lenfirst_launch_17(frames_dev, n_frames, lut_dev, bound, out_len, uniform, pack, stream);
 }
 #ifdef ACHIP_ALL_GEOMETRIES
-extern "C" int achip_variant_has_crc(int variant) { return variant == 16 || variant == 17 || (ACHIP_IS_ROWS_VARIANT(variant) && variant != 26); }
+extern "C" int achip_variant_has_crc(int variant) { return variant == 16 || variant == 17 || (ACHIP_IS_ROWS_VARIANT(variant) && variant != 26 && !ACHIP_ROWS_VARIANT_WIDE(variant)); }
 #else
 extern "C" int achip_variant_has_crc(int variant) { return variant == 16 || variant == 17; }
 #endif
@@ -158,9 +158,9 @@ extern "C" int achip_variant_cap(int variant) {
     return ACHIP_STREAM_MAXBLK * 64 * C;
     ACHIP_STREAM_VARIANTS(X)
 #undef X
-#define X(id, W, C) /* rows geometries: cells of the widest padded row a block can hold */                           \
+#define X(id, W, C) /* rows geometries: cells of the widest padded row -- a block's, or W segments of a block each */   \
   case id:                                                                                                             \
-    return 64 * C;
+    return !ACHIP_ROWS_VARIANT_WIDE(id) ? 64 * C : 64 * C * W < ACHIP_ROWS_WIDE_MAX_ROW ? 64 * C * W : ACHIP_ROWS_WIDE_MAX_ROW;
     ACHIP_ROWS_VARIANTS(X)
 #undef X
 #define X(id, B, C, R)                                                                                                 \

@@ -70,7 +70,7 @@ __host__ __device__ constexpr int rows_max_token(int m) {
                                   : 16;  /* mono / mono half blocks: glyph <= 4 + 7 + NL                */
 }
 
-template <int MODE, int WAVES, bool CRC = false> struct RLds {
+template <int MODE, int WAVES, bool CRC = false, bool WIDE = false> struct RLds {
   /* one slice + the 16-byte group it starts in; plain instantiations: + the 128-byte line it starts in (the tail of
    * the slice before it, carried: whole lines leave the wave) + the 128 bytes the carry's move may read behind it */
   static constexpr int STAGE = 64 * rows_max_token(MODE) + (CRC ? 16 : 256);
@@ -106,7 +106,8 @@ template <int MODE, int WAVES, bool CRC = false> struct RLds {
   static constexpr int TAB_BYTES = (CRC ? o_xk + 256 : o_tab) - o_tab;
   static constexpr int o_crcacc = o_tab + TAB_BYTES;
   static constexpr int o_slots = o_crcacc + (CRC ? 16 : 0);
-  static constexpr int bytes_for(int maxblk) { return o_slots + maxblk * 4 * (CRC ? 2 : 1); }
+  /* per block: the look-back word (+ the CRC's) and, WIDE, the segment's summary word (rows_seg_*, below) */
+  static constexpr int bytes_for(int maxblk) { return o_slots + maxblk * 4 * ((CRC ? 2 : 1) + (WIDE ? 1 : 0)); }
   static constexpr int bytes = bytes_for(ACHIP_STREAM_MAXBLK);
   static_assert(STAGE % 16 == 0 && o_tab % 16 == 0 && TAB_BYTES % 16 == 0, "16-byte aligned areas");
   static_assert(bytes <= 160 * 1024, "one workgroup's LDS");
@@ -306,6 +307,68 @@ __device__ inline int rows_next_bit(uint64_t m, const LaneMasks &lm) {
   return lo ? __ffs((int)lo) - 1 : (hi ? 31 + __ffs((int)hi) : -1);
 }
 
+/* ---- WIDE: rows beyond one block (round 6) -------------------------------------------------------------------------------
+ * A padded row of more than 64 * CPL cells is cut into ceil(row / (64 * CPL)) SEGMENTS of equal width (the last one
+ * shorter), block b = segment b % nseg of text row b / nseg, taken by consecutive waves.  A segment decides its own run
+ * heads: beside its cells it samples the cell in front of it and the cell behind it (a GHOST slot: lane 0 / lane 1 of one
+ * more register per array), so "does my first cell continue your last run" is a comparison of two of its own pixels.  What
+ * it cannot know by itself is how far the run it starts in reaches back (its head, the head's transparency) and how far
+ * its last run goes on: every segment publishes ONE LDS word -- cells in front of its first head, cells from its last head
+ * on, that head's transparency, whether its last cell's run goes on behind it -- BEFORE it waits for anything, and only a
+ * segment whose first cell continues a run / whose last run goes on reads its neighbours' words (a frame without flat
+ * areas never waits).  No deadlock: a word of block x is published at the top of x's turn, which follows the turn of
+ * block x - WAVES of the same wave; that turn waits for words of its own row only (blocks < x - WAVES + nseg <= x for
+ * nseg <= WAVES -- the kernel refuses wider rows, the host never sends them) and for byte counts of earlier blocks.
+ * ascii.c:204 admits rows of up to 10 000 cells; a run's repeat count is kept in 12 bits here, so 4 096 (the phase
+ * kernel's limit as well). */
+#ifndef ACHIP_ROWS_WIDE_MAX_ROW
+#define ACHIP_ROWS_WIDE_MAX_ROW 4096 /* (render_variants.h states it for the host as well) */
+#endif
+#define ACHIP_SEG_PUB (1u << 31)
+#define ACHIP_SEG_HAS_HEAD (1u << 18)
+#define ACHIP_SEG_LAST_T (1u << 19)  /* the segment's last head is transparent                        */
+#define ACHIP_SEG_CONT (1u << 20)    /* the run of the segment's last cell goes on in the next segment */
+__host__ __device__ constexpr uint32_t rows_seg_word(uint32_t lead, uint32_t tail, bool has_head, bool last_t, bool cont) {
+  return ACHIP_SEG_PUB | lead | (tail << 9) | (has_head ? ACHIP_SEG_HAS_HEAD : 0u) | (last_t ? ACHIP_SEG_LAST_T : 0u) |
+         (cont ? ACHIP_SEG_CONT : 0u);
+}
+/* a published word of the row (wave-uniform); 0 if it never comes (bounded) */
+__device__ inline uint32_t rows_seg_wait(const uint32_t *sumw, int j) {
+  for (int spin = 0; spin < (1 << 22); spin++) {
+    const uint32_t w = wave_read_lane(slot_load(&sumw[j]), 0); /* (a wave operation: where the emulator's fibers take turns) */
+    if (w & ACHIP_SEG_PUB)
+      return w;
+    spin_nap<1>();
+  }
+  return 0u;
+}
+/* the run that is open where block b starts: {cells of it in front of the block: bits 15..0, its head transparent: bit 16};
+ * 0xFFFFFFFF if a word never comes.  (Never walks past the row's first segment: that one starts with a head.) */
+__device__ inline uint32_t rows_seg_back(const uint32_t *sumw, int b, uint32_t segw) {
+  uint32_t acc = 0;
+  for (int j = b - 1;; j--) {
+    const uint32_t w = rows_seg_wait(sumw, j);
+    if (!w)
+      return 0xFFFFFFFFu;
+    if (w & ACHIP_SEG_HAS_HEAD)
+      return (acc + ((w >> 9) & 0x1FFu)) | ((w & ACHIP_SEG_LAST_T) ? 1u << 16 : 0u);
+    acc += segw;
+  }
+}
+/* cells behind block b that go on with its last cell's run (the caller knows that the run goes on); 0xFFFFFFFF if a word
+ * never comes.  (Ends at the row's last segment at the latest: that one never sets ACHIP_SEG_CONT.) */
+__device__ inline uint32_t rows_seg_ahead(const uint32_t *sumw, int b) {
+  uint32_t acc = 0;
+  for (int j = b + 1;; j++) {
+    const uint32_t w = rows_seg_wait(sumw, j);
+    if (!w)
+      return 0xFFFFFFFFu;
+    acc += w & 0x1FFu;
+    if ((w & ACHIP_SEG_HAS_HEAD) || !(w & ACHIP_SEG_CONT))
+      return acc;
+  }
+}
+
 /* two 512-thread workgroups per CU need <= 128 VGPRs (4 waves per SIMD): left alone the compiler spreads the 7-slot
  * geometry over 140-180 registers for scheduling freedom it has no use for (the kernel waits on memory, not on issue) */
 /* (not the CRC instantiations: their tables leave room for one workgroup per CU anyway, so they may spread out; nor the
@@ -317,15 +380,17 @@ template <int MODE, int CPL, bool GENERIC, bool CRC> struct RowsMinWaves {
   static constexpr int value = (!CRC && !(GENERIC && MODE == ACHIP_MODE_HB_16 && CPL > 4)) ? 4 : 1;
 #endif
 };
-template <int MODE, int WAVES, int CPL, bool GENERIC, bool CRC = false>
-__global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<MODE, CPL, GENERIC, CRC>::value))
+template <int MODE, int WAVES, int CPL, bool GENERIC, bool CRC = false, bool WIDE = false>
+__global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<MODE, CPL + (WIDE ? 1 : 0), GENERIC, CRC>::value))
     render_rows_kernel(const achip_frame_t *__restrict__ frames, const achip_lut_t *__restrict__ lut,
                        uint8_t *__restrict__ out, uint64_t out_stride, uint32_t *__restrict__ out_len, int n_frames,
                        achip_uniform_t uni, achip_wire_t wire, const uint4 *__restrict__ crc_tab) {
   /* uni.flags bits 31..8 (ACHIP_UNIFORM_MAX_CELLS' field) carry the BLOCKS of the launch's largest frame here: the host
    * knows every frame's row width and rows, and the per-block LDS words are sized by it */
   static_assert(mode_has_runs(MODE), "per-cell modes use render_stream_kernel");
-  using L = RLds<MODE, WAVES, CRC>;
+  static_assert(!WIDE || (!GENERIC && !CRC), "rows cut into segments: fast sampler, no fused checksum");
+  using L = RLds<MODE, WAVES, CRC, WIDE>;
+  constexpr int CPG = CPL + (WIDE ? 1 : 0); /* registers per array: WIDE keeps the segment's two ghost cells in one more */
   constexpr bool HB = mode_is_halfblock(MODE);
   constexpr bool HBC = MODE == ACHIP_MODE_HB_TRUE || MODE == ACHIP_MODE_HB_256 || MODE == ACHIP_MODE_HB_16;
   constexpr int BLOCK = WAVES * 64;
@@ -382,8 +447,12 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
   const int wp = f.pad_left + f.out_w;
   const int rows = HB ? (f.out_h + 1) / 2 : f.out_h;
   const int nblk_cap = stream_maxblk(uni.flags, 1); /* words in each per-block LDS array of this launch */
-  const int rpb = wp > 0 ? SLOTS / wp : 0;          /* text rows per block */
-  const int nblk = rpb > 0 ? (rows + rpb - 1) / rpb : 0;
+  /* WIDE: a row is nseg segments of segw cells (the last one shorter, never empty), a block is one segment */
+  const int nseg0 = WIDE && wp > 0 ? (wp + SLOTS - 1) / SLOTS : 1;
+  const int segw = WIDE && wp > 0 ? (wp + nseg0 - 1) / nseg0 : wp;
+  const int nseg = WIDE && wp > 0 ? (wp + segw - 1) / segw : 1;
+  const int rpb = WIDE ? (wp > 0 && wp <= ACHIP_ROWS_WIDE_MAX_ROW && nseg <= WAVES ? 1 : 0) : (wp > 0 ? SLOTS / wp : 0); /* text rows per block */
+  const int nblk = WIDE ? rows * nseg : (rpb > 0 ? (rows + rpb - 1) / rpb : 0);
   auto bad_frame = [&]() {
     if (tid == 0) {
       out_len[fidx] = ACHIP_LEN_BADDESC;
@@ -428,8 +497,28 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
    * A cell exists in block b iff its row is below the block's row count: ONE unsigned compare of the whole word. */
   constexpr uint32_t CM_PAD = 1u << 16, CM_FIRST = 1u << 17, CM_END = 1u << 18;
   constexpr int CM_ROW = 23;
-  uint32_t cm[CPL];
-  {
+  uint32_t cm[CPG];
+  /* WIDE: a record per slot of ONE segment -- made again for every block (a block's segment changes from turn to turn):
+   * columns x0 + slot, the slots behind the segment's last cell marked as a row the block does not have; the ghost slot's
+   * lane 0 is the cell in front of the segment, lane 1 the cell behind it (where the row has them) */
+  auto seg_records = [&](int seg, uint32_t (&c)[CPG]) {
+    const uint32_t x0 = (uint32_t)(seg * segw), n = min((uint32_t)segw, uwp - x0);
+    auto record = [&](uint32_t xp, bool exists) {
+      uint32_t lo = 0;
+      if (xp >= pad_left) {
+        const uint32_t sx = min(((xp - pad_left) * src.xr) >> 16, src.w1);
+        lo = __umul24(src.flip_x ? src.w1 - sx : sx, 3u);
+      }
+      return lo | (xp < pad_left ? CM_PAD : 0u) | (xp <= pad_left ? CM_FIRST : 0u) | (xp == uwp - 1u ? CM_END : 0u) |
+             (exists ? 0u : 1u << CM_ROW);
+    };
+#pragma unroll
+    for (int k = 0; k < CPL; k++)
+      c[k] = record(x0 + (uint32_t)(64 * k + lane), (uint32_t)(64 * k + lane) < n);
+    const bool gl = lane == 0 && seg > 0, gr = lane == 1 && x0 + n < uwp;
+    c[CPG - 1] = record(gl ? x0 - 1u : gr ? x0 + n : 0u, gl || gr);
+  };
+  if constexpr (!WIDE) {
     const uint32_t q64 = 64u / uwp, r64 = 64u - q64 * uwp;
     uint32_t rr = (uint32_t)lane / uwp, xp = (uint32_t)lane - rr * uwp; /* one division per lane per frame, then constant steps */
 #pragma unroll
@@ -451,7 +540,7 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
       rr += wrap ? 1u : 0u;
     }
   }
-  auto block_rows = [&](int blk) { return (uint32_t)min(rpb, rows - blk * rpb); };
+  auto block_rows = [&](int blk) { return WIDE ? 1u : (uint32_t)min(rpb, rows - blk * rpb); };
   /* ROW1: every block is exactly one text row (4K -> 400x120 half blocks in 448 slots, 200x60 in 256): the source rows of
    * a block are wave-uniform, so a sample's address is (scalar row base) + (the slot's byte offset) and costs no vector
    * arithmetic at all.  The dword is requested one byte early (finish: >> 8) so that the last pixel's request stays inside
@@ -461,7 +550,7 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
                                the listing's static instruction counts are the counts a 4K -> 400x120 block executes */
   const bool row1 = true;
 #else
-  const bool row1 = !GENERIC && rpb == 1;
+  const bool row1 = WIDE || (!GENERIC && rpb == 1);
 #endif
   auto src_row = [&](uint32_t y) { /* wave-uniform */
     const uint32_t sy = min((y * src.yr) >> 16, src.h1);
@@ -469,10 +558,11 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
   };
 
   /* request the samples of block `blk`: nothing here consumes loaded data */
-  auto issue = [&](auto nt_tag, int blk, uint32_t (&rawT)[CPL], uint32_t (&rawB)[CPL], uint32_t &kinds) {
+  /* (row0 = the block's first text row, cm = its records: the frame's, or WIDE the records of the block's segment) */
+  auto issue = [&](auto nt_tag, int blk, uint32_t row0, const uint32_t (&cm)[CPG], uint32_t (&rawT)[CPG], uint32_t (&rawB)[CPG], uint32_t &kinds) {
     constexpr bool NT = decltype(nt_tag)::value;
     kinds = 0;
-    const uint32_t vlim = block_rows(blk) << CM_ROW, row0 = (uint32_t)(blk * rpb);
+    const uint32_t vlim = block_rows(blk) << CM_ROW;
     if (row1) {
       const uint32_t yt = HB ? 2u * row0 : row0;
       const bool two = HB && yt + 1u < (uint32_t)f.out_h; /* odd height: the last row's bottom half repeats the top (halfblock.c:81-88) */
@@ -480,7 +570,7 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
       const uint8_t *bt = src.base + rot - 1, *bb = src.base + rob - 1;
       const uint32_t ft = rot == 0u ? 1u : 0u, fb = rob == 0u ? 1u : 0u;
 #pragma unroll
-      for (int k = 0; k < CPL; k++) {
+      for (int k = 0; k < CPG; k++) {
         rawT[k] = 0;
         rawB[k] = 0;
         if (cm[k] < vlim && !(cm[k] & CM_PAD)) {
@@ -495,6 +585,7 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
       }
       return;
     }
+    if constexpr (!WIDE) {
 #pragma unroll
     for (int k = 0; k < CPL; k++) {
       rawT[k] = 0;
@@ -523,23 +614,32 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
         }
       }
     }
+    }
   };
-  auto issue_any = [&](int blk, uint32_t (&rawT)[CPL], uint32_t (&rawB)[CPL], uint32_t &kinds) {
+  auto issue_any = [&](int blk, uint32_t row0, const uint32_t (&cmx)[CPG], uint32_t (&rawT)[CPG], uint32_t (&rawB)[CPG], uint32_t &kinds) {
 #ifndef ACHIP_ROWS_COUNT_ROW1
     if (!GENERIC && src.nt)
-      issue(StreamTagNT{}, blk, rawT, rawB, kinds);
+      issue(StreamTagNT{}, blk, row0, cmx, rawT, rawB, kinds);
     else
 #endif
-      issue(StreamTagCached{}, blk, rawT, rawB, kinds);
+      issue(StreamTagCached{}, blk, row0, cmx, rawT, rawB, kinds);
   };
   static_assert(4 * CPL <= 32, "two bits per sample in one word");
 
-  uint32_t rawT[CPL], rawB[CPL], kinds = 0;
+  /* WIDE: (text row, segment) of the wave's block, and the step to its next one (blk + WAVES) */
+  int row_c = 0, seg_c = 0;
+  const int step_q = WIDE ? WAVES / nseg : 0, step_r = WIDE ? WAVES - step_q * nseg : 0;
+  if constexpr (WIDE) {
+    row_c = wave / nseg;
+    seg_c = wave - row_c * nseg;
+    seg_records(seg_c, cm);
+  }
+  uint32_t rawT[CPG], rawB[CPG], kinds = 0;
   const bool late_first = GENERIC && f.comp != nullptr;
   if (late_first)
     comp_stage<L::o_comp, BLOCK>(f.comp, tid);
   else if (wave < nblk)
-    issue_any(wave, rawT, rawB, kinds);
+    issue_any(wave, (uint32_t)(WIDE ? row_c : wave * rpb), cm, rawT, rawB, kinds);
 
   /* tables -> LDS; look-back words of this frame cleared */
   uint32_t *glyph = lds_ptr<uint32_t>(L::o_glyph);
@@ -571,6 +671,10 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
   }
   for (int k = tid; k < nblk; k += BLOCK)
     slots[k] = 0u;
+  uint32_t *sumw = slots + nblk_cap; /* WIDE: the segments' summary words */
+  if (WIDE)
+    for (int k = tid; k < nblk; k += BLOCK)
+      sumw[k] = 0u;
   if (EMIT_OR) /* the OR-filled staging areas start out zero; every slice clears what it used */
     for (int k = tid; k < WAVES * L::STAGE / 16; k += BLOCK)
       lds_ptr<uint4>(L::o_stage)[k] = make_uint4(0u, 0u, 0u, 0u);
@@ -592,7 +696,7 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
   if (late_first) {
     chead = comp_head<L::o_comp>();
     if (wave < nblk)
-      issue_any(wave, rawT, rawB, kinds);
+      issue_any(wave, (uint32_t)(wave * rpb), cm, rawT, rawB, kinds);
   }
 
   const LaneMasks lm = lane_masks(lane);
@@ -607,8 +711,8 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
   }
 
   /* ---- samples -> pixels with the mode's run key in bits 31..24 (as the phase kernel parks them in LDS), in place */
-  auto to_pixels = [&](int blk, uint32_t (&pt)[CPL], uint32_t (&pb)[CPL], uint32_t kinds) {
-    const uint32_t row0 = (uint32_t)(blk * rpb), vlim = block_rows(blk) << CM_ROW;
+  auto to_pixels = [&](int blk, uint32_t row0, const uint32_t (&cm)[CPG], uint32_t (&pt)[CPG], uint32_t (&pb)[CPG], uint32_t kinds) {
+    const uint32_t vlim = block_rows(blk) << CM_ROW;
     const uint32_t yt = HB ? 2u * row0 : row0;
     const bool two = HB && yt + 1u < (uint32_t)f.out_h;
     const bool ft = row1 && src_row(yt) == 0u, fb = row1 && two && src_row(yt + 1u) == 0u; /* wave-uniform */
@@ -617,14 +721,14 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
      * read source row 0 and no others, every sample is finished by the same shift below) */
     if (row1 && (ft || fb)) {
 #pragma unroll
-      for (int k = 0; k < CPL; k++)
+      for (int k = 0; k < CPG; k++)
         if ((cm[k] & 0xFFFFu) == 0u) {
           pt[k] = ft ? pt[k] << 8 : pt[k];
           pb[k] = fb ? pb[k] << 8 : pb[k];
         }
     }
 #pragma unroll
-    for (int k = 0; k < CPL; k++) {
+    for (int k = 0; k < CPG; k++) {
       const bool pix = cm[k] < vlim && !(cm[k] & CM_PAD);
       const uint32_t rawT = pt[k], rawB = pb[k];
       uint32_t t = 0, b = 0;
@@ -666,16 +770,40 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
    * cached / non-temporal -- define the samples in different registers, and the phi moves that join them are moves of
    * loaded values.  A build with one load per sample has no such wait, measured: no faster here, slower on the metric's
    * shape in the stream kernel -- docs/history/round5.md 2b.) */
-  uint32_t (&pt)[CPL] = rawT, (&pb)[CPL] = rawB;
+  uint32_t (&pt)[CPG] = rawT, (&pb)[CPG] = rawB;
   if (wave < nblk)
-    to_pixels(wave, pt, pb, kinds);
+    to_pixels(wave, (uint32_t)(WIDE ? row_c : wave * rpb), cm, pt, pb, kinds);
   for (int blk = wave; blk < nblk; blk += WAVES) {
-    uint32_t pt_n[CPL], pb_n[CPL], kinds_n = 0;
+    uint32_t pt_n[CPG], pb_n[CPG], kinds_n = 0;
+    uint32_t cm_n[WIDE ? CPG : 1];
+    int row_n = 0, seg_n = 0;
     const bool more = blk + WAVES < nblk;
-    if (more)
-      issue_any(blk + WAVES, pt_n, pb_n, kinds_n);
+    if constexpr (WIDE) {
+      seg_n = seg_c + step_r;
+      row_n = row_c + step_q;
+      if (seg_n >= nseg) {
+        seg_n -= nseg;
+        row_n++;
+      }
+      if (more) {
+        seg_records(seg_n, cm_n);
+        issue_any(blk + WAVES, (uint32_t)row_n, cm_n, pt_n, pb_n, kinds_n);
+      }
+    } else {
+      if (more)
+        issue_any(blk + WAVES, (uint32_t)((blk + WAVES) * rpb), cm, pt_n, pb_n, kinds_n);
+    }
 
-    const uint32_t nrb = block_rows(blk), ncb = nrb * uwp, row0 = (uint32_t)(blk * rpb), vlim = nrb << CM_ROW;
+    /* (WIDE: a block's cells are its segment's: ncb of them from column seg_x0 on) */
+    const uint32_t seg_x0 = (uint32_t)(seg_c * segw);
+    const uint32_t nrb = block_rows(blk), ncb = WIDE ? min((uint32_t)segw, uwp - seg_x0) : nrb * uwp,
+                   row0 = (uint32_t)(WIDE ? row_c : blk * rpb), vlim = nrb << CM_ROW;
+    auto next_to_pixels = [&]() {
+      if constexpr (WIDE)
+        to_pixels(blk + WAVES, (uint32_t)row_n, cm_n, pt_n, pb_n, kinds_n);
+      else
+        to_pixels(blk + WAVES, (uint32_t)((blk + WAVES) * rpb), cm, pt_n, pb_n, kinds_n);
+    };
     /* the records do not change, but the compiler must not know: it would hoist every flag test out of the loop as a lane
      * mask (four scalar pairs per slot) and spill most of them -- two lane reads per use instead of the AND + compare */
 #ifndef ACHIP_ROWS_HOIST_FLAGS /* A/B builds: make EXTRA=-DACHIP_ROWS_HOIST_FLAGS */
@@ -686,8 +814,9 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
     /* ---- run heads: one ballot per slot; a cell starts a run at or in front of its row's first pixel, or where its
      * key differs from its left neighbour's (the lane below; lane 0 takes lane 63 of the slot before) */
     uint64_t hm[CPL];
-    auto left_T = [&](int k) { return wave_shift_up1(pt[k], k > 0 ? wave_read_lane(pt[k > 0 ? k - 1 : 0], 63) : 0u); };
-    auto left_B = [&](int k) { return HB ? wave_shift_up1(pb[k], k > 0 ? wave_read_lane(pb[k > 0 ? k - 1 : 0], 63) : 0u) : 0u; };
+    /* (WIDE: the cell in front of the segment is lane 0 of the ghost slot) */
+    auto left_T = [&](int k) { return wave_shift_up1(pt[k], k > 0 ? wave_read_lane(pt[k > 0 ? k - 1 : 0], 63) : WIDE ? wave_read_lane(pt[CPG - 1], 0) : 0u); };
+    auto left_B = [&](int k) { return HB ? wave_shift_up1(pb[k], k > 0 ? wave_read_lane(pb[k > 0 ? k - 1 : 0], 63) : WIDE ? wave_read_lane(pb[CPG - 1], 0) : 0u) : 0u; };
 #pragma unroll
     for (int k = 0; k < CPL; k++) {
       const bool valid = cm[k] < vlim;
@@ -700,16 +829,81 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
      * word k and its transparency -- is carried along by the length pass below.  (Held as arrays of scalars, these and
      * the transparency masks were 42 of the 96 scalar registers the seven-slot geometry spilled.) */
     static_assert(64 * CPL < 512 && 9 * CPL <= 64, "nine bits per slot");
+    /* (WIDE: "the block's end" is the value 511 here -- a segment's last run may end thousands of cells further on, at
+     * e_end, which takes its place where the field is read) */
+    constexpr uint32_t E_BLOCK_END = 511u;
     uint64_t e_pack = 0;
+    uint32_t first_head; /* the block's first head, or where the scan started: no head at all */
     {
-      uint32_t next = ncb;
+      uint32_t next = WIDE ? E_BLOCK_END : ncb;
 #pragma unroll
       for (int k = CPL - 1; k >= 0; k--) {
         e_pack |= (uint64_t)next << (9 * k);
         if (hm[k] != 0ull)
           next = (uint32_t)(64 * k + __ffsll((unsigned long long)hm[k]) - 1);
       }
+      first_head = next;
     }
+    /* ---- WIDE: what the segment's neighbours contribute.  Publish first, then read (the file's header) */
+    uint32_t e_end = ncb;  /* where the run of the block's last cell ends, in cells from the block's first */
+    int h_open = -1;       /* the head of the run that is open where the block starts (<= 0: cells in front of the block) */
+    bool t_open = false;   /* ... transparent */
+    bool seg_lost = false; /* a neighbour's word never came */
+    if constexpr (WIDE) {
+      const bool has_head = first_head != E_BLOCK_END;
+      const uint32_t lead = has_head ? first_head : ncb;
+      uint32_t last_head = 0, lastT = 0, lastB = 0, endT = 0, endB = 0; /* the last head's / the last cell's pixels */
+#pragma unroll
+      for (int k = 0; k < CPL; k++) {
+        if (hm[k] != 0ull) {
+          const int b = 63 - __clzll((long long)hm[k]);
+          last_head = (uint32_t)(64 * k + b);
+          lastT = wave_read_lane(pt[k], b);
+          lastB = HB ? wave_read_lane(pb[k], b) : 0u;
+        }
+        if ((int)((ncb - 1u) >> 6) == k) {
+          endT = wave_read_lane(pt[k], (int)((ncb - 1u) & 63u));
+          endB = HB ? wave_read_lane(pb[k], (int)((ncb - 1u) & 63u)) : 0u;
+        }
+      }
+      const bool last_t = HBC && has_head && (px_rgb(lastT) | px_rgb(lastB)) == 0u;
+      /* the cell behind the segment continues the last cell's run: it exists, lies behind its row's first pixel, same key */
+      const uint32_t xg = seg_x0 + ncb;
+      const uint32_t gRT = wave_read_lane(pt[CPG - 1], 1), gRB = HB ? wave_read_lane(pb[CPG - 1], 1) : 0u;
+      const bool cont = xg < uwp && xg > pad_left && rows_same_run<MODE>(gRT, gRB, endT, endB);
+      if (lane == 0)
+        slot_store(&sumw[blk], rows_seg_word(lead, ncb - (has_head ? last_head : 0u), has_head, last_t, cont));
+      /* the open run: only a segment whose first cell continues it needs its length; its head's transparency decides the
+       * first head's SGRs -- equal rgb in the truecolor mode (the ghost cell tells), equal KEYS in the 256- / 16-colour
+       * modes, where only a ghost cell with black's keys can belong to a run with a raw-black head (halfblock.c:357,476) */
+      const uint32_t gLT = wave_read_lane(pt[CPG - 1], 0), gLB = HB ? wave_read_lane(pb[CPG - 1], 0) : 0u;
+      const bool joined = seg_c > 0 && seg_x0 > pad_left; /* the first cell has a left neighbour in its row's image */
+      bool look_back = joined && lead > 0u;
+      if (HBC && joined) {
+        if (MODE == ACHIP_MODE_HB_TRUE) {
+          t_open = (px_rgb(gLT) | px_rgb(gLB)) == 0u;
+        } else {
+          const uint32_t kb = MODE == ACHIP_MODE_HB_256 ? quant256(0u) : quant16(0u);
+          look_back |= px_key(gLT) == kb && px_key(gLB) == kb;
+        }
+      }
+      if (look_back) {
+        const uint32_t w = rows_seg_back(sumw, blk, (uint32_t)segw);
+        seg_lost |= w == 0xFFFFFFFFu;
+        h_open = -(int)(w & 0xFFFFu);
+        t_open = HBC && (w >> 16) != 0u;
+      }
+      if (cont) {
+        const uint32_t w = rows_seg_ahead(sumw, blk);
+        seg_lost |= w == 0xFFFFFFFFu;
+        e_end = ncb + (w & 0xFFFFu);
+      }
+    }
+    /* the end of the run that is open behind word k (wave-uniform) */
+    auto e_field = [&](int k) {
+      const uint32_t e = (uint32_t)(e_pack >> (9 * k)) & 0x1FFu;
+      return (int)(WIDE && e == E_BLOCK_END ? e_end : e);
+    };
     /* ---- the token of slot k.  Built twice -- once for its length, once for the store pass -- from the pixels and the
      * masks, instead of being held: five registers per slot would put the 7-slot geometry beyond 128 VGPRs, i.e. at one
      * workgroup per CU instead of two */
@@ -722,7 +916,7 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
       const int below = rows_prev_bit(hm[k], lm); /* nearest head strictly below in this word */
       const int h = c.is_head ? s : (below >= 0 ? 64 * k + below : h_in);
       const int above = rows_next_bit(hm[k], lm);
-      const int e = above >= 0 ? 64 * k + above : (int)((e_pack >> (9 * k)) & 0x1FFull);
+      const int e = above >= 0 ? 64 * k + above : e_field(k);
       c.run = (uint32_t)(e - h);
       /* transparency of the run's head; and, for a head behind its row's first pixel, of the previous run's head */
       const bool t_below = below >= 0 ? ((tmk >> below) & 1ull) != 0ull : t_in;
@@ -742,7 +936,7 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
       RunCtx c;
       c.is_head = true;
       /* (the word's LAST head may start a run that goes on in the words above: its end is the first head there) */
-      c.run = lane_bit(hm[k] >> 1) ? 1u : (uint32_t)((int)((e_pack >> (9 * k)) & 0x1FFull) - (64 * k + lane));
+      c.run = lane_bit(hm[k] >> 1) ? 1u : (uint32_t)(e_field(k) - (64 * k + lane));
       c.prevT = left_T(k);
       c.prevB = left_B(k);
       c.head_transparent = HBC && (px_rgb(pt[k]) | px_rgb(pb[k])) == 0u;
@@ -767,8 +961,8 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
     uint32_t pk[NPK], tot2[NPK];
     uint32_t total = 0;
     {
-      int last = -1;   /* the last head below the word being processed, and whether it is transparent */
-      bool lt = false;
+      int last = WIDE ? h_open : -1; /* the last head below the word being processed, and whether it is transparent */
+      bool lt = WIDE ? t_open : false;
 #pragma unroll
       for (int j = 0; j < NPK; j++) {
         uint32_t two_n = 0;
@@ -807,7 +1001,7 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
         slot_store(&slots[blk], ACHIP_SLOT_AGG | total);
       base = stream_lookback(slots, blk, lane);
     }
-    const bool ok = base != 0xFFFFFFFFu && (uint64_t)base + total <= cap_bytes;
+    const bool ok = base != 0xFFFFFFFFu && (uint64_t)base + total <= cap_bytes && !seg_lost;
     if (lane == 0)
       slot_store(&slots[blk], ACHIP_SLOT_PREFIX | (ok ? base + total : cap_bytes + 1u));
 
@@ -815,7 +1009,7 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
      * there the conversion waits for the end of the turn) */
     constexpr bool MID_TURN = !(MODE == ACHIP_MODE_HB_16 && CPL > 4);
     if (MID_TURN && more)
-      to_pixels(blk + WAVES, pt_n, pb_n, kinds_n);
+      next_to_pixels();
 
     uint32_t braw = 0; /* CRC: register after the block's bytes, starting from 0 */
     if (ok) {
@@ -1042,12 +1236,16 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
     }
 
     if (!MID_TURN && more)
-      to_pixels(blk + WAVES, pt_n, pb_n, kinds_n);
+      next_to_pixels();
 #pragma unroll
-    for (int k = 0; k < CPL; k++) {
+    for (int k = 0; k < CPG; k++) {
       pt[k] = pt_n[k];
       pb[k] = pb_n[k];
+      if constexpr (WIDE)
+        cm[k] = cm_n[k];
     }
+    row_c = row_n;
+    seg_c = seg_n;
   }
   (void)glyph;
 }

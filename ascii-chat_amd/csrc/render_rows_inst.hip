@@ -24,6 +24,7 @@ template <int ID> struct RGeometry;
 #define X(id, W, C)                                                                                                    \
   template <> struct RGeometry<id> {                                                                                   \
     static constexpr int WAVES = W, CPL = C;                                                                           \
+    static constexpr bool WIDE = ACHIP_ROWS_VARIANT_WIDE(id);                                                          \
   };
 ACHIP_ROWS_VARIANTS(X)
 #undef X
@@ -32,11 +33,11 @@ using G = RGeometry<ACHIP_RINST>;
 /* the frame CRC riding the rows kernel's drain costs more than the stand-alone pass (hip_launch.hip:
  * achip_variant_crc_pays), so no plan takes it by itself: those instantiations exist in -DACHIP_ALL_GEOMETRIES builds only */
 #ifdef ACHIP_ALL_GEOMETRIES
-constexpr bool HAS_CRC = ACHIP_RINST != 26;
+constexpr bool HAS_CRC = ACHIP_RINST != 26 && !G::WIDE;
 #else
 constexpr bool HAS_CRC = false;
 #endif
-constexpr bool HAS_COMP = ACHIP_RINST != 26; /* (the sixteen-wave geometry carries the fast sampler only: achip_choose_geometry never takes it for composites / 1x1 sources) */
+constexpr bool HAS_COMP = ACHIP_RINST != 26 && !G::WIDE; /* (the sixteen-wave geometry carries the fast sampler only: achip_choose_geometry never takes it for composites / 1x1 sources) */
 
 /* the constant tables of <MODE>'s CRC instantiation: built on the device once per process, then read-only */
 template <int MODE> hipError_t crc_tables(const uint4 **out) {
@@ -73,8 +74,8 @@ template <int MODE> hipError_t crc_tables(const uint4 **out) {
 template <int MODE, bool COMP, bool CRC>
 hipError_t launch_one(const achip_frame_t *frames, int n, const achip_lut_t *lut, uint8_t *out, uint64_t stride,
                       uint32_t *len, const achip_uniform_t &uni, const achip_wire_t &wire, hipStream_t stream) {
-  using L = achip::RLds<MODE, G::WAVES, CRC>;
-  auto kern = achip::render_rows_kernel<MODE, G::WAVES, G::CPL, COMP, CRC>;
+  using L = achip::RLds<MODE, G::WAVES, CRC, G::WIDE>;
+  auto kern = achip::render_rows_kernel<MODE, G::WAVES, G::CPL, COMP, CRC, G::WIDE>;
   static bool attr_set = false; /* one flag per instantiation; benign race (idempotent call) */
   if (!attr_set) {
     if (L::bytes > 48 * 1024) {
@@ -141,7 +142,7 @@ extern "C" int ACHIP_CAT(ACHIP_CAT(ACHIP_CAT(achipk_render_rinst_lds_, ACHIP_RIN
   switch (mode) {
 #define M(m)                                                                                                           \
   case m:                                                                                                              \
-    return achip::RLds<m, G::WAVES>::bytes;
+    return achip::RLds<m, G::WAVES, false, G::WIDE>::bytes;
     M(ACHIP_RMODE)
 #undef M
   }

@@ -64,8 +64,9 @@
  *   WAVES  waves per workgroup (one workgroup renders one frame)
  *   CPL    cells per lane per block
  * X(id, WAVES, CPL) */
-#ifdef ACHIP_TEST_GEOMETRY /* emulator builds only: two-row blocks of tiny frames, many blocks per wave */
-#define ACHIP_ROWS_TEST_VARIANT(X) X(28, 2, 2)
+#ifdef ACHIP_TEST_GEOMETRY /* emulator builds only: two-row blocks of tiny frames, many blocks per wave; rows of up to four
+                              64-cell segments */
+#define ACHIP_ROWS_TEST_VARIANT(X) X(28, 2, 2) X(30, 4, 1)
 #else
 #define ACHIP_ROWS_TEST_VARIANT(X)
 #endif
@@ -77,7 +78,13 @@
   X(25, 8, 4) /* rows up to 256 cells: 200x60, 160x48 one row per block; three 80-cell rows per block             */ \
   X(26, 16, 7) /* geometry 24 as ONE sixteen-wave workgroup per frame (round 5): whole-frame launches of at most a frame
                   per CU of the plan's share (achip_choose_geometry); fast sampler only, no fused CRC              */ \
+  X(27, 16, 6) /* WIDE (round 6): rows beyond 448 cells cut into at most sixteen segments of <= 384 cells, a segment per
+                  block, its two ghost cells in the seventh slot (render_rows.hpp); rows up to 4096 cells          */ \
+  X(29, 8, 6)  /* WIDE, two eight-wave workgroups per CU: rows of at most eight segments (3072 cells)              */ \
   ACHIP_ROWS_TEST_VARIANT(X)
 #define ACHIP_IS_ROWS_VARIANT(v) ((v) >= ACHIP_ROWS_VARIANT_FIRST)
+/* the geometries whose blocks are SEGMENTS of a row (render_rows.hpp WIDE): fast sampler only, no fused CRC */
+#define ACHIP_ROWS_VARIANT_WIDE(v) ((v) == 27 || (v) == 29 || (v) == 30)
+#define ACHIP_ROWS_WIDE_MAX_ROW 4096
 
 #endif

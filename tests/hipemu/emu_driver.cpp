@@ -283,15 +283,25 @@ extern "C" int emu_render_stream_lenfirst(int variant, const achip_frame_t *fram
 }
 
 /* the rows kernel (render_rows.hpp): run-structured modes, whole frames; wire != nullptr: its CRC instantiation */
-template <int MODE, int WAVES, int CPL, bool CRC>
+template <int MODE, int WAVES, int CPL, bool CRC, bool WIDE>
 static void run_rows(int variant, const achip_frame_t *frames, int n, const achip_lut_t *lut, uint8_t *out, uint64_t stride,
                      uint32_t *len, const achip_wire_t &wire) {
-  using L = achip::RLds<MODE, WAVES, CRC>;
+  using L = achip::RLds<MODE, WAVES, CRC, WIDE>;
   achip_uniform_t uni = {};
   if (g_uniform)
     (void)achip_frames_uniform(frames, n, &uni);
   uni.flags = ((lut->flags & ACHIP_LUT_MULTIBYTE) ? 0u : ACHIP_UNIFORM_PALETTE_ASCII) |
               ACHIP_UNIFORM_MAX_CELLS(achip_uniform_extent(MODE, variant, frames, n)); /* what plan.c passes */
+  if constexpr (WIDE) { /* rows cut into segments: fast sampler only, no fused checksum (render_rows.hpp) */
+    if (!needs_generic(frames, n))
+      hipemu::launch(dim3((unsigned)n), dim3(WAVES * 64), (size_t)((L::bytes_for(achip::stream_maxblk(uni.flags, 1)) + 15) & ~15), [&] {
+        achip::render_rows_kernel<MODE, WAVES, CPL, false, false, true>(frames, lut, out, stride, len, n, uni, wire, nullptr);
+      });
+    else
+      for (int i = 0; i < n; i++)
+        len[i] = ACHIP_LEN_BADDESC;
+    return;
+  } else {
   static std::vector<uint32_t> tab;
   const uint4 *tabv = nullptr;
   if (CRC) {
@@ -312,14 +322,15 @@ static void run_rows(int variant, const achip_frame_t *frames, int n, const achi
   hipemu::launch(dim3((unsigned)n), dim3(WAVES * 64), lds, [&] {
     achip::render_rows_kernel<MODE, WAVES, CPL, true, CRC>(frames, lut, out, stride, len, n, uni, wire, tabv);
   });
+  }
 }
-template <int WAVES, int CPL, bool CRC>
+template <int WAVES, int CPL, bool CRC, bool WIDE>
 static int rows_by_mode(int mode, int variant, const achip_frame_t *frames, int n, const achip_lut_t *lut, uint8_t *out,
                         uint64_t stride, uint32_t *len, const achip_wire_t &wire) {
   switch (mode) {
 #define M(m)                                                                                                           \
   case m:                                                                                                              \
-    run_rows<m, WAVES, CPL, CRC>(variant, frames, n, lut, out, stride, len, wire);                                      \
+    run_rows<m, WAVES, CPL, CRC && !WIDE, WIDE>(variant, frames, n, lut, out, stride, len, wire);                                     \
     return 0;
     M(ACHIP_MODE_MONO)
     M(ACHIP_MODE_HB_TRUE)
@@ -337,7 +348,7 @@ extern "C" int emu_render_rows_crc(int mode, int variant, const achip_frame_t *f
   switch (variant) {
 #define X(id, W, C)                                                                                                    \
   case id:                                                                                                             \
-    return rows_by_mode<W, C, true>(mode, variant, frames, n, lut, out, stride, len, wire);
+    return ACHIP_ROWS_VARIANT_WIDE(id) ? -1 : rows_by_mode<W, C, true, ACHIP_ROWS_VARIANT_WIDE(id)>(mode, variant, frames, n, lut, out, stride, len, wire);
     ACHIP_ROWS_VARIANTS(X)
 #undef X
   }
@@ -357,7 +368,7 @@ extern "C" int emu_render_batch(int mode, int variant, const achip_frame_t *fram
     switch (variant) {
 #define X(id, W, C)                                                                                                    \
   case id:                                                                                                             \
-    return rows_by_mode<W, C, false>(mode, variant, frames, n, lut, out, stride, len, achip_wire_t{});
+    return rows_by_mode<W, C, false, ACHIP_ROWS_VARIANT_WIDE(id)>(mode, variant, frames, n, lut, out, stride, len, achip_wire_t{});
       ACHIP_ROWS_VARIANTS(X)
 #undef X
     }

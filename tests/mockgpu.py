@@ -34,15 +34,19 @@ def build_library():
         return so
     os.makedirs(BUILD, exist_ok=True)
     objs = []
-    for src in [os.path.join(CSRC, f) for f in HOST_C] + [os.path.join(MOCK, "mock_hip.c")]:
-        obj = os.path.join(BUILD, os.path.basename(src).replace(".c", ".o"))
+    tag = ".%d" % os.getpid()  # objects and library of this process only, then one rename: concurrent test processes (pytest -n)
+    for src in [os.path.join(CSRC, f) for f in HOST_C] + [os.path.join(MOCK, "mock_hip.c")]:  # never link or load each other's halves
+        obj = os.path.join(BUILD, os.path.basename(src).replace(".c", tag + ".o"))
         subprocess.check_call(["gcc", "-std=gnu11", "-O1", "-g", "-fPIC", "-pthread", "-I" + INC, "-I" + CSRC, "-I" + HIP_INC,
                                "-c", src, "-o", obj])
         objs.append(obj)
-    lobj = os.path.join(BUILD, "mock_launch.o")
+    lobj = os.path.join(BUILD, "mock_launch" + tag + ".o")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-DACHIP_ALL_GEOMETRIES", "-I" + EMU, "-I" + CSRC, "-I" + INC, "-c",
                            os.path.join(MOCK, "mock_launch.cpp"), "-o", lobj])
-    subprocess.check_call(["g++", "-shared", "-o", so, *objs, lobj, "-lpthread", "-lm", "-ldl"])
+    subprocess.check_call(["g++", "-shared", "-o", so + tag, *objs, lobj, "-lpthread", "-lm", "-ldl"])
+    os.replace(so + tag, so)
+    for o in objs + [lobj]:
+        os.remove(o)
     return so
 
 

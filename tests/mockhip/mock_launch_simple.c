@@ -206,7 +206,7 @@ int achip_variant_cap(int variant) {
 #undef X
 #define X(id, W, C)                                                                                                    \
   case id:                                                                                                             \
-    return 64 * C;
+    return !ACHIP_ROWS_VARIANT_WIDE(id) ? 64 * C : 64 * C * W < ACHIP_ROWS_WIDE_MAX_ROW ? 64 * C * W : ACHIP_ROWS_WIDE_MAX_ROW;
     ACHIP_ROWS_VARIANTS(X)
 #undef X
 #define X(id, B, C, R)                                                                                                 \

@@ -688,6 +688,162 @@ def test_rows_kernel_random_run_structures_across_word_boundaries(seed):
                 assert emu.render_frames(mode, [f], orc.PALETTE_STANDARD, variant)[0] == exp, (seed, case, MODE_NAMES[mode], variant, w, W, H, pad)
 
 
+# ---- rows cut into segments (render_rows.hpp WIDE; round 6): geometries 27 (16 waves x 384-cell segments), 29 (8 waves) and
+# the emulator's 30 (4 waves x 64-cell segments: rows of up to 256 cells put tiny frames through every segment case)
+WIDE_CAP = {30: 256, 27: 4096, 29: 3072}
+
+
+@pytest.mark.parametrize("mode", ROWS_MODES, ids=ROWS_IDS)
+def test_rows_kernel_wide_rows_torture_and_run_structures(mode):
+    """rows of two to four segments (and of one: the same kernel must take narrow rows), runs that cross none, one and every
+    segment boundary of a row (flat: one run per row, its repeat count summed over the segments; black: a transparent run;
+    blocks: 7-cell runs that straddle the boundaries; stripes: no run at all), against the oracle"""
+    for (W, H) in [(65, 3), (100, 5), (128, 4), (129, 6), (200, 7), (256, 3), (64, 2), (30, 4), (1, 1), (255, 5), (193, 9)]:
+        for src in (TORTURE, run_frames(W, 2 * H, "blocks"), run_frames(W, 2 * H, "flat"), run_frames(W, 2 * H, "black"),
+                    run_frames(W, 2 * H, "stripes")):
+            exp = oracle_convert(src, mode, W, H, orc.PALETTE_STANDARD)
+            assert emu_convert(src, mode, W, H, orc.PALETTE_STANDARD, 30) == exp, (MODE_NAMES[mode], W, H, src.shape)
+    # the product's segment geometries: 449 cells = two segments of 225 / 224; 1000 = three of 334 / 334 / 332; one row of 3840
+    # cells (the widest the reference resizes to, image.c: ten segments, a four-digit repeat count) on 27, 3072 (eight) on 29
+    for (W, H, variant) in [(449, 2, 27), (449, 3, 29), (1000, 2, 27), (640, 3, 29), (3840, 1, 27), (3072, 1, 29)]:
+        for kind in ("blocks", "flat", "black"):
+            src = run_frames(W, 2 * H, kind)
+            exp = oracle_convert(src, mode, W, H, orc.PALETTE_STANDARD)
+            assert emu_convert(src, mode, W, H, orc.PALETTE_STANDARD, variant) == exp, (MODE_NAMES[mode], W, H, variant, kind)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_rows_kernel_wide_rows_random_run_structures_across_segment_boundaries(seed):
+    """random rows built from pieces -- noise, flat colour, black, stripes, NEAR-black (raw rgb 0..2: equal keys in the 256- /
+    16-colour modes, where the run HEAD's raw rgb decides transparency, halfblock.c:357,476 -- a head in one segment, its
+    run's cells in the next) -- whose lengths cluster around the segment widths, with and without aspect + padding (pad cells
+    may fill whole segments): every run-structured mode on every segment geometry against the oracle"""
+    rng = np.random.default_rng(6000 + seed)
+    for case in range(9):
+        variant = (30, 30, 27, 30, 29, 30)[case % 6]
+        cap = WIDE_CAP[variant]
+        if variant == 30:
+            w = int(rng.choice([65, 100, 127, 128, 129, 191, 192, 193, 255, 256])) if case % 2 else int(rng.integers(60, 257))
+        else:
+            w = int(rng.choice([449, 450, 511, 512, 640, 767, 768, 769, 1000, 1153])) if case % 2 else int(rng.integers(449, 1300))
+        n0 = -(-w // (64 if variant == 30 else 384))
+        segw = -(-w // n0)
+        rows = int(rng.integers(1, 4))
+        img = np.zeros((2 * rows, w, 3), np.uint8)
+        for y in range(2 * rows):
+            x = 0
+            while x < w:
+                if rng.integers(0, 3):
+                    n = int(rng.choice([1, 2, segw - 1, segw, segw + 1, 2 * segw - 1, 2 * segw, 2 * segw + 1, 3 * segw]))
+                else:
+                    n = int(rng.integers(1, 2 * segw))
+                if rng.integers(0, 4) == 0:  # end exactly at a segment boundary, or one cell off it
+                    n = max(1, (x // segw + 1) * segw - x + int(rng.integers(-1, 2)))
+                n = min(n, w - x)
+                kind = int(rng.integers(0, 5))
+                if kind == 0:
+                    img[y, x:x + n] = rng.integers(0, 256, (n, 3))
+                elif kind == 1:
+                    img[y, x:x + n] = rng.integers(0, 256, 3)
+                elif kind == 2:
+                    img[y, x:x + n] = 0
+                elif kind == 3:
+                    img[y, x:x + n:2] = rng.integers(0, 256, 3)
+                    img[y, x + 1:x + n:2] = rng.integers(0, 256, 3)
+                else:
+                    img[y, x:x + n] = rng.integers(0, 3, (n, 3))
+                x += n
+            if y % 2 and rng.integers(0, 2):
+                img[y] = img[y - 1]
+        pad = bool(rng.integers(0, 2))
+        for mode in ROWS_MODES:
+            rm = MODE_CAPS[mode][1]
+            H = rows if rm == 2 else 2 * rows
+            W = w if not pad else min(cap, w + int(rng.integers(0, 2 * segw)))
+            f = emu.frame_for_convert(img, W, H, rm, pad, pad)
+            if f is None or f.pad_left + f.out_w > cap:
+                continue
+            exp = oracle_convert(img, mode, W, H, orc.PALETTE_STANDARD, pad, pad)
+            assert emu.render_frames(mode, [f], orc.PALETTE_STANDARD, variant)[0] == exp, (seed, case, MODE_NAMES[mode], variant, w, W, H, pad)
+
+
+@pytest.mark.parametrize("mode", [MODE_HB_256, MODE_HB_16, MODE_HB_TRUE], ids=["hb_256", "hb_16", "hb_true"])
+def test_rows_kernel_wide_rows_open_run_transparency_across_segments(mode):
+    """the state a transparent run leaves (no SGR state: the next head carries both SGRs, halfblock.c:357,476) when the run's
+    HEAD lies one or two segments in front of the head that needs it: raw black heads followed by cells of equal keys but
+    other raw rgb, and the other way round, at every offset around the boundaries of 64-cell segments"""
+    for head_at in (0, 40, 63, 64, 65, 127, 128):
+        for run in (1, 24, 64, 65, 130):
+            for head_rgb, tail_rgb in (((0, 0, 0), (1, 1, 1)), ((1, 1, 1), (0, 0, 0)), ((0, 0, 0), (0, 0, 0)), ((2, 1, 0), (1, 2, 2))):
+                w = 230
+                img = np.zeros((2, w, 3), np.uint8)
+                img[:, :] = (200, 10, 90)
+                img[:, :head_at] = np.random.default_rng(head_at).integers(3, 256, (2, head_at, 3)) if head_at else 0
+                end = min(w - 3, head_at + run)
+                img[:, head_at:end] = tail_rgb
+                img[:, head_at] = head_rgb
+                img[:, end:end + 2] = (9, 200, 33)  # the head that reads the state
+                exp = oracle_convert(img, mode, w, 1, orc.PALETTE_STANDARD)
+                assert emu_convert(img, mode, w, 1, orc.PALETTE_STANDARD, 30) == exp, (MODE_NAMES[mode], head_at, run, head_rgb)
+
+
+@pytest.mark.parametrize("mode", ROWS_MODES, ids=ROWS_IDS)
+def test_rows_kernel_wide_rows_with_padding_flips_tint_and_batches(mode):
+    """segments with everything the cell records fold in (left padding from the aspect fit -- pad cells filling the first
+    segment --, top padding, flips, the colour filter, odd half-block heights, the buffer's first pixel), then a ragged batch
+    (frames of one, two and four segments in ONE launch, by descriptor table and by value)"""
+    import ctypes as C
+    rm, cl = MODE_CAPS[mode][1], MODE_CAPS[mode][0]
+    imgs = [orc.frame_hash_noise(120, 90, 3), run_frames(37, 29, "blocks"), orc.frame_smooth(300, 7)]
+    padded = 0
+    for img in imgs:
+        for (W, H, variant) in [(250, 21, 30), (200, 9, 30), (129, 5, 30), (700, 7, 27), (500, 5, 29)]:
+            for fx, fy, flt in [(False, False, 0), (True, True, 3), (False, True, 7)]:
+                f = emu.frame_for_convert(img, W, H, rm, True, True)
+                padded += f.pad_left >= 64
+                assert emu.lib().achip_frame_set_display_ops(C.byref(f), fx, fy, flt) == 0
+                exp = orc.display_convert(img, W, H, cl, rm, True, True, fx, fy, flt)
+                assert emu.render_frames(mode, [f], orc.PALETTE_STANDARD, variant)[0] == exp, (MODE_NAMES[mode], img.shape, W, H, variant, fx, fy, flt)
+    assert padded >= 3, padded
+    dims = [(256, 6), (100, 3), (60, 4), (129, 7), (255, 2), (64, 5), (200, 1)]
+    srcs = [run_frames(w, 2 * h, kind) for (w, h), kind in zip(dims, ("blocks", "flat", "stripes", "black", "blocks", "flat", "blocks"))]
+    frames = [emu.frame_for_convert(s_, w, h, rm, False, False) for s_, (w, h) in zip(srcs, dims)]
+    exp = [oracle_convert(s_, mode, w, h, orc.PALETTE_STANDARD) for s_, (w, h) in zip(srcs, dims)]
+    assert emu.render_frames(mode, frames, orc.PALETTE_STANDARD, 30) == exp
+    same = [emu.frame_for_convert(srcs[0], 256, 6, rm, False, False) for _ in range(3)]
+    assert emu.render_frames(mode, same, orc.PALETTE_STANDARD, 30, uniform=True) == [exp[0]] * 3
+
+
+def test_rows_kernel_wide_rows_limits_and_choice():
+    """a row of more segments than the workgroup has waves is refused by the kernel (a segment may wait for every other
+    segment of its row: all of them must be in flight) and never sent there; composites and 1x1 sources neither; whole-frame
+    launches of rows beyond 448 cells take the segment geometries by themselves"""
+    import ctypes as C
+    img = run_frames(300, 4, "blocks")
+    f = emu.frame_for_convert(img, 257, 2, 0, False, False)
+    assert emu.render_frames(MODE_MONO, [f], orc.PALETTE_STANDARD, 30)[0] == 0xFFFFFFFE  # ACHIP_LEN_BADDESC: five segments, four waves
+    L = emu.lib()
+    caps = (C.c_int * 5)(4096, 2048, 1024, 256, 2048)
+
+    def choice(src, W, H, mode, n, n_cus, forced=-1):
+        rm = MODE_CAPS[mode][1]
+        fr = emu.frame_for_convert(src, W, H, rm, False, False)
+        arr = (emu.Frame * n)(*([fr] * n))
+        v, parts, rpp = C.c_int(-1), C.c_int(0), C.c_int(0)
+        rc = L.achip_choose_geometry(mode, arr, n, True, caps, n_cus, 0, forced, C.byref(v), C.byref(parts), C.byref(rpp))
+        return v.value if rc == 0 else None
+
+    uhd = np.zeros((2160, 3840, 3), np.uint8)
+    assert choice(uhd, 640, 180, MODE_HB_TRUE, 256, 256) == 27
+    assert choice(uhd, 640, 180, MODE_HB_TRUE, 512, 256) == 29
+    assert choice(uhd, 1000, 40, MODE_MONO, 256, 256) == 27
+    assert choice(uhd, 3500, 40, MODE_MONO, 512, 256) == 27      # nine segments: beyond the eight-wave geometry
+    assert choice(uhd, 640, 180, MODE_HB_TRUE, 256, 256, forced=29) == 29 and choice(uhd, 3500, 40, MODE_MONO, 256, 256, forced=29) is None
+    assert choice(uhd, 448, 120, MODE_HB_TRUE, 512, 256) == 24    # one block still holds the row
+    one = np.zeros((1, 1, 3), np.uint8)
+    assert choice(one, 640, 20, MODE_MONO, 256, 256) in (0, 4)    # 1x1 source: the general sampler, which the segment geometries lack
+
+
 @pytest.mark.parametrize("variant", [16, 17, 20])
 def test_stream_kernel_word_built_sgrs_at_every_field_length_and_alignment(variant):
     for (w, h, seed) in [(97, 7, 5), (200, 3, 6), (61, 5, 7)]:
