@@ -534,8 +534,11 @@ long achip_max_cells(const achip_frame_t *frames, int n_frames) {
 
 /* the rows-kernel family (render_variants.h: ACHIP_ROWS_VARIANTS): a block is a whole number of text rows */
 #define ACHIP_HOST_ROWS_FIRST 24
+#ifndef ACHIP_ROWS_WIDE_CPL
+#define ACHIP_ROWS_WIDE_CPL 5 /* (render_variants.h) */
+#endif
 static int rows_variant_cpl(int variant) {
-  return variant == 24 || variant == 26 ? 7 : variant == 25 ? 4 : variant == 27 || variant == 29 ? 6 : variant == 28 ? 2 : variant == 30 ? 1 : 0;
+  return variant == 24 || variant == 26 ? 7 : variant == 25 ? 4 : variant == 27 || variant == 29 ? ACHIP_ROWS_WIDE_CPL : variant == 28 ? 2 : variant == 30 ? 1 : 0;
 }
 /* the geometries whose blocks are SEGMENTS of a row (render_variants.h ACHIP_ROWS_VARIANT_WIDE; render_rows.hpp WIDE): rows of
  * at most `waves` segments of 64 * cpl cells, and of at most ACHIP_ROWS_WIDE_MAX_ROW cells */

@@ -73,14 +73,20 @@
 #ifndef ACHIP_ROWS24_WAVES
 #define ACHIP_ROWS24_WAVES 8 /* (A/B builds: other workgroup sizes of the seven-slot geometry) */
 #endif
+#ifndef ACHIP_ROWS_WIDE_CPL
+#define ACHIP_ROWS_WIDE_CPL 5 /* cell slots of a segment (achip_host.c restates it).  Measured with 5 / 6 / 7 (A/B builds,
+                                 profiles/r06_wide_rows.txt): 640-cell rows = two segments of 320 cells, sampled 640x360 half
+                                 blocks 346 / 361 / 377 us -- the slots a segment leaves empty cost a quarter of what they
+                                 hold, so ONE width serves: 320 cells, which cuts 640 / 960 / 1280 / 1920 exactly */
+#endif
 #define ACHIP_ROWS_VARIANTS(X)                                                                                    \
   X(24, ACHIP_ROWS24_WAVES, 7) /* rows up to 448 cells: 4K -> 400x120 half blocks is one row per block (89 % of the slots)        */ \
   X(25, 8, 4) /* rows up to 256 cells: 200x60, 160x48 one row per block; three 80-cell rows per block             */ \
   X(26, 16, 7) /* geometry 24 as ONE sixteen-wave workgroup per frame (round 5): whole-frame launches of at most a frame
                   per CU of the plan's share (achip_choose_geometry); fast sampler only, no fused CRC              */ \
-  X(27, 16, 6) /* WIDE (round 6): rows beyond 448 cells cut into at most sixteen segments of <= 384 cells, a segment per
-                  block, its two ghost cells in the seventh slot (render_rows.hpp); rows up to 4096 cells          */ \
-  X(29, 8, 6)  /* WIDE, two eight-wave workgroups per CU: rows of at most eight segments (3072 cells)              */ \
+  X(27, 16, ACHIP_ROWS_WIDE_CPL) /* WIDE (round 6): rows beyond 448 cells cut into at most sixteen segments of <= 320 cells, a
+                  segment per block, its two ghost cells in one more slot (render_rows.hpp); rows up to 4096 cells */ \
+  X(29, 8, ACHIP_ROWS_WIDE_CPL)  /* WIDE, two eight-wave workgroups per CU: rows of at most eight segments (2560 cells) */ \
   ACHIP_ROWS_TEST_VARIANT(X)
 #define ACHIP_IS_ROWS_VARIANT(v) ((v) >= ACHIP_ROWS_VARIANT_FIRST)
 /* the geometries whose blocks are SEGMENTS of a row (render_rows.hpp WIDE): fast sampler only, no fused CRC */

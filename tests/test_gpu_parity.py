@@ -159,9 +159,9 @@ def test_rows_wider_than_one_block_take_the_segment_geometries(gpu, mode):
             for variant in (27, 29, -1, 0):
                 got = render_batch(gpu, mode, [img], W, Ht, variant=variant)[0]
                 assert got == exp, (MODE_NAMES[mode], W, Ht, variant, img.shape)
-    for (W, variant) in ((3840, 27), (3072, 29), (3840, -1)):
+    for (W, variant) in ((3840, 27), (2560, 29), (3840, -1)):
         img = _run_image(W, 4, "blocks")
-        img[2:, 100:3000] = (7, 7, 200)  # one run of 2900 cells over eight segments in the second text row
+        img[2:, 100:2500] = (7, 7, 200)  # one run of 2400 cells over eight segments in the second text row
         Ht = 2 if hb else 4
         assert render_batch(gpu, mode, [img], W, Ht, variant=variant)[0] == oracle_convert(img, mode, W, Ht, orc.PALETTE_STANDARD), (MODE_NAMES[mode], W, variant)
     # aspect fit + padding: pad cells in front of every row, whole segments of them

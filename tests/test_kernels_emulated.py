@@ -688,9 +688,10 @@ def test_rows_kernel_random_run_structures_across_word_boundaries(seed):
                 assert emu.render_frames(mode, [f], orc.PALETTE_STANDARD, variant)[0] == exp, (seed, case, MODE_NAMES[mode], variant, w, W, H, pad)
 
 
-# ---- rows cut into segments (render_rows.hpp WIDE; round 6): geometries 27 (16 waves x 384-cell segments), 29 (8 waves) and
+# ---- rows cut into segments (render_rows.hpp WIDE; round 6): geometries 27 (16 waves x 320-cell segments), 29 (8 waves) and
 # the emulator's 30 (4 waves x 64-cell segments: rows of up to 256 cells put tiny frames through every segment case)
-WIDE_CAP = {30: 256, 27: 4096, 29: 3072}
+WIDE_CAP = {30: 256, 27: 4096, 29: 2560}
+WIDE_SLOTS = {30: 64, 27: 320, 29: 320}
 
 
 @pytest.mark.parametrize("mode", ROWS_MODES, ids=ROWS_IDS)
@@ -703,9 +704,9 @@ def test_rows_kernel_wide_rows_torture_and_run_structures(mode):
                     run_frames(W, 2 * H, "stripes")):
             exp = oracle_convert(src, mode, W, H, orc.PALETTE_STANDARD)
             assert emu_convert(src, mode, W, H, orc.PALETTE_STANDARD, 30) == exp, (MODE_NAMES[mode], W, H, src.shape)
-    # the product's segment geometries: 449 cells = two segments of 225 / 224; 1000 = three of 334 / 334 / 332; one row of 3840
-    # cells (the widest the reference resizes to, image.c: ten segments, a four-digit repeat count) on 27, 3072 (eight) on 29
-    for (W, H, variant) in [(449, 2, 27), (449, 3, 29), (1000, 2, 27), (640, 3, 29), (3840, 1, 27), (3072, 1, 29)]:
+    # the product's segment geometries: 449 cells = two segments of 225 / 224; 1000 = four of 250; one row of 3840 cells (the
+    # widest the reference resizes to, image.c: twelve segments, a four-digit repeat count) on 27, 2560 (eight) on 29
+    for (W, H, variant) in [(449, 2, 27), (449, 3, 29), (1000, 2, 27), (640, 3, 29), (3840, 1, 27), (2560, 1, 29)]:
         for kind in ("blocks", "flat", "black"):
             src = run_frames(W, 2 * H, kind)
             exp = oracle_convert(src, mode, W, H, orc.PALETTE_STANDARD)
@@ -726,7 +727,7 @@ def test_rows_kernel_wide_rows_random_run_structures_across_segment_boundaries(s
             w = int(rng.choice([65, 100, 127, 128, 129, 191, 192, 193, 255, 256])) if case % 2 else int(rng.integers(60, 257))
         else:
             w = int(rng.choice([449, 450, 511, 512, 640, 767, 768, 769, 1000, 1153])) if case % 2 else int(rng.integers(449, 1300))
-        n0 = -(-w // (64 if variant == 30 else 384))
+        n0 = -(-w // WIDE_SLOTS[variant])
         segw = -(-w // n0)
         rows = int(rng.integers(1, 4))
         img = np.zeros((2 * rows, w, 3), np.uint8)
@@ -837,7 +838,7 @@ def test_rows_kernel_wide_rows_limits_and_choice():
     assert choice(uhd, 640, 180, MODE_HB_TRUE, 256, 256) == 27
     assert choice(uhd, 640, 180, MODE_HB_TRUE, 512, 256) == 29
     assert choice(uhd, 1000, 40, MODE_MONO, 256, 256) == 27
-    assert choice(uhd, 3500, 40, MODE_MONO, 512, 256) == 27      # nine segments: beyond the eight-wave geometry
+    assert choice(uhd, 3500, 40, MODE_MONO, 512, 256) == 27      # eleven segments: beyond the eight-wave geometry
     assert choice(uhd, 640, 180, MODE_HB_TRUE, 256, 256, forced=29) == 29 and choice(uhd, 3500, 40, MODE_MONO, 256, 256, forced=29) is None
     assert choice(uhd, 448, 120, MODE_HB_TRUE, 512, 256) == 24    # one block still holds the row
     one = np.zeros((1, 1, 3), np.uint8)
