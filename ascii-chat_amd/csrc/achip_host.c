@@ -537,9 +537,15 @@ long achip_max_cells(const achip_frame_t *frames, int n_frames) {
 #ifndef ACHIP_ROWS_WIDE_CPL
 #define ACHIP_ROWS_WIDE_CPL 5 /* (render_variants.h) */
 #endif
+#ifndef ACHIP_ROWS_PARTS_CPL
+#define ACHIP_ROWS_PARTS_CPL 2 /* (render_variants.h) */
+#endif
 static int rows_variant_cpl(int variant) {
-  return variant == 24 || variant == 26 ? 7 : variant == 25 ? 4 : variant == 27 || variant == 29 ? ACHIP_ROWS_WIDE_CPL : variant == 28 ? 2 : variant == 30 ? 1 : 0;
+  return variant == 24 || variant == 26 ? 7 : variant == 25 ? 4 : variant == 27 || variant == 29 ? ACHIP_ROWS_WIDE_CPL
+         : variant == 31 ? ACHIP_ROWS_PARTS_CPL : variant == 28 ? 2 : variant == 30 || variant == 33 ? 1 : 0;
 }
+/* the geometries that share a frame's blocks out over workgroups (render_variants.h ACHIP_ROWS_VARIANT_PARTS): fast sampler only */
+static bool rows_variant_parts(int variant) { return variant == 31 || variant == 33; }
 /* the geometries whose blocks are SEGMENTS of a row (render_variants.h ACHIP_ROWS_VARIANT_WIDE; render_rows.hpp WIDE): rows of
  * at most `waves` segments of 64 * cpl cells, and of at most ACHIP_ROWS_WIDE_MAX_ROW cells */
 #define ACHIP_HOST_ROWS_WIDE_MAX_ROW 4096
@@ -642,7 +648,7 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
     const int cpl = rows_variant_cpl(forced_variant);
     if (!run_mode || !cpl || max_wp > rows_variant_max_row(forced_variant) || achip_uniform_extent(mode, forced_variant, frames, n_frames) > ACHIP_HOST_STREAM_MAXBLK)
       return -1;
-    if ((forced_variant == 26 || rows_variant_wide_waves(forced_variant)) && general_sampler) /* (geometry 26 and the segment geometries carry the fast sampler only) */
+    if ((forced_variant == 26 || rows_variant_wide_waves(forced_variant) || rows_variant_parts(forced_variant)) && general_sampler) /* (geometry 26, the segment geometries and the shared-out one carry the fast sampler only) */
       return -1;
     *variant = forced_variant;
     return 0; /* whole frames only */
@@ -724,6 +730,37 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
    * against 12.6 whole, eight of them 9.7 against 12.9, sixty-four in four bands each 10.2 against 13.3, ninety-six 17.9 against
    * 13.4; profiles/r04_small_run_modes.txt) */
   const bool short_tokens = mode == ACHIP_MODE_MONO || mode == ACHIP_MODE_HB_MONO;
+  /* Small launches of the run-structured modes (round 6) -- a lone mono frame, a few half-block frames --
+   * share a frame's blocks out over four-wave workgroups of the rows kernel (render_rows.hpp PARTS, geometry 31: 128-cell
+   * blocks -- ONE text row at 80 or 120 columns --, one block per wave) as the per-cell modes do above, while every workgroup
+   * of the launch has a CU to itself.  Measured (scripts/gpu_r6_k.sh, profiles/r06_small_rows_parts.txt; one launch after the
+   * other, us per launch): a lone 80x24 mono frame 6.5 against 7.6 whole on geometry 25 and 7.5-8.2 as row bands; a lone
+   * half-block truecolor frame 8.3 against 9.0-9.4 as bands (11.6 whole); eight frames 7.4 / 9.2 against 8.0 / 9.7.  With
+   * 256-cell blocks (three rows each, two workgroups) nothing is gained: the shorter block shortens the chain, not the idle
+   * SIMDs. */
+  if (forced_variant < 0 && run_mode && !general_sampler && may_split && split_request == 0 && max_wp <= 64 * ACHIP_ROWS_PARTS_CPL) {
+    const long nblk = achip_uniform_extent(mode, 31, frames, n_frames);
+    long np = (nblk + 3) / 4;
+    if (np > 64)
+      np = 64;
+    if (np * n_frames > n_cus)
+      np = n_cus / n_frames;
+    { /* ASCIICHAT_HIP_ROWS_PARTS (diagnostics, read once): 1 = never, N = this many where the CUs allow */
+      static int forced = -1;
+      if (forced < 0) {
+        const char *e = getenv("ASCIICHAT_HIP_ROWS_PARTS");
+        forced = e && e[0] ? atoi(e) : 0;
+      }
+      if (forced >= 1 && forced <= 64 && (long)forced * n_frames <= n_cus)
+        np = forced;
+    }
+    if (np >= 2 && nblk > 0 && (nblk + np - 1) / np <= 4) {
+      *variant = 31;
+      *parts = (int)np;
+      *rows_per_part = 1;
+      return 0;
+    }
+  }
   if (forced_variant < 0 && run_mode && may_split && split_request == 0 && max_wp <= 256 &&
       (short_tokens || 4 * n_frames > n_cus) && achip_uniform_extent(mode, 25, frames, n_frames) <= 8) {
     *variant = 25; /* one block of whole rows per wave of its eight: see above */

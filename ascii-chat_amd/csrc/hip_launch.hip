@@ -25,13 +25,16 @@ extern "C" int achip_launch_render(int mode, int variant, int has_composite, con
   if (parts < 1 || (parts > 1 && (!part_sync || rows_per_part < 1)))
     return (int)hipErrorInvalidValue;
   if (ACHIP_IS_ROWS_VARIANT(variant)) { /* wave-autonomous kernel of the run-structured modes (render_rows.hpp) */
-    if (parts != 1) /* (the profiled entry points' per-wave stamps do not exist here: prof is ignored) */
+    /* (the profiled entry points' per-wave stamps do not exist here: prof is ignored) */
+    /* a frame's blocks shared out over `parts` workgroups: the PARTS geometry only (rows_per_part means nothing here) */
+    if (parts != 1 && (!ACHIP_ROWS_VARIANT_PARTS(variant) || parts > 64 || epoch == 0u))
       return (int)hipErrorInvalidValue;
+    const achip_partsdev_t ps = {parts, epoch, part_sync};
     switch (variant) {
 #define X(id, W, C)                                                                                                    \
   case id:                                                                                                             \
     return achipk_render_rinst_launch_##id(mode, has_composite, frames_dev, n_frames, lut_dev, out, out_stride, out_len, \
-                                          uniform, nullptr, stream);
+                                          uniform, nullptr, &ps, stream);
       ACHIP_ROWS_VARIANTS(X)
 #undef X
     }
@@ -85,7 +88,7 @@ extern "C" int achip_launch_render_crc(int mode, int variant, int has_composite,
 #define X(id, W, C)                                                                                                    \
   case id:                                                                                                             \
     return achipk_render_rinst_launch_##id(mode, has_composite, frames_dev, n_frames, lut_dev, out, out_stride, out_len,  \
-                                          uniform, wire, stream);
+                                          uniform, wire, nullptr, stream);
     ACHIP_ROWS_VARIANTS(X)
 #undef X
   }
@@ -115,7 +118,7 @@ extern "C" int achip_launch_render_length_first(int variant, const achip_frame_t
                        : achipk_render_sinst_lenfirst_launch_17(frames_dev, n_frames, lut_dev, bound, out_len, uniform, pack, stream);
 }
 #ifdef ACHIP_ALL_GEOMETRIES
-extern "C" int achip_variant_has_crc(int variant) { return variant == 16 || variant == 17 || (ACHIP_IS_ROWS_VARIANT(variant) && variant != 26 && !ACHIP_ROWS_VARIANT_WIDE(variant)); }
+extern "C" int achip_variant_has_crc(int variant) { return variant == 16 || variant == 17 || (ACHIP_IS_ROWS_VARIANT(variant) && variant != 26 && !ACHIP_ROWS_VARIANT_WIDE(variant) && !ACHIP_ROWS_VARIANT_PARTS(variant)); }
 #else
 extern "C" int achip_variant_has_crc(int variant) { return variant == 16 || variant == 17; }
 #endif

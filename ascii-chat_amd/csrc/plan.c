@@ -248,6 +248,11 @@ static int device_cus(void) {
   return cached;
 }
 
+/* a geometry whose multi-workgroup form shares a frame's BLOCKS out over workgroups of a wave-autonomous kernel (stream
+ * geometry 18, rows geometry 31) -- its wire stage and its graph captures launch whole frames instead -- as opposed to the row
+ * bands of the phase kernel */
+static int variant_shares_out(int v) { return ACHIP_IS_STREAM_VARIANT(v) || ACHIP_IS_ROWS_VARIANT(v); }
+
 static int choose_geometry(asciichat_hip_plan_t *p, const achip_frame_t *frames) {
   int caps[ACHIP_VARIANT_COUNT];
   for (int v = 0; v < ACHIP_VARIANT_COUNT; v++)
@@ -272,7 +277,7 @@ static int choose_geometry(asciichat_hip_plan_t *p, const achip_frame_t *frames)
   p->rows_per_part = rpp;
   p->max_cells = achip_uniform_extent(p->mode, variant, frames, p->n);
   p->whole_variant = variant;
-  if (parts > 1 && ACHIP_IS_STREAM_VARIANT(variant)) { /* what the same plan takes when it must not be shared out */
+  if (parts > 1 && variant_shares_out(variant)) { /* what the same plan takes when it must not be shared out */
     int wv = -1, wp = 1, wr = 1;
     if (achip_choose_geometry(p->mode, frames, p->n, p->palette_ascii != 0, caps, cus > 0 ? cus : 1, -1, -1, &wv, &wp, &wr) != 0 ||
         wv < 0 || wp != 1)
@@ -512,7 +517,7 @@ static int render_range_as(asciichat_hip_plan_t *p, int first, int count, uint8_
     uni.enabled = 0;
   uni.flags = (p->palette_ascii ? ACHIP_UNIFORM_PALETTE_ASCII : 0u) | ACHIP_UNIFORM_MAX_CELLS(p->max_cells);
   uni.f.src = uni.f.src ? uni.f.src + (int64_t)first * uni.src_pitch : NULL;
-  const int shared_out = p->parts > 1 && ACHIP_IS_STREAM_VARIANT(p->variant);
+  const int shared_out = p->parts > 1 && variant_shares_out(p->variant);
   if (whole && p->parts > 1 && !shared_out)
     return achip_fail(ASCIICHAT_HIP_ERR_NOT_SUPPORTED, "this plan renders row bands");
   const int variant = whole && shared_out ? p->whole_variant : p->variant, parts = whole ? 1 : p->parts;
@@ -604,7 +609,7 @@ int asciichat_hip_plan_render_packets(asciichat_hip_plan_t *p, uint8_t *out_dev,
  * pass over the slab (asciichat_hip_frame_packets_packed) -- two launches either way. */
 /* whether a wire-stage launch of this plan has every frame in ONE workgroup: whole-frame plans, and plans whose plain render
  * shares frames out over workgroups of the stream kernel (those launch whole_variant instead); not row bands */
-static int plan_frames_whole(const asciichat_hip_plan_t *p) { return p->parts == 1 || ACHIP_IS_STREAM_VARIANT(p->variant); }
+static int plan_frames_whole(const asciichat_hip_plan_t *p) { return p->parts == 1 || variant_shares_out(p->variant); }
 
 /* ---- frames at their exact lengths straight from the render kernel ------------------------- */
 /* Whole-frame launches of the per-cell foreground modes whose frames fit the kernel's LDS image (48 KB: 1080p -> 80x24
@@ -890,7 +895,7 @@ int asciichat_hip_schedule_create(asciichat_hip_schedule_t **sched, asciichat_hi
                       "schedule_create: bad arguments (n_plans must be a multiple of n_lanes, n_lanes <= 16)");
   *sched = NULL;
   for (int i = 0; i < n_plans; i++)
-    if (!plans[i] || (plans[i]->parts > 1 && !ACHIP_IS_STREAM_VARIANT(plans[i]->variant))) /* row-band launches carry a per-launch
+    if (!plans[i] || (plans[i]->parts > 1 && !variant_shares_out(plans[i]->variant))) /* row-band launches carry a per-launch
                                                                        epoch: not replayable (shared-out frames of the
                                                                        stream kernel are captured whole instead) */
       return achip_fail(ASCIICHAT_HIP_ERR_NOT_SUPPORTED, "schedule_create: plan %d renders row bands (small batch)", i);

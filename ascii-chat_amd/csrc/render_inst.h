@@ -74,7 +74,7 @@ int achipk_render_sinst_parts_launch_18(int mode, int comp, const achip_frame_t 
  * frames; one translation unit per (geometry, mode) */
 #define ACHIP_RINST_ARGS                                                                                               \
   int mode, int comp, const achip_frame_t *frames, int n, const achip_lut_t *lut, uint8_t *out, uint64_t stride,       \
-      uint32_t *len, const achip_uniform_t *uniform, const achip_wire_t *wire, void *stream
+      uint32_t *len, const achip_uniform_t *uniform, const achip_wire_t *wire, const achip_partsdev_t *ps, void *stream
 #define ACHIP_RINST_MODES(Y, id) Y(id, 0) Y(id, 5) Y(id, 6) Y(id, 7) Y(id, 8) /* mono, the four half-block modes */
 #define Y(id, m)                                                                                                       \
   int achipk_render_rinst_launch_##id##_m##m(ACHIP_RINST_ARGS);                                                         \
@@ -85,7 +85,7 @@ ACHIP_ROWS_VARIANTS(X)
 #undef Y
 #define Y(id, m)                                                                                                       \
   case m:                                                                                                              \
-    return achipk_render_rinst_launch_##id##_m##m(mode, comp, frames, n, lut, out, stride, len, uniform, wire, stream);
+    return achipk_render_rinst_launch_##id##_m##m(mode, comp, frames, n, lut, out, stride, len, uniform, wire, ps, stream);
 #define Z(id, m)                                                                                                       \
   case m:                                                                                                              \
     return achipk_render_rinst_lds_##id##_m##m(mode);

@@ -380,15 +380,21 @@ template <int MODE, int CPL, bool GENERIC, bool CRC> struct RowsMinWaves {
   static constexpr int value = (!CRC && !(GENERIC && MODE == ACHIP_MODE_HB_16 && CPL > 4)) ? 4 : 1;
 #endif
 };
-template <int MODE, int WAVES, int CPL, bool GENERIC, bool CRC = false, bool WIDE = false>
+/* PARTS (round 6; small launches -- a lone mono frame, a handful of half-block frames): a frame's blocks shared out over
+ * ps.parts four-wave workgroups exactly as the stream kernel shares out a per-cell frame (render_stream.hpp PARTS): the grid
+ * is n_frames * parts, workgroup f * parts + p takes the p-th run of ceil(blocks / parts) blocks, the look-back inside a
+ * workgroup stays in LDS, and every workgroup publishes the bytes of its blocks (ps.sync[workgroup] = {epoch, bytes}, agent
+ * scope) when its last block is counted; the first block of a workgroup waits for the words of the parts in front of it. */
+template <int MODE, int WAVES, int CPL, bool GENERIC, bool CRC = false, bool WIDE = false, bool PARTS = false>
 __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<MODE, CPL + (WIDE ? 1 : 0), GENERIC, CRC>::value))
     render_rows_kernel(const achip_frame_t *__restrict__ frames, const achip_lut_t *__restrict__ lut,
                        uint8_t *__restrict__ out, uint64_t out_stride, uint32_t *__restrict__ out_len, int n_frames,
-                       achip_uniform_t uni, achip_wire_t wire, const uint4 *__restrict__ crc_tab) {
+                       achip_uniform_t uni, achip_wire_t wire, const uint4 *__restrict__ crc_tab, achip_partsdev_t ps) {
   /* uni.flags bits 31..8 (ACHIP_UNIFORM_MAX_CELLS' field) carry the BLOCKS of the launch's largest frame here: the host
    * knows every frame's row width and rows, and the per-block LDS words are sized by it */
   static_assert(mode_has_runs(MODE), "per-cell modes use render_stream_kernel");
   static_assert(!WIDE || (!GENERIC && !CRC), "rows cut into segments: fast sampler, no fused checksum");
+  static_assert(!PARTS || (!GENERIC && !CRC && !WIDE), "shared-out frames: fast sampler, whole rows per block, no fused checksum");
   using L = RLds<MODE, WAVES, CRC, WIDE>;
   constexpr int CPG = CPL + (WIDE ? 1 : 0); /* registers per array: WIDE keeps the segment's two ghost cells in one more */
   constexpr bool HB = mode_is_halfblock(MODE);
@@ -404,8 +410,12 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
   uint32_t *slots = lds_ptr<uint32_t>(L::o_slots);
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63, wave = wave_uniform(tid >> 6);
-  const int fidx = (int)blockIdx.x;
+  const int wg = (int)blockIdx.x;
+  const int parts = PARTS ? ps.parts : 1;
+  const int fidx = PARTS ? wg / parts : wg;
+  const int part = PARTS ? wg - fidx * parts : 0;
   ACHIP_DEVICE_ONLY(
+      if (PARTS) asm volatile("" ::"s"(ps.parts), "s"(ps.epoch), "s"(ps.sync));
       asm volatile("" ::"s"(n_frames), "s"(lut), "s"(out), "s"(out_stride), "s"(out_len), "s"(frames), "s"(uni.enabled),
                    "s"(uni.flags), "s"(uni.src_pitch), "s"(uni.f.src), "s"(uni.f.comp));
       asm volatile("" ::"s"(uni.f.src_w), "s"(uni.f.src_h), "s"(uni.f.out_w), "s"(uni.f.out_h), "s"(uni.f.pad_left),
@@ -470,6 +480,15 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
       (!f.src && !f.comp) || (!GENERIC && (f.comp || f.src_w * f.src_h == 1 || f.src_w > ACHIP_ROWS_MAX_SRC_W)) || rpb < 1 || nblk > nblk_cap ||
       out_stride > (uint64_t)ACHIP_STREAM_MAX_STRIDE) {
     bad_frame();
+    return;
+  }
+  /* PARTS: this workgroup's run of blocks [b0, b1); a part behind the frame's last block only reports in */
+  const int bpp = PARTS ? (nblk + parts - 1) / parts : nblk;
+  const int b0 = PARTS ? min(part * bpp, nblk) : 0, b1 = PARTS ? min(b0 + bpp, nblk) : nblk;
+  uint32_t *partacc = lds_ptr<uint32_t>(L::o_flags); /* PARTS: [0] bytes of this workgroup's blocks so far, [1] blocks counted */
+  if (PARTS && b0 >= b1) {
+    if (tid == 0)
+      agent_store_u64(&ps.sync[wg], ((unsigned long long)ps.epoch << 32));
     return;
   }
   const uint32_t cap_bytes = (uint32_t)out_stride;
@@ -638,8 +657,8 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
   const bool late_first = GENERIC && f.comp != nullptr;
   if (late_first)
     comp_stage<L::o_comp, BLOCK>(f.comp, tid);
-  else if (wave < nblk)
-    issue_any(wave, (uint32_t)(WIDE ? row_c : wave * rpb), cm, rawT, rawB, kinds);
+  else if (b0 + wave < b1)
+    issue_any(b0 + wave, (uint32_t)(WIDE ? row_c : (b0 + wave) * rpb), cm, rawT, rawB, kinds);
 
   /* tables -> LDS; look-back words of this frame cleared */
   uint32_t *glyph = lds_ptr<uint32_t>(L::o_glyph);
@@ -669,8 +688,10 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
     glyph64[tid] = lut_g64;
     ramp[tid] = (uint8_t)lut_ramp;
   }
-  for (int k = tid; k < nblk; k += BLOCK)
+  for (int k = tid; k < b1 - b0; k += BLOCK) /* (indexed from the workgroup's first block) */
     slots[k] = 0u;
+  if (PARTS && tid < 2)
+    partacc[tid] = 0u;
   uint32_t *sumw = slots + nblk_cap; /* WIDE: the segments' summary words */
   if (WIDE)
     for (int k = tid; k < nblk; k += BLOCK)
@@ -689,14 +710,14 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
       lds_ptr<uint32_t>(L::o_crcacc)[tid] = 0u;
   }
   const uint32_t first_base = (uint32_t)f.pad_top;
-  if (first_base > 0u && first_base <= cap_bytes)
+  if (first_base > 0u && first_base <= cap_bytes && part == 0)
     for (uint32_t o = (uint32_t)tid; o < first_base; o += BLOCK)
       dst[o] = '\n';
   __syncthreads(); /* the only workgroup barrier */
   if (late_first) {
     chead = comp_head<L::o_comp>();
-    if (wave < nblk)
-      issue_any(wave, (uint32_t)(wave * rpb), cm, rawT, rawB, kinds);
+    if (b0 + wave < b1)
+      issue_any(b0 + wave, (uint32_t)((b0 + wave) * rpb), cm, rawT, rawB, kinds);
   }
 
   const LaneMasks lm = lane_masks(lane);
@@ -771,13 +792,13 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
    * loaded values.  A build with one load per sample has no such wait, measured: no faster here, slower on the metric's
    * shape in the stream kernel -- docs/history/round5.md 2b.) */
   uint32_t (&pt)[CPG] = rawT, (&pb)[CPG] = rawB;
-  if (wave < nblk)
-    to_pixels(wave, (uint32_t)(WIDE ? row_c : wave * rpb), cm, pt, pb, kinds);
-  for (int blk = wave; blk < nblk; blk += WAVES) {
+  if (b0 + wave < b1)
+    to_pixels(b0 + wave, (uint32_t)(WIDE ? row_c : (b0 + wave) * rpb), cm, pt, pb, kinds);
+  for (int blk = b0 + wave; blk < b1; blk += WAVES) {
     uint32_t pt_n[CPG], pb_n[CPG], kinds_n = 0;
     uint32_t cm_n[WIDE ? CPG : 1];
     int row_n = 0, seg_n = 0;
-    const bool more = blk + WAVES < nblk;
+    const bool more = blk + WAVES < b1;
     if constexpr (WIDE) {
       seg_n = seg_c + step_r;
       row_n = row_c + step_q;
@@ -996,14 +1017,40 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
     auto stot = [&](int k) { return (tot2[k / 2] >> (16 * (k & 1))) & 0xFFFFu; };
     /* ---- where the block starts in the frame (decoupled look-back over LDS words, as the stream kernel) */
     uint32_t base = first_base;
-    if (blk > 0) {
+    const int lb = blk - b0; /* the block's look-back word */
+    if (PARTS) {
+      /* the workgroup's bytes, for the parts behind it: whoever counts the workgroup's last block publishes the sum (its own
+       * add to [0] precedes its add to [1] in the LDS queue, like everybody's: the sum is complete) */
+      if (lane == 0) {
+        (void)slot_fetch_add(&partacc[0], total);
+        const uint32_t counted = slot_fetch_add(&partacc[1], 1u);
+        if ((int)counted == b1 - b0 - 1)
+          agent_store_u64(&ps.sync[wg], ((unsigned long long)ps.epoch << 32) | (unsigned long long)slot_load(&partacc[0]));
+      }
+    }
+    if (lb > 0) {
       if (lane == 0)
-        slot_store(&slots[blk], ACHIP_SLOT_AGG | total);
-      base = stream_lookback(slots, blk, lane);
+        slot_store(&slots[lb], ACHIP_SLOT_AGG | total);
+      base = stream_lookback(slots, lb, lane);
+    } else if (PARTS && part > 0) {
+      /* the bytes of the parts in front: lane q waits for part q's word of this launch (bounded, like the look-back) */
+      unsigned long long w = 0ull;
+      bool got = lane >= part;
+      if (!got)
+        for (int spin = 0; spin < (1 << 22); spin++) {
+          w = agent_load_u64(&ps.sync[wg - part + lane]);
+          got = (uint32_t)(w >> 32) == ps.epoch;
+          if (got)
+            break;
+          spin_nap<1>();
+        }
+      const bool lost = wave_ballot(!got) != 0ull;
+      const uint32_t sum = wave_read_lane(wave_inclusive_scan(got ? (uint32_t)w & ACHIP_SLOT_VALUE : 0u), 63);
+      base = lost ? 0xFFFFFFFFu : min(first_base + sum, cap_bytes + 1u);
     }
     const bool ok = base != 0xFFFFFFFFu && (uint64_t)base + total <= cap_bytes && !seg_lost;
     if (lane == 0)
-      slot_store(&slots[blk], ACHIP_SLOT_PREFIX | (ok ? base + total : cap_bytes + 1u));
+      slot_store(&slots[lb], ACHIP_SLOT_PREFIX | (ok ? base + total : cap_bytes + 1u));
 
     /* (the 16-colour quantiser's temporaries do not fit next to the store pass's registers in the seven-slot geometry:
      * there the conversion waits for the end of the turn) */

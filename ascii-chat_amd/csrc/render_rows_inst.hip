@@ -24,7 +24,7 @@ template <int ID> struct RGeometry;
 #define X(id, W, C)                                                                                                    \
   template <> struct RGeometry<id> {                                                                                   \
     static constexpr int WAVES = W, CPL = C;                                                                           \
-    static constexpr bool WIDE = ACHIP_ROWS_VARIANT_WIDE(id);                                                          \
+    static constexpr bool WIDE = ACHIP_ROWS_VARIANT_WIDE(id), PARTS = ACHIP_ROWS_VARIANT_PARTS(id);                    \
   };
 ACHIP_ROWS_VARIANTS(X)
 #undef X
@@ -33,11 +33,11 @@ using G = RGeometry<ACHIP_RINST>;
 /* the frame CRC riding the rows kernel's drain costs more than the stand-alone pass (hip_launch.hip:
  * achip_variant_crc_pays), so no plan takes it by itself: those instantiations exist in -DACHIP_ALL_GEOMETRIES builds only */
 #ifdef ACHIP_ALL_GEOMETRIES
-constexpr bool HAS_CRC = ACHIP_RINST != 26 && !G::WIDE;
+constexpr bool HAS_CRC = ACHIP_RINST != 26 && !G::WIDE && !G::PARTS;
 #else
 constexpr bool HAS_CRC = false;
 #endif
-constexpr bool HAS_COMP = ACHIP_RINST != 26 && !G::WIDE; /* (the sixteen-wave geometry carries the fast sampler only: achip_choose_geometry never takes it for composites / 1x1 sources) */
+constexpr bool HAS_COMP = ACHIP_RINST != 26 && !G::WIDE && !G::PARTS; /* (the sixteen-wave geometry carries the fast sampler only: achip_choose_geometry never takes it for composites / 1x1 sources) */
 
 /* the constant tables of <MODE>'s CRC instantiation: built on the device once per process, then read-only */
 template <int MODE> hipError_t crc_tables(const uint4 **out) {
@@ -73,9 +73,9 @@ template <int MODE> hipError_t crc_tables(const uint4 **out) {
 
 template <int MODE, bool COMP, bool CRC>
 hipError_t launch_one(const achip_frame_t *frames, int n, const achip_lut_t *lut, uint8_t *out, uint64_t stride,
-                      uint32_t *len, const achip_uniform_t &uni, const achip_wire_t &wire, hipStream_t stream) {
+                      uint32_t *len, const achip_uniform_t &uni, const achip_wire_t &wire, const achip_partsdev_t &ps, hipStream_t stream) {
   using L = achip::RLds<MODE, G::WAVES, CRC, G::WIDE>;
-  auto kern = achip::render_rows_kernel<MODE, G::WAVES, G::CPL, COMP, CRC, G::WIDE>;
+  auto kern = achip::render_rows_kernel<MODE, G::WAVES, G::CPL, COMP, CRC, G::WIDE, G::PARTS>;
   static bool attr_set = false; /* one flag per instantiation; benign race (idempotent call) */
   if (!attr_set) {
     if (L::bytes > 48 * 1024) {
@@ -94,8 +94,9 @@ hipError_t launch_one(const achip_frame_t *frames, int n, const achip_lut_t *lut
   }
   /* uni.flags carries the blocks of the launch's largest frame (achip_rows_max_blocks): the per-block words */
   const size_t lds = (size_t)((L::bytes_for(achip::stream_maxblk(uni.flags, 1)) + 15) & ~15);
-  hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(G::WAVES * 64), lds, stream, frames, lut, out, stride, len, n, uni, wire,
-                     tab);
+  /* (PARTS: workgroup f * parts + p renders the p-th run of frame f's blocks) */
+  hipLaunchKernelGGL(kern, dim3((unsigned)n * (unsigned)(G::PARTS ? ps.parts : 1)), dim3(G::WAVES * 64), lds, stream, frames, lut, out,
+                     stride, len, n, uni, wire, tab, ps);
   return hipGetLastError();
 }
 
@@ -107,8 +108,13 @@ hipError_t launch_one(const achip_frame_t *frames, int n, const achip_lut_t *lut
 extern "C" int ACHIP_CAT(ACHIP_CAT(ACHIP_CAT(achipk_render_rinst_launch_, ACHIP_RINST), _m), ACHIP_RMODE)(int mode, int comp, const achip_frame_t *frames, int n,
                                                                   const achip_lut_t *lut, uint8_t *out, uint64_t stride,
                                                                   uint32_t *len, const achip_uniform_t *uniform,
-                                                                  const achip_wire_t *wire, void *stream) {
+                                                                  const achip_wire_t *wire, const achip_partsdev_t *parts, void *stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
+  achip_partsdev_t ps = {1, 1u, nullptr};
+  if (parts)
+    ps = *parts;
+  if (ps.parts < 1 || ps.parts > 64 || (ps.parts > 1 && (!G::PARTS || !ps.sync || ps.epoch == 0u)))
+    return (int)hipErrorInvalidValue;
   achip_uniform_t uni = {};
   if (uniform && uniform->enabled) /* (composite batches too: achip_frames_uniform) */
     uni = *uniform;
@@ -120,18 +126,18 @@ extern "C" int ACHIP_CAT(ACHIP_CAT(ACHIP_CAT(achipk_render_rinst_launch_, ACHIP_
     if (wire) {                                                                                                        \
       if constexpr (HAS_CRC)                                                                                           \
         return (int)(!wire->crc ? hipErrorInvalidValue                                                                 \
-                     : comp     ? launch_one<m, true, true>(frames, n, lut, out, stride, len, uni, *wire, s)           \
-                                : launch_one<m, false, true>(frames, n, lut, out, stride, len, uni, *wire, s));        \
+                     : comp     ? launch_one<m, true, true>(frames, n, lut, out, stride, len, uni, *wire, ps, s)       \
+                                : launch_one<m, false, true>(frames, n, lut, out, stride, len, uni, *wire, ps, s));    \
       else                                                                                                             \
         return (int)hipErrorInvalidValue;                                                                              \
     }                                                                                                                  \
     if (comp) {                                                                                                        \
       if constexpr (HAS_COMP)                                                                                          \
-        return (int)launch_one<m, true, false>(frames, n, lut, out, stride, len, uni, achip_wire_t{}, s);              \
+        return (int)launch_one<m, true, false>(frames, n, lut, out, stride, len, uni, achip_wire_t{}, ps, s);          \
       else                                                                                                             \
         return (int)hipErrorInvalidValue;                                                                              \
     }                                                                                                                  \
-    return (int)launch_one<m, false, false>(frames, n, lut, out, stride, len, uni, achip_wire_t{}, s);
+    return (int)launch_one<m, false, false>(frames, n, lut, out, stride, len, uni, achip_wire_t{}, ps, s);
     M(ACHIP_RMODE)
 #undef M
   }

@@ -66,7 +66,7 @@
  * X(id, WAVES, CPL) */
 #ifdef ACHIP_TEST_GEOMETRY /* emulator builds only: two-row blocks of tiny frames, many blocks per wave; rows of up to four
                               64-cell segments */
-#define ACHIP_ROWS_TEST_VARIANT(X) X(28, 2, 2) X(30, 4, 1)
+#define ACHIP_ROWS_TEST_VARIANT(X) X(28, 2, 2) X(30, 4, 1) X(33, 2, 1)
 #else
 #define ACHIP_ROWS_TEST_VARIANT(X)
 #endif
@@ -79,6 +79,14 @@
                                  blocks 346 / 361 / 377 us -- the slots a segment leaves empty cost a quarter of what they
                                  hold, so ONE width serves: 320 cells, which cuts 640 / 960 / 1280 / 1920 exactly */
 #endif
+#ifndef ACHIP_ROWS_PARTS_CPL
+#define ACHIP_ROWS_PARTS_CPL 2 /* rows of up to 128 cells (achip_host.c restates it).  Measured with 2 and 4 (A/B builds,
+                                  profiles/r06_small_rows_parts.txt): with four slots -- three 80-cell rows per block, two
+                                  workgroups per frame -- nothing is gained over one eight-wave workgroup (a lone mono frame
+                                  8.1-8.4 us against 7.6); with two -- ONE row per block, six workgroups -- 6.5 us, a lone
+                                  half-block truecolor frame 8.3 against the row bands' 9.4: what shortens the frame's
+                                  latency chain is the shorter block, not the idle SIMDs */
+#endif
 #define ACHIP_ROWS_VARIANTS(X)                                                                                    \
   X(24, ACHIP_ROWS24_WAVES, 7) /* rows up to 448 cells: 4K -> 400x120 half blocks is one row per block (89 % of the slots)        */ \
   X(25, 8, 4) /* rows up to 256 cells: 200x60, 160x48 one row per block; three 80-cell rows per block             */ \
@@ -87,10 +95,14 @@
   X(27, 16, ACHIP_ROWS_WIDE_CPL) /* WIDE (round 6): rows beyond 448 cells cut into at most sixteen segments of <= 320 cells, a
                   segment per block, its two ghost cells in one more slot (render_rows.hpp); rows up to 4096 cells */ \
   X(29, 8, ACHIP_ROWS_WIDE_CPL)  /* WIDE, two eight-wave workgroups per CU: rows of at most eight segments (2560 cells) */ \
+  X(31, 4, ACHIP_ROWS_PARTS_CPL) /* PARTS (round 6): small launches of rows up to 128 cells, a frame's blocks (a text row each at
+                  80 columns) shared out over four-wave workgroups, a block per wave; fast sampler only, no fused CRC */ \
   ACHIP_ROWS_TEST_VARIANT(X)
 #define ACHIP_IS_ROWS_VARIANT(v) ((v) >= ACHIP_ROWS_VARIANT_FIRST)
 /* the geometries whose blocks are SEGMENTS of a row (render_rows.hpp WIDE): fast sampler only, no fused CRC */
 #define ACHIP_ROWS_VARIANT_WIDE(v) ((v) == 27 || (v) == 29 || (v) == 30)
 #define ACHIP_ROWS_WIDE_MAX_ROW 4096
+/* the geometries that share a frame's blocks out over several workgroups (render_rows.hpp PARTS; 33: the emulator's) */
+#define ACHIP_ROWS_VARIANT_PARTS(v) ((v) == 31 || (v) == 33)
 
 #endif

@@ -283,7 +283,7 @@ extern "C" int emu_render_stream_lenfirst(int variant, const achip_frame_t *fram
 }
 
 /* the rows kernel (render_rows.hpp): run-structured modes, whole frames; wire != nullptr: its CRC instantiation */
-template <int MODE, int WAVES, int CPL, bool CRC, bool WIDE>
+template <int MODE, int WAVES, int CPL, bool CRC, bool WIDE, bool PARTS>
 static void run_rows(int variant, const achip_frame_t *frames, int n, const achip_lut_t *lut, uint8_t *out, uint64_t stride,
                      uint32_t *len, const achip_wire_t &wire) {
   using L = achip::RLds<MODE, WAVES, CRC, WIDE>;
@@ -295,7 +295,17 @@ static void run_rows(int variant, const achip_frame_t *frames, int n, const achi
   if constexpr (WIDE) { /* rows cut into segments: fast sampler only, no fused checksum (render_rows.hpp) */
     if (!needs_generic(frames, n))
       hipemu::launch(dim3((unsigned)n), dim3(WAVES * 64), (size_t)((L::bytes_for(achip::stream_maxblk(uni.flags, 1)) + 15) & ~15), [&] {
-        achip::render_rows_kernel<MODE, WAVES, CPL, false, false, true>(frames, lut, out, stride, len, n, uni, wire, nullptr);
+        achip::render_rows_kernel<MODE, WAVES, CPL, false, false, true>(frames, lut, out, stride, len, n, uni, wire, nullptr, achip_partsdev_t{});
+      });
+    else
+      for (int i = 0; i < n; i++)
+        len[i] = ACHIP_LEN_BADDESC;
+    return;
+  } else if constexpr (PARTS) { /* a frame's blocks shared out over g_parts workgroups: fast sampler only, no fused checksum */
+    const achip_partsdev_t ps = {g_parts, g_epoch, g_part_sync};
+    if (!needs_generic(frames, n))
+      hipemu::launch(dim3((unsigned)(n * g_parts)), dim3(WAVES * 64), (size_t)((L::bytes_for(achip::stream_maxblk(uni.flags, 1)) + 15) & ~15), [&] {
+        achip::render_rows_kernel<MODE, WAVES, CPL, false, false, false, true>(frames, lut, out, stride, len, n, uni, wire, nullptr, ps);
       });
     else
       for (int i = 0; i < n; i++)
@@ -315,22 +325,22 @@ static void run_rows(int variant, const achip_frame_t *frames, int n, const achi
   const size_t lds = (size_t)((L::bytes_for(achip::stream_maxblk(uni.flags, 1)) + 15) & ~15);
   if (!needs_generic(frames, n)) {
     hipemu::launch(dim3((unsigned)n), dim3(WAVES * 64), lds, [&] {
-      achip::render_rows_kernel<MODE, WAVES, CPL, false, CRC>(frames, lut, out, stride, len, n, uni, wire, tabv);
+      achip::render_rows_kernel<MODE, WAVES, CPL, false, CRC>(frames, lut, out, stride, len, n, uni, wire, tabv, achip_partsdev_t{});
     });
     return;
   }
   hipemu::launch(dim3((unsigned)n), dim3(WAVES * 64), lds, [&] {
-    achip::render_rows_kernel<MODE, WAVES, CPL, true, CRC>(frames, lut, out, stride, len, n, uni, wire, tabv);
+    achip::render_rows_kernel<MODE, WAVES, CPL, true, CRC>(frames, lut, out, stride, len, n, uni, wire, tabv, achip_partsdev_t{});
   });
   }
 }
-template <int WAVES, int CPL, bool CRC, bool WIDE>
+template <int WAVES, int CPL, bool CRC, bool WIDE, bool PARTS>
 static int rows_by_mode(int mode, int variant, const achip_frame_t *frames, int n, const achip_lut_t *lut, uint8_t *out,
                         uint64_t stride, uint32_t *len, const achip_wire_t &wire) {
   switch (mode) {
 #define M(m)                                                                                                           \
   case m:                                                                                                              \
-    run_rows<m, WAVES, CPL, CRC && !WIDE, WIDE>(variant, frames, n, lut, out, stride, len, wire);                                     \
+    run_rows<m, WAVES, CPL, CRC && !WIDE && !PARTS, WIDE, PARTS>(variant, frames, n, lut, out, stride, len, wire);                                     \
     return 0;
     M(ACHIP_MODE_MONO)
     M(ACHIP_MODE_HB_TRUE)
@@ -348,7 +358,7 @@ extern "C" int emu_render_rows_crc(int mode, int variant, const achip_frame_t *f
   switch (variant) {
 #define X(id, W, C)                                                                                                    \
   case id:                                                                                                             \
-    return ACHIP_ROWS_VARIANT_WIDE(id) ? -1 : rows_by_mode<W, C, true, ACHIP_ROWS_VARIANT_WIDE(id)>(mode, variant, frames, n, lut, out, stride, len, wire);
+    return ACHIP_ROWS_VARIANT_WIDE(id) || ACHIP_ROWS_VARIANT_PARTS(id) ? -1 : rows_by_mode<W, C, true, ACHIP_ROWS_VARIANT_WIDE(id), ACHIP_ROWS_VARIANT_PARTS(id)>(mode, variant, frames, n, lut, out, stride, len, wire);
     ACHIP_ROWS_VARIANTS(X)
 #undef X
   }
@@ -364,11 +374,11 @@ extern "C" int emu_render_batch(int mode, int variant, const achip_frame_t *fram
     ACHIP_STREAM_VARIANTS(X)
 #undef X
   }
-  if (g_parts == 1)
+  if (g_parts == 1 || ACHIP_ROWS_VARIANT_PARTS(variant)) /* (the PARTS geometries take g_parts themselves) */
     switch (variant) {
 #define X(id, W, C)                                                                                                    \
   case id:                                                                                                             \
-    return rows_by_mode<W, C, false, ACHIP_ROWS_VARIANT_WIDE(id)>(mode, variant, frames, n, lut, out, stride, len, achip_wire_t{});
+    return rows_by_mode<W, C, false, ACHIP_ROWS_VARIANT_WIDE(id), ACHIP_ROWS_VARIANT_PARTS(id)>(mode, variant, frames, n, lut, out, stride, len, achip_wire_t{});
       ACHIP_ROWS_VARIANTS(X)
 #undef X
     }

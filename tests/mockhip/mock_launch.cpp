@@ -20,7 +20,7 @@ extern "C" int achip_launch_render(int mode, int variant, int has_composite, con
   (void)phase_cycles, (void)stream;
   if (n_frames <= 0)
     return MOCK_OK;
-  if ((variant == 26 || ACHIP_ROWS_VARIANT_WIDE(variant)) && has_composite) /* as the product's launcher: the sixteen-wave rows geometry and the segment geometries carry the fast sampler only (render_rows_inst.hip) */
+  if ((variant == 26 || ACHIP_ROWS_VARIANT_WIDE(variant) || ACHIP_ROWS_VARIANT_PARTS(variant)) && has_composite) /* as the product's launcher: the sixteen-wave rows geometry and the segment geometries carry the fast sampler only (render_rows_inst.hip) */
     return MOCK_INVALID;
   std::lock_guard<std::mutex> lock(g_emu_mu);
   const int was = emu_set_uniform(uniform && uniform->enabled ? 1 : 0);
@@ -105,7 +105,7 @@ extern "C" int achip_launch_packets_from_crc(const uint32_t *len, const uint32_t
                  [&] { achip::crc_packets_kernel(len, crc, dims, n, hdr_out, pkt_out); });
   return MOCK_OK;
 }
-extern "C" int achip_variant_has_crc(int variant) { return variant == 16 || variant == 17 || (ACHIP_IS_ROWS_VARIANT(variant) && !ACHIP_ROWS_VARIANT_WIDE(variant)); }
+extern "C" int achip_variant_has_crc(int variant) { return variant == 16 || variant == 17 || (ACHIP_IS_ROWS_VARIANT(variant) && !ACHIP_ROWS_VARIANT_WIDE(variant) && !ACHIP_ROWS_VARIANT_PARTS(variant)); }
 extern "C" int achip_variant_crc_pays(int variant) { return variant == 16 || variant == 17; }
 extern "C" int achip_launch_render_crc(int mode, int variant, int has_composite, const achip_frame_t *frames, int n,
                                        const achip_lut_t *lut, uint8_t *out, uint64_t stride, uint32_t *out_len,

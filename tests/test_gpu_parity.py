@@ -422,20 +422,24 @@ def test_multi_workgroup_frames(gpu, mode):
 
     render_batch(gpu, mode, [TORTURE], 160, 48, split=0, want_parts=shared_out(160 * 48) if cell else 48)
     render_batch(gpu, mode, [TORTURE], 160, 48, split=-1, want_parts=1)
-    # (a frame of one block per wave of the rows kernel goes whole in the short-token modes only; a lone coloured half-block
-    # frame is 24 one-row bands of the phase kernel: profiles/r04_small_run_modes.txt)
-    long_tokens = mode in (MODE_HB_TRUE, MODE_HB_TRUE + 1, MODE_HB_TRUE + 2)
-    render_batch(gpu, mode, [TORTURE], 80, 24, split=0, want_parts=shared_out(80 * 24) if cell else (24 if long_tokens else 1))
+    # (round 6: a lone 80x24 frame of a run-structured mode is 24 one-row blocks of the rows kernel shared out over six
+    # four-wave workgroups -- render_rows.hpp PARTS, profiles/r06_small_rows_parts.txt; until round 5 whole on geometry 25 in
+    # the short-token modes, 24 one-row bands of the phase kernel in the coloured half-block modes)
+    render_batch(gpu, mode, [TORTURE], 80, 24, split=0, want_parts=shared_out(80 * 24) if cell else 6)
     render_batch(gpu, mode, [TORTURE], 80, 24, split=2, want_parts=12)
 
 
-@pytest.mark.parametrize("mode", [MODE_TRUE_FG, MODE_256_FG, MODE_16_FG, MODE_TRUE_BG], ids=["true_fg", "256_fg", "16_fg", "true_bg"])
+@pytest.mark.parametrize("mode", [MODE_TRUE_FG, MODE_256_FG, MODE_16_FG, MODE_TRUE_BG, 0, 5, 6, 7, 8],
+                         ids=["true_fg", "256_fg", "16_fg", "true_bg", "mono", "hb_true", "hb_256", "hb_16", "hb_mono"])
 def test_small_launches_share_frames_out_over_workgroups(gpu, mode):
-    """PARTS instantiations of the stream kernel (geometry 18): what small launches of the per-cell modes take by themselves.
-    Lone frames, small and ragged batches, padding, three launches on the same hand-off words (a new epoch each), a range of
-    the plan's frames, and the wire-stage entry points of such a plan (which launch whole frames instead)."""
+    """PARTS instantiations of the stream kernel (geometry 18) and, round 6, of the rows kernel (geometry 31): what small
+    launches of the per-cell / the run-structured modes take by themselves.  Lone frames, small and ragged batches, padding,
+    three launches on the same hand-off words (a new epoch each), a range of the plan's frames, and the wire-stage entry
+    points of such a plan (which launch whole frames instead)."""
     pkg, torch = gpu
     per_block = 127 if mode == MODE_TRUE_FG else 128
+    run_mode = mode in (0, 5, 6, 7, 8)
+    rm = MODE_CAPS[mode][1] if run_mode else 0
     for (W, H, n, pad) in [(80, 24, 1, False), (80, 24, 9, False), (160, 48, 9, False), (97, 31, 5, True), (80, 24, 64, False),
                            (200, 60, 2, False)]:
         aspect = pad and mode != MODE_TRUE_BG
@@ -445,9 +449,10 @@ def test_small_launches_share_frames_out_over_workgroups(gpu, mode):
             assert got[k] == oracle_convert(img, mode, W, H, orc.PALETTE_STANDARD, pad, aspect), (MODE_NAMES[mode], W, H, n, k)
     # the geometry really is the shared-out one
     dev = torch.from_numpy(np.ascontiguousarray(TORTURE)).cuda()
-    fr = [pkg.frame_setup(dev.data_ptr(), TORTURE.shape[1], TORTURE.shape[0], 80, 24, 0, False, False, False) for _ in range(9)]
+    fr = [pkg.frame_setup(dev.data_ptr(), TORTURE.shape[1], TORTURE.shape[0], 80, 24, rm, False, False, False) for _ in range(9)]
     plan = pkg.Plan(mode, orc.PALETTE_STANDARD, fr)
-    assert (plan.variant, plan.parts) == (18, min(-(-1920 // per_block), 16))
+    # (run-structured modes: 24 one-row blocks, one per wave of six four-wave workgroups)
+    assert (plan.variant, plan.parts) == ((31, 6) if run_mode else (18, min(-(-1920 // per_block), 16)))
     want = oracle_convert(TORTURE, mode, 80, 24, orc.PALETTE_STANDARD)
     # frames [2, 7) only
     out = torch.full((9 * plan.stride,), 0xEE, dtype=torch.uint8, device="cuda")
@@ -501,8 +506,8 @@ def test_graph_replay_of_small_plans_captures_whole_frames(gpu):
     sched.close()
     for p in plans:
         p.close()
-    # a row-band plan (one coloured half-block frame) still cannot be captured
-    f = pkg.frame_setup(dev[0].data_ptr(), 160, 120, 80, 24, 2, False, False, False)
+    # a row-band plan (one coloured half-block frame of rows beyond the shared-out rows geometry's 128 cells) still cannot be captured
+    f = pkg.frame_setup(dev[0].data_ptr(), 160, 120, 160, 48, 2, False, False, False)
     band = pkg.Plan(MODE_HB_TRUE, orc.PALETTE_STANDARD, [f])
     assert band.parts > 1 and band.variant < 16
     o = torch.zeros(band.stride, dtype=torch.uint8, device="cuda")

@@ -845,6 +845,32 @@ def test_rows_kernel_wide_rows_limits_and_choice():
     assert choice(one, 640, 20, MODE_MONO, 256, 256) in (0, 4)    # 1x1 source: the general sampler, which the segment geometries lack
 
 
+# ---- a frame's blocks shared out over workgroups of the rows kernel (render_rows.hpp PARTS; round 6): geometry 31 (four waves x
+# two slots: rows of up to 128 cells) and the emulator's 33 (two waves x one slot: 64-cell blocks, many of them for tiny frames)
+@pytest.mark.parametrize("mode", ROWS_MODES, ids=ROWS_IDS)
+def test_rows_kernel_shared_out_over_workgroups(mode):
+    """every part count from one block per workgroup to more workgroups than blocks (the parts behind the frame's last block
+    only report in), runs that end and start at part boundaries, padding, ragged batches, three launches on the same hand-off
+    words (a new epoch each)"""
+    for (W, H, variant, parts) in [(80, 24, 31, 2), (80, 24, 31, 6), (80, 24, 31, 24), (120, 9, 31, 4), (60, 7, 33, 4), (60, 7, 33, 7),
+                                   (64, 9, 33, 5), (30, 10, 33, 5), (30, 10, 33, 16), (128, 5, 31, 2), (1, 1, 33, 2), (97, 31, 31, 8), (40, 30, 31, 3)]:
+        for src in (TORTURE, run_frames(W, 2 * H, "blocks"), run_frames(W, 2 * H, "flat"), run_frames(W, 2 * H, "black")):
+            exp = oracle_convert(src, mode, W, H, orc.PALETTE_STANDARD)
+            assert emu_convert_parts(src, mode, W, H, orc.PALETTE_STANDARD, variant, parts) == exp, (MODE_NAMES[mode], W, H, variant, parts)
+    rm = MODE_CAPS[mode][1]
+    f = emu.frame_for_convert(TORTURE, 61, 19, rm, True, True)  # aspect fit + padding: pad cells, pad_top newlines (part 0 writes them)
+    exp = oracle_convert(TORTURE, mode, 61, 19, orc.PALETTE_STANDARD, True, True)
+    for parts in (2, 5):
+        assert emu.render_frames(mode, [f], orc.PALETTE_STANDARD, 33, parts=parts)[0] == exp, (MODE_NAMES[mode], parts)
+    dims = [(64, 6), (50, 3), (60, 4), (33, 7), (64, 2), (1, 5), (20, 1)]
+    srcs = [run_frames(w, 2 * h, kind) for (w, h), kind in zip(dims, ("blocks", "flat", "stripes", "black", "blocks", "flat", "blocks"))]
+    frames = [emu.frame_for_convert(s_, w, h, rm, False, False) for s_, (w, h) in zip(srcs, dims)]
+    exp = [oracle_convert(s_, mode, w, h, orc.PALETTE_STANDARD) for s_, (w, h) in zip(srcs, dims)]
+    sync = np.zeros(len(frames) * 3, dtype=np.uint64)
+    for _ in range(3):
+        assert emu.render_frames(mode, frames, orc.PALETTE_STANDARD, 33, parts=3, sync=sync) == exp
+
+
 @pytest.mark.parametrize("variant", [16, 17, 20])
 def test_stream_kernel_word_built_sgrs_at_every_field_length_and_alignment(variant):
     for (w, h, seed) in [(97, 7, 5), (200, 3, 6), (61, 5, 7)]:

@@ -64,13 +64,18 @@ def test_split_ragged_batch_and_policy():
     assert choose(1, one) == (18, 16, 1)                      # sixteen blocks: a workgroup each while the CUs allow
     assert choose(1, one * 64) == (18, 4, 1) and choose(1, one * 65) == (16, 1, 24) and choose(1, one * 150) == (16, 1, 24)
     assert choose(1, one * 16, cus=64) == (18, 4, 1) and choose(1, one * 17, cus=64) == (16, 1, 24)  # a share of the CUs
-    assert choose(0, one) == (25, 1, 24) and choose(0, one * 64) == (25, 1, 24)   # mono: eight blocks of three rows, one per wave
+    # round 6 (profiles/r06_small_rows_parts.txt): small launches of the run-structured modes the same way on the rows kernel
+    # (geometry 31: a text row per block, a block per wave of six four-wave workgroups; a lone mono frame 6.5 us against 7.6
+    # whole, a lone half-block truecolor frame 8.3 against 9.0-9.4 as bands) while the workgroups have a CU each ...
+    assert choose(0, one) == (31, 6, 1) and choose(0, one * 42) == (31, 6, 1)
+    assert choose(0, one * 64) == (25, 1, 24)   # ... then mono whole: eight blocks of three rows, one per wave
     # ... the coloured half-block modes only from a frame per four CUs on: with fewer, row bands of the phase kernel (a thread
     # per cell) beat one wave taking 256 cells of long tokens through the path (profiles/r04_small_run_modes.txt: a lone 80x24
     # half-block truecolor frame 9.0 us as bands against 12.6 whole; 64 frames in four bands each 10.2 against 13.3)
     hb = [emu.frame_for_convert(imgs[0], 80, 24, 2)]
-    assert choose(5, hb) == (4, 24, 1) and choose(6, hb * 8) == (4, 24, 1) and choose(7, hb * 64) == (4, 4, 6)
-    assert choose(5, hb * 65) == (25, 1, 24) and choose(8, hb) == (25, 1, 24)  # (half-block mono: short tokens, whole frames)
+    assert choose(5, hb) == (31, 6, 1) and choose(6, hb * 8) == (31, 6, 1) and choose(7, hb * 64) == (4, 4, 6)
+    assert choose(5, hb, req=1) == (4, 24, 1)  # (row bands when asked for rows)
+    assert choose(5, hb * 65) == (25, 1, 24) and choose(8, hb) == (31, 6, 1) and choose(8, hb * 60) == (25, 1, 24)  # (half-block mono: short tokens, whole frames)
     assert choose(5, hb * 48) == (4, 5, 5)   # never more bands than CUs: five per frame at most (240 workgroups)
     mid = [emu.frame_for_convert(imgs[0], 160, 48, 0)]        # 7 680 cells = 61 blocks: sixteen parts (the grid's nine targets)
     assert choose(1, mid) == (18, 16, 1) and choose(1, mid * 9) == (18, 16, 1) and choose(0, mid)[1] > 1
@@ -92,11 +97,11 @@ def test_split_ragged_batch_and_policy():
     assert choose(0, one * 256, forced=4) == (4, 1, 24) and choose(0, one * 256, forced=24) == (24, 1, 24)
     with pytest.raises(AssertionError):
         choose(1, one * 256, forced=24)                       # a per-cell mode has no rows kernel
-    assert choose(1, one * 256, ascii_only=False) == (4, 1, 24)  # truecolor-fg with multi-byte glyphs too
+    assert choose(1, one * 256, ascii_only=False) == (16, 1, 24)  # truecolor-fg with multi-byte glyphs: the stream kernel too (round 6)
     assert choose(1, one * 256, forced=4) == (4, 1, 24) and choose(1, one * 256, forced=19) == (19, 1, 24)
     assert choose(5, [emu.frame_for_convert(imgs[0], 80, 24, 2)] * 600) == (25, 1, 24)  # half-block whole frames: rows kernel
     assert choose(9, one) == (4, 1, 24)                       # serial dither: never split
-    assert choose(1, one, ascii_only=False) == (4, 1, 24)     # truecolor-fg with multi-byte glyphs: never split
+    assert choose(1, one, ascii_only=False) == (16, 1, 24)    # truecolor-fg with multi-byte glyphs: never split nor shared out (its RLE state crosses blocks through LDS words)
     assert choose(2, one, ascii_only=False) == (18, 15, 1)    # (the other per-cell modes carry multi-byte glyphs on the stream kernel)
     assert choose(1, one, req=-1) == (16, 1, 24)             # never split: one whole frame -> stream kernel
     assert choose(1, one, req=12) == (4, 2, 12)
@@ -138,7 +143,9 @@ def test_split_ragged_batch_and_policy():
     k5_4k = [emu.frame_for_convert(np.zeros((2160, 3840, 3), np.uint8), 400, 120, 2)]
     assert choose(5, k5_4k * 256) == (4, 1, 120)             # BASELINE configs[4] itself, a frame per CU from 4K sources: the phase kernel
     assert choose(5, k5_4k * 192) == (26, 1, 120)            # ... up to three quarters of a frame per CU: 219 against 245 us
-    assert choose(5, [emu.frame_for_convert(imgs[0], 449, 20, 2)] * 256) == (4, 1, 20)  # a row wider than a block: phase kernel
+    wide = [emu.frame_for_convert(imgs[0], 449, 20, 2)]
+    assert choose(5, wide * 256) == (27, 1, 20) and choose(5, wide * 257) == (29, 1, 20)  # a row wider than a block: cut into segments (round 6)
+    assert choose(5, wide * 256, forced=4) == (4, 1, 20)
     wide = [emu.frame_for_convert(imgs[0], 3000, 4, 0)]
     assert choose(0, wide) == (0, 1, 4)                       # rows wider than the band geometries: no split
     assert L.achip_palette_ascii_only(orc.PALETTE_STANDARD.encode()) and not L.achip_palette_ascii_only(orc.PALETTE_COOL.encode())
