@@ -843,7 +843,12 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
   /* Rows beyond one block of the rows kernel (448 cells; round 6): cut into segments, a segment per wave (render_rows.hpp
    * WIDE) -- whole-frame launches of single sources; rows of up to 4096 cells as sixteen-wave workgroups (27), with more
    * than a frame per CU two eight-wave workgroups per CU (29) while a row is at most eight segments. */
-  if (forced_variant < 0 && run_mode && !may_split && !general_sampler && max_wp > 64 * 7) {
+  /* (audited over four row widths x seven batch sizes x {mono, truecolor half blocks} x {dense, 1080p sources} x {one launch
+   * at a time, four plans in flight}, every geometry forced in turn: profiles/r06_policy_audit_wide.txt -- ahead of the phase
+   * kernel by 15-45 % everywhere but one corner, mono on a shared GPU at up to two frames per CU of the share, where the
+   * 512-thread phase geometry is 5-12 % ahead: 128 frames of 1000x40 at a share of 64 CUs 47.6 against 53.5 us) */
+  const bool wide_corner = mode == ACHIP_MODE_MONO && n_cus <= 128 && n_frames > n_cus && n_frames <= 2 * n_cus && max_wp <= variant_caps[1];
+  if (forced_variant < 0 && run_mode && !may_split && !general_sampler && max_wp > 64 * 7 && !wide_corner) {
     const int v = n_frames > n_cus && max_wp <= rows_variant_max_row(29) ? 29 : 27;
     if (max_wp <= rows_variant_max_row(v) && achip_uniform_extent(mode, v, frames, n_frames) <= ACHIP_HOST_STREAM_MAXBLK) {
       *variant = v;

@@ -6,7 +6,8 @@ that can carry the plan is forced in turn -- whole frames on the stream / rows /
 with --inflight, four plans in flight through bench.py's C-issued schedule (what a saturated server is).  Every forced geometry's frames are compared with the
 automatic choice's on the GPU (all kernels must agree byte for byte; the automatic choice's first frame is checked against
 the oracle).  Prints one line per case: the automatic choice, the best, the regret.  GPU box only.
-usage: gpu_policy_audit.py [--inflight] [--quick] [--other-modes] [--4k] [--grid] [--dense] [--modes=name,...]"""
+--wide (round 6): rows beyond one block of the rows kernel -- the segment geometries 27 / 29 next to the phase kernel's.
+usage: gpu_policy_audit.py [--inflight] [--quick] [--other-modes] [--4k] [--grid] [--dense] [--wide] [--modes=name,...]"""
 import os
 import statistics
 import sys
@@ -80,9 +81,13 @@ if QUICK:
 SRC_W, SRC_H = (3840, 2160) if "--4k" in sys.argv else (1920, 1080)
 if "--4k" in sys.argv:
     SIZES = [(200, 60), (320, 90), (400, 120)]
+WIDE = "--wide" in sys.argv
+if WIDE:
+    SIZES = [(512, 60), (640, 90), (1000, 40), (1920, 54)]
+    BATCHES = [1, 8, 64, 128, 192, 256, 512]
 DENSE = "--dense" in sys.argv
 GRID = "--grid" in sys.argv  # the targets are composite frames: the 3x3 grid of nine 1080p sources (stream.c:523-854), sampled directly
-frames_t = bench.make_frames(torch, 9 if GRID else 256, SRC_W, SRC_H, 4242)
+frames_t = bench.make_frames(torch, 9 if GRID else 256, SRC_W, SRC_H, 4242)  # (larger batches repeat the sources)
 host0 = np.ascontiguousarray(frames_t[0].cpu().numpy())
 if GRID:
     BATCHES = [1, 4, 9, 32, 64, 256]
@@ -93,7 +98,7 @@ print(f"# {SRC_W}x{SRC_H} sources, {'four launches in flight through the C-issue
 for (mode, mname, cl, rm) in MODES:
     cell = mode in (1, 2, 3, 4)
     forced = ([("stream 16", 16, -1), ("stream 17", 17, -1), ("stream 18", 18, -1), ("stream 18 shared", 18, 0), ("stream 19", 19, -1)] if cell
-              else [("rows 25", 25, -1), ("rows 24", 24, -1), ("rows 26", 26, -1)])
+              else [("rows 27", 27, -1), ("rows 29", 29, -1)] if WIDE else [("rows 25", 25, -1), ("rows 24", 24, -1), ("rows 26", 26, -1)])
     forced += [("phase 4 whole", 4, -1), ("phase 4 bands", 4, 0), ("phase 1 whole", 1, -1), ("phase 0 whole", 0, -1), ("phase 0 bands", 0, 0)]
     for (W, H) in SIZES:
         for n in BATCHES:
@@ -112,7 +117,7 @@ for (mode, mname, cl, rm) in MODES:
                 host0 = np.ascontiguousarray(dense_t[0].cpu().numpy())
                 descs = [pkg.frame_setup(dense_t[k].data_ptr(), W, hs, W, H, rm, False, False, False) for k in range(n)]
             else:
-                descs = [pkg.frame_setup(frames_t[k].data_ptr(), SRC_W, SRC_H, W, H, rm, False, False, False) for k in range(n)]
+                descs = [pkg.frame_setup(frames_t[k % 256].data_ptr(), SRC_W, SRC_H, W, H, rm, False, False, False) for k in range(n)]
             bytes_per_frame = W * H * (41 if mode == 5 else 20)
             reps = max(8, min(300, int(4e8 / max(1, bytes_per_frame * n) / 50)))
             res = []

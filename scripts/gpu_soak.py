@@ -37,6 +37,7 @@ def main():
         rm = MODE_CAPS.get(mode, (3, 0))[1]
         nframes = int(rng.choice([1, 2, 3, 7, 16, 40, 100, 200, 300, 420]))
         big = rng.integers(0, 4) == 0
+        wide = rng.integers(0, 3) == 0
         flt = int(rng.choice([0, 0, 0, 3, 7, 11]))
         fx, fy = bool(rng.integers(0, 4) == 0), bool(rng.integers(0, 4) == 0)
         pool = []
@@ -48,6 +49,8 @@ def main():
         for k in range(nframes):
             img, dev = pool[k % len(pool)]
             W, H = (int(rng.integers(1, 520)), int(rng.integers(1, 140))) if big else (int(rng.integers(1, 200)), int(rng.integers(1, 70)))
+            if big and wide:  # round 6: rows beyond one block of the rows kernel (cut into segments, geometries 27 / 29)
+                W, H = int(rng.integers(449, 1500)), int(rng.integers(1, 40))
             f = pkg.frame_setup(dev.data_ptr(), img.shape[1], img.shape[0], W, H, rm, pad, aspect, False)
             if f is None:
                 continue
@@ -72,7 +75,7 @@ def main():
                 plan.set_split(int(rng.integers(1, 6)))
             elif choice >= 5:  # the wave-autonomous kernels: stream geometries (per-cell modes) / rows geometries (run-structured
                 # modes); refused for the other family and for rows wider than a block, with the fused CRC forced on
-                plan.set_variant(int(rng.choice([24, 25, 25, 26]) if mode in (0, 5, 6, 7, 8) else rng.choice([16, 17, 17, 18, 19])))
+                plan.set_variant(int(rng.choice([24, 25, 25, 26, 27, 29]) if mode in (0, 5, 6, 7, 8) else rng.choice([16, 17, 17, 18, 19])))
                 plan.set_fused_crc(1)
         except RuntimeError:
             pass  # geometry cannot hold this batch's rows: keep the automatic one
