@@ -19,7 +19,10 @@ def time_plan(plan, n, reps=300):
         e1.record(cur); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) / reps * 1e3)
     return statistics.median(ts), out, ln.cpu().numpy().astype("uint32")
 MODES = ((0, "mono", 0, 0), (5, "half-block truecolor", 3, 2), (6, "half-block 256", 2, 2), (7, "half-block 16", 1, 2), (8, "half-block mono", 0, 2))
-for (sw, sh, W, H) in [(640, 480, 80, 24), (1920, 1080, 80, 24), (1920, 1080, 120, 40)]:
+SIZES = [(640, 480, 80, 24), (1920, 1080, 80, 24), (1920, 1080, 120, 40)]
+if os.environ.get("SMALL_SIZES"):  # e.g. SMALL_SIZES=160x48,200x60 (1080p sources): rows beyond the shared-out geometry 31
+    SIZES = [(1920, 1080, int(t.split("x")[0]), int(t.split("x")[1])) for t in os.environ["SMALL_SIZES"].split(",")]
+for (sw, sh, W, H) in SIZES:
     for nb in ((1, 8, 64) if len(sys.argv) < 2 else tuple(int(a) for a in sys.argv[1:])):
         imgs = bench.make_frames(torch, nb, sw, sh, 5)
         host0 = np.ascontiguousarray(imgs[0].cpu().numpy())

@@ -78,7 +78,8 @@ def test_split_ragged_batch_and_policy():
     assert choose(5, hb * 65) == (25, 1, 24) and choose(8, hb) == (31, 6, 1) and choose(8, hb * 60) == (25, 1, 24)  # (half-block mono: short tokens, whole frames)
     assert choose(5, hb * 48) == (4, 5, 5)   # never more bands than CUs: five per frame at most (240 workgroups)
     mid = [emu.frame_for_convert(imgs[0], 160, 48, 0)]        # 7 680 cells = 61 blocks: sixteen parts (the grid's nine targets)
-    assert choose(1, mid) == (18, 16, 1) and choose(1, mid * 9) == (18, 16, 1) and choose(0, mid)[1] > 1
+    assert choose(1, mid) == (18, 16, 1) and choose(1, mid * 9) == (18, 16, 1)
+    assert choose(0, mid) == (32, 12, 1) and choose(0, mid * 21) == (32, 12, 1) and choose(0, mid * 22)[0] < 16  # (rows of 129-256 cells: geometry 32, a row per block; then row bands)
     assert choose(1, mid * 17)[0] < 16 and choose(1, mid * 17)[1] > 1  # sixteen parts no longer fit: row bands of the phase kernel as before
     # whole-frame launches of the per-cell modes take the stream kernel (render_stream.hpp): 1024 threads while every
     # frame has a CU to itself, 512-thread workgroups beyond that
