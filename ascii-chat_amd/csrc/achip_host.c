@@ -542,10 +542,10 @@ long achip_max_cells(const achip_frame_t *frames, int n_frames) {
 #endif
 static int rows_variant_cpl(int variant) {
   return variant == 24 || variant == 26 ? 7 : variant == 25 ? 4 : variant == 27 || variant == 29 ? ACHIP_ROWS_WIDE_CPL
-         : variant == 31 ? ACHIP_ROWS_PARTS_CPL : variant == 32 ? 4 : variant == 28 ? 2 : variant == 30 || variant == 33 ? 1 : 0;
+         : variant == 31 ? ACHIP_ROWS_PARTS_CPL : variant == 28 ? 2 : variant == 30 || variant == 33 ? 1 : 0;
 }
 /* the geometries that share a frame's blocks out over workgroups (render_variants.h ACHIP_ROWS_VARIANT_PARTS): fast sampler only */
-static bool rows_variant_parts(int variant) { return variant == 31 || variant == 32 || variant == 33; }
+static bool rows_variant_parts(int variant) { return variant == 31 || variant == 33; }
 /* the geometries whose blocks are SEGMENTS of a row (render_variants.h ACHIP_ROWS_VARIANT_WIDE; render_rows.hpp WIDE): rows of
  * at most `waves` segments of 64 * cpl cells, and of at most ACHIP_ROWS_WIDE_MAX_ROW cells */
 #define ACHIP_HOST_ROWS_WIDE_MAX_ROW 4096
@@ -738,16 +738,11 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
    * half-block truecolor frame 8.3 against 9.0-9.4 as bands (11.6 whole); eight frames 7.4 / 9.2 against 8.0 / 9.7.  With
    * 256-cell blocks (three rows each, two workgroups) nothing is gained: the shorter block shortens the chain, not the idle
    * SIMDs. */
-  /* (rows of 129-256 cells: geometry 32, four cell slots -- still ONE row per block) */
-  const int parts_variant = max_wp <= 64 * ACHIP_ROWS_PARTS_CPL ? 31 : 32;
-  static int rows32 = -1; /* ASCIICHAT_HIP_ROWS_PARTS_WIDE=0 (diagnostics, read once): rows beyond 128 cells keep their row bands */
-  if (rows32 < 0) {
-    const char *e = getenv("ASCIICHAT_HIP_ROWS_PARTS_WIDE");
-    rows32 = e && e[0] ? atoi(e) : 1;
-  }
-  if (forced_variant < 0 && run_mode && !general_sampler && may_split && split_request == 0 && max_wp <= (rows32 ? 256 : 64 * ACHIP_ROWS_PARTS_CPL) &&
-      (parts_variant == 31 || max_wp > 128)) {
-    const long nblk = achip_uniform_extent(mode, parts_variant, frames, n_frames);
+  /* (rows of 129-256 cells as ONE row per block of four cell slots were measured too -- scripts/gpu_r6_n.sh: a lone 160x48 mono
+   * frame 8.2 us against the row bands' 8.1-8.3, half-block truecolor 11.1 against 9.8-10.0, 200x60 12.6 against 10.1 -- and
+   * stay with the bands: the block is what a wave walks alone, and 160 cells are twice 80) */
+  if (forced_variant < 0 && run_mode && !general_sampler && may_split && split_request == 0 && max_wp <= 64 * ACHIP_ROWS_PARTS_CPL) {
+    const long nblk = achip_uniform_extent(mode, 31, frames, n_frames);
     long np = (nblk + 3) / 4;
     if (np > 64)
       np = 64;
@@ -763,7 +758,7 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
         np = forced;
     }
     if (np >= 2 && nblk > 0 && (nblk + np - 1) / np <= 4) {
-      *variant = parts_variant;
+      *variant = 31;
       *parts = (int)np;
       *rows_per_part = 1;
       return 0;

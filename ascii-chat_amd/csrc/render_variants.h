@@ -97,13 +97,12 @@
   X(29, 8, ACHIP_ROWS_WIDE_CPL)  /* WIDE, two eight-wave workgroups per CU: rows of at most eight segments (2560 cells) */ \
   X(31, 4, ACHIP_ROWS_PARTS_CPL) /* PARTS (round 6): small launches of rows up to 128 cells, a frame's blocks (a text row each at
                   80 columns) shared out over four-wave workgroups, a block per wave; fast sampler only, no fused CRC */ \
-  X(32, 4, 4)  /* PARTS for rows of 129-256 cells: ONE row per block (160 columns in 256 slots)                     */ \
   ACHIP_ROWS_TEST_VARIANT(X)
 #define ACHIP_IS_ROWS_VARIANT(v) ((v) >= ACHIP_ROWS_VARIANT_FIRST)
 /* the geometries whose blocks are SEGMENTS of a row (render_rows.hpp WIDE): fast sampler only, no fused CRC */
 #define ACHIP_ROWS_VARIANT_WIDE(v) ((v) == 27 || (v) == 29 || (v) == 30)
 #define ACHIP_ROWS_WIDE_MAX_ROW 4096
 /* the geometries that share a frame's blocks out over several workgroups (render_rows.hpp PARTS; 33: the emulator's) */
-#define ACHIP_ROWS_VARIANT_PARTS(v) ((v) == 31 || (v) == 32 || (v) == 33)
+#define ACHIP_ROWS_VARIANT_PARTS(v) ((v) == 31 || (v) == 33)
 
 #endif

@@ -79,7 +79,7 @@ def test_split_ragged_batch_and_policy():
     assert choose(5, hb * 48) == (4, 5, 5)   # never more bands than CUs: five per frame at most (240 workgroups)
     mid = [emu.frame_for_convert(imgs[0], 160, 48, 0)]        # 7 680 cells = 61 blocks: sixteen parts (the grid's nine targets)
     assert choose(1, mid) == (18, 16, 1) and choose(1, mid * 9) == (18, 16, 1)
-    assert choose(0, mid) == (32, 12, 1) and choose(0, mid * 21) == (32, 12, 1) and choose(0, mid * 22)[0] < 16  # (rows of 129-256 cells: geometry 32, a row per block; then row bands)
+    assert choose(0, mid)[0] < 16 and choose(0, mid)[1] > 1  # (run-structured rows beyond 128 cells: row bands of the phase kernel -- one row per 256-slot block was measured and lost, profiles/r06_small_rows_parts.txt)
     assert choose(1, mid * 17)[0] < 16 and choose(1, mid * 17)[1] > 1  # sixteen parts no longer fit: row bands of the phase kernel as before
     # whole-frame launches of the per-cell modes take the stream kernel (render_stream.hpp): 1024 threads while every
     # frame has a CU to itself, 512-thread workgroups beyond that
