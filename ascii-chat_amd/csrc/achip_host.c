@@ -826,12 +826,16 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
     if (!general_sampler && n_frames <= n_cus && achip_uniform_extent(mode, 26, frames, n_frames) <= ACHIP_HOST_STREAM_MAXBLK) {
       const bool big_src = max_src_w > 1920;
       bool take26;
+      /* (round 6, the audit again with this round's forms among the automatic choices, profiles/r06_policy_audit_run_modes.txt:
+       * from sources up to 1080p already from 120 columns -- 192 mono frames of 120x40 17.8 against 19.7 us, 64 at a share of
+       * 64 CUs 4.6 against 5.3, truecolor half blocks 128 frames 28.1 against 30.2; 256 colours from 200 columns at a full
+       * frame per CU too -- 238x70 70.5 against 81.6; mono half blocks from 220 columns -- 128 frames of 238x70 45.2 against 51.2) */
       if (mode == ACHIP_MODE_HB_TRUE || mode == ACHIP_MODE_MONO)
-        take26 = dense ? max_wp >= 120 : !big_src ? max_wp >= 160 : (max_wp > 256 && (shared_gpu || 4 * n_frames <= 3 * n_cus));
+        take26 = dense ? max_wp >= 120 : !big_src ? max_wp >= 120 : (max_wp > 256 && (shared_gpu || 4 * n_frames <= 3 * n_cus));
       else if (mode == ACHIP_MODE_HB_MONO)
-        take26 = dense ? max_wp >= 120 : (!shared_gpu && max_wp > 256);
+        take26 = dense ? max_wp >= 120 : (!shared_gpu && max_wp > 220);
       else
-        take26 = max_wp > 256 || (max_wp >= 160 && (dense || 4 * n_frames <= 3 * n_cus));
+        take26 = max_wp >= 200 || (max_wp >= 160 && (dense || 4 * n_frames <= 3 * n_cus));
       if (take26) {
         *variant = 26;
         return 0;

@@ -67,11 +67,13 @@ WORKLOADS = {
     "4k_200x60_truecolor_cool": (3840, 2160, 200, 60, 3, 0),
     "sampled_200x60_truecolor_blocks": (200, 60, 200, 60, 3, 0),
     # rows wider than one block of the rows kernel (448 cells): ascii.c:204 admits terminals up to 10 000 columns, and 4K ->
-    # 640x180 half blocks is a plain use; not part of the default run (1 GB of output per launch)
+    # 640x180 half blocks is a plain use: the rows kernel's segment geometries (render_rows.hpp WIDE)
     "4k_640x180_halfblock": (3840, 2160, 640, 180, 3, 2),
     "sampled_640x360_halfblock": (640, 360, 640, 180, 3, 2),
 }
-HEAVY_WORKLOADS = ("4k_640x180_halfblock", "sampled_640x360_halfblock")  # only when asked for by name
+# the wide-row workloads: part of the default run since round 6 (the rows kernel's segment geometries: 350-400 us per launch;
+# on the phase kernel they were 600 us of 1 GB each), but not with aspect + padding on top (4K sources twice more)
+HEAVY_WORKLOADS = ("4k_640x180_halfblock", "sampled_640x360_halfblock")
 PALETTE_BLOCKS = "   \u2591\u2591\u2592\u2592\u2593\u2593\u2588\u2588"  # PALETTE_CHARS_BLOCKS (palette.h)
 PALETTE_COOL = "   \u2581\u2582\u2583\u2584\u2585\u2586\u2587\u2588"    # PALETTE_CHARS_COOL
 WORKLOAD_PALETTE = {"1080p_80x24_truecolor_blocks": PALETTE_BLOCKS, "4k_200x60_truecolor_cool": PALETTE_COOL,
@@ -1333,7 +1335,7 @@ def main():
         if args.others == "default":
             # every BASELINE config at its own shape (noise, full W x H), then SURVEY 8(d)'s variants: the other three
             # inputs on the metric's shape and aspect + padding on every workload
-            todo = [(n, "noise", False) for n in WORKLOADS if n not in HEAVY_WORKLOADS and (n != args.workload or args.input != "noise" or args.aspect)]
+            todo = [(n, "noise", False) for n in WORKLOADS if (n != args.workload or args.input != "noise" or args.aspect)]
             todo += [(args.workload, k, False) for k in INPUT_KINDS if k != "noise"]
             todo += [(n, "noise", True) for n in WORKLOADS if n not in WORKLOAD_PALETTE and n not in HEAVY_WORKLOADS]
         else:

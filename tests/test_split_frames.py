@@ -116,10 +116,10 @@ def test_split_ragged_batch_and_policy():
     assert choose(1, m40 * 128) == (16, 1, 40)                # ... whole from half a frame per CU on (12.9 us against 16.8 as bands)
     assert choose(1, m40 * 64)[1] > 1                         # below that: row bands (10.6 against 12.1)
     hb40 = [emu.frame_for_convert(imgs[0], 120, 40, 2)]       # half blocks (40 text rows): twenty blocks a frame on the four-slot rows geometry
-    assert choose(5, hb40 * 256) == (4, 1, 40)                # a frame per CU, several blocks per wave: the phase kernel (37.5 vs 42.9)
+    assert choose(5, hb40 * 256) == (26, 1, 40)               # a frame per CU: ONE sixteen-wave workgroup of the rows kernel (round 6 audit: level with the phase kernel at 256 frames, 5-8 % ahead at 128-192)
     assert choose(8, hb40 * 256) == (4, 1, 40)                # ... the mono half-block mode too (26.1 vs 28.9)
     assert choose(5, hb40 * 256, cus=64) == (25, 1, 40)       # above a frame per CU: the rows kernel
-    assert choose(5, hb40 * 128) == (4, 1, 40)                # half blocks are not cut into bands from half a frame per CU on (30.3 vs 32.1)
+    assert choose(5, hb40 * 128) == (26, 1, 40)               # half blocks are not cut into bands from half a frame per CU on (28.1 on geometry 26 vs 30.2 on the phase kernel, 32.1 as bands)
     assert choose(5, hb40 * 64)[1] > 1                        # (64 frames: bands, 14.0 vs 28.4)
     m90 = [emu.frame_for_convert(imgs[0], 320, 90, 0)]
     assert choose(0, m90 * 256) == (26, 1, 90)                # wide mono rows: seven slots, sixteen waves (round 5: 59.5 us against 81.9 on eight)
