@@ -68,14 +68,16 @@ int asciichat_hip_plan_update(asciichat_hip_plan_t *plan, const achip_frame_t *f
 size_t asciichat_hip_plan_out_stride(const asciichat_hip_plan_t *plan);
 
 /* Kernel geometry: -1 = automatic (achip_choose_geometry: by mode, row width, frames per CU of the plan's share and the kind
- * of source), else a variant id from render_variants.h; NOT_SUPPORTED when the geometry cannot carry the plan (rows geometry
- * 26, for one, has no general sampler: no composites, no 1 x 1 sources) or is not in this build. */
+ * of source), else a variant id from render_variants.h; NOT_SUPPORTED when the geometry cannot carry the plan (rows geometries
+ * 26 / 27 / 29 / 31, for one, have no general sampler: no composites, no 1 x 1 sources; 24-26 hold rows of at most 448 cells,
+ * 27 / 29 cut rows of up to 4096 / 2560 cells into segments) or is not in this build. */
 int asciichat_hip_plan_set_variant(asciichat_hip_plan_t *plan, int variant);
 int asciichat_hip_plan_get_variant(const asciichat_hip_plan_t *plan);
 
 /* Multi-workgroup frames: 0 = automatic (small batches are shared out over several workgroups so that more of the GPU works
- * on them: a frame's blocks over four-wave workgroups of the stream kernel for the per-cell modes, variant 18; row bands of
- * the phase kernel otherwise), < 0 = never, > 0 = row bands of this many text rows per workgroup.  get_parts() reports
+ * on them: a frame's blocks over four-wave workgroups of the stream kernel for the per-cell modes, variant 18, and of the rows
+ * kernel for the run-structured modes while a row is at most 128 cells, variant 31; row bands of the phase kernel otherwise),
+ * < 0 = never, > 0 = row bands of this many text rows per workgroup.  get_parts() reports
  * workgroups per frame.  The wire-stage entry points (render_crc, render_packets*, *_packed) of a shared-out plan launch its
  * whole-frame geometry instead: a frame's checksum and its exact-length image belong to one workgroup. */
 int asciichat_hip_plan_set_split(asciichat_hip_plan_t *plan, int rows_per_part);
