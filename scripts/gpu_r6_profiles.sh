@@ -37,6 +37,10 @@ trace headline_sampled_80x24 --workload sampled_80x24_truecolor --steps 400 --re
 trace headline_sampled_80x24_s1 --workload sampled_80x24_truecolor --steps 400 --regions 3 --streams 1
 trace u8_1080p_80x24_blocks --workload 1080p_80x24_truecolor_blocks --steps 400 --regions 3 --streams 4
 trace u8_4k_200x60_cool --workload 4k_200x60_truecolor_cool --steps 100 --regions 3 --input-sets 4 --streams 4
+trace k6_sampled_640x360_hb --workload sampled_640x360_halfblock --steps 20 --regions 3 --streams 4
+trace k6_sampled_640x360_hb_s1 --workload sampled_640x360_halfblock --steps 20 --regions 3 --streams 1
+trace k6_4k_640x180_hb --workload 4k_640x180_halfblock --steps 20 --regions 3 --input-sets 4 --streams 4
+trace k1_mono_lone_frame --workload 640x480_80x24_mono --batch 1 --steps 400 --regions 3 --streams 1
 pmc() { # name, counter, bench args...
   local name=$1 ctr=$2; shift 2
   ( cd /tmp && timeout 200 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/p_$name -o p -- python $GRAFT_REPO_ROOT/bench.py $COMMON --steps 20 --regions 3 "$@" > $OUT/pmc_$name.log 2>&1 )
@@ -59,4 +63,11 @@ PY
   pmc k5_sampled_fetch FETCH_SIZE --workload sampled_400x240_halfblock --streams 4
   pmc k5_sampled_write WRITE_SIZE --workload sampled_400x240_halfblock --streams 4
   pmc k5_4k_fetch FETCH_SIZE --workload 4k_400x120_halfblock --input-sets 4 --streams 4
-  pmc k5_4k_write WRITE_SIZE --workload 4k_400x120_halfblock --input-sets 4 --streams 4; } | tee $OUT/pmc_summary.txt
+  pmc k5_4k_write WRITE_SIZE --workload 4k_400x120_halfblock --input-sets 4 --streams 4
+  pmc k6_sampled_fetch FETCH_SIZE --workload sampled_640x360_halfblock --streams 4
+  pmc k6_sampled_write WRITE_SIZE --workload sampled_640x360_halfblock --streams 4
+  pmc k6_4k_fetch FETCH_SIZE --workload 4k_640x180_halfblock --input-sets 4 --streams 4
+  pmc k6_4k_write WRITE_SIZE --workload 4k_640x180_halfblock --input-sets 4 --streams 4; } | tee $OUT/pmc_summary.txt
+# the driver's own command, twice (the round's bench line as the driver will see it)
+cd $GRAFT_REPO_ROOT
+for i in 1 2; do timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 --extra $OUT/bench_extra_driver_flags_$i.json > $OUT/bench_driver_stdout_$i.txt 2> $OUT/bench_driver_stderr_$i.txt; tail -c 600 $OUT/bench_driver_stdout_$i.txt; done

@@ -31,6 +31,11 @@ NAMES = {  # trace name -> (workload key of bench.py, kernel substring, entry ke
     "headline_sampled_80x24_s1": ("sampled_80x24_truecolor", "render_stream_kernel", "one_launch_at_a_time"),
     "u8_1080p_80x24_blocks": ("1080p_80x24_truecolor_blocks", "render_stream_kernel", "four_launches_requested_under_the_tracer"),
     "u8_4k_200x60_cool": ("4k_200x60_truecolor_cool", "render_stream_kernel", "four_launches_requested_under_the_tracer"),
+    # rows cut into segments (rows kernel, geometries 29 / 27) and the shared-out small launch (geometry 31)
+    "k6_sampled_640x360_hb": ("sampled_640x360_halfblock", "render_rows_kernel", "four_launches_requested_under_the_tracer"),
+    "k6_sampled_640x360_hb_s1": ("sampled_640x360_halfblock", "render_rows_kernel", "one_launch_at_a_time"),
+    "k6_4k_640x180_hb": ("4k_640x180_halfblock", "render_rows_kernel", "four_launches_requested_under_the_tracer"),
+    "k1_mono_lone_frame": ("640x480_80x24_mono", "render_rows_kernel", "one_launch_at_a_time"),
 }
 SOURCE = ("profiles/r06_* (round 6, one MI355X through gpurun, scripts/gpu_r6_profiles.sh: rocprofv3 --kernel-trace of bench.py, "
           "reduced by scripts/trace_stats.py; scripts/r6_commit_profiles.py)")
@@ -123,7 +128,7 @@ def main():
             if m:
                 vals[(m.group(1), m.group(2))] = float(m.group(3))
         for key, wl in (("k5_4k", "4k_400x120_halfblock"), ("k5_sampled", "sampled_400x240_halfblock"), ("headline", "1080p_80x24_truecolor"),
-                        ("k3_sampled", "sampled_200x60_truecolor")):
+                        ("k3_sampled", "sampled_200x60_truecolor"), ("k6_sampled", "sampled_640x360_halfblock"), ("k6_4k", "4k_640x180_halfblock")):
             fe, wr = vals.get((key + "_fetch", "FETCH_SIZE")), vals.get((key + "_write", "WRITE_SIZE"))
             if fe and wr:
                 ent = cp.setdefault(wl, {"not_measured_by_this_run": True})
@@ -132,6 +137,10 @@ def main():
                       "note": "FETCH_SIZE on gfx950 tallies 128-byte line fills at 64 B (MI355X_MICROARCH.md): x 2"}
                 ent.setdefault("round6", {"source": SOURCE, "not_measured_by_this_run": True, "source_id": sid})["traffic"] = tr
                 ent["traffic"] = dict(tr, alg_bytes_per_launch=(ent.get("traffic") or {}).get("alg_bytes_per_launch"))
+    for i in (1, 2):  # the driver's own command as run at the end of the visit
+        for src, dst in ((f"bench_driver_stdout_{i}.txt", f"r06_bench_driver_stdout_{i}.txt"), (f"bench_extra_driver_flags_{i}.json", f"r06_bench_extra_driver_flags_{i}.json")):
+            if os.path.exists(os.path.join(d, src)):
+                shutil.copy(os.path.join(d, src), os.path.join(PROF, dst))
     json.dump(cp, open(os.path.join(PROF, "committed_profile.json"), "w"), indent=1)
     for wl, ent in cp.items():
         fp = ent.get("frac_profile") or {}
