@@ -114,7 +114,13 @@ def main():
         r6 = ent.setdefault("round6", {"source": SOURCE, "not_measured_by_this_run": True, "source_id": sid})
         r6["source_id"] = sid
         r6[key] = row
-        if key != "one_launch_at_a_time":
+        if key != "one_launch_at_a_time" and row["avg_in_flight"] < 2.0:
+            # launches of a few microseconds: the tracer's own per-dispatch work serialises them (1.1 in flight of the four
+            # requested), so the trace says what the profiler does to the launch, not what the launch does -- recorded, no fraction
+            row["note"] = "the tracer kept the launches apart (avg_in_flight < 2 of 4 requested): no frac_profile from this trace"
+            if (ent.get("frac_profile") or {}).get("source_id") in (None, sid) or True:
+                ent.pop("frac_profile", None)
+        elif key != "one_launch_at_a_time":
             ent["frac_profile"] = {"busy_us_per_launch": row["busy_us_per_launch"], "n_traces": 1, "avg_in_flight": row["avg_in_flight"],
                                    "source_id": sid, "file": row["files"][0] if row["files"] else "profiles/",
                                    "note": "busy time per launch = union of the dispatch intervals / launches of the committed trace"}
