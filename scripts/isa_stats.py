@@ -102,12 +102,13 @@ def main():
         limit, why = None, ""
         m = re.search(r"render_frames_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb([01])ELb([01])E", name)
         ms = re.search(r"render_stream_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb([01])ELb([01])ELi(\d+)ELb([01])ELb([01])E", name)
-        mr = re.search(r"render_rows_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb([01])ELb([01])E", name)
+        mr = re.search(r"render_rows_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb([01])ELb([01])ELb([01])ELb([01])E", name)
         if mr:
             mode, waves, cpl = int(mr.group(1)), int(mr.group(2)), int(mr.group(3))
             crc = mr.group(5) == "1"
             short = (f"render_rows_kernel<mode {mode}, {waves} waves, {cpl} cells/lane, generic {mr.group(4)}"
-                     f"{', +crc' if crc else ''}>")
+                     f"{', +crc' if crc else ''}{', rows cut into segments' if mr.group(6) == '1' else ''}"
+                     f"{', frames shared out' if mr.group(7) == '1' else ''}>")
             if not crc and not (mr.group(4) == "1" and mode == 7 and cpl > 4):
                 limit, why = 128, "4 waves per SIMD: two 8-wave workgroups per CU"
         elif m:

@@ -478,34 +478,36 @@ def test_small_launches_share_frames_out_over_workgroups(gpu, mode):
 
 def test_graph_replay_of_small_plans_captures_whole_frames(gpu):
     """asciichat_hip_schedule_*: a captured launch cannot carry the per-launch epoch of frames shared out over workgroups, so
-    small plans of the per-cell modes are captured in their whole-frame geometry; row-band plans are refused as before."""
+    small plans of the per-cell modes (stream geometry 18) and -- round 6 -- of the run-structured modes (rows geometry 31) are
+    captured in their whole-frame geometry; row-band plans are refused as before."""
     pkg, torch = gpu
     imgs = [orc.frame_hash_noise(160, 120, 300 + k) for k in range(4)]
     dev = [torch.from_numpy(np.ascontiguousarray(i)).cuda() for i in imgs]
-    plans = []
-    for k in range(2):
-        fr = [pkg.frame_setup(dev[(k + j) % 4].data_ptr(), 160, 120, 80, 24, 0, False, False, False) for j in range(3)]
-        plans.append(pkg.Plan(MODE_TRUE_FG, orc.PALETTE_STANDARD, fr))
-    assert all(p.parts > 1 and p.variant == 18 for p in plans)
-    stride = plans[0].stride
-    out = [torch.full((3 * stride,), 0xEE, dtype=torch.uint8, device="cuda") for _ in range(2)]
-    ln = [torch.zeros(3, dtype=torch.int32, device="cuda") for _ in range(2)]
-    lanes = [torch.cuda.current_stream(), torch.cuda.Stream()]
-    sched = pkg.Schedule(plans, [o.data_ptr() for o in out], [x.data_ptr() for x in ln], stride, [s.cuda_stream for s in lanes])
-    for _ in range(3):  # replays of ONE captured graph
-        for o in out:
-            o.fill_(0xEE)
-        torch.cuda.synchronize()
-        sched.replay(0, 2, torch.cuda.current_stream().cuda_stream)
-        torch.cuda.synchronize()
+    for mode, rm, shared in ((MODE_TRUE_FG, 0, 18), (0, 0, 31), (MODE_HB_TRUE, 2, 31)):
+        plans = []
         for k in range(2):
-            host, lens = out[k].cpu().numpy(), ln[k].cpu().numpy()
-            for j in range(3):
-                want = oracle_convert(imgs[(k + j) % 4], MODE_TRUE_FG, 80, 24, orc.PALETTE_STANDARD)
-                assert int(lens[j]) == len(want) and host[j * stride:j * stride + len(want)].tobytes() == want, (k, j)
-    sched.close()
-    for p in plans:
-        p.close()
+            fr = [pkg.frame_setup(dev[(k + j) % 4].data_ptr(), 160, 120, 80, 24, rm, False, False, False) for j in range(3)]
+            plans.append(pkg.Plan(mode, orc.PALETTE_STANDARD, fr))
+        assert all(p.parts > 1 and p.variant == shared for p in plans), (mode, [(p.variant, p.parts) for p in plans])
+        stride = plans[0].stride
+        out = [torch.full((3 * stride,), 0xEE, dtype=torch.uint8, device="cuda") for _ in range(2)]
+        ln = [torch.zeros(3, dtype=torch.int32, device="cuda") for _ in range(2)]
+        lanes = [torch.cuda.current_stream(), torch.cuda.Stream()]
+        sched = pkg.Schedule(plans, [o.data_ptr() for o in out], [x.data_ptr() for x in ln], stride, [s.cuda_stream for s in lanes])
+        for _ in range(3):  # replays of ONE captured graph
+            for o in out:
+                o.fill_(0xEE)
+            torch.cuda.synchronize()
+            sched.replay(0, 2, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            for k in range(2):
+                host, lens = out[k].cpu().numpy(), ln[k].cpu().numpy()
+                for j in range(3):
+                    want = oracle_convert(imgs[(k + j) % 4], mode, 80, 24, orc.PALETTE_STANDARD)
+                    assert int(lens[j]) == len(want) and host[j * stride:j * stride + len(want)].tobytes() == want, (mode, k, j)
+        sched.close()
+        for p in plans:
+            p.close()
     # a row-band plan (one coloured half-block frame of rows beyond the shared-out rows geometry's 128 cells) still cannot be captured
     f = pkg.frame_setup(dev[0].data_ptr(), 160, 120, 160, 48, 2, False, False, False)
     band = pkg.Plan(MODE_HB_TRUE, orc.PALETTE_STANDARD, [f])
