@@ -542,14 +542,14 @@ long achip_max_cells(const achip_frame_t *frames, int n_frames) {
 #endif
 static int rows_variant_cpl(int variant) {
   return variant == 24 || variant == 26 ? 7 : variant == 25 ? 4 : variant == 27 || variant == 29 ? ACHIP_ROWS_WIDE_CPL
-         : variant == 31 ? ACHIP_ROWS_PARTS_CPL : variant == 28 ? 2 : variant == 30 || variant == 33 ? 1 : 0;
+         : variant == 31 ? ACHIP_ROWS_PARTS_CPL : variant == 32 || variant == 28 ? 2 : variant == 30 || variant == 33 || variant == 34 ? 1 : 0;
 }
 /* the geometries that share a frame's blocks out over workgroups (render_variants.h ACHIP_ROWS_VARIANT_PARTS): fast sampler only */
-static bool rows_variant_parts(int variant) { return variant == 31 || variant == 33; }
+static bool rows_variant_parts(int variant) { return variant == 31 || variant == 32 || variant == 33 || variant == 34; }
 /* the geometries whose blocks are SEGMENTS of a row (render_variants.h ACHIP_ROWS_VARIANT_WIDE; render_rows.hpp WIDE): rows of
  * at most `waves` segments of 64 * cpl cells, and of at most ACHIP_ROWS_WIDE_MAX_ROW cells */
 #define ACHIP_HOST_ROWS_WIDE_MAX_ROW 4096
-static int rows_variant_wide_waves(int variant) { return variant == 27 ? 16 : variant == 29 ? 8 : variant == 30 ? 4 : 0; }
+static int rows_variant_wide_waves(int variant) { return variant == 27 ? 16 : variant == 29 ? 8 : variant == 30 || variant == 32 ? 4 : variant == 34 ? 2 : 0; }
 /* segments of a padded row of wp cells (the kernel's own arithmetic: equal widths, the last one shorter, never empty) */
 static long rows_wide_segments(long wp, int cpl) {
   if (wp <= 0)
@@ -563,6 +563,26 @@ static int rows_variant_max_row(int variant) {
   if (!waves)
     return 64 * cpl;
   return 64 * cpl * waves < ACHIP_HOST_ROWS_WIDE_MAX_ROW ? 64 * cpl * waves : ACHIP_HOST_ROWS_WIDE_MAX_ROW;
+}
+
+/* ASCIICHAT_HIP_ROWS_PARTS (diagnostics, read once): 1 = the run-structured modes' small launches are never shared out over
+ * workgroups of the rows kernel, N = over this many where the CUs allow; ASCIICHAT_HIP_ROWS_PARTS_WIDE=0: not the rows of
+ * 129-512 cells (geometry 32), which keep their row bands then */
+static int rows_parts_forced(void) {
+  static int forced = -1; /* benign race */
+  if (forced < 0) {
+    const char *e = getenv("ASCIICHAT_HIP_ROWS_PARTS");
+    forced = e && e[0] ? atoi(e) : 0;
+  }
+  return forced;
+}
+static bool rows_parts_wide_enabled(void) {
+  static int on = -1; /* benign race */
+  if (on < 0) {
+    const char *e = getenv("ASCIICHAT_HIP_ROWS_PARTS_WIDE");
+    on = !(e && e[0] == '0');
+  }
+  return on != 0;
 }
 
 /* what the ACHIP_UNIFORM_MAX_CELLS field of a launch carries: cells of the largest frame for the stream geometries,
@@ -740,7 +760,7 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
    * SIMDs. */
   /* (rows of 129-256 cells as ONE row per block of four cell slots were measured too -- scripts/gpu_r6_n.sh: a lone 160x48 mono
    * frame 8.2 us against the row bands' 8.1-8.3, half-block truecolor 11.1 against 9.8-10.0, 200x60 12.6 against 10.1 -- and
-   * stay with the bands: the block is what a wave walks alone, and 160 cells are twice 80) */
+   * lost: the block is what a wave walks alone, and 160 cells are twice 80.  Such rows are cut into segments instead: below) */
   if (forced_variant < 0 && run_mode && !general_sampler && may_split && split_request == 0 && max_wp <= 64 * ACHIP_ROWS_PARTS_CPL) {
     const long nblk = achip_uniform_extent(mode, 31, frames, n_frames);
     long np = (nblk + 3) / 4;
@@ -748,17 +768,44 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
       np = 64;
     if (np * n_frames > n_cus)
       np = n_cus / n_frames;
-    { /* ASCIICHAT_HIP_ROWS_PARTS (diagnostics, read once): 1 = never, N = this many where the CUs allow */
-      static int forced = -1;
-      if (forced < 0) {
-        const char *e = getenv("ASCIICHAT_HIP_ROWS_PARTS");
-        forced = e && e[0] ? atoi(e) : 0;
-      }
+    {
+      const int forced = rows_parts_forced();
       if (forced >= 1 && forced <= 64 && (long)forced * n_frames <= n_cus)
         np = forced;
     }
     if (np >= 2 && nblk > 0 && (nblk + np - 1) / np <= 4) {
       *variant = 31;
+      *parts = (int)np;
+      *rows_per_part = 1;
+      return 0;
+    }
+  }
+  /* ... and rows of 129-512 cells cut into at most four segments of at most 128 cells, WHOLE rows per four-wave workgroup
+   * (geometry 32 = render_rows.hpp WIDE + PARTS: the segments of a row talk through LDS words, so a row never leaves its
+   * workgroup; the workgroups hand their byte counts on as above), a segment per wave: two rows per workgroup at two
+   * segments a row (160x48: 24 workgroups for a mono frame), one at three or four.  Only while every wave has ONE block.
+   * Measured against the row bands, interleaved (scripts/gpu_r6_q.sh, profiles/r06_small_rows_parts.txt visit Q; 1 / 4 / 10
+   * frames of 160x48, 200x60, 256x30, 300x40, 400x30, us per launch): mono 8.0-8.2 against 8.5 (160x48), 7.3-7.6 against
+   * 8.3-8.5 (256x30), 3-11 % ahead everywhere; mono half blocks 2-10 % ahead; truecolor half blocks level to 6 % ahead (9.8
+   * against 9.9, 9.1 against 9.7 at 256x30; never more than 0.5 % behind); the 256- / 16-colour half blocks 6-20 % BEHIND
+   * (byte-built tokens of one wave against a thread per cell: 9.7 against 9.0, 11.3 against 9.4) -- those keep their bands. */
+  const bool parts_wide_mode = short_tokens || mode == ACHIP_MODE_HB_TRUE;
+  if (forced_variant < 0 && run_mode && parts_wide_mode && !general_sampler && may_split && split_request == 0 && rows_parts_wide_enabled() &&
+      max_wp > 64 * ACHIP_ROWS_PARTS_CPL && max_wp <= rows_variant_max_row(32)) {
+    const long nseg = rows_wide_segments(max_wp, rows_variant_cpl(32));
+    const long rpw = nseg > 0 ? 4 / nseg : 0; /* rows of a workgroup */
+    long np = rpw > 0 ? (max_rows + rpw - 1) / rpw : 0;
+    if (np > 64)
+      np = 64;
+    if (np * n_frames > n_cus)
+      np = n_cus / n_frames;
+    {
+      const int forced = rows_parts_forced();
+      if (forced >= 1 && forced <= 64 && (long)forced * n_frames <= n_cus)
+        np = forced;
+    }
+    if (np >= 2 && ((max_rows + np - 1) / np) * nseg <= 4 && achip_uniform_extent(mode, 32, frames, n_frames) <= ACHIP_HOST_STREAM_MAXBLK) {
+      *variant = 32;
       *parts = (int)np;
       *rows_per_part = 1;
       return 0;

@@ -249,7 +249,7 @@ static int device_cus(void) {
 }
 
 /* a geometry whose multi-workgroup form shares a frame's BLOCKS out over workgroups of a wave-autonomous kernel (stream
- * geometry 18, rows geometry 31) -- its wire stage and its graph captures launch whole frames instead -- as opposed to the row
+ * geometry 18, rows geometries 31 / 32) -- its wire stage and its graph captures launch whole frames instead -- as opposed to the row
  * bands of the phase kernel */
 static int variant_shares_out(int v) { return ACHIP_IS_STREAM_VARIANT(v) || ACHIP_IS_ROWS_VARIANT(v); }
 
@@ -328,8 +328,8 @@ static int plan_measure(asciichat_hip_plan_t *p, const achip_frame_t *frames) {
       return achip_fail(ASCIICHAT_HIP_ERR_NOT_SUPPORTED,
                         "geometry %d does not apply to this plan (mode %d, widest padded row %d cells, %ld cells in the largest "
                         "frame): stream geometries 16-19 take the per-cell modes, rows geometries 24-26 the run-structured "
-                        "modes with rows of at most %d cells (27 / 29: rows of up to 4096 / 2560 cells cut into segments, 31: "
-                        "rows of at most 128 cells; single sources only), 1-2 no half-block mode",
+                        "modes with rows of at most %d cells (27 / 29: rows of up to 4096 / 2560 cells cut into segments, 31 / 32: "
+                        "rows of at most 128 / 512 cells; single sources only), 1-2 no half-block mode",
                         q.variant_user, q.mode, max_wp, achip_max_cells(frames, q.n), 64 * 7);
     return achip_fail(ASCIICHAT_HIP_ERR_NOT_SUPPORTED, "padded row of %d cells exceeds the kernel chunk (max %d)",
                       max_wp, achip_variant_cap(0));

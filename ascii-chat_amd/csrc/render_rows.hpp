@@ -394,7 +394,7 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
    * knows every frame's row width and rows, and the per-block LDS words are sized by it */
   static_assert(mode_has_runs(MODE), "per-cell modes use render_stream_kernel");
   static_assert(!WIDE || (!GENERIC && !CRC), "rows cut into segments: fast sampler, no fused checksum");
-  static_assert(!PARTS || (!GENERIC && !CRC && !WIDE), "shared-out frames: fast sampler, whole rows per block, no fused checksum");
+  static_assert(!PARTS || (!GENERIC && !CRC), "shared-out frames: fast sampler, no fused checksum");
   using L = RLds<MODE, WAVES, CRC, WIDE>;
   constexpr int CPG = CPL + (WIDE ? 1 : 0); /* registers per array: WIDE keeps the segment's two ghost cells in one more */
   constexpr bool HB = mode_is_halfblock(MODE);
@@ -483,7 +483,8 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
     return;
   }
   /* PARTS: this workgroup's run of blocks [b0, b1); a part behind the frame's last block only reports in */
-  const int bpp = PARTS ? (nblk + parts - 1) / parts : nblk;
+  /* (WIDE && PARTS: whole text rows per workgroup -- the segments of a row talk through LDS words) */
+  const int bpp = !PARTS ? nblk : WIDE ? ((rows + parts - 1) / parts) * nseg : (nblk + parts - 1) / parts;
   const int b0 = PARTS ? min(part * bpp, nblk) : 0, b1 = PARTS ? min(b0 + bpp, nblk) : nblk;
   uint32_t *partacc = lds_ptr<uint32_t>(L::o_flags); /* PARTS: [0] bytes of this workgroup's blocks so far, [1] blocks counted */
   if (PARTS && b0 >= b1) {
@@ -648,9 +649,10 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
   /* WIDE: (text row, segment) of the wave's block, and the step to its next one (blk + WAVES) */
   int row_c = 0, seg_c = 0;
   const int step_q = WIDE ? WAVES / nseg : 0, step_r = WIDE ? WAVES - step_q * nseg : 0;
-  if constexpr (WIDE) {
+  if constexpr (WIDE) { /* (PARTS: b0 is a multiple of nseg) */
     row_c = wave / nseg;
     seg_c = wave - row_c * nseg;
+    row_c += b0 / nseg;
     seg_records(seg_c, cm);
   }
   uint32_t rawT[CPG], rawB[CPG], kinds = 0;
@@ -692,9 +694,9 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
     slots[k] = 0u;
   if (PARTS && tid < 2)
     partacc[tid] = 0u;
-  uint32_t *sumw = slots + nblk_cap; /* WIDE: the segments' summary words */
+  uint32_t *sumw = slots + nblk_cap; /* WIDE: the segments' summary words (indexed from the workgroup's first block too) */
   if (WIDE)
-    for (int k = tid; k < nblk; k += BLOCK)
+    for (int k = tid; k < b1 - b0; k += BLOCK)
       sumw[k] = 0u;
   if (EMIT_OR) /* the OR-filled staging areas start out zero; every slice clears what it used */
     for (int k = tid; k < WAVES * L::STAGE / 16; k += BLOCK)
@@ -893,7 +895,7 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
       const uint32_t gRT = wave_read_lane(pt[CPG - 1], 1), gRB = HB ? wave_read_lane(pb[CPG - 1], 1) : 0u;
       const bool cont = xg < uwp && xg > pad_left && rows_same_run<MODE>(gRT, gRB, endT, endB);
       if (lane == 0)
-        slot_store(&sumw[blk], rows_seg_word(lead, ncb - (has_head ? last_head : 0u), has_head, last_t, cont));
+        slot_store(&sumw[blk - b0], rows_seg_word(lead, ncb - (has_head ? last_head : 0u), has_head, last_t, cont));
       /* the open run: only a segment whose first cell continues it needs its length; its head's transparency decides the
        * first head's SGRs -- equal rgb in the truecolor mode (the ghost cell tells), equal KEYS in the 256- / 16-colour
        * modes, where only a ghost cell with black's keys can belong to a run with a raw-black head (halfblock.c:357,476) */
@@ -909,13 +911,13 @@ __global__ void __launch_bounds__(WAVES * 64) ACHIP_WAVES_PER_EU((RowsMinWaves<M
         }
       }
       if (look_back) {
-        const uint32_t w = rows_seg_back(sumw, blk, (uint32_t)segw);
+        const uint32_t w = rows_seg_back(sumw, blk - b0, (uint32_t)segw);
         seg_lost |= w == 0xFFFFFFFFu;
         h_open = -(int)(w & 0xFFFFu);
         t_open = HBC && (w >> 16) != 0u;
       }
       if (cont) {
-        const uint32_t w = rows_seg_ahead(sumw, blk);
+        const uint32_t w = rows_seg_ahead(sumw, blk - b0);
         seg_lost |= w == 0xFFFFFFFFu;
         e_end = ncb + (w & 0xFFFFu);
       }

@@ -66,7 +66,7 @@
  * X(id, WAVES, CPL) */
 #ifdef ACHIP_TEST_GEOMETRY /* emulator builds only: two-row blocks of tiny frames, many blocks per wave; rows of up to four
                               64-cell segments */
-#define ACHIP_ROWS_TEST_VARIANT(X) X(28, 2, 2) X(30, 4, 1) X(33, 2, 1)
+#define ACHIP_ROWS_TEST_VARIANT(X) X(28, 2, 2) X(30, 4, 1) X(33, 2, 1) X(34, 2, 1)
 #else
 #define ACHIP_ROWS_TEST_VARIANT(X)
 #endif
@@ -97,12 +97,14 @@
   X(29, 8, ACHIP_ROWS_WIDE_CPL)  /* WIDE, two eight-wave workgroups per CU: rows of at most eight segments (2560 cells) */ \
   X(31, 4, ACHIP_ROWS_PARTS_CPL) /* PARTS (round 6): small launches of rows up to 128 cells, a frame's blocks (a text row each at
                   80 columns) shared out over four-wave workgroups, a block per wave; fast sampler only, no fused CRC */ \
+  X(32, 4, 2)  /* WIDE + PARTS: small launches of rows of 129-512 cells -- a row cut into at most four segments of <= 128
+                  cells, whole rows per four-wave workgroup                                                          */ \
   ACHIP_ROWS_TEST_VARIANT(X)
 #define ACHIP_IS_ROWS_VARIANT(v) ((v) >= ACHIP_ROWS_VARIANT_FIRST)
 /* the geometries whose blocks are SEGMENTS of a row (render_rows.hpp WIDE): fast sampler only, no fused CRC */
-#define ACHIP_ROWS_VARIANT_WIDE(v) ((v) == 27 || (v) == 29 || (v) == 30)
+#define ACHIP_ROWS_VARIANT_WIDE(v) ((v) == 27 || (v) == 29 || (v) == 30 || (v) == 32 || (v) == 34)
 #define ACHIP_ROWS_WIDE_MAX_ROW 4096
 /* the geometries that share a frame's blocks out over several workgroups (render_rows.hpp PARTS; 33: the emulator's) */
-#define ACHIP_ROWS_VARIANT_PARTS(v) ((v) == 31 || (v) == 33)
+#define ACHIP_ROWS_VARIANT_PARTS(v) ((v) == 31 || (v) == 32 || (v) == 33 || (v) == 34)
 
 #endif

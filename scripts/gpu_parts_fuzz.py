@@ -26,7 +26,7 @@ for it in range(rounds):
     pal = orc.PALETTE_STANDARD if mode == 1 else PALS[int(rng.integers(0, len(PALS)))]
     n = int(rng.choice([1, 1, 2, 3, 5, 9]))
     big = rng.random() < 0.25
-    W, H = (int(rng.integers(60, 201)), int(rng.integers(20, 71))) if big else (int(rng.integers(1, 100 if not ROWS else 129)), int(rng.integers(1, 40)))
+    W, H = (int(rng.integers(60, 201 if not ROWS else 521)), int(rng.integers(20, 71))) if big else (int(rng.integers(1, 100 if not ROWS else 129)), int(rng.integers(1, 40)))
     pad = mode != 4 and rng.random() < 0.4
     ragged = rng.random() < 0.3
     fr, want = [], []
@@ -40,7 +40,7 @@ for it in range(rounds):
             want.append(orc.convert_with_caps(srcs[i], w, h, CAPS[mode][0], CAPS[mode][1], pad, pad, False, pal))
     plan = pkg.Plan(mode, pal, fr)
     hist[(plan.variant, plan.parts > 1)] = hist.get((plan.variant, plan.parts > 1), 0) + 1
-    shared += plan.parts > 1 and plan.variant in (18, 31)
+    shared += plan.parts > 1 and plan.variant in (18, 31, 32)
     out = torch.full((n * plan.stride,), 0xEE, dtype=torch.uint8, device="cuda")
     ln = torch.zeros(n, dtype=torch.int32, device="cuda")
     for rep in range(3):

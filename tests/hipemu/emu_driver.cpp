@@ -293,9 +293,10 @@ static void run_rows(int variant, const achip_frame_t *frames, int n, const achi
   uni.flags = ((lut->flags & ACHIP_LUT_MULTIBYTE) ? 0u : ACHIP_UNIFORM_PALETTE_ASCII) |
               ACHIP_UNIFORM_MAX_CELLS(achip_uniform_extent(MODE, variant, frames, n)); /* what plan.c passes */
   if constexpr (WIDE) { /* rows cut into segments: fast sampler only, no fused checksum (render_rows.hpp) */
+    const achip_partsdev_t ps = {PARTS ? g_parts : 1, g_epoch, g_part_sync}; /* (WIDE + PARTS: whole rows per workgroup) */
     if (!needs_generic(frames, n))
-      hipemu::launch(dim3((unsigned)n), dim3(WAVES * 64), (size_t)((L::bytes_for(achip::stream_maxblk(uni.flags, 1)) + 15) & ~15), [&] {
-        achip::render_rows_kernel<MODE, WAVES, CPL, false, false, true>(frames, lut, out, stride, len, n, uni, wire, nullptr, achip_partsdev_t{});
+      hipemu::launch(dim3((unsigned)(n * ps.parts)), dim3(WAVES * 64), (size_t)((L::bytes_for(achip::stream_maxblk(uni.flags, 1)) + 15) & ~15), [&] {
+        achip::render_rows_kernel<MODE, WAVES, CPL, false, false, true, PARTS>(frames, lut, out, stride, len, n, uni, wire, nullptr, ps);
       });
     else
       for (int i = 0; i < n; i++)

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 import orc  # noqa: E402
-from achip_ctypes import (ALL_MODES, MODE_16_FG, MODE_256_FG, MODE_CAPS, MODE_HB_TRUE, MODE_NAMES, MODE_16_DITHER_BG,  # noqa: E402
+from achip_ctypes import (ALL_MODES, MODE_16_FG, MODE_256_FG, MODE_CAPS, MODE_HB_256, MODE_HB_TRUE, MODE_NAMES, MODE_16_DITHER_BG,  # noqa: E402
                           MODE_TRUE_BG, MODE_TRUE_FG)
 
 
@@ -420,7 +420,10 @@ def test_multi_workgroup_frames(gpu, mode):
         blocks = -(-cells // per_block)
         return max(-(-blocks // 4), min(blocks, 16))
 
-    render_batch(gpu, mode, [TORTURE], 160, 48, split=0, want_parts=shared_out(160 * 48) if cell else 48)
+    # (round 6, visit Q: rows of 129-512 cells of the short-token modes and of truecolor half blocks are cut into segments of at
+    # most 128 cells, whole rows per four-wave workgroup of the rows kernel -- geometry 32, 24 workgroups of two rows here; the
+    # 256- / 16-colour half blocks keep their 48 one-row bands)
+    render_batch(gpu, mode, [TORTURE], 160, 48, split=0, want_parts=shared_out(160 * 48) if cell else 24 if mode in (0, 5, 8) else 48)
     render_batch(gpu, mode, [TORTURE], 160, 48, split=-1, want_parts=1)
     # (round 6: a lone 80x24 frame of a run-structured mode is 24 one-row blocks of the rows kernel shared out over six
     # four-wave workgroups -- render_rows.hpp PARTS, profiles/r06_small_rows_parts.txt; until round 5 whole on geometry 25 in
@@ -441,7 +444,7 @@ def test_small_launches_share_frames_out_over_workgroups(gpu, mode):
     run_mode = mode in (0, 5, 6, 7, 8)
     rm = MODE_CAPS[mode][1] if run_mode else 0
     for (W, H, n, pad) in [(80, 24, 1, False), (80, 24, 9, False), (160, 48, 9, False), (97, 31, 5, True), (80, 24, 64, False),
-                           (200, 60, 2, False)]:
+                           (200, 60, 2, False), (300, 20, 3, False), (512, 9, 1, False), (257, 13, 2, True), (129, 50, 1, False)]:
         aspect = pad and mode != MODE_TRUE_BG
         imgs = [TORTURE] + [orc.frame_hash_noise(160, 120, 70 + k) for k in range(n - 1)]
         got = render_batch(gpu, mode, imgs, W, H, wants_padding=pad, use_aspect=aspect, repeat=3)
@@ -453,6 +456,10 @@ def test_small_launches_share_frames_out_over_workgroups(gpu, mode):
     plan = pkg.Plan(mode, orc.PALETTE_STANDARD, fr)
     # (run-structured modes: 24 one-row blocks, one per wave of six four-wave workgroups)
     assert (plan.variant, plan.parts) == ((31, 6) if run_mode else (18, min(-(-1920 // per_block), 16)))
+    if run_mode:  # rows of 129-512 cells: segments of at most 128 cells, whole rows per workgroup (geometry 32 = WIDE + PARTS)
+        mid = pkg.Plan(mode, orc.PALETTE_STANDARD, [pkg.frame_setup(dev.data_ptr(), TORTURE.shape[1], TORTURE.shape[0], 160, 48, rm, False, False, False)] * 2)
+        assert (mid.variant, mid.parts) == ((32, 24) if mode in (0, 5, 8) else (4, 48))  # (256 / 16 colours: row bands, measured)
+        mid.close()
     want = oracle_convert(TORTURE, mode, 80, 24, orc.PALETTE_STANDARD)
     # frames [2, 7) only
     out = torch.full((9 * plan.stride,), 0xEE, dtype=torch.uint8, device="cuda")
@@ -478,15 +485,15 @@ def test_small_launches_share_frames_out_over_workgroups(gpu, mode):
 
 def test_graph_replay_of_small_plans_captures_whole_frames(gpu):
     """asciichat_hip_schedule_*: a captured launch cannot carry the per-launch epoch of frames shared out over workgroups, so
-    small plans of the per-cell modes (stream geometry 18) and -- round 6 -- of the run-structured modes (rows geometry 31) are
-    captured in their whole-frame geometry; row-band plans are refused as before."""
+    small plans of the per-cell modes (stream geometry 18) and -- round 6 -- of the run-structured modes (rows geometries 31 / 32)
+    are captured in their whole-frame geometry; row-band plans are refused as before."""
     pkg, torch = gpu
     imgs = [orc.frame_hash_noise(160, 120, 300 + k) for k in range(4)]
     dev = [torch.from_numpy(np.ascontiguousarray(i)).cuda() for i in imgs]
-    for mode, rm, shared in ((MODE_TRUE_FG, 0, 18), (0, 0, 31), (MODE_HB_TRUE, 2, 31)):
+    for mode, rm, shared, W, H in ((MODE_TRUE_FG, 0, 18, 80, 24), (0, 0, 31, 80, 24), (MODE_HB_TRUE, 2, 31, 80, 24), (0, 0, 32, 160, 48), (MODE_HB_TRUE, 2, 32, 300, 20)):
         plans = []
         for k in range(2):
-            fr = [pkg.frame_setup(dev[(k + j) % 4].data_ptr(), 160, 120, 80, 24, rm, False, False, False) for j in range(3)]
+            fr = [pkg.frame_setup(dev[(k + j) % 4].data_ptr(), 160, 120, W, H, rm, False, False, False) for j in range(3)]
             plans.append(pkg.Plan(mode, orc.PALETTE_STANDARD, fr))
         assert all(p.parts > 1 and p.variant == shared for p in plans), (mode, [(p.variant, p.parts) for p in plans])
         stride = plans[0].stride
@@ -503,14 +510,14 @@ def test_graph_replay_of_small_plans_captures_whole_frames(gpu):
             for k in range(2):
                 host, lens = out[k].cpu().numpy(), ln[k].cpu().numpy()
                 for j in range(3):
-                    want = oracle_convert(imgs[(k + j) % 4], mode, 80, 24, orc.PALETTE_STANDARD)
+                    want = oracle_convert(imgs[(k + j) % 4], mode, W, H, orc.PALETTE_STANDARD)
                     assert int(lens[j]) == len(want) and host[j * stride:j * stride + len(want)].tobytes() == want, (mode, k, j)
         sched.close()
         for p in plans:
             p.close()
-    # a row-band plan (one coloured half-block frame of rows beyond the shared-out rows geometry's 128 cells) still cannot be captured
+    # a row-band plan (one 256-colour half-block frame of rows beyond the shared-out rows geometry's 128 cells) still cannot be captured
     f = pkg.frame_setup(dev[0].data_ptr(), 160, 120, 160, 48, 2, False, False, False)
-    band = pkg.Plan(MODE_HB_TRUE, orc.PALETTE_STANDARD, [f])
+    band = pkg.Plan(MODE_HB_256, orc.PALETTE_STANDARD, [f])
     assert band.parts > 1 and band.variant < 16
     o = torch.zeros(band.stride, dtype=torch.uint8, device="cuda")
     x = torch.zeros(1, dtype=torch.int32, device="cuda")

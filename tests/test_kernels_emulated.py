@@ -786,6 +786,20 @@ def test_rows_kernel_wide_rows_open_run_transparency_across_segments(mode):
                 img[:, end:end + 2] = (9, 200, 33)  # the head that reads the state
                 exp = oracle_convert(img, mode, w, 1, orc.PALETTE_STANDARD)
                 assert emu_convert(img, mode, w, 1, orc.PALETTE_STANDARD, 30) == exp, (MODE_NAMES[mode], head_at, run, head_rgb)
+    # ... and in a workgroup that is not the frame's first (WIDE + PARTS, the emulator's 34: two 64-cell segments, a row per part)
+    for head_at in (0, 40, 63, 64, 65):
+        for run in (1, 24, 60):
+            for head_rgb, tail_rgb in (((0, 0, 0), (1, 1, 1)), ((1, 1, 1), (0, 0, 0)), ((0, 0, 0), (0, 0, 0))):
+                w = 126
+                img = np.zeros((6, w, 3), np.uint8)
+                img[:, :] = (200, 10, 90)
+                img[:, :head_at] = np.random.default_rng(head_at).integers(3, 256, (6, head_at, 3)) if head_at else 0
+                end = min(w - 3, head_at + run)
+                img[:, head_at:end] = tail_rgb
+                img[:, head_at] = head_rgb
+                img[:, end:end + 2] = (9, 200, 33)
+                exp = oracle_convert(img, mode, w, 3, orc.PALETTE_STANDARD)
+                assert emu_convert_parts(img, mode, w, 3, orc.PALETTE_STANDARD, 34, 3) == exp, (MODE_NAMES[mode], head_at, run, head_rgb)
 
 
 @pytest.mark.parametrize("mode", ROWS_MODES, ids=ROWS_IDS)
@@ -869,6 +883,29 @@ def test_rows_kernel_shared_out_over_workgroups(mode):
     sync = np.zeros(len(frames) * 3, dtype=np.uint64)
     for _ in range(3):
         assert emu.render_frames(mode, frames, orc.PALETTE_STANDARD, 33, parts=3, sync=sync) == exp
+
+
+@pytest.mark.parametrize("mode", ROWS_MODES, ids=ROWS_IDS)
+def test_rows_kernel_segments_shared_out_over_workgroups(mode):
+    """WIDE + PARTS (geometry 32: rows of 129-512 cells in segments of at most 128, whole rows per four-wave workgroup) through
+    the emulator's 34 (two waves x 64-cell segments: rows of up to 128 cells): runs across the segment boundary inside a
+    workgroup, rows that end a part, more parts than rows, one-segment rows, padding, ragged batches on the same hand-off words"""
+    for (W, H, parts) in [(100, 6, 2), (128, 7, 3), (65, 5, 5), (128, 4, 4), (90, 9, 9), (127, 3, 7), (64, 4, 2), (30, 5, 3), (128, 1, 2)]:
+        for src in (TORTURE, run_frames(W, 2 * H, "blocks"), run_frames(W, 2 * H, "flat"), run_frames(W, 2 * H, "black"), run_frames(W, 2 * H, "stripes")):
+            exp = oracle_convert(src, mode, W, H, orc.PALETTE_STANDARD)
+            assert emu_convert_parts(src, mode, W, H, orc.PALETTE_STANDARD, 34, parts) == exp, (MODE_NAMES[mode], W, H, parts)
+    rm = MODE_CAPS[mode][1]
+    f = emu.frame_for_convert(TORTURE, 120, 19, rm, True, True)  # aspect fit + padding: pad cells in the first segment, pad_top newlines
+    exp = oracle_convert(TORTURE, mode, 120, 19, orc.PALETTE_STANDARD, True, True)
+    for parts in (2, 5, 19):
+        assert emu.render_frames(mode, [f], orc.PALETTE_STANDARD, 34, parts=parts)[0] == exp, (MODE_NAMES[mode], parts)
+    dims = [(128, 6), (100, 3), (65, 4), (33, 7), (128, 2), (1, 5), (90, 1)]
+    srcs = [run_frames(w, 2 * h, kind) for (w, h), kind in zip(dims, ("blocks", "flat", "stripes", "black", "blocks", "flat", "blocks"))]
+    frames = [emu.frame_for_convert(s_, w, h, rm, False, False) for s_, (w, h) in zip(srcs, dims)]
+    exp = [oracle_convert(s_, mode, w, h, orc.PALETTE_STANDARD) for s_, (w, h) in zip(srcs, dims)]
+    sync = np.zeros(len(frames) * 3, dtype=np.uint64)
+    for _ in range(3):
+        assert emu.render_frames(mode, frames, orc.PALETTE_STANDARD, 34, parts=3, sync=sync) == exp
 
 
 @pytest.mark.parametrize("variant", [16, 17, 20])

@@ -79,7 +79,16 @@ def test_split_ragged_batch_and_policy():
     assert choose(5, hb * 48) == (4, 5, 5)   # never more bands than CUs: five per frame at most (240 workgroups)
     mid = [emu.frame_for_convert(imgs[0], 160, 48, 0)]        # 7 680 cells = 61 blocks: sixteen parts (the grid's nine targets)
     assert choose(1, mid) == (18, 16, 1) and choose(1, mid * 9) == (18, 16, 1)
-    assert choose(0, mid)[0] < 16 and choose(0, mid)[1] > 1  # (run-structured rows beyond 128 cells: row bands of the phase kernel -- one row per 256-slot block was measured and lost, profiles/r06_small_rows_parts.txt)
+    # run-structured rows of 129-512 cells: cut into segments of at most 128 cells, whole rows per four-wave workgroup, a segment
+    # per wave (geometry 32 = the rows kernel's WIDE + PARTS; one row per 256-slot block was measured before and lost to the row
+    # bands, profiles/r06_small_rows_parts.txt) -- while every workgroup has a CU and every wave one block
+    hbmid = [emu.frame_for_convert(imgs[0], 160, 48, 2)]
+    assert choose(0, mid) == (32, 24, 1) and choose(5, hbmid) == (32, 24, 1) and choose(0, mid * 10) == (32, 24, 1) and choose(8, hbmid) == (32, 24, 1)
+    assert choose(6, hbmid)[0] < 16 and choose(7, hbmid) == choose(6, hbmid) and choose(6, hbmid)[1] > 1  # 256 / 16 colours: 6-20 % behind their row bands (visit Q), which they keep
+    assert choose(0, mid * 11)[0] < 16 and choose(0, mid * 11)[1] > 1   # 264 workgroups: row bands of the phase kernel as before
+    wide3 = [emu.frame_for_convert(imgs[0], 300, 20, 0)]  # three segments of 100 cells: a row per workgroup
+    assert choose(0, wide3) == (32, 20, 1) and choose(0, [emu.frame_for_convert(imgs[0], 512, 9, 0)]) == (32, 9, 1)
+    assert choose(0, [emu.frame_for_convert(imgs[0], 513, 9, 0)])[0] < 16   # five segments: no four-wave workgroup holds the row
     assert choose(1, mid * 17)[0] < 16 and choose(1, mid * 17)[1] > 1  # sixteen parts no longer fit: row bands of the phase kernel as before
     # whole-frame launches of the per-cell modes take the stream kernel (render_stream.hpp): 1024 threads while every
     # frame has a CU to itself, 512-thread workgroups beyond that
