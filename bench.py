@@ -1004,7 +1004,7 @@ LINE_TARGET_BYTES = 4096  # the stdout line the driver parses: small enough to s
 LINE_HARD_LIMIT_BYTES = 8192
 _COMPACT_TOP = ("metric", "value", "unit", "n_gpus", "rccl_ranks", "steps", "warmup", "ms_per_step", "higher_is_better",
                 "scaling", "vs_baseline", "dtype", "data")
-_COMPACT_ROOFLINE = ("bound", "achieved", "peak", "unit", "frac", "frac_profile", "frac_profile_best", "frac_profile_n", "frac_profile_source", "traffic",
+_COMPACT_ROOFLINE = ("bound", "achieved", "peak", "unit", "frac", "frac_timed_region", "frac_profile", "frac_profile_best", "frac_profile_n", "frac_profile_source", "traffic",
                      "traffic_source", "alg_bytes_per_launch", "kernel_ms", "launches_in_flight")
 _COMPACT_CPU = ("value", "unit", "cores", "kind", "sample", "cpu_model")
 
@@ -1236,6 +1236,9 @@ def main():
                    "launches_in_flight": res["streams"]},
         "roofline": {"bound": "hbm", "achieved": main_d["roofline_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": main_d["roofline_frac"], "traffic": None,
+                     # the same algorithmic bytes over the TIMED REGIONS' own clock (ms_per_step, what `value` is made of:
+                     # a short region carries the queues' wake-up, so this one is the lower of the two -- VERDICT r5 weak 9)
+                     "frac_timed_region": res["alg_bytes_per_launch"] / (main_d["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "alg_bytes_per_launch": res["alg_bytes_per_launch"], "kernel_ms": res["gpu_ms"],
                      "launches_in_flight": res["streams"], "out_bytes_per_frame": res["out_bytes_per_frame"],
                      "kernel_ms_note": "GPU time per step (HIP events on the launch streams, first begin -> last end of a "
