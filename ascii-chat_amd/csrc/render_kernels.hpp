@@ -115,35 +115,34 @@ __device__ inline uint32_t quant256(uint32_t p) {
   return (uint32_t)(16 + 36 * ((r * 5) / 255) + 6 * ((g * 5) / 255) + ((b * 5) / 255));
 }
 
-/* rgb_to_16color, ansi.c:437-477: first minimum of the squared distance to the 16 fixed colours */
+/* rgb_to_16color, ansi.c:437-477: first minimum of the squared distance to the 16 fixed colours (table at ansi.c:442-459:
+ *   0-6, 8: {0, 128}^3 with index = R | G << 1 | B << 2 (all three set: 8); 7: (192, 192, 192); 9-15: {0, 255}^3, 8 + the same bits)
+ * -- found without walking the table (round 6: 144 -> ~45 vector instructions; the 16-colour modes run this once or twice per
+ * cell, the Floyd-Steinberg renderer once per step of its serial chain).  The nearest colour of {0, 128}^3 and of {0, 255}^3 is
+ * decided channel by channel (the squared distance is a sum over channels), and so is the lowest-index one among equals: a
+ * channel exactly between 0 and 128 (64) keeps its bit clear, 127.5 is no byte.  The three candidates -- the dark cube's, the
+ * bright cube's, colour 7 -- then compete as (distance << 4 | index): the smallest key is the smallest distance and, among
+ * equals, the smallest index, which is what the reference's strict `<` over ascending indices keeps.  (Black belongs to both
+ * cubes with the same key.)  Checked against the table walk for all 2^24 colours: tests/test_kernels_emulated.py. */
 __device__ inline uint32_t quant16(uint32_t p) {
   const int r = (int)px_r(p), g = (int)px_g(p), b = (int)px_b(p);
-  /* packed 0xBBGGRR of the table at ansi.c:442-459 */
-  const uint32_t tbl[16] = {0x000000u, 0x000080u, 0x008000u, 0x008080u, 0x800000u, 0x800080u, 0x808000u, 0xC0C0C0u,
-                            0x808080u, 0x0000FFu, 0x00FF00u, 0x00FFFFu, 0xFF0000u, 0xFF00FFu, 0xFFFF00u, 0xFFFFFFu};
-  uint32_t best = 0;
-  int best_d = 0x7FFFFFFF;
-#pragma unroll
-  for (int i = 0; i < 16; i++) {
-    const int dr = r - (int)(tbl[i] & 0xFF), dg = g - (int)((tbl[i] >> 8) & 0xFF), db = b - (int)(tbl[i] >> 16);
-    const int d = dr * dr + dg * dg + db * db;
-    if (d < best_d) {
-      best_d = d;
-      best = (uint32_t)i;
-    }
-  }
-  return best;
+  const bool r1 = r > 64, g1 = g > 64, b1 = b > 64;       /* nearer to 128 than to 0 */
+  const bool r2 = r >= 128, g2 = g >= 128, b2 = b >= 128; /* nearer to 255 than to 0 */
+  const int dr1 = r1 ? r - 128 : r, dg1 = g1 ? g - 128 : g, db1 = b1 ? b - 128 : b;
+  const int dr2 = r2 ? r - 255 : r, dg2 = g2 ? g - 255 : g, db2 = b2 ? b - 255 : b;
+  const int dr7 = r - 192, dg7 = g - 192, db7 = b - 192;
+  const uint32_t bits1 = (r1 ? 1u : 0u) | (g1 ? 2u : 0u) | (b1 ? 4u : 0u), bits2 = (r2 ? 1u : 0u) | (g2 ? 2u : 0u) | (b2 ? 4u : 0u);
+  const uint32_t k1 = ((uint32_t)(dr1 * dr1 + dg1 * dg1 + db1 * db1) << 4) | (bits1 == 7u ? 8u : bits1);
+  const uint32_t k2 = ((uint32_t)(dr2 * dr2 + dg2 * dg2 + db2 * db2) << 4) | (bits2 ? 8u + bits2 : 0u);
+  const uint32_t k7 = ((uint32_t)(dr7 * dr7 + dg7 * dg7 + db7 * db7) << 4) | 7u;
+  return min(min(k1, k2), k7) & 15u;
 }
 
-/* packed 0xBBGGRR of ANSI colour idx (get_16color_rgb, ansi.c:480-509) */
+/* packed 0xBBGGRR of ANSI colour idx (get_16color_rgb, ansi.c:480-509): the table's structure again */
 __device__ inline uint32_t ansi16_rgb(uint32_t idx) {
-  const uint32_t tbl[16] = {0x000000u, 0x000080u, 0x008000u, 0x008080u, 0x800000u, 0x800080u, 0x808000u, 0xC0C0C0u,
-                            0x808080u, 0x0000FFu, 0x00FF00u, 0x00FFFFu, 0xFF0000u, 0xFF00FFu, 0xFFFF00u, 0xFFFFFFu};
-  uint32_t v = 0;
-#pragma unroll
-  for (int i = 0; i < 16; i++)
-    v = idx == (uint32_t)i ? tbl[i] : v;
-  return v;
+  const uint32_t bits = idx & 7u; /* 1-6, 9-15: the channels that are set; 7: all at 192; 8: all at 128 */
+  const uint32_t spread = (bits & 1u) | ((bits & 2u) << 7) | ((bits & 4u) << 14);
+  return idx == 7u ? 0xC0C0C0u : idx == 8u ? 0x808080u : spread * (idx > 8u ? 0xFFu : 0x80u);
 }
 
 /* UTF-8 sequence length from the lead byte -- the palette parser's rule (common.c:397-410) */

@@ -70,7 +70,17 @@ WORKLOADS = {
     # 640x180 half blocks is a plain use: the rows kernel's segment geometries (render_rows.hpp WIDE)
     "4k_640x180_halfblock": (3840, 2160, 640, 180, 3, 2),
     "sampled_640x360_halfblock": (640, 360, 640, 180, 3, 2),
+    # the two renderers of SURVEY 8(a) no other leg reaches at the metric's shape: monochrome frames in a batch (PM, rows kernel)
+    # and the serial Floyd-Steinberg 16-colour background renderer (PD: TRUECOLOR + BACKGROUND, sgr.c:429) -- one wave per frame
+    # on the phase kernel; plain legs only (no aspect + padding variant)
+    "1080p_80x24_mono": (1920, 1080, 80, 24, 0, 0),
+    "1080p_80x24_dither16_bg": (1920, 1080, 80, 24, 3, 1),
 }
+PLAIN_ONLY_WORKLOADS = ("1080p_80x24_mono", "1080p_80x24_dither16_bg")
+# the 16-colour renderers (P16, H16) beside them: named workloads for A/B runs (scripts/gpu_abn.sh), not part of the default run
+WORKLOADS.update({"1080p_80x24_ansi16": (1920, 1080, 80, 24, 1, 0), "sampled_200x60_ansi16": (200, 60, 200, 60, 1, 0),
+                  "1080p_80x24_halfblock16": (1920, 1080, 80, 24, 1, 2), "sampled_400x240_halfblock16": (400, 240, 400, 120, 1, 2)})
+ON_REQUEST_WORKLOADS = ("1080p_80x24_ansi16", "sampled_200x60_ansi16", "1080p_80x24_halfblock16", "sampled_400x240_halfblock16")
 # the wide-row workloads: part of the default run since round 6 (the rows kernel's segment geometries: 350-400 us per launch;
 # on the phase kernel they were 600 us of 1 GB each), but not with aspect + padding on top (4K sources twice more)
 HEAVY_WORKLOADS = ("4k_640x180_halfblock", "sampled_640x360_halfblock")
@@ -1338,9 +1348,9 @@ def main():
         if args.others == "default":
             # every BASELINE config at its own shape (noise, full W x H), then SURVEY 8(d)'s variants: the other three
             # inputs on the metric's shape and aspect + padding on every workload
-            todo = [(n, "noise", False) for n in WORKLOADS if (n != args.workload or args.input != "noise" or args.aspect)]
+            todo = [(n, "noise", False) for n in WORKLOADS if (n != args.workload or args.input != "noise" or args.aspect) and n not in ON_REQUEST_WORKLOADS]
             todo += [(args.workload, k, False) for k in INPUT_KINDS if k != "noise"]
-            todo += [(n, "noise", True) for n in WORKLOADS if n not in WORKLOAD_PALETTE and n not in HEAVY_WORKLOADS]
+            todo += [(n, "noise", True) for n in WORKLOADS if n not in WORKLOAD_PALETTE and n not in HEAVY_WORKLOADS and n not in PLAIN_ONLY_WORKLOADS and n not in ON_REQUEST_WORKLOADS]
         else:
             todo = [(n, "noise", False) for n in args.others.split(",") if n in WORKLOADS and n != args.workload]
         for name, kind, aspect in todo:

@@ -457,6 +457,35 @@ static achip::CrcFinish span_finish(uint32_t *counters, int rounds, uint64_t v_b
   return fin;
 }
 
+/* quant16 / ansi16_rgb (render_kernels.hpp: the 16-colour table's structure instead of a walk over it) against the walk itself --
+ * rgb_to_16color's loop, ansi.c:437-477, restated here -- for ALL 2^24 colours; returns the number of colours that differ */
+extern "C" long emu_quant16_check(uint32_t *first_bad) {
+  static const uint8_t tbl[16][3] = {{0, 0, 0},       {128, 0, 0},   {0, 128, 0},   {128, 128, 0}, {0, 0, 128},   {128, 0, 128},
+                                     {0, 128, 128},   {192, 192, 192}, {128, 128, 128}, {255, 0, 0},   {0, 255, 0},   {255, 255, 0},
+                                     {0, 0, 255},     {255, 0, 255}, {0, 255, 255}, {255, 255, 255}};
+  long bad = 0;
+  for (uint32_t i = 0; i < 16; i++) {
+    const uint32_t want = (uint32_t)tbl[i][0] | ((uint32_t)tbl[i][1] << 8) | ((uint32_t)tbl[i][2] << 16);
+    if (achip::ansi16_rgb(i) != want && !bad++ && first_bad)
+      *first_bad = 0xFF000000u | i;
+  }
+  for (uint32_t p = 0; p < (1u << 24); p++) {
+    const int r = (int)(p & 0xFF), g = (int)((p >> 8) & 0xFF), b = (int)(p >> 16);
+    int best = 0, best_d = 0x7FFFFFFF;
+    for (int i = 0; i < 16; i++) {
+      const int dr = r - tbl[i][0], dg = g - tbl[i][1], db = b - tbl[i][2];
+      const int d = dr * dr + dg * dg + db * db;
+      if (d < best_d) {
+        best_d = d;
+        best = i;
+      }
+    }
+    if (achip::quant16(p) != (uint32_t)best && !bad++ && first_bad)
+      *first_bad = p;
+  }
+  return bad;
+}
+
 /* the launcher's geometry (hip_launch.hip: achip_launch_crc32c) restated for the emulator; force_parts > 1
  * sends small buffers through the multi-span path with spans of force_rounds * 4 KB */
 extern "C" void emu_crc32c(const uint8_t *base, uint64_t stride, const uint32_t *len, uint32_t fixed_len, uint32_t max_len,

@@ -908,6 +908,15 @@ def test_rows_kernel_segments_shared_out_over_workgroups(mode):
         assert emu.render_frames(mode, frames, orc.PALETTE_STANDARD, 34, parts=3, sync=sync) == exp
 
 
+def test_quant16_without_the_table_walk_for_every_colour():
+    """render_kernels.hpp quant16 / ansi16_rgb decide the nearest of the 16 ANSI colours from the table's structure (two cubes and
+    colour 7 competing as distance << 4 | index); against the reference's table walk (ansi.c:437-477, first minimum) for all
+    2^24 colours, and against the reference's own known answers (ansi_test.c via reference_kats.json) through the walk"""
+    import ctypes as C
+    first = C.c_uint32(0)
+    assert emu.lib().emu_quant16_check(C.byref(first)) == 0, hex(first.value)
+
+
 @pytest.mark.parametrize("variant", [16, 17, 20])
 def test_stream_kernel_word_built_sgrs_at_every_field_length_and_alignment(variant):
     for (w, h, seed) in [(97, 7, 5), (200, 3, 6), (61, 5, 7)]:
