@@ -165,8 +165,13 @@ __device__ inline uint32_t digits_u32(uint32_t v) {
   return d;
 }
 
-/* rep_is_profitable, lib/video/ascii/output_buffer.c:148-155 */
-__device__ inline bool rep_profitable(uint32_t run) {
+/* rep_is_profitable, lib/video/ascii/output_buffer.c:148-155: `run > 2 && k > digits(k) + 3` with k = run - 1 -- which is
+ * `run >= 6` for every 32-bit run: k <= 4 has one digit and fails k > 4; k in 5..9 passes it; from there on k grows by a factor of ten
+ * per digit and the bound by one (k >= 10^(d-1) > d + 3 for every d >= 2).  Twenty vector instructions per token less than
+ * counting the digits (round 6; tests/test_kernels_emulated.py walks both over the boundaries and the first 2^22 runs). */
+__device__ inline bool rep_profitable(uint32_t run) { return run >= 6u; }
+/* (the rule as the reference writes it: the emulator's check compares the two) */
+__device__ inline bool rep_profitable_as_written(uint32_t run) {
   if (run <= 2u)
     return false;
   const uint32_t k = run - 1u;
@@ -1148,6 +1153,8 @@ __device__ inline void dither16_rows(int lane, int chunk_rows, int wp, int pad_l
     int pa[3] = {0, 0, 0}, pb[3] = {0, 0, 0}; /* partial sums entering columns x-1 and x of the row below  */
     int in[3] = {0, 0, 0};                 /* complete sum entering the pixel this lane processes next      */
     const int steps = out_w + 1 + 2 * (nrows - 1);
+    /* (requesting a step's LDS reads -- the pixel, the first row's carried sums -- one step ahead was measured and is slower:
+     * 41.6 -> 44.0 us per 256 frames, one launch at a time 78.8 -> 83.2; the chain is dependent arithmetic, not LDS latency) */
     for (int t = 0; t < steps; t++) {
       const int x = t - 2 * lane;
       const bool active = row_ok && x >= 0 && x <= out_w;

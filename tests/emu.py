@@ -46,6 +46,8 @@ def lib():
                                                C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.emu_render_rows_crc.restype = C.c_int
         _lib.emu_render_rows_crc.argtypes = _lib.emu_render_stream_crc.argtypes
+        _lib.emu_rep_rule_check.restype = C.c_long
+        _lib.emu_rep_rule_check.argtypes = []
         _lib.emu_quant16_check.restype = C.c_long
         _lib.emu_quant16_check.argtypes = [C.POINTER(C.c_uint32)]
         _lib.emu_set_uniform.restype = C.c_int

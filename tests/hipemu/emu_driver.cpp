@@ -486,6 +486,28 @@ extern "C" long emu_quant16_check(uint32_t *first_bad) {
   return bad;
 }
 
+/* rep_profitable (render_kernels.hpp: `run >= 6`) against the rule as the reference writes it (output_buffer.c:148-155) over the
+ * first 2^22 runs and around every power of ten and of two up to 2^32 - 1; returns the number of runs that differ */
+extern "C" long emu_rep_rule_check(void) {
+  long bad = 0;
+  for (uint32_t run = 0; run < (1u << 22); run++)
+    bad += achip::rep_profitable(run) != achip::rep_profitable_as_written(run);
+  for (uint64_t p10 = 1; p10 <= 10000000000ull; p10 *= 10)
+    for (int64_t d = -12; d <= 12; d++) {
+      const int64_t v = (int64_t)p10 + d;
+      if (v >= 0 && v <= 0xFFFFFFFFll)
+        bad += achip::rep_profitable((uint32_t)v) != achip::rep_profitable_as_written((uint32_t)v);
+    }
+  for (int sh = 0; sh < 32; sh++)
+    for (int64_t d = -3; d <= 3; d++) {
+      const int64_t v = ((int64_t)1 << sh) + d;
+      if (v >= 0 && v <= 0xFFFFFFFFll)
+        bad += achip::rep_profitable((uint32_t)v) != achip::rep_profitable_as_written((uint32_t)v);
+    }
+  bad += achip::rep_profitable(0xFFFFFFFFu) != achip::rep_profitable_as_written(0xFFFFFFFFu);
+  return bad;
+}
+
 /* the launcher's geometry (hip_launch.hip: achip_launch_crc32c) restated for the emulator; force_parts > 1
  * sends small buffers through the multi-span path with spans of force_rounds * 4 KB */
 extern "C" void emu_crc32c(const uint8_t *base, uint64_t stride, const uint32_t *len, uint32_t fixed_len, uint32_t max_len,

@@ -917,6 +917,12 @@ def test_quant16_without_the_table_walk_for_every_colour():
     assert emu.lib().emu_quant16_check(C.byref(first)) == 0, hex(first.value)
 
 
+def test_rep_rule_as_one_comparison():
+    """render_kernels.hpp rep_profitable is `run >= 6`; the rule as the reference writes it (output_buffer.c:148-155, pinned by its
+    own known answers in test_reference_kats.py) over the first 2^22 runs and around every power of ten / two"""
+    assert emu.lib().emu_rep_rule_check() == 0
+
+
 @pytest.mark.parametrize("variant", [16, 17, 20])
 def test_stream_kernel_word_built_sgrs_at_every_field_length_and_alignment(variant):
     for (w, h, seed) in [(97, 7, 5), (200, 3, 6), (61, 5, 7)]:
