@@ -567,7 +567,7 @@ static int rows_variant_max_row(int variant) {
 
 /* ASCIICHAT_HIP_ROWS_PARTS (diagnostics, read once): 1 = the run-structured modes' small launches are never shared out over
  * workgroups of the rows kernel, N = over this many where the CUs allow; ASCIICHAT_HIP_ROWS_PARTS_WIDE=0: not the rows of
- * 129-512 cells (geometry 32), which keep their row bands then */
+ * 129-512 cells (geometry 32), which keep their row bands then; =2: geometry 32 for the 256- / 16-colour half blocks too */
 static int rows_parts_forced(void) {
   static int forced = -1; /* benign race */
   if (forced < 0) {
@@ -576,13 +576,13 @@ static int rows_parts_forced(void) {
   }
   return forced;
 }
-static bool rows_parts_wide_enabled(void) {
+static int rows_parts_wide_level(void) { /* 0: never; 1 (default): the modes it was measured ahead for; 2 (diagnostics): all five */
   static int on = -1; /* benign race */
   if (on < 0) {
     const char *e = getenv("ASCIICHAT_HIP_ROWS_PARTS_WIDE");
-    on = !(e && e[0] == '0');
+    on = e && e[0] == '0' ? 0 : e && e[0] == '2' ? 2 : 1;
   }
-  return on != 0;
+  return on;
 }
 
 /* what the ACHIP_UNIFORM_MAX_CELLS field of a launch carries: cells of the largest frame for the stream geometries,
@@ -789,8 +789,8 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
    * 8.3-8.5 (256x30), 3-11 % ahead everywhere; mono half blocks 2-10 % ahead; truecolor half blocks level to 6 % ahead (9.8
    * against 9.9, 9.1 against 9.7 at 256x30; never more than 0.5 % behind); the 256- / 16-colour half blocks 6-20 % BEHIND
    * (byte-built tokens of one wave against a thread per cell: 9.7 against 9.0, 11.3 against 9.4) -- those keep their bands. */
-  const bool parts_wide_mode = short_tokens || mode == ACHIP_MODE_HB_TRUE;
-  if (forced_variant < 0 && run_mode && parts_wide_mode && !general_sampler && may_split && split_request == 0 && rows_parts_wide_enabled() &&
+  const bool parts_wide_mode = short_tokens || mode == ACHIP_MODE_HB_TRUE || rows_parts_wide_level() == 2;
+  if (forced_variant < 0 && run_mode && parts_wide_mode && !general_sampler && may_split && split_request == 0 && rows_parts_wide_level() != 0 &&
       max_wp > 64 * ACHIP_ROWS_PARTS_CPL && max_wp <= rows_variant_max_row(32)) {
     const long nseg = rows_wide_segments(max_wp, rows_variant_cpl(32));
     const long rpw = nseg > 0 ? 4 / nseg : 0; /* rows of a workgroup */
