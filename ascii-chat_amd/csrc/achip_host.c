@@ -3,6 +3,7 @@
 #include "internal.h"
 
 #include <math.h>
+#include <stdatomic.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -568,21 +569,31 @@ static int rows_variant_max_row(int variant) {
 /* ASCIICHAT_HIP_ROWS_PARTS (diagnostics, read once): 1 = the run-structured modes' small launches are never shared out over
  * workgroups of the rows kernel, N = over this many where the CUs allow; ASCIICHAT_HIP_ROWS_PARTS_WIDE=0: not the rows of
  * 129-512 cells (geometry 32), which keep their row bands then; =2: geometry 32 for the 256- / 16-colour half blocks too */
-static int rows_parts_forced(void) {
-  static int forced = -1; /* benign race */
-  if (forced < 0) {
-    const char *e = getenv("ASCIICHAT_HIP_ROWS_PARTS");
-    forced = e && e[0] ? atoi(e) : 0;
+/* (read once per process; relaxed atomics: every thread that finds -1 computes the same value) */
+static int env_int_once(_Atomic int *cache, const char *name) {
+  int v = atomic_load_explicit(cache, memory_order_relaxed);
+  if (v < 0) {
+    const char *e = getenv(name);
+    v = e && e[0] ? atoi(e) : 0;
+    if (v < 0)
+      v = 0;
+    atomic_store_explicit(cache, v, memory_order_relaxed);
   }
-  return forced;
+  return v;
+}
+static int rows_parts_forced(void) {
+  static _Atomic int forced = -1;
+  return env_int_once(&forced, "ASCIICHAT_HIP_ROWS_PARTS");
 }
 static int rows_parts_wide_level(void) { /* 0: never; 1 (default): the modes it was measured ahead for; 2 (diagnostics): all five */
-  static int on = -1; /* benign race */
-  if (on < 0) {
+  static _Atomic int on = -1;
+  int v = atomic_load_explicit(&on, memory_order_relaxed);
+  if (v < 0) {
     const char *e = getenv("ASCIICHAT_HIP_ROWS_PARTS_WIDE");
-    on = e && e[0] == '0' ? 0 : e && e[0] == '2' ? 2 : 1;
+    v = e && e[0] == '0' ? 0 : e && e[0] == '2' ? 2 : 1;
+    atomic_store_explicit(&on, v, memory_order_relaxed);
   }
-  return on;
+  return v;
 }
 
 /* what the ACHIP_UNIFORM_MAX_CELLS field of a launch carries: cells of the largest frame for the stream geometries,
@@ -703,11 +714,8 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
     if (np * n_frames > n_cus)
       np = n_cus / n_frames;
     { /* ASCIICHAT_HIP_STREAM_PARTS (diagnostics, read once): 1 = never, N = this many where the CUs allow */
-      static int forced = -1;
-      if (forced < 0) {
-        const char *e = getenv("ASCIICHAT_HIP_STREAM_PARTS");
-        forced = e && e[0] ? atoi(e) : 0;
-      }
+      static _Atomic int forced_cache = -1;
+      const int forced = env_int_once(&forced_cache, "ASCIICHAT_HIP_STREAM_PARTS");
       if (forced >= 1 && forced <= 64 && (long)forced * n_frames <= n_cus)
         np = forced;
     }
