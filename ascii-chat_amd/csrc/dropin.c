@@ -195,13 +195,15 @@ static const uint8_t *stage_source(tls_ctx_t *c, achip_frame_t *d, size_t src_by
 #define DROPIN_MAX_PARTS 2160 /* IMAGE_MAX_HEIGHT text rows at one row per part */
 
 static int device_cu_count(void) {
-  static int cached = 0; /* benign race */
+  static int cached_cus = 0; /* idempotent: every thread that finds 0 stores the same value */
+  int cached = __atomic_load_n(&cached_cus, __ATOMIC_RELAXED);
   if (!cached) {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
       n = 256;
     cached = n;
+    __atomic_store_n(&cached_cus, cached, __ATOMIC_RELAXED);
   }
   return cached;
 }

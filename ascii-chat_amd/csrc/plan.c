@@ -238,12 +238,14 @@ struct asciichat_hip_plan {
 };
 
 static int device_cus(void) {
-  static int cached = 0; /* benign race */
+  static int cached_cus = 0; /* idempotent: every thread that finds 0 stores the same value */
+  int cached = __atomic_load_n(&cached_cus, __ATOMIC_RELAXED);
   if (!cached) {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
       n = 256;
     cached = n;
+    __atomic_store_n(&cached_cus, cached, __ATOMIC_RELAXED);
   }
   return cached;
 }
