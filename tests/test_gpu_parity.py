@@ -661,6 +661,51 @@ def test_full_size_batches(gpu, name, sw, sh, W, H, mode, batch, nsample):
     plan.close()
 
 
+OTHER_FULL = [(0, "mono"), (3, "16_fg"), (6, "hb_256"), (7, "hb_16"), (8, "hb_mono"), (MODE_16_DITHER_BG, "dither16_bg")]
+
+
+@pytest.mark.parametrize("mode,name", OTHER_FULL, ids=[m[1] for m in OTHER_FULL])
+def test_full_size_batches_other_renderers(gpu, mode, name):
+    """The renderers of SURVEY 8(a) that no BASELINE configuration names (PM, P16, H256, H16, HM, PD) at the metric's shape and full
+    batch -- 256 x (1080p -> 80x24): oracle compare of a sample (noise, bars, smooth, black, a duplicate), newline count and
+    idempotence on every frame.  (bench.py's legs 1080p_80x24_mono / _dither16_bg / _ansi16 / _halfblock16 are these launches.)"""
+    pkg, torch = gpu
+    sw, sh, W, H, batch = 1920, 1080, 80, 24, 256
+    g = torch.Generator(device="cuda")
+    g.manual_seed(44 + mode)
+    frames_t = torch.randint(0, 256, (batch, sh, sw, 3), dtype=torch.uint8, device="cuda", generator=g)
+    frames_t[1] = torch.from_numpy(orc.frame_bars(sw, sh, 6)).cuda()
+    frames_t[2] = torch.from_numpy(orc.frame_smooth(sw, sh)).cuda()
+    frames_t[3] = 0
+    frames_t[4] = frames_t[0]
+    frames_t[5] = torch.from_numpy(orc.frame_gray(sw, sh)).cuda() if hasattr(orc, "frame_gray") else frames_t[2]
+    rm = MODE_CAPS[mode][1]
+    descs = [pkg.frame_setup(frames_t.data_ptr() + i * sh * sw * 3, sw, sh, W, H, rm) for i in range(batch)]
+    plan = pkg.Plan(mode, orc.PALETTE_STANDARD, descs)
+    out = torch.zeros(batch * plan.stride, dtype=torch.uint8, device="cuda")
+    ln = torch.zeros(batch, dtype=torch.int32, device="cuda")
+    plan.render(out.data_ptr(), plan.stride, ln.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    lens = ln.cpu().numpy().astype(np.uint32)
+    assert (lens < 0xFFFFFFF0).all()
+    outs = {}
+    for k in (0, 1, 2, 3, 4, 5, 6, 7, batch - 1):
+        got = out[k * plan.stride:k * plan.stride + int(lens[k])].cpu().numpy().tobytes()
+        outs[k] = got
+        assert got == oracle_convert(frames_t[k].cpu().numpy(), mode, W, H, orc.PALETTE_STANDARD), (name, k)
+    assert outs[0] == outs[4]
+    host = out.cpu().numpy().reshape(batch, plan.stride)
+    for k in range(batch):
+        fr = host[k, :int(lens[k])]
+        assert int((fr == 10).sum()) == H - 1, (name, k)
+        assert host[k, int(lens[k])] == 0
+    out2 = torch.zeros_like(out)
+    plan.render(out2.data_ptr(), plan.stride, ln.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)
+    plan.close()
+
+
 U8_FULL = [
     ("K2' 1080p->80x24 truecolor b256", 1920, 1080, 80, 24, 256, 5),
     ("K3 4K->200x60 truecolor b256", 3840, 2160, 200, 60, 256, 3),
