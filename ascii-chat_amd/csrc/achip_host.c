@@ -889,8 +889,10 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
         take26 = dense ? max_wp >= 120 : !big_src ? max_wp >= 120 : (max_wp > 256 && (shared_gpu || 4 * n_frames <= 3 * n_cus));
       else if (mode == ACHIP_MODE_HB_MONO)
         take26 = dense ? max_wp >= 120 : (!shared_gpu && max_wp > 220);
-      else
-        take26 = max_wp >= 200 || (max_wp >= 160 && (dense || 4 * n_frames <= 3 * n_cus));
+      else /* (... from dense sources already from 120 columns, audited again after quant16's diet, profiles/r06_policy_audit_hb16.txt:
+              * 128-256 frames of 120x40, one launch at a time, 256 colours 22.9-23.5 against 26.5-27.2 us, 16 colours 24.5-25.4 against
+              * 27.4-27.7; 64 frames at a share of 64 CUs 6.6 / 7.1 against 7.4 / 7.7) */
+        take26 = max_wp >= 200 || (max_wp >= 160 && (dense || 4 * n_frames <= 3 * n_cus)) || (dense && max_wp >= 120);
       if (take26) {
         *variant = 26;
         return 0;

@@ -1045,7 +1045,10 @@ def test_policy_takes_the_sixteen_wave_rows_geometry_for_one_launch_of_dense_hal
     assert choice(dense(200, 60), 200, 60, MODE_HB_256, 256, 256) == 26
     assert choice(hd, 200, 60, MODE_HB_256, 128, 256) == 26 and choice(hd, 200, 60, MODE_HB_256, 192, 256) == 26
     assert choice(hd, 200, 60, MODE_HB_256, 256, 256) == 26 and choice(hd, 160, 45, MODE_HB_256, 256, 256) != 26  # (round 6 audit: from 200 columns at a full frame per CU too -- 58.1 against 60.5 us, 238x70 70.5 against 81.6; 160x45 level)
-    assert choice(dense(120, 40), 120, 40, MODE_HB_16, 256, 256) != 26
+    # (dense sources from 120 columns on since quant16's diet -- profiles/r06_policy_audit_hb16.txt: 128-256 frames of 120x40
+    # 22.9-25.4 us against 26.5-27.7; full-frame sources keep 160 / 200 columns)
+    assert choice(dense(120, 40), 120, 40, MODE_HB_16, 256, 256) == 26 and choice(dense(120, 40), 120, 40, MODE_HB_256, 64, 64) == 26
+    assert choice(hd, 120, 40, MODE_HB_16, 256, 256) != 26 and choice(dense(100, 40), 100, 40, MODE_HB_256, 256, 256) != 26
     # the short-token modes (profiles/r05_policy_audit_mono.txt): mono as truecolor half blocks; mono half blocks from dense
     # sources, from full frames only rows beyond the four-slot geometry with the GPU to itself
     assert choice(dense(400, 120), 400, 120, MODE_HB_MONO, 256, 256) == 26
