@@ -733,7 +733,20 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
   const bool one_block_per_wave = cell_mode && split_request == 0 && max_cells <= 16 * (128 - ghost);
   /* (round 4 audit: from half a frame per CU on, frames of at most three blocks per wave of the sixteen-wave geometry go
    * whole too -- 128 frames of 120x40, one launch at a time: 12.9 us whole against 16.8 as three bands each) */
-  const bool few_blocks = cell_mode && split_request == 0 && max_cells <= 3 * 16 * (128 - ghost) && 2 * n_frames >= n_cus;
+  /* (round 6, after the stream kernel's lean loop -- scripts/gpu_truecolor_half_cu.py, profiles/r06_whole_from_three_eighths.txt,
+   * one launch at a time, 1080p sources: the row bands' phase kernel is now the slower one per cell, so whole frames win well below
+   * 3/4 frame per CU.  Truecolor foreground from single sources (the lean loop), any size, from 3/8 frame per CU on: 96 frames of
+   * 120x40 9.7 us against 16.0 as bands, 160x45 12.7 / 16.1, 200x60 19.9 / 25.7, 238x70 25.9 / 29.7, 320x90 43.1 / 43.7 -- and
+   * 160 frames 13.7 / 26.3, 20.8 / 31.7, 26.9 / 43.5, 44.0 / 69.1; at 80 frames the bands are still ahead from 200 columns on
+   * (16.8 / 19.8).  The other per-cell modes, frames of at most four blocks per wave (160x45), from 3/8 too: 256 colours 96 frames
+   * of 120x40 10.1 / 13.4, 160x45 13.0 / 13.6, 128 frames 13.3 / 14.5; larger frames keep their bands up to 3/4 (200x60, 128
+   * frames: 22.6 whole against 18.8)) */
+  const bool lean_true = mode == ACHIP_MODE_TRUE_FG && palette_ascii_only && !general_sampler;
+  /* (... and truecolor frames of at most four blocks per wave already from 5/16: 80 frames of 120x40 9.7 against 11.0, 160x45
+   * 12.6 against 15.9; at 64 frames 160x45 is behind its bands, 12.6 against 11.6) */
+  const bool four_blocks = max_cells <= 4 * 16 * (128 - ghost);
+  const bool few_blocks = cell_mode && split_request == 0 &&
+                          ((8 * n_frames >= 3 * n_cus && (lean_true || four_blocks)) || (16 * n_frames >= 5 * n_cus && lean_true && four_blocks));
   if (forced_variant < 0 && cell_mode && (!may_split || max_wp > variant_caps[0] || one_block_per_wave || few_blocks) &&
       max_cells <= (long)ACHIP_HOST_STREAM_MAXBLK * (128 - ghost)) {
     /* measured (profiles/r02_stream_sweep.txt): 1024 threads x 2 cells -- one block per wave for a 1080p -> 80x24
@@ -887,8 +900,9 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
        * frame per CU too -- 238x70 70.5 against 81.6; mono half blocks from 220 columns -- 128 frames of 238x70 45.2 against 51.2) */
       if (mode == ACHIP_MODE_HB_TRUE || mode == ACHIP_MODE_MONO)
         take26 = dense ? max_wp >= 120 : !big_src ? max_wp >= 120 : (max_wp > 256 && (shared_gpu || 4 * n_frames <= 3 * n_cus));
-      else if (mode == ACHIP_MODE_HB_MONO)
-        take26 = dense ? max_wp >= 120 : (!shared_gpu && max_wp > 220);
+      else if (mode == ACHIP_MODE_HB_MONO) /* (rows beyond the four-slot geometry on a shared GPU too -- round 6's last audit: 64 frames of
+                                             * 320x90 at a share of 64 CUs 17.6 us against the phase kernel's 22.2, geometry 24 27.9) */
+        take26 = dense ? max_wp >= 120 : ((!shared_gpu && max_wp > 220) || max_wp > 256);
       else /* (... from dense sources already from 120 columns, audited again after quant16's diet, profiles/r06_policy_audit_hb16.txt:
               * 128-256 frames of 120x40, one launch at a time, 256 colours 22.9-23.5 against 26.5-27.2 us, 16 colours 24.5-25.4 against
               * 27.4-27.7; 64 frames at a share of 64 CUs 6.6 / 7.1 against 7.4 / 7.7) */

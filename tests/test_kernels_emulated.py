@@ -1053,7 +1053,8 @@ def test_policy_takes_the_sixteen_wave_rows_geometry_for_one_launch_of_dense_hal
     # sources, from full frames only rows beyond the four-slot geometry with the GPU to itself
     assert choice(dense(400, 120), 400, 120, MODE_HB_MONO, 256, 256) == 26
     assert choice(dense(120, 40), 120, 40, MODE_HB_MONO, 64, 64) == 26
-    assert choice(hd, 320, 90, MODE_HB_MONO, 256, 256) == 26 and choice(hd, 320, 90, MODE_HB_MONO, 64, 64) != 26
+    assert choice(hd, 320, 90, MODE_HB_MONO, 256, 256) == 26 and choice(hd, 320, 90, MODE_HB_MONO, 64, 64) == 26   # (shared GPU too since round 6's last audit: 17.6 against 22.2 us)
+    assert choice(hd, 238, 70, MODE_HB_MONO, 64, 64) != 26                                                          # (rows the four-slot geometry holds: as before)
     assert choice(hd, 200, 60, MODE_HB_MONO, 256, 256) != 26
 
 

@@ -90,6 +90,17 @@ def test_split_ragged_batch_and_policy():
     assert choose(0, wide3) == (32, 20, 1) and choose(0, [emu.frame_for_convert(imgs[0], 512, 9, 0)]) == (32, 9, 1)
     assert choose(0, [emu.frame_for_convert(imgs[0], 513, 9, 0)])[0] < 16   # five segments: no four-wave workgroup holds the row
     assert choose(1, mid * 17)[0] < 16 and choose(1, mid * 17)[1] > 1  # sixteen parts no longer fit: row bands of the phase kernel as before
+    # round 6, after the stream kernel's lean loop (profiles/r06_whole_from_three_eighths.txt): truecolor foreground from single
+    # sources goes whole from 3/8 frame per CU on whatever the frame's size (96 frames of 200x60: 19.9 us against 25.7 as bands;
+    # 160 frames 20.8 against 31.7), the other per-cell modes with frames of at most four blocks per wave (160x45)
+    big = [emu.frame_for_convert(imgs[0], 200, 60, 0)]
+    assert choose(1, big * 96)[:2] == (16, 1) and choose(1, big * 160)[:2] == (16, 1)
+    assert choose(1, big * 95)[0] < 16 and choose(1, big * 95)[1] > 1       # below 3/8: row bands of the phase kernel (80 frames: 16.8 against 19.8 whole)
+    assert choose(1, big * 24, cus=64)[:2] == (16, 1)                        # (a share of the CUs: the same fraction)
+    mid45 = [emu.frame_for_convert(imgs[0], 160, 45, 0)]
+    assert choose(1, mid45 * 80)[:2] == (16, 1) and choose(1, mid45 * 79)[1] > 1 and choose(1, big * 80)[1] > 1   # (frames of at most four blocks per wave from 5/16)
+    assert choose(2, mid45 * 96)[:2] == (16, 1) and choose(3, mid45 * 128)[:2] == (16, 1)
+    assert choose(2, big * 128)[0] < 16 and choose(2, big * 128)[1] > 1    # 256 colours at 200x60: bands up to 3/4 (18.8 against 22.6 whole)
     # whole-frame launches of the per-cell modes take the stream kernel (render_stream.hpp): 1024 threads while every
     # frame has a CU to itself, 512-thread workgroups beyond that
     assert choose(1, one * 256) == (16, 1, 24)                # BASELINE batch = one frame per CU: whole frames
