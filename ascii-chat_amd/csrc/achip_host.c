@@ -899,7 +899,11 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
        * 64 CUs 4.6 against 5.3, truecolor half blocks 128 frames 28.1 against 30.2; 256 colours from 200 columns at a full
        * frame per CU too -- 238x70 70.5 against 81.6; mono half blocks from 220 columns -- 128 frames of 238x70 45.2 against 51.2) */
       if (mode == ACHIP_MODE_HB_TRUE || mode == ACHIP_MODE_MONO)
-        take26 = dense ? max_wp >= 120 : !big_src ? max_wp >= 120 : (max_wp > 256 && (shared_gpu || 4 * n_frames <= 3 * n_cus));
+        /* (mono from 4K sources at a full frame per CU too -- round 6's last audit, 256 frames one launch at a time: 320x90 69.2 against
+         * 90.7 us on geometry 24 and 87.2 on the phase kernel, 400x120 104.2 against 145.4 / 137.1; truecolor half blocks there are level:
+         * BASELINE configs[4] 242-246 against the phase kernel's 248) */
+        take26 = dense ? max_wp >= 120 : !big_src ? max_wp >= 120
+                 : (max_wp > 256 && (shared_gpu || 4 * n_frames <= 3 * n_cus || mode == ACHIP_MODE_MONO));
       else if (mode == ACHIP_MODE_HB_MONO) /* (rows beyond the four-slot geometry on a shared GPU too -- round 6's last audit: 64 frames of
                                              * 320x90 at a share of 64 CUs 17.6 us against the phase kernel's 22.2, geometry 24 27.9) */
         take26 = dense ? max_wp >= 120 : ((!shared_gpu && max_wp > 220) || max_wp > 256);
@@ -907,6 +911,10 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
               * 128-256 frames of 120x40, one launch at a time, 256 colours 22.9-23.5 against 26.5-27.2 us, 16 colours 24.5-25.4 against
               * 27.4-27.7; 64 frames at a share of 64 CUs 6.6 / 7.1 against 7.4 / 7.7) */
         take26 = max_wp >= 200 || (max_wp >= 160 && (dense || 4 * n_frames <= 3 * n_cus)) || (dense && max_wp >= 120);
+      /* (... but not from 4K sources from 3/4 frame per CU on while the four-slot geometry holds the rows: 192 / 256 frames of 4K -> 200x60,
+       * 256 colours 70.8 / 86.0 us against the phase kernel's 65.5 / 79.5, 16 colours 73.1 / 87.8 against 66.8 / 78.1 -- the last audit) */
+      if ((mode == ACHIP_MODE_HB_256 || mode == ACHIP_MODE_HB_16) && big_src && max_wp <= 256 && 4 * n_frames >= 3 * n_cus)
+        take26 = false;
       if (take26) {
         *variant = 26;
         return 0;

@@ -1034,6 +1034,9 @@ def test_policy_takes_the_sixteen_wave_rows_geometry_for_one_launch_of_dense_hal
     assert choice(hd, 120, 40, MODE_HB_TRUE, 256, 256) == 26                  # (round 6 audit: level with the phase kernel at 256 frames, 5-8 % ahead at 128-192)
     assert choice(uhd, 400, 120, MODE_HB_TRUE, 192, 256) == 26
     assert choice(uhd, 400, 120, MODE_HB_TRUE, 256, 256) != 26                # BASELINE configs[4], one launch at a time: the phase kernel
+    assert choice(uhd, 400, 120, MODE_MONO, 256, 256) == 26 and choice(uhd, 320, 90, MODE_MONO, 256, 256) == 26   # (mono there: 104 against 137-145 us, round 6's last audit)
+    assert choice(uhd, 200, 60, MODE_MONO, 256, 256) != 26                     # (rows the four-slot geometry holds: the phase kernel, 40.5 against 45.6)
+    assert choice(uhd, 200, 60, MODE_HB_256, 192, 256) != 26 and choice(uhd, 200, 60, MODE_HB_16, 256, 256) != 26 and choice(uhd, 200, 60, MODE_HB_256, 128, 256) == 26   # (256 / 16 colours from 4K sources: the phase kernel from 3/4 frame per CU on, 65.5 against 70.8 us)
     assert choice(uhd, 400, 120, MODE_HB_TRUE, 64, 64) == 26
     assert choice(uhd, 200, 60, MODE_HB_TRUE, 128, 256) != 26
     assert choice(dense(400, 120), 400, 120, MODE_HB_TRUE, 257, 256) == 24    # more than a frame per CU
