@@ -762,7 +762,13 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
      * 512-thread workgroups share a CU and win or tie (256 frames, four in flight: 35.7 vs 36.9 at 200x60). */
     /* (up to TWO frames per CU: 128 frames at a share of 64 CUs, 200x60: 23.5 vs 29.6 us; at three they tie, at four
      * the 512-thread workgroups win by 3-10 %) */
-    *variant = n_frames <= 2 * n_cus ? 16 : 17;
+    /* (round 6's last audit, AUDIT_BATCHES=320..2048 of scripts/gpu_policy_audit.py, profiles/r06_whole_from_three_eighths.txt: with
+     * the GPU to itself, between one and two frames per CU, frames of more than one block per wave pack better as 512-thread
+     * workgroups -- 512 frames of 120x40 21.2-22.9 us against 28.1-29.2, 160x45 26.6-28.4 against 34.3-35.1; 320 / 384 / 512 frames of 200x60 truecolor 36.3 / 37.5 / 40.8 us against 41.3 / 42.3 / 49.9, 320x90 80.1-86.4 against
+     * 87.0-96.7, 640x90 150.8-162.2 against 168.3-182.5, 256 colours 13-22 %; 80x24 frames level; at a share of 64 CUs two frames per
+     * CU stay level between the two) */
+    const bool big_alone = n_cus > 128 && n_frames > n_cus && max_cells > 16L * (128 - ghost);
+    *variant = n_frames <= 2 * n_cus && !big_alone ? 16 : 17;
     return 0;
   }
   /* (the coloured half-block modes only from a frame per four CUs on: their tokens are long -- two SGRs and a three-byte glyph

@@ -85,6 +85,10 @@ WIDE = "--wide" in sys.argv
 if WIDE:
     SIZES = [(512, 60), (640, 90), (1000, 40), (1920, 54)]
     BATCHES = [1, 8, 64, 128, 192, 256, 512]
+if os.environ.get("AUDIT_SIZES"):  # targeted grids: AUDIT_SIZES=80x24,640x90 AUDIT_BATCHES=384,512,1024
+    SIZES = [tuple(int(v) for v in t.split("x")) for t in os.environ["AUDIT_SIZES"].split(",")]
+if os.environ.get("AUDIT_BATCHES"):
+    BATCHES = [int(v) for v in os.environ["AUDIT_BATCHES"].split(",")]
 DENSE = "--dense" in sys.argv
 GRID = "--grid" in sys.argv  # the targets are composite frames: the 3x3 grid of nine 1080p sources (stream.c:523-854), sampled directly
 frames_t = bench.make_frames(torch, 9 if GRID else 256, SRC_W, SRC_H, 4242)  # (larger batches repeat the sources)

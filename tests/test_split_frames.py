@@ -97,6 +97,8 @@ def test_split_ragged_batch_and_policy():
     assert choose(1, big * 96)[:2] == (16, 1) and choose(1, big * 160)[:2] == (16, 1)
     assert choose(1, big * 95)[0] < 16 and choose(1, big * 95)[1] > 1       # below 3/8: row bands of the phase kernel (80 frames: 16.8 against 19.8 whole)
     assert choose(1, big * 24, cus=64)[:2] == (16, 1)                        # (a share of the CUs: the same fraction)
+    assert choose(1, big * 257)[:2] == (17, 1) and choose(1, big * 512)[:2] == (17, 1) and choose(1, big * 256)[:2] == (16, 1)   # (the GPU to itself, one to two frames per CU, frames of more than one block per wave: 512-thread workgroups, 36-41 us against 41-50)
+    assert choose(1, big * 128, cus=64)[:2] == (16, 1) and choose(1, one * 512)[:2] == (16, 1)                                # (a share of the CUs / small frames: as before)
     mid45 = [emu.frame_for_convert(imgs[0], 160, 45, 0)]
     assert choose(1, mid45 * 80)[:2] == (16, 1) and choose(1, mid45 * 79)[1] > 1 and choose(1, big * 80)[1] > 1   # (frames of at most four blocks per wave from 5/16)
     assert choose(2, mid45 * 96)[:2] == (16, 1) and choose(3, mid45 * 128)[:2] == (16, 1)
