@@ -207,6 +207,7 @@ struct asciichat_hip_plan {
   int max_wp;
   int has_comp; /* some frame samples a virtual composite */
   int all_dense; /* every source IS the image its target samples (ratio 1.0: the sampled-image ingest, frame_dense.c) */
+  int big_src;   /* some source is wider than 1920 pixels (4K frames: a second gather costs more than a pack pass) */
   int parts, rows_per_part, split_request; /* multi-workgroup frames (achip_choose_geometry) */
   int whole_variant; /* the geometry of the wire-stage entry points (frame checksums, exact-length frames: a frame belongs to ONE
                         workgroup there): `variant`, unless that shares frames out over workgroups of the stream kernel */
@@ -298,12 +299,15 @@ static int plan_measure(asciichat_hip_plan_t *p, const achip_frame_t *frames) {
   int max_wp = 0;
   q.has_comp = 0;
   q.all_dense = 1;
+  q.big_src = 0;
   for (int i = 0; i < q.n; i++) {
     const achip_frame_t *f = &frames[i];
     if (f->comp || (long)f->src_w * (long)f->src_h == 1) /* the kernels' general sampler: composites, 1x1 sources */
       q.has_comp = 1;
     if (f->comp || f->src_w != f->out_w || f->src_h != f->out_h)
       q.all_dense = 0;
+    if (!f->comp && f->src_w > 1920)
+      q.big_src = 1;
     if (f->out_w <= 0 || f->out_h <= 0 || f->src_w <= 0 || f->src_h <= 0 || f->pad_left < 0 || f->pad_top < 0 ||
         (!f->src && !f->comp))
       return achip_fail(ASCIICHAT_HIP_ERR_INVALID_PARAM, "frame %d: bad descriptor", i);
@@ -679,7 +683,13 @@ static int plan_length_first_this_call(asciichat_hip_plan_t *p, const void *dst,
     return 0;
   if (p->exact_length > 0)
     return 1;
-  return p->all_dense && plan_dst_is_device(p, dst);
+  /* (round 6's wire audit, scripts/gpu_wire_audit.py, profiles/r06_wire_audit.txt: sources up to 1080p as well -- 128 / 256 frames of
+   * 1080p -> 200x60 49.2 / 62.3 us in one launch against 64.8 / 76.9 for render + pack pass, 320x90 94.6 / 123.4 against 144.4 / 175.2,
+   * 160x45 34.4 / 46.2 against 39.4 / 49.1, 120x40 level; NOT a plan whose plain render shares its frames out over workgroups unless a
+   * wave has one block: the one-launch form renders them whole, one workgroup a frame -- a lone 200x60 frame 34.9 us against 16.9) */
+  if (p->parts > 1 && p->max_cells > 16 * 127)
+    return 0;
+  return (p->all_dense || !p->big_src) && plan_dst_is_device(p, dst);
 }
 static int plan_render_pack(asciichat_hip_plan_t *p, uint32_t *out_len_dev, const achip_wire_t *wire, uint8_t *dst,
                             size_t dst_capacity, uint64_t *off_out, uint32_t *len_out, void *stream) {
@@ -714,8 +724,8 @@ static int plan_render_pack(asciichat_hip_plan_t *p, uint32_t *out_len_dev, cons
  * The stream kernel's lean loop run twice -- lengths first, then the emission at the place the frame claimed -- for whole-frame
  * plans of truecolor foreground with an all-ASCII palette (render_stream.hpp LF).  Measured (profiles/r06_length_first_ab.txt,
  * 256 frames of 200x60): from sampled images 16.5 us against 34.5 for render + pack pass; from 4K sources the second gather
- * costs more than the pass (71.9 against 60.4) -- so the automatic choice takes it for DENSE sources only, device destinations,
- * callers that receive off_out (completion order, like the PACK form). */
+ * costs more than the pass (71.9 against 60.4) -- so the automatic choice takes it for dense sources and (the round's wire audit) for
+ * sources up to 1080p, device destinations, callers that receive off_out (completion order, like the PACK form). */
 static int plan_length_first_ok(const asciichat_hip_plan_t *p) {
   return p->mode == ACHIP_MODE_TRUE_FG && p->palette_ascii && !p->has_comp && plan_frames_whole(p) &&
          (p->whole_variant == 16 || p->whole_variant == 17);
@@ -809,6 +819,12 @@ int asciichat_hip_plan_has_fused_crc(const asciichat_hip_plan_t *p) {
    * 13.2 for shared-out render + stand-alone pass), a multiple of the render beyond (a lone 200x60 truecolor frame 49 us
    * fused, 320x90 116, against a 7 us render + a 19-26 us pass; scripts/gpu_wire_audit.py, profiles/r04_wire_audit.txt) */
   if (p->parts > 1 && p->max_cells > 16 * 127)
+    return 0;
+  /* (round 6's wire audit: the checksumming instantiations kept the general per-block loop, so beside the lean loop of truecolor
+   * foreground the fused form pays only for small frames -- 256 frames of 80x24 13.0 us fused against 18.4 with the stand-alone pass,
+   * 120x40 26.7 / 29.0, 160x45 34.4 / 35.4, but 200x60 55.9 / 49.6 and 320x90 129.0 / 102.9 (128 frames: 122.8 / 80.5); the other
+   * per-cell modes up to 200x60: 256 colours 44.9 / 44.3, 320x90 101.3 / 89.3) */
+  if (ACHIP_IS_STREAM_VARIANT(p->whole_variant) && p->max_cells > (p->mode == ACHIP_MODE_TRUE_FG ? 8192 : 12288))
     return 0;
   return achip_variant_crc_pays(p->whole_variant);
 }

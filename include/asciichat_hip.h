@@ -416,15 +416,17 @@ int asciichat_hip_plan_render_packets_packed(asciichat_hip_plan_t *plan, uint8_t
  * palette; ASCIICHAT_HIP_ERR_NOT_SUPPORTED otherwise).  Frames land in completion order (off_out[i], 16-byte aligned;
  * off_out[n] = total), lengths in out_len_dev / len_out.  plan_render_packed / plan_render_packets_packed take this form by
  * themselves for plans whose sources are the sampled images (ratio 1.0: 16.5 us against 34.5 for render + pack pass per 256
- * frames of 200x60; from full-size sources the second gather costs more than the pass -- profiles/r06_length_first_ab.txt);
- * plan_set_exact_length(1) forces it wherever it applies, 0 turns it off. */
+ * frames of 200x60) or at most 1920 pixels wide (128 frames of 1080p -> 320x90: 94.6 us against 144.4; from 4K sources the second
+ * gather costs more than the pass -- profiles/r06_length_first_ab.txt, r06_wire_audit.txt), device destinations, whole-frame
+ * launches; plan_set_exact_length(1) forces it wherever it applies, 0 turns it off. */
 int asciichat_hip_plan_render_length_first(asciichat_hip_plan_t *plan, uint32_t *out_len_dev, uint8_t *dst, size_t dst_capacity,
                                            uint64_t *off_out, uint32_t *len_out, void *stream);
 int asciichat_hip_plan_get_length_first(const asciichat_hip_plan_t *plan); /* 1: the packed entry points may take that form for this plan */
 /* Which form plan_render_crc / plan_render_packets take: -1 (default) the fused one where it is the faster form (the
- * per-cell modes' stream kernel -- for a small launch whose render is shared out over workgroups only while a wave has one
- * block: fusing means one workgroup per frame, and a lone 320x90 frame then takes 116 us where render + stand-alone pass
- * take 17), 1 wherever the plan's geometry carries it (also the rows kernel of the run-structured modes, where the
+ * per-cell modes' stream kernel, frames of at most 8192 cells in truecolor foreground / 12288 in the other modes: beside the
+ * lean render of larger frames the stand-alone pass is faster, profiles/r06_wire_audit.txt -- for a small launch whose render
+ * is shared out over workgroups only while a wave has one block: fusing means one workgroup per frame, and a lone 320x90 frame
+ * then takes 116 us where render + stand-alone pass take 17), 1 wherever the plan's geometry carries it (also the rows kernel of the run-structured modes, where the
  * stand-alone pass is measured faster), 0 never.  plan_has_fused_crc() tells what a call will do.  Mode 1 on a plan whose
  * geometry has no fused instantiation in this build (the rows kernel's exist in -DACHIP_ALL_GEOMETRIES builds only) returns
  * ASCIICHAT_HIP_ERR_NOT_SUPPORTED -- the setting is kept, the calls run render + stand-alone pass. */

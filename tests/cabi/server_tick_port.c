@@ -113,8 +113,12 @@ static void run_tick(int force_variant) {
   asciichat_hip_plan_t *plan = NULL;
   CHECK(asciichat_hip_plan_create(&plan, achip_mode_from_caps(caps.color_level, caps.render_mode), palette, frames, CLIENTS) == 0,
         "plan_create");
-  if (force_variant >= 0)
+  if (force_variant >= 0) {
     CHECK(asciichat_hip_plan_set_variant(plan, force_variant) == 0, "set_variant %d", force_variant);
+    /* (the whole-frame tick is here for the fused checksum: asked for -- by itself the plan takes it for small frames only, and
+     * one of these terminals is 200 columns wide; round 6's wire audit) */
+    CHECK(asciichat_hip_plan_set_fused_crc(plan, 1) == 0, "set_fused_crc(1) on geometry %d", force_variant);
+  }
   const size_t stride = asciichat_hip_plan_out_stride(plan);
   uint8_t *slab = NULL, *hdr = NULL;
   uint32_t *len = NULL, *crc = NULL, *pkt = NULL, *dims = NULL;

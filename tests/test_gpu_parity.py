@@ -926,6 +926,9 @@ def test_render_with_fused_frame_crc(gpu):
             assert not plan.fused_crc  # it by themselves (slower there); asked for in a default build, the stand-alone pass runs
             plan.set_fused_crc(1)
             want_fused = rows_crc_built(pkg)
+        if mode == 1 and variant in (16, 17):  # round 6's wire audit: beside the lean loop of truecolor foreground the fused form pays for
+            assert not plan.fused_crc           # small frames only (<= 8192 cells; this batch holds a 200x60 frame): asked for here
+            plan.set_fused_crc(1)
         if want_fused is not None:
             assert plan.fused_crc == want_fused, (mode, variant, plan.variant)
         n = len(imgs)
@@ -1423,8 +1426,8 @@ def test_exact_length_frames_full_batch(gpu):
 
 def test_length_first_exact_length_frames_through_the_plan(gpu):
     """Frames beyond the 48 KB of the LDS-image form leave ONE launch at their exact lengths (render_stream.hpp LF, round 6):
-    plan_render_packed / plan_render_packets_packed take the form by themselves for sampled-image (dense) sources, on request
-    (set_exact_length 1) for any single source, never without off_out; bytes, lengths, checksums, headers and packet CRCs equal
+    plan_render_packed / plan_render_packets_packed take the form by themselves for sampled-image (dense) sources and sources up to
+    1080p, on request (set_exact_length 1) for any single source, never without off_out; bytes, lengths, checksums, headers and packet CRCs equal
     those of render + pass, frames tile the destination (completion order)."""
     pkg, torch = gpu
     stream = torch.cuda.current_stream().cuda_stream
@@ -1432,8 +1435,9 @@ def test_length_first_exact_length_frames_through_the_plan(gpu):
     dense = [orc.frame_hash_noise(W, H, 70 + i) for i in range(24)]
     dense[3][:] = 0
     dense[4] = orc.frame_smooth(W, H)
-    big = [orc.frame_hash_noise(1920, 1080, 7 + i) for i in range(5)]
-    for pool, auto_takes_it in ((dense, True), (big, False)):
+    hd = [orc.frame_hash_noise(1920, 1080, 7 + i) for i in range(5)]     # sources up to 1080p: by itself too (round 6's wire audit)
+    big = [orc.frame_hash_noise(2048, 1152, 17 + i) for i in range(5)]   # wider ones: a second gather costs more than the pack pass
+    for pool, auto_takes_it in ((dense, True), (hd, True), (big, False)):
         dev = [torch.from_numpy(np.ascontiguousarray(i)).cuda() for i in pool]
         imgs = [pool[i % len(pool)] for i in range(n)]
         frames = [pkg.frame_setup(dev[i % len(pool)].data_ptr(), imgs[i].shape[1], imgs[i].shape[0], W, H, 0, False, False, False) for i in range(n)]

@@ -323,11 +323,12 @@ def test_wire_stage_on_the_mock(mock):
 
 def test_length_first_exact_length_frames_on_the_mock(mock):
     """plan.c's choice of the LENGTH-FIRST form (frames beyond the 48 KB of the LDS-image form; render_stream.hpp LF): by itself
-    for dense sources (the sampled images: ratio 1.0), on request for any single source, never without off_out; checksums,
-    headers and packet CRCs of the frames where they lie (crc32c over offsets) equal those of render + pass."""
+    for dense sources (the sampled images: ratio 1.0) and -- since round 6's wire audit -- for sources up to 1920 pixels wide, on
+    request for any single source (here: 2000 pixels wide, a second gather of which costs more than a pack pass), never without
+    off_out; checksums, headers and packet CRCs of the frames where they lie (crc32c over offsets) equal those of render + pass."""
     W, H = 200, 60
     for dense in (True, False):
-        imgs = [orc.frame_hash_noise(W if dense else 333, H if dense else 201, 90 + i) for i in range(3)]
+        imgs = [orc.frame_hash_noise(W if dense else 2000, H if dense else 75, 90 + i) for i in range(3)]
         keep = [np.ascontiguousarray(im) for im in imgs]
         frames = [mock.frame_setup(k.ctypes.data, k.shape[1], k.shape[0], W, H, 0, False, False, False) for k in keep]
         want = [orc.convert_with_caps(im, W, H, 3, 0, False, False, False) for im in imgs]
