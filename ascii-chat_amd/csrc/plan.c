@@ -824,7 +824,11 @@ int asciichat_hip_plan_has_fused_crc(const asciichat_hip_plan_t *p) {
    * foreground the fused form pays only for small frames -- 256 frames of 80x24 13.0 us fused against 18.4 with the stand-alone pass,
    * 120x40 26.7 / 29.0, 160x45 34.4 / 35.4, but 200x60 55.9 / 49.6 and 320x90 129.0 / 102.9 (128 frames: 122.8 / 80.5); the other
    * per-cell modes up to 200x60: 256 colours 44.9 / 44.3, 320x90 101.3 / 89.3) */
-  if (ACHIP_IS_STREAM_VARIANT(p->whole_variant) && p->max_cells > (p->mode == ACHIP_MODE_TRUE_FG ? 8192 : 12288))
+  /* (... and from dense sources, where the lean render has no line fills to wait for, earlier still: truecolor foreground only while
+   * a wave has one block -- 128 frames of 160x45 31.5 us fused against 27.2, 120x40 23.0 / 21.4, 80x24 12.5 / 14.5 the other way --,
+   * 256 colours up to 160x45: 200x60 43.8 / 40.2) */
+  const long fused_limit = p->mode == ACHIP_MODE_TRUE_FG ? (p->all_dense ? 16 * 127 : 8192) : (p->all_dense ? 8192 : 12288);
+  if (ACHIP_IS_STREAM_VARIANT(p->whole_variant) && p->max_cells > fused_limit)
     return 0;
   return achip_variant_crc_pays(p->whole_variant);
 }

@@ -423,7 +423,7 @@ int asciichat_hip_plan_render_length_first(asciichat_hip_plan_t *plan, uint32_t 
                                            uint64_t *off_out, uint32_t *len_out, void *stream);
 int asciichat_hip_plan_get_length_first(const asciichat_hip_plan_t *plan); /* 1: the packed entry points may take that form for this plan */
 /* Which form plan_render_crc / plan_render_packets take: -1 (default) the fused one where it is the faster form (the
- * per-cell modes' stream kernel, frames of at most 8192 cells in truecolor foreground / 12288 in the other modes: beside the
+ * per-cell modes' stream kernel, frames of at most 8192 cells in truecolor foreground / 12288 in the other modes (2032 / 8192 from sampled-image sources): beside the
  * lean render of larger frames the stand-alone pass is faster, profiles/r06_wire_audit.txt -- for a small launch whose render
  * is shared out over workgroups only while a wave has one block: fusing means one workgroup per frame, and a lone 320x90 frame
  * then takes 116 us where render + stand-alone pass take 17), 1 wherever the plan's geometry carries it (also the rows kernel of the run-structured modes, where the

@@ -6,7 +6,7 @@
            (set_exact_length 1), render + pack / checksum-and-pack (0), against the plan's own choice (-1).
 Terminal sizes x batch sizes x modes, 1080p sources, launches back to back on one stream (HIP events).  Every form's
 checksums, headers and packed frames are compared with the automatic form's (the automatic form's first frame and CRC with the
-oracle).  GPU box only.  usage: gpu_wire_audit.py [--quick]"""
+oracle).  GPU box only.  usage: gpu_wire_audit.py [--quick] [--dense] [--modes=truecolor,ansi256]"""
 import os
 import statistics
 import sys
@@ -31,6 +31,9 @@ BATCHES = [1, 16, 64, 128, 256]
 if QUICK:
     SIZES, BATCHES = [(80, 24), (200, 60)], [16, 256]
 SRC_W, SRC_H = 1920, 1080
+DENSE = "--dense" in sys.argv
+if "--modes" in " ".join(sys.argv):
+    MODES = [m for m in MODES if m[1] in [a[8:] for a in sys.argv if a.startswith("--modes=")][0].split(",")]
 frames_t = bench.make_frames(torch, 256, SRC_W, SRC_H, 4242)
 host0 = np.ascontiguousarray(frames_t[0].cpu().numpy())
 
@@ -58,7 +61,13 @@ print("# 1080p sources, one stream, back to back (HIP events); us per launch.  p
 for (mode, mname, cl, rm) in MODES:
     for (W, H) in SIZES:
         for n in BATCHES:
-            descs = [pkg.frame_setup(frames_t[k].data_ptr(), SRC_W, SRC_H, W, H, rm, False, False, False) for k in range(n)]
+            if DENSE:  # what a server tick renders after the sampled-image ingest: the source IS the image the target samples
+                hs = 2 * H if rm == 2 else H
+                dense_t = bench.make_frames(torch, n, W, hs, 99)
+                host0 = np.ascontiguousarray(dense_t[0].cpu().numpy())
+                descs = [pkg.frame_setup(dense_t[k].data_ptr(), W, hs, W, H, rm, False, False, False) for k in range(n)]
+            else:
+                descs = [pkg.frame_setup(frames_t[k].data_ptr(), SRC_W, SRC_H, W, H, rm, False, False, False) for k in range(n)]
             plan = pkg.Plan(mode, bench.PALETTE_STANDARD, descs)
             stride = plan.stride
             reps = max(8, min(200, int(4e8 / max(1, W * H * (41 if mode == 5 else 20) * n) / 60)))
