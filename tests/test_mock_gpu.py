@@ -268,6 +268,41 @@ def test_plans_and_packed_output_on_the_mock(mock):
     plan.close()
 
 
+def test_send_side_rules_of_the_plan(mock):
+    """plan.c's own choices for the send side since round 6's wire audit (profiles/r06_wire_audit.txt): the checksum rides the render
+    only for small frames -- truecolor foreground up to 8192 cells a frame (from dense sources: while a wave has one block), the other
+    per-cell modes up to 12288 (dense: 8192) -- and the length-first form is the plan's own for dense sources and sources up to 1920
+    pixels wide; both still follow set_fused_crc / set_exact_length."""
+    def plan_for(mode, W, H, dense, src_w=333):
+        img = np.ascontiguousarray(orc.frame_hash_noise(W if dense else src_w, H if dense else 50, 5))
+        keep.append(img)
+        frames = [mock.frame_setup(img.ctypes.data, img.shape[1], img.shape[0], W, H, 0, False, False, False) for _ in range(3)]
+        p = mock.Plan(mode, orc.PALETTE_STANDARD, frames)
+        p.set_variant(17)  # (whole frames: three frames alone would be cut into row bands)
+        return p
+    keep = []
+    for mode, W, H, dense, fused in ((1, 80, 24, False, True), (1, 160, 45, False, True), (1, 200, 60, False, False),
+                                      (1, 80, 24, True, True), (1, 120, 40, True, False),
+                                      (2, 200, 60, False, True), (2, 320, 90, False, False), (2, 160, 45, True, True), (2, 200, 60, True, False)):
+        p = plan_for(mode, W, H, dense)
+        assert p.fused_crc == fused, (mode, W, H, dense)
+        p.set_fused_crc(1)
+        assert p.fused_crc
+        p.set_fused_crc(0)
+        assert not p.fused_crc
+        p.close()
+    for dense, src_w, auto in ((True, 0, True), (False, 1920, True), (False, 1921, False)):
+        p = plan_for(1, 200, 60, dense, src_w)
+        assert p.length_first  # the plan MAY take the form ...
+        n, stride = 3, p.stride
+        slab, ln = np.zeros(n * stride, np.uint8), np.zeros(n, np.uint32)
+        dst, off, lo = np.zeros(n * stride + 16, np.uint8), np.zeros(n + 1, np.uint64), np.zeros(n, np.uint32)
+        dbase = dst.ctypes.data + (-dst.ctypes.data % 16)
+        p.render_packed(slab.ctypes.data, stride, ln.ctypes.data, dbase, n * stride, off.ctypes.data, lo.ctypes.data)
+        assert (not slab.any()) == auto, (dense, src_w)  # ... and takes it by itself (the slab stays untouched) for these sources only
+        p.close()
+
+
 def test_wire_stage_on_the_mock(mock):
     """plan_render_packets through plan.c's own choice between the fused form (the CRC rides the stream kernel's drain) and a
     second pass over the slab (the rows kernel, row bands): frame CRC-32C, the 24-byte ascii_frame_packet_t headers and the
