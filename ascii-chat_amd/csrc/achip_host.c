@@ -926,7 +926,12 @@ int achip_choose_geometry(int mode, const achip_frame_t *frames, int n_frames, b
         return 0;
       }
     }
-    const bool take = n_frames > n_cus ? true : mono ? !(shared_gpu && ext > 8) : (ext <= 8 && !shared_gpu);
+    /* (round 6's last audits: the 256- / 16-colour and mono half blocks of one block per wave take the rows kernel at no more than a frame
+     * per CU from dense sources only -- from full-frame sources the phase kernel is 8-10 % ahead there: 128 / 192 / 256 frames of 1080p ->
+     * 80x24, 256 colours 16.0 / 17.3 / 20.2 us against 17.4 / 18.7 / 21.0, 16 colours 16.0 / 17.3 / 19.7 against 17.3 / 19.1 / 21.8, mono
+     * half blocks 12.4 against 13.4; truecolor half blocks the other way, 18.3 against 17.5) */
+    const bool take = n_frames > n_cus ? true : mono ? !(shared_gpu && ext > 8)
+                                                     : (ext <= 8 && !shared_gpu && (dense || mode == ACHIP_MODE_HB_TRUE));
     if ((v == 25 || n_frames > n_cus || (mono && max_wp > 256)) && ext <= ACHIP_HOST_STREAM_MAXBLK && take) {
       *variant = v;
       return 0;

@@ -77,6 +77,11 @@ def test_split_ragged_batch_and_policy():
     assert choose(5, hb, req=1) == (4, 24, 1)  # (row bands when asked for rows)
     assert choose(5, hb * 65) == (25, 1, 24) and choose(8, hb) == (31, 6, 1) and choose(8, hb * 60) == (25, 1, 24)  # (half-block mono: short tokens, whole frames)
     assert choose(5, hb * 48) == (4, 5, 5)   # never more bands than CUs: five per frame at most (240 workgroups)
+    # (round 6's last audits: at no more than a frame per CU the 256- / 16-colour and mono half blocks of one block per wave leave
+    # full-frame sources to the phase kernel -- 8-10 % ahead there -- and keep the rows kernel for dense sources; truecolor half blocks keep it)
+    assert choose(6, hb * 200)[:2] == (4, 1) and choose(7, hb * 256)[:2] == (4, 1) and choose(8, hb * 200)[:2] == (4, 1) and choose(5, hb * 200) == (25, 1, 24)
+    dense_hb = [emu.frame_for_convert(np.ascontiguousarray(imgs[0][:48, :80]), 80, 24, 2)]
+    assert choose(6, dense_hb * 200) == (25, 1, 24) and choose(6, hb * 300) == (25, 1, 24)   # (dense sources / more than a frame per CU: the rows kernel)
     mid = [emu.frame_for_convert(imgs[0], 160, 48, 0)]        # 7 680 cells = 61 blocks: sixteen parts (the grid's nine targets)
     assert choose(1, mid) == (18, 16, 1) and choose(1, mid * 9) == (18, 16, 1)
     # run-structured rows of 129-512 cells: cut into segments of at most 128 cells, whole rows per four-wave workgroup, a segment
